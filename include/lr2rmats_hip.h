@@ -1,0 +1,190 @@
+/* lr2rmats_hip.h -- C-ABI of the MI355X (gfx950) read-vs-annotation engine.
+ *
+ * This is the drop-in boundary for the one hot path of lr2rmats `update-gtf`
+ * (and the CIGAR half of `bam2gtf` / `unique-gtf`): everything between
+ * "alignment records and annotation are in memory" and "every read carries its
+ * exons, class, flags and reference transcript".  In the reference that seam is
+ *
+ *     read_bam_trans()   src/bam2gtf.c:89-110   (gen_exon :31-78 per record)
+ *     check_trans()      src/update_gtf.c:936-965
+ *         check_with_anno_trans()  :792-835   check_full() :629-681
+ *         check_splice_site()      :717-779   set_full()   :683-696
+ *         check_with_short_sj()    :698-709   check_short_sj{,1}() :589-627
+ *
+ * called from update_gtf() src/update_gtf.c:1069 and :1083.  The list routing,
+ * split_trans(), merge_trans() and the writers stay on the host (they are
+ * order dependent); they consume the arrays this library returns.
+ *
+ * Plain C types only: caller-owned host buffers, sizes, int return codes
+ * (0 = ok, negative = error, text from l2r_last_error()).  One context drives
+ * one GPU (one process per GPU); all device work of a context is issued on the
+ * context's own HIP stream.  There is no CPU fallback: l2r_create() fails when
+ * no gfx950 device is usable.
+ */
+#ifndef LR2RMATS_HIP_H
+#define LR2RMATS_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L2R_ABI_VERSION 1
+
+typedef struct l2r_ctx l2r_ctx;
+
+/* The fields of update_gtf_para (src/update_gtf.h:8-15) that the path reads;
+ * defaults in src/update_gtf.c:24-35 and src/gtf.h:118-127. */
+typedef struct {
+    int32_t min_exon;               /* -e  INTER_EXON_MIN_LEN 3  */
+    int32_t min_intron;             /* -i  INTRON_MIN_LEN 3      */
+    int32_t max_delet;              /* -t  DELETION_MAX_LEN 50   */
+    int32_t ss_dis;                 /* -d  SPLICE_DISTANCE 0     */
+    int32_t end_dis;                /* -D  END_DISTANCE 0x7fffffff (host merge only) */
+    int32_t full_level;             /* -l  1..5, default 5       */
+    int32_t split_trans;            /* -s  */
+    int32_t use_multi;              /* -M  */
+    int32_t min_sj_cnt;             /* -J  MIN_SJ_CNT 1          */
+    int32_t force_strand;           /* -c  (host merge only)     */
+    float   single_exon_ovlp_frac;  /* -f  SING_OVLP_FRAC 0.80   */
+} l2r_params;
+
+/* Annotation transcripts in GTF FILE ORDER, as read_anno_trans() leaves them
+ * (src/gtf.c:468-521): exons of a transcript sorted by (start,end), tx_start =
+ * first exon start, tx_end = end of the LAST exon in that order, tid = index in
+ * the BAM header or -1.  1-based closed coordinates. */
+typedef struct {
+    int64_t n_tx, n_exon;
+    const int32_t *tx_tid, *tx_start, *tx_end;
+    const uint8_t *tx_rev;
+    const int64_t *tx_ex_off;       /* n_tx + 1 */
+    const int32_t *ex_start, *ex_end;
+} l2r_annotation;
+
+/* STAR SJ.out.tab rows as read_sj_group() leaves them (src/gtf.c:431-449):
+ * sorted by (tid, don, acc); don/acc = first/last intron base. */
+typedef struct {
+    int64_t n;
+    const int32_t *tid, *don, *acc, *uniq_c, *multi_c;
+} l2r_junctions;
+
+/* Alignment records in input order: what gen_exon() reads from a bam1_t
+ * (src/bam2gtf.c:34-41): core.tid, core.pos (0-based), the strand resolved as
+ * "XS aux present ? (XS:A == '+' ? 0 : 1) : FLAG & 16", and the raw CIGAR words
+ * (len << 4 | op).  Unmapped records must be rejected by the caller (the
+ * reference aborts on them in update-gtf, skips them in bam2gtf). */
+typedef struct {
+    int64_t n_reads, n_cigar;
+    const int32_t *tid, *pos;
+    const uint8_t *rev;
+    const int64_t *cig_off;         /* n_reads + 1 */
+    const uint32_t *cig;
+    int64_t first_read_index;       /* global index of record 0 (read shards of a multi-GPU run) */
+} l2r_reads;
+
+/* bits of info[] : one word per read; bits 8..31 = exon count */
+#define L2R_INFO_KNOWN      0x01u   /* trans_t.known                       */
+#define L2R_INFO_KNOWN_SITE 0x02u   /* trans_t.has_known_site              */
+#define L2R_INFO_FULL       0x04u   /* trans_t.full                        */
+#define L2R_INFO_REV        0x08u   /* is_rev after update_gtf.c:825-831   */
+#define L2R_INFO_UNREL      0x10u   /* has_unreliable_junction             */
+#define L2R_INFO_SJ_CHECKED 0x20u   /* check_with_short_sj() was reached   */
+#define L2R_INFO_SJ_PASS    0x40u   /* ... and returned 1                  */
+#define L2R_INFO_ACCEPTED   0x80u   /* goes to novel_T / updated_T (whole or, with -s, as split pieces) */
+#define L2R_INFO_NEXON(i)   ((i) >> 8)
+
+/* bits of ex_flag[] : one byte per exon j; junction j (exon j -> j+1) lives with exon j */
+#define L2R_EXF_NOVEL_EXON  0x01u   /* novel_exon_flag[j]          */
+#define L2R_EXF_NOVEL_DON   0x02u   /* novel_site_flag[2j]         */
+#define L2R_EXF_NOVEL_ACC   0x04u   /* novel_site_flag[2j+1]       */
+#define L2R_EXF_NOVEL_JUNC  0x08u   /* novel_junction_flag[j]      */
+#define L2R_EXF_UNREL_JUNC  0x10u   /* unreliable_junction_flag[j] */
+
+/* Per-read results in read order (what check_trans() leaves in bam_T). */
+typedef struct {
+    int64_t n_reads;                /* in: capacity of the per-read arrays; out: reads written  */
+    int64_t ex_cap;                 /* in: capacity of the per-exon arrays                       */
+    int64_t n_exons;                /* out */
+    int64_t *ex_off;                /* n_reads + 1 */
+    int32_t *ex_start, *ex_end;
+    uint8_t *ex_flag;
+    uint32_t *info;
+    int32_t *ref_tx;                /* ref_anno_i or -1 */
+} l2r_result;
+
+/* Accepted-novel records, compacted in read order: the reads check_trans()
+ * hands to novel_T/merge_trans (update_gtf.c:946-960).  This is the message of
+ * the multi-GPU all-gatherv. */
+typedef struct {
+    uint32_t read_lo, read_hi;      /* global read index (64 bit, split) */
+    uint32_t info;
+    int32_t  ref_tx;
+} l2r_accepted_read;                /* 16 bytes */
+
+typedef struct {
+    int64_t n_reads, ex_cap;        /* in: capacities; out n_reads = records written */
+    int64_t n_exons;                /* out */
+    l2r_accepted_read *rec;
+    int64_t *ex_off;                /* n_reads + 1, into the arrays below */
+    int32_t *ex_start, *ex_end;
+    uint8_t *ex_flag;
+} l2r_accepted;
+
+/* Raw device views (for a caller that keeps data in HBM: bench, RCCL gather). */
+typedef struct {
+    int64_t n_reads, n_exons, n_accepted, n_accepted_exons;
+    const uint32_t *ex_off;         /* device, n_reads (exclusive offsets) */
+    const int32_t *ex_start, *ex_end;
+    const uint8_t *ex_flag;
+    const uint32_t *info;
+    const int32_t *ref_tx;
+    const l2r_accepted_read *acc_rec;
+    const uint32_t *acc_ex_off;     /* device, n_accepted */
+    const int32_t *acc_ex_start, *acc_ex_end;
+    const uint8_t *acc_ex_flag;
+} l2r_device_view;
+
+/* Average device time per kernel of the last l2r_run_timed(), milliseconds. */
+#define L2R_N_STAGES 8
+typedef struct {
+    float stage_ms[L2R_N_STAGES];   /* 0 count_exons 1 scan 2 fill_classify 3 validate_junctions
+                                       4 count_accepted 5 scan 6 gather_accepted 7 reserved */
+    float total_ms;                 /* first launch -> last completion, per iteration */
+    int32_t iters;
+} l2r_timing;
+
+int          l2r_abi_version(void);
+const char  *l2r_last_error(void);
+int          l2r_device_count(void);
+
+l2r_ctx     *l2r_create(int device);
+void         l2r_destroy(l2r_ctx *ctx);
+
+int          l2r_set_params(l2r_ctx *ctx, const l2r_params *prm);
+int          l2r_set_annotation(l2r_ctx *ctx, const l2r_annotation *anno);
+int          l2r_set_junctions(l2r_ctx *ctx, const l2r_junctions *sj);   /* NULL or n == 0: no -j file */
+
+/* host -> HBM; detects whether the records are coordinate sorted and, if not,
+ * prepares the history-dependent cursor values on the host. */
+int          l2r_upload_reads(l2r_ctx *ctx, const l2r_reads *reads);
+
+/* The hot path on resident inputs; asynchronous on the context stream. */
+int          l2r_run(l2r_ctx *ctx);
+int          l2r_sync(l2r_ctx *ctx);
+/* `iters` back-to-back runs bracketed by HIP events on the context stream. */
+int          l2r_run_timed(l2r_ctx *ctx, int iters, l2r_timing *out);
+
+int          l2r_result_sizes(l2r_ctx *ctx, int64_t *n_reads, int64_t *n_exons,
+                              int64_t *n_accepted, int64_t *n_accepted_exons);
+int          l2r_download(l2r_ctx *ctx, l2r_result *res);               /* HBM -> host */
+int          l2r_download_accepted(l2r_ctx *ctx, l2r_accepted *acc);
+int          l2r_device_view_get(l2r_ctx *ctx, l2r_device_view *view);
+void        *l2r_stream(l2r_ctx *ctx);                                  /* hipStream_t */
+
+/* upload + run + sync + download in one call (the host CLI uses this). */
+int          l2r_classify(l2r_ctx *ctx, const l2r_reads *reads, l2r_result *res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,531 @@
+// l2r_engine.hip -- C-ABI implementation (include/lr2rmats_hip.h) over the gfx950
+// kernels of l2r_kernels.hip.h.  One context = one GPU = one HIP stream.
+// There is deliberately no CPU path in this file: every entry point that does
+// work needs a HIP device and fails with a message otherwise.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/lr2rmats_hip.h"
+#include "l2r_kernels.hip.h"
+
+using namespace l2r;
+
+static thread_local char g_err[1024] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(-2, "[%s] %s: %s", __func__, #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;     // elements
+    int ensure(size_t n)
+    {
+        if (n <= cap && p) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n ? n : 1;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return fail(-2, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e)); }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct l2r_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    l2r_params prm;
+    // annotation
+    int64_t n_tx = 0, n_anno_exon = 0;
+    DevBuf<TxHdr> hdr;
+    DevBuf<int2> anno_ex;
+    DevBuf<int64_t> anno_key;
+    std::vector<int64_t> h_anno_key_raw;    // per transcript (tid,end) key, NOT prefix-maxed (unsorted-input cursor)
+    // junctions
+    int64_t n_sj = 0;
+    DevBuf<int32_t> sj_tid, sj_don, sj_acc, sj_uniq, sj_multi;
+    DevBuf<int64_t> sj_key;
+    std::vector<int64_t> h_sj_key_raw;      // per row (tid,acc) key
+    // reads
+    int64_t n_reads = 0, n_cigar = 0, first_read = 0;
+    bool sorted = true;
+    int reads_per_tile = TILE_THREADS;
+    DevBuf<int32_t> r_tid, r_pos;
+    DevBuf<uint8_t> r_rev;
+    DevBuf<int64_t> cig_off;
+    DevBuf<uint32_t> cig;
+    std::vector<int32_t> h_tid, h_pos;      // kept only for unsorted input
+    DevBuf<int32_t> win_start, sj_cursor;   // only for unsorted input
+    bool have_win = false;
+    // work + results
+    int64_t n_tiles = 0, n_tiles256 = 0;
+    DevBuf<uint32_t> n_ex, tile_base, ex_off, info, tile_acc, tile_acc_ex, totals;   // totals[0]=exons [1]=accepted [2]=accepted exons
+    DevBuf<int32_t> ex_start, ex_end, ref_tx;
+    DevBuf<uint8_t> ex_flag;
+    int64_t ex_cap = 0;
+    DevBuf<AccRec> acc_rec;
+    DevBuf<uint32_t> acc_ex_off;
+    DevBuf<int32_t> acc_start, acc_end;
+    DevBuf<uint8_t> acc_flag;
+    bool ran = false;
+    uint32_t h_totals[3] = {0, 0, 0};
+    bool totals_valid = false;
+};
+
+static DevParams dev_params(const l2r_ctx *c)
+{
+    DevParams p;
+    p.min_exon = c->prm.min_exon; p.min_intron = c->prm.min_intron; p.max_delet = c->prm.max_delet;
+    p.ss_dis = c->prm.ss_dis; p.full_level = c->prm.full_level; p.use_multi = c->prm.use_multi;
+    p.min_sj_cnt = c->prm.min_sj_cnt; p.split_trans = c->prm.split_trans; p.frac = c->prm.single_exon_ovlp_frac;
+    p.n_tx = (int32_t)c->n_tx; p.n_sj = (int32_t)c->n_sj; p.reads_per_tile = c->reads_per_tile;
+    return p;
+}
+
+static inline int64_t host_key(int32_t tid, int32_t x) { return ((int64_t)(tid + 1) << 32) | (uint32_t)x; }
+
+extern "C" {
+
+int l2r_abi_version(void) { return L2R_ABI_VERSION; }
+const char *l2r_last_error(void) { return g_err; }
+
+int l2r_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+l2r_ctx *l2r_create(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { fail(-1, "[l2r_create] no HIP device available (%s); this library has no CPU path", hipGetErrorString(e)); return nullptr; }
+    if (device < 0 || device >= n) { fail(-1, "[l2r_create] device %d out of range (have %d)", device, n); return nullptr; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { fail(-2, "[l2r_create] hipSetDevice: %s", hipGetErrorString(e)); return nullptr; }
+    l2r_ctx *c = new l2r_ctx();
+    c->device = device;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        fail(-2, "[l2r_create] hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr;
+    }
+    // src/update_gtf.c:24-35 defaults
+    c->prm = l2r_params{3, 3, 50, 0, 0x7fffffff, 5, 0, 0, 1, 0, 0.80f};
+    return c;
+}
+
+void l2r_destroy(l2r_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    c->hdr.release(); c->anno_ex.release(); c->anno_key.release();
+    c->sj_tid.release(); c->sj_don.release(); c->sj_acc.release(); c->sj_uniq.release(); c->sj_multi.release(); c->sj_key.release();
+    c->r_tid.release(); c->r_pos.release(); c->r_rev.release(); c->cig_off.release(); c->cig.release();
+    c->win_start.release(); c->sj_cursor.release();
+    c->n_ex.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->totals.release();
+    c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
+    c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void *l2r_stream(l2r_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int l2r_set_params(l2r_ctx *c, const l2r_params *prm)
+{
+    if (!c || !prm) return fail(-1, "[l2r_set_params] null argument");
+    c->prm = *prm;
+    c->ran = false;
+    return 0;
+}
+
+int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
+{
+    if (!c || !a) return fail(-1, "[l2r_set_annotation] null argument");
+    if (a->n_tx < 0 || a->n_tx > 0x7ffffff0LL || a->n_exon < 0 || a->n_exon > 0x7ffffff0LL) return fail(-1, "[l2r_set_annotation] size out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t T = a->n_tx;
+    std::vector<TxHdr> h((size_t)T);
+    std::vector<int64_t> key((size_t)T);
+    c->h_anno_key_raw.assign((size_t)T, 0);
+    int64_t run = INT64_MIN;
+    for (int64_t i = 0; i < T; ++i) {
+        const int64_t lo = a->tx_ex_off[i], hi = a->tx_ex_off[i + 1];
+        if (lo < 0 || hi < lo || hi > a->n_exon) return fail(-1, "[l2r_set_annotation] bad exon offsets at transcript %lld", (long long)i);
+        if (hi == lo) return fail(-1, "[l2r_set_annotation] transcript %lld has no exon", (long long)i);
+        TxHdr &t = h[(size_t)i];
+        t.tid = a->tx_tid[i]; t.start = a->tx_start[i]; t.end = a->tx_end[i]; t.ex_off = (int32_t)lo;
+        t.n = (int32_t)(hi - lo); t.rev = a->tx_rev[i] ? 1 : 0; t.pad = 0;
+        int mono = 1;
+        for (int64_t k = lo + 1; k < hi; ++k)
+            if (!(a->ex_start[k] > a->ex_start[k - 1] && a->ex_end[k] > a->ex_end[k - 1])) { mono = 0; break; }
+        t.mono = mono;
+        // "annotation before read": tid smaller, or same tid and end <= read start (update_gtf.c:786-790).
+        // The sequential cursor equals the longest prefix that is entirely before the read = first index
+        // whose running maximum of (tid,end) exceeds (read.tid, read.start)  (SURVEY.md 3.3).
+        const int64_t k = host_key(t.tid, t.end);
+        c->h_anno_key_raw[(size_t)i] = k;
+        if (k > run) run = k;
+        key[(size_t)i] = run;
+    }
+    std::vector<int2> ex((size_t)a->n_exon);
+    for (int64_t k = 0; k < a->n_exon; ++k) ex[(size_t)k] = make_int2(a->ex_start[k], a->ex_end[k]);
+    if (c->hdr.ensure((size_t)T) || c->anno_ex.ensure((size_t)a->n_exon) || c->anno_key.ensure((size_t)T)) return -2;
+    if (T) {
+        HIP_TRY(hipMemcpyAsync(c->hdr.p, h.data(), (size_t)T * sizeof(TxHdr), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->anno_key.p, key.data(), (size_t)T * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    }
+    if (a->n_exon) HIP_TRY(hipMemcpyAsync(c->anno_ex.p, ex.data(), (size_t)a->n_exon * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_tx = T; c->n_anno_exon = a->n_exon;
+    c->have_win = false; c->ran = false;
+    return 0;
+}
+
+int l2r_set_junctions(l2r_ctx *c, const l2r_junctions *s)
+{
+    if (!c) return fail(-1, "[l2r_set_junctions] null context");
+    HIP_TRY(hipSetDevice(c->device));
+    c->ran = false;
+    if (!s || s->n == 0) { c->n_sj = 0; c->h_sj_key_raw.clear(); return 0; }
+    if (s->n < 0 || s->n > 0x7ffffff0LL) return fail(-1, "[l2r_set_junctions] size out of range");
+    const int64_t n = s->n;
+    std::vector<int64_t> key((size_t)n);
+    c->h_sj_key_raw.assign((size_t)n, 0);
+    int64_t run = INT64_MIN;
+    for (int64_t i = 0; i < n; ++i) {
+        if (i && (s->tid[i] < s->tid[i - 1] || (s->tid[i] == s->tid[i - 1] && (s->don[i] < s->don[i - 1] ||
+            (s->don[i] == s->don[i - 1] && s->acc[i] < s->acc[i - 1])))))
+            return fail(-1, "[l2r_set_junctions] rows are not sorted by (tid, don, acc) at row %lld", (long long)i);
+        // "row before read": tid smaller, or same tid and acc <= read start (update_gtf.c:613)
+        const int64_t k = host_key(s->tid[i], s->acc[i]);
+        c->h_sj_key_raw[(size_t)i] = k;
+        if (k > run) run = k;
+        key[(size_t)i] = run;
+    }
+    if (c->sj_tid.ensure((size_t)n) || c->sj_don.ensure((size_t)n) || c->sj_acc.ensure((size_t)n) ||
+        c->sj_uniq.ensure((size_t)n) || c->sj_multi.ensure((size_t)n) || c->sj_key.ensure((size_t)n)) return -2;
+    const size_t b = (size_t)n * 4;
+    HIP_TRY(hipMemcpyAsync(c->sj_tid.p, s->tid, b, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->sj_don.p, s->don, b, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->sj_acc.p, s->acc, b, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->sj_uniq.p, s->uniq_c, b, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->sj_multi.p, s->multi_c, b, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->sj_key.p, key.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_sj = n;
+    return 0;
+}
+
+int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
+{
+    if (!c || !r) return fail(-1, "[l2r_upload_reads] null argument");
+    if (r->n_reads < 0 || r->n_cigar < 0) return fail(-1, "[l2r_upload_reads] negative size");
+    // exon offsets are 32 bit on the device: n_exon(read) <= n_cigar(read) + 1
+    if ((uint64_t)r->n_cigar + (uint64_t)r->n_reads >= 0xfffffff0ULL)
+        return fail(-1, "[l2r_upload_reads] shard too large for 32-bit exon offsets (%lld ops + %lld reads); split it", (long long)r->n_cigar, (long long)r->n_reads);
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t N = r->n_reads;
+    if (N && (r->cig_off[0] != 0 || r->cig_off[N] != r->n_cigar)) return fail(-1, "[l2r_upload_reads] cig_off does not span n_cigar");
+    bool sorted = true;
+    for (int64_t i = 0; i < N; ++i) {
+        if (r->tid[i] < 0) return fail(-1, "[l2r_upload_reads] record %lld has no reference (unmapped); the reference aborts on it (bam2gtf.c:100)", (long long)i);
+        if (r->cig_off[i + 1] < r->cig_off[i]) return fail(-1, "[l2r_upload_reads] cig_off not monotone at %lld", (long long)i);
+        if (i && (r->tid[i] < r->tid[i - 1] || (r->tid[i] == r->tid[i - 1] && r->pos[i] < r->pos[i - 1]))) sorted = false;
+    }
+    c->sorted = sorted; c->have_win = false;
+    if (!sorted) { c->h_tid.assign(r->tid, r->tid + N); c->h_pos.assign(r->pos, r->pos + N); }
+    else { c->h_tid.clear(); c->h_pos.clear(); }
+
+    // tile size: keep the expected exons of a tile inside the LDS staging area.
+    // Estimate exons/read from a sample of the CIGARs (ops that can start an exon).
+    int rpt = TILE_THREADS;
+    if (N) {
+        const int64_t sample = N < 4096 ? N : 4096;
+        const int64_t step = N / sample;
+        double cuts = 0;
+        for (int64_t s = 0; s < sample; ++s) {
+            const int64_t i = s * step;
+            for (int64_t k = r->cig_off[i]; k < r->cig_off[i + 1]; ++k) {
+                const uint32_t op = r->cig[k] & 15u; const int len = (int)(r->cig[k] >> 4);
+                cuts += (op == 3u && len >= c->prm.min_intron) || (op == 2u && len > c->prm.max_delet);
+            }
+        }
+        const double est = cuts / (double)sample + 1.0;
+        while (rpt > 32 && est * rpt * 1.25 > (double)LDS_EXON_CAP) rpt >>= 1;
+    }
+    c->reads_per_tile = rpt;
+    c->n_tiles = (N + rpt - 1) / rpt;
+    c->n_tiles256 = (N + TILE_THREADS - 1) / TILE_THREADS;
+
+    if (c->r_tid.ensure((size_t)N) || c->r_pos.ensure((size_t)N) || c->r_rev.ensure((size_t)N) ||
+        c->cig_off.ensure((size_t)N + 1) || c->cig.ensure((size_t)r->n_cigar)) return -2;
+    if (N) {
+        HIP_TRY(hipMemcpyAsync(c->r_tid.p, r->tid, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->r_pos.p, r->pos, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->r_rev.p, r->rev, (size_t)N, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->cig_off.p, r->cig_off, (size_t)(N + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        if (r->n_cigar) HIP_TRY(hipMemcpyAsync(c->cig.p, r->cig, (size_t)r->n_cigar * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    // work buffers.  n_exon(read) <= ops(read) + 1, so n_cigar + n_reads bounds the exon arrays.
+    const size_t exb = (size_t)r->n_cigar + (size_t)N;
+    if (c->n_ex.ensure((size_t)N) || c->ex_off.ensure((size_t)N) || c->info.ensure((size_t)N) || c->ref_tx.ensure((size_t)N) ||
+        c->tile_base.ensure((size_t)c->n_tiles) || c->tile_acc.ensure((size_t)c->n_tiles256) || c->tile_acc_ex.ensure((size_t)c->n_tiles256) ||
+        c->totals.ensure(4) || c->ex_start.ensure(exb) || c->ex_end.ensure(exb) || c->ex_flag.ensure(exb) ||
+        c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
+        c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb)) return -2;
+    c->ex_cap = (int64_t)exb;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_reads = N; c->n_cigar = r->n_cigar; c->first_read = r->first_read_index;
+    c->ran = false; c->totals_valid = false;
+    return 0;
+}
+
+// Unsorted input: the annotation cursor is history dependent (update_gtf.c:801-802).  Replay it on the
+// host (O(N + T)); the per-read work still runs on the GPU.
+static int prepare_unsorted_windows(l2r_ctx *c)
+{
+    if (c->sorted || c->have_win) return 0;
+    const int64_t N = c->n_reads, T = c->n_tx;
+    std::vector<int32_t> w((size_t)N);
+    int64_t cur = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const int64_t q = host_key(c->h_tid[(size_t)i], c->h_pos[(size_t)i] + 1);
+        while (cur < T && c->h_anno_key_raw[(size_t)cur] <= q) ++cur;
+        w[(size_t)i] = (int32_t)cur;
+    }
+    if (c->win_start.ensure((size_t)N)) return -2;
+    if (N) HIP_TRY(hipMemcpyAsync(c->win_start.p, w.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_win = true;
+    return 0;
+}
+
+// Unsorted input with a junction table: the junction cursor only moves for reads that reach the check
+// (update_gtf.c:947), so it needs the classification first.
+static int prepare_unsorted_sj_cursor(l2r_ctx *c)
+{
+    const int64_t N = c->n_reads, S = c->n_sj;
+    std::vector<uint32_t> info((size_t)N);
+    if (N) HIP_TRY(hipMemcpyAsync(info.data(), c->info.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<int32_t> cur_v((size_t)N, 0);
+    int64_t cur = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        if ((info[(size_t)i] & (I_FULL | I_KNOWN | I_KSITE)) != (I_FULL | I_KSITE)) continue;
+        const int64_t q = host_key(c->h_tid[(size_t)i], c->h_pos[(size_t)i] + 1);
+        while (cur < S && c->h_sj_key_raw[(size_t)cur] <= q) ++cur;
+        cur_v[(size_t)i] = (int32_t)cur;
+    }
+    if (c->sj_cursor.ensure((size_t)N)) return -2;
+    if (N) HIP_TRY(hipMemcpyAsync(c->sj_cursor.p, cur_v.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+enum { ST_COUNT = 0, ST_SCAN1, ST_FILL, ST_SJ, ST_CNTACC, ST_SCAN2, ST_GATHER, ST_N };
+
+static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
+{
+    const DevParams p = dev_params(c);
+    const int64_t N = c->n_reads;
+    hipStream_t s = c->stream;
+    const unsigned gt = (unsigned)(c->n_tiles ? c->n_tiles : 1), g256 = (unsigned)(c->n_tiles256 ? c->n_tiles256 : 1);
+#define MARK(i) do { if (ev) HIP_TRY(hipEventRecord(ev[i], s)); } while (0)
+    MARK(ST_COUNT);
+    hipLaunchKernelGGL(k_count_exons, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_pos.p, c->cig_off.p, c->cig.p, p, c->n_ex.p, c->tile_base.p);
+    MARK(ST_SCAN1);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, c->tile_base.p, c->n_tiles, c->totals.p + 0);
+    MARK(ST_FILL);
+    hipLaunchKernelGGL(k_fill_classify, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->r_rev.p, c->cig_off.p, c->cig.p,
+                       c->n_ex.p, c->tile_base.p, c->anno_key.p, (c->sorted ? (const int32_t *)nullptr : c->win_start.p), c->hdr.p, c->anno_ex.p, p,
+                       c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->info.p, c->ref_tx.p);
+    MARK(ST_SJ);
+    if (c->n_sj > 0) {
+        if (!c->sorted) { int rc = prepare_unsorted_sj_cursor(c); if (rc) return rc; }
+        hipLaunchKernelGGL(k_validate_sj, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p,
+                           c->sj_key.p, (c->sorted ? (const int32_t *)nullptr : c->sj_cursor.p), c->sj_tid.p, c->sj_don.p, c->sj_acc.p,
+                           c->sj_uniq.p, c->sj_multi.p, p, c->info.p);
+    }
+    MARK(ST_CNTACC);
+    hipLaunchKernelGGL(k_count_accepted, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->info.p, c->tile_acc.p, c->tile_acc_ex.p);
+    MARK(ST_SCAN2);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, c->tile_acc.p, c->n_tiles256, c->totals.p + 1);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, c->tile_acc_ex.p, c->n_tiles256, c->totals.p + 2);
+    MARK(ST_GATHER);
+    hipLaunchKernelGGL(k_gather_accepted, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->first_read, c->info.p, c->ref_tx.p, c->ex_off.p,
+                       c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->tile_acc.p, c->tile_acc_ex.p,
+                       c->acc_rec.p, c->acc_ex_off.p, c->acc_start.p, c->acc_end.p, c->acc_flag.p);
+    MARK(ST_N);
+#undef MARK
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int l2r_run(l2r_ctx *c)
+{
+    if (!c) return fail(-1, "[l2r_run] null context");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = prepare_unsorted_windows(c);
+    if (rc) return rc;
+    rc = launch_all(c, nullptr);
+    if (rc) return rc;
+    c->ran = true; c->totals_valid = false;
+    return 0;
+}
+
+int l2r_sync(l2r_ctx *c)
+{
+    if (!c) return fail(-1, "[l2r_sync] null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int fetch_totals(l2r_ctx *c)
+{
+    if (!c->ran) return fail(-1, "no completed run on this context");
+    if (c->totals_valid) return 0;
+    HIP_TRY(hipMemcpyAsync(c->h_totals, c->totals.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->totals_valid = true;
+    return 0;
+}
+
+int l2r_run_timed(l2r_ctx *c, int iters, l2r_timing *out)
+{
+    if (!c || !out || iters <= 0) return fail(-1, "[l2r_run_timed] bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = prepare_unsorted_windows(c);
+    if (rc) return rc;
+    memset(out, 0, sizeof *out);
+    hipEvent_t t0, t1, ev[ST_N + 1];
+    HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1));
+    for (int i = 0; i <= ST_N; ++i) HIP_TRY(hipEventCreate(&ev[i]));
+    // pass A: whole pipeline, back to back
+    HIP_TRY(hipEventRecord(t0, c->stream));
+    for (int it = 0; it < iters; ++it) { rc = launch_all(c, nullptr); if (rc) return rc; }
+    HIP_TRY(hipEventRecord(t1, c->stream));
+    HIP_TRY(hipEventSynchronize(t1));
+    float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+    out->total_ms = ms / (float)iters;
+    // pass B: per-stage events
+    for (int it = 0; it < iters; ++it) {
+        rc = launch_all(c, ev); if (rc) return rc;
+        HIP_TRY(hipEventSynchronize(ev[ST_N]));
+        for (int i = 0; i < ST_N; ++i) { float d = 0; HIP_TRY(hipEventElapsedTime(&d, ev[i], ev[i + 1])); out->stage_ms[i] += d / (float)iters; }
+    }
+    out->iters = iters;
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    for (int i = 0; i <= ST_N; ++i) (void)hipEventDestroy(ev[i]);
+    c->ran = true; c->totals_valid = false;
+    return 0;
+}
+
+int l2r_result_sizes(l2r_ctx *c, int64_t *n_reads, int64_t *n_exons, int64_t *n_acc, int64_t *n_acc_ex)
+{
+    if (!c) return fail(-1, "[l2r_result_sizes] null context");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = fetch_totals(c);
+    if (rc) return rc;
+    if (n_reads) *n_reads = c->n_reads;
+    if (n_exons) *n_exons = c->h_totals[0];
+    if (n_acc) *n_acc = c->h_totals[1];
+    if (n_acc_ex) *n_acc_ex = c->h_totals[2];
+    return 0;
+}
+
+int l2r_download(l2r_ctx *c, l2r_result *res)
+{
+    if (!c || !res) return fail(-1, "[l2r_download] null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = fetch_totals(c);
+    if (rc) return rc;
+    const int64_t N = c->n_reads, X = c->h_totals[0];
+    if (res->n_reads < N || res->ex_cap < X) return fail(-3, "[l2r_download] buffers too small: need %lld reads, %lld exons", (long long)N, (long long)X);
+    std::vector<uint32_t> off((size_t)N);
+    if (N) {
+        HIP_TRY(hipMemcpyAsync(off.data(), c->ex_off.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(res->info, c->info.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(res->ref_tx, c->ref_tx.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (X) {
+        HIP_TRY(hipMemcpyAsync(res->ex_start, c->ex_start.p, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(res->ex_end, c->ex_end.p, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(res->ex_flag, c->ex_flag.p, (size_t)X, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < N; ++i) res->ex_off[i] = off[(size_t)i];
+    res->ex_off[N] = X;
+    res->n_reads = N; res->n_exons = X;
+    return 0;
+}
+
+int l2r_download_accepted(l2r_ctx *c, l2r_accepted *a)
+{
+    if (!c || !a) return fail(-1, "[l2r_download_accepted] null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = fetch_totals(c);
+    if (rc) return rc;
+    const int64_t M = c->h_totals[1], X = c->h_totals[2];
+    if (a->n_reads < M || a->ex_cap < X) return fail(-3, "[l2r_download_accepted] buffers too small: need %lld records, %lld exons", (long long)M, (long long)X);
+    std::vector<uint32_t> off((size_t)M);
+    if (M) {
+        HIP_TRY(hipMemcpyAsync(a->rec, c->acc_rec.p, (size_t)M * sizeof(AccRec), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(off.data(), c->acc_ex_off.p, (size_t)M * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (X) {
+        HIP_TRY(hipMemcpyAsync(a->ex_start, c->acc_start.p, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(a->ex_end, c->acc_end.p, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(a->ex_flag, c->acc_flag.p, (size_t)X, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < M; ++i) a->ex_off[i] = off[(size_t)i];
+    a->ex_off[M] = X;
+    a->n_reads = M; a->n_exons = X;
+    return 0;
+}
+
+int l2r_device_view_get(l2r_ctx *c, l2r_device_view *v)
+{
+    if (!c || !v) return fail(-1, "[l2r_device_view_get] null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = fetch_totals(c);
+    if (rc) return rc;
+    v->n_reads = c->n_reads; v->n_exons = c->h_totals[0]; v->n_accepted = c->h_totals[1]; v->n_accepted_exons = c->h_totals[2];
+    v->ex_off = c->ex_off.p; v->ex_start = c->ex_start.p; v->ex_end = c->ex_end.p; v->ex_flag = c->ex_flag.p;
+    v->info = c->info.p; v->ref_tx = c->ref_tx.p;
+    v->acc_rec = (const l2r_accepted_read *)c->acc_rec.p; v->acc_ex_off = c->acc_ex_off.p;
+    v->acc_ex_start = c->acc_start.p; v->acc_ex_end = c->acc_end.p; v->acc_ex_flag = c->acc_flag.p;
+    return 0;
+}
+
+int l2r_classify(l2r_ctx *c, const l2r_reads *reads, l2r_result *res)
+{
+    int rc = l2r_upload_reads(c, reads);
+    if (rc) return rc;
+    if ((rc = l2r_run(c))) return rc;
+    if ((rc = l2r_sync(c))) return rc;
+    return l2r_download(c, res);
+}
+
+}  // extern "C"
+
+static_assert(sizeof(AccRec) == sizeof(l2r_accepted_read), "accepted record layout");
+static_assert(sizeof(TxHdr) == 32, "TxHdr must be two int4");

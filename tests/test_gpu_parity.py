@@ -1,0 +1,173 @@
+"""GPU: the HIP path, called through the C-ABI, against the CPU oracle -- bit exact."""
+import numpy as np
+import pytest
+
+from lr2rmats_amd import capi
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    e = capi.Engine(0)
+    yield e
+    e.close()
+
+
+def _set_anno(engine, af):
+    engine.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
+
+
+def _check(engine, oracle, af, reads, op, sj=None):
+    want = util.oracle_run(oracle, af, reads, op, sj)
+    engine.set_junctions(sj)
+    got = engine.classify(reads, util.to_engine_params(capi, op))
+    util.assert_same_result(got, want, 0 if sj is None else len(sj[0]), op.split_trans)
+    return got, want
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5])
+def test_levels(engine, oracle, level):
+    anno, af, reads = util.make_case(11, n_reads=30000, n_exons=5, anno_exons=20000)
+    _set_anno(engine, af)
+    got, want = _check(engine, oracle, af, reads, oracle.default_params(full_level=level))
+    # sanity: the case exercises all three classes
+    k = (want.info & 1) != 0
+    ks = ((want.info & 2) != 0) & ~k
+    assert k.sum() > 100 and ks.sum() > 100 and (~k & ~ks).sum() > 100
+
+
+@pytest.mark.parametrize("dis", [0, 2, 7])
+def test_splice_distance(engine, oracle, dis):
+    anno, af, reads = util.make_case(12, n_reads=20000, n_exons=6, anno_exons=15000)
+    _set_anno(engine, af)
+    _check(engine, oracle, af, reads, oracle.default_params(full_level=3, ss_dis=dis))
+
+
+@pytest.mark.parametrize("opts", [dict(min_exon=1), dict(min_exon=10, min_intron=200), dict(max_delet=3), dict(min_intron=0)])
+def test_cigar_thresholds_ont(engine, oracle, opts):
+    anno, af, reads = util.make_case(13, n_reads=8000, n_exons=6, anno_exons=15000, ont=True, micro=3, xs=0.02)
+    _set_anno(engine, af)
+    _check(engine, oracle, af, reads, oracle.default_params(full_level=3, **opts))
+
+
+def test_unsorted_gtf_and_long_transcripts(engine, oracle):
+    anno, af, reads = util.make_case(14, n_reads=20000, n_exons=5, anno_exons=15000, shuffle=True, long_tx=2)
+    _set_anno(engine, af)
+    _check(engine, oracle, af, reads, oracle.default_params(full_level=3))
+    _check(engine, oracle, af, reads, oracle.default_params(full_level=5, ss_dis=3))
+
+
+@pytest.mark.parametrize("split,multi,mincnt,dis", [(0, 0, 1, 0), (1, 0, 1, 0), (1, 1, 5, 0), (0, 0, 3, 2)])
+def test_junction_validation(engine, oracle, split, multi, mincnt, dis):
+    anno, af, reads = util.make_case(15, n_reads=20000, n_exons=5, anno_exons=15000)
+    _set_anno(engine, af)
+    base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3))
+    _, sj = util.junction_table(af, reads, base, 15, cover=0.7)
+    op = oracle.default_params(full_level=3, split_trans=split, use_multi=multi, min_sj_cnt=mincnt, ss_dis=dis)
+    got, want = _check(engine, oracle, af, reads, op, sj)
+    assert ((want.info & 32) != 0).sum() > 100 and ((want.info & 64) != 0).sum() > 10
+    assert ((want.ex_flag & 16) != 0).sum() > 10
+    engine.set_junctions(None)
+
+
+def test_sparse_junction_table_q7(engine, oracle):
+    # a table with rows on a few chromosomes only: cursor exhausted / beyond the read (Q7)
+    anno, af, reads = util.make_case(16, n_reads=10000, n_exons=5, anno_exons=10000)
+    _set_anno(engine, af)
+    base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=5))
+    j, sj = util.junction_table(af, reads, base, 16, cover=0.5)
+    keep = (j.tid % 5) == 2
+    sj = tuple(x[keep] for x in sj)
+    _check(engine, oracle, af, reads, oracle.default_params(full_level=5, split_trans=1), sj)
+    engine.set_junctions(None)
+
+
+def test_unsorted_reads_history_cursor(engine, oracle):
+    anno, af, reads = util.make_case(17, n_reads=15000, n_exons=5, anno_exons=10000, unsorted=True)
+    assert not reads.sorted
+    _set_anno(engine, af)
+    _check(engine, oracle, af, reads, oracle.default_params(full_level=3))
+    base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3))
+    _, sj = util.junction_table(af, reads, base, 17, cover=0.7)
+    _check(engine, oracle, af, reads, oracle.default_params(full_level=3, split_trans=1), sj)
+    engine.set_junctions(None)
+
+
+def test_edge_shapes(engine, oracle):
+    anno, af, reads = util.make_case(18, n_reads=3000, n_exons=4, anno_exons=5000)
+    _set_anno(engine, af)
+    op = oracle.default_params(full_level=3)
+    # empty input
+    empty = reads.slice(0, 0)
+    got = engine.classify(empty, util.to_engine_params(capi, op))
+    assert got.info.size == 0 and got.ex_start.size == 0 and got.ex_off.tolist() == [0]
+    # one read; a ragged count that is not a multiple of the tile
+    for n in (1, 257, 1023):
+        _check(engine, oracle, af, reads.slice(0, n), op)
+    # reads whose CIGAR is empty ('*') or starts with N: zero-length first exon
+    r = reads.slice(0, 300)
+    cig = r.cig.copy()
+    cig[r.cig_off[5]] = (100 << 4) | 3            # first op of read 5 becomes an N
+    r.cig = cig
+    _check(engine, oracle, af, r, op)
+    # many-exon reads: more than 64 exons per read and an oversize tile (HBM fallback path)
+    n_big = 300
+    ops_per = 2 * 90 - 1
+    big = np.empty(n_big * ops_per, np.uint32)
+    big[0::2][:] = (30 << 4) | 0
+    tmp = big.reshape(n_big, ops_per)
+    tmp[:, 1::2] = (120 << 4) | 3
+    tmp[:, 0::2] = (30 << 4) | 0
+    from lr2rmats_amd.synth import Reads
+    pos = np.sort(np.random.default_rng(5).integers(10_000, 400_000, n_big)).astype(np.int32)
+    rb = Reads(reads.chrom_names, np.zeros(n_big, np.int32), pos, np.zeros(n_big, np.uint8), np.zeros(n_big, np.uint8),
+               np.zeros(n_big, np.uint8), np.arange(n_big + 1, dtype=np.int64) * ops_per, tmp.ravel())
+    _check(engine, oracle, af, rb, op)
+
+
+def test_single_exon_fraction_float_compare(engine, oracle):
+    # Q6: float ratio compare at several -f values including ones that are not exactly representable
+    anno, af, reads = util.make_case(19, n_reads=20000, n_exons=3, anno_exons=10000, full_frac=0.2)
+    _set_anno(engine, af)
+    for f in (0.8, 0.5, 0.3333333, 1.0, 0.95):
+        _check(engine, oracle, af, reads, oracle.default_params(full_level=5, single_exon_ovlp_frac=f))
+
+
+def test_accepted_compaction_in_read_order(engine, oracle):
+    anno, af, reads = util.make_case(20, n_reads=25000, n_exons=5, anno_exons=15000)
+    _set_anno(engine, af)
+    op = oracle.default_params(full_level=3)
+    engine.set_junctions(None)
+    got = engine.classify(reads, util.to_engine_params(capi, op), first_read_index=1 << 33)
+    acc = engine.download_accepted()
+    idx = np.nonzero((got.info & 128) != 0)[0]
+    np.testing.assert_array_equal(acc.read_index, idx + (1 << 33))
+    np.testing.assert_array_equal(acc.rec["info"], got.info[idx])
+    np.testing.assert_array_equal(acc.rec["ref_tx"], got.ref_tx[idx])
+    lens = (got.info[idx] >> 8).astype(np.int64)
+    np.testing.assert_array_equal(np.diff(acc.ex_off), lens)
+    from lr2rmats_amd.synth import _ragged_gather_index
+    g = _ragged_gather_index(got.ex_off[idx], lens)
+    np.testing.assert_array_equal(acc.ex_start, got.ex_start[g])
+    np.testing.assert_array_equal(acc.ex_end, got.ex_end[g])
+    np.testing.assert_array_equal(acc.ex_flag, got.ex_flag[g])
+
+
+def test_full_size_properties(engine, oracle):
+    """Config-2 size (100k reads x 5 exons, 50k-exon GTF) against the oracle, plus size-independent
+    properties: idempotence (same launch twice) and shard invariance (two halves == whole)."""
+    anno, af, reads = util.make_case(2, n_reads=100000, n_exons=5, anno_exons=50000)
+    _set_anno(engine, af)
+    op = oracle.default_params(full_level=3)
+    got, want = _check(engine, oracle, af, reads, op)
+    again = engine.classify(reads, util.to_engine_params(capi, op))
+    for a, b in ((got.info, again.info), (got.ex_flag, again.ex_flag), (got.ref_tx, again.ref_tx)):
+        np.testing.assert_array_equal(a, b)
+    h = reads.n // 2
+    lo = engine.classify(reads.slice(0, h), util.to_engine_params(capi, op))
+    hi = engine.classify(reads.slice(h, reads.n), util.to_engine_params(capi, op), first_read_index=h)
+    np.testing.assert_array_equal(np.concatenate([lo.info, hi.info]), got.info)
+    np.testing.assert_array_equal(np.concatenate([lo.ex_flag, hi.ex_flag]), got.ex_flag)
+    np.testing.assert_array_equal(np.concatenate([lo.ref_tx, hi.ref_tx]), got.ref_tx)
