@@ -1,0 +1,114 @@
+"""Bench / multi-GPU helpers: the BASELINE.json workloads, read sharding and the
+accepted-record exchange (RCCL all-gatherv through torch.distributed).
+
+Sharding: reads are independent once the cursor values are
+computed by binary search, so the coordinate-sorted read array is cut into
+contiguous ranges, one per rank; annotation and junction table are replicated.
+The only exchange is the all-gatherv of the compacted accepted-novel records
+(the input of the order-dependent host merge), in rank order = read order.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+from . import synth
+
+# BASELINE.json "configs"
+CONFIGS = {
+    "cfg2": dict(n_reads=100_000, n_exons=5, anno_exons=50_000, seed=2, ont=False, micro=0, xs=0.0),
+    "cfg3": dict(n_reads=10_000_000, n_exons=8, anno_exons=1_500_000, seed=3, ont=False, micro=0, xs=0.0),
+    "cfg5": dict(n_reads=20_000_000, n_exons=12, anno_exons=2_000_000, seed=5, ont=True, micro=3, xs=0.02),
+}
+
+
+def algorithmic_bytes(n_reads: int, n_cigar: int, n_exons: int, n_tx: int, n_anno_exons: int, n_sj: int = 0) -> int:
+    """B(r) = 4c + 12 + 8n + (5n - 4) + 8 per read, plus 8E + 20T (+16S) once per launch."""
+    return 4 * n_cigar + 12 * n_reads + 8 * n_exons + (5 * n_exons - 4 * n_reads) + 8 * n_reads + \
+        8 * n_anno_exons + 20 * n_tx + 16 * n_sj
+
+
+def shard_bounds(n_reads: int, world: int, weights: np.ndarray | None = None) -> List[Tuple[int, int]]:
+    """Contiguous read ranges per rank, balanced by ``weights`` (bytes per read) when given."""
+    if weights is None:
+        cuts = [(n_reads * k) // world for k in range(world + 1)]
+    else:
+        cum = np.concatenate([[0], np.cumsum(weights, dtype=np.float64)])
+        cuts = [int(np.searchsorted(cum, cum[-1] * k / world)) for k in range(world)] + [n_reads]
+        cuts[0] = 0
+    return [(cuts[k], cuts[k + 1]) for k in range(world)]
+
+
+def make_rank_workload(cfg: dict, rank: int, world: int):
+    """Weak-scaling workload: every rank gets ``cfg['n_reads']`` reads of the same mix, drawn from its own
+    block of chromosomes, so that the concatenation over ranks is one coordinate-sorted read set of
+    ``world * n_reads`` alignments against the one replicated annotation."""
+    anno = synth.make_annotation(cfg["anno_exons"], cfg["seed"], mean_tx_exons=cfg["n_exons"] + 1)
+    af = anno.in_file_order()
+    nchr = len(anno.chrom_names)
+    lo_c, hi_c = (nchr * rank) // world, (nchr * (rank + 1)) // world
+    if world == 1:
+        sub = anno
+    else:
+        keep = np.nonzero((anno.tx_tid >= lo_c) & (anno.tx_tid < hi_c))[0]
+        lens = np.diff(anno.tx_ex_off)[keep]
+        off = np.zeros(len(keep) + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
+        idx = synth._ragged_gather_index(anno.tx_ex_off[keep], lens)
+        sub = synth.Annotation(anno.chrom_names, anno.tx_tid[keep], anno.tx_rev[keep], anno.tx_gene[keep], off,
+                               anno.ex_start[idx], anno.ex_end[idx], anno.n_genes, None)
+    reads = synth.make_reads(sub, cfg["n_reads"], cfg["n_exons"], cfg["seed"] * 1000 + rank, ont=cfg["ont"],
+                             micro_exons=cfg["micro"], xs_conflict_frac=cfg["xs"])
+    return af, reads
+
+
+# --------------------------------------------------------------------------- exchange
+
+class _DevArray:
+    """Zero-copy torch view of engine-owned HBM through ``__cuda_array_interface__``."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (max(nbytes, 0),), "typestr": "|u1", "data": (ptr or 0, False),
+                                         "version": 2, "strides": None}
+
+
+def device_bytes(ptr: int, nbytes: int, device):
+    import torch
+    if nbytes == 0 or not ptr:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    return torch.as_tensor(_DevArray(ptr, nbytes), device=device)
+
+
+def all_gatherv(t, group=None):
+    """All-gather of 1-D uint8 tensors of different lengths, rank order preserved.
+
+    nccl (= RCCL over xGMI): counts first, then one ``all_gather`` with per-rank sizes (torch issues it as a
+    grouped broadcast when the sizes differ).  gloo (CPU tests): pad to the maximum."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    if dist.get_backend(group) == "nccl":
+        outs = [torch.empty(c, dtype=t.dtype, device=t.device) for c in counts]
+        dist.all_gather(outs, t, group=group)
+        return outs, counts
+    m = max(counts) if counts else 0
+    pad = torch.zeros(m, dtype=t.dtype, device=t.device)
+    pad[: t.numel()] = t
+    outs = [torch.empty(m, dtype=t.dtype, device=t.device) for _ in range(world)]
+    dist.all_gather(outs, pad, group=group)
+    return [o[:c] for o, c in zip(outs, counts)], counts
+
+
+def merge_gathered(rec_parts, off_parts, start_parts, end_parts, flag_parts):
+    """Concatenate per-rank accepted-record arrays (numpy) in rank order; exon offsets are rebased."""
+    rec = np.concatenate(rec_parts)
+    lens = [np.diff(o) if len(o) > 1 else np.zeros(0, np.int64) for o in off_parts]
+    alll = np.concatenate(lens) if lens else np.zeros(0, np.int64)
+    off = np.zeros(len(alll) + 1, np.int64)
+    np.cumsum(alll, out=off[1:])
+    return rec, off, np.concatenate(start_parts), np.concatenate(end_parts), np.concatenate(flag_parts)
