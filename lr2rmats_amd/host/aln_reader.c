@@ -1,0 +1,277 @@
+/* aln_reader.c -- SAM / gzip-SAM / BAM -> structure-of-arrays alignment records.
+ *
+ * Replaces the reference's use of htslib for this path (sam_open, sam_hdr_read,
+ * sam_read1, bam_aux_get, bam_aux2A: src/bam2gtf.c:35-37,92,107;
+ * src/update_gtf.c:1065-1070).  Only the fields gen_exon() reads are kept:
+ * refID, pos, FLAG, CIGAR words, QNAME, and the XS aux tag.  Formats follow the
+ * SAM/BAM specification (SAMv1 sections 1.4, 4.2).
+ */
+#define _GNU_SOURCE
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+#include "l2r_host.h"
+
+typedef struct { uint8_t *p; size_t n; } blob;
+
+static blob slurp(const char *fn, const char *who)
+{
+    /* gzread() passes plain files through and inflates gzip/BGZF (concatenated members) */
+    gzFile g = gzopen(fn, "rb");
+    if (!g) h_fatal(who, "Can not open \"%s\"\n", fn);
+    gzbuffer(g, 1 << 20);
+    blob b = {NULL, 0};
+    size_t cap = 1 << 22;
+    b.p = (uint8_t *)h_malloc(cap);
+    for (;;) {
+        if (b.n + (1 << 20) > cap) { cap *= 2; b.p = (uint8_t *)h_realloc(b.p, cap); }
+        int k = gzread(g, b.p + b.n, 1 << 20);
+        if (k < 0) h_fatal(who, "read error in \"%s\"", fn);
+        if (k == 0) break;
+        b.n += (size_t)k;
+    }
+    gzclose(g);
+    return b;
+}
+
+static void reads_reserve(h_reads *r, int64_t more_reads, int64_t more_cig)
+{
+    if (r->n + more_reads + 1 > r->cap) {
+        int64_t c = r->cap ? r->cap * 2 : 1 << 16;
+        while (c < r->n + more_reads + 1) c *= 2;
+        r->tid = (int32_t *)h_realloc(r->tid, (size_t)c * 4); r->pos = (int32_t *)h_realloc(r->pos, (size_t)c * 4);
+        r->rev = (uint8_t *)h_realloc(r->rev, (size_t)c); r->cig_off = (int64_t *)h_realloc(r->cig_off, (size_t)(c + 1) * 8);
+        r->qname = (uint32_t *)h_realloc(r->qname, (size_t)c * 4);
+        r->cap = c;
+    }
+    if (r->n_cig + more_cig > r->cap_cig) {
+        int64_t c = r->cap_cig ? r->cap_cig * 2 : 1 << 20;
+        while (c < r->n_cig + more_cig) c *= 2;
+        r->cig = (uint32_t *)h_realloc(r->cig, (size_t)c * 4); r->cap_cig = c;
+    }
+}
+
+void h_reads_free(h_reads *r)
+{
+    free(r->tid); free(r->pos); free(r->rev); free(r->cig_off); free(r->cig); free(r->qname); free(r->names.buf);
+    memset(r, 0, sizeof *r);
+}
+
+static void add_qname(h_reads *r, const char *s, size_t len, const char *who)
+{
+    char tmp[H_NAME_MAX];
+    if (len >= H_NAME_MAX) h_fatal(who, "read name of %zu characters; the reference stores names in char[100]", len);
+    memcpy(tmp, s, len); tmp[len] = 0;
+    r->qname[r->n] = h_str_add(&r->names, tmp);
+}
+
+/* ------------------------------------------------------------------ SAM text */
+
+static void parse_sam_header_line(const char *l, const char *e, h_chroms *chr)
+{
+    if (e - l < 3 || memcmp(l, "@SQ", 3) != 0) return;
+    const char *p = l;
+    while (p < e) {
+        const char *t = memchr(p, '\t', (size_t)(e - p));
+        if (!t) break;
+        p = t + 1;
+        if (e - p > 3 && memcmp(p, "SN:", 3) == 0) {
+            const char *q = memchr(p, '\t', (size_t)(e - p));
+            size_t len = (size_t)((q ? q : e) - (p + 3));
+            char name[H_NAME_MAX];
+            if (len >= H_NAME_MAX) h_fatal("sam_hdr_read", "reference name of 100 or more characters");
+            memcpy(name, p + 3, len); name[len] = 0;
+            h_chrom_intern(chr, name);
+            return;
+        }
+    }
+}
+
+static void parse_sam(const blob *b, h_chroms *chr, h_reads *out, int skip_unmapped, int header_only, const char *who)
+{
+    const char *p = (const char *)b->p, *end = p + b->n;
+    int in_header = 1;
+    while (p < end) {
+        const char *nl = memchr(p, '\n', (size_t)(end - p));
+        const char *e = nl ? nl : end;
+        const char *le = e;
+        if (le > p && le[-1] == '\r') --le;
+        if (le == p) { p = e + 1; continue; }
+        if (*p == '@') { if (in_header) parse_sam_header_line(p, le, chr); p = e + 1; continue; }
+        if (in_header) { in_header = 0; chr->n_hdr = chr->n; if (header_only) return; }
+        /* QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL [aux...] */
+        const char *f[12]; int nf = 0; const char *q = p;
+        while (nf < 11) {
+            f[nf++] = q;
+            const char *t = memchr(q, '\t', (size_t)(le - q));
+            if (!t) { q = le; break; }
+            q = t + 1;
+        }
+        if (nf < 11) h_fatal(who, "truncated SAM record");
+        f[11] = q;                                           /* start of aux (or le) */
+        const int flag = atoi(f[1]);
+        if (flag & 4) {
+            if (skip_unmapped) { p = e + 1; continue; }
+            /* reference: gen_trans() leaves exon_n = 0, then malloc((0-1)*2) aborts (src/bam2gtf.c:82,100) */
+            h_fatal_core("read_bam_trans", "Malloc fail!\nSize: -2\n");
+        }
+        size_t ops_bound = (size_t)(f[6] - f[5]);
+        reads_reserve(out, 1, (int64_t)ops_bound);
+        add_qname(out, f[0], (size_t)(f[1] - 1 - f[0]), who);
+        /* RNAME */
+        {
+            size_t len = (size_t)(f[3] - 1 - f[2]);
+            char name[H_NAME_MAX];
+            if (len >= H_NAME_MAX) h_fatal(who, "reference name too long");
+            memcpy(name, f[2], len); name[len] = 0;
+            int tid = (len == 1 && name[0] == '*') ? -1 : h_chrom_find(chr, name, chr->n_hdr);
+            if (tid < 0) h_fatal(who, "record \"%.*s\": reference \"%s\" is not in the header", (int)(f[1] - 1 - f[0]), f[0], name);
+            out->tid[out->n] = tid;
+        }
+        out->pos[out->n] = atoi(f[3]) - 1;
+        /* CIGAR */
+        out->cig_off[out->n] = out->n_cig;
+        {
+            const char *c = f[5], *ce = f[6] - 1;
+            if (!(ce - c == 1 && *c == '*')) {
+                while (c < ce) {
+                    uint32_t len = 0;
+                    while (c < ce && *c >= '0' && *c <= '9') { len = len * 10u + (uint32_t)(*c - '0'); ++c; }
+                    if (c >= ce) h_fatal(who, "bad CIGAR");
+                    uint32_t op;
+                    switch (*c) {
+                    case 'M': op = 0; break; case 'I': op = 1; break; case 'D': op = 2; break; case 'N': op = 3; break;
+                    case 'S': op = 4; break; case 'H': op = 5; break; case 'P': op = 6; break; case '=': op = 7; break;
+                    case 'X': op = 8; break; case 'B': op = 9; break;
+                    default: h_fatal(who, "bad CIGAR operator '%c'", *c); op = 0;
+                    }
+                    out->cig[out->n_cig++] = (len << 4) | op;
+                    ++c;
+                }
+            }
+        }
+        /* strand: XS aux present ? (type 'A' and value '+' ? 0 : 1) : FLAG & 16   (src/bam2gtf.c:35-37;
+         * htslib's bam_aux2A returns 0 for a tag that is not of type 'A') */
+        {
+            uint8_t rev = (flag & 16) ? 1 : 0;
+            const char *a = f[11];
+            while (a < le) {
+                const char *t = memchr(a, '\t', (size_t)(le - a));
+                const char *ae = t ? t : le;
+                if (ae - a >= 5 && a[0] == 'X' && a[1] == 'S' && a[2] == ':') {
+                    rev = (a[3] == 'A' && ae - a >= 6 && a[5] == '+') ? 0 : 1;
+                    break;
+                }
+                if (!t) break;
+                a = t + 1;
+            }
+            out->rev[out->n] = rev;
+        }
+        out->n++;
+        out->cig_off[out->n] = out->n_cig;
+        p = e + 1;
+    }
+    if (in_header) chr->n_hdr = chr->n;
+}
+
+/* ------------------------------------------------------------------ BAM */
+
+static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+/* size of one aux value of the given type at p (SAMv1 4.2.4); 0 on error */
+static size_t aux_size(uint8_t type, const uint8_t *p, const uint8_t *end)
+{
+    switch (type) {
+    case 'A': case 'c': case 'C': return 1;
+    case 's': case 'S': return 2;
+    case 'i': case 'I': case 'f': return 4;
+    case 'Z': case 'H': { const uint8_t *z = memchr(p, 0, (size_t)(end - p)); return z ? (size_t)(z - p) + 1 : 0; }
+    case 'B': {
+        if (end - p < 5) return 0;
+        size_t w;
+        switch (p[0]) { case 'c': case 'C': w = 1; break; case 's': case 'S': w = 2; break; case 'i': case 'I': case 'f': w = 4; break; default: return 0; }
+        return 5 + w * (size_t)le32(p + 1);
+    }
+    default: return 0;
+    }
+}
+
+static void parse_bam(const blob *b, h_chroms *chr, h_reads *out, int skip_unmapped, int header_only, const char *who)
+{
+    const uint8_t *p = b->p, *end = p + b->n;
+    if (end - p < 12 || memcmp(p, "BAM\1", 4) != 0) h_fatal(who, "not a BAM stream");
+    uint32_t l_text = le32(p + 4);
+    p += 8 + l_text;
+    if (p + 4 > end) h_fatal(who, "truncated BAM header");
+    uint32_t n_ref = le32(p); p += 4;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (p + 4 > end) h_fatal(who, "truncated BAM header");
+        uint32_t l_name = le32(p); p += 4;
+        if (p + l_name + 4 > end) h_fatal(who, "truncated BAM header");
+        h_chrom_intern(chr, (const char *)p);            /* NUL terminated */
+        p += l_name + 4;
+    }
+    chr->n_hdr = chr->n;
+    if (header_only) return;
+    while (p + 4 <= end) {
+        uint32_t bs = le32(p); p += 4;
+        if (bs < 32 || p + bs > end) h_fatal(who, "truncated BAM record");
+        const uint8_t *rec = p, *rend = p + bs;
+        p = rend;
+        int32_t refid = (int32_t)le32(rec), pos = (int32_t)le32(rec + 4);
+        uint32_t l_read_name = rec[8], n_cig = le16(rec + 12), flag = le16(rec + 14), l_seq = le32(rec + 16);
+        if (flag & 4) {
+            if (skip_unmapped) continue;
+            h_fatal_core("read_bam_trans", "Malloc fail!\nSize: -2\n");
+        }
+        const uint8_t *name = rec + 32, *cig = name + l_read_name;
+        const uint8_t *aux = cig + 4 * (size_t)n_cig + (l_seq + 1) / 2 + l_seq;
+        if (aux > rend || l_read_name == 0) h_fatal(who, "corrupt BAM record");
+        if (refid < 0 || refid >= chr->n_hdr) h_fatal(who, "BAM record without a valid reference id");
+        /* long CIGARs (> 65535 ops) are stored in the CG:B,I tag with a <len>S<reflen>N placeholder */
+        const uint8_t *cg = NULL; uint32_t cg_n = 0;
+        uint8_t rev = (flag & 16) ? 1 : 0; int xs_seen = 0;
+        for (const uint8_t *a = aux; a + 3 <= rend;) {
+            uint8_t t = a[2];
+            size_t sz = aux_size(t, a + 3, rend);
+            if (sz == 0 || a + 3 + sz > rend) h_fatal(who, "corrupt BAM aux field");
+            if (!xs_seen && a[0] == 'X' && a[1] == 'S') { xs_seen = 1; rev = (t == 'A' && a[3] == '+') ? 0 : 1; }
+            if (a[0] == 'C' && a[1] == 'G' && t == 'B' && a[3] == 'I') { cg_n = le32(a + 4); cg = a + 8; }
+            a += 3 + sz;
+        }
+        const uint8_t *cp = cig; uint32_t cn = n_cig;
+        if (cg && n_cig == 2 && (le32(cig) & 15u) == 4 && (le32(cig) >> 4) == l_seq && (le32(cig + 4) & 15u) == 3) { cp = cg; cn = cg_n; }
+        reads_reserve(out, 1, cn);
+        add_qname(out, (const char *)name, strnlen((const char *)name, l_read_name), who);
+        out->tid[out->n] = refid; out->pos[out->n] = pos; out->rev[out->n] = rev;
+        out->cig_off[out->n] = out->n_cig;
+        for (uint32_t k = 0; k < cn; ++k) out->cig[out->n_cig++] = le32(cp + 4 * (size_t)k);
+        out->n++;
+        out->cig_off[out->n] = out->n_cig;
+    }
+}
+
+static void read_any(const char *fn, h_chroms *chr, h_reads *out, int skip_unmapped, int header_only, const char *who)
+{
+    blob b = slurp(fn, who);
+    h_reads tmp; memset(&tmp, 0, sizeof tmp);
+    h_reads *dst = out ? out : &tmp;
+    reads_reserve(dst, 1, 1);
+    dst->cig_off[0] = 0;
+    if (b.n >= 4 && memcmp(b.p, "BAM\1", 4) == 0) parse_bam(&b, chr, dst, skip_unmapped, header_only, who);
+    else parse_sam(&b, chr, dst, skip_unmapped, header_only, who);
+    free(b.p);
+    if (!out) h_reads_free(&tmp);
+}
+
+void h_read_alignments(const char *fn, h_chroms *chr, h_reads *out, int skip_unmapped, const char *who)
+{
+    memset(out, 0, sizeof *out);
+    read_any(fn, chr, out, skip_unmapped, 0, who);
+}
+
+void h_read_header_only(const char *fn, h_chroms *chr, const char *who)
+{
+    read_any(fn, chr, NULL, 1, 1, who);
+}

@@ -1,0 +1,342 @@
+/* cmds.c -- sub-command drivers with the reference's option tables.
+ *
+ *   update-gtf  src/update_gtf.c:967-1117  (optstring :999, long options :967-993 -- kept verbatim,
+ *               including "M:" consuming an argument and --source mapping to 's': Q13)
+ *   bam2gtf     src/bam2gtf.c:112-161
+ *   unique-gtf  src/unique_gtf.c:53-158
+ *   dispatch    src/main.c:37-49
+ *
+ * The per-read work goes through the C-ABI engine (include/lr2rmats_hip.h); there is no other
+ * implementation of it in this program.
+ */
+#define _GNU_SOURCE
+#include <getopt.h>
+#include <stdlib.h>
+#include <string.h>
+#include "l2r_host.h"
+
+static const char PROG[] = "lr2rmats";
+
+struct h_job {
+    h_update_opts o;
+    h_chroms chr;
+    h_reads reads;
+    h_gtf anno;
+    h_sj sj;
+    FILE *sj_fp;
+    int mode;
+};
+
+static FILE *open_w(const char *fn)
+{
+    FILE *f = fopen(fn, "w");
+    if (!f) h_fatal("update_gtf", "Can not open \"%s\" for writing\n", fn);
+    return f;
+}
+
+static int update_usage(void)
+{
+    /* src/update_gtf.c:37-77 */
+    fprintf(stderr, "\nUsage:   %s update-gtf [option] <in.bam/in.gtf> <old.gtf> > new.gtf\n\n", PROG);
+    fprintf(stderr, "Notice:  the BAM and GTF files should be sorted in advance.\n\n");
+    fprintf(stderr, "Input options:\n\n");
+    fprintf(stderr, "         -m --input-mode   [STR]    format of input file <in.bam/in.gtf>, BAM file(b) or GTF file(g). [b]\n");
+    fprintf(stderr, "         -b --bam          [STR]    for GTF input <in.gtf>, BAM file is needed to obtain BAM header information. [NULL]\n");
+    fprintf(stderr, "         -j --sj           [STR]    junction information file output by STAR(*.out.tab). [NULL]\n\n");
+    fprintf(stderr, "Function options:\n\n");
+    fprintf(stderr, "         -c --force-strand         force to match strand when merging transcripts. [False]\n");
+    fprintf(stderr, "         -e --min-exon     [INT]    minimum length of internal exon. [3]\n");
+    fprintf(stderr, "         -i --min-intron   [INT]    minimum length of intron. [3]\n");
+    fprintf(stderr, "         -t --max-delet    [INT]    maximum length of deletion, longer deletion will be considered as intron. [50]\n");
+    fprintf(stderr, "         -d --distance     [INT]    consider same if distance between two splice site is not bigger than d. [0]\n");
+    fprintf(stderr, "         -D --DISTANCE     [INT]    consider same if distance between two start/end site is not bigger than D. [%d]\n", 0x7fffffff);
+    fprintf(stderr, "         -f --frac         [INT]    consider same if overlapping between two single-exon transcript is bigger than f. [0.80]\n");
+    fprintf(stderr, "         -s --split-trans           split read on unreliable junctions. [False]\n");
+    fprintf(stderr, "         -M --use-multi             use junction information of multi-mapped read. [False]\n");
+    fprintf(stderr, "         -J --min-junc-cnt [INT]    minimum short-read junction count of novel junction. [1]\n");
+    fprintf(stderr, "         -l --full-length  [INT]    level of strict criterion for considering full-length transcript. \n");
+    fprintf(stderr, "                                    (1->5, most strict->most relaxed) [5]\n\n");
+    fprintf(stderr, "Output options:\n\n");
+    fprintf(stderr, "         -o --output       [STR]    updated GTF file. [stdout]\n");
+    fprintf(stderr, "         -n --min-output            only keep the minimal set of novel transcripts in the updated GTF file. [False]\n");
+    fprintf(stderr, "         -E --exon-bed     [STR]    updated novel exon file in bed format. [NULL]\n");
+    fprintf(stderr, "         -a --bam-gtf      [STR]    bam-derived transcript GTF file. [NULL]\n");
+    fprintf(stderr, "         -A --bam-detial   [STR]    detailed information of each bam-derived transcript. [NULL]\n");
+    fprintf(stderr, "         -k --known-gtf    [STR]    bam-derived known transcript GTF file. [NULL]\n");
+    fprintf(stderr, "         -v --novel-gtf    [STR]    bam-derived novel transcript GTF file. [NULL]\n");
+    fprintf(stderr, "         -u --unrecog      [STR]    bam-derived unrecognized transcript GTF file. [NULL]\n");
+    fprintf(stderr, "         -y --summary      [STR]    Staticstic summary of bam-derived transcript. [NULL]\n");
+    fprintf(stderr, "         -S --source       [STR]    'source' field in GTF: program, database or project name. [%s]\n\n", PROG);
+    return 1;
+}
+
+static void default_params(l2r_params *p)
+{
+    /* src/update_gtf.c:24-35, src/gtf.h:118-127 */
+    p->min_exon = 3; p->min_intron = 3; p->max_delet = 50; p->ss_dis = 0; p->end_dis = 0x7fffffff; p->full_level = 5;
+    p->split_trans = 0; p->use_multi = 0; p->min_sj_cnt = 1; p->force_strand = 0; p->single_exon_ovlp_frac = 0.80;
+}
+
+h_job *h_job_open(int argc, char **argv, int *exit_code)
+{
+    static const struct option lopt[] = {
+        {"input-mode", 1, 0, 'm'}, {"bam", 1, 0, 'b'}, {"sj", 1, 0, 'j'}, {"force-strand", 0, 0, 'c'},
+        {"min-exon", 1, 0, 'e'}, {"min-intron", 1, 0, 'i'}, {"distance", 1, 0, 'd'}, {"DISTANCE", 1, 0, 'D'},
+        {"frac", 1, 0, 'f'}, {"full-gtf", 1, 0, 'l'}, {"use-multi", 0, 0, 'M'}, {"min_sj_cnt", 1, 0, 'J'},
+        {"output", 1, 0, 'o'}, {"bam-gtf", 1, 0, 'a'}, {"known-gtf", 1, 0, 'k'}, {"novel-gtf", 1, 0, 'v'},
+        {"unrecog", 1, 0, 'u'}, {"source", 1, 0, 's'}, {0, 0, 0, 0}};
+    h_job *j = (h_job *)calloc(1, sizeof *j);
+    default_params(&j->o.prm);
+    j->o.out_gtf = stdout; strcpy(j->o.source, PROG);
+    const char *hdr_file = NULL;
+    int c;
+    *exit_code = 0;
+    optind = 1;
+    while ((c = getopt_long(argc, argv, "m:b:j:J:M:e:i:t:sd:D:f:cl:o:nE:a:A:k:v:u:y:S:", lopt, NULL)) >= 0) {
+        switch (c) {
+        case 'm': if (optarg[0] == 'b') j->mode = 0; else if (optarg[0] == 'g') j->mode = 1; else { *exit_code = update_usage(); free(j); return NULL; } break;
+        case 'b': hdr_file = optarg; { FILE *t = fopen(optarg, "rb"); if (!t) h_fatal("update_gtf", "Cannot open \"%s\"\n", optarg); fclose(t); } break;
+        case 'j': if (!(j->sj_fp = fopen(optarg, "r"))) h_fatal("update_gtf", "Can not open splice-junction file \"%s\"\n", optarg); break;
+        case 'e': j->o.prm.min_exon = atoi(optarg); break;
+        case 'i': j->o.prm.min_intron = atoi(optarg); break;
+        case 't': j->o.prm.max_delet = atoi(optarg); break;
+        case 'd': j->o.prm.ss_dis = atoi(optarg); break;
+        case 'D': j->o.prm.end_dis = atoi(optarg); break;
+        case 'f': j->o.prm.single_exon_ovlp_frac = atof(optarg); break;
+        case 'c': j->o.prm.force_strand = 1; break;
+        case 's': j->o.prm.split_trans = 1; break;
+        case 'l': j->o.prm.full_level = atoi(optarg); break;
+        case 'M': j->o.prm.use_multi = 1; break;
+        case 'J': j->o.prm.min_sj_cnt = atoi(optarg); break;
+        case 'o': j->o.out_gtf = open_w(optarg); break;
+        case 'n': break;                                   /* accepted, unused (src/update_gtf.c:1031,1084) */
+        case 'E': j->o.exon_bed = open_w(optarg); break;
+        case 'a': j->o.bam_gtf = open_w(optarg); break;
+        case 'A': j->o.bam_detail = open_w(optarg); break;
+        case 'k': j->o.known_gtf = open_w(optarg); break;
+        case 'v': j->o.novel_gtf = open_w(optarg); break;
+        case 'u': j->o.unrecog_gtf = open_w(optarg); break;
+        case 'y': j->o.summary = open_w(optarg); break;
+        case 'S': strncpy(j->o.source, optarg, sizeof j->o.source - 1); break;
+        default: fprintf(stderr, "Error: unknown option: %s.\n", optarg); *exit_code = update_usage(); free(j); return NULL;
+        }
+    }
+    if (argc - optind != 2) { *exit_code = update_usage(); free(j); return NULL; }
+
+    if (j->mode == 0) {
+        h_read_alignments(argv[optind], &j->chr, &j->reads, 0, "update_gtf");
+    } else {
+        if (!hdr_file) h_fatal("update_gtf", "Couldn't read header of provided BAM file.\n");
+        h_read_header_only(hdr_file, &j->chr, "update_gtf");
+        h_fatal("update_gtf", "GTF input (-m g) is not wired to the GPU engine yet; use unique-gtf -m g or BAM/SAM input");
+    }
+    fprintf(stderr, "[read_anno_trans] reading transcript annotation from %s ...\n", argv[optind + 1]);
+    h_read_gtf(argv[optind + 1], &j->chr, &j->anno, 0);
+    fprintf(stderr, "[read_anno_trans] reading transcript annotation from %s done.\n", argv[optind + 1]);
+    h_read_sj(j->sj_fp, &j->chr, &j->sj);
+    return j;
+}
+
+void h_job_views(h_job *j, l2r_params *prm, l2r_annotation *a, l2r_junctions *s, l2r_reads *r)
+{
+    *prm = j->o.prm;
+    a->n_tx = j->anno.n_tx; a->n_exon = j->anno.n_ex; a->tx_tid = j->anno.tid; a->tx_start = j->anno.start; a->tx_end = j->anno.end;
+    a->tx_rev = j->anno.rev; a->tx_ex_off = j->anno.ex_off; a->ex_start = j->anno.ex_start; a->ex_end = j->anno.ex_end;
+    s->n = j->sj.n; s->tid = j->sj.tid; s->don = j->sj.don; s->acc = j->sj.acc; s->uniq_c = j->sj.uniq; s->multi_c = j->sj.multi;
+    r->n_reads = j->reads.n; r->n_cigar = j->reads.n_cig; r->tid = j->reads.tid; r->pos = j->reads.pos; r->rev = j->reads.rev;
+    r->cig_off = j->reads.cig_off; r->cig = j->reads.cig; r->first_read_index = 0;
+}
+
+int h_job_finish(h_job *j, const l2r_result *res)
+{
+    h_result hr;
+    hr.n = res->n_reads; hr.n_ex = res->n_exons; hr.ex_off = res->ex_off; hr.ex_start = res->ex_start; hr.ex_end = res->ex_end;
+    hr.ex_flag = res->ex_flag; hr.info = res->info; hr.ref_tx = res->ref_tx;
+    if (hr.n != j->reads.n) h_fatal("update_gtf", "result covers %lld reads, input has %lld", (long long)hr.n, (long long)j->reads.n);
+    h_update_tail(&j->o, &j->chr, &j->reads, &j->anno, &hr, j->sj.n);
+    FILE **fs[] = {&j->o.exon_bed, &j->o.bam_gtf, &j->o.bam_detail, &j->o.known_gtf, &j->o.novel_gtf, &j->o.unrecog_gtf, &j->o.summary};
+    for (size_t k = 0; k < sizeof fs / sizeof fs[0]; ++k) if (*fs[k]) { fclose(*fs[k]); *fs[k] = NULL; }
+    if (j->o.out_gtf && j->o.out_gtf != stdout) { fclose(j->o.out_gtf); j->o.out_gtf = NULL; } else fflush(stdout);
+    return 0;
+}
+
+void h_job_free(h_job *j)
+{
+    if (!j) return;
+    if (j->sj_fp) fclose(j->sj_fp);
+    h_reads_free(&j->reads); h_gtf_free(&j->anno); h_sj_free(&j->sj); h_chroms_free(&j->chr);
+    free(j);
+}
+
+/* engine helpers ----------------------------------------------------------- */
+
+static void engine_fail(const char *who) { h_fatal(who, "%s", l2r_last_error()); }
+
+static void run_engine(const char *who, const l2r_params *prm, const l2r_annotation *a, const l2r_junctions *s,
+                       const l2r_reads *r, h_result *out)
+{
+    l2r_ctx *ctx = l2r_create(0);
+    if (!ctx) engine_fail(who);
+    if (l2r_set_params(ctx, prm) || l2r_set_annotation(ctx, a) || l2r_set_junctions(ctx, s->n ? s : NULL)) engine_fail(who);
+    if (l2r_upload_reads(ctx, r) || l2r_run(ctx) || l2r_sync(ctx)) engine_fail(who);
+    int64_t n = 0, x = 0;
+    if (l2r_result_sizes(ctx, &n, &x, NULL, NULL)) engine_fail(who);
+    h_result_alloc(out, n, x);
+    l2r_result res = { n, x, 0, out->ex_off, out->ex_start, out->ex_end, out->ex_flag, out->info, out->ref_tx };
+    if (l2r_download(ctx, &res)) engine_fail(who);
+    out->n = res.n_reads; out->n_ex = res.n_exons;
+    l2r_destroy(ctx);
+}
+
+int h_cmd_update_gtf(int argc, char **argv)
+{
+    int rc = 0;
+    h_job *j = h_job_open(argc, argv, &rc);
+    if (!j) return rc;
+    l2r_params prm; l2r_annotation a; l2r_junctions s; l2r_reads r;
+    h_job_views(j, &prm, &a, &s, &r);
+    h_result out;
+    run_engine("update_gtf", &prm, &a, &s, &r, &out);
+    l2r_result res = { out.n, out.n_ex, out.n_ex, out.ex_off, out.ex_start, out.ex_end, out.ex_flag, out.info, out.ref_tx };
+    rc = h_job_finish(j, &res);
+    h_result_free(&out);
+    h_job_free(j);
+    return rc;
+}
+
+static int bam2gtf_usage(void)
+{
+    fprintf(stderr, "\nUsage:   %s bam2gtf [option] <in.bam> > out.gtf\n\nOptions:\n\n", PROG);
+    fprintf(stderr, "         -e --min-exon    [INT]    minimum length of internal exon. [3]\n");
+    fprintf(stderr, "         -i --min-intron  [INT]    minimum length of intron. [3]\n");
+    fprintf(stderr, "         -t --max-delet   [INT]    maximum length of deletion, longer deletion will be considered as intron. [50]\n");
+    fprintf(stderr, "         -s --source      [STR]    source field in GTF, program, database or project name. [%s]\n\n", PROG);
+    return 1;
+}
+
+/* exon chains of every mapped record through the engine (annotation empty) */
+static void exons_only(const char *who, const char *fn, const l2r_params *prm, h_chroms *chr, h_reads *reads, h_result *out, int skip_unmapped)
+{
+    h_read_alignments(fn, chr, reads, skip_unmapped, who);
+    l2r_annotation a; memset(&a, 0, sizeof a);
+    int64_t zero_off = 0; a.tx_ex_off = &zero_off;
+    l2r_junctions s; memset(&s, 0, sizeof s);
+    l2r_reads r = { reads->n, reads->n_cig, reads->tid, reads->pos, reads->rev, reads->cig_off, reads->cig, 0 };
+    run_engine(who, prm, &a, &s, &r, out);
+}
+
+int h_cmd_bam2gtf(int argc, char **argv)
+{
+    static const struct option lopt[] = {{"exon-min", 1, 0, 'e'}, {"intron-len", 1, 0, 'i'}, {"source", 1, 0, 's'}, {0, 0, 0, 0}};
+    l2r_params p; default_params(&p);
+    char src[1024]; strcpy(src, PROG);
+    int c;
+    optind = 1;
+    while ((c = getopt_long(argc, argv, "s:e:i:t:", lopt, NULL)) >= 0) {
+        switch (c) {
+        case 'e': p.min_exon = atoi(optarg); break;
+        case 'i': p.min_intron = atoi(optarg); break;
+        case 't': p.max_delet = atoi(optarg); break;
+        case 's': strncpy(src, optarg, sizeof src - 1); break;
+        default: fprintf(stderr, "Error: unknown option: %s.\n", optarg); return bam2gtf_usage();
+        }
+    }
+    if (argc - optind != 1) return bam2gtf_usage();
+    h_chroms chr; memset(&chr, 0, sizeof chr);
+    h_reads reads; h_result out;
+    exons_only("bam2gtf", argv[optind], &p, &chr, &reads, &out, 1);
+    /* src/gtf.c:597-604 print_trans: gene_id + transcript_id only, exons always ascending */
+    char line[512];
+    for (int64_t i = 0; i < out.n; ++i) {
+        const int64_t off = out.ex_off[i]; const int n = (int)L2R_INFO_NEXON(out.info[i]);
+        const char *q = h_str(&reads.names, reads.qname[i]), *cn = chr.name[reads.tid[i]];
+        const char st = "+-"[reads.rev[i] != 0];
+        snprintf(line, sizeof line, "%s\t%s\ttranscript\t%d\t%d\t.\t%c\t.\tgene_id \"%s\"; transcript_id \"%s\";\n", cn, src, out.ex_start[off], out.ex_end[off + n - 1], st, q, q);
+        fputs(line, stdout);
+        for (int k = 0; k < n; ++k) {
+            snprintf(line, sizeof line, "%s\t%s\texon\t%d\t%d\t.\t%c\t.\tgene_id \"%s\"; transcript_id \"%s\";\n", cn, src, out.ex_start[off + k], out.ex_end[off + k], st, q, q);
+            fputs(line, stdout);
+        }
+    }
+    fflush(stdout);
+    h_result_free(&out); h_reads_free(&reads); h_chroms_free(&chr);
+    return 0;
+}
+
+static int unique_usage(void)
+{
+    fprintf(stderr, "\nUsage:   %s unique-gtf [option] <in.sorted.bam/in.sorted.gtf> > unique.gtf\n\n", PROG);
+    fprintf(stderr, "Notice:  the BAM and GTF files should be sorted in advance.\n\n");
+    fprintf(stderr, "         -m --input-mode  [STR]    BAM file(b) or GTF file(g). [b]\n");
+    fprintf(stderr, "         -b --bam         [STR]    for GTF input, BAM file to obtain BAM header information. [NULL]\n");
+    fprintf(stderr, "         -s --force-strand         force to match strand when merging transcripts. [False]\n");
+    fprintf(stderr, "         -e -i -d -D -f            as update-gtf\n");
+    fprintf(stderr, "         -I --intersect            output intersected transcript. [False]\n");
+    fprintf(stderr, "         -o --output      [STR]    unique GTF file. [stdout]\n");
+    fprintf(stderr, "         -S --source      [STR]    'source' field in GTF. [%s]\n\n", PROG);
+    return 1;
+}
+
+int h_cmd_unique_gtf(int argc, char **argv)
+{
+    /* src/unique_gtf.c:53-158; optstring :90 (no 't': -t is not accepted although :109 would handle it) */
+    static const struct option lopt[] = {
+        {"input-mode", 1, 0, 'm'}, {"bam", 1, 0, 'b'}, {"force-strand", 0, 0, 's'}, {"min-exon", 1, 0, 'e'},
+        {"min-intron", 1, 0, 'i'}, {"distance", 1, 0, 'd'}, {"DISTANCE", 1, 0, 'D'}, {"frac", 1, 0, 'f'},
+        {"intersect", 0, 0, 'I'}, {"output", 1, 0, 'o'}, {"source", 1, 0, 's'}, {0, 0, 0, 0}};
+    l2r_params p; default_params(&p);
+    int mode = 0, c, intersect = 0; const char *hdr_file = NULL; char src[1024]; strcpy(src, PROG); FILE *out = stdout;
+    optind = 1;
+    while ((c = getopt_long(argc, argv, "m:b:se:i:Id:D:f:o:S:", lopt, NULL)) >= 0) {
+        switch (c) {
+        case 'm': if (optarg[0] == 'b') mode = 0; else if (optarg[0] == 'g') mode = 1; else return unique_usage(); break;
+        case 'b': hdr_file = optarg; break;
+        case 's': p.force_strand = 1; break;
+        case 'e': p.min_exon = atoi(optarg); break;
+        case 'i': p.min_intron = atoi(optarg); break;
+        case 'd': p.ss_dis = atoi(optarg); break;
+        case 'D': p.end_dis = atoi(optarg); break;
+        case 'f': p.single_exon_ovlp_frac = atof(optarg); break;
+        case 'I': intersect = 1; break;
+        case 'o': out = open_w(optarg); break;
+        case 'S': strncpy(src, optarg, sizeof src - 1); break;
+        default: fprintf(stderr, "Error: unknown option: %s.\n", optarg); return unique_usage();
+        }
+    }
+    if (argc - optind != 1) return unique_usage();
+    h_chroms chr; memset(&chr, 0, sizeof chr);
+    if (mode == 0) {
+        h_reads reads; h_result res;
+        exons_only("unique_gtf", argv[optind], &p, &chr, &reads, &res, 0);
+        /* strand as gen_exon gives it; all four names = QNAME (src/bam2gtf.c:104) */
+        h_unique_tail(&p, src, out, intersect, &chr, res.n, reads.tid, reads.rev, res.ex_off, res.ex_start, res.ex_end,
+                      &reads.names, reads.qname, reads.qname, reads.qname, reads.qname);
+        h_result_free(&res); h_reads_free(&reads);
+    } else {
+        if (!hdr_file) h_fatal("unique_gtf", "Couldn't read header of provided BAM file.\n");
+        h_read_header_only(hdr_file, &chr, "unique_gtf");
+        h_gtf g;
+        h_read_gtf(argv[optind], &chr, &g, 1);
+        h_unique_tail(&p, src, out, intersect, &chr, g.n_tx, g.tid, g.rev, g.ex_off, g.ex_start, g.ex_end,
+                      &g.names, g.gid, g.tids, g.gname, g.tname);
+        h_gtf_free(&g);
+    }
+    if (out != stdout) fclose(out); else fflush(stdout);
+    h_chroms_free(&chr);
+    return 0;
+}
+
+int h_main(int argc, char **argv)
+{
+    /* src/main.c:37-49 */
+    if (argc < 1) return 1;
+    if (strcmp(argv[0], "update-gtf") == 0) return h_cmd_update_gtf(argc, argv);
+    if (strcmp(argv[0], "bam2gtf") == 0) return h_cmd_bam2gtf(argc, argv);
+    if (strcmp(argv[0], "unique-gtf") == 0) return h_cmd_unique_gtf(argc, argv);
+    if (!strcmp(argv[0], "filter") || !strcmp(argv[0], "fusion") || !strcmp(argv[0], "bam2sj")) {
+        fprintf(stderr, "[main] command '%s' is outside the MI355X build (see DESIGN.md, scope)\n", argv[0]);
+        return 1;
+    }
+    fprintf(stderr, "[main] unrecognized command '%s'\n", argv[0]);
+    return 1;
+}

@@ -1,0 +1,114 @@
+/* l2r_host.h -- host side (C) of the MI355X lr2rmats build.
+ *
+ * Mirrors the reference's sub-command surface (src/main.c:41-47:
+ * update-gtf, unique-gtf, bam2gtf) around the C-ABI engine of
+ * include/lr2rmats_hip.h.  Data lives in structure-of-arrays containers that
+ * are handed to the engine unchanged; the order-dependent tail of the
+ * reference (list routing, split_trans, merge_trans, writers) runs here.
+ */
+#ifndef L2R_HOST_H
+#define L2R_HOST_H
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/lr2rmats_hip.h"
+
+#define H_NAME_MAX 100          /* reference name buffers are char[100] (src/gtf.h:44-45) */
+
+/* ---- errors: reference exit behaviour (src/utils.c:91-111) */
+void h_fatal(const char *where, const char *fmt, ...);        /* "[where] msg" + exit(1) */
+void h_fatal_core(const char *where, const char *fmt, ...);   /* "[where] msg Abort!" + abort() */
+void *h_malloc(size_t n);
+void *h_realloc(void *p, size_t n);
+
+/* ---- append-only string table: ids are byte offsets */
+typedef struct { char *buf; size_t len, cap; } h_strtab;
+uint32_t h_str_add(h_strtab *t, const char *s);
+static inline const char *h_str(const h_strtab *t, uint32_t id) { return t->buf + id; }
+
+/* ---- chromosome names: BAM header first, then first-seen in the SJ file (src/gtf.c:389-412) */
+typedef struct { char **name; int n, cap, n_hdr; } h_chroms;
+int  h_chrom_find(const h_chroms *c, const char *s, int limit);
+int  h_chrom_intern(h_chroms *c, const char *s);
+void h_chroms_free(h_chroms *c);
+
+/* ---- alignment records (what l2r_reads wants) + names */
+typedef struct {
+    int64_t n, cap;
+    int32_t *tid, *pos;
+    uint8_t *rev;
+    int64_t *cig_off;
+    uint32_t *cig; int64_t n_cig, cap_cig;
+    uint32_t *qname;             /* ids into names */
+    h_strtab names;
+} h_reads;
+
+/* Reads every record of a SAM (text), gzip/BGZF-compressed SAM or BAM file.
+ * skip_unmapped = 0: an unmapped record is the reference's abort (Q9). */
+void h_read_alignments(const char *fn, h_chroms *chr, h_reads *out, int skip_unmapped, const char *who);
+void h_read_header_only(const char *fn, h_chroms *chr, const char *who);
+void h_reads_free(h_reads *r);
+
+/* ---- transcripts from a GTF (annotation, or read-like input of `-m g`) */
+typedef struct {
+    int64_t n_tx, cap_tx, n_ex, cap_ex;
+    int32_t *tid, *start, *end;
+    uint8_t *rev;
+    int64_t *ex_off;             /* n_tx + 1 */
+    int32_t *ex_start, *ex_end;
+    uint32_t *gid, *gname, *tids, *tname;   /* ids into names */
+    h_strtab names;
+    int gene_n;
+} h_gtf;
+void h_read_gtf(const char *fn, const h_chroms *chr, h_gtf *out, int as_reads);
+void h_gtf_free(h_gtf *g);
+
+/* ---- STAR SJ.out.tab */
+typedef struct { int64_t n; int32_t *tid, *don, *acc, *uniq, *multi; } h_sj;
+void h_read_sj(FILE *fp, h_chroms *chr, h_sj *out);
+void h_sj_free(h_sj *s);
+
+/* ---- per-read results as the engine returns them */
+typedef struct {
+    int64_t n, n_ex;
+    int64_t *ex_off;
+    int32_t *ex_start, *ex_end;
+    uint8_t *ex_flag;
+    uint32_t *info;
+    int32_t *ref_tx;
+} h_result;
+void h_result_alloc(h_result *r, int64_t n_reads, int64_t ex_cap);
+void h_result_free(h_result *r);
+
+/* ---- the sequential tail + writers */
+typedef struct {
+    l2r_params prm;
+    FILE *out_gtf, *exon_bed, *bam_gtf, *bam_detail, *known_gtf, *novel_gtf, *unrecog_gtf, *summary;
+    char source[1024];
+} h_update_opts;
+
+/* Everything update_gtf() does after check_with_anno_trans/check_with_short_sj:
+ * routing + split + merge (src/update_gtf.c:943-964) and all writers (:1087-1095).
+ * read names / gene names come from `reads` and `anno`. */
+void h_update_tail(const h_update_opts *o, const h_chroms *chr, const h_reads *reads, const h_gtf *anno,
+                   const h_result *res, int64_t n_sj);
+
+void h_unique_tail(const l2r_params *p, const char *source, FILE *out, int intersect, const h_chroms *chr,
+                   int64_t n, const int32_t *tid, const uint8_t *rev, const int64_t *ex_off, const int32_t *xs, const int32_t *xe,
+                   const h_strtab *names, const uint32_t *gid, const uint32_t *tids, const uint32_t *gname, const uint32_t *tname);
+
+/* ---- sub-commands (argv[0] = sub-command name) */
+int h_cmd_update_gtf(int argc, char **argv);
+int h_cmd_bam2gtf(int argc, char **argv);
+int h_cmd_unique_gtf(int argc, char **argv);
+int h_main(int argc, char **argv);
+
+/* ---- staged form of update-gtf, used by the CLI itself and by the one-process-per-GPU driver
+ * (lr2rmats_amd/dist.py): open = parse options + read all inputs; views = the structure-of-arrays
+ * the engine consumes; finish = sequential tail + writers with the per-read results. */
+typedef struct h_job h_job;
+h_job *h_job_open(int argc, char **argv, int *exit_code);
+void   h_job_views(h_job *j, l2r_params *prm, l2r_annotation *anno, l2r_junctions *sj, l2r_reads *reads);
+int    h_job_finish(h_job *j, const l2r_result *res);
+void   h_job_free(h_job *j);
+
+#endif

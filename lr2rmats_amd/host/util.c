@@ -1,0 +1,93 @@
+/* util.c -- errors, memory, string table, chromosome table. */
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include "l2r_host.h"
+
+void h_fatal(const char *where, const char *fmt, ...)
+{
+    /* reference src/utils.c:91-100 err_fatal: message on stderr, exit status 1 */
+    va_list ap;
+    fprintf(stderr, "[%s] ", where);
+    va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap);
+    fprintf(stderr, "\n");
+    exit(EXIT_FAILURE);
+}
+
+void h_fatal_core(const char *where, const char *fmt, ...)
+{
+    /* reference src/utils.c:102-111 err_fatal_core: abort() (SIGABRT) */
+    va_list ap;
+    fprintf(stderr, "[%s] ", where);
+    va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap);
+    fprintf(stderr, " Abort!\n");
+    abort();
+}
+
+void *h_malloc(size_t n)
+{
+    void *p = malloc(n ? n : 1);
+    if (!p) h_fatal_core("h_malloc", "Malloc fail!\nSize: %lld\n", (long long)n);
+    return p;
+}
+
+void *h_realloc(void *q, size_t n)
+{
+    void *p = realloc(q, n ? n : 1);
+    if (!p) h_fatal_core("h_realloc", "Realloc fail!\nSize: %lld\n", (long long)n);
+    return p;
+}
+
+uint32_t h_str_add(h_strtab *t, const char *s)
+{
+    size_t n = strlen(s) + 1;
+    if (t->len + n > t->cap) {
+        size_t c = t->cap ? t->cap * 2 : 1 << 16;
+        while (c < t->len + n) c *= 2;
+        if (c >= 0xffffffffu) h_fatal("h_str_add", "string table exceeds 4 GiB");
+        t->buf = (char *)h_realloc(t->buf, c); t->cap = c;
+    }
+    memcpy(t->buf + t->len, s, n);
+    uint32_t id = (uint32_t)t->len;
+    t->len += n;
+    return id;
+}
+
+int h_chrom_find(const h_chroms *c, const char *s, int limit)
+{
+    for (int i = 0; i < limit; ++i) if (strcmp(c->name[i], s) == 0) return i;
+    return -1;
+}
+
+int h_chrom_intern(h_chroms *c, const char *s)
+{
+    int i = h_chrom_find(c, s, c->n);
+    if (i >= 0) return i;
+    if (strlen(s) >= H_NAME_MAX) h_fatal("get_chr_id", "chromosome name \"%s\" has 100 or more characters", s);
+    if (c->n == c->cap) { c->cap = c->cap ? c->cap * 2 : 32; c->name = (char **)h_realloc(c->name, (size_t)c->cap * sizeof(char *)); }
+    c->name[c->n] = strdup(s);
+    return c->n++;
+}
+
+void h_chroms_free(h_chroms *c)
+{
+    for (int i = 0; i < c->n; ++i) free(c->name[i]);
+    free(c->name); memset(c, 0, sizeof *c);
+}
+
+void h_result_alloc(h_result *r, int64_t n, int64_t cap)
+{
+    r->n = n; r->n_ex = cap;
+    r->ex_off = (int64_t *)h_malloc((size_t)(n + 1) * 8);
+    r->ex_start = (int32_t *)h_malloc((size_t)cap * 4);
+    r->ex_end = (int32_t *)h_malloc((size_t)cap * 4);
+    r->ex_flag = (uint8_t *)h_malloc((size_t)cap);
+    r->info = (uint32_t *)h_malloc((size_t)n * 4);
+    r->ref_tx = (int32_t *)h_malloc((size_t)n * 4);
+}
+
+void h_result_free(h_result *r)
+{
+    free(r->ex_off); free(r->ex_start); free(r->ex_end); free(r->ex_flag); free(r->info); free(r->ref_tx);
+    memset(r, 0, sizeof *r);
+}

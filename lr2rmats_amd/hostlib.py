@@ -1,0 +1,107 @@
+"""ctypes view of ``libl2r_host.so`` -- the C host side in its staged form.
+
+``Job.open(argv)`` parses the update-gtf options and reads all inputs (C code),
+``job.views()`` exposes the structure-of-arrays the engine consumes as numpy
+arrays (zero copy), ``job.finish(result)`` runs the sequential tail and writes
+every output file.  Used by the one-process-per-GPU driver (``dist.py``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List
+
+import numpy as np
+
+from . import capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libl2r_host.so")
+CLI_PATH = os.path.join(HERE, "bin", "lr2rmats")
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError("%s is missing: build it with `make -C lr2rmats_amd/host`" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.h_job_open.restype = C.c_void_p
+        lib.h_job_open.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+        lib.h_job_views.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.h_job_finish.argtypes = [C.c_void_p, C.c_void_p]
+        lib.h_job_finish.restype = C.c_int
+        lib.h_job_free.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype) if False else np.frombuffer(
+        (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(C.addressof(ptr.contents)), dtype=dtype, count=n)
+
+
+class Job:
+    """One ``update-gtf`` invocation: argv = ["update-gtf", options..., in.bam, old.gtf]."""
+
+    def __init__(self, argv: List[str]):
+        self.lib = load_library()
+        args = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+        rc = C.c_int(0)
+        self._argv_keep = args
+        self.h = self.lib.h_job_open(len(argv), args, C.byref(rc))
+        self.exit_code = rc.value
+        if not self.h:
+            raise SystemExit(self.exit_code or 1)
+        self.prm = capi.Params()
+        self.anno = capi.CAnnotation()
+        self.sj = capi.CJunctions()
+        self.reads = capi.CReads()
+        self.lib.h_job_views(self.h, C.byref(self.prm), C.byref(self.anno), C.byref(self.sj), C.byref(self.reads))
+
+    # numpy views (zero copy, valid until close())
+    def annotation_arrays(self):
+        a = self.anno
+        t, e = a.n_tx, a.n_exon
+        return dict(tx_tid=_arr(a.tx_tid, t, np.int32), tx_start=_arr(a.tx_start, t, np.int32), tx_end=_arr(a.tx_end, t, np.int32),
+                    tx_rev=_arr(a.tx_rev, t, np.uint8), tx_ex_off=_arr(a.tx_ex_off, t + 1, np.int64),
+                    ex_start=_arr(a.ex_start, e, np.int32), ex_end=_arr(a.ex_end, e, np.int32))
+
+    def junction_arrays(self):
+        s = self.sj
+        if s.n == 0:
+            return None
+        return tuple(_arr(p, s.n, np.int32) for p in (s.tid, s.don, s.acc, s.uniq_c, s.multi_c))
+
+    def read_arrays(self):
+        r = self.reads
+        return dict(tid=_arr(r.tid, r.n_reads, np.int32), pos=_arr(r.pos, r.n_reads, np.int32), rev=_arr(r.rev, r.n_reads, np.uint8),
+                    cig_off=_arr(r.cig_off, r.n_reads + 1, np.int64), cig=_arr(r.cig, r.n_cigar, np.uint32))
+
+    def finish(self, ex_off, ex_start, ex_end, ex_flag, info, ref_tx) -> int:
+        """Sequential tail + writers.  Arrays as in ``capi.Result`` (info carries the exon count in bits 8..31)."""
+        n = int(info.shape[0])
+        x = int(ex_start.shape[0])
+        keep = [np.ascontiguousarray(ex_off, np.int64), np.ascontiguousarray(ex_start, np.int32), np.ascontiguousarray(ex_end, np.int32),
+                np.ascontiguousarray(ex_flag, np.uint8), np.ascontiguousarray(info, np.uint32), np.ascontiguousarray(ref_tx, np.int32)]
+        res = capi.CResult(n, x, x, keep[0].ctypes.data_as(capi._i64p), keep[1].ctypes.data_as(capi._i32p), keep[2].ctypes.data_as(capi._i32p),
+                           keep[3].ctypes.data_as(capi._u8p), keep[4].ctypes.data_as(capi._u32p), keep[5].ctypes.data_as(capi._i32p))
+        return self.lib.h_job_finish(self.h, C.byref(res))
+
+    def close(self):
+        if self.h:
+            self.lib.h_job_free(self.h)
+            self.h = None
+
+
+def run_cli(args, stdout_path=None, cwd=None) -> subprocess.CompletedProcess:
+    """Run the C binary ``lr2rmats <args>`` (needs a GPU for update-gtf / bam2gtf / unique-gtf -m b)."""
+    if stdout_path:
+        with open(stdout_path, "wb") as fh:
+            return subprocess.run([CLI_PATH] + list(args), stdout=fh, stderr=subprocess.PIPE, cwd=cwd)
+    return subprocess.run([CLI_PATH] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=cwd)

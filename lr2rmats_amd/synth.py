@@ -237,6 +237,45 @@ class Reads:
                     self.cigar_string(i), aux))
 
 
+def write_bam(reads: "Reads", path: str, level: int = 1, long_cigar_as_cg: bool = True) -> None:
+    """Minimal BAM (BGZF) writer for tests: header with @SQ lines, one record per read, SEQ/QUAL absent
+    (l_seq = 0), XS:A aux when ``has_xs``; CIGARs of more than 65535 ops go to the CG:B,I tag as SAMv1 4.2.2 says."""
+    import struct
+    import zlib
+    text = "@HD\tVN:1.6\tSO:%s\n" % ("coordinate" if reads.sorted else "unsorted")
+    text += "".join("@SQ\tSN:%s\tLN:%d\n" % (c, reads.chrom_len) for c in reads.chrom_names)
+    raw = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(reads.chrom_names)))
+    for c in reads.chrom_names:
+        raw += struct.pack("<i", len(c) + 1) + c.encode() + b"\0" + struct.pack("<i", reads.chrom_len)
+    for i in range(reads.n):
+        name = reads.qname(i).encode() + b"\0"
+        ops = reads.cig[int(reads.cig_off[i]):int(reads.cig_off[i + 1])].astype("<u4")
+        aux = b""
+        if reads.has_xs[i]:
+            aux += b"XSA" + (b"-" if reads.rev[i] else b"+")
+        cig_bytes = ops.tobytes()
+        n_cig = len(ops)
+        if n_cig > 65535 and long_cigar_as_cg:
+            reflen = int(sum(int(c) >> 4 for c in ops if (int(c) & 15) in (0, 2, 3, 7, 8)))
+            aux += b"CGBI" + struct.pack("<I", n_cig) + cig_bytes
+            cig_bytes = struct.pack("<II", (0 << 4) | 4, (reflen << 4) | 3)
+            n_cig = 2
+        flag = 16 if reads.flag_rev[i] else 0
+        body = struct.pack("<iiBBHHHIiii", int(reads.tid[i]), int(reads.pos[i]), len(name), 60, 4680, n_cig, flag, 0, -1, -1, 0)
+        body += name + cig_bytes + aux
+        raw += struct.pack("<I", len(body)) + body
+    with open(path, "wb") as fh:
+        def block(data: bytes):
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            comp = co.compress(data) + co.flush()
+            bsize = len(comp) + 25
+            fh.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize))
+            fh.write(comp + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+        for a in range(0, len(raw), 0xff00):
+            block(bytes(raw[a:a + 0xff00]))
+        block(b"")
+
+
 def _compact_rows(vals: np.ndarray, mask: np.ndarray):
     """Row-wise compaction of a padded [R, L] array: returns flat values (row-major) and offsets."""
     cnt = mask.sum(axis=1)

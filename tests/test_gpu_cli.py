@@ -1,0 +1,104 @@
+"""GPU: the `lr2rmats` C binary end to end (file in -> files out) against the oracle CLI -- byte identical."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+from lr2rmats_amd import hostlib, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "toy")
+OUTS = ("gtf", "detail", "summary", "bed", "known", "novel", "unrec", "all")
+
+
+def _paths(tmp, tag):
+    return {k: str(tmp / ("%s.%s" % (tag, k))) for k in OUTS}
+
+
+def _args(extra, o, sam, gtf):
+    return ["update-gtf"] + extra + ["-A", o["detail"], "-y", o["summary"], "-E", o["bed"], "-k", o["known"], "-v", o["novel"],
+                                     "-u", o["unrec"], "-a", o["all"], "-o", o["gtf"], sam, gtf]
+
+
+def _compare(oracle, tmp_path, extra, aln, gtf, tag, oracle_aln=None):
+    oo, ho = _paths(tmp_path, tag + ".o"), _paths(tmp_path, tag + ".h")
+    assert oracle.run_cli(_args(extra, oo, oracle_aln or aln, gtf)) == 0
+    r = hostlib.run_cli(_args(extra, ho, aln, gtf))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    for k in OUTS:
+        assert filecmp.cmp(oo[k], ho[k], shallow=False), (tag, k)
+    return oo
+
+
+@pytest.mark.parametrize("name", ["l3", "sj_support", "sj_far", "sj_other"])
+def test_toy_golden_files(tmp_path, name):
+    """The committed known-answer files (values recorded from the reference)."""
+    extra = ["-l", "3"] if name == "l3" else ["-s", "-l", "3", "-J", "1", "-j", os.path.join(G, name + ".tab")]
+    o = {k: str(tmp_path / k) for k in ("gtf", "detail", "summary", "bed")}
+    r = hostlib.run_cli(["update-gtf"] + extra + ["-A", o["detail"], "-y", o["summary"], "-E", o["bed"],
+                                                 os.path.join(G, "toy.sam"), os.path.join(G, "original.gtf")], stdout_path=o["gtf"])
+    assert r.returncode == 0, r.stderr.decode()
+    for k, ext in (("gtf", "updated.gtf"), ("detail", "detail.txt"), ("summary", "summary.txt"), ("bed", "novel_exon.bed")):
+        assert filecmp.cmp(o[k], os.path.join(G, "expect_%s.%s" % (name, ext)), shallow=False), (name, k)
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("syn")
+    anno = synth.make_annotation(20000, 41, nchr=8, shuffle_within_gene=True, long_tx_per_chrom=1)
+    reads = synth.make_reads(anno, 40000, 5, 41, xs_conflict_frac=0.02)
+    sam, bam, gtf = str(d / "r.sam"), str(d / "r.bam"), str(d / "a.gtf")
+    reads.write_sam(sam)
+    synth.write_bam(reads, bam)
+    anno.write_gtf(gtf)
+    return d, anno, reads, sam, bam, gtf
+
+
+@pytest.mark.parametrize("extra,tag", [(["-l", "3"], "a"), (["-l", "5", "-d", "2", "-c"], "b"), (["-l", "2", "-e", "6", "-i", "120", "-t", "10"], "c")])
+def test_sam_and_bam_input(oracle, tmp_path, files, extra, tag):
+    d, anno, reads, sam, bam, gtf = files
+    _compare(oracle, tmp_path, extra, sam, gtf, tag + "s")
+    _compare(oracle, tmp_path, extra, bam, gtf, tag + "b", oracle_aln=sam)
+
+
+def test_pipeline_second_pass_options(oracle, tmp_path, files):
+    """Snakefile:170 option set: -s -l 3 -J 1 -j SJ.tab -y -a -A -k -v -u -E."""
+    d, anno, reads, sam, bam, gtf = files
+    af = anno.in_file_order()
+    base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3))
+    j, _ = util.junction_table(af, reads, base, 41, cover=0.7)
+    tab = str(d / "SJ.out.tab")
+    j.write(tab)
+    oo = _compare(oracle, tmp_path, ["-s", "-l", "3", "-J", "1", "-j", tab], bam, gtf, "p2", oracle_aln=sam)
+    assert ".split." in open(oo["gtf"]).read()
+
+
+def test_ont_like_reads(oracle, tmp_path):
+    anno = synth.make_annotation(8000, 43, nchr=4)
+    reads = synth.make_reads(anno, 5000, 8, 43, ont=True, micro_exons=3, xs_conflict_frac=0.02)
+    sam, gtf = str(tmp_path / "o.sam"), str(tmp_path / "o.gtf")
+    reads.write_sam(sam)
+    anno.write_gtf(gtf)
+    _compare(oracle, tmp_path, ["-l", "3"], sam, gtf, "ont")
+
+
+def test_unsorted_bam(oracle, tmp_path):
+    anno = synth.make_annotation(8000, 44, nchr=4)
+    reads = synth.make_reads(anno, 8000, 5, 44, unsorted=True)
+    sam, gtf = str(tmp_path / "u.sam"), str(tmp_path / "u.gtf")
+    reads.write_sam(sam)
+    anno.write_gtf(gtf)
+    _compare(oracle, tmp_path, ["-l", "3"], sam, gtf, "uns")
+
+
+def test_bam2gtf_and_unique_gtf(oracle, tmp_path, files):
+    d, anno, reads, sam, bam, gtf = files
+    for cmd, extra in (("bam2gtf", ["-e", "5"]), ("unique-gtf", []), ("unique-gtf", ["-I", "-s"])):
+        a, b = str(tmp_path / "o.out"), str(tmp_path / "h.out")
+        assert oracle.run_cli([cmd] + extra + [sam], stdout_path=a) == 0
+        r = hostlib.run_cli([cmd] + extra + [bam], stdout_path=b)
+        assert r.returncode == 0, r.stderr.decode()[-1000:]
+        assert filecmp.cmp(a, b, shallow=False), (cmd, extra)
+        assert os.path.getsize(a) > 10000

@@ -1,0 +1,170 @@
+"""CPU: the C host side (readers + sequential tail + writers) through its staged API.
+
+The per-read results come from the oracle here (no GPU in this container); what is under test is
+that the host parsers produce the arrays the oracle's own parsers produce, and that routing / split /
+merge / writers turn identical per-read results into byte-identical files.
+"""
+import filecmp
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from lr2rmats_amd import hostlib, synth
+from tests import util
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "toy")
+OUTS = ("gtf", "detail", "summary", "bed", "known", "novel", "unrec", "all")
+
+
+def _paths(tmp, tag):
+    return {k: str(tmp / ("%s.%s" % (tag, k))) for k in OUTS}
+
+
+def _args(extra, o, sam, gtf):
+    return ["update-gtf"] + extra + ["-A", o["detail"], "-y", o["summary"], "-E", o["bed"], "-k", o["known"], "-v", o["novel"],
+                                     "-u", o["unrec"], "-a", o["all"], "-o", o["gtf"], sam, gtf]
+
+
+_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from lr2rmats_amd import hostlib
+from oracle import pyoracle as po
+job = hostlib.Job(sys.argv[1:])
+a, r, sj, p = job.annotation_arrays(), job.read_arrays(), job.junction_arrays(), job.prm
+op = po.default_params(min_exon=p.min_exon, min_intron=p.min_intron, max_delet=p.max_delet, ss_dis=p.ss_dis, end_dis=p.end_dis,
+                       full_level=p.full_level, split_trans=p.split_trans, use_multi=p.use_multi, min_sj_cnt=p.min_sj_cnt,
+                       force_strand=p.force_strand, single_exon_ovlp_frac=p.single_exon_ovlp_frac)
+res = po.classify_soa(r["tid"], r["pos"], r["rev"], r["cig_off"], r["cig"], a["tx_tid"], a["tx_start"], a["tx_end"], a["tx_rev"],
+                      a["tx_ex_off"], a["ex_start"], a["ex_end"], sj=sj, params=op)
+info = (res.info & 0x7f) | (np.diff(res.ex_off).astype(np.uint32) << 8)
+sys.exit(job.finish(res.ex_off, res.ex_start, res.ex_end, res.ex_flag, info, res.ref_tx))
+"""
+
+
+def _host_with_oracle_results(argv):
+    """Staged host run in a child process (the C code exits the process on fatal errors)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, "-c", _CHILD % root] + argv, stderr=subprocess.PIPE).returncode
+
+
+def _compare(oracle, tmp_path, extra, sam, gtf, tag):
+    oo, ho = _paths(tmp_path, tag + ".o"), _paths(tmp_path, tag + ".h")
+    assert oracle.run_cli(_args(extra, oo, sam, gtf)) == 0
+    assert _host_with_oracle_results(_args(extra, ho, sam, gtf)) == 0
+    for k in OUTS:
+        assert filecmp.cmp(oo[k], ho[k], shallow=False), (tag, k)
+    return oo
+
+
+@pytest.mark.parametrize("extra,tag", [(["-l", "3"], "l3"), (["-l", "5"], "l5"),
+                                       (["-s", "-l", "3", "-J", "1", "-j", os.path.join(G, "sj_far.tab")], "far"),
+                                       (["-s", "-l", "3", "-J", "1", "-j", os.path.join(G, "sj_other.tab")], "oth"),
+                                       (["-l", "3", "-j", os.path.join(G, "sj_support.tab"), "-S", "mysrc"], "sup")])
+def test_toy_files_identical(oracle, tmp_path, extra, tag):
+    _compare(oracle, tmp_path, extra, os.path.join(G, "toy.sam"), os.path.join(G, "original.gtf"), tag)
+
+
+@pytest.fixture(scope="module")
+def synth_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("syn")
+    anno = synth.make_annotation(6000, 31, nchr=6, shuffle_within_gene=True, long_tx_per_chrom=1)
+    reads = synth.make_reads(anno, 6000, 5, 31, xs_conflict_frac=0.03)
+    sam, gtf = str(d / "r.sam"), str(d / "a.gtf")
+    reads.write_sam(sam)
+    anno.write_gtf(gtf)
+    return d, anno, reads, sam, gtf
+
+
+@pytest.mark.parametrize("extra,tag", [(["-l", "3"], "a"), (["-l", "5", "-d", "3", "-c"], "b"), (["-l", "1", "-e", "8", "-i", "150"], "c"),
+                                       (["-l", "4", "-f", "0.5", "-D", "20"], "d")])
+def test_synthetic_files_identical(oracle, tmp_path, synth_files, extra, tag):
+    d, anno, reads, sam, gtf = synth_files
+    oo = _compare(oracle, tmp_path, extra, sam, gtf, tag)
+    assert os.path.getsize(oo["gtf"]) > 1000 and os.path.getsize(oo["detail"]) > 100000
+
+
+@pytest.mark.parametrize("extra,tag", [(["-l", "3", "-J", "2"], "j1"), (["-s", "-l", "3", "-J", "3", "-M", "x"], "j2"), (["-s", "-l", "5", "-d", "2"], "j3")])
+def test_synthetic_with_junction_table(oracle, tmp_path, synth_files, extra, tag):
+    d, anno, reads, sam, gtf = synth_files
+    af = anno.in_file_order()
+    base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=5))
+    j, _ = util.junction_table(af, reads, base, 31, cover=0.6)
+    tab = str(d / "sj.tab")
+    # shuffle the rows and add a chromosome that is not in the header: the reader sorts and interns it
+    order = np.random.default_rng(1).permutation(len(j.don))
+    j.chrom = [j.chrom[i] for i in order] + ["chrUn_x"]
+    for f in ("tid", "don", "acc", "strand", "uniq", "multi"):
+        setattr(j, f, np.concatenate([getattr(j, f)[order], [7]]))
+    j.write(tab)
+    oo = _compare(oracle, tmp_path, extra + ["-j", tab], sam, gtf, tag)
+    if "-s" in extra:
+        assert ".split." in open(oo["gtf"]).read()
+
+
+def test_gtf_reader_quirks(oracle, tmp_path, synth_files):
+    """Q10-Q12: long lines split at 1023 bytes, blank / short lines re-using stale fields, tag substring lookup,
+    id<->name fallbacks, chromosomes that are not in the header."""
+    d, anno, reads, sam, gtf = synth_files
+    lines = open(gtf).read().split("\n")
+    out = []
+    for i, l in enumerate(lines):
+        out.append(l)
+        if i == 40:
+            out.append("")                                                   # blank line: stale type/attrs
+        if i == 60 and "\texon\t" in l:
+            out.append(l + " note \"" + "x" * 1500 + "\";")                 # > 1023 bytes
+        if i == 80 and "\texon\t" in l:
+            f = l.split("\t"); f[8] = 'ref_gene_id "zz"; ' + f[8]; out.append("\t".join(f))
+        if i == 100 and "\texon\t" in l:
+            f = l.split("\t"); f[8] = 'transcript_id "only_id_%d"; gene_name "only_name";' % i; out.append("\t".join(f))
+        if i == 120 and "\texon\t" in l:
+            f = l.split("\t"); f[0] = "chrNotInHeader"; f[8] = f[8].replace("SYNT", "ZZZT"); out.append("\t".join(f))
+        if i == 140:
+            out.append("chr1 synth exon 5 9")                                # short line, space separated
+    g2 = str(tmp_path / "quirk.gtf")
+    open(g2, "w").write("\n".join(out))
+    _compare(oracle, tmp_path, ["-l", "3"], sam, g2, "q")
+
+
+def test_unmapped_record_aborts_like_reference(tmp_path):
+    sam = tmp_path / "u.sam"
+    sam.write_text("@SQ\tSN:chr1\tLN:10000000\nu1\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*\n")
+    rc = _host_with_oracle_results(["update-gtf", str(sam), os.path.join(G, "original.gtf")])
+    assert rc == -6                                                           # SIGABRT, as the reference (Q9)
+
+
+def test_usage_errors_return_1(tmp_path):
+    assert _host_with_oracle_results(["update-gtf", "only_one_positional"]) == 1
+    assert _host_with_oracle_results(["update-gtf", "-m", "x", "a", "b"]) == 1
+
+
+def test_bam_reader_equals_sam_reader(tmp_path, synth_files):
+    """The BGZF/BAM route of the alignment reader yields the arrays of the SAM text route."""
+    d, anno, reads, sam, gtf = synth_files
+    bam = str(tmp_path / "r.bam")
+    synth.write_bam(reads, bam)
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from lr2rmats_amd import hostlib
+a = hostlib.Job(["update-gtf", sys.argv[1], sys.argv[3]]).read_arrays()
+b = hostlib.Job(["update-gtf", sys.argv[2], sys.argv[3]]).read_arrays()
+assert a["tid"].size > 1000
+for k in a:
+    assert np.array_equal(a[k], b[k]), k
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code, sam, bam, gtf], stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    # and the arrays are the generator's
+    j = hostlib.Job(["update-gtf", bam, gtf])
+    ra = j.read_arrays()
+    np.testing.assert_array_equal(ra["tid"], reads.tid)
+    np.testing.assert_array_equal(ra["pos"], reads.pos)
+    np.testing.assert_array_equal(ra["rev"], reads.rev)
+    np.testing.assert_array_equal(ra["cig_off"], reads.cig_off)
+    np.testing.assert_array_equal(ra["cig"], reads.cig)
+    j.close()
