@@ -27,8 +27,10 @@ struct h_job {
     int mode;
 };
 
+static int g_open_outputs = 1;
 static FILE *open_w(const char *fn)
 {
+    if (!g_open_outputs) return NULL;
     FILE *f = fopen(fn, "w");
     if (!f) h_fatal("update_gtf", "Can not open \"%s\" for writing\n", fn);
     return f;
@@ -75,6 +77,17 @@ static void default_params(l2r_params *p)
     /* src/update_gtf.c:24-35, src/gtf.h:118-127 */
     p->min_exon = 3; p->min_intron = 3; p->max_delet = 50; p->ss_dis = 0; p->end_dis = 0x7fffffff; p->full_level = 5;
     p->split_trans = 0; p->use_multi = 0; p->min_sj_cnt = 1; p->force_strand = 0; p->single_exon_ovlp_frac = 0.80;
+}
+
+h_job *h_job_open2(int argc, char **argv, int *exit_code, int open_outputs)
+{
+    /* ranks other than the writer of a multi-process run parse the same command line without
+     * creating (truncating) the output files */
+    g_open_outputs = open_outputs;
+    h_job *j = h_job_open(argc, argv, exit_code);
+    g_open_outputs = 1;
+    if (j && !open_outputs) j->o.out_gtf = NULL;
+    return j;
 }
 
 h_job *h_job_open(int argc, char **argv, int *exit_code)

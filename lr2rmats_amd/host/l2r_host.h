@@ -107,6 +107,7 @@ int h_main(int argc, char **argv);
  * the engine consumes; finish = sequential tail + writers with the per-read results. */
 typedef struct h_job h_job;
 h_job *h_job_open(int argc, char **argv, int *exit_code);
+h_job *h_job_open2(int argc, char **argv, int *exit_code, int open_outputs);   /* 0: do not create output files */
 void   h_job_views(h_job *j, l2r_params *prm, l2r_annotation *anno, l2r_junctions *sj, l2r_reads *reads);
 int    h_job_finish(h_job *j, const l2r_result *res);
 void   h_job_free(h_job *j);

@@ -31,6 +31,8 @@ def load_library():
         lib = C.CDLL(LIB_PATH)
         lib.h_job_open.restype = C.c_void_p
         lib.h_job_open.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+        lib.h_job_open2.restype = C.c_void_p
+        lib.h_job_open2.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int]
         lib.h_job_views.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.h_job_finish.argtypes = [C.c_void_p, C.c_void_p]
         lib.h_job_finish.restype = C.c_int
@@ -49,12 +51,12 @@ def _arr(ptr, n, dtype):
 class Job:
     """One ``update-gtf`` invocation: argv = ["update-gtf", options..., in.bam, old.gtf]."""
 
-    def __init__(self, argv: List[str]):
+    def __init__(self, argv: List[str], open_outputs: bool = True):
         self.lib = load_library()
         args = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
         rc = C.c_int(0)
         self._argv_keep = args
-        self.h = self.lib.h_job_open(len(argv), args, C.byref(rc))
+        self.h = self.lib.h_job_open2(len(argv), args, C.byref(rc), 1 if open_outputs else 0)
         self.exit_code = rc.value
         if not self.h:
             raise SystemExit(self.exit_code or 1)
