@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/lr2rmats_hip.h"
@@ -57,6 +58,12 @@ struct l2r_ctx {
     DevBuf<TxHdr> hdr;
     DevBuf<int2> anno_ex;
     DevBuf<int64_t> anno_key;
+    DevBuf<int4> sk_st, sk_en;                      // site dictionaries (l2r_kernels.hip.h): START / END entries by rank
+    DevBuf<uint32_t> sd_st, sd_en;                  // bucket directories
+    DevBuf<int32_t> tid_base; int32_t n_tid_dir = 0;
+    DevBuf<uint32_t> key_dir; DevBuf<int32_t> kb_base; int32_t n_tid_key = 0;   // cursor directory
+    DevBuf<int32_t> j0;
+    int64_t n_compact = 0;
     std::vector<int64_t> h_anno_key_raw;    // per transcript (tid,end) key, NOT prefix-maxed (unsorted-input cursor)
     // junctions
     int64_t n_sj = 0;
@@ -96,6 +103,7 @@ static DevParams dev_params(const l2r_ctx *c)
     p.ss_dis = c->prm.ss_dis; p.full_level = c->prm.full_level; p.use_multi = c->prm.use_multi;
     p.min_sj_cnt = c->prm.min_sj_cnt; p.split_trans = c->prm.split_trans; p.frac = c->prm.single_exon_ovlp_frac;
     p.n_tx = (int32_t)c->n_tx; p.n_sj = (int32_t)c->n_sj; p.reads_per_tile = c->reads_per_tile;
+    { const char *e = getenv("L2R_ABLATE"); p.ablate = e ? atoi(e) : 0; }
     return p;
 }
 
@@ -135,6 +143,8 @@ void l2r_destroy(l2r_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     c->hdr.release(); c->anno_ex.release(); c->anno_key.release();
+    c->sk_st.release(); c->sk_en.release(); c->sd_st.release(); c->sd_en.release(); c->tid_base.release();
+    c->key_dir.release(); c->kb_base.release(); c->j0.release();
     c->sj_tid.release(); c->sj_don.release(); c->sj_acc.release(); c->sj_uniq.release(); c->sj_multi.release(); c->sj_key.release();
     c->r_tid.release(); c->r_pos.release(); c->r_rev.release(); c->cig_off.release(); c->cig.release();
     c->win_start.release(); c->sj_cursor.release();
@@ -155,6 +165,61 @@ int l2r_set_params(l2r_ctx *c, const l2r_params *prm)
     return 0;
 }
 
+// ---- site dictionaries -------------------------------------------------------------------------
+struct Site3 {
+    int32_t k0, k1, k2;
+    bool operator<(const Site3 &o) const { return k0 != o.k0 ? k0 < o.k0 : (k1 != o.k1 ? k1 < o.k1 : k2 < o.k2); }
+    bool operator==(const Site3 &o) const { return k0 == o.k0 && k1 == o.k1 && k2 == o.k2; }
+};
+
+static void sort_unique(std::vector<Site3> &v)
+{
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+}
+
+static inline int rank_of(const std::vector<Site3> &v, const Site3 &k)
+{
+    return (int)(std::lower_bound(v.begin(), v.end(), k) - v.begin());
+}
+
+// entries {k1, k2, single rank, 0} of one dictionary + its bucket directory
+static int upload_dict(l2r_ctx *c, const std::vector<Site3> &keys, const std::vector<Site3> &singles, const std::vector<int32_t> &tid_base,
+                       DevBuf<int4> &kbuf, DevBuf<uint32_t> &dbuf)
+{
+    const size_t nb = (size_t)tid_base.back();
+    std::vector<uint32_t> dir(nb + 1, 0);                 // dir[b] = number of entries whose bucket id is < b
+    std::vector<int4> kk(keys.size());
+    for (size_t i = 0; i < keys.size(); ++i) {
+        const Site3 one{keys[i].k0, keys[i].k1, 0};
+        auto it = std::lower_bound(singles.begin(), singles.end(), one);
+        const int single = (it != singles.end() && *it == one) ? (int)(it - singles.begin()) : -1;
+        kk[i] = make_int4(keys[i].k1, keys[i].k2, single, 0);
+        const size_t b = (size_t)tid_base[(size_t)keys[i].k0] + (size_t)(keys[i].k1 >> SITE_SHIFT);
+        dir[b + 1]++;
+    }
+    for (size_t b = 0; b < nb; ++b) dir[b + 1] += dir[b];
+    if (kbuf.ensure(kk.size()) || dbuf.ensure(dir.size())) return -2;
+    if (!kk.empty()) HIP_TRY(hipMemcpyAsync(kbuf.p, kk.data(), kk.size() * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dbuf.p, dir.data(), dir.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// relative 64-bit mask of the ranks r[0..k) (increasing); false when one does not fit
+static bool rel_mask(const std::vector<int> &r, int32_t &base, uint32_t w[2])
+{
+    w[0] = w[1] = 0; base = 0;
+    if (r.empty()) return true;
+    base = r[0];
+    for (int g : r) {
+        const int off = g - base;
+        if (off < 0 || off >= 64) return false;
+        w[off >> 5] |= 1u << (off & 31);
+    }
+    return true;
+}
+
 int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
 {
     if (!c || !a) return fail(-1, "[l2r_set_annotation] null argument");
@@ -165,17 +230,32 @@ int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
     std::vector<int64_t> key((size_t)T);
     c->h_anno_key_raw.assign((size_t)T, 0);
     int64_t run = INT64_MIN;
+    // pass 1: headers, cursor keys, and the distinct sites of every kind
+    std::vector<Site3> kd, ka, kx, kj;
+    kd.reserve((size_t)a->n_exon); ka.reserve((size_t)a->n_exon); kx.reserve((size_t)a->n_exon); kj.reserve((size_t)a->n_exon);
     for (int64_t i = 0; i < T; ++i) {
         const int64_t lo = a->tx_ex_off[i], hi = a->tx_ex_off[i + 1];
         if (lo < 0 || hi < lo || hi > a->n_exon) return fail(-1, "[l2r_set_annotation] bad exon offsets at transcript %lld", (long long)i);
         if (hi == lo) return fail(-1, "[l2r_set_annotation] transcript %lld has no exon", (long long)i);
         TxHdr &t = h[(size_t)i];
+        memset(&t, 0, sizeof t);
         t.tid = a->tx_tid[i]; t.start = a->tx_start[i]; t.end = a->tx_end[i]; t.ex_off = (int32_t)lo;
-        t.n = (int32_t)(hi - lo); t.rev = a->tx_rev[i] ? 1 : 0; t.pad = 0;
-        int mono = 1;
-        for (int64_t k = lo + 1; k < hi; ++k)
-            if (!(a->ex_start[k] > a->ex_start[k - 1] && a->ex_end[k] > a->ex_end[k - 1])) { mono = 0; break; }
-        t.mono = mono;
+        t.n = (int32_t)(hi - lo); t.rev = a->tx_rev[i] ? 1 : 0;
+        t.s0 = a->ex_start[lo]; t.e0 = a->ex_end[lo]; t.sl = a->ex_start[hi - 1]; t.el = a->ex_end[hi - 1];
+        bool mono = true, sane = a->ex_start[lo] <= a->ex_end[lo];
+        for (int64_t k = lo + 1; k < hi; ++k) {
+            if (!(a->ex_start[k] > a->ex_start[k - 1] && a->ex_end[k] > a->ex_end[k - 1])) mono = false;
+            if (a->ex_start[k] > a->ex_end[k]) sane = false;
+        }
+        int flags = mono ? TX_MONO : 0;
+        // dictionary path only for transcripts the equality => in-span argument holds for
+        if (mono && sane && t.tid >= 0 && t.n >= 2 && t.start == t.s0 && t.end == t.el) flags |= TX_COMPACT;   // masks checked in pass 2
+        t.flags = flags;
+        if (t.tid >= 0) for (int64_t k = lo; k < hi; ++k) {
+            kx.push_back(Site3{t.tid, a->ex_start[k], a->ex_end[k]});
+            if (k + 1 < hi) { kd.push_back(Site3{t.tid, a->ex_end[k], 0}); kj.push_back(Site3{t.tid, a->ex_end[k], a->ex_start[k + 1]}); }
+            if (k > lo) ka.push_back(Site3{t.tid, a->ex_start[k], 0});
+        }
         // "annotation before read": tid smaller, or same tid and end <= read start (update_gtf.c:786-790).
         // The sequential cursor equals the longest prefix that is entirely before the read = first index
         // whose running maximum of (tid,end) exceeds (read.tid, read.start)  (SURVEY.md 3.3).
@@ -183,6 +263,78 @@ int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
         c->h_anno_key_raw[(size_t)i] = k;
         if (k > run) run = k;
         key[(size_t)i] = run;
+    }
+    sort_unique(kd); sort_unique(ka); sort_unique(kx); sort_unique(kj);
+    // pass 2: per-transcript rank masks
+    int64_t n_compact = 0;
+    std::vector<int> rd, ra, rx, rj;
+    for (int64_t i = 0; i < T; ++i) {
+        TxHdr &t = h[(size_t)i];
+        if (!(t.flags & TX_COMPACT)) continue;
+        const int64_t lo = a->tx_ex_off[i], hi = a->tx_ex_off[i + 1];
+        rd.clear(); ra.clear(); rx.clear(); rj.clear();
+        for (int64_t k = lo; k < hi; ++k) {
+            rx.push_back(rank_of(kx, Site3{t.tid, a->ex_start[k], a->ex_end[k]}));
+            if (k + 1 < hi) { rd.push_back(rank_of(kd, Site3{t.tid, a->ex_end[k], 0})); rj.push_back(rank_of(kj, Site3{t.tid, a->ex_end[k], a->ex_start[k + 1]})); }
+            if (k > lo) ra.push_back(rank_of(ka, Site3{t.tid, a->ex_start[k], 0}));
+        }
+        const bool f1 = rel_mask(rd, t.gb_d, t.md), f2 = rel_mask(ra, t.gb_a, t.ma), f3 = rel_mask(rx, t.gb_x, t.mx), f4 = rel_mask(rj, t.gb_j, t.mj);
+        const bool fit = f1 && f2 && f3 && f4;
+        if (!fit) { t.flags &= ~TX_COMPACT; memset(t.md, 0, 8); memset(t.ma, 0, 8); memset(t.mx, 0, 8); memset(t.mj, 0, 8); }
+        else ++n_compact;
+    }
+    c->n_compact = n_compact;
+    {   // one bucket grid for the four kinds: per tid, enough 512-bp buckets for its largest site coordinate
+        int32_t n_tid = 0; 
+        for (const auto *v : {&kd, &ka, &kx, &kj}) if (!v->empty()) n_tid = std::max(n_tid, v->back().k0 + 1);
+        std::vector<int64_t> mx((size_t)n_tid, -1);
+        for (const auto *v : {&kd, &ka, &kx, &kj}) for (const Site3 &k : *v) {
+            if (k.k1 < 0) return fail(-1, "[l2r_set_annotation] negative exon coordinate");
+            mx[(size_t)k.k0] = std::max<int64_t>(mx[(size_t)k.k0], k.k1);
+        }
+        std::vector<int32_t> tb((size_t)n_tid + 1, 0);
+        int64_t acc = 0;
+        for (int32_t t = 0; t < n_tid; ++t) { tb[(size_t)t] = (int32_t)acc; acc += mx[(size_t)t] < 0 ? 0 : (mx[(size_t)t] >> SITE_SHIFT) + 1; }
+        if (acc > 0x7ffffff0LL) return fail(-1, "[l2r_set_annotation] site directory too large");
+        tb[(size_t)n_tid] = (int32_t)acc;
+        // START: exons + acceptor rank of their start; END: junctions + donor rank of their end
+        if (upload_dict(c, kx, ka, tb, c->sk_st, c->sd_st) || upload_dict(c, kj, kd, tb, c->sk_en, c->sd_en)) return -2;
+        if (c->tid_base.ensure(tb.size())) return -2;
+        HIP_TRY(hipMemcpyAsync(c->tid_base.p, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->n_tid_dir = n_tid;
+    }
+    {   // cursor directory over the prefix-max keys: dir[kb_base[tid] + c] = first j with key_j >= (tid, c << 9)
+        int32_t n_tid = 0;
+        for (int64_t i = 0; i < T; ++i) n_tid = std::max(n_tid, h[(size_t)i].tid + 1);
+        std::vector<int64_t> mxe((size_t)n_tid, -1);
+        for (int64_t i = 0; i < T; ++i) if (h[(size_t)i].tid >= 0) mxe[(size_t)h[(size_t)i].tid] = std::max<int64_t>(mxe[(size_t)h[(size_t)i].tid], std::max(h[(size_t)i].end, 0));
+        std::vector<int32_t> kb((size_t)n_tid + 1, 0);
+        int64_t acc = 0;
+        for (int32_t t = 0; t < n_tid; ++t) { kb[(size_t)t] = (int32_t)acc; acc += mxe[(size_t)t] < 0 ? 0 : (mxe[(size_t)t] >> SITE_SHIFT) + 1; }
+        if (acc > 0x7ffffff0LL) return fail(-1, "[l2r_set_annotation] cursor directory too large");
+        kb[(size_t)n_tid] = (int32_t)acc;
+        std::vector<uint32_t> dir((size_t)acc + 1);
+        size_t j = 0;
+        for (int32_t t = 0; t < n_tid; ++t) {
+            const int32_t nbk = kb[(size_t)t + 1] - kb[(size_t)t];
+            for (int32_t cb = 0; cb < nbk; ++cb) {
+                const int64_t q = host_key(t, cb << SITE_SHIFT);
+                while (j < (size_t)T && key[j] < q) ++j;
+                dir[(size_t)kb[(size_t)t] + (size_t)cb] = (uint32_t)j;
+            }
+        }
+        {   // closing word: first j with key >= (n_tid, 0)
+            const int64_t q = host_key(n_tid, 0);
+            while (j < (size_t)T && key[j] < q) ++j;
+            dir[(size_t)acc] = (uint32_t)j;
+        }
+        // words of chromosomes without buckets (no transcript): they share the next chromosome's first word
+        if (c->key_dir.ensure(dir.size()) || c->kb_base.ensure(kb.size())) return -2;
+        HIP_TRY(hipMemcpyAsync(c->key_dir.p, dir.data(), dir.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->kb_base.p, kb.data(), kb.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->n_tid_key = n_tid;
     }
     std::vector<int2> ex((size_t)a->n_exon);
     for (int64_t k = 0; k < a->n_exon; ++k) ex[(size_t)k] = make_int2(a->ex_start[k], a->ex_end[k]);
@@ -285,7 +437,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     }
     // work buffers.  n_exon(read) <= ops(read) + 1, so n_cigar + n_reads bounds the exon arrays.
     const size_t exb = (size_t)r->n_cigar + (size_t)N;
-    if (c->n_ex.ensure((size_t)N) || c->ex_off.ensure((size_t)N) || c->info.ensure((size_t)N) || c->ref_tx.ensure((size_t)N) ||
+    if (c->j0.ensure((size_t)N) || c->n_ex.ensure((size_t)N) || c->ex_off.ensure((size_t)N) || c->info.ensure((size_t)N) || c->ref_tx.ensure((size_t)N) ||
         c->tile_base.ensure((size_t)c->n_tiles) || c->tile_acc.ensure((size_t)c->n_tiles256) || c->tile_acc_ex.ensure((size_t)c->n_tiles256) ||
         c->totals.ensure(4) || c->ex_start.ensure(exb) || c->ex_end.ensure(exb) || c->ex_flag.ensure(exb) ||
         c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
@@ -349,12 +501,16 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     const unsigned gt = (unsigned)(c->n_tiles ? c->n_tiles : 1), g256 = (unsigned)(c->n_tiles256 ? c->n_tiles256 : 1);
 #define MARK(i) do { if (ev) HIP_TRY(hipEventRecord(ev[i], s)); } while (0)
     MARK(ST_COUNT);
-    hipLaunchKernelGGL(k_count_exons, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_pos.p, c->cig_off.p, c->cig.p, p, c->n_ex.p, c->tile_base.p);
+    const CursorDir cd{c->anno_key.p, c->key_dir.p, c->kb_base.p, c->n_tid_key, (int32_t)c->n_tx};
+    // sorted input: the cursor value of every read is computed on the device; unsorted input: it was replayed on the host
+    hipLaunchKernelGGL(k_count_exons, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, p, c->n_ex.p,
+                       (c->sorted ? c->j0.p : (int32_t *)nullptr), c->tile_base.p);
     MARK(ST_SCAN1);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, c->tile_base.p, c->n_tiles, c->totals.p + 0);
     MARK(ST_FILL);
     hipLaunchKernelGGL(k_fill_classify, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->r_rev.p, c->cig_off.p, c->cig.p,
-                       c->n_ex.p, c->tile_base.p, c->anno_key.p, (c->sorted ? (const int32_t *)nullptr : c->win_start.p), c->hdr.p, c->anno_ex.p, p,
+                       c->n_ex.p, c->tile_base.p, (c->sorted ? (const int32_t *)c->j0.p : (const int32_t *)c->win_start.p), c->hdr.p, c->anno_ex.p,
+                       SiteTabs{{c->sk_st.p, c->sd_st.p}, {c->sk_en.p, c->sd_en.p}, c->tid_base.p, c->n_tid_dir}, p,
                        c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->info.p, c->ref_tx.p);
     MARK(ST_SJ);
     if (c->n_sj > 0) {
@@ -528,4 +684,4 @@ int l2r_classify(l2r_ctx *c, const l2r_reads *reads, l2r_result *res)
 }  // extern "C"
 
 static_assert(sizeof(AccRec) == sizeof(l2r_accepted_read), "accepted record layout");
-static_assert(sizeof(TxHdr) == 32, "TxHdr must be two int4");
+static_assert(sizeof(TxHdr) == 96, "TxHdr must be six int4");

@@ -21,11 +21,50 @@ namespace l2r {
 
 constexpr int TILE_THREADS = 256;
 constexpr int WAVE = 64;
-constexpr int LDS_EXON_CAP = 4096;      // exons of one tile staged in LDS (9 B each)
+constexpr int LDS_EXON_CAP = 2816;      // exons of one tile staged in LDS (9 B each)
 
-struct TxHdr {                          // 32 B, one annotation transcript (file order)
-    int32_t tid, start, end, ex_off;
-    int32_t n, rev, mono, pad;
+// One annotation transcript (file order), 96 B = six 16-byte loads; the sweep reads h0 for every
+// transcript it passes, h1..h2 for the ones that overlap, h3..h5 only on the dictionary path.
+struct TxHdr {
+    int32_t tid, start, end, ex_off;          // h0
+    int32_t n, rev, flags, pad;               // h1  flags: TX_MONO | TX_COMPACT
+    int32_t s0, e0, sl, el;                   // h2  first and last exon
+    int32_t gb_d, gb_a, gb_x, gb_j;           // h3  rank of the transcript's first donor / acceptor / exon / junction
+    uint32_t md[2], ma[2];                    // h4  site masks relative to those ranks (bit k = rank gb+k is in the transcript)
+    uint32_t mx[2], mj[2];                    // h5
+};
+constexpr int TX_MONO = 1;      // exon starts and ends strictly increasing
+constexpr int TX_COMPACT = 2;   // TX_MONO, start <= end for every exon, header span == exon span, all four masks fit 64 bits
+
+// Site dictionaries (built once per annotation on the host).  Every distinct annotation site of a
+// kind (donor, acceptor, exon, junction) has a RANK = its index among the sorted distinct sites of
+// that kind on all chromosomes.  Two probe structures serve the four kinds:
+//   START dictionary: the distinct exons sorted by (tid, start, end); entry {start, end, acceptor rank of
+//                     `start` or -1, 0}; the entry's index is the exon rank;
+//   END dictionary:   the distinct junctions sorted by (tid, end, next start); entry {end, next start,
+//                     donor rank of `end`, 0}; the entry's index is the junction rank;
+// each with a directory over 512-bp coordinate buckets: dir[tid_base[tid] + (k1 >> 9)] = first entry of the
+// bucket.  Neighbouring coordinates hit neighbouring directory words and entries, so the reads of a tile
+// (one locus) keep re-using a handful of lines, which the tile stages in LDS.
+constexpr int SITE_SHIFT = 9;
+struct SiteDict {
+    const int4 *ent;           // entries by rank
+    const uint32_t *dir;       // bucket -> first entry; one extra word closes the last bucket
+};
+struct SiteTabs {
+    SiteDict st, en;           // START and END dictionaries
+    const int32_t *tid_base;   // [n_tid + 1] first bucket of every tid (one bucket grid for both)
+    int32_t n_tid;
+};
+
+// Cursor directory: the prefix-max keys of the annotation with the same kind of
+// 512-bp bucket directory, so the cursor value of a read costs two directory words and a search inside
+// one bucket instead of a 17-step binary search.  dir[kb_base[tid] + c] = first j with key_j >= (tid, c << 9).
+struct CursorDir {
+    const int64_t *key;        // [n_tx] non-decreasing
+    const uint32_t *dir;
+    const int32_t *kb_base;    // [n_tid + 1]
+    int32_t n_tid, n_tx;
 };
 
 struct DevParams {
@@ -33,6 +72,7 @@ struct DevParams {
     int32_t full_level, use_multi, min_sj_cnt, split_trans;
     float   frac;
     int32_t n_tx, n_sj, reads_per_tile;
+    int32_t ablate;          // diagnostics (env L2R_ABLATE): 1 no sweep, 2 no site match, 4 no full-length test, 16 no dictionary path
 };
 
 // info / exon-flag bit layout: keep in sync with include/lr2rmats_hip.h
@@ -69,13 +109,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 
 // ------------------------------------------------------------------ CIGAR -> exons
 
-// src/bam2gtf.c:31-78 gen_exon.  EMIT(start,end) is called for every exon kept.
+// src/bam2gtf.c:31-78 gen_exon.  emit(k, start, end) is called for every exon kept.
+// CIGAR words are fetched four at a time so that the loads of one read are in flight together.
 template <typename Emit>
-__device__ __forceinline__ int walk_cigar(const uint32_t *cig, int n_cig, int pos0, const DevParams &p, Emit emit)
+__device__ __forceinline__ int walk_cigar(const uint32_t *__restrict__ cig, int n_cig, int pos0, const DevParams &p, Emit emit)
 {
     int start = pos0 + 1, end = start - 1, n = 0;
-    for (int k = 0; k < n_cig; ++k) {
-        const uint32_t c = cig[k];
+    auto step = [&](uint32_t c) {
         const int len = (int)(c >> 4);
         const uint32_t op = c & 0xfu;
         // N (3) cuts at len >= min_intron, D (2) at len > max_delet; M,=,X,N,D advance the reference
@@ -85,22 +125,47 @@ __device__ __forceinline__ int walk_cigar(const uint32_t *cig, int n_cig, int po
             start = end + len + 1;
         }
         if (op == 0u || op == 2u || op == 3u || op == 7u || op == 8u) end += len;
+    };
+    int k = 0;
+    for (; k + 4 <= n_cig; k += 4) {
+        const uint32_t c0 = cig[k], c1 = cig[k + 1], c2 = cig[k + 2], c3 = cig[k + 3];
+        step(c0); step(c1); step(c2); step(c3);
     }
+    for (; k < n_cig; ++k) step(cig[k]);
     emit(n, start, end);
     return n + 1;
 }
 
+// first j with key_j > (tid, start): the value the reference's annotation cursor has for this read
+__device__ __forceinline__ int cursor_value(const CursorDir &cd, int32_t tid, int32_t start)
+{
+    if (tid >= cd.n_tid) return cd.n_tx;                       // beyond every annotated chromosome
+    const int32_t kb = cd.kb_base[tid], nb = cd.kb_base[tid + 1] - kb;
+    if (nb <= 0) return (int)cd.dir[kb];
+    const int c = min(max(start, 0) >> SITE_SHIFT, nb - 1);
+    int lo = (int)cd.dir[kb + c], hi = (int)cd.dir[kb + c + 1];
+    if (c == nb - 1) hi = (int)cd.dir[kb + nb];               // last bucket of the chromosome is open ended
+    const int64_t q = pack_key(tid, start);
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cd.key[mid] > q) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(TILE_THREADS)
-void k_count_exons(int64_t n_reads, const int32_t *__restrict__ r_pos, const int64_t *__restrict__ cig_off,
-                   const uint32_t *__restrict__ cig, DevParams p,
-                   uint32_t *__restrict__ n_ex, uint32_t *__restrict__ tile_sum)
+void k_count_exons(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t *__restrict__ r_pos,
+                   const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ cig, CursorDir cd, DevParams p,
+                   uint32_t *__restrict__ n_ex, int32_t *__restrict__ j0_out, uint32_t *__restrict__ tile_sum)
 {
     __shared__ uint32_t s_wave[4];
     const int64_t r = (int64_t)blockIdx.x * p.reads_per_tile + threadIdx.x;
     uint32_t n = 0;
     if (threadIdx.x < p.reads_per_tile && r < n_reads) {
         const int64_t a = cig_off[r], b = cig_off[r + 1];
-        n = (uint32_t)walk_cigar(cig + a, (int)(b - a), r_pos[r], p, [](int, int, int) {});
+        const int32_t pos = r_pos[r];
+        if (j0_out) j0_out[r] = cursor_value(cd, r_tid[r], pos + 1);       // first exon always starts at pos + 1
+        n = (uint32_t)walk_cigar(cig + a, (int)(b - a), pos, p, [](int, int, int) {});
         n_ex[r] = n;
     }
     uint32_t total;
@@ -161,30 +226,30 @@ struct ReadState {
     bool lfull, rfull, lnoth, rnoth, known, ksite;
 };
 
-// src/update_gtf.c:629-681 check_full for one overlapping annotation transcript
-__device__ __forceinline__ void full_evidence(ReadState &st, int level, const int *S, const int *E, int n,
-                                              const int2 *__restrict__ ax, int m)
+// src/update_gtf.c:629-681 check_full for one overlapping annotation transcript.  The read's and the
+// transcript's terminal exons come in registers / from the header; only the "overlaps some other exon"
+// scans of levels 3 and 4 touch the transcript's exon array.
+struct ReadEnds { int s0, e0, sl, el; };     // first and last exon of the read
+
+__device__ __forceinline__ void full_evidence(ReadState &st, int level, const ReadEnds &r, const TxHdr &a, const int2 *__restrict__ ax)
 {
     if (st.lfull && st.rfull) return;
-    const int2 a0 = ax[0], al = ax[m - 1];
     if (level == 1) {
-        if (!st.lfull && E[0] == a0.y) st.lfull = true;
-        if (!st.rfull && S[n - 1] == al.x) st.rfull = true;
+        if (!st.lfull && r.e0 == a.e0) st.lfull = true;
+        if (!st.rfull && r.sl == a.sl) st.rfull = true;
     } else if (level == 2) {
-        if (!st.lfull && closed_overlap(S[0], E[0], a0.x, a0.y)) st.lfull = true;
-        if (!st.rfull && closed_overlap(S[n - 1], E[n - 1], al.x, al.y)) st.rfull = true;
+        if (!st.lfull && closed_overlap(r.s0, r.e0, a.s0, a.e0)) st.lfull = true;
+        if (!st.rfull && closed_overlap(r.sl, r.el, a.sl, a.el)) st.rfull = true;
     } else if (level == 3 || level == 4) {
         if (!st.lfull) {
-            const int s = S[0], e = E[0];
-            if (closed_overlap(s, e, a0.x, a0.y)) st.lfull = true;
+            if (closed_overlap(r.s0, r.e0, a.s0, a.e0)) st.lfull = true;
             else if (st.lnoth)
-                for (int k = 0; k < m; ++k) { const int2 a = ax[k]; if (closed_overlap(s, e, a.x, a.y)) { st.lnoth = false; break; } }
+                for (int k = 0; k < a.n; ++k) { const int2 x = ax[k]; if (closed_overlap(r.s0, r.e0, x.x, x.y)) { st.lnoth = false; break; } }
         }
         if (level == 3 && !st.rfull) {
-            const int s = S[n - 1], e = E[n - 1];
-            if (closed_overlap(s, e, al.x, al.y)) st.rfull = true;
+            if (closed_overlap(r.sl, r.el, a.sl, a.el)) st.rfull = true;
             else if (st.rnoth)
-                for (int k = 0; k < m; ++k) { const int2 a = ax[k]; if (closed_overlap(s, e, a.x, a.y)) { st.rnoth = false; break; } }
+                for (int k = 0; k < a.n; ++k) { const int2 x = ax[k]; if (closed_overlap(r.sl, r.el, x.x, x.y)) { st.rnoth = false; break; } }
         }
     }
 }
@@ -228,37 +293,138 @@ __device__ __forceinline__ int site_compare(const int *S, const int *E, uint8_t 
     return same > 0 ? 2 : 0;
 }
 
-// src/update_gtf.c:792-835 check_with_anno_trans for one read whose exons (S,E) and
-// flag bytes F are addressable.  j0 = cursor value the sequential code would have
-// (SURVEY.md 3.3).  Returns info bits (without exon count), ref in `ref`.
-__device__ __forceinline__ uint32_t sweep_annotation(const int *S, const int *E, uint8_t *F, int n, int tid, bool rev,
-                                                     int j0, const TxHdr *__restrict__ hdr, const int2 *__restrict__ anno_ex,
-                                                     const DevParams &p, int &ref)
+// ------------------------------------------------------------------ site dictionaries (-d 0)
+//
+// With -d 0, check_splice_site only asks "is this read coordinate (pair) also a site of the transcript".
+// Every distinct annotation site has a rank (host, once per annotation); a transcript carries a 64-bit
+// mask of its sites relative to its first rank, a read maps its sites to ranks once (hash probes) and
+// keeps a 64-bit mask relative to its first hit.  A candidate is then shift + AND + popcount.
+// Preconditions, checked per read and per transcript (anything else takes the literal loops):
+// strictly increasing exon starts and ends and start <= end on both sides -- then a value can pair with
+// at most one value of the other chain (pair count == common values) and equality implies that the
+// site lies inside both spans, i.e. inside the overlap window of check_splice_site.
+
+// Probe one bucket for key (k1, k2): `single` = third word of any entry whose first word is k1 (acceptor
+// rank of a start / donor rank of an end), `pair` = index of the entry equal to (k1, k2).
+struct Probe { int single, pair; };
+
+__device__ __forceinline__ Probe site_probe(const SiteDict &t, int bucket, int32_t k1, int32_t k2)
 {
-    const int r_start = S[0], r_end = E[n - 1];
+    Probe pr{-1, -1};
+    if (bucket < 0) return pr;
+    const uint32_t lo = t.dir[bucket], hi = t.dir[bucket + 1];
+    for (uint32_t r = lo; r < hi; ++r) {
+        const int4 k = t.ent[r];
+        if (k.x == k1) { pr.single = k.z; if (k.y == k2) pr.pair = (int)r; }
+    }
+    return pr;
+}
+
+// bucket of coordinate x on `tid`, or -1 when the annotation has no site that far
+__device__ __forceinline__ int site_bucket(int32_t tb, int32_t nb, int32_t x)
+{
+    const int b = x >> SITE_SHIFT;
+    return (x >= 0 && b < nb) ? tb + b : -1;
+}
+
+struct ReadSites {          // the read's sites in rank space
+    unsigned long long rd, ra, rx, rj;      // masks relative to bd/ba/bx/bj
+    int bd, ba, bx, bj;                     // rank of the first hit (or -1)
+    uint32_t hd, ha, hx, hj;                // bit j: exon/junction j of the read had a hit
+    bool ok;                                // representable (every hit within 64 ranks of the first)
+};
+
+__device__ __forceinline__ void add_hit(unsigned long long &m, int &base, uint32_t &h, bool &ok, int g, int j)
+{
+    if (g < 0) return;
+    if (base < 0) base = g;
+    const int off = g - base;
+    if (off >= 64) { ok = false; return; }
+    m |= 1ull << off;
+    h |= 1u << j;
+}
+
+__device__ __forceinline__ unsigned long long align_mask(const uint32_t w[2], int tx_base, int read_base)
+{
+    const unsigned long long m = ((unsigned long long)w[1] << 32) | w[0];
+    const int d = tx_base - read_base;               // transcript bit k is rank tx_base + k
+    if (d >= 0) return d < 64 ? m << d : 0ull;
+    return -d < 64 ? m >> (-d) : 0ull;
+}
+
+// src/update_gtf.c:792-835 check_with_anno_trans for one read.  (S,E,F) address the read's exons and
+// flag bytes (LDS or HBM).  j0 = cursor value the sequential code would have.
+// Returns info bits (without exon count), ref in `ref`.
+// The annotation window of a tile staged in LDS: headers [lo, lo + n) and the exons [ex_lo, ex_lo + ex_n).
+struct AnnoWindow { const TxHdr *hdr; const int2 *ex; int lo, n, ex_lo, ex_n; };
+
+__device__ __forceinline__ uint32_t sweep_annotation(const int *S, const int *E, uint8_t *F, int n, int tid, bool rev, bool read_ok,
+                                                     const ReadEnds &re, int e_pen, int s_2nd, const ReadSites &rs,
+                                                     int j0, const TxHdr *__restrict__ hdr, const int2 *__restrict__ anno_ex,
+                                                     const AnnoWindow &w, const DevParams &p, int &ref)
+{
+    const int r_start = re.s0, r_end = re.el;
     ReadState st{false, false, true, true, false, false};
+    unsigned long long md = 0, ma = 0, mx = 0, mj = 0;      // sites matched by some visited transcript
     ref = -1;
+    int ref_rev = 0;
     for (int j = j0; j < p.n_tx; ++j) {
-        const int4 h0 = reinterpret_cast<const int4 *>(hdr + j)[0];
+        const bool in_w = (unsigned)(j - w.lo) < (unsigned)w.n;
+        const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);
+        const int4 *wp = reinterpret_cast<const int4 *>(w.hdr + (in_w ? j - w.lo : 0));
+        const int4 h0 = in_w ? wp[0] : hp[0];
         TxHdr a; a.tid = h0.x; a.start = h0.y; a.end = h0.z; a.ex_off = h0.w;
         // src/update_gtf.c:786-790 comp_trans: <= (Q5)
         if (tid < a.tid || (tid == a.tid && r_end <= a.start)) break;
         if (a.tid < tid || (a.tid == tid && a.end <= r_start)) continue;
-        const int4 h1 = reinterpret_cast<const int4 *>(hdr + j)[1];
-        a.n = h1.x; a.rev = h1.y; a.mono = h1.z;
+        const int4 h1 = in_w ? wp[1] : hp[1], h2 = in_w ? wp[2] : hp[2];
+        a.n = h1.x; a.rev = h1.y; a.flags = h1.z; a.s0 = h2.x; a.e0 = h2.y; a.sl = h2.z; a.el = h2.w;
         const int2 *ax = anno_ex + a.ex_off;
-        full_evidence(st, p.full_level, S, E, n, ax, a.n);
+        if (!(p.ablate & 4)) {
+            if (in_w && (unsigned)(a.ex_off - w.ex_lo) + (unsigned)a.n <= (unsigned)w.ex_n) full_evidence(st, p.full_level, re, a, w.ex + (a.ex_off - w.ex_lo));
+            else full_evidence(st, p.full_level, re, a, ax);
+        }
+        int v = 0;
         if (n == 1 && a.n == 1) {
-            const int2 a0 = ax[0];
-            if (overlap_frac(S[0], E[0], a0.x, a0.y) >= p.frac) { ref = j; st.known = true; break; }
-        } else if (n > 1 && a.n > 1) {
-            const int v = site_compare(S, E, F, n, r_start, r_end, a, ax, p.ss_dis);
-            if (v == 1) { st.known = true; ref = j; break; }
-            if (v == 2) { st.ksite = true; ref = j; }
+            if (overlap_frac(re.s0, re.e0, a.s0, a.e0) >= p.frac) { st.known = true; v = 1; }
+        } else if (n > 1 && a.n > 1 && !(p.ablate & 2)) {
+            if (read_ok && (a.flags & TX_COMPACT)) {
+                const int4 h3 = in_w ? wp[3] : hp[3], h4 = in_w ? wp[4] : hp[4], h5 = in_w ? wp[5] : hp[5];
+                const uint32_t wd[2] = {(uint32_t)h4.x, (uint32_t)h4.y}, wa[2] = {(uint32_t)h4.z, (uint32_t)h4.w};
+                const uint32_t wx[2] = {(uint32_t)h5.x, (uint32_t)h5.y}, wj[2] = {(uint32_t)h5.z, (uint32_t)h5.w};
+                const unsigned long long cd = rs.rd & align_mask(wd, h3.x, rs.bd), ca = rs.ra & align_mask(wa, h3.y, rs.ba);
+                md |= cd; ma |= ca;
+                mx |= rs.rx & align_mask(wx, h3.z, rs.bx);
+                mj |= rs.rj & align_mask(wj, h3.w, rs.bj);
+                const int same = __popcll(cd) + __popcll(ca);
+                const int lo = max(r_start, a.start), hi = min(r_end, a.end);
+                // every one of the 2(n-1) read sites inside [lo,hi]: donors e_0..e_{n-2}, acceptors s_1..s_{n-1} increase
+                const bool all_in = re.e0 >= lo && e_pen <= hi && s_2nd >= lo && re.sl <= hi;
+                v = (all_in && same == 2 * (n - 1)) ? 1 : (same > 0 ? 2 : 0);
+            } else {
+                v = site_compare(S, E, F, n, r_start, r_end, a, ax, p.ss_dis);
+            }
+            if (v == 1) st.known = true;
+            if (v == 2) st.ksite = true;
+        }
+        if (v) { ref = j; ref_rev = a.rev; }
+        if (v == 1) break;
+    }
+    if (md | ma | mx | mj) {
+        // hits were recorded in exon order and ranks increase with the exon index, so the k-th hit of a
+        // kind is the k-th set bit of its mask
+        unsigned long long qd = rs.rd, qa = rs.ra, qx = rs.rx, qj = rs.rj;
+        for (int k = 0; k < n; ++k) {
+            uint8_t clr = 0;
+            if ((rs.hx >> k) & 1u) { const unsigned long long b = qx & (0ull - qx); qx ^= b; if (mx & b) clr |= F_EXON; }
+            if ((rs.hd >> k) & 1u) { const unsigned long long b = qd & (0ull - qd); qd ^= b; if (md & b) clr |= F_DON; }
+            if ((rs.ha >> k) & 1u) { const unsigned long long b = qa & (0ull - qa); qa ^= b; if (ma & b) clr |= F_ACC; }
+            if ((rs.hj >> k) & 1u) { const unsigned long long b = qj & (0ull - qj); qj ^= b; if (mj & b) clr |= F_JUNC; }
+            if (clr) F[k] &= (uint8_t)~clr;
         }
     }
     bool out_rev = rev;
-    if (ref >= 0) out_rev = hdr[ref].rev != 0;          // :825-831 strand taken from the reference transcript
+    if (ref >= 0) out_rev = ref_rev != 0;               // :825-831 strand taken from the reference transcript
     bool full;                                           // :683-696 set_full
     if (p.full_level == 5) full = true;
     else if (p.full_level == 4) full = st.lfull || st.lnoth;
@@ -282,62 +448,201 @@ __device__ __forceinline__ int first_key_above(const int64_t *__restrict__ key, 
     return lo;
 }
 
-// One read: exons -> (S,E,F) at the given pointers, then the annotation sweep.
-__device__ __forceinline__ uint32_t process_read(int *S, int *E, uint8_t *F, int n, int32_t tid, int32_t pos0, bool rev,
-                                                 const uint32_t *cig, int n_cig, int64_t r,
-                                                 const int64_t *__restrict__ anno_key, const int32_t *__restrict__ win_start,
-                                                 const TxHdr *__restrict__ hdr, const int2 *__restrict__ anno_ex,
-                                                 const DevParams &p, int &ref)
+// Exons of one read into (S,E,F); terminal-exon registers; `sane` = strictly increasing starts and ends
+// and start <= end (the precondition of the dictionary path on the read side).
+struct ReadShape { ReadEnds re; int s_2nd, e_pen; bool sane; };
+
+__device__ __forceinline__ ReadShape exons_from_cigar(int *S, int *E, uint8_t *F, int n, int32_t pos0,
+                                                      const uint32_t *__restrict__ cig, int n_cig, const DevParams &p)
 {
+    ReadShape sh{{0, 0, 0, 0}, 0, 0, true};
+    int ps = INT32_MIN, pe = INT32_MIN;
     walk_cigar(cig, n_cig, pos0, p, [&](int k, int s, int e) {
         S[k] = s; E[k] = e;
+        sh.sane = sh.sane && s > ps && e > pe && s <= e;
+        if (k == 0) { sh.re.s0 = s; sh.re.e0 = e; }
+        if (k == 1) sh.s_2nd = s;
+        sh.e_pen = pe; ps = s; pe = e;
     });
+    sh.re.sl = ps; sh.re.el = pe;
     for (int k = 0; k < n; ++k) F[k] = (k + 1 < n) ? (uint8_t)(F_EXON | F_DON | F_ACC | F_JUNC) : F_EXON;
-    const int j0 = win_start ? win_start[r] : first_key_above(anno_key, p.n_tx, pack_key(tid, S[0]));
-    uint32_t info = sweep_annotation(S, E, F, n, tid, rev, j0, hdr, anno_ex, p, ref);
+    return sh;
+}
+
+// The slice of one dictionary that covers a tile, staged in LDS: directory words of the buckets
+// [b0, b0 + nb] and the entries [r0, r0 + nk).
+struct DictSlice { const uint32_t *dir; const int4 *ent; int b0; uint32_t r0; };
+
+__device__ __forceinline__ Probe slice_probe(const DictSlice &t, int bucket, int32_t k1, int32_t k2)
+{
+    Probe pr{-1, -1};
+    if (bucket < 0) return pr;
+    const uint32_t lo = t.dir[bucket - t.b0] - t.r0, hi = t.dir[bucket - t.b0 + 1] - t.r0;
+    for (uint32_t r = lo; r < hi; ++r) {
+        const int4 k = t.ent[r];
+        if (k.x == k1) { pr.single = k.z; if (k.y == k2) pr.pair = (int)(r + t.r0); }
+    }
+    return pr;
+}
+
+// ranks of the read's sites -> ReadSites; PROBE(which 0 = START / 1 = END, bucket, k1, k2)
+template <typename ProbeFn>
+__device__ __forceinline__ ReadSites map_read_sites(const int *S, const int *E, int n, int32_t tb, int32_t nb, ProbeFn probe)
+{
+    ReadSites rs{0, 0, 0, 0, -1, -1, -1, -1, 0, 0, 0, 0, true};
+    int s = S[0], e = E[0];
+    for (int k = 0; k < n; ++k) {
+        const Probe ps = probe(0, site_bucket(tb, nb, s), s, e);           // exon (s,e); acceptor rank of s
+        add_hit(rs.rx, rs.bx, rs.hx, rs.ok, ps.pair, k);
+        if (k + 1 < n) {
+            const int s2 = S[k + 1], e2 = E[k + 1];
+            const Probe pe = probe(1, site_bucket(tb, nb, e), e, s2);      // junction (e,s2); donor rank of e
+            add_hit(rs.ra, rs.ba, rs.ha, rs.ok, ps.single, k);             // Q1: start of exon k itself, k < n-1
+            add_hit(rs.rd, rs.bd, rs.hd, rs.ok, pe.single, k);
+            add_hit(rs.rj, rs.bj, rs.hj, rs.ok, pe.pair, k);
+            s = s2; e = e2;
+        }
+    }
+    return rs;
+}
+
+__device__ __forceinline__ uint32_t finish_info(uint32_t info, int n, const DevParams &p)
+{
     // routing of update_gtf.c:943-950 when there is no junction table
     if (p.n_sj == 0 && (info & (I_FULL | I_KNOWN | I_KSITE)) == (I_FULL | I_KSITE)) info |= I_ACCEPT;
     return info | ((uint32_t)n << 8);
 }
 
+constexpr int DIR_CAP = 384;        // directory words staged per kind (tile span up to ~196 kb of buckets)
+constexpr int KEY_CAP = 256;        // dictionary entries staged per dictionary
+constexpr int WIN_HDRS = 64;        // annotation headers staged per tile
+constexpr int WIN_EXONS = 768;      // annotation exons staged per tile
+
 __global__ __launch_bounds__(TILE_THREADS)
 void k_fill_classify(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t *__restrict__ r_pos,
                      const uint8_t *__restrict__ r_rev, const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ cig,
                      const uint32_t *__restrict__ n_ex, const uint32_t *__restrict__ tile_base,
-                     const int64_t *__restrict__ anno_key, const int32_t *__restrict__ win_start,
-                     const TxHdr *__restrict__ hdr, const int2 *__restrict__ anno_ex, DevParams p,
+                     const int32_t *__restrict__ j0_arr,
+                     const TxHdr *__restrict__ hdr, const int2 *__restrict__ anno_ex, SiteTabs tabs, DevParams p,
                      uint32_t *__restrict__ ex_off, int32_t *__restrict__ ex_start, int32_t *__restrict__ ex_end,
                      uint8_t *__restrict__ ex_flag, uint32_t *__restrict__ info_out, int32_t *__restrict__ ref_out)
 {
     __shared__ uint32_t s_wave[4];
+    __shared__ int s_bmin, s_bmax, s_jlo;
+    __shared__ __attribute__((aligned(16))) TxHdr s_whdr[WIN_HDRS];
+    __shared__ int2 s_wex[WIN_EXONS];
     __shared__ int s_start[LDS_EXON_CAP];
     __shared__ int s_end[LDS_EXON_CAP];
     __shared__ uint8_t s_flag[LDS_EXON_CAP];
+    __shared__ uint32_t s_dir[2][DIR_CAP + 1];
+    __shared__ __attribute__((aligned(16))) int4 s_keys[2][KEY_CAP];
 
     const int64_t r = (int64_t)blockIdx.x * p.reads_per_tile + threadIdx.x;
     const bool active = threadIdx.x < p.reads_per_tile && r < n_reads;
     const uint32_t n = active ? n_ex[r] : 0u;
+    if (threadIdx.x == 0) { s_bmin = INT32_MAX; s_bmax = -1; s_jlo = INT32_MAX; }
     uint32_t tile_total;
     const uint32_t local = block_exclusive_scan(n, s_wave, tile_total);
     const uint32_t base = tile_base[blockIdx.x];
-    uint32_t info = 0; int ref = -1;
-    if (tile_total <= (uint32_t)LDS_EXON_CAP) {
-        if (active) {
-            const int64_t a = cig_off[r], b = cig_off[r + 1];
-            info = process_read(s_start + local, s_end + local, s_flag + local, (int)n, r_tid[r], r_pos[r], r_rev[r] != 0,
-                                cig + a, (int)(b - a), r, anno_key, win_start, hdr, anno_ex, p, ref);
+    const bool in_lds = tile_total <= (uint32_t)LDS_EXON_CAP;       // else: very long exon chains, work in HBM
+
+    // ---- phase 1: CIGAR -> exons, cursor value, bucket span of the read
+    ReadShape sh{{0, 0, 0, 0}, 0, 0, true};
+    int32_t tid = 0, tb = 0, nb = 0; int j0 = 0;
+    bool want_dict = false;
+    if (active) {
+        const int64_t a = cig_off[r], b = cig_off[r + 1];
+        tid = r_tid[r];
+        if (in_lds) sh = exons_from_cigar(s_start + local, s_end + local, s_flag + local, (int)n, r_pos[r], cig + a, (int)(b - a), p);
+        else sh = exons_from_cigar(ex_start + base + local, ex_end + base + local, ex_flag + base + local, (int)n, r_pos[r], cig + a, (int)(b - a), p);
+        j0 = j0_arr[r];
+        want_dict = p.ss_dis == 0 && sh.sane && n > 1 && n <= 32 && tid < tabs.n_tid && !(p.ablate & (16 | 1));
+        if (want_dict) { tb = tabs.tid_base[tid]; nb = tabs.tid_base[tid + 1] - tb; want_dict = nb > 0; }
+    }
+    {   // bucket span of the tile's dictionary reads: wave reduction, one LDS atomic per wave
+        int lo = INT32_MAX, hi = -1, jl = active ? j0 : INT32_MAX;
+        if (want_dict) {
+            lo = tb + min(max(sh.re.s0, 0) >> SITE_SHIFT, nb - 1);
+            hi = tb + min(max(sh.re.el, 0) >> SITE_SHIFT, nb - 1);
         }
+#pragma unroll
+        for (int d = WAVE / 2; d > 0; d >>= 1) {
+            lo = min(lo, __shfl_xor(lo, d, WAVE)); hi = max(hi, __shfl_xor(hi, d, WAVE)); jl = min(jl, __shfl_xor(jl, d, WAVE));
+        }
+        if ((threadIdx.x & (WAVE - 1)) == 0) {
+            if (hi >= 0) { atomicMin(&s_bmin, lo); atomicMax(&s_bmax, hi); }
+            atomicMin(&s_jlo, jl);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: stage the dictionary slices of the tile in LDS (directory words, then keys)
+    const int b0 = s_bmin, nbk = s_bmax - s_bmin + 1;                // buckets b0 .. b0+nbk-1
+    bool staged = in_lds && s_bmax >= 0 && nbk <= DIR_CAP && !(p.ablate & 64);
+    // annotation window: headers of the transcripts [w_lo, w_lo + w_n)
+    const int w_lo = min(s_jlo, p.n_tx), w_n = min(WIN_HDRS, p.n_tx - w_lo);
+    for (int i = threadIdx.x; i < w_n * 6; i += TILE_THREADS)
+        reinterpret_cast<int4 *>(s_whdr)[i] = reinterpret_cast<const int4 *>(hdr + w_lo)[i];
+    if (staged) {
+        for (int i = threadIdx.x; i < 2 * (nbk + 1); i += TILE_THREADS) {
+            const int kind = i >= nbk + 1, w = i - kind * (nbk + 1);
+            s_dir[kind][w] = (kind ? tabs.en.dir : tabs.st.dir)[b0 + w];
+        }
+    }
+    __syncthreads();
+    if (staged) {
+#pragma unroll
+        for (int kind = 0; kind < 2; ++kind) staged = staged && (s_dir[kind][nbk] - s_dir[kind][0]) <= (uint32_t)KEY_CAP;
+    }
+    int w_ex_lo = 0, w_ex_n = 0;
+    if (w_n > 0) {          // exon rows are stored in transcript order: the window's exons are one range
+        w_ex_lo = s_whdr[0].ex_off;
+        w_ex_n = min(WIN_EXONS, max(s_whdr[w_n - 1].ex_off + s_whdr[w_n - 1].n - w_ex_lo, 0));
+        for (int i = threadIdx.x; i < w_ex_n; i += TILE_THREADS) s_wex[i] = anno_ex[w_ex_lo + i];
+    }
+    if (staged) {
+#pragma unroll
+        for (int kind = 0; kind < 2; ++kind) {
+            const int4 *src = kind ? tabs.en.ent : tabs.st.ent;
+            const uint32_t r0 = s_dir[kind][0], nk = s_dir[kind][nbk] - r0;
+            for (uint32_t i = threadIdx.x; i < nk; i += TILE_THREADS) s_keys[kind][i] = src[r0 + i];
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: ranks of the read's sites, then the sweep
+    uint32_t info = 0; int ref = -1;
+    const AnnoWindow win{s_whdr, s_wex, w_lo, max(w_n, 0), w_ex_lo, w_ex_n};
+    auto phase3 = [&](const int *S, const int *E, uint8_t *F) {
+        ReadSites rs{0, 0, 0, 0, -1, -1, -1, -1, 0, 0, 0, 0, true};
+        bool read_ok = want_dict;
+        if (want_dict && !(p.ablate & 32)) {
+            if (staged) {
+                const DictSlice ss{s_dir[0], s_keys[0], b0, s_dir[0][0]}, se{s_dir[1], s_keys[1], b0, s_dir[1][0]};
+                rs = map_read_sites(S, E, (int)n, tb, nb, [&](int which, int bucket, int k1, int k2) {
+                    return which ? slice_probe(se, bucket, k1, k2) : slice_probe(ss, bucket, k1, k2);
+                });
+            } else {
+                rs = map_read_sites(S, E, (int)n, tb, nb, [&](int which, int bucket, int k1, int k2) {
+                    return which ? site_probe(tabs.en, bucket, k1, k2) : site_probe(tabs.st, bucket, k1, k2);
+                });
+            }
+            read_ok = rs.ok;
+        }
+        if (!(p.ablate & 1))
+            info = sweep_annotation(S, E, F, (int)n, tid, r_rev[r] != 0, read_ok, sh.re, sh.e_pen, sh.s_2nd, rs, j0, hdr, anno_ex, win, p, ref);
+        info = finish_info(info, (int)n, p);
+    };
+    if (active) {
+        if (in_lds) phase3(s_start + local, s_end + local, s_flag + local);
+        else phase3(ex_start + base + local, ex_end + base + local, ex_flag + base + local);
+    }
+    // ---- phase 4: coalesced write-out of the tile
+    if (in_lds) {
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < tile_total; i += TILE_THREADS) {      // coalesced write-out
+        for (uint32_t i = threadIdx.x; i < tile_total; i += TILE_THREADS) {
             ex_start[base + i] = s_start[i];
             ex_end[base + i] = s_end[i];
             ex_flag[base + i] = s_flag[i];
         }
-    } else if (active) {
-        // oversize tile (very long exon chains): work directly on the output arrays in HBM
-        const int64_t a = cig_off[r], b = cig_off[r + 1];
-        info = process_read(ex_start + base + local, ex_end + base + local, ex_flag + base + local, (int)n, r_tid[r], r_pos[r],
-                            r_rev[r] != 0, cig + a, (int)(b - a), r, anno_key, win_start, hdr, anno_ex, p, ref);
     }
     if (active) {
         ex_off[r] = base + local;

@@ -1,4 +1,3 @@
-"""Quick timing probe on the GPU box (diagnostics, not part of the product)."""
 import sys, time, json, os
 import numpy as np
 sys.path.insert(0, '.')
@@ -7,13 +6,11 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000000
 cfg = dict(workload.CONFIGS['cfg3']); cfg['n_reads'] = N
 af, reads = workload.make_rank_workload(cfg, 0, 1)
 e = capi.Engine(0)
-t = time.time()
 e.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
-print('set_annotation %.2f s' % (time.time() - t))
-e.set_params(capi.default_params(full_level=3))
 e.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)
-for ab in (sys.argv[2].split(',') if len(sys.argv) > 2 else ['0']):
-    os.environ['L2R_ABLATE'] = ab
+for lvl, dis in ((3,0),(3,1),(5,0),(5,1)):
+    e.set_params(capi.default_params(full_level=lvl, ss_dis=dis))
     e.run(); e.sync()
     tm = e.run_timed(5)
-    print('ablate', ab, 'total %.3f' % tm['total_ms'], ' '.join('%s=%.3f' % (k[:10], v) for k, v in tm['stage_ms'].items()), flush=True)
+    r = e.download()
+    print('lvl', lvl, 'dis', dis, 'fill %.3f' % tm['stage_ms']['fill_classify'], 'known', int(((r.info&1)!=0).sum()), flush=True)
