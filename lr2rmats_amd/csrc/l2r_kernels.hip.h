@@ -21,7 +21,7 @@ namespace l2r {
 
 constexpr int TILE_THREADS = 256;
 constexpr int WAVE = 64;
-constexpr int LDS_EXON_CAP = 2816;      // exons of one tile staged in LDS (9 B each)
+constexpr int LDS_EXON_CAP = 3072;      // exons of one tile staged in LDS (9 B each)
 
 // One annotation transcript (file order), 96 B = six 16-byte loads; the sweep reads h0 for every
 // transcript it passes, h1..h2 for the ones that overlap, h3..h5 only on the dictionary path.
@@ -355,60 +355,97 @@ __device__ __forceinline__ unsigned long long align_mask(const uint32_t w[2], in
 // src/update_gtf.c:792-835 check_with_anno_trans for one read.  (S,E,F) address the read's exons and
 // flag bytes (LDS or HBM).  j0 = cursor value the sequential code would have.
 // Returns info bits (without exon count), ref in `ref`.
-// The annotation window of a tile staged in LDS: headers [lo, lo + n) and the exons [ex_lo, ex_lo + ex_n).
-struct AnnoWindow { const TxHdr *hdr; const int2 *ex; int lo, n, ex_lo, ex_n; };
-
-__device__ __forceinline__ uint32_t sweep_annotation(const int *S, const int *E, uint8_t *F, int n, int tid, bool rev, bool read_ok,
+// src/update_gtf.c:792-835 check_with_anno_trans, WAVE-UNIFORM form.  The 64 reads of a wave are
+// neighbours in a coordinate-sorted input, so they sweep (almost) the same annotation transcripts.  The
+// whole wave therefore walks ONE transcript index j upwards from the smallest cursor value of its reads;
+// j is wave-uniform, so the transcript header (and, for the exon scans of check_full, its exons) come in
+// through scalar loads once per wave, and every lane applies its own read's predicates: not started yet
+// (j < its cursor), finished (the read lies before transcript j, or it was found known -- the reference's
+// two `break`s), transcript before the read (`continue`), or overlap.  Per read the transcripts are still
+// visited in file order with the reference's early exits; only the interleaving across reads changes.
+// Every lane of the wave must call this (act = lane owns a read).
+__device__ __forceinline__ uint32_t sweep_annotation(bool act, const int *S, const int *E, uint8_t *F, int n, int tid, bool rev, bool read_ok,
                                                      const ReadEnds &re, int e_pen, int s_2nd, const ReadSites &rs,
                                                      int j0, const TxHdr *__restrict__ hdr, const int2 *__restrict__ anno_ex,
-                                                     const AnnoWindow &w, const DevParams &p, int &ref)
+                                                     const DevParams &p, int &ref)
 {
     const int r_start = re.s0, r_end = re.el;
     ReadState st{false, false, true, true, false, false};
     unsigned long long md = 0, ma = 0, mx = 0, mj = 0;      // sites matched by some visited transcript
     ref = -1;
     int ref_rev = 0;
-    for (int j = j0; j < p.n_tx; ++j) {
-        const bool in_w = (unsigned)(j - w.lo) < (unsigned)w.n;
-        const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);
-        const int4 *wp = reinterpret_cast<const int4 *>(w.hdr + (in_w ? j - w.lo : 0));
-        const int4 h0 = in_w ? wp[0] : hp[0];
+    bool done = !act || (p.ablate & 1);
+    int jm = done ? INT32_MAX : j0;
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) jm = min(jm, __shfl_xor(jm, d, WAVE));
+    const int level = p.full_level;
+    for (int j = __builtin_amdgcn_readfirstlane(jm); j < p.n_tx && __any(!done); ++j) {
+        const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);           // wave-uniform address
+        const int4 h0 = hp[0];
+        bool ov = false;
+        if (!done && j >= j0) {
+            // src/update_gtf.c:786-790 comp_trans: <= (Q5)
+            if (tid < h0.x || (tid == h0.x && r_end <= h0.y)) done = true;                  // :799-800 break
+            else ov = !(h0.x < tid || (h0.x == tid && h0.z <= r_start));                    // :801 skip when before
+        }
+        if (!__any(ov)) continue;
+        const int4 h1 = hp[1], h2 = hp[2];
         TxHdr a; a.tid = h0.x; a.start = h0.y; a.end = h0.z; a.ex_off = h0.w;
-        // src/update_gtf.c:786-790 comp_trans: <= (Q5)
-        if (tid < a.tid || (tid == a.tid && r_end <= a.start)) break;
-        if (a.tid < tid || (a.tid == tid && a.end <= r_start)) continue;
-        const int4 h1 = in_w ? wp[1] : hp[1], h2 = in_w ? wp[2] : hp[2];
         a.n = h1.x; a.rev = h1.y; a.flags = h1.z; a.s0 = h2.x; a.e0 = h2.y; a.sl = h2.z; a.el = h2.w;
         const int2 *ax = anno_ex + a.ex_off;
-        if (!(p.ablate & 4)) {
-            if (in_w && (unsigned)(a.ex_off - w.ex_lo) + (unsigned)a.n <= (unsigned)w.ex_n) full_evidence(st, p.full_level, re, a, w.ex + (a.ex_off - w.ex_lo));
-            else full_evidence(st, p.full_level, re, a, ax);
-        }
-        int v = 0;
-        if (n == 1 && a.n == 1) {
-            if (overlap_frac(re.s0, re.e0, a.s0, a.e0) >= p.frac) { st.known = true; v = 1; }
-        } else if (n > 1 && a.n > 1 && !(p.ablate & 2)) {
-            if (read_ok && (a.flags & TX_COMPACT)) {
-                const int4 h3 = in_w ? wp[3] : hp[3], h4 = in_w ? wp[4] : hp[4], h5 = in_w ? wp[5] : hp[5];
-                const uint32_t wd[2] = {(uint32_t)h4.x, (uint32_t)h4.y}, wa[2] = {(uint32_t)h4.z, (uint32_t)h4.w};
-                const uint32_t wx[2] = {(uint32_t)h5.x, (uint32_t)h5.y}, wj[2] = {(uint32_t)h5.z, (uint32_t)h5.w};
-                const unsigned long long cd = rs.rd & align_mask(wd, h3.x, rs.bd), ca = rs.ra & align_mask(wa, h3.y, rs.ba);
-                md |= cd; ma |= ca;
-                mx |= rs.rx & align_mask(wx, h3.z, rs.bx);
-                mj |= rs.rj & align_mask(wj, h3.w, rs.bj);
-                const int same = __popcll(cd) + __popcll(ca);
-                const int lo = max(r_start, a.start), hi = min(r_end, a.end);
-                // every one of the 2(n-1) read sites inside [lo,hi]: donors e_0..e_{n-2}, acceptors s_1..s_{n-1} increase
-                const bool all_in = re.e0 >= lo && e_pen <= hi && s_2nd >= lo && re.sl <= hi;
-                v = (all_in && same == 2 * (n - 1)) ? 1 : (same > 0 ? 2 : 0);
-            } else {
-                v = site_compare(S, E, F, n, r_start, r_end, a, ax, p.ss_dis);
+        // ---- check_full :629-681
+        if (!(p.ablate & 4) && ov && !(st.lfull && st.rfull)) {
+            if (level == 1) {
+                if (!st.lfull && re.e0 == a.e0) st.lfull = true;
+                if (!st.rfull && re.sl == a.sl) st.rfull = true;
+            } else if (level == 2) {
+                if (!st.lfull && closed_overlap(re.s0, re.e0, a.s0, a.e0)) st.lfull = true;
+                if (!st.rfull && closed_overlap(re.sl, re.el, a.sl, a.el)) st.rfull = true;
             }
+        }
+        if (!(p.ablate & 4) && (level == 3 || level == 4)) {
+            bool need_l = false, need_r = false;
+            if (ov && !(st.lfull && st.rfull)) {
+                if (!st.lfull) { if (closed_overlap(re.s0, re.e0, a.s0, a.e0)) st.lfull = true; else need_l = st.lnoth; }
+                if (level == 3 && !st.rfull) { if (closed_overlap(re.sl, re.el, a.sl, a.el)) st.rfull = true; else need_r = st.rnoth; }
+            }
+            if (__any(need_l || need_r)) {
+                for (int k = 0; k < a.n; ++k) {                      // exon k of the transcript: scalar load
+                    const int2 x = ax[k];
+                    if (need_l && closed_overlap(re.s0, re.e0, x.x, x.y)) { st.lnoth = false; need_l = false; }
+                    if (need_r && closed_overlap(re.sl, re.el, x.x, x.y)) { st.rnoth = false; need_r = false; }
+                }
+            }
+        }
+        // ---- :806-820
+        int v = 0;
+        if (a.n == 1) {
+            if (ov && n == 1 && overlap_frac(re.s0, re.e0, a.s0, a.e0) >= p.frac) { st.known = true; v = 1; }
+        } else if (!(p.ablate & 2)) {
+            const bool multi = ov && n > 1;
+            const bool use_dict = multi && read_ok && (a.flags & TX_COMPACT);
+            if (__any(use_dict)) {
+                const int4 h3 = hp[3], h4 = hp[4], h5 = hp[5];
+                if (use_dict) {
+                    const uint32_t wd[2] = {(uint32_t)h4.x, (uint32_t)h4.y}, wa[2] = {(uint32_t)h4.z, (uint32_t)h4.w};
+                    const uint32_t wx[2] = {(uint32_t)h5.x, (uint32_t)h5.y}, wj[2] = {(uint32_t)h5.z, (uint32_t)h5.w};
+                    const unsigned long long cd = rs.rd & align_mask(wd, h3.x, rs.bd), ca = rs.ra & align_mask(wa, h3.y, rs.ba);
+                    md |= cd; ma |= ca;
+                    mx |= rs.rx & align_mask(wx, h3.z, rs.bx);
+                    mj |= rs.rj & align_mask(wj, h3.w, rs.bj);
+                    const int same = __popcll(cd) + __popcll(ca);
+                    const int lo = max(r_start, a.start), hi = min(r_end, a.end);
+                    // every one of the 2(n-1) read sites inside [lo,hi]: donors e_0..e_{n-2}, acceptors s_1..s_{n-1} increase
+                    const bool all_in = re.e0 >= lo && e_pen <= hi && s_2nd >= lo && re.sl <= hi;
+                    v = (all_in && same == 2 * (n - 1)) ? 1 : (same > 0 ? 2 : 0);
+                }
+            }
+            if (multi && !use_dict) v = site_compare(S, E, F, n, r_start, r_end, a, ax, p.ss_dis);      // literal loops
             if (v == 1) st.known = true;
             if (v == 2) st.ksite = true;
         }
         if (v) { ref = j; ref_rev = a.rev; }
-        if (v == 1) break;
+        if (v == 1) done = true;                                                            // :810,816 break
     }
     if (md | ma | mx | mj) {
         // hits were recorded in exon order and ranks increase with the exon index, so the k-th hit of a
@@ -426,9 +463,9 @@ __device__ __forceinline__ uint32_t sweep_annotation(const int *S, const int *E,
     bool out_rev = rev;
     if (ref >= 0) out_rev = ref_rev != 0;               // :825-831 strand taken from the reference transcript
     bool full;                                           // :683-696 set_full
-    if (p.full_level == 5) full = true;
-    else if (p.full_level == 4) full = st.lfull || st.lnoth;
-    else if (p.full_level == 3) full = (st.lfull || st.lnoth) && (st.rfull || st.rnoth);
+    if (level == 5) full = true;
+    else if (level == 4) full = st.lfull || st.lnoth;
+    else if (level == 3) full = (st.lfull || st.lnoth) && (st.rfull || st.rnoth);
     else full = st.lfull && st.rfull;
     uint32_t info = 0;
     if (st.known) info |= I_KNOWN;
@@ -515,8 +552,7 @@ __device__ __forceinline__ uint32_t finish_info(uint32_t info, int n, const DevP
 
 constexpr int DIR_CAP = 384;        // directory words staged per kind (tile span up to ~196 kb of buckets)
 constexpr int KEY_CAP = 256;        // dictionary entries staged per dictionary
-constexpr int WIN_HDRS = 64;        // annotation headers staged per tile
-constexpr int WIN_EXONS = 768;      // annotation exons staged per tile
+
 
 __global__ __launch_bounds__(TILE_THREADS)
 void k_fill_classify(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t *__restrict__ r_pos,
@@ -528,9 +564,7 @@ void k_fill_classify(int64_t n_reads, const int32_t *__restrict__ r_tid, const i
                      uint8_t *__restrict__ ex_flag, uint32_t *__restrict__ info_out, int32_t *__restrict__ ref_out)
 {
     __shared__ uint32_t s_wave[4];
-    __shared__ int s_bmin, s_bmax, s_jlo;
-    __shared__ __attribute__((aligned(16))) TxHdr s_whdr[WIN_HDRS];
-    __shared__ int2 s_wex[WIN_EXONS];
+    __shared__ int s_bmin, s_bmax;
     __shared__ int s_start[LDS_EXON_CAP];
     __shared__ int s_end[LDS_EXON_CAP];
     __shared__ uint8_t s_flag[LDS_EXON_CAP];
@@ -540,7 +574,7 @@ void k_fill_classify(int64_t n_reads, const int32_t *__restrict__ r_tid, const i
     const int64_t r = (int64_t)blockIdx.x * p.reads_per_tile + threadIdx.x;
     const bool active = threadIdx.x < p.reads_per_tile && r < n_reads;
     const uint32_t n = active ? n_ex[r] : 0u;
-    if (threadIdx.x == 0) { s_bmin = INT32_MAX; s_bmax = -1; s_jlo = INT32_MAX; }
+    if (threadIdx.x == 0) { s_bmin = INT32_MAX; s_bmax = -1; }
     uint32_t tile_total;
     const uint32_t local = block_exclusive_scan(n, s_wave, tile_total);
     const uint32_t base = tile_base[blockIdx.x];
@@ -560,28 +594,19 @@ void k_fill_classify(int64_t n_reads, const int32_t *__restrict__ r_tid, const i
         if (want_dict) { tb = tabs.tid_base[tid]; nb = tabs.tid_base[tid + 1] - tb; want_dict = nb > 0; }
     }
     {   // bucket span of the tile's dictionary reads: wave reduction, one LDS atomic per wave
-        int lo = INT32_MAX, hi = -1, jl = active ? j0 : INT32_MAX;
+        int lo = INT32_MAX, hi = -1;
         if (want_dict) {
             lo = tb + min(max(sh.re.s0, 0) >> SITE_SHIFT, nb - 1);
             hi = tb + min(max(sh.re.el, 0) >> SITE_SHIFT, nb - 1);
         }
 #pragma unroll
-        for (int d = WAVE / 2; d > 0; d >>= 1) {
-            lo = min(lo, __shfl_xor(lo, d, WAVE)); hi = max(hi, __shfl_xor(hi, d, WAVE)); jl = min(jl, __shfl_xor(jl, d, WAVE));
-        }
-        if ((threadIdx.x & (WAVE - 1)) == 0) {
-            if (hi >= 0) { atomicMin(&s_bmin, lo); atomicMax(&s_bmax, hi); }
-            atomicMin(&s_jlo, jl);
-        }
+        for (int d = WAVE / 2; d > 0; d >>= 1) { lo = min(lo, __shfl_xor(lo, d, WAVE)); hi = max(hi, __shfl_xor(hi, d, WAVE)); }
+        if ((threadIdx.x & (WAVE - 1)) == 0 && hi >= 0) { atomicMin(&s_bmin, lo); atomicMax(&s_bmax, hi); }
     }
     __syncthreads();
     // ---- phase 2: stage the dictionary slices of the tile in LDS (directory words, then keys)
     const int b0 = s_bmin, nbk = s_bmax - s_bmin + 1;                // buckets b0 .. b0+nbk-1
     bool staged = in_lds && s_bmax >= 0 && nbk <= DIR_CAP && !(p.ablate & 64);
-    // annotation window: headers of the transcripts [w_lo, w_lo + w_n)
-    const int w_lo = min(s_jlo, p.n_tx), w_n = min(WIN_HDRS, p.n_tx - w_lo);
-    for (int i = threadIdx.x; i < w_n * 6; i += TILE_THREADS)
-        reinterpret_cast<int4 *>(s_whdr)[i] = reinterpret_cast<const int4 *>(hdr + w_lo)[i];
     if (staged) {
         for (int i = threadIdx.x; i < 2 * (nbk + 1); i += TILE_THREADS) {
             const int kind = i >= nbk + 1, w = i - kind * (nbk + 1);
@@ -592,12 +617,6 @@ void k_fill_classify(int64_t n_reads, const int32_t *__restrict__ r_tid, const i
     if (staged) {
 #pragma unroll
         for (int kind = 0; kind < 2; ++kind) staged = staged && (s_dir[kind][nbk] - s_dir[kind][0]) <= (uint32_t)KEY_CAP;
-    }
-    int w_ex_lo = 0, w_ex_n = 0;
-    if (w_n > 0) {          // exon rows are stored in transcript order: the window's exons are one range
-        w_ex_lo = s_whdr[0].ex_off;
-        w_ex_n = min(WIN_EXONS, max(s_whdr[w_n - 1].ex_off + s_whdr[w_n - 1].n - w_ex_lo, 0));
-        for (int i = threadIdx.x; i < w_ex_n; i += TILE_THREADS) s_wex[i] = anno_ex[w_ex_lo + i];
     }
     if (staged) {
 #pragma unroll
@@ -610,7 +629,6 @@ void k_fill_classify(int64_t n_reads, const int32_t *__restrict__ r_tid, const i
     __syncthreads();
     // ---- phase 3: ranks of the read's sites, then the sweep
     uint32_t info = 0; int ref = -1;
-    const AnnoWindow win{s_whdr, s_wex, w_lo, max(w_n, 0), w_ex_lo, w_ex_n};
     auto phase3 = [&](const int *S, const int *E, uint8_t *F) {
         ReadSites rs{0, 0, 0, 0, -1, -1, -1, -1, 0, 0, 0, 0, true};
         bool read_ok = want_dict;
@@ -627,14 +645,13 @@ void k_fill_classify(int64_t n_reads, const int32_t *__restrict__ r_tid, const i
             }
             read_ok = rs.ok;
         }
-        if (!(p.ablate & 1))
-            info = sweep_annotation(S, E, F, (int)n, tid, r_rev[r] != 0, read_ok, sh.re, sh.e_pen, sh.s_2nd, rs, j0, hdr, anno_ex, win, p, ref);
+        // the sweep is wave-uniform: every lane of the wave takes part
+        info = sweep_annotation(active, S, E, F, (int)n, tid, active && r_rev[r] != 0, read_ok, sh.re, sh.e_pen, sh.s_2nd, rs, j0,
+                                hdr, anno_ex, p, ref);
         info = finish_info(info, (int)n, p);
     };
-    if (active) {
-        if (in_lds) phase3(s_start + local, s_end + local, s_flag + local);
-        else phase3(ex_start + base + local, ex_end + base + local, ex_flag + base + local);
-    }
+    if (in_lds) phase3(s_start + local, s_end + local, s_flag + local);
+    else phase3(ex_start + base + local, ex_end + base + local, ex_flag + base + local);
     // ---- phase 4: coalesced write-out of the tile
     if (in_lds) {
         __syncthreads();
