@@ -147,8 +147,9 @@ typedef struct {
 /* Average device time per kernel of the last l2r_run_timed(), milliseconds. */
 #define L2R_N_STAGES 8
 typedef struct {
-    float stage_ms[L2R_N_STAGES];   /* 0 count_exons 1 scan 2 fill_classify 3 validate_junctions
-                                       4 count_accepted 5 scan 6 gather_accepted 7 reserved */
+    float stage_ms[L2R_N_STAGES];   /* 0 pass_a (exon counts, cursors, tile descriptors) 1 scan 2 classify_fast
+                                       3 classify_generic (redo list) 4 validate_junctions (+ recount)
+                                       5 scan of accepted counts 6 gather_accepted 7 reserved */
     float total_ms;                 /* first launch -> last completion, per iteration */
     int32_t iters;
 } l2r_timing;

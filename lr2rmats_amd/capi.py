@@ -20,7 +20,7 @@ INFO_KNOWN, INFO_KNOWN_SITE, INFO_FULL, INFO_REV, INFO_UNREL, INFO_SJ_CHECKED, I
     1, 2, 4, 8, 16, 32, 64, 128
 EXF_NOVEL_EXON, EXF_NOVEL_DON, EXF_NOVEL_ACC, EXF_NOVEL_JUNC, EXF_UNREL_JUNC = 1, 2, 4, 8, 16
 N_STAGES = 8
-STAGE_NAMES = ["count_exons", "scan_tiles", "fill_classify", "validate_sj", "count_accepted", "scan_accepted",
+STAGE_NAMES = ["pass_a", "scan_tiles", "classify_fast", "classify_generic", "validate_sj", "scan_accepted",
                "gather_accepted", "reserved"]
 
 EXPORTS = [

@@ -58,12 +58,12 @@ struct l2r_ctx {
     DevBuf<TxHdr> hdr;
     DevBuf<int2> anno_ex;
     DevBuf<int64_t> anno_key;
-    DevBuf<int4> sk_st, sk_en;                      // site dictionaries (l2r_kernels.hip.h): START / END entries by rank
-    DevBuf<uint32_t> sd_st, sd_en;                  // bucket directories
+    DevBuf<SiteEnt> sk_st, sk_en;                   // site dictionaries (l2r_kernels.hip.h): START / END entries
+    DevBuf<uint32_t> sd_st, sd_en, sr_st;           // bucket directories, reach-back directory of START
     DevBuf<int32_t> tid_base; int32_t n_tid_dir = 0;
     DevBuf<uint32_t> key_dir; DevBuf<int32_t> kb_base; int32_t n_tid_key = 0;   // cursor directory
     DevBuf<int32_t> j0;
-    int64_t n_compact = 0;
+    int64_t n_compact = 0, n_wide = 0;
     std::vector<int64_t> h_anno_key_raw;    // per transcript (tid,end) key, NOT prefix-maxed (unsorted-input cursor)
     // junctions
     int64_t n_sj = 0;
@@ -83,7 +83,9 @@ struct l2r_ctx {
     bool have_win = false;
     // work + results
     int64_t n_tiles = 0, n_tiles256 = 0;
-    DevBuf<uint32_t> n_ex, tile_base, ex_off, info, tile_acc, tile_acc_ex, totals;   // totals[0]=exons [1]=accepted [2]=accepted exons
+    DevBuf<uint32_t> local, tile_base, ex_off, info, tile_acc, tile_acc_ex, totals;  // totals[0]=exons [1]=accepted [2]=accepted exons [3]=redo count
+    DevBuf<uint32_t> redo;                  // reads the fast kernel hands to the generic one
+    DevBuf<TileDesc> desc;
     DevBuf<int32_t> ex_start, ex_end, ref_tx;
     DevBuf<uint8_t> ex_flag;
     int64_t ex_cap = 0;
@@ -92,6 +94,7 @@ struct l2r_ctx {
     DevBuf<int32_t> acc_start, acc_end;
     DevBuf<uint8_t> acc_flag;
     bool ran = false;
+    DevBuf<unsigned long long> stamps;      // diagnostics, L2R_STAMPS=1
     uint32_t h_totals[3] = {0, 0, 0};
     bool totals_valid = false;
 };
@@ -143,12 +146,12 @@ void l2r_destroy(l2r_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     c->hdr.release(); c->anno_ex.release(); c->anno_key.release();
-    c->sk_st.release(); c->sk_en.release(); c->sd_st.release(); c->sd_en.release(); c->tid_base.release();
+    c->sk_st.release(); c->sk_en.release(); c->sd_st.release(); c->sd_en.release(); c->sr_st.release(); c->tid_base.release();
     c->key_dir.release(); c->kb_base.release(); c->j0.release();
     c->sj_tid.release(); c->sj_don.release(); c->sj_acc.release(); c->sj_uniq.release(); c->sj_multi.release(); c->sj_key.release();
     c->r_tid.release(); c->r_pos.release(); c->r_rev.release(); c->cig_off.release(); c->cig.release();
     c->win_start.release(); c->sj_cursor.release();
-    c->n_ex.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->totals.release();
+    c->local.release(); c->redo.release(); c->desc.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -166,58 +169,80 @@ int l2r_set_params(l2r_ctx *c, const l2r_params *prm)
 }
 
 // ---- site dictionaries -------------------------------------------------------------------------
-struct Site3 {
-    int32_t k0, k1, k2;
-    bool operator<(const Site3 &o) const { return k0 != o.k0 ? k0 < o.k0 : (k1 != o.k1 ? k1 < o.k1 : k2 < o.k2); }
-    bool operator==(const Site3 &o) const { return k0 == o.k0 && k1 == o.k1 && k2 == o.k2; }
+// A site of a kind with the transcript (file order) that has it.  Sorting by (tid, k1, k2, tx) groups the
+// members of every distinct site.
+struct SiteTx {
+    int32_t tid, k1, k2, tx;
+    bool operator<(const SiteTx &o) const
+    {
+        if (tid != o.tid) return tid < o.tid;
+        if (k1 != o.k1) return k1 < o.k1;
+        if (k2 != o.k2) return k2 < o.k2;
+        return tx < o.tx;
+    }
 };
 
-static void sort_unique(std::vector<Site3> &v)
-{
-    std::sort(v.begin(), v.end());
-    v.erase(std::unique(v.begin(), v.end()), v.end());
-}
-
-static inline int rank_of(const std::vector<Site3> &v, const Site3 &k)
-{
-    return (int)(std::lower_bound(v.begin(), v.end(), k) - v.begin());
-}
-
-// entries {k1, k2, single rank, 0} of one dictionary + its bucket directory
-static int upload_dict(l2r_ctx *c, const std::vector<Site3> &keys, const std::vector<Site3> &singles, const std::vector<int32_t> &tid_base,
-                       DevBuf<int4> &kbuf, DevBuf<uint32_t> &dbuf)
+// Entries of one dictionary + its bucket directory.  `pairs`: sorted (tid, k1, k2, tx) rows of the pair kind
+// (exons for START, junctions for END); `singles`: sorted (tid, k1, 0, tx) rows of the single kind (acceptors /
+// donors).  An entry's masks are relative to the smallest member transcript of either kind.
+static int upload_dict(l2r_ctx *c, const std::vector<SiteTx> &pairs, const std::vector<SiteTx> &singles, const std::vector<int32_t> &tid_base,
+                       DevBuf<SiteEnt> &kbuf, DevBuf<uint32_t> &dbuf, DevBuf<uint32_t> *rbuf, int64_t &n_wide)
 {
     const size_t nb = (size_t)tid_base.back();
     std::vector<uint32_t> dir(nb + 1, 0);                 // dir[b] = number of entries whose bucket id is < b
-    std::vector<int4> kk(keys.size());
-    for (size_t i = 0; i < keys.size(); ++i) {
-        const Site3 one{keys[i].k0, keys[i].k1, 0};
-        auto it = std::lower_bound(singles.begin(), singles.end(), one);
-        const int single = (it != singles.end() && *it == one) ? (int)(it - singles.begin()) : -1;
-        kk[i] = make_int4(keys[i].k1, keys[i].k2, single, 0);
-        const size_t b = (size_t)tid_base[(size_t)keys[i].k0] + (size_t)(keys[i].k1 >> SITE_SHIFT);
+    std::vector<SiteEnt> ent;
+    ent.reserve(pairs.size());
+    size_t si = 0;                                        // walks `singles` in step (both sorted by (tid, k1))
+    for (size_t i = 0; i < pairs.size();) {
+        size_t j = i;
+        while (j < pairs.size() && pairs[j].tid == pairs[i].tid && pairs[j].k1 == pairs[i].k1 && pairs[j].k2 == pairs[i].k2) ++j;
+        // members of the single kind with the same (tid, k1)
+        while (si < singles.size() && (singles[si].tid < pairs[i].tid || (singles[si].tid == pairs[i].tid && singles[si].k1 < pairs[i].k1))) ++si;
+        size_t sj = si;
+        while (sj < singles.size() && singles[sj].tid == pairs[i].tid && singles[sj].k1 == pairs[i].k1) ++sj;
+        int32_t lo = pairs[i].tx;
+        if (sj > si) lo = std::min(lo, singles[si].tx);
+        SiteEnt e;
+        memset(&e, 0, sizeof e);
+        e.k1 = pairs[i].k1; e.k2 = pairs[i].k2; e.tx_base = lo;
+        for (size_t k = i; k < j; ++k) {
+            const int off = pairs[k].tx - lo;
+            if (off >= 64) e.flags |= SE_WIDE; else e.pm[off >> 5] |= 1u << (off & 31);
+        }
+        for (size_t k = si; k < sj; ++k) {
+            const int off = singles[k].tx - lo;
+            if (off >= 64) e.flags |= SE_WIDE; else e.sm[off >> 5] |= 1u << (off & 31);
+        }
+        if (e.flags & SE_WIDE) ++n_wide;
+        ent.push_back(e);
+        const size_t b = (size_t)tid_base[(size_t)pairs[i].tid] + (size_t)(pairs[i].k1 >> SITE_SHIFT);
         dir[b + 1]++;
+        i = j;                                             // `si` stays: the next pair may share (tid, k1)
     }
     for (size_t b = 0; b < nb; ++b) dir[b + 1] += dir[b];
-    if (kbuf.ensure(kk.size()) || dbuf.ensure(dir.size())) return -2;
-    if (!kk.empty()) HIP_TRY(hipMemcpyAsync(kbuf.p, kk.data(), kk.size() * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+    if (rbuf) {
+        // reach-back directory (START: k1 = exon start, k2 = exon end): first entry whose exon reaches into the bucket
+        std::vector<uint32_t> rdir(dir);
+        size_t i = 0;
+        for (size_t q = 0; q < pairs.size();) {           // entry i <-> the q-th distinct pair
+            size_t j = q;
+            while (j < pairs.size() && pairs[j].tid == pairs[q].tid && pairs[j].k1 == pairs[q].k1 && pairs[j].k2 == pairs[q].k2) ++j;
+            const size_t t0 = (size_t)tid_base[(size_t)pairs[q].tid], nbt = (size_t)tid_base[(size_t)pairs[q].tid + 1] - t0;
+            const size_t sb = (size_t)(pairs[q].k1 >> SITE_SHIFT);
+            size_t eb = pairs[q].k2 < 0 ? sb : (size_t)(pairs[q].k2 >> SITE_SHIFT);
+            if (eb >= nbt) eb = nbt - 1;
+            for (size_t b = sb + 1; b <= eb; ++b) if (rdir[t0 + b] > (uint32_t)i) rdir[t0 + b] = (uint32_t)i;
+            ++i; q = j;
+        }
+        if (rbuf->ensure(rdir.size())) return -2;
+        HIP_TRY(hipMemcpyAsync(rbuf->p, rdir.data(), rdir.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (kbuf.ensure(ent.size()) || dbuf.ensure(dir.size())) return -2;
+    if (!ent.empty()) HIP_TRY(hipMemcpyAsync(kbuf.p, ent.data(), ent.size() * sizeof(SiteEnt), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(dbuf.p, dir.data(), dir.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
-}
-
-// relative 64-bit mask of the ranks r[0..k) (increasing); false when one does not fit
-static bool rel_mask(const std::vector<int> &r, int32_t &base, uint32_t w[2])
-{
-    w[0] = w[1] = 0; base = 0;
-    if (r.empty()) return true;
-    base = r[0];
-    for (int g : r) {
-        const int off = g - base;
-        if (off < 0 || off >= 64) return false;
-        w[off >> 5] |= 1u << (off & 31);
-    }
-    return true;
 }
 
 int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
@@ -230,9 +255,10 @@ int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
     std::vector<int64_t> key((size_t)T);
     c->h_anno_key_raw.assign((size_t)T, 0);
     int64_t run = INT64_MIN;
-    // pass 1: headers, cursor keys, and the distinct sites of every kind
-    std::vector<Site3> kd, ka, kx, kj;
+    // headers, cursor keys, and the (site, transcript) rows of every kind
+    std::vector<SiteTx> kd, ka, kx, kj;
     kd.reserve((size_t)a->n_exon); ka.reserve((size_t)a->n_exon); kx.reserve((size_t)a->n_exon); kj.reserve((size_t)a->n_exon);
+    int64_t n_compact = 0;
     for (int64_t i = 0; i < T; ++i) {
         const int64_t lo = a->tx_ex_off[i], hi = a->tx_ex_off[i + 1];
         if (lo < 0 || hi < lo || hi > a->n_exon) return fail(-1, "[l2r_set_annotation] bad exon offsets at transcript %lld", (long long)i);
@@ -248,13 +274,14 @@ int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
             if (a->ex_start[k] > a->ex_end[k]) sane = false;
         }
         int flags = mono ? TX_MONO : 0;
-        // dictionary path only for transcripts the equality => in-span argument holds for
-        if (mono && sane && t.tid >= 0 && t.n >= 2 && t.start == t.s0 && t.end == t.el) flags |= TX_COMPACT;   // masks checked in pass 2
+        // the "equal value => inside both spans" argument of the fast kernel holds for these
+        if (mono && sane && t.tid >= 0 && t.n >= 2 && t.start == t.s0 && t.end == t.el) { flags |= TX_COMPACT; ++n_compact; }
         t.flags = flags;
-        if (t.tid >= 0) for (int64_t k = lo; k < hi; ++k) {
-            kx.push_back(Site3{t.tid, a->ex_start[k], a->ex_end[k]});
-            if (k + 1 < hi) { kd.push_back(Site3{t.tid, a->ex_end[k], 0}); kj.push_back(Site3{t.tid, a->ex_end[k], a->ex_start[k + 1]}); }
-            if (k > lo) ka.push_back(Site3{t.tid, a->ex_start[k], 0});
+        if (t.tid >= 0 && t.n >= 2) for (int64_t k = lo; k < hi; ++k) {
+            if (a->ex_start[k] < 0 || a->ex_end[k] < 0) return fail(-1, "[l2r_set_annotation] negative exon coordinate");
+            kx.push_back(SiteTx{t.tid, a->ex_start[k], a->ex_end[k], (int32_t)i});
+            if (k + 1 < hi) { kd.push_back(SiteTx{t.tid, a->ex_end[k], 0, (int32_t)i}); kj.push_back(SiteTx{t.tid, a->ex_end[k], a->ex_start[k + 1], (int32_t)i}); }
+            if (k > lo) ka.push_back(SiteTx{t.tid, a->ex_start[k], 0, (int32_t)i});
         }
         // "annotation before read": tid smaller, or same tid and end <= read start (update_gtf.c:786-790).
         // The sequential cursor equals the longest prefix that is entirely before the read = first index
@@ -264,41 +291,21 @@ int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
         if (k > run) run = k;
         key[(size_t)i] = run;
     }
-    sort_unique(kd); sort_unique(ka); sort_unique(kx); sort_unique(kj);
-    // pass 2: per-transcript rank masks
-    int64_t n_compact = 0;
-    std::vector<int> rd, ra, rx, rj;
-    for (int64_t i = 0; i < T; ++i) {
-        TxHdr &t = h[(size_t)i];
-        if (!(t.flags & TX_COMPACT)) continue;
-        const int64_t lo = a->tx_ex_off[i], hi = a->tx_ex_off[i + 1];
-        rd.clear(); ra.clear(); rx.clear(); rj.clear();
-        for (int64_t k = lo; k < hi; ++k) {
-            rx.push_back(rank_of(kx, Site3{t.tid, a->ex_start[k], a->ex_end[k]}));
-            if (k + 1 < hi) { rd.push_back(rank_of(kd, Site3{t.tid, a->ex_end[k], 0})); rj.push_back(rank_of(kj, Site3{t.tid, a->ex_end[k], a->ex_start[k + 1]})); }
-            if (k > lo) ra.push_back(rank_of(ka, Site3{t.tid, a->ex_start[k], 0}));
-        }
-        const bool f1 = rel_mask(rd, t.gb_d, t.md), f2 = rel_mask(ra, t.gb_a, t.ma), f3 = rel_mask(rx, t.gb_x, t.mx), f4 = rel_mask(rj, t.gb_j, t.mj);
-        const bool fit = f1 && f2 && f3 && f4;
-        if (!fit) { t.flags &= ~TX_COMPACT; memset(t.md, 0, 8); memset(t.ma, 0, 8); memset(t.mx, 0, 8); memset(t.mj, 0, 8); }
-        else ++n_compact;
-    }
+    std::sort(kd.begin(), kd.end()); std::sort(ka.begin(), ka.end()); std::sort(kx.begin(), kx.end()); std::sort(kj.begin(), kj.end());
     c->n_compact = n_compact;
     {   // one bucket grid for the four kinds: per tid, enough 512-bp buckets for its largest site coordinate
-        int32_t n_tid = 0; 
-        for (const auto *v : {&kd, &ka, &kx, &kj}) if (!v->empty()) n_tid = std::max(n_tid, v->back().k0 + 1);
+        int32_t n_tid = 0;
+        for (const auto *v : {&kd, &ka, &kx, &kj}) if (!v->empty()) n_tid = std::max(n_tid, v->back().tid + 1);
         std::vector<int64_t> mx((size_t)n_tid, -1);
-        for (const auto *v : {&kd, &ka, &kx, &kj}) for (const Site3 &k : *v) {
-            if (k.k1 < 0) return fail(-1, "[l2r_set_annotation] negative exon coordinate");
-            mx[(size_t)k.k0] = std::max<int64_t>(mx[(size_t)k.k0], k.k1);
-        }
+        for (const auto *v : {&kd, &ka, &kx, &kj}) for (const SiteTx &k : *v) mx[(size_t)k.tid] = std::max<int64_t>(mx[(size_t)k.tid], k.k1);
         std::vector<int32_t> tb((size_t)n_tid + 1, 0);
         int64_t acc = 0;
         for (int32_t t = 0; t < n_tid; ++t) { tb[(size_t)t] = (int32_t)acc; acc += mx[(size_t)t] < 0 ? 0 : (mx[(size_t)t] >> SITE_SHIFT) + 1; }
         if (acc > 0x7ffffff0LL) return fail(-1, "[l2r_set_annotation] site directory too large");
         tb[(size_t)n_tid] = (int32_t)acc;
-        // START: exons + acceptor rank of their start; END: junctions + donor rank of their end
-        if (upload_dict(c, kx, ka, tb, c->sk_st, c->sd_st) || upload_dict(c, kj, kd, tb, c->sk_en, c->sd_en)) return -2;
+        // START: exons + the transcripts in which their start is an acceptor; END: junctions + donors
+        c->n_wide = 0;
+        if (upload_dict(c, kx, ka, tb, c->sk_st, c->sd_st, &c->sr_st, c->n_wide) || upload_dict(c, kj, kd, tb, c->sk_en, c->sd_en, nullptr, c->n_wide)) return -2;
         if (c->tid_base.ensure(tb.size())) return -2;
         HIP_TRY(hipMemcpyAsync(c->tid_base.p, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -437,13 +444,19 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     }
     // work buffers.  n_exon(read) <= ops(read) + 1, so n_cigar + n_reads bounds the exon arrays.
     const size_t exb = (size_t)r->n_cigar + (size_t)N;
-    if (c->j0.ensure((size_t)N) || c->n_ex.ensure((size_t)N) || c->ex_off.ensure((size_t)N) || c->info.ensure((size_t)N) || c->ref_tx.ensure((size_t)N) ||
-        c->tile_base.ensure((size_t)c->n_tiles) || c->tile_acc.ensure((size_t)c->n_tiles256) || c->tile_acc_ex.ensure((size_t)c->n_tiles256) ||
+    if (c->j0.ensure((size_t)N) || c->local.ensure((size_t)N + 1) || c->ex_off.ensure((size_t)N) || c->info.ensure((size_t)N) || c->ref_tx.ensure((size_t)N) ||
+        c->redo.ensure((size_t)N) || c->desc.ensure((size_t)c->n_tiles) ||
+        c->tile_base.ensure((size_t)c->n_tiles + 1) || c->tile_acc.ensure((size_t)c->n_tiles + 1) || c->tile_acc_ex.ensure((size_t)c->n_tiles + 1) ||
         c->totals.ensure(4) || c->ex_start.ensure(exb) || c->ex_end.ensure(exb) || c->ex_flag.ensure(exb) ||
         c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
         c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb)) return -2;
     c->ex_cap = (int64_t)exb;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (getenv("L2R_STAMPS") && !c->stamps.p) {
+        if (c->stamps.ensure(1024 * 8)) return -2;
+        HIP_TRY(hipMemsetAsync(c->stamps.p, 0, 1024 * 8 * 8, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     c->n_reads = N; c->n_cigar = r->n_cigar; c->first_read = r->first_read_index;
     c->ran = false; c->totals_valid = false;
     return 0;
@@ -491,7 +504,9 @@ static int prepare_unsorted_sj_cursor(l2r_ctx *c)
     return 0;
 }
 
-enum { ST_COUNT = 0, ST_SCAN1, ST_FILL, ST_SJ, ST_CNTACC, ST_SCAN2, ST_GATHER, ST_N };
+enum { ST_PASS_A = 0, ST_SCAN1, ST_FAST, ST_GENERIC, ST_SJ, ST_SCAN2, ST_GATHER, ST_N };
+
+#define launch_fast_level(L, fa, grid, s) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L>), dim3(grid), dim3(TILE_THREADS), 0, s, fa)
 
 static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
 {
@@ -499,38 +514,92 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     const int64_t N = c->n_reads;
     hipStream_t s = c->stream;
     const unsigned gt = (unsigned)(c->n_tiles ? c->n_tiles : 1), g256 = (unsigned)(c->n_tiles256 ? c->n_tiles256 : 1);
+    const int32_t *j0 = c->sorted ? (const int32_t *)c->j0.p : (const int32_t *)c->win_start.p;
 #define MARK(i) do { if (ev) HIP_TRY(hipEventRecord(ev[i], s)); } while (0)
-    MARK(ST_COUNT);
+    MARK(ST_PASS_A);
     const CursorDir cd{c->anno_key.p, c->key_dir.p, c->kb_base.p, c->n_tid_key, (int32_t)c->n_tx};
+    const SiteTabs tabs{{c->sk_st.p, c->sd_st.p, c->sr_st.p}, {c->sk_en.p, c->sd_en.p, nullptr}, c->tid_base.p, c->n_tid_dir};
     // sorted input: the cursor value of every read is computed on the device; unsorted input: it was replayed on the host
-    hipLaunchKernelGGL(k_count_exons, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, p, c->n_ex.p,
-                       (c->sorted ? c->j0.p : (int32_t *)nullptr), c->tile_base.p);
+    hipLaunchKernelGGL(k_pass_a, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, tabs, p,
+                       (c->sorted ? (const int32_t *)nullptr : (const int32_t *)c->win_start.p), c->j0.p, c->local.p, c->tile_base.p, c->desc.p,
+                       c->totals.p + 3);
     MARK(ST_SCAN1);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, c->tile_base.p, c->n_tiles, c->totals.p + 0);
-    MARK(ST_FILL);
-    hipLaunchKernelGGL(k_fill_classify, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->r_rev.p, c->cig_off.p, c->cig.p,
-                       c->n_ex.p, c->tile_base.p, (c->sorted ? (const int32_t *)c->j0.p : (const int32_t *)c->win_start.p), c->hdr.p, c->anno_ex.p,
-                       SiteTabs{{c->sk_st.p, c->sd_st.p}, {c->sk_en.p, c->sd_en.p}, c->tid_base.p, c->n_tid_dir}, p,
-                       c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->info.p, c->ref_tx.p);
+    {
+        ScanJobs jobs; jobs.job[0] = ScanJob{c->tile_base.p, c->n_tiles, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, jobs);
+    }
+    MARK(ST_FAST);
+    {
+        FastArgs fa;
+        fa.n_reads = N; fa.r_tid = c->r_tid.p; fa.r_pos = c->r_pos.p; fa.r_rev = c->r_rev.p; fa.cig_off = c->cig_off.p; fa.cig = c->cig.p;
+        fa.local = c->local.p; fa.tile_base = c->tile_base.p; fa.j0 = j0; fa.desc = c->desc.p;
+        fa.hdr = c->hdr.p; fa.st = tabs.st; fa.en = tabs.en;
+        fa.ex_off = c->ex_off.p; fa.ex_start = c->ex_start.p; fa.ex_end = c->ex_end.p; fa.ex_flag = c->ex_flag.p; fa.info = c->info.p; fa.ref_tx = c->ref_tx.p;
+        fa.tile_acc = c->tile_acc.p; fa.tile_acc_ex = c->tile_acc_ex.p; fa.redo_count = c->totals.p + 3; fa.redo = c->redo.p;
+        fa.stamps = c->stamps.p; fa.p = p;
+        switch (p.full_level) {
+        case 1: launch_fast_level(1, fa, gt, s); break;
+        case 2: launch_fast_level(2, fa, gt, s); break;
+        case 3: launch_fast_level(3, fa, gt, s); break;
+        case 4: launch_fast_level(4, fa, gt, s); break;
+        case 5: launch_fast_level(5, fa, gt, s); break;
+        default: launch_fast_level(0, fa, gt, s); break;      // src/update_gtf.c:629-696: no evidence is gathered, full = lfull && rfull = 0
+        }
+    }
+    MARK(ST_GENERIC);
+    {
+        const unsigned gg = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, 2048);
+        hipLaunchKernelGGL(k_classify_generic, dim3(gg), dim3(TILE_THREADS), 0, s, c->totals.p + 3, c->redo.p, c->r_tid.p, c->r_rev.p, j0,
+                           c->hdr.p, c->anno_ex.p, p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->info.p, c->ref_tx.p,
+                           c->tile_acc.p, c->tile_acc_ex.p);
+    }
     MARK(ST_SJ);
     if (c->n_sj > 0) {
         if (!c->sorted) { int rc = prepare_unsorted_sj_cursor(c); if (rc) return rc; }
         hipLaunchKernelGGL(k_validate_sj, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p,
                            c->sj_key.p, (c->sorted ? (const int32_t *)nullptr : c->sj_cursor.p), c->sj_tid.p, c->sj_don.p, c->sj_acc.p,
                            c->sj_uniq.p, c->sj_multi.p, p, c->info.p);
+        // acceptance is decided by the junction check: recount per tile
+        hipLaunchKernelGGL(k_count_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->reads_per_tile, c->info.p, c->tile_acc.p, c->tile_acc_ex.p);
     }
-    MARK(ST_CNTACC);
-    hipLaunchKernelGGL(k_count_accepted, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->info.p, c->tile_acc.p, c->tile_acc_ex.p);
     MARK(ST_SCAN2);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, c->tile_acc.p, c->n_tiles256, c->totals.p + 1);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, c->tile_acc_ex.p, c->n_tiles256, c->totals.p + 2);
+    {
+        ScanJobs jobs; jobs.job[0] = ScanJob{c->tile_acc.p, c->n_tiles, c->totals.p + 1}; jobs.job[1] = ScanJob{c->tile_acc_ex.p, c->n_tiles, c->totals.p + 2};
+        hipLaunchKernelGGL(k_scan_u32, dim3(2), dim3(1024), 0, s, jobs);
+    }
     MARK(ST_GATHER);
-    hipLaunchKernelGGL(k_gather_accepted, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->first_read, c->info.p, c->ref_tx.p, c->ex_off.p,
+    hipLaunchKernelGGL(k_gather_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->reads_per_tile, c->first_read, c->info.p, c->ref_tx.p, c->ex_off.p,
                        c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->tile_acc.p, c->tile_acc_ex.p,
                        c->acc_rec.p, c->acc_ex_off.p, c->acc_start.p, c->acc_end.p, c->acc_flag.p);
     MARK(ST_N);
 #undef MARK
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* diagnostics: L2R_STAMPS=1 makes k_classify_fast accumulate per-phase cycles; this prints and clears them */
+int l2r_debug_stamps(l2r_ctx *c, unsigned long long *out, int n)
+{
+    if (!c || !out) return fail(-1, "[l2r_debug_stamps] null argument");
+    if (!c->stamps.p) { for (int i = 0; i < n; ++i) out[i] = 0; return 0; }
+    std::vector<unsigned long long> h(1024 * 8);
+    HIP_TRY(hipMemcpyAsync(h.data(), c->stamps.p, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->stamps.p, 0, h.size() * 8, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) out[i] = 0;
+    for (size_t k = 0; k < h.size(); ++k) if ((int)(k & 7) < n) out[k & 7] += h[k];
+    return 0;
+}
+
+/* diagnostics: [0] reads the last run sent to the generic kernel, [1] dictionary entries flagged wide,
+   [2] compact transcripts, [3] tiles */
+int l2r_debug_counters(l2r_ctx *c, long long *out, int n)
+{
+    if (!c || !out || n < 4) return fail(-1, "[l2r_debug_counters] bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t redo = 0;
+    if (c->totals.p) { HIP_TRY(hipMemcpyAsync(&redo, c->totals.p + 3, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+    out[0] = redo; out[1] = c->n_wide; out[2] = c->n_compact; out[3] = c->n_tiles;
     return 0;
 }
 
@@ -684,4 +753,5 @@ int l2r_classify(l2r_ctx *c, const l2r_reads *reads, l2r_result *res)
 }  // extern "C"
 
 static_assert(sizeof(AccRec) == sizeof(l2r_accepted_read), "accepted record layout");
-static_assert(sizeof(TxHdr) == 96, "TxHdr must be six int4");
+static_assert(sizeof(TxHdr) == 48, "TxHdr must be three int4");
+static_assert(sizeof(SiteEnt) == 32 && sizeof(TileDesc) == 48, "dictionary entry / tile descriptor layout");

@@ -1,18 +1,24 @@
 // l2r_kernels.hip.h -- gfx950 device code of the read-vs-annotation path.
 //
-// Work decomposition (all int32 interval arithmetic, no contraction -> no MFMA):
-//   * a TILE is up to 256 consecutive alignment records handled by one 256-thread
-//     workgroup (4 wave64), one thread per record;
-//   * k_count_exons   : CIGAR -> exon count per record + per-tile sums
-//   * k_scan_tiles    : exclusive scan of the per-tile sums (one workgroup)
-//   * k_fill_classify : CIGAR -> exons into an LDS tile, annotation sweep with the
-//                       reference's early-exit rules, flag bytes, coalesced write-out
-//   * k_validate_sj   : short-read junction support for accepted candidates
-//   * k_count_accepted / k_gather_accepted : wave-ballot + prefix-sum compaction of
-//                       the accepted-novel records in read order
+// All int32 interval arithmetic, no contraction -> no MFMA.  A TILE is up to 256 consecutive alignment
+// records handled by one 256-thread workgroup (4 wave64), one thread per record.
 //
-// Semantics follow the reference line by line where bytes of the graded outputs
-// depend on it; each device function cites the lines it restates.
+//   k_pass_a           CIGAR -> exon count per record, cursor value per record, tile sums, and a
+//                      TILE DESCRIPTOR: the slice of the site dictionaries and the window of annotation
+//                      transcripts the tile is going to need, so that the classification kernel can issue
+//                      every one of its loads when it starts
+//   k_scan_u32         exclusive scan of per-tile sums (one workgroup per array)
+//   k_classify_fast    CIGAR -> exons into an LDS tile; dictionary slices and transcript window staged in LDS,
+//                      re-based into the tile's own transcript frame; per read: visit mask over the window,
+//                      one START and one END dictionary probe per exon, known / known-site / flags from
+//                      32-bit membership masks; coalesced write-out; per-tile accepted counts.
+//                      Anything it cannot decide exactly goes to a redo list.
+//   k_classify_generic thread per listed read, literal loops of the reference (any -d, any annotation)
+//   k_validate_sj      short-read junction support for accepted candidates
+//   k_count_accepted / k_gather_accepted   compaction of the accepted-novel records in read order
+//
+// Semantics follow the reference line by line where bytes of the graded outputs depend on it; each device
+// function cites the lines it restates.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,35 +27,39 @@ namespace l2r {
 
 constexpr int TILE_THREADS = 256;
 constexpr int WAVE = 64;
-constexpr int LDS_EXON_CAP = 3072;      // exons of one tile staged in LDS (9 B each)
+constexpr int LDS_EXON_CAP = 3072;      // exons of one tile staged in LDS (12 B each)
+constexpr int DIR_CAP = 384;            // 512-bp buckets staged per tile (span up to ~196 kb)
+constexpr int KEY_CAP = 256;            // dictionary entries staged per dictionary and tile
+constexpr int WIN_TX = 32;              // annotation transcripts in a tile's window = bits of a membership mask
+constexpr int SITE_SHIFT = 9;
 
-// One annotation transcript (file order), 96 B = six 16-byte loads; the sweep reads h0 for every
-// transcript it passes, h1..h2 for the ones that overlap, h3..h5 only on the dictionary path.
+// One annotation transcript (file order), 48 B = three 16-byte loads.
 struct TxHdr {
     int32_t tid, start, end, ex_off;          // h0
-    int32_t n, rev, flags, pad;               // h1  flags: TX_MONO | TX_COMPACT
+    int32_t n, rev, flags, pad;               // h1
     int32_t s0, e0, sl, el;                   // h2  first and last exon
-    int32_t gb_d, gb_a, gb_x, gb_j;           // h3  rank of the transcript's first donor / acceptor / exon / junction
-    uint32_t md[2], ma[2];                    // h4  site masks relative to those ranks (bit k = rank gb+k is in the transcript)
-    uint32_t mx[2], mj[2];                    // h5
 };
 constexpr int TX_MONO = 1;      // exon starts and ends strictly increasing
-constexpr int TX_COMPACT = 2;   // TX_MONO, start <= end for every exon, header span == exon span, all four masks fit 64 bits
+constexpr int TX_COMPACT = 2;   // TX_MONO, start <= end for every exon, header span == exon span, tid >= 0, n >= 2
 
-// Site dictionaries (built once per annotation on the host).  Every distinct annotation site of a
-// kind (donor, acceptor, exon, junction) has a RANK = its index among the sorted distinct sites of
-// that kind on all chromosomes.  Two probe structures serve the four kinds:
-//   START dictionary: the distinct exons sorted by (tid, start, end); entry {start, end, acceptor rank of
-//                     `start` or -1, 0}; the entry's index is the exon rank;
-//   END dictionary:   the distinct junctions sorted by (tid, end, next start); entry {end, next start,
-//                     donor rank of `end`, 0}; the entry's index is the junction rank;
-// each with a directory over 512-bp coordinate buckets: dir[tid_base[tid] + (k1 >> 9)] = first entry of the
-// bucket.  Neighbouring coordinates hit neighbouring directory words and entries, so the reads of a tile
-// (one locus) keep re-using a handful of lines, which the tile stages in LDS.
-constexpr int SITE_SHIFT = 9;
+// Site dictionaries (built once per annotation on the host, multi-exon transcripts with tid >= 0 only).
+//   START dictionary: the distinct exons sorted by (tid, start, end).  pm = transcripts that contain the exon,
+//                     sm = transcripts in which `start` begins a non-first exon (an acceptor);
+//   END dictionary:   the distinct junctions sorted by (tid, end, next start).  pm = transcripts that contain
+//                     the junction, sm = transcripts in which `end` closes a non-last exon (a donor).
+// Masks are 64 bits relative to tx_base (bit b = transcript tx_base + b, file order); SE_WIDE when a member does
+// not fit.  Each dictionary has a directory over 512-bp coordinate buckets: dir[tid_base[tid] + (k1 >> 9)] = first
+// entry of the bucket.  The reads of a tile (one locus) need a handful of buckets and entries; the classification
+// kernel stages them in LDS with the masks re-based to the tile's transcript window.
+struct SiteEnt {
+    int32_t k1, k2, tx_base, flags;
+    uint32_t pm[2], sm[2];
+};
+constexpr int SE_WIDE = 1;
 struct SiteDict {
-    const int4 *ent;           // entries by rank
+    const SiteEnt *ent;
     const uint32_t *dir;       // bucket -> first entry; one extra word closes the last bucket
+    const uint32_t *rdir;      // START only: bucket -> first entry whose exon reaches into the bucket (<= dir[bucket])
 };
 struct SiteTabs {
     SiteDict st, en;           // START and END dictionaries
@@ -57,9 +67,8 @@ struct SiteTabs {
     int32_t n_tid;
 };
 
-// Cursor directory: the prefix-max keys of the annotation with the same kind of
-// 512-bp bucket directory, so the cursor value of a read costs two directory words and a search inside
-// one bucket instead of a 17-step binary search.  dir[kb_base[tid] + c] = first j with key_j >= (tid, c << 9).
+// Cursor directory: the prefix-max keys of the annotation with the same kind of 512-bp bucket
+// directory: dir[kb_base[tid] + c] = first j with key_j >= (tid, c << 9).
 struct CursorDir {
     const int64_t *key;        // [n_tx] non-decreasing
     const uint32_t *dir;
@@ -67,12 +76,25 @@ struct CursorDir {
     int32_t n_tid, n_tx;
 };
 
+// What k_pass_a leaves for every tile.
+struct TileDesc {
+    int32_t j_lo;              // smallest cursor value of the tile's reads = first transcript of the window
+    int32_t tid;               // the tile's chromosome = the one of its first read (other reads: generic kernel)
+    int32_t b_off;             // bucket of x in the staged slice = (x >> 9) + b_off
+    int32_t nb;                // buckets the annotation has on this chromosome
+    int32_t b0, nbk;           // first staged bucket (absolute), number of staged buckets
+    uint32_t st_r0, st_nk;     // START entries [st_r0, st_r0 + st_nk)
+    uint32_t en_r0, en_nk;     // END entries
+    uint32_t flags, pad;
+};
+constexpr uint32_t TD_FAST = 1;    // exons fit the LDS tile, dictionary slices fit DIR_CAP / KEY_CAP
+
 struct DevParams {
     int32_t min_exon, min_intron, max_delet, ss_dis;
     int32_t full_level, use_multi, min_sj_cnt, split_trans;
     float   frac;
     int32_t n_tx, n_sj, reads_per_tile;
-    int32_t ablate;          // diagnostics (env L2R_ABLATE): 1 no sweep, 2 no site match, 4 no full-length test, 16 no dictionary path
+    int32_t ablate;          // diagnostics (env L2R_ABLATE): 1 = every read through the generic kernel
 };
 
 // info / exon-flag bit layout: keep in sync with include/lr2rmats_hip.h
@@ -85,23 +107,49 @@ __device__ __forceinline__ int64_t pack_key(int32_t tid, int32_t x)
     return ((int64_t)(tid + 1) << 32) | (uint32_t)x;
 }
 
-// ------------------------------------------------------------------ block primitives
+// ------------------------------------------------------------------ wave / block primitives
 
-// Exclusive scan over the 256 threads of a workgroup; returns the exclusive prefix,
-// `total` receives the workgroup sum.  Wave-level shuffles + 4 wave totals in LDS.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, WAVE);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_min(int v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, WAVE));
+    return v;
+}
+
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, WAVE));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+    return v;
+}
+
+// Exclusive scan over the 256 threads of a workgroup; returns the exclusive prefix, `total` = workgroup sum.
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave /*[4]*/, uint32_t &total)
 {
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        uint32_t t = __shfl_up(inc, d, WAVE);
-        if (lane >= d) inc += t;
-    }
+    const uint32_t inc = wave_inclusive_scan(v);
     if (lane == WAVE - 1) s_wave[w] = inc;
     __syncthreads();
-    uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
-    uint32_t base = (w > 0 ? w0 : 0) + (w > 1 ? w1 : 0) + (w > 2 ? w2 : 0);
+    const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
+    const uint32_t base = (w > 0 ? w0 : 0) + (w > 1 ? w1 : 0) + (w > 2 ? w2 : 0);
     total = w0 + w1 + w2 + w3;
     __syncthreads();
     return base + inc - v;
@@ -124,7 +172,7 @@ __device__ __forceinline__ int walk_cigar(const uint32_t *__restrict__ cig, int 
             if (n == 0 || end - start + 1 >= p.min_exon) { emit(n, start, end); ++n; }
             start = end + len + 1;
         }
-        if (op == 0u || op == 2u || op == 3u || op == 7u || op == 8u) end += len;
+        if ((0x18du >> op) & 1u) end += len;            // ops 0 2 3 7 8
     };
     int k = 0;
     for (; k + 4 <= n_cig; k += 4) {
@@ -153,56 +201,112 @@ __device__ __forceinline__ int cursor_value(const CursorDir &cd, int32_t tid, in
     return lo;
 }
 
+// Pass A.  j0_in != null: the cursor values were replayed on the host (unsorted input) and are only read here.
 __global__ __launch_bounds__(TILE_THREADS)
-void k_count_exons(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t *__restrict__ r_pos,
-                   const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ cig, CursorDir cd, DevParams p,
-                   uint32_t *__restrict__ n_ex, int32_t *__restrict__ j0_out, uint32_t *__restrict__ tile_sum)
+void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t *__restrict__ r_pos,
+              const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ cig, CursorDir cd, SiteTabs tabs, DevParams p,
+              const int32_t *__restrict__ j0_in, int32_t *__restrict__ j0_out, uint32_t *__restrict__ local_out,
+              uint32_t *__restrict__ tile_sum, TileDesc *__restrict__ desc, uint32_t *__restrict__ redo_count)
 {
     __shared__ uint32_t s_wave[4];
+    __shared__ int s_red[4][3];
+    __shared__ int s_tid0;
     const int64_t r = (int64_t)blockIdx.x * p.reads_per_tile + threadIdx.x;
+    const bool active = (int)threadIdx.x < p.reads_per_tile && r < n_reads;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *redo_count = 0u;         // the classification kernels run after this one
     uint32_t n = 0;
-    if (threadIdx.x < p.reads_per_tile && r < n_reads) {
+    int j0 = INT32_MAX, tid = 0, pos = 0, el = 0;
+    if (active) {
         const int64_t a = cig_off[r], b = cig_off[r + 1];
-        const int32_t pos = r_pos[r];
-        if (j0_out) j0_out[r] = cursor_value(cd, r_tid[r], pos + 1);       // first exon always starts at pos + 1
-        n = (uint32_t)walk_cigar(cig + a, (int)(b - a), pos, p, [](int, int, int) {});
-        n_ex[r] = n;
+        pos = r_pos[r];
+        tid = r_tid[r];
+        if (threadIdx.x == 0) s_tid0 = tid;
+        if (j0_in) j0 = j0_in[r];
+        else { j0 = cursor_value(cd, tid, pos + 1); j0_out[r] = j0; }       // first exon always starts at pos + 1
+        el = pos;
+        n = (uint32_t)walk_cigar(cig + a, (int)(b - a), pos, p, [&](int, int, int e) { el = e; });
     }
     uint32_t total;
-    block_exclusive_scan(n, s_wave, total);
-    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+    const uint32_t local = block_exclusive_scan(n, s_wave, total);
+    if (active) local_out[r] = local;
+    // the tile's chromosome is the one of its first read; reads on another one go to the generic kernel
+    const int tid0 = s_tid0;
+    int tb = 0, nb = 0;
+    if (tid0 < tabs.n_tid) { tb = tabs.tid_base[tid0]; nb = tabs.tid_base[tid0 + 1] - tb; }
+    int blo = INT32_MAX, bhi = -1;
+    const bool mine = active && tid == tid0;
+    if (mine && nb > 0) {             // bucket span of the read, clamped to the annotation's grid
+        blo = min(max(pos + 1, 0) >> SITE_SHIFT, nb - 1);
+        bhi = min(max(el, 0) >> SITE_SHIFT, nb - 1);
+    }
+    {   // tile reductions: min cursor, bucket span
+        const int a0 = wave_min(mine ? j0 : INT32_MAX), a3 = wave_min(blo), a4 = wave_max(bhi);
+        if ((threadIdx.x & (WAVE - 1)) == 0) {
+            int *q = s_red[threadIdx.x >> 6];
+            q[0] = a0; q[1] = a3; q[2] = a4;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tile_sum[blockIdx.x] = total;
+        int jl = INT32_MAX, lo = INT32_MAX, hi = -1;
+        for (int w = 0; w < 4; ++w) { jl = min(jl, s_red[w][0]); lo = min(lo, s_red[w][1]); hi = max(hi, s_red[w][2]); }
+        TileDesc d;
+        d.j_lo = jl == INT32_MAX ? 0 : jl; d.tid = tid0; d.b_off = 0; d.nb = 0; d.b0 = 0; d.nbk = 0;
+        d.st_r0 = d.st_nk = d.en_r0 = d.en_nk = 0u; d.pad = 0u;
+        bool fast = total <= (uint32_t)LDS_EXON_CAP && p.ss_dis == 0 && !(p.ablate & 1);
+        if (fast && hi >= 0) {
+            const int nbk = hi - lo + 1;
+            if (nbk > DIR_CAP) fast = false;
+            else {
+                // START entries from the first one that reaches into the first bucket (full-length evidence scans them)
+                d.b_off = -lo; d.nb = nb; d.b0 = tb + lo; d.nbk = nbk;
+                d.st_r0 = tabs.st.rdir[tb + lo]; d.st_nk = tabs.st.dir[tb + hi + 1] - d.st_r0;
+                d.en_r0 = tabs.en.dir[tb + lo]; d.en_nk = tabs.en.dir[tb + hi + 1] - d.en_r0;
+                if (d.st_nk > (uint32_t)KEY_CAP || d.en_nk > (uint32_t)KEY_CAP) fast = false;
+            }
+        }
+        d.flags = fast ? TD_FAST : 0u;
+        desc[blockIdx.x] = d;
+    }
 }
 
-// In-place exclusive scan of `n` uint32 by ONE workgroup of 1024 threads; *total = sum.
+// In-place exclusive scan of v[0..n) by ONE workgroup of 1024 threads, 4 elements per thread and round;
+// v[n] receives the sum (the array has n + 1 words) and so does *total.  blockIdx.x selects the array.
+struct ScanJob { uint32_t *v; int64_t n; uint32_t *total; };
+struct ScanJobs { ScanJob job[2]; };
+
 __global__ __launch_bounds__(1024)
-void k_scan_tiles(uint32_t *__restrict__ v, int64_t n, uint32_t *__restrict__ total)
+void k_scan_u32(ScanJobs jobs)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
+    uint32_t *__restrict__ v = jobs.job[blockIdx.x].v;
+    const int64_t n = jobs.job[blockIdx.x].n;
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    for (int64_t base = 0; base < n; base += 1024) {
-        const int64_t i = base + threadIdx.x;
-        const uint32_t x = i < n ? v[i] : 0u;
-        uint32_t inc = x;
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            uint32_t t = __shfl_up(inc, d, WAVE);
-            if (lane >= d) inc += t;
-        }
+    for (int64_t base = 0; base < n; base += 4096) {
+        const int64_t i = base + 4 * (int64_t)threadIdx.x;
+        uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+        if (i + 3 < n) { const uint4 q = *reinterpret_cast<const uint4 *>(v + i); x0 = q.x; x1 = q.y; x2 = q.z; x3 = q.w; }
+        else { if (i < n) x0 = v[i]; if (i + 1 < n) x1 = v[i + 1]; if (i + 2 < n) x2 = v[i + 2]; }
+        const uint32_t mine = x0 + x1 + x2 + x3;
+        const uint32_t inc = wave_inclusive_scan(mine);
         if (lane == WAVE - 1) s_wave[w] = inc;
         __syncthreads();
         uint32_t wbase = 0, tot = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) { const uint32_t t = s_wave[k]; if (k < w) wbase += t; tot += t; }
         const uint32_t carry = s_carry;
-        if (i < n) v[i] = carry + wbase + inc - x;
+        const uint32_t e0 = carry + wbase + inc - mine, e1 = e0 + x0, e2 = e1 + x1, e3 = e2 + x2;
+        if (i + 3 < n) *reinterpret_cast<uint4 *>(v + i) = make_uint4(e0, e1, e2, e3);
+        else { if (i < n) v[i] = e0; if (i + 1 < n) v[i + 1] = e1; if (i + 2 < n) v[i + 2] = e2; }
         __syncthreads();
         if (threadIdx.x == 0) s_carry = carry + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = s_carry;
+    if (threadIdx.x == 0) { v[n] = s_carry; *jobs.job[blockIdx.x].total = s_carry; }
 }
 
 // ------------------------------------------------------------------ comparison rules
@@ -222,15 +326,10 @@ __device__ __forceinline__ float overlap_frac(int s1, int e1, int s2, int e2)
     return (float)((double)ov / ((double)ml + 0.0));
 }
 
-struct ReadState {
-    bool lfull, rfull, lnoth, rnoth, known, ksite;
-};
-
-// src/update_gtf.c:629-681 check_full for one overlapping annotation transcript.  The read's and the
-// transcript's terminal exons come in registers / from the header; only the "overlaps some other exon"
-// scans of levels 3 and 4 touch the transcript's exon array.
+struct ReadState { bool lfull, rfull, lnoth, rnoth, known, ksite; };
 struct ReadEnds { int s0, e0, sl, el; };     // first and last exon of the read
 
+// src/update_gtf.c:629-681 check_full for one overlapping annotation transcript.
 __device__ __forceinline__ void full_evidence(ReadState &st, int level, const ReadEnds &r, const TxHdr &a, const int2 *__restrict__ ax)
 {
     if (st.lfull && st.rfull) return;
@@ -254,10 +353,18 @@ __device__ __forceinline__ void full_evidence(ReadState &st, int level, const Re
     }
 }
 
-// src/update_gtf.c:717-779 check_splice_site, all four double loops folded into one
-// (i over annotation exons, j over read exons); clears are idempotent and the
-// counters are plain sums, so the visiting order does not matter.  The acceptor
-// comparison uses the read exon j start, j < n-1 (Q1, :746).
+// src/update_gtf.c:683-696 set_full
+__device__ __forceinline__ bool full_decision(int level, bool lfull, bool lnoth, bool rfull, bool rnoth)
+{
+    if (level == 5) return true;
+    if (level == 4) return lfull || lnoth;
+    if (level == 3) return (lfull || lnoth) && (rfull || rnoth);
+    return lfull && rfull;
+}
+
+// src/update_gtf.c:717-779 check_splice_site, all four double loops folded into one (i over annotation exons,
+// j over read exons); clears are idempotent and the counters are plain sums, so the visiting order does not
+// matter.  The acceptor comparison uses the read exon j start, j < n-1 (Q1, :746).
 // returns 1 known, 2 has known site, 0 neither.
 __device__ __forceinline__ int site_compare(const int *S, const int *E, uint8_t *F, int n, int r_start, int r_end,
                                             const TxHdr &a, const int2 *__restrict__ ax, int dis)
@@ -293,187 +400,472 @@ __device__ __forceinline__ int site_compare(const int *S, const int *E, uint8_t 
     return same > 0 ? 2 : 0;
 }
 
-// ------------------------------------------------------------------ site dictionaries (-d 0)
-//
-// With -d 0, check_splice_site only asks "is this read coordinate (pair) also a site of the transcript".
-// Every distinct annotation site has a rank (host, once per annotation); a transcript carries a 64-bit
-// mask of its sites relative to its first rank, a read maps its sites to ranks once (hash probes) and
-// keeps a 64-bit mask relative to its first hit.  A candidate is then shift + AND + popcount.
-// Preconditions, checked per read and per transcript (anything else takes the literal loops):
-// strictly increasing exon starts and ends and start <= end on both sides -- then a value can pair with
-// at most one value of the other chain (pair count == common values) and equality implies that the
-// site lies inside both spans, i.e. inside the overlap window of check_splice_site.
-
-// Probe one bucket for key (k1, k2): `single` = third word of any entry whose first word is k1 (acceptor
-// rank of a start / donor rank of an end), `pair` = index of the entry equal to (k1, k2).
-struct Probe { int single, pair; };
-
-__device__ __forceinline__ Probe site_probe(const SiteDict &t, int bucket, int32_t k1, int32_t k2)
+__device__ __forceinline__ uint32_t finish_info(uint32_t info, int n, const DevParams &p)
 {
-    Probe pr{-1, -1};
-    if (bucket < 0) return pr;
-    const uint32_t lo = t.dir[bucket], hi = t.dir[bucket + 1];
-    for (uint32_t r = lo; r < hi; ++r) {
-        const int4 k = t.ent[r];
-        if (k.x == k1) { pr.single = k.z; if (k.y == k2) pr.pair = (int)r; }
-    }
-    return pr;
+    // routing of update_gtf.c:943-950 when there is no junction table
+    if (p.n_sj == 0 && (info & (I_FULL | I_KNOWN | I_KSITE)) == (I_FULL | I_KSITE)) info |= I_ACCEPT;
+    return info | ((uint32_t)n << 8);
 }
 
-// bucket of coordinate x on `tid`, or -1 when the annotation has no site that far
-__device__ __forceinline__ int site_bucket(int32_t tb, int32_t nb, int32_t x)
-{
-    const int b = x >> SITE_SHIFT;
-    return (x >= 0 && b < nb) ? tb + b : -1;
-}
+// ------------------------------------------------------------------ generic classification (any -d, any annotation)
 
-struct ReadSites {          // the read's sites in rank space
-    unsigned long long rd, ra, rx, rj;      // masks relative to bd/ba/bx/bj
-    int bd, ba, bx, bj;                     // rank of the first hit (or -1)
-    uint32_t hd, ha, hx, hj;                // bit j: exon/junction j of the read had a hit
-    bool ok;                                // representable (every hit within 64 ranks of the first)
-};
+// src/update_gtf.c:792-835 check_with_anno_trans for one read with the literal loops.  (S, E, F) = the read's
+// exons and flag bytes, in LDS or in HBM.
+struct Verdict { uint32_t info; int ref; };
 
-__device__ __forceinline__ void add_hit(unsigned long long &m, int &base, uint32_t &h, bool &ok, int g, int j)
+__device__ __forceinline__ Verdict sweep_literal(const int *S, const int *E, uint8_t *F, int n, int tid, bool rev, int j0,
+                                                 const TxHdr *__restrict__ hdr, const int2 *__restrict__ anno_ex, const DevParams &p)
 {
-    if (g < 0) return;
-    if (base < 0) base = g;
-    const int off = g - base;
-    if (off >= 64) { ok = false; return; }
-    m |= 1ull << off;
-    h |= 1u << j;
-}
-
-__device__ __forceinline__ unsigned long long align_mask(const uint32_t w[2], int tx_base, int read_base)
-{
-    const unsigned long long m = ((unsigned long long)w[1] << 32) | w[0];
-    const int d = tx_base - read_base;               // transcript bit k is rank tx_base + k
-    if (d >= 0) return d < 64 ? m << d : 0ull;
-    return -d < 64 ? m >> (-d) : 0ull;
-}
-
-// src/update_gtf.c:792-835 check_with_anno_trans for one read.  (S,E,F) address the read's exons and
-// flag bytes (LDS or HBM).  j0 = cursor value the sequential code would have.
-// Returns info bits (without exon count), ref in `ref`.
-// src/update_gtf.c:792-835 check_with_anno_trans, WAVE-UNIFORM form.  The 64 reads of a wave are
-// neighbours in a coordinate-sorted input, so they sweep (almost) the same annotation transcripts.  The
-// whole wave therefore walks ONE transcript index j upwards from the smallest cursor value of its reads;
-// j is wave-uniform, so the transcript header (and, for the exon scans of check_full, its exons) come in
-// through scalar loads once per wave, and every lane applies its own read's predicates: not started yet
-// (j < its cursor), finished (the read lies before transcript j, or it was found known -- the reference's
-// two `break`s), transcript before the read (`continue`), or overlap.  Per read the transcripts are still
-// visited in file order with the reference's early exits; only the interleaving across reads changes.
-// Every lane of the wave must call this (act = lane owns a read).
-__device__ __forceinline__ uint32_t sweep_annotation(bool act, const int *S, const int *E, uint8_t *F, int n, int tid, bool rev, bool read_ok,
-                                                     const ReadEnds &re, int e_pen, int s_2nd, const ReadSites &rs,
-                                                     int j0, const TxHdr *__restrict__ hdr, const int2 *__restrict__ anno_ex,
-                                                     const DevParams &p, int &ref)
-{
+    for (int k = 0; k < n; ++k) F[k] = (k + 1 < n) ? (uint8_t)(F_EXON | F_DON | F_ACC | F_JUNC) : F_EXON;
+    const ReadEnds re{S[0], E[0], S[n - 1], E[n - 1]};
     const int r_start = re.s0, r_end = re.el;
     ReadState st{false, false, true, true, false, false};
-    unsigned long long md = 0, ma = 0, mx = 0, mj = 0;      // sites matched by some visited transcript
-    ref = -1;
-    int ref_rev = 0;
-    bool done = !act || (p.ablate & 1);
-    int jm = done ? INT32_MAX : j0;
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) jm = min(jm, __shfl_xor(jm, d, WAVE));
-    const int level = p.full_level;
-    for (int j = __builtin_amdgcn_readfirstlane(jm); j < p.n_tx && __any(!done); ++j) {
-        const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);           // wave-uniform address
+    int ref = -1, ref_rev = 0;
+    for (int j = j0; j < p.n_tx; ++j) {
+        const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);
         const int4 h0 = hp[0];
-        bool ov = false;
-        if (!done && j >= j0) {
-            // src/update_gtf.c:786-790 comp_trans: <= (Q5)
-            if (tid < h0.x || (tid == h0.x && r_end <= h0.y)) done = true;                  // :799-800 break
-            else ov = !(h0.x < tid || (h0.x == tid && h0.z <= r_start));                    // :801 skip when before
-        }
-        if (!__any(ov)) continue;
+        // src/update_gtf.c:786-790 comp_trans: <= (Q5)
+        if (tid < h0.x || (tid == h0.x && r_end <= h0.y)) break;                 // :799-800
+        if (h0.x < tid || (h0.x == tid && h0.z <= r_start)) continue;            // :801
         const int4 h1 = hp[1], h2 = hp[2];
         TxHdr a; a.tid = h0.x; a.start = h0.y; a.end = h0.z; a.ex_off = h0.w;
         a.n = h1.x; a.rev = h1.y; a.flags = h1.z; a.s0 = h2.x; a.e0 = h2.y; a.sl = h2.z; a.el = h2.w;
         const int2 *ax = anno_ex + a.ex_off;
-        // ---- check_full :629-681
-        if (!(p.ablate & 4) && ov && !(st.lfull && st.rfull)) {
-            if (level == 1) {
-                if (!st.lfull && re.e0 == a.e0) st.lfull = true;
-                if (!st.rfull && re.sl == a.sl) st.rfull = true;
-            } else if (level == 2) {
-                if (!st.lfull && closed_overlap(re.s0, re.e0, a.s0, a.e0)) st.lfull = true;
-                if (!st.rfull && closed_overlap(re.sl, re.el, a.sl, a.el)) st.rfull = true;
-            }
-        }
-        if (!(p.ablate & 4) && (level == 3 || level == 4)) {
-            bool need_l = false, need_r = false;
-            if (ov && !(st.lfull && st.rfull)) {
-                if (!st.lfull) { if (closed_overlap(re.s0, re.e0, a.s0, a.e0)) st.lfull = true; else need_l = st.lnoth; }
-                if (level == 3 && !st.rfull) { if (closed_overlap(re.sl, re.el, a.sl, a.el)) st.rfull = true; else need_r = st.rnoth; }
-            }
-            if (__any(need_l || need_r)) {
-                for (int k = 0; k < a.n; ++k) {                      // exon k of the transcript: scalar load
-                    const int2 x = ax[k];
-                    if (need_l && closed_overlap(re.s0, re.e0, x.x, x.y)) { st.lnoth = false; need_l = false; }
-                    if (need_r && closed_overlap(re.sl, re.el, x.x, x.y)) { st.rnoth = false; need_r = false; }
-                }
-            }
-        }
-        // ---- :806-820
+        full_evidence(st, p.full_level, re, a, ax);
         int v = 0;
-        if (a.n == 1) {
-            if (ov && n == 1 && overlap_frac(re.s0, re.e0, a.s0, a.e0) >= p.frac) { st.known = true; v = 1; }
-        } else if (!(p.ablate & 2)) {
-            const bool multi = ov && n > 1;
-            const bool use_dict = multi && read_ok && (a.flags & TX_COMPACT);
-            if (__any(use_dict)) {
-                const int4 h3 = hp[3], h4 = hp[4], h5 = hp[5];
-                if (use_dict) {
-                    const uint32_t wd[2] = {(uint32_t)h4.x, (uint32_t)h4.y}, wa[2] = {(uint32_t)h4.z, (uint32_t)h4.w};
-                    const uint32_t wx[2] = {(uint32_t)h5.x, (uint32_t)h5.y}, wj[2] = {(uint32_t)h5.z, (uint32_t)h5.w};
-                    const unsigned long long cd = rs.rd & align_mask(wd, h3.x, rs.bd), ca = rs.ra & align_mask(wa, h3.y, rs.ba);
-                    md |= cd; ma |= ca;
-                    mx |= rs.rx & align_mask(wx, h3.z, rs.bx);
-                    mj |= rs.rj & align_mask(wj, h3.w, rs.bj);
-                    const int same = __popcll(cd) + __popcll(ca);
-                    const int lo = max(r_start, a.start), hi = min(r_end, a.end);
-                    // every one of the 2(n-1) read sites inside [lo,hi]: donors e_0..e_{n-2}, acceptors s_1..s_{n-1} increase
-                    const bool all_in = re.e0 >= lo && e_pen <= hi && s_2nd >= lo && re.sl <= hi;
-                    v = (all_in && same == 2 * (n - 1)) ? 1 : (same > 0 ? 2 : 0);
-                }
-            }
-            if (multi && !use_dict) v = site_compare(S, E, F, n, r_start, r_end, a, ax, p.ss_dis);      // literal loops
+        if (n == 1 && a.n == 1) {
+            if (overlap_frac(re.s0, re.e0, a.s0, a.e0) >= p.frac) { st.known = true; v = 1; }
+        } else if (n > 1 && a.n > 1) {
+            v = site_compare(S, E, F, n, r_start, r_end, a, ax, p.ss_dis);
             if (v == 1) st.known = true;
             if (v == 2) st.ksite = true;
         }
         if (v) { ref = j; ref_rev = a.rev; }
-        if (v == 1) done = true;                                                            // :810,816 break
-    }
-    if (md | ma | mx | mj) {
-        // hits were recorded in exon order and ranks increase with the exon index, so the k-th hit of a
-        // kind is the k-th set bit of its mask
-        unsigned long long qd = rs.rd, qa = rs.ra, qx = rs.rx, qj = rs.rj;
-        for (int k = 0; k < n; ++k) {
-            uint8_t clr = 0;
-            if ((rs.hx >> k) & 1u) { const unsigned long long b = qx & (0ull - qx); qx ^= b; if (mx & b) clr |= F_EXON; }
-            if ((rs.hd >> k) & 1u) { const unsigned long long b = qd & (0ull - qd); qd ^= b; if (md & b) clr |= F_DON; }
-            if ((rs.ha >> k) & 1u) { const unsigned long long b = qa & (0ull - qa); qa ^= b; if (ma & b) clr |= F_ACC; }
-            if ((rs.hj >> k) & 1u) { const unsigned long long b = qj & (0ull - qj); qj ^= b; if (mj & b) clr |= F_JUNC; }
-            if (clr) F[k] &= (uint8_t)~clr;
-        }
+        if (v == 1) break;                                                        // :810,816
     }
     bool out_rev = rev;
     if (ref >= 0) out_rev = ref_rev != 0;               // :825-831 strand taken from the reference transcript
-    bool full;                                           // :683-696 set_full
-    if (level == 5) full = true;
-    else if (level == 4) full = st.lfull || st.lnoth;
-    else if (level == 3) full = (st.lfull || st.lnoth) && (st.rfull || st.rnoth);
-    else full = st.lfull && st.rfull;
     uint32_t info = 0;
     if (st.known) info |= I_KNOWN;
     if (st.ksite) info |= I_KSITE;
-    if (full) info |= I_FULL;
+    if (full_decision(p.full_level, st.lfull, st.lnoth, st.rfull, st.rnoth)) info |= I_FULL;
     if (out_rev) info |= I_REV;
-    return info;
+    return Verdict{finish_info(info, n, p), ref};
 }
+
+// One thread per entry of the redo list.  Reads of up to GEN_CAP exons are worked on in LDS.
+constexpr int GEN_CAP = 16;
+
+__global__ __launch_bounds__(TILE_THREADS)
+void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t *__restrict__ redo,
+                        const int32_t *__restrict__ r_tid, const uint8_t *__restrict__ r_rev, const int32_t *__restrict__ j0_arr,
+                        const TxHdr *__restrict__ hdr, const int2 *__restrict__ anno_ex, DevParams p,
+                        const uint32_t *__restrict__ ex_off, const int32_t *__restrict__ ex_start, const int32_t *__restrict__ ex_end,
+                        uint8_t *__restrict__ ex_flag, uint32_t *__restrict__ info_io, int32_t *__restrict__ ref_out,
+                        uint32_t *__restrict__ tile_acc, uint32_t *__restrict__ tile_acc_ex)
+{
+    __shared__ int g_S[TILE_THREADS * GEN_CAP];
+    __shared__ int g_E[TILE_THREADS * GEN_CAP];
+    __shared__ uint8_t g_F[TILE_THREADS * GEN_CAP];
+    const uint32_t cnt = *redo_count;
+    for (uint32_t i = blockIdx.x * TILE_THREADS + threadIdx.x; i < cnt; i += gridDim.x * TILE_THREADS) {
+        const uint32_t r = redo[i];
+        const int n = (int)(info_io[r] >> 8);
+        const uint32_t off = ex_off[r];
+        const int tid = r_tid[r], j0 = j0_arr[r];
+        const bool rev = r_rev[r] != 0;
+        Verdict v;
+        if (n <= GEN_CAP) {
+            int *S = g_S + threadIdx.x * GEN_CAP, *E = g_E + threadIdx.x * GEN_CAP;
+            uint8_t *F = g_F + threadIdx.x * GEN_CAP;
+            for (int k = 0; k < n; ++k) { S[k] = ex_start[off + k]; E[k] = ex_end[off + k]; }
+            v = sweep_literal(S, E, F, n, tid, rev, j0, hdr, anno_ex, p);
+            for (int k = 0; k < n; ++k) ex_flag[off + k] = F[k];
+        } else {
+            v = sweep_literal(ex_start + off, ex_end + off, ex_flag + off, n, tid, rev, j0, hdr, anno_ex, p);
+        }
+        info_io[r] = v.info;
+        ref_out[r] = v.ref;
+        if (v.info & I_ACCEPT) {
+            const uint32_t t = r / (uint32_t)p.reads_per_tile;
+            atomicAdd(&tile_acc[t], 1u);
+            atomicAdd(&tile_acc_ex[t], (uint32_t)n);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ fast classification (-d 0)
+//
+// With -d 0, check_splice_site only asks "is this read coordinate (pair) also a site of the transcript".
+// The dictionaries answer that for ALL transcripts at once: a probe returns the set of transcripts that
+// contain the site as a bit mask.  The tile re-bases those masks, while staging them in LDS, into its own frame:
+// bit b = transcript j_lo + b of the tile's window.  Per read:
+//     V'   = window transcripts the sequential sweep would visit and that overlap the read  (one pass over the window)
+//     AND over the 2(n-1) probed sites of their masks = transcripts that contain every site  -> "known" candidates
+//     OR  ...                                         = transcripts that share a site       -> "has known site"
+//     the first known candidate j* in V' (file order) ends the sweep: V = V' up to j*
+//     a novel_* flag is cleared iff its site's mask meets V: per site the first member in V' is kept (7 bits)
+// Preconditions, checked per read / per visited transcript; anything else goes to the redo list:
+//   * strictly increasing exon starts and ends and start <= end on both sides (then a value pairs with at most one
+//     value of the other chain, pair count == common values, and equality implies that the site lies inside both
+//     spans, i.e. inside the overlap window of check_splice_site);
+//   * the read's sweep ends inside the window (WIN_TX transcripts from the tile's smallest cursor value);
+//   * no dictionary entry of the tile's slices has members beyond 64 transcripts of its first.
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));    // LDS copy of a dictionary entry {k1, k2, pm, sm}, masks in the tile frame
+
+struct FastArgs {
+    int64_t n_reads;
+    const int32_t *r_tid; const int32_t *r_pos; const uint8_t *r_rev; const int64_t *cig_off; const uint32_t *cig;
+    const uint32_t *local; const uint32_t *tile_base; const int32_t *j0; const TileDesc *desc;
+    const TxHdr *hdr; SiteDict st, en;
+    uint32_t *ex_off; int32_t *ex_start; int32_t *ex_end; uint8_t *ex_flag; uint32_t *info; int32_t *ref_tx;
+    uint32_t *tile_acc, *tile_acc_ex; uint32_t *redo_count, *redo;
+    unsigned long long *stamps;
+    DevParams p;
+};
+
+__device__ __forceinline__ uint32_t rebase_mask(uint32_t lo, uint32_t hi, int d)
+{
+    // 64-bit mask relative to tx_base -> 32 bits relative to j_lo, d = tx_base - j_lo
+    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+    if (d >= 0) return d < 32 ? (uint32_t)(m << d) : 0u;
+    return -d < 64 ? (uint32_t)(m >> (-d)) : 0u;
+}
+
+// Staged dictionary entries are read as one 16-byte vector {k1, k2, pm, sm}: one ds_read_b128.
+__device__ __forceinline__ v4i_t lds_entry(const v4i_t *ent, uint32_t i) { return ent[i]; }
+
+// One probe of a staged slice: pm of the entry equal to (k1, k2), sm of any entry whose first key is k1.
+// lo/hi = the bucket's entry range.  The first two entries are examined without a branch (buckets are 512 bp,
+// most hold 0..2 entries); the caller runs probe_rest when some lane has a longer bucket.
+__device__ __forceinline__ void probe2(const v4i_t q0, const v4i_t q1, uint32_t lo, uint32_t hi, int32_t k1, int32_t k2, uint32_t &pm, uint32_t &sm)
+{
+    const bool m0 = lo < hi && q0.x == k1, m1 = lo + 1u < hi && q1.x == k1;
+    sm = m1 ? (uint32_t)q1.w : (m0 ? (uint32_t)q0.w : 0u);
+    pm = (m1 && q1.y == k2) ? (uint32_t)q1.z : ((m0 && q0.y == k2) ? (uint32_t)q0.z : 0u);
+}
+
+__device__ __forceinline__ void probe_rest(const v4i_t *ent, uint32_t lo, uint32_t hi, int32_t k1, int32_t k2, uint32_t &pm, uint32_t &sm)
+{
+    for (uint32_t r = lo + 2u; r < hi; ++r) {
+        const v4i_t q = lds_entry(ent, r);
+        if (q.x == k1) { sm = (uint32_t)q.w; if (q.y == k2) pm = (uint32_t)q.z; }
+    }
+}
+
+// Transcripts (tile frame) that have an exon overlapping [s, e]: union of the exon masks of the START entries
+// from the first one that reaches into the bucket of s up to the last one that starts in the bucket of e.
+__device__ __forceinline__ uint32_t overlapping_exon_members(const uint32_t *rdir, const uint32_t *dir, const v4i_t *ent,
+                                                             int b_off, int nb, int s, int e)
+{
+    const int bs = s >> SITE_SHIFT;
+    if (bs >= nb) return 0u;                                 // beyond the last annotated site of the chromosome
+    const int be = min(e >> SITE_SHIFT, nb - 1);
+    uint32_t m = 0u;
+    const uint32_t i1 = dir[be + b_off + 1];
+    for (uint32_t i = rdir[bs + b_off]; i < i1; ++i) {
+        const v4i_t q = ent[i];
+        if (q.x <= e && q.y >= s) m |= (uint32_t)q.z;
+    }
+    return m;
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(TILE_THREADS)
+void k_classify_fast(FastArgs a)
+{
+    __shared__ int s_S[LDS_EXON_CAP];
+    __shared__ int s_E[LDS_EXON_CAP];
+    __shared__ uint32_t s_W[LDS_EXON_CAP];                  // per exon: first-visit bytes, then the flag byte
+    __shared__ uint32_t s_dir[2][DIR_CAP + 2];              // entry index relative to the slice, per staged bucket
+    __shared__ uint32_t s_rdir[DIR_CAP + 2];                // START: first entry that reaches into the bucket
+    __shared__ v4i_t s_ent[2][KEY_CAP];
+    __shared__ __attribute__((aligned(16))) int4 s_hk[WIN_TX];     // {start, end, n, flags | rev << 8} on the tile's chromosome
+    __shared__ __attribute__((aligned(16))) int4 s_hx[WIN_TX];     // {s0, e0, sl, el}
+    __shared__ uint32_t s_cnt[4][2];
+
+    const DevParams &p = a.p;
+    unsigned long long t_prev = a.stamps ? __builtin_readcyclecounter() : 0ull;
+#define L2R_STAMP(i) do { if (a.stamps && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+        atomicAdd(&a.stamps[(blockIdx.x & 1023u) * 8u + (i)], t_ - t_prev); t_prev = t_; } } while (0)
+
+    const int64_t r = (int64_t)blockIdx.x * p.reads_per_tile + threadIdx.x;
+    const bool active = (int)threadIdx.x < p.reads_per_tile && r < a.n_reads;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const TileDesc d = a.desc[blockIdx.x];
+    const uint32_t base = a.tile_base[blockIdx.x], tile_total = a.tile_base[blockIdx.x + 1] - base;
+    const bool fast = (d.flags & TD_FAST) != 0;
+    const bool in_lds = tile_total <= (uint32_t)LDS_EXON_CAP;
+    int my_wide = 0;
+
+    // ---- phase 0: every load of the tile is issued here
+    uint32_t local = 0, n = 0;
+    int64_t c_lo = 0, c_hi = 0;
+    int32_t pos = 0, j0 = 0, tid = 0;
+    if (active) {
+        local = a.local[r];
+        const bool last = (int)threadIdx.x + 1 == p.reads_per_tile || r + 1 == a.n_reads;
+        const uint32_t nxt = last ? tile_total : a.local[r + 1];
+        n = nxt - local;
+        c_lo = a.cig_off[r]; c_hi = a.cig_off[r + 1];
+        pos = a.r_pos[r];
+        tid = a.r_tid[r];
+        j0 = a.j0[r];
+    }
+    const int w_n = fast ? min(WIN_TX, p.n_tx - d.j_lo) : 0;          // transcripts in the window
+    int4 g_h0 = make_int4(0, 0, 0, 0), g_h1 = g_h0, g_h2 = g_h0;
+    if ((int)threadIdx.x < w_n) {
+        const int4 *hp = reinterpret_cast<const int4 *>(a.hdr + d.j_lo + threadIdx.x);
+        g_h0 = hp[0]; g_h1 = hp[1]; g_h2 = hp[2];
+    }
+    const bool st_thread = fast && threadIdx.x < d.st_nk;             // threads [0, st_nk): START entries
+    const bool en_thread = fast && threadIdx.x < d.en_nk;             // the same threads again: END entries
+    int4 g_e0 = make_int4(0, 0, 0, 0), g_e1 = g_e0, g_f0 = g_e0, g_f1 = g_e0;
+    if (st_thread) { const int4 *q = reinterpret_cast<const int4 *>(a.st.ent + d.st_r0 + threadIdx.x); g_e0 = q[0]; g_e1 = q[1]; }
+    if (en_thread) { const int4 *q = reinterpret_cast<const int4 *>(a.en.ent + d.en_r0 + threadIdx.x); g_f0 = q[0]; g_f1 = q[1]; }
+    uint32_t g_d[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
+    if (fast && d.nbk > 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = (int)threadIdx.x + q * TILE_THREADS;
+            if (i <= d.nbk) { g_d[0][q] = a.st.dir[d.b0 + i]; g_d[1][q] = a.en.dir[d.b0 + i]; g_d[2][q] = a.st.rdir[d.b0 + i]; }
+        }
+    }
+    L2R_STAMP(0);
+
+    // ---- phase 1: CIGAR -> exons
+    ReadEnds re{0, 0, 0, 0};
+    bool sane = true;
+    if (active) {
+        const uint32_t *cg = a.cig + c_lo;
+        if (in_lds) {
+            // every exon non-empty <=> starts and ends strictly increasing and start <= end (an exon starts after
+            // the previous one ends)
+            walk_cigar(cg, (int)(c_hi - c_lo), pos, p, [&](int k, int s, int e) {
+                s_S[local + k] = s; s_E[local + k] = e;
+                sane = sane && s <= e;
+                re.sl = s; re.el = e;
+            });
+            re.s0 = s_S[local]; re.e0 = s_E[local];
+        } else {
+            walk_cigar(cg, (int)(c_hi - c_lo), pos, p, [&](int k, int s, int e) {
+                a.ex_start[base + local + k] = s; a.ex_end[base + local + k] = e;
+            });
+        }
+    }
+    // ---- stage the dictionary slices and the transcript window, re-based to the tile
+    if (fast) {
+        if ((int)threadIdx.x < w_n) {
+            // coordinates on another chromosome become -inf (before every read) / +inf (after every read)
+            int st = g_h0.y, en = g_h0.z;
+            if (g_h0.x < d.tid) { st = INT32_MIN; en = INT32_MIN; }
+            else if (g_h0.x > d.tid) { st = INT32_MAX; en = INT32_MAX; }
+            s_hk[threadIdx.x] = make_int4(st, en, g_h1.x, (g_h1.z & 0xff) | (g_h1.y << 8));
+            s_hx[threadIdx.x] = g_h2;
+        }
+        if (st_thread) {
+            v4i_t e; e.x = g_e0.x; e.y = g_e0.y;
+            e.z = (int)rebase_mask((uint32_t)g_e1.x, (uint32_t)g_e1.y, g_e0.z - d.j_lo);
+            e.w = (int)rebase_mask((uint32_t)g_e1.z, (uint32_t)g_e1.w, g_e0.z - d.j_lo);
+            s_ent[0][threadIdx.x] = e;
+            if (g_e0.w & SE_WIDE) my_wide = 1;
+        }
+        if (en_thread) {
+            v4i_t e; e.x = g_f0.x; e.y = g_f0.y;
+            e.z = (int)rebase_mask((uint32_t)g_f1.x, (uint32_t)g_f1.y, g_f0.z - d.j_lo);
+            e.w = (int)rebase_mask((uint32_t)g_f1.z, (uint32_t)g_f1.w, g_f0.z - d.j_lo);
+            s_ent[1][threadIdx.x] = e;
+            if (g_f0.w & SE_WIDE) my_wide = 1;
+        }
+        if (d.nbk > 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = (int)threadIdx.x + q * TILE_THREADS;
+                if (i <= d.nbk) { s_dir[0][i] = g_d[0][q] - d.st_r0; s_dir[1][i] = g_d[1][q] - d.en_r0; s_rdir[i] = g_d[2][q] - d.st_r0; }
+            }
+        }
+    }
+    const int any_wide = __syncthreads_or(my_wide);
+    L2R_STAMP(1);
+
+    // ---- phase 2: classification
+    uint32_t info = 0; int ref = -1;
+    bool redo = active && (!fast || !in_lds || any_wide != 0 || tid != d.tid || (n > 1 && !sane));
+    const bool work = active && !redo;
+    const int *S = s_S + local, *E = s_E + local;
+    uint32_t *W = s_W + local;
+    uint32_t vpre = 0, lmask = 0, rmask = 0, k1mask = 0;
+    {
+        // V': transcripts j >= j0 up to the first one the read lies before (:799-800), minus the ones that lie
+        // before the read (:801); wave-uniform j, header words broadcast from LDS
+        const int jrel0 = j0 - d.j_lo;
+        bool stopped = !work;
+        for (int j = 0; j < w_n; ++j) {
+            const int4 hk = s_hk[j];
+            const bool act = !stopped && j >= jrel0;
+            const bool aft = re.el <= hk.x;                                     // comp_trans <= (Q5)
+            stopped = stopped || (act && aft);
+            const bool ov = act && !aft && !(hk.y <= re.s0);
+            if (!__any(ov)) { if (__all(stopped)) break; continue; }
+            const uint32_t bit = 1u << j;
+            if (ov) vpre |= bit;
+            const int4 hx = s_hx[j];
+            if (LEVEL == 1) {
+                if (ov && re.e0 == hx.y) lmask |= bit;
+                if (ov && re.sl == hx.z) rmask |= bit;
+            } else if (LEVEL >= 2 && LEVEL <= 4) {
+                if (ov && closed_overlap(re.s0, re.e0, hx.x, hx.y)) lmask |= bit;
+                if (LEVEL != 4 && ov && closed_overlap(re.sl, re.el, hx.z, hx.w)) rmask |= bit;
+            }
+            if (hk.z == 1) {                 // single-exon transcript: :806-811, only against single-exon reads
+                if (ov && n == 1 && overlap_frac(re.s0, re.e0, hx.x, hx.y) >= p.frac) k1mask |= bit;
+            } else if (!((hk.w & 0xff) & TX_COMPACT)) {
+                if (ov && n > 1) redo = true;                                   // literal loops needed for this pair
+            }
+        }
+        // the sweep must have ended inside the window
+        if (work && !stopped && d.j_lo + w_n < p.n_tx) redo = true;
+    }
+    L2R_STAMP(2);
+    uint32_t kand = 0xffffffffu, kor = 0u, dm_first = 0u, am_last = 0u;
+    {
+        // one START and one END probe per exon; the wave runs as many rounds as its longest read has exons.
+        // Per round: {next exon, both bucket ranges} are read together, then the first two entries of both buckets.
+        const bool mapping = work && !redo && n > 1;
+        const uint32_t *dS = s_dir[0], *dE = s_dir[1];
+        const v4i_t *eS = s_ent[0], *eE = s_ent[1];
+        int s = 0, e = 0;
+        if (mapping) { s = S[0]; e = E[0]; }
+        for (int k = 0; __any(mapping && k < (int)n); ++k) {
+            const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
+            const uint32_t inext = junc ? local + (uint32_t)k + 1u : 0u;
+            const int bs = s >> SITE_SHIFT, be = e >> SITE_SHIFT;
+            const bool vs = live && bs < d.nb, ve = junc && be < d.nb;
+            const int is = vs ? bs + d.b_off : 0, ie = ve ? be + d.b_off : 0;
+            const int s2 = s_S[inext], e2 = s_E[inext];
+            const uint32_t ls = dS[is], hs0 = dS[is + 1], le = dE[ie], he0 = dE[ie + 1];
+            const uint32_t hs = vs ? hs0 : ls, he = ve ? he0 : le;          // no bucket -> empty range
+            const v4i_t qs0 = lds_entry(eS, min(ls, (uint32_t)KEY_CAP - 1u)), qs1 = lds_entry(eS, min(ls + 1u, (uint32_t)KEY_CAP - 1u));
+            const v4i_t qe0 = lds_entry(eE, min(le, (uint32_t)KEY_CAP - 1u)), qe1 = lds_entry(eE, min(le + 1u, (uint32_t)KEY_CAP - 1u));
+            uint32_t xm, am, jm, dm;
+            probe2(qs0, qs1, ls, hs, s, e, xm, am);
+            probe2(qe0, qe1, le, he, e, s2, jm, dm);
+            if (__any(hs > ls + 2u || he > le + 2u)) { probe_rest(eS, ls, hs, s, e, xm, am); probe_rest(eE, le, he, e, s2, jm, dm); }
+            uint32_t word = min((uint32_t)__ffs((int)(xm & vpre)) - 1u, 0x7fu);
+            word |= min((uint32_t)__ffs((int)(dm & vpre)) - 1u, 0x7fu) << 8;       // without a junction: dm = am... = 0 -> 0x7f
+            word |= min((uint32_t)__ffs((int)((junc ? am : 0u) & vpre)) - 1u, 0x7fu) << 16;
+            word |= min((uint32_t)__ffs((int)(jm & vpre)) - 1u, 0x7fu) << 24;
+            if (junc) {
+                kand &= am & dm;                          // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
+                kor |= am | dm;
+                if (k == 0) dm_first = dm;
+            } else if (live) am_last = am;                // transcripts in which the last exon's start begins a later exon
+            if (live) W[k] = word;
+            s = s2; e = e2;
+        }
+    }
+    L2R_STAMP(3);
+    if (work && !redo) {
+        // ---- first known transcript in visiting order
+        int jstar = -1;
+        if (n > 1) {
+            // every probed site is in the transcript; known also needs every read site inside the overlap span:
+            // donors e_0..e_{n-2} and acceptors s_1..s_{n-1} increase, so e_0 >= a.start and s_{n-1} <= a.end suffice
+            uint32_t c = kand & vpre;
+            while (c) {
+                const int j = __ffs((int)c) - 1;
+                c &= c - 1u;
+                const int4 hk = s_hk[j];
+                if (hk.x <= re.e0 && re.sl <= hk.y) { jstar = j; break; }
+            }
+        } else if (k1mask) jstar = __ffs((int)k1mask) - 1;
+        const bool known = jstar >= 0;
+        const uint32_t V = known ? (vpre & ((2u << jstar) - 1u)) : vpre;
+        const uint32_t ks = (n > 1) ? (kor & V) : 0u;
+        const bool ksite = (ks & ~(known ? (1u << jstar) : 0u)) != 0u;
+        int jref = -1;
+        if (n > 1) { if (ks) jref = 31 - __clz((int)ks); }
+        else jref = jstar;
+        // ---- full-length evidence (:629-681) over V.  lfull: the first exon of a member of V overlaps the read's
+        // first exon.  lnoth stays set unless SOME exon of a member of V overlaps it; that is certain when the
+        // read's first donor is a donor of a member (the exon that ends there), else the START slice decides.
+        bool lfull = false, rfull = false, lnoth = true, rnoth = true;
+        if (LEVEL >= 1 && LEVEL <= 4) { lfull = (lmask & V) != 0u; rfull = (rmask & V) != 0u; }
+        if (LEVEL == 3 || LEVEL == 4) {
+            if (!lfull) {
+                if (dm_first & V) lnoth = false;
+                else if (V) lnoth = (overlapping_exon_members(s_rdir, s_dir[0], s_ent[0], d.b_off, d.nb, re.s0, re.e0) & V) == 0u;
+            }
+            if (LEVEL == 3 && !rfull) {
+                if (am_last & V) rnoth = false;
+                else if (V) rnoth = (overlapping_exon_members(s_rdir, s_dir[0], s_ent[0], d.b_off, d.nb, re.sl, re.el) & V) == 0u;
+            }
+        }
+        // ---- flags: a site is no longer novel iff the first member of V' that has it comes no later than j*
+        {
+            const uint32_t lim = known ? (uint32_t)jstar : 63u;
+            const uint32_t add = (127u - lim) * 0x01010101u;
+            for (int k = 0; k < (int)n; ++k) {
+                uint32_t f;
+                if (n > 1) {
+                    const uint32_t hb = ((W[k] + add) >> 7) & 0x01010101u;       // byte > lim  ->  still novel
+                    f = (hb & 1u) | ((hb >> 7) & 2u) | ((hb >> 14) & 4u) | ((hb >> 21) & 8u);
+                    if (k + 1 == (int)n) f &= 1u;
+                } else f = F_EXON;
+                W[k] = f;
+            }
+        }
+        bool out_rev = a.r_rev[r] != 0;
+        if (jref >= 0) { ref = d.j_lo + jref; out_rev = ((s_hk[jref].w >> 8) & 1) != 0; }     // :825-831
+        if (known) info |= I_KNOWN;
+        if (ksite) info |= I_KSITE;
+        if (full_decision(LEVEL, lfull, lnoth, rfull, rnoth)) info |= I_FULL;
+        if (out_rev) info |= I_REV;
+        info = finish_info(info, (int)n, p);
+    } else if (active) {
+        info = n << 8;
+        if (in_lds) for (int k = 0; k < (int)n; ++k) W[k] = 0u;
+    }
+    L2R_STAMP(4);
+
+    // ---- phase 3: redo list, accepted counts, coalesced write-out of the tile
+    redo = redo && active;
+    {
+        const unsigned long long m = __ballot(redo);
+        if (m) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(a.redo_count, (uint32_t)__popcll(m));
+            at = __shfl(at, 0, WAVE);
+            if (redo) a.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+        }
+        const bool acc = (info & I_ACCEPT) != 0;
+        const uint32_t ca = (uint32_t)__popcll(__ballot(acc)), cx = wave_sum(acc ? n : 0u);
+        if (lane == 0) { s_cnt[wv][0] = ca; s_cnt[wv][1] = cx; }
+    }
+    __syncthreads();
+    L2R_STAMP(5);
+    if (threadIdx.x == 0) {
+        a.tile_acc[blockIdx.x] = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+        a.tile_acc_ex[blockIdx.x] = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+    }
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i < tile_total; i += TILE_THREADS) {
+            a.ex_start[base + i] = s_S[i];
+            a.ex_end[base + i] = s_E[i];
+            a.ex_flag[base + i] = (uint8_t)s_W[i];
+        }
+    }
+    if (active) {
+        a.ex_off[r] = base + local;
+        a.info[r] = info;
+        a.ref_tx[r] = ref;
+    }
+    L2R_STAMP(6);
+#undef L2R_STAMP
+}
+
+// ------------------------------------------------------------------ short-read junction support
 
 __device__ __forceinline__ int first_key_above(const int64_t *__restrict__ key, int n, int64_t q)
 {
@@ -485,194 +877,8 @@ __device__ __forceinline__ int first_key_above(const int64_t *__restrict__ key, 
     return lo;
 }
 
-// Exons of one read into (S,E,F); terminal-exon registers; `sane` = strictly increasing starts and ends
-// and start <= end (the precondition of the dictionary path on the read side).
-struct ReadShape { ReadEnds re; int s_2nd, e_pen; bool sane; };
-
-__device__ __forceinline__ ReadShape exons_from_cigar(int *S, int *E, uint8_t *F, int n, int32_t pos0,
-                                                      const uint32_t *__restrict__ cig, int n_cig, const DevParams &p)
-{
-    ReadShape sh{{0, 0, 0, 0}, 0, 0, true};
-    int ps = INT32_MIN, pe = INT32_MIN;
-    walk_cigar(cig, n_cig, pos0, p, [&](int k, int s, int e) {
-        S[k] = s; E[k] = e;
-        sh.sane = sh.sane && s > ps && e > pe && s <= e;
-        if (k == 0) { sh.re.s0 = s; sh.re.e0 = e; }
-        if (k == 1) sh.s_2nd = s;
-        sh.e_pen = pe; ps = s; pe = e;
-    });
-    sh.re.sl = ps; sh.re.el = pe;
-    for (int k = 0; k < n; ++k) F[k] = (k + 1 < n) ? (uint8_t)(F_EXON | F_DON | F_ACC | F_JUNC) : F_EXON;
-    return sh;
-}
-
-// The slice of one dictionary that covers a tile, staged in LDS: directory words of the buckets
-// [b0, b0 + nb] and the entries [r0, r0 + nk).
-struct DictSlice { const uint32_t *dir; const int4 *ent; int b0; uint32_t r0; };
-
-__device__ __forceinline__ Probe slice_probe(const DictSlice &t, int bucket, int32_t k1, int32_t k2)
-{
-    Probe pr{-1, -1};
-    if (bucket < 0) return pr;
-    const uint32_t lo = t.dir[bucket - t.b0] - t.r0, hi = t.dir[bucket - t.b0 + 1] - t.r0;
-    for (uint32_t r = lo; r < hi; ++r) {
-        const int4 k = t.ent[r];
-        if (k.x == k1) { pr.single = k.z; if (k.y == k2) pr.pair = (int)(r + t.r0); }
-    }
-    return pr;
-}
-
-// ranks of the read's sites -> ReadSites; PROBE(which 0 = START / 1 = END, bucket, k1, k2)
-template <typename ProbeFn>
-__device__ __forceinline__ ReadSites map_read_sites(const int *S, const int *E, int n, int32_t tb, int32_t nb, ProbeFn probe)
-{
-    ReadSites rs{0, 0, 0, 0, -1, -1, -1, -1, 0, 0, 0, 0, true};
-    int s = S[0], e = E[0];
-    for (int k = 0; k < n; ++k) {
-        const Probe ps = probe(0, site_bucket(tb, nb, s), s, e);           // exon (s,e); acceptor rank of s
-        add_hit(rs.rx, rs.bx, rs.hx, rs.ok, ps.pair, k);
-        if (k + 1 < n) {
-            const int s2 = S[k + 1], e2 = E[k + 1];
-            const Probe pe = probe(1, site_bucket(tb, nb, e), e, s2);      // junction (e,s2); donor rank of e
-            add_hit(rs.ra, rs.ba, rs.ha, rs.ok, ps.single, k);             // Q1: start of exon k itself, k < n-1
-            add_hit(rs.rd, rs.bd, rs.hd, rs.ok, pe.single, k);
-            add_hit(rs.rj, rs.bj, rs.hj, rs.ok, pe.pair, k);
-            s = s2; e = e2;
-        }
-    }
-    return rs;
-}
-
-__device__ __forceinline__ uint32_t finish_info(uint32_t info, int n, const DevParams &p)
-{
-    // routing of update_gtf.c:943-950 when there is no junction table
-    if (p.n_sj == 0 && (info & (I_FULL | I_KNOWN | I_KSITE)) == (I_FULL | I_KSITE)) info |= I_ACCEPT;
-    return info | ((uint32_t)n << 8);
-}
-
-constexpr int DIR_CAP = 384;        // directory words staged per kind (tile span up to ~196 kb of buckets)
-constexpr int KEY_CAP = 256;        // dictionary entries staged per dictionary
-
-
-__global__ __launch_bounds__(TILE_THREADS)
-void k_fill_classify(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t *__restrict__ r_pos,
-                     const uint8_t *__restrict__ r_rev, const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ cig,
-                     const uint32_t *__restrict__ n_ex, const uint32_t *__restrict__ tile_base,
-                     const int32_t *__restrict__ j0_arr,
-                     const TxHdr *__restrict__ hdr, const int2 *__restrict__ anno_ex, SiteTabs tabs, DevParams p,
-                     uint32_t *__restrict__ ex_off, int32_t *__restrict__ ex_start, int32_t *__restrict__ ex_end,
-                     uint8_t *__restrict__ ex_flag, uint32_t *__restrict__ info_out, int32_t *__restrict__ ref_out)
-{
-    __shared__ uint32_t s_wave[4];
-    __shared__ int s_bmin, s_bmax;
-    __shared__ int s_start[LDS_EXON_CAP];
-    __shared__ int s_end[LDS_EXON_CAP];
-    __shared__ uint8_t s_flag[LDS_EXON_CAP];
-    __shared__ uint32_t s_dir[2][DIR_CAP + 1];
-    __shared__ __attribute__((aligned(16))) int4 s_keys[2][KEY_CAP];
-
-    const int64_t r = (int64_t)blockIdx.x * p.reads_per_tile + threadIdx.x;
-    const bool active = threadIdx.x < p.reads_per_tile && r < n_reads;
-    const uint32_t n = active ? n_ex[r] : 0u;
-    if (threadIdx.x == 0) { s_bmin = INT32_MAX; s_bmax = -1; }
-    uint32_t tile_total;
-    const uint32_t local = block_exclusive_scan(n, s_wave, tile_total);
-    const uint32_t base = tile_base[blockIdx.x];
-    const bool in_lds = tile_total <= (uint32_t)LDS_EXON_CAP;       // else: very long exon chains, work in HBM
-
-    // ---- phase 1: CIGAR -> exons, cursor value, bucket span of the read
-    ReadShape sh{{0, 0, 0, 0}, 0, 0, true};
-    int32_t tid = 0, tb = 0, nb = 0; int j0 = 0;
-    bool want_dict = false;
-    if (active) {
-        const int64_t a = cig_off[r], b = cig_off[r + 1];
-        tid = r_tid[r];
-        if (in_lds) sh = exons_from_cigar(s_start + local, s_end + local, s_flag + local, (int)n, r_pos[r], cig + a, (int)(b - a), p);
-        else sh = exons_from_cigar(ex_start + base + local, ex_end + base + local, ex_flag + base + local, (int)n, r_pos[r], cig + a, (int)(b - a), p);
-        j0 = j0_arr[r];
-        want_dict = p.ss_dis == 0 && sh.sane && n > 1 && n <= 32 && tid < tabs.n_tid && !(p.ablate & (16 | 1));
-        if (want_dict) { tb = tabs.tid_base[tid]; nb = tabs.tid_base[tid + 1] - tb; want_dict = nb > 0; }
-    }
-    {   // bucket span of the tile's dictionary reads: wave reduction, one LDS atomic per wave
-        int lo = INT32_MAX, hi = -1;
-        if (want_dict) {
-            lo = tb + min(max(sh.re.s0, 0) >> SITE_SHIFT, nb - 1);
-            hi = tb + min(max(sh.re.el, 0) >> SITE_SHIFT, nb - 1);
-        }
-#pragma unroll
-        for (int d = WAVE / 2; d > 0; d >>= 1) { lo = min(lo, __shfl_xor(lo, d, WAVE)); hi = max(hi, __shfl_xor(hi, d, WAVE)); }
-        if ((threadIdx.x & (WAVE - 1)) == 0 && hi >= 0) { atomicMin(&s_bmin, lo); atomicMax(&s_bmax, hi); }
-    }
-    __syncthreads();
-    // ---- phase 2: stage the dictionary slices of the tile in LDS (directory words, then keys)
-    const int b0 = s_bmin, nbk = s_bmax - s_bmin + 1;                // buckets b0 .. b0+nbk-1
-    bool staged = in_lds && s_bmax >= 0 && nbk <= DIR_CAP && !(p.ablate & 64);
-    if (staged) {
-        for (int i = threadIdx.x; i < 2 * (nbk + 1); i += TILE_THREADS) {
-            const int kind = i >= nbk + 1, w = i - kind * (nbk + 1);
-            s_dir[kind][w] = (kind ? tabs.en.dir : tabs.st.dir)[b0 + w];
-        }
-    }
-    __syncthreads();
-    if (staged) {
-#pragma unroll
-        for (int kind = 0; kind < 2; ++kind) staged = staged && (s_dir[kind][nbk] - s_dir[kind][0]) <= (uint32_t)KEY_CAP;
-    }
-    if (staged) {
-#pragma unroll
-        for (int kind = 0; kind < 2; ++kind) {
-            const int4 *src = kind ? tabs.en.ent : tabs.st.ent;
-            const uint32_t r0 = s_dir[kind][0], nk = s_dir[kind][nbk] - r0;
-            for (uint32_t i = threadIdx.x; i < nk; i += TILE_THREADS) s_keys[kind][i] = src[r0 + i];
-        }
-    }
-    __syncthreads();
-    // ---- phase 3: ranks of the read's sites, then the sweep
-    uint32_t info = 0; int ref = -1;
-    auto phase3 = [&](const int *S, const int *E, uint8_t *F) {
-        ReadSites rs{0, 0, 0, 0, -1, -1, -1, -1, 0, 0, 0, 0, true};
-        bool read_ok = want_dict;
-        if (want_dict && !(p.ablate & 32)) {
-            if (staged) {
-                const DictSlice ss{s_dir[0], s_keys[0], b0, s_dir[0][0]}, se{s_dir[1], s_keys[1], b0, s_dir[1][0]};
-                rs = map_read_sites(S, E, (int)n, tb, nb, [&](int which, int bucket, int k1, int k2) {
-                    return which ? slice_probe(se, bucket, k1, k2) : slice_probe(ss, bucket, k1, k2);
-                });
-            } else {
-                rs = map_read_sites(S, E, (int)n, tb, nb, [&](int which, int bucket, int k1, int k2) {
-                    return which ? site_probe(tabs.en, bucket, k1, k2) : site_probe(tabs.st, bucket, k1, k2);
-                });
-            }
-            read_ok = rs.ok;
-        }
-        // the sweep is wave-uniform: every lane of the wave takes part
-        info = sweep_annotation(active, S, E, F, (int)n, tid, active && r_rev[r] != 0, read_ok, sh.re, sh.e_pen, sh.s_2nd, rs, j0,
-                                hdr, anno_ex, p, ref);
-        info = finish_info(info, (int)n, p);
-    };
-    if (in_lds) phase3(s_start + local, s_end + local, s_flag + local);
-    else phase3(ex_start + base + local, ex_end + base + local, ex_flag + base + local);
-    // ---- phase 4: coalesced write-out of the tile
-    if (in_lds) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < tile_total; i += TILE_THREADS) {
-            ex_start[base + i] = s_start[i];
-            ex_end[base + i] = s_end[i];
-            ex_flag[base + i] = s_flag[i];
-        }
-    }
-    if (active) {
-        ex_off[r] = base + local;
-        info_out[r] = info;
-        ref_out[r] = ref;
-    }
-}
-
-// ------------------------------------------------------------------ short-read junction support
-
-// src/update_gtf.c:589-603 check_short_sj1 with the linear scan from the cursor row
-// replaced by a lower-bound on (tid, don): rows below don-dis cannot match, and the
-// reference stops at the first row with don >= acc (intron end).
+// src/update_gtf.c:589-603 check_short_sj1 with the linear scan from the cursor row replaced by a lower-bound on
+// (tid, don): rows below don-dis cannot match, and the reference stops at the first row with don >= acc (intron end).
 __device__ __forceinline__ bool junction_supported(int tid, int don, int acc, int from, const int32_t *__restrict__ sj_tid,
                                                    const int32_t *__restrict__ sj_don, const int32_t *__restrict__ sj_acc,
                                                    const int32_t *__restrict__ sj_uniq, const int32_t *__restrict__ sj_multi,
@@ -700,8 +906,8 @@ __device__ __forceinline__ bool junction_supported(int tid, int don, int acc, in
     return false;
 }
 
-// src/update_gtf.c:698-709 check_with_short_sj + :609-627 check_short_sj for every
-// read that reaches it (full, not known, has a known site), one thread per read.
+// src/update_gtf.c:698-709 check_with_short_sj + :609-627 check_short_sj for every read that reaches it
+// (full, not known, has a known site), one thread per read.
 __global__ __launch_bounds__(TILE_THREADS)
 void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uint32_t *__restrict__ ex_off,
                    const int32_t *__restrict__ ex_start, const int32_t *__restrict__ ex_end, uint8_t *__restrict__ ex_flag,
@@ -741,19 +947,18 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
 }
 
 // ------------------------------------------------------------------ compaction of accepted reads
+// Tiles are the classification tiles (reads_per_tile records, one workgroup).
 
 __global__ __launch_bounds__(TILE_THREADS)
-void k_count_accepted(int64_t n_reads, const uint32_t *__restrict__ info, uint32_t *__restrict__ tile_reads,
+void k_count_accepted(int64_t n_reads, int reads_per_tile, const uint32_t *__restrict__ info, uint32_t *__restrict__ tile_reads,
                       uint32_t *__restrict__ tile_exons)
 {
     __shared__ uint32_t s_cnt[4], s_ex[4];
-    const int64_t r = (int64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
-    const uint32_t w = r < n_reads ? info[r] : 0u;
+    const int64_t r = (int64_t)blockIdx.x * reads_per_tile + threadIdx.x;
+    const uint32_t w = ((int)threadIdx.x < reads_per_tile && r < n_reads) ? info[r] : 0u;
     const bool acc = (w & I_ACCEPT) != 0;
     const unsigned long long m = __ballot(acc);
-    uint32_t ex = acc ? (w >> 8) : 0u;
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) ex += __shfl_down(ex, d, WAVE);
+    const uint32_t ex = wave_sum(acc ? (w >> 8) : 0u);
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     if (lane == 0) { s_cnt[wv] = (uint32_t)__popcll(m); s_ex[wv] = ex; }
     __syncthreads();
@@ -765,41 +970,65 @@ void k_count_accepted(int64_t n_reads, const uint32_t *__restrict__ info, uint32
 
 struct AccRec { uint32_t read_lo, read_hi, info; int32_t ref_tx; };
 
+// Dense accepted records in read order.  tile_reads / tile_exons hold the exclusive scans (n_tiles + 1 words).
+// Every accepted read writes, for each of its exons, the source position into an LDS map at the exon's compacted
+// slot; the tile then copies slot by slot, so the stores are contiguous and the loads run over contiguous pieces.
+constexpr uint32_t MAP_DIRECT = 0xffffu;      // map entry of an exon that its read has copied itself
+
 __global__ __launch_bounds__(TILE_THREADS)
-void k_gather_accepted(int64_t n_reads, int64_t first_read, const uint32_t *__restrict__ info, const int32_t *__restrict__ ref_tx,
+void k_gather_accepted(int64_t n_reads, int reads_per_tile, int64_t first_read, const uint32_t *__restrict__ info, const int32_t *__restrict__ ref_tx,
                        const uint32_t *__restrict__ ex_off, const int32_t *__restrict__ ex_start, const int32_t *__restrict__ ex_end,
                        const uint8_t *__restrict__ ex_flag, const uint32_t *__restrict__ tile_reads, const uint32_t *__restrict__ tile_exons,
                        AccRec *__restrict__ rec, uint32_t *__restrict__ acc_ex_off, int32_t *__restrict__ acc_start,
                        int32_t *__restrict__ acc_end, uint8_t *__restrict__ acc_flag)
 {
     __shared__ uint32_t s_wcnt[4], s_wex[4];
-    const int64_t r = (int64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
-    const uint32_t w = r < n_reads ? info[r] : 0u;
+    __shared__ uint16_t s_map[LDS_EXON_CAP];
+    const int64_t r = (int64_t)blockIdx.x * reads_per_tile + threadIdx.x;
+    const bool active = (int)threadIdx.x < reads_per_tile && r < n_reads;
+    const uint32_t w = active ? info[r] : 0u;
     const bool acc = (w & I_ACCEPT) != 0;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    // rank inside the wave: ballot + popcount of the lanes below
     const unsigned long long m = __ballot(acc);
     const uint32_t rank_w = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    // exon prefix inside the wave: shuffle scan
     const uint32_t nex = acc ? (w >> 8) : 0u;
-    uint32_t inc = nex;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) { const uint32_t t = __shfl_up(inc, d, WAVE); if (lane >= d) inc += t; }
+    const uint32_t inc = wave_inclusive_scan(nex);
     if (lane == WAVE - 1) { s_wcnt[wv] = (uint32_t)__popcll(m); s_wex[wv] = inc; }
     __syncthreads();
-    uint32_t cbase = tile_reads[blockIdx.x], ebase = tile_exons[blockIdx.x];
-    for (int k = 0; k < wv; ++k) { cbase += s_wcnt[k]; ebase += s_wex[k]; }
-    if (!acc) return;
-    const uint32_t slot = cbase + rank_w, eo = ebase + inc - nex;
-    const uint64_t gidx = (uint64_t)(first_read + r);
-    AccRec a; a.read_lo = (uint32_t)gidx; a.read_hi = (uint32_t)(gidx >> 32); a.info = w; a.ref_tx = ref_tx[r];
-    rec[slot] = a;
-    acc_ex_off[slot] = eo;
-    const uint32_t src = ex_off[r];
-    for (uint32_t k = 0; k < nex; ++k) {
-        acc_start[eo + k] = ex_start[src + k];
-        acc_end[eo + k] = ex_end[src + k];
-        acc_flag[eo + k] = ex_flag[src + k];
+    const uint32_t cbase0 = tile_reads[blockIdx.x], ebase0 = tile_exons[blockIdx.x];
+    const uint32_t e_tot = tile_exons[blockIdx.x + 1] - ebase0;              // accepted exons of the tile
+    uint32_t cb = 0, eb = 0;
+    for (int k = 0; k < wv; ++k) { cb += s_wcnt[k]; eb += s_wex[k]; }
+    const uint32_t src0 = ex_off[(int64_t)blockIdx.x * reads_per_tile];      // first exon of the tile
+    const uint32_t e_loc = eb + inc - nex;                                    // tile-local compacted exon offset
+    const bool mapped = e_tot <= (uint32_t)LDS_EXON_CAP;
+    if (acc) {
+        const uint32_t src = ex_off[r];
+        const uint32_t slot = cbase0 + cb + rank_w;
+        const uint64_t gidx = (uint64_t)(first_read + r);
+        AccRec a; a.read_lo = (uint32_t)gidx; a.read_hi = (uint32_t)(gidx >> 32); a.info = w; a.ref_tx = ref_tx[r];
+        rec[slot] = a;
+        acc_ex_off[slot] = ebase0 + e_loc;
+        if (mapped && src - src0 + nex < MAP_DIRECT) {
+            for (uint32_t k = 0; k < nex; ++k) s_map[e_loc + k] = (uint16_t)(src - src0 + k);
+        } else {
+            for (uint32_t k = 0; k < nex; ++k) {
+                if (mapped) s_map[e_loc + k] = (uint16_t)MAP_DIRECT;
+                acc_start[ebase0 + e_loc + k] = ex_start[src + k];
+                acc_end[ebase0 + e_loc + k] = ex_end[src + k];
+                acc_flag[ebase0 + e_loc + k] = ex_flag[src + k];
+            }
+        }
+    }
+    if (!mapped) return;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < e_tot; i += TILE_THREADS) {
+        const uint32_t q = s_map[i];
+        if (q == MAP_DIRECT) continue;
+        const uint32_t sidx = src0 + q;
+        acc_start[ebase0 + i] = ex_start[sidx];
+        acc_end[ebase0 + i] = ex_end[sidx];
+        acc_flag[ebase0 + i] = ex_flag[sidx];
     }
 }
 

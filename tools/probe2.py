@@ -13,4 +13,4 @@ for lvl, dis in ((3,0),(3,1),(5,0),(5,1)):
     e.run(); e.sync()
     tm = e.run_timed(5)
     r = e.download()
-    print('lvl', lvl, 'dis', dis, 'fill %.3f' % tm['stage_ms']['fill_classify'], 'known', int(((r.info&1)!=0).sum()), flush=True)
+    print('lvl', lvl, 'dis', dis, 'fill %.3f' % tm['stage_ms']['classify_fast'], 'known', int(((r.info&1)!=0).sum()), flush=True)

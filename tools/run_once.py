@@ -1,13 +1,33 @@
-import sys, os
+"""Diagnostics on the GPU box: a few launches of the hot path on one config; with L2R_STAMPS=1 prints
+the per-phase cycle sums of k_classify_fast (thread 0 of every tile).  Not part of the product."""
+import ctypes as C
+import os
+import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from lr2rmats_amd import capi, workload
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000000
-cfg = dict(workload.CONFIGS['cfg3']); cfg['n_reads'] = N
+cfgname = sys.argv[2] if len(sys.argv) > 2 else 'cfg3'
+cfg = dict(workload.CONFIGS[cfgname]); cfg['n_reads'] = N
 af, reads = workload.make_rank_workload(cfg, 0, 1)
 e = capi.Engine(0)
 e.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
 e.set_params(capi.default_params(full_level=3))
 e.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)
-for _ in range(3):
+lib = capi.load_library()
+out = (C.c_ulonglong * 16)()
+for _ in range(2):
     e.run(); e.sync()
-print(e.sizes())
+if os.environ.get("L2R_STAMPS"):
+    lib.l2r_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.l2r_debug_stamps(e.ctx, out, 16)
+    e.run(); e.sync()
+    lib.l2r_debug_stamps(e.ctx, out, 16)
+    v = list(out)
+    tot = sum(v) or 1
+    print("stamps (cycles of thread 0 summed over tiles):", [(i, x, round(100.0 * x / tot, 1)) for i, x in enumerate(v) if x])
+cnt = (C.c_longlong * 4)()
+lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+lib.l2r_debug_counters(e.ctx, cnt, 4)
+print("redo reads %d, wide entries %d, compact tx %d, tiles %d" % tuple(cnt))
+tm = e.run_timed(5)
+print(e.sizes(), tm)
