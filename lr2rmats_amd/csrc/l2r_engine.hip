@@ -51,6 +51,7 @@ struct DevBuf {
 
 struct l2r_ctx {
     int device = 0;
+    int n_cu = 256, wg_per_cu = 3;          // persistent grid of k_classify_fast (L2R_WG_PER_CU overrides)
     hipStream_t stream = nullptr;
     l2r_params prm;
     // annotation
@@ -138,6 +139,12 @@ l2r_ctx *l2r_create(int device)
     }
     // src/update_gtf.c:24-35 defaults
     c->prm = l2r_params{3, 3, 50, 0, 0x7fffffff, 5, 0, 0, 1, 0, 0.80f};
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+        const char *e = getenv("L2R_WG_PER_CU");
+        if (e && atoi(e) > 0) c->wg_per_cu = atoi(e);
+    }
     return c;
 }
 
@@ -434,7 +441,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     c->n_tiles256 = (N + TILE_THREADS - 1) / TILE_THREADS;
 
     if (c->r_tid.ensure((size_t)N) || c->r_pos.ensure((size_t)N) || c->r_rev.ensure((size_t)N) ||
-        c->cig_off.ensure((size_t)N + 1) || c->cig.ensure((size_t)r->n_cigar)) return -2;
+        c->cig_off.ensure((size_t)N + 1) || c->cig.ensure((size_t)r->n_cigar + 4)) return -2;     // + 4: the tile staging reads whole 16-byte vectors
     if (N) {
         HIP_TRY(hipMemcpyAsync(c->r_tid.p, r->tid, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->r_pos.p, r->pos, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
@@ -506,7 +513,7 @@ static int prepare_unsorted_sj_cursor(l2r_ctx *c)
 
 enum { ST_PASS_A = 0, ST_SCAN1, ST_FAST, ST_GENERIC, ST_SJ, ST_SCAN2, ST_GATHER, ST_N };
 
-#define launch_fast_level(L, fa, grid, s) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L>), dim3(grid), dim3(TILE_THREADS), 0, s, fa)
+#define launch_fast_level(L, fa, grid, s) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles)
 
 static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
 {
@@ -537,13 +544,15 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         fa.ex_off = c->ex_off.p; fa.ex_start = c->ex_start.p; fa.ex_end = c->ex_end.p; fa.ex_flag = c->ex_flag.p; fa.info = c->info.p; fa.ref_tx = c->ref_tx.p;
         fa.tile_acc = c->tile_acc.p; fa.tile_acc_ex = c->tile_acc_ex.p; fa.redo_count = c->totals.p + 3; fa.redo = c->redo.p;
         fa.stamps = c->stamps.p; fa.p = p;
+        // persistent grid: a few workgroups per CU walk over the tiles (l2r_kernels.hip.h)
+        const unsigned gp = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * c->wg_per_cu);
         switch (p.full_level) {
-        case 1: launch_fast_level(1, fa, gt, s); break;
-        case 2: launch_fast_level(2, fa, gt, s); break;
-        case 3: launch_fast_level(3, fa, gt, s); break;
-        case 4: launch_fast_level(4, fa, gt, s); break;
-        case 5: launch_fast_level(5, fa, gt, s); break;
-        default: launch_fast_level(0, fa, gt, s); break;      // src/update_gtf.c:629-696: no evidence is gathered, full = lfull && rfull = 0
+        case 1: launch_fast_level(1, fa, gp, s); break;
+        case 2: launch_fast_level(2, fa, gp, s); break;
+        case 3: launch_fast_level(3, fa, gp, s); break;
+        case 4: launch_fast_level(4, fa, gp, s); break;
+        case 5: launch_fast_level(5, fa, gp, s); break;
+        default: launch_fast_level(0, fa, gp, s); break;      // src/update_gtf.c:629-696: no evidence is gathered, full = lfull && rfull = 0
         }
     }
     MARK(ST_GENERIC);

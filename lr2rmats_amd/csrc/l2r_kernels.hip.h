@@ -158,21 +158,22 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 // ------------------------------------------------------------------ CIGAR -> exons
 
 // src/bam2gtf.c:31-78 gen_exon.  emit(k, start, end) is called for every exon kept.
-// CIGAR words are fetched four at a time so that the loads of one read are in flight together.
-template <typename Emit>
-__device__ __forceinline__ int walk_cigar(const uint32_t *__restrict__ cig, int n_cig, int pos0, const DevParams &p, Emit emit)
+// CIGAR words are fetched four at a time so that the loads of one read are in flight together; the state update
+// is written without short-circuit logic so that it compiles to selects (one predicated region per op: the emit).
+template <typename Ptr, typename Emit>
+__device__ __forceinline__ int walk_cigar(Ptr cig, int n_cig, int pos0, const DevParams &p, Emit emit)
 {
     int start = pos0 + 1, end = start - 1, n = 0;
     auto step = [&](uint32_t c) {
         const int len = (int)(c >> 4);
         const uint32_t op = c & 0xfu;
         // N (3) cuts at len >= min_intron, D (2) at len > max_delet; M,=,X,N,D advance the reference
-        const bool cut = (op == 3u && len >= p.min_intron) || (op == 2u && len > p.max_delet);
-        if (cut) {
-            if (n == 0 || end - start + 1 >= p.min_exon) { emit(n, start, end); ++n; }
-            start = end + len + 1;
-        }
-        if ((0x18du >> op) & 1u) end += len;            // ops 0 2 3 7 8
+        const bool cut = ((op == 3u) & (len >= p.min_intron)) | ((op == 2u) & (len > p.max_delet));
+        const bool keep = cut & ((n == 0) | (end - start + 1 >= p.min_exon));
+        if (keep) emit(n, start, end);
+        n += keep ? 1 : 0;
+        start = cut ? end + len + 1 : start;
+        end += ((0x18du >> op) & 1u) ? len : 0;         // ops 0 2 3 7 8
     };
     int k = 0;
     for (; k + 4 <= n_cig; k += 4) {
@@ -217,14 +218,14 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
     uint32_t n = 0;
     int j0 = INT32_MAX, tid = 0, pos = 0, el = 0;
     if (active) {
-        const int64_t a = cig_off[r], b = cig_off[r + 1];
+        const int64_t c_a = cig_off[r], c_b = cig_off[r + 1];
         pos = r_pos[r];
         tid = r_tid[r];
         if (threadIdx.x == 0) s_tid0 = tid;
         if (j0_in) j0 = j0_in[r];
         else { j0 = cursor_value(cd, tid, pos + 1); j0_out[r] = j0; }       // first exon always starts at pos + 1
         el = pos;
-        n = (uint32_t)walk_cigar(cig + a, (int)(b - a), pos, p, [&](int, int, int e) { el = e; });
+        n = (uint32_t)walk_cigar(cig + c_a, (int)(c_b - c_a), pos, p, [&](int, int, int e) { el = e; });
     }
     uint32_t total;
     const uint32_t local = block_exclusive_scan(n, s_wave, total);
@@ -571,16 +572,109 @@ __device__ __forceinline__ uint32_t overlapping_exon_members(const uint32_t *rdi
     return m;
 }
 
+// The kernel is PERSISTENT and software pipelined: a workgroup walks over tiles t, t + grid, ... and holds the
+// raw inputs of its next tile in registers while it computes the current one, so no tile waits on HBM:
+//     uniforms of tile t+G (descriptor, offsets)      issued at the top of tile t
+//     vectors of tile t+G (CIGAR words, per-read fields, dictionary entries, directory words, headers)
+//                                                     issued after tile t has staged its own dictionary
+//     ... consumed (registers -> LDS) at the top of tile t+G.
+constexpr int PF_CIG_VEC = 4;                              // 16-byte CIGAR vectors a thread holds for the next tile
+
+struct TileUniforms {                                       // wave-uniform inputs of a tile
+    TileDesc d;
+    uint32_t base, total;
+    int64_t c0, c1;                                         // the tile's CIGAR words [c0, c1)
+};
+
+struct TileVectors {                                        // per-thread raw inputs of a tile
+    uint32_t local, nxt;
+    int64_t c_lo, c_hi;
+    int32_t pos, j0, tid, rev;
+    uint4 cg[PF_CIG_VEC];
+    int4 h0, h1, h2, e0, e1, f0, f1;
+    uint32_t dd[3][2];
+};
+
+__device__ __forceinline__ TileUniforms load_uniforms(const FastArgs &a, int64_t t)
+{
+    TileUniforms u;
+    const int64_t r0 = t * a.p.reads_per_tile, r1 = min(r0 + a.p.reads_per_tile, a.n_reads);
+    u.d = a.desc[t];
+    u.base = a.tile_base[t]; u.total = a.tile_base[t + 1] - u.base;
+    u.c0 = a.cig_off[r0]; u.c1 = a.cig_off[r1];
+    return u;
+}
+
+// CIGAR staging geometry: the copy starts at the 16-byte boundary below c0 (the array is padded at its end)
+__device__ __forceinline__ int cigar_vectors(const TileUniforms &u) { return (int)((u.c1 - (u.c0 & ~(int64_t)3) + 3) >> 2); }
+__device__ __forceinline__ bool cigar_staged(const TileUniforms &u, int region_words)
+{
+    const int n4 = cigar_vectors(u);
+    return n4 <= PF_CIG_VEC * TILE_THREADS && 4 * n4 <= region_words;
+}
+
+__device__ __forceinline__ TileVectors load_vectors(const FastArgs &a, int64_t t, const TileUniforms &u, int region_words)
+{
+    TileVectors v;
+    const DevParams &p = a.p;
+    const int64_t r = t * p.reads_per_tile + threadIdx.x;
+    const bool active = (int)threadIdx.x < p.reads_per_tile && r < a.n_reads;
+    v.local = 0; v.nxt = 0; v.c_lo = 0; v.c_hi = 0; v.pos = 0; v.j0 = 0; v.tid = 0; v.rev = 0;
+    if (active) {
+        v.local = a.local[r];
+        const bool last = (int)threadIdx.x + 1 == p.reads_per_tile || r + 1 == a.n_reads;
+        v.nxt = last ? u.total : a.local[r + 1];
+        v.c_lo = a.cig_off[r]; v.c_hi = a.cig_off[r + 1];
+        v.pos = a.r_pos[r]; v.tid = a.r_tid[r]; v.j0 = a.j0[r]; v.rev = a.r_rev[r];
+    }
+    const bool staged = cigar_staged(u, region_words);
+    const int n4 = cigar_vectors(u);
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.cig + (u.c0 & ~(int64_t)3));
+#pragma unroll
+    for (int q = 0; q < PF_CIG_VEC; ++q) {
+        const int i = q * TILE_THREADS + (int)threadIdx.x;
+        v.cg[q] = make_uint4(0u, 0u, 0u, 0u);
+        if (staged && i < n4) v.cg[q] = src[i];
+    }
+    const TileDesc &d = u.d;
+    const bool fast = (d.flags & TD_FAST) != 0;
+    const int w_n = fast ? min(WIN_TX, p.n_tx - d.j_lo) : 0;
+    v.h0 = v.h1 = v.h2 = v.e0 = v.e1 = v.f0 = v.f1 = make_int4(0, 0, 0, 0);
+    if ((int)threadIdx.x < w_n) {
+        const int4 *hp = reinterpret_cast<const int4 *>(a.hdr + d.j_lo + threadIdx.x);
+        v.h0 = hp[0]; v.h1 = hp[1]; v.h2 = hp[2];
+    }
+    if (fast && threadIdx.x < d.st_nk) { const int4 *q = reinterpret_cast<const int4 *>(a.st.ent + d.st_r0 + threadIdx.x); v.e0 = q[0]; v.e1 = q[1]; }
+    if (fast && threadIdx.x < d.en_nk) { const int4 *q = reinterpret_cast<const int4 *>(a.en.ent + d.en_r0 + threadIdx.x); v.f0 = q[0]; v.f1 = q[1]; }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = (int)threadIdx.x + q * TILE_THREADS;
+        v.dd[0][q] = v.dd[1][q] = v.dd[2][q] = 0u;
+        if (fast && d.nbk > 0 && i <= d.nbk) { v.dd[0][q] = a.st.dir[d.b0 + i]; v.dd[1][q] = a.en.dir[d.b0 + i]; v.dd[2][q] = a.st.rdir[d.b0 + i]; }
+    }
+    return v;
+}
+
 template <int LEVEL>
-__global__ __launch_bounds__(TILE_THREADS)
-void k_classify_fast(FastArgs a)
+__global__ __launch_bounds__(TILE_THREADS, 3)
+void k_classify_fast(FastArgs a, int64_t n_tiles)
 {
     __shared__ int s_S[LDS_EXON_CAP];
     __shared__ int s_E[LDS_EXON_CAP];
-    __shared__ uint32_t s_W[LDS_EXON_CAP];                  // per exon: first-visit bytes, then the flag byte
-    __shared__ uint32_t s_dir[2][DIR_CAP + 2];              // entry index relative to the slice, per staged bucket
-    __shared__ uint32_t s_rdir[DIR_CAP + 2];                // START: first entry that reaches into the bucket
-    __shared__ v4i_t s_ent[2][KEY_CAP];
+    // One region, used twice per tile: first the tile's CIGAR words (phase 1), then
+    //   s_W    per exon: first-visit bytes, then the flag byte
+    //   s_ent  dictionary entries {k1, k2, pm, sm} (START, END)
+    //   s_dir  entry index relative to the slice, per staged bucket (START, END); s_rdir: START reach-back
+    constexpr int DIR_WORDS = DIR_CAP + 2;
+    constexpr int REGION_WORDS = (LDS_EXON_CAP + 3 * DIR_WORDS + 2 * KEY_CAP * 4 + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) uint32_t s_region[REGION_WORDS];
+    uint32_t *const s_W = s_region;
+    v4i_t *const s_ent0 = reinterpret_cast<v4i_t *>(s_region + LDS_EXON_CAP);           // LDS_EXON_CAP % 4 == 0
+    v4i_t *const s_ent1 = s_ent0 + KEY_CAP;
+    uint32_t *const s_dir0 = s_region + LDS_EXON_CAP + 2 * KEY_CAP * 4;
+    uint32_t *const s_dir1 = s_dir0 + DIR_WORDS;
+    uint32_t *const s_rdir = s_dir1 + DIR_WORDS;
+    uint32_t *const s_cig = s_region;
     __shared__ __attribute__((aligned(16))) int4 s_hk[WIN_TX];     // {start, end, n, flags | rev << 8} on the tile's chromosome
     __shared__ __attribute__((aligned(16))) int4 s_hx[WIN_TX];     // {s0, e0, sl, el}
     __shared__ uint32_t s_cnt[4][2];
@@ -589,279 +683,278 @@ void k_classify_fast(FastArgs a)
     unsigned long long t_prev = a.stamps ? __builtin_readcyclecounter() : 0ull;
 #define L2R_STAMP(i) do { if (a.stamps && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
         atomicAdd(&a.stamps[(blockIdx.x & 1023u) * 8u + (i)], t_ - t_prev); t_prev = t_; } } while (0)
-
-    const int64_t r = (int64_t)blockIdx.x * p.reads_per_tile + threadIdx.x;
-    const bool active = (int)threadIdx.x < p.reads_per_tile && r < a.n_reads;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    const TileDesc d = a.desc[blockIdx.x];
-    const uint32_t base = a.tile_base[blockIdx.x], tile_total = a.tile_base[blockIdx.x + 1] - base;
-    const bool fast = (d.flags & TD_FAST) != 0;
-    const bool in_lds = tile_total <= (uint32_t)LDS_EXON_CAP;
-    int my_wide = 0;
 
-    // ---- phase 0: every load of the tile is issued here
-    uint32_t local = 0, n = 0;
-    int64_t c_lo = 0, c_hi = 0;
-    int32_t pos = 0, j0 = 0, tid = 0;
-    if (active) {
-        local = a.local[r];
-        const bool last = (int)threadIdx.x + 1 == p.reads_per_tile || r + 1 == a.n_reads;
-        const uint32_t nxt = last ? tile_total : a.local[r + 1];
-        n = nxt - local;
-        c_lo = a.cig_off[r]; c_hi = a.cig_off[r + 1];
-        pos = a.r_pos[r];
-        tid = a.r_tid[r];
-        j0 = a.j0[r];
-    }
-    const int w_n = fast ? min(WIN_TX, p.n_tx - d.j_lo) : 0;          // transcripts in the window
-    int4 g_h0 = make_int4(0, 0, 0, 0), g_h1 = g_h0, g_h2 = g_h0;
-    if ((int)threadIdx.x < w_n) {
-        const int4 *hp = reinterpret_cast<const int4 *>(a.hdr + d.j_lo + threadIdx.x);
-        g_h0 = hp[0]; g_h1 = hp[1]; g_h2 = hp[2];
-    }
-    const bool st_thread = fast && threadIdx.x < d.st_nk;             // threads [0, st_nk): START entries
-    const bool en_thread = fast && threadIdx.x < d.en_nk;             // the same threads again: END entries
-    int4 g_e0 = make_int4(0, 0, 0, 0), g_e1 = g_e0, g_f0 = g_e0, g_f1 = g_e0;
-    if (st_thread) { const int4 *q = reinterpret_cast<const int4 *>(a.st.ent + d.st_r0 + threadIdx.x); g_e0 = q[0]; g_e1 = q[1]; }
-    if (en_thread) { const int4 *q = reinterpret_cast<const int4 *>(a.en.ent + d.en_r0 + threadIdx.x); g_f0 = q[0]; g_f1 = q[1]; }
-    uint32_t g_d[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
-    if (fast && d.nbk > 0) {
+    int64_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    TileUniforms u = load_uniforms(a, t);
+    TileVectors v = load_vectors(a, t, u, REGION_WORDS);
+
+    for (; t < n_tiles; t += gridDim.x) {
+        const int64_t t_next = t + gridDim.x;
+        const bool has_next = t_next < n_tiles;
+        TileUniforms u_next = u;
+        if (has_next) u_next = load_uniforms(a, t_next);
+
+        const int64_t r = t * p.reads_per_tile + threadIdx.x;
+        const bool active = (int)threadIdx.x < p.reads_per_tile && r < a.n_reads;
+        const TileDesc d = u.d;
+        const uint32_t base = u.base, tile_total = u.total;
+        const bool fast = (d.flags & TD_FAST) != 0;
+        const bool in_lds = tile_total <= (uint32_t)LDS_EXON_CAP;
+        const uint32_t local = v.local, n = active ? v.nxt - v.local : 0u;
+        const int32_t pos = v.pos, j0 = v.j0, tid = v.tid;
+        const int w_n = fast ? min(WIN_TX, p.n_tx - d.j_lo) : 0;          // transcripts in the window
+
+        // ---- phase 0: the tile's CIGAR words, registers -> LDS
+        const bool staged = cigar_staged(u, REGION_WORDS);
+        if (staged) {
+            const int n4 = cigar_vectors(u);
+            uint4 *dst = reinterpret_cast<uint4 *>(s_cig);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int i = (int)threadIdx.x + q * TILE_THREADS;
-            if (i <= d.nbk) { g_d[0][q] = a.st.dir[d.b0 + i]; g_d[1][q] = a.en.dir[d.b0 + i]; g_d[2][q] = a.st.rdir[d.b0 + i]; }
+            for (int q = 0; q < PF_CIG_VEC; ++q) { const int i = q * TILE_THREADS + (int)threadIdx.x; if (i < n4) dst[i] = v.cg[q]; }
         }
-    }
-    L2R_STAMP(0);
+        __syncthreads();
+        L2R_STAMP(0);
 
-    // ---- phase 1: CIGAR -> exons
-    ReadEnds re{0, 0, 0, 0};
-    bool sane = true;
-    if (active) {
-        const uint32_t *cg = a.cig + c_lo;
-        if (in_lds) {
-            // every exon non-empty <=> starts and ends strictly increasing and start <= end (an exon starts after
-            // the previous one ends)
-            walk_cigar(cg, (int)(c_hi - c_lo), pos, p, [&](int k, int s, int e) {
-                s_S[local + k] = s; s_E[local + k] = e;
-                sane = sane && s <= e;
-                re.sl = s; re.el = e;
-            });
-            re.s0 = s_S[local]; re.e0 = s_E[local];
-        } else {
-            walk_cigar(cg, (int)(c_hi - c_lo), pos, p, [&](int k, int s, int e) {
-                a.ex_start[base + local + k] = s; a.ex_end[base + local + k] = e;
-            });
+        // ---- phase 1: CIGAR -> exons
+        ReadEnds re{0, 0, 0, 0};
+        bool sane = true;
+        if (active) {
+            const int n_cig = (int)(v.c_hi - v.c_lo);
+            if (in_lds) {
+                // every exon non-empty <=> starts and ends strictly increasing and start <= end (an exon starts after
+                // the previous one ends)
+                auto emit = [&](int k, int s, int e) {
+                    s_S[local + k] = s; s_E[local + k] = e;
+                    sane = sane & (s <= e);
+                    re.sl = s; re.el = e;
+                };
+                if (staged) walk_cigar(s_cig + (int)(v.c_lo - (u.c0 & ~(int64_t)3)), n_cig, pos, p, emit);
+                else walk_cigar(a.cig + v.c_lo, n_cig, pos, p, emit);
+                re.s0 = s_S[local]; re.e0 = s_E[local];
+            } else {
+                walk_cigar(a.cig + v.c_lo, n_cig, pos, p, [&](int k, int s, int e) {
+                    a.ex_start[base + local + k] = s; a.ex_end[base + local + k] = e;
+                });
+            }
         }
-    }
-    // ---- stage the dictionary slices and the transcript window, re-based to the tile
-    if (fast) {
-        if ((int)threadIdx.x < w_n) {
-            // coordinates on another chromosome become -inf (before every read) / +inf (after every read)
-            int st = g_h0.y, en = g_h0.z;
-            if (g_h0.x < d.tid) { st = INT32_MIN; en = INT32_MIN; }
-            else if (g_h0.x > d.tid) { st = INT32_MAX; en = INT32_MAX; }
-            s_hk[threadIdx.x] = make_int4(st, en, g_h1.x, (g_h1.z & 0xff) | (g_h1.y << 8));
-            s_hx[threadIdx.x] = g_h2;
-        }
-        if (st_thread) {
-            v4i_t e; e.x = g_e0.x; e.y = g_e0.y;
-            e.z = (int)rebase_mask((uint32_t)g_e1.x, (uint32_t)g_e1.y, g_e0.z - d.j_lo);
-            e.w = (int)rebase_mask((uint32_t)g_e1.z, (uint32_t)g_e1.w, g_e0.z - d.j_lo);
-            s_ent[0][threadIdx.x] = e;
-            if (g_e0.w & SE_WIDE) my_wide = 1;
-        }
-        if (en_thread) {
-            v4i_t e; e.x = g_f0.x; e.y = g_f0.y;
-            e.z = (int)rebase_mask((uint32_t)g_f1.x, (uint32_t)g_f1.y, g_f0.z - d.j_lo);
-            e.w = (int)rebase_mask((uint32_t)g_f1.z, (uint32_t)g_f1.w, g_f0.z - d.j_lo);
-            s_ent[1][threadIdx.x] = e;
-            if (g_f0.w & SE_WIDE) my_wide = 1;
-        }
-        if (d.nbk > 0) {
+        __syncthreads();                 // every walk is done: the CIGAR region is free
+        // ---- stage the dictionary slices and the transcript window, re-based to the tile
+        int my_wide = 0;
+        if (fast) {
+            if ((int)threadIdx.x < w_n) {
+                // coordinates on another chromosome become -inf (before every read) / +inf (after every read)
+                int st = v.h0.y, en = v.h0.z;
+                if (v.h0.x < d.tid) { st = INT32_MIN; en = INT32_MIN; }
+                else if (v.h0.x > d.tid) { st = INT32_MAX; en = INT32_MAX; }
+                s_hk[threadIdx.x] = make_int4(st, en, v.h1.x, (v.h1.z & 0xff) | (v.h1.y << 8));
+                s_hx[threadIdx.x] = v.h2;
+            }
+            if (threadIdx.x < d.st_nk) {
+                v4i_t e; e.x = v.e0.x; e.y = v.e0.y;
+                e.z = (int)rebase_mask((uint32_t)v.e1.x, (uint32_t)v.e1.y, v.e0.z - d.j_lo);
+                e.w = (int)rebase_mask((uint32_t)v.e1.z, (uint32_t)v.e1.w, v.e0.z - d.j_lo);
+                s_ent0[threadIdx.x] = e;
+                if (v.e0.w & SE_WIDE) my_wide = 1;
+            }
+            if (threadIdx.x < d.en_nk) {
+                v4i_t e; e.x = v.f0.x; e.y = v.f0.y;
+                e.z = (int)rebase_mask((uint32_t)v.f1.x, (uint32_t)v.f1.y, v.f0.z - d.j_lo);
+                e.w = (int)rebase_mask((uint32_t)v.f1.z, (uint32_t)v.f1.w, v.f0.z - d.j_lo);
+                s_ent1[threadIdx.x] = e;
+                if (v.f0.w & SE_WIDE) my_wide = 1;
+            }
+            if (d.nbk > 0) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int i = (int)threadIdx.x + q * TILE_THREADS;
-                if (i <= d.nbk) { s_dir[0][i] = g_d[0][q] - d.st_r0; s_dir[1][i] = g_d[1][q] - d.en_r0; s_rdir[i] = g_d[2][q] - d.st_r0; }
+                for (int q = 0; q < 2; ++q) {
+                    const int i = (int)threadIdx.x + q * TILE_THREADS;
+                    if (i <= d.nbk) { s_dir0[i] = v.dd[0][q] - d.st_r0; s_dir1[i] = v.dd[1][q] - d.en_r0; s_rdir[i] = v.dd[2][q] - d.st_r0; }
+                }
             }
         }
-    }
-    const int any_wide = __syncthreads_or(my_wide);
-    L2R_STAMP(1);
+        const bool rev_in = v.rev != 0;
+        const int any_wide = __syncthreads_or(my_wide);
+        // ---- the next tile's vectors start their trip now; they are not needed before the top of the next round
+        if (has_next) v = load_vectors(a, t_next, u_next, REGION_WORDS);
+        L2R_STAMP(1);
 
-    // ---- phase 2: classification
-    uint32_t info = 0; int ref = -1;
-    bool redo = active && (!fast || !in_lds || any_wide != 0 || tid != d.tid || (n > 1 && !sane));
-    const bool work = active && !redo;
-    const int *S = s_S + local, *E = s_E + local;
-    uint32_t *W = s_W + local;
-    uint32_t vpre = 0, lmask = 0, rmask = 0, k1mask = 0;
-    {
-        // V': transcripts j >= j0 up to the first one the read lies before (:799-800), minus the ones that lie
-        // before the read (:801); wave-uniform j, header words broadcast from LDS
-        const int jrel0 = j0 - d.j_lo;
-        bool stopped = !work;
-        for (int j = 0; j < w_n; ++j) {
-            const int4 hk = s_hk[j];
-            const bool act = !stopped && j >= jrel0;
-            const bool aft = re.el <= hk.x;                                     // comp_trans <= (Q5)
-            stopped = stopped || (act && aft);
-            const bool ov = act && !aft && !(hk.y <= re.s0);
-            if (!__any(ov)) { if (__all(stopped)) break; continue; }
-            const uint32_t bit = 1u << j;
-            if (ov) vpre |= bit;
-            const int4 hx = s_hx[j];
-            if (LEVEL == 1) {
-                if (ov && re.e0 == hx.y) lmask |= bit;
-                if (ov && re.sl == hx.z) rmask |= bit;
-            } else if (LEVEL >= 2 && LEVEL <= 4) {
-                if (ov && closed_overlap(re.s0, re.e0, hx.x, hx.y)) lmask |= bit;
-                if (LEVEL != 4 && ov && closed_overlap(re.sl, re.el, hx.z, hx.w)) rmask |= bit;
-            }
-            if (hk.z == 1) {                 // single-exon transcript: :806-811, only against single-exon reads
-                if (ov && n == 1 && overlap_frac(re.s0, re.e0, hx.x, hx.y) >= p.frac) k1mask |= bit;
-            } else if (!((hk.w & 0xff) & TX_COMPACT)) {
-                if (ov && n > 1) redo = true;                                   // literal loops needed for this pair
-            }
-        }
-        // the sweep must have ended inside the window
-        if (work && !stopped && d.j_lo + w_n < p.n_tx) redo = true;
-    }
-    L2R_STAMP(2);
-    uint32_t kand = 0xffffffffu, kor = 0u, dm_first = 0u, am_last = 0u;
-    {
-        // one START and one END probe per exon; the wave runs as many rounds as its longest read has exons.
-        // Per round: {next exon, both bucket ranges} are read together, then the first two entries of both buckets.
-        const bool mapping = work && !redo && n > 1;
-        const uint32_t *dS = s_dir[0], *dE = s_dir[1];
-        const v4i_t *eS = s_ent[0], *eE = s_ent[1];
-        int s = 0, e = 0;
-        if (mapping) { s = S[0]; e = E[0]; }
-        for (int k = 0; __any(mapping && k < (int)n); ++k) {
-            const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
-            const uint32_t inext = junc ? local + (uint32_t)k + 1u : 0u;
-            const int bs = s >> SITE_SHIFT, be = e >> SITE_SHIFT;
-            const bool vs = live && bs < d.nb, ve = junc && be < d.nb;
-            const int is = vs ? bs + d.b_off : 0, ie = ve ? be + d.b_off : 0;
-            const int s2 = s_S[inext], e2 = s_E[inext];
-            const uint32_t ls = dS[is], hs0 = dS[is + 1], le = dE[ie], he0 = dE[ie + 1];
-            const uint32_t hs = vs ? hs0 : ls, he = ve ? he0 : le;          // no bucket -> empty range
-            const v4i_t qs0 = lds_entry(eS, min(ls, (uint32_t)KEY_CAP - 1u)), qs1 = lds_entry(eS, min(ls + 1u, (uint32_t)KEY_CAP - 1u));
-            const v4i_t qe0 = lds_entry(eE, min(le, (uint32_t)KEY_CAP - 1u)), qe1 = lds_entry(eE, min(le + 1u, (uint32_t)KEY_CAP - 1u));
-            uint32_t xm, am, jm, dm;
-            probe2(qs0, qs1, ls, hs, s, e, xm, am);
-            probe2(qe0, qe1, le, he, e, s2, jm, dm);
-            if (__any(hs > ls + 2u || he > le + 2u)) { probe_rest(eS, ls, hs, s, e, xm, am); probe_rest(eE, le, he, e, s2, jm, dm); }
-            uint32_t word = min((uint32_t)__ffs((int)(xm & vpre)) - 1u, 0x7fu);
-            word |= min((uint32_t)__ffs((int)(dm & vpre)) - 1u, 0x7fu) << 8;       // without a junction: dm = am... = 0 -> 0x7f
-            word |= min((uint32_t)__ffs((int)((junc ? am : 0u) & vpre)) - 1u, 0x7fu) << 16;
-            word |= min((uint32_t)__ffs((int)(jm & vpre)) - 1u, 0x7fu) << 24;
-            if (junc) {
-                kand &= am & dm;                          // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
-                kor |= am | dm;
-                if (k == 0) dm_first = dm;
-            } else if (live) am_last = am;                // transcripts in which the last exon's start begins a later exon
-            if (live) W[k] = word;
-            s = s2; e = e2;
-        }
-    }
-    L2R_STAMP(3);
-    if (work && !redo) {
-        // ---- first known transcript in visiting order
-        int jstar = -1;
-        if (n > 1) {
-            // every probed site is in the transcript; known also needs every read site inside the overlap span:
-            // donors e_0..e_{n-2} and acceptors s_1..s_{n-1} increase, so e_0 >= a.start and s_{n-1} <= a.end suffice
-            uint32_t c = kand & vpre;
-            while (c) {
-                const int j = __ffs((int)c) - 1;
-                c &= c - 1u;
-                const int4 hk = s_hk[j];
-                if (hk.x <= re.e0 && re.sl <= hk.y) { jstar = j; break; }
-            }
-        } else if (k1mask) jstar = __ffs((int)k1mask) - 1;
-        const bool known = jstar >= 0;
-        const uint32_t V = known ? (vpre & ((2u << jstar) - 1u)) : vpre;
-        const uint32_t ks = (n > 1) ? (kor & V) : 0u;
-        const bool ksite = (ks & ~(known ? (1u << jstar) : 0u)) != 0u;
-        int jref = -1;
-        if (n > 1) { if (ks) jref = 31 - __clz((int)ks); }
-        else jref = jstar;
-        // ---- full-length evidence (:629-681) over V.  lfull: the first exon of a member of V overlaps the read's
-        // first exon.  lnoth stays set unless SOME exon of a member of V overlaps it; that is certain when the
-        // read's first donor is a donor of a member (the exon that ends there), else the START slice decides.
-        bool lfull = false, rfull = false, lnoth = true, rnoth = true;
-        if (LEVEL >= 1 && LEVEL <= 4) { lfull = (lmask & V) != 0u; rfull = (rmask & V) != 0u; }
-        if (LEVEL == 3 || LEVEL == 4) {
-            if (!lfull) {
-                if (dm_first & V) lnoth = false;
-                else if (V) lnoth = (overlapping_exon_members(s_rdir, s_dir[0], s_ent[0], d.b_off, d.nb, re.s0, re.e0) & V) == 0u;
-            }
-            if (LEVEL == 3 && !rfull) {
-                if (am_last & V) rnoth = false;
-                else if (V) rnoth = (overlapping_exon_members(s_rdir, s_dir[0], s_ent[0], d.b_off, d.nb, re.sl, re.el) & V) == 0u;
-            }
-        }
-        // ---- flags: a site is no longer novel iff the first member of V' that has it comes no later than j*
+        // ---- phase 2: classification
+        uint32_t info = 0; int ref = -1;
+        bool redo = active && (!fast || !in_lds || any_wide != 0 || tid != d.tid || (n > 1 && !sane));
+        const bool work = active && !redo;
+        const int *S = s_S + local, *E = s_E + local;
+        uint32_t *W = s_W + local;
+        uint32_t vpre = 0, lmask = 0, rmask = 0, k1mask = 0;
         {
-            const uint32_t lim = known ? (uint32_t)jstar : 63u;
-            const uint32_t add = (127u - lim) * 0x01010101u;
-            for (int k = 0; k < (int)n; ++k) {
-                uint32_t f;
-                if (n > 1) {
-                    const uint32_t hb = ((W[k] + add) >> 7) & 0x01010101u;       // byte > lim  ->  still novel
-                    f = (hb & 1u) | ((hb >> 7) & 2u) | ((hb >> 14) & 4u) | ((hb >> 21) & 8u);
-                    if (k + 1 == (int)n) f &= 1u;
-                } else f = F_EXON;
-                W[k] = f;
+            // V': transcripts j >= j0 up to the first one the read lies before (:799-800), minus the ones that lie
+            // before the read (:801); wave-uniform j, header words broadcast from LDS
+            const int jrel0 = j0 - d.j_lo;
+            bool stopped = !work;
+            for (int j = 0; j < w_n; ++j) {
+                const int4 hk = s_hk[j];
+                const bool act = !stopped && j >= jrel0;
+                const bool aft = re.el <= hk.x;                                     // comp_trans <= (Q5)
+                stopped = stopped || (act && aft);
+                const bool ov = act && !aft && !(hk.y <= re.s0);
+                if (!__any(ov)) { if (__all(stopped)) break; continue; }
+                const uint32_t bit = 1u << j;
+                if (ov) vpre |= bit;
+                const int4 hx = s_hx[j];
+                if (LEVEL == 1) {
+                    if (ov && re.e0 == hx.y) lmask |= bit;
+                    if (ov && re.sl == hx.z) rmask |= bit;
+                } else if (LEVEL >= 2 && LEVEL <= 4) {
+                    if (ov && closed_overlap(re.s0, re.e0, hx.x, hx.y)) lmask |= bit;
+                    if (LEVEL != 4 && ov && closed_overlap(re.sl, re.el, hx.z, hx.w)) rmask |= bit;
+                }
+                if (hk.z == 1) {                 // single-exon transcript: :806-811, only against single-exon reads
+                    if (ov && n == 1 && overlap_frac(re.s0, re.e0, hx.x, hx.y) >= p.frac) k1mask |= bit;
+                } else if (!((hk.w & 0xff) & TX_COMPACT)) {
+                    if (ov && n > 1) redo = true;                                   // literal loops needed for this pair
+                }
+            }
+            // the sweep must have ended inside the window
+            if (work && !stopped && d.j_lo + w_n < p.n_tx) redo = true;
+        }
+        L2R_STAMP(2);
+        uint32_t kand = 0xffffffffu, kor = 0u, dm_first = 0u, am_last = 0u;
+        {
+            // one START and one END probe per exon; the wave runs as many rounds as its longest read has exons.
+            // Per round: {next exon, both bucket ranges} are read together, then the first two entries of both buckets.
+            const bool mapping = work && !redo && n > 1;
+            const uint32_t *dS = s_dir0, *dE = s_dir1;
+            const v4i_t *eS = s_ent0, *eE = s_ent1;
+            int s = 0, e = 0;
+            if (mapping) { s = S[0]; e = E[0]; }
+            for (int k = 0; __any(mapping && k < (int)n); ++k) {
+                const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
+                const uint32_t inext = junc ? local + (uint32_t)k + 1u : 0u;
+                const int bs = s >> SITE_SHIFT, be = e >> SITE_SHIFT;
+                const bool vs = live && bs < d.nb, ve = junc && be < d.nb;
+                const int is = vs ? bs + d.b_off : 0, ie = ve ? be + d.b_off : 0;
+                const int s2 = s_S[inext], e2 = s_E[inext];
+                const uint32_t ls = dS[is], hs0 = dS[is + 1], le = dE[ie], he0 = dE[ie + 1];
+                const uint32_t hs = vs ? hs0 : ls, he = ve ? he0 : le;          // no bucket -> empty range
+                const v4i_t qs0 = lds_entry(eS, min(ls, (uint32_t)KEY_CAP - 1u)), qs1 = lds_entry(eS, min(ls + 1u, (uint32_t)KEY_CAP - 1u));
+                const v4i_t qe0 = lds_entry(eE, min(le, (uint32_t)KEY_CAP - 1u)), qe1 = lds_entry(eE, min(le + 1u, (uint32_t)KEY_CAP - 1u));
+                uint32_t xm, am, jm, dm;
+                probe2(qs0, qs1, ls, hs, s, e, xm, am);
+                probe2(qe0, qe1, le, he, e, s2, jm, dm);
+                if (__any(hs > ls + 2u || he > le + 2u)) { probe_rest(eS, ls, hs, s, e, xm, am); probe_rest(eE, le, he, e, s2, jm, dm); }
+                uint32_t word = min((uint32_t)__ffs((int)(xm & vpre)) - 1u, 0x7fu);
+                word |= min((uint32_t)__ffs((int)(dm & vpre)) - 1u, 0x7fu) << 8;       // without a junction: dm = jm = 0 -> 0x7f
+                word |= min((uint32_t)__ffs((int)((junc ? am : 0u) & vpre)) - 1u, 0x7fu) << 16;
+                word |= min((uint32_t)__ffs((int)(jm & vpre)) - 1u, 0x7fu) << 24;
+                if (junc) {
+                    kand &= am & dm;                          // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
+                    kor |= am | dm;
+                    if (k == 0) dm_first = dm;
+                } else if (live) am_last = am;                // transcripts in which the last exon's start begins a later exon
+                if (live) W[k] = word;
+                s = s2; e = e2;
             }
         }
-        bool out_rev = a.r_rev[r] != 0;
-        if (jref >= 0) { ref = d.j_lo + jref; out_rev = ((s_hk[jref].w >> 8) & 1) != 0; }     // :825-831
-        if (known) info |= I_KNOWN;
-        if (ksite) info |= I_KSITE;
-        if (full_decision(LEVEL, lfull, lnoth, rfull, rnoth)) info |= I_FULL;
-        if (out_rev) info |= I_REV;
-        info = finish_info(info, (int)n, p);
-    } else if (active) {
-        info = n << 8;
-        if (in_lds) for (int k = 0; k < (int)n; ++k) W[k] = 0u;
-    }
-    L2R_STAMP(4);
+        L2R_STAMP(3);
+        if (work && !redo) {
+            // ---- first known transcript in visiting order
+            int jstar = -1;
+            if (n > 1) {
+                // every probed site is in the transcript; known also needs every read site inside the overlap span:
+                // donors e_0..e_{n-2} and acceptors s_1..s_{n-1} increase, so e_0 >= a.start and s_{n-1} <= a.end suffice
+                uint32_t c = kand & vpre;
+                while (c) {
+                    const int j = __ffs((int)c) - 1;
+                    c &= c - 1u;
+                    const int4 hk = s_hk[j];
+                    if (hk.x <= re.e0 && re.sl <= hk.y) { jstar = j; break; }
+                }
+            } else if (k1mask) jstar = __ffs((int)k1mask) - 1;
+            const bool known = jstar >= 0;
+            const uint32_t V = known ? (vpre & ((2u << jstar) - 1u)) : vpre;
+            const uint32_t ks = (n > 1) ? (kor & V) : 0u;
+            const bool ksite = (ks & ~(known ? (1u << jstar) : 0u)) != 0u;
+            int jref = -1;
+            if (n > 1) { if (ks) jref = 31 - __clz((int)ks); }
+            else jref = jstar;
+            // ---- full-length evidence (:629-681) over V.  lfull: the first exon of a member of V overlaps the read's
+            // first exon.  lnoth stays set unless SOME exon of a member of V overlaps it; that is certain when the
+            // read's first donor is a donor of a member (the exon that ends there), else the START slice decides.
+            bool lfull = false, rfull = false, lnoth = true, rnoth = true;
+            if (LEVEL >= 1 && LEVEL <= 4) { lfull = (lmask & V) != 0u; rfull = (rmask & V) != 0u; }
+            if (LEVEL == 3 || LEVEL == 4) {
+                if (!lfull) {
+                    if (dm_first & V) lnoth = false;
+                    else if (V) lnoth = (overlapping_exon_members(s_rdir, s_dir0, s_ent0, d.b_off, d.nb, re.s0, re.e0) & V) == 0u;
+                }
+                if (LEVEL == 3 && !rfull) {
+                    if (am_last & V) rnoth = false;
+                    else if (V) rnoth = (overlapping_exon_members(s_rdir, s_dir0, s_ent0, d.b_off, d.nb, re.sl, re.el) & V) == 0u;
+                }
+            }
+            // ---- flags: a site is no longer novel iff the first member of V' that has it comes no later than j*
+            {
+                const uint32_t lim = known ? (uint32_t)jstar : 63u;
+                const uint32_t add = (127u - lim) * 0x01010101u;
+                for (int k = 0; k < (int)n; ++k) {
+                    uint32_t f;
+                    if (n > 1) {
+                        const uint32_t hb = ((W[k] + add) >> 7) & 0x01010101u;       // byte > lim  ->  still novel
+                        f = (hb & 1u) | ((hb >> 7) & 2u) | ((hb >> 14) & 4u) | ((hb >> 21) & 8u);
+                        if (k + 1 == (int)n) f &= 1u;
+                    } else f = F_EXON;
+                    W[k] = f;
+                }
+            }
+            bool out_rev = rev_in;
+            if (jref >= 0) { ref = d.j_lo + jref; out_rev = ((s_hk[jref].w >> 8) & 1) != 0; }     // :825-831
+            if (known) info |= I_KNOWN;
+            if (ksite) info |= I_KSITE;
+            if (full_decision(LEVEL, lfull, lnoth, rfull, rnoth)) info |= I_FULL;
+            if (out_rev) info |= I_REV;
+            info = finish_info(info, (int)n, p);
+        } else if (active) {
+            info = n << 8;
+            if (in_lds) for (int k = 0; k < (int)n; ++k) W[k] = 0u;
+        }
+        L2R_STAMP(4);
 
-    // ---- phase 3: redo list, accepted counts, coalesced write-out of the tile
-    redo = redo && active;
-    {
-        const unsigned long long m = __ballot(redo);
-        if (m) {
-            uint32_t at = 0;
-            if (lane == 0) at = atomicAdd(a.redo_count, (uint32_t)__popcll(m));
-            at = __shfl(at, 0, WAVE);
-            if (redo) a.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+        // ---- phase 3: redo list, accepted counts, coalesced write-out of the tile
+        redo = redo && active;
+        {
+            const unsigned long long m = __ballot(redo);
+            if (m) {
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(a.redo_count, (uint32_t)__popcll(m));
+                at = __shfl(at, 0, WAVE);
+                if (redo) a.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+            }
+            const bool acc = (info & I_ACCEPT) != 0;
+            const uint32_t ca = (uint32_t)__popcll(__ballot(acc)), cx = wave_sum(acc ? n : 0u);
+            if (lane == 0) { s_cnt[wv][0] = ca; s_cnt[wv][1] = cx; }
         }
-        const bool acc = (info & I_ACCEPT) != 0;
-        const uint32_t ca = (uint32_t)__popcll(__ballot(acc)), cx = wave_sum(acc ? n : 0u);
-        if (lane == 0) { s_cnt[wv][0] = ca; s_cnt[wv][1] = cx; }
-    }
-    __syncthreads();
-    L2R_STAMP(5);
-    if (threadIdx.x == 0) {
-        a.tile_acc[blockIdx.x] = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
-        a.tile_acc_ex[blockIdx.x] = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
-    }
-    if (in_lds) {
-        for (uint32_t i = threadIdx.x; i < tile_total; i += TILE_THREADS) {
-            a.ex_start[base + i] = s_S[i];
-            a.ex_end[base + i] = s_E[i];
-            a.ex_flag[base + i] = (uint8_t)s_W[i];
+        __syncthreads();
+        L2R_STAMP(5);
+        if (threadIdx.x == 0) {
+            a.tile_acc[t] = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+            a.tile_acc_ex[t] = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
         }
+        if (in_lds) {
+            for (uint32_t i = threadIdx.x; i < tile_total; i += TILE_THREADS) {
+                a.ex_start[base + i] = s_S[i];
+                a.ex_end[base + i] = s_E[i];
+                a.ex_flag[base + i] = (uint8_t)s_W[i];
+            }
+        }
+        if (active) {
+            a.ex_off[r] = base + local;
+            a.info[r] = info;
+            a.ref_tx[r] = ref;
+        }
+        __syncthreads();                 // the tile's LDS image has been written out: the next tile may overwrite it
+        L2R_STAMP(6);
+        u = u_next;
     }
-    if (active) {
-        a.ex_off[r] = base + local;
-        a.info[r] = info;
-        a.ref_tx[r] = ref;
-    }
-    L2R_STAMP(6);
 #undef L2R_STAMP
 }
 
