@@ -51,7 +51,7 @@ struct DevBuf {
 
 struct l2r_ctx {
     int device = 0;
-    int n_cu = 256, wg_per_cu = 3;          // persistent grid of k_classify_fast (L2R_WG_PER_CU overrides)
+    int n_cu = 256, wg_per_cu = 4;          // persistent grid of k_classify_fast (L2R_WG_PER_CU overrides)
     hipStream_t stream = nullptr;
     l2r_params prm;
     // annotation
@@ -86,6 +86,7 @@ struct l2r_ctx {
     int64_t n_tiles = 0, n_tiles256 = 0;
     DevBuf<uint32_t> local, tile_base, ex_off, info, tile_acc, tile_acc_ex, totals;  // totals[0]=exons [1]=accepted [2]=accepted exons [3]=redo count
     DevBuf<uint32_t> redo;                  // reads the fast kernel hands to the generic one
+    DevBuf<uint8_t> order;                  // per tile: reads by falling exon count (pass A)
     DevBuf<TileDesc> desc;
     DevBuf<int32_t> ex_start, ex_end, ref_tx;
     DevBuf<uint8_t> ex_flag;
@@ -158,7 +159,7 @@ void l2r_destroy(l2r_ctx *c)
     c->sj_tid.release(); c->sj_don.release(); c->sj_acc.release(); c->sj_uniq.release(); c->sj_multi.release(); c->sj_key.release();
     c->r_tid.release(); c->r_pos.release(); c->r_rev.release(); c->cig_off.release(); c->cig.release();
     c->win_start.release(); c->sj_cursor.release();
-    c->local.release(); c->redo.release(); c->desc.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->totals.release();
+    c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -452,7 +453,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     // work buffers.  n_exon(read) <= ops(read) + 1, so n_cigar + n_reads bounds the exon arrays.
     const size_t exb = (size_t)r->n_cigar + (size_t)N;
     if (c->j0.ensure((size_t)N) || c->local.ensure((size_t)N + 1) || c->ex_off.ensure((size_t)N) || c->info.ensure((size_t)N) || c->ref_tx.ensure((size_t)N) ||
-        c->redo.ensure((size_t)N) || c->desc.ensure((size_t)c->n_tiles) ||
+        c->redo.ensure((size_t)N) || c->order.ensure((size_t)c->n_tiles * TILE_THREADS) || c->desc.ensure((size_t)c->n_tiles) ||
         c->tile_base.ensure((size_t)c->n_tiles + 1) || c->tile_acc.ensure((size_t)c->n_tiles + 1) || c->tile_acc_ex.ensure((size_t)c->n_tiles + 1) ||
         c->totals.ensure(4) || c->ex_start.ensure(exb) || c->ex_end.ensure(exb) || c->ex_flag.ensure(exb) ||
         c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
@@ -513,7 +514,7 @@ static int prepare_unsorted_sj_cursor(l2r_ctx *c)
 
 enum { ST_PASS_A = 0, ST_SCAN1, ST_FAST, ST_GENERIC, ST_SJ, ST_SCAN2, ST_GATHER, ST_N };
 
-#define launch_fast_level(L, fa, grid, s) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles)
+#define launch_fast_level(L, fa, grid, s) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles, (const TileDesc *)c->desc.p, (const uint32_t *)c->tile_base.p, (const int64_t *)c->cig_off.p)
 
 static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
 {
@@ -528,7 +529,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     const SiteTabs tabs{{c->sk_st.p, c->sd_st.p, c->sr_st.p}, {c->sk_en.p, c->sd_en.p, nullptr}, c->tid_base.p, c->n_tid_dir};
     // sorted input: the cursor value of every read is computed on the device; unsorted input: it was replayed on the host
     hipLaunchKernelGGL(k_pass_a, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, tabs, p,
-                       (c->sorted ? (const int32_t *)nullptr : (const int32_t *)c->win_start.p), c->j0.p, c->local.p, c->tile_base.p, c->desc.p,
+                       (c->sorted ? (const int32_t *)nullptr : (const int32_t *)c->win_start.p), c->j0.p, c->local.p, c->order.p, c->tile_base.p, c->desc.p,
                        c->totals.p + 3);
     MARK(ST_SCAN1);
     {
@@ -539,7 +540,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     {
         FastArgs fa;
         fa.n_reads = N; fa.r_tid = c->r_tid.p; fa.r_pos = c->r_pos.p; fa.r_rev = c->r_rev.p; fa.cig_off = c->cig_off.p; fa.cig = c->cig.p;
-        fa.local = c->local.p; fa.tile_base = c->tile_base.p; fa.j0 = j0; fa.desc = c->desc.p;
+        fa.local = c->local.p; fa.order = c->order.p; fa.tile_base = c->tile_base.p; fa.j0 = j0; fa.desc = c->desc.p;
         fa.hdr = c->hdr.p; fa.st = tabs.st; fa.en = tabs.en;
         fa.ex_off = c->ex_off.p; fa.ex_start = c->ex_start.p; fa.ex_end = c->ex_end.p; fa.ex_flag = c->ex_flag.p; fa.info = c->info.p; fa.ref_tx = c->ref_tx.p;
         fa.tile_acc = c->tile_acc.p; fa.tile_acc_ex = c->tile_acc_ex.p; fa.redo_count = c->totals.p + 3; fa.redo = c->redo.p;

@@ -27,9 +27,9 @@ namespace l2r {
 
 constexpr int TILE_THREADS = 256;
 constexpr int WAVE = 64;
-constexpr int LDS_EXON_CAP = 3072;      // exons of one tile staged in LDS (12 B each)
+constexpr int LDS_EXON_CAP = 3072;      // exons of one tile staged in LDS (10 B each)
 constexpr int DIR_CAP = 384;            // 512-bp buckets staged per tile (span up to ~196 kb)
-constexpr int KEY_CAP = 256;            // dictionary entries staged per dictionary and tile
+constexpr int KEY_CAP = 224;            // dictionary entries staged per dictionary and tile (threads 224..255 stage the headers)
 constexpr int WIN_TX = 32;              // annotation transcripts in a tile's window = bits of a membership mask
 constexpr int SITE_SHIFT = 9;
 
@@ -207,11 +207,13 @@ __global__ __launch_bounds__(TILE_THREADS)
 void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t *__restrict__ r_pos,
               const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ cig, CursorDir cd, SiteTabs tabs, DevParams p,
               const int32_t *__restrict__ j0_in, int32_t *__restrict__ j0_out, uint32_t *__restrict__ local_out,
-              uint32_t *__restrict__ tile_sum, TileDesc *__restrict__ desc, uint32_t *__restrict__ redo_count)
+              uint8_t *__restrict__ order_out, uint32_t *__restrict__ tile_sum, TileDesc *__restrict__ desc, uint32_t *__restrict__ redo_count)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ int s_red[4][3];
     __shared__ int s_tid0;
+    __shared__ uint32_t s_hist[WAVE];
+    if (threadIdx.x < WAVE) s_hist[threadIdx.x] = 0u;
     const int64_t r = (int64_t)blockIdx.x * p.reads_per_tile + threadIdx.x;
     const bool active = (int)threadIdx.x < p.reads_per_tile && r < n_reads;
     if (blockIdx.x == 0 && threadIdx.x == 0) *redo_count = 0u;         // the classification kernels run after this one
@@ -230,6 +232,16 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
     uint32_t total;
     const uint32_t local = block_exclusive_scan(n, s_wave, total);
     if (active) local_out[r] = local;
+    {   // Order of the tile's reads by falling exon count (counting sort, ties in arrival order): the classification
+        // kernel gives read order_out[slot] to thread `slot`, so the reads of a wave need about the same number of
+        // rounds in its per-exon loops.  Results do not depend on the order: every read owns its output slots.
+        const uint32_t bin = (uint32_t)(WAVE - 1) - min(n, (uint32_t)(WAVE - 1));      // inactive threads (n = 0) sort last
+        const uint32_t rank = atomicAdd(&s_hist[bin], 1u);
+        __syncthreads();
+        if (threadIdx.x < WAVE) { const uint32_t c = s_hist[threadIdx.x]; s_hist[threadIdx.x] = wave_inclusive_scan(c) - c; }
+        __syncthreads();
+        if (active) order_out[(int64_t)blockIdx.x * p.reads_per_tile + s_hist[bin] + rank] = (uint8_t)threadIdx.x;
+    }
     // the tile's chromosome is the one of its first read; reads on another one go to the generic kernel
     const int tid0 = s_tid0;
     int tb = 0, nb = 0;
@@ -518,7 +530,7 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));    // LDS copy of a dicti
 struct FastArgs {
     int64_t n_reads;
     const int32_t *r_tid; const int32_t *r_pos; const uint8_t *r_rev; const int64_t *cig_off; const uint32_t *cig;
-    const uint32_t *local; const uint32_t *tile_base; const int32_t *j0; const TileDesc *desc;
+    const uint32_t *local; const uint8_t *order; const uint32_t *tile_base; const int32_t *j0; const TileDesc *desc;
     const TxHdr *hdr; SiteDict st, en;
     uint32_t *ex_off; int32_t *ex_start; int32_t *ex_end; uint8_t *ex_flag; uint32_t *info; int32_t *ref_tx;
     uint32_t *tile_acc, *tile_acc_ex; uint32_t *redo_count, *redo;
@@ -547,9 +559,9 @@ __device__ __forceinline__ void probe2(const v4i_t q0, const v4i_t q1, uint32_t 
     pm = (m1 && q1.y == k2) ? (uint32_t)q1.z : ((m0 && q0.y == k2) ? (uint32_t)q0.z : 0u);
 }
 
-__device__ __forceinline__ void probe_rest(const v4i_t *ent, uint32_t lo, uint32_t hi, int32_t k1, int32_t k2, uint32_t &pm, uint32_t &sm)
+__device__ __forceinline__ void probe_rest(const v4i_t *ent, uint32_t lo, uint32_t hi, int32_t k1, int32_t k2, uint32_t &pm, uint32_t &sm, uint32_t)
 {
-    for (uint32_t r = lo + 2u; r < hi; ++r) {
+    for (uint32_t r = lo; r < hi; ++r) {
         const v4i_t q = lds_entry(ent, r);
         if (q.x == k1) { sm = (uint32_t)q.w; if (q.y == k2) pm = (uint32_t)q.z; }
     }
@@ -557,7 +569,7 @@ __device__ __forceinline__ void probe_rest(const v4i_t *ent, uint32_t lo, uint32
 
 // Transcripts (tile frame) that have an exon overlapping [s, e]: union of the exon masks of the START entries
 // from the first one that reaches into the bucket of s up to the last one that starts in the bucket of e.
-__device__ __forceinline__ uint32_t overlapping_exon_members(const uint32_t *rdir, const uint32_t *dir, const v4i_t *ent,
+__device__ __forceinline__ uint32_t overlapping_exon_members(const uint8_t *rdir, const uint8_t *dir, const v4i_t *ent,
                                                              int b_off, int nb, int s, int e)
 {
     const int bs = s >> SITE_SHIFT;
@@ -579,11 +591,15 @@ __device__ __forceinline__ uint32_t overlapping_exon_members(const uint32_t *rdi
 //                                                     issued after tile t has staged its own dictionary
 //     ... consumed (registers -> LDS) at the top of tile t+G.
 constexpr int PF_CIG_VEC = 4;                              // 16-byte CIGAR vectors a thread holds for the next tile
+constexpr int FAST_DIR_BYTES = (DIR_CAP + 2 + 3) & ~3;
+constexpr int FAST_TAIL_WORDS = LDS_EXON_CAP / 2 + 2 * KEY_CAP * 4 + 3 * FAST_DIR_BYTES / 4;
+constexpr int FAST_ALL_WORDS = 2 * LDS_EXON_CAP + FAST_TAIL_WORDS;
 
-struct TileUniforms {                                       // wave-uniform inputs of a tile
+struct TileUniforms {                                       // wave-uniform inputs of a tile ...
     TileDesc d;
     uint32_t base, total;
     int64_t c0, c1;                                         // the tile's CIGAR words [c0, c1)
+    int32_t src;                                            // ... and the thread's read of the tile (pass A's order), -1: none
 };
 
 struct TileVectors {                                        // per-thread raw inputs of a tile
@@ -591,22 +607,32 @@ struct TileVectors {                                        // per-thread raw in
     int64_t c_lo, c_hi;
     int32_t pos, j0, tid, rev;
     uint4 cg[PF_CIG_VEC];
-    int4 h0, h1, h2, e0, e1, f0, f1;
+    int4 xa, xb, xc, xd;        // threads < KEY_CAP: START entry (xa, xb) and END entry (xc, xd); threads >= KEY_CAP: header words (xa, xb, xc)
     uint32_t dd[3][2];
 };
 
-__device__ __forceinline__ TileUniforms load_uniforms(const FastArgs &a, int64_t t)
+// (the three arrays come in as __restrict__ kernel parameters of their own, so that these are scalar loads that
+//  wait at their first use, not vector loads that wait where they are issued)
+__device__ __forceinline__ TileUniforms load_uniforms(const FastArgs &a, const TileDesc *__restrict__ desc, const uint32_t *__restrict__ tile_base,
+                                                     const int64_t *__restrict__ cig_off, int64_t t)
 {
     TileUniforms u;
     const int64_t r0 = t * a.p.reads_per_tile, r1 = min(r0 + a.p.reads_per_tile, a.n_reads);
-    u.d = a.desc[t];
-    u.base = a.tile_base[t]; u.total = a.tile_base[t + 1] - u.base;
-    u.c0 = a.cig_off[r0]; u.c1 = a.cig_off[r1];
+    u.d = desc[t];
+    u.base = tile_base[t]; u.total = tile_base[t + 1] - u.base;
+    u.c0 = cig_off[r0]; u.c1 = cig_off[r1];
+    u.src = (int64_t)threadIdx.x < r1 - r0 ? (int32_t)a.order[r0 + threadIdx.x] : -1;
     return u;
 }
 
 // CIGAR staging geometry: the copy starts at the 16-byte boundary below c0 (the array is padded at its end)
 __device__ __forceinline__ int cigar_vectors(const TileUniforms &u) { return (int)((u.c1 - (u.c0 & ~(int64_t)3) + 3) >> 2); }
+// LDS words left for the CIGAR of a tile behind its S and E arrays (layout in k_classify_fast)
+__device__ __forceinline__ int cigar_room(const TileUniforms &u)
+{
+    const uint32_t lay = u.total <= (uint32_t)LDS_EXON_CAP ? u.total : 0u;
+    return FAST_ALL_WORDS - (int)((2u * lay + 3u) & ~3u);
+}
 __device__ __forceinline__ bool cigar_staged(const TileUniforms &u, int region_words)
 {
     const int n4 = cigar_vectors(u);
@@ -617,12 +643,12 @@ __device__ __forceinline__ TileVectors load_vectors(const FastArgs &a, int64_t t
 {
     TileVectors v;
     const DevParams &p = a.p;
-    const int64_t r = t * p.reads_per_tile + threadIdx.x;
-    const bool active = (int)threadIdx.x < p.reads_per_tile && r < a.n_reads;
+    const int64_t r = t * p.reads_per_tile + u.src;
+    const bool active = u.src >= 0;
     v.local = 0; v.nxt = 0; v.c_lo = 0; v.c_hi = 0; v.pos = 0; v.j0 = 0; v.tid = 0; v.rev = 0;
     if (active) {
         v.local = a.local[r];
-        const bool last = (int)threadIdx.x + 1 == p.reads_per_tile || r + 1 == a.n_reads;
+        const bool last = u.src + 1 == p.reads_per_tile || r + 1 == a.n_reads;
         v.nxt = last ? u.total : a.local[r + 1];
         v.c_lo = a.cig_off[r]; v.c_hi = a.cig_off[r + 1];
         v.pos = a.r_pos[r]; v.tid = a.r_tid[r]; v.j0 = a.j0[r]; v.rev = a.r_rev[r];
@@ -639,13 +665,16 @@ __device__ __forceinline__ TileVectors load_vectors(const FastArgs &a, int64_t t
     const TileDesc &d = u.d;
     const bool fast = (d.flags & TD_FAST) != 0;
     const int w_n = fast ? min(WIN_TX, p.n_tx - d.j_lo) : 0;
-    v.h0 = v.h1 = v.h2 = v.e0 = v.e1 = v.f0 = v.f1 = make_int4(0, 0, 0, 0);
-    if ((int)threadIdx.x < w_n) {
-        const int4 *hp = reinterpret_cast<const int4 *>(a.hdr + d.j_lo + threadIdx.x);
-        v.h0 = hp[0]; v.h1 = hp[1]; v.h2 = hp[2];
+    v.xa = v.xb = v.xc = v.xd = make_int4(0, 0, 0, 0);
+    if ((int)threadIdx.x >= KEY_CAP) {
+        if ((int)threadIdx.x - KEY_CAP < w_n) {
+            const int4 *hp = reinterpret_cast<const int4 *>(a.hdr + d.j_lo + ((int)threadIdx.x - KEY_CAP));
+            v.xa = hp[0]; v.xb = hp[1]; v.xc = hp[2];
+        }
+    } else {
+        if (fast && threadIdx.x < d.st_nk) { const int4 *q = reinterpret_cast<const int4 *>(a.st.ent + d.st_r0 + threadIdx.x); v.xa = q[0]; v.xb = q[1]; }
+        if (fast && threadIdx.x < d.en_nk) { const int4 *q = reinterpret_cast<const int4 *>(a.en.ent + d.en_r0 + threadIdx.x); v.xc = q[0]; v.xd = q[1]; }
     }
-    if (fast && threadIdx.x < d.st_nk) { const int4 *q = reinterpret_cast<const int4 *>(a.st.ent + d.st_r0 + threadIdx.x); v.e0 = q[0]; v.e1 = q[1]; }
-    if (fast && threadIdx.x < d.en_nk) { const int4 *q = reinterpret_cast<const int4 *>(a.en.ent + d.en_r0 + threadIdx.x); v.f0 = q[0]; v.f1 = q[1]; }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int i = (int)threadIdx.x + q * TILE_THREADS;
@@ -656,25 +685,20 @@ __device__ __forceinline__ TileVectors load_vectors(const FastArgs &a, int64_t t
 }
 
 template <int LEVEL>
-__global__ __launch_bounds__(TILE_THREADS, 3)
-void k_classify_fast(FastArgs a, int64_t n_tiles)
+__global__ __launch_bounds__(TILE_THREADS, 4)
+void k_classify_fast(FastArgs a, int64_t n_tiles, const TileDesc *__restrict__ u_desc, const uint32_t *__restrict__ u_tile_base,
+                     const int64_t *__restrict__ u_cig_off)
 {
-    __shared__ int s_S[LDS_EXON_CAP];
-    __shared__ int s_E[LDS_EXON_CAP];
-    // One region, used twice per tile: first the tile's CIGAR words (phase 1), then
-    //   s_W    per exon: first-visit bytes, then the flag byte
-    //   s_ent  dictionary entries {k1, k2, pm, sm} (START, END)
-    //   s_dir  entry index relative to the slice, per staged bucket (START, END); s_rdir: START reach-back
-    constexpr int DIR_WORDS = DIR_CAP + 2;
-    constexpr int REGION_WORDS = (LDS_EXON_CAP + 3 * DIR_WORDS + 2 * KEY_CAP * 4 + 3) & ~3;
-    __shared__ __attribute__((aligned(16))) uint32_t s_region[REGION_WORDS];
-    uint32_t *const s_W = s_region;
-    v4i_t *const s_ent0 = reinterpret_cast<v4i_t *>(s_region + LDS_EXON_CAP);           // LDS_EXON_CAP % 4 == 0
-    v4i_t *const s_ent1 = s_ent0 + KEY_CAP;
-    uint32_t *const s_dir0 = s_region + LDS_EXON_CAP + 2 * KEY_CAP * 4;
-    uint32_t *const s_dir1 = s_dir0 + DIR_WORDS;
-    uint32_t *const s_rdir = s_dir1 + DIR_WORDS;
-    uint32_t *const s_cig = s_region;
+    // One LDS array per workgroup, laid out per tile (total = the tile's exon count <= LDS_EXON_CAP):
+    //   [0, total)            S   exon starts            [total, 2 total)   E   exon ends
+    //   tail = 2 total rounded up to 4 words, at least TAIL_WORDS long, used twice:
+    //     phase 1: the tile's CIGAR words (when they fit; else the walk reads HBM)
+    //     then:    W     16 bits per exon: first member of V' with the exon / with the junction (6 bits each),
+    //                    "donor / acceptor not in V'" (1 bit each); later the flag byte
+    //              ent   dictionary entries {k1, k2, pm, sm} (START, END)
+    //              dir   entry index relative to the slice per staged bucket, 8 bits (START, END, START reach-back)
+    constexpr int DIR_BYTES = FAST_DIR_BYTES, W_WORDS = LDS_EXON_CAP / 2, ALL_WORDS = FAST_ALL_WORDS;
+    __shared__ __attribute__((aligned(16))) uint32_t s_all[ALL_WORDS];
     __shared__ __attribute__((aligned(16))) int4 s_hk[WIN_TX];     // {start, end, n, flags | rev << 8} on the tile's chromosome
     __shared__ __attribute__((aligned(16))) int4 s_hx[WIN_TX];     // {s0, e0, sl, el}
     __shared__ uint32_t s_cnt[4][2];
@@ -687,27 +711,35 @@ void k_classify_fast(FastArgs a, int64_t n_tiles)
 
     int64_t t = blockIdx.x;
     if (t >= n_tiles) return;
-    TileUniforms u = load_uniforms(a, t);
-    TileVectors v = load_vectors(a, t, u, REGION_WORDS);
+    TileUniforms u = load_uniforms(a, u_desc, u_tile_base, u_cig_off, t);
+    TileVectors v = load_vectors(a, t, u, cigar_room(u));
 
     for (; t < n_tiles; t += gridDim.x) {
         const int64_t t_next = t + gridDim.x;
         const bool has_next = t_next < n_tiles;
         TileUniforms u_next = u;
-        if (has_next) u_next = load_uniforms(a, t_next);
+        if (has_next) u_next = load_uniforms(a, u_desc, u_tile_base, u_cig_off, t_next);
 
-        const int64_t r = t * p.reads_per_tile + threadIdx.x;
-        const bool active = (int)threadIdx.x < p.reads_per_tile && r < a.n_reads;
+        const int64_t r = t * p.reads_per_tile + u.src;
+        const bool active = u.src >= 0;
         const TileDesc d = u.d;
         const uint32_t base = u.base, tile_total = u.total;
         const bool fast = (d.flags & TD_FAST) != 0;
         const bool in_lds = tile_total <= (uint32_t)LDS_EXON_CAP;
+        const uint32_t lay_total = in_lds ? tile_total : 0u;
+        int *const s_S = reinterpret_cast<int *>(s_all), *const s_E = s_S + lay_total;
+        const int tail_off = (int)((2u * lay_total + 3u) & ~3u), tail_words = ALL_WORDS - tail_off;
+        uint32_t *const s_cig = s_all + tail_off;
+        uint16_t *const s_W = reinterpret_cast<uint16_t *>(s_all + tail_off);
+        v4i_t *const s_ent0 = reinterpret_cast<v4i_t *>(s_all + tail_off + W_WORDS), *const s_ent1 = s_ent0 + KEY_CAP;
+        uint8_t *const s_dir0 = reinterpret_cast<uint8_t *>(s_all + tail_off + W_WORDS + 2 * KEY_CAP * 4);
+        uint8_t *const s_dir1 = s_dir0 + DIR_BYTES, *const s_rdir = s_dir1 + DIR_BYTES;
         const uint32_t local = v.local, n = active ? v.nxt - v.local : 0u;
         const int32_t pos = v.pos, j0 = v.j0, tid = v.tid;
         const int w_n = fast ? min(WIN_TX, p.n_tx - d.j_lo) : 0;          // transcripts in the window
 
         // ---- phase 0: the tile's CIGAR words, registers -> LDS
-        const bool staged = cigar_staged(u, REGION_WORDS);
+        const bool staged = cigar_staged(u, tail_words);
         if (staged) {
             const int n4 = cigar_vectors(u);
             uint4 *dst = reinterpret_cast<uint4 *>(s_cig);
@@ -743,40 +775,47 @@ void k_classify_fast(FastArgs a, int64_t n_tiles)
         // ---- stage the dictionary slices and the transcript window, re-based to the tile
         int my_wide = 0;
         if (fast) {
-            if ((int)threadIdx.x < w_n) {
-                // coordinates on another chromosome become -inf (before every read) / +inf (after every read)
-                int st = v.h0.y, en = v.h0.z;
-                if (v.h0.x < d.tid) { st = INT32_MIN; en = INT32_MIN; }
-                else if (v.h0.x > d.tid) { st = INT32_MAX; en = INT32_MAX; }
-                s_hk[threadIdx.x] = make_int4(st, en, v.h1.x, (v.h1.z & 0xff) | (v.h1.y << 8));
-                s_hx[threadIdx.x] = v.h2;
-            }
-            if (threadIdx.x < d.st_nk) {
-                v4i_t e; e.x = v.e0.x; e.y = v.e0.y;
-                e.z = (int)rebase_mask((uint32_t)v.e1.x, (uint32_t)v.e1.y, v.e0.z - d.j_lo);
-                e.w = (int)rebase_mask((uint32_t)v.e1.z, (uint32_t)v.e1.w, v.e0.z - d.j_lo);
-                s_ent0[threadIdx.x] = e;
-                if (v.e0.w & SE_WIDE) my_wide = 1;
-            }
-            if (threadIdx.x < d.en_nk) {
-                v4i_t e; e.x = v.f0.x; e.y = v.f0.y;
-                e.z = (int)rebase_mask((uint32_t)v.f1.x, (uint32_t)v.f1.y, v.f0.z - d.j_lo);
-                e.w = (int)rebase_mask((uint32_t)v.f1.z, (uint32_t)v.f1.w, v.f0.z - d.j_lo);
-                s_ent1[threadIdx.x] = e;
-                if (v.f0.w & SE_WIDE) my_wide = 1;
+            if ((int)threadIdx.x >= KEY_CAP) {
+                const int j = (int)threadIdx.x - KEY_CAP;
+                if (j < w_n) {
+                    // coordinates on another chromosome become -inf (before every read) / +inf (after every read)
+                    int st = v.xa.y, en = v.xa.z;
+                    if (v.xa.x < d.tid) { st = INT32_MIN; en = INT32_MIN; }
+                    else if (v.xa.x > d.tid) { st = INT32_MAX; en = INT32_MAX; }
+                    s_hk[j] = make_int4(st, en, v.xb.x, (v.xb.z & 0xff) | (v.xb.y << 8));
+                    s_hx[j] = v.xc;
+                }
+            } else {
+                if (threadIdx.x < d.st_nk) {
+                    v4i_t e; e.x = v.xa.x; e.y = v.xa.y;
+                    e.z = (int)rebase_mask((uint32_t)v.xb.x, (uint32_t)v.xb.y, v.xa.z - d.j_lo);
+                    e.w = (int)rebase_mask((uint32_t)v.xb.z, (uint32_t)v.xb.w, v.xa.z - d.j_lo);
+                    s_ent0[threadIdx.x] = e;
+                    if (v.xa.w & SE_WIDE) my_wide = 1;
+                }
+                if (threadIdx.x < d.en_nk) {
+                    v4i_t e; e.x = v.xc.x; e.y = v.xc.y;
+                    e.z = (int)rebase_mask((uint32_t)v.xd.x, (uint32_t)v.xd.y, v.xc.z - d.j_lo);
+                    e.w = (int)rebase_mask((uint32_t)v.xd.z, (uint32_t)v.xd.w, v.xc.z - d.j_lo);
+                    s_ent1[threadIdx.x] = e;
+                    if (v.xc.w & SE_WIDE) my_wide = 1;
+                }
             }
             if (d.nbk > 0) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int i = (int)threadIdx.x + q * TILE_THREADS;
-                    if (i <= d.nbk) { s_dir0[i] = v.dd[0][q] - d.st_r0; s_dir1[i] = v.dd[1][q] - d.en_r0; s_rdir[i] = v.dd[2][q] - d.st_r0; }
+                    if (i <= d.nbk) {
+                        s_dir0[i] = (uint8_t)(v.dd[0][q] - d.st_r0); s_dir1[i] = (uint8_t)(v.dd[1][q] - d.en_r0);
+                        s_rdir[i] = (uint8_t)(v.dd[2][q] - d.st_r0);
+                    }
                 }
             }
         }
         const bool rev_in = v.rev != 0;
         const int any_wide = __syncthreads_or(my_wide);
         // ---- the next tile's vectors start their trip now; they are not needed before the top of the next round
-        if (has_next) v = load_vectors(a, t_next, u_next, REGION_WORDS);
+        if (has_next) v = load_vectors(a, t_next, u_next, cigar_room(u_next));
         L2R_STAMP(1);
 
         // ---- phase 2: classification
@@ -784,7 +823,7 @@ void k_classify_fast(FastArgs a, int64_t n_tiles)
         bool redo = active && (!fast || !in_lds || any_wide != 0 || tid != d.tid || (n > 1 && !sane));
         const bool work = active && !redo;
         const int *S = s_S + local, *E = s_E + local;
-        uint32_t *W = s_W + local;
+        uint16_t *W = s_W + local;
         uint32_t vpre = 0, lmask = 0, rmask = 0, k1mask = 0;
         {
             // V': transcripts j >= j0 up to the first one the read lies before (:799-800), minus the ones that lie
@@ -823,7 +862,7 @@ void k_classify_fast(FastArgs a, int64_t n_tiles)
             // one START and one END probe per exon; the wave runs as many rounds as its longest read has exons.
             // Per round: {next exon, both bucket ranges} are read together, then the first two entries of both buckets.
             const bool mapping = work && !redo && n > 1;
-            const uint32_t *dS = s_dir0, *dE = s_dir1;
+            const uint8_t *dS = s_dir0, *dE = s_dir1;
             const v4i_t *eS = s_ent0, *eE = s_ent1;
             int s = 0, e = 0;
             if (mapping) { s = S[0]; e = E[0]; }
@@ -836,22 +875,24 @@ void k_classify_fast(FastArgs a, int64_t n_tiles)
                 const int s2 = s_S[inext], e2 = s_E[inext];
                 const uint32_t ls = dS[is], hs0 = dS[is + 1], le = dE[ie], he0 = dE[ie + 1];
                 const uint32_t hs = vs ? hs0 : ls, he = ve ? he0 : le;          // no bucket -> empty range
-                const v4i_t qs0 = lds_entry(eS, min(ls, (uint32_t)KEY_CAP - 1u)), qs1 = lds_entry(eS, min(ls + 1u, (uint32_t)KEY_CAP - 1u));
+                // START buckets mostly hold one exon, END buckets often several junctions of one donor
+                const v4i_t qs0 = lds_entry(eS, min(ls, (uint32_t)KEY_CAP - 1u));
                 const v4i_t qe0 = lds_entry(eE, min(le, (uint32_t)KEY_CAP - 1u)), qe1 = lds_entry(eE, min(le + 1u, (uint32_t)KEY_CAP - 1u));
                 uint32_t xm, am, jm, dm;
-                probe2(qs0, qs1, ls, hs, s, e, xm, am);
+                {   const bool m0 = ls < hs && qs0.x == s;
+                    am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
                 probe2(qe0, qe1, le, he, e, s2, jm, dm);
-                if (__any(hs > ls + 2u || he > le + 2u)) { probe_rest(eS, ls, hs, s, e, xm, am); probe_rest(eE, le, he, e, s2, jm, dm); }
-                uint32_t word = min((uint32_t)__ffs((int)(xm & vpre)) - 1u, 0x7fu);
-                word |= min((uint32_t)__ffs((int)(dm & vpre)) - 1u, 0x7fu) << 8;       // without a junction: dm = jm = 0 -> 0x7f
-                word |= min((uint32_t)__ffs((int)((junc ? am : 0u) & vpre)) - 1u, 0x7fu) << 16;
-                word |= min((uint32_t)__ffs((int)(jm & vpre)) - 1u, 0x7fu) << 24;
+                if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(eS, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(eE, le + 2u, he, e, s2, jm, dm, 0u); }
+                // first member of V' with the exon / the junction (63: none), "donor / acceptor not in V'"
+                uint32_t word = min((uint32_t)__ffs((int)(xm & vpre)) - 1u, 63u);
+                word |= min((uint32_t)__ffs((int)(jm & vpre)) - 1u, 63u) << 6;        // without a junction: jm = dm = 0
+                word |= ((dm & vpre) ? 0u : 1u << 12) | ((((junc ? am : 0u) & vpre)) ? 0u : 1u << 13);
                 if (junc) {
                     kand &= am & dm;                          // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
                     kor |= am | dm;
                     if (k == 0) dm_first = dm;
                 } else if (live) am_last = am;                // transcripts in which the last exon's start begins a later exon
-                if (live) W[k] = word;
+                if (live) W[k] = (uint16_t)word;
                 s = s2; e = e2;
             }
         }
@@ -892,18 +933,19 @@ void k_classify_fast(FastArgs a, int64_t n_tiles)
                     else if (V) rnoth = (overlapping_exon_members(s_rdir, s_dir0, s_ent0, d.b_off, d.nb, re.sl, re.el) & V) == 0u;
                 }
             }
-            // ---- flags: a site is no longer novel iff the first member of V' that has it comes no later than j*
+            // ---- flags: an exon / junction is no longer novel iff the first member of V' that has it comes no later
+            // than j*; a known read has every probed donor and acceptor in transcript j*
             {
-                const uint32_t lim = known ? (uint32_t)jstar : 63u;
-                const uint32_t add = (127u - lim) * 0x01010101u;
+                const uint32_t lim = known ? (uint32_t)jstar : 62u;
                 for (int k = 0; k < (int)n; ++k) {
-                    uint32_t f;
+                    uint32_t f = F_EXON;
                     if (n > 1) {
-                        const uint32_t hb = ((W[k] + add) >> 7) & 0x01010101u;       // byte > lim  ->  still novel
-                        f = (hb & 1u) | ((hb >> 7) & 2u) | ((hb >> 14) & 4u) | ((hb >> 21) & 8u);
-                        if (k + 1 == (int)n) f &= 1u;
-                    } else f = F_EXON;
-                    W[k] = f;
+                        const uint32_t w = W[k];
+                        f = ((w & 63u) > lim ? F_EXON : 0u) | (((w >> 6) & 63u) > lim ? F_JUNC : 0u);
+                        if (!known) f |= ((w >> 12) & 1u ? F_DON : 0u) | ((w >> 13) & 1u ? F_ACC : 0u);
+                        if (k + 1 == (int)n) f &= F_EXON;
+                    }
+                    W[k] = (uint16_t)f;
                 }
             }
             bool out_rev = rev_in;
@@ -915,7 +957,7 @@ void k_classify_fast(FastArgs a, int64_t n_tiles)
             info = finish_info(info, (int)n, p);
         } else if (active) {
             info = n << 8;
-            if (in_lds) for (int k = 0; k < (int)n; ++k) W[k] = 0u;
+            if (in_lds) for (int k = 0; k < (int)n; ++k) W[k] = (uint16_t)0;
         }
         L2R_STAMP(4);
 
