@@ -558,7 +558,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     }
     MARK(ST_GENERIC);
     {
-        const unsigned gg = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, 2048);
+        const unsigned gg = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles * 4 : 1, 4096);      // one wave per listed read, grid-stride
         hipLaunchKernelGGL(k_classify_generic, dim3(gg), dim3(TILE_THREADS), 0, s, c->totals.p + 3, c->redo.p, c->r_tid.p, c->r_rev.p, j0,
                            c->hdr.p, c->anno_ex.p, p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->info.p, c->ref_tx.p,
                            c->tile_acc.p, c->tile_acc_ex.p);

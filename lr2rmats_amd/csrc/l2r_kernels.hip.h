@@ -466,8 +466,12 @@ __device__ __forceinline__ Verdict sweep_literal(const int *S, const int *E, uin
     return Verdict{finish_info(info, n, p), ref};
 }
 
-// One thread per entry of the redo list.  Reads of up to GEN_CAP exons are worked on in LDS.
-constexpr int GEN_CAP = 16;
+// ONE WAVE per entry of the redo list: the reference's loops over annotation exons run across the 64 lanes
+// (lane i takes annotation exons i, i + 64, ...), the loops over the read's exons run inside a lane; every branch
+// of the sweep is wave-uniform because the whole wave works on one read.  Reads of up to GEN_CAP exons are held in
+// LDS (flags as one word per exon, cleared with LDS atomics); longer ones take the one-thread sweep_literal.
+constexpr int GEN_CAP = 128;
+constexpr int GEN_WAVES = TILE_THREADS / WAVE;
 
 __global__ __launch_bounds__(TILE_THREADS)
 void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t *__restrict__ redo,
@@ -477,32 +481,119 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
                         uint8_t *__restrict__ ex_flag, uint32_t *__restrict__ info_io, int32_t *__restrict__ ref_out,
                         uint32_t *__restrict__ tile_acc, uint32_t *__restrict__ tile_acc_ex)
 {
-    __shared__ int g_S[TILE_THREADS * GEN_CAP];
-    __shared__ int g_E[TILE_THREADS * GEN_CAP];
-    __shared__ uint8_t g_F[TILE_THREADS * GEN_CAP];
+    __shared__ int g_S[GEN_WAVES][GEN_CAP];
+    __shared__ int g_E[GEN_WAVES][GEN_CAP];
+    __shared__ uint32_t g_F[GEN_WAVES][GEN_CAP];
     const uint32_t cnt = *redo_count;
-    for (uint32_t i = blockIdx.x * TILE_THREADS + threadIdx.x; i < cnt; i += gridDim.x * TILE_THREADS) {
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    int *S = g_S[wv], *E = g_E[wv];
+    uint32_t *F = g_F[wv];
+    for (uint32_t i = blockIdx.x * GEN_WAVES + wv; i < cnt; i += gridDim.x * GEN_WAVES) {
         const uint32_t r = redo[i];
         const int n = (int)(info_io[r] >> 8);
         const uint32_t off = ex_off[r];
         const int tid = r_tid[r], j0 = j0_arr[r];
         const bool rev = r_rev[r] != 0;
-        Verdict v;
-        if (n <= GEN_CAP) {
-            int *S = g_S + threadIdx.x * GEN_CAP, *E = g_E + threadIdx.x * GEN_CAP;
-            uint8_t *F = g_F + threadIdx.x * GEN_CAP;
-            for (int k = 0; k < n; ++k) { S[k] = ex_start[off + k]; E[k] = ex_end[off + k]; }
-            v = sweep_literal(S, E, F, n, tid, rev, j0, hdr, anno_ex, p);
-            for (int k = 0; k < n; ++k) ex_flag[off + k] = F[k];
+        Verdict v{0u, -1};
+        if (n > GEN_CAP) {
+            if (lane == 0) v = sweep_literal(ex_start + off, ex_end + off, ex_flag + off, n, tid, rev, j0, hdr, anno_ex, p);
         } else {
-            v = sweep_literal(ex_start + off, ex_end + off, ex_flag + off, n, tid, rev, j0, hdr, anno_ex, p);
+            for (int k = lane; k < n; k += WAVE) {
+                S[k] = ex_start[off + k]; E[k] = ex_end[off + k];
+                F[k] = (k + 1 < n) ? (uint32_t)(F_EXON | F_DON | F_ACC | F_JUNC) : (uint32_t)F_EXON;
+            }
+            const ReadEnds re{ex_start[off], ex_end[off], ex_start[off + n - 1], ex_end[off + n - 1]};
+            const int r_start = re.s0, r_end = re.el, dis = p.ss_dis, level = p.full_level;
+            bool lfull = false, rfull = false, lnoth = true, rnoth = true, known = false, ksite = false;
+            int ref = -1, ref_rev = 0;
+            for (int j = j0; j < p.n_tx; ++j) {
+                const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);
+                const int4 h0 = hp[0];
+                // src/update_gtf.c:786-790 comp_trans: <= (Q5)
+                if (tid < h0.x || (tid == h0.x && r_end <= h0.y)) break;                 // :799-800
+                if (h0.x < tid || (h0.x == tid && h0.z <= r_start)) continue;            // :801
+                const int4 h1 = hp[1], h2 = hp[2];
+                const int a_start = h0.y, a_end = h0.z, m = h1.x;
+                const int2 *ax = anno_ex + h0.w;
+                // ---- check_full :629-681
+                if (!(lfull && rfull)) {
+                    if (level == 1) {
+                        if (re.e0 == h2.y) lfull = true;
+                        if (re.sl == h2.z) rfull = true;
+                    } else if (level == 2) {
+                        if (closed_overlap(re.s0, re.e0, h2.x, h2.y)) lfull = true;
+                        if (closed_overlap(re.sl, re.el, h2.z, h2.w)) rfull = true;
+                    } else if (level == 3 || level == 4) {
+                        bool need_l = false, need_r = false;
+                        if (!lfull) { if (closed_overlap(re.s0, re.e0, h2.x, h2.y)) lfull = true; else need_l = lnoth; }
+                        if (level == 3 && !rfull) { if (closed_overlap(re.sl, re.el, h2.z, h2.w)) rfull = true; else need_r = rnoth; }
+                        if (need_l || need_r) {
+                            bool hit_l = false, hit_r = false;
+                            for (int k = lane; k < m; k += WAVE) {
+                                const int2 x = ax[k];
+                                hit_l = hit_l || closed_overlap(re.s0, re.e0, x.x, x.y);
+                                hit_r = hit_r || closed_overlap(re.sl, re.el, x.x, x.y);
+                            }
+                            if (need_l && __any(hit_l)) lnoth = false;
+                            if (need_r && __any(hit_r)) rnoth = false;
+                        }
+                    }
+                }
+                // ---- :806-820
+                int vv = 0;
+                if (n == 1 && m == 1) {
+                    if (overlap_frac(re.s0, re.e0, h2.x, h2.y) >= p.frac) { known = true; vv = 1; }
+                } else if (n > 1 && m > 1) {
+                    // src/update_gtf.c:717-779 check_splice_site
+                    const int lo = max(r_start, a_start), hi = min(r_end, a_end);
+                    int r_in = 0, same = 0;
+                    for (int q = lane; q + 1 < n; q += WAVE) {
+                        const int e = E[q], s2 = S[q + 1];
+                        r_in += (e >= lo && e <= hi) + (s2 >= lo && s2 <= hi);
+                    }
+                    for (int k = lane; k < m; k += WAVE) {                 // annotation exon k and its successor
+                        const bool has_next = k + 1 < m;
+                        const int2 cur = ax[k], nxt = has_next ? ax[k + 1] : cur;
+                        const bool don_in = has_next && cur.y >= lo && cur.y <= hi;
+                        const bool acc_in = has_next && nxt.x >= lo && nxt.x <= hi;
+                        for (int q = 0; q < n; ++q) {
+                            const int sq = S[q], eq = E[q];
+                            const bool end_eq = near_eq(cur.y, eq, dis);
+                            uint32_t clr = 0;
+                            if (end_eq && near_eq(cur.x, sq, dis)) clr |= F_EXON;
+                            if (has_next && q + 1 < n) {
+                                if (don_in && end_eq) { ++same; clr |= F_DON; }
+                                if (acc_in && near_eq(nxt.x, sq, dis)) { ++same; clr |= F_ACC; }        // Q1: read exon q's own start
+                                if (end_eq && near_eq(nxt.x, S[q + 1], dis)) clr |= F_JUNC;
+                            }
+                            if (clr) atomicAnd(&F[q], ~clr);
+                        }
+                    }
+                    r_in = (int)wave_sum((uint32_t)r_in); same = (int)wave_sum((uint32_t)same);
+                    if (2 * (n - 1) == r_in && r_in == same) { vv = 1; known = true; }
+                    else if (same > 0) { vv = 2; ksite = true; }
+                }
+                if (vv) { ref = j; ref_rev = h1.y; }
+                if (vv == 1) break;                                                        // :810,816
+            }
+            bool out_rev = rev;
+            if (ref >= 0) out_rev = ref_rev != 0;               // :825-831 strand taken from the reference transcript
+            uint32_t info = 0;
+            if (known) info |= I_KNOWN;
+            if (ksite) info |= I_KSITE;
+            if (full_decision(level, lfull, lnoth, rfull, rnoth)) info |= I_FULL;
+            if (out_rev) info |= I_REV;
+            v = Verdict{finish_info(info, n, p), ref};
+            for (int k = lane; k < n; k += WAVE) ex_flag[off + k] = (uint8_t)F[k];
         }
-        info_io[r] = v.info;
-        ref_out[r] = v.ref;
-        if (v.info & I_ACCEPT) {
-            const uint32_t t = r / (uint32_t)p.reads_per_tile;
-            atomicAdd(&tile_acc[t], 1u);
-            atomicAdd(&tile_acc_ex[t], (uint32_t)n);
+        if (lane == 0) {
+            info_io[r] = v.info;
+            ref_out[r] = v.ref;
+            if (v.info & I_ACCEPT) {
+                const uint32_t t = r / (uint32_t)p.reads_per_tile;
+                atomicAdd(&tile_acc[t], 1u);
+                atomicAdd(&tile_acc_ex[t], (uint32_t)n);
+            }
         }
     }
 }
@@ -598,13 +689,13 @@ constexpr int FAST_ALL_WORDS = 2 * LDS_EXON_CAP + FAST_TAIL_WORDS;
 struct TileUniforms {                                       // wave-uniform inputs of a tile ...
     TileDesc d;
     uint32_t base, total;
-    int64_t c0, c1;                                         // the tile's CIGAR words [c0, c1)
+    uint32_t c0, c1;                                        // the tile's CIGAR words [c0, c1) (a shard has < 2^32 of them)
     int32_t src;                                            // ... and the thread's read of the tile (pass A's order), -1: none
 };
 
 struct TileVectors {                                        // per-thread raw inputs of a tile
     uint32_t local, nxt;
-    int64_t c_lo, c_hi;
+    uint32_t c_lo, c_hi;
     int32_t pos, j0, tid, rev;
     uint4 cg[PF_CIG_VEC];
     int4 xa, xb, xc, xd;        // threads < KEY_CAP: START entry (xa, xb) and END entry (xc, xd); threads >= KEY_CAP: header words (xa, xb, xc)
@@ -614,19 +705,20 @@ struct TileVectors {                                        // per-thread raw in
 // (the three arrays come in as __restrict__ kernel parameters of their own, so that these are scalar loads that
 //  wait at their first use, not vector loads that wait where they are issued)
 __device__ __forceinline__ TileUniforms load_uniforms(const FastArgs &a, const TileDesc *__restrict__ desc, const uint32_t *__restrict__ tile_base,
-                                                     const int64_t *__restrict__ cig_off, int64_t t)
+                                                     const int64_t *__restrict__ cig_off, uint32_t t)
 {
+    // 32-bit indices throughout: a shard has fewer than 2^32 reads and CIGAR words (l2r_upload_reads checks)
     TileUniforms u;
-    const int64_t r0 = t * a.p.reads_per_tile, r1 = min(r0 + a.p.reads_per_tile, a.n_reads);
+    const uint32_t r0 = t * (uint32_t)a.p.reads_per_tile, r1 = min(r0 + (uint32_t)a.p.reads_per_tile, (uint32_t)a.n_reads);
     u.d = desc[t];
-    u.base = tile_base[t]; u.total = tile_base[t + 1] - u.base;
-    u.c0 = cig_off[r0]; u.c1 = cig_off[r1];
-    u.src = (int64_t)threadIdx.x < r1 - r0 ? (int32_t)a.order[r0 + threadIdx.x] : -1;
+    u.base = tile_base[t]; u.total = tile_base[t + 1u] - u.base;
+    u.c0 = (uint32_t)cig_off[r0]; u.c1 = (uint32_t)cig_off[r1];
+    u.src = threadIdx.x < r1 - r0 ? (int32_t)a.order[r0 + threadIdx.x] : -1;
     return u;
 }
 
 // CIGAR staging geometry: the copy starts at the 16-byte boundary below c0 (the array is padded at its end)
-__device__ __forceinline__ int cigar_vectors(const TileUniforms &u) { return (int)((u.c1 - (u.c0 & ~(int64_t)3) + 3) >> 2); }
+__device__ __forceinline__ int cigar_vectors(const TileUniforms &u) { return (int)((u.c1 - (u.c0 & ~3u) + 3u) >> 2); }
 // LDS words left for the CIGAR of a tile behind its S and E arrays (layout in k_classify_fast)
 __device__ __forceinline__ int cigar_room(const TileUniforms &u)
 {
@@ -639,23 +731,23 @@ __device__ __forceinline__ bool cigar_staged(const TileUniforms &u, int region_w
     return n4 <= PF_CIG_VEC * TILE_THREADS && 4 * n4 <= region_words;
 }
 
-__device__ __forceinline__ TileVectors load_vectors(const FastArgs &a, int64_t t, const TileUniforms &u, int region_words)
+__device__ __forceinline__ TileVectors load_vectors(const FastArgs &a, uint32_t t, const TileUniforms &u, int region_words)
 {
     TileVectors v;
     const DevParams &p = a.p;
-    const int64_t r = t * p.reads_per_tile + u.src;
+    const uint32_t r = t * (uint32_t)p.reads_per_tile + (uint32_t)u.src;
     const bool active = u.src >= 0;
     v.local = 0; v.nxt = 0; v.c_lo = 0; v.c_hi = 0; v.pos = 0; v.j0 = 0; v.tid = 0; v.rev = 0;
     if (active) {
         v.local = a.local[r];
-        const bool last = u.src + 1 == p.reads_per_tile || r + 1 == a.n_reads;
-        v.nxt = last ? u.total : a.local[r + 1];
-        v.c_lo = a.cig_off[r]; v.c_hi = a.cig_off[r + 1];
+        const bool last = u.src + 1 == p.reads_per_tile || r + 1u == (uint32_t)a.n_reads;
+        v.nxt = last ? u.total : a.local[r + 1u];
+        v.c_lo = (uint32_t)a.cig_off[r]; v.c_hi = (uint32_t)a.cig_off[r + 1u];
         v.pos = a.r_pos[r]; v.tid = a.r_tid[r]; v.j0 = a.j0[r]; v.rev = a.r_rev[r];
     }
     const bool staged = cigar_staged(u, region_words);
     const int n4 = cigar_vectors(u);
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.cig + (u.c0 & ~(int64_t)3));
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.cig + (u.c0 & ~3u));
 #pragma unroll
     for (int q = 0; q < PF_CIG_VEC; ++q) {
         const int i = q * TILE_THREADS + (int)threadIdx.x;
@@ -709,18 +801,18 @@ void k_classify_fast(FastArgs a, int64_t n_tiles, const TileDesc *__restrict__ u
         atomicAdd(&a.stamps[(blockIdx.x & 1023u) * 8u + (i)], t_ - t_prev); t_prev = t_; } } while (0)
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
 
-    int64_t t = blockIdx.x;
-    if (t >= n_tiles) return;
+    uint32_t t = blockIdx.x;
+    if ((int64_t)t >= n_tiles) return;
     TileUniforms u = load_uniforms(a, u_desc, u_tile_base, u_cig_off, t);
     TileVectors v = load_vectors(a, t, u, cigar_room(u));
 
-    for (; t < n_tiles; t += gridDim.x) {
-        const int64_t t_next = t + gridDim.x;
-        const bool has_next = t_next < n_tiles;
+    for (; (int64_t)t < n_tiles; t += gridDim.x) {
+        const uint32_t t_next = t + gridDim.x;
+        const bool has_next = (int64_t)t_next < n_tiles;
         TileUniforms u_next = u;
         if (has_next) u_next = load_uniforms(a, u_desc, u_tile_base, u_cig_off, t_next);
 
-        const int64_t r = t * p.reads_per_tile + u.src;
+        const uint32_t r = t * (uint32_t)p.reads_per_tile + (uint32_t)u.src;
         const bool active = u.src >= 0;
         const TileDesc d = u.d;
         const uint32_t base = u.base, tile_total = u.total;
@@ -762,7 +854,7 @@ void k_classify_fast(FastArgs a, int64_t n_tiles, const TileDesc *__restrict__ u
                     sane = sane & (s <= e);
                     re.sl = s; re.el = e;
                 };
-                if (staged) walk_cigar(s_cig + (int)(v.c_lo - (u.c0 & ~(int64_t)3)), n_cig, pos, p, emit);
+                if (staged) walk_cigar(s_cig + (v.c_lo - (u.c0 & ~3u)), n_cig, pos, p, emit);
                 else walk_cigar(a.cig + v.c_lo, n_cig, pos, p, emit);
                 re.s0 = s_S[local]; re.e0 = s_E[local];
             } else {
