@@ -42,6 +42,22 @@ def cpu_baseline(af, reads, sample: int, level: int):
     return sub.n / dt, sub, res, dt
 
 
+def pmc_traffic(kernel: str, config: str, n_reads: int):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE and WRITE_SIZE need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots"; tools/pmc_traffic.py
+    writes the file).  Only reported when the file was measured on this kernel, config and read count."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+    except (OSError, ValueError):
+        return None, "no PMC file"
+    ent = t.get(kernel)
+    if not ent or ent.get("config") != config or ent.get("reads") != n_reads:
+        return None, "PMC file is for another kernel/config"
+    return ent["hbm_bytes_per_launch"], ent.get("note", "profiles/pmc_traffic.json")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,7 +66,7 @@ def main():
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--reads", type=int, default=0, help="override reads per rank")
     ap.add_argument("--level", type=int, default=3)
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -143,9 +159,11 @@ def main():
         dom = max(stage, key=lambda k: stage[k])
         abytes = workload.algorithmic_bytes(n_r, int(reads.cig.shape[0]), n_x, af.n_tx, af.n_exons, 0)
         ach = abytes / (stage[dom] * 1e-3) / 1e9
+        traffic, traffic_note = pmc_traffic(dom, args.config, reads.n)
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_measured_copy_peak": round(ach / HBM_COPY_GBS, 4),
-                "traffic": None, "algorithmic_bytes_per_launch": abytes, "kernel_ms": round(stage[dom], 4),
+                "traffic": traffic, "traffic_source": traffic_note,
+                "algorithmic_bytes_per_launch": abytes, "kernel_ms": round(stage[dom], 4),
                 "all_kernels_ms": round(tm["total_ms"], 4),
                 "all_kernels_achieved_GBs": round(abytes / (tm["total_ms"] * 1e-3) / 1e9, 1),
                 "stage_ms": {k: round(v, 4) for k, v in stage.items()}}

@@ -51,6 +51,7 @@ struct DevBuf {
 
 struct l2r_ctx {
     int device = 0;
+    int fast_grid = 0;
     int n_cu = 256, wg_per_cu = 4;          // persistent grid of k_classify_fast (L2R_WG_PER_CU overrides)
     hipStream_t stream = nullptr;
     l2r_params prm;
@@ -145,6 +146,8 @@ l2r_ctx *l2r_create(int device)
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
         const char *e = getenv("L2R_WG_PER_CU");
         if (e && atoi(e) > 0) c->wg_per_cu = atoi(e);
+        e = getenv("L2R_FAST_GRID");
+        if (e && atoi(e) > 0) c->fast_grid = atoi(e);
     }
     return c;
 }
@@ -306,6 +309,9 @@ int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
         for (const auto *v : {&kd, &ka, &kx, &kj}) if (!v->empty()) n_tid = std::max(n_tid, v->back().tid + 1);
         std::vector<int64_t> mx((size_t)n_tid, -1);
         for (const auto *v : {&kd, &ka, &kx, &kj}) for (const SiteTx &k : *v) mx[(size_t)k.tid] = std::max<int64_t>(mx[(size_t)k.tid], k.k1);
+        // ... and for the last exon END of every chromosome: the full-length evidence looks for exons that reach into
+        // the bucket of a read's terminal exon (rdir), so the grid has to cover exon ends, not only the probe keys
+        for (const SiteTx &k : kx) mx[(size_t)k.tid] = std::max<int64_t>(mx[(size_t)k.tid], k.k2);
         std::vector<int32_t> tb((size_t)n_tid + 1, 0);
         int64_t acc = 0;
         for (int32_t t = 0; t < n_tid; ++t) { tb[(size_t)t] = (int32_t)acc; acc += mx[(size_t)t] < 0 ? 0 : (mx[(size_t)t] >> SITE_SHIFT) + 1; }
@@ -546,7 +552,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         fa.tile_acc = c->tile_acc.p; fa.tile_acc_ex = c->tile_acc_ex.p; fa.redo_count = c->totals.p + 3; fa.redo = c->redo.p;
         fa.stamps = c->stamps.p; fa.p = p;
         // persistent grid: a few workgroups per CU walk over the tiles (l2r_kernels.hip.h)
-        const unsigned gp = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * c->wg_per_cu);
+        unsigned gp = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * c->wg_per_cu);
+        if (c->fast_grid > 0) gp = (unsigned)std::min<int64_t>(gp, c->fast_grid);           // L2R_FAST_GRID: tests force many tiles per workgroup
         switch (p.full_level) {
         case 1: launch_fast_level(1, fa, gp, s); break;
         case 2: launch_fast_level(2, fa, gp, s); break;

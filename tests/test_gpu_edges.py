@@ -1,0 +1,131 @@
+"""GPU: hand-built corner cases of the fast classification path against the oracle -- bit exact.
+
+Each case targets one precondition of k_classify_fast (lr2rmats_amd/csrc/l2r_kernels.hip.h): the bucket grid at
+the end of a chromosome, transcript windows wider than the membership masks, tiles that straddle chromosomes,
+many tiles per persistent workgroup, crowded dictionary buckets, reads far longer than the dictionary span."""
+import os
+
+import numpy as np
+import pytest
+
+from lr2rmats_amd import capi, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+M, N_ = 0, 3
+
+
+def _reads(rows, chrom_names=("chr1", "chr2", "chr3")):
+    """rows: (tid, pos0, rev, [(len, op), ...]) sorted by (tid, pos)."""
+    tid = np.array([r[0] for r in rows], np.int32)
+    pos = np.array([r[1] for r in rows], np.int32)
+    rev = np.array([r[2] for r in rows], np.uint8)
+    off = np.zeros(len(rows) + 1, np.int64)
+    np.cumsum([len(r[3]) for r in rows], out=off[1:])
+    cig = np.array([(l << 4) | op for r in rows for (l, op) in r[3]], np.uint32)
+    return synth.Reads(list(chrom_names), tid, pos, rev, rev.copy(), np.zeros(len(rows), np.uint8), off, cig)
+
+
+def _anno(txs):
+    """txs: (tid, rev, [(start, end), ...]) in file order."""
+    tx_tid = np.array([t[0] for t in txs], np.int32)
+    tx_rev = np.array([t[1] for t in txs], np.uint8)
+    off = np.zeros(len(txs) + 1, np.int64)
+    np.cumsum([len(t[2]) for t in txs], out=off[1:])
+    es = np.array([e[0] for t in txs for e in t[2]], np.int32)
+    ee = np.array([e[1] for t in txs for e in t[2]], np.int32)
+    return synth.Annotation(["chr1", "chr2", "chr3"], tx_tid, tx_rev, np.arange(len(txs), dtype=np.int32), off, es, ee, len(txs), None)
+
+
+def _chain(exons):
+    """CIGAR of a read made of the given exons (1-based closed), and its 0-based position."""
+    ops = []
+    for k, (s, e) in enumerate(exons):
+        if k:
+            ops.append((s - exons[k - 1][1] - 1, N_))
+        ops.append((e - s + 1, M))
+    return exons[0][0] - 1, ops
+
+
+def _run(oracle, af, reads, **kw):
+    want = util.oracle_run(oracle, af, reads, oracle.default_params(**kw))
+    eng = capi.Engine(0)
+    try:
+        eng.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
+        got = eng.classify(reads, capi.default_params(**kw))
+    finally:
+        eng.close()
+    util.assert_same_result(got, want, 0, 0)
+    return got, want
+
+
+@pytest.mark.parametrize("level", [3, 4])
+def test_read_over_last_exon_of_chromosome(oracle, level):
+    # the read's first exon overlaps only the LAST exon of the chromosome's last transcripts: "overlaps some exon"
+    # must be seen although no probe key lies that far (the bucket grid has to cover exon ends)
+    base = 83_291_818
+    tx = [(base, base + 156), (base + 1899, base + 2007), (base + 29_888, base + 30_106)]
+    af = _anno([(0, 0, tx), (0, 0, [tx[0], tx[2]]), (1, 0, [(1000, 1200), (5000, 5100)])])
+    rows = []
+    for shift in (0, 7, 50, 160, 217, 218, 219, 600):
+        ex = [(tx[2][0] + 162 + shift, tx[2][0] + 318 + shift), (tx[2][0] + 2061 + shift, tx[2][0] + 2169 + shift)]
+        p, ops = _chain(ex)
+        rows.append((0, p, 0, ops))
+    rows.sort(key=lambda r: (r[0], r[1]))
+    got, want = _run(oracle, af, _reads(rows), full_level=level)
+    assert ((want.info & 4) == 0).any() and ((want.info & 4) != 0).any()
+
+
+def test_window_wider_than_masks_and_crowded_buckets(oracle):
+    # 80 isoforms of one locus sharing exons (dictionary entries with more than 64 members, windows of more than
+    # 32 transcripts) and 40 alternative ends inside one 512-bp bucket
+    rng = np.random.default_rng(5)
+    pool = [(10_000 + 700 * k, 10_000 + 700 * k + 150) for k in range(14)]
+    txs = []
+    for t in range(80):
+        keep = sorted(set([0, 13] + list(rng.choice(np.arange(1, 13), size=8, replace=False))))
+        ex = [pool[k] for k in keep]
+        if t % 2:
+            ex[-2] = (ex[-2][0], ex[-2][1] + int(t // 2) + 1)        # crowded bucket: many ends for one start
+        txs.append((0, t & 1, ex))
+    txs.sort(key=lambda t: (t[2][0][0], t[2][-1][1]))
+    af = _anno(txs)
+    rows = []
+    for i in range(3000):
+        t = txs[int(rng.integers(len(txs)))][2]
+        a = int(rng.integers(0, len(t) - 2))
+        ex = [list(x) for x in t[a:a + int(rng.integers(2, 7))]]
+        if i % 3 == 0:
+            ex[0][0] += int(rng.integers(0, 40))
+        if i % 7 == 0:
+            ex[-1][1] -= int(rng.integers(0, 40))
+        p, ops = _chain([tuple(x) for x in ex])
+        rows.append((0, p, int(i & 1), ops))
+    rows.sort(key=lambda r: (r[0], r[1]))
+    got, want = _run(oracle, af, _reads(rows), full_level=3)
+    assert ((want.info & 1) != 0).sum() > 100 and ((want.info & 2) != 0).sum() > 100
+
+
+def test_tiles_straddling_chromosomes_and_many_tiles_per_workgroup(oracle, monkeypatch):
+    # small chromosomes: nearly every tile holds reads of two or three chromosomes; a grid of 2 workgroups walks
+    # over all tiles (the persistent loop and its register prefetch)
+    monkeypatch.setenv("L2R_FAST_GRID", "2")
+    anno, af, reads = util.make_case(31, n_reads=9000, n_exons=5, anno_exons=3000, nchr=24)
+    want = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3))
+    eng = capi.Engine(0)
+    try:
+        eng.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
+        got = eng.classify(reads, capi.default_params(full_level=3))
+    finally:
+        eng.close()
+    util.assert_same_result(got, want, 0, 0)
+    assert len(np.unique(reads.tid)) >= 20
+
+
+def test_long_reads_and_long_cigars(oracle):
+    # reads of 40..90 exons (more than a tile's LDS share when they cluster) and ONT-like CIGARs: the tile falls back
+    # to smaller tiles / HBM exons / the generic kernel without changing a byte
+    anno, af, reads = util.make_case(32, n_reads=3000, n_exons=60, anno_exons=40000, ont=True, micro=3, xs=0.02)
+    _run(oracle, af, reads, full_level=3)
+    _run(oracle, af, reads, full_level=1, min_exon=1)
