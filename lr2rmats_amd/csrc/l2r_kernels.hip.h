@@ -686,6 +686,25 @@ constexpr int FAST_DIR_BYTES = (DIR_CAP + 2 + 3) & ~3;
 constexpr int FAST_TAIL_WORDS = LDS_EXON_CAP / 2 + 2 * KEY_CAP * 4 + 3 * FAST_DIR_BYTES / 4;
 constexpr int FAST_ALL_WORDS = 2 * LDS_EXON_CAP + FAST_TAIL_WORDS;
 
+// base[idx] with a 32-bit BYTE offset, so that the load takes the form "uniform base + 32-bit lane offset" (one shift per
+// lane instead of a 64-bit multiply-add); l2r_upload_reads keeps every array of a shard below 4 GB.
+template <typename T>
+__device__ __forceinline__ T ld32(const T *base, uint32_t idx)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(idx * (uint32_t)sizeof(T)));
+}
+
+// The kernel's argument block is read through the kernarg segment pointer, re-fetched opaquely at every phase: a
+// pointer is then loaded (one scalar load) where a phase needs it instead of occupying two SGPRs for the whole tile
+// loop -- with ~25 arrays the alternative is dozens of SGPR spills and v_readlane reloads per tile.
+typedef const __attribute__((address_space(4))) FastArgs *FastArgsK;
+__device__ __forceinline__ FastArgsK fast_args()
+{
+    FastArgsK q = (FastArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return q;
+}
+
 struct TileUniforms {                                       // wave-uniform inputs of a tile ...
     TileDesc d;
     uint32_t base, total;
@@ -704,16 +723,16 @@ struct TileVectors {                                        // per-thread raw in
 
 // (the three arrays come in as __restrict__ kernel parameters of their own, so that these are scalar loads that
 //  wait at their first use, not vector loads that wait where they are issued)
-__device__ __forceinline__ TileUniforms load_uniforms(const FastArgs &a, const TileDesc *__restrict__ desc, const uint32_t *__restrict__ tile_base,
+__device__ __forceinline__ TileUniforms load_uniforms(FastArgsK a, const TileDesc *__restrict__ desc, const uint32_t *__restrict__ tile_base,
                                                      const int64_t *__restrict__ cig_off, uint32_t t)
 {
     // 32-bit indices throughout: a shard has fewer than 2^32 reads and CIGAR words (l2r_upload_reads checks)
     TileUniforms u;
-    const uint32_t r0 = t * (uint32_t)a.p.reads_per_tile, r1 = min(r0 + (uint32_t)a.p.reads_per_tile, (uint32_t)a.n_reads);
+    const uint32_t rpt = (uint32_t)a->p.reads_per_tile, r0 = t * rpt, r1 = min(r0 + rpt, (uint32_t)a->n_reads);
     u.d = desc[t];
     u.base = tile_base[t]; u.total = tile_base[t + 1u] - u.base;
     u.c0 = (uint32_t)cig_off[r0]; u.c1 = (uint32_t)cig_off[r1];
-    u.src = threadIdx.x < r1 - r0 ? (int32_t)a.order[r0 + threadIdx.x] : -1;
+    u.src = threadIdx.x < r1 - r0 ? (int32_t)ld32(a->order, r0 + threadIdx.x) : -1;
     return u;
 }
 
@@ -731,54 +750,55 @@ __device__ __forceinline__ bool cigar_staged(const TileUniforms &u, int region_w
     return n4 <= PF_CIG_VEC * TILE_THREADS && 4 * n4 <= region_words;
 }
 
-__device__ __forceinline__ TileVectors load_vectors(const FastArgs &a, uint32_t t, const TileUniforms &u, int region_words)
+__device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, const TileUniforms &u, int region_words)
 {
     TileVectors v;
-    const DevParams &p = a.p;
-    const uint32_t r = t * (uint32_t)p.reads_per_tile + (uint32_t)u.src;
+    const int rpt = a->p.reads_per_tile, n_tx = a->p.n_tx;
+    const uint32_t n_reads = (uint32_t)a->n_reads;
+    const uint32_t r = t * (uint32_t)rpt + (uint32_t)u.src;
     const bool active = u.src >= 0;
     v.local = 0; v.nxt = 0; v.c_lo = 0; v.c_hi = 0; v.pos = 0; v.j0 = 0; v.tid = 0; v.rev = 0;
     if (active) {
-        v.local = a.local[r];
-        const bool last = u.src + 1 == p.reads_per_tile || r + 1u == (uint32_t)a.n_reads;
-        v.nxt = last ? u.total : a.local[r + 1u];
-        v.c_lo = (uint32_t)a.cig_off[r]; v.c_hi = (uint32_t)a.cig_off[r + 1u];
-        v.pos = a.r_pos[r]; v.tid = a.r_tid[r]; v.j0 = a.j0[r]; v.rev = a.r_rev[r];
+        v.local = ld32(a->local, r);
+        const bool last = u.src + 1 == rpt || r + 1u == n_reads;
+        v.nxt = last ? u.total : ld32(a->local, r + 1u);
+        v.c_lo = (uint32_t)ld32(a->cig_off, r); v.c_hi = (uint32_t)ld32(a->cig_off, r + 1u);
+        v.pos = ld32(a->r_pos, r); v.tid = ld32(a->r_tid, r); v.j0 = ld32(a->j0, r); v.rev = ld32(a->r_rev, r);
     }
     const bool staged = cigar_staged(u, region_words);
     const int n4 = cigar_vectors(u);
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.cig + (u.c0 & ~3u));
+    const uint4 *src = reinterpret_cast<const uint4 *>(a->cig + (u.c0 & ~3u));
 #pragma unroll
     for (int q = 0; q < PF_CIG_VEC; ++q) {
         const int i = q * TILE_THREADS + (int)threadIdx.x;
         v.cg[q] = make_uint4(0u, 0u, 0u, 0u);
-        if (staged && i < n4) v.cg[q] = src[i];
+        if (staged && i < n4) v.cg[q] = ld32(src, (uint32_t)i);
     }
     const TileDesc &d = u.d;
     const bool fast = (d.flags & TD_FAST) != 0;
-    const int w_n = fast ? min(WIN_TX, p.n_tx - d.j_lo) : 0;
+    const int w_n = fast ? min(WIN_TX, n_tx - d.j_lo) : 0;
     v.xa = v.xb = v.xc = v.xd = make_int4(0, 0, 0, 0);
     if ((int)threadIdx.x >= KEY_CAP) {
         if ((int)threadIdx.x - KEY_CAP < w_n) {
-            const int4 *hp = reinterpret_cast<const int4 *>(a.hdr + d.j_lo + ((int)threadIdx.x - KEY_CAP));
+            const int4 *hp = reinterpret_cast<const int4 *>(a->hdr + d.j_lo + ((int)threadIdx.x - KEY_CAP));
             v.xa = hp[0]; v.xb = hp[1]; v.xc = hp[2];
         }
     } else {
-        if (fast && threadIdx.x < d.st_nk) { const int4 *q = reinterpret_cast<const int4 *>(a.st.ent + d.st_r0 + threadIdx.x); v.xa = q[0]; v.xb = q[1]; }
-        if (fast && threadIdx.x < d.en_nk) { const int4 *q = reinterpret_cast<const int4 *>(a.en.ent + d.en_r0 + threadIdx.x); v.xc = q[0]; v.xd = q[1]; }
+        if (fast && threadIdx.x < d.st_nk) { const int4 *q = reinterpret_cast<const int4 *>(a->st.ent + d.st_r0 + threadIdx.x); v.xa = q[0]; v.xb = q[1]; }
+        if (fast && threadIdx.x < d.en_nk) { const int4 *q = reinterpret_cast<const int4 *>(a->en.ent + d.en_r0 + threadIdx.x); v.xc = q[0]; v.xd = q[1]; }
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int i = (int)threadIdx.x + q * TILE_THREADS;
         v.dd[0][q] = v.dd[1][q] = v.dd[2][q] = 0u;
-        if (fast && d.nbk > 0 && i <= d.nbk) { v.dd[0][q] = a.st.dir[d.b0 + i]; v.dd[1][q] = a.en.dir[d.b0 + i]; v.dd[2][q] = a.st.rdir[d.b0 + i]; }
+        if (fast && d.nbk > 0 && i <= d.nbk) { v.dd[0][q] = a->st.dir[d.b0 + i]; v.dd[1][q] = a->en.dir[d.b0 + i]; v.dd[2][q] = a->st.rdir[d.b0 + i]; }
     }
     return v;
 }
 
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, 4)
-void k_classify_fast(FastArgs a, int64_t n_tiles, const TileDesc *__restrict__ u_desc, const uint32_t *__restrict__ u_tile_base,
+void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int64_t n_tiles, const TileDesc *__restrict__ u_desc, const uint32_t *__restrict__ u_tile_base,
                      const int64_t *__restrict__ u_cig_off)
 {
     // One LDS array per workgroup, laid out per tile (total = the tile's exon count <= LDS_EXON_CAP):
@@ -795,24 +815,25 @@ void k_classify_fast(FastArgs a, int64_t n_tiles, const TileDesc *__restrict__ u
     __shared__ __attribute__((aligned(16))) int4 s_hx[WIN_TX];     // {s0, e0, sl, el}
     __shared__ uint32_t s_cnt[4][2];
 
-    const DevParams &p = a.p;
-    unsigned long long t_prev = a.stamps ? __builtin_readcyclecounter() : 0ull;
-#define L2R_STAMP(i) do { if (a.stamps && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
-        atomicAdd(&a.stamps[(blockIdx.x & 1023u) * 8u + (i)], t_ - t_prev); t_prev = t_; } } while (0)
+    (void)kernarg_block;
+    const bool stamping = fast_args()->stamps != nullptr;
+    unsigned long long t_prev = stamping ? __builtin_readcyclecounter() : 0ull;
+#define L2R_STAMP(i) do { if (stamping && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+        atomicAdd(&fast_args()->stamps[(blockIdx.x & 1023u) * 8u + (i)], t_ - t_prev); t_prev = t_; } } while (0)
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
 
     uint32_t t = blockIdx.x;
     if ((int64_t)t >= n_tiles) return;
-    TileUniforms u = load_uniforms(a, u_desc, u_tile_base, u_cig_off, t);
-    TileVectors v = load_vectors(a, t, u, cigar_room(u));
+    TileUniforms u = load_uniforms(fast_args(), u_desc, u_tile_base, u_cig_off, t);
+    TileVectors v = load_vectors(fast_args(), t, u, cigar_room(u));
 
     for (; (int64_t)t < n_tiles; t += gridDim.x) {
         const uint32_t t_next = t + gridDim.x;
         const bool has_next = (int64_t)t_next < n_tiles;
         TileUniforms u_next = u;
-        if (has_next) u_next = load_uniforms(a, u_desc, u_tile_base, u_cig_off, t_next);
+        if (has_next) u_next = load_uniforms(fast_args(), u_desc, u_tile_base, u_cig_off, t_next);
 
-        const uint32_t r = t * (uint32_t)p.reads_per_tile + (uint32_t)u.src;
+        const uint32_t r = t * (uint32_t)fast_args()->p.reads_per_tile + (uint32_t)u.src;
         const bool active = u.src >= 0;
         const TileDesc d = u.d;
         const uint32_t base = u.base, tile_total = u.total;
@@ -828,7 +849,8 @@ void k_classify_fast(FastArgs a, int64_t n_tiles, const TileDesc *__restrict__ u
         uint8_t *const s_dir1 = s_dir0 + DIR_BYTES, *const s_rdir = s_dir1 + DIR_BYTES;
         const uint32_t local = v.local, n = active ? v.nxt - v.local : 0u;
         const int32_t pos = v.pos, j0 = v.j0, tid = v.tid;
-        const int w_n = fast ? min(WIN_TX, p.n_tx - d.j_lo) : 0;          // transcripts in the window
+        const int n_tx = fast_args()->p.n_tx;
+        const int w_n = fast ? min(WIN_TX, n_tx - d.j_lo) : 0;          // transcripts in the window
 
         // ---- phase 0: the tile's CIGAR words, registers -> LDS
         const bool staged = cigar_staged(u, tail_words);
@@ -845,6 +867,9 @@ void k_classify_fast(FastArgs a, int64_t n_tiles, const TileDesc *__restrict__ u
         ReadEnds re{0, 0, 0, 0};
         bool sane = true;
         if (active) {
+            const FastArgsK a = fast_args();
+            DevParams p;                                    // the three thresholds the walk reads
+            p.min_exon = a->p.min_exon; p.min_intron = a->p.min_intron; p.max_delet = a->p.max_delet;
             const int n_cig = (int)(v.c_hi - v.c_lo);
             if (in_lds) {
                 // every exon non-empty <=> starts and ends strictly increasing and start <= end (an exon starts after
@@ -855,11 +880,12 @@ void k_classify_fast(FastArgs a, int64_t n_tiles, const TileDesc *__restrict__ u
                     re.sl = s; re.el = e;
                 };
                 if (staged) walk_cigar(s_cig + (v.c_lo - (u.c0 & ~3u)), n_cig, pos, p, emit);
-                else walk_cigar(a.cig + v.c_lo, n_cig, pos, p, emit);
+                else walk_cigar(a->cig + v.c_lo, n_cig, pos, p, emit);
                 re.s0 = s_S[local]; re.e0 = s_E[local];
             } else {
-                walk_cigar(a.cig + v.c_lo, n_cig, pos, p, [&](int k, int s, int e) {
-                    a.ex_start[base + local + k] = s; a.ex_end[base + local + k] = e;
+                int32_t *const xs = a->ex_start, *const xe = a->ex_end;
+                walk_cigar(a->cig + v.c_lo, n_cig, pos, p, [&](int k, int s, int e) {
+                    xs[base + local + k] = s; xe[base + local + k] = e;
                 });
             }
         }
@@ -907,7 +933,7 @@ void k_classify_fast(FastArgs a, int64_t n_tiles, const TileDesc *__restrict__ u
         const bool rev_in = v.rev != 0;
         const int any_wide = __syncthreads_or(my_wide);
         // ---- the next tile's vectors start their trip now; they are not needed before the top of the next round
-        if (has_next) v = load_vectors(a, t_next, u_next, cigar_room(u_next));
+        if (has_next) v = load_vectors(fast_args(), t_next, u_next, cigar_room(u_next));
         L2R_STAMP(1);
 
         // ---- phase 2: classification
@@ -940,13 +966,13 @@ void k_classify_fast(FastArgs a, int64_t n_tiles, const TileDesc *__restrict__ u
                     if (LEVEL != 4 && ov && closed_overlap(re.sl, re.el, hx.z, hx.w)) rmask |= bit;
                 }
                 if (hk.z == 1) {                 // single-exon transcript: :806-811, only against single-exon reads
-                    if (ov && n == 1 && overlap_frac(re.s0, re.e0, hx.x, hx.y) >= p.frac) k1mask |= bit;
+                    if (ov && n == 1 && overlap_frac(re.s0, re.e0, hx.x, hx.y) >= fast_args()->p.frac) k1mask |= bit;
                 } else if (!((hk.w & 0xff) & TX_COMPACT)) {
                     if (ov && n > 1) redo = true;                                   // literal loops needed for this pair
                 }
             }
             // the sweep must have ended inside the window
-            if (work && !stopped && d.j_lo + w_n < p.n_tx) redo = true;
+            if (work && !stopped && d.j_lo + w_n < n_tx) redo = true;
         }
         L2R_STAMP(2);
         uint32_t kand = 0xffffffffu, kor = 0u, dm_first = 0u, am_last = 0u;
@@ -1046,7 +1072,10 @@ void k_classify_fast(FastArgs a, int64_t n_tiles, const TileDesc *__restrict__ u
             if (ksite) info |= I_KSITE;
             if (full_decision(LEVEL, lfull, lnoth, rfull, rnoth)) info |= I_FULL;
             if (out_rev) info |= I_REV;
-            info = finish_info(info, (int)n, p);
+            {   // routing of update_gtf.c:943-950 when there is no junction table (finish_info)
+                if (fast_args()->p.n_sj == 0 && (info & (I_FULL | I_KNOWN | I_KSITE)) == (I_FULL | I_KSITE)) info |= I_ACCEPT;
+                info |= n << 8;
+            }
         } else if (active) {
             info = n << 8;
             if (in_lds) for (int k = 0; k < (int)n; ++k) W[k] = (uint16_t)0;
@@ -1055,13 +1084,14 @@ void k_classify_fast(FastArgs a, int64_t n_tiles, const TileDesc *__restrict__ u
 
         // ---- phase 3: redo list, accepted counts, coalesced write-out of the tile
         redo = redo && active;
+        const FastArgsK ao = fast_args();
         {
             const unsigned long long m = __ballot(redo);
             if (m) {
                 uint32_t at = 0;
-                if (lane == 0) at = atomicAdd(a.redo_count, (uint32_t)__popcll(m));
+                if (lane == 0) at = atomicAdd(ao->redo_count, (uint32_t)__popcll(m));
                 at = __shfl(at, 0, WAVE);
-                if (redo) a.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+                if (redo) ao->redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
             }
             const bool acc = (info & I_ACCEPT) != 0;
             const uint32_t ca = (uint32_t)__popcll(__ballot(acc)), cx = wave_sum(acc ? n : 0u);
@@ -1070,20 +1100,20 @@ void k_classify_fast(FastArgs a, int64_t n_tiles, const TileDesc *__restrict__ u
         __syncthreads();
         L2R_STAMP(5);
         if (threadIdx.x == 0) {
-            a.tile_acc[t] = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
-            a.tile_acc_ex[t] = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+            ao->tile_acc[t] = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+            ao->tile_acc_ex[t] = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
         }
         if (in_lds) {
             for (uint32_t i = threadIdx.x; i < tile_total; i += TILE_THREADS) {
-                a.ex_start[base + i] = s_S[i];
-                a.ex_end[base + i] = s_E[i];
-                a.ex_flag[base + i] = (uint8_t)s_W[i];
+                ao->ex_start[base + i] = s_S[i];
+                ao->ex_end[base + i] = s_E[i];
+                ao->ex_flag[base + i] = (uint8_t)s_W[i];
             }
         }
         if (active) {
-            a.ex_off[r] = base + local;
-            a.info[r] = info;
-            a.ref_tx[r] = ref;
+            ao->ex_off[r] = base + local;
+            ao->info[r] = info;
+            ao->ref_tx[r] = ref;
         }
         __syncthreads();                 // the tile's LDS image has been written out: the next tile may overwrite it
         L2R_STAMP(6);
