@@ -240,7 +240,12 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
         __syncthreads();
         if (threadIdx.x < WAVE) { const uint32_t c = s_hist[threadIdx.x]; s_hist[threadIdx.x] = wave_inclusive_scan(c) - c; }
         __syncthreads();
-        if (active) order_out[(int64_t)blockIdx.x * p.reads_per_tile + s_hist[bin] + rank] = (uint8_t)threadIdx.x;
+        // A workgroup's wave w runs on SIMD w of its CU: rotating the slots by one wave per tile spreads the long-read
+        // waves over the four SIMDs (full 256-read tiles only; a partial tile keeps its active reads in the first slots)
+        uint32_t slot = s_hist[bin] + rank;
+        if (p.reads_per_tile == TILE_THREADS && (int64_t)(blockIdx.x + 1) * TILE_THREADS <= n_reads)
+            slot = (slot + (uint32_t)WAVE * ((blockIdx.x + (blockIdx.x >> 10)) & 3u)) & (uint32_t)(TILE_THREADS - 1);    // (a persistent workgroup sees tiles b, b + 1024, ...)
+        if (active) order_out[(int64_t)blockIdx.x * p.reads_per_tile + slot] = (uint8_t)threadIdx.x;
     }
     // the tile's chromosome is the one of its first read; reads on another one go to the generic kernel
     const int tid0 = s_tid0;
