@@ -442,6 +442,41 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         }
         const double est = cuts / (double)sample + 1.0;
         while (rpt > 32 && est * rpt * 1.25 > (double)LDS_EXON_CAP) rpt >>= 1;
+        // ... and keep the genomic span of a tile inside the staged bucket directory (DIR_CAP buckets of 512 bp):
+        // sparse input (few reads per locus) makes 256 consecutive reads span many genes, and a tile that does not
+        // fit goes to the generic kernel read by read (~30x the cost).  Sample windows of the sorted input, take for
+        // every candidate size the share of windows that would not fit, and pick the cheapest size.
+        if (sorted && N >= 2 * TILE_THREADS) {
+            const int64_t n_win = std::min<int64_t>(N / TILE_THREADS, 384);
+            const int64_t wstep = (N / TILE_THREADS) / n_win;
+            const int64_t limit = (int64_t)(DIR_CAP - 8) << SITE_SHIFT;
+            int64_t bad[4] = {0, 0, 0, 0};                 // sizes 256, 128, 64, 32
+            for (int64_t w = 0; w < n_win; ++w) {
+                const int64_t i0 = w * wstep * TILE_THREADS;
+                int64_t hi = 0;
+                int size_idx = 3, next_mark = 32;
+                for (int64_t q = 0; q < TILE_THREADS && i0 + q < N; ++q) {
+                    const int64_t i = i0 + q;
+                    if (r->tid[i] != r->tid[i0]) break;
+                    int64_t end = r->pos[i];
+                    for (int64_t k = r->cig_off[i]; k < r->cig_off[i + 1]; ++k) if ((0x18du >> (r->cig[k] & 15u)) & 1u) end += r->cig[k] >> 4;
+                    hi = std::max(hi, end - r->pos[i0]);
+                    if (q + 1 == next_mark) {              // the first 32 / 64 / 128 / 256 reads of the window
+                        if (hi > limit) { for (int z = 0; z <= size_idx; ++z) bad[z]++; break; }   // this size and every larger one
+                        --size_idx; next_mark <<= 1;
+                    }
+                }
+            }
+            double best = 1e300; int best_rpt = rpt;
+            for (int z = 0; z < 4; ++z) {
+                const int cand = TILE_THREADS >> z;
+                if (cand > rpt) continue;
+                const double f = (double)bad[z] / (double)n_win;
+                const double cost = (1.0 - f) * (z == 0 ? 1.0 : z == 1 ? 1.6 : z == 2 ? 2.6 : 4.5) + 30.0 * f;
+                if (cost < best - 1e-9) { best = cost; best_rpt = cand; }
+            }
+            rpt = best_rpt;
+        }
     }
     c->reads_per_tile = rpt;
     c->n_tiles = (N + rpt - 1) / rpt;
@@ -467,8 +502,8 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     c->ex_cap = (int64_t)exb;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (getenv("L2R_STAMPS") && !c->stamps.p) {
-        if (c->stamps.ensure(1024 * 8)) return -2;
-        HIP_TRY(hipMemsetAsync(c->stamps.p, 0, 1024 * 8 * 8, c->stream));
+        if (c->stamps.ensure(1024 * 8 + 16)) return -2;
+        HIP_TRY(hipMemsetAsync(c->stamps.p, 0, (1024 * 8 + 16) * 8, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     c->n_reads = N; c->n_cigar = r->n_cigar; c->first_read = r->first_read_index;
@@ -599,12 +634,13 @@ int l2r_debug_stamps(l2r_ctx *c, unsigned long long *out, int n)
 {
     if (!c || !out) return fail(-1, "[l2r_debug_stamps] null argument");
     if (!c->stamps.p) { for (int i = 0; i < n; ++i) out[i] = 0; return 0; }
-    std::vector<unsigned long long> h(1024 * 8);
+    std::vector<unsigned long long> h(1024 * 8 + 16);
     HIP_TRY(hipMemcpyAsync(h.data(), c->stamps.p, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemsetAsync(c->stamps.p, 0, h.size() * 8, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; ++i) out[i] = 0;
-    for (size_t k = 0; k < h.size(); ++k) if ((int)(k & 7) < n) out[k & 7] += h[k];
+    for (size_t k = 0; k < 1024 * 8; ++k) if ((int)(k & 7) < n) out[k & 7] += h[k];
+    for (int i = 8; i < n && i < 16; ++i) out[i] = h[1024 * 8 + (i - 8)];      /* redo reasons: not fast, not in LDS, wide, other tid, not sane, window/compact */
     return 0;
 }
 

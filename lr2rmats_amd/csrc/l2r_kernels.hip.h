@@ -1089,6 +1089,10 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
 
         // ---- phase 3: redo list, accepted counts, coalesced write-out of the tile
         redo = redo && active;
+        if (stamping && redo) {          // diagnostics: why reads leave the fast path
+            const int why = !fast ? 0 : !in_lds ? 1 : any_wide ? 2 : tid != d.tid ? 3 : (n > 1 && !sane) ? 4 : 5;
+            atomicAdd(&fast_args()->stamps[8192 + why], 1ull);
+        }
         const FastArgsK ao = fast_args();
         {
             const unsigned long long m = __ballot(redo);

@@ -28,6 +28,18 @@ struct h_job {
 };
 
 static int g_open_outputs = 1;
+
+/* L2R_TIMING=1: wall-clock per stage on stderr (diagnostics; the reference prints nothing comparable) */
+#include <time.h>
+static double h_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static double g_t_last = 0.0;
+static void h_stage_time(const char *what)
+{
+    if (!getenv("L2R_TIMING")) return;
+    const double t = h_now();
+    if (g_t_last > 0.0) fprintf(stderr, "[timing] %-28s %9.3f s\n", what, t - g_t_last);
+    g_t_last = t;
+}
 static FILE *open_w(const char *fn)
 {
     if (!g_open_outputs) return NULL;
@@ -136,8 +148,10 @@ h_job *h_job_open(int argc, char **argv, int *exit_code)
     }
     if (argc - optind != 2) { *exit_code = update_usage(); free(j); return NULL; }
 
+    h_stage_time("start");
     if (j->mode == 0) {
         h_read_alignments(argv[optind], &j->chr, &j->reads, 0, "update_gtf");
+        h_stage_time("read alignments");
     } else {
         if (!hdr_file) h_fatal("update_gtf", "Couldn't read header of provided BAM file.\n");
         h_read_header_only(hdr_file, &j->chr, "update_gtf");
@@ -146,6 +160,7 @@ h_job *h_job_open(int argc, char **argv, int *exit_code)
     fprintf(stderr, "[read_anno_trans] reading transcript annotation from %s ...\n", argv[optind + 1]);
     h_read_gtf(argv[optind + 1], &j->chr, &j->anno, 0);
     fprintf(stderr, "[read_anno_trans] reading transcript annotation from %s done.\n", argv[optind + 1]);
+    h_stage_time("read annotation");
     h_read_sj(j->sj_fp, &j->chr, &j->sj);
     return j;
 }
@@ -190,14 +205,20 @@ static void run_engine(const char *who, const l2r_params *prm, const l2r_annotat
 {
     l2r_ctx *ctx = l2r_create(0);
     if (!ctx) engine_fail(who);
+    h_stage_time("engine: create");
     if (l2r_set_params(ctx, prm) || l2r_set_annotation(ctx, a) || l2r_set_junctions(ctx, s->n ? s : NULL)) engine_fail(who);
-    if (l2r_upload_reads(ctx, r) || l2r_run(ctx) || l2r_sync(ctx)) engine_fail(who);
+    h_stage_time("engine: annotation tables");
+    if (l2r_upload_reads(ctx, r)) engine_fail(who);
+    h_stage_time("engine: upload reads");
+    if (l2r_run(ctx) || l2r_sync(ctx)) engine_fail(who);
+    h_stage_time("engine: kernels");
     int64_t n = 0, x = 0;
     if (l2r_result_sizes(ctx, &n, &x, NULL, NULL)) engine_fail(who);
     h_result_alloc(out, n, x);
     l2r_result res = { n, x, 0, out->ex_off, out->ex_start, out->ex_end, out->ex_flag, out->info, out->ref_tx };
     if (l2r_download(ctx, &res)) engine_fail(who);
     out->n = res.n_reads; out->n_ex = res.n_exons;
+    h_stage_time("engine: download");
     l2r_destroy(ctx);
 }
 
@@ -212,6 +233,7 @@ int h_cmd_update_gtf(int argc, char **argv)
     run_engine("update_gtf", &prm, &a, &s, &r, &out);
     l2r_result res = { out.n, out.n_ex, out.n_ex, out.ex_off, out.ex_start, out.ex_end, out.ex_flag, out.info, out.ref_tx };
     rc = h_job_finish(j, &res);
+    h_stage_time("merge + writers");
     h_result_free(&out);
     h_job_free(j);
     return rc;

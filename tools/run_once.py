@@ -24,7 +24,9 @@ if os.environ.get("L2R_STAMPS"):
     lib.l2r_debug_stamps(e.ctx, out, 16)
     v = list(out)
     tot = sum(v) or 1
-    print("stamps (cycles of thread 0 summed over tiles):", [(i, x, round(100.0 * x / tot, 1)) for i, x in enumerate(v) if x])
+    tot = sum(v[:8]) or 1
+    print("stamps (cycles of thread 0 summed over tiles):", [(i, x, round(100.0 * x / tot, 1)) for i, x in enumerate(v[:8]) if x])
+    print("redo reasons [not fast, not in LDS, wide, other tid, not sane, window/compact]:", v[8:14])
 cnt = (C.c_longlong * 4)()
 lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 lib.l2r_debug_counters(e.ctx, cnt, 4)
