@@ -105,7 +105,7 @@ def main():
     gathered = {}
 
     def exchange():
-        # counts of (records, exons) per rank, then four all-gathervs of engine-owned HBM
+        # counts of (records, exons) per rank, then four padded all-gathers of engine-owned HBM (workload.all_gatherv)
         _, _, m, x = eng.sizes()
         v = eng.device_view()
         cnt = torch.tensor([m, x], dtype=torch.int64, device=device)
@@ -115,8 +115,7 @@ def main():
         parts = (("rec", v.acc_rec, 16, 0), ("ex_start", v.acc_ex_start, 4, 1), ("ex_end", v.acc_ex_end, 4, 1), ("ex_flag", v.acc_ex_flag, 1, 1))
         for name, ptr, width, which in parts:
             mine = workload.device_bytes(ptr, (m if which == 0 else x) * width, device)
-            outs = [torch.empty(c[which] * width, dtype=torch.uint8, device=device) for c in allc]
-            dist.all_gather(outs, mine)
+            outs, _ = workload.all_gatherv(mine, counts=[c[which] * width for c in allc])
             gathered[name] = outs
         return sum(c[0] for c in allc), sum(c[1] for c in allc)
 

@@ -158,7 +158,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 // ------------------------------------------------------------------ CIGAR -> exons
 
 // src/bam2gtf.c:31-78 gen_exon.  emit(k, start, end) is called for every exon kept.
-// CIGAR words are fetched four at a time so that the loads of one read are in flight together; the state update
+// CIGAR words are fetched eight (then four) at a time so that the loads of one read are in flight together; the state update
 // is written without short-circuit logic so that it compiles to selects (one predicated region per op: the emit).
 template <typename Ptr, typename Emit>
 __device__ __forceinline__ int walk_cigar(Ptr cig, int n_cig, int pos0, const DevParams &p, Emit emit)
@@ -176,6 +176,11 @@ __device__ __forceinline__ int walk_cigar(Ptr cig, int n_cig, int pos0, const De
         end += ((0x18du >> op) & 1u) ? len : 0;         // ops 0 2 3 7 8
     };
     int k = 0;
+    for (; k + 8 <= n_cig; k += 8) {
+        const uint32_t c0 = cig[k], c1 = cig[k + 1], c2 = cig[k + 2], c3 = cig[k + 3];
+        const uint32_t c4 = cig[k + 4], c5 = cig[k + 5], c6 = cig[k + 6], c7 = cig[k + 7];
+        step(c0); step(c1); step(c2); step(c3); step(c4); step(c5); step(c6); step(c7);
+    }
     for (; k + 4 <= n_cig; k += 4) {
         const uint32_t c0 = cig[k], c1 = cig[k + 1], c2 = cig[k + 2], c3 = cig[k + 3];
         step(c0); step(c1); step(c2); step(c3);
@@ -195,6 +200,17 @@ __device__ __forceinline__ int cursor_value(const CursorDir &cd, int32_t tid, in
     int lo = (int)cd.dir[kb + c], hi = (int)cd.dir[kb + c + 1];
     if (c == nb - 1) hi = (int)cd.dir[kb + nb];               // last bucket of the chromosome is open ended
     const int64_t q = pack_key(tid, start);
+    if (hi - lo <= 8) {
+        // a 512-bp bucket rarely holds more than a few transcripts: fetch them in one round trip and count the keys
+        // that are not above q (the keys do not decrease)
+        int64_t k[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) k[u] = lo + u < hi ? cd.key[lo + u] : INT64_MAX;
+        int below = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) below += k[u] <= q ? 1 : 0;
+        return lo + below;
+    }
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (cd.key[mid] > q) hi = mid; else lo = mid + 1;

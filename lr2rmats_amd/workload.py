@@ -80,28 +80,35 @@ def device_bytes(ptr: int, nbytes: int, device):
     return torch.as_tensor(_DevArray(ptr, nbytes), device=device)
 
 
-def all_gatherv(t, group=None):
+def all_gatherv(t, group=None, counts=None):
     """All-gather of 1-D uint8 tensors of different lengths, rank order preserved.
 
-    nccl (= RCCL over xGMI): counts first, then one ``all_gather`` with per-rank sizes (torch issues it as a
-    grouped broadcast when the sizes differ).  gloo (CPU tests): pad to the maximum."""
+    Counts first (one tiny all-gather), then ONE uniform collective: every rank contributes ``max(counts)`` bytes
+    (its payload, padded) to ``all_gather_into_tensor`` -- over RCCL that is a single ring/tree all-gather on xGMI
+    instead of a grouped send per rank, and the same code runs on gloo (CPU tests).  ``t`` may be longer than the
+    rank's own count (a view of an engine buffer with garbage behind the payload): pass ``counts`` then."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    if dist.get_backend(group) == "nccl":
-        outs = [torch.empty(c, dtype=t.dtype, device=t.device) for c in counts]
-        dist.all_gather(outs, t, group=group)
-        return outs, counts
+    if counts is None:
+        n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+        allc = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(allc, n, group=group)
+        counts = [int(c.item()) for c in allc]
     m = max(counts) if counts else 0
-    pad = torch.zeros(m, dtype=t.dtype, device=t.device)
-    pad[: t.numel()] = t
-    outs = [torch.empty(m, dtype=t.dtype, device=t.device) for _ in range(world)]
-    dist.all_gather(outs, pad, group=group)
-    return [o[:c] for o, c in zip(outs, counts)], counts
+    if m == 0:
+        return [t[:0] for _ in range(world)], counts
+    if t.numel() >= m:
+        mine = t[:m]
+    else:
+        mine = torch.zeros(m, dtype=t.dtype, device=t.device)
+        mine[: t.numel()] = t
+    out = torch.empty(world * m, dtype=t.dtype, device=t.device)
+    if hasattr(dist, "all_gather_into_tensor") and dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, mine.contiguous(), group=group)
+    else:
+        dist.all_gather([out[k * m:(k + 1) * m] for k in range(world)], mine.contiguous(), group=group)
+    return [out[k * m: k * m + counts[k]] for k in range(world)], counts
 
 
 def merge_gathered(rec_parts, off_parts, start_parts, end_parts, flag_parts):
