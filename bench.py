@@ -3,8 +3,13 @@
 
 One "step" = one pass of the hot path (CIGAR -> exons, annotation sweep,
 classification, compaction of the accepted-novel records) over the rank's
-resident read shard; at N > 1 a step also performs the one exchange the path
-has: the RCCL all-gatherv of the accepted records (rank order = read order).
+resident read shard.  At N > 1 the shards are blocks of whole chromosomes, which
+is what lr2rmats_amd/dist.py makes of a sorted input: the order-dependent host
+tail never looks across chromosomes, so every rank merges and writes its own
+shard and the step's only collective is the RCCL all-gather of the per-rank list
+sizes (--exchange partitioned, default).  --exchange gathered times the other
+route of dist.py (shards that cut through a chromosome, or -s with a junction
+table): the RCCL all-gatherv of the compacted accepted records to every rank.
 
 Workload at N=1: BASELINE.json configs[2] -- synthetic 10 M long reads, 8 exons/read
 target, GENCODE-scale 1.5 M-exon GTF, pipeline option set `-l 3` (Snakefile:93).
@@ -68,6 +73,7 @@ def main():
     ap.add_argument("--level", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--exchange", choices=("partitioned", "gathered"), default="partitioned")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,6 +118,8 @@ def main():
         allc = [torch.zeros_like(cnt) for _ in range(world)]
         dist.all_gather(allc, cnt)
         allc = [c.tolist() for c in allc]
+        if args.exchange == "partitioned":
+            return sum(c[0] for c in allc), sum(c[1] for c in allc)
         parts = (("rec", v.acc_rec, 16, 0), ("ex_start", v.acc_ex_start, 4, 1), ("ex_end", v.acc_ex_end, 4, 1), ("ex_flag", v.acc_ex_flag, 1, 1))
         for name, ptr, width, which in parts:
             mine = workload.device_bytes(ptr, (m if which == 0 else x) * width, device)
@@ -187,7 +195,10 @@ def main():
                                    "%d-exon / %d-transcript GTF, update-gtf -l %d" % (
                                        reads.n, n_x / max(n_r, 1), reads.cig.shape[0] / max(n_r, 1), af.n_exons, af.n_tx, args.level),
                        "reads_per_gpu": reads.n, "total_reads": total_reads, "accepted_reads_rank0": n_acc,
-                       "exchange": "none (1 GPU)" if world == 1 else "RCCL all-gatherv of accepted records, %s records / %s exons total" % (last[0], last[1]),
+                       "exchange": "none (1 GPU)" if world == 1 else (
+                           "partitioned: chromosome-aligned shards merge on their own rank, RCCL all-gather of the list sizes only (%s accepted records / %s exons in total stay local)" % (last[0], last[1])
+                           if args.exchange == "partitioned" else
+                           "gathered: RCCL all-gatherv (padded all_gather_into_tensor) of %s accepted records / %s exons to every rank" % (last[0], last[1])),
                        "parallelism": "reads sharded over %d GPU(s), annotation replicated" % world},
             "roofline": roof,
             "cpu_baseline": cpu,

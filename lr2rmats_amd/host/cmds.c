@@ -25,6 +25,7 @@ struct h_job {
     h_sj sj;
     FILE *sj_fp;
     int mode;
+    char *out_path[8];           /* 0 updated gtf (NULL = stdout), 1 exon bed, 2 bam gtf, 3 detail, 4 known, 5 novel, 6 unrecog, 7 summary */
 };
 
 static int g_open_outputs = 1;
@@ -133,15 +134,15 @@ h_job *h_job_open(int argc, char **argv, int *exit_code)
         case 'l': j->o.prm.full_level = atoi(optarg); break;
         case 'M': j->o.prm.use_multi = 1; break;
         case 'J': j->o.prm.min_sj_cnt = atoi(optarg); break;
-        case 'o': j->o.out_gtf = open_w(optarg); break;
+        case 'o': j->o.out_gtf = open_w(optarg); free(j->out_path[0]); j->out_path[0] = strdup(optarg); break;
         case 'n': break;                                   /* accepted, unused (src/update_gtf.c:1031,1084) */
-        case 'E': j->o.exon_bed = open_w(optarg); break;
-        case 'a': j->o.bam_gtf = open_w(optarg); break;
-        case 'A': j->o.bam_detail = open_w(optarg); break;
-        case 'k': j->o.known_gtf = open_w(optarg); break;
-        case 'v': j->o.novel_gtf = open_w(optarg); break;
-        case 'u': j->o.unrecog_gtf = open_w(optarg); break;
-        case 'y': j->o.summary = open_w(optarg); break;
+        case 'E': j->o.exon_bed = open_w(optarg); free(j->out_path[1]); j->out_path[1] = strdup(optarg); break;
+        case 'a': j->o.bam_gtf = open_w(optarg); free(j->out_path[2]); j->out_path[2] = strdup(optarg); break;
+        case 'A': j->o.bam_detail = open_w(optarg); free(j->out_path[3]); j->out_path[3] = strdup(optarg); break;
+        case 'k': j->o.known_gtf = open_w(optarg); free(j->out_path[4]); j->out_path[4] = strdup(optarg); break;
+        case 'v': j->o.novel_gtf = open_w(optarg); free(j->out_path[5]); j->out_path[5] = strdup(optarg); break;
+        case 'u': j->o.unrecog_gtf = open_w(optarg); free(j->out_path[6]); j->out_path[6] = strdup(optarg); break;
+        case 'y': j->o.summary = open_w(optarg); free(j->out_path[7]); j->out_path[7] = strdup(optarg); break;
         case 'S': strncpy(j->o.source, optarg, sizeof j->o.source - 1); break;
         default: fprintf(stderr, "Error: unknown option: %s.\n", optarg); *exit_code = update_usage(); free(j); return NULL;
         }
@@ -188,9 +189,72 @@ int h_job_finish(h_job *j, const l2r_result *res)
     return 0;
 }
 
+void h_job_open_outputs(h_job *j)
+{
+    /* a job opened without output files (h_job_open2(..., 0)) that turns out to be the writer */
+    FILE **fs[8] = {&j->o.out_gtf, &j->o.exon_bed, &j->o.bam_gtf, &j->o.bam_detail, &j->o.known_gtf, &j->o.novel_gtf, &j->o.unrecog_gtf, &j->o.summary};
+    for (int k = 0; k < 8; ++k) if (j->out_path[k] && (!*fs[k] || *fs[k] == stdout)) {
+        *fs[k] = fopen(j->out_path[k], "w");
+        if (!*fs[k]) h_fatal("update_gtf", "Can not open \"%s\" for writing\n", j->out_path[k]);
+    }
+    if (!j->o.out_gtf) j->o.out_gtf = stdout;
+}
+
+void h_job_set_out_path(h_job *j, int which, const char *path)
+{
+    if (which < 0 || which >= 8) return;
+    free(j->out_path[which]); j->out_path[which] = path ? strdup(path) : NULL;
+}
+
+const char *h_job_out_path(const h_job *j, int which) { return (j && which >= 0 && which < 8) ? j->out_path[which] : NULL; }
+
+static FILE *open_part(const char *path, const char *suffix)
+{
+    if (!path) return NULL;
+    char *fn = (char *)h_malloc(strlen(path) + strlen(suffix) + 1);
+    strcpy(fn, path); strcat(fn, suffix);
+    FILE *f = fopen(fn, "w");
+    if (!f) h_fatal("update_gtf", "Can not open \"%s\" for writing\n", fn);
+    free(fn);
+    return f;
+}
+
+int h_job_finish_part(h_job *j, int64_t lo, int64_t hi, const l2r_result *res, const char *suffix, const char *stdout_base,
+                      int first_part, int64_t counters[H_N_SUMMARY])
+{
+    if (lo < 0 || hi < lo || hi > j->reads.n) h_fatal("update_gtf", "bad read range [%lld, %lld)", (long long)lo, (long long)hi);
+    if (res->n_reads != hi - lo) h_fatal("update_gtf", "result covers %lld reads, the part has %lld", (long long)res->n_reads, (long long)(hi - lo));
+    h_update_opts o = j->o;
+    o.out_gtf = open_part(j->out_path[0] ? j->out_path[0] : stdout_base, suffix);
+    o.exon_bed = open_part(j->out_path[1], suffix); o.bam_gtf = open_part(j->out_path[2], suffix); o.bam_detail = open_part(j->out_path[3], suffix);
+    o.known_gtf = open_part(j->out_path[4], suffix); o.novel_gtf = open_part(j->out_path[5], suffix); o.unrecog_gtf = open_part(j->out_path[6], suffix);
+    o.summary = NULL; o.summary_counts = counters; o.no_detail_header = !first_part;
+    if (!o.out_gtf) h_fatal("update_gtf", "a partitioned run needs -o or a base path for the updated GTF");
+    h_reads part = j->reads;                                   /* a view: per-read arrays shifted, string table shared */
+    part.n = hi - lo; part.tid += lo; part.pos += lo; part.rev += lo; part.qname += lo; part.cig_off += lo;
+    h_result hr;
+    hr.n = res->n_reads; hr.n_ex = res->n_exons; hr.ex_off = res->ex_off; hr.ex_start = res->ex_start; hr.ex_end = res->ex_end;
+    hr.ex_flag = res->ex_flag; hr.info = res->info; hr.ref_tx = res->ref_tx;
+    memset(counters, 0, H_N_SUMMARY * sizeof counters[0]);
+    h_update_tail(&o, &j->chr, &part, &j->anno, &hr, j->sj.n);
+    FILE *fs[] = {o.out_gtf, o.exon_bed, o.bam_gtf, o.bam_detail, o.known_gtf, o.novel_gtf, o.unrecog_gtf};
+    for (size_t k = 0; k < sizeof fs / sizeof fs[0]; ++k) if (fs[k]) fclose(fs[k]);
+    return 0;
+}
+
+int h_job_write_summary(h_job *j, const int64_t counters[H_N_SUMMARY], const char *path)
+{
+    FILE *f = fopen(path, "w");
+    if (!f) h_fatal("update_gtf", "Can not open \"%s\" for writing\n", path);
+    h_write_summary_text(f, j->anno.gene_n, (int)j->anno.n_tx, counters);
+    fclose(f);
+    return 0;
+}
+
 void h_job_free(h_job *j)
 {
     if (!j) return;
+    for (int k = 0; k < 8; ++k) free(j->out_path[k]);
     if (j->sj_fp) fclose(j->sj_fp);
     h_reads_free(&j->reads); h_gtf_free(&j->anno); h_sj_free(&j->sj); h_chroms_free(&j->chr);
     free(j);

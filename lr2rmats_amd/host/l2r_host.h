@@ -80,10 +80,13 @@ void h_result_alloc(h_result *r, int64_t n_reads, int64_t ex_cap);
 void h_result_free(h_result *r);
 
 /* ---- the sequential tail + writers */
+#define H_N_SUMMARY 16            /* counters of summary.txt, see tail.c summary_and_bed */
 typedef struct {
     l2r_params prm;
     FILE *out_gtf, *exon_bed, *bam_gtf, *bam_detail, *known_gtf, *novel_gtf, *unrecog_gtf, *summary;
     char source[1024];
+    int no_detail_header;        /* parts after the first of a partitioned run: detail.txt without its column line */
+    int64_t *summary_counts;     /* non-NULL: the summary counters go here (H_N_SUMMARY values) instead of being printed */
 } h_update_opts;
 
 /* Everything update_gtf() does after check_with_anno_trans/check_with_short_sj:
@@ -91,6 +94,8 @@ typedef struct {
  * read names / gene names come from `reads` and `anno`. */
 void h_update_tail(const h_update_opts *o, const h_chroms *chr, const h_reads *reads, const h_gtf *anno,
                    const h_result *res, int64_t n_sj);
+
+void h_write_summary_text(FILE *s, int anno_genes, int anno_tx, const int64_t *counters);
 
 void h_unique_tail(const l2r_params *p, const char *source, FILE *out, int intersect, const h_chroms *chr,
                    int64_t n, const int32_t *tid, const uint8_t *rev, const int64_t *ex_off, const int32_t *xs, const int32_t *xe,
@@ -111,5 +116,19 @@ h_job *h_job_open2(int argc, char **argv, int *exit_code, int open_outputs);   /
 void   h_job_views(h_job *j, l2r_params *prm, l2r_annotation *anno, l2r_junctions *sj, l2r_reads *reads);
 int    h_job_finish(h_job *j, const l2r_result *res);
 void   h_job_free(h_job *j);
+
+/* Partitioned form (one-process-per-GPU runs whose read shards are cut at chromosome boundaries: the order-dependent
+ * tail never looks across chromosomes -- merge_trans stops at a smaller tid, src/update_gtf.c:147, the novel-exon
+ * and gene lists likewise, :181-222 -- so every rank can run it on its own shard).  Writes every requested output
+ * of the reads [lo, hi) to "<output path><suffix>" (the updated GTF of a stdout run to "<stdout_base><suffix>") and
+ * returns the summary counters; the caller concatenates the parts in shard order and adds the counters up.
+ * Not valid with -s and a junction table (split pieces carry tid 0 and are compared across chromosomes, Q2). */
+int    h_job_finish_part(h_job *j, int64_t lo, int64_t hi, const l2r_result *res, const char *suffix, const char *stdout_base,
+                         int first_part, int64_t counters[H_N_SUMMARY]);
+/* which: 0 updated gtf (NULL = stdout), 1 exon bed, 2 bam gtf, 3 detail, 4 known, 5 novel, 6 unrecog, 7 summary */
+const char *h_job_out_path(const h_job *j, int which);
+void   h_job_set_out_path(h_job *j, int which, const char *path);
+void   h_job_open_outputs(h_job *j);                       /* open the output files of a job that was opened without them */
+int    h_job_write_summary(h_job *j, const int64_t counters[H_N_SUMMARY], const char *path);
 
 #endif

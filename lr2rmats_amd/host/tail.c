@@ -273,7 +273,9 @@ static void print_detail(FILE *fp, const tail_ctx *c)
     /* src/update_gtf.c:297-419 print_bam_detail_trans */
     obuf o; ob_init(&o, fp);
     const h_result *r = c->res;
-    ob_s(&o, "ReadName\tchr\tstrand\tNovel\tGeneID\tGeneName\tExonCount\tExonStart\tExonEnd\tNovelExonCount\tNovelExonIndex\tNovelSiteCount\tNovelSiteIndex\tNovelJunctionCount\tNovelJunctionIndex\tUnreliableJunctionCount\tUnreliableJunctionIndex\n");
+    if (!c->o->no_detail_header) {
+        ob_s(&o, "ReadName\tchr\tstrand\tNovel\tGeneID\tGeneName\tExonCount\tExonStart\tExonEnd\tNovelExonCount\tNovelExonIndex\tNovelSiteCount\tNovelSiteIndex\tNovelJunctionCount\tNovelJunctionIndex\tUnreliableJunctionCount\tUnreliableJunctionIndex\n");
+    }
     for (int64_t i = 0; i < r->n; ++i) {
         const int64_t off = r->ex_off[i];
         const uint32_t info = r->info[i];
@@ -312,6 +314,36 @@ static void add_gene(s_gene **G, int *n, int *cap, int32_t tid, const char *gid)
     /* src/update_gtf.c:181-203: backward scan, equal gene_id first, then stop at a smaller tid */
     for (int k = *n - 1; k >= 0; --k) { if (strcmp(gid, (*G)[k].gid) == 0) return; if (tid > (*G)[k].tid) break; }
     S_GROW(*G, *n, *cap, s_gene); (*G)[*n].tid = tid; (*G)[*n].gid = gid; ++*n;
+}
+
+void h_write_summary_text(FILE *s, int anno_genes, int anno_tx, const int64_t *k)
+{
+    /* src/update_gtf.c:530-569; k = the counters in the order summary_and_bed fills them */
+    fprintf(s, "==== Annotaion ====\n");
+    fprintf(s, "Genes_of_annotation_GTF\t%d\n", anno_genes);
+    fprintf(s, "Transcripts_of_annotation_GTF\t%d\n", anno_tx);
+    fprintf(s, "\n===================\n\n==== Updated information ====\n");
+    fprintf(s, "Updated_Genes\t%d\n", (int)k[0]);
+    fprintf(s, "Added_Novel_Transcripts\t%d\n", (int)k[1]);
+    fprintf(s, "Added_Novel_Full-read_Transcripts\t%d\n", (int)(k[1] - k[2]));
+    fprintf(s, "Added_Novel_Partial-read_Transcripts\t%d\n", (int)k[2]);
+    fprintf(s, "Added_Novel_Exons\t%d\n", (int)k[3]);
+    fprintf(s, "Added_Novel_Sites\t%d\n", (int)k[4]);
+    fprintf(s, "Added_Novel_Splice_Junctions\t%d\n", (int)k[5]);
+    fprintf(s, "\n=============================\n\n==== Known information ====\n");
+    fprintf(s, "Known_Transcripts_from_BAM\t%d\n", (int)k[6]);
+    fprintf(s, "Genes_of_Known_Transcripts_from_BAM\t%d\n", (int)k[7]);
+    fprintf(s, "Uniq_Known_Transcripts_from_BAM\t%d\n", (int)k[8]);
+    fprintf(s, "\n===========================\n\n==== Novel information ====\n");
+    fprintf(s, "Novel_Transcript_from_BAM\t%d\n", (int)(k[9] + k[10]));
+    fprintf(s, "Novel_Transcript_from_BAM_with_All_Reliable_Junction\t%d\n", (int)k[9]);
+    fprintf(s, "Uniq_Novel_Transcript_from_BAM_with_All_Reliable_Junction\t%d\n", (int)k[11]);
+    fprintf(s, "Novel_Transcript_from_BAM_with_Unreliable_Junction\t%d\n", (int)k[10]);
+    fprintf(s, "Uniq_Novel_Transcript_from_BAM_with_Unreliable_Junction\t%d\n", (int)k[12]);
+    fprintf(s, "\n===========================\n\n==== Unrecognized information ====\n");
+    fprintf(s, "Unrecognized_Transcript_from_BAM\t%d\n", (int)k[13]);
+    fprintf(s, "Uniq_Unrecognized_Transcript_from_BAM\t%d\n", (int)k[14]);
+    fprintf(s, "\n==================================\n");
 }
 
 static void summary_and_bed(const tail_ctx *c, const m_list *U)
@@ -353,7 +385,7 @@ static void summary_and_bed(const tail_ctx *c, const m_list *U)
             if (!hit) { S_GROW(J, j_n, j_cap, s_junc); J[j_n].tid = t->tid; J[j_n].don = xe[j]; J[j_n].acc = xs[j + 1]; ++j_n; }
         }
     }
-    if (c->o->summary) {
+    if (c->o->summary || c->o->summary_counts) {
         /* :496-528: classes of every input read + unique counts through merge_trans on fresh lists */
         int n_known = 0, n_rel = 0, n_unrel = 0, n_unrec = 0;
         m_list uk, ur, uu, un; memset(&uk, 0, sizeof uk); memset(&ur, 0, sizeof ur); memset(&uu, 0, sizeof uu); memset(&un, 0, sizeof un);
@@ -366,32 +398,10 @@ static void summary_and_bed(const tail_ctx *c, const m_list *U)
             else { ++n_unrec; dst = &un; }
             if (!m_merge(&t, dst, p)) m_push(dst, &t);
         }
-        FILE *s = c->o->summary;
-        fprintf(s, "==== Annotaion ====\n");
-        fprintf(s, "Genes_of_annotation_GTF\t%d\n", c->anno->gene_n);
-        fprintf(s, "Transcripts_of_annotation_GTF\t%d\n", (int)c->anno->n_tx);
-        fprintf(s, "\n===================\n\n==== Updated information ====\n");
-        fprintf(s, "Updated_Genes\t%d\n", upd_genes);
-        fprintf(s, "Added_Novel_Transcripts\t%d\n", (int)U->n);
-        fprintf(s, "Added_Novel_Full-read_Transcripts\t%d\n", (int)U->n - partial);
-        fprintf(s, "Added_Novel_Partial-read_Transcripts\t%d\n", partial);
-        fprintf(s, "Added_Novel_Exons\t%d\n", e_n);
-        fprintf(s, "Added_Novel_Sites\t%d\n", d_n + a_n);
-        fprintf(s, "Added_Novel_Splice_Junctions\t%d\n", j_n);
-        fprintf(s, "\n=============================\n\n==== Known information ====\n");
-        fprintf(s, "Known_Transcripts_from_BAM\t%d\n", n_known);
-        fprintf(s, "Genes_of_Known_Transcripts_from_BAM\t%d\n", known_genes);
-        fprintf(s, "Uniq_Known_Transcripts_from_BAM\t%d\n", (int)uk.n);
-        fprintf(s, "\n===========================\n\n==== Novel information ====\n");
-        fprintf(s, "Novel_Transcript_from_BAM\t%d\n", n_rel + n_unrel);
-        fprintf(s, "Novel_Transcript_from_BAM_with_All_Reliable_Junction\t%d\n", n_rel);
-        fprintf(s, "Uniq_Novel_Transcript_from_BAM_with_All_Reliable_Junction\t%d\n", (int)ur.n);
-        fprintf(s, "Novel_Transcript_from_BAM_with_Unreliable_Junction\t%d\n", n_unrel);
-        fprintf(s, "Uniq_Novel_Transcript_from_BAM_with_Unreliable_Junction\t%d\n", (int)uu.n);
-        fprintf(s, "\n===========================\n\n==== Unrecognized information ====\n");
-        fprintf(s, "Unrecognized_Transcript_from_BAM\t%d\n", n_unrec);
-        fprintf(s, "Uniq_Unrecognized_Transcript_from_BAM\t%d\n", (int)un.n);
-        fprintf(s, "\n==================================\n");
+        int64_t cnt[H_N_SUMMARY] = { upd_genes, U->n, partial, e_n, (int64_t)d_n + a_n, j_n, n_known, known_genes, uk.n,
+                                     n_rel, n_unrel, ur.n, uu.n, n_unrec, un.n, 0 };
+        if (c->o->summary_counts) memcpy(c->o->summary_counts, cnt, sizeof cnt);
+        if (c->o->summary) h_write_summary_text(c->o->summary, c->anno->gene_n, (int)c->anno->n_tx, cnt);
         m_free(&uk); m_free(&ur); m_free(&uu); m_free(&un);
     }
     if (c->o->exon_bed) {                                          /* :571-576 (BAM header names) */
@@ -471,7 +481,7 @@ void h_update_tail(const h_update_opts *o, const h_chroms *chr, const h_reads *r
     if (want_k) print_ref_list(o->known_gtf, &c, &K);
     if (want_n) print_ref_list(o->novel_gtf, &c, &N);
     if (want_x) print_ref_list(o->unrecog_gtf, &c, &X);
-    if (o->summary || o->exon_bed) summary_and_bed(&c, &U);
+    if (o->summary || o->summary_counts || o->exon_bed) summary_and_bed(&c, &U);
     m_free(&U); free(K.v); free(N.v); free(X.v);
 }
 

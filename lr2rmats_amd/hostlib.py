@@ -37,6 +37,14 @@ def load_library():
         lib.h_job_finish.argtypes = [C.c_void_p, C.c_void_p]
         lib.h_job_finish.restype = C.c_int
         lib.h_job_free.argtypes = [C.c_void_p]
+        lib.h_job_finish_part.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]
+        lib.h_job_finish_part.restype = C.c_int
+        lib.h_job_out_path.argtypes = [C.c_void_p, C.c_int]
+        lib.h_job_out_path.restype = C.c_char_p
+        lib.h_job_write_summary.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_char_p]
+        lib.h_job_write_summary.restype = C.c_int
+        lib.h_job_open_outputs.argtypes = [C.c_void_p]
+        lib.h_job_set_out_path.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
         _lib = lib
     return _lib
 
@@ -94,6 +102,37 @@ class Job:
         res = capi.CResult(n, x, x, keep[0].ctypes.data_as(capi._i64p), keep[1].ctypes.data_as(capi._i32p), keep[2].ctypes.data_as(capi._i32p),
                            keep[3].ctypes.data_as(capi._u8p), keep[4].ctypes.data_as(capi._u32p), keep[5].ctypes.data_as(capi._i32p))
         return self.lib.h_job_finish(self.h, C.byref(res))
+
+    # ---- partitioned tail (shards cut at chromosome boundaries; see l2r_host.h h_job_finish_part)
+    N_SUMMARY = 16
+    OUTPUTS = ("gtf", "bed", "bam_gtf", "detail", "known", "novel", "unrecog", "summary")
+
+    def open_outputs(self) -> None:
+        self.lib.h_job_open_outputs(self.h)
+
+    def set_out_path(self, which: int, path: str) -> None:
+        self.lib.h_job_set_out_path(self.h, which, path.encode())
+
+    def out_path(self, which: int):
+        p = self.lib.h_job_out_path(self.h, which)
+        return p.decode() if p else None
+
+    def finish_part(self, lo: int, hi: int, ex_off, ex_start, ex_end, ex_flag, info, ref_tx, suffix: str, stdout_base: str,
+                    first_part: bool) -> np.ndarray:
+        """Tail + writers for the reads [lo, hi) into "<output><suffix>" files; returns the summary counters."""
+        n, x = int(info.shape[0]), int(ex_start.shape[0])
+        keep = [np.ascontiguousarray(ex_off, np.int64), np.ascontiguousarray(ex_start, np.int32), np.ascontiguousarray(ex_end, np.int32),
+                np.ascontiguousarray(ex_flag, np.uint8), np.ascontiguousarray(info, np.uint32), np.ascontiguousarray(ref_tx, np.int32)]
+        res = capi.CResult(n, x, x, keep[0].ctypes.data_as(capi._i64p), keep[1].ctypes.data_as(capi._i32p), keep[2].ctypes.data_as(capi._i32p),
+                           keep[3].ctypes.data_as(capi._u8p), keep[4].ctypes.data_as(capi._u32p), keep[5].ctypes.data_as(capi._i32p))
+        cnt = np.zeros(self.N_SUMMARY, np.int64)
+        self.lib.h_job_finish_part(self.h, lo, hi, C.byref(res), suffix.encode(), stdout_base.encode(), 1 if first_part else 0,
+                                   cnt.ctypes.data_as(C.POINTER(C.c_int64)))
+        return cnt
+
+    def write_summary(self, counters: np.ndarray, path: str) -> None:
+        c = np.ascontiguousarray(counters, np.int64)
+        self.lib.h_job_write_summary(self.h, c.ctypes.data_as(C.POINTER(C.c_int64)), path.encode())
 
     def close(self):
         if self.h:

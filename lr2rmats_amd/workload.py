@@ -40,6 +40,22 @@ def shard_bounds(n_reads: int, world: int, weights: np.ndarray | None = None) ->
     return [(cuts[k], cuts[k + 1]) for k in range(world)]
 
 
+def aligned_shard_bounds(tid: np.ndarray, world: int, weights: np.ndarray | None = None):
+    """Shard bounds snapped to chromosome boundaries of a tid-sorted read array, or None when the reads are not
+    grouped by chromosome.  A rank may get an empty shard when there are fewer chromosomes than ranks."""
+    n = int(tid.shape[0])
+    if n == 0 or np.any(np.diff(tid) < 0):
+        return None
+    edges = np.concatenate([[0], np.nonzero(np.diff(tid) != 0)[0] + 1, [n]])       # starts of the chromosomes + n
+    ideal = [b[0] for b in shard_bounds(n, world, weights)] + [n]
+    cuts = [0]
+    for k in range(1, world):
+        e = int(edges[np.argmin(np.abs(edges - ideal[k]))])
+        cuts.append(max(e, cuts[-1]))
+    cuts.append(n)
+    return [(cuts[k], cuts[k + 1]) for k in range(world)]
+
+
 def make_rank_workload(cfg: dict, rank: int, world: int):
     """Weak-scaling workload: every rank gets ``cfg['n_reads']`` reads of the same mix, drawn from its own
     block of chromosomes, so that the concatenation over ranks is one coordinate-sorted read set of

@@ -49,25 +49,88 @@ def test_shard_bounds():
     assert workload.algorithmic_bytes(10, 150, 80, 5, 50) == 4 * 150 + 120 + 640 + (400 - 40) + 80 + 400 + 100
 
 
-@pytest.mark.timeout(300)
-def test_two_ranks_equal_single_process(oracle, tmp_path):
-    anno = synth.make_annotation(5000, 51, nchr=4, shuffle_within_gene=True)
-    reads = synth.make_reads(anno, 5001, 5, 51)
-    sam, gtf = str(tmp_path / "r.sam"), str(tmp_path / "a.gtf")
-    reads.write_sam(sam)
-    anno.write_gtf(gtf)
-    single = {k: str(tmp_path / ("s." + k)) for k in ("gtf", "detail", "bed", "summary")}
-    multi = {k: str(tmp_path / ("m." + k)) for k in ("gtf", "detail", "bed", "summary")}
-    args = lambda o: ["update-gtf", "-l", "3", "-A", o["detail"], "-E", o["bed"], "-y", o["summary"], "-o", o["gtf"], sam, gtf]
-    assert oracle.run_cli(args(single)) == 0
+def _run_ranks(world, argv, extra_env=None, stdout_path=None):
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, "-c", _WORKER % ROOT] + args(multi), env=env, stderr=subprocess.PIPE))
-    for p in procs:
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.update(extra_env or {})
+        out = open(stdout_path, "wb") if (stdout_path and rank == 0) else subprocess.DEVNULL
+        procs.append((subprocess.Popen([sys.executable, "-c", _WORKER % ROOT] + argv, env=env, stderr=subprocess.PIPE, stdout=out), out))
+    for p, out in procs:
         _, err = p.communicate(timeout=280)
+        if out is not subprocess.DEVNULL:
+            out.close()
         assert p.returncode == 0, err.decode()[-3000:]
-    for k in single:
-        assert filecmp.cmp(single[k], multi[k], shallow=False), k
+
+
+@pytest.fixture(scope="module")
+def inputs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("dist")
+    anno = synth.make_annotation(5000, 51, nchr=5, shuffle_within_gene=True)
+    reads = synth.make_reads(anno, 5001, 5, 51)
+    sam, gtf = str(d / "r.sam"), str(d / "a.gtf")
+    reads.write_sam(sam)
+    anno.write_gtf(gtf)
+    return d, anno, reads, sam, gtf
+
+
+KEYS = ("gtf", "detail", "bed", "summary", "known", "novel", "unrec", "all")
+
+
+def _args(o, sam, gtf, extra=()):
+    return ["update-gtf", "-l", "3"] + list(extra) + ["-A", o["detail"], "-E", o["bed"], "-y", o["summary"], "-k", o["known"], "-v", o["novel"],
+                                                        "-u", o["unrec"], "-a", o["all"], "-o", o["gtf"], sam, gtf]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,route", [(2, "partitioned"), (3, "partitioned"), (2, "gathered")])
+def test_ranks_equal_single_process(oracle, tmp_path, inputs, world, route):
+    d, anno, reads, sam, gtf = inputs
+    single = {k: str(tmp_path / ("s." + k)) for k in KEYS}
+    multi = {k: str(tmp_path / ("m." + k)) for k in KEYS}
+    assert oracle.run_cli(_args(single, sam, gtf)) == 0
+    _run_ranks(world, _args(multi, sam, gtf), {"L2R_DIST_GATHER": "1"} if route == "gathered" else None)
+    for k in KEYS:
+        assert filecmp.cmp(single[k], multi[k], shallow=False), (world, route, k)
     assert os.path.getsize(single["detail"]) > 100000
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+
+
+@pytest.mark.timeout(300)
+def test_split_with_junctions_takes_the_gathered_route_and_stdout(oracle, tmp_path, inputs):
+    # -s with a junction table: split pieces are compared across chromosomes (Q2), so the tail runs once on rank 0;
+    # the updated GTF goes to stdout here
+    d, anno, reads, sam, gtf = inputs
+    from tests import util
+    af = anno.in_file_order()
+    base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3))
+    j, _ = util.junction_table(af, reads, base, 51, cover=0.7)
+    tab = str(tmp_path / "SJ.out.tab")
+    j.write(tab)
+    extra = ["-s", "-J", "1", "-j", tab]
+    a, b = str(tmp_path / "s.gtf"), str(tmp_path / "m.gtf")
+    det_a, det_b = str(tmp_path / "s.det"), str(tmp_path / "m.det")
+    assert oracle.run_cli(["update-gtf", "-l", "3"] + extra + ["-A", det_a, sam, gtf], stdout_path=a) == 0
+    _run_ranks(2, ["update-gtf", "-l", "3"] + extra + ["-A", det_b, sam, gtf], stdout_path=b)
+    assert filecmp.cmp(a, b, shallow=False) and filecmp.cmp(det_a, det_b, shallow=False)
+
+
+@pytest.mark.timeout(300)
+def test_partitioned_route_to_stdout(oracle, tmp_path, inputs):
+    d, anno, reads, sam, gtf = inputs
+    a, b = str(tmp_path / "s.gtf"), str(tmp_path / "m.gtf")
+    assert oracle.run_cli(["update-gtf", "-l", "3", sam, gtf], stdout_path=a) == 0
+    _run_ranks(2, ["update-gtf", "-l", "3", sam, gtf], {"TMPDIR": str(tmp_path)}, stdout_path=b)
+    assert filecmp.cmp(a, b, shallow=False)
+
+
+def test_aligned_shard_bounds():
+    tid = np.repeat(np.arange(5, dtype=np.int32), [10, 50, 5, 20, 15])
+    b = workload.aligned_shard_bounds(tid, 3)
+    assert b[0][0] == 0 and b[-1][1] == 100 and all(b[i][1] == b[i + 1][0] for i in range(2))
+    for lo, hi in b:
+        assert lo == hi or lo == 0 or tid[lo - 1] != tid[lo]
+    assert workload.aligned_shard_bounds(np.array([0, 1, 0], np.int32), 2) is None
+    b = workload.aligned_shard_bounds(np.zeros(10, np.int32), 4)          # one chromosome, four ranks: three empty shards
+    assert sum(hi - lo for lo, hi in b) == 10 and sum(1 for lo, hi in b if hi > lo) == 1
