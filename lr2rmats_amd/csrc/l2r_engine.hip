@@ -52,6 +52,7 @@ struct DevBuf {
 struct l2r_ctx {
     int device = 0;
     int fast_grid = 0;
+    bool wide_cigar = false;                // long CIGARs: the HBM walks fetch 16 words per lane and round (l2r_upload_reads decides)
     int n_cu = 256, wg_per_cu = 4;          // persistent grid of k_classify_fast (L2R_WG_PER_CU overrides)
     hipStream_t stream = nullptr;
     l2r_params prm;
@@ -479,6 +480,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         }
     }
     c->reads_per_tile = rpt;
+    c->wide_cigar = N > 0 && (double)r->n_cigar / (double)N > 32.0;
     c->n_tiles = (N + rpt - 1) / rpt;
     c->n_tiles256 = (N + TILE_THREADS - 1) / TILE_THREADS;
 
@@ -555,7 +557,8 @@ static int prepare_unsorted_sj_cursor(l2r_ctx *c)
 
 enum { ST_PASS_A = 0, ST_SCAN1, ST_FAST, ST_GENERIC, ST_SJ, ST_SCAN2, ST_GATHER, ST_N };
 
-#define launch_fast_level(L, fa, grid, s) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles, (const TileDesc *)c->desc.p, (const uint32_t *)c->tile_base.p, (const int64_t *)c->cig_off.p)
+#define launch_fast_level(L, fa, grid, s) if (c->wide_cigar) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L, true>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles, (const TileDesc *)c->desc.p, (const uint32_t *)c->tile_base.p, (const int64_t *)c->cig_off.p); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L, false>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles, (const TileDesc *)c->desc.p, (const uint32_t *)c->tile_base.p, (const int64_t *)c->cig_off.p)
 
 static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
 {
@@ -569,7 +572,12 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     const CursorDir cd{c->anno_key.p, c->key_dir.p, c->kb_base.p, c->n_tid_key, (int32_t)c->n_tx};
     const SiteTabs tabs{{c->sk_st.p, c->sd_st.p, c->sr_st.p}, {c->sk_en.p, c->sd_en.p, nullptr}, c->tid_base.p, c->n_tid_dir};
     // sorted input: the cursor value of every read is computed on the device; unsorted input: it was replayed on the host
-    hipLaunchKernelGGL(k_pass_a, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, tabs, p,
+    if (c->wide_cigar)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass_a<true>), dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, tabs, p,
+                           (c->sorted ? (const int32_t *)nullptr : (const int32_t *)c->win_start.p), c->j0.p, c->local.p, c->order.p, c->tile_base.p, c->desc.p,
+                           c->totals.p + 3);
+    else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass_a<false>), dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, tabs, p,
                        (c->sorted ? (const int32_t *)nullptr : (const int32_t *)c->win_start.p), c->j0.p, c->local.p, c->order.p, c->tile_base.p, c->desc.p,
                        c->totals.p + 3);
     MARK(ST_SCAN1);

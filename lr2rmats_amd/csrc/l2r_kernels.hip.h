@@ -160,7 +160,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 // src/bam2gtf.c:31-78 gen_exon.  emit(k, start, end) is called for every exon kept.
 // CIGAR words are fetched eight (then four) at a time so that the loads of one read are in flight together; the state update
 // is written without short-circuit logic so that it compiles to selects (one predicated region per op: the emit).
-template <typename Ptr, typename Emit>
+// WIDE: the words come from HBM, one read per lane; a lane then fetches 16 words (a whole 64-byte sector) at a time,
+// otherwise every 16-byte load of a long CIGAR drags in a sector of its own (ONT reads: hundreds of ops).
+template <bool WIDE, typename Ptr, typename Emit>
 __device__ __forceinline__ int walk_cigar(Ptr cig, int n_cig, int pos0, const DevParams &p, Emit emit)
 {
     int start = pos0 + 1, end = start - 1, n = 0;
@@ -176,6 +178,15 @@ __device__ __forceinline__ int walk_cigar(Ptr cig, int n_cig, int pos0, const De
         end += ((0x18du >> op) & 1u) ? len : 0;         // ops 0 2 3 7 8
     };
     int k = 0;
+    if (WIDE) {
+        for (; k + 16 <= n_cig; k += 16) {
+            uint32_t c[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c[u] = cig[k + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) step(c[u]);
+        }
+    }
     for (; k + 8 <= n_cig; k += 8) {
         const uint32_t c0 = cig[k], c1 = cig[k + 1], c2 = cig[k + 2], c3 = cig[k + 3];
         const uint32_t c4 = cig[k + 4], c5 = cig[k + 5], c6 = cig[k + 6], c7 = cig[k + 7];
@@ -219,6 +230,8 @@ __device__ __forceinline__ int cursor_value(const CursorDir &cd, int32_t tid, in
 }
 
 // Pass A.  j0_in != null: the cursor values were replayed on the host (unsorted input) and are only read here.
+// WIDE: the input has long CIGARs (the host decides per upload), see walk_cigar.
+template <bool WIDE>
 __global__ __launch_bounds__(TILE_THREADS)
 void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t *__restrict__ r_pos,
               const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ cig, CursorDir cd, SiteTabs tabs, DevParams p,
@@ -243,7 +256,7 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
         if (j0_in) j0 = j0_in[r];
         else { j0 = cursor_value(cd, tid, pos + 1); j0_out[r] = j0; }       // first exon always starts at pos + 1
         el = pos;
-        n = (uint32_t)walk_cigar(cig + c_a, (int)(c_b - c_a), pos, p, [&](int, int, int e) { el = e; });
+        n = (uint32_t)walk_cigar<WIDE>(cig + c_a, (int)(c_b - c_a), pos, p, [&](int, int, int e) { el = e; });
     }
     uint32_t total;
     const uint32_t local = block_exclusive_scan(n, s_wave, total);
@@ -817,7 +830,7 @@ __device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, con
     return v;
 }
 
-template <int LEVEL>
+template <int LEVEL, bool WIDE>
 __global__ __launch_bounds__(TILE_THREADS, 4)
 void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int64_t n_tiles, const TileDesc *__restrict__ u_desc, const uint32_t *__restrict__ u_tile_base,
                      const int64_t *__restrict__ u_cig_off)
@@ -900,12 +913,12 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
                     sane = sane & (s <= e);
                     re.sl = s; re.el = e;
                 };
-                if (staged) walk_cigar(s_cig + (v.c_lo - (u.c0 & ~3u)), n_cig, pos, p, emit);
-                else walk_cigar(a->cig + v.c_lo, n_cig, pos, p, emit);
+                if (staged) walk_cigar<false>(s_cig + (v.c_lo - (u.c0 & ~3u)), n_cig, pos, p, emit);
+                else walk_cigar<WIDE>(a->cig + v.c_lo, n_cig, pos, p, emit);
                 re.s0 = s_S[local]; re.e0 = s_E[local];
             } else {
                 int32_t *const xs = a->ex_start, *const xe = a->ex_end;
-                walk_cigar(a->cig + v.c_lo, n_cig, pos, p, [&](int k, int s, int e) {
+                walk_cigar<WIDE>(a->cig + v.c_lo, n_cig, pos, p, [&](int k, int s, int e) {
                     xs[base + local + k] = s; xe[base + local + k] = e;
                 });
             }
