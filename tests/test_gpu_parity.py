@@ -171,3 +171,29 @@ def test_full_size_properties(engine, oracle):
     np.testing.assert_array_equal(np.concatenate([lo.info, hi.info]), got.info)
     np.testing.assert_array_equal(np.concatenate([lo.ex_flag, hi.ex_flag]), got.ex_flag)
     np.testing.assert_array_equal(np.concatenate([lo.ref_tx, hi.ref_tx]), got.ref_tx)
+
+
+def test_config3_full_size(engine, oracle):
+    """BASELINE config 3 at full size (10 M reads, 1.46 M-exon GTF, the bench workload): idempotence of the whole launch,
+    shard invariance of a 1 M-read slice out of the middle, and that slice bit-exact against the oracle."""
+    from lr2rmats_amd import workload
+    af, reads = workload.make_rank_workload(dict(workload.CONFIGS["cfg3"]), 0, 1)
+    _set_anno(engine, af)
+    engine.set_junctions(None)
+    op = oracle.default_params(full_level=3)
+    prm = util.to_engine_params(capi, op)
+    got = engine.classify(reads, prm)
+    again = engine.classify(reads, prm)
+    for name in ("ex_off", "ex_start", "ex_end", "ex_flag", "info", "ref_tx"):
+        np.testing.assert_array_equal(getattr(got, name), getattr(again, name))
+    assert got.ex_start.size == int(got.ex_off[-1]) == int((got.info >> 8).sum())
+    lo, hi = 4_500_000 - 4_500_000 % 256 + 128, 5_500_000            # not aligned to the tiles of the whole run
+    part = reads.slice(lo, hi)
+    sub = engine.classify(part, prm, first_read_index=lo)
+    want = util.oracle_run(oracle, af, part, op)
+    util.assert_same_result(sub, want, 0, 0)
+    a, b = int(got.ex_off[lo]), int(got.ex_off[hi])
+    np.testing.assert_array_equal(got.info[lo:hi], sub.info)
+    np.testing.assert_array_equal(got.ref_tx[lo:hi], sub.ref_tx)
+    np.testing.assert_array_equal(got.ex_flag[a:b], sub.ex_flag)
+    np.testing.assert_array_equal(got.ex_start[a:b], sub.ex_start)
