@@ -176,13 +176,18 @@ void h_job_views(h_job *j, l2r_params *prm, l2r_annotation *a, l2r_junctions *s,
     r->cig_off = j->reads.cig_off; r->cig = j->reads.cig; r->first_read_index = 0;
 }
 
+static int tail_threads(const h_job *j);
+static int finish_threaded(h_job *j, const l2r_result *res, int n_thr);
+
 int h_job_finish(h_job *j, const l2r_result *res)
 {
     h_result hr;
     hr.n = res->n_reads; hr.n_ex = res->n_exons; hr.ex_off = res->ex_off; hr.ex_start = res->ex_start; hr.ex_end = res->ex_end;
     hr.ex_flag = res->ex_flag; hr.info = res->info; hr.ref_tx = res->ref_tx;
     if (hr.n != j->reads.n) h_fatal("update_gtf", "result covers %lld reads, input has %lld", (long long)hr.n, (long long)j->reads.n);
-    h_update_tail(&j->o, &j->chr, &j->reads, &j->anno, &hr, j->sj.n);
+    const int n_thr = tail_threads(j);
+    if (n_thr > 1) finish_threaded(j, res, n_thr);
+    else h_update_tail(&j->o, &j->chr, &j->reads, &j->anno, &hr, j->sj.n);
     FILE **fs[] = {&j->o.exon_bed, &j->o.bam_gtf, &j->o.bam_detail, &j->o.known_gtf, &j->o.novel_gtf, &j->o.unrecog_gtf, &j->o.summary};
     for (size_t k = 0; k < sizeof fs / sizeof fs[0]; ++k) if (*fs[k]) { fclose(*fs[k]); *fs[k] = NULL; }
     if (j->o.out_gtf && j->o.out_gtf != stdout) { fclose(j->o.out_gtf); j->o.out_gtf = NULL; } else fflush(stdout);
@@ -239,6 +244,94 @@ int h_job_finish_part(h_job *j, int64_t lo, int64_t hi, const l2r_result *res, c
     h_update_tail(&o, &j->chr, &part, &j->anno, &hr, j->sj.n);
     FILE *fs[] = {o.out_gtf, o.exon_bed, o.bam_gtf, o.bam_detail, o.known_gtf, o.novel_gtf, o.unrecog_gtf};
     for (size_t k = 0; k < sizeof fs / sizeof fs[0]; ++k) if (fs[k]) fclose(fs[k]);
+    return 0;
+}
+
+/* ---- the tail on several host threads ------------------------------------------------------------------
+ * Same partition argument as h_job_finish_part: chromosome-aligned parts of the read array do not interact in the
+ * order-dependent tail, so the parts run on their own threads into memory streams and are written out in order. */
+#include <pthread.h>
+#include <unistd.h>
+typedef struct {
+    h_job *j; const l2r_result *res; int64_t lo, hi; int first;
+    char *buf[7]; size_t len[7]; int64_t cnt[H_N_SUMMARY];
+} tail_part;
+
+static void *tail_part_main(void *arg)
+{
+    tail_part *t = (tail_part *)arg;
+    h_job *j = t->j;
+    h_update_opts o = j->o;
+    FILE *want[7] = {j->o.out_gtf, j->o.exon_bed, j->o.bam_gtf, j->o.bam_detail, j->o.known_gtf, j->o.novel_gtf, j->o.unrecog_gtf};
+    FILE *fs[7];
+    for (int k = 0; k < 7; ++k) {
+        t->buf[k] = NULL; t->len[k] = 0;
+        fs[k] = want[k] ? open_memstream(&t->buf[k], &t->len[k]) : NULL;
+        if (want[k] && !fs[k]) h_fatal("update_gtf", "open_memstream failed");
+    }
+    o.out_gtf = fs[0]; o.exon_bed = fs[1]; o.bam_gtf = fs[2]; o.bam_detail = fs[3]; o.known_gtf = fs[4]; o.novel_gtf = fs[5]; o.unrecog_gtf = fs[6];
+    o.summary = NULL; o.summary_counts = t->cnt; o.no_detail_header = !t->first;
+    h_reads part = j->reads;
+    part.n = t->hi - t->lo; part.tid += t->lo; part.pos += t->lo; part.rev += t->lo; part.qname += t->lo; part.cig_off += t->lo;
+    const l2r_result *res = t->res;
+    const int64_t x0 = res->ex_off[t->lo], x1 = res->ex_off[t->hi];
+    int64_t *off = (int64_t *)h_malloc((size_t)(part.n + 1) * sizeof(int64_t));
+    for (int64_t i = 0; i <= part.n; ++i) off[i] = res->ex_off[t->lo + i] - x0;
+    h_result hr;
+    hr.n = part.n; hr.n_ex = x1 - x0; hr.ex_off = off; hr.ex_start = res->ex_start + x0; hr.ex_end = res->ex_end + x0;
+    hr.ex_flag = res->ex_flag + x0; hr.info = res->info + t->lo; hr.ref_tx = res->ref_tx + t->lo;
+    memset(t->cnt, 0, sizeof t->cnt);
+    h_update_tail(&o, &j->chr, &part, &j->anno, &hr, j->sj.n);
+    for (int k = 0; k < 7; ++k) if (fs[k]) fclose(fs[k]);
+    free(off);
+    return NULL;
+}
+
+/* number of tail threads: L2R_THREADS, else the online CPUs (at most 64); 1 when the partition argument does not hold */
+static int tail_threads(const h_job *j)
+{
+    const char *e = getenv("L2R_THREADS");
+    long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    if (n > 64) n = 64;
+    if (n < 2 || (!e && j->reads.n < 20000)) return 1;                       /* small inputs: not worth the threads (unless asked for) */
+    if (j->o.prm.split_trans && j->sj.n > 0) return 1;                      /* Q2: split pieces are compared across chromosomes */
+    for (int64_t i = 1; i < j->reads.n; ++i) if (j->reads.tid[i] < j->reads.tid[i - 1]) return 1;     /* not grouped by chromosome */
+    return (int)n;
+}
+
+static int finish_threaded(h_job *j, const l2r_result *res, int n_thr)
+{
+    /* cut points: chromosome boundaries nearest to the equal-count cuts */
+    const int64_t N = j->reads.n;
+    int64_t *cut = (int64_t *)h_malloc((size_t)(n_thr + 1) * sizeof(int64_t));
+    cut[0] = 0;
+    for (int k = 1; k < n_thr; ++k) {
+        int64_t want = N * k / n_thr, lo = want, hi = want;
+        while (lo > cut[k - 1] && j->reads.tid[lo] == j->reads.tid[lo - 1]) --lo;           /* boundary at or below */
+        while (hi < N && j->reads.tid[hi] == j->reads.tid[hi - 1]) ++hi;                    /* boundary above */
+        int64_t c = (want - lo <= hi - want) ? lo : hi;
+        if (c < cut[k - 1]) c = cut[k - 1];
+        cut[k] = c;
+    }
+    cut[n_thr] = N;
+    tail_part *parts = (tail_part *)calloc((size_t)n_thr, sizeof *parts);
+    pthread_t *th = (pthread_t *)calloc((size_t)n_thr, sizeof *th);
+    int first_nonempty = 1;
+    for (int k = 0; k < n_thr; ++k) {
+        parts[k].j = j; parts[k].res = res; parts[k].lo = cut[k]; parts[k].hi = cut[k + 1];
+        parts[k].first = first_nonempty && k == 0;
+        if (pthread_create(&th[k], NULL, tail_part_main, &parts[k])) h_fatal("update_gtf", "pthread_create failed");
+    }
+    int64_t total[H_N_SUMMARY]; memset(total, 0, sizeof total);
+    FILE *outs[7] = {j->o.out_gtf, j->o.exon_bed, j->o.bam_gtf, j->o.bam_detail, j->o.known_gtf, j->o.novel_gtf, j->o.unrecog_gtf};
+    for (int k = 0; k < n_thr; ++k) {
+        pthread_join(th[k], NULL);
+        for (int q = 0; q < 7; ++q) if (outs[q] && parts[k].len[q]) fwrite(parts[k].buf[q], 1, parts[k].len[q], outs[q]);
+        for (int q = 0; q < 7; ++q) free(parts[k].buf[q]);
+        for (int q = 0; q < H_N_SUMMARY; ++q) total[q] += parts[k].cnt[q];
+    }
+    if (j->o.summary) h_write_summary_text(j->o.summary, j->anno.gene_n, (int)j->anno.n_tx, total);
+    free(parts); free(th); free(cut);
     return 0;
 }
 

@@ -45,10 +45,10 @@ sys.exit(job.finish(res.ex_off, res.ex_start, res.ex_end, res.ex_flag, info, res
 """
 
 
-def _host_with_oracle_results(argv):
+def _host_with_oracle_results(argv, env=None):
     """Staged host run in a child process (the C code exits the process on fatal errors)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    return subprocess.run([sys.executable, "-c", _CHILD % root] + argv, stderr=subprocess.PIPE).returncode
+    return subprocess.run([sys.executable, "-c", _CHILD % root] + argv, stderr=subprocess.PIPE, env=env).returncode
 
 
 def _compare(oracle, tmp_path, extra, sam, gtf, tag):
@@ -168,3 +168,20 @@ for k in a:
     np.testing.assert_array_equal(ra["cig_off"], reads.cig_off)
     np.testing.assert_array_equal(ra["cig"], reads.cig)
     j.close()
+
+
+@pytest.mark.parametrize("threads", ["3", "8"])
+def test_threaded_tail_is_byte_identical(oracle, tmp_path, threads):
+    """The tail on several host threads (chromosome-aligned parts into memory streams, written out in order) against the
+    oracle's single sequential pass; more threads than chromosomes leaves some parts empty."""
+    anno = synth.make_annotation(6000, 61, nchr=5, shuffle_within_gene=True)
+    reads = synth.make_reads(anno, 6000, 5, 61, xs_conflict_frac=0.02)
+    sam, gtf = str(tmp_path / "r.sam"), str(tmp_path / "a.gtf")
+    reads.write_sam(sam)
+    anno.write_gtf(gtf)
+    oo, ho = _paths(tmp_path, "t.o"), _paths(tmp_path, "t.h")
+    assert oracle.run_cli(_args(["-l", "3"], oo, sam, gtf)) == 0
+    assert _host_with_oracle_results(_args(["-l", "3"], ho, sam, gtf), env=dict(os.environ, L2R_THREADS=threads)) == 0
+    for k in OUTS:
+        assert filecmp.cmp(oo[k], ho[k], shallow=False), (threads, k)
+    assert os.path.getsize(oo["detail"]) > 100000
