@@ -14,7 +14,7 @@
 
 typedef struct { uint8_t *p; size_t n; } blob;
 
-static blob slurp(const char *fn, const char *who)
+static blob slurp_gz(const char *fn, const char *who)
 {
     /* gzread() passes plain files through and inflates gzip/BGZF (concatenated members) */
     gzFile g = gzopen(fn, "rb");
@@ -31,6 +31,89 @@ static blob slurp(const char *fn, const char *who)
         b.n += (size_t)k;
     }
     gzclose(g);
+    return b;
+}
+
+/* ---- BGZF: independent deflate blocks (SAMv1 4.1), inflated on several threads ------------------------
+ * Every block is a gzip member with a "BC" extra subfield that holds its total size and ends with CRC32 and the
+ * uncompressed size, so the block table and the output offsets come from one pass over the headers. */
+#include <pthread.h>
+#include <unistd.h>
+#include <stdio.h>
+
+typedef struct { size_t in_off, in_len, out_off, out_len; } bgzf_block;
+typedef struct { const uint8_t *in; uint8_t *out; const bgzf_block *blk; size_t n_blk; size_t next; pthread_mutex_t mu; int failed; } bgzf_job;
+
+static void *bgzf_worker(void *arg)
+{
+    bgzf_job *jb = (bgzf_job *)arg;
+    z_stream z; memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, -15) != Z_OK) { jb->failed = 1; return NULL; }
+    for (;;) {
+        pthread_mutex_lock(&jb->mu);
+        size_t lo = jb->next, hi = lo + 64 < jb->n_blk ? lo + 64 : jb->n_blk;            /* 64 blocks (<= 4 MB) per grab */
+        jb->next = hi;
+        pthread_mutex_unlock(&jb->mu);
+        if (lo >= hi) break;
+        for (size_t k = lo; k < hi; ++k) {
+            const bgzf_block *b = &jb->blk[k];
+            if (b->out_len == 0) continue;
+            inflateReset(&z);
+            z.next_in = (Bytef *)(jb->in + b->in_off); z.avail_in = (uInt)b->in_len;
+            z.next_out = jb->out + b->out_off; z.avail_out = (uInt)b->out_len;
+            const int rc = inflate(&z, Z_FINISH);
+            if (rc != Z_STREAM_END || z.avail_out != 0) { jb->failed = 1; break; }
+        }
+    }
+    inflateEnd(&z);
+    return NULL;
+}
+
+/* Whole file -> memory; BGZF is inflated block-parallel, anything else goes through gzread. */
+static blob slurp(const char *fn, const char *who)
+{
+    FILE *f = fopen(fn, "rb");
+    if (!f) h_fatal(who, "Can not open \"%s\"\n", fn);
+    uint8_t hd[18];
+    const size_t got = fread(hd, 1, sizeof hd, f);
+    const int bgzf = got == sizeof hd && hd[0] == 0x1f && hd[1] == 0x8b && hd[2] == 8 && (hd[3] & 4) && hd[12] == 'B' && hd[13] == 'C' &&
+                     hd[14] == 2 && hd[15] == 0 && (hd[10] | (hd[11] << 8)) == 6;
+    if (!bgzf) { fclose(f); return slurp_gz(fn, who); }
+    fseek(f, 0, SEEK_END);
+    const long fsz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    uint8_t *raw = (uint8_t *)h_malloc((size_t)fsz + 1);
+    if (fread(raw, 1, (size_t)fsz, f) != (size_t)fsz) h_fatal(who, "read error in \"%s\"", fn);
+    fclose(f);
+    /* block table */
+    size_t n_blk = 0, cap = 1024, out_total = 0;
+    bgzf_block *blk = (bgzf_block *)h_malloc(cap * sizeof *blk);
+    for (size_t p = 0; p < (size_t)fsz;) {
+        if ((size_t)fsz - p < 28 || raw[p] != 0x1f || raw[p + 1] != 0x8b || raw[p + 12] != 'B' || raw[p + 13] != 'C') {
+            free(blk); free(raw); return slurp_gz(fn, who);                                 /* not plain BGZF after all */
+        }
+        const size_t bsize = (size_t)(raw[p + 16] | (raw[p + 17] << 8)) + 1;
+        if (bsize < 28 || p + bsize > (size_t)fsz) h_fatal(who, "truncated BGZF block in \"%s\"", fn);
+        const uint8_t *tail = raw + p + bsize - 4;
+        const size_t isize = (size_t)tail[0] | ((size_t)tail[1] << 8) | ((size_t)tail[2] << 16) | ((size_t)tail[3] << 24);
+        if (n_blk == cap) { cap *= 2; blk = (bgzf_block *)h_realloc(blk, cap * sizeof *blk); }
+        blk[n_blk].in_off = p + 18; blk[n_blk].in_len = bsize - 18 - 8; blk[n_blk].out_off = out_total; blk[n_blk].out_len = isize;
+        ++n_blk; out_total += isize; p += bsize;
+    }
+    blob b; b.n = out_total; b.p = (uint8_t *)h_malloc(out_total + 1);
+    bgzf_job jb; memset(&jb, 0, sizeof jb);
+    jb.in = raw; jb.out = b.p; jb.blk = blk; jb.n_blk = n_blk; jb.next = 0; pthread_mutex_init(&jb.mu, NULL);
+    const char *e = getenv("L2R_THREADS");
+    long n_thr = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    if (n_thr > 32) n_thr = 32;
+    if (n_thr < 1 || n_blk < 8) n_thr = 1;
+    pthread_t th[32];
+    for (long k = 1; k < n_thr; ++k) if (pthread_create(&th[k], NULL, bgzf_worker, &jb)) h_fatal(who, "pthread_create failed");
+    bgzf_worker(&jb);
+    for (long k = 1; k < n_thr; ++k) pthread_join(th[k], NULL);
+    pthread_mutex_destroy(&jb.mu);
+    if (jb.failed) h_fatal(who, "corrupt BGZF block in \"%s\"", fn);
+    free(blk); free(raw);
     return b;
 }
 

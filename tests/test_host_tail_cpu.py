@@ -185,3 +185,37 @@ def test_threaded_tail_is_byte_identical(oracle, tmp_path, threads):
     for k in OUTS:
         assert filecmp.cmp(oo[k], ho[k], shallow=False), (threads, k)
     assert os.path.getsize(oo["detail"]) > 100000
+
+
+def test_bgzf_blocks_inflated_on_several_threads(tmp_path):
+    """A BAM of a few hundred BGZF blocks read with 1 and with 5 inflate threads gives the generator's arrays; a
+    gzip-compressed SAM (one gzip member, not BGZF) still goes through the sequential route."""
+    import gzip
+    anno = synth.make_annotation(8000, 71, nchr=3)
+    reads = synth.make_reads(anno, 60000, 6, 71, ont=True)
+    bam, gtf, samgz = str(tmp_path / "big.bam"), str(tmp_path / "a.gtf"), str(tmp_path / "r.sam.gz")
+    synth.write_bam(reads, bam)
+    anno.write_gtf(gtf)
+    assert os.path.getsize(bam) > 8 * 20000
+    sam = str(tmp_path / "r.sam")
+    reads.write_sam(sam)
+    with open(sam, "rb") as fi, gzip.open(samgz, "wb", compresslevel=1) as fo:
+        fo.write(fi.read())
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from lr2rmats_amd import hostlib
+j = hostlib.Job(["update-gtf", sys.argv[1], sys.argv[2]])
+a = j.read_arrays()
+np.savez(sys.argv[3], **a)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tag, fn, thr in (("t1", bam, "1"), ("t5", bam, "5"), ("gz", samgz, "5")):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, fn, gtf, out], stderr=subprocess.PIPE, env=dict(os.environ, L2R_THREADS=thr))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        z = np.load(out)
+        np.testing.assert_array_equal(z["tid"], reads.tid)
+        np.testing.assert_array_equal(z["pos"], reads.pos)
+        np.testing.assert_array_equal(z["rev"], reads.rev)
+        np.testing.assert_array_equal(z["cig_off"], reads.cig_off)
+        np.testing.assert_array_equal(z["cig"], reads.cig)
