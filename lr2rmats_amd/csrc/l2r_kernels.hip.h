@@ -830,6 +830,161 @@ __device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, con
     return v;
 }
 
+// ---- the three classification phases of a tile (all lanes of a wave call them together) -------------------------
+
+struct TileLds {                 // the tile's LDS image (layout in k_classify_fast)
+    int *S, *E; uint16_t *W;
+    const v4i_t *ent0, *ent1; const uint8_t *dir0, *dir1, *rdir;
+    const int4 *hk, *hx;
+};
+struct VisitMasks { uint32_t vpre, lmask, rmask, k1mask; bool redo; };
+struct SiteMasks { uint32_t kand, kor, dm_first, am_last; };
+
+// V' = window transcripts j >= j0 up to the first one the read lies before (src/update_gtf.c:799-800), minus the ones
+// that lie before the read (:801); terminal-exon masks of check_full (:629-681); single-exon known candidates (:806-811).
+// Wave-uniform j, header words broadcast from LDS.
+template <int LEVEL>
+__device__ __forceinline__ VisitMasks visit_window(const TileLds &L, const TileDesc &d, int w_n, int n_tx, bool work, uint32_t n, int j0,
+                                                   const ReadEnds &re)
+{
+    VisitMasks m{0u, 0u, 0u, 0u, false};
+    const int jrel0 = j0 - d.j_lo;
+    bool stopped = !work;
+    for (int j = 0; j < w_n; ++j) {
+        const int4 hk = L.hk[j];
+        const bool act = !stopped && j >= jrel0;
+        const bool aft = re.el <= hk.x;                                     // comp_trans <= (Q5)
+        stopped = stopped || (act && aft);
+        const bool ov = act && !aft && !(hk.y <= re.s0);
+        if (!__any(ov)) { if (__all(stopped)) break; continue; }
+        const uint32_t bit = 1u << j;
+        if (ov) m.vpre |= bit;
+        const int4 hx = L.hx[j];
+        if (LEVEL == 1) {
+            if (ov && re.e0 == hx.y) m.lmask |= bit;
+            if (ov && re.sl == hx.z) m.rmask |= bit;
+        } else if (LEVEL >= 2 && LEVEL <= 4) {
+            if (ov && closed_overlap(re.s0, re.e0, hx.x, hx.y)) m.lmask |= bit;
+            if (LEVEL != 4 && ov && closed_overlap(re.sl, re.el, hx.z, hx.w)) m.rmask |= bit;
+        }
+        if (hk.z == 1) {                 // single-exon transcript: only against single-exon reads
+            if (ov && n == 1 && overlap_frac(re.s0, re.e0, hx.x, hx.y) >= fast_args()->p.frac) m.k1mask |= bit;
+        } else if (!((hk.w & 0xff) & TX_COMPACT)) {
+            if (ov && n > 1) m.redo = true;                                 // literal loops needed for this pair
+        }
+    }
+    if (work && !stopped && d.j_lo + w_n < n_tx) m.redo = true;             // the sweep must have ended inside the window
+    return m;
+}
+
+// One START and one END probe per exon; the wave runs as many rounds as its longest read has exons.  Per round
+// {next exon, both bucket ranges} are read together, then the first entries of both buckets.  Leaves per exon in W:
+// first member of V' with the exon / the junction (6 bits each, 63: none), "donor / acceptor not in V'" (bits 12, 13).
+__device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc &d, bool mapping, uint32_t local, uint32_t n, uint32_t vpre)
+{
+    SiteMasks m{0xffffffffu, 0u, 0u, 0u};
+    const int *S = L.S + local, *E = L.E + local;
+    uint16_t *W = L.W + local;
+    int s = 0, e = 0;
+    if (mapping) { s = S[0]; e = E[0]; }
+    for (int k = 0; __any(mapping && k < (int)n); ++k) {
+        const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
+        const uint32_t inext = junc ? local + (uint32_t)k + 1u : 0u;
+        const int bs = s >> SITE_SHIFT, be = e >> SITE_SHIFT;
+        const bool vs = live && bs < d.nb, ve = junc && be < d.nb;
+        const int is = vs ? bs + d.b_off : 0, ie = ve ? be + d.b_off : 0;
+        const int s2 = L.S[inext], e2 = L.E[inext];
+        const uint32_t ls = L.dir0[is], hs0 = L.dir0[is + 1], le = L.dir1[ie], he0 = L.dir1[ie + 1];
+        const uint32_t hs = vs ? hs0 : ls, he = ve ? he0 : le;          // no bucket -> empty range
+        // START buckets mostly hold one exon, END buckets often several junctions of one donor
+        const v4i_t qs0 = lds_entry(L.ent0, min(ls, (uint32_t)KEY_CAP - 1u));
+        const v4i_t qe0 = lds_entry(L.ent1, min(le, (uint32_t)KEY_CAP - 1u)), qe1 = lds_entry(L.ent1, min(le + 1u, (uint32_t)KEY_CAP - 1u));
+        uint32_t xm, am, jm, dm;
+        {   const bool m0 = ls < hs && qs0.x == s;
+            am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
+        probe2(qe0, qe1, le, he, e, s2, jm, dm);
+        if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(L.ent0, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + 2u, he, e, s2, jm, dm, 0u); }
+        uint32_t word = min((uint32_t)__ffs((int)(xm & vpre)) - 1u, 63u);
+        word |= min((uint32_t)__ffs((int)(jm & vpre)) - 1u, 63u) << 6;        // without a junction: jm = dm = 0
+        word |= ((dm & vpre) ? 0u : 1u << 12) | ((((junc ? am : 0u) & vpre)) ? 0u : 1u << 13);
+        if (junc) {
+            m.kand &= am & dm;                        // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
+            m.kor |= am | dm;
+            if (k == 0) m.dm_first = dm;
+        } else if (live) m.am_last = am;              // transcripts in which the last exon's start begins a later exon
+        if (live) W[k] = (uint16_t)word;
+        s = s2; e = e2;
+    }
+    return m;
+}
+
+// Known / known site / reference transcript / full-length / flag bytes of one read from its masks.
+template <int LEVEL>
+__device__ __forceinline__ Verdict decide(const TileLds &L, const TileDesc &d, uint32_t local, uint32_t n, const ReadEnds &re,
+                                          const VisitMasks &vm, const SiteMasks &sm, bool rev_in)
+{
+    uint16_t *W = L.W + local;
+    // ---- first known transcript in visiting order
+    int jstar = -1;
+    if (n > 1) {
+        // every probed site is in the transcript; known also needs every read site inside the overlap span:
+        // donors e_0..e_{n-2} and acceptors s_1..s_{n-1} increase, so e_0 >= a.start and s_{n-1} <= a.end suffice
+        uint32_t c = sm.kand & vm.vpre;
+        while (c) {
+            const int j = __ffs((int)c) - 1;
+            c &= c - 1u;
+            const int4 hk = L.hk[j];
+            if (hk.x <= re.e0 && re.sl <= hk.y) { jstar = j; break; }
+        }
+    } else if (vm.k1mask) jstar = __ffs((int)vm.k1mask) - 1;
+    const bool known = jstar >= 0;
+    const uint32_t V = known ? (vm.vpre & ((2u << jstar) - 1u)) : vm.vpre;
+    const uint32_t ks = (n > 1) ? (sm.kor & V) : 0u;
+    const bool ksite = (ks & ~(known ? (1u << jstar) : 0u)) != 0u;
+    int jref = -1;
+    if (n > 1) { if (ks) jref = 31 - __clz((int)ks); }
+    else jref = jstar;
+    // ---- full-length evidence (:629-681) over V.  lfull: the first exon of a member of V overlaps the read's first
+    // exon.  lnoth stays set unless SOME exon of a member of V overlaps it; that is certain when the read's first donor
+    // is a donor of a member (the exon that ends there), else the START slice decides.
+    bool lfull = false, rfull = false, lnoth = true, rnoth = true;
+    if (LEVEL >= 1 && LEVEL <= 4) { lfull = (vm.lmask & V) != 0u; rfull = (vm.rmask & V) != 0u; }
+    if (LEVEL == 3 || LEVEL == 4) {
+        if (!lfull) {
+            if (sm.dm_first & V) lnoth = false;
+            else if (V) lnoth = (overlapping_exon_members(L.rdir, L.dir0, L.ent0, d.b_off, d.nb, re.s0, re.e0) & V) == 0u;
+        }
+        if (LEVEL == 3 && !rfull) {
+            if (sm.am_last & V) rnoth = false;
+            else if (V) rnoth = (overlapping_exon_members(L.rdir, L.dir0, L.ent0, d.b_off, d.nb, re.sl, re.el) & V) == 0u;
+        }
+    }
+    // ---- flags: an exon / junction is no longer novel iff the first member of V' that has it comes no later than
+    // j*; a known read has every probed donor and acceptor in transcript j*
+    const uint32_t lim = known ? (uint32_t)jstar : 62u;
+    for (int k = 0; k < (int)n; ++k) {
+        uint32_t f = F_EXON;
+        if (n > 1) {
+            const uint32_t w = W[k];
+            f = ((w & 63u) > lim ? F_EXON : 0u) | (((w >> 6) & 63u) > lim ? F_JUNC : 0u);
+            if (!known) f |= ((w >> 12) & 1u ? F_DON : 0u) | ((w >> 13) & 1u ? F_ACC : 0u);
+            if (k + 1 == (int)n) f &= F_EXON;
+        }
+        W[k] = (uint16_t)f;
+    }
+    int ref = -1;
+    bool out_rev = rev_in;
+    if (jref >= 0) { ref = d.j_lo + jref; out_rev = ((L.hk[jref].w >> 8) & 1) != 0; }     // :825-831
+    uint32_t info = 0;
+    if (known) info |= I_KNOWN;
+    if (ksite) info |= I_KSITE;
+    if (full_decision(LEVEL, lfull, lnoth, rfull, rnoth)) info |= I_FULL;
+    if (out_rev) info |= I_REV;
+    // routing of update_gtf.c:943-950 when there is no junction table (finish_info)
+    if (fast_args()->p.n_sj == 0 && (info & (I_FULL | I_KNOWN | I_KSITE)) == (I_FULL | I_KSITE)) info |= I_ACCEPT;
+    return Verdict{info | (n << 8), ref};
+}
+
 template <int LEVEL, bool WIDE>
 __global__ __launch_bounds__(TILE_THREADS, 4)
 void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int64_t n_tiles, const TileDesc *__restrict__ u_desc, const uint32_t *__restrict__ u_tile_base,
@@ -971,148 +1126,20 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         L2R_STAMP(1);
 
         // ---- phase 2: classification
-        uint32_t info = 0; int ref = -1;
+        uint32_t info = n << 8; int ref = -1;
         bool redo = active && (!fast || !in_lds || any_wide != 0 || tid != d.tid || (n > 1 && !sane));
         const bool work = active && !redo;
-        const int *S = s_S + local, *E = s_E + local;
-        uint16_t *W = s_W + local;
-        uint32_t vpre = 0, lmask = 0, rmask = 0, k1mask = 0;
-        {
-            // V': transcripts j >= j0 up to the first one the read lies before (:799-800), minus the ones that lie
-            // before the read (:801); wave-uniform j, header words broadcast from LDS
-            const int jrel0 = j0 - d.j_lo;
-            bool stopped = !work;
-            for (int j = 0; j < w_n; ++j) {
-                const int4 hk = s_hk[j];
-                const bool act = !stopped && j >= jrel0;
-                const bool aft = re.el <= hk.x;                                     // comp_trans <= (Q5)
-                stopped = stopped || (act && aft);
-                const bool ov = act && !aft && !(hk.y <= re.s0);
-                if (!__any(ov)) { if (__all(stopped)) break; continue; }
-                const uint32_t bit = 1u << j;
-                if (ov) vpre |= bit;
-                const int4 hx = s_hx[j];
-                if (LEVEL == 1) {
-                    if (ov && re.e0 == hx.y) lmask |= bit;
-                    if (ov && re.sl == hx.z) rmask |= bit;
-                } else if (LEVEL >= 2 && LEVEL <= 4) {
-                    if (ov && closed_overlap(re.s0, re.e0, hx.x, hx.y)) lmask |= bit;
-                    if (LEVEL != 4 && ov && closed_overlap(re.sl, re.el, hx.z, hx.w)) rmask |= bit;
-                }
-                if (hk.z == 1) {                 // single-exon transcript: :806-811, only against single-exon reads
-                    if (ov && n == 1 && overlap_frac(re.s0, re.e0, hx.x, hx.y) >= fast_args()->p.frac) k1mask |= bit;
-                } else if (!((hk.w & 0xff) & TX_COMPACT)) {
-                    if (ov && n > 1) redo = true;                                   // literal loops needed for this pair
-                }
-            }
-            // the sweep must have ended inside the window
-            if (work && !stopped && d.j_lo + w_n < n_tx) redo = true;
-        }
+        const TileLds L{s_S, s_E, s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_hk, s_hx};
+        const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, n_tx, work, n, j0, re);
+        redo = redo || vm.redo;
         L2R_STAMP(2);
-        uint32_t kand = 0xffffffffu, kor = 0u, dm_first = 0u, am_last = 0u;
-        {
-            // one START and one END probe per exon; the wave runs as many rounds as its longest read has exons.
-            // Per round: {next exon, both bucket ranges} are read together, then the first two entries of both buckets.
-            const bool mapping = work && !redo && n > 1;
-            const uint8_t *dS = s_dir0, *dE = s_dir1;
-            const v4i_t *eS = s_ent0, *eE = s_ent1;
-            int s = 0, e = 0;
-            if (mapping) { s = S[0]; e = E[0]; }
-            for (int k = 0; __any(mapping && k < (int)n); ++k) {
-                const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
-                const uint32_t inext = junc ? local + (uint32_t)k + 1u : 0u;
-                const int bs = s >> SITE_SHIFT, be = e >> SITE_SHIFT;
-                const bool vs = live && bs < d.nb, ve = junc && be < d.nb;
-                const int is = vs ? bs + d.b_off : 0, ie = ve ? be + d.b_off : 0;
-                const int s2 = s_S[inext], e2 = s_E[inext];
-                const uint32_t ls = dS[is], hs0 = dS[is + 1], le = dE[ie], he0 = dE[ie + 1];
-                const uint32_t hs = vs ? hs0 : ls, he = ve ? he0 : le;          // no bucket -> empty range
-                // START buckets mostly hold one exon, END buckets often several junctions of one donor
-                const v4i_t qs0 = lds_entry(eS, min(ls, (uint32_t)KEY_CAP - 1u));
-                const v4i_t qe0 = lds_entry(eE, min(le, (uint32_t)KEY_CAP - 1u)), qe1 = lds_entry(eE, min(le + 1u, (uint32_t)KEY_CAP - 1u));
-                uint32_t xm, am, jm, dm;
-                {   const bool m0 = ls < hs && qs0.x == s;
-                    am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
-                probe2(qe0, qe1, le, he, e, s2, jm, dm);
-                if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(eS, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(eE, le + 2u, he, e, s2, jm, dm, 0u); }
-                // first member of V' with the exon / the junction (63: none), "donor / acceptor not in V'"
-                uint32_t word = min((uint32_t)__ffs((int)(xm & vpre)) - 1u, 63u);
-                word |= min((uint32_t)__ffs((int)(jm & vpre)) - 1u, 63u) << 6;        // without a junction: jm = dm = 0
-                word |= ((dm & vpre) ? 0u : 1u << 12) | ((((junc ? am : 0u) & vpre)) ? 0u : 1u << 13);
-                if (junc) {
-                    kand &= am & dm;                          // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
-                    kor |= am | dm;
-                    if (k == 0) dm_first = dm;
-                } else if (live) am_last = am;                // transcripts in which the last exon's start begins a later exon
-                if (live) W[k] = (uint16_t)word;
-                s = s2; e = e2;
-            }
-        }
+        const SiteMasks sm = map_exons(L, d, work && !redo && n > 1, local, n, vm.vpre);
         L2R_STAMP(3);
         if (work && !redo) {
-            // ---- first known transcript in visiting order
-            int jstar = -1;
-            if (n > 1) {
-                // every probed site is in the transcript; known also needs every read site inside the overlap span:
-                // donors e_0..e_{n-2} and acceptors s_1..s_{n-1} increase, so e_0 >= a.start and s_{n-1} <= a.end suffice
-                uint32_t c = kand & vpre;
-                while (c) {
-                    const int j = __ffs((int)c) - 1;
-                    c &= c - 1u;
-                    const int4 hk = s_hk[j];
-                    if (hk.x <= re.e0 && re.sl <= hk.y) { jstar = j; break; }
-                }
-            } else if (k1mask) jstar = __ffs((int)k1mask) - 1;
-            const bool known = jstar >= 0;
-            const uint32_t V = known ? (vpre & ((2u << jstar) - 1u)) : vpre;
-            const uint32_t ks = (n > 1) ? (kor & V) : 0u;
-            const bool ksite = (ks & ~(known ? (1u << jstar) : 0u)) != 0u;
-            int jref = -1;
-            if (n > 1) { if (ks) jref = 31 - __clz((int)ks); }
-            else jref = jstar;
-            // ---- full-length evidence (:629-681) over V.  lfull: the first exon of a member of V overlaps the read's
-            // first exon.  lnoth stays set unless SOME exon of a member of V overlaps it; that is certain when the
-            // read's first donor is a donor of a member (the exon that ends there), else the START slice decides.
-            bool lfull = false, rfull = false, lnoth = true, rnoth = true;
-            if (LEVEL >= 1 && LEVEL <= 4) { lfull = (lmask & V) != 0u; rfull = (rmask & V) != 0u; }
-            if (LEVEL == 3 || LEVEL == 4) {
-                if (!lfull) {
-                    if (dm_first & V) lnoth = false;
-                    else if (V) lnoth = (overlapping_exon_members(s_rdir, s_dir0, s_ent0, d.b_off, d.nb, re.s0, re.e0) & V) == 0u;
-                }
-                if (LEVEL == 3 && !rfull) {
-                    if (am_last & V) rnoth = false;
-                    else if (V) rnoth = (overlapping_exon_members(s_rdir, s_dir0, s_ent0, d.b_off, d.nb, re.sl, re.el) & V) == 0u;
-                }
-            }
-            // ---- flags: an exon / junction is no longer novel iff the first member of V' that has it comes no later
-            // than j*; a known read has every probed donor and acceptor in transcript j*
-            {
-                const uint32_t lim = known ? (uint32_t)jstar : 62u;
-                for (int k = 0; k < (int)n; ++k) {
-                    uint32_t f = F_EXON;
-                    if (n > 1) {
-                        const uint32_t w = W[k];
-                        f = ((w & 63u) > lim ? F_EXON : 0u) | (((w >> 6) & 63u) > lim ? F_JUNC : 0u);
-                        if (!known) f |= ((w >> 12) & 1u ? F_DON : 0u) | ((w >> 13) & 1u ? F_ACC : 0u);
-                        if (k + 1 == (int)n) f &= F_EXON;
-                    }
-                    W[k] = (uint16_t)f;
-                }
-            }
-            bool out_rev = rev_in;
-            if (jref >= 0) { ref = d.j_lo + jref; out_rev = ((s_hk[jref].w >> 8) & 1) != 0; }     // :825-831
-            if (known) info |= I_KNOWN;
-            if (ksite) info |= I_KSITE;
-            if (full_decision(LEVEL, lfull, lnoth, rfull, rnoth)) info |= I_FULL;
-            if (out_rev) info |= I_REV;
-            {   // routing of update_gtf.c:943-950 when there is no junction table (finish_info)
-                if (fast_args()->p.n_sj == 0 && (info & (I_FULL | I_KNOWN | I_KSITE)) == (I_FULL | I_KSITE)) info |= I_ACCEPT;
-                info |= n << 8;
-            }
-        } else if (active) {
-            info = n << 8;
-            if (in_lds) for (int k = 0; k < (int)n; ++k) W[k] = (uint16_t)0;
+            const Verdict vd = decide<LEVEL>(L, d, local, n, re, vm, sm, rev_in);
+            info = vd.info; ref = vd.ref;
+        } else if (active && in_lds) {
+            for (int k = 0; k < (int)n; ++k) s_W[local + k] = (uint16_t)0;
         }
         L2R_STAMP(4);
 
