@@ -191,9 +191,9 @@ def main():
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: synthetic %d long reads/GPU x %.2f exons/read (%.1f CIGAR ops/read), "
+            "config": {"workload": "BASELINE configs[%d]: synthetic %d long reads/GPU x %.2f exons/read (%.1f CIGAR ops/read), "
                                    "%d-exon / %d-transcript GTF, update-gtf -l %d" % (
-                                       reads.n, n_x / max(n_r, 1), reads.cig.shape[0] / max(n_r, 1), af.n_exons, af.n_tx, args.level),
+                                       {"cfg2": 1, "cfg3": 2, "cfg5": 4}.get(args.config, 2), reads.n, n_x / max(n_r, 1), reads.cig.shape[0] / max(n_r, 1), af.n_exons, af.n_tx, args.level),
                        "reads_per_gpu": reads.n, "total_reads": total_reads, "accepted_reads_rank0": n_acc,
                        "exchange": "none (1 GPU)" if world == 1 else (
                            "partitioned: chromosome-aligned shards merge on their own rank, RCCL all-gather of the list sizes only (%s accepted records / %s exons in total stay local)" % (last[0], last[1])
