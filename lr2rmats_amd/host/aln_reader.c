@@ -136,7 +136,7 @@ static void reads_reserve(h_reads *r, int64_t more_reads, int64_t more_cig)
 
 void h_reads_free(h_reads *r)
 {
-    free(r->tid); free(r->pos); free(r->rev); free(r->cig_off); free(r->cig); free(r->qname); free(r->names.buf);
+    free(r->tid); free(r->pos); free(r->rev); free(r->cig_off); free(r->cig); free(r->qname); free(r->tid_name); free(r->names.buf);
     memset(r, 0, sizeof *r);
 }
 

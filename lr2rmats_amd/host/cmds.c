@@ -25,6 +25,7 @@ struct h_job {
     h_sj sj;
     FILE *sj_fp;
     int mode;
+    l2r_params engine_prm;       /* what the engine gets: o.prm, except that `-m g` input passes its exons through unchanged */
     char *out_path[8];           /* 0 updated gtf (NULL = stdout), 1 exon bed, 2 bam gtf, 3 detail, 4 known, 5 novel, 6 unrecog, 7 summary */
 };
 
@@ -32,6 +33,7 @@ static int g_open_outputs = 1;
 
 /* L2R_TIMING=1: wall-clock per stage on stderr (diagnostics; the reference prints nothing comparable) */
 #include <time.h>
+#include <stdint.h>
 static double h_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static double g_t_last = 0.0;
 static void h_stage_time(const char *what)
@@ -90,6 +92,46 @@ static void default_params(l2r_params *p)
     /* src/update_gtf.c:24-35, src/gtf.h:118-127 */
     p->min_exon = 3; p->min_intron = 3; p->max_delet = 50; p->ss_dis = 0; p->end_dis = 0x7fffffff; p->full_level = 5;
     p->split_trans = 0; p->use_multi = 0; p->min_sj_cnt = 1; p->force_strand = 0; p->single_exon_ovlp_frac = 0.80;
+}
+
+/* `-m g` (src/update_gtf.c:1071-1075, read_gtf_trans src/gtf.c:524-595): the transcripts of a GTF take the place of the
+ * alignment records.  The engine consumes CIGARs, so every transcript becomes <exon length>M <gap>N ...; the engine is
+ * then run with thresholds that keep every exon and cut at every N (h_job_open), i.e. the exons arrive unchanged.
+ * trans_name -> QNAME, trans_id -> tid_name; gene names come from the annotation, as for alignments (:832-833). */
+static void reads_from_gtf(const char *fn, const h_chroms *chr, h_reads *out)
+{
+    h_gtf g;
+    h_read_gtf(fn, chr, &g, 1);
+    memset(out, 0, sizeof *out);
+    const int64_t T = g.n_tx;
+    out->n = T; out->cap = T + 1;
+    out->tid = (int32_t *)h_malloc((size_t)(T + 1) * 4); out->pos = (int32_t *)h_malloc((size_t)(T + 1) * 4);
+    out->rev = (uint8_t *)h_malloc((size_t)T + 1); out->cig_off = (int64_t *)h_malloc((size_t)(T + 2) * 8);
+    out->qname = (uint32_t *)h_malloc((size_t)(T + 1) * 4); out->tid_name = (uint32_t *)h_malloc((size_t)(T + 1) * 4);
+    out->cap_cig = 2 * g.n_ex + 1; out->cig = (uint32_t *)h_malloc((size_t)out->cap_cig * 4);
+    out->cig_off[0] = 0;
+    for (int64_t i = 0; i < T; ++i) {
+        if (g.tid[i] < 0)
+            h_fatal("read_gtf_trans", "transcript \"%s\" is on a chromosome that is not in the BAM header (the reference indexes its name table with -1 there)",
+                    h_str(&g.names, g.tids[i]));
+        out->tid[i] = g.tid[i]; out->rev[i] = g.rev[i];
+        out->qname[i] = g.tname[i]; out->tid_name[i] = g.tids[i];
+        const int64_t lo = g.ex_off[i], hi = g.ex_off[i + 1];
+        out->pos[i] = g.ex_start[lo] - 1;
+        for (int64_t k = lo; k < hi; ++k) {
+            const int64_t len = (int64_t)g.ex_end[k] - g.ex_start[k] + 1;
+            if (k > lo) {
+                const int64_t gap = (int64_t)g.ex_start[k] - g.ex_end[k - 1] - 1;
+                if (gap < 0 || gap >= (1 << 28)) h_fatal("read_gtf_trans", "transcript \"%s\": exons overlap or lie more than 2^28 bp apart", h_str(&g.names, g.tids[i]));
+                out->cig[out->n_cig++] = ((uint32_t)gap << 4) | 3u;
+            }
+            if (len < 1 || len >= (1 << 28)) h_fatal("read_gtf_trans", "transcript \"%s\": exon of length %lld", h_str(&g.names, g.tids[i]), (long long)len);
+            out->cig[out->n_cig++] = ((uint32_t)len << 4) | 0u;
+        }
+        out->cig_off[i + 1] = out->n_cig;
+    }
+    out->names = g.names; memset(&g.names, 0, sizeof g.names);      /* the string table moves to the reads */
+    h_gtf_free(&g);
 }
 
 h_job *h_job_open2(int argc, char **argv, int *exit_code, int open_outputs)
@@ -156,8 +198,11 @@ h_job *h_job_open(int argc, char **argv, int *exit_code)
     } else {
         if (!hdr_file) h_fatal("update_gtf", "Couldn't read header of provided BAM file.\n");
         h_read_header_only(hdr_file, &j->chr, "update_gtf");
-        h_fatal("update_gtf", "GTF input (-m g) is not wired to the GPU engine yet; use unique-gtf -m g or BAM/SAM input");
+        reads_from_gtf(argv[optind], &j->chr, &j->reads);
+        h_stage_time("read GTF as reads");
     }
+    j->engine_prm = j->o.prm;
+    if (j->mode == 1) { j->engine_prm.min_exon = INT32_MIN; j->engine_prm.min_intron = 0; j->engine_prm.max_delet = INT32_MAX; }
     fprintf(stderr, "[read_anno_trans] reading transcript annotation from %s ...\n", argv[optind + 1]);
     h_read_gtf(argv[optind + 1], &j->chr, &j->anno, 0);
     fprintf(stderr, "[read_anno_trans] reading transcript annotation from %s done.\n", argv[optind + 1]);
@@ -168,7 +213,7 @@ h_job *h_job_open(int argc, char **argv, int *exit_code)
 
 void h_job_views(h_job *j, l2r_params *prm, l2r_annotation *a, l2r_junctions *s, l2r_reads *r)
 {
-    *prm = j->o.prm;
+    *prm = j->engine_prm;
     a->n_tx = j->anno.n_tx; a->n_exon = j->anno.n_ex; a->tx_tid = j->anno.tid; a->tx_start = j->anno.start; a->tx_end = j->anno.end;
     a->tx_rev = j->anno.rev; a->tx_ex_off = j->anno.ex_off; a->ex_start = j->anno.ex_start; a->ex_end = j->anno.ex_end;
     s->n = j->sj.n; s->tid = j->sj.tid; s->don = j->sj.don; s->acc = j->sj.acc; s->uniq_c = j->sj.uniq; s->multi_c = j->sj.multi;
@@ -237,6 +282,7 @@ int h_job_finish_part(h_job *j, int64_t lo, int64_t hi, const l2r_result *res, c
     if (!o.out_gtf) h_fatal("update_gtf", "a partitioned run needs -o or a base path for the updated GTF");
     h_reads part = j->reads;                                   /* a view: per-read arrays shifted, string table shared */
     part.n = hi - lo; part.tid += lo; part.pos += lo; part.rev += lo; part.qname += lo; part.cig_off += lo;
+    if (part.tid_name) part.tid_name += lo;
     h_result hr;
     hr.n = res->n_reads; hr.n_ex = res->n_exons; hr.ex_off = res->ex_off; hr.ex_start = res->ex_start; hr.ex_end = res->ex_end;
     hr.ex_flag = res->ex_flag; hr.info = res->info; hr.ref_tx = res->ref_tx;
@@ -273,6 +319,7 @@ static void *tail_part_main(void *arg)
     o.summary = NULL; o.summary_counts = t->cnt; o.no_detail_header = !t->first;
     h_reads part = j->reads;
     part.n = t->hi - t->lo; part.tid += t->lo; part.pos += t->lo; part.rev += t->lo; part.qname += t->lo; part.cig_off += t->lo;
+    if (part.tid_name) part.tid_name += t->lo;
     const l2r_result *res = t->res;
     const int64_t x0 = res->ex_off[t->lo], x1 = res->ex_off[t->hi];
     int64_t *off = (int64_t *)h_malloc((size_t)(part.n + 1) * sizeof(int64_t));

@@ -38,7 +38,8 @@ typedef struct {
     uint8_t *rev;
     int64_t *cig_off;
     uint32_t *cig; int64_t n_cig, cap_cig;
-    uint32_t *qname;             /* ids into names */
+    uint32_t *qname;             /* ids into names: QNAME = trans_name (and trans_id, unless tid_name is set) */
+    uint32_t *tid_name;          /* `-m g` input only: transcript_id of the read-like transcript (NULL for alignments) */
     h_strtab names;
 } h_reads;
 

@@ -187,14 +187,24 @@ static void emit_gtf_named(obuf *o, const char *src, const char *tchr, int start
     }
 }
 
+/* trans_name and trans_id of read i: both the QNAME for alignments, two GTF attributes for `-m g` input */
+static const char *read_name(const tail_ctx *c, int64_t i) { return h_str(&c->reads->names, c->reads->qname[i]); }
+static const char *read_tid_name(const tail_ctx *c, int64_t i)
+{
+    return h_str(&c->reads->names, c->reads->tid_name ? c->reads->tid_name[i] : c->reads->qname[i]);
+}
+
 static void emit_gtf(obuf *o, const tail_ctx *c, const char *tchr, int start, int end, int rev, int cov,
-                     const char *gid, const char *gname, const char *qname, int piece,
+                     const char *gid, const char *gname, int64_t read, int piece,
                      const char *xchr, int ex_rev, const int32_t *xs, const int32_t *xe, int n)
 {
-    char nm[H_NAME_MAX + 32];
-    if (piece >= 0) snprintf(nm, sizeof nm, "%s.split.%d", qname, piece); else { strncpy(nm, qname, sizeof nm - 1); nm[sizeof nm - 1] = 0; }
-    if (piece >= 0 && strlen(nm) >= H_NAME_MAX) h_fatal("split_trans", "piece name \"%s\" has 100 or more characters", nm);
-    emit_gtf_named(o, c->o->source, tchr, start, end, rev, cov, gid, nm, gname, nm, xchr, ex_rev, xs, xe, n);
+    /* src/update_gtf.c:871-872,904-905: a split piece is "<trans_id>.split.<k>" / "<trans_name>.split.<k>" */
+    const char *qname = read_name(c, read), *tidn = read_tid_name(c, read);
+    char nm[H_NAME_MAX + 32], ni[H_NAME_MAX + 32];
+    if (piece >= 0) { snprintf(nm, sizeof nm, "%s.split.%d", qname, piece); snprintf(ni, sizeof ni, "%s.split.%d", tidn, piece); }
+    else { strncpy(nm, qname, sizeof nm - 1); nm[sizeof nm - 1] = 0; strncpy(ni, tidn, sizeof ni - 1); ni[sizeof ni - 1] = 0; }
+    if (piece >= 0 && (strlen(nm) >= H_NAME_MAX || strlen(ni) >= H_NAME_MAX)) h_fatal("split_trans", "piece name \"%s\" has 100 or more characters", nm);
+    emit_gtf_named(o, c->o->source, tchr, start, end, rev, cov, gid, ni, gname, nm, xchr, ex_rev, xs, xe, n);
 }
 
 static void print_ref_list(FILE *fp, const tail_ctx *c, const l_list *L)
@@ -207,7 +217,7 @@ static void print_ref_list(FILE *fp, const tail_ctx *c, const l_list *L)
         const uint32_t info = r->info[x->read];
         const int rev = (info & L2R_INFO_REV) != 0;
         const int32_t ref = r->ref_tx[x->read];
-        const char *q = h_str(&c->reads->names, c->reads->qname[x->read]);
+        const int64_t q = x->read;
         const char *xc = c->chr->name[c->reads->tid[x->read]];
         if (x->piece < 0) {
             const int n = (int)L2R_INFO_NEXON(info);
@@ -227,7 +237,7 @@ static void print_merged(FILE *fp, const tail_ctx *c, const m_list *U)
     obuf o; ob_init(&o, fp);
     for (int64_t i = 0; i < U->n; ++i) {
         const m_ent *e = &U->e[i];
-        const char *q = h_str(&c->reads->names, c->reads->qname[e->read]);
+        const int64_t q = e->read;
         emit_gtf(&o, c, c->chr->name[e->tid], e->start, e->end, e->rev, e->cov, gene_id_of(c, e->gene_tx), gene_name_of(c, e->gene_tx),
                  q, e->piece, c->chr->name[e->ex_tid], e->ex_rev, U->xs + e->ex, U->xe + e->ex, e->n);
     }
@@ -245,7 +255,7 @@ static void print_all_reads(FILE *fp, const tail_ctx *c)
         const int n = (int)L2R_INFO_NEXON(info), rev = (info & L2R_INFO_REV) != 0;
         const char *xc = c->chr->name[c->reads->tid[i]];
         emit_gtf(&o, c, xc, r->ex_start[off], r->ex_end[off + n - 1], rev, 1, gene_id_of(c, r->ref_tx[i]), gene_name_of(c, r->ref_tx[i]),
-                 h_str(&c->reads->names, c->reads->qname[i]), -1, xc, rev, r->ex_start + off, r->ex_end + off, n);
+                 i, -1, xc, rev, r->ex_start + off, r->ex_end + off, n);
     }
     ob_done(&o);
 }

@@ -102,3 +102,12 @@ def test_bam2gtf_and_unique_gtf(oracle, tmp_path, files):
         assert r.returncode == 0, r.stderr.decode()[-1000:]
         assert filecmp.cmp(a, b, shallow=False), (cmd, extra)
         assert os.path.getsize(a) > 10000
+
+
+def test_gtf_input_mode(oracle, tmp_path, files):
+    """`update-gtf -m g -b`: the reads' bam2gtf output as read-like input; the engine gets synthesized M/N CIGARs."""
+    d, anno, reads, sam, bam, gtf = files
+    rgtf = str(tmp_path / "reads.gtf")
+    assert oracle.run_cli(["bam2gtf", sam], stdout_path=rgtf) == 0
+    _compare(oracle, tmp_path, ["-m", "g", "-b", bam, "-l", "3"], rgtf, gtf, "mg")
+    _compare(oracle, tmp_path, ["-m", "g", "-b", sam, "-l", "5", "-d", "1"], rgtf, gtf, "mg2")

@@ -219,3 +219,31 @@ np.savez(sys.argv[3], **a)
         np.testing.assert_array_equal(z["rev"], reads.rev)
         np.testing.assert_array_equal(z["cig_off"], reads.cig_off)
         np.testing.assert_array_equal(z["cig"], reads.cig)
+
+
+def test_gtf_input_mode(oracle, tmp_path):
+    """`update-gtf -m g -b hdr.sam reads.gtf anno.gtf`: read-like transcripts from a GTF (here the reads' own bam2gtf
+    output, trans_name != trans_id after editing) take the alignment records' place; files equal the oracle's."""
+    anno = synth.make_annotation(6000, 81, nchr=4, shuffle_within_gene=True)
+    reads = synth.make_reads(anno, 4000, 5, 81, xs_conflict_frac=0.02)
+    sam, gtf, rgtf = str(tmp_path / "r.sam"), str(tmp_path / "a.gtf"), str(tmp_path / "reads.gtf")
+    reads.write_sam(sam)
+    anno.write_gtf(gtf)
+    assert oracle.run_cli(["bam2gtf", sam], stdout_path=rgtf) == 0
+    # give every transcript a transcript_name that differs from its transcript_id
+    lines = []
+    for l in open(rgtf):
+        f = l.rstrip("\n").split("\t")
+        if len(f) > 8 and 'transcript_id "' in f[8]:
+            tid = f[8].split('transcript_id "')[1].split('"')[0]
+            if "transcript_name" not in f[8]:
+                f[8] = f[8].rstrip() + ' transcript_name "N_%s";' % tid
+        lines.append("\t".join(f))
+    open(rgtf, "w").write("\n".join(lines) + "\n")
+    oo, ho = _paths(tmp_path, "g.o"), _paths(tmp_path, "g.h")
+    extra = ["-m", "g", "-b", sam, "-l", "3"]
+    assert oracle.run_cli(_args(extra, oo, rgtf, gtf)) == 0
+    assert _host_with_oracle_results(_args(extra, ho, rgtf, gtf)) == 0
+    for k in OUTS:
+        assert filecmp.cmp(oo[k], ho[k], shallow=False), k
+    assert os.path.getsize(oo["detail"]) > 50000 and "N_" in open(oo["detail"]).read(4000)
