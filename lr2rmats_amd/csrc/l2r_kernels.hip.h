@@ -518,6 +518,7 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
     __shared__ int g_S[GEN_WAVES][GEN_CAP];
     __shared__ int g_E[GEN_WAVES][GEN_CAP];
     __shared__ uint32_t g_F[GEN_WAVES][GEN_CAP];
+    __shared__ uint32_t g_cnt[GEN_WAVES][2];
     const uint32_t cnt = *redo_count;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     int *S = g_S[wv], *E = g_E[wv];
@@ -603,7 +604,12 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
                             if (clr) atomicAnd(&F[q], ~clr);
                         }
                     }
-                    r_in = (int)wave_sum((uint32_t)r_in); same = (int)wave_sum((uint32_t)same);
+                    // the two counters of check_splice_site are sums over the wave: LDS atomics instead of a shuffle tree
+                    // (two dependent six-step ds_bpermute chains per candidate transcript otherwise)
+                    if (lane == 0) { g_cnt[wv][0] = 0u; g_cnt[wv][1] = 0u; }
+                    if (r_in) atomicAdd(&g_cnt[wv][0], (uint32_t)r_in);
+                    if (same) atomicAdd(&g_cnt[wv][1], (uint32_t)same);
+                    r_in = (int)g_cnt[wv][0]; same = (int)g_cnt[wv][1];
                     if (2 * (n - 1) == r_in && r_in == same) { vv = 1; known = true; }
                     else if (same > 0) { vv = 2; ksite = true; }
                 }

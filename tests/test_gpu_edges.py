@@ -129,3 +129,54 @@ def test_long_reads_and_long_cigars(oracle):
     anno, af, reads = util.make_case(32, n_reads=3000, n_exons=60, anno_exons=40000, ont=True, micro=3, xs=0.02)
     _run(oracle, af, reads, full_level=3)
     _run(oracle, af, reads, full_level=1, min_exon=1)
+
+
+def test_dictionary_slice_and_span_overflow(oracle):
+    """Tiles whose dictionary slices do not fit the staged tables (more than 224 distinct exons in the tile's span) and
+    reads that span more than the staged bucket directory (a 400-kb intron): everything falls back to the generic
+    kernel, nothing changes in the results."""
+    rng = np.random.default_rng(9)
+    txs, pool = [], []
+    for k in range(320):                                     # 320 distinct exons inside 64 kb
+        s = 20_000 + 200 * k
+        pool.append((s, s + 60 + int(rng.integers(0, 80))))
+    for t in range(60):
+        keep = sorted(rng.choice(np.arange(len(pool)), size=12, replace=False))
+        txs.append((0, t & 1, [pool[k] for k in keep]))
+    txs.append((0, 0, [(600_000, 600_200), (1_000_400, 1_000_600)]))          # one junction 400 kb long
+    txs.sort(key=lambda t: (t[2][0][0], t[2][-1][1]))
+    af = _anno(txs)
+    rows = []
+    for i in range(1500):
+        t = txs[int(rng.integers(len(txs)))][2]
+        a = int(rng.integers(0, max(1, len(t) - 2)))
+        ex = [list(x) for x in t[a:a + int(rng.integers(2, 6))]]
+        if i % 4 == 0:
+            ex[0][0] += int(rng.integers(0, 30))
+        p, ops = _chain([tuple(x) for x in ex])
+        rows.append((0, p, int(i & 1), ops))
+    rows.sort(key=lambda r: (r[0], r[1]))
+    got, want = _run(oracle, af, _reads(rows), full_level=3)
+    assert ((want.info & 1) != 0).sum() > 50
+
+
+def test_reads_longer_than_the_lds_tile(oracle):
+    """150-exon reads: even the smallest tile (32 reads) has more exons than the LDS image holds, so the walk writes
+    its exons straight to HBM and the generic kernel classifies them."""
+    n_ex, n_reads = 150, 200
+    ex = [(50_000 + 400 * k, 50_000 + 400 * k + 120) for k in range(n_ex + 40)]
+    af = _anno([(0, 0, ex[:n_ex]), (0, 1, ex[5:n_ex + 20:2]), (1, 0, [(100, 300), (900, 1200)])])
+    rng = np.random.default_rng(11)
+    rows = []
+    for i in range(n_reads):
+        a = int(rng.integers(0, 30))
+        chain = [list(x) for x in ex[a:a + n_ex]]
+        if i % 3 == 0:
+            chain[0][0] += 7
+        if i % 5 == 0:
+            del chain[60]
+        p, ops = _chain([tuple(x) for x in chain])
+        rows.append((0, p, 0, ops))
+    rows.sort(key=lambda r: (r[0], r[1]))
+    got, want = _run(oracle, af, _reads(rows), full_level=3)
+    assert int((got.info >> 8).max()) >= 149

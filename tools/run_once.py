@@ -11,7 +11,7 @@ cfg = dict(workload.CONFIGS[cfgname]); cfg['n_reads'] = N
 af, reads = workload.make_rank_workload(cfg, 0, 1)
 e = capi.Engine(0)
 e.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
-e.set_params(capi.default_params(full_level=3))
+e.set_params(capi.default_params(full_level=int(os.environ.get("L2R_LEVEL", "3")), ss_dis=int(os.environ.get("L2R_DIS", "0"))))
 e.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)
 lib = capi.load_library()
 out = (C.c_ulonglong * 16)()
