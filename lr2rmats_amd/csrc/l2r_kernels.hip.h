@@ -252,12 +252,12 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
         const int64_t c_a = cig_off[r], c_b = cig_off[r + 1];
         pos = r_pos[r];
         tid = r_tid[r];
-        if (threadIdx.x == 0) s_tid0 = tid;
         if (j0_in) j0 = j0_in[r];
         else { j0 = cursor_value(cd, tid, pos + 1); j0_out[r] = j0; }       // first exon always starts at pos + 1
         el = pos;
         n = (uint32_t)walk_cigar<WIDE>(cig + c_a, (int)(c_b - c_a), pos, p, [&](int, int, int e) { el = e; });
     }
+    if (threadIdx.x == 0) s_tid0 = active ? tid : INT32_MAX;          // (an empty launch has no first read: no chromosome matches)
     uint32_t total;
     const uint32_t local = block_exclusive_scan(n, s_wave, total);
     if (active) local_out[r] = local;
