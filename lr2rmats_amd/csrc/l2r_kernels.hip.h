@@ -30,7 +30,7 @@ constexpr int WAVE = 64;
 constexpr int LDS_EXON_CAP = 3072;      // exons of one tile staged in LDS (10 B each)
 constexpr int DIR_CAP = 384;            // 512-bp buckets staged per tile (span up to ~196 kb)
 constexpr int KEY_CAP = 224;            // dictionary entries staged per dictionary and tile (threads 224..255 stage the headers)
-constexpr int WIN_TX = 32;              // annotation transcripts in a tile's window = bits of a membership mask
+constexpr int WIN_TX = 32;              // annotation transcripts in a tile's window = bits of a tile-frame membership mask
 constexpr int SITE_SHIFT = 9;
 
 // One annotation transcript (file order), 48 B = three 16-byte loads.
@@ -78,16 +78,18 @@ struct CursorDir {
 
 // What k_pass_a leaves for every tile.
 struct TileDesc {
-    int32_t j_lo;              // smallest cursor value of the tile's reads = first transcript of the window
+    int32_t j_lo;              // first transcript of the tile's window (no member: the tile's smallest cursor value)
     int32_t tid;               // the tile's chromosome = the one of its first read (other reads: generic kernel)
     int32_t b_off;             // bucket of x in the staged slice = (x >> 9) + b_off
     int32_t nb;                // buckets the annotation has on this chromosome
     int32_t b0, nbk;           // first staged bucket (absolute), number of staged buckets
     uint32_t st_r0, st_nk;     // START entries [st_r0, st_r0 + st_nk)
     uint32_t en_r0, en_nk;     // END entries
-    uint32_t flags, pad;
+    uint32_t flags, n_win;     // n_win: transcripts in the tile's window (win_hdr[tile * WIN_TX + 0 .. n_win))
 };
-constexpr uint32_t TD_FAST = 1;    // exons fit the LDS tile, dictionary slices fit DIR_CAP / KEY_CAP
+constexpr uint32_t TD_FAST = 1;    // exons fit the LDS tile, dictionary slices fit DIR_CAP / KEY_CAP, window fits WIN_TX
+constexpr uint32_t TD_CONTIG = 2;  // the window's transcripts are consecutive in the annotation: j_lo, j_lo + 1, ...
+constexpr int WIN_SCAN_TRIPS = 64; // pass A looks at up to 64 * WIN_SCAN_TRIPS transcripts for a tile's window
 
 struct DevParams {
     int32_t min_exon, min_intron, max_delet, ss_dis;
@@ -236,10 +238,11 @@ __global__ __launch_bounds__(TILE_THREADS)
 void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t *__restrict__ r_pos,
               const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ cig, CursorDir cd, SiteTabs tabs, DevParams p,
               const int32_t *__restrict__ j0_in, int32_t *__restrict__ j0_out, uint32_t *__restrict__ local_out,
-              uint8_t *__restrict__ order_out, uint32_t *__restrict__ tile_sum, TileDesc *__restrict__ desc, uint32_t *__restrict__ redo_count)
+              uint8_t *__restrict__ order_out, uint32_t *__restrict__ tile_sum, TileDesc *__restrict__ desc, uint32_t *__restrict__ redo_count,
+              const TxHdr *__restrict__ hdr, TxHdr *__restrict__ win_hdr)
 {
     __shared__ uint32_t s_wave[4];
-    __shared__ int s_red[4][3];
+    __shared__ int s_red[4][6];
     __shared__ int s_tid0;
     __shared__ uint32_t s_hist[WAVE];
     if (threadIdx.x < WAVE) s_hist[threadIdx.x] = 0u;
@@ -286,21 +289,25 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
         blo = min(max(pos + 1, 0) >> SITE_SHIFT, nb - 1);
         bhi = min(max(el, 0) >> SITE_SHIFT, nb - 1);
     }
-    {   // tile reductions: min cursor, bucket span
-        const int a0 = wave_min(mine ? j0 : INT32_MAX), a3 = wave_min(blo), a4 = wave_max(bhi);
+    {   // tile reductions: cursor range, bucket span, coordinate span
+        const int a0 = wave_min(mine ? j0 : INT32_MAX), a1 = wave_max(mine ? j0 : -1), a3 = wave_min(blo), a4 = wave_max(bhi);
+        const int a5 = wave_min(mine ? pos + 1 : INT32_MAX), a6 = wave_max(mine ? el : INT32_MIN);
         if ((threadIdx.x & (WAVE - 1)) == 0) {
             int *q = s_red[threadIdx.x >> 6];
-            q[0] = a0; q[1] = a3; q[2] = a4;
+            q[0] = a0; q[1] = a3; q[2] = a4; q[3] = a1; q[4] = a5; q[5] = a6;
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        tile_sum[blockIdx.x] = total;
-        int jl = INT32_MAX, lo = INT32_MAX, hi = -1;
-        for (int w = 0; w < 4; ++w) { jl = min(jl, s_red[w][0]); lo = min(lo, s_red[w][1]); hi = max(hi, s_red[w][2]); }
+    if (threadIdx.x < WAVE) {             // wave 0 finishes the tile; everything below is wave-uniform but `lane`
+        const int lane = (int)threadIdx.x;
+        int jl = INT32_MAX, lo = INT32_MAX, hi = -1, jh = -1, tlo = INT32_MAX, thi = INT32_MIN;
+        for (int w = 0; w < 4; ++w) {
+            jl = min(jl, s_red[w][0]); lo = min(lo, s_red[w][1]); hi = max(hi, s_red[w][2]);
+            jh = max(jh, s_red[w][3]); tlo = min(tlo, s_red[w][4]); thi = max(thi, s_red[w][5]);
+        }
         TileDesc d;
         d.j_lo = jl == INT32_MAX ? 0 : jl; d.tid = tid0; d.b_off = 0; d.nb = 0; d.b0 = 0; d.nbk = 0;
-        d.st_r0 = d.st_nk = d.en_r0 = d.en_nk = 0u; d.pad = 0u;
+        d.st_r0 = d.st_nk = d.en_r0 = d.en_nk = 0u; d.n_win = 0u;
         bool fast = total <= (uint32_t)LDS_EXON_CAP && p.ss_dis == 0 && !(p.ablate & 1);
         if (fast && hi >= 0) {
             const int nbk = hi - lo + 1;
@@ -313,8 +320,55 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
                 if (d.st_nk > (uint32_t)KEY_CAP || d.en_nk > (uint32_t)KEY_CAP) fast = false;
             }
         }
-        d.flags = fast ? TD_FAST : 0u;
-        desc[blockIdx.x] = d;
+        // The tile's WINDOW: the transcripts from its smallest cursor value on that some read of the tile can overlap,
+        // in file order, up to the first transcript every read of the tile lies before (src/update_gtf.c:799-800 ends
+        // every sweep there; a sweep that starts behind it would leave the window, so then the tile is not fast).
+        // Left out are transcripts that end before every read of the tile starts: :801 skips them for each read and they
+        // can end no sweep (their start lies below every read end).  At most WIN_TX members = bits of a tile-frame mask.
+        bool contig = true;
+        if (fast && jl != INT32_MAX) {
+            int first = -1, last = -1, after = INT32_MAX;
+            uint32_t n_win = 0;
+            for (int base = jl, trip = 0; ; ++trip) {
+                const int j = base + lane;
+                bool ov = false, aft = false;
+                if (j < p.n_tx) {
+                    const int4 h0 = *reinterpret_cast<const int4 *>(hdr + j);                 // {tid, start, end, .}
+                    aft = tid0 < h0.x || (tid0 == h0.x && thi <= h0.y);                       // comp_trans <= (Q5)
+                    const bool bef = h0.x < tid0 || (h0.x == tid0 && h0.z <= tlo && h0.y < tlo);
+                    ov = !aft && !bef;
+                }
+                const unsigned long long ma = __ballot(aft);
+                const int stop = ma ? __ffsll((long long)ma) - 1 : WAVE;
+                const unsigned long long mo = __ballot(ov) & (stop < WAVE ? (1ull << stop) - 1ull : ~0ull);
+                if ((mo >> lane) & 1ull) {
+                    const uint32_t rank = n_win + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull));
+                    if (rank < (uint32_t)WIN_TX) {          // the member's header, with its annotation index in the spare word
+                        const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);
+                        int4 *wp = reinterpret_cast<int4 *>(win_hdr + (int64_t)blockIdx.x * WIN_TX + rank);
+                        int4 h1 = hp[1];
+                        h1.w = j;
+                        wp[0] = hp[0]; wp[1] = h1; wp[2] = hp[2];
+                    }
+                }
+                if (mo) {
+                    if (first < 0) first = base + __ffsll((long long)mo) - 1;
+                    last = base + 63 - __clzll((long long)mo);
+                }
+                n_win += (uint32_t)__popcll(mo);
+                if (ma) { after = base + stop; break; }
+                base += WAVE;
+                if (base >= p.n_tx) break;
+                if (n_win > (uint32_t)WIN_TX || trip == WIN_SCAN_TRIPS - 1) { fast = false; break; }
+            }
+            if (n_win > (uint32_t)WIN_TX || jh > after) fast = false;
+            if (fast) {
+                d.n_win = n_win;
+                if (n_win) { d.j_lo = first; contig = (uint32_t)(last - first + 1) == n_win; }
+            }
+        }
+        d.flags = (fast ? TD_FAST : 0u) | (contig ? TD_CONTIG : 0u);
+        if (lane == 0) { tile_sum[blockIdx.x] = total; desc[blockIdx.x] = d; }
     }
 }
 
@@ -662,6 +716,7 @@ struct FastArgs {
     int64_t n_reads;
     const int32_t *r_tid; const int32_t *r_pos; const uint8_t *r_rev; const int64_t *cig_off; const uint32_t *cig;
     const uint32_t *local; const uint8_t *order; const uint32_t *tile_base; const int32_t *j0; const TileDesc *desc;
+    const TxHdr *win_hdr;        // per tile WIN_TX header copies, the annotation index in the spare word (pass A)
     const TxHdr *hdr; SiteDict st, en;
     uint32_t *ex_off; int32_t *ex_start; int32_t *ex_end; uint8_t *ex_flag; uint32_t *info; int32_t *ref_tx;
     uint32_t *tile_acc, *tile_acc_ex; uint32_t *redo_count, *redo;
@@ -675,6 +730,20 @@ __device__ __forceinline__ uint32_t rebase_mask(uint32_t lo, uint32_t hi, int d)
     const unsigned long long m = ((unsigned long long)hi << 32) | lo;
     if (d >= 0) return d < 32 ? (uint32_t)(m << d) : 0u;
     return -d < 64 ? (uint32_t)(m >> (-d)) : 0u;
+}
+
+// The same for a window whose members win[0 .. w_n) are not consecutive (rare: the loop is kept small on purpose, the
+// staging code around it has little register room)
+__device__ __forceinline__ uint32_t rebase_gaps(const int *win, int w_n, uint32_t lo, uint32_t hi, int tx_base)
+{
+    uint32_t out = 0u;
+#pragma unroll 1
+    for (int j = 0; j < w_n; ++j) {
+        const uint32_t b = (uint32_t)(win[j] - tx_base);
+        const uint32_t word = b < 32u ? lo : hi;
+        out |= (b < 64u ? (word >> (b & 31u)) & 1u : 0u) << j;
+    }
+    return out;
 }
 
 // Staged dictionary entries are read as one 16-byte vector {k1, k2, pm, sm}: one ds_read_b128.
@@ -793,7 +862,7 @@ __device__ __forceinline__ bool cigar_staged(const TileUniforms &u, int region_w
 __device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, const TileUniforms &u, int region_words)
 {
     TileVectors v;
-    const int rpt = a->p.reads_per_tile, n_tx = a->p.n_tx;
+    const int rpt = a->p.reads_per_tile;
     const uint32_t n_reads = (uint32_t)a->n_reads;
     const uint32_t r = t * (uint32_t)rpt + (uint32_t)u.src;
     const bool active = u.src >= 0;
@@ -816,11 +885,11 @@ __device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, con
     }
     const TileDesc &d = u.d;
     const bool fast = (d.flags & TD_FAST) != 0;
-    const int w_n = fast ? min(WIN_TX, n_tx - d.j_lo) : 0;
+    const int w_n = fast ? (int)d.n_win : 0;
     v.xa = v.xb = v.xc = v.xd = make_int4(0, 0, 0, 0);
     if ((int)threadIdx.x >= KEY_CAP) {
         if ((int)threadIdx.x - KEY_CAP < w_n) {
-            const int4 *hp = reinterpret_cast<const int4 *>(a->hdr + d.j_lo + ((int)threadIdx.x - KEY_CAP));
+            const int4 *hp = reinterpret_cast<const int4 *>(a->win_hdr + (t * (uint32_t)WIN_TX + (threadIdx.x - (uint32_t)KEY_CAP)));
             v.xa = hp[0]; v.xb = hp[1]; v.xc = hp[2];
         }
     } else {
@@ -842,6 +911,7 @@ struct TileLds {                 // the tile's LDS image (layout in k_classify_f
     int *S, *E; uint16_t *W;
     const v4i_t *ent0, *ent1; const uint8_t *dir0, *dir1, *rdir;
     const int4 *hk, *hx;
+    const int *win;              // window member -> annotation index
 };
 struct VisitMasks { uint32_t vpre, lmask, rmask, k1mask; bool redo; };
 struct SiteMasks { uint32_t kand, kor, dm_first, am_last; };
@@ -850,11 +920,15 @@ struct SiteMasks { uint32_t kand, kor, dm_first, am_last; };
 // that lie before the read (:801); terminal-exon masks of check_full (:629-681); single-exon known candidates (:806-811).
 // Wave-uniform j, header words broadcast from LDS.
 template <int LEVEL>
-__device__ __forceinline__ VisitMasks visit_window(const TileLds &L, const TileDesc &d, int w_n, int n_tx, bool work, uint32_t n, int j0,
+__device__ __forceinline__ VisitMasks visit_window(const TileLds &L, const TileDesc &d, int w_n, bool work, uint32_t n, int j0,
                                                    const ReadEnds &re)
 {
     VisitMasks m{0u, 0u, 0u, 0u, false};
-    const int jrel0 = j0 - d.j_lo;
+    int jrel0 = j0 - d.j_lo;                       // first member the read's sweep reaches
+    if (!(d.flags & TD_CONTIG)) {
+        jrel0 = 0;
+        for (int j = 0; j < w_n; ++j) jrel0 += L.win[j] < j0 ? 1 : 0;
+    }
     bool stopped = !work;
     for (int j = 0; j < w_n; ++j) {
         const int4 hk = L.hk[j];
@@ -879,7 +953,6 @@ __device__ __forceinline__ VisitMasks visit_window(const TileLds &L, const TileD
             if (ov && n > 1) m.redo = true;                                 // literal loops needed for this pair
         }
     }
-    if (work && !stopped && d.j_lo + w_n < n_tx) m.redo = true;             // the sweep must have ended inside the window
     return m;
 }
 
@@ -980,7 +1053,7 @@ __device__ __forceinline__ Verdict decide(const TileLds &L, const TileDesc &d, u
     }
     int ref = -1;
     bool out_rev = rev_in;
-    if (jref >= 0) { ref = d.j_lo + jref; out_rev = ((L.hk[jref].w >> 8) & 1) != 0; }     // :825-831
+    if (jref >= 0) { ref = L.win[jref]; out_rev = ((L.hk[jref].w >> 8) & 1) != 0; }     // :825-831
     uint32_t info = 0;
     if (known) info |= I_KNOWN;
     if (ksite) info |= I_KSITE;
@@ -1008,6 +1081,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
     __shared__ __attribute__((aligned(16))) uint32_t s_all[ALL_WORDS];
     __shared__ __attribute__((aligned(16))) int4 s_hk[WIN_TX];     // {start, end, n, flags | rev << 8} on the tile's chromosome
     __shared__ __attribute__((aligned(16))) int4 s_hx[WIN_TX];     // {s0, e0, sl, el}
+    __shared__ int s_win[WIN_TX];                                   // window member -> annotation index
     __shared__ uint32_t s_cnt[4][2];
 
     (void)kernarg_block;
@@ -1044,8 +1118,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         uint8_t *const s_dir1 = s_dir0 + DIR_BYTES, *const s_rdir = s_dir1 + DIR_BYTES;
         const uint32_t local = v.local, n = active ? v.nxt - v.local : 0u;
         const int32_t pos = v.pos, j0 = v.j0, tid = v.tid;
-        const int n_tx = fast_args()->p.n_tx;
-        const int w_n = fast ? min(WIN_TX, n_tx - d.j_lo) : 0;          // transcripts in the window
+        const int w_n = fast ? (int)d.n_win : 0;                         // transcripts in the window
 
         // ---- phase 0: the tile's CIGAR words, registers -> LDS
         const bool staged = cigar_staged(u, tail_words);
@@ -1097,22 +1170,27 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
                     else if (v.xa.x > d.tid) { st = INT32_MAX; en = INT32_MAX; }
                     s_hk[j] = make_int4(st, en, v.xb.x, (v.xb.z & 0xff) | (v.xb.y << 8));
                     s_hx[j] = v.xc;
+                    s_win[j] = v.xb.w;
                 }
-            } else {
-                if (threadIdx.x < d.st_nk) {
-                    v4i_t e; e.x = v.xa.x; e.y = v.xa.y;
-                    e.z = (int)rebase_mask((uint32_t)v.xb.x, (uint32_t)v.xb.y, v.xa.z - d.j_lo);
-                    e.w = (int)rebase_mask((uint32_t)v.xb.z, (uint32_t)v.xb.w, v.xa.z - d.j_lo);
-                    s_ent0[threadIdx.x] = e;
-                    if (v.xa.w & SE_WIDE) my_wide = 1;
+            }
+            if (!(d.flags & TD_CONTIG)) __syncthreads();         // (tile-uniform) the entries below need the member list
+            if ((int)threadIdx.x < KEY_CAP) {
+                const bool has_st = threadIdx.x < d.st_nk, has_en = threadIdx.x < d.en_nk;
+                v4i_t e0, e1;
+                e0.x = v.xa.x; e0.y = v.xa.y; e1.x = v.xc.x; e1.y = v.xc.y;
+                if (d.flags & TD_CONTIG) {           // consecutive window: a shift moves a mask into the tile frame
+                    e0.z = (int)rebase_mask((uint32_t)v.xb.x, (uint32_t)v.xb.y, v.xa.z - d.j_lo);
+                    e0.w = (int)rebase_mask((uint32_t)v.xb.z, (uint32_t)v.xb.w, v.xa.z - d.j_lo);
+                    e1.z = (int)rebase_mask((uint32_t)v.xd.x, (uint32_t)v.xd.y, v.xc.z - d.j_lo);
+                    e1.w = (int)rebase_mask((uint32_t)v.xd.z, (uint32_t)v.xd.w, v.xc.z - d.j_lo);
+                } else {                             // window with gaps: member by member
+                    e0.z = (int)rebase_gaps(s_win, w_n, (uint32_t)v.xb.x, (uint32_t)v.xb.y, v.xa.z);
+                    e0.w = (int)rebase_gaps(s_win, w_n, (uint32_t)v.xb.z, (uint32_t)v.xb.w, v.xa.z);
+                    e1.z = (int)rebase_gaps(s_win, w_n, (uint32_t)v.xd.x, (uint32_t)v.xd.y, v.xc.z);
+                    e1.w = (int)rebase_gaps(s_win, w_n, (uint32_t)v.xd.z, (uint32_t)v.xd.w, v.xc.z);
                 }
-                if (threadIdx.x < d.en_nk) {
-                    v4i_t e; e.x = v.xc.x; e.y = v.xc.y;
-                    e.z = (int)rebase_mask((uint32_t)v.xd.x, (uint32_t)v.xd.y, v.xc.z - d.j_lo);
-                    e.w = (int)rebase_mask((uint32_t)v.xd.z, (uint32_t)v.xd.w, v.xc.z - d.j_lo);
-                    s_ent1[threadIdx.x] = e;
-                    if (v.xc.w & SE_WIDE) my_wide = 1;
-                }
+                if (has_st) { s_ent0[threadIdx.x] = e0; if (v.xa.w & SE_WIDE) my_wide = 1; }
+                if (has_en) { s_ent1[threadIdx.x] = e1; if (v.xc.w & SE_WIDE) my_wide = 1; }
             }
             if (d.nbk > 0) {
 #pragma unroll
@@ -1135,8 +1213,8 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         uint32_t info = n << 8; int ref = -1;
         bool redo = active && (!fast || !in_lds || any_wide != 0 || tid != d.tid || (n > 1 && !sane));
         const bool work = active && !redo;
-        const TileLds L{s_S, s_E, s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_hk, s_hx};
-        const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, n_tx, work, n, j0, re);
+        const TileLds L{s_S, s_E, s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_hk, s_hx, s_win};
+        const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, j0, re);
         redo = redo || vm.redo;
         L2R_STAMP(2);
         const SiteMasks sm = map_exons(L, d, work && !redo && n > 1, local, n, vm.vpre);

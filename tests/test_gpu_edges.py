@@ -48,12 +48,19 @@ def _chain(exons):
     return exons[0][0] - 1, ops
 
 
-def _run(oracle, af, reads, **kw):
+def _run(oracle, af, reads, counters=None, **kw):
     want = util.oracle_run(oracle, af, reads, oracle.default_params(**kw))
     eng = capi.Engine(0)
     try:
         eng.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
         got = eng.classify(reads, capi.default_params(**kw))
+        if counters is not None:            # [reads the generic kernel took, wide entries, compact transcripts, tiles]
+            import ctypes as C
+            lib = capi.load_library()
+            cnt = (C.c_longlong * 4)()
+            lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            lib.l2r_debug_counters(eng.ctx, cnt, 4)
+            counters[:] = list(cnt)
     finally:
         eng.close()
     util.assert_same_result(got, want, 0, 0)
@@ -180,3 +187,44 @@ def test_reads_longer_than_the_lds_tile(oracle):
     rows.sort(key=lambda r: (r[0], r[1]))
     got, want = _run(oracle, af, _reads(rows), full_level=3)
     assert int((got.info >> 8).max()) >= 149
+
+
+@pytest.mark.parametrize("level", [1, 3, 5])
+def test_windows_with_gaps_stay_on_the_fast_path(oracle, level):
+    # Two chromosome-long transcripts at the head of the file pin the reference's cursor: every tile's window is
+    # {the long ones} + {the local genes}, with hundreds of transcripts in between that end before the tile.  Genes
+    # hold their transcripts in arbitrary order (GENCODE style), so sweeps end at different members per read.
+    rng = np.random.default_rng(11)
+    txs = [(0, 0, [(1_000, 1_200), (1_990_000, 1_990_300)]), (0, 1, [(1_100, 1_200), (5_000, 5_050), (1_995_000, 1_995_100)])]
+    genes = []
+    for g in range(300):
+        base = 10_000 + 6_000 * g
+        pool = [(base + 400 * k, base + 400 * k + 120) for k in range(10)]
+        iso = []
+        for t in range(4):
+            keep = sorted(set([0] + list(rng.choice(np.arange(1, 10), size=5, replace=False))))
+            iso.append((0, g & 1, [pool[k] for k in keep]))
+        order = rng.permutation(4)
+        genes.append([iso[i] for i in order])
+        txs.extend(genes[-1])
+    af = _anno(txs)
+    rows = []
+    for i in range(30000):                  # about 2.5 genes = 10 transcripts under a tile of 256 reads
+        iso = genes[int(rng.integers(len(genes)))]
+        t = iso[int(rng.integers(4))][2]
+        a = int(rng.integers(0, len(t) - 1))
+        ex = [list(x) for x in t[a:a + int(rng.integers(1, 5))]]
+        if i % 4 == 0:
+            ex[0][0] -= int(rng.integers(0, 30))
+        if i % 9 == 0:
+            ex[-1][1] += int(rng.integers(0, 30))
+        p, ops = _chain([tuple(x) for x in ex])
+        rows.append((0, p, int(i & 1), ops))
+    rows.append((0, 999, 0, _chain([(1_000, 1_200), (1_990_000, 1_990_300)])[1]))        # the long transcript itself
+    rows.sort(key=lambda r: (r[0], r[1]))
+    cnt = [0, 0, 0, 0]
+    got, want = _run(oracle, af, _reads(rows), counters=cnt, full_level=level)
+    assert ((want.info & 1) != 0).sum() > 2000
+    # the long read covers the whole chromosome: the tile that holds it may go to the generic kernel, no other
+    if not os.environ.get("L2R_ABLATE"):
+        assert cnt[0] <= 2 * 256, cnt
