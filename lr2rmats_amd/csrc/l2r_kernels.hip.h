@@ -164,43 +164,81 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 // is written without short-circuit logic so that it compiles to selects (one predicated region per op: the emit).
 // WIDE: the words come from HBM, one read per lane; a lane then fetches 16 words (a whole 64-byte sector) at a time,
 // otherwise every 16-byte load of a long CIGAR drags in a sector of its own (ONT reads: hundreds of ops).
-template <bool WIDE, typename Ptr, typename Emit>
-__device__ __forceinline__ int walk_cigar(Ptr cig, int n_cig, int pos0, const DevParams &p, Emit emit)
+struct WalkState { int start, end, n; };
+
+template <typename Emit>
+__device__ __forceinline__ void walk_step(WalkState &w, uint32_t c, const DevParams &p, Emit &emit)
 {
-    int start = pos0 + 1, end = start - 1, n = 0;
-    auto step = [&](uint32_t c) {
-        const int len = (int)(c >> 4);
-        const uint32_t op = c & 0xfu;
-        // N (3) cuts at len >= min_intron, D (2) at len > max_delet; M,=,X,N,D advance the reference
-        const bool cut = ((op == 3u) & (len >= p.min_intron)) | ((op == 2u) & (len > p.max_delet));
-        const bool keep = cut & ((n == 0) | (end - start + 1 >= p.min_exon));
-        if (keep) emit(n, start, end);
-        n += keep ? 1 : 0;
-        start = cut ? end + len + 1 : start;
-        end += ((0x18du >> op) & 1u) ? len : 0;         // ops 0 2 3 7 8
-    };
-    int k = 0;
+    const int len = (int)(c >> 4);
+    const uint32_t op = c & 0xfu;
+    // N (3) cuts at len >= min_intron, D (2) at len > max_delet; M,=,X,N,D advance the reference
+    const bool cut = ((op == 3u) & (len >= p.min_intron)) | ((op == 2u) & (len > p.max_delet));
+    const bool keep = cut & ((w.n == 0) | (w.end - w.start + 1 >= p.min_exon));
+    if (keep) emit(w.n, w.start, w.end);
+    w.n += keep ? 1 : 0;
+    w.start = cut ? w.end + len + 1 : w.start;
+    w.end += len & __builtin_amdgcn_sbfe(0x18d, op, 1u);         // ops 0 2 3 7 8 advance: bit `op` of 0x18d as 0 / -1
+}
+
+// ops [k, n_cig) of a read
+template <bool WIDE, typename Ptr, typename Emit>
+__device__ __forceinline__ void walk_ops(WalkState &w, Ptr cig, int k, int n_cig, const DevParams &p, Emit &emit)
+{
     if (WIDE) {
         for (; k + 16 <= n_cig; k += 16) {
             uint32_t c[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) c[u] = cig[k + u];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) step(c[u]);
+            for (int u = 0; u < 16; ++u) walk_step(w, c[u], p, emit);
         }
     }
     for (; k + 8 <= n_cig; k += 8) {
         const uint32_t c0 = cig[k], c1 = cig[k + 1], c2 = cig[k + 2], c3 = cig[k + 3];
         const uint32_t c4 = cig[k + 4], c5 = cig[k + 5], c6 = cig[k + 6], c7 = cig[k + 7];
-        step(c0); step(c1); step(c2); step(c3); step(c4); step(c5); step(c6); step(c7);
+        walk_step(w, c0, p, emit); walk_step(w, c1, p, emit); walk_step(w, c2, p, emit); walk_step(w, c3, p, emit);
+        walk_step(w, c4, p, emit); walk_step(w, c5, p, emit); walk_step(w, c6, p, emit); walk_step(w, c7, p, emit);
     }
     for (; k + 4 <= n_cig; k += 4) {
         const uint32_t c0 = cig[k], c1 = cig[k + 1], c2 = cig[k + 2], c3 = cig[k + 3];
-        step(c0); step(c1); step(c2); step(c3);
+        walk_step(w, c0, p, emit); walk_step(w, c1, p, emit); walk_step(w, c2, p, emit); walk_step(w, c3, p, emit);
     }
-    for (; k < n_cig; ++k) step(cig[k]);
-    emit(n, start, end);
-    return n + 1;
+    for (; k < n_cig; ++k) walk_step(w, cig[k], p, emit);
+}
+
+template <bool WIDE, typename Ptr, typename Emit>
+__device__ __forceinline__ int walk_cigar(Ptr cig, int n_cig, int pos0, const DevParams &p, Emit emit)
+{
+    WalkState w{pos0 + 1, pos0, 0};
+    walk_ops<WIDE>(w, cig, 0, n_cig, p, emit);
+    emit(w.n, w.start, w.end);
+    return w.n + 1;
+}
+
+// The first WALK_HEAD ops of a read, fetched ahead of use (pass A issues them together with its cursor lookup).
+// Words behind the read's last op become "I, length 0", which changes nothing (the array is padded by four words).
+constexpr int WALK_HEAD = 16;
+struct CigarHead { uint32_t c[WALK_HEAD]; };
+__device__ __forceinline__ CigarHead load_cigar_head(const uint32_t *__restrict__ cig, int n_cig)
+{
+    CigarHead h;
+#pragma unroll
+    for (int q = 0; q < WALK_HEAD / 4; ++q) {
+        uint32_t c0 = 1u, c1 = 1u, c2 = 1u, c3 = 1u;
+        if (4 * q < n_cig) { c0 = cig[4 * q]; c1 = cig[4 * q + 1]; c2 = cig[4 * q + 2]; c3 = cig[4 * q + 3]; }
+        h.c[4 * q] = c0; h.c[4 * q + 1] = 4 * q + 1 < n_cig ? c1 : 1u; h.c[4 * q + 2] = 4 * q + 2 < n_cig ? c2 : 1u; h.c[4 * q + 3] = 4 * q + 3 < n_cig ? c3 : 1u;
+    }
+    return h;
+}
+template <bool WIDE, typename Emit>
+__device__ __forceinline__ int walk_cigar_headed(const CigarHead &h, const uint32_t *__restrict__ cig, int n_cig, int pos0, const DevParams &p, Emit emit)
+{
+    WalkState w{pos0 + 1, pos0, 0};
+#pragma unroll
+    for (int u = 0; u < WALK_HEAD; ++u) walk_step(w, h.c[u], p, emit);
+    if (n_cig > WALK_HEAD) walk_ops<WIDE>(w, cig, WALK_HEAD, n_cig, p, emit);
+    emit(w.n, w.start, w.end);
+    return w.n + 1;
 }
 
 // first j with key_j > (tid, start): the value the reference's annotation cursor has for this read
@@ -255,10 +293,11 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
         const int64_t c_a = cig_off[r], c_b = cig_off[r + 1];
         pos = r_pos[r];
         tid = r_tid[r];
+        const CigarHead head = load_cigar_head(cig + c_a, (int)(c_b - c_a));      // in flight during the cursor lookup
         if (j0_in) j0 = j0_in[r];
         else { j0 = cursor_value(cd, tid, pos + 1); j0_out[r] = j0; }       // first exon always starts at pos + 1
         el = pos;
-        n = (uint32_t)walk_cigar<WIDE>(cig + c_a, (int)(c_b - c_a), pos, p, [&](int, int, int e) { el = e; });
+        n = (uint32_t)walk_cigar_headed<WIDE>(head, cig + c_a, (int)(c_b - c_a), pos, p, [&](int, int, int e) { el = e; });
     }
     if (threadIdx.x == 0) s_tid0 = active ? tid : INT32_MAX;          // (an empty launch has no first read: no chromosome matches)
     uint32_t total;
@@ -309,16 +348,15 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
         d.j_lo = jl == INT32_MAX ? 0 : jl; d.tid = tid0; d.b_off = 0; d.nb = 0; d.b0 = 0; d.nbk = 0;
         d.st_r0 = d.st_nk = d.en_r0 = d.en_nk = 0u; d.n_win = 0u;
         bool fast = total <= (uint32_t)LDS_EXON_CAP && p.ss_dis == 0 && !(p.ablate & 1);
-        if (fast && hi >= 0) {
-            const int nbk = hi - lo + 1;
-            if (nbk > DIR_CAP) fast = false;
-            else {
-                // START entries from the first one that reaches into the first bucket (full-length evidence scans them)
-                d.b_off = -lo; d.nb = nb; d.b0 = tb + lo; d.nbk = nbk;
-                d.st_r0 = tabs.st.rdir[tb + lo]; d.st_nk = tabs.st.dir[tb + hi + 1] - d.st_r0;
-                d.en_r0 = tabs.en.dir[tb + lo]; d.en_nk = tabs.en.dir[tb + hi + 1] - d.en_r0;
-                if (d.st_nk > (uint32_t)KEY_CAP || d.en_nk > (uint32_t)KEY_CAP) fast = false;
-            }
+        // dictionary slices of the tile's bucket span: four directory words, used after the window scan below (the
+        // loads and the scan's header loads are in flight together)
+        uint32_t sd_r0 = 0u, sd_r1 = 0u, ed_r0 = 0u, ed_r1 = 0u;
+        const bool sliced = fast && hi >= 0 && hi - lo + 1 <= DIR_CAP;
+        if (fast && hi >= 0 && !sliced) fast = false;
+        if (sliced) {
+            // START entries from the first one that reaches into the first bucket (full-length evidence scans them)
+            sd_r0 = tabs.st.rdir[tb + lo]; sd_r1 = tabs.st.dir[tb + hi + 1];
+            ed_r0 = tabs.en.dir[tb + lo]; ed_r1 = tabs.en.dir[tb + hi + 1];
         }
         // The tile's WINDOW: the transcripts from its smallest cursor value on that some read of the tile can overlap,
         // in file order, up to the first transcript every read of the tile lies before (src/update_gtf.c:799-800 ends
@@ -366,6 +404,12 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
                 d.n_win = n_win;
                 if (n_win) { d.j_lo = first; contig = (uint32_t)(last - first + 1) == n_win; }
             }
+        }
+        if (sliced) {
+            d.b_off = -lo; d.nb = nb; d.b0 = tb + lo; d.nbk = hi - lo + 1;
+            d.st_r0 = sd_r0; d.st_nk = sd_r1 - sd_r0;
+            d.en_r0 = ed_r0; d.en_nk = ed_r1 - ed_r0;
+            if (d.st_nk > (uint32_t)KEY_CAP || d.en_nk > (uint32_t)KEY_CAP) fast = false;
         }
         d.flags = (fast ? TD_FAST : 0u) | (contig ? TD_CONTIG : 0u);
         if (lane == 0) { tile_sum[blockIdx.x] = total; desc[blockIdx.x] = d; }
@@ -900,7 +944,7 @@ __device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, con
     for (int q = 0; q < 2; ++q) {
         const int i = (int)threadIdx.x + q * TILE_THREADS;
         v.dd[0][q] = v.dd[1][q] = v.dd[2][q] = 0u;
-        if (fast && d.nbk > 0 && i <= d.nbk) { v.dd[0][q] = a->st.dir[d.b0 + i]; v.dd[1][q] = a->en.dir[d.b0 + i]; v.dd[2][q] = a->st.rdir[d.b0 + i]; }
+        if (fast && d.nbk > 0 && i <= d.nbk) { const uint32_t b = (uint32_t)(d.b0 + i); v.dd[0][q] = ld32(a->st.dir, b); v.dd[1][q] = ld32(a->en.dir, b); v.dd[2][q] = ld32(a->st.rdir, b); }
     }
     return v;
 }
@@ -956,9 +1000,23 @@ __device__ __forceinline__ VisitMasks visit_window(const TileLds &L, const TileD
     return m;
 }
 
+// index of the lowest set bit, 63 when there is none
+__device__ __forceinline__ uint32_t first_member(uint32_t x)
+{
+    return (uint32_t)__builtin_ctzll((unsigned long long)x | (1ull << 63));
+}
+
+// x != 0 as 0 / 1 in one VALU instruction (the compiler turns min(x, 1) into compare + select + a literal move)
+__device__ __forceinline__ uint32_t nonzero(uint32_t x)
+{
+    uint32_t r;
+    asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // One START and one END probe per exon; the wave runs as many rounds as its longest read has exons.  Per round
 // {next exon, both bucket ranges} are read together, then the first entries of both buckets.  Leaves per exon in W:
-// first member of V' with the exon / the junction (6 bits each, 63: none), "donor / acceptor not in V'" (bits 12, 13).
+// first member of V' with the exon / the junction (6 bits each, 63: none), "donor / acceptor is in V'" (bits 12, 13).
 __device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc &d, bool mapping, uint32_t local, uint32_t n, uint32_t vpre)
 {
     SiteMasks m{0xffffffffu, 0u, 0u, 0u};
@@ -966,31 +1024,34 @@ __device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc 
     uint16_t *W = L.W + local;
     int s = 0, e = 0;
     if (mapping) { s = S[0]; e = E[0]; }
+    const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
     for (int k = 0; __any(mapping && k < (int)n); ++k) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
         const uint32_t inext = junc ? local + (uint32_t)k + 1u : 0u;
-        const int bs = s >> SITE_SHIFT, be = e >> SITE_SHIFT;
-        const bool vs = live && bs < d.nb, ve = junc && be < d.nb;
-        const int is = vs ? bs + d.b_off : 0, ie = ve ? be + d.b_off : 0;
+        // (unsigned: a coordinate below the staged span wraps to a huge index and lands on `none` as well)
+        const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
+        const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
         const int s2 = L.S[inext], e2 = L.E[inext];
-        const uint32_t ls = L.dir0[is], hs0 = L.dir0[is + 1], le = L.dir1[ie], he0 = L.dir1[ie + 1];
-        const uint32_t hs = vs ? hs0 : ls, he = ve ? he0 : le;          // no bucket -> empty range
-        // START buckets mostly hold one exon, END buckets often several junctions of one donor
-        const v4i_t qs0 = lds_entry(L.ent0, min(ls, (uint32_t)KEY_CAP - 1u));
-        const v4i_t qe0 = lds_entry(L.ent1, min(le, (uint32_t)KEY_CAP - 1u)), qe1 = lds_entry(L.ent1, min(le + 1u, (uint32_t)KEY_CAP - 1u));
+        const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
+        // START buckets mostly hold one exon, END buckets often several junctions of one donor.  (An index up to
+        // KEY_CAP + 1 reads on into the arrays behind the slice; such an entry is never inside [ls, hs).)
+        const v4i_t qs0 = lds_entry(L.ent0, ls);
+        const v4i_t qe0 = lds_entry(L.ent1, le), qe1 = lds_entry(L.ent1, le + 1u);
         uint32_t xm, am, jm, dm;
         {   const bool m0 = ls < hs && qs0.x == s;
             am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
         probe2(qe0, qe1, le, he, e, s2, jm, dm);
         if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(L.ent0, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + 2u, he, e, s2, jm, dm, 0u); }
-        uint32_t word = min((uint32_t)__ffs((int)(xm & vpre)) - 1u, 63u);
-        word |= min((uint32_t)__ffs((int)(jm & vpre)) - 1u, 63u) << 6;        // without a junction: jm = dm = 0
-        word |= ((dm & vpre) ? 0u : 1u << 12) | ((((junc ? am : 0u) & vpre)) ? 0u : 1u << 13);
-        if (junc) {
-            m.kand &= am & dm;                        // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
-            m.kor |= am | dm;
-            if (k == 0) m.dm_first = dm;
-        } else if (live) m.am_last = am;              // transcripts in which the last exon's start begins a later exon
+        // without a junction jm = dm = 0 (empty bucket); the acceptor of the last exon is not a probed site (Q1)
+        const uint32_t amj = junc ? am : 0u;
+        uint32_t word = first_member(xm & vpre);
+        word |= first_member(jm & vpre) << 6;
+        word |= nonzero(dm & vpre) << 12;
+        word |= nonzero(amj & vpre) << 13;
+        m.kand &= junc ? (am & dm) : 0xffffffffu;     // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
+        m.kor |= amj | dm;
+        if (k == 0) m.dm_first = dm;
+        m.am_last = (live && !junc) ? am : m.am_last;  // transcripts in which the last exon's start begins a later exon
         if (live) W[k] = (uint16_t)word;
         s = s2; e = e2;
     }
@@ -1046,7 +1107,7 @@ __device__ __forceinline__ Verdict decide(const TileLds &L, const TileDesc &d, u
         if (n > 1) {
             const uint32_t w = W[k];
             f = ((w & 63u) > lim ? F_EXON : 0u) | (((w >> 6) & 63u) > lim ? F_JUNC : 0u);
-            if (!known) f |= ((w >> 12) & 1u ? F_DON : 0u) | ((w >> 13) & 1u ? F_ACC : 0u);
+            if (!known) f |= (~w >> 11) & (uint32_t)(F_DON | F_ACC);          // bits 12, 13: the site is in V' (F_DON = 2, F_ACC = 4)
             if (k + 1 == (int)n) f &= F_EXON;
         }
         W[k] = (uint16_t)f;
@@ -1201,6 +1262,10 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
                         s_rdir[i] = (uint8_t)(v.dd[2][q] - d.st_r0);
                     }
                 }
+            }
+            // two empty buckets behind the staged ones: where probes of coordinates outside the span land (map_exons)
+            if (threadIdx.x < 3u && (threadIdx.x > 0u || d.nbk == 0)) {
+                s_dir0[d.nbk + (int)threadIdx.x] = (uint8_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint8_t)d.en_nk;
             }
         }
         const bool rev_in = v.rev != 0;
