@@ -111,7 +111,7 @@ def main():
     gathered = {}
 
     def exchange():
-        # counts of (records, exons) per rank, then four padded all-gathers of engine-owned HBM (workload.all_gatherv)
+        # counts of (records, exons) per rank, then five padded all-gathers of engine-owned HBM (workload.all_gatherv)
         _, _, m, x = eng.sizes()
         v = eng.device_view()
         cnt = torch.tensor([m, x], dtype=torch.int64, device=device)
@@ -120,7 +120,9 @@ def main():
         allc = [c.tolist() for c in allc]
         if args.exchange == "partitioned":
             return sum(c[0] for c in allc), sum(c[1] for c in allc)
-        parts = (("rec", v.acc_rec, 16, 0), ("ex_start", v.acc_ex_start, 4, 1), ("ex_end", v.acc_ex_end, 4, 1), ("ex_flag", v.acc_ex_flag, 1, 1))
+        # (the exon arrays are chunked per tile, see include/lr2rmats_hip.h: the per-record offsets travel with the records)
+        parts = (("rec", v.acc_rec, 16, 0), ("ex_off", v.acc_ex_off, 4, 0), ("ex_start", v.acc_ex_start, 4, 1), ("ex_end", v.acc_ex_end, 4, 1),
+                 ("ex_flag", v.acc_ex_flag, 1, 1))
         for name, ptr, width, which in parts:
             mine = workload.device_bytes(ptr, (m if which == 0 else x) * width, device)
             outs, _ = workload.all_gatherv(mine, counts=[c[which] * width for c in allc])

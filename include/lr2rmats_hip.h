@@ -138,6 +138,11 @@ typedef struct {
     const uint8_t *ex_flag;
     const uint32_t *info;
     const int32_t *ref_tx;
+    /* Accepted list in HBM.  acc_rec / acc_ex_off: one entry per accepted read, in read order; record i has
+     * info >> 8 exons starting at acc_ex_off[i] in the three exon arrays.  The exon arrays hold n_accepted_exons
+     * entries and no gaps, but they are a sequence of per-tile chunks in the order the kernels handed the chunks
+     * out, so acc_ex_off is NOT increasing: always address through it (l2r_download_accepted() lays the exons out
+     * record by record for the caller). */
     const l2r_accepted_read *acc_rec;
     const uint32_t *acc_ex_off;     /* device, n_accepted */
     const int32_t *acc_ex_start, *acc_ex_end;
@@ -149,7 +154,8 @@ typedef struct {
 typedef struct {
     float stage_ms[L2R_N_STAGES];   /* 0 pass_a (exon counts, cursors, tile descriptors) 1 scan 2 classify_fast
                                        3 classify_generic (redo list) 4 validate_junctions (+ recount)
-                                       5 scan of accepted counts 6 gather_accepted 7 reserved */
+                                       5 scan of accepted counts 6 gather_accepted (records; exons of the tiles
+                                       classify_fast did not compact itself) 7 reserved */
     float total_ms;                 /* first launch -> last completion, per iteration */
     int32_t iters;
 } l2r_timing;

@@ -86,7 +86,7 @@ struct l2r_ctx {
     bool have_win = false;
     // work + results
     int64_t n_tiles = 0, n_tiles256 = 0;
-    DevBuf<uint32_t> local, tile_base, ex_off, info, tile_acc, tile_acc_ex, totals;  // totals[0]=exons [1]=accepted [2]=accepted exons [3]=redo count
+    DevBuf<uint32_t> local, tile_base, ex_off, info, tile_acc, tile_acc_ex, tile_chunk, totals;  // totals[0]=exons [1]=accepted [2]=accepted exons [3]=redo count [4]=accepted-exon chunk cursor
     DevBuf<uint32_t> redo;                  // reads the fast kernel hands to the generic one
     DevBuf<uint8_t> order;                  // per tile: reads by falling exon count (pass A)
     DevBuf<TileDesc> desc;
@@ -172,7 +172,7 @@ void l2r_destroy(l2r_ctx *c)
     c->sj_tid.release(); c->sj_don.release(); c->sj_acc.release(); c->sj_uniq.release(); c->sj_multi.release(); c->sj_key.release();
     c->r_tid.release(); c->r_pos.release(); c->r_rev.release(); c->cig_off.release(); c->cig.release();
     c->win_start.release(); c->sj_cursor.release();
-    c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->totals.release();
+    c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -508,7 +508,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     if (c->j0.ensure((size_t)N) || c->local.ensure((size_t)N + 1) || c->ex_off.ensure((size_t)N) || c->info.ensure((size_t)N) || c->ref_tx.ensure((size_t)N) ||
         c->redo.ensure((size_t)N) || c->order.ensure((size_t)c->n_tiles * TILE_THREADS) || c->desc.ensure((size_t)c->n_tiles) || c->win_hdr.ensure((size_t)c->n_tiles * WIN_TX) ||
         c->tile_base.ensure((size_t)c->n_tiles + 1) || c->tile_acc.ensure((size_t)c->n_tiles + 1) || c->tile_acc_ex.ensure((size_t)c->n_tiles + 1) ||
-        c->totals.ensure(4) || c->ex_start.ensure(exb) || c->ex_end.ensure(exb) || c->ex_flag.ensure(exb) ||
+        c->totals.ensure(8) || c->tile_chunk.ensure((size_t)c->n_tiles + 1) || c->ex_start.ensure(exb) || c->ex_end.ensure(exb) || c->ex_flag.ensure(exb) ||
         c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
         c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb)) return -2;
     c->ex_cap = (int64_t)exb;
@@ -603,6 +603,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         fa.hdr = c->hdr.p; fa.st = tabs.st; fa.en = tabs.en;
         fa.ex_off = c->ex_off.p; fa.ex_start = c->ex_start.p; fa.ex_end = c->ex_end.p; fa.ex_flag = c->ex_flag.p; fa.info = c->info.p; fa.ref_tx = c->ref_tx.p;
         fa.tile_acc = c->tile_acc.p; fa.tile_acc_ex = c->tile_acc_ex.p; fa.redo_count = c->totals.p + 3; fa.redo = c->redo.p;
+        fa.tile_chunk = c->tile_chunk.p; fa.chunk_cursor = c->totals.p + 4; fa.acc_start = c->acc_start.p; fa.acc_end = c->acc_end.p; fa.acc_flag = c->acc_flag.p;
         fa.stamps = c->stamps.p; fa.p = p;
         // persistent grid: a few workgroups per CU walk over the tiles (l2r_kernels.hip.h)
         unsigned gp = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * c->wg_per_cu);
@@ -639,7 +640,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     }
     MARK(ST_GATHER);
     hipLaunchKernelGGL(k_gather_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->reads_per_tile, c->first_read, c->info.p, c->ref_tx.p, c->ex_off.p,
-                       c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->tile_acc.p, c->tile_acc_ex.p,
+                       c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->tile_acc.p, c->tile_acc_ex.p, c->tile_chunk.p, c->totals.p + 4,
                        c->acc_rec.p, c->acc_ex_off.p, c->acc_start.p, c->acc_end.p, c->acc_flag.p);
     MARK(ST_N);
 #undef MARK
@@ -713,8 +714,11 @@ static int fetch_totals(l2r_ctx *c)
 {
     if (!c->ran) return fail(-1, "no completed run on this context");
     if (c->totals_valid) return 0;
-    HIP_TRY(hipMemcpyAsync(c->h_totals, c->totals.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    uint32_t dev[5];
+    HIP_TRY(hipMemcpyAsync(dev, c->totals.p, sizeof dev, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    // accepted exons = the chunks the classification kernel placed itself (cursor) + the ones k_gather_accepted placed
+    c->h_totals[0] = dev[0]; c->h_totals[1] = dev[1]; c->h_totals[2] = dev[2] + dev[4];
     c->totals_valid = true;
     return 0;
 }
@@ -796,19 +800,32 @@ int l2r_download_accepted(l2r_ctx *c, l2r_accepted *a)
     if (rc) return rc;
     const int64_t M = c->h_totals[1], X = c->h_totals[2];
     if (a->n_reads < M || a->ex_cap < X) return fail(-3, "[l2r_download_accepted] buffers too small: need %lld records, %lld exons", (long long)M, (long long)X);
+    // On the device the exon arrays are a sequence of per-tile chunks in arbitrary order (see k_gather_accepted); the
+    // caller's buffers receive them record by record, so that ex_off is the usual running sum.
     std::vector<uint32_t> off((size_t)M);
+    std::vector<int32_t> xs((size_t)X), xe((size_t)X);
+    std::vector<uint8_t> xf((size_t)X);
     if (M) {
         HIP_TRY(hipMemcpyAsync(a->rec, c->acc_rec.p, (size_t)M * sizeof(AccRec), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(off.data(), c->acc_ex_off.p, (size_t)M * 4, hipMemcpyDeviceToHost, c->stream));
     }
     if (X) {
-        HIP_TRY(hipMemcpyAsync(a->ex_start, c->acc_start.p, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(a->ex_end, c->acc_end.p, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(a->ex_flag, c->acc_flag.p, (size_t)X, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(xs.data(), c->acc_start.p, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(xe.data(), c->acc_end.p, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(xf.data(), c->acc_flag.p, (size_t)X, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int64_t i = 0; i < M; ++i) a->ex_off[i] = off[(size_t)i];
-    a->ex_off[M] = X;
+    int64_t at = 0;
+    for (int64_t i = 0; i < M; ++i) {
+        const int64_t n = (int64_t)(a->rec[i].info >> 8), from = off[(size_t)i];
+        if (from + n > X || at + n > X) return fail(-5, "[l2r_download_accepted] inconsistent accepted list");
+        a->ex_off[i] = at;
+        memcpy(a->ex_start + at, xs.data() + from, (size_t)n * 4);
+        memcpy(a->ex_end + at, xe.data() + from, (size_t)n * 4);
+        memcpy(a->ex_flag + at, xf.data() + from, (size_t)n);
+        at += n;
+    }
+    a->ex_off[M] = at;
     a->n_reads = M; a->n_exons = X;
     return 0;
 }

@@ -87,6 +87,7 @@ struct TileDesc {
     uint32_t en_r0, en_nk;     // END entries
     uint32_t flags, n_win;     // n_win: transcripts in the tile's window (win_hdr[tile * WIN_TX + 0 .. n_win))
 };
+constexpr uint32_t CHUNK_DEFERRED = 0xffffffffu;   // tile_chunk: the tile's accepted exons are compacted by k_gather_accepted
 constexpr uint32_t TD_FAST = 1;    // exons fit the LDS tile, dictionary slices fit DIR_CAP / KEY_CAP, window fits WIN_TX
 constexpr uint32_t TD_CONTIG = 2;  // the window's transcripts are consecutive in the annotation: j_lo, j_lo + 1, ...
 constexpr int WIN_SCAN_TRIPS = 64; // pass A looks at up to 64 * WIN_SCAN_TRIPS transcripts for a tile's window
@@ -111,37 +112,32 @@ __device__ __forceinline__ int64_t pack_key(int32_t tid, int32_t x)
 
 // ------------------------------------------------------------------ wave / block primitives
 
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
-{
-    const int lane = threadIdx.x & (WAVE - 1);
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, WAVE);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
+// Wave-wide scans and reductions on the DPP data path (no LDS round trips): shifts inside the 16-lane rows, then the
+// last lane of a row is added to the following row(s).  All 64 lanes must be active.
+struct OpAdd { static constexpr int identity = 0; static __device__ __forceinline__ int apply(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); } };
+struct OpMin { static constexpr int identity = INT32_MAX; static __device__ __forceinline__ int apply(int a, int b) { return min(a, b); } };
+struct OpMax { static constexpr int identity = INT32_MIN; static __device__ __forceinline__ int apply(int a, int b) { return max(a, b); } };
 
-__device__ __forceinline__ int wave_min(int v)
+template <typename Op, int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_step(int v)
 {
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, WAVE));
+    return Op::apply(v, __builtin_amdgcn_update_dpp(Op::identity, v, CTRL, ROW_MASK, 0xf, false));
+}
+template <typename Op>
+__device__ __forceinline__ int wave_scan(int v)                 // inclusive
+{
+    v = dpp_step<Op, 0x111, 0xf>(v);        // row_shr:1
+    v = dpp_step<Op, 0x112, 0xf>(v);        // row_shr:2
+    v = dpp_step<Op, 0x114, 0xf>(v);        // row_shr:4
+    v = dpp_step<Op, 0x118, 0xf>(v);        // row_shr:8
+    v = dpp_step<Op, 0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3
+    v = dpp_step<Op, 0x143, 0xc>(v);        // row_bcast:31 into rows 2 and 3
     return v;
 }
-
-__device__ __forceinline__ int wave_max(int v)
-{
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, WAVE));
-    return v;
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) { return (uint32_t)wave_scan<OpAdd>((int)v); }
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane(wave_scan<OpAdd>((int)v), WAVE - 1); }
+__device__ __forceinline__ int wave_min(int v) { return __builtin_amdgcn_readlane(wave_scan<OpMin>(v), WAVE - 1); }
+__device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_scan<OpMax>(v), WAVE - 1); }
 
 // Exclusive scan over the 256 threads of a workgroup; returns the exclusive prefix, `total` = workgroup sum.
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave /*[4]*/, uint32_t &total)
@@ -286,7 +282,7 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
     if (threadIdx.x < WAVE) s_hist[threadIdx.x] = 0u;
     const int64_t r = (int64_t)blockIdx.x * p.reads_per_tile + threadIdx.x;
     const bool active = (int)threadIdx.x < p.reads_per_tile && r < n_reads;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *redo_count = 0u;         // the classification kernels run after this one
+    if (blockIdx.x == 0 && threadIdx.x == 0) { redo_count[0] = 0u; redo_count[1] = 0u; }   // redo list and accepted-exon cursor: the kernels that fill them run after this one
     uint32_t n = 0;
     int j0 = INT32_MAX, tid = 0, pos = 0, el = 0;
     if (active) {
@@ -764,6 +760,8 @@ struct FastArgs {
     const TxHdr *hdr; SiteDict st, en;
     uint32_t *ex_off; int32_t *ex_start; int32_t *ex_end; uint8_t *ex_flag; uint32_t *info; int32_t *ref_tx;
     uint32_t *tile_acc, *tile_acc_ex; uint32_t *redo_count, *redo;
+    uint32_t *tile_chunk, *chunk_cursor;          // accepted exons: first slot per tile / next free slot
+    int32_t *acc_start, *acc_end; uint8_t *acc_flag;
     unsigned long long *stamps;
     DevParams p;
 };
@@ -906,21 +904,29 @@ __device__ __forceinline__ bool cigar_staged(const TileUniforms &u, int region_w
 __device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, const TileUniforms &u, int region_words)
 {
     TileVectors v;
+    // every pointer this needs, fetched from the argument block in one go (left to the compiler, each one is loaded
+    // inside the branch that uses it and waited for there: a chain of scalar-cache round trips per tile)
+    const uint32_t *const p_local = a->local; const int64_t *const p_cig_off = a->cig_off; const uint32_t *const p_cig = a->cig;
+    const int32_t *const p_pos = a->r_pos, *const p_tid = a->r_tid, *const p_j0 = a->j0; const uint8_t *const p_rev = a->r_rev;
+    const TxHdr *const p_win = a->win_hdr; const SiteEnt *const p_st = a->st.ent, *const p_en = a->en.ent;
+    const uint32_t *const p_sd = a->st.dir, *const p_ed = a->en.dir, *const p_sr = a->st.rdir;
     const int rpt = a->p.reads_per_tile;
     const uint32_t n_reads = (uint32_t)a->n_reads;
+    asm volatile("" :: "s"(p_local), "s"(p_cig_off), "s"(p_cig), "s"(p_pos), "s"(p_tid), "s"(p_j0), "s"(p_rev), "s"(p_win),
+                 "s"(p_st), "s"(p_en), "s"(p_sd), "s"(p_ed), "s"(p_sr), "s"(rpt), "s"(n_reads));
     const uint32_t r = t * (uint32_t)rpt + (uint32_t)u.src;
     const bool active = u.src >= 0;
     v.local = 0; v.nxt = 0; v.c_lo = 0; v.c_hi = 0; v.pos = 0; v.j0 = 0; v.tid = 0; v.rev = 0;
     if (active) {
-        v.local = ld32(a->local, r);
+        v.local = ld32(p_local, r);
         const bool last = u.src + 1 == rpt || r + 1u == n_reads;
-        v.nxt = last ? u.total : ld32(a->local, r + 1u);
-        v.c_lo = (uint32_t)ld32(a->cig_off, r); v.c_hi = (uint32_t)ld32(a->cig_off, r + 1u);
-        v.pos = ld32(a->r_pos, r); v.tid = ld32(a->r_tid, r); v.j0 = ld32(a->j0, r); v.rev = ld32(a->r_rev, r);
+        v.nxt = last ? u.total : ld32(p_local, r + 1u);
+        v.c_lo = (uint32_t)ld32(p_cig_off, r); v.c_hi = (uint32_t)ld32(p_cig_off, r + 1u);
+        v.pos = ld32(p_pos, r); v.tid = ld32(p_tid, r); v.j0 = ld32(p_j0, r); v.rev = ld32(p_rev, r);
     }
     const bool staged = cigar_staged(u, region_words);
     const int n4 = cigar_vectors(u);
-    const uint4 *src = reinterpret_cast<const uint4 *>(a->cig + (u.c0 & ~3u));
+    const uint4 *src = reinterpret_cast<const uint4 *>(p_cig + (u.c0 & ~3u));
 #pragma unroll
     for (int q = 0; q < PF_CIG_VEC; ++q) {
         const int i = q * TILE_THREADS + (int)threadIdx.x;
@@ -933,18 +939,18 @@ __device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, con
     v.xa = v.xb = v.xc = v.xd = make_int4(0, 0, 0, 0);
     if ((int)threadIdx.x >= KEY_CAP) {
         if ((int)threadIdx.x - KEY_CAP < w_n) {
-            const int4 *hp = reinterpret_cast<const int4 *>(a->win_hdr + (t * (uint32_t)WIN_TX + (threadIdx.x - (uint32_t)KEY_CAP)));
+            const int4 *hp = reinterpret_cast<const int4 *>(p_win + (t * (uint32_t)WIN_TX + (threadIdx.x - (uint32_t)KEY_CAP)));
             v.xa = hp[0]; v.xb = hp[1]; v.xc = hp[2];
         }
     } else {
-        if (fast && threadIdx.x < d.st_nk) { const int4 *q = reinterpret_cast<const int4 *>(a->st.ent + d.st_r0 + threadIdx.x); v.xa = q[0]; v.xb = q[1]; }
-        if (fast && threadIdx.x < d.en_nk) { const int4 *q = reinterpret_cast<const int4 *>(a->en.ent + d.en_r0 + threadIdx.x); v.xc = q[0]; v.xd = q[1]; }
+        if (fast && threadIdx.x < d.st_nk) { const int4 *q = reinterpret_cast<const int4 *>(p_st + d.st_r0 + threadIdx.x); v.xa = q[0]; v.xb = q[1]; }
+        if (fast && threadIdx.x < d.en_nk) { const int4 *q = reinterpret_cast<const int4 *>(p_en + d.en_r0 + threadIdx.x); v.xc = q[0]; v.xd = q[1]; }
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int i = (int)threadIdx.x + q * TILE_THREADS;
         v.dd[0][q] = v.dd[1][q] = v.dd[2][q] = 0u;
-        if (fast && d.nbk > 0 && i <= d.nbk) { const uint32_t b = (uint32_t)(d.b0 + i); v.dd[0][q] = ld32(a->st.dir, b); v.dd[1][q] = ld32(a->en.dir, b); v.dd[2][q] = ld32(a->st.rdir, b); }
+        if (fast && d.nbk > 0 && i <= d.nbk) { const uint32_t b = (uint32_t)(d.b0 + i); v.dd[0][q] = ld32(p_sd, b); v.dd[1][q] = ld32(p_ed, b); v.dd[2][q] = ld32(p_sr, b); }
     }
     return v;
 }
@@ -1143,7 +1149,10 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
     __shared__ __attribute__((aligned(16))) int4 s_hk[WIN_TX];     // {start, end, n, flags | rev << 8} on the tile's chromosome
     __shared__ __attribute__((aligned(16))) int4 s_hx[WIN_TX];     // {s0, e0, sl, el}
     __shared__ int s_win[WIN_TX];                                   // window member -> annotation index
-    __shared__ uint32_t s_cnt[4][2];
+    __shared__ uint32_t s_cnt[4][3];
+    __shared__ int s_wide;                                          // some staged entry has members beyond its 64-bit masks
+    __shared__ uint16_t s_nat[TILE_THREADS];                        // per read of the tile in READ order: exon count, bit 15 = accepted
+    __shared__ uint32_t s_chunk;
 
     (void)kernarg_block;
     const bool stamping = fast_args()->stamps != nullptr;
@@ -1189,6 +1198,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
 #pragma unroll
             for (int q = 0; q < PF_CIG_VEC; ++q) { const int i = q * TILE_THREADS + (int)threadIdx.x; if (i < n4) dst[i] = v.cg[q]; }
         }
+        if (threadIdx.x == 0) s_wide = 0;
         __syncthreads();
         L2R_STAMP(0);
 
@@ -1219,6 +1229,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
             }
         }
         __syncthreads();                 // every walk is done: the CIGAR region is free
+        L2R_STAMP(7);
         // ---- stage the dictionary slices and the transcript window, re-based to the tile
         int my_wide = 0;
         if (fast) {
@@ -1269,7 +1280,9 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
             }
         }
         const bool rev_in = v.rev != 0;
-        const int any_wide = __syncthreads_or(my_wide);
+        if (my_wide) s_wide = 1;
+        __syncthreads();
+        const int any_wide = s_wide;             // (cleared at the top of the next tile, two barriers from here)
         // ---- the next tile's vectors start their trip now; they are not needed before the top of the next round
         if (has_next) v = load_vectors(fast_args(), t_next, u_next, cigar_room(u_next));
         L2R_STAMP(1);
@@ -1309,13 +1322,40 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
             }
             const bool acc = (info & I_ACCEPT) != 0;
             const uint32_t ca = (uint32_t)__popcll(__ballot(acc)), cx = wave_sum(acc ? n : 0u);
-            if (lane == 0) { s_cnt[wv][0] = ca; s_cnt[wv][1] = cx; }
+            if (lane == 0) { s_cnt[wv][0] = ca; s_cnt[wv][1] = cx; s_cnt[wv][2] = (uint32_t)__popcll(m); }
+            if (active) s_nat[u.src] = (uint16_t)(min(n, 0x7fffu) | (acc ? 0x8000u : 0u));
         }
         __syncthreads();
         L2R_STAMP(5);
+        // ---- accepted exons of the tile, compacted in read order into a chunk of the accepted arrays (chunks are handed
+        // out by an atomic cursor: their order is arbitrary, tile_chunk says where a tile's chunk starts).  Only when
+        // every verdict of the tile is final here: no read on the redo list, no junction table (k_validate_sj decides).
+        const uint32_t ca_t = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0], cx_t = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+        const bool fused = in_lds && (s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2]) == 0u && ao->p.n_sj == 0 && !(ao->p.ablate & 2);
+        uint32_t chunk = 0u;
         if (threadIdx.x == 0) {
-            ao->tile_acc[t] = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
-            ao->tile_acc_ex[t] = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+            ao->tile_acc[t] = ca_t;
+            ao->tile_acc_ex[t] = fused ? 0u : cx_t;       // exons that k_gather_accepted has to place
+            if (!fused) ao->tile_chunk[t] = CHUNK_DEFERRED;
+            else if (cx_t) chunk = (ao->p.ablate & 4) ? base : atomicAdd(ao->chunk_cursor, cx_t);          // (answer needed after the write-out below)
+        }
+        uint16_t *const s_map = reinterpret_cast<uint16_t *>(s_ent0);           // the dictionary slices are dead by now
+        if (fused && cx_t) {
+            // thread i takes read i of the tile (reads are spread over the threads in pass A's order): exclusive sums
+            // of {all exons, accepted exons} over the reads before it, both below 2^16, packed in one word
+            const uint32_t rpt_u = (uint32_t)ao->p.reads_per_tile, n_act = min(rpt_u, (uint32_t)ao->n_reads - t * rpt_u);
+            const uint32_t w16 = threadIdx.x < n_act ? (uint32_t)s_nat[threadIdx.x] : 0u;
+            const uint32_t nn = w16 & 0x7fffu, pk = nn | ((w16 >> 15) ? nn << 16 : 0u);
+            uint32_t before = wave_inclusive_scan(pk) - pk;
+            for (int k = 0; k < wv; ++k) {
+                const uint32_t idx = (uint32_t)(k * WAVE + lane);
+                const uint32_t z = idx < n_act ? (uint32_t)s_nat[idx] : 0u, zn = z & 0x7fffu;
+                before += wave_sum(zn | ((z >> 15) ? zn << 16 : 0u));
+            }
+            if (w16 >> 15) {
+                const uint32_t from = before & 0xffffu, to = before >> 16;
+                for (uint32_t k = 0; k < nn; ++k) s_map[to + k] = (uint16_t)(from + k);
+            }
         }
         if (in_lds) {
             for (uint32_t i = threadIdx.x; i < tile_total; i += TILE_THREADS) {
@@ -1328,6 +1368,22 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
             ao->ex_off[r] = base + local;
             ao->info[r] = info;
             ao->ref_tx[r] = ref;
+        }
+        if (fused) {
+            if (threadIdx.x == 0) { s_chunk = chunk; ao->tile_chunk[t] = chunk; }
+            if (cx_t) {
+                __syncthreads();
+                const uint32_t to = s_chunk;
+                uint32_t q = threadIdx.x < cx_t ? (uint32_t)s_map[threadIdx.x] : 0u;
+                for (uint32_t i = threadIdx.x; i < cx_t; i += TILE_THREADS) {
+                    const uint32_t i_next = i + TILE_THREADS;                    // its map entry travels while this one is copied
+                    const uint32_t q_next = i_next < cx_t ? (uint32_t)s_map[i_next] : 0u;
+                    ao->acc_start[to + i] = s_S[q];
+                    ao->acc_end[to + i] = s_E[q];
+                    ao->acc_flag[to + i] = (uint8_t)s_W[q];
+                    q = q_next;
+                }
+            }
         }
         __syncthreads();                 // the tile's LDS image has been written out: the next tile may overwrite it
         L2R_STAMP(6);
@@ -1441,8 +1497,12 @@ void k_count_accepted(int64_t n_reads, int reads_per_tile, const uint32_t *__res
 
 struct AccRec { uint32_t read_lo, read_hi, info; int32_t ref_tx; };
 
-// Dense accepted records in read order.  tile_reads / tile_exons hold the exclusive scans (n_tiles + 1 words).
-// Every accepted read writes, for each of its exons, the source position into an LDS map at the exon's compacted
+// Accepted records in read order (tile_reads = exclusive scan of the per-tile counts, n_tiles + 1 words), each with the
+// offset of its exons in the accepted exon arrays.  Those arrays are made of one chunk per tile, the reads of a chunk in
+// read order, the chunks in the order an atomic cursor handed them out.  Most chunks were filled by k_classify_fast
+// from its LDS image (tile_chunk[tile] = first slot); a tile marked CHUNK_DEFERRED gets its chunk here (tile_exons =
+// exclusive scan of the deferred tiles' accepted exon counts; the chunks follow the cursor's final value):
+// every accepted read writes, for each of its exons, the source position into an LDS map at the exon's compacted
 // slot; the tile then copies slot by slot, so the stores are contiguous and the loads run over contiguous pieces.
 constexpr uint32_t MAP_DIRECT = 0xffffu;      // map entry of an exon that its read has copied itself
 
@@ -1450,6 +1510,7 @@ __global__ __launch_bounds__(TILE_THREADS)
 void k_gather_accepted(int64_t n_reads, int reads_per_tile, int64_t first_read, const uint32_t *__restrict__ info, const int32_t *__restrict__ ref_tx,
                        const uint32_t *__restrict__ ex_off, const int32_t *__restrict__ ex_start, const int32_t *__restrict__ ex_end,
                        const uint8_t *__restrict__ ex_flag, const uint32_t *__restrict__ tile_reads, const uint32_t *__restrict__ tile_exons,
+                       uint32_t *__restrict__ tile_chunk, const uint32_t *__restrict__ chunk_cursor,
                        AccRec *__restrict__ rec, uint32_t *__restrict__ acc_ex_off, int32_t *__restrict__ acc_start,
                        int32_t *__restrict__ acc_end, uint8_t *__restrict__ acc_flag)
 {
@@ -1466,8 +1527,14 @@ void k_gather_accepted(int64_t n_reads, int reads_per_tile, int64_t first_read, 
     const uint32_t inc = wave_inclusive_scan(nex);
     if (lane == WAVE - 1) { s_wcnt[wv] = (uint32_t)__popcll(m); s_wex[wv] = inc; }
     __syncthreads();
-    const uint32_t cbase0 = tile_reads[blockIdx.x], ebase0 = tile_exons[blockIdx.x];
-    const uint32_t e_tot = tile_exons[blockIdx.x + 1] - ebase0;              // accepted exons of the tile
+    const uint32_t cbase0 = tile_reads[blockIdx.x];
+    const uint32_t e_tot = s_wex[0] + s_wex[1] + s_wex[2] + s_wex[3];        // accepted exons of the tile
+    uint32_t ebase0 = tile_chunk[blockIdx.x];
+    const bool deferred = ebase0 == CHUNK_DEFERRED;
+    if (deferred) {          // behind every chunk of the classification kernel, in tile order among the deferred ones
+        ebase0 = *chunk_cursor + tile_exons[blockIdx.x];
+        if (threadIdx.x == 0) tile_chunk[blockIdx.x] = ebase0;
+    }
     uint32_t cb = 0, eb = 0;
     for (int k = 0; k < wv; ++k) { cb += s_wcnt[k]; eb += s_wex[k]; }
     const uint32_t src0 = ex_off[(int64_t)blockIdx.x * reads_per_tile];      // first exon of the tile
@@ -1480,18 +1547,20 @@ void k_gather_accepted(int64_t n_reads, int reads_per_tile, int64_t first_read, 
         AccRec a; a.read_lo = (uint32_t)gidx; a.read_hi = (uint32_t)(gidx >> 32); a.info = w; a.ref_tx = ref_tx[r];
         rec[slot] = a;
         acc_ex_off[slot] = ebase0 + e_loc;
-        if (mapped && src - src0 + nex < MAP_DIRECT) {
-            for (uint32_t k = 0; k < nex; ++k) s_map[e_loc + k] = (uint16_t)(src - src0 + k);
-        } else {
-            for (uint32_t k = 0; k < nex; ++k) {
-                if (mapped) s_map[e_loc + k] = (uint16_t)MAP_DIRECT;
-                acc_start[ebase0 + e_loc + k] = ex_start[src + k];
-                acc_end[ebase0 + e_loc + k] = ex_end[src + k];
-                acc_flag[ebase0 + e_loc + k] = ex_flag[src + k];
+        if (deferred) {
+            if (mapped && src - src0 + nex < MAP_DIRECT) {
+                for (uint32_t k = 0; k < nex; ++k) s_map[e_loc + k] = (uint16_t)(src - src0 + k);
+            } else {
+                for (uint32_t k = 0; k < nex; ++k) {
+                    if (mapped) s_map[e_loc + k] = (uint16_t)MAP_DIRECT;
+                    acc_start[ebase0 + e_loc + k] = ex_start[src + k];
+                    acc_end[ebase0 + e_loc + k] = ex_end[src + k];
+                    acc_flag[ebase0 + e_loc + k] = ex_flag[src + k];
+                }
             }
         }
     }
-    if (!mapped) return;
+    if (!deferred || !mapped) return;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < e_tot; i += TILE_THREADS) {
         const uint32_t q = s_map[i];

@@ -54,6 +54,17 @@ def _run(oracle, af, reads, counters=None, **kw):
     try:
         eng.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
         got = eng.classify(reads, capi.default_params(**kw))
+        # the accepted list (chunks placed by the classification kernel and by k_gather_accepted, mixed) == the
+        # accepted reads of the full result, in read order
+        acc = eng.download_accepted()
+        idx = np.nonzero((got.info & 128) != 0)[0]
+        lens = (got.info[idx] >> 8).astype(np.int64)
+        g = synth._ragged_gather_index(got.ex_off[idx], lens)
+        np.testing.assert_array_equal(acc.read_index, idx)
+        np.testing.assert_array_equal(np.diff(acc.ex_off), lens)
+        np.testing.assert_array_equal(acc.ex_start, got.ex_start[g])
+        np.testing.assert_array_equal(acc.ex_end, got.ex_end[g])
+        np.testing.assert_array_equal(acc.ex_flag, got.ex_flag[g])
         if counters is not None:            # [reads the generic kernel took, wide entries, compact transcripts, tiles]
             import ctypes as C
             lib = capi.load_library()

@@ -135,15 +135,11 @@ def test_single_exon_fraction_float_compare(engine, oracle):
         _check(engine, oracle, af, reads, oracle.default_params(full_level=5, single_exon_ovlp_frac=f))
 
 
-def test_accepted_compaction_in_read_order(engine, oracle):
-    anno, af, reads = util.make_case(20, n_reads=25000, n_exons=5, anno_exons=15000)
-    _set_anno(engine, af)
-    op = oracle.default_params(full_level=3)
-    engine.set_junctions(None)
-    got = engine.classify(reads, util.to_engine_params(capi, op), first_read_index=1 << 33)
+def _check_accepted_list(engine, got, first):
+    """The accepted list of the last launch == the accepted reads of its full result, in read order."""
     acc = engine.download_accepted()
     idx = np.nonzero((got.info & 128) != 0)[0]
-    np.testing.assert_array_equal(acc.read_index, idx + (1 << 33))
+    np.testing.assert_array_equal(acc.read_index, idx + first)
     np.testing.assert_array_equal(acc.rec["info"], got.info[idx])
     np.testing.assert_array_equal(acc.rec["ref_tx"], got.ref_tx[idx])
     lens = (got.info[idx] >> 8).astype(np.int64)
@@ -153,6 +149,31 @@ def test_accepted_compaction_in_read_order(engine, oracle):
     np.testing.assert_array_equal(acc.ex_start, got.ex_start[g])
     np.testing.assert_array_equal(acc.ex_end, got.ex_end[g])
     np.testing.assert_array_equal(acc.ex_flag, got.ex_flag[g])
+    return acc
+
+
+def test_accepted_compaction_in_read_order(engine, oracle, monkeypatch):
+    anno, af, reads = util.make_case(20, n_reads=25000, n_exons=5, anno_exons=15000)
+    _set_anno(engine, af)
+    op = oracle.default_params(full_level=3)
+    engine.set_junctions(None)
+    got = engine.classify(reads, util.to_engine_params(capi, op), first_read_index=1 << 33)
+    acc = _check_accepted_list(engine, got, 1 << 33)
+    assert acc.rec.shape[0] > 1000
+    # the same list when k_gather_accepted places every tile's exons (what a junction table or redo reads lead to)
+    monkeypatch.setenv("L2R_ABLATE", "2")
+    got2 = engine.classify(reads, util.to_engine_params(capi, op), first_read_index=1 << 33)
+    np.testing.assert_array_equal(got2.info, got.info)
+    _check_accepted_list(engine, got2, 1 << 33)
+    monkeypatch.delenv("L2R_ABLATE")
+    # ... and with a junction table (acceptance decided by k_validate_sj)
+    base = util.oracle_run(oracle, af, reads, op)
+    _, sj = util.junction_table(af, reads, base, 20, cover=0.7)
+    engine.set_junctions(sj)
+    got3 = engine.classify(reads, util.to_engine_params(capi, oracle.default_params(full_level=3, min_sj_cnt=1)), first_read_index=5)
+    assert 0 < int(((got3.info & 128) != 0).sum()) < int(((got.info & 128) != 0).sum())
+    _check_accepted_list(engine, got3, 5)
+    engine.set_junctions(None)
 
 
 def test_full_size_properties(engine, oracle):
@@ -187,6 +208,7 @@ def test_config3_full_size(engine, oracle):
     for name in ("ex_off", "ex_start", "ex_end", "ex_flag", "info", "ref_tx"):
         np.testing.assert_array_equal(getattr(got, name), getattr(again, name))
     assert got.ex_start.size == int(got.ex_off[-1]) == int((got.info >> 8).sum())
+    _check_accepted_list(engine, got, 0)
     lo, hi = 4_500_000 - 4_500_000 % 256 + 128, 5_500_000            # not aligned to the tiles of the whole run
     part = reads.slice(lo, hi)
     sub = engine.classify(part, prm, first_read_index=lo)
