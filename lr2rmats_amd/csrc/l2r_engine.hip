@@ -672,6 +672,13 @@ int l2r_debug_counters(l2r_ctx *c, long long *out, int n)
     uint32_t redo = 0;
     if (c->totals.p) { HIP_TRY(hipMemcpyAsync(&redo, c->totals.p + 3, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     out[0] = redo; out[1] = c->n_wide; out[2] = c->n_compact; out[3] = c->n_tiles;
+    if (n >= 12 && c->desc.p && c->n_tiles > 0) {          // out[4 + k]: tiles that are not fast for reason k (k_pass_a), k = 0: fast
+        std::vector<TileDesc> d((size_t)c->n_tiles);
+        HIP_TRY(hipMemcpyAsync(d.data(), c->desc.p, d.size() * sizeof(TileDesc), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < 8; ++k) out[4 + k] = 0;
+        for (const TileDesc &t : d) out[4 + ((t.flags >> 8) & 7u)]++;
+    }
     return 0;
 }
 

@@ -307,11 +307,7 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
         __syncthreads();
         if (threadIdx.x < WAVE) { const uint32_t c = s_hist[threadIdx.x]; s_hist[threadIdx.x] = wave_inclusive_scan(c) - c; }
         __syncthreads();
-        // A workgroup's wave w runs on SIMD w of its CU: rotating the slots by one wave per tile spreads the long-read
-        // waves over the four SIMDs (full 256-read tiles only; a partial tile keeps its active reads in the first slots)
-        uint32_t slot = s_hist[bin] + rank;
-        if (p.reads_per_tile == TILE_THREADS && (int64_t)(blockIdx.x + 1) * TILE_THREADS <= n_reads)
-            slot = (slot + (uint32_t)WAVE * ((blockIdx.x + (blockIdx.x >> 10)) & 3u)) & (uint32_t)(TILE_THREADS - 1);    // (a persistent workgroup sees tiles b, b + 1024, ...)
+        const uint32_t slot = s_hist[bin] + rank;
         if (active) order_out[(int64_t)blockIdx.x * p.reads_per_tile + slot] = (uint8_t)threadIdx.x;
     }
     // the tile's chromosome is the one of its first read; reads on another one go to the generic kernel
@@ -344,11 +340,12 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
         d.j_lo = jl == INT32_MAX ? 0 : jl; d.tid = tid0; d.b_off = 0; d.nb = 0; d.b0 = 0; d.nbk = 0;
         d.st_r0 = d.st_nk = d.en_r0 = d.en_nk = 0u; d.n_win = 0u;
         bool fast = total <= (uint32_t)LDS_EXON_CAP && p.ss_dis == 0 && !(p.ablate & 1);
+        uint32_t why = fast ? 0u : (total > (uint32_t)LDS_EXON_CAP ? 1u : 7u);       // diagnostics: why a tile is not fast (flags bits 8..11)
         // dictionary slices of the tile's bucket span: four directory words, used after the window scan below (the
         // loads and the scan's header loads are in flight together)
         uint32_t sd_r0 = 0u, sd_r1 = 0u, ed_r0 = 0u, ed_r1 = 0u;
         const bool sliced = fast && hi >= 0 && hi - lo + 1 <= DIR_CAP;
-        if (fast && hi >= 0 && !sliced) fast = false;
+        if (fast && hi >= 0 && !sliced) { fast = false; why = 2u; }
         if (sliced) {
             // START entries from the first one that reaches into the first bucket (full-length evidence scans them)
             sd_r0 = tabs.st.rdir[tb + lo]; sd_r1 = tabs.st.dir[tb + hi + 1];
@@ -393,9 +390,9 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
                 if (ma) { after = base + stop; break; }
                 base += WAVE;
                 if (base >= p.n_tx) break;
-                if (n_win > (uint32_t)WIN_TX || trip == WIN_SCAN_TRIPS - 1) { fast = false; break; }
+                if (n_win > (uint32_t)WIN_TX || trip == WIN_SCAN_TRIPS - 1) { fast = false; why = n_win > (uint32_t)WIN_TX ? 4u : 5u; break; }
             }
-            if (n_win > (uint32_t)WIN_TX || jh > after) fast = false;
+            if (fast && (n_win > (uint32_t)WIN_TX || jh > after)) { fast = false; why = n_win > (uint32_t)WIN_TX ? 4u : 6u; }
             if (fast) {
                 d.n_win = n_win;
                 if (n_win) { d.j_lo = first; contig = (uint32_t)(last - first + 1) == n_win; }
@@ -405,9 +402,9 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
             d.b_off = -lo; d.nb = nb; d.b0 = tb + lo; d.nbk = hi - lo + 1;
             d.st_r0 = sd_r0; d.st_nk = sd_r1 - sd_r0;
             d.en_r0 = ed_r0; d.en_nk = ed_r1 - ed_r0;
-            if (d.st_nk > (uint32_t)KEY_CAP || d.en_nk > (uint32_t)KEY_CAP) fast = false;
+            if (fast && (d.st_nk > (uint32_t)KEY_CAP || d.en_nk > (uint32_t)KEY_CAP)) { fast = false; why = 3u; }
         }
-        d.flags = (fast ? TD_FAST : 0u) | (contig ? TD_CONTIG : 0u);
+        d.flags = (fast ? TD_FAST : 0u) | (contig ? TD_CONTIG : 0u) | (why << 8);
         if (lane == 0) { tile_sum[blockIdx.x] = total; desc[blockIdx.x] = d; }
     }
 }
@@ -883,7 +880,11 @@ __device__ __forceinline__ TileUniforms load_uniforms(FastArgsK a, const TileDes
     u.d = desc[t];
     u.base = tile_base[t]; u.total = tile_base[t + 1u] - u.base;
     u.c0 = (uint32_t)cig_off[r0]; u.c1 = (uint32_t)cig_off[r1];
-    u.src = threadIdx.x < r1 - r0 ? (int32_t)ld32(a->order, r0 + threadIdx.x) : -1;
+    // Thread -> slot of pass A's order.  A workgroup's wave w runs on SIMD w of its CU: the slots are rotated by one
+    // wave per tile (a persistent workgroup sees tiles b, b + 1024, ...), which spreads the waves with the long reads
+    // -- and, for tiles of fewer than 256 reads, the only waves that hold reads at all -- over the four SIMDs.
+    const uint32_t slot = (threadIdx.x - (((t + (t >> 10)) & 3u) << 6)) & (uint32_t)(TILE_THREADS - 1);
+    u.src = slot < r1 - r0 ? (int32_t)ld32(a->order, r0 + slot) : -1;
     return u;
 }
 

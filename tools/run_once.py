@@ -27,9 +27,10 @@ if os.environ.get("L2R_STAMPS"):
     tot = sum(v[:8]) or 1
     print("stamps (cycles of thread 0 summed over tiles):", [(i, x, round(100.0 * x / tot, 1)) for i, x in enumerate(v[:8]) if x])
     print("redo reasons [not fast, not in LDS, wide, other tid, not sane, window/compact]:", v[8:14])
-cnt = (C.c_longlong * 4)()
+cnt = (C.c_longlong * 12)()
 lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-lib.l2r_debug_counters(e.ctx, cnt, 4)
-print("redo reads %d, wide entries %d, compact tx %d, tiles %d" % tuple(cnt))
+lib.l2r_debug_counters(e.ctx, cnt, 12)
+print("redo reads %d, wide entries %d, compact tx %d, tiles %d" % tuple(cnt[:4]))
+print("tiles [fast, exons > LDS cap, bucket span, dictionary slice, window > 32, window scan, cursor behind window, off]:", list(cnt[4:12]))
 tm = e.run_timed(5)
 print(e.sizes(), tm)
