@@ -219,3 +219,40 @@ def test_config3_full_size(engine, oracle):
     np.testing.assert_array_equal(got.ref_tx[lo:hi], sub.ref_tx)
     np.testing.assert_array_equal(got.ex_flag[a:b], sub.ex_flag)
     np.testing.assert_array_equal(got.ex_start[a:b], sub.ex_start)
+
+
+def test_config5_shard(engine, oracle):
+    """BASELINE config 5 at the size one of its 8 GPUs sees (2.5 M ONT-like reads on rank 0's chromosomes = the density of
+    the 20 M-read set, 12 exons + 3 micro-exons, ~400 CIGAR ops per read, 2 M-exon GTF) with the pipeline's second-pass
+    options (-s -l 3 -J 1 -j): idempotence, the accepted list, and a 150 k-read slice bit-exact against the oracle --
+    without and with the junction table -- plus shard invariance of that slice."""
+    from lr2rmats_amd import workload
+    cfg = dict(workload.CONFIGS["cfg5"]); cfg["n_reads"] = 2_500_000
+    af, reads = workload.make_rank_workload(cfg, 0, 8)
+    _set_anno(engine, af)
+    engine.set_junctions(None)
+    op = oracle.default_params(full_level=3)
+    prm = util.to_engine_params(capi, op)
+    got = engine.classify(reads, prm)
+    again = engine.classify(reads, prm)
+    for name in ("ex_off", "ex_start", "ex_end", "ex_flag", "info", "ref_tx"):
+        np.testing.assert_array_equal(getattr(got, name), getattr(again, name))
+    _check_accepted_list(engine, got, 0)
+    lo, hi = 1_200_000 + 77, 1_350_000
+    part = reads.slice(lo, hi)
+    want = util.oracle_run(oracle, af, part, op)
+    sub = engine.classify(part, prm, first_read_index=lo)
+    util.assert_same_result(sub, want, 0, 0)
+    a, b = int(got.ex_off[lo]), int(got.ex_off[hi])
+    np.testing.assert_array_equal(got.info[lo:hi], sub.info)
+    np.testing.assert_array_equal(got.ref_tx[lo:hi], sub.ref_tx)
+    np.testing.assert_array_equal(got.ex_flag[a:b], sub.ex_flag)
+    np.testing.assert_array_equal(got.ex_start[a:b], sub.ex_start)
+    np.testing.assert_array_equal(got.ex_end[a:b], sub.ex_end)
+    # second pass: short-read junction table, split at unsupported junctions
+    _, sj = util.junction_table(af, part, want, 5, cover=0.8)
+    op2 = oracle.default_params(full_level=3, split_trans=1, min_sj_cnt=1)
+    got2, want2 = _check(engine, oracle, af, part, op2, sj)
+    assert ((want2.info & 32) != 0).sum() > 1000 and ((want2.ex_flag & 16) != 0).sum() > 100
+    _check_accepted_list(engine, got2, 0)
+    engine.set_junctions(None)
