@@ -747,7 +747,9 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
 //   * the read's sweep ends inside the window (WIN_TX transcripts from the tile's smallest cursor value);
 //   * no dictionary entry of the tile's slices has members beyond 64 transcripts of its first.
 
-typedef int v4i_t __attribute__((ext_vector_type(4)));    // LDS copy of a dictionary entry {k1, k2, pm, sm}, masks in the tile frame
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));       // a 16-byte access at any 4-byte boundary (global memory)
+typedef uint32_t u32_a1 __attribute__((aligned(1)));                      // a 4-byte access at any address (global memory)    // LDS copy of a dictionary entry {k1, k2, pm, sm}, masks in the tile frame
 
 struct FastArgs {
     int64_t n_reads;
@@ -894,7 +896,7 @@ __device__ __forceinline__ int cigar_vectors(const TileUniforms &u) { return (in
 __device__ __forceinline__ int cigar_room(const TileUniforms &u)
 {
     const uint32_t lay = u.total <= (uint32_t)LDS_EXON_CAP ? u.total : 0u;
-    return FAST_ALL_WORDS - (int)((2u * lay + 3u) & ~3u);
+    return FAST_ALL_WORDS - (int)(2u * ((lay + 3u) & ~3u));
 }
 __device__ __forceinline__ bool cigar_staged(const TileUniforms &u, int region_words)
 {
@@ -937,16 +939,17 @@ __device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, con
     const TileDesc &d = u.d;
     const bool fast = (d.flags & TD_FAST) != 0;
     const int w_n = fast ? (int)d.n_win : 0;
+    // One load site per register group, whatever the thread stages (a START and an END entry, or a window header): with a
+    // load per role the compiler merges the roles through register copies -- and waits for the loads right here.
     v.xa = v.xb = v.xc = v.xd = make_int4(0, 0, 0, 0);
-    if ((int)threadIdx.x >= KEY_CAP) {
-        if ((int)threadIdx.x - KEY_CAP < w_n) {
-            const int4 *hp = reinterpret_cast<const int4 *>(p_win + (t * (uint32_t)WIN_TX + (threadIdx.x - (uint32_t)KEY_CAP)));
-            v.xa = hp[0]; v.xb = hp[1]; v.xc = hp[2];
-        }
-    } else {
-        if (fast && threadIdx.x < d.st_nk) { const int4 *q = reinterpret_cast<const int4 *>(p_st + d.st_r0 + threadIdx.x); v.xa = q[0]; v.xb = q[1]; }
-        if (fast && threadIdx.x < d.en_nk) { const int4 *q = reinterpret_cast<const int4 *>(p_en + d.en_r0 + threadIdx.x); v.xc = q[0]; v.xd = q[1]; }
-    }
+    const bool hdr_role = (int)threadIdx.x >= KEY_CAP;
+    const int4 *const hp = reinterpret_cast<const int4 *>(p_win + (t * (uint32_t)WIN_TX + (threadIdx.x - (uint32_t)KEY_CAP)));
+    const int4 *const qs = reinterpret_cast<const int4 *>(p_st + d.st_r0 + threadIdx.x), *const qe = reinterpret_cast<const int4 *>(p_en + d.en_r0 + threadIdx.x);
+    const int4 *const pa = hdr_role ? hp : qs, *const pc = hdr_role ? hp + 2 : qe;          // (the header's third word; xd is not used then)
+    const bool va = hdr_role ? (int)threadIdx.x - KEY_CAP < w_n : (fast && threadIdx.x < d.st_nk);
+    const bool vc = hdr_role ? (int)threadIdx.x - KEY_CAP < w_n : (fast && threadIdx.x < d.en_nk);
+    if (va) { v.xa = pa[0]; v.xb = pa[1]; }
+    if (vc) { v.xc = pc[0]; if (!hdr_role) v.xd = pc[1]; }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int i = (int)threadIdx.x + q * TILE_THREADS;
@@ -954,6 +957,20 @@ __device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, con
         if (fast && d.nbk > 0 && i <= d.nbk) { const uint32_t b = (uint32_t)(d.b0 + i); v.dd[0][q] = ld32(p_sd, b); v.dd[1][q] = ld32(p_ed, b); v.dd[2][q] = ld32(p_sr, b); }
     }
     return v;
+}
+
+// Makes every prefetched register of `v` a (no-op) operand: the compiler has to wait for those loads here.  Placed in
+// front of the tile's write-out: the loads are long done by then, the wait is free -- and without it the first use of
+// `v` at the top of the next tile waits with vmcnt(small), which on gfx9 (one in-order counter for loads and stores)
+// also waits for the write-out's stores, issued moments before, to be acknowledged.
+__device__ __forceinline__ void settle_vectors(const TileVectors &v)
+{
+    asm volatile("" :: "v"(v.local), "v"(v.nxt), "v"(v.c_lo), "v"(v.c_hi), "v"(v.pos), "v"(v.j0), "v"(v.tid), "v"(v.rev),
+                 "v"(v.dd[0][0]), "v"(v.dd[0][1]), "v"(v.dd[1][0]), "v"(v.dd[1][1]), "v"(v.dd[2][0]), "v"(v.dd[2][1]));
+    asm volatile("" :: "v"(v.cg[0].x), "v"(v.cg[0].y), "v"(v.cg[0].z), "v"(v.cg[0].w), "v"(v.cg[1].x), "v"(v.cg[1].y), "v"(v.cg[1].z), "v"(v.cg[1].w),
+                 "v"(v.cg[2].x), "v"(v.cg[2].y), "v"(v.cg[2].z), "v"(v.cg[2].w), "v"(v.cg[3].x), "v"(v.cg[3].y), "v"(v.cg[3].z), "v"(v.cg[3].w));
+    asm volatile("" :: "v"(v.xa.x), "v"(v.xa.y), "v"(v.xa.z), "v"(v.xa.w), "v"(v.xb.x), "v"(v.xb.y), "v"(v.xb.z), "v"(v.xb.w),
+                 "v"(v.xc.x), "v"(v.xc.y), "v"(v.xc.z), "v"(v.xc.w), "v"(v.xd.x), "v"(v.xd.y), "v"(v.xd.z), "v"(v.xd.w));
 }
 
 // ---- the three classification phases of a tile (all lanes of a wave call them together) -------------------------
@@ -1166,6 +1183,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
     if ((int64_t)t >= n_tiles) return;
     TileUniforms u = load_uniforms(fast_args(), u_desc, u_tile_base, u_cig_off, t);
     TileVectors v = load_vectors(fast_args(), t, u, cigar_room(u));
+    settle_vectors(v);               // (first tile only: every later one is settled in front of its predecessor's write-out)
 
     for (; (int64_t)t < n_tiles; t += gridDim.x) {
         const uint32_t t_next = t + gridDim.x;
@@ -1180,8 +1198,9 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         const bool fast = (d.flags & TD_FAST) != 0;
         const bool in_lds = tile_total <= (uint32_t)LDS_EXON_CAP;
         const uint32_t lay_total = in_lds ? tile_total : 0u;
-        int *const s_S = reinterpret_cast<int *>(s_all), *const s_E = s_S + lay_total;
-        const int tail_off = (int)((2u * lay_total + 3u) & ~3u), tail_words = ALL_WORDS - tail_off;
+        const uint32_t lay4 = (lay_total + 3u) & ~3u;                     // E starts on a 16-byte boundary as well (vector write-out)
+        int *const s_S = reinterpret_cast<int *>(s_all), *const s_E = s_S + lay4;
+        const int tail_off = (int)(2u * lay4), tail_words = ALL_WORDS - tail_off;
         uint32_t *const s_cig = s_all + tail_off;
         uint16_t *const s_W = reinterpret_cast<uint16_t *>(s_all + tail_off);
         v4i_t *const s_ent0 = reinterpret_cast<v4i_t *>(s_all + tail_off + W_WORDS), *const s_ent1 = s_ent0 + KEY_CAP;
@@ -1328,6 +1347,8 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         }
         __syncthreads();
         L2R_STAMP(5);
+        settle_vectors(v);                           // (unconditional: the compiler cannot tell that `has_next` guards both)
+        asm volatile("" :: "v"(u_next.src));
         // ---- accepted exons of the tile, compacted in read order into a chunk of the accepted arrays (chunks are handed
         // out by an atomic cursor: their order is arbitrary, tile_chunk says where a tile's chunk starts).  Only when
         // every verdict of the tile is final here: no read on the redo list, no junction table (k_validate_sj decides).
@@ -1338,7 +1359,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
             ao->tile_acc[t] = ca_t;
             ao->tile_acc_ex[t] = fused ? 0u : cx_t;       // exons that k_gather_accepted has to place
             if (!fused) ao->tile_chunk[t] = CHUNK_DEFERRED;
-            else if (cx_t) chunk = (ao->p.ablate & 4) ? base : atomicAdd(ao->chunk_cursor, cx_t);          // (answer needed after the write-out below)
+            else if (cx_t) chunk = atomicAdd(ao->chunk_cursor, cx_t);          // (answer needed after the write-out below)
         }
         uint16_t *const s_map = reinterpret_cast<uint16_t *>(s_ent0);           // the dictionary slices are dead by now
         if (fused && cx_t) {
