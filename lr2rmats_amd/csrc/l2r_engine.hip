@@ -567,8 +567,8 @@ static int prepare_unsorted_sj_cursor(l2r_ctx *c)
 
 enum { ST_PASS_A = 0, ST_SCAN1, ST_FAST, ST_GENERIC, ST_SJ, ST_SCAN2, ST_GATHER, ST_N };
 
-#define launch_fast_level(L, fa, grid, s) if (c->wide_cigar) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L, true>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles, (const TileDesc *)c->desc.p, (const uint32_t *)c->tile_base.p, (const int64_t *)c->cig_off.p); \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L, false>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles, (const TileDesc *)c->desc.p, (const uint32_t *)c->tile_base.p, (const int64_t *)c->cig_off.p)
+#define launch_fast_level(L, fa, grid, s) if (c->wide_cigar) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L, true>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles, (const TileDesc *)c->desc.p, (const uint32_t *)c->tile_base.p, (const int64_t *)c->cig_off.p, (const uint8_t *)c->order.p, (uint32_t)c->reads_per_tile, (uint32_t)N); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L, false>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles, (const TileDesc *)c->desc.p, (const uint32_t *)c->tile_base.p, (const int64_t *)c->cig_off.p, (const uint8_t *)c->order.p, (uint32_t)c->reads_per_tile, (uint32_t)N)
 
 static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
 {

@@ -873,12 +873,13 @@ struct TileVectors {                                        // per-thread raw in
 
 // (the three arrays come in as __restrict__ kernel parameters of their own, so that these are scalar loads that
 //  wait at their first use, not vector loads that wait where they are issued)
-__device__ __forceinline__ TileUniforms load_uniforms(FastArgsK a, const TileDesc *__restrict__ desc, const uint32_t *__restrict__ tile_base,
-                                                     const int64_t *__restrict__ cig_off, uint32_t t)
+__device__ __forceinline__ TileUniforms load_uniforms(const TileDesc *__restrict__ desc, const uint32_t *__restrict__ tile_base,
+                                                     const int64_t *__restrict__ cig_off, const uint8_t *__restrict__ order,
+                                                     uint32_t rpt, uint32_t n_reads, uint32_t t)
 {
     // 32-bit indices throughout: a shard has fewer than 2^32 reads and CIGAR words (l2r_upload_reads checks)
     TileUniforms u;
-    const uint32_t rpt = (uint32_t)a->p.reads_per_tile, r0 = t * rpt, r1 = min(r0 + rpt, (uint32_t)a->n_reads);
+    const uint32_t r0 = t * rpt, r1 = min(r0 + rpt, n_reads);
     u.d = desc[t];
     u.base = tile_base[t]; u.total = tile_base[t + 1u] - u.base;
     u.c0 = (uint32_t)cig_off[r0]; u.c1 = (uint32_t)cig_off[r1];
@@ -886,7 +887,7 @@ __device__ __forceinline__ TileUniforms load_uniforms(FastArgsK a, const TileDes
     // wave per tile (a persistent workgroup sees tiles b, b + 1024, ...), which spreads the waves with the long reads
     // -- and, for tiles of fewer than 256 reads, the only waves that hold reads at all -- over the four SIMDs.
     const uint32_t slot = (threadIdx.x - (((t + (t >> 10)) & 3u) << 6)) & (uint32_t)(TILE_THREADS - 1);
-    u.src = slot < r1 - r0 ? (int32_t)ld32(a->order, r0 + slot) : -1;
+    u.src = slot < r1 - r0 ? (int32_t)ld32(order, r0 + slot) : -1;
     return u;
 }
 
@@ -1152,7 +1153,7 @@ __device__ __forceinline__ Verdict decide(const TileLds &L, const TileDesc &d, u
 template <int LEVEL, bool WIDE>
 __global__ __launch_bounds__(TILE_THREADS, 4)
 void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int64_t n_tiles, const TileDesc *__restrict__ u_desc, const uint32_t *__restrict__ u_tile_base,
-                     const int64_t *__restrict__ u_cig_off)
+                     const int64_t *__restrict__ u_cig_off, const uint8_t *__restrict__ u_order, uint32_t u_rpt, uint32_t u_n_reads)
 {
     // One LDS array per workgroup, laid out per tile (total = the tile's exon count <= LDS_EXON_CAP):
     //   [0, total)            S   exon starts            [total, 2 total)   E   exon ends
@@ -1181,7 +1182,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
 
     uint32_t t = blockIdx.x;
     if ((int64_t)t >= n_tiles) return;
-    TileUniforms u = load_uniforms(fast_args(), u_desc, u_tile_base, u_cig_off, t);
+    TileUniforms u = load_uniforms(u_desc, u_tile_base, u_cig_off, u_order, u_rpt, u_n_reads, t);
     TileVectors v = load_vectors(fast_args(), t, u, cigar_room(u));
     settle_vectors(v);               // (first tile only: every later one is settled in front of its predecessor's write-out)
 
@@ -1189,9 +1190,9 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         const uint32_t t_next = t + gridDim.x;
         const bool has_next = (int64_t)t_next < n_tiles;
         TileUniforms u_next = u;
-        if (has_next) u_next = load_uniforms(fast_args(), u_desc, u_tile_base, u_cig_off, t_next);
+        if (has_next) u_next = load_uniforms(u_desc, u_tile_base, u_cig_off, u_order, u_rpt, u_n_reads, t_next);
 
-        const uint32_t r = t * (uint32_t)fast_args()->p.reads_per_tile + (uint32_t)u.src;
+        const uint32_t r = t * u_rpt + (uint32_t)u.src;
         const bool active = u.src >= 0;
         const TileDesc d = u.d;
         const uint32_t base = u.base, tile_total = u.total;
@@ -1332,13 +1333,21 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
             atomicAdd(&fast_args()->stamps[8192 + why], 1ull);
         }
         const FastArgsK ao = fast_args();
+        // the output pointers of the rest of the tile, fetched from the argument block in one go (see load_vectors)
+        uint32_t *const o_redo_count = ao->redo_count, *const o_redo = ao->redo, *const o_tile_acc = ao->tile_acc, *const o_tile_acc_ex = ao->tile_acc_ex;
+        uint32_t *const o_tile_chunk = ao->tile_chunk, *const o_cursor = ao->chunk_cursor, *const o_ex_off = ao->ex_off, *const o_info = ao->info;
+        int32_t *const o_ex_start = ao->ex_start, *const o_ex_end = ao->ex_end, *const o_ref = ao->ref_tx, *const o_acc_start = ao->acc_start, *const o_acc_end = ao->acc_end;
+        uint8_t *const o_ex_flag = ao->ex_flag, *const o_acc_flag = ao->acc_flag;
+        const int32_t o_n_sj = ao->p.n_sj, o_ablate = ao->p.ablate;
+        asm volatile("" :: "s"(o_redo_count), "s"(o_redo), "s"(o_tile_acc), "s"(o_tile_acc_ex), "s"(o_tile_chunk), "s"(o_cursor), "s"(o_ex_off), "s"(o_info),
+                     "s"(o_ex_start), "s"(o_ex_end), "s"(o_ref), "s"(o_acc_start), "s"(o_acc_end), "s"(o_ex_flag), "s"(o_acc_flag), "s"(o_n_sj), "s"(o_ablate));
         {
             const unsigned long long m = __ballot(redo);
             if (m) {
                 uint32_t at = 0;
-                if (lane == 0) at = atomicAdd(ao->redo_count, (uint32_t)__popcll(m));
+                if (lane == 0) at = atomicAdd(o_redo_count, (uint32_t)__popcll(m));
                 at = __shfl(at, 0, WAVE);
-                if (redo) ao->redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+                if (redo) o_redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
             }
             const bool acc = (info & I_ACCEPT) != 0;
             const uint32_t ca = (uint32_t)__popcll(__ballot(acc)), cx = wave_sum(acc ? n : 0u);
@@ -1353,19 +1362,19 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         // out by an atomic cursor: their order is arbitrary, tile_chunk says where a tile's chunk starts).  Only when
         // every verdict of the tile is final here: no read on the redo list, no junction table (k_validate_sj decides).
         const uint32_t ca_t = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0], cx_t = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
-        const bool fused = in_lds && (s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2]) == 0u && ao->p.n_sj == 0 && !(ao->p.ablate & 2);
+        const bool fused = in_lds && (s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2]) == 0u && o_n_sj == 0 && !(o_ablate & 2);
         uint32_t chunk = 0u;
         if (threadIdx.x == 0) {
-            ao->tile_acc[t] = ca_t;
-            ao->tile_acc_ex[t] = fused ? 0u : cx_t;       // exons that k_gather_accepted has to place
-            if (!fused) ao->tile_chunk[t] = CHUNK_DEFERRED;
-            else if (cx_t) chunk = atomicAdd(ao->chunk_cursor, cx_t);          // (answer needed after the write-out below)
+            o_tile_acc[t] = ca_t;
+            o_tile_acc_ex[t] = fused ? 0u : cx_t;       // exons that k_gather_accepted has to place
+            if (!fused) o_tile_chunk[t] = CHUNK_DEFERRED;
+            else if (cx_t) chunk = atomicAdd(o_cursor, cx_t);          // (answer needed after the write-out below)
         }
         uint16_t *const s_map = reinterpret_cast<uint16_t *>(s_ent0);           // the dictionary slices are dead by now
         if (fused && cx_t) {
             // thread i takes read i of the tile (reads are spread over the threads in pass A's order): exclusive sums
             // of {all exons, accepted exons} over the reads before it, both below 2^16, packed in one word
-            const uint32_t rpt_u = (uint32_t)ao->p.reads_per_tile, n_act = min(rpt_u, (uint32_t)ao->n_reads - t * rpt_u);
+            const uint32_t n_act = min(u_rpt, u_n_reads - t * u_rpt);
             const uint32_t w16 = threadIdx.x < n_act ? (uint32_t)s_nat[threadIdx.x] : 0u;
             const uint32_t nn = w16 & 0x7fffu, pk = nn | ((w16 >> 15) ? nn << 16 : 0u);
             uint32_t before = wave_inclusive_scan(pk) - pk;
@@ -1381,18 +1390,18 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         }
         if (in_lds) {
             for (uint32_t i = threadIdx.x; i < tile_total; i += TILE_THREADS) {
-                ao->ex_start[base + i] = s_S[i];
-                ao->ex_end[base + i] = s_E[i];
-                ao->ex_flag[base + i] = (uint8_t)s_W[i];
+                o_ex_start[base + i] = s_S[i];
+                o_ex_end[base + i] = s_E[i];
+                o_ex_flag[base + i] = (uint8_t)s_W[i];
             }
         }
         if (active) {
-            ao->ex_off[r] = base + local;
-            ao->info[r] = info;
-            ao->ref_tx[r] = ref;
+            o_ex_off[r] = base + local;
+            o_info[r] = info;
+            o_ref[r] = ref;
         }
         if (fused) {
-            if (threadIdx.x == 0) { s_chunk = chunk; ao->tile_chunk[t] = chunk; }
+            if (threadIdx.x == 0) { s_chunk = chunk; o_tile_chunk[t] = chunk; }
             if (cx_t) {
                 __syncthreads();
                 const uint32_t to = s_chunk;
@@ -1400,9 +1409,9 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
                 for (uint32_t i = threadIdx.x; i < cx_t; i += TILE_THREADS) {
                     const uint32_t i_next = i + TILE_THREADS;                    // its map entry travels while this one is copied
                     const uint32_t q_next = i_next < cx_t ? (uint32_t)s_map[i_next] : 0u;
-                    ao->acc_start[to + i] = s_S[q];
-                    ao->acc_end[to + i] = s_E[q];
-                    ao->acc_flag[to + i] = (uint8_t)s_W[q];
+                    o_acc_start[to + i] = s_S[q];
+                    o_acc_end[to + i] = s_E[q];
+                    o_acc_flag[to + i] = (uint8_t)s_W[q];
                     q = q_next;
                 }
             }
