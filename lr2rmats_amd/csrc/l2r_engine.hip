@@ -90,6 +90,7 @@ struct l2r_ctx {
     DevBuf<uint32_t> redo;                  // reads the fast kernel hands to the generic one
     DevBuf<uint8_t> order;                  // per tile: reads by falling exon count (pass A)
     DevBuf<TileDesc> desc;
+    DevBuf<uint32_t> tile_first;       // first read of every tile (+ one closing entry)
     DevBuf<TxHdr> win_hdr;             // WIN_TX window headers per tile (pass A)
     DevBuf<int32_t> ex_start, ex_end, ref_tx;
     DevBuf<uint8_t> ex_flag;
@@ -172,7 +173,7 @@ void l2r_destroy(l2r_ctx *c)
     c->sj_tid.release(); c->sj_don.release(); c->sj_acc.release(); c->sj_uniq.release(); c->sj_multi.release(); c->sj_key.release();
     c->r_tid.release(); c->r_pos.release(); c->r_rev.release(); c->cig_off.release(); c->cig.release();
     c->win_start.release(); c->sj_cursor.release();
-    c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->totals.release();
+    c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -491,8 +492,22 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     }
     c->reads_per_tile = rpt;
     c->wide_cigar = N > 0 && (double)r->n_cigar / (double)N > 32.0;
-    c->n_tiles = (N + rpt - 1) / rpt;
+    // Tiles: runs of up to rpt consecutive reads; for sorted input a tile also ends where the chromosome changes, so
+    // that every read of a tile can use the tile's dictionary slices (unsorted input: plain runs, the reads that are
+    // not on the chromosome of their tile's first read take the generic kernel).
+    std::vector<uint32_t> tile_first;
+    tile_first.reserve((size_t)(N / rpt + 64));
+    for (int64_t i = 0, start = 0; i <= N; ++i) {
+        if (i == N) { if (i > start) tile_first.push_back((uint32_t)start); break; }
+        if (i - start == rpt || (sorted && r->tid[i] != r->tid[start])) { tile_first.push_back((uint32_t)start); start = i; }
+    }
+    c->n_tiles = (int64_t)tile_first.size();
+    tile_first.push_back((uint32_t)N);
+    if (tile_first.size() < 2) tile_first.push_back((uint32_t)N);        // (an empty launch still runs one workgroup)
     c->n_tiles256 = (N + TILE_THREADS - 1) / TILE_THREADS;
+    if (c->tile_first.ensure(tile_first.size())) return -2;
+    HIP_TRY(hipMemcpyAsync(c->tile_first.p, tile_first.data(), tile_first.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));                              // (tile_first is a local)
 
     if (c->r_tid.ensure((size_t)N) || c->r_pos.ensure((size_t)N) || c->r_rev.ensure((size_t)N) ||
         c->cig_off.ensure((size_t)N + 1) || c->cig.ensure((size_t)r->n_cigar + 4)) return -2;     // + 4: the tile staging reads whole 16-byte vectors
@@ -506,7 +521,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     // work buffers.  n_exon(read) <= ops(read) + 1, so n_cigar + n_reads bounds the exon arrays.
     const size_t exb = (size_t)r->n_cigar + (size_t)N;
     if (c->j0.ensure((size_t)N) || c->local.ensure((size_t)N + 1) || c->ex_off.ensure((size_t)N) || c->info.ensure((size_t)N) || c->ref_tx.ensure((size_t)N) ||
-        c->redo.ensure((size_t)N) || c->order.ensure((size_t)c->n_tiles * TILE_THREADS) || c->desc.ensure((size_t)c->n_tiles) || c->win_hdr.ensure((size_t)c->n_tiles * WIN_TX) ||
+        c->redo.ensure((size_t)N) || c->order.ensure((size_t)N + TILE_THREADS) || c->desc.ensure((size_t)c->n_tiles) || c->win_hdr.ensure((size_t)c->n_tiles * WIN_TX) ||
         c->tile_base.ensure((size_t)c->n_tiles + 1) || c->tile_acc.ensure((size_t)c->n_tiles + 1) || c->tile_acc_ex.ensure((size_t)c->n_tiles + 1) ||
         c->totals.ensure(8) || c->tile_chunk.ensure((size_t)c->n_tiles + 1) || c->ex_start.ensure(exb) || c->ex_end.ensure(exb) || c->ex_flag.ensure(exb) ||
         c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
@@ -567,8 +582,8 @@ static int prepare_unsorted_sj_cursor(l2r_ctx *c)
 
 enum { ST_PASS_A = 0, ST_SCAN1, ST_FAST, ST_GENERIC, ST_SJ, ST_SCAN2, ST_GATHER, ST_N };
 
-#define launch_fast_level(L, fa, grid, s) if (c->wide_cigar) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L, true>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles, (const TileDesc *)c->desc.p, (const uint32_t *)c->tile_base.p, (const int64_t *)c->cig_off.p, (const uint8_t *)c->order.p, (uint32_t)c->reads_per_tile, (uint32_t)N); \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L, false>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles, (const TileDesc *)c->desc.p, (const uint32_t *)c->tile_base.p, (const int64_t *)c->cig_off.p, (const uint8_t *)c->order.p, (uint32_t)c->reads_per_tile, (uint32_t)N)
+#define launch_fast_level(L, fa, grid, s) if (c->wide_cigar) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L, true>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles, (const TileDesc *)c->desc.p, (const uint32_t *)c->tile_base.p, (const int64_t *)c->cig_off.p, (const uint8_t *)c->order.p, (const uint32_t *)c->tile_first.p); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_classify_fast<L, false>), dim3(grid), dim3(TILE_THREADS), 0, s, fa, c->n_tiles, (const TileDesc *)c->desc.p, (const uint32_t *)c->tile_base.p, (const int64_t *)c->cig_off.p, (const uint8_t *)c->order.p, (const uint32_t *)c->tile_first.p)
 
 static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
 {
@@ -585,11 +600,11 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     if (c->wide_cigar)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass_a<true>), dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, tabs, p,
                            (c->sorted ? (const int32_t *)nullptr : (const int32_t *)c->win_start.p), c->j0.p, c->local.p, c->order.p, c->tile_base.p, c->desc.p,
-                           c->totals.p + 3, (const TxHdr *)c->hdr.p, c->win_hdr.p);
+                           c->totals.p + 3, (const TxHdr *)c->hdr.p, c->win_hdr.p, (const uint32_t *)c->tile_first.p);
     else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass_a<false>), dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, tabs, p,
                        (c->sorted ? (const int32_t *)nullptr : (const int32_t *)c->win_start.p), c->j0.p, c->local.p, c->order.p, c->tile_base.p, c->desc.p,
-                       c->totals.p + 3, (const TxHdr *)c->hdr.p, c->win_hdr.p);
+                       c->totals.p + 3, (const TxHdr *)c->hdr.p, c->win_hdr.p, (const uint32_t *)c->tile_first.p);
     MARK(ST_SCAN1);
     {
         ScanJobs jobs; jobs.job[0] = ScanJob{c->tile_base.p, c->n_tiles, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
@@ -622,7 +637,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         const unsigned gg = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles * 4 : 1, 4096);      // one wave per listed read, grid-stride
         hipLaunchKernelGGL(k_classify_generic, dim3(gg), dim3(TILE_THREADS), 0, s, c->totals.p + 3, c->redo.p, c->r_tid.p, c->r_rev.p, j0,
                            c->hdr.p, c->anno_ex.p, p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->info.p, c->ref_tx.p,
-                           c->tile_acc.p, c->tile_acc_ex.p);
+                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles);
     }
     MARK(ST_SJ);
     if (c->n_sj > 0) {
@@ -631,7 +646,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
                            c->sj_key.p, (c->sorted ? (const int32_t *)nullptr : c->sj_cursor.p), c->sj_tid.p, c->sj_don.p, c->sj_acc.p,
                            c->sj_uniq.p, c->sj_multi.p, p, c->info.p);
         // acceptance is decided by the junction check: recount per tile
-        hipLaunchKernelGGL(k_count_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->reads_per_tile, c->info.p, c->tile_acc.p, c->tile_acc_ex.p);
+        hipLaunchKernelGGL(k_count_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->info.p, c->tile_acc.p, c->tile_acc_ex.p);
     }
     MARK(ST_SCAN2);
     {
@@ -639,7 +654,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         hipLaunchKernelGGL(k_scan_u32, dim3(2), dim3(1024), 0, s, jobs);
     }
     MARK(ST_GATHER);
-    hipLaunchKernelGGL(k_gather_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, N, c->reads_per_tile, c->first_read, c->info.p, c->ref_tx.p, c->ex_off.p,
+    hipLaunchKernelGGL(k_gather_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->first_read, c->info.p, c->ref_tx.p, c->ex_off.p,
                        c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->tile_acc.p, c->tile_acc_ex.p, c->tile_chunk.p, c->totals.p + 4,
                        c->acc_rec.p, c->acc_ex_off.p, c->acc_start.p, c->acc_end.p, c->acc_flag.p);
     MARK(ST_N);

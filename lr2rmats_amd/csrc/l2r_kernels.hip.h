@@ -273,15 +273,17 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
               const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ cig, CursorDir cd, SiteTabs tabs, DevParams p,
               const int32_t *__restrict__ j0_in, int32_t *__restrict__ j0_out, uint32_t *__restrict__ local_out,
               uint8_t *__restrict__ order_out, uint32_t *__restrict__ tile_sum, TileDesc *__restrict__ desc, uint32_t *__restrict__ redo_count,
-              const TxHdr *__restrict__ hdr, TxHdr *__restrict__ win_hdr)
+              const TxHdr *__restrict__ hdr, TxHdr *__restrict__ win_hdr, const uint32_t *__restrict__ tile_first)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ int s_red[4][6];
     __shared__ int s_tid0;
     __shared__ uint32_t s_hist[WAVE];
     if (threadIdx.x < WAVE) s_hist[threadIdx.x] = 0u;
-    const int64_t r = (int64_t)blockIdx.x * p.reads_per_tile + threadIdx.x;
-    const bool active = (int)threadIdx.x < p.reads_per_tile && r < n_reads;
+    // tile = reads [tile_first[b], tile_first[b + 1]): at most reads_per_tile of them, of one chromosome when the input is sorted
+    const uint32_t r0 = tile_first[blockIdx.x], n_act = tile_first[blockIdx.x + 1] - r0;
+    const int64_t r = (int64_t)r0 + threadIdx.x;
+    const bool active = threadIdx.x < n_act;
     if (blockIdx.x == 0 && threadIdx.x == 0) { redo_count[0] = 0u; redo_count[1] = 0u; }   // redo list and accepted-exon cursor: the kernels that fill them run after this one
     uint32_t n = 0;
     int j0 = INT32_MAX, tid = 0, pos = 0, el = 0;
@@ -308,7 +310,7 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
         if (threadIdx.x < WAVE) { const uint32_t c = s_hist[threadIdx.x]; s_hist[threadIdx.x] = wave_inclusive_scan(c) - c; }
         __syncthreads();
         const uint32_t slot = s_hist[bin] + rank;
-        if (active) order_out[(int64_t)blockIdx.x * p.reads_per_tile + slot] = (uint8_t)threadIdx.x;
+        if (active) order_out[(int64_t)r0 + slot] = (uint8_t)threadIdx.x;
     }
     // the tile's chromosome is the one of its first read; reads on another one go to the generic kernel
     const int tid0 = s_tid0;
@@ -604,7 +606,7 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
                         const TxHdr *__restrict__ hdr, const int2 *__restrict__ anno_ex, DevParams p,
                         const uint32_t *__restrict__ ex_off, const int32_t *__restrict__ ex_start, const int32_t *__restrict__ ex_end,
                         uint8_t *__restrict__ ex_flag, uint32_t *__restrict__ info_io, int32_t *__restrict__ ref_out,
-                        uint32_t *__restrict__ tile_acc, uint32_t *__restrict__ tile_acc_ex)
+                        uint32_t *__restrict__ tile_acc, uint32_t *__restrict__ tile_acc_ex, const uint32_t *__restrict__ tile_first, int n_tiles)
 {
     __shared__ int g_S[GEN_WAVES][GEN_CAP];
     __shared__ int g_E[GEN_WAVES][GEN_CAP];
@@ -721,7 +723,9 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
             info_io[r] = v.info;
             ref_out[r] = v.ref;
             if (v.info & I_ACCEPT) {
-                const uint32_t t = r / (uint32_t)p.reads_per_tile;
+                int lo = 0, hi = n_tiles;                  // the tile of read r: last t with tile_first[t] <= r
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_first[mid] <= r) lo = mid; else hi = mid; }
+                const uint32_t t = (uint32_t)lo;
                 atomicAdd(&tile_acc[t], 1u);
                 atomicAdd(&tile_acc_ex[t], (uint32_t)n);
             }
@@ -859,6 +863,7 @@ struct TileUniforms {                                       // wave-uniform inpu
     TileDesc d;
     uint32_t base, total;
     uint32_t c0, c1;                                        // the tile's CIGAR words [c0, c1) (a shard has < 2^32 of them)
+    uint32_t r0, n_act;                                     // the tile's reads [r0, r0 + n_act)
     int32_t src;                                            // ... and the thread's read of the tile (pass A's order), -1: none
 };
 
@@ -875,11 +880,12 @@ struct TileVectors {                                        // per-thread raw in
 //  wait at their first use, not vector loads that wait where they are issued)
 __device__ __forceinline__ TileUniforms load_uniforms(const TileDesc *__restrict__ desc, const uint32_t *__restrict__ tile_base,
                                                      const int64_t *__restrict__ cig_off, const uint8_t *__restrict__ order,
-                                                     uint32_t rpt, uint32_t n_reads, uint32_t t)
+                                                     const uint32_t *__restrict__ tile_first, uint32_t t)
 {
     // 32-bit indices throughout: a shard has fewer than 2^32 reads and CIGAR words (l2r_upload_reads checks)
     TileUniforms u;
-    const uint32_t r0 = t * rpt, r1 = min(r0 + rpt, n_reads);
+    const uint32_t r0 = tile_first[t], r1 = tile_first[t + 1u];
+    u.r0 = r0; u.n_act = r1 - r0;
     u.d = desc[t];
     u.base = tile_base[t]; u.total = tile_base[t + 1u] - u.base;
     u.c0 = (uint32_t)cig_off[r0]; u.c1 = (uint32_t)cig_off[r1];
@@ -914,16 +920,14 @@ __device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, con
     const int32_t *const p_pos = a->r_pos, *const p_tid = a->r_tid, *const p_j0 = a->j0; const uint8_t *const p_rev = a->r_rev;
     const TxHdr *const p_win = a->win_hdr; const SiteEnt *const p_st = a->st.ent, *const p_en = a->en.ent;
     const uint32_t *const p_sd = a->st.dir, *const p_ed = a->en.dir, *const p_sr = a->st.rdir;
-    const int rpt = a->p.reads_per_tile;
-    const uint32_t n_reads = (uint32_t)a->n_reads;
     asm volatile("" :: "s"(p_local), "s"(p_cig_off), "s"(p_cig), "s"(p_pos), "s"(p_tid), "s"(p_j0), "s"(p_rev), "s"(p_win),
-                 "s"(p_st), "s"(p_en), "s"(p_sd), "s"(p_ed), "s"(p_sr), "s"(rpt), "s"(n_reads));
-    const uint32_t r = t * (uint32_t)rpt + (uint32_t)u.src;
+                 "s"(p_st), "s"(p_en), "s"(p_sd), "s"(p_ed), "s"(p_sr));
+    const uint32_t r = u.r0 + (uint32_t)u.src;
     const bool active = u.src >= 0;
     v.local = 0; v.nxt = 0; v.c_lo = 0; v.c_hi = 0; v.pos = 0; v.j0 = 0; v.tid = 0; v.rev = 0;
     if (active) {
         v.local = ld32(p_local, r);
-        const bool last = u.src + 1 == rpt || r + 1u == n_reads;
+        const bool last = (uint32_t)u.src + 1u == u.n_act;
         v.nxt = last ? u.total : ld32(p_local, r + 1u);
         v.c_lo = (uint32_t)ld32(p_cig_off, r); v.c_hi = (uint32_t)ld32(p_cig_off, r + 1u);
         v.pos = ld32(p_pos, r); v.tid = ld32(p_tid, r); v.j0 = ld32(p_j0, r); v.rev = ld32(p_rev, r);
@@ -1153,7 +1157,7 @@ __device__ __forceinline__ Verdict decide(const TileLds &L, const TileDesc &d, u
 template <int LEVEL, bool WIDE>
 __global__ __launch_bounds__(TILE_THREADS, 4)
 void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int64_t n_tiles, const TileDesc *__restrict__ u_desc, const uint32_t *__restrict__ u_tile_base,
-                     const int64_t *__restrict__ u_cig_off, const uint8_t *__restrict__ u_order, uint32_t u_rpt, uint32_t u_n_reads)
+                     const int64_t *__restrict__ u_cig_off, const uint8_t *__restrict__ u_order, const uint32_t *__restrict__ u_tile_first)
 {
     // One LDS array per workgroup, laid out per tile (total = the tile's exon count <= LDS_EXON_CAP):
     //   [0, total)            S   exon starts            [total, 2 total)   E   exon ends
@@ -1182,7 +1186,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
 
     uint32_t t = blockIdx.x;
     if ((int64_t)t >= n_tiles) return;
-    TileUniforms u = load_uniforms(u_desc, u_tile_base, u_cig_off, u_order, u_rpt, u_n_reads, t);
+    TileUniforms u = load_uniforms(u_desc, u_tile_base, u_cig_off, u_order, u_tile_first, t);
     TileVectors v = load_vectors(fast_args(), t, u, cigar_room(u));
     settle_vectors(v);               // (first tile only: every later one is settled in front of its predecessor's write-out)
 
@@ -1190,9 +1194,9 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         const uint32_t t_next = t + gridDim.x;
         const bool has_next = (int64_t)t_next < n_tiles;
         TileUniforms u_next = u;
-        if (has_next) u_next = load_uniforms(u_desc, u_tile_base, u_cig_off, u_order, u_rpt, u_n_reads, t_next);
+        if (has_next) u_next = load_uniforms(u_desc, u_tile_base, u_cig_off, u_order, u_tile_first, t_next);
 
-        const uint32_t r = t * u_rpt + (uint32_t)u.src;
+        const uint32_t r = u.r0 + (uint32_t)u.src;
         const bool active = u.src >= 0;
         const TileDesc d = u.d;
         const uint32_t base = u.base, tile_total = u.total;
@@ -1374,7 +1378,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         if (fused && cx_t) {
             // thread i takes read i of the tile (reads are spread over the threads in pass A's order): exclusive sums
             // of {all exons, accepted exons} over the reads before it, both below 2^16, packed in one word
-            const uint32_t n_act = min(u_rpt, u_n_reads - t * u_rpt);
+            const uint32_t n_act = u.n_act;
             const uint32_t w16 = threadIdx.x < n_act ? (uint32_t)s_nat[threadIdx.x] : 0u;
             const uint32_t nn = w16 & 0x7fffu, pk = nn | ((w16 >> 15) ? nn << 16 : 0u);
             uint32_t before = wave_inclusive_scan(pk) - pk;
@@ -1508,12 +1512,13 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
 // Tiles are the classification tiles (reads_per_tile records, one workgroup).
 
 __global__ __launch_bounds__(TILE_THREADS)
-void k_count_accepted(int64_t n_reads, int reads_per_tile, const uint32_t *__restrict__ info, uint32_t *__restrict__ tile_reads,
+void k_count_accepted(const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ info, uint32_t *__restrict__ tile_reads,
                       uint32_t *__restrict__ tile_exons)
 {
     __shared__ uint32_t s_cnt[4], s_ex[4];
-    const int64_t r = (int64_t)blockIdx.x * reads_per_tile + threadIdx.x;
-    const uint32_t w = ((int)threadIdx.x < reads_per_tile && r < n_reads) ? info[r] : 0u;
+    const uint32_t r0 = tile_first[blockIdx.x], n_act = tile_first[blockIdx.x + 1] - r0;
+    const int64_t r = (int64_t)r0 + threadIdx.x;
+    const uint32_t w = threadIdx.x < n_act ? info[r] : 0u;
     const bool acc = (w & I_ACCEPT) != 0;
     const unsigned long long m = __ballot(acc);
     const uint32_t ex = wave_sum(acc ? (w >> 8) : 0u);
@@ -1538,7 +1543,7 @@ struct AccRec { uint32_t read_lo, read_hi, info; int32_t ref_tx; };
 constexpr uint32_t MAP_DIRECT = 0xffffu;      // map entry of an exon that its read has copied itself
 
 __global__ __launch_bounds__(TILE_THREADS)
-void k_gather_accepted(int64_t n_reads, int reads_per_tile, int64_t first_read, const uint32_t *__restrict__ info, const int32_t *__restrict__ ref_tx,
+void k_gather_accepted(const uint32_t *__restrict__ tile_first, int64_t first_read, const uint32_t *__restrict__ info, const int32_t *__restrict__ ref_tx,
                        const uint32_t *__restrict__ ex_off, const int32_t *__restrict__ ex_start, const int32_t *__restrict__ ex_end,
                        const uint8_t *__restrict__ ex_flag, const uint32_t *__restrict__ tile_reads, const uint32_t *__restrict__ tile_exons,
                        uint32_t *__restrict__ tile_chunk, const uint32_t *__restrict__ chunk_cursor,
@@ -1547,8 +1552,9 @@ void k_gather_accepted(int64_t n_reads, int reads_per_tile, int64_t first_read, 
 {
     __shared__ uint32_t s_wcnt[4], s_wex[4];
     __shared__ uint16_t s_map[LDS_EXON_CAP];
-    const int64_t r = (int64_t)blockIdx.x * reads_per_tile + threadIdx.x;
-    const bool active = (int)threadIdx.x < reads_per_tile && r < n_reads;
+    const uint32_t r0 = tile_first[blockIdx.x], n_act = tile_first[blockIdx.x + 1] - r0;
+    const int64_t r = (int64_t)r0 + threadIdx.x;
+    const bool active = threadIdx.x < n_act;
     const uint32_t w = active ? info[r] : 0u;
     const bool acc = (w & I_ACCEPT) != 0;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
@@ -1568,7 +1574,7 @@ void k_gather_accepted(int64_t n_reads, int reads_per_tile, int64_t first_read, 
     }
     uint32_t cb = 0, eb = 0;
     for (int k = 0; k < wv; ++k) { cb += s_wcnt[k]; eb += s_wex[k]; }
-    const uint32_t src0 = ex_off[(int64_t)blockIdx.x * reads_per_tile];      // first exon of the tile
+    const uint32_t src0 = n_act ? ex_off[r0] : 0u;                            // first exon of the tile
     const uint32_t e_loc = eb + inc - nex;                                    // tile-local compacted exon offset
     const bool mapped = e_tot <= (uint32_t)LDS_EXON_CAP;
     if (acc) {
