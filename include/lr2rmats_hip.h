@@ -138,11 +138,12 @@ typedef struct {
     const uint8_t *ex_flag;
     const uint32_t *info;
     const int32_t *ref_tx;
-    /* Accepted list in HBM.  acc_rec / acc_ex_off: one entry per accepted read, in read order; record i has
-     * info >> 8 exons starting at acc_ex_off[i] in the three exon arrays.  The exon arrays hold n_accepted_exons
-     * entries and no gaps, but they are a sequence of per-tile chunks in the order the kernels handed the chunks
-     * out, so acc_ex_off is NOT increasing: always address through it (l2r_download_accepted() lays the exons out
-     * record by record for the caller). */
+    /* Accepted list in HBM.  acc_rec / acc_ex_off: one entry per accepted read; record i has info >> 8 exons starting
+     * at acc_ex_off[i] in the three exon arrays.  All five arrays are dense (n_accepted / n_accepted_exons entries, no
+     * gaps) but made of one CHUNK PER TILE of reads: inside a chunk the reads are in read order, the chunks follow each
+     * other in the order the kernels handed them out.  A consumer that needs read order sorts by the 64-bit read index
+     * of the records (l2r_download_accepted() does, and lays the exons out record by record); always address the exon
+     * arrays through acc_ex_off. */
     const l2r_accepted_read *acc_rec;
     const uint32_t *acc_ex_off;     /* device, n_accepted */
     const int32_t *acc_ex_start, *acc_ex_end;

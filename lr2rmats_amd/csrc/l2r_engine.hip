@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "../../include/lr2rmats_hip.h"
@@ -86,7 +87,7 @@ struct l2r_ctx {
     bool have_win = false;
     // work + results
     int64_t n_tiles = 0, n_tiles256 = 0;
-    DevBuf<uint32_t> local, tile_base, ex_off, info, tile_acc, tile_acc_ex, tile_chunk, totals;  // totals[0]=exons [1]=accepted [2]=accepted exons [3]=redo count [4]=accepted-exon chunk cursor
+    DevBuf<uint32_t> local, tile_base, ex_off, info, tile_acc, tile_acc_ex, tile_chunk, tile_rchunk, totals;  // totals[0]=exons [1]=accepted [2]=accepted exons [3]=redo count [4],[5]=chunk cursor of the accepted list (one 64-bit word: exon slot low, record slot high)
     DevBuf<uint32_t> redo;                  // reads the fast kernel hands to the generic one
     DevBuf<uint8_t> order;                  // per tile: reads by falling exon count (pass A)
     DevBuf<TileDesc> desc;
@@ -173,7 +174,7 @@ void l2r_destroy(l2r_ctx *c)
     c->sj_tid.release(); c->sj_don.release(); c->sj_acc.release(); c->sj_uniq.release(); c->sj_multi.release(); c->sj_key.release();
     c->r_tid.release(); c->r_pos.release(); c->r_rev.release(); c->cig_off.release(); c->cig.release();
     c->win_start.release(); c->sj_cursor.release();
-    c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->totals.release();
+    c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -523,7 +524,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     if (c->j0.ensure((size_t)N) || c->local.ensure((size_t)N + 1) || c->ex_off.ensure((size_t)N) || c->info.ensure((size_t)N) || c->ref_tx.ensure((size_t)N) ||
         c->redo.ensure((size_t)N) || c->order.ensure((size_t)N + TILE_THREADS) || c->desc.ensure((size_t)c->n_tiles) || c->win_hdr.ensure((size_t)c->n_tiles * WIN_TX) ||
         c->tile_base.ensure((size_t)c->n_tiles + 1) || c->tile_acc.ensure((size_t)c->n_tiles + 1) || c->tile_acc_ex.ensure((size_t)c->n_tiles + 1) ||
-        c->totals.ensure(8) || c->tile_chunk.ensure((size_t)c->n_tiles + 1) || c->ex_start.ensure(exb) || c->ex_end.ensure(exb) || c->ex_flag.ensure(exb) ||
+        c->totals.ensure(8) || c->tile_chunk.ensure((size_t)c->n_tiles + 1) || c->tile_rchunk.ensure((size_t)c->n_tiles + 1) || c->ex_start.ensure(exb) || c->ex_end.ensure(exb) || c->ex_flag.ensure(exb) ||
         c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
         c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb)) return -2;
     c->ex_cap = (int64_t)exb;
@@ -618,7 +619,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         fa.hdr = c->hdr.p; fa.st = tabs.st; fa.en = tabs.en;
         fa.ex_off = c->ex_off.p; fa.ex_start = c->ex_start.p; fa.ex_end = c->ex_end.p; fa.ex_flag = c->ex_flag.p; fa.info = c->info.p; fa.ref_tx = c->ref_tx.p;
         fa.tile_acc = c->tile_acc.p; fa.tile_acc_ex = c->tile_acc_ex.p; fa.redo_count = c->totals.p + 3; fa.redo = c->redo.p;
-        fa.tile_chunk = c->tile_chunk.p; fa.chunk_cursor = c->totals.p + 4; fa.acc_start = c->acc_start.p; fa.acc_end = c->acc_end.p; fa.acc_flag = c->acc_flag.p;
+        fa.tile_chunk = c->tile_chunk.p; fa.tile_rchunk = c->tile_rchunk.p; fa.chunk_cursor = (unsigned long long *)(c->totals.p + 4);
+        fa.acc_start = c->acc_start.p; fa.acc_end = c->acc_end.p; fa.acc_flag = c->acc_flag.p; fa.acc_rec = (AccRec *)c->acc_rec.p; fa.acc_ex_off = c->acc_ex_off.p; fa.first_read = c->first_read;
         fa.stamps = c->stamps.p; fa.p = p;
         // persistent grid: a few workgroups per CU walk over the tiles (l2r_kernels.hip.h)
         unsigned gp = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * c->wg_per_cu);
@@ -655,7 +657,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     }
     MARK(ST_GATHER);
     hipLaunchKernelGGL(k_gather_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->first_read, c->info.p, c->ref_tx.p, c->ex_off.p,
-                       c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->tile_acc.p, c->tile_acc_ex.p, c->tile_chunk.p, c->totals.p + 4,
+                       c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->tile_acc.p, c->tile_acc_ex.p, c->tile_chunk.p, c->tile_rchunk.p, c->totals.p + 4,
                        c->acc_rec.p, c->acc_ex_off.p, c->acc_start.p, c->acc_end.p, c->acc_flag.p);
     MARK(ST_N);
 #undef MARK
@@ -736,11 +738,11 @@ static int fetch_totals(l2r_ctx *c)
 {
     if (!c->ran) return fail(-1, "no completed run on this context");
     if (c->totals_valid) return 0;
-    uint32_t dev[5];
+    uint32_t dev[6];
     HIP_TRY(hipMemcpyAsync(dev, c->totals.p, sizeof dev, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     // accepted exons = the chunks the classification kernel placed itself (cursor) + the ones k_gather_accepted placed
-    c->h_totals[0] = dev[0]; c->h_totals[1] = dev[1]; c->h_totals[2] = dev[2] + dev[4];
+    c->h_totals[0] = dev[0]; c->h_totals[1] = dev[1] + dev[5]; c->h_totals[2] = dev[2] + dev[4];
     c->totals_valid = true;
     return 0;
 }
@@ -822,14 +824,17 @@ int l2r_download_accepted(l2r_ctx *c, l2r_accepted *a)
     if (rc) return rc;
     const int64_t M = c->h_totals[1], X = c->h_totals[2];
     if (a->n_reads < M || a->ex_cap < X) return fail(-3, "[l2r_download_accepted] buffers too small: need %lld records, %lld exons", (long long)M, (long long)X);
-    // On the device the exon arrays are a sequence of per-tile chunks in arbitrary order (see k_gather_accepted); the
-    // caller's buffers receive them record by record, so that ex_off is the usual running sum.
-    std::vector<uint32_t> off((size_t)M);
+    // On the device the list is a sequence of per-tile chunks in the order they were handed out (see k_gather_accepted):
+    // the chunks are put into read order here (each is in read order inside; they are told apart by the first-record
+    // slots the tiles left in tile_rchunk) and the exons laid out record by record, so that ex_off is the running sum.
+    std::vector<AccRec> rec((size_t)M);
+    std::vector<uint32_t> off((size_t)M), starts((size_t)c->n_tiles);
     std::vector<int32_t> xs((size_t)X), xe((size_t)X);
     std::vector<uint8_t> xf((size_t)X);
     if (M) {
-        HIP_TRY(hipMemcpyAsync(a->rec, c->acc_rec.p, (size_t)M * sizeof(AccRec), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(rec.data(), c->acc_rec.p, (size_t)M * sizeof(AccRec), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(off.data(), c->acc_ex_off.p, (size_t)M * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(starts.data(), c->tile_rchunk.p, (size_t)c->n_tiles * 4, hipMemcpyDeviceToHost, c->stream));
     }
     if (X) {
         HIP_TRY(hipMemcpyAsync(xs.data(), c->acc_start.p, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
@@ -837,15 +842,32 @@ int l2r_download_accepted(l2r_ctx *c, l2r_accepted *a)
         HIP_TRY(hipMemcpyAsync(xf.data(), c->acc_flag.p, (size_t)X, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    int64_t at = 0;
-    for (int64_t i = 0; i < M; ++i) {
-        const int64_t n = (int64_t)(a->rec[i].info >> 8), from = off[(size_t)i];
-        if (from + n > X || at + n > X) return fail(-5, "[l2r_download_accepted] inconsistent accepted list");
-        a->ex_off[i] = at;
-        memcpy(a->ex_start + at, xs.data() + from, (size_t)n * 4);
-        memcpy(a->ex_end + at, xe.data() + from, (size_t)n * 4);
-        memcpy(a->ex_flag + at, xf.data() + from, (size_t)n);
-        at += n;
+    int64_t at_r = 0, at = 0;
+    if (M) {
+        // (a tile without accepted reads leaves the slot of some other chunk, 0 or M: duplicates and M drop out)
+        starts.push_back(0u);
+        std::sort(starts.begin(), starts.end());
+        starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
+        while (!starts.empty() && (int64_t)starts.back() >= M) starts.pop_back();
+        std::vector<std::pair<uint64_t, std::pair<uint32_t, uint32_t>>> chunks;        // first read index -> [from, to)
+        for (size_t k = 0; k < starts.size(); ++k) {
+            const uint32_t from = starts[k], to = k + 1 < starts.size() ? starts[k + 1] : (uint32_t)M;
+            chunks.push_back({((uint64_t)rec[from].read_hi << 32) | rec[from].read_lo, {from, to}});
+        }
+        std::sort(chunks.begin(), chunks.end());
+        for (const auto &ch : chunks) {
+            for (uint32_t i = ch.second.first; i < ch.second.second; ++i) {
+                const int64_t n = (int64_t)(rec[i].info >> 8), from = off[i];
+                if (from + n > X || at + n > X || at_r >= M) return fail(-5, "[l2r_download_accepted] inconsistent accepted list");
+                memcpy(&a->rec[at_r], &rec[i], sizeof(AccRec));
+                a->ex_off[at_r] = at;
+                memcpy(a->ex_start + at, xs.data() + from, (size_t)n * 4);
+                memcpy(a->ex_end + at, xe.data() + from, (size_t)n * 4);
+                memcpy(a->ex_flag + at, xf.data() + from, (size_t)n);
+                at += n; ++at_r;
+            }
+        }
+        if (at_r != M) return fail(-5, "[l2r_download_accepted] inconsistent accepted list (%lld of %lld records)", (long long)at_r, (long long)M);
     }
     a->ex_off[M] = at;
     a->n_reads = M; a->n_exons = X;

@@ -284,7 +284,7 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
     const uint32_t r0 = tile_first[blockIdx.x], n_act = tile_first[blockIdx.x + 1] - r0;
     const int64_t r = (int64_t)r0 + threadIdx.x;
     const bool active = threadIdx.x < n_act;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { redo_count[0] = 0u; redo_count[1] = 0u; }   // redo list and accepted-exon cursor: the kernels that fill them run after this one
+    if (blockIdx.x == 0 && threadIdx.x == 0) { redo_count[0] = 0u; redo_count[1] = 0u; redo_count[2] = 0u; }   // redo list and accepted-exon cursor: the kernels that fill them run after this one
     uint32_t n = 0;
     int j0 = INT32_MAX, tid = 0, pos = 0, el = 0;
     if (active) {
@@ -755,6 +755,8 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));       // a 16-byte access at any 4-byte boundary (global memory)
 typedef uint32_t u32_a1 __attribute__((aligned(1)));                      // a 4-byte access at any address (global memory)    // LDS copy of a dictionary entry {k1, k2, pm, sm}, masks in the tile frame
 
+struct AccRec { uint32_t read_lo, read_hi, info; int32_t ref_tx; };
+
 struct FastArgs {
     int64_t n_reads;
     const int32_t *r_tid; const int32_t *r_pos; const uint8_t *r_rev; const int64_t *cig_off; const uint32_t *cig;
@@ -763,8 +765,9 @@ struct FastArgs {
     const TxHdr *hdr; SiteDict st, en;
     uint32_t *ex_off; int32_t *ex_start; int32_t *ex_end; uint8_t *ex_flag; uint32_t *info; int32_t *ref_tx;
     uint32_t *tile_acc, *tile_acc_ex; uint32_t *redo_count, *redo;
-    uint32_t *tile_chunk, *chunk_cursor;          // accepted exons: first slot per tile / next free slot
-    int32_t *acc_start, *acc_end; uint8_t *acc_flag;
+    uint32_t *tile_chunk, *tile_rchunk;           // accepted list: first exon slot / first record slot of every tile's chunk
+    unsigned long long *chunk_cursor;             // next free {record slot (high word), exon slot (low word)}
+    int32_t *acc_start, *acc_end; uint8_t *acc_flag; AccRec *acc_rec; uint32_t *acc_ex_off; int64_t first_read;
     unsigned long long *stamps;
     DevParams p;
 };
@@ -1175,7 +1178,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
     __shared__ uint32_t s_cnt[4][3];
     __shared__ int s_wide;                                          // some staged entry has members beyond its 64-bit masks
     __shared__ uint16_t s_nat[TILE_THREADS];                        // per read of the tile in READ order: exon count, bit 15 = accepted
-    __shared__ uint32_t s_chunk;
+    __shared__ uint32_t s_chunk[2];
 
     (void)kernarg_block;
     const bool stamping = fast_args()->stamps != nullptr;
@@ -1339,12 +1342,14 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         const FastArgsK ao = fast_args();
         // the output pointers of the rest of the tile, fetched from the argument block in one go (see load_vectors)
         uint32_t *const o_redo_count = ao->redo_count, *const o_redo = ao->redo, *const o_tile_acc = ao->tile_acc, *const o_tile_acc_ex = ao->tile_acc_ex;
-        uint32_t *const o_tile_chunk = ao->tile_chunk, *const o_cursor = ao->chunk_cursor, *const o_ex_off = ao->ex_off, *const o_info = ao->info;
+        uint32_t *const o_tile_chunk = ao->tile_chunk, *const o_tile_rchunk = ao->tile_rchunk, *const o_ex_off = ao->ex_off, *const o_info = ao->info, *const o_acc_ex_off = ao->acc_ex_off;
+        unsigned long long *const o_cursor = ao->chunk_cursor; AccRec *const o_acc_rec = ao->acc_rec; const int64_t o_first_read = ao->first_read;
         int32_t *const o_ex_start = ao->ex_start, *const o_ex_end = ao->ex_end, *const o_ref = ao->ref_tx, *const o_acc_start = ao->acc_start, *const o_acc_end = ao->acc_end;
         uint8_t *const o_ex_flag = ao->ex_flag, *const o_acc_flag = ao->acc_flag;
         const int32_t o_n_sj = ao->p.n_sj, o_ablate = ao->p.ablate;
         asm volatile("" :: "s"(o_redo_count), "s"(o_redo), "s"(o_tile_acc), "s"(o_tile_acc_ex), "s"(o_tile_chunk), "s"(o_cursor), "s"(o_ex_off), "s"(o_info),
-                     "s"(o_ex_start), "s"(o_ex_end), "s"(o_ref), "s"(o_acc_start), "s"(o_acc_end), "s"(o_ex_flag), "s"(o_acc_flag), "s"(o_n_sj), "s"(o_ablate));
+                     "s"(o_ex_start), "s"(o_ex_end), "s"(o_ref), "s"(o_acc_start), "s"(o_acc_end), "s"(o_ex_flag), "s"(o_acc_flag), "s"(o_n_sj), "s"(o_ablate),
+                     "s"(o_tile_rchunk), "s"(o_acc_ex_off), "s"(o_acc_rec), "s"(o_first_read));
         {
             const unsigned long long m = __ballot(redo);
             if (m) {
@@ -1367,28 +1372,33 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         // every verdict of the tile is final here: no read on the redo list, no junction table (k_validate_sj decides).
         const uint32_t ca_t = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0], cx_t = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
         const bool fused = in_lds && (s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2]) == 0u && o_n_sj == 0 && !(o_ablate & 2);
-        uint32_t chunk = 0u;
+        unsigned long long chunk = 0ull;               // {first record slot, first exon slot} of the tile's chunk
         if (threadIdx.x == 0) {
-            o_tile_acc[t] = ca_t;
-            o_tile_acc_ex[t] = fused ? 0u : cx_t;       // exons that k_gather_accepted has to place
+            o_tile_acc[t] = fused ? 0u : ca_t;          // what k_gather_accepted has to place: reads ...
+            o_tile_acc_ex[t] = fused ? 0u : cx_t;       // ... and exons
             if (!fused) o_tile_chunk[t] = CHUNK_DEFERRED;
-            else if (cx_t) chunk = atomicAdd(o_cursor, cx_t);          // (answer needed after the write-out below)
+            else if (ca_t) chunk = atomicAdd(o_cursor, ((unsigned long long)ca_t << 32) | cx_t);      // (answer needed after the write-out below)
         }
         uint16_t *const s_map = reinterpret_cast<uint16_t *>(s_ent0);           // the dictionary slices are dead by now
-        if (fused && cx_t) {
+        uint32_t *const s_rk = reinterpret_cast<uint32_t *>(s_map + LDS_EXON_CAP);   // per read of the tile: rank among the accepted | exon offset << 16
+        if (fused && ca_t) {
             // thread i takes read i of the tile (reads are spread over the threads in pass A's order): exclusive sums
-            // of {all exons, accepted exons} over the reads before it, both below 2^16, packed in one word
+            // of {all exons, accepted exons} over the reads before it, both below 2^16, packed in one word; accepted reads before it
             const uint32_t n_act = u.n_act;
             const uint32_t w16 = threadIdx.x < n_act ? (uint32_t)s_nat[threadIdx.x] : 0u;
             const uint32_t nn = w16 & 0x7fffu, pk = nn | ((w16 >> 15) ? nn << 16 : 0u);
+            const unsigned long long am = __ballot((w16 >> 15) != 0u);
             uint32_t before = wave_inclusive_scan(pk) - pk;
+            uint32_t rank = (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
             for (int k = 0; k < wv; ++k) {
                 const uint32_t idx = (uint32_t)(k * WAVE + lane);
                 const uint32_t z = idx < n_act ? (uint32_t)s_nat[idx] : 0u, zn = z & 0x7fffu;
                 before += wave_sum(zn | ((z >> 15) ? zn << 16 : 0u));
+                rank += (uint32_t)__popcll(__ballot((z >> 15) != 0u));
             }
             if (w16 >> 15) {
                 const uint32_t from = before & 0xffffu, to = before >> 16;
+                s_rk[threadIdx.x] = rank | (to << 16);
                 for (uint32_t k = 0; k < nn; ++k) s_map[to + k] = (uint16_t)(from + k);
             }
         }
@@ -1405,10 +1415,21 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
             o_ref[r] = ref;
         }
         if (fused) {
-            if (threadIdx.x == 0) { s_chunk = chunk; o_tile_chunk[t] = chunk; }
-            if (cx_t) {
+            if (threadIdx.x == 0) {
+                s_chunk[0] = (uint32_t)chunk; s_chunk[1] = (uint32_t)(chunk >> 32);
+                o_tile_chunk[t] = (uint32_t)chunk; o_tile_rchunk[t] = (uint32_t)(chunk >> 32);
+            }
+            if (ca_t) {
                 __syncthreads();
-                const uint32_t to = s_chunk;
+                const uint32_t to = s_chunk[0], to_r = s_chunk[1];
+                if (info & I_ACCEPT) {          // the record of the thread's own read
+                    const uint32_t rk = s_rk[u.src];
+                    const uint32_t slot = to_r + (rk & 0xffffu);
+                    const uint64_t gidx = (uint64_t)(o_first_read + (int64_t)r);
+                    AccRec a; a.read_lo = (uint32_t)gidx; a.read_hi = (uint32_t)(gidx >> 32); a.info = info; a.ref_tx = ref;
+                    o_acc_rec[slot] = a;
+                    o_acc_ex_off[slot] = to + (rk >> 16);
+                }
                 uint32_t q = threadIdx.x < cx_t ? (uint32_t)s_map[threadIdx.x] : 0u;
                 for (uint32_t i = threadIdx.x; i < cx_t; i += TILE_THREADS) {
                     const uint32_t i_next = i + TILE_THREADS;                    // its map entry travels while this one is copied
@@ -1531,27 +1552,29 @@ void k_count_accepted(const uint32_t *__restrict__ tile_first, const uint32_t *_
     }
 }
 
-struct AccRec { uint32_t read_lo, read_hi, info; int32_t ref_tx; };
 
-// Accepted records in read order (tile_reads = exclusive scan of the per-tile counts, n_tiles + 1 words), each with the
-// offset of its exons in the accepted exon arrays.  Those arrays are made of one chunk per tile, the reads of a chunk in
-// read order, the chunks in the order an atomic cursor handed them out.  Most chunks were filled by k_classify_fast
-// from its LDS image (tile_chunk[tile] = first slot); a tile marked CHUNK_DEFERRED gets its chunk here (tile_exons =
-// exclusive scan of the deferred tiles' accepted exon counts; the chunks follow the cursor's final value):
-// every accepted read writes, for each of its exons, the source position into an LDS map at the exon's compacted
-// slot; the tile then copies slot by slot, so the stores are contiguous and the loads run over contiguous pieces.
+// The accepted list: records {read index, info, ref_tx} + the offset of the read's exons, and the exon arrays themselves.
+// Both are made of one chunk per tile -- the reads of a chunk in read order, the chunks in the order they were handed
+// out -- so a consumer that needs read order sorts the chunks by their first record (l2r_download_accepted does).
+// Most chunks are written by k_classify_fast from its LDS image (tile_rchunk / tile_chunk = first record / exon slot,
+// taken from an atomic cursor).  A tile it marked CHUNK_DEFERRED (a read on the redo list, or a junction table:
+// acceptance is decided after it) gets its chunk here, behind the cursor's final value, in tile order among the
+// deferred ones (tile_reads / tile_exons = exclusive scans of their counts): every accepted read writes, for each of
+// its exons, the source position into an LDS map at the exon's compacted slot; the tile then copies slot by slot, so
+// the stores are contiguous and the loads run over contiguous pieces.
 constexpr uint32_t MAP_DIRECT = 0xffffu;      // map entry of an exon that its read has copied itself
 
 __global__ __launch_bounds__(TILE_THREADS)
 void k_gather_accepted(const uint32_t *__restrict__ tile_first, int64_t first_read, const uint32_t *__restrict__ info, const int32_t *__restrict__ ref_tx,
                        const uint32_t *__restrict__ ex_off, const int32_t *__restrict__ ex_start, const int32_t *__restrict__ ex_end,
                        const uint8_t *__restrict__ ex_flag, const uint32_t *__restrict__ tile_reads, const uint32_t *__restrict__ tile_exons,
-                       uint32_t *__restrict__ tile_chunk, const uint32_t *__restrict__ chunk_cursor,
+                       uint32_t *__restrict__ tile_chunk, uint32_t *__restrict__ tile_rchunk, const uint32_t *__restrict__ chunk_cursor /* {exons, records} */,
                        AccRec *__restrict__ rec, uint32_t *__restrict__ acc_ex_off, int32_t *__restrict__ acc_start,
                        int32_t *__restrict__ acc_end, uint8_t *__restrict__ acc_flag)
 {
     __shared__ uint32_t s_wcnt[4], s_wex[4];
     __shared__ uint16_t s_map[LDS_EXON_CAP];
+    if (tile_chunk[blockIdx.x] != CHUNK_DEFERRED) return;          // (workgroup-uniform)
     const uint32_t r0 = tile_first[blockIdx.x], n_act = tile_first[blockIdx.x + 1] - r0;
     const int64_t r = (int64_t)r0 + threadIdx.x;
     const bool active = threadIdx.x < n_act;
@@ -1563,15 +1586,10 @@ void k_gather_accepted(const uint32_t *__restrict__ tile_first, int64_t first_re
     const uint32_t nex = acc ? (w >> 8) : 0u;
     const uint32_t inc = wave_inclusive_scan(nex);
     if (lane == WAVE - 1) { s_wcnt[wv] = (uint32_t)__popcll(m); s_wex[wv] = inc; }
+    const uint32_t ebase0 = chunk_cursor[0] + tile_exons[blockIdx.x], cbase0 = chunk_cursor[1] + tile_reads[blockIdx.x];
     __syncthreads();
-    const uint32_t cbase0 = tile_reads[blockIdx.x];
     const uint32_t e_tot = s_wex[0] + s_wex[1] + s_wex[2] + s_wex[3];        // accepted exons of the tile
-    uint32_t ebase0 = tile_chunk[blockIdx.x];
-    const bool deferred = ebase0 == CHUNK_DEFERRED;
-    if (deferred) {          // behind every chunk of the classification kernel, in tile order among the deferred ones
-        ebase0 = *chunk_cursor + tile_exons[blockIdx.x];
-        if (threadIdx.x == 0) tile_chunk[blockIdx.x] = ebase0;
-    }
+    if (threadIdx.x == 0) { tile_chunk[blockIdx.x] = ebase0; tile_rchunk[blockIdx.x] = cbase0; }
     uint32_t cb = 0, eb = 0;
     for (int k = 0; k < wv; ++k) { cb += s_wcnt[k]; eb += s_wex[k]; }
     const uint32_t src0 = n_act ? ex_off[r0] : 0u;                            // first exon of the tile
@@ -1584,20 +1602,18 @@ void k_gather_accepted(const uint32_t *__restrict__ tile_first, int64_t first_re
         AccRec a; a.read_lo = (uint32_t)gidx; a.read_hi = (uint32_t)(gidx >> 32); a.info = w; a.ref_tx = ref_tx[r];
         rec[slot] = a;
         acc_ex_off[slot] = ebase0 + e_loc;
-        if (deferred) {
-            if (mapped && src - src0 + nex < MAP_DIRECT) {
-                for (uint32_t k = 0; k < nex; ++k) s_map[e_loc + k] = (uint16_t)(src - src0 + k);
-            } else {
-                for (uint32_t k = 0; k < nex; ++k) {
-                    if (mapped) s_map[e_loc + k] = (uint16_t)MAP_DIRECT;
-                    acc_start[ebase0 + e_loc + k] = ex_start[src + k];
-                    acc_end[ebase0 + e_loc + k] = ex_end[src + k];
-                    acc_flag[ebase0 + e_loc + k] = ex_flag[src + k];
-                }
+        if (mapped && src - src0 + nex < MAP_DIRECT) {
+            for (uint32_t k = 0; k < nex; ++k) s_map[e_loc + k] = (uint16_t)(src - src0 + k);
+        } else {
+            for (uint32_t k = 0; k < nex; ++k) {
+                if (mapped) s_map[e_loc + k] = (uint16_t)MAP_DIRECT;
+                acc_start[ebase0 + e_loc + k] = ex_start[src + k];
+                acc_end[ebase0 + e_loc + k] = ex_end[src + k];
+                acc_flag[ebase0 + e_loc + k] = ex_flag[src + k];
             }
         }
     }
-    if (!deferred || !mapped) return;
+    if (!mapped) return;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < e_tot; i += TILE_THREADS) {
         const uint32_t q = s_map[i];
