@@ -411,10 +411,12 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
     }
 }
 
-// In-place exclusive scan of v[0..n) by ONE workgroup of 1024 threads, 4 elements per thread and round;
+// In-place exclusive scan of v[0..n) by ONE workgroup of 1024 threads, 16 consecutive elements per thread and round (four
+// 16-byte loads in flight together: the kernel is a chain of load -> scan -> store round trips, so fewer, wider rounds);
 // v[n] receives the sum (the array has n + 1 words) and so does *total.  blockIdx.x selects the array.
 struct ScanJob { uint32_t *v; int64_t n; uint32_t *total; };
 struct ScanJobs { ScanJob job[2]; };
+constexpr int SCAN_PER_THREAD = 16;
 
 __global__ __launch_bounds__(1024)
 void k_scan_u32(ScanJobs jobs)
@@ -426,12 +428,22 @@ void k_scan_u32(ScanJobs jobs)
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    for (int64_t base = 0; base < n; base += 4096) {
-        const int64_t i = base + 4 * (int64_t)threadIdx.x;
-        uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;
-        if (i + 3 < n) { const uint4 q = *reinterpret_cast<const uint4 *>(v + i); x0 = q.x; x1 = q.y; x2 = q.z; x3 = q.w; }
-        else { if (i < n) x0 = v[i]; if (i + 1 < n) x1 = v[i + 1]; if (i + 2 < n) x2 = v[i + 2]; }
-        const uint32_t mine = x0 + x1 + x2 + x3;
+    for (int64_t base = 0; base < n; base += 1024 * SCAN_PER_THREAD) {
+        const int64_t i = base + SCAN_PER_THREAD * (int64_t)threadIdx.x;
+        uint32_t x[SCAN_PER_THREAD];
+        if (i + SCAN_PER_THREAD <= n) {
+#pragma unroll
+            for (int q = 0; q < SCAN_PER_THREAD / 4; ++q) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(v + i + 4 * q);
+                x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < SCAN_PER_THREAD; ++q) x[q] = i + q < n ? v[i + q] : 0u;
+        }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < SCAN_PER_THREAD; ++q) { const uint32_t t = x[q]; x[q] = mine; mine += t; }      // x: exclusive inside the thread
         const uint32_t inc = wave_inclusive_scan(mine);
         if (lane == WAVE - 1) s_wave[w] = inc;
         __syncthreads();
@@ -439,9 +451,15 @@ void k_scan_u32(ScanJobs jobs)
 #pragma unroll
         for (int k = 0; k < 16; ++k) { const uint32_t t = s_wave[k]; if (k < w) wbase += t; tot += t; }
         const uint32_t carry = s_carry;
-        const uint32_t e0 = carry + wbase + inc - mine, e1 = e0 + x0, e2 = e1 + x1, e3 = e2 + x2;
-        if (i + 3 < n) *reinterpret_cast<uint4 *>(v + i) = make_uint4(e0, e1, e2, e3);
-        else { if (i < n) v[i] = e0; if (i + 1 < n) v[i + 1] = e1; if (i + 2 < n) v[i + 2] = e2; }
+        const uint32_t e0 = carry + wbase + inc - mine;
+        if (i + SCAN_PER_THREAD <= n) {
+#pragma unroll
+            for (int q = 0; q < SCAN_PER_THREAD / 4; ++q)
+                *reinterpret_cast<uint4 *>(v + i + 4 * q) = make_uint4(e0 + x[4 * q], e0 + x[4 * q + 1], e0 + x[4 * q + 2], e0 + x[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < SCAN_PER_THREAD; ++q) if (i + q < n) v[i + q] = e0 + x[q];
+        }
         __syncthreads();
         if (threadIdx.x == 0) s_carry = carry + tot;
         __syncthreads();
