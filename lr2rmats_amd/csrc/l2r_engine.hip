@@ -91,6 +91,7 @@ struct l2r_ctx {
     DevBuf<uint32_t> redo;                  // reads the fast kernel hands to the generic one
     DevBuf<uint8_t> order;                  // per tile: reads by falling exon count (pass A)
     DevBuf<TileDesc> desc;
+    DevBuf<int2> walked;               // long-CIGAR inputs: exons walked by pass A (n_cigar + n_reads slots)
     DevBuf<uint32_t> tile_first;       // first read of every tile (+ one closing entry)
     DevBuf<TxHdr> win_hdr;             // WIN_TX window headers per tile (pass A)
     DevBuf<int32_t> ex_start, ex_end, ref_tx;
@@ -174,7 +175,7 @@ void l2r_destroy(l2r_ctx *c)
     c->sj_tid.release(); c->sj_don.release(); c->sj_acc.release(); c->sj_uniq.release(); c->sj_multi.release(); c->sj_key.release();
     c->r_tid.release(); c->r_pos.release(); c->r_rev.release(); c->cig_off.release(); c->cig.release();
     c->win_start.release(); c->sj_cursor.release();
-    c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
+    c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -526,7 +527,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         c->tile_base.ensure((size_t)c->n_tiles + 1) || c->tile_acc.ensure((size_t)c->n_tiles + 1) || c->tile_acc_ex.ensure((size_t)c->n_tiles + 1) ||
         c->totals.ensure(8) || c->tile_chunk.ensure((size_t)c->n_tiles + 1) || c->tile_rchunk.ensure((size_t)c->n_tiles + 1) || c->ex_start.ensure(exb) || c->ex_end.ensure(exb) || c->ex_flag.ensure(exb) ||
         c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
-        c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb)) return -2;
+        c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb) || (c->wide_cigar && c->walked.ensure(exb))) return -2;
     c->ex_cap = (int64_t)exb;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (getenv("L2R_STAMPS") && !c->stamps.p) {
@@ -601,11 +602,11 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     if (c->wide_cigar)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass_a<true>), dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, tabs, p,
                            (c->sorted ? (const int32_t *)nullptr : (const int32_t *)c->win_start.p), c->j0.p, c->local.p, c->order.p, c->tile_base.p, c->desc.p,
-                           c->totals.p + 3, (const TxHdr *)c->hdr.p, c->win_hdr.p, (const uint32_t *)c->tile_first.p);
+                           c->totals.p + 3, (const TxHdr *)c->hdr.p, c->win_hdr.p, (const uint32_t *)c->tile_first.p, c->walked.p);
     else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass_a<false>), dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, tabs, p,
                        (c->sorted ? (const int32_t *)nullptr : (const int32_t *)c->win_start.p), c->j0.p, c->local.p, c->order.p, c->tile_base.p, c->desc.p,
-                       c->totals.p + 3, (const TxHdr *)c->hdr.p, c->win_hdr.p, (const uint32_t *)c->tile_first.p);
+                       c->totals.p + 3, (const TxHdr *)c->hdr.p, c->win_hdr.p, (const uint32_t *)c->tile_first.p, c->walked.p);
     MARK(ST_SCAN1);
     {
         ScanJobs jobs; jobs.job[0] = ScanJob{c->tile_base.p, c->n_tiles, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
@@ -615,7 +616,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     {
         FastArgs fa;
         fa.n_reads = N; fa.r_tid = c->r_tid.p; fa.r_pos = c->r_pos.p; fa.r_rev = c->r_rev.p; fa.cig_off = c->cig_off.p; fa.cig = c->cig.p;
-        fa.local = c->local.p; fa.order = c->order.p; fa.tile_base = c->tile_base.p; fa.j0 = j0; fa.desc = c->desc.p; fa.win_hdr = c->win_hdr.p;
+        fa.walked = c->walked.p; fa.local = c->local.p; fa.order = c->order.p; fa.tile_base = c->tile_base.p; fa.j0 = j0; fa.desc = c->desc.p; fa.win_hdr = c->win_hdr.p;
         fa.hdr = c->hdr.p; fa.st = tabs.st; fa.en = tabs.en;
         fa.ex_off = c->ex_off.p; fa.ex_start = c->ex_start.p; fa.ex_end = c->ex_end.p; fa.ex_flag = c->ex_flag.p; fa.info = c->info.p; fa.ref_tx = c->ref_tx.p;
         fa.tile_acc = c->tile_acc.p; fa.tile_acc_ex = c->tile_acc_ex.p; fa.redo_count = c->totals.p + 3; fa.redo = c->redo.p;

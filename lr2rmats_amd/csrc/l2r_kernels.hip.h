@@ -213,6 +213,7 @@ __device__ __forceinline__ int walk_cigar(Ptr cig, int n_cig, int pos0, const De
 
 // The first WALK_HEAD ops of a read, fetched ahead of use (pass A issues them together with its cursor lookup).
 // Words behind the read's last op become "I, length 0", which changes nothing (the array is padded by four words).
+constexpr int WALK_SLAB = 12;             // long-CIGAR pass A: exons per read staged in LDS before they go to HBM
 constexpr int WALK_HEAD = 16;
 struct CigarHead { uint32_t c[WALK_HEAD]; };
 __device__ __forceinline__ CigarHead load_cigar_head(const uint32_t *__restrict__ cig, int n_cig)
@@ -273,12 +274,14 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
               const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ cig, CursorDir cd, SiteTabs tabs, DevParams p,
               const int32_t *__restrict__ j0_in, int32_t *__restrict__ j0_out, uint32_t *__restrict__ local_out,
               uint8_t *__restrict__ order_out, uint32_t *__restrict__ tile_sum, TileDesc *__restrict__ desc, uint32_t *__restrict__ redo_count,
-              const TxHdr *__restrict__ hdr, TxHdr *__restrict__ win_hdr, const uint32_t *__restrict__ tile_first)
+              const TxHdr *__restrict__ hdr, TxHdr *__restrict__ win_hdr, const uint32_t *__restrict__ tile_first,
+              int2 *__restrict__ walked /* WIDE: the exons of every read, at slot cig_off[r] + r + k */)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ int s_red[4][6];
     __shared__ int s_tid0;
     __shared__ uint32_t s_hist[WAVE];
+    __shared__ int2 s_slab[WIDE ? WALK_SLAB * TILE_THREADS : 1];
     if (threadIdx.x < WAVE) s_hist[threadIdx.x] = 0u;
     // tile = reads [tile_first[b], tile_first[b + 1]): at most reads_per_tile of them, of one chromosome when the input is sorted
     const uint32_t r0 = tile_first[blockIdx.x], n_act = tile_first[blockIdx.x + 1] - r0;
@@ -295,7 +298,21 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
         if (j0_in) j0 = j0_in[r];
         else { j0 = cursor_value(cd, tid, pos + 1); j0_out[r] = j0; }       // first exon always starts at pos + 1
         el = pos;
-        n = (uint32_t)walk_cigar_headed<WIDE>(head, cig + c_a, (int)(c_b - c_a), pos, p, [&](int, int, int e) { el = e; });
+        if (WIDE) {
+            // long CIGARs: the classification kernel shall not read them again (they are 10-50 times the bytes of the
+            // exons they describe); the exons are left at a slot that needs no scan: a read has at most ops + 1 of them
+            // (a store per CIGAR step with the few lanes that cut there would cost more than the walk: the first
+            //  WALK_SLAB exons of a read wait in LDS, exon-major, and leave with full waves)
+            int2 *const out = walked + (c_a + r);
+            n = (uint32_t)walk_cigar_headed<WIDE>(head, cig + c_a, (int)(c_b - c_a), pos, p, [&](int k, int s, int e) {
+                if (k < WALK_SLAB) s_slab[k * TILE_THREADS + (int)threadIdx.x] = make_int2(s, e); else out[k] = make_int2(s, e);
+                el = e;
+            });
+            const int n_slab = min((int)n, WALK_SLAB);
+            for (int k = 0; k < n_slab; ++k) out[k] = s_slab[k * TILE_THREADS + (int)threadIdx.x];
+        } else {
+            n = (uint32_t)walk_cigar_headed<WIDE>(head, cig + c_a, (int)(c_b - c_a), pos, p, [&](int, int, int e) { el = e; });
+        }
     }
     if (threadIdx.x == 0) s_tid0 = active ? tid : INT32_MAX;          // (an empty launch has no first read: no chromosome matches)
     uint32_t total;
@@ -778,6 +795,7 @@ struct AccRec { uint32_t read_lo, read_hi, info; int32_t ref_tx; };
 struct FastArgs {
     int64_t n_reads;
     const int32_t *r_tid; const int32_t *r_pos; const uint8_t *r_rev; const int64_t *cig_off; const uint32_t *cig;
+    const int2 *walked;          // long-CIGAR inputs: the exons pass A has walked (slot cig_off[r] + r + k)
     const uint32_t *local; const uint8_t *order; const uint32_t *tile_base; const int32_t *j0; const TileDesc *desc;
     const TxHdr *win_hdr;        // per tile WIN_TX header copies, the annotation index in the spare word (pass A)
     const TxHdr *hdr; SiteDict st, en;
@@ -932,7 +950,7 @@ __device__ __forceinline__ bool cigar_staged(const TileUniforms &u, int region_w
     return n4 <= PF_CIG_VEC * TILE_THREADS && 4 * n4 <= region_words;
 }
 
-__device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, const TileUniforms &u, int region_words)
+__device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, const TileUniforms &u, int region_words, bool want_cigar)
 {
     TileVectors v;
     // every pointer this needs, fetched from the argument block in one go (left to the compiler, each one is loaded
@@ -953,7 +971,7 @@ __device__ __forceinline__ TileVectors load_vectors(FastArgsK a, uint32_t t, con
         v.c_lo = (uint32_t)ld32(p_cig_off, r); v.c_hi = (uint32_t)ld32(p_cig_off, r + 1u);
         v.pos = ld32(p_pos, r); v.tid = ld32(p_tid, r); v.j0 = ld32(p_j0, r); v.rev = ld32(p_rev, r);
     }
-    const bool staged = cigar_staged(u, region_words);
+    const bool staged = want_cigar && cigar_staged(u, region_words);
     const int n4 = cigar_vectors(u);
     const uint4 *src = reinterpret_cast<const uint4 *>(p_cig + (u.c0 & ~3u));
 #pragma unroll
@@ -1208,7 +1226,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
     uint32_t t = blockIdx.x;
     if ((int64_t)t >= n_tiles) return;
     TileUniforms u = load_uniforms(u_desc, u_tile_base, u_cig_off, u_order, u_tile_first, t);
-    TileVectors v = load_vectors(fast_args(), t, u, cigar_room(u));
+    TileVectors v = load_vectors(fast_args(), t, u, cigar_room(u), !WIDE);
     settle_vectors(v);               // (first tile only: every later one is settled in front of its predecessor's write-out)
 
     for (; (int64_t)t < n_tiles; t += gridDim.x) {
@@ -1237,7 +1255,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         const int w_n = fast ? (int)d.n_win : 0;                         // transcripts in the window
 
         // ---- phase 0: the tile's CIGAR words, registers -> LDS
-        const bool staged = cigar_staged(u, tail_words);
+        const bool staged = !WIDE && cigar_staged(u, tail_words);          // (long CIGARs are not read here at all: pass A leaves the exons)
         if (staged) {
             const int n4 = cigar_vectors(u);
             uint4 *dst = reinterpret_cast<uint4 *>(s_cig);
@@ -1264,7 +1282,16 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
                     sane = sane & (s <= e);
                     re.sl = s; re.el = e;
                 };
-                if (staged) walk_cigar<false>(s_cig + (v.c_lo - (u.c0 & ~3u)), n_cig, pos, p, emit);
+                if (WIDE) {
+                    // the exons come from pass A (cig_off[r] + r = c_lo + r: the tile's reads are one shard, 32-bit offsets)
+                    const int2 *const src = a->walked + ((size_t)v.c_lo + (size_t)r);
+                    int k = 0;
+                    for (; k + 4 <= (int)n; k += 4) {
+                        const int2 x0 = src[k], x1 = src[k + 1], x2 = src[k + 2], x3 = src[k + 3];
+                        emit(k, x0.x, x0.y); emit(k + 1, x1.x, x1.y); emit(k + 2, x2.x, x2.y); emit(k + 3, x3.x, x3.y);
+                    }
+                    for (; k < (int)n; ++k) { const int2 x = src[k]; emit(k, x.x, x.y); }
+                } else if (staged) walk_cigar<false>(s_cig + (v.c_lo - (u.c0 & ~3u)), n_cig, pos, p, emit);
                 else walk_cigar<WIDE>(a->cig + v.c_lo, n_cig, pos, p, emit);
                 re.s0 = s_S[local]; re.e0 = s_E[local];
             } else {
@@ -1330,7 +1357,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         __syncthreads();
         const int any_wide = s_wide;             // (cleared at the top of the next tile, two barriers from here)
         // ---- the next tile's vectors start their trip now; they are not needed before the top of the next round
-        if (has_next) v = load_vectors(fast_args(), t_next, u_next, cigar_room(u_next));
+        if (has_next) v = load_vectors(fast_args(), t_next, u_next, cigar_room(u_next), !WIDE);
         L2R_STAMP(1);
 
         // ---- phase 2: classification
