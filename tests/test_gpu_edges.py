@@ -239,3 +239,16 @@ def test_windows_with_gaps_stay_on_the_fast_path(oracle, level):
     # the long read covers the whole chromosome: the tile that holds it may go to the generic kernel, no other
     if not os.environ.get("L2R_ABLATE"):
         assert cnt[0] <= 2 * 256, cnt
+
+
+def test_gencode_style_annotation_keeps_the_fast_path(oracle):
+    # transcripts in arbitrary order inside their gene and one chromosome-long transcript per chromosome that pins the
+    # reference's cursor: every tile's window has gaps (the long transcript + the local genes).  Bit exact, and the
+    # generic kernel sees (almost) nothing.
+    anno, af, reads = util.make_case(41, n_reads=120000, n_exons=6, anno_exons=60000, shuffle=True, long_tx=1)
+    cnt = [0, 0, 0, 0]
+    for level in (3, 5):
+        got, want = _run(oracle, af, reads, counters=cnt, full_level=level)
+        assert ((want.info & 1) != 0).sum() > 10000 and ((want.info & 2) != 0).sum() > 10000
+        if not os.environ.get("L2R_ABLATE"):
+            assert cnt[0] < reads.n // 20, cnt           # (sparse input: a few tiles span more than the staged buckets)
