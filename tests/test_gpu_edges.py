@@ -252,3 +252,47 @@ def test_gencode_style_annotation_keeps_the_fast_path(oracle):
         assert ((want.info & 1) != 0).sum() > 10000 and ((want.info & 2) != 0).sum() > 10000
         if not os.environ.get("L2R_ABLATE"):
             assert cnt[0] < reads.n // 20, cnt           # (sparse input: a few tiles span more than the staged buckets)
+
+
+def test_reference_quirks_q1_q4_q5(oracle):
+    """Hand-built reads whose classification hinges on three quirks of the reference: the GPU path
+    must agree with the oracle, and the oracle must show the documented outcome."""
+    af = _anno([(0, 0, [(100, 200), (300, 400), (500, 600)]),          # Q1 transcript
+                (0, 0, [(10_000, 10_100)])])                          # Q5 transcript (one exon)
+    I, D = 1, 2
+    rows = [
+        # Q1 (update_gtf.c:746): the acceptor loop looks at read exon j's OWN start.  A chain that begins with the
+        # transcript's first exon has no matching acceptor -> not known, only "has known site" ...
+        (0, *_chain([(100, 200), (300, 400)])),
+        # ... the same kind of chain beginning at an annotated acceptor is known
+        (0, *_chain([(300, 400), (500, 600)])),
+        # Q4 (bam2gtf.c:52-66, -e 3): a 2-base inner exon is dropped and its two introns fuse; a 2-base FIRST or LAST exon stays
+        (0, 2_000, [(50, M), (100, N_), (2, M), (100, N_), (50, M)]),
+        (0, 3_000, [(2, M), (100, N_), (50, M)]),
+        (0, 4_000, [(50, M), (100, N_), (2, M)]),
+        # ... and an insertion / a short deletion (<= -t 50) do not cut, a long deletion does
+        (0, 5_000, [(30, M), (5, I), (20, M), (50, D), (10, M), (51, D), (40, M)]),
+        # Q5 (update_gtf.c:786-801, <=): touching the transcript by its first / last base only is no overlap
+        (0, *_chain([(9_900, 10_000)])),
+        (0, *_chain([(9_900, 10_001)])),
+        (0, *_chain([(10_099, 10_200)])),
+        (0, *_chain([(10_100, 10_200)])),
+    ]
+    rows = [(r[0], r[1], 0, r[2]) for r in rows]
+    order = sorted(range(len(rows)), key=lambda i: (rows[i][0], rows[i][1]))
+    pos_of = {orig: new for new, orig in enumerate(order)}
+    got, want = _run(oracle, af, _reads([rows[i] for i in order]), full_level=5)
+    info = lambda i: int(want.info[pos_of[i]])
+    exons = lambda i: list(zip(want.ex_start[want.ex_off[pos_of[i]]:want.ex_off[pos_of[i] + 1]].tolist(),
+                               want.ex_end[want.ex_off[pos_of[i]]:want.ex_off[pos_of[i] + 1]].tolist()))
+    ref = lambda i: int(want.ref_tx[pos_of[i]])
+    assert (info(0) & 1) == 0 and (info(0) & 2) != 0                  # Q1: not known, has a known site
+    assert (info(1) & 1) != 0 and ref(1) == 0                         # known
+    assert exons(2) == [(2_001, 2_050), (2_253, 2_302)]              # Q4: inner micro-exon gone, introns fused
+    assert exons(3) == [(3_001, 3_002), (3_103, 3_152)]              # first exon is never length-checked
+    assert exons(4) == [(4_001, 4_050), (4_151, 4_152)]              # nor the last
+    assert exons(5) == [(5_001, 5_110), (5_162, 5_201)]              # I ignored, D 50 absorbed, D 51 cuts
+    # Q5 at -l 2 (full <=> first and last exons overlap; the only exon of the transcript is both): a read that merely touches
+    # the transcript never reaches check_full
+    got, want = _run(oracle, af, _reads([rows[i] for i in order]), full_level=2)
+    assert [(info(i) & 4) != 0 for i in (6, 7, 8, 9)] == [False, True, True, False]
