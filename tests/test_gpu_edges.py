@@ -254,9 +254,9 @@ def test_gencode_style_annotation_keeps_the_fast_path(oracle):
             assert cnt[0] < reads.n // 20, cnt           # (sparse input: a few tiles span more than the staged buckets)
 
 
-def test_reference_quirks_q1_q4_q5(oracle):
-    """Hand-built reads whose classification hinges on three quirks of the reference: the GPU path
-    must agree with the oracle, and the oracle must show the documented outcome."""
+def quirk_case():
+    """Hand-built reads whose classification hinges on quirks Q1, Q4, Q5 of the reference (SURVEY.md Appendix A);
+    returns (annotation, reads, position of row i in the sorted read set)."""
     af = _anno([(0, 0, [(100, 200), (300, 400), (500, 600)]),          # Q1 transcript
                 (0, 0, [(10_000, 10_100)])])                          # Q5 transcript (one exon)
     I, D = 1, 2
@@ -281,18 +281,28 @@ def test_reference_quirks_q1_q4_q5(oracle):
     rows = [(r[0], r[1], 0, r[2]) for r in rows]
     order = sorted(range(len(rows)), key=lambda i: (rows[i][0], rows[i][1]))
     pos_of = {orig: new for new, orig in enumerate(order)}
-    got, want = _run(oracle, af, _reads([rows[i] for i in order]), full_level=5)
-    info = lambda i: int(want.info[pos_of[i]])
-    exons = lambda i: list(zip(want.ex_start[want.ex_off[pos_of[i]]:want.ex_off[pos_of[i] + 1]].tolist(),
-                               want.ex_end[want.ex_off[pos_of[i]]:want.ex_off[pos_of[i] + 1]].tolist()))
-    ref = lambda i: int(want.ref_tx[pos_of[i]])
-    assert (info(0) & 1) == 0 and (info(0) & 2) != 0                  # Q1: not known, has a known site
-    assert (info(1) & 1) != 0 and ref(1) == 0                         # known
+    return af, _reads([rows[i] for i in order]), pos_of
+
+
+def check_quirk_outcomes(want5, want2, pos_of):
+    """The documented outcomes (want5 / want2: results at -l 5 / -l 2)."""
+    info = lambda w, i: int(w.info[pos_of[i]])
+    exons = lambda i: list(zip(want5.ex_start[want5.ex_off[pos_of[i]]:want5.ex_off[pos_of[i] + 1]].tolist(),
+                               want5.ex_end[want5.ex_off[pos_of[i]]:want5.ex_off[pos_of[i] + 1]].tolist()))
+    assert (info(want5, 0) & 1) == 0 and (info(want5, 0) & 2) != 0    # Q1: not known, has a known site
+    assert (info(want5, 1) & 1) != 0 and int(want5.ref_tx[pos_of[1]]) == 0     # known
     assert exons(2) == [(2_001, 2_050), (2_253, 2_302)]              # Q4: inner micro-exon gone, introns fused
     assert exons(3) == [(3_001, 3_002), (3_103, 3_152)]              # first exon is never length-checked
     assert exons(4) == [(4_001, 4_050), (4_151, 4_152)]              # nor the last
     assert exons(5) == [(5_001, 5_110), (5_162, 5_201)]              # I ignored, D 50 absorbed, D 51 cuts
-    # Q5 at -l 2 (full <=> first and last exons overlap; the only exon of the transcript is both): a read that merely touches
-    # the transcript never reaches check_full
-    got, want = _run(oracle, af, _reads([rows[i] for i in order]), full_level=2)
-    assert [(info(i) & 4) != 0 for i in (6, 7, 8, 9)] == [False, True, True, False]
+    # Q5 at -l 2 (full <=> first and last exons overlap; the only exon of the transcript is both): a read that merely
+    # touches the transcript never reaches check_full
+    assert [(info(want2, i) & 4) != 0 for i in (6, 7, 8, 9)] == [False, True, True, False]
+
+
+def test_reference_quirks_q1_q4_q5(oracle):
+    """The GPU path agrees with the oracle on the quirk reads, and the oracle shows the documented outcome."""
+    af, reads, pos_of = quirk_case()
+    _, want5 = _run(oracle, af, reads, full_level=5)
+    _, want2 = _run(oracle, af, reads, full_level=2)
+    check_quirk_outcomes(want5, want2, pos_of)

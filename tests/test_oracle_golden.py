@@ -90,3 +90,12 @@ def test_bam2gtf_golden(oracle, tmp_path):
     rc = oracle.run_cli(["bam2gtf", os.path.join(G, "toy.sam")], stdout_path=str(tmp_path / "b.gtf"))
     assert rc == 0
     assert filecmp.cmp(str(tmp_path / "b.gtf"), os.path.join(G, "expect.bam2gtf.gtf"), shallow=False)
+
+
+def test_quirk_reads_known_answers(oracle):
+    """Q1 / Q4 / Q5 outcomes worked out by hand from SURVEY.md Appendix A (the same reads the GPU suite runs)."""
+    from tests import test_gpu_edges as edges, util
+    af, reads, pos_of = edges.quirk_case()
+    want5 = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=5))
+    want2 = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=2))
+    edges.check_quirk_outcomes(want5, want2, pos_of)
