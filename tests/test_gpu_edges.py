@@ -306,3 +306,28 @@ def test_reference_quirks_q1_q4_q5(oracle):
     _, want5 = _run(oracle, af, reads, full_level=5)
     _, want2 = _run(oracle, af, reads, full_level=2)
     check_quirk_outcomes(want5, want2, pos_of)
+
+
+def full_length_case():
+    """check_full / set_full (update_gtf.c:629-696) worked out by hand: transcript (100,200)(300,400)(500,600);
+    read A ends inside the transcript (its last exon is the transcript's MIDDLE exon), read B's last exon is novel."""
+    af = _anno([(0, 0, [(100, 200), (300, 400), (500, 600)])])
+    rows = [(0, *_chain([(150, 200), (300, 400)])),         # A
+            (0, *_chain([(160, 200), (700, 800)]))]         # B
+    rows = [(r[0], r[1], 0, r[2]) for r in rows]
+    # level:            1      2      3      4     5
+    expect = {"A": [False, False, False, True, True],      # left end anchored; right end overlaps a non-terminal exon
+              "B": [False, False, True, True, True]}       # right end overlaps nothing of the transcript: not held against it at -l 3
+    return af, _reads(rows), expect
+
+
+def check_full_length_outcomes(results_by_level, expect):
+    for name, i in (("A", 0), ("B", 1)):
+        got = [(int(results_by_level[l].info[i]) & 4) != 0 for l in (1, 2, 3, 4, 5)]
+        assert got == expect[name], (name, got)
+
+
+def test_full_length_levels_known_answers(oracle):
+    af, reads, expect = full_length_case()
+    res = {l: _run(oracle, af, reads, full_level=l)[1] for l in (1, 2, 3, 4, 5)}
+    check_full_length_outcomes(res, expect)

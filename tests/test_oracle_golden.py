@@ -99,3 +99,11 @@ def test_quirk_reads_known_answers(oracle):
     want5 = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=5))
     want2 = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=2))
     edges.check_quirk_outcomes(want5, want2, pos_of)
+
+
+def test_full_length_levels_known_answers(oracle):
+    """check_full / set_full at -l 1..5, outcomes worked out by hand from SURVEY.md Appendix A.4."""
+    from tests import test_gpu_edges as edges, util
+    af, reads, expect = edges.full_length_case()
+    res = {l: util.oracle_run(oracle, af, reads, oracle.default_params(full_level=l)) for l in (1, 2, 3, 4, 5)}
+    edges.check_full_length_outcomes(res, expect)
