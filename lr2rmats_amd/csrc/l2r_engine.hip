@@ -520,14 +520,27 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         HIP_TRY(hipMemcpyAsync(c->cig_off.p, r->cig_off, (size_t)(N + 1) * 8, hipMemcpyHostToDevice, c->stream));
         if (r->n_cigar) HIP_TRY(hipMemcpyAsync(c->cig.p, r->cig, (size_t)r->n_cigar * 4, hipMemcpyHostToDevice, c->stream));
     }
-    // work buffers.  n_exon(read) <= ops(read) + 1, so n_cigar + n_reads bounds the exon arrays.
-    const size_t exb = (size_t)r->n_cigar + (size_t)N;
+    // work buffers.  n_exon(read) <= ops(read) + 1, so n_cigar + n_reads bounds the exon arrays; for long CIGARs (hundreds of
+    // M/I/D ops per exon) that bound is 10-50 times too generous, so the ops that can end an exon at all (N, D) are
+    // counted on the device (one pass over the words that were just uploaded; sizing only, nothing of it is kept).
+    const size_t slots = (size_t)r->n_cigar + (size_t)N;             // pass A's hand-over slots (cig_off[r] + r + k)
+    size_t exb = slots;
+    if (c->wide_cigar) {
+        unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(c->totals.p ? c->totals.p : nullptr);
+        if (!d_cnt) { if (c->totals.ensure(8)) return -2; d_cnt = reinterpret_cast<unsigned long long *>(c->totals.p); }
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, c->stream));
+        hipLaunchKernelGGL(k_count_cut_ops, dim3(4096), dim3(TILE_THREADS), 0, c->stream, (const uint32_t *)c->cig.p, (int64_t)r->n_cigar, d_cnt);
+        unsigned long long cuts = 0;
+        HIP_TRY(hipMemcpyAsync(&cuts, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        exb = (size_t)cuts + (size_t)N;
+    }
     if (c->j0.ensure((size_t)N) || c->local.ensure((size_t)N + 1) || c->ex_off.ensure((size_t)N) || c->info.ensure((size_t)N) || c->ref_tx.ensure((size_t)N) ||
         c->redo.ensure((size_t)N) || c->order.ensure((size_t)N + TILE_THREADS) || c->desc.ensure((size_t)c->n_tiles) || c->win_hdr.ensure((size_t)c->n_tiles * WIN_TX) ||
         c->tile_base.ensure((size_t)c->n_tiles + 1) || c->tile_acc.ensure((size_t)c->n_tiles + 1) || c->tile_acc_ex.ensure((size_t)c->n_tiles + 1) ||
         c->totals.ensure(8) || c->tile_chunk.ensure((size_t)c->n_tiles + 1) || c->tile_rchunk.ensure((size_t)c->n_tiles + 1) || c->ex_start.ensure(exb) || c->ex_end.ensure(exb) || c->ex_flag.ensure(exb) ||
         c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
-        c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb) || (c->wide_cigar && c->walked.ensure(exb))) return -2;
+        c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb) || (c->wide_cigar && c->walked.ensure(slots))) return -2;
     c->ex_cap = (int64_t)exb;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (getenv("L2R_STAMPS") && !c->stamps.p) {

@@ -1493,6 +1493,20 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
 #undef L2R_STAMP
 }
 
+// ------------------------------------------------------------------ buffer sizing at upload
+// Number of CIGAR words that can end an exon whatever the thresholds are (N or D): reads + this bounds the exons of a shard.
+__global__ __launch_bounds__(TILE_THREADS)
+void k_count_cut_ops(const uint32_t *__restrict__ cig, int64_t n_words, unsigned long long *__restrict__ total)
+{
+    unsigned long long mine = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t op = cig[i] & 15u;
+        mine += (op == 2u || op == 3u) ? 1u : 0u;
+    }
+    const uint32_t w = wave_sum((uint32_t)mine);          // (a thread sees < 2^32 words)
+    if ((threadIdx.x & (WAVE - 1)) == 0 && w) atomicAdd(total, (unsigned long long)w);
+}
+
 // ------------------------------------------------------------------ short-read junction support
 
 __device__ __forceinline__ int first_key_above(const int64_t *__restrict__ key, int n, int64_t q)
