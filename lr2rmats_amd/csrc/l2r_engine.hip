@@ -523,8 +523,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     // work buffers.  n_exon(read) <= ops(read) + 1, so n_cigar + n_reads bounds the exon arrays; for long CIGARs (hundreds of
     // M/I/D ops per exon) that bound is 10-50 times too generous, so the ops that can end an exon at all (N, D) are
     // counted on the device (one pass over the words that were just uploaded; sizing only, nothing of it is kept).
-    const size_t slots = (size_t)r->n_cigar + (size_t)N;             // pass A's hand-over slots (cig_off[r] + r + k)
-    size_t exb = slots;
+    size_t exb = (size_t)r->n_cigar + (size_t)N;
     if (c->wide_cigar) {
         unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(c->totals.p ? c->totals.p : nullptr);
         if (!d_cnt) { if (c->totals.ensure(8)) return -2; d_cnt = reinterpret_cast<unsigned long long *>(c->totals.p); }
@@ -540,7 +539,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         c->tile_base.ensure((size_t)c->n_tiles + 1) || c->tile_acc.ensure((size_t)c->n_tiles + 1) || c->tile_acc_ex.ensure((size_t)c->n_tiles + 1) ||
         c->totals.ensure(8) || c->tile_chunk.ensure((size_t)c->n_tiles + 1) || c->tile_rchunk.ensure((size_t)c->n_tiles + 1) || c->ex_start.ensure(exb) || c->ex_end.ensure(exb) || c->ex_flag.ensure(exb) ||
         c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
-        c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb) || (c->wide_cigar && c->walked.ensure(slots))) return -2;
+        c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb) || (c->wide_cigar && c->walked.ensure((size_t)(c->n_tiles + 1) * LDS_EXON_CAP))) return -2;
     c->ex_cap = (int64_t)exb;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (getenv("L2R_STAMPS") && !c->stamps.p) {
@@ -613,7 +612,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     const SiteTabs tabs{{c->sk_st.p, c->sd_st.p, c->sr_st.p}, {c->sk_en.p, c->sd_en.p, nullptr}, c->tid_base.p, c->n_tid_dir};
     // sorted input: the cursor value of every read is computed on the device; unsorted input: it was replayed on the host
     if (c->wide_cigar)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass_a<true>), dim3(gt), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, tabs, p,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass_a<true>), dim3(gt), dim3(TILE_THREADS), pass_a_dynamic_lds(c->reads_per_tile), s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, tabs, p,
                            (c->sorted ? (const int32_t *)nullptr : (const int32_t *)c->win_start.p), c->j0.p, c->local.p, c->order.p, c->tile_base.p, c->desc.p,
                            c->totals.p + 3, (const TxHdr *)c->hdr.p, c->win_hdr.p, (const uint32_t *)c->tile_first.p, c->walked.p);
     else

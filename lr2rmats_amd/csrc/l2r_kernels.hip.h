@@ -89,6 +89,7 @@ struct TileDesc {
 };
 constexpr uint32_t CHUNK_DEFERRED = 0xffffffffu;   // tile_chunk: the tile's accepted exons are compacted by k_gather_accepted
 constexpr uint32_t TD_FAST = 1;    // exons fit the LDS tile, dictionary slices fit DIR_CAP / KEY_CAP, window fits WIN_TX
+constexpr uint32_t TD_WALKED = 4;  // long-CIGAR input: pass A has left the tile's exons in `walked` (tile * LDS_EXON_CAP + in-tile offset)
 constexpr uint32_t TD_CONTIG = 2;  // the window's transcripts are consecutive in the annotation: j_lo, j_lo + 1, ...
 constexpr int WIN_SCAN_TRIPS = 64; // pass A looks at up to 64 * WIN_SCAN_TRIPS transcripts for a tile's window
 
@@ -213,7 +214,9 @@ __device__ __forceinline__ int walk_cigar(Ptr cig, int n_cig, int pos0, const De
 
 // The first WALK_HEAD ops of a read, fetched ahead of use (pass A issues them together with its cursor lookup).
 // Words behind the read's last op become "I, length 0", which changes nothing (the array is padded by four words).
-constexpr int WALK_SLAB = 12;             // long-CIGAR pass A: exons per read staged in LDS before they go to HBM
+constexpr int WALK_SLAB = 15;             // long-CIGAR pass A: exons per read staged in LDS before they go to HBM (6 bytes each)
+constexpr int WALK_OVF = 256;             // ... and exons beyond that, per tile
+constexpr int WALK_SENTINEL = INT32_MIN;    // first slot of a read whose exons pass A could not hand over
 constexpr int WALK_HEAD = 16;
 struct CigarHead { uint32_t c[WALK_HEAD]; };
 __device__ __forceinline__ CigarHead load_cigar_head(const uint32_t *__restrict__ cig, int n_cig)
@@ -237,6 +240,9 @@ __device__ __forceinline__ int walk_cigar_headed(const CigarHead &h, const uint3
     emit(w.n, w.start, w.end);
     return w.n + 1;
 }
+
+// dynamic LDS of k_pass_a<true> for tiles of up to `rpt` reads
+inline size_t pass_a_dynamic_lds(int rpt) { return (size_t)WALK_SLAB * rpt * 6 + (size_t)3 * WALK_OVF * 4 + (size_t)TILE_THREADS * 2; }
 
 // first j with key_j > (tid, start): the value the reference's annotation cursor has for this read
 __device__ __forceinline__ int cursor_value(const CursorDir &cd, int32_t tid, int32_t start)
@@ -275,13 +281,21 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
               const int32_t *__restrict__ j0_in, int32_t *__restrict__ j0_out, uint32_t *__restrict__ local_out,
               uint8_t *__restrict__ order_out, uint32_t *__restrict__ tile_sum, TileDesc *__restrict__ desc, uint32_t *__restrict__ redo_count,
               const TxHdr *__restrict__ hdr, TxHdr *__restrict__ win_hdr, const uint32_t *__restrict__ tile_first,
-              int2 *__restrict__ walked /* WIDE: the exons of every read, at slot cig_off[r] + r + k */)
+              int2 *__restrict__ walked /* WIDE: the tile's exons, LDS_EXON_CAP slots per tile */)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ int s_red[4][6];
     __shared__ int s_tid0;
     __shared__ uint32_t s_hist[WAVE];
-    __shared__ int2 s_slab[WIDE ? WALK_SLAB * TILE_THREADS : 1];
+    // WIDE only, dynamic LDS sized by the tile size (pass_a_dynamic_lds): small tiles keep the kernel's occupancy
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+    const int slab_w = p.reads_per_tile;                                     // reads per exon row of the slab
+    int32_t *const s_slab_s = reinterpret_cast<int32_t *>(s_dyn);            // exon-major: start ...
+    int *const s_ovf = s_slab_s + WALK_SLAB * slab_w;                        // exons beyond the slab: {thread | k << 8, start, end}
+    uint16_t *const s_slab_l = reinterpret_cast<uint16_t *>(s_ovf + 3 * WALK_OVF);      // ... and length (0: empty exon)
+    uint16_t *const s_loc = s_slab_l + WALK_SLAB * slab_w;                   // in-tile exon offset of every thread's read
+    __shared__ uint32_t s_ovf_n;
+    if (WIDE) { if (threadIdx.x == 0) s_ovf_n = 0u; __syncthreads(); }
     if (threadIdx.x < WAVE) s_hist[threadIdx.x] = 0u;
     // tile = reads [tile_first[b], tile_first[b + 1]): at most reads_per_tile of them, of one chromosome when the input is sorted
     const uint32_t r0 = tile_first[blockIdx.x], n_act = tile_first[blockIdx.x + 1] - r0;
@@ -289,6 +303,7 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
     const bool active = threadIdx.x < n_act;
     if (blockIdx.x == 0 && threadIdx.x == 0) { redo_count[0] = 0u; redo_count[1] = 0u; redo_count[2] = 0u; }   // redo list and accepted-exon cursor: the kernels that fill them run after this one
     uint32_t n = 0;
+    bool unwalked = false;
     int j0 = INT32_MAX, tid = 0, pos = 0, el = 0;
     if (active) {
         const int64_t c_a = cig_off[r], c_b = cig_off[r + 1];
@@ -300,16 +315,22 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
         el = pos;
         if (WIDE) {
             // long CIGARs: the classification kernel shall not read them again (they are 10-50 times the bytes of the
-            // exons they describe); the exons are left at a slot that needs no scan: a read has at most ops + 1 of them
-            // (a store per CIGAR step with the few lanes that cut there would cost more than the walk: the first
-            //  WALK_SLAB exons of a read wait in LDS, exon-major, and leave with full waves)
-            int2 *const out = walked + (c_a + r);
+            // exons they describe).  A store per CIGAR step with the few lanes that cut there would cost more than the
+            // walk, and the place of an exon in the tile is not known before the scan below: the exons wait in LDS
+            // (exon-major, start + 16-bit length) and leave afterwards.  A read with more than WALK_SLAB exons or an exon
+            // of 64 kb and more: the classification kernel walks that read itself (its first slot says so).
             n = (uint32_t)walk_cigar_headed<WIDE>(head, cig + c_a, (int)(c_b - c_a), pos, p, [&](int k, int s, int e) {
-                if (k < WALK_SLAB) s_slab[k * TILE_THREADS + (int)threadIdx.x] = make_int2(s, e); else out[k] = make_int2(s, e);
+                const uint32_t len = (uint32_t)(e - s + 1);
+                if (k < WALK_SLAB) {
+                    s_slab_s[k * slab_w + (int)threadIdx.x] = s; s_slab_l[k * slab_w + (int)threadIdx.x] = (uint16_t)len;
+                    unwalked = unwalked | (len > 0xffffu);
+                } else {
+                    const uint32_t at = atomicAdd(&s_ovf_n, 1u);
+                    if (at < (uint32_t)WALK_OVF) { s_ovf[3 * at] = (int)threadIdx.x | (k << 8); s_ovf[3 * at + 1] = s; s_ovf[3 * at + 2] = e; }
+                    else unwalked = true;
+                }
                 el = e;
             });
-            const int n_slab = min((int)n, WALK_SLAB);
-            for (int k = 0; k < n_slab; ++k) out[k] = s_slab[k * TILE_THREADS + (int)threadIdx.x];
         } else {
             n = (uint32_t)walk_cigar_headed<WIDE>(head, cig + c_a, (int)(c_b - c_a), pos, p, [&](int, int, int e) { el = e; });
         }
@@ -318,6 +339,26 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
     uint32_t total;
     const uint32_t local = block_exclusive_scan(n, s_wave, total);
     if (active) local_out[r] = local;
+    const bool walked_tile = WIDE && total <= (uint32_t)LDS_EXON_CAP;
+    if (walked_tile) {
+        int2 *const tile_out = walked + (size_t)blockIdx.x * LDS_EXON_CAP;
+        if (active) {
+            int2 *const out = tile_out + local;
+            s_loc[threadIdx.x] = (uint16_t)local;
+            const int n_slab = min((int)n, WALK_SLAB);
+            for (int k = 0; k < n_slab; ++k) {
+                const int s0 = s_slab_s[k * slab_w + (int)threadIdx.x];
+                out[k] = make_int2(s0, s0 + (int)s_slab_l[k * slab_w + (int)threadIdx.x] - 1);
+            }
+        }
+        __syncthreads();
+        const uint32_t n_ovf = min(s_ovf_n, (uint32_t)WALK_OVF);
+        for (uint32_t i = threadIdx.x; i < n_ovf; i += TILE_THREADS) {
+            const int who = s_ovf[3 * i] & 0xff, k = s_ovf[3 * i] >> 8;
+            tile_out[(uint32_t)s_loc[who] + (uint32_t)k] = make_int2(s_ovf[3 * i + 1], s_ovf[3 * i + 2]);
+        }
+        if (active && unwalked) tile_out[local] = make_int2(WALK_SENTINEL, 0);      // (after the exons above: this slot wins)
+    }
     {   // Order of the tile's reads by falling exon count (counting sort, ties in arrival order): the classification
         // kernel gives read order_out[slot] to thread `slot`, so the reads of a wave need about the same number of
         // rounds in its per-exon loops.  Results do not depend on the order: every read owns its output slots.
@@ -423,7 +464,7 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
             d.en_r0 = ed_r0; d.en_nk = ed_r1 - ed_r0;
             if (fast && (d.st_nk > (uint32_t)KEY_CAP || d.en_nk > (uint32_t)KEY_CAP)) { fast = false; why = 3u; }
         }
-        d.flags = (fast ? TD_FAST : 0u) | (contig ? TD_CONTIG : 0u) | (why << 8);
+        d.flags = (fast ? TD_FAST : 0u) | (contig ? TD_CONTIG : 0u) | (walked_tile ? TD_WALKED : 0u) | (why << 8);
         if (lane == 0) { tile_sum[blockIdx.x] = total; desc[blockIdx.x] = d; }
     }
 }
@@ -795,7 +836,7 @@ struct AccRec { uint32_t read_lo, read_hi, info; int32_t ref_tx; };
 struct FastArgs {
     int64_t n_reads;
     const int32_t *r_tid; const int32_t *r_pos; const uint8_t *r_rev; const int64_t *cig_off; const uint32_t *cig;
-    const int2 *walked;          // long-CIGAR inputs: the exons pass A has walked (slot cig_off[r] + r + k)
+    const int2 *walked;          // long-CIGAR inputs: the exons pass A has walked (tile * LDS_EXON_CAP + in-tile offset), tiles with TD_WALKED
     const uint32_t *local; const uint8_t *order; const uint32_t *tile_base; const int32_t *j0; const TileDesc *desc;
     const TxHdr *win_hdr;        // per tile WIN_TX header copies, the annotation index in the spare word (pass A)
     const TxHdr *hdr; SiteDict st, en;
@@ -1269,6 +1310,12 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         // ---- phase 1: CIGAR -> exons
         ReadEnds re{0, 0, 0, 0};
         bool sane = true;
+        const bool bulk = WIDE && in_lds && (d.flags & TD_WALKED) != 0u;      // (tile-uniform) pass A has left the exons
+        if (bulk) {
+            const int2 *const src = fast_args()->walked + (size_t)t * LDS_EXON_CAP;
+            for (uint32_t i = threadIdx.x; i < tile_total; i += TILE_THREADS) { const int2 x = src[i]; s_S[i] = x.x; s_E[i] = x.y; }
+            __syncthreads();
+        }
         if (active) {
             const FastArgsK a = fast_args();
             DevParams p;                                    // the three thresholds the walk reads
@@ -1282,15 +1329,9 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
                     sane = sane & (s <= e);
                     re.sl = s; re.el = e;
                 };
-                if (WIDE) {
-                    // the exons come from pass A (cig_off[r] + r = c_lo + r: the tile's reads are one shard, 32-bit offsets)
-                    const int2 *const src = a->walked + ((size_t)v.c_lo + (size_t)r);
-                    int k = 0;
-                    for (; k + 4 <= (int)n; k += 4) {
-                        const int2 x0 = src[k], x1 = src[k + 1], x2 = src[k + 2], x3 = src[k + 3];
-                        emit(k, x0.x, x0.y); emit(k + 1, x1.x, x1.y); emit(k + 2, x2.x, x2.y); emit(k + 3, x3.x, x3.y);
-                    }
-                    for (; k < (int)n; ++k) { const int2 x = src[k]; emit(k, x.x, x.y); }
+                if (bulk && s_S[local] != WALK_SENTINEL) {
+                    for (int k = 0; k < (int)n; ++k) sane = sane & (s_S[local + k] <= s_E[local + k]);
+                    re.sl = s_S[local + n - 1u]; re.el = s_E[local + n - 1u];
                 } else if (staged) walk_cigar<false>(s_cig + (v.c_lo - (u.c0 & ~3u)), n_cig, pos, p, emit);
                 else walk_cigar<WIDE>(a->cig + v.c_lo, n_cig, pos, p, emit);
                 re.s0 = s_S[local]; re.e0 = s_E[local];
