@@ -1,21 +1,26 @@
 // l2r_kernels.hip.h -- gfx950 device code of the read-vs-annotation path.
 //
 // All int32 interval arithmetic, no contraction -> no MFMA.  A TILE is up to 256 consecutive alignment
-// records handled by one 256-thread workgroup (4 wave64), one thread per record.
+// records of one chromosome (tile_first, built at upload) handled by one 256-thread workgroup (4 wave64), one
+// thread per record.
 //
-//   k_pass_a           CIGAR -> exon count per record, cursor value per record, tile sums, and a
-//                      TILE DESCRIPTOR: the slice of the site dictionaries and the window of annotation
-//                      transcripts the tile is going to need, so that the classification kernel can issue
-//                      every one of its loads when it starts
+//   k_pass_a           CIGAR -> exon count per record, cursor value per record, tile sums, the
+//                      tile's reads ordered by exon count, and a TILE DESCRIPTOR: the slice of the site
+//                      dictionaries and the window of annotation transcripts (copies of their headers) the tile
+//                      is going to need, so that the classification kernel can issue every one of its loads when
+//                      it starts.  Long-CIGAR inputs: also the exons themselves, tile-compact (the CIGAR is read once)
 //   k_scan_u32         exclusive scan of per-tile sums (one workgroup per array)
-//   k_classify_fast    CIGAR -> exons into an LDS tile; dictionary slices and transcript window staged in LDS,
-//                      re-based into the tile's own transcript frame; per read: visit mask over the window,
-//                      one START and one END dictionary probe per exon, known / known-site / flags from
-//                      32-bit membership masks; coalesced write-out; per-tile accepted counts.
+//   k_classify_fast    persistent, software pipelined.  CIGAR -> exons into an LDS tile; dictionary slices and
+//                      transcript window staged in LDS, re-based into the tile's own transcript frame; per read:
+//                      visit mask over the window, one START and one END dictionary probe per exon, known /
+//                      known-site / flags from 32-bit membership masks; coalesced write-out of the per-read
+//                      results AND of the tile's chunk of the accepted list (records + exons, compacted in LDS).
 //                      Anything it cannot decide exactly goes to a redo list.
-//   k_classify_generic thread per listed read, literal loops of the reference (any -d, any annotation)
+//   k_classify_generic wave per listed read, literal loops of the reference (any -d, any annotation)
 //   k_validate_sj      short-read junction support for accepted candidates
-//   k_count_accepted / k_gather_accepted   compaction of the accepted-novel records in read order
+//   k_count_accepted / k_gather_accepted   accepted-list chunks of the tiles the classification kernel could not
+//                      finish itself (redo reads, junction table)
+//   k_count_cut_ops    upload-time sizing of the exon buffers for long CIGARs
 //
 // Semantics follow the reference line by line where bytes of the graded outputs depend on it; each device
 // function cites the lines it restates.
