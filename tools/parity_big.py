@@ -9,17 +9,20 @@ cfg = dict(workload.CONFIGS['cfg3']); cfg['n_reads'] = N
 af, reads = workload.make_rank_workload(cfg, 0, 1)
 e = capi.Engine(0)
 e.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
-got = e.classify(reads, capi.default_params(full_level=3))
 po.build()
-want = po.classify_soa(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, af.tx_tid, af.tx_start, af.tx_end, af.tx_rev,
-                       af.tx_ex_off, af.ex_start, af.ex_end, params=po.default_params(full_level=3))
-for name in ("ex_off", "ex_start", "ex_end", "ex_flag", "ref_tx"):
-    a, b = getattr(got, name), getattr(want, name)
-    m = min(len(a), len(b))
-    d = np.nonzero(a[:m] != b[:m])[0]
-    print(name, len(a), len(b), "diffs", len(d), d[:10])
-a, b = got.info & 0x7f, want.info & 0x7f
-d = np.nonzero(a != b)[0]
-print("info diffs", len(d), d[:10], a[d[:10]], b[d[:10]])
-if len(d):
-    print("tiles of first diffs", d[:20] // 256, "lane", d[:20] % 256)
+levels = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [3]
+for level in levels:
+    got = e.classify(reads, capi.default_params(full_level=level))
+    want = po.classify_soa(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, af.tx_tid, af.tx_start, af.tx_end, af.tx_rev,
+                           af.tx_ex_off, af.ex_start, af.ex_end, params=po.default_params(full_level=level))
+    print("-l", level)
+    for name in ("ex_off", "ex_start", "ex_end", "ex_flag", "ref_tx"):
+        a, b = getattr(got, name), getattr(want, name)
+        m = min(len(a), len(b))
+        d = np.nonzero(a[:m] != b[:m])[0]
+        print(name, len(a), len(b), "diffs", len(d), d[:10])
+    a, b = got.info & 0x7f, want.info & 0x7f
+    d = np.nonzero(a != b)[0]
+    print("info diffs", len(d), d[:10], a[d[:10]], b[d[:10]])
+    if len(d):
+        print("tiles of first diffs", d[:20] // 256, "lane", d[:20] % 256)
