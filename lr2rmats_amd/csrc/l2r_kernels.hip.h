@@ -1139,7 +1139,9 @@ __device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc 
     int s = 0, e = 0;
     if (mapping) { s = S[0]; e = E[0]; }
     const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
-    for (int k = 0; __any(mapping && k < (int)n); ++k) {
+    // (scalar trip count: the wave's longest mapped read)
+    const int k_max = wave_max(mapping ? (int)n : 0);
+    for (int k = 0; k < k_max; ++k) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
         const uint32_t inext = junc ? local + (uint32_t)k + 1u : 0u;
         // (unsigned: a coordinate below the staged span wraps to a huge index and lands on `none` as well)
