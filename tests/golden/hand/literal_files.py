@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Hand-derived known answers for the ORDER-DEPENDENT half of update-gtf / unique-gtf.
+
+Every byte of every file this script writes is a literal below: nothing here calls the oracle, the
+product, or any code that computes an expected value.  The expected outputs were worked out BY HAND
+from the reference's rules (file:line into /root/reference/src), and the derivation of each row is
+in README.md next to this file.  Running the script only re-materialises the committed files:
+
+    python tests/golden/hand/literal_files.py            # rewrites the files in this directory
+
+The tests (tests/test_hand_known_answers.py) compare the oracle CLI (CPU suite) and the HIP CLI
+(GPU suite) with the committed files byte for byte.
+"""
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+T = "\t"
+
+
+def gtf_rows(chrom, strand, gid, gname, tid, tname, exons):
+    """One `transcript` row (ignored by the reader, src/gtf.c:478) + one `exon` row per exon, in the order given."""
+    attr = 'gene_id "%s"; transcript_id "%s"; gene_name "%s"; transcript_name "%s";' % (gid, tid, gname, tname)
+    lo, hi = min(s for s, _ in exons), max(e for _, e in exons)
+    rows = [T.join([chrom, "hand", "transcript", str(lo), str(hi), ".", strand, ".", attr])]
+    rows += [T.join([chrom, "hand", "exon", str(s), str(e), ".", strand, ".", attr]) for s, e in exons]
+    return rows
+
+
+# --------------------------------------------------------------------------------------------------
+# Annotation (GTF FILE ORDER matters: the sweep of check_with_anno_trans walks it, update_gtf.c:792-835).
+# TFAR sits in front of TA2 although TA2 starts earlier (unsorted GTF, GENCODE style): a read that ends
+# before TFAR stops there and never sees TA2 (:799-800); TR1 is a '-' gene written with descending exons.
+ANNO = []
+ANNO += gtf_rows("chrA", "+", "GA", "ga", "TA1", "ta1", [(1000, 1100), (2000, 2100), (3000, 3100), (4000, 4100)])
+ANNO += gtf_rows("chrA", "+", "GF", "gf", "TFAR", "tfar", [(9000, 9100), (9200, 9300)])
+ANNO += gtf_rows("chrA", "-", "GN", "gn", "TA2", "ta2", [(2900, 2950), (2000, 2100)])
+ANNO += gtf_rows("chrA", "-", "GR", "gr", "TR1", "tr1", [(13000, 13100), (12000, 12100), (11000, 11100)])
+ANNO += gtf_rows("chrB", "+", "GB", "gb", "TB1", "tb1", [(1000, 1100), (2000, 2100), (3000, 3100), (4000, 4100)])
+ANNO += gtf_rows("chrB", "+", "GC", "gc", "TC1", "tc1", [(20000, 20100), (21000, 21100), (22000, 22100), (23000, 23100)])
+ANNO += gtf_rows("chrB", "+", "GS", "gs", "TS1", "ts1", [(50000, 50099)])
+
+SAM_HEADER = ["@HD\tVN:1.0\tSO:coordinate", "@SQ\tSN:chrA\tLN:100000000", "@SQ\tSN:chrB\tLN:100000000"]
+
+
+def sam(name, flag, chrom, pos, cigar):
+    return T.join([name, str(flag), chrom, str(pos), "60", cigar, "*", "0", "0", "*", "*"])
+
+
+# --------------------------------------------------------------------------------------------------
+# Case "upd": update-gtf -l 5  (and the same with -c).  README.md section 1.
+UPD_SAM = SAM_HEADER + [
+    sam("a1", 0, "chrA", 1000, "101M899N101M399N101M399N101M899N101M"),
+    sam("a2", 0, "chrA", 1000, "101M899N101M399N101M399N101M899N201M"),
+    sam("c1", 0, "chrA", 1000, "101M899N101M899N51M"),
+    sam("c2", 0, "chrA", 1000, "101M899N101M899N6501M"),
+    sam("k1", 0, "chrA", 2000, "101M899N101M899N101M"),
+    sam("a3", 0, "chrA", 2050, "51M399N101M399N51M"),
+    sam("r1", 0, "chrA", 11000, "101M899N101M399N101M"),
+    sam("u1", 0, "chrA", 20000, "101M399N101M"),
+    sam("d2", 16, "chrB", 1000, "101M949N51M1399N101M"),
+    sam("b1", 0, "chrB", 2050, "51M899N101M"),
+    sam("b2", 0, "chrB", 2050, "51M899N101M899N151M"),
+    sam("s1", 0, "chrB", 50020, "100M"),
+    sam("s2", 0, "chrB", 50021, "100M"),
+]
+
+DETAIL_HEADER = T.join(["ReadName", "chr", "strand", "Novel", "GeneID", "GeneName", "ExonCount", "ExonStart", "ExonEnd", "NovelExonCount",
+                        "NovelExonIndex", "NovelSiteCount", "NovelSiteIndex", "NovelJunctionCount", "NovelJunctionIndex",
+                        "UnreliableJunctionCount", "UnreliableJunctionIndex"])
+
+
+def detail(name, chrom, strand, novel, gid, gname, starts, ends, nov_exon, nov_site, nov_junc, unrel):
+    """One detail.txt row (update_gtf.c:297-419): every field is followed by a tab except a non-empty last list."""
+    def lst(v):
+        return (str(len(v)), ",".join(str(x) for x in v) if v else "NA")
+    f = [name, chrom, strand, str(novel), gid, gname, str(len(starts)), ",".join(map(str, starts)), ",".join(map(str, ends))]
+    for v in (nov_exon, nov_site, nov_junc):
+        f += list(lst(v))
+    f += list(lst(unrel))
+    return T.join(f) + ("" if unrel else T)
+
+
+UPD_DETAIL = [
+    DETAIL_HEADER,
+    detail("a1", "chrA", "+", 1, "GA", "ga", [1000, 2000, 2500, 3000, 4000], [1100, 2100, 2600, 3100, 4100], [2], [1, 4, 5], [1, 2], []),
+    detail("a2", "chrA", "+", 1, "GA", "ga", [1000, 2000, 2500, 3000, 4000], [1100, 2100, 2600, 3100, 4200], [2, 4], [1, 4, 5], [1, 2], []),
+    detail("c1", "chrA", "+", 1, "GA", "ga", [1000, 2000, 3000], [1100, 2100, 3050], [2], [1], [], []),
+    detail("c2", "chrA", "-", 1, "GN", "gn", [1000, 2000, 3000], [1100, 2100, 9500], [2], [1], [], []),
+    detail("k1", "chrA", "+", 0, "GA", "ga", [2000, 3000, 4000], [2100, 3100, 4100], [], [], [], []),
+    detail("a3", "chrA", "+", 1, "GA", "ga", [2050, 2500, 3000], [2100, 2600, 3050], [0, 1, 2], [1, 2, 3], [0, 1], []),
+    detail("r1", "chrA", "-", 1, "GR", "gr", [11000, 12000, 12500], [11100, 12100, 12600], [2], [1], [1], []),
+    detail("u1", "chrA", "+", 2, "NA", "NA", [20000, 20500], [20100, 20600], [0, 1], [0, 1], [0], []),
+    detail("d2", "chrB", "+", 1, "GB", "gb", [1000, 2050, 3500], [1100, 2100, 3600], [1, 2], [1, 3], [0, 1], []),
+    detail("b1", "chrB", "+", 1, "GB", "gb", [2050, 3000], [2100, 3100], [0], [1], [], []),
+    detail("b2", "chrB", "+", 1, "GB", "gb", [2050, 3000, 4000], [2100, 3100, 4150], [0, 2], [1], [], []),
+    detail("s1", "chrB", "+", 0, "GS", "gs", [50020], [50119], [0], [], [], []),
+    detail("s2", "chrB", "+", 2, "NA", "NA", [50021], [50120], [0], [], [], []),
+]
+
+
+def gtf_block(tchrom, start, end, strand, gid, gname, name, cov, xchrom, xstrand, exons):
+    """print_read_trans (gtf.c:607-632): transcript row with transcript_cov, exon rows without; exons descending when
+    the TRANSCRIPT is '-'; every exon row carries its own chromosome and strand."""
+    attr = 'gene_id "%s"; transcript_id "%s"; gene_name "%s"; transcript_name "%s";' % (gid, name, gname, name)
+    rows = [T.join([tchrom, "lr2rmats", "transcript", str(start), str(end), ".", strand, ".", attr + ' transcript_cov "%d";' % cov])]
+    order = list(reversed(exons)) if strand == "-" else list(exons)
+    rows += [T.join([xchrom, "lr2rmats", "exon", str(s), str(e), ".", xstrand, ".", attr]) for s, e in order]
+    return rows
+
+
+_A = gtf_block("chrA", 1000, 4200, "+", "GA", "ga", "a1", 2, "chrA", "+", [(1000, 1100), (2000, 2100), (2500, 2600), (3000, 3100), (4000, 4200)])
+_R1 = gtf_block("chrA", 11000, 12600, "-", "GR", "gr", "r1", 1, "chrA", "-", [(11000, 11100), (12000, 12100), (12500, 12600)])
+_D2 = gtf_block("chrB", 1000, 3600, "+", "GB", "gb", "d2", 1, "chrB", "+", [(1000, 1100), (2050, 2100), (3500, 3600)])
+_B1 = gtf_block("chrB", 2050, 3100, "+", "GB", "gb", "b1", 1, "chrB", "+", [(2050, 2100), (3000, 3100)])
+# without -c: c2 merges into c1's entry (cov 2, last exon and transcript end extended to 9500, strand stays '+')
+UPD_GTF = _A + gtf_block("chrA", 1000, 9500, "+", "GA", "ga", "c1", 2, "chrA", "+", [(1000, 1100), (2000, 2100), (3000, 9500)]) + _R1 + _D2 + _B1
+# with -c: c2 ('-' after it took TA2's strand) is skipped at c1's and a1's entries (update_gtf.c:149) and becomes its own entry
+UPD_GTF_C = (_A + gtf_block("chrA", 1000, 3050, "+", "GA", "ga", "c1", 1, "chrA", "+", [(1000, 1100), (2000, 2100), (3000, 3050)])
+             + gtf_block("chrA", 1000, 9500, "-", "GN", "gn", "c2", 1, "chrA", "-", [(1000, 1100), (2000, 2100), (3000, 9500)]) + _R1 + _D2 + _B1)
+
+
+def bed(chrom, start, end, kind, score, strand):
+    return T.join([chrom, str(start - 1), str(end), kind + "_exon", str(score), strand])
+
+
+UPD_BED = [bed("chrA", 2500, 2600, "I", 2, "+"), bed("chrA", 3000, 9500, "T", 2, "+"), bed("chrA", 12500, 12600, "T", 1, "-"),
+           bed("chrB", 2050, 2100, "I", 2, "+"), bed("chrB", 3500, 3600, "T", 1, "+")]
+UPD_BED_C = [bed("chrA", 2500, 2600, "I", 2, "+"), bed("chrA", 3000, 3050, "T", 1, "+"), bed("chrA", 3000, 9500, "T", 1, "-"),
+             bed("chrA", 12500, 12600, "T", 1, "-"), bed("chrB", 2050, 2100, "I", 2, "+"), bed("chrB", 3500, 3600, "T", 1, "+")]
+
+
+def summary(anno_genes, anno_tx, upd_genes, added, partial, exons, sites, juncs, known, known_genes, uniq_known,
+            reliable, uniq_reliable, unreliable, uniq_unreliable, unrec, uniq_unrec):
+    """update_gtf.c:530-569, literal text."""
+    return [
+        "==== Annotaion ====", "Genes_of_annotation_GTF\t%d" % anno_genes, "Transcripts_of_annotation_GTF\t%d" % anno_tx, "",
+        "===================", "", "==== Updated information ====", "Updated_Genes\t%d" % upd_genes, "Added_Novel_Transcripts\t%d" % added,
+        "Added_Novel_Full-read_Transcripts\t%d" % (added - partial), "Added_Novel_Partial-read_Transcripts\t%d" % partial,
+        "Added_Novel_Exons\t%d" % exons, "Added_Novel_Sites\t%d" % sites, "Added_Novel_Splice_Junctions\t%d" % juncs, "",
+        "=============================", "", "==== Known information ====", "Known_Transcripts_from_BAM\t%d" % known,
+        "Genes_of_Known_Transcripts_from_BAM\t%d" % known_genes, "Uniq_Known_Transcripts_from_BAM\t%d" % uniq_known, "",
+        "===========================", "", "==== Novel information ====", "Novel_Transcript_from_BAM\t%d" % (reliable + unreliable),
+        "Novel_Transcript_from_BAM_with_All_Reliable_Junction\t%d" % reliable,
+        "Uniq_Novel_Transcript_from_BAM_with_All_Reliable_Junction\t%d" % uniq_reliable,
+        "Novel_Transcript_from_BAM_with_Unreliable_Junction\t%d" % unreliable,
+        "Uniq_Novel_Transcript_from_BAM_with_Unreliable_Junction\t%d" % uniq_unreliable, "",
+        "===========================", "", "==== Unrecognized information ====", "Unrecognized_Transcript_from_BAM\t%d" % unrec,
+        "Uniq_Unrecognized_Transcript_from_BAM\t%d" % uniq_unrec, "", "=================================="]
+
+
+UPD_SUMMARY = summary(7, 7, 3, 5, 0, 5, 7, 5, 2, 2, 2, 9, 5, 0, 0, 2, 2)
+# -c: c2 is its own entry (gene GN), its novel exon its own bed row; the unique novel list is merged with -c as well
+UPD_SUMMARY_C = summary(7, 7, 4, 6, 0, 6, 7, 5, 2, 2, 2, 9, 6, 0, 0, 2, 2)
+
+# --------------------------------------------------------------------------------------------------
+# Case "uniq": unique-gtf (and the same with -s = force strand).  README.md section 2.
+UNIQ_SAM = SAM_HEADER + [
+    sam("u1", 0, "chrA", 100, "101M99N101M99N101M"),
+    sam("u2", 0, "chrA", 90, "111M99N101M99N151M"),
+    sam("u3", 0, "chrA", 95, "106M99N101M99N121M"),
+    sam("u4", 0, "chrA", 150, "51M99N101M"),
+    sam("v1", 0, "chrA", 1000, "101M99N101M"),
+    sam("v2", 0, "chrA", 1000, "101M99N101M99N101M"),
+    sam("w1", 0, "chrA", 2000, "101M99N101M99N101M99N101M"),
+    sam("w2", 0, "chrA", 2450, "51M99N101M99N101M"),
+    sam("x1", 0, "chrA", 3000, "101M499N101M199N101M"),
+    sam("x2", 0, "chrA", 3200, "101M99N101M"),
+    sam("x3", 0, "chrA", 3650, "51M199N101M"),
+    sam("y1", 0, "chrA", 5000, "101M99N101M"),
+    sam("y2", 16, "chrA", 5000, "101M99N101M"),
+    sam("z1", 0, "chrA", 6000, "100M"),
+    sam("z2", 0, "chrA", 6020, "100M"),
+    sam("z3", 0, "chrA", 6041, "100M"),
+    sam("q1", 0, "chrB", 1000, "50000001M"),
+    sam("q2", 0, "chrB", 10001001, "50000001M"),
+]
+
+
+def ublock(chrom, start, end, strand, name, cov, exons):
+    return gtf_block(chrom, start, end, strand, name, name, name, cov, chrom, strand, exons)
+
+
+_U = [
+    ublock("chrA", 90, 650, "+", "u1", 3, [(90, 200), (300, 400), (500, 650)]),
+    ublock("chrA", 1000, 1300, "+", "v1", 1, [(1000, 1100), (1200, 1300)]),
+    ublock("chrA", 2000, 2700, "+", "w1", 1, [(2000, 2100), (2200, 2300), (2400, 2500), (2600, 2700)]),
+    ublock("chrA", 3000, 4000, "+", "x1", 1, [(3000, 3100), (3600, 3700), (3900, 4000)]),
+    ublock("chrA", 3200, 3500, "+", "x2", 1, [(3200, 3300), (3400, 3500)]),
+    ublock("chrA", 3650, 4000, "+", "x3", 1, [(3650, 3700), (3900, 4000)]),
+]
+_Z = [
+    ublock("chrA", 6000, 6119, "+", "z1", 2, [(6000, 6119)]),
+    ublock("chrA", 6041, 6140, "+", "z3", 1, [(6041, 6140)]),
+    ublock("chrB", 1000, 60001001, "+", "q1", 2, [(1000, 60001001)]),
+]
+UNIQ_GTF = sum(_U, []) + ublock("chrA", 5000, 5300, "+", "y1", 2, [(5000, 5100), (5200, 5300)]) + sum(_Z, [])
+UNIQ_GTF_S = (sum(_U, []) + ublock("chrA", 5000, 5300, "+", "y1", 1, [(5000, 5100), (5200, 5300)])
+              + ublock("chrA", 5000, 5300, "-", "y2", 1, [(5000, 5100), (5200, 5300)]) + sum(_Z, []))
+
+# --------------------------------------------------------------------------------------------------
+# Case "split": update-gtf -s -l 5 -J 1 -j split_sj.tab.  README.md section 3.
+SPLIT_SAM = SAM_HEADER + [
+    sam("a1", 0, "chrA", 1000, "101M899N101M399N101M399N101M899N101M"),
+    sam("p1", 0, "chrB", 1000, "101M899N101M399N101M399N101M899N101M899N101M"),
+    sam("w1", 0, "chrB", 20050, "51M899N101M"),
+    sam("p2", 0, "chrB", 20900, "51M69N81M899N101M1399N101M"),
+    sam("w2", 0, "chrB", 20960, "21M19N101M899N101M"),
+]
+# STAR SJ.out.tab columns: chr, first intron base, last intron base, strand, motif, annotated, unique, multi, overhang
+SPLIT_SJ = [T.join(r) for r in [
+    ("chrA", "2101", "2499", "1", "1", "0", "5", "0", "30"),
+    ("chrA", "2601", "2999", "1", "1", "0", "5", "0", "30"),
+    ("chrB", "2101", "2499", "1", "1", "0", "5", "0", "30"),
+    ("chrB", "2601", "2999", "1", "1", "0", "5", "0", "30"),
+    ("chrB", "20981", "20999", "1", "1", "0", "3", "0", "30"),
+    ("chrB", "90000", "90100", "1", "1", "0", "9", "0", "30"),
+]]
+SPLIT_DETAIL = [
+    DETAIL_HEADER,
+    detail("a1", "chrA", "+", 1, "GA", "ga", [1000, 2000, 2500, 3000, 4000], [1100, 2100, 2600, 3100, 4100], [2], [1, 4, 5], [1, 2], []),
+    detail("p1", "chrB", "+", 1, "GB", "gb", [1000, 2000, 2500, 3000, 4000, 5000], [1100, 2100, 2600, 3100, 4100, 5100], [2, 5], [1, 4, 5, 8], [1, 2, 4], [4]),
+    detail("w1", "chrB", "+", 1, "GC", "gc", [20050, 21000], [20100, 21100], [0], [1], [], []),
+    detail("p2", "chrB", "+", 1, "GC", "gc", [20900, 21020, 22000, 23500], [20950, 21100, 22100, 23600], [0, 1, 3], [0, 1, 3], [0, 2], [0, 2]),
+    detail("w2", "chrB", "+", 1, "GC", "gc", [20960, 21000, 22000], [20980, 21100, 22100], [0], [0, 1], [0], []),
+]
+SPLIT_GTF = (
+    # a1's entry got cov 2 from the split piece of the chrB read p1 (Q2: the piece has tid 0 and is compared with every entry)
+    gtf_block("chrA", 1000, 4100, "+", "GA", "ga", "a1", 2, "chrA", "+", [(1000, 1100), (2000, 2100), (2500, 2600), (3000, 3100), (4000, 4100)])
+    + gtf_block("chrB", 20050, 21100, "+", "GC", "gc", "w1", 1, "chrB", "+", [(20050, 20100), (21000, 21100)])
+    # Q2: the piece's transcript row prints chr_name[0], 0, 0, '+'; its exon rows carry the real chromosome and strand
+    + gtf_block("chrA", 0, 0, "+", "GC", "gc", "p2.split.0", 1, "chrB", "+", [(21020, 21100), (22000, 22100)])
+    + gtf_block("chrB", 20960, 22100, "+", "GC", "gc", "w2", 1, "chrB", "+", [(20960, 20980), (21000, 21100), (22000, 22100)]))
+SPLIT_BED = [bed("chrA", 2500, 2600, "I", 2, "+"), bed("chrB", 20050, 20100, "T", 1, "+"), bed("chrB", 21020, 21100, "T", 1, "+"),
+             bed("chrB", 20960, 20980, "T", 1, "+")]
+SPLIT_SUMMARY = summary(7, 7, 2, 4, 1, 4, 7, 3, 0, 0, 0, 3, 3, 2, 2, 0, 0)
+
+FILES = {
+    "anno.gtf": ANNO,
+    "upd.sam": UPD_SAM, "upd.detail.txt": UPD_DETAIL, "upd.updated.gtf": UPD_GTF, "upd.novel_exon.bed": UPD_BED, "upd.summary.txt": UPD_SUMMARY,
+    "upd_c.updated.gtf": UPD_GTF_C, "upd_c.novel_exon.bed": UPD_BED_C, "upd_c.summary.txt": UPD_SUMMARY_C,
+    "uniq.sam": UNIQ_SAM, "uniq.unique.gtf": UNIQ_GTF, "uniq_s.unique.gtf": UNIQ_GTF_S,
+    "split.sam": SPLIT_SAM, "split_sj.tab": SPLIT_SJ, "split.detail.txt": SPLIT_DETAIL, "split.updated.gtf": SPLIT_GTF,
+    "split.novel_exon.bed": SPLIT_BED, "split.summary.txt": SPLIT_SUMMARY,
+}
+
+if __name__ == "__main__":
+    for name, rows in FILES.items():
+        with open(os.path.join(HERE, name), "w") as fh:
+            fh.write("".join(r + "\n" for r in rows))
+    print("wrote %d files into %s" % (len(FILES), HERE))

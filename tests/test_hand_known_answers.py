@@ -1,0 +1,72 @@
+"""Hand-derived known answers for the order-dependent tail (merge_trans / check_iden / split pieces / summary /
+novel_exon.bed): the expected files under tests/golden/hand/ are literals written by hand from the reference's
+rules (derivations: tests/golden/hand/README.md), NOT by the oracle.  The CPU suite holds the oracle CLI to them,
+the GPU suite the HIP CLI, byte for byte."""
+import filecmp
+import os
+
+import pytest
+
+H = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hand")
+
+# case -> (sub-command + options, input, uses the annotation, {output kind: expected file})
+CASES = {
+    "upd": (["update-gtf", "-l", "5"], "upd.sam", True,
+            {"gtf": "upd.updated.gtf", "detail": "upd.detail.txt", "summary": "upd.summary.txt", "bed": "upd.novel_exon.bed"}),
+    "upd_c": (["update-gtf", "-l", "5", "-c"], "upd.sam", True,
+              {"gtf": "upd_c.updated.gtf", "detail": "upd.detail.txt", "summary": "upd_c.summary.txt", "bed": "upd_c.novel_exon.bed"}),
+    "split": (["update-gtf", "-s", "-l", "5", "-J", "1", "-j", os.path.join(H, "split_sj.tab")], "split.sam", True,
+              {"gtf": "split.updated.gtf", "detail": "split.detail.txt", "summary": "split.summary.txt", "bed": "split.novel_exon.bed"}),
+    "uniq": (["unique-gtf"], "uniq.sam", False, {"gtf": "uniq.unique.gtf"}),
+    "uniq_s": (["unique-gtf", "-s"], "uniq.sam", False, {"gtf": "uniq_s.unique.gtf"}),
+}
+
+
+def _argv(case, tmp_path):
+    cmd, inp, with_anno, expect = CASES[case]
+    out = {k: str(tmp_path / ("%s.%s" % (case, k))) for k in expect}
+    args = list(cmd)
+    if with_anno:
+        args += ["-A", out["detail"], "-y", out["summary"], "-E", out["bed"]]
+    args += [os.path.join(H, inp)]
+    if with_anno:
+        args += [os.path.join(H, "anno.gtf")]
+    return args, out, expect
+
+
+def _check(out, expect, case):
+    for k, name in expect.items():
+        want = os.path.join(H, name)
+        if not filecmp.cmp(out[k], want, shallow=False):
+            got = open(out[k]).read().split("\n")
+            exp = open(want).read().split("\n")
+            diff = [(i, g, e) for i, (g, e) in enumerate(zip(got, exp)) if g != e][:3]
+            raise AssertionError("%s: %s differs from the hand-derived %s (lines %d vs %d); first differences: %r" %
+                                 (case, k, name, len(got), len(exp), diff))
+
+
+def test_literal_files_are_current():
+    """The committed files are exactly what literal_files.py holds (nobody regenerated them from a program's output)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("literal_files", os.path.join(H, "literal_files.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for name, rows in m.FILES.items():
+        assert open(os.path.join(H, name)).read() == "".join(r + "\n" for r in rows), name
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_oracle_matches_hand_derived_files(oracle, tmp_path, case):
+    args, out, expect = _argv(case, tmp_path)
+    assert oracle.run_cli(args, stdout_path=out["gtf"]) == 0
+    _check(out, expect, case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_hip_cli_matches_hand_derived_files(tmp_path, case):
+    from lr2rmats_amd import hostlib
+    args, out, expect = _argv(case, tmp_path)
+    r = hostlib.run_cli(args, stdout_path=out["gtf"])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    _check(out, expect, case)
