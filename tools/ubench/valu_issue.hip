@@ -32,9 +32,9 @@ __global__ __launch_bounds__(256) void k_issue(uint32_t *out, unsigned long long
                          "v_cmp_lt_u32 vcc, %1, %0\n v_cndmask_b32 %3, %3, %2, vcc\n v_cmp_lt_u32 vcc, %5, %4\n v_cndmask_b32 %7, %7, %6, vcc\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :: "vcc");
         } else if (KIND == 2) {
-            asm volatile("v_add_u32 %0, %0, %8\n s_add_u32 %9, %9, 1\n v_add_u32 %1, %1, %8\n s_add_u32 %9, %9, 1\n v_add_u32 %2, %2, %8\n s_add_u32 %9, %9, 1\n v_add_u32 %3, %3, %8\n s_add_u32 %9, %9, 1\n"
-                         "v_add_u32 %4, %4, %8\n s_add_u32 %9, %9, 1\n v_add_u32 %5, %5, %8\n s_add_u32 %9, %9, 1\n v_add_u32 %6, %6, %8\n s_add_u32 %9, %9, 1\n v_add_u32 %7, %7, %8\n s_add_u32 %9, %9, 1\n"
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(seed), "s"(s0));
+            asm volatile("v_add_u32 %0, %0, %9\n s_add_u32 %8, %8, 1\n v_add_u32 %1, %1, %9\n s_add_u32 %8, %8, 1\n v_add_u32 %2, %2, %9\n s_add_u32 %8, %8, 1\n v_add_u32 %3, %3, %9\n s_add_u32 %8, %8, 1\n"
+                         "v_add_u32 %4, %4, %9\n s_add_u32 %8, %8, 1\n v_add_u32 %5, %5, %9\n s_add_u32 %8, %8, 1\n v_add_u32 %6, %6, %9\n s_add_u32 %8, %8, 1\n v_add_u32 %7, %7, %9\n s_add_u32 %8, %8, 1\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0) : "v"(seed) : "scc");
         } else if (KIND == 3) {
             // dependent LDS chain: address from the last value, 8 links per iteration
 #pragma unroll
@@ -79,6 +79,7 @@ static void run(const char *name, int per_iter)
 
 int main()
 {
+    setvbuf(stdout, NULL, _IOLBF, 0);
     run<0>("v_add_u32 x8 independent", 8);
     run<1>("v_cmp + v_cndmask x4", 8);
     run<2>("v_add_u32 / s_add_u32 x8", 16);
