@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--exchange", choices=("partitioned", "gathered"), default="partitioned")
+    ap.add_argument("--accepted", action="store_true", help="also compact the accepted-novel list at N=1 (always on at N>1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,6 +107,8 @@ def main():
     eng = capi.Engine(local_rank)
     eng.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
     eng.set_params(capi.default_params(full_level=args.level))
+    # the step produces the per-read results (SURVEY.md 8(d) bytes); the compacted accepted list only where the exchange sends it
+    eng.set_outputs(capi.WANT_RESULTS | (capi.WANT_ACCEPTED if (world > 1 or args.accepted) else 0))
     eng.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, first_read_index=rank * reads.n)
 
     gathered = {}

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define L2R_ABI_VERSION 1
+#define L2R_ABI_VERSION 2
 
 typedef struct l2r_ctx l2r_ctx;
 
@@ -169,6 +169,13 @@ l2r_ctx     *l2r_create(int device);
 void         l2r_destroy(l2r_ctx *ctx);
 
 int          l2r_set_params(l2r_ctx *ctx, const l2r_params *prm);
+/* Which outputs a run produces (default: both).  L2R_WANT_RESULTS = the per-read arrays of l2r_result (what
+ * check_trans() leaves in bam_T: detail.txt, -a/-k/-u, summary.txt need them); L2R_WANT_ACCEPTED = the compacted
+ * accepted-novel records of l2r_accepted (what check_trans() hands to novel_T / merge_trans, update_gtf.c:946-960:
+ * all that `update-gtf ... > new.gtf`, -v and -E need; the message of the multi-GPU all-gatherv). */
+#define L2R_WANT_RESULTS  1u
+#define L2R_WANT_ACCEPTED 2u
+int          l2r_set_outputs(l2r_ctx *ctx, unsigned want);
 int          l2r_set_annotation(l2r_ctx *ctx, const l2r_annotation *anno);
 int          l2r_set_junctions(l2r_ctx *ctx, const l2r_junctions *sj);   /* NULL or n == 0: no -j file */
 

@@ -19,13 +19,14 @@ LIB_PATH = os.path.join(HERE, "lib", "libl2r_hip.so")
 INFO_KNOWN, INFO_KNOWN_SITE, INFO_FULL, INFO_REV, INFO_UNREL, INFO_SJ_CHECKED, INFO_SJ_PASS, INFO_ACCEPTED = \
     1, 2, 4, 8, 16, 32, 64, 128
 EXF_NOVEL_EXON, EXF_NOVEL_DON, EXF_NOVEL_ACC, EXF_NOVEL_JUNC, EXF_UNREL_JUNC = 1, 2, 4, 8, 16
+WANT_RESULTS, WANT_ACCEPTED = 1, 2
 N_STAGES = 8
 STAGE_NAMES = ["pass_a", "scan_tiles", "classify_fast", "classify_generic", "validate_sj", "scan_accepted",
                "gather_accepted", "reserved"]
 
 EXPORTS = [
     "l2r_abi_version", "l2r_last_error", "l2r_device_count", "l2r_create", "l2r_destroy", "l2r_set_params",
-    "l2r_set_annotation", "l2r_set_junctions", "l2r_upload_reads", "l2r_run", "l2r_sync", "l2r_run_timed",
+    "l2r_set_outputs", "l2r_set_annotation", "l2r_set_junctions", "l2r_upload_reads", "l2r_run", "l2r_sync", "l2r_run_timed",
     "l2r_result_sizes", "l2r_download", "l2r_download_accepted", "l2r_device_view_get", "l2r_stream", "l2r_classify",
 ]
 
@@ -100,9 +101,10 @@ def load_library():
         lib.l2r_destroy.argtypes = [C.c_void_p]
         lib.l2r_stream.restype = C.c_void_p
         lib.l2r_stream.argtypes = [C.c_void_p]
-        for name in ("l2r_set_params", "l2r_set_annotation", "l2r_set_junctions", "l2r_upload_reads", "l2r_download",
+        for name in ("l2r_set_params", "l2r_set_outputs", "l2r_set_annotation", "l2r_set_junctions", "l2r_upload_reads", "l2r_download",
                      "l2r_download_accepted", "l2r_device_view_get"):
             getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p]
+        lib.l2r_set_outputs.argtypes = [C.c_void_p, C.c_uint]
         lib.l2r_run.argtypes = [C.c_void_p]
         lib.l2r_sync.argtypes = [C.c_void_p]
         lib.l2r_run_timed.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -170,6 +172,10 @@ class Engine:
 
     def set_params(self, p: Params):
         self._chk(self.lib.l2r_set_params(self.ctx, C.byref(p)))
+
+    def set_outputs(self, want: int):
+        """WANT_RESULTS (1) and/or WANT_ACCEPTED (2): include/lr2rmats_hip.h l2r_set_outputs."""
+        self._chk(self.lib.l2r_set_outputs(self.ctx, want))
 
     def set_annotation(self, tx_tid, tx_start, tx_end, tx_rev, tx_ex_off, ex_start, ex_end):
         a = [np.ascontiguousarray(tx_tid, np.int32), np.ascontiguousarray(tx_start, np.int32),

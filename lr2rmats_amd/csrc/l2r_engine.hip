@@ -40,11 +40,14 @@ struct DevBuf {
     int ensure(size_t n)
     {
         if (n <= cap && p) return 0;
+        // (contents are never carried over: every user refills the buffer.)  The old buffer is released first -- at 288 GB
+        // shards both would not always fit -- so a failed grow leaves an EMPTY buffer (p = null, cap = 0), never a stale one.
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = n ? n : 1;
-        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
-        if (e != hipSuccess) { p = nullptr; return fail(-2, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e)); }
-        cap = want;
+        const size_t want = n ? n : 1;
+        T *q = nullptr;
+        const hipError_t e = hipMalloc((void **)&q, want * sizeof(T));
+        if (e != hipSuccess) return fail(-2, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+        p = q; cap = want;
         return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -55,6 +58,8 @@ struct l2r_ctx {
     int fast_grid = 0;
     bool wide_cigar = false;                // long CIGARs: the HBM walks fetch 16 words per lane and round (l2r_upload_reads decides)
     int n_cu = 256, wg_per_cu = 4;          // persistent grid of k_classify_fast (L2R_WG_PER_CU overrides)
+    int ablate = 0;                         // diagnostics, L2R_ABLATE (read once, at l2r_create)
+    unsigned want = L2R_WANT_RESULTS | L2R_WANT_ACCEPTED;      // l2r_set_outputs
     hipStream_t stream = nullptr;
     l2r_params prm;
     // annotation
@@ -69,11 +74,13 @@ struct l2r_ctx {
     DevBuf<int32_t> j0;
     int64_t n_compact = 0, n_wide = 0;
     std::vector<int64_t> h_anno_key_raw;    // per transcript (tid,end) key, NOT prefix-maxed (unsorted-input cursor)
+    std::vector<int64_t> h_anno_key_pm;     // ... and its running maximum (what anno_key holds on the device)
     // junctions
     int64_t n_sj = 0;
     DevBuf<int32_t> sj_tid, sj_don, sj_acc, sj_uniq, sj_multi;
     DevBuf<int64_t> sj_key;
     std::vector<int64_t> h_sj_key_raw;      // per row (tid,acc) key
+    std::vector<int64_t> h_sj_key_pm;       // ... and its running maximum
     // reads
     int64_t n_reads = 0, n_cigar = 0, first_read = 0;
     bool sorted = true;
@@ -82,7 +89,19 @@ struct l2r_ctx {
     DevBuf<uint8_t> r_rev;
     DevBuf<int64_t> cig_off;
     DevBuf<uint32_t> cig;
-    std::vector<int32_t> h_tid, h_pos;      // kept only for unsorted input
+    std::vector<int32_t> h_tid, h_pos;      // kept for unsorted input, and with a junction table (cursor carry, below)
+    // One input may arrive as SEVERAL uploads (a single-GPU run too large for one shard: l2r_upload_reads with
+    // first_read_index == the number of records uploaded so far).  The two sequential cursors of check_trans()
+    // (src/update_gtf.c:938 last_anno_i, last_sj_i) are then carried from upload to upload, so that unsorted input
+    // sees the same history as one sequential pass.
+    struct Stream {
+        bool valid = false, sorted = true;
+        int64_t next = 0;                   // first_read_index a continuation must have
+        int64_t last_key = INT64_MIN;       // (tid, pos) of the last record so far (sortedness across uploads)
+        int64_t anno_cur = 0, sj_cur = 0;   // cursor values after everything uploaded (and, for sj_cur, classified) so far
+        int64_t anno_cur_start = 0, sj_cur_start = 0;   // ... and at the start of the current upload
+        bool sj_pending = false;            // the current upload used the device's prefix cursor: sj_cur is brought up to date at the next upload
+    } stream;
     DevBuf<int32_t> win_start, sj_cursor;   // only for unsorted input
     bool have_win = false;
     // work + results
@@ -122,7 +141,7 @@ static DevParams dev_params(const l2r_ctx *c)
     p.ss_dis = c->prm.ss_dis; p.full_level = c->prm.full_level; p.use_multi = c->prm.use_multi;
     p.min_sj_cnt = c->prm.min_sj_cnt; p.split_trans = c->prm.split_trans; p.frac = c->prm.single_exon_ovlp_frac;
     p.n_tx = (int32_t)c->n_tx; p.n_sj = (int32_t)c->n_sj; p.reads_per_tile = c->reads_per_tile;
-    { const char *e = getenv("L2R_ABLATE"); p.ablate = e ? atoi(e) : 0; }
+    p.ablate = c->ablate; p.want = (int32_t)c->want;
     return p;
 }
 
@@ -161,6 +180,8 @@ l2r_ctx *l2r_create(int device)
         if (e && atoi(e) > 0) c->wg_per_cu = atoi(e);
         e = getenv("L2R_FAST_GRID");
         if (e && atoi(e) > 0) c->fast_grid = atoi(e);
+        e = getenv("L2R_ABLATE");
+        c->ablate = e ? atoi(e) : 0;
     }
     return c;
 }
@@ -184,6 +205,18 @@ void l2r_destroy(l2r_ctx *c)
 }
 
 void *l2r_stream(l2r_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int l2r_set_outputs(l2r_ctx *c, unsigned want)
+{
+    if (!c) return fail(-1, "[l2r_set_outputs] null context");
+    if (!(want & (L2R_WANT_RESULTS | L2R_WANT_ACCEPTED)) || (want & ~(unsigned)(L2R_WANT_RESULTS | L2R_WANT_ACCEPTED)))
+        return fail(-1, "[l2r_set_outputs] want = %u: expected L2R_WANT_RESULTS and/or L2R_WANT_ACCEPTED", want);
+    // The per-read result arrays are always produced on the device (the junction check and the redo list read them);
+    // what the flag saves is the compaction of the accepted list (kernel work, 16 + 9n bytes per accepted read).
+    c->want = want;
+    c->ran = false; drop_graph(c);
+    return 0;
+}
 
 int l2r_set_params(l2r_ctx *c, const l2r_params *prm)
 {
@@ -316,6 +349,8 @@ int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
         if (k > run) run = k;
         key[(size_t)i] = run;
     }
+    c->h_anno_key_pm = key;
+    c->stream = l2r_ctx::Stream();
     std::sort(kd.begin(), kd.end()); std::sort(ka.begin(), ka.end()); std::sort(kx.begin(), kx.end()); std::sort(kj.begin(), kj.end());
     c->n_compact = n_compact;
     {   // one bucket grid for the four kinds: per tid, enough 512-bp buckets for its largest site coordinate
@@ -390,7 +425,7 @@ int l2r_set_junctions(l2r_ctx *c, const l2r_junctions *s)
     if (!c) return fail(-1, "[l2r_set_junctions] null context");
     HIP_TRY(hipSetDevice(c->device));
     c->ran = false; drop_graph(c);
-    if (!s || s->n == 0) { c->n_sj = 0; c->h_sj_key_raw.clear(); return 0; }
+    if (!s || s->n == 0) { c->n_sj = 0; c->h_sj_key_raw.clear(); c->h_sj_key_pm.clear(); c->stream = l2r_ctx::Stream(); return 0; }
     if (s->n < 0 || s->n > 0x7ffffff0LL) return fail(-1, "[l2r_set_junctions] size out of range");
     const int64_t n = s->n;
     std::vector<int64_t> key((size_t)n);
@@ -417,8 +452,13 @@ int l2r_set_junctions(l2r_ctx *c, const l2r_junctions *s)
     HIP_TRY(hipMemcpyAsync(c->sj_key.p, key.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_sj = n;
+    c->h_sj_key_pm = key;
+    c->stream = l2r_ctx::Stream();
     return 0;
 }
+
+static int prepare_unsorted_windows(l2r_ctx *c);
+static int finish_stream_sj_cursor(l2r_ctx *c);
 
 int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
 {
@@ -436,8 +476,23 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         if (r->cig_off[i + 1] < r->cig_off[i]) return fail(-1, "[l2r_upload_reads] cig_off not monotone at %lld", (long long)i);
         if (i && (r->tid[i] < r->tid[i - 1] || (r->tid[i] == r->tid[i - 1] && r->pos[i] < r->pos[i - 1]))) sorted = false;
     }
+    {   // is this upload the continuation of the previous one?  (see l2r_ctx::Stream)
+        l2r_ctx::Stream &st = c->stream;
+        const bool cont = st.valid && r->first_read_index > 0 && r->first_read_index == st.next;
+        if (cont) { int rc = finish_stream_sj_cursor(c); if (rc) return rc; }      // (needs the previous upload's results: before they are overwritten)
+        else st = l2r_ctx::Stream();
+        if (N && st.sorted) {
+            const int64_t first = ((int64_t)r->tid[0] << 32) | (uint32_t)r->pos[0];
+            if (!sorted || first < st.last_key) st.sorted = false;            // from here on the cursors depend on the history
+        }
+        sorted = st.sorted;
+        if (N) st.last_key = ((int64_t)r->tid[N - 1] << 32) | (uint32_t)r->pos[N - 1];
+        st.anno_cur_start = st.anno_cur; st.sj_cur_start = st.sj_cur;
+        st.next = r->first_read_index + N; st.valid = true;
+        st.sj_pending = false;
+    }
     c->sorted = sorted; c->have_win = false;
-    if (!sorted) { c->h_tid.assign(r->tid, r->tid + N); c->h_pos.assign(r->pos, r->pos + N); }
+    if (!sorted || c->n_sj > 0) { c->h_tid.assign(r->tid, r->tid + N); c->h_pos.assign(r->pos, r->pos + N); }
     else { c->h_tid.clear(); c->h_pos.clear(); }
 
     // tile size: keep the expected exons of a tile inside the LDS staging area.
@@ -549,6 +604,40 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     }
     c->n_reads = N; c->n_cigar = r->n_cigar; c->first_read = r->first_read_index;
     c->ran = false; c->totals_valid = false; drop_graph(c);
+    if (sorted) {
+        // the annotation cursor after a sorted prefix is the prefix function of its last record
+        if (N) {
+            const int64_t q = host_key(r->tid[N - 1], r->pos[N - 1] + 1);
+            const int64_t at = std::upper_bound(c->h_anno_key_pm.begin(), c->h_anno_key_pm.end(), q) - c->h_anno_key_pm.begin();
+            c->stream.anno_cur = std::max(c->stream.anno_cur, at);
+        }
+        c->stream.sj_pending = c->n_sj > 0;
+    } else {
+        int rc = prepare_unsorted_windows(c);            // replays the cursor now, so that the next upload can continue it
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// Brings Stream::sj_cur up to date after an upload whose junction cursor ran on the device (sorted so far): the
+// reference's last_sj_i only moves for reads that reach check_short_sj (src/update_gtf.c:947,613-614), so it is the
+// prefix function of the LAST such read -- known only once that upload has been classified.
+static int finish_stream_sj_cursor(l2r_ctx *c)
+{
+    l2r_ctx::Stream &st = c->stream;
+    if (!st.sj_pending || !c->ran || c->n_sj == 0 || c->n_reads == 0) { st.sj_pending = false; return 0; }
+    const int64_t N = c->n_reads;
+    std::vector<uint32_t> info((size_t)N);
+    HIP_TRY(hipMemcpyAsync(info.data(), c->info.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int64_t i = N - 1; i >= 0; --i) {
+        if ((info[(size_t)i] & (I_FULL | I_KNOWN | I_KSITE)) != (I_FULL | I_KSITE)) continue;
+        const int64_t q = host_key(c->h_tid[(size_t)i], c->h_pos[(size_t)i] + 1);
+        const int64_t at = std::upper_bound(c->h_sj_key_pm.begin(), c->h_sj_key_pm.end(), q) - c->h_sj_key_pm.begin();
+        st.sj_cur = std::max(st.sj_cur, at);
+        break;
+    }
+    st.sj_pending = false;
     return 0;
 }
 
@@ -559,12 +648,13 @@ static int prepare_unsorted_windows(l2r_ctx *c)
     if (c->sorted || c->have_win) return 0;
     const int64_t N = c->n_reads, T = c->n_tx;
     std::vector<int32_t> w((size_t)N);
-    int64_t cur = 0;
+    int64_t cur = c->stream.anno_cur_start;              // 0 unless this upload continues an earlier one
     for (int64_t i = 0; i < N; ++i) {
         const int64_t q = host_key(c->h_tid[(size_t)i], c->h_pos[(size_t)i] + 1);
         while (cur < T && c->h_anno_key_raw[(size_t)cur] <= q) ++cur;
         w[(size_t)i] = (int32_t)cur;
     }
+    c->stream.anno_cur = cur;
     if (c->win_start.ensure((size_t)N)) return -2;
     if (N) HIP_TRY(hipMemcpyAsync(c->win_start.p, w.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -581,13 +671,14 @@ static int prepare_unsorted_sj_cursor(l2r_ctx *c)
     if (N) HIP_TRY(hipMemcpyAsync(info.data(), c->info.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<int32_t> cur_v((size_t)N, 0);
-    int64_t cur = 0;
+    int64_t cur = c->stream.sj_cur_start;                // 0 unless this upload continues an earlier one
     for (int64_t i = 0; i < N; ++i) {
         if ((info[(size_t)i] & (I_FULL | I_KNOWN | I_KSITE)) != (I_FULL | I_KSITE)) continue;
         const int64_t q = host_key(c->h_tid[(size_t)i], c->h_pos[(size_t)i] + 1);
         while (cur < S && c->h_sj_key_raw[(size_t)cur] <= q) ++cur;
         cur_v[(size_t)i] = (int32_t)cur;
     }
+    c->stream.sj_cur = cur;
     if (c->sj_cursor.ensure((size_t)N)) return -2;
     if (N) HIP_TRY(hipMemcpyAsync(c->sj_cursor.p, cur_v.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -661,14 +752,16 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
                            c->sj_key.p, (c->sorted ? (const int32_t *)nullptr : c->sj_cursor.p), c->sj_tid.p, c->sj_don.p, c->sj_acc.p,
                            c->sj_uniq.p, c->sj_multi.p, p, c->info.p);
         // acceptance is decided by the junction check: recount per tile
-        hipLaunchKernelGGL(k_count_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->info.p, c->tile_acc.p, c->tile_acc_ex.p);
+        if (c->want & L2R_WANT_ACCEPTED)
+            hipLaunchKernelGGL(k_count_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->info.p, c->tile_acc.p, c->tile_acc_ex.p);
     }
     MARK(ST_SCAN2);
-    {
+    if (c->want & L2R_WANT_ACCEPTED) {
         ScanJobs jobs; jobs.job[0] = ScanJob{c->tile_acc.p, c->n_tiles, c->totals.p + 1}; jobs.job[1] = ScanJob{c->tile_acc_ex.p, c->n_tiles, c->totals.p + 2};
         hipLaunchKernelGGL(k_scan_u32, dim3(2), dim3(1024), 0, s, jobs);
     }
     MARK(ST_GATHER);
+    if (c->want & L2R_WANT_ACCEPTED)
     hipLaunchKernelGGL(k_gather_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->first_read, c->info.p, c->ref_tx.p, c->ex_off.p,
                        c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->tile_acc.p, c->tile_acc_ex.p, c->tile_chunk.p, c->tile_rchunk.p, c->totals.p + 4,
                        c->acc_rec.p, c->acc_ex_off.p, c->acc_start.p, c->acc_end.p, c->acc_flag.p);
@@ -756,6 +849,7 @@ static int fetch_totals(l2r_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     // accepted exons = the chunks the classification kernel placed itself (cursor) + the ones k_gather_accepted placed
     c->h_totals[0] = dev[0]; c->h_totals[1] = dev[1] + dev[5]; c->h_totals[2] = dev[2] + dev[4];
+    if (!(c->want & L2R_WANT_ACCEPTED)) c->h_totals[1] = c->h_totals[2] = 0;
     c->totals_valid = true;
     return 0;
 }
@@ -767,9 +861,13 @@ int l2r_run_timed(l2r_ctx *c, int iters, l2r_timing *out)
     int rc = prepare_unsorted_windows(c);
     if (rc) return rc;
     memset(out, 0, sizeof *out);
-    hipEvent_t t0, t1, ev[ST_N + 1];
-    HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1));
-    for (int i = 0; i <= ST_N; ++i) HIP_TRY(hipEventCreate(&ev[i]));
+    // every event lives in one holder that releases them on every way out of this function
+    struct Events {
+        hipEvent_t e[ST_N + 3]; int n = 0;
+        ~Events() { for (int i = 0; i < n; ++i) (void)hipEventDestroy(e[i]); }
+    } evs;
+    for (int i = 0; i < ST_N + 3; ++i) { HIP_TRY(hipEventCreate(&evs.e[i])); evs.n = i + 1; }
+    hipEvent_t t0 = evs.e[ST_N + 1], t1 = evs.e[ST_N + 2], *ev = evs.e;
     // pass A: whole pipeline, back to back
     HIP_TRY(hipEventRecord(t0, c->stream));
     for (int it = 0; it < iters; ++it) { rc = launch_all(c, nullptr); if (rc) return rc; }
@@ -784,8 +882,6 @@ int l2r_run_timed(l2r_ctx *c, int iters, l2r_timing *out)
         for (int i = 0; i < ST_N; ++i) { float d = 0; HIP_TRY(hipEventElapsedTime(&d, ev[i], ev[i + 1])); out->stage_ms[i] += d / (float)iters; }
     }
     out->iters = iters;
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
-    for (int i = 0; i <= ST_N; ++i) (void)hipEventDestroy(ev[i]);
     c->ran = true; c->totals_valid = false;
     return 0;
 }
@@ -833,6 +929,7 @@ int l2r_download_accepted(l2r_ctx *c, l2r_accepted *a)
 {
     if (!c || !a) return fail(-1, "[l2r_download_accepted] null argument");
     HIP_TRY(hipSetDevice(c->device));
+    if (!(c->want & L2R_WANT_ACCEPTED)) return fail(-1, "[l2r_download_accepted] the accepted list was not requested (l2r_set_outputs)");
     int rc = fetch_totals(c);
     if (rc) return rc;
     const int64_t M = c->h_totals[1], X = c->h_totals[2];

@@ -104,7 +104,9 @@ struct DevParams {
     float   frac;
     int32_t n_tx, n_sj, reads_per_tile;
     int32_t ablate;          // diagnostics (env L2R_ABLATE): 1 = every read through the generic kernel
+    int32_t want;            // l2r_set_outputs: bit 0 per-read results, bit 1 the compacted accepted list
 };
+constexpr int32_t WANT_RESULTS = 1, WANT_ACCEPTED = 2;
 
 // info / exon-flag bit layout: keep in sync with include/lr2rmats_hip.h
 constexpr uint32_t I_KNOWN = 1u, I_KSITE = 2u, I_FULL = 4u, I_REV = 8u, I_UNREL = 16u,
@@ -803,7 +805,7 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
         if (lane == 0) {
             info_io[r] = v.info;
             ref_out[r] = v.ref;
-            if (v.info & I_ACCEPT) {
+            if ((v.info & I_ACCEPT) && (p.want & WANT_ACCEPTED)) {
                 int lo = 0, hi = n_tiles;                  // the tile of read r: last t with tile_first[t] <= r
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_first[mid] <= r) lo = mid; else hi = mid; }
                 const uint32_t t = (uint32_t)lo;
@@ -1076,48 +1078,62 @@ struct SiteMasks { uint32_t kand, kor, dm_first, am_last; };
 
 // V' = window transcripts j >= j0 up to the first one the read lies before (src/update_gtf.c:799-800), minus the ones
 // that lie before the read (:801); terminal-exon masks of check_full (:629-681); single-exon known candidates (:806-811).
-// Wave-uniform j, header words broadcast from LDS.
+// One pass over the window with a wave-uniform member index (header words broadcast from LDS) that only BUILDS per-read
+// bit masks -- "the read lies before member j", "member j lies before the read", "first / last exons overlap" -- with no
+// per-member branch; the sweep's stop (:799) and the cursor (:801-802) are applied to the masks afterwards:
+//     V' = ~before & (members below the first "read lies before") & (members from the cursor value on).
+// tilemask[0] / [1]: the tile's members with one exon / without TX_COMPACT (set where the headers are staged).
 template <int LEVEL>
 __device__ __forceinline__ VisitMasks visit_window(const TileLds &L, const TileDesc &d, int w_n, bool work, uint32_t n, int j0,
-                                                   const ReadEnds &re)
+                                                   const ReadEnds &re, const uint32_t *tilemask)
 {
     VisitMasks m{0u, 0u, 0u, 0u, false};
+    uint32_t m_aft = 0u, m_bef = 0u;
+    for (int j = 0; j < w_n; ++j) {
+        const int4 hk = L.hk[j];
+        const uint32_t bit = 1u << j;
+        m_aft |= re.el <= hk.x ? bit : 0u;                                   // comp_trans <= (Q5): the read lies before the member
+        m_bef |= hk.y <= re.s0 ? bit : 0u;                                   // the member lies before the read
+        if (LEVEL >= 1 && LEVEL <= 4) {
+            const int4 hx = L.hx[j];
+            if (LEVEL == 1) {
+                m.lmask |= re.e0 == hx.y ? bit : 0u;
+                m.rmask |= re.sl == hx.z ? bit : 0u;
+            } else {
+                m.lmask |= closed_overlap(re.s0, re.e0, hx.x, hx.y) ? bit : 0u;
+                if (LEVEL != 4) m.rmask |= closed_overlap(re.sl, re.el, hx.z, hx.w) ? bit : 0u;
+            }
+        }
+    }
     int jrel0 = j0 - d.j_lo;                       // first member the read's sweep reaches
     if (!(d.flags & TD_CONTIG)) {
         jrel0 = 0;
         for (int j = 0; j < w_n; ++j) jrel0 += L.win[j] < j0 ? 1 : 0;
     }
-    bool stopped = !work;
-    for (int j = 0; j < w_n; ++j) {
-        const int4 hk = L.hk[j];
-        const bool act = !stopped && j >= jrel0;
-        const bool aft = re.el <= hk.x;                                     // comp_trans <= (Q5)
-        stopped = stopped || (act && aft);
-        const bool ov = act && !aft && !(hk.y <= re.s0);
-        if (!__any(ov)) { if (__all(stopped)) break; continue; }
-        const uint32_t bit = 1u << j;
-        if (ov) m.vpre |= bit;
-        const int4 hx = L.hx[j];
-        if (LEVEL == 1) {
-            if (ov && re.e0 == hx.y) m.lmask |= bit;
-            if (ov && re.sl == hx.z) m.rmask |= bit;
-        } else if (LEVEL >= 2 && LEVEL <= 4) {
-            if (ov && closed_overlap(re.s0, re.e0, hx.x, hx.y)) m.lmask |= bit;
-            if (LEVEL != 4 && ov && closed_overlap(re.sl, re.el, hx.z, hx.w)) m.rmask |= bit;
+    // members the sweep reaches: index >= jrel0 (which may be negative or beyond the window)
+    const uint32_t reach = jrel0 <= 0 ? 0xffffffffu : (jrel0 >= 32 ? 0u : ~((1u << jrel0) - 1u));
+    const uint32_t stop = m_aft & reach;                                     // the sweep ends at the lowest of these (:799-800)
+    const uint32_t below = (stop & (0u - stop)) - 1u;                        // all ones when there is none
+    m.vpre = work ? (~m_bef & below & reach & (w_n >= 32 ? 0xffffffffu : ((1u << w_n) - 1u))) : 0u;
+    m.lmask &= m.vpre; m.rmask &= m.vpre;
+    // single-exon members only count against single-exon reads (:806-811); a member without TX_COMPACT needs the literal loops
+    const uint32_t single = tilemask[0];
+    if (n == 1) {
+        uint32_t c = m.vpre & single;
+        while (c) {
+            const int j = __ffs((int)c) - 1;
+            c &= c - 1u;
+            const int4 hx = L.hx[j];
+            if (overlap_frac(re.s0, re.e0, hx.x, hx.y) >= fast_args()->p.frac) m.k1mask |= 1u << j;
         }
-        if (hk.z == 1) {                 // single-exon transcript: only against single-exon reads
-            if (ov && n == 1 && overlap_frac(re.s0, re.e0, hx.x, hx.y) >= fast_args()->p.frac) m.k1mask |= bit;
-        } else if (!((hk.w & 0xff) & TX_COMPACT)) {
-            if (ov && n > 1) m.redo = true;                                 // literal loops needed for this pair
-        }
-    }
+    } else if (m.vpre & tilemask[1] & ~single) m.redo = true;
     return m;
 }
 
 // index of the lowest set bit, 63 when there is none
 __device__ __forceinline__ uint32_t first_member(uint32_t x)
 {
-    return (uint32_t)__builtin_ctzll((unsigned long long)x | (1ull << 63));
+    return (uint32_t)(__ffs((int)x) - 1) & 63u;                         // v_ffbl_b32 (-1 for 0), masked to 63
 }
 
 // x != 0 as 0 / 1 in one VALU instruction (the compiler turns min(x, 1) into compare + select + a literal move)
@@ -1263,6 +1279,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
     __shared__ int s_wide;                                          // some staged entry has members beyond its 64-bit masks
     __shared__ uint16_t s_nat[TILE_THREADS];                        // per read of the tile in READ order: exon count, bit 15 = accepted
     __shared__ uint32_t s_chunk[2];
+    __shared__ uint32_t s_tilemask[2];                              // window members with one exon / without TX_COMPACT
 
     (void)kernarg_block;
     const bool stamping = fast_args()->stamps != nullptr;
@@ -1310,7 +1327,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
 #pragma unroll
             for (int q = 0; q < PF_CIG_VEC; ++q) { const int i = q * TILE_THREADS + (int)threadIdx.x; if (i < n4) dst[i] = v.cg[q]; }
         }
-        if (threadIdx.x == 0) s_wide = 0;
+        if (threadIdx.x == 0) { s_wide = 0; s_tilemask[0] = 0u; s_tilemask[1] = 0u; }
         __syncthreads();
         L2R_STAMP(0);
 
@@ -1366,6 +1383,12 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
                     s_win[j] = v.xb.w;
                 }
             }
+            if (wv == TILE_THREADS / WAVE - 1) {                    // (wave-uniform) the header lanes are the upper half of the last wave
+                const int j = (int)threadIdx.x - KEY_CAP;
+                const bool mine = j >= 0 && j < w_n;
+                const unsigned long long b1 = __ballot(mine && v.xb.x == 1), b2 = __ballot(mine && !((v.xb.z & 0xff) & TX_COMPACT));
+                if (lane == WAVE / 2) { s_tilemask[0] = (uint32_t)(b1 >> 32); s_tilemask[1] = (uint32_t)(b2 >> 32); }
+            }
             if (!(d.flags & TD_CONTIG)) __syncthreads();         // (tile-uniform) the entries below need the member list
             if ((int)threadIdx.x < KEY_CAP) {
                 const bool has_st = threadIdx.x < d.st_nk, has_en = threadIdx.x < d.en_nk;
@@ -1413,7 +1436,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         bool redo = active && (!fast || !in_lds || any_wide != 0 || tid != d.tid || (n > 1 && !sane));
         const bool work = active && !redo;
         const TileLds L{s_S, s_E, s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_hk, s_hx, s_win};
-        const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, j0, re);
+        const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, j0, re, s_tilemask);
         redo = redo || vm.redo;
         L2R_STAMP(2);
         const SiteMasks sm = map_exons(L, d, work && !redo && n > 1, local, n, vm.vpre);
@@ -1440,6 +1463,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         int32_t *const o_ex_start = ao->ex_start, *const o_ex_end = ao->ex_end, *const o_ref = ao->ref_tx, *const o_acc_start = ao->acc_start, *const o_acc_end = ao->acc_end;
         uint8_t *const o_ex_flag = ao->ex_flag, *const o_acc_flag = ao->acc_flag;
         const int32_t o_n_sj = ao->p.n_sj, o_ablate = ao->p.ablate;
+        const bool want_acc = (ao->p.want & WANT_ACCEPTED) != 0;
         asm volatile("" :: "s"(o_redo_count), "s"(o_redo), "s"(o_tile_acc), "s"(o_tile_acc_ex), "s"(o_tile_chunk), "s"(o_cursor), "s"(o_ex_off), "s"(o_info),
                      "s"(o_ex_start), "s"(o_ex_end), "s"(o_ref), "s"(o_acc_start), "s"(o_acc_end), "s"(o_ex_flag), "s"(o_acc_flag), "s"(o_n_sj), "s"(o_ablate),
                      "s"(o_tile_rchunk), "s"(o_acc_ex_off), "s"(o_acc_rec), "s"(o_first_read));
@@ -1451,10 +1475,12 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
                 at = __shfl(at, 0, WAVE);
                 if (redo) o_redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
             }
-            const bool acc = (info & I_ACCEPT) != 0;
-            const uint32_t ca = (uint32_t)__popcll(__ballot(acc)), cx = wave_sum(acc ? n : 0u);
-            if (lane == 0) { s_cnt[wv][0] = ca; s_cnt[wv][1] = cx; s_cnt[wv][2] = (uint32_t)__popcll(m); }
-            if (active) s_nat[u.src] = (uint16_t)(min(n, 0x7fffu) | (acc ? 0x8000u : 0u));
+            if (want_acc) {                  // (uniform) the accepted list is compacted only when somebody asked for it
+                const bool acc = (info & I_ACCEPT) != 0;
+                const uint32_t ca = (uint32_t)__popcll(__ballot(acc)), cx = wave_sum(acc ? n : 0u);
+                if (lane == 0) { s_cnt[wv][0] = ca; s_cnt[wv][1] = cx; s_cnt[wv][2] = (uint32_t)__popcll(m); }
+                if (active) s_nat[u.src] = (uint16_t)(min(n, 0x7fffu) | (acc ? 0x8000u : 0u));
+            }
         }
         __syncthreads();
         L2R_STAMP(5);
@@ -1464,9 +1490,9 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         // out by an atomic cursor: their order is arbitrary, tile_chunk says where a tile's chunk starts).  Only when
         // every verdict of the tile is final here: no read on the redo list, no junction table (k_validate_sj decides).
         const uint32_t ca_t = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0], cx_t = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
-        const bool fused = in_lds && (s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2]) == 0u && o_n_sj == 0 && !(o_ablate & 2);
+        const bool fused = want_acc && in_lds && (s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2]) == 0u && o_n_sj == 0 && !(o_ablate & 2);
         unsigned long long chunk = 0ull;               // {first record slot, first exon slot} of the tile's chunk
-        if (threadIdx.x == 0) {
+        if (want_acc && threadIdx.x == 0) {
             o_tile_acc[t] = fused ? 0u : ca_t;          // what k_gather_accepted has to place: reads ...
             o_tile_acc_ex[t] = fused ? 0u : cx_t;       // ... and exons
             if (!fused) o_tile_chunk[t] = CHUNK_DEFERRED;

@@ -24,7 +24,7 @@ def test_library_exports_every_symbol():
     for name in _declared():
         assert hasattr(lib, name), name
     lib.l2r_abi_version.restype = ctypes.c_int
-    assert lib.l2r_abi_version() == 1
+    assert lib.l2r_abi_version() == 2
 
 
 def test_struct_layouts():
