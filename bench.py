@@ -2,19 +2,24 @@
 """bench.py -- lr2rmats update-gtf hot path on MI355X.
 
 One "step" = one pass of the hot path (CIGAR -> exons, annotation sweep,
-classification, compaction of the accepted-novel records) over the rank's
-resident read shard.  At N > 1 the shards are blocks of whole chromosomes, which
-is what lr2rmats_amd/dist.py makes of a sorted input: the order-dependent host
-tail never looks across chromosomes, so every rank merges and writes its own
-shard and the step's only collective is the RCCL all-gather of the per-rank list
-sizes (--exchange partitioned, default).  --exchange gathered times the other
-route of dist.py (shards that cut through a chromosome, or -s with a junction
-table): the RCCL all-gatherv of the compacted accepted records to every rank.
+classification, per-read results in HBM) over the rank's resident read shard.
+At N > 1 the shards are blocks of whole chromosomes, which is what
+lr2rmats_amd/dist.py makes of a sorted input: the order-dependent host tail never
+looks across chromosomes, so every rank merges and writes its own shard and the
+step has NO collective (--exchange partitioned, default; the list sizes travel
+once, after the timed region).  --exchange gathered times the other route of
+dist.py (shards that cut through a chromosome, or -s with a junction table): the
+compaction of the accepted records + their RCCL all-gatherv to every rank.
 
 Workload at N=1: BASELINE.json configs[2] -- synthetic 10 M long reads, 8 exons/read
 target, GENCODE-scale 1.5 M-exon GTF, pipeline option set `-l 3` (Snakefile:93).
-Inputs are resident in HBM when the timed region starts.  Weak scaling: every
-rank gets its own 10 M-read shard (its block of chromosomes of one sorted set).
+Inputs are resident in HBM when the timed region starts.
+--scaling strong (default) = BASELINE.json configs[3]: the SAME 10 M reads cut into N
+chromosome-aligned shards (10 M / N reads per GPU).  --scaling weak: 10 M per GPU.
+After the timed region rank 0 adds, at N=1: the dominant kernel's roofline figure
+(HIP events on the engine's stream), the CPU oracle timed on one host core, and an
+end-to-end run of the C CLI through files (BAM + GTF in, GTF / detail / summary / bed
+out) on the same 10 M reads (--no-e2e skips it).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -47,6 +52,44 @@ def cpu_baseline(af, reads, sample: int, level: int):
     return sub.n / dt, sub, res, dt
 
 
+def e2e_leg(af, reads, level: int):
+    """End to end through files on the same reads: the C CLI reads a BAM and the GTF, classifies on the GPU and writes the
+    updated GTF, detail.txt, summary.txt and novel_exon.bed (`lr2rmats update-gtf -l N -A -y -E -o`).  Wall clock of that
+    one process; its own stage split (L2R_TIMING=1) is kept.  Inputs are written here first (not timed)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from lr2rmats_amd import hostlib, synth
+    d = tempfile.mkdtemp(prefix="l2r_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        bam, gtf = os.path.join(d, "reads.bam"), os.path.join(d, "anno.gtf")
+        t0 = time.perf_counter()
+        synth.write_bam_fast(reads, bam)
+        af.write_gtf(gtf)
+        t_in = time.perf_counter() - t0
+        out = {k: os.path.join(d, k) for k in ("updated.gtf", "detail.txt", "summary.txt", "novel_exon.bed")}
+        env = dict(os.environ)
+        env["L2R_TIMING"] = "1"
+        cmd = [hostlib.CLI_PATH, "update-gtf", "-l", str(level), "-A", out["detail.txt"], "-y", out["summary.txt"], "-E", out["novel_exon.bed"],
+               "-o", out["updated.gtf"], bam, gtf]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        wall = time.perf_counter() - t0
+        stages = {}
+        for line in r.stderr.decode(errors="replace").splitlines():
+            if line.startswith("[timing]"):
+                parts = line[len("[timing]"):].rsplit(None, 2)
+                if len(parts) == 3:
+                    stages[parts[0].strip()] = float(parts[1])
+        return {"wall_s": round(wall, 3), "rc": r.returncode, "reads": reads.n, "reads_per_s": round(reads.n / wall, 1),
+                "stages_s": stages, "input_bytes": {"bam": os.path.getsize(bam), "gtf": os.path.getsize(gtf)},
+                "outputs_bytes": {k: (os.path.getsize(v) if os.path.exists(v) else 0) for k, v in out.items()},
+                "command": "lr2rmats update-gtf -l %d -A detail.txt -y summary.txt -E novel_exon.bed -o updated.gtf reads.bam anno.gtf" % level,
+                "inputs_written_s": round(t_in, 1)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def pmc_traffic(kernel: str, config: str, n_reads: int):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE and WRITE_SIZE need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots"; tools/pmc_traffic.py
@@ -74,7 +117,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--exchange", choices=("partitioned", "gathered"), default="partitioned")
-    ap.add_argument("--accepted", action="store_true", help="also compact the accepted-novel list at N=1 (always on at N>1)")
+    ap.add_argument("--accepted", action="store_true", help="also compact the accepted-novel list (always on with --exchange gathered)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,13 +147,17 @@ def main():
     cfg = dict(workload.CONFIGS[args.config])
     if args.reads:
         cfg["n_reads"] = args.reads
+    if args.scaling == "strong":
+        # configs[3]: one read set of cfg["n_reads"] cut into `world` chromosome-aligned shards
+        cfg["n_reads"] = cfg["n_reads"] // world + (1 if rank < cfg["n_reads"] % world else 0)
     af, reads = workload.make_rank_workload(cfg, rank, world)
 
     eng = capi.Engine(local_rank)
     eng.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
     eng.set_params(capi.default_params(full_level=args.level))
     # the step produces the per-read results (SURVEY.md 8(d) bytes); the compacted accepted list only where the exchange sends it
-    eng.set_outputs(capi.WANT_RESULTS | (capi.WANT_ACCEPTED if (world > 1 or args.accepted) else 0))
+    gather = world > 1 and args.exchange == "gathered"
+    eng.set_outputs(capi.WANT_RESULTS | (capi.WANT_ACCEPTED if (gather or args.accepted) else 0))
     eng.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, first_read_index=rank * reads.n)
 
     gathered = {}
@@ -121,8 +170,6 @@ def main():
         allc = [torch.zeros_like(cnt) for _ in range(world)]
         dist.all_gather(allc, cnt)
         allc = [c.tolist() for c in allc]
-        if args.exchange == "partitioned":
-            return sum(c[0] for c in allc), sum(c[1] for c in allc)
         # (the exon arrays are chunked per tile, see include/lr2rmats_hip.h: the per-record offsets travel with the records)
         parts = (("rec", v.acc_rec, 16, 0), ("ex_off", v.acc_ex_off, 4, 0), ("ex_start", v.acc_ex_start, 4, 1), ("ex_end", v.acc_ex_end, 4, 1),
                  ("ex_flag", v.acc_ex_flag, 1, 1))
@@ -135,7 +182,7 @@ def main():
     def step():
         eng.run()
         eng.sync()
-        if world > 1:
+        if gather:
             return exchange()
         return None
 
@@ -160,7 +207,13 @@ def main():
         dt = float(tt.item())
 
     n_r, n_x, n_acc, n_acc_x = eng.sizes()
-    total_reads = reads.n * world
+    if world > 1:
+        # reads of all ranks (strong scaling: the shards differ by at most one read); outside the timed region
+        tr = torch.tensor([reads.n], dtype=torch.int64, device=device)
+        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+        total_reads = int(tr.item())
+    else:
+        total_reads = reads.n
     value = total_reads * args.steps / dt
 
     out = None
@@ -189,24 +242,33 @@ def main():
                   and np.array_equal(got.ex_end[:nx], ores.ex_end) and np.array_equal(got.ex_flag[:nx], ores.ex_flag)
                   and np.array_equal(got.info[: sub.n] & 0x7f, ores.info & 0x7f) and np.array_equal(got.ref_tx[: sub.n], ores.ref_tx))
             cpu = {"value": round(rate, 1), "unit": "reads/s", "cores": 1, "kind": "port",
-                   "sample": "first %d reads of the same workload, oracle/ (sequential C restatement), %.1f s" % (sub.n, cdt),
-                   "parity_on_sample": bool(ok)}
+                   "sample": "first %d reads of the same workload, oracle/ (sequential C restatement: comparison core only, "
+                             "structure-of-arrays in, no parsing, no lists), %.1f s" % (sub.n, cdt),
+                   "parity_on_sample": bool(ok),
+                   # the reference itself cannot be built or shipped (htslib); its survey-time probe on a 2.1 GHz Xeon, BASELINE.md section 2
+                   "reference_core_reads_per_s": 3.0e5, "reference_e2e_reads_per_s": 3.2e4,
+                   "reference_note": "BASELINE.md section 2 (survey-time probe of the unmodified reference, other host; indicative only)"}
+        e2e = None
+        if world == 1 and not args.no_e2e:
+            e2e = e2e_leg(af, reads, args.level)
         out = {
             "metric": "long-read alignments classified/sec; achieved HBM GB/s vs roofline",
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: synthetic %d long reads/GPU x %.2f exons/read (%.1f CIGAR ops/read), "
+            "config": {"workload": "BASELINE configs[%d]: synthetic %d long reads (%d per GPU) x %.2f exons/read (%.1f CIGAR ops/read), "
                                    "%d-exon / %d-transcript GTF, update-gtf -l %d" % (
-                                       {"cfg2": 1, "cfg3": 2, "cfg5": 4}.get(args.config, 2), reads.n, n_x / max(n_r, 1), reads.cig.shape[0] / max(n_r, 1), af.n_exons, af.n_tx, args.level),
+                                       ({"cfg2": 1, "cfg3": 2, "cfg5": 4}.get(args.config, 2) + (1 if (world > 1 and args.scaling == "strong" and args.config == "cfg3") else 0)),
+                                       total_reads, reads.n, n_x / max(n_r, 1), reads.cig.shape[0] / max(n_r, 1), af.n_exons, af.n_tx, args.level),
                        "reads_per_gpu": reads.n, "total_reads": total_reads, "accepted_reads_rank0": n_acc,
                        "exchange": "none (1 GPU)" if world == 1 else (
-                           "partitioned: chromosome-aligned shards merge on their own rank, RCCL all-gather of the list sizes only (%s accepted records / %s exons in total stay local)" % (last[0], last[1])
-                           if args.exchange == "partitioned" else
+                           "partitioned: chromosome-aligned shards merge and write on their own rank; no collective inside a step"
+                           if not gather else
                            "gathered: RCCL all-gatherv (padded all_gather_into_tensor) of %s accepted records / %s exons to every rank" % (last[0], last[1])),
                        "parallelism": "reads sharded over %d GPU(s), annotation replicated" % world},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "e2e": e2e,
         }
     if world > 1:
         dist.barrier()

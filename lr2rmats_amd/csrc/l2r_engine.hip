@@ -101,7 +101,7 @@ struct l2r_ctx {
         int64_t anno_cur = 0, sj_cur = 0;   // cursor values after everything uploaded (and, for sj_cur, classified) so far
         int64_t anno_cur_start = 0, sj_cur_start = 0;   // ... and at the start of the current upload
         bool sj_pending = false;            // the current upload used the device's prefix cursor: sj_cur is brought up to date at the next upload
-    } stream;
+    } seq;
     DevBuf<int32_t> win_start, sj_cursor;   // only for unsorted input
     bool have_win = false;
     // work + results
@@ -350,7 +350,7 @@ int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
         key[(size_t)i] = run;
     }
     c->h_anno_key_pm = key;
-    c->stream = l2r_ctx::Stream();
+    c->seq = l2r_ctx::Stream();
     std::sort(kd.begin(), kd.end()); std::sort(ka.begin(), ka.end()); std::sort(kx.begin(), kx.end()); std::sort(kj.begin(), kj.end());
     c->n_compact = n_compact;
     {   // one bucket grid for the four kinds: per tid, enough 512-bp buckets for its largest site coordinate
@@ -425,7 +425,7 @@ int l2r_set_junctions(l2r_ctx *c, const l2r_junctions *s)
     if (!c) return fail(-1, "[l2r_set_junctions] null context");
     HIP_TRY(hipSetDevice(c->device));
     c->ran = false; drop_graph(c);
-    if (!s || s->n == 0) { c->n_sj = 0; c->h_sj_key_raw.clear(); c->h_sj_key_pm.clear(); c->stream = l2r_ctx::Stream(); return 0; }
+    if (!s || s->n == 0) { c->n_sj = 0; c->h_sj_key_raw.clear(); c->h_sj_key_pm.clear(); c->seq = l2r_ctx::Stream(); return 0; }
     if (s->n < 0 || s->n > 0x7ffffff0LL) return fail(-1, "[l2r_set_junctions] size out of range");
     const int64_t n = s->n;
     std::vector<int64_t> key((size_t)n);
@@ -453,7 +453,7 @@ int l2r_set_junctions(l2r_ctx *c, const l2r_junctions *s)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_sj = n;
     c->h_sj_key_pm = key;
-    c->stream = l2r_ctx::Stream();
+    c->seq = l2r_ctx::Stream();
     return 0;
 }
 
@@ -477,7 +477,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         if (i && (r->tid[i] < r->tid[i - 1] || (r->tid[i] == r->tid[i - 1] && r->pos[i] < r->pos[i - 1]))) sorted = false;
     }
     {   // is this upload the continuation of the previous one?  (see l2r_ctx::Stream)
-        l2r_ctx::Stream &st = c->stream;
+        l2r_ctx::Stream &st = c->seq;
         const bool cont = st.valid && r->first_read_index > 0 && r->first_read_index == st.next;
         if (cont) { int rc = finish_stream_sj_cursor(c); if (rc) return rc; }      // (needs the previous upload's results: before they are overwritten)
         else st = l2r_ctx::Stream();
@@ -609,9 +609,9 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         if (N) {
             const int64_t q = host_key(r->tid[N - 1], r->pos[N - 1] + 1);
             const int64_t at = std::upper_bound(c->h_anno_key_pm.begin(), c->h_anno_key_pm.end(), q) - c->h_anno_key_pm.begin();
-            c->stream.anno_cur = std::max(c->stream.anno_cur, at);
+            c->seq.anno_cur = std::max(c->seq.anno_cur, at);
         }
-        c->stream.sj_pending = c->n_sj > 0;
+        c->seq.sj_pending = c->n_sj > 0;
     } else {
         int rc = prepare_unsorted_windows(c);            // replays the cursor now, so that the next upload can continue it
         if (rc) return rc;
@@ -624,7 +624,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
 // prefix function of the LAST such read -- known only once that upload has been classified.
 static int finish_stream_sj_cursor(l2r_ctx *c)
 {
-    l2r_ctx::Stream &st = c->stream;
+    l2r_ctx::Stream &st = c->seq;
     if (!st.sj_pending || !c->ran || c->n_sj == 0 || c->n_reads == 0) { st.sj_pending = false; return 0; }
     const int64_t N = c->n_reads;
     std::vector<uint32_t> info((size_t)N);
@@ -648,13 +648,13 @@ static int prepare_unsorted_windows(l2r_ctx *c)
     if (c->sorted || c->have_win) return 0;
     const int64_t N = c->n_reads, T = c->n_tx;
     std::vector<int32_t> w((size_t)N);
-    int64_t cur = c->stream.anno_cur_start;              // 0 unless this upload continues an earlier one
+    int64_t cur = c->seq.anno_cur_start;              // 0 unless this upload continues an earlier one
     for (int64_t i = 0; i < N; ++i) {
         const int64_t q = host_key(c->h_tid[(size_t)i], c->h_pos[(size_t)i] + 1);
         while (cur < T && c->h_anno_key_raw[(size_t)cur] <= q) ++cur;
         w[(size_t)i] = (int32_t)cur;
     }
-    c->stream.anno_cur = cur;
+    c->seq.anno_cur = cur;
     if (c->win_start.ensure((size_t)N)) return -2;
     if (N) HIP_TRY(hipMemcpyAsync(c->win_start.p, w.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -671,14 +671,14 @@ static int prepare_unsorted_sj_cursor(l2r_ctx *c)
     if (N) HIP_TRY(hipMemcpyAsync(info.data(), c->info.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<int32_t> cur_v((size_t)N, 0);
-    int64_t cur = c->stream.sj_cur_start;                // 0 unless this upload continues an earlier one
+    int64_t cur = c->seq.sj_cur_start;                // 0 unless this upload continues an earlier one
     for (int64_t i = 0; i < N; ++i) {
         if ((info[(size_t)i] & (I_FULL | I_KNOWN | I_KSITE)) != (I_FULL | I_KSITE)) continue;
         const int64_t q = host_key(c->h_tid[(size_t)i], c->h_pos[(size_t)i] + 1);
         while (cur < S && c->h_sj_key_raw[(size_t)cur] <= q) ++cur;
         cur_v[(size_t)i] = (int32_t)cur;
     }
-    c->stream.sj_cur = cur;
+    c->seq.sj_cur = cur;
     if (c->sj_cursor.ensure((size_t)N)) return -2;
     if (N) HIP_TRY(hipMemcpyAsync(c->sj_cursor.p, cur_v.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

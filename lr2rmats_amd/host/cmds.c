@@ -404,26 +404,109 @@ void h_job_free(h_job *j)
 
 static void engine_fail(const char *who) { h_fatal(who, "%s", l2r_last_error()); }
 
+/* One engine shard holds fewer than 2^32 reads + CIGAR ops (32-bit exon offsets on the device); an input beyond that is
+ * classified shard by shard -- the reference has no such limit (src/update_gtf.c:1063-1083 reads whatever memory
+ * holds).  Results do not depend on where the cuts fall: every read owns its result, and for unsorted input the
+ * engine carries the two sequential cursors from upload to upload (l2r_upload_reads with consecutive
+ * first_read_index).  L2R_CHUNK_READS = reads per shard (tests force small shards with it). */
+static int64_t shard_end(const l2r_reads *r, int64_t lo)
+{
+    const char *e = getenv("L2R_CHUNK_READS");
+    const int64_t max_reads = (e && atoll(e) > 0) ? atoll(e) : INT64_MAX;
+    const int64_t max_units = 0xf0000000LL;                 /* reads + ops of a shard */
+    int64_t a = lo, b = r->n_reads;                         /* largest hi with units(lo, hi) <= max_units */
+    while (a < b) {
+        const int64_t mid = a + (b - a + 1) / 2;
+        if ((r->cig_off[mid] - r->cig_off[lo]) + (mid - lo) <= max_units) a = mid; else b = mid - 1;
+    }
+    if (a == lo && lo < r->n_reads) h_fatal("update_gtf", "record %lld alone exceeds the engine's shard limit", (long long)lo);
+    if (a - lo > max_reads) a = lo + max_reads;
+    return a;
+}
+
+static void result_reserve(h_result *r, int64_t reads_cap, int64_t ex_cap)
+{
+    r->ex_off = (int64_t *)h_realloc(r->ex_off, (size_t)(reads_cap + 1) * 8);
+    r->info = (uint32_t *)h_realloc(r->info, (size_t)(reads_cap ? reads_cap : 1) * 4);
+    r->ref_tx = (int32_t *)h_realloc(r->ref_tx, (size_t)(reads_cap ? reads_cap : 1) * 4);
+    r->ex_start = (int32_t *)h_realloc(r->ex_start, (size_t)(ex_cap ? ex_cap : 1) * 4);
+    r->ex_end = (int32_t *)h_realloc(r->ex_end, (size_t)(ex_cap ? ex_cap : 1) * 4);
+    r->ex_flag = (uint8_t *)h_realloc(r->ex_flag, (size_t)(ex_cap ? ex_cap : 1));
+}
+
+/* Runs the engine over the whole input.
+ *   acc_read == NULL: `out` = the per-read results of every record, in input order (l2r_download);
+ *   acc_read != NULL: `out` = only the reads check_trans() hands to novel_T / merge_trans (update_gtf.c:946-960), in
+ *                     input order, through the device-side compaction (l2r_download_accepted: about a third of the bytes
+ *                     over PCIe and no host pass over the rest); *acc_read[k] = input index of row k. */
 static void run_engine(const char *who, const l2r_params *prm, const l2r_annotation *a, const l2r_junctions *s,
-                       const l2r_reads *r, h_result *out)
+                       const l2r_reads *r, h_result *out, int64_t **acc_read)
 {
     l2r_ctx *ctx = l2r_create(0);
     if (!ctx) engine_fail(who);
     h_stage_time("engine: create");
-    if (l2r_set_params(ctx, prm) || l2r_set_annotation(ctx, a) || l2r_set_junctions(ctx, s->n ? s : NULL)) engine_fail(who);
+    if (l2r_set_params(ctx, prm) || l2r_set_outputs(ctx, acc_read ? L2R_WANT_ACCEPTED : L2R_WANT_RESULTS) ||
+        l2r_set_annotation(ctx, a) || l2r_set_junctions(ctx, s->n ? s : NULL)) engine_fail(who);
     h_stage_time("engine: annotation tables");
-    if (l2r_upload_reads(ctx, r)) engine_fail(who);
-    h_stage_time("engine: upload reads");
-    if (l2r_run(ctx) || l2r_sync(ctx)) engine_fail(who);
-    h_stage_time("engine: kernels");
-    int64_t n = 0, x = 0;
-    if (l2r_result_sizes(ctx, &n, &x, NULL, NULL)) engine_fail(who);
-    h_result_alloc(out, n, x);
-    l2r_result res = { n, x, 0, out->ex_off, out->ex_start, out->ex_end, out->ex_flag, out->info, out->ref_tx };
-    if (l2r_download(ctx, &res)) engine_fail(who);
-    out->n = res.n_reads; out->n_ex = res.n_exons;
-    h_stage_time("engine: download");
+    memset(out, 0, sizeof *out);
+    int64_t rows = 0, exons = 0, rows_cap = 0, ex_cap = 0, *idx = NULL, *off_tmp = NULL;
+    l2r_accepted_read *rec = NULL; int64_t rec_cap = 0;
+    int64_t lo = 0;
+    do {
+        const int64_t hi = shard_end(r, lo), n = hi - lo;
+        l2r_reads sub = *r;
+        sub.n_reads = n; sub.n_cigar = r->cig_off[hi] - r->cig_off[lo];
+        sub.tid = r->tid + lo; sub.pos = r->pos + lo; sub.rev = r->rev + lo; sub.cig = r->cig + r->cig_off[lo];
+        sub.first_read_index = lo;
+        if (lo > 0) {                                        /* the engine wants offsets that start at 0 */
+            off_tmp = (int64_t *)h_realloc(off_tmp, (size_t)(n + 1) * 8);
+            for (int64_t i = 0; i <= n; ++i) off_tmp[i] = r->cig_off[lo + i] - r->cig_off[lo];
+            sub.cig_off = off_tmp;
+        } else sub.cig_off = r->cig_off;
+        if (l2r_upload_reads(ctx, &sub)) engine_fail(who);
+        if (l2r_run(ctx) || l2r_sync(ctx)) engine_fail(who);
+        int64_t nr = 0, nx = 0, na = 0, nax = 0;
+        if (l2r_result_sizes(ctx, &nr, &nx, &na, &nax)) engine_fail(who);
+        const int64_t add_rows = acc_read ? na : nr, add_ex = acc_read ? nax : nx;
+        if (rows + add_rows > rows_cap || exons + add_ex > ex_cap || !out->ex_off) {
+            /* a single shard (the usual case) is allocated exactly; later shards grow geometrically */
+            rows_cap = lo == 0 && hi == r->n_reads ? add_rows : (rows + add_rows) * 2;
+            ex_cap = lo == 0 && hi == r->n_reads ? add_ex : (exons + add_ex) * 2;
+            result_reserve(out, rows_cap, ex_cap);
+            if (acc_read) idx = (int64_t *)h_realloc(idx, (size_t)(rows_cap ? rows_cap : 1) * 8);
+        }
+        if (!acc_read) {
+            l2r_result res = { add_rows, add_ex, 0, out->ex_off + rows, out->ex_start + exons, out->ex_end + exons, out->ex_flag + exons,
+                               out->info + rows, out->ref_tx + rows };
+            if (l2r_download(ctx, &res)) engine_fail(who);
+        } else {
+            if (add_rows > rec_cap) { rec_cap = add_rows; rec = (l2r_accepted_read *)h_realloc(rec, (size_t)(rec_cap ? rec_cap : 1) * sizeof *rec); }
+            l2r_accepted acc = { add_rows, add_ex, 0, rec, out->ex_off + rows, out->ex_start + exons, out->ex_end + exons, out->ex_flag + exons };
+            if (l2r_download_accepted(ctx, &acc)) engine_fail(who);
+            for (int64_t k = 0; k < add_rows; ++k) {
+                idx[rows + k] = (int64_t)(((uint64_t)rec[k].read_hi << 32) | rec[k].read_lo);     /* global index: first_read_index + local */
+                out->info[rows + k] = rec[k].info; out->ref_tx[rows + k] = rec[k].ref_tx;
+            }
+        }
+        if (exons) for (int64_t k = 0; k <= add_rows; ++k) out->ex_off[rows + k] += exons;          /* shard-local -> global offsets */
+        rows += add_rows; exons += add_ex;
+        lo = hi;
+    } while (lo < r->n_reads);
+    out->n = rows; out->n_ex = exons;
+    if (!out->ex_off) result_reserve(out, 0, 0);
+    out->ex_off[rows] = exons;
+    if (acc_read) *acc_read = idx;
+    free(off_tmp); free(rec);
+    h_stage_time("engine: upload, kernels, download");
     l2r_destroy(ctx);
+}
+
+/* which outputs need every read (detail.txt, the all / known / unrecognised lists, summary.txt) -- without them only
+ * the accepted reads matter: that is the pipeline's first pass, `update-gtf -l N in.bam old.gtf > new.gtf` (Snakefile:93) */
+static int needs_all_reads(const h_job *j)
+{
+    return j->o.bam_gtf || j->o.bam_detail || j->o.known_gtf || j->o.unrecog_gtf || j->o.summary ||
+           j->out_path[2] || j->out_path[3] || j->out_path[4] || j->out_path[6] || j->out_path[7];
 }
 
 int h_cmd_update_gtf(int argc, char **argv)
@@ -434,9 +517,34 @@ int h_cmd_update_gtf(int argc, char **argv)
     l2r_params prm; l2r_annotation a; l2r_junctions s; l2r_reads r;
     h_job_views(j, &prm, &a, &s, &r);
     h_result out;
-    run_engine("update_gtf", &prm, &a, &s, &r, &out);
-    l2r_result res = { out.n, out.n_ex, out.n_ex, out.ex_off, out.ex_start, out.ex_end, out.ex_flag, out.info, out.ref_tx };
-    rc = h_job_finish(j, &res);
+    const char *force = getenv("L2R_ROUTE");                 /* diagnostics / tests: "full" or "accepted" */
+    const int accepted_only = force ? !strcmp(force, "accepted") && !needs_all_reads(j) : !needs_all_reads(j);
+    if (!accepted_only) {
+        run_engine("update_gtf", &prm, &a, &s, &r, &out, NULL);
+        l2r_result res = { out.n, out.n_ex, out.n_ex, out.ex_off, out.ex_start, out.ex_end, out.ex_flag, out.info, out.ref_tx };
+        rc = h_job_finish(j, &res);
+    } else {
+        /* the tail runs over the accepted reads alone: a view of the input records that keeps just them */
+        int64_t *idx = NULL;
+        run_engine("update_gtf", &prm, &a, &s, &r, &out, &idx);
+        h_reads *rd = &j->reads;
+        const int64_t m = out.n;
+        int32_t *tid = (int32_t *)h_malloc((size_t)(m + 1) * 4), *pos = (int32_t *)h_malloc((size_t)(m + 1) * 4);
+        uint8_t *rev = (uint8_t *)h_malloc((size_t)m + 1);
+        uint32_t *qn = (uint32_t *)h_malloc((size_t)(m + 1) * 4), *tn = rd->tid_name ? (uint32_t *)h_malloc((size_t)(m + 1) * 4) : NULL;
+        for (int64_t k = 0; k < m; ++k) {
+            const int64_t i = idx[k];
+            if (i < 0 || i >= rd->n) h_fatal("update_gtf", "accepted record %lld points at read %lld of %lld", (long long)k, (long long)i, (long long)rd->n);
+            tid[k] = rd->tid[i]; pos[k] = rd->pos[i]; rev[k] = rd->rev[i]; qn[k] = rd->qname[i];
+            if (tn) tn[k] = rd->tid_name[i];
+        }
+        int32_t *o_tid = rd->tid, *o_pos = rd->pos; uint8_t *o_rev = rd->rev; uint32_t *o_qn = rd->qname, *o_tn = rd->tid_name; const int64_t o_n = rd->n;
+        rd->tid = tid; rd->pos = pos; rd->rev = rev; rd->qname = qn; rd->tid_name = tn; rd->n = m;      /* (cig_off is not read by the tail) */
+        l2r_result res = { out.n, out.n_ex, out.n_ex, out.ex_off, out.ex_start, out.ex_end, out.ex_flag, out.info, out.ref_tx };
+        rc = h_job_finish(j, &res);
+        rd->tid = o_tid; rd->pos = o_pos; rd->rev = o_rev; rd->qname = o_qn; rd->tid_name = o_tn; rd->n = o_n;
+        free(tid); free(pos); free(rev); free(qn); free(tn); free(idx);
+    }
     h_stage_time("merge + writers");
     h_result_free(&out);
     h_job_free(j);
@@ -461,7 +569,7 @@ static void exons_only(const char *who, const char *fn, const l2r_params *prm, h
     int64_t zero_off = 0; a.tx_ex_off = &zero_off;
     l2r_junctions s; memset(&s, 0, sizeof s);
     l2r_reads r = { reads->n, reads->n_cig, reads->tid, reads->pos, reads->rev, reads->cig_off, reads->cig, 0 };
-    run_engine(who, prm, &a, &s, &r, out);
+    run_engine(who, prm, &a, &s, &r, out, NULL);
 }
 
 int h_cmd_bam2gtf(int argc, char **argv)

@@ -140,9 +140,14 @@ class Job:
             self.h = None
 
 
-def run_cli(args, stdout_path=None, cwd=None) -> subprocess.CompletedProcess:
-    """Run the C binary ``lr2rmats <args>`` (needs a GPU for update-gtf / bam2gtf / unique-gtf -m b)."""
+def run_cli(args, stdout_path=None, cwd=None, env=None) -> subprocess.CompletedProcess:
+    """Run the C binary ``lr2rmats <args>`` (needs a GPU for update-gtf / bam2gtf / unique-gtf -m b).
+    ``env``: extra environment variables (L2R_CHUNK_READS, L2R_ROUTE, L2R_THREADS ...)."""
+    full_env = None
+    if env:
+        full_env = dict(os.environ)
+        full_env.update({k: str(v) for k, v in env.items()})
     if stdout_path:
         with open(stdout_path, "wb") as fh:
-            return subprocess.run([CLI_PATH] + list(args), stdout=fh, stderr=subprocess.PIPE, cwd=cwd)
-    return subprocess.run([CLI_PATH] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=cwd)
+            return subprocess.run([CLI_PATH] + list(args), stdout=fh, stderr=subprocess.PIPE, cwd=cwd, env=full_env)
+    return subprocess.run([CLI_PATH] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=cwd, env=full_env)

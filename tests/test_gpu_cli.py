@@ -111,3 +111,74 @@ def test_gtf_input_mode(oracle, tmp_path, files):
     assert oracle.run_cli(["bam2gtf", sam], stdout_path=rgtf) == 0
     _compare(oracle, tmp_path, ["-m", "g", "-b", sam, "-l", "3"], rgtf, gtf, "mg")          # (the oracle reads SAM headers only)
     _compare(oracle, tmp_path, ["-m", "g", "-b", sam, "-l", "5", "-d", "1"], rgtf, gtf, "mg2")
+
+
+def _run_all_outputs(tmp_path, tag, extra, aln, gtf, env=None):
+    o = _paths(tmp_path, tag)
+    r = hostlib.run_cli(_args(extra, o, aln, gtf), env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return o
+
+
+@pytest.mark.parametrize("kind", ["sorted", "unsorted", "unsorted_sj"])
+def test_sharded_single_gpu_run_is_byte_identical(oracle, tmp_path, files, kind):
+    """A single-GPU run cut into many engine shards (L2R_CHUNK_READS; the engine's own limit is 2^32 reads + ops per
+    shard) writes the bytes of the unsharded run -- also for unsorted input, whose two sequential cursors
+    (src/update_gtf.c:938) the engine carries from shard to shard."""
+    d, anno, reads, sam, bam, gtf = files
+    extra = ["-l", "3"]
+    aln = bam
+    if kind != "sorted":
+        ur = synth.make_reads(anno, 30000, 5, 47, unsorted=True)
+        aln = str(tmp_path / "u.sam")
+        ur.write_sam(aln)
+        if kind == "unsorted_sj":
+            af = anno.in_file_order()
+            base = util.oracle_run(oracle, af, ur, oracle.default_params(full_level=3))
+            j, _ = util.junction_table(af, ur, base, 47, cover=0.6)
+            tab = str(tmp_path / "SJ.out.tab")
+            j.write(tab)
+            extra = ["-s", "-l", "3", "-J", "1", "-j", tab]
+    whole = _run_all_outputs(tmp_path, "whole", extra, aln, gtf)
+    # unsorted input: also against the oracle (sequential cursors)
+    if kind != "sorted":
+        oo = _paths(tmp_path, "orc")
+        assert oracle.run_cli(_args(extra, oo, aln, gtf)) == 0
+        for k in OUTS:
+            assert filecmp.cmp(oo[k], whole[k], shallow=False), (kind, "oracle", k)
+    for chunk in (7001, 1500):
+        part = _run_all_outputs(tmp_path, "c%d" % chunk, extra, aln, gtf, env={"L2R_CHUNK_READS": chunk})
+        for k in OUTS:
+            assert filecmp.cmp(whole[k], part[k], shallow=False), (kind, chunk, k)
+
+
+@pytest.mark.parametrize("extra", [["-l", "3"], ["-l", "5", "-c"], "sj"])
+def test_accepted_route_writes_the_same_files(oracle, tmp_path, files, extra):
+    """`update-gtf ... > new.gtf` with at most -v / -E asks the engine for the compacted accepted list only
+    (l2r_download_accepted, the pipeline's first pass, Snakefile:93); the files equal the ones of the full-result route
+    and of the oracle.  Sharded too."""
+    d, anno, reads, sam, bam, gtf = files
+    if extra == "sj":
+        af = anno.in_file_order()
+        base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3))
+        j, _ = util.junction_table(af, reads, base, 43, cover=0.7)
+        tab = str(tmp_path / "SJ.out.tab")
+        j.write(tab)
+        extra = ["-s", "-l", "3", "-J", "1", "-j", tab]
+
+    def run(tag, env, binary=True):
+        o = {k: str(tmp_path / ("%s.%s" % (tag, k))) for k in ("gtf", "bed", "novel")}
+        args = ["update-gtf"] + extra + ["-E", o["bed"], "-v", o["novel"], "-o", o["gtf"], bam if binary else sam, gtf]
+        if binary:
+            r = hostlib.run_cli(args, env=env)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+        else:
+            assert oracle.run_cli(args) == 0
+        return o
+
+    want = run("orc", None, binary=False)
+    for tag, env in (("acc", None), ("full", {"L2R_ROUTE": "full"}), ("acc_sharded", {"L2R_CHUNK_READS": 9000})):
+        got = run(tag, env)
+        for k in want:
+            assert filecmp.cmp(want[k], got[k], shallow=False), (tag, k)
+        assert os.path.getsize(got["gtf"]) > 1000
