@@ -13,6 +13,7 @@
 
 #include "../../include/lr2rmats_hip.h"
 #include "l2r_kernels.hip.h"
+#include "l2r_fused.hip.h"
 
 using namespace l2r;
 
@@ -59,6 +60,12 @@ struct l2r_ctx {
     bool wide_cigar = false;                // long CIGARs: the HBM walks fetch 16 words per lane and round (l2r_upload_reads decides)
     int n_cu = 256, wg_per_cu = 4;          // persistent grid of k_classify_fast (L2R_WG_PER_CU overrides)
     int ablate = 0;                         // diagnostics, L2R_ABLATE (read once, at l2r_create)
+    bool allow_fused = true;                // L2R_PIPELINE=classic keeps the two-walk kernels for every input
+    bool fused = false;                     // the current upload runs the one-walk pipeline (l2r_fused.hip.h): sorted input, short CIGARs
+    DevBuf<uint16_t> lub;                   // k_order: first LDS slot of every read
+    DevBuf<uint32_t> tile_ub, tile_start, tile_total, tile_dest;
+    DevBuf<int32_t> lin_start, lin_end;     // l2r_download of a fused run: the exon arrays in read order (k_linearize)
+    DevBuf<uint8_t> lin_flag;
     unsigned want = L2R_WANT_RESULTS | L2R_WANT_ACCEPTED;      // l2r_set_outputs
     hipStream_t stream = nullptr;
     l2r_params prm;
@@ -182,6 +189,8 @@ l2r_ctx *l2r_create(int device)
         if (e && atoi(e) > 0) c->fast_grid = atoi(e);
         e = getenv("L2R_ABLATE");
         c->ablate = e ? atoi(e) : 0;
+        e = getenv("L2R_PIPELINE");
+        c->allow_fused = !(e && !strcmp(e, "classic"));
     }
     return c;
 }
@@ -198,6 +207,8 @@ void l2r_destroy(l2r_ctx *c)
     c->win_start.release(); c->sj_cursor.release();
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
+    c->lub.release(); c->tile_ub.release(); c->tile_start.release(); c->tile_total.release(); c->tile_dest.release();
+    c->lin_start.release(); c->lin_end.release(); c->lin_flag.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -596,6 +607,9 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
         c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb) || (c->wide_cigar && c->walked.ensure((size_t)(c->n_tiles + 1) * LDS_EXON_CAP))) return -2;
     c->ex_cap = (int64_t)exb;
+    c->fused = c->allow_fused && sorted && !c->wide_cigar;
+    if (c->fused && (c->lub.ensure((size_t)N + 1) || c->tile_ub.ensure((size_t)c->n_tiles + 1) || c->tile_start.ensure((size_t)c->n_tiles + 1) ||
+                     c->tile_total.ensure((size_t)c->n_tiles + 1) || c->tile_dest.ensure((size_t)c->n_tiles + 1))) return -2;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (getenv("L2R_STAMPS") && !c->stamps.p) {
         if (c->stamps.ensure(1024 * 8 + 16)) return -2;
@@ -701,6 +715,42 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     MARK(ST_PASS_A);
     const CursorDir cd{c->anno_key.p, c->key_dir.p, c->kb_base.p, c->n_tid_key, (int32_t)c->n_tx};
     const SiteTabs tabs{{c->sk_st.p, c->sd_st.p, c->sr_st.p}, {c->sk_en.p, c->sd_en.p, nullptr}, c->tid_base.p, c->n_tid_dir};
+    FastArgs fa;
+    fa.n_reads = N; fa.r_tid = c->r_tid.p; fa.r_pos = c->r_pos.p; fa.r_rev = c->r_rev.p; fa.cig_off = c->cig_off.p; fa.cig = c->cig.p;
+    fa.walked = c->walked.p; fa.local = c->local.p; fa.order = c->order.p; fa.tile_base = c->tile_base.p; fa.j0 = j0; fa.desc = c->desc.p; fa.win_hdr = c->win_hdr.p;
+    fa.hdr = c->hdr.p; fa.st = tabs.st; fa.en = tabs.en;
+    fa.ex_off = c->ex_off.p; fa.ex_start = c->ex_start.p; fa.ex_end = c->ex_end.p; fa.ex_flag = c->ex_flag.p; fa.info = c->info.p; fa.ref_tx = c->ref_tx.p;
+    fa.tile_acc = c->tile_acc.p; fa.tile_acc_ex = c->tile_acc_ex.p; fa.redo_count = c->totals.p + 3; fa.redo = c->redo.p;
+    fa.tile_chunk = c->tile_chunk.p; fa.tile_rchunk = c->tile_rchunk.p; fa.chunk_cursor = (unsigned long long *)(c->totals.p + 4);
+    fa.acc_start = c->acc_start.p; fa.acc_end = c->acc_end.p; fa.acc_flag = c->acc_flag.p; fa.acc_rec = (AccRec *)c->acc_rec.p; fa.acc_ex_off = c->acc_ex_off.p; fa.first_read = c->first_read;
+    fa.stamps = c->stamps.p; fa.p = p;
+    // persistent grid: a few workgroups per CU walk over the tiles (l2r_kernels.hip.h)
+    unsigned gp = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * c->wg_per_cu);
+    if (c->fast_grid > 0) gp = (unsigned)std::min<int64_t>(gp, c->fast_grid);           // L2R_FAST_GRID: tests force many tiles per workgroup
+    if (c->fused) {
+        // ---- the one-walk pipeline (l2r_fused.hip.h): k_order, then the persistent k_fused
+        unsigned long long *const ex_cursor = (unsigned long long *)(c->totals.p + 6);
+        hipLaunchKernelGGL(k_order, dim3(gt), dim3(TILE_THREADS), 0, s, (const int64_t *)c->cig_off.p, (const uint32_t *)c->tile_first.p, p,
+                           c->order.p, c->lub.p, c->tile_ub.p, c->totals.p + 3, ex_cursor);
+        MARK(ST_SCAN1);
+        MARK(ST_FAST);
+        FusedArgs ga;
+        ga.f = fa; ga.cd = cd; ga.tid_base = c->tid_base.p; ga.n_tid_dir = c->n_tid_dir; ga.lub = c->lub.p; ga.tile_ub = c->tile_ub.p;
+        ga.tile_start = c->tile_start.p; ga.tile_total = c->tile_total.p; ga.ex_cursor = ex_cursor;
+#define launch_fused_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused<L>), dim3(gp), dim3(TILE_THREADS), 0, s, ga, c->n_tiles, (const uint32_t *)c->tile_first.p, \
+            (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_ub.p)
+        switch (p.full_level) {
+        case 1: launch_fused_level(1); break;
+        case 2: launch_fused_level(2); break;
+        case 3: launch_fused_level(3); break;
+        case 4: launch_fused_level(4); break;
+        case 5: launch_fused_level(5); break;
+        default: launch_fused_level(0); break;
+        }
+#undef launch_fused_level
+        // every tile's accepted reads are compacted by k_gather_accepted (nothing is fused into the classification here)
+        if (c->want & L2R_WANT_ACCEPTED) HIP_TRY(hipMemsetAsync(c->tile_chunk.p, 0xff, (size_t)(c->n_tiles + 1) * 4, s));
+    } else {
     // sorted input: the cursor value of every read is computed on the device; unsorted input: it was replayed on the host
     if (c->wide_cigar)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass_a<true>), dim3(gt), dim3(TILE_THREADS), pass_a_dynamic_lds(c->reads_per_tile), s, N, c->r_tid.p, c->r_pos.p, c->cig_off.p, c->cig.p, cd, tabs, p,
@@ -717,18 +767,6 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     }
     MARK(ST_FAST);
     {
-        FastArgs fa;
-        fa.n_reads = N; fa.r_tid = c->r_tid.p; fa.r_pos = c->r_pos.p; fa.r_rev = c->r_rev.p; fa.cig_off = c->cig_off.p; fa.cig = c->cig.p;
-        fa.walked = c->walked.p; fa.local = c->local.p; fa.order = c->order.p; fa.tile_base = c->tile_base.p; fa.j0 = j0; fa.desc = c->desc.p; fa.win_hdr = c->win_hdr.p;
-        fa.hdr = c->hdr.p; fa.st = tabs.st; fa.en = tabs.en;
-        fa.ex_off = c->ex_off.p; fa.ex_start = c->ex_start.p; fa.ex_end = c->ex_end.p; fa.ex_flag = c->ex_flag.p; fa.info = c->info.p; fa.ref_tx = c->ref_tx.p;
-        fa.tile_acc = c->tile_acc.p; fa.tile_acc_ex = c->tile_acc_ex.p; fa.redo_count = c->totals.p + 3; fa.redo = c->redo.p;
-        fa.tile_chunk = c->tile_chunk.p; fa.tile_rchunk = c->tile_rchunk.p; fa.chunk_cursor = (unsigned long long *)(c->totals.p + 4);
-        fa.acc_start = c->acc_start.p; fa.acc_end = c->acc_end.p; fa.acc_flag = c->acc_flag.p; fa.acc_rec = (AccRec *)c->acc_rec.p; fa.acc_ex_off = c->acc_ex_off.p; fa.first_read = c->first_read;
-        fa.stamps = c->stamps.p; fa.p = p;
-        // persistent grid: a few workgroups per CU walk over the tiles (l2r_kernels.hip.h)
-        unsigned gp = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * c->wg_per_cu);
-        if (c->fast_grid > 0) gp = (unsigned)std::min<int64_t>(gp, c->fast_grid);           // L2R_FAST_GRID: tests force many tiles per workgroup
         switch (p.full_level) {
         case 1: launch_fast_level(1, fa, gp, s); break;
         case 2: launch_fast_level(2, fa, gp, s); break;
@@ -738,12 +776,14 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         default: launch_fast_level(0, fa, gp, s); break;      // src/update_gtf.c:629-696: no evidence is gathered, full = lfull && rfull = 0
         }
     }
+    }
     MARK(ST_GENERIC);
     {
         const unsigned gg = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles * 4 : 1, 4096);      // one wave per listed read, grid-stride
-        hipLaunchKernelGGL(k_classify_generic, dim3(gg), dim3(TILE_THREADS), 0, s, c->totals.p + 3, c->redo.p, c->r_tid.p, c->r_rev.p, j0,
+        hipLaunchKernelGGL(k_classify_generic, dim3(gg), dim3(TILE_THREADS), 0, s, c->totals.p + 3, c->redo.p, c->r_tid.p, c->r_rev.p,
+                           (c->fused ? (const int32_t *)nullptr : j0),
                            c->hdr.p, c->anno_ex.p, p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->info.p, c->ref_tx.p,
-                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles);
+                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles, cd);
     }
     MARK(ST_SJ);
     if (c->n_sj > 0) {
@@ -751,8 +791,9 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         hipLaunchKernelGGL(k_validate_sj, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p,
                            c->sj_key.p, (c->sorted ? (const int32_t *)nullptr : c->sj_cursor.p), c->sj_tid.p, c->sj_don.p, c->sj_acc.p,
                            c->sj_uniq.p, c->sj_multi.p, p, c->info.p);
-        // acceptance is decided by the junction check: recount per tile
-        if (c->want & L2R_WANT_ACCEPTED)
+    }
+    if ((c->n_sj > 0 || c->fused) && (c->want & L2R_WANT_ACCEPTED)) {
+        // acceptance is decided by the junction check (and the one-walk pipeline counts nothing itself): count per tile
             hipLaunchKernelGGL(k_count_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->info.p, c->tile_acc.p, c->tile_acc_ex.p);
     }
     MARK(ST_SCAN2);
@@ -844,9 +885,10 @@ static int fetch_totals(l2r_ctx *c)
 {
     if (!c->ran) return fail(-1, "no completed run on this context");
     if (c->totals_valid) return 0;
-    uint32_t dev[6];
+    uint32_t dev[8];
     HIP_TRY(hipMemcpyAsync(dev, c->totals.p, sizeof dev, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->fused) dev[0] = dev[6];                       // the one-walk pipeline's exon cursor (a shard has < 2^32 exons)
     // accepted exons = the chunks the classification kernel placed itself (cursor) + the ones k_gather_accepted placed
     c->h_totals[0] = dev[0]; c->h_totals[1] = dev[1] + dev[5]; c->h_totals[2] = dev[2] + dev[4];
     if (!(c->want & L2R_WANT_ACCEPTED)) c->h_totals[1] = c->h_totals[2] = 0;
@@ -908,18 +950,42 @@ int l2r_download(l2r_ctx *c, l2r_result *res)
     const int64_t N = c->n_reads, X = c->h_totals[0];
     if (res->n_reads < N || res->ex_cap < X) return fail(-3, "[l2r_download] buffers too small: need %lld reads, %lld exons", (long long)N, (long long)X);
     std::vector<uint32_t> off((size_t)N);
+    const int32_t *xs = c->ex_start.p, *xe = c->ex_end.p; const uint8_t *xf = c->ex_flag.p;
+    if (c->fused && X) {
+        // the one-walk pipeline leaves the exon arrays as one chunk per tile, chunks in the order an atomic cursor handed
+        // them out (l2r_fused.hip.h): k_linearize copies them into read order on the device (HBM speed, ahead of the PCIe copy)
+        const size_t T = (size_t)c->n_tiles;
+        std::vector<uint32_t> tot(T), dest(T);
+        HIP_TRY(hipMemcpyAsync(tot.data(), c->tile_total.p, T * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        uint64_t run = 0;
+        for (size_t t = 0; t < T; ++t) { dest[t] = (uint32_t)run; run += tot[t]; }
+        if ((int64_t)run != X) return fail(-5, "[l2r_download] tile totals (%llu) do not add up to the exon count (%lld)", (unsigned long long)run, (long long)X);
+        if (c->lin_start.ensure((size_t)X) || c->lin_end.ensure((size_t)X) || c->lin_flag.ensure((size_t)X)) return -2;
+        HIP_TRY(hipMemcpyAsync(c->tile_dest.p, dest.data(), T * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_linearize, dim3((unsigned)T), dim3(TILE_THREADS), 0, c->stream, (const uint32_t *)c->tile_start.p, (const uint32_t *)c->tile_dest.p,
+                           (const uint32_t *)c->tile_total.p, (const int32_t *)c->ex_start.p, (const int32_t *)c->ex_end.p, (const uint8_t *)c->ex_flag.p,
+                           c->lin_start.p, c->lin_end.p, c->lin_flag.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));          // (dest is a local)
+        xs = c->lin_start.p; xe = c->lin_end.p; xf = c->lin_flag.p;
+    }
     if (N) {
-        HIP_TRY(hipMemcpyAsync(off.data(), c->ex_off.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+        if (!c->fused) HIP_TRY(hipMemcpyAsync(off.data(), c->ex_off.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(res->info, c->info.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(res->ref_tx, c->ref_tx.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
     }
     if (X) {
-        HIP_TRY(hipMemcpyAsync(res->ex_start, c->ex_start.p, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(res->ex_end, c->ex_end.p, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(res->ex_flag, c->ex_flag.p, (size_t)X, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(res->ex_start, xs, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(res->ex_end, xe, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(res->ex_flag, xf, (size_t)X, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int64_t i = 0; i < N; ++i) res->ex_off[i] = off[(size_t)i];
+    if (c->fused) {                                        // read order: the offsets are the running sum of the exon counts
+        int64_t at = 0;
+        for (int64_t i = 0; i < N; ++i) { res->ex_off[i] = at; at += (int64_t)(res->info[i] >> 8); }
+        if (at != X) return fail(-5, "[l2r_download] exon counts (%lld) do not add up to the exon total (%lld)", (long long)at, (long long)X);
+    } else for (int64_t i = 0; i < N; ++i) res->ex_off[i] = off[(size_t)i];
     res->ex_off[N] = X;
     res->n_reads = N; res->n_exons = X;
     return 0;

@@ -1,0 +1,406 @@
+// l2r_fused.hip.h -- the ONE-WALK pipeline for short-CIGAR, coordinate-sorted input (gfx950).
+//
+// The classic pipeline (l2r_kernels.hip.h) walks every CIGAR twice: k_pass_a needs the exon counts (LDS placement,
+// output offsets) and the read ends (which slice of the dictionaries and which transcripts a tile will need) before
+// k_classify_fast can start, so the CIGAR stream is read from HBM twice and ~17 VALU per op are spent twice.  Here:
+//
+//   k_order     per tile of up to 256 reads, from the CIGAR LENGTHS alone (cig_off, 8 bytes per read): an upper bound
+//               of every read's exon count -> its slot range in the LDS exon arrays; the tile's reads by falling length
+//               (the order in which the classification kernel deals them to its lanes)
+//   k_fused     persistent; per tile: CIGAR words straight into registers (one lane = one read), ONE walk -> exons in
+//               LDS and the read ends; one wave turns the tile's span into the dictionary slices and the transcript
+//               window (what k_pass_a's descriptor was); staging, window pass, probes, verdicts exactly as
+//               k_classify_fast (same device functions); the tile's exons leave through an LDS map (output slot ->
+//               LDS slot), coalesced, into a chunk of the result arrays taken from an atomic cursor once the tile's
+//               exon count is known.  No k_pass_a, no scan.
+//
+// The result arrays are therefore made of one chunk per tile (reads of a chunk in read order, chunks in the order the
+// cursor handed them out); ex_off[r] is explicit.  l2r_download() puts them into read order with k_linearize.
+// Unsorted input (history-dependent cursors), long CIGARs (ONT) and every read the masks cannot decide take the classic
+// kernels / the generic kernel, as before.
+#pragma once
+#include "l2r_kernels.hip.h"
+
+namespace l2r {
+
+constexpr int FUSED_HEAD_VEC = 6;                          // 16-byte CIGAR vectors a lane holds: 24 ops; longer reads finish from memory
+constexpr int FUSED_HEAD = 4 * FUSED_HEAD_VEC;
+
+// upper bound of a read's exon count from its number of CIGAR ops: with min_exon >= 1 every kept exon but the first and
+// the last needs an op of its own next to its cut (src/bam2gtf.c:31-78), so n <= (c + 3) / 2; otherwise n <= c + 1
+__device__ __forceinline__ uint32_t exon_bound(uint32_t c, int min_exon)
+{
+    return min_exon >= 1 ? (c + 3u) >> 1 : c + 1u;
+}
+
+__global__ __launch_bounds__(TILE_THREADS)
+void k_order(const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ tile_first, DevParams p,
+             uint8_t *__restrict__ order_out, uint16_t *__restrict__ lub_out, uint32_t *__restrict__ tile_ub,
+             uint32_t *__restrict__ redo_count /* [3]: redo list, chunk cursor of the accepted list */, unsigned long long *__restrict__ ex_cursor)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) { redo_count[0] = 0u; redo_count[1] = 0u; redo_count[2] = 0u; *ex_cursor = 0ull; }    // the kernels that use them run after this one
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_hist[WAVE];
+    if (threadIdx.x < WAVE) s_hist[threadIdx.x] = 0u;
+    const uint32_t r0 = tile_first[blockIdx.x], n_act = tile_first[blockIdx.x + 1] - r0;
+    const bool active = threadIdx.x < n_act;
+    const int64_t r = (int64_t)r0 + threadIdx.x;
+    uint32_t c = 0u;
+    if (active) c = (uint32_t)min((int64_t)0x7fffffff, cig_off[r + 1] - cig_off[r]);
+    const uint32_t ub = active ? min(exon_bound(c, p.min_exon), 0xffffu) : 0u;
+    uint32_t total;
+    const uint32_t local = block_exclusive_scan(ub, s_wave, total);          // (two barriers: s_hist is clear behind them)
+    if (active) lub_out[r] = (uint16_t)min(local, 0xffffu);                   // (a tile beyond the LDS capacity does not use it)
+    if (threadIdx.x == 0) tile_ub[blockIdx.x] = total;
+    // the tile's reads by falling length (counting sort, ties in arrival order); threads without a read sort last
+    const uint32_t est = active ? max(1u, min((c + 1u) >> 1, (uint32_t)(WAVE - 1))) : 0u;
+    const uint32_t bin = (uint32_t)(WAVE - 1) - est;
+    const uint32_t rank = atomicAdd(&s_hist[bin], 1u);
+    __syncthreads();
+    if (threadIdx.x < WAVE) { const uint32_t v = s_hist[threadIdx.x]; s_hist[threadIdx.x] = wave_inclusive_scan(v) - v; }
+    __syncthreads();
+    const uint32_t slot = s_hist[bin] + rank;
+    if (active) order_out[(int64_t)r0 + slot] = (uint8_t)threadIdx.x;
+}
+
+// What the fused kernel needs beyond FastArgs (appended to it, so that the device functions of the classic kernel
+// find their fields where they expect them).
+struct FusedArgs {
+    FastArgs f;
+    CursorDir cd;
+    const int32_t *tid_base; int32_t n_tid_dir;
+    const uint16_t *lub;                     // k_order: first LDS slot of every read inside its tile
+    const uint32_t *tile_ub;                 // k_order: slots the tile needs
+    uint32_t *tile_start, *tile_total;       // out: the tile's chunk of the exon arrays
+    unsigned long long *ex_cursor;           // next free exon slot
+};
+typedef const __attribute__((address_space(4))) FusedArgs *FusedArgsK;
+__device__ __forceinline__ FusedArgsK fused_args()
+{
+    FusedArgsK q = (FusedArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return q;
+}
+
+constexpr int FUSED_EXON_CAP = 2944;                     // exon slots of a tile in LDS (10 bytes each): four workgroups per CU
+constexpr int FUSED_W_WORDS = FUSED_EXON_CAP / 2;
+constexpr int FUSED_TAIL_WORDS = FUSED_W_WORDS + 2 * KEY_CAP * 4 + 3 * FAST_DIR_BYTES / 4;
+constexpr int FUSED_ALL_WORDS = 2 * FUSED_EXON_CAP + FUSED_TAIL_WORDS;
+static_assert(2 * KEY_CAP * 16 >= FUSED_EXON_CAP * 2, "the output map (16 bits per exon) lives in the dead dictionary slices");
+
+// The tile's dictionary slices and transcript window from its span [tlo, thi] on chromosome tid0 -- the descriptor
+// k_pass_a leaves in HBM, made by ONE WAVE of the tile itself (everything is wave-uniform but `lane`).  The window's
+// member headers go straight into LDS (s_hk / s_hx / s_win), the two member masks into tilemask.
+__device__ __forceinline__ void make_descriptor(FusedArgsK a, int lane, int32_t tid0, int32_t tlo, int32_t thi, bool in_lds,
+                                                TileDesc *s_desc, int4 *s_hk, int4 *s_hx, int *s_win, uint32_t *tilemask)
+{
+    const TxHdr *const hdr = a->f.hdr;
+    const int32_t n_tx = a->f.p.n_tx;
+    int tb = 0, nb = 0;
+    if (tid0 >= 0 && tid0 < a->n_tid_dir) { tb = a->tid_base[tid0]; nb = a->tid_base[tid0 + 1] - tb; }
+    int lo = INT32_MAX, hi = -1;
+    if (nb > 0) { lo = min(max(tlo, 0) >> SITE_SHIFT, nb - 1); hi = min(max(thi, 0) >> SITE_SHIFT, nb - 1); }
+    TileDesc d;
+    d.tid = tid0; d.b_off = 0; d.nb = 0; d.b0 = 0; d.nbk = 0;
+    d.st_r0 = d.st_nk = d.en_r0 = d.en_nk = 0u; d.n_win = 0u;
+    bool fast = in_lds && a->f.p.ss_dis == 0 && !(a->f.p.ablate & 1);
+    uint32_t why = fast ? 0u : (!in_lds ? 1u : 7u);
+    uint32_t sd_r0 = 0u, sd_r1 = 0u, ed_r0 = 0u, ed_r1 = 0u;
+    const bool sliced = fast && hi >= 0 && hi - lo + 1 <= DIR_CAP;
+    if (fast && hi >= 0 && !sliced) { fast = false; why = 2u; }
+    if (sliced) {
+        sd_r0 = a->f.st.rdir[tb + lo]; sd_r1 = a->f.st.dir[tb + hi + 1];
+        ed_r0 = a->f.en.dir[tb + lo]; ed_r1 = a->f.en.dir[tb + hi + 1];
+    }
+    // sorted input: the smallest cursor value of the tile is the one of its first read, and no read needs
+    // its own: a member below a read's cursor value lies entirely before that read, which visit_window sees by itself
+    CursorDir cd;
+    cd.key = a->cd.key; cd.dir = a->cd.dir; cd.kb_base = a->cd.kb_base; cd.n_tid = a->cd.n_tid; cd.n_tx = a->cd.n_tx;
+    const int jl = cursor_value(cd, tid0, tlo);
+    d.j_lo = jl;
+    bool contig = true;
+    uint32_t n_win = 0;
+    if (fast) {
+        int first = -1, last = -1;
+        for (int base = jl, trip = 0; base < n_tx; ++trip) {
+            const int j = base + lane;
+            bool ov = false, aft = false;
+            if (j < n_tx) {
+                const int4 h0 = *reinterpret_cast<const int4 *>(hdr + j);                 // {tid, start, end, .}
+                aft = tid0 < h0.x || (tid0 == h0.x && thi <= h0.y);                       // comp_trans <= (Q5)
+                const bool bef = h0.x < tid0 || (h0.x == tid0 && h0.z <= tlo && h0.y < tlo);
+                ov = !aft && !bef;
+            }
+            const unsigned long long ma = __ballot(aft);
+            const int stop = ma ? __ffsll((long long)ma) - 1 : WAVE;
+            const unsigned long long mo = __ballot(ov) & (stop < WAVE ? (1ull << stop) - 1ull : ~0ull);
+            if ((mo >> lane) & 1ull) {
+                const uint32_t rank = n_win + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull));
+                if (rank < (uint32_t)WIN_TX) s_win[rank] = j;
+            }
+            if (mo) {
+                if (first < 0) first = base + __ffsll((long long)mo) - 1;
+                last = base + 63 - __clzll((long long)mo);
+            }
+            n_win += (uint32_t)__popcll(mo);
+            if (ma) break;
+            base += WAVE;
+            if (n_win > (uint32_t)WIN_TX || trip == WIN_SCAN_TRIPS - 1) { fast = false; why = n_win > (uint32_t)WIN_TX ? 4u : 5u; break; }
+        }
+        if (fast && n_win > (uint32_t)WIN_TX) { fast = false; why = 4u; }
+        if (fast) {
+            d.n_win = n_win;
+            if (n_win) { d.j_lo = first; contig = (uint32_t)(last - first + 1) == n_win; }
+        }
+    }
+    if (sliced) {
+        d.b_off = -lo; d.nb = nb; d.b0 = tb + lo; d.nbk = hi - lo + 1;
+        d.st_r0 = sd_r0; d.st_nk = sd_r1 - sd_r0;
+        d.en_r0 = ed_r0; d.en_nk = ed_r1 - ed_r0;
+        if (fast && (d.st_nk > (uint32_t)KEY_CAP || d.en_nk > (uint32_t)KEY_CAP)) { fast = false; why = 3u; }
+    }
+    d.flags = (fast ? TD_FAST : 0u) | (contig ? TD_CONTIG : 0u) | (why << 8);
+    // the members' headers (the wave's own LDS writes above are visible to it: same wave, in order)
+    const int w_n = fast ? (int)d.n_win : 0;
+    bool single = false, loose = false;
+    if (lane < w_n) {
+        const int j = s_win[lane];
+        const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);
+        const int4 h0 = hp[0], h1 = hp[1], h2 = hp[2];
+        int st = h0.y, en = h0.z;
+        if (h0.x < tid0) { st = INT32_MIN; en = INT32_MIN; }            // another chromosome: before / after every read
+        else if (h0.x > tid0) { st = INT32_MAX; en = INT32_MAX; }
+        s_hk[lane] = make_int4(st, en, h1.x, (h1.z & 0xff) | (h1.y << 8));
+        s_hx[lane] = h2;
+        single = h1.x == 1; loose = !((h1.z & 0xff) & TX_COMPACT);
+    }
+    const unsigned long long b1 = __ballot(single), b2 = __ballot(loose);
+    if (lane == 0) { *s_desc = d; tilemask[0] = (uint32_t)b1; tilemask[1] = (uint32_t)b2; }
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(TILE_THREADS, 4)
+void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() */, int64_t n_tiles, const uint32_t *__restrict__ u_tile_first,
+             const uint8_t *__restrict__ u_order, const int32_t *__restrict__ u_tid, const int32_t *__restrict__ u_pos,
+             const uint32_t *__restrict__ u_tile_ub)
+{
+    // LDS image of a tile:  S[cap] | E[cap] | W (16 bits per exon) | START entries | END entries | dir bytes x 3
+    // (the output map, 16 bits per exon, takes the place of the entries once the verdicts are in)
+    constexpr int DIR_BYTES = FAST_DIR_BYTES;
+    __shared__ __attribute__((aligned(16))) uint32_t s_all[FUSED_ALL_WORDS];
+    __shared__ __attribute__((aligned(16))) int4 s_hk[WIN_TX];
+    __shared__ __attribute__((aligned(16))) int4 s_hx[WIN_TX];
+    __shared__ int s_win[WIN_TX];
+    __shared__ TileDesc s_desc;
+    __shared__ uint32_t s_tilemask[2];
+    __shared__ int s_wide;
+    __shared__ int s_wmax[4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_nx[TILE_THREADS];        // per read, READ order: exon count, then (in place) exact exon offset inside the tile
+    __shared__ uint32_t s_base[2];
+    (void)kernarg_block;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    int *const s_S = reinterpret_cast<int *>(s_all), *const s_E = s_S + FUSED_EXON_CAP;
+    uint16_t *const s_W = reinterpret_cast<uint16_t *>(s_all + 2 * FUSED_EXON_CAP);
+    v4i_t *const s_ent0 = reinterpret_cast<v4i_t *>(s_all + 2 * FUSED_EXON_CAP + FUSED_W_WORDS), *const s_ent1 = s_ent0 + KEY_CAP;
+    uint8_t *const s_dir0 = reinterpret_cast<uint8_t *>(s_all + 2 * FUSED_EXON_CAP + FUSED_W_WORDS + 2 * KEY_CAP * 4);
+    uint8_t *const s_dir1 = s_dir0 + DIR_BYTES, *const s_rdir = s_dir1 + DIR_BYTES;
+    uint16_t *const s_map = reinterpret_cast<uint16_t *>(s_ent0);
+
+    for (uint32_t t = blockIdx.x; (int64_t)t < n_tiles; t += gridDim.x) {
+        const FusedArgsK a = fused_args();
+        const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
+        const int32_t tid0 = n_act ? u_tid[r0] : 0, pos0 = n_act ? u_pos[r0] : 0;
+        const bool in_lds = u_tile_ub[t] <= (uint32_t)FUSED_EXON_CAP;
+        // thread -> slot of k_order's order, rotated by one wave per tile (see load_uniforms of the classic kernel)
+        const uint32_t slot = (threadIdx.x - (((t + (t >> 10)) & 3u) << 6)) & (uint32_t)(TILE_THREADS - 1);
+        const int32_t src = slot < n_act ? (int32_t)ld32(u_order, r0 + slot) : -1;
+        const bool active = src >= 0;
+        const uint32_t r = r0 + (uint32_t)max(src, 0);
+        // ---- the read and the head of its CIGAR
+        uint32_t c_lo = 0u, n_cig = 0u, lub = 0u;
+        int32_t pos = 0, tid = tid0;
+        bool rev_in = false;
+        uint4 cg[FUSED_HEAD_VEC];
+#pragma unroll
+        for (int q = 0; q < FUSED_HEAD_VEC; ++q) cg[q] = make_uint4(1u, 1u, 1u, 1u);
+        if (active) {
+            const int64_t *const p_off = a->f.cig_off;
+            c_lo = (uint32_t)ld32(p_off, r); n_cig = (uint32_t)ld32(p_off, r + 1u) - c_lo;
+            pos = ld32(a->f.r_pos, r); tid = ld32(a->f.r_tid, r); rev_in = ld32(a->f.r_rev, r) != 0;
+            lub = ld32(a->lub, r);
+            const uint32_t *const words = a->f.cig + c_lo;
+#pragma unroll
+            for (int q = 0; q < FUSED_HEAD_VEC; ++q)
+                if ((uint32_t)(4 * q) < n_cig) { const v4i_a4 x = *reinterpret_cast<const v4i_a4 *>(words + 4 * q); cg[q] = make_uint4((uint32_t)x.x, (uint32_t)x.y, (uint32_t)x.z, (uint32_t)x.w); }
+        }
+        if (threadIdx.x == 0) { s_wide = 0; }
+        // ---- phase 1: the ONE walk, CIGAR words out of registers (words behind the read's last op become "I, length 0")
+        DevParams p;
+        p.min_exon = a->f.p.min_exon; p.min_intron = a->f.p.min_intron; p.max_delet = a->f.p.max_delet;
+        const uint32_t room = exon_bound(n_cig, p.min_exon);
+        uint32_t n = 0u;
+        ReadEnds re{0, 0, 0, 0};
+        bool sane = true, over = false;
+        if (active) {
+            WalkState w{pos + 1, pos, 0};
+            auto emit = [&](int k, int s, int e) {
+                if (in_lds && (uint32_t)k < room) { s_S[lub + (uint32_t)k] = s; s_E[lub + (uint32_t)k] = e; }
+                else over = true;
+                sane = sane & (s <= e);
+                re.sl = s; re.el = e;
+            };
+#pragma unroll
+            for (int q = 0; q < FUSED_HEAD_VEC; ++q) {
+                const uint32_t c0 = (uint32_t)(4 * q) < n_cig ? cg[q].x : 1u, c1 = (uint32_t)(4 * q + 1) < n_cig ? cg[q].y : 1u;
+                const uint32_t c2 = (uint32_t)(4 * q + 2) < n_cig ? cg[q].z : 1u, c3 = (uint32_t)(4 * q + 3) < n_cig ? cg[q].w : 1u;
+                walk_step(w, c0, p, emit); walk_step(w, c1, p, emit); walk_step(w, c2, p, emit); walk_step(w, c3, p, emit);
+            }
+            if (n_cig > (uint32_t)FUSED_HEAD) walk_ops<false>(w, a->f.cig + c_lo, FUSED_HEAD, (int)n_cig, p, emit);
+            emit(w.n, w.start, w.end);
+            n = (uint32_t)w.n + 1u;
+            if (in_lds && !over) { re.s0 = s_S[lub]; re.e0 = s_E[lub]; }
+        }
+        // the tile's span: its reads are sorted, so it starts at its first read; the ends take a reduction
+        {
+            const int m = wave_max((active && tid == tid0) ? re.el : INT32_MIN);
+            if (lane == 0) s_wmax[wv] = m;
+        }
+        __syncthreads();
+        if (wv == TILE_THREADS / WAVE - 1) {
+            const int32_t thi = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+            make_descriptor(a, lane, tid0, pos0 + 1, thi, in_lds, &s_desc, s_hk, s_hx, s_win, s_tilemask);
+        }
+        __syncthreads();
+        const TileDesc d = s_desc;
+        const bool fast = (d.flags & TD_FAST) != 0;
+        const int w_n = fast ? (int)d.n_win : 0;
+        // ---- stage the dictionary slices, re-based to the tile's window
+        int my_wide = 0;
+        if (fast) {
+            if ((int)threadIdx.x < KEY_CAP) {
+                const bool has_st = threadIdx.x < d.st_nk, has_en = threadIdx.x < d.en_nk;
+                int4 xa = make_int4(0, 0, 0, 0), xb = xa, xc = xa, xd = xa;
+                if (has_st) { const int4 *q = reinterpret_cast<const int4 *>(a->f.st.ent + d.st_r0 + threadIdx.x); xa = q[0]; xb = q[1]; }
+                if (has_en) { const int4 *q = reinterpret_cast<const int4 *>(a->f.en.ent + d.en_r0 + threadIdx.x); xc = q[0]; xd = q[1]; }
+                v4i_t e0, e1;
+                e0.x = xa.x; e0.y = xa.y; e1.x = xc.x; e1.y = xc.y;
+                if (d.flags & TD_CONTIG) {
+                    e0.z = (int)rebase_mask((uint32_t)xb.x, (uint32_t)xb.y, xa.z - d.j_lo);
+                    e0.w = (int)rebase_mask((uint32_t)xb.z, (uint32_t)xb.w, xa.z - d.j_lo);
+                    e1.z = (int)rebase_mask((uint32_t)xd.x, (uint32_t)xd.y, xc.z - d.j_lo);
+                    e1.w = (int)rebase_mask((uint32_t)xd.z, (uint32_t)xd.w, xc.z - d.j_lo);
+                } else {
+                    e0.z = (int)rebase_gaps(s_win, w_n, (uint32_t)xb.x, (uint32_t)xb.y, xa.z);
+                    e0.w = (int)rebase_gaps(s_win, w_n, (uint32_t)xb.z, (uint32_t)xb.w, xa.z);
+                    e1.z = (int)rebase_gaps(s_win, w_n, (uint32_t)xd.x, (uint32_t)xd.y, xc.z);
+                    e1.w = (int)rebase_gaps(s_win, w_n, (uint32_t)xd.z, (uint32_t)xd.w, xc.z);
+                }
+                if (has_st) { s_ent0[threadIdx.x] = e0; if (xa.w & SE_WIDE) my_wide = 1; }
+                if (has_en) { s_ent1[threadIdx.x] = e1; if (xc.w & SE_WIDE) my_wide = 1; }
+            }
+            if (d.nbk > 0) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int i = (int)threadIdx.x + q * TILE_THREADS;
+                    if (i <= d.nbk) {
+                        const uint32_t b = (uint32_t)(d.b0 + i);
+                        s_dir0[i] = (uint8_t)(ld32(a->f.st.dir, b) - d.st_r0); s_dir1[i] = (uint8_t)(ld32(a->f.en.dir, b) - d.en_r0);
+                        s_rdir[i] = (uint8_t)(ld32(a->f.st.rdir, b) - d.st_r0);
+                    }
+                }
+            }
+            if (threadIdx.x < 3u && (threadIdx.x > 0u || d.nbk == 0)) {
+                s_dir0[d.nbk + (int)threadIdx.x] = (uint8_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint8_t)d.en_nk;
+            }
+        }
+        if (my_wide) s_wide = 1;
+        __syncthreads();
+        const int any_wide = s_wide;
+        // ---- phase 2: classification (the classic kernel's device functions; a read's slot range starts at `lub`)
+        uint32_t info = n << 8; int ref = -1;
+        bool redo = active && (!fast || !in_lds || over || any_wide != 0 || tid != d.tid || (n > 1 && !sane));
+        const bool work = active && !redo;
+        const TileLds L{s_S, s_E, s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_hk, s_hx, s_win};
+        const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, s_tilemask);
+        redo = redo || vm.redo;
+        const SiteMasks sm = map_exons(L, d, work && !redo && n > 1, lub, n, vm.vpre);
+        if (work && !redo) {
+            const Verdict vd = decide<LEVEL>(L, d, lub, n, re, vm, sm, rev_in);
+            info = vd.info; ref = vd.ref;
+        } else if (active && in_lds && !over) {
+            for (uint32_t k = 0; k < n; ++k) s_W[lub + k] = (uint16_t)0;
+        }
+        redo = redo && active;
+        {
+            const unsigned long long m = __ballot(redo);
+            if (m) {
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(a->f.redo_count, (uint32_t)__popcll(m));
+                at = __shfl(at, 0, WAVE);
+                if (redo) a->f.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+            }
+        }
+        if (active) s_nx[src] = n;
+        __syncthreads();
+        // ---- exact exon offsets in read order (one wave, four reads per lane) and the tile's chunk of the result arrays
+        if (wv == 0) {
+            const uint4 quad = *reinterpret_cast<const uint4 *>(s_nx + 4 * lane);
+            const uint32_t c0 = (uint32_t)(4 * lane) < n_act ? quad.x : 0u, c1 = (uint32_t)(4 * lane + 1) < n_act ? quad.y : 0u;
+            const uint32_t c2 = (uint32_t)(4 * lane + 2) < n_act ? quad.z : 0u, c3 = (uint32_t)(4 * lane + 3) < n_act ? quad.w : 0u;
+            const uint32_t mine = c0 + c1 + c2 + c3;
+            const uint32_t inc = wave_inclusive_scan(mine), ex = inc - mine;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+            *reinterpret_cast<uint4 *>(s_nx + 4 * lane) = make_uint4(ex, ex + c0, ex + c0 + c1, ex + c0 + c1 + c2);
+            if (lane == 0) {
+                const unsigned long long at = total ? atomicAdd(a->ex_cursor, (unsigned long long)total) : 0ull;
+                s_base[0] = (uint32_t)at; s_base[1] = total;
+                a->tile_start[t] = (uint32_t)at; a->tile_total[t] = total;
+            }
+        }
+        __syncthreads();
+        const uint32_t base = s_base[0], tile_total = s_base[1];
+        // tiles whose exons could not be kept in LDS (capacity, or a read beyond its bound): walked again, straight to HBM
+        const bool direct = !in_lds || tile_total > (uint32_t)FUSED_EXON_CAP;
+        if (active) {
+            const uint32_t loc = s_nx[src];
+            a->f.ex_off[r] = base + loc;
+            a->f.info[r] = info;
+            a->f.ref_tx[r] = ref;
+            if (!direct && !over) for (uint32_t k = 0; k < n; ++k) s_map[loc + k] = (uint16_t)(lub + k);
+            if (direct || over) {
+                // (rare) the read's exons go out lane by lane
+                int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end; uint8_t *const xf = a->f.ex_flag;
+                WalkState w{pos + 1, pos, 0};
+                auto put = [&](int k, int s, int e) { xs[base + loc + (uint32_t)k] = s; xe[base + loc + (uint32_t)k] = e; xf[base + loc + (uint32_t)k] = 0; };
+                walk_ops<false>(w, a->f.cig + c_lo, 0, (int)n_cig, p, put);
+                put(w.n, w.start, w.end);
+                if (!direct) for (uint32_t k = 0; k < n; ++k) s_map[loc + k] = (uint16_t)0xffffu;       // (skipped by the copy below)
+            }
+        }
+        __syncthreads();
+        if (!direct) {
+            int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end; uint8_t *const xf = a->f.ex_flag;
+            for (uint32_t i = threadIdx.x; i < tile_total; i += TILE_THREADS) {
+                const uint32_t q = s_map[i];
+                if (q == 0xffffu) continue;
+                xs[base + i] = s_S[q];
+                xe[base + i] = s_E[q];
+                xf[base + i] = (uint8_t)s_W[q];
+            }
+        }
+        __syncthreads();                 // the tile's LDS image has been written out
+    }
+}
+
+// The result arrays of the fused pipeline, tile chunk by tile chunk, into read order (l2r_download): tile t's exons
+// [start[t], start[t] + total[t]) -> [dest[t], ...), dest = exclusive scan of the totals in tile order.
+__global__ __launch_bounds__(TILE_THREADS)
+void k_linearize(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ tile_dest, const uint32_t *__restrict__ tile_total,
+                 const int32_t *__restrict__ xs, const int32_t *__restrict__ xe, const uint8_t *__restrict__ xf,
+                 int32_t *__restrict__ os, int32_t *__restrict__ oe, uint8_t *__restrict__ of)
+{
+    const uint32_t from = tile_start[blockIdx.x], to = tile_dest[blockIdx.x], n = tile_total[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < n; i += TILE_THREADS) { os[to + i] = xs[from + i]; oe[to + i] = xe[from + i]; of[to + i] = xf[from + i]; }
+}
+
+}  // namespace l2r

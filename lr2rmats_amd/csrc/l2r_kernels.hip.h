@@ -689,7 +689,8 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
                         const TxHdr *__restrict__ hdr, const int2 *__restrict__ anno_ex, DevParams p,
                         const uint32_t *__restrict__ ex_off, const int32_t *__restrict__ ex_start, const int32_t *__restrict__ ex_end,
                         uint8_t *__restrict__ ex_flag, uint32_t *__restrict__ info_io, int32_t *__restrict__ ref_out,
-                        uint32_t *__restrict__ tile_acc, uint32_t *__restrict__ tile_acc_ex, const uint32_t *__restrict__ tile_first, int n_tiles)
+                        uint32_t *__restrict__ tile_acc, uint32_t *__restrict__ tile_acc_ex, const uint32_t *__restrict__ tile_first, int n_tiles,
+                        CursorDir cd /* used when j0_arr is null: the one-walk pipeline keeps no per-read cursor values */)
 {
     __shared__ int g_S[GEN_WAVES][GEN_CAP];
     __shared__ int g_E[GEN_WAVES][GEN_CAP];
@@ -703,7 +704,8 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
         const uint32_t r = redo[i];
         const int n = (int)(info_io[r] >> 8);
         const uint32_t off = ex_off[r];
-        const int tid = r_tid[r], j0 = j0_arr[r];
+        const int tid = r_tid[r];
+        const int j0 = j0_arr ? j0_arr[r] : cursor_value(cd, tid, ex_start[off]);        // (the first exon starts at pos + 1)
         const bool rev = r_rev[r] != 0;
         Verdict v{0u, -1};
         if (n > GEN_CAP) {
