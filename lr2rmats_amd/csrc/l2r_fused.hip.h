@@ -82,17 +82,27 @@ __device__ __forceinline__ FusedArgsK fused_args()
     return q;
 }
 
-constexpr int FUSED_EXON_CAP = 2944;                     // exon slots of a tile in LDS (10 bytes each): four workgroups per CU
+constexpr int FUSED_EXON_CAP = 2880;                     // exon slots of a tile in LDS (10 bytes each): four workgroups per CU
+constexpr int FUSED_KEY_CAP = 200;                       // dictionary entries staged per dictionary and tile
 constexpr int FUSED_W_WORDS = FUSED_EXON_CAP / 2;
-constexpr int FUSED_TAIL_WORDS = FUSED_W_WORDS + 2 * KEY_CAP * 4 + 3 * FAST_DIR_BYTES / 4;
+constexpr int FUSED_TAIL_WORDS = FUSED_W_WORDS + 2 * FUSED_KEY_CAP * 4 + 3 * FAST_DIR_BYTES / 4;
 constexpr int FUSED_ALL_WORDS = 2 * FUSED_EXON_CAP + FUSED_TAIL_WORDS;
-static_assert(2 * KEY_CAP * 16 >= FUSED_EXON_CAP * 2, "the output map (16 bits per exon) lives in the dead dictionary slices");
+static_assert(2 * FUSED_KEY_CAP * 16 >= FUSED_EXON_CAP * 2, "the output map (16 bits per exon) lives in the dead dictionary slices");
+
+// A tile's window and descriptor in LDS.  Two of them: while tile t is classified, one wave prepares tile t + 1's.
+struct TileWin {
+    int4 hk[WIN_TX];             // {start, end, n, flags | rev << 8} on the tile's chromosome
+    int4 hx[WIN_TX];             // {s0, e0, sl, el}
+    int win[WIN_TX];             // window member -> annotation index
+    TileDesc d;
+    uint32_t mask[2];            // members with one exon / without TX_COMPACT
+    uint32_t pad[2];
+};
 
 // The tile's dictionary slices and transcript window from its span [tlo, thi] on chromosome tid0 -- the descriptor
-// k_pass_a leaves in HBM, made by ONE WAVE of the tile itself (everything is wave-uniform but `lane`).  The window's
-// member headers go straight into LDS (s_hk / s_hx / s_win), the two member masks into tilemask.
-__device__ __forceinline__ void make_descriptor(FusedArgsK a, int lane, int32_t tid0, int32_t tlo, int32_t thi, bool in_lds,
-                                                TileDesc *s_desc, int4 *s_hk, int4 *s_hx, int *s_win, uint32_t *tilemask)
+// k_pass_a leaves in HBM, made by ONE WAVE of the workgroup (everything is wave-uniform but `lane`).  The window's
+// member headers go straight into LDS.
+__device__ __forceinline__ void make_descriptor(FusedArgsK a, int lane, int32_t tid0, int32_t tlo, int32_t thi, bool in_lds, TileWin *W)
 {
     const TxHdr *const hdr = a->f.hdr;
     const int32_t n_tx = a->f.p.n_tx;
@@ -136,7 +146,7 @@ __device__ __forceinline__ void make_descriptor(FusedArgsK a, int lane, int32_t 
             const unsigned long long mo = __ballot(ov) & (stop < WAVE ? (1ull << stop) - 1ull : ~0ull);
             if ((mo >> lane) & 1ull) {
                 const uint32_t rank = n_win + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull));
-                if (rank < (uint32_t)WIN_TX) s_win[rank] = j;
+                if (rank < (uint32_t)WIN_TX) W->win[rank] = j;
             }
             if (mo) {
                 if (first < 0) first = base + __ffsll((long long)mo) - 1;
@@ -157,27 +167,116 @@ __device__ __forceinline__ void make_descriptor(FusedArgsK a, int lane, int32_t 
         d.b_off = -lo; d.nb = nb; d.b0 = tb + lo; d.nbk = hi - lo + 1;
         d.st_r0 = sd_r0; d.st_nk = sd_r1 - sd_r0;
         d.en_r0 = ed_r0; d.en_nk = ed_r1 - ed_r0;
-        if (fast && (d.st_nk > (uint32_t)KEY_CAP || d.en_nk > (uint32_t)KEY_CAP)) { fast = false; why = 3u; }
+        if (fast && (d.st_nk > (uint32_t)FUSED_KEY_CAP || d.en_nk > (uint32_t)FUSED_KEY_CAP)) { fast = false; why = 3u; }
     }
     d.flags = (fast ? TD_FAST : 0u) | (contig ? TD_CONTIG : 0u) | (why << 8);
     // the members' headers (the wave's own LDS writes above are visible to it: same wave, in order)
     const int w_n = fast ? (int)d.n_win : 0;
     bool single = false, loose = false;
     if (lane < w_n) {
-        const int j = s_win[lane];
+        const int j = W->win[lane];
         const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);
         const int4 h0 = hp[0], h1 = hp[1], h2 = hp[2];
         int st = h0.y, en = h0.z;
         if (h0.x < tid0) { st = INT32_MIN; en = INT32_MIN; }            // another chromosome: before / after every read
         else if (h0.x > tid0) { st = INT32_MAX; en = INT32_MAX; }
-        s_hk[lane] = make_int4(st, en, h1.x, (h1.z & 0xff) | (h1.y << 8));
-        s_hx[lane] = h2;
+        W->hk[lane] = make_int4(st, en, h1.x, (h1.z & 0xff) | (h1.y << 8));
+        W->hx[lane] = h2;
         single = h1.x == 1; loose = !((h1.z & 0xff) & TX_COMPACT);
     }
     const unsigned long long b1 = __ballot(single), b2 = __ballot(loose);
-    if (lane == 0) { *s_desc = d; tilemask[0] = (uint32_t)b1; tilemask[1] = (uint32_t)b2; }
+    if (lane == 0) { W->d = d; W->mask[0] = (uint32_t)b1; W->mask[1] = (uint32_t)b2; }
 }
 
+// per-thread inputs of a tile: the read a thread is dealt, and the head of its CIGAR (words behind the read's last op
+// are replaced by "I, length 0", which changes nothing in the walk)
+struct FusedRead {
+    int32_t src;                 // the thread's read of the tile (k_order's order), -1: none
+    uint32_t c_lo, n_cig, lub;
+    int32_t pos, tid;
+    uint32_t rev;
+    uint32_t cg[FUSED_HEAD];
+};
+struct FusedTile { uint32_t r0, n_act; int32_t tid0, pos0; bool in_lds; };   // (wave-uniform)
+
+__device__ __forceinline__ FusedTile fused_tile(const uint32_t *__restrict__ tile_first, const int32_t *__restrict__ r_tid,
+                                                const int32_t *__restrict__ r_pos, const uint32_t *__restrict__ tile_ub, uint32_t t)
+{
+    FusedTile T;
+    T.r0 = tile_first[t]; T.n_act = tile_first[t + 1u] - T.r0;
+    T.tid0 = T.n_act ? r_tid[T.r0] : 0; T.pos0 = T.n_act ? r_pos[T.r0] : 0;
+    T.in_lds = tile_ub[t] <= (uint32_t)FUSED_EXON_CAP;
+    return T;
+}
+// thread -> slot of k_order's order, rotated by one wave per tile (see load_uniforms of the classic kernel)
+__device__ __forceinline__ int32_t fused_src(const uint8_t *__restrict__ order, const FusedTile &T, uint32_t t)
+{
+    const uint32_t slot = (threadIdx.x - (((t + (t >> 10)) & 3u) << 6)) & (uint32_t)(TILE_THREADS - 1);
+    return slot < T.n_act ? (int32_t)ld32(order, T.r0 + slot) : -1;
+}
+__device__ __forceinline__ FusedRead fused_load_read(FusedArgsK a, const FusedTile &T, int32_t src)
+{
+    FusedRead v;
+    v.src = src; v.c_lo = 0u; v.n_cig = 0u; v.lub = 0u; v.pos = 0; v.tid = T.tid0; v.rev = 0u;
+#pragma unroll
+    for (int i = 0; i < FUSED_HEAD; ++i) v.cg[i] = 1u;
+    if (src >= 0) {
+        const uint32_t r = T.r0 + (uint32_t)src;
+        const int64_t *const p_off = a->f.cig_off;
+        v.c_lo = (uint32_t)ld32(p_off, r); v.n_cig = (uint32_t)ld32(p_off, r + 1u) - v.c_lo;
+        v.pos = ld32(a->f.r_pos, r); v.tid = ld32(a->f.r_tid, r); v.rev = ld32(a->f.r_rev, r);
+        v.lub = ld32(a->lub, r);
+        const uint32_t *const words = a->f.cig + v.c_lo;
+#pragma unroll
+        for (int q = 0; q < FUSED_HEAD_VEC; ++q)
+            if ((uint32_t)(4 * q) < v.n_cig) {
+                const v4i_a4 x = *reinterpret_cast<const v4i_a4 *>(words + 4 * q);
+                v.cg[4 * q] = (uint32_t)x.x;
+                v.cg[4 * q + 1] = (uint32_t)(4 * q + 1) < v.n_cig ? (uint32_t)x.y : 1u;
+                v.cg[4 * q + 2] = (uint32_t)(4 * q + 2) < v.n_cig ? (uint32_t)x.z : 1u;
+                v.cg[4 * q + 3] = (uint32_t)(4 * q + 3) < v.n_cig ? (uint32_t)x.w : 1u;
+            }
+    }
+    return v;
+}
+// upper bound of the read's end: every op counted as if it advanced the reference (exact for M / N / D / = / X CIGARs)
+__device__ __forceinline__ int32_t fused_end_bound(FusedArgsK a, const FusedRead &v)
+{
+    uint32_t sum = 0u;
+#pragma unroll
+    for (int i = 0; i < FUSED_HEAD; i += 2) sum += (v.cg[i] >> 4) + (v.cg[i + 1] >> 4);
+    if (v.n_cig > (uint32_t)FUSED_HEAD) {
+        const uint32_t *const words = a->f.cig + v.c_lo;
+        for (uint32_t i = FUSED_HEAD; i < v.n_cig; ++i) sum += words[i] >> 4;
+    }
+    return (int32_t)min((uint32_t)v.pos + sum, 0x7fffffffu);
+}
+// a tile's dictionary entries / bucket directory words as loaded, one START and one END entry per thread
+struct FusedDict { int4 xa, xb, xc, xd; uint32_t dd[3][2]; };
+__device__ __forceinline__ FusedDict fused_load_dict(FusedArgsK a, const TileDesc &d)
+{
+    FusedDict v;
+    v.xa = v.xb = v.xc = v.xd = make_int4(0, 0, 0, 0);
+    const bool fast = (d.flags & TD_FAST) != 0;
+    if (fast && threadIdx.x < d.st_nk) { const int4 *q = reinterpret_cast<const int4 *>(a->f.st.ent + d.st_r0 + threadIdx.x); v.xa = q[0]; v.xb = q[1]; }
+    if (fast && threadIdx.x < d.en_nk) { const int4 *q = reinterpret_cast<const int4 *>(a->f.en.ent + d.en_r0 + threadIdx.x); v.xc = q[0]; v.xd = q[1]; }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = (int)threadIdx.x + q * TILE_THREADS;
+        v.dd[0][q] = v.dd[1][q] = v.dd[2][q] = 0u;
+        if (fast && d.nbk > 0 && i <= d.nbk) {
+            const uint32_t b = (uint32_t)(d.b0 + i);
+            v.dd[0][q] = ld32(a->f.st.dir, b); v.dd[1][q] = ld32(a->f.en.dir, b); v.dd[2][q] = ld32(a->f.st.rdir, b);
+        }
+    }
+    return v;
+}
+
+// PERSISTENT and software pipelined over the workgroup's tiles t, t + grid, ...:
+//     reads of tile t+G (fields, CIGAR head)        issued after tile t's walk (the order byte a tile earlier), in registers
+//     span of tile t+G (upper bound of the ends)    from those registers after tile t's window pass, reduced over the workgroup
+//     descriptor + window of tile t+G               made by the LAST wave (it holds the tile's shortest reads) while the others probe
+//     dictionary entries / directory of tile t+G    issued at the top of tile t+G, consumed after its walk
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, 4)
 void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() */, int64_t n_tiles, const uint32_t *__restrict__ u_tile_first,
@@ -188,11 +287,7 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
     // (the output map, 16 bits per exon, takes the place of the entries once the verdicts are in)
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
     __shared__ __attribute__((aligned(16))) uint32_t s_all[FUSED_ALL_WORDS];
-    __shared__ __attribute__((aligned(16))) int4 s_hk[WIN_TX];
-    __shared__ __attribute__((aligned(16))) int4 s_hx[WIN_TX];
-    __shared__ int s_win[WIN_TX];
-    __shared__ TileDesc s_desc;
-    __shared__ uint32_t s_tilemask[2];
+    __shared__ __attribute__((aligned(16))) TileWin s_tw[2];
     __shared__ int s_wide;
     __shared__ int s_wmax[4];
     __shared__ __attribute__((aligned(16))) uint32_t s_nx[TILE_THREADS];        // per read, READ order: exon count, then (in place) exact exon offset inside the tile
@@ -201,40 +296,47 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     int *const s_S = reinterpret_cast<int *>(s_all), *const s_E = s_S + FUSED_EXON_CAP;
     uint16_t *const s_W = reinterpret_cast<uint16_t *>(s_all + 2 * FUSED_EXON_CAP);
-    v4i_t *const s_ent0 = reinterpret_cast<v4i_t *>(s_all + 2 * FUSED_EXON_CAP + FUSED_W_WORDS), *const s_ent1 = s_ent0 + KEY_CAP;
-    uint8_t *const s_dir0 = reinterpret_cast<uint8_t *>(s_all + 2 * FUSED_EXON_CAP + FUSED_W_WORDS + 2 * KEY_CAP * 4);
+    v4i_t *const s_ent0 = reinterpret_cast<v4i_t *>(s_all + 2 * FUSED_EXON_CAP + FUSED_W_WORDS), *const s_ent1 = s_ent0 + FUSED_KEY_CAP;
+    uint8_t *const s_dir0 = reinterpret_cast<uint8_t *>(s_all + 2 * FUSED_EXON_CAP + FUSED_W_WORDS + 2 * FUSED_KEY_CAP * 4);
     uint8_t *const s_dir1 = s_dir0 + DIR_BYTES, *const s_rdir = s_dir1 + DIR_BYTES;
     uint16_t *const s_map = reinterpret_cast<uint16_t *>(s_ent0);
 
-    for (uint32_t t = blockIdx.x; (int64_t)t < n_tiles; t += gridDim.x) {
+    uint32_t t = blockIdx.x;
+    if ((int64_t)t >= n_tiles) return;
+    // ---- prologue: the first tile's reads, span, descriptor (nothing to hide behind yet)
+    FusedTile T = fused_tile(u_tile_first, u_tid, u_pos, u_tile_ub, t);
+    FusedRead v = fused_load_read(fused_args(), T, fused_src(u_order, T, t));
+    {
+        const int m = wave_max((v.src >= 0 && v.tid == T.tid0) ? fused_end_bound(fused_args(), v) : INT32_MIN);
+        if (lane == 0) s_wmax[wv] = m;
+    }
+    __syncthreads();
+    if (wv == TILE_THREADS / WAVE - 1)
+        make_descriptor(fused_args(), lane, T.tid0, T.pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), T.in_lds, &s_tw[0]);
+    __syncthreads();
+    int cur = 0;                                   // which TileWin holds the current tile
+
+    for (; (int64_t)t < n_tiles; t += gridDim.x) {
         const FusedArgsK a = fused_args();
-        const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
-        const int32_t tid0 = n_act ? u_tid[r0] : 0, pos0 = n_act ? u_pos[r0] : 0;
-        const bool in_lds = u_tile_ub[t] <= (uint32_t)FUSED_EXON_CAP;
-        // thread -> slot of k_order's order, rotated by one wave per tile (see load_uniforms of the classic kernel)
-        const uint32_t slot = (threadIdx.x - (((t + (t >> 10)) & 3u) << 6)) & (uint32_t)(TILE_THREADS - 1);
-        const int32_t src = slot < n_act ? (int32_t)ld32(u_order, r0 + slot) : -1;
-        const bool active = src >= 0;
-        const uint32_t r = r0 + (uint32_t)max(src, 0);
-        // ---- the read and the head of its CIGAR
-        uint32_t c_lo = 0u, n_cig = 0u, lub = 0u;
-        int32_t pos = 0, tid = tid0;
-        bool rev_in = false;
-        uint4 cg[FUSED_HEAD_VEC];
-#pragma unroll
-        for (int q = 0; q < FUSED_HEAD_VEC; ++q) cg[q] = make_uint4(1u, 1u, 1u, 1u);
-        if (active) {
-            const int64_t *const p_off = a->f.cig_off;
-            c_lo = (uint32_t)ld32(p_off, r); n_cig = (uint32_t)ld32(p_off, r + 1u) - c_lo;
-            pos = ld32(a->f.r_pos, r); tid = ld32(a->f.r_tid, r); rev_in = ld32(a->f.r_rev, r) != 0;
-            lub = ld32(a->lub, r);
-            const uint32_t *const words = a->f.cig + c_lo;
-#pragma unroll
-            for (int q = 0; q < FUSED_HEAD_VEC; ++q)
-                if ((uint32_t)(4 * q) < n_cig) { const v4i_a4 x = *reinterpret_cast<const v4i_a4 *>(words + 4 * q); cg[q] = make_uint4((uint32_t)x.x, (uint32_t)x.y, (uint32_t)x.z, (uint32_t)x.w); }
-        }
-        if (threadIdx.x == 0) { s_wide = 0; }
-        // ---- phase 1: the ONE walk, CIGAR words out of registers (words behind the read's last op become "I, length 0")
+        const uint32_t t_next = t + gridDim.x;
+        const bool has_next = (int64_t)t_next < n_tiles;
+        FusedTile Tn = T;
+        int32_t src_next = -1;
+        if (has_next) { Tn = fused_tile(u_tile_first, u_tid, u_pos, u_tile_ub, t_next); src_next = fused_src(u_order, Tn, t_next); }
+        TileWin *const tw = &s_tw[cur], *const tw_next = &s_tw[cur ^ 1];
+        const TileDesc d = tw->d;
+        const bool fast = (d.flags & TD_FAST) != 0, in_lds = T.in_lds;
+        const int w_n = fast ? (int)d.n_win : 0;
+        // the tile's dictionary entries and directory words start their trip; they are staged after the walk
+        const FusedDict dv = fused_load_dict(a, d);
+        const bool active = v.src >= 0;
+        const uint32_t r = T.r0 + (uint32_t)max(v.src, 0);
+        const uint32_t lub = v.lub, n_cig = v.n_cig, c_lo = v.c_lo;
+        const int32_t pos = v.pos, tid = v.tid;
+        const bool rev_in = v.rev != 0u;
+        const int32_t src = v.src;
+        if (threadIdx.x == 0) s_wide = 0;
+        // ---- phase 1: the ONE walk, CIGAR words out of registers
         DevParams p;
         p.min_exon = a->f.p.min_exon; p.min_intron = a->f.p.min_intron; p.max_delet = a->f.p.max_delet;
         const uint32_t room = exon_bound(n_cig, p.min_exon);
@@ -250,62 +352,43 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
                 re.sl = s; re.el = e;
             };
 #pragma unroll
-            for (int q = 0; q < FUSED_HEAD_VEC; ++q) {
-                const uint32_t c0 = (uint32_t)(4 * q) < n_cig ? cg[q].x : 1u, c1 = (uint32_t)(4 * q + 1) < n_cig ? cg[q].y : 1u;
-                const uint32_t c2 = (uint32_t)(4 * q + 2) < n_cig ? cg[q].z : 1u, c3 = (uint32_t)(4 * q + 3) < n_cig ? cg[q].w : 1u;
-                walk_step(w, c0, p, emit); walk_step(w, c1, p, emit); walk_step(w, c2, p, emit); walk_step(w, c3, p, emit);
-            }
+            for (int i = 0; i < FUSED_HEAD; ++i) walk_step(w, v.cg[i], p, emit);
             if (n_cig > (uint32_t)FUSED_HEAD) walk_ops<false>(w, a->f.cig + c_lo, FUSED_HEAD, (int)n_cig, p, emit);
             emit(w.n, w.start, w.end);
             n = (uint32_t)w.n + 1u;
             if (in_lds && !over) { re.s0 = s_S[lub]; re.e0 = s_E[lub]; }
         }
-        // the tile's span: its reads are sorted, so it starts at its first read; the ends take a reduction
-        {
-            const int m = wave_max((active && tid == tid0) ? re.el : INT32_MIN);
-            if (lane == 0) s_wmax[wv] = m;
-        }
-        __syncthreads();
-        if (wv == TILE_THREADS / WAVE - 1) {
-            const int32_t thi = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-            make_descriptor(a, lane, tid0, pos0 + 1, thi, in_lds, &s_desc, s_hk, s_hx, s_win, s_tilemask);
-        }
-        __syncthreads();
-        const TileDesc d = s_desc;
-        const bool fast = (d.flags & TD_FAST) != 0;
-        const int w_n = fast ? (int)d.n_win : 0;
+        // the next tile's reads: fields and CIGAR heads (their order byte has had the walk to arrive)
+        if (has_next) v = fused_load_read(a, Tn, src_next);
+        __syncthreads();                 // every walk is done
         // ---- stage the dictionary slices, re-based to the tile's window
         int my_wide = 0;
         if (fast) {
-            if ((int)threadIdx.x < KEY_CAP) {
+            if ((int)threadIdx.x < FUSED_KEY_CAP) {
                 const bool has_st = threadIdx.x < d.st_nk, has_en = threadIdx.x < d.en_nk;
-                int4 xa = make_int4(0, 0, 0, 0), xb = xa, xc = xa, xd = xa;
-                if (has_st) { const int4 *q = reinterpret_cast<const int4 *>(a->f.st.ent + d.st_r0 + threadIdx.x); xa = q[0]; xb = q[1]; }
-                if (has_en) { const int4 *q = reinterpret_cast<const int4 *>(a->f.en.ent + d.en_r0 + threadIdx.x); xc = q[0]; xd = q[1]; }
                 v4i_t e0, e1;
-                e0.x = xa.x; e0.y = xa.y; e1.x = xc.x; e1.y = xc.y;
+                e0.x = dv.xa.x; e0.y = dv.xa.y; e1.x = dv.xc.x; e1.y = dv.xc.y;
                 if (d.flags & TD_CONTIG) {
-                    e0.z = (int)rebase_mask((uint32_t)xb.x, (uint32_t)xb.y, xa.z - d.j_lo);
-                    e0.w = (int)rebase_mask((uint32_t)xb.z, (uint32_t)xb.w, xa.z - d.j_lo);
-                    e1.z = (int)rebase_mask((uint32_t)xd.x, (uint32_t)xd.y, xc.z - d.j_lo);
-                    e1.w = (int)rebase_mask((uint32_t)xd.z, (uint32_t)xd.w, xc.z - d.j_lo);
+                    e0.z = (int)rebase_mask((uint32_t)dv.xb.x, (uint32_t)dv.xb.y, dv.xa.z - d.j_lo);
+                    e0.w = (int)rebase_mask((uint32_t)dv.xb.z, (uint32_t)dv.xb.w, dv.xa.z - d.j_lo);
+                    e1.z = (int)rebase_mask((uint32_t)dv.xd.x, (uint32_t)dv.xd.y, dv.xc.z - d.j_lo);
+                    e1.w = (int)rebase_mask((uint32_t)dv.xd.z, (uint32_t)dv.xd.w, dv.xc.z - d.j_lo);
                 } else {
-                    e0.z = (int)rebase_gaps(s_win, w_n, (uint32_t)xb.x, (uint32_t)xb.y, xa.z);
-                    e0.w = (int)rebase_gaps(s_win, w_n, (uint32_t)xb.z, (uint32_t)xb.w, xa.z);
-                    e1.z = (int)rebase_gaps(s_win, w_n, (uint32_t)xd.x, (uint32_t)xd.y, xc.z);
-                    e1.w = (int)rebase_gaps(s_win, w_n, (uint32_t)xd.z, (uint32_t)xd.w, xc.z);
+                    e0.z = (int)rebase_gaps(tw->win, w_n, (uint32_t)dv.xb.x, (uint32_t)dv.xb.y, dv.xa.z);
+                    e0.w = (int)rebase_gaps(tw->win, w_n, (uint32_t)dv.xb.z, (uint32_t)dv.xb.w, dv.xa.z);
+                    e1.z = (int)rebase_gaps(tw->win, w_n, (uint32_t)dv.xd.x, (uint32_t)dv.xd.y, dv.xc.z);
+                    e1.w = (int)rebase_gaps(tw->win, w_n, (uint32_t)dv.xd.z, (uint32_t)dv.xd.w, dv.xc.z);
                 }
-                if (has_st) { s_ent0[threadIdx.x] = e0; if (xa.w & SE_WIDE) my_wide = 1; }
-                if (has_en) { s_ent1[threadIdx.x] = e1; if (xc.w & SE_WIDE) my_wide = 1; }
+                if (has_st) { s_ent0[threadIdx.x] = e0; if (dv.xa.w & SE_WIDE) my_wide = 1; }
+                if (has_en) { s_ent1[threadIdx.x] = e1; if (dv.xc.w & SE_WIDE) my_wide = 1; }
             }
             if (d.nbk > 0) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int i = (int)threadIdx.x + q * TILE_THREADS;
                     if (i <= d.nbk) {
-                        const uint32_t b = (uint32_t)(d.b0 + i);
-                        s_dir0[i] = (uint8_t)(ld32(a->f.st.dir, b) - d.st_r0); s_dir1[i] = (uint8_t)(ld32(a->f.en.dir, b) - d.en_r0);
-                        s_rdir[i] = (uint8_t)(ld32(a->f.st.rdir, b) - d.st_r0);
+                        s_dir0[i] = (uint8_t)(dv.dd[0][q] - d.st_r0); s_dir1[i] = (uint8_t)(dv.dd[1][q] - d.en_r0);
+                        s_rdir[i] = (uint8_t)(dv.dd[2][q] - d.st_r0);
                     }
                 }
             }
@@ -320,9 +403,18 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
         uint32_t info = n << 8; int ref = -1;
         bool redo = active && (!fast || !in_lds || over || any_wide != 0 || tid != d.tid || (n > 1 && !sane));
         const bool work = active && !redo;
-        const TileLds L{s_S, s_E, s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_hk, s_hx, s_win};
-        const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, s_tilemask);
+        const TileLds L{s_S, s_E, s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, tw->hk, tw->hx, tw->win};
+        const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, tw->mask);
         redo = redo || vm.redo;
+        // the next tile's span: upper bounds of its read ends (the registers loaded above), reduced over the workgroup
+        if (has_next) {
+            const int m = wave_max((v.src >= 0 && v.tid == Tn.tid0) ? fused_end_bound(a, v) : INT32_MIN);
+            if (lane == 0) s_wmax[wv] = m;
+        }
+        __syncthreads();
+        // ... and its descriptor and window, by the last wave, into the other TileWin, while the others start probing
+        if (has_next && wv == TILE_THREADS / WAVE - 1)
+            make_descriptor(a, lane, Tn.tid0, Tn.pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), Tn.in_lds, tw_next);
         const SiteMasks sm = map_exons(L, d, work && !redo && n > 1, lub, n, vm.vpre);
         if (work && !redo) {
             const Verdict vd = decide<LEVEL>(L, d, lub, n, re, vm, sm, rev_in);
@@ -345,8 +437,8 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
         // ---- exact exon offsets in read order (one wave, four reads per lane) and the tile's chunk of the result arrays
         if (wv == 0) {
             const uint4 quad = *reinterpret_cast<const uint4 *>(s_nx + 4 * lane);
-            const uint32_t c0 = (uint32_t)(4 * lane) < n_act ? quad.x : 0u, c1 = (uint32_t)(4 * lane + 1) < n_act ? quad.y : 0u;
-            const uint32_t c2 = (uint32_t)(4 * lane + 2) < n_act ? quad.z : 0u, c3 = (uint32_t)(4 * lane + 3) < n_act ? quad.w : 0u;
+            const uint32_t c0 = (uint32_t)(4 * lane) < T.n_act ? quad.x : 0u, c1 = (uint32_t)(4 * lane + 1) < T.n_act ? quad.y : 0u;
+            const uint32_t c2 = (uint32_t)(4 * lane + 2) < T.n_act ? quad.z : 0u, c3 = (uint32_t)(4 * lane + 3) < T.n_act ? quad.w : 0u;
             const uint32_t mine = c0 + c1 + c2 + c3;
             const uint32_t inc = wave_inclusive_scan(mine), ex = inc - mine;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
@@ -359,8 +451,8 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
         }
         __syncthreads();
         const uint32_t base = s_base[0], tile_total = s_base[1];
-        // tiles whose exons could not be kept in LDS (capacity, or a read beyond its bound): walked again, straight to HBM
-        const bool direct = !in_lds || tile_total > (uint32_t)FUSED_EXON_CAP;
+        // a tile whose exons could not be kept in LDS (capacity), or a read beyond its bound: walked again, straight to HBM
+        const bool direct = !in_lds;
         if (active) {
             const uint32_t loc = s_nx[src];
             a->f.ex_off[r] = base + loc;
@@ -368,7 +460,6 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
             a->f.ref_tx[r] = ref;
             if (!direct && !over) for (uint32_t k = 0; k < n; ++k) s_map[loc + k] = (uint16_t)(lub + k);
             if (direct || over) {
-                // (rare) the read's exons go out lane by lane
                 int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end; uint8_t *const xf = a->f.ex_flag;
                 WalkState w{pos + 1, pos, 0};
                 auto put = [&](int k, int s, int e) { xs[base + loc + (uint32_t)k] = s; xe[base + loc + (uint32_t)k] = e; xf[base + loc + (uint32_t)k] = 0; };
@@ -388,7 +479,8 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
                 xf[base + i] = (uint8_t)s_W[q];
             }
         }
-        __syncthreads();                 // the tile's LDS image has been written out
+        __syncthreads();                 // the tile's LDS image has been written out; the next descriptor is complete
+        T = Tn; cur ^= 1;
     }
 }
 
