@@ -14,6 +14,7 @@
 #include "../../include/lr2rmats_hip.h"
 #include "l2r_kernels.hip.h"
 #include "l2r_fused.hip.h"
+#include "l2r_split.hip.h"
 
 using namespace l2r;
 
@@ -60,8 +61,10 @@ struct l2r_ctx {
     bool wide_cigar = false;                // long CIGARs: the HBM walks fetch 16 words per lane and round (l2r_upload_reads decides)
     int n_cu = 256, wg_per_cu = 4;          // persistent grid of k_classify_fast (L2R_WG_PER_CU overrides)
     int ablate = 0;                         // diagnostics, L2R_ABLATE (read once, at l2r_create)
-    bool allow_fused = true;                // L2R_PIPELINE=classic keeps the two-walk kernels for every input
-    bool fused = false;                     // the current upload runs the one-walk pipeline (l2r_fused.hip.h): sorted input, short CIGARs
+    int want_pipeline = 2;                  // L2R_PIPELINE: classic (0: two walks), fused (1: l2r_fused.hip.h), split (2, default: l2r_split.hip.h)
+    bool fused = false;                     // the current upload runs a one-walk pipeline: sorted input, short CIGARs
+    bool split = false;                     // ... the two-kernel form of it (k_walk + k_probe)
+    DevBuf<TileWin> tw;                     // split: descriptor + window per tile
     DevBuf<uint16_t> lub;                   // k_order: first LDS slot of every read
     DevBuf<uint32_t> tile_ub, tile_start, tile_total, tile_dest;
     DevBuf<int32_t> lin_start, lin_end;     // l2r_download of a fused run: the exon arrays in read order (k_linearize)
@@ -190,7 +193,7 @@ l2r_ctx *l2r_create(int device)
         e = getenv("L2R_ABLATE");
         c->ablate = e ? atoi(e) : 0;
         e = getenv("L2R_PIPELINE");
-        c->allow_fused = !(e && !strcmp(e, "classic"));
+        if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : !strcmp(e, "fused") ? 1 : 2;
     }
     return c;
 }
@@ -208,7 +211,7 @@ void l2r_destroy(l2r_ctx *c)
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->lub.release(); c->tile_ub.release(); c->tile_start.release(); c->tile_total.release(); c->tile_dest.release();
-    c->lin_start.release(); c->lin_end.release(); c->lin_flag.release();
+    c->lin_start.release(); c->lin_end.release(); c->lin_flag.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -607,7 +610,9 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
         c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb) || (c->wide_cigar && c->walked.ensure((size_t)(c->n_tiles + 1) * LDS_EXON_CAP))) return -2;
     c->ex_cap = (int64_t)exb;
-    c->fused = c->allow_fused && sorted && !c->wide_cigar;
+    c->fused = c->want_pipeline > 0 && sorted && !c->wide_cigar;
+    c->split = c->fused && c->want_pipeline == 2;
+    if (c->split && c->tw.ensure((size_t)c->n_tiles + 1)) return -2;
     if (c->fused && (c->lub.ensure((size_t)N + 1) || c->tile_ub.ensure((size_t)c->n_tiles + 1) || c->tile_start.ensure((size_t)c->n_tiles + 1) ||
                      c->tile_total.ensure((size_t)c->n_tiles + 1) || c->tile_dest.ensure((size_t)c->n_tiles + 1))) return -2;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -733,10 +738,28 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         hipLaunchKernelGGL(k_order, dim3(gt), dim3(TILE_THREADS), 0, s, (const int64_t *)c->cig_off.p, (const uint32_t *)c->tile_first.p, p,
                            c->order.p, c->lub.p, c->tile_ub.p, c->totals.p + 3, ex_cursor);
         MARK(ST_SCAN1);
-        MARK(ST_FAST);
         FusedArgs ga;
         ga.f = fa; ga.cd = cd; ga.tid_base = c->tid_base.p; ga.n_tid_dir = c->n_tid_dir; ga.lub = c->lub.p; ga.tile_ub = c->tile_ub.p;
         ga.tile_start = c->tile_start.p; ga.tile_total = c->tile_total.p; ga.ex_cursor = ex_cursor;
+        if (c->split) {
+            // ---- two kernels: the walk (exons to HBM), then the probes at full occupancy (l2r_split.hip.h)
+            SplitArgs sa; sa.g = ga; sa.tw = c->tw.p;
+            hipLaunchKernelGGL(k_walk, dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, (const uint8_t *)c->order.p,
+                               (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_ub.p);
+            MARK(ST_FAST);
+#define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe<L>), dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
+                (const uint8_t *)c->order.p, (const uint32_t *)c->tile_start.p, (const uint32_t *)c->tile_total.p)
+            switch (p.full_level) {
+            case 1: launch_probe_level(1); break;
+            case 2: launch_probe_level(2); break;
+            case 3: launch_probe_level(3); break;
+            case 4: launch_probe_level(4); break;
+            case 5: launch_probe_level(5); break;
+            default: launch_probe_level(0); break;
+            }
+#undef launch_probe_level
+        } else {
+        MARK(ST_FAST);
 #define launch_fused_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused<L>), dim3(gp), dim3(TILE_THREADS), 0, s, ga, c->n_tiles, (const uint32_t *)c->tile_first.p, \
             (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_ub.p)
         switch (p.full_level) {
@@ -748,6 +771,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         default: launch_fused_level(0); break;
         }
 #undef launch_fused_level
+        }
         // every tile's accepted reads are compacted by k_gather_accepted (nothing is fused into the classification here)
         if (c->want & L2R_WANT_ACCEPTED) HIP_TRY(hipMemsetAsync(c->tile_chunk.p, 0xff, (size_t)(c->n_tiles + 1) * 4, s));
     } else {
