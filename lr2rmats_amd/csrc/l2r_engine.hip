@@ -61,7 +61,7 @@ struct l2r_ctx {
     bool wide_cigar = false;                // long CIGARs: the HBM walks fetch 16 words per lane and round (l2r_upload_reads decides)
     int n_cu = 256, wg_per_cu = 4;          // persistent grid of k_classify_fast (L2R_WG_PER_CU overrides)
     int ablate = 0;                         // diagnostics, L2R_ABLATE (read once, at l2r_create)
-    int want_pipeline = 2;                  // L2R_PIPELINE: classic (0: two walks), fused (1: l2r_fused.hip.h), split (2, default: l2r_split.hip.h)
+    int want_pipeline = 1;                  // L2R_PIPELINE: classic (0: two walks), fused (1, default: l2r_fused.hip.h), split (2: l2r_split.hip.h, measured slower)
     bool fused = false;                     // the current upload runs a one-walk pipeline: sorted input, short CIGARs
     bool split = false;                     // ... the two-kernel form of it (k_walk + k_probe)
     DevBuf<TileWin> tw;                     // split: descriptor + window per tile
@@ -193,7 +193,7 @@ l2r_ctx *l2r_create(int device)
         e = getenv("L2R_ABLATE");
         c->ablate = e ? atoi(e) : 0;
         e = getenv("L2R_PIPELINE");
-        if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : !strcmp(e, "fused") ? 1 : 2;
+        if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : !strcmp(e, "split") ? 2 : 1;
     }
     return c;
 }

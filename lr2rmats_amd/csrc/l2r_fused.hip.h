@@ -188,6 +188,69 @@ __device__ __forceinline__ void make_descriptor(FusedArgsK a, int lane, int32_t 
     if (lane == 0) { W->d = d; W->mask[0] = (uint32_t)b1; W->mask[1] = (uint32_t)b2; }
 }
 
+// base[idx] = v with a 32-bit byte offset (see ld32): one shift per lane instead of a 64-bit multiply-add
+template <typename T>
+__device__ __forceinline__ void st32(T *base, uint32_t idx, T v)
+{
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (size_t)(idx * (uint32_t)sizeof(T))) = v;
+}
+
+// One CIGAR op of the register walk (src/bam2gtf.c:31-78, the rules of walk_step) without a branch: the exon in progress
+// is written to its LDS slot {start, end} at EVERY step, and a kept cut finalises the slot by moving on to the next one.
+// t3 / t2 = the smallest words "N, length min_intron" / "D, length max_delet + 1": op and length compare as one number.
+struct WalkRegs { int start, end; uint32_t n; bool first; };          // first: no exon kept yet (the chain through n stays one add per op)
+__device__ __forceinline__ void walk_word(WalkRegs &w, uint32_t c, uint32_t t3, uint32_t t2, int min_len_m1, int2 *slots, uint32_t room_m1)
+{
+    const uint32_t op = c & 0xfu;
+    const int len = (int)(c >> 4);
+    const bool cut = ((op == 3u) & (c >= t3)) | ((op == 2u) & (c >= t2));
+    const bool keep = cut & (w.first | (w.end - w.start >= min_len_m1));
+    slots[min(w.n, room_m1)] = make_int2(w.start, w.end);
+    w.first = w.first & !keep;
+    w.n += keep ? 1u : 0u;
+    w.start = cut ? w.end + len + 1 : w.start;
+    w.end += len & __builtin_amdgcn_sbfe(0x18d, op, 1u);         // ops 0 2 3 7 8 advance the reference
+}
+
+// map_exons (l2r_kernels.hip.h) over exon PAIRS {start, end} in LDS: one 8-byte read per exon
+__device__ __forceinline__ SiteMasks map_exons_se(const TileLds &L, const int2 *SE, const TileDesc &d, bool mapping, uint32_t local, uint32_t n, uint32_t vpre)
+{
+    SiteMasks m{0xffffffffu, 0u, 0u, 0u};
+    uint16_t *W = L.W + local;
+    int s = 0, e = 0;
+    if (mapping) { const int2 x = SE[local]; s = x.x; e = x.y; }
+    const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
+    const int k_max = wave_max(mapping ? (int)n : 0);
+#pragma unroll 2
+    for (int k = 0; k < k_max; ++k) {
+        const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
+        const uint32_t is = min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none);
+        const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
+        const int2 nx = SE[local + (uint32_t)k + 1u];         // (a slot behind the read's last exon: read, not used)
+        const int s2 = nx.x, e2 = nx.y;
+        const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
+        const v4i_t qs0 = lds_entry(L.ent0, ls);
+        const v4i_t qe0 = lds_entry(L.ent1, le), qe1 = lds_entry(L.ent1, le + 1u);
+        uint32_t xm, am, jm, dm;
+        {   const bool m0 = ls < hs && qs0.x == s;
+            am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
+        probe2(qe0, qe1, le, he, e, s2, jm, dm);
+        if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(L.ent0, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + 2u, he, e, s2, jm, dm, 0u); }
+        const uint32_t amj = junc ? am : 0u;
+        uint32_t word = first_member(xm & vpre);
+        word |= first_member(jm & vpre) << 6;
+        word |= nonzero(dm & vpre) << 12;
+        word |= nonzero(amj & vpre) << 13;
+        m.kand &= junc ? (am & dm) : 0xffffffffu;     // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
+        m.kor |= amj | dm;
+        if (k == 0) m.dm_first = dm;
+        m.am_last = (live && !junc) ? am : m.am_last;
+        if (live) W[k] = (uint16_t)word;
+        s = s2; e = e2;
+    }
+    return m;
+}
+
 // per-thread inputs of a tile: the read a thread is dealt, and the head of its CIGAR (words behind the read's last op
 // are replaced by "I, length 0", which changes nothing in the walk)
 struct FusedRead {
@@ -214,29 +277,45 @@ __device__ __forceinline__ int32_t fused_src(const uint8_t *__restrict__ order, 
     const uint32_t slot = (threadIdx.x - (((t + (t >> 10)) & 3u) << 6)) & (uint32_t)(TILE_THREADS - 1);
     return slot < T.n_act ? (int32_t)ld32(order, T.r0 + slot) : -1;
 }
-__device__ __forceinline__ FusedRead fused_load_read(FusedArgsK a, const FusedTile &T, int32_t src)
+// The reads of a tile arrive in three steps, each issued a phase before its result is needed (order byte -> record
+// fields -> CIGAR words are dependent loads): fields, words, then masking of the words behind the read's last op.
+__device__ __forceinline__ void fused_load_fields(FusedArgsK a, const FusedTile &T, int32_t src, FusedRead &v)
 {
-    FusedRead v;
     v.src = src; v.c_lo = 0u; v.n_cig = 0u; v.lub = 0u; v.pos = 0; v.tid = T.tid0; v.rev = 0u;
-#pragma unroll
-    for (int i = 0; i < FUSED_HEAD; ++i) v.cg[i] = 1u;
     if (src >= 0) {
         const uint32_t r = T.r0 + (uint32_t)src;
         const int64_t *const p_off = a->f.cig_off;
-        v.c_lo = (uint32_t)ld32(p_off, r); v.n_cig = (uint32_t)ld32(p_off, r + 1u) - v.c_lo;
+        v.c_lo = (uint32_t)ld32(p_off, r); v.n_cig = (uint32_t)ld32(p_off, r + 1u);        // (n_cig holds c_hi until fused_load_words)
         v.pos = ld32(a->f.r_pos, r); v.tid = ld32(a->f.r_tid, r); v.rev = ld32(a->f.r_rev, r);
         v.lub = ld32(a->lub, r);
+    }
+}
+__device__ __forceinline__ void fused_load_words(FusedArgsK a, FusedRead &v)
+{
+    v.n_cig -= v.c_lo;
+#pragma unroll
+    for (int i = 0; i < FUSED_HEAD; ++i) v.cg[i] = 1u;
+    if (v.src >= 0) {
         const uint32_t *const words = a->f.cig + v.c_lo;
 #pragma unroll
         for (int q = 0; q < FUSED_HEAD_VEC; ++q)
             if ((uint32_t)(4 * q) < v.n_cig) {
                 const v4i_a4 x = *reinterpret_cast<const v4i_a4 *>(words + 4 * q);
-                v.cg[4 * q] = (uint32_t)x.x;
-                v.cg[4 * q + 1] = (uint32_t)(4 * q + 1) < v.n_cig ? (uint32_t)x.y : 1u;
-                v.cg[4 * q + 2] = (uint32_t)(4 * q + 2) < v.n_cig ? (uint32_t)x.z : 1u;
-                v.cg[4 * q + 3] = (uint32_t)(4 * q + 3) < v.n_cig ? (uint32_t)x.w : 1u;
+                v.cg[4 * q] = (uint32_t)x.x; v.cg[4 * q + 1] = (uint32_t)x.y; v.cg[4 * q + 2] = (uint32_t)x.z; v.cg[4 * q + 3] = (uint32_t)x.w;
             }
     }
+}
+__device__ __forceinline__ void fused_mask_words(FusedRead &v)
+{
+#pragma unroll
+    for (int i = 0; i < FUSED_HEAD; ++i) v.cg[i] = (uint32_t)i < v.n_cig ? v.cg[i] : 1u;
+}
+__device__ __forceinline__ FusedRead fused_load_read(FusedArgsK a, const FusedTile &T, int32_t src)
+{
+    FusedRead v;
+    fused_load_fields(a, T, src, v);
+    fused_load_words(a, v);
+    fused_mask_words(v);
     return v;
 }
 // upper bound of the read's end: every op counted as if it advanced the reference (exact for M / N / D / = / X CIGARs)
@@ -294,13 +373,22 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
     __shared__ uint32_t s_base[2];
     (void)kernarg_block;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    int *const s_S = reinterpret_cast<int *>(s_all), *const s_E = s_S + FUSED_EXON_CAP;
+    int2 *const s_SE = reinterpret_cast<int2 *>(s_all);                 // exon pairs {start, end}
     uint16_t *const s_W = reinterpret_cast<uint16_t *>(s_all + 2 * FUSED_EXON_CAP);
     v4i_t *const s_ent0 = reinterpret_cast<v4i_t *>(s_all + 2 * FUSED_EXON_CAP + FUSED_W_WORDS), *const s_ent1 = s_ent0 + FUSED_KEY_CAP;
     uint8_t *const s_dir0 = reinterpret_cast<uint8_t *>(s_all + 2 * FUSED_EXON_CAP + FUSED_W_WORDS + 2 * FUSED_KEY_CAP * 4);
     uint8_t *const s_dir1 = s_dir0 + DIR_BYTES, *const s_rdir = s_dir1 + DIR_BYTES;
     uint16_t *const s_map = reinterpret_cast<uint16_t *>(s_ent0);
 
+    // diagnostics (L2R_STAMPS=1): cycles of wave 0 per phase [0 walk, 1 staging, 2 window pass + next span, 3 probes + verdicts,
+    // 4 offsets + map + write-out], barrier waits of wave 0 [5] and of the last wave [6], the last wave's descriptor work [7]
+    const bool stamping = fused_args()->f.stamps != nullptr;
+    unsigned long long t_prev = stamping ? __builtin_readcyclecounter() : 0ull;
+#define F_STAMP(i) do { if (stamping && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+        atomicAdd(&fused_args()->f.stamps[(blockIdx.x & 1023u) * 8u + (i)], t_ - t_prev); t_prev = t_; } } while (0)
+#define F_BARRIER() do { const unsigned long long b0_ = stamping ? __builtin_readcyclecounter() : 0ull; __syncthreads(); \
+        if (stamping && lane == 0 && (wv == 0 || wv == TILE_THREADS / WAVE - 1)) { const unsigned long long b1_ = __builtin_readcyclecounter(); \
+            atomicAdd(&fused_args()->f.stamps[(blockIdx.x & 1023u) * 8u + (wv == 0 ? 5u : 6u)], b1_ - b0_); t_prev += b1_ - b0_; } } while (0)
     uint32_t t = blockIdx.x;
     if ((int64_t)t >= n_tiles) return;
     // ---- prologue: the first tile's reads, span, descriptor (nothing to hide behind yet)
@@ -315,14 +403,24 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
         make_descriptor(fused_args(), lane, T.tid0, T.pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), T.in_lds, &s_tw[0]);
     __syncthreads();
     int cur = 0;                                   // which TileWin holds the current tile
+    // ... and of the tile after it: uniforms, order byte, record fields (its CIGAR words follow inside the loop)
+    FusedTile Tn = T;
+    FusedRead vn = v;
+    int32_t src_n1 = -1;                           // the thread's read of the next tile (its order byte)
+    {
+        const uint32_t t1 = t + gridDim.x;
+        if ((int64_t)t1 < n_tiles) { Tn = fused_tile(u_tile_first, u_tid, u_pos, u_tile_ub, t1); src_n1 = fused_src(u_order, Tn, t1); }
+    }
 
     for (; (int64_t)t < n_tiles; t += gridDim.x) {
         const FusedArgsK a = fused_args();
-        const uint32_t t_next = t + gridDim.x;
-        const bool has_next = (int64_t)t_next < n_tiles;
-        FusedTile Tn = T;
-        int32_t src_next = -1;
-        if (has_next) { Tn = fused_tile(u_tile_first, u_tid, u_pos, u_tile_ub, t_next); src_next = fused_src(u_order, Tn, t_next); }
+        const uint32_t t_next = t + gridDim.x, t_next2 = t_next + gridDim.x;
+        const bool has_next = (int64_t)t_next < n_tiles, has_next2 = (int64_t)t_next2 < n_tiles;
+        // uniforms of the tile after the next one (scalar loads; their order byte is fetched after this tile's walk)
+        FusedTile Tn2 = Tn;
+        if (has_next2) Tn2 = fused_tile(u_tile_first, u_tid, u_pos, u_tile_ub, t_next2);
+        // record fields of the next tile's reads (their CIGAR words follow after this tile's walk)
+        if (has_next) fused_load_fields(a, Tn, src_n1, vn);
         TileWin *const tw = &s_tw[cur], *const tw_next = &s_tw[cur ^ 1];
         const TileDesc d = tw->d;
         const bool fast = (d.flags & TD_FAST) != 0, in_lds = T.in_lds;
@@ -336,31 +434,55 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
         const bool rev_in = v.rev != 0u;
         const int32_t src = v.src;
         if (threadIdx.x == 0) s_wide = 0;
-        // ---- phase 1: the ONE walk, CIGAR words out of registers
+        // ---- phase 1: the ONE walk, CIGAR words out of registers; a wave stops where its longest CIGAR ends
         DevParams p;
         p.min_exon = a->f.p.min_exon; p.min_intron = a->f.p.min_intron; p.max_delet = a->f.p.max_delet;
         const uint32_t room = exon_bound(n_cig, p.min_exon);
+        // the straight-line walk wants every kept inner exon non-empty by construction (min_exon >= 1, thresholds that fit a CIGAR word);
+        // anything else takes the generic rules read by read (`over`)
+        const bool plain = p.min_exon >= 1 && p.min_intron >= 0 && p.min_intron < (1 << 28) && p.max_delet >= -1 && p.max_delet < (1 << 28) - 1;
+        const uint32_t t3 = ((uint32_t)p.min_intron << 4) | 3u, t2 = ((uint32_t)(p.max_delet + 1) << 4) | 2u;
+        const int c_max = wave_max(active ? (int)min(n_cig, (uint32_t)FUSED_HEAD) : 0);
         uint32_t n = 0u;
         ReadEnds re{0, 0, 0, 0};
         bool sane = true, over = false;
-        if (active) {
+        if (active && in_lds && plain && n_cig <= (uint32_t)FUSED_HEAD) {
+            WalkRegs w{pos + 1, pos, 0u, true};
+            int2 *const slots = s_SE + lub;
+            const uint32_t room_m1 = room - 1u;
+#pragma unroll
+            for (int q = 0; q < FUSED_HEAD_VEC; ++q) {
+                if (4 * q < c_max) {         // (wave-uniform)
+                    walk_word(w, v.cg[4 * q], t3, t2, p.min_exon - 1, slots, room_m1); walk_word(w, v.cg[4 * q + 1], t3, t2, p.min_exon - 1, slots, room_m1);
+                    walk_word(w, v.cg[4 * q + 2], t3, t2, p.min_exon - 1, slots, room_m1); walk_word(w, v.cg[4 * q + 3], t3, t2, p.min_exon - 1, slots, room_m1);
+                }
+            }
+            over = w.n >= room;                                    // (cannot happen: exon_bound; the slot index was clamped)
+            slots[min(w.n, room_m1)] = make_int2(w.start, w.end);
+            n = w.n + 1u;
+            const int2 x0 = slots[0];
+            re.s0 = x0.x; re.e0 = x0.y; re.sl = w.start; re.el = w.end;
+            // kept inner exons are at least min_exon >= 1 long; the first and the last one are kept whatever their length
+            sane = re.s0 <= re.e0 && re.sl <= re.el;
+        } else if (active) {
+            // a CIGAR beyond the register head, unusual thresholds, or a tile beyond the LDS capacity: the literal walk
             WalkState w{pos + 1, pos, 0};
             auto emit = [&](int k, int s, int e) {
-                if (in_lds && (uint32_t)k < room) { s_S[lub + (uint32_t)k] = s; s_E[lub + (uint32_t)k] = e; }
+                if (in_lds && (uint32_t)k < room) s_SE[lub + (uint32_t)k] = make_int2(s, e);
                 else over = true;
                 sane = sane & (s <= e);
                 re.sl = s; re.el = e;
             };
-#pragma unroll
-            for (int i = 0; i < FUSED_HEAD; ++i) walk_step(w, v.cg[i], p, emit);
-            if (n_cig > (uint32_t)FUSED_HEAD) walk_ops<false>(w, a->f.cig + c_lo, FUSED_HEAD, (int)n_cig, p, emit);
+            walk_ops<false>(w, a->f.cig + c_lo, 0, (int)n_cig, p, emit);
             emit(w.n, w.start, w.end);
             n = (uint32_t)w.n + 1u;
-            if (in_lds && !over) { re.s0 = s_S[lub]; re.e0 = s_E[lub]; }
+            if (in_lds && !over) { const int2 x0 = s_SE[lub]; re.s0 = x0.x; re.e0 = x0.y; }
         }
-        // the next tile's reads: fields and CIGAR heads (their order byte has had the walk to arrive)
-        if (has_next) v = fused_load_read(a, Tn, src_next);
-        __syncthreads();                 // every walk is done
+        // the next tile's CIGAR heads (its record fields were issued a tile ago), the order byte of the tile after it
+        if (has_next) fused_load_words(a, vn);
+        const int32_t src_n2 = has_next2 ? fused_src(u_order, Tn2, t_next2) : -1;
+        F_STAMP(0);
+        F_BARRIER();                     // every walk is done
         // ---- stage the dictionary slices, re-based to the tile's window
         int my_wide = 0;
         if (fast) {
@@ -397,25 +519,31 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
             }
         }
         if (my_wide) s_wide = 1;
-        __syncthreads();
+        F_STAMP(1);
+        F_BARRIER();
         const int any_wide = s_wide;
         // ---- phase 2: classification (the classic kernel's device functions; a read's slot range starts at `lub`)
         uint32_t info = n << 8; int ref = -1;
         bool redo = active && (!fast || !in_lds || over || any_wide != 0 || tid != d.tid || (n > 1 && !sane));
         const bool work = active && !redo;
-        const TileLds L{s_S, s_E, s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, tw->hk, tw->hx, tw->win};
+        const TileLds L{nullptr, nullptr, s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, tw->hk, tw->hx, tw->win};
         const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, tw->mask);
         redo = redo || vm.redo;
         // the next tile's span: upper bounds of its read ends (the registers loaded above), reduced over the workgroup
         if (has_next) {
-            const int m = wave_max((v.src >= 0 && v.tid == Tn.tid0) ? fused_end_bound(a, v) : INT32_MIN);
+            fused_mask_words(vn);
+            const int m = wave_max((vn.src >= 0 && vn.tid == Tn.tid0) ? fused_end_bound(a, vn) : INT32_MIN);
             if (lane == 0) s_wmax[wv] = m;
         }
-        __syncthreads();
+        F_STAMP(2);
+        F_BARRIER();
         // ... and its descriptor and window, by the last wave, into the other TileWin, while the others start probing
-        if (has_next && wv == TILE_THREADS / WAVE - 1)
+        if (has_next && wv == TILE_THREADS / WAVE - 1) {
+            const unsigned long long d0 = stamping ? __builtin_readcyclecounter() : 0ull;
             make_descriptor(a, lane, Tn.tid0, Tn.pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), Tn.in_lds, tw_next);
-        const SiteMasks sm = map_exons(L, d, work && !redo && n > 1, lub, n, vm.vpre);
+            if (stamping && lane == 0) atomicAdd(&a->f.stamps[(blockIdx.x & 1023u) * 8u + 7u], __builtin_readcyclecounter() - d0);
+        }
+        const SiteMasks sm = map_exons_se(L, s_SE, d, work && !redo && n > 1, lub, n, vm.vpre);
         if (work && !redo) {
             const Verdict vd = decide<LEVEL>(L, d, lub, n, re, vm, sm, rev_in);
             info = vd.info; ref = vd.ref;
@@ -433,7 +561,8 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
             }
         }
         if (active) s_nx[src] = n;
-        __syncthreads();
+        F_STAMP(3);
+        F_BARRIER();
         // ---- exact exon offsets in read order (one wave, four reads per lane) and the tile's chunk of the result arrays
         if (wv == 0) {
             const uint4 quad = *reinterpret_cast<const uint4 *>(s_nx + 4 * lane);
@@ -449,7 +578,7 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
                 a->tile_start[t] = (uint32_t)at; a->tile_total[t] = total;
             }
         }
-        __syncthreads();
+        F_BARRIER();
         const uint32_t base = s_base[0], tile_total = s_base[1];
         // a tile whose exons could not be kept in LDS (capacity), or a read beyond its bound: walked again, straight to HBM
         const bool direct = !in_lds;
@@ -468,20 +597,24 @@ void k_fused(FusedArgs kernarg_block /* read through fused_args() / fast_args() 
                 if (!direct) for (uint32_t k = 0; k < n; ++k) s_map[loc + k] = (uint16_t)0xffffu;       // (skipped by the copy below)
             }
         }
-        __syncthreads();
+        F_BARRIER();
         if (!direct) {
             int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end; uint8_t *const xf = a->f.ex_flag;
             for (uint32_t i = threadIdx.x; i < tile_total; i += TILE_THREADS) {
                 const uint32_t q = s_map[i];
                 if (q == 0xffffu) continue;
-                xs[base + i] = s_S[q];
-                xe[base + i] = s_E[q];
-                xf[base + i] = (uint8_t)s_W[q];
+                const int2 x = s_SE[q];
+                st32(xs, base + i, x.x);
+                st32(xe, base + i, x.y);
+                st32(xf, base + i, (uint8_t)s_W[q]);
             }
         }
-        __syncthreads();                 // the tile's LDS image has been written out; the next descriptor is complete
-        T = Tn; cur ^= 1;
+        F_STAMP(4);
+        F_BARRIER();                     // the tile's LDS image has been written out; the next descriptor is complete
+        T = Tn; Tn = Tn2; v = vn; src_n1 = src_n2; cur ^= 1;
     }
+#undef F_STAMP
+#undef F_BARRIER
 }
 
 // The result arrays of the fused pipeline, tile chunk by tile chunk, into read order (l2r_download): tile t's exons

@@ -1236,16 +1236,15 @@ __device__ __forceinline__ Verdict decide(const TileLds &L, const TileDesc &d, u
     // ---- flags: an exon / junction is no longer novel iff the first member of V' that has it comes no later than
     // j*; a known read has every probed donor and acceptor in transcript j*
     const uint32_t lim = known ? (uint32_t)jstar : 62u;
-    for (int k = 0; k < (int)n; ++k) {
-        uint32_t f = F_EXON;
-        if (n > 1) {
+    const uint32_t site_bits = known ? 0u : (uint32_t)(F_DON | F_ACC);         // bits 12, 13 of a work word: the site is in V' (F_DON = 2, F_ACC = 4)
+    if (n > 1) {
+        for (int k = 0; k < (int)n; ++k) {
             const uint32_t w = W[k];
-            f = ((w & 63u) > lim ? F_EXON : 0u) | (((w >> 6) & 63u) > lim ? F_JUNC : 0u);
-            if (!known) f |= (~w >> 11) & (uint32_t)(F_DON | F_ACC);          // bits 12, 13: the site is in V' (F_DON = 2, F_ACC = 4)
-            if (k + 1 == (int)n) f &= F_EXON;
+            uint32_t f = ((w & 63u) > lim ? (uint32_t)F_EXON : 0u) | (((w >> 6) & 63u) > lim ? (uint32_t)F_JUNC : 0u) | ((~w >> 11) & site_bits);
+            f &= (k + 1 == (int)n) ? (uint32_t)F_EXON : 0xffu;                   // the last exon has no junction behind it
+            W[k] = (uint16_t)f;
         }
-        W[k] = (uint16_t)f;
-    }
+    } else W[0] = (uint16_t)F_EXON;
     int ref = -1;
     bool out_rev = rev_in;
     if (jref >= 0) { ref = L.win[jref]; out_rev = ((L.hk[jref].w >> 8) & 1) != 0; }     // :825-831

@@ -12,6 +12,7 @@ af, reads = workload.make_rank_workload(cfg, 0, 1)
 e = capi.Engine(0)
 e.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
 e.set_params(capi.default_params(full_level=int(os.environ.get("L2R_LEVEL", "3")), ss_dis=int(os.environ.get("L2R_DIS", "0"))))
+e.set_outputs(int(os.environ.get("L2R_WANT", "1")))          # 1 = per-read results (what bench.py times), 3 = + accepted list
 e.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)
 lib = capi.load_library()
 out = (C.c_ulonglong * 16)()
@@ -26,6 +27,8 @@ if os.environ.get("L2R_STAMPS"):
     tot = sum(v) or 1
     tot = sum(v[:8]) or 1
     print("stamps (cycles of thread 0 summed over tiles):", [(i, x, round(100.0 * x / tot, 1)) for i, x in enumerate(v[:8]) if x])
+    print("  classic kernel: 0 CIGAR staging 7 walk 1 dictionary staging 2 window pass 3 probes 4 verdicts 5 counts 6 write-out")
+    print("  one-walk kernel: 0 walk 1 staging 2 window pass + next span 3 probes + verdicts 4 offsets/map/write-out | 5 barrier waits of wave 0, 6 of the last wave, 7 descriptor work of the last wave (5-7 are not phases: compare with the sum of 0-4)")
     print("redo reasons [not fast, not in LDS, wide, other tid, not sane, window/compact]:", v[8:14])
 cnt = (C.c_longlong * 12)()
 lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
