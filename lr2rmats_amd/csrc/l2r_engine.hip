@@ -14,7 +14,7 @@
 #include "../../include/lr2rmats_hip.h"
 #include "l2r_kernels.hip.h"
 #include "l2r_fused.hip.h"
-#include "l2r_split.hip.h"
+#include "l2r_slab.hip.h"
 
 using namespace l2r;
 
@@ -61,10 +61,14 @@ struct l2r_ctx {
     bool wide_cigar = false;                // long CIGARs: the HBM walks fetch 16 words per lane and round (l2r_upload_reads decides)
     int n_cu = 256, wg_per_cu = 4;          // persistent grid of k_classify_fast (L2R_WG_PER_CU overrides)
     int ablate = 0;                         // diagnostics, L2R_ABLATE (read once, at l2r_create)
-    int want_pipeline = 1;                  // L2R_PIPELINE: classic (0: two walks), fused (1, default: l2r_fused.hip.h), split (2: l2r_split.hip.h, measured slower)
+    int want_pipeline = 2;                  // L2R_PIPELINE: classic (0: two walks), fused (1: l2r_fused.hip.h), slab (2, default: l2r_slab.hip.h)
     bool fused = false;                     // the current upload runs a one-walk pipeline: sorted input, short CIGARs
-    bool split = false;                     // ... the two-kernel form of it (k_walk + k_probe)
-    DevBuf<TileWin> tw;                     // split: descriptor + window per tile
+    bool slab_ok = false;                   // ... and its slab layout fits (l2r_slab.hip.h); slab = the last launch used it
+    bool slab = false;
+    DevBuf<uint32_t> tile_sbase, tile_rows, lin_dest;
+    DevBuf<int32_t> tile_thi;
+    DevBuf<unsigned long long> ovf_cursor;
+    uint32_t ovf_base = 0;
     DevBuf<uint16_t> lub;                   // k_order: first LDS slot of every read
     DevBuf<uint32_t> tile_ub, tile_start, tile_total, tile_dest;
     DevBuf<int32_t> lin_start, lin_end;     // l2r_download of a fused run: the exon arrays in read order (k_linearize)
@@ -193,7 +197,7 @@ l2r_ctx *l2r_create(int device)
         e = getenv("L2R_ABLATE");
         c->ablate = e ? atoi(e) : 0;
         e = getenv("L2R_PIPELINE");
-        if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : !strcmp(e, "split") ? 2 : 1;
+        if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : !strcmp(e, "fused") ? 1 : 2;
     }
     return c;
 }
@@ -211,7 +215,8 @@ void l2r_destroy(l2r_ctx *c)
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->lub.release(); c->tile_ub.release(); c->tile_start.release(); c->tile_total.release(); c->tile_dest.release();
-    c->lin_start.release(); c->lin_end.release(); c->lin_flag.release(); c->tw.release();
+    c->lin_start.release(); c->lin_end.release(); c->lin_flag.release();
+    c->tile_sbase.release(); c->tile_rows.release(); c->lin_dest.release(); c->tile_thi.release(); c->ovf_cursor.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -611,8 +616,33 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb) || (c->wide_cigar && c->walked.ensure((size_t)(c->n_tiles + 1) * LDS_EXON_CAP))) return -2;
     c->ex_cap = (int64_t)exb;
     c->fused = c->want_pipeline > 0 && sorted && !c->wide_cigar;
-    c->split = c->fused && c->want_pipeline == 2;
-    if (c->split && c->tw.ensure((size_t)c->n_tiles + 1)) return -2;
+    c->slab_ok = false; c->slab = false;
+    if (c->fused && c->want_pipeline == 2) {
+        // the slab layout (l2r_slab.hip.h): per tile as many rows of 256 elements as its longest read can have exons (bound from
+        // the CIGAR lengths); reads beyond SLAB_ROWS rows are outliers and get a run of the dense area behind the slabs
+        const size_t T = (size_t)c->n_tiles;
+        std::vector<uint32_t> rows(T + 1, 1u), sbase(T + 1, 0u);
+        uint64_t total = 0, ovf = 0;
+        for (size_t t = 0; t < T; ++t) {
+            uint32_t m = 1;
+            for (uint32_t i = tile_first[t]; i < tile_first[t + 1]; ++i) {
+                const uint64_t cc = (uint64_t)(r->cig_off[i + 1] - r->cig_off[i]);
+                const uint64_t rw = (cc + 3u) >> 1;
+                if (rw > (uint64_t)SLAB_ROWS) ovf += cc + 1; else m = std::max<uint32_t>(m, (uint32_t)rw);
+            }
+            rows[t] = m; sbase[t] = (uint32_t)total; total += (uint64_t)m * SLAB_STRIDE;
+            if (total + ovf >= 0x7ffffff0ULL) break;
+        }
+        if (total + ovf < 0x7ffffff0ULL) {
+            c->slab_ok = true; c->ovf_base = (uint32_t)total;
+            if (c->tile_sbase.ensure(T + 1) || c->tile_rows.ensure(T + 1) || c->tile_thi.ensure(T + 1) || c->ovf_cursor.ensure(1) ||
+                c->ex_start.ensure(std::max<size_t>(exb, total + ovf)) || c->ex_end.ensure(std::max<size_t>(exb, total + ovf)) ||
+                c->ex_flag.ensure(std::max<size_t>(exb, total + ovf))) return -2;
+            HIP_TRY(hipMemcpyAsync(c->tile_sbase.p, sbase.data(), (T + 1) * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->tile_rows.p, rows.data(), (T + 1) * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));       // (locals)
+        }
+    }
     if (c->fused && (c->lub.ensure((size_t)N + 1) || c->tile_ub.ensure((size_t)c->n_tiles + 1) || c->tile_start.ensure((size_t)c->n_tiles + 1) ||
                      c->tile_total.ensure((size_t)c->n_tiles + 1) || c->tile_dest.ensure((size_t)c->n_tiles + 1))) return -2;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -735,20 +765,25 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     if (c->fused) {
         // ---- the one-walk pipeline (l2r_fused.hip.h): k_order, then the persistent k_fused
         unsigned long long *const ex_cursor = (unsigned long long *)(c->totals.p + 6);
+        // the slab form wants the straight-line walk: min_exon >= 1 and thresholds that fit a CIGAR word (else: k_fused)
+        c->slab = c->slab_ok && p.min_exon >= 1 && p.min_intron >= 0 && p.min_intron < (1 << 28) && p.max_delet >= -1 && p.max_delet < (1 << 28) - 1;
         hipLaunchKernelGGL(k_order, dim3(gt), dim3(TILE_THREADS), 0, s, (const int64_t *)c->cig_off.p, (const uint32_t *)c->tile_first.p, p,
-                           c->order.p, c->lub.p, c->tile_ub.p, c->totals.p + 3, ex_cursor);
+                           c->order.p, c->lub.p, c->tile_ub.p, c->totals.p + 3, ex_cursor,
+                           (c->slab ? c->tile_thi.p : (int32_t *)nullptr), (c->slab ? c->ovf_cursor.p : (unsigned long long *)nullptr),
+                           (c->slab ? c->tile_total.p : (uint32_t *)nullptr));
         MARK(ST_SCAN1);
         FusedArgs ga;
         ga.f = fa; ga.cd = cd; ga.tid_base = c->tid_base.p; ga.n_tid_dir = c->n_tid_dir; ga.lub = c->lub.p; ga.tile_ub = c->tile_ub.p;
         ga.tile_start = c->tile_start.p; ga.tile_total = c->tile_total.p; ga.ex_cursor = ex_cursor;
-        if (c->split) {
-            // ---- two kernels: the walk (exons to HBM), then the probes at full occupancy (l2r_split.hip.h)
-            SplitArgs sa; sa.g = ga; sa.tw = c->tw.p;
-            hipLaunchKernelGGL(k_walk, dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, (const uint8_t *)c->order.p,
-                               (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_ub.p);
+        if (c->slab) {
+            // ---- two light kernels at high occupancy: the walk (exons into the tiles' slabs), then the probes (l2r_slab.hip.h)
+            SlabArgs sa; sa.g = ga; sa.tile_sbase = c->tile_sbase.p; sa.tile_rows = c->tile_rows.p; sa.tile_thi = c->tile_thi.p;
+            sa.ovf_cursor = c->ovf_cursor.p; sa.ovf_base = c->ovf_base;
+            hipLaunchKernelGGL(k_walk_slab, dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, (const uint8_t *)c->order.p,
+                               (const int32_t *)c->r_tid.p, (const uint32_t *)c->tile_sbase.p);
             MARK(ST_FAST);
-#define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe<L>), dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
-                (const uint8_t *)c->order.p, (const uint32_t *)c->tile_start.p, (const uint32_t *)c->tile_total.p)
+#define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L>), dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
+                (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_rows.p, (const int32_t *)c->tile_thi.p)
             switch (p.full_level) {
             case 1: launch_probe_level(1); break;
             case 2: launch_probe_level(2); break;
@@ -801,20 +836,22 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         }
     }
     }
+    const bool slab_now = c->fused && c->slab;
+    const uint32_t ex_stride = slab_now ? SLAB_STRIDE : 1u;
     MARK(ST_GENERIC);
     {
         const unsigned gg = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles * 4 : 1, 4096);      // one wave per listed read, grid-stride
         hipLaunchKernelGGL(k_classify_generic, dim3(gg), dim3(TILE_THREADS), 0, s, c->totals.p + 3, c->redo.p, c->r_tid.p, c->r_rev.p,
                            (c->fused ? (const int32_t *)nullptr : j0),
                            c->hdr.p, c->anno_ex.p, p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->info.p, c->ref_tx.p,
-                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles, cd);
+                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles, cd, ex_stride);
     }
     MARK(ST_SJ);
     if (c->n_sj > 0) {
         if (!c->sorted) { int rc = prepare_unsorted_sj_cursor(c); if (rc) return rc; }
         hipLaunchKernelGGL(k_validate_sj, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p,
                            c->sj_key.p, (c->sorted ? (const int32_t *)nullptr : c->sj_cursor.p), c->sj_tid.p, c->sj_don.p, c->sj_acc.p,
-                           c->sj_uniq.p, c->sj_multi.p, p, c->info.p);
+                           c->sj_uniq.p, c->sj_multi.p, p, c->info.p, ex_stride);
     }
     if ((c->n_sj > 0 || c->fused) && (c->want & L2R_WANT_ACCEPTED)) {
         // acceptance is decided by the junction check (and the one-walk pipeline counts nothing itself): count per tile
@@ -829,7 +866,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     if (c->want & L2R_WANT_ACCEPTED)
     hipLaunchKernelGGL(k_gather_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->first_read, c->info.p, c->ref_tx.p, c->ex_off.p,
                        c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->tile_acc.p, c->tile_acc_ex.p, c->tile_chunk.p, c->tile_rchunk.p, c->totals.p + 4,
-                       c->acc_rec.p, c->acc_ex_off.p, c->acc_start.p, c->acc_end.p, c->acc_flag.p);
+                       c->acc_rec.p, c->acc_ex_off.p, c->acc_start.p, c->acc_end.p, c->acc_flag.p,
+                       (slab_now ? (const uint32_t *)c->tile_sbase.p : (const uint32_t *)nullptr), ex_stride);
     MARK(ST_N);
 #undef MARK
     HIP_TRY(hipGetLastError());
@@ -913,6 +951,14 @@ static int fetch_totals(l2r_ctx *c)
     HIP_TRY(hipMemcpyAsync(dev, c->totals.p, sizeof dev, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->fused) dev[0] = dev[6];                       // the one-walk pipeline's exon cursor (a shard has < 2^32 exons)
+    if (c->fused && c->slab) {                           // the slab pipeline counts per tile
+        std::vector<uint32_t> tot((size_t)c->n_tiles);
+        if (c->n_tiles) HIP_TRY(hipMemcpyAsync(tot.data(), c->tile_total.p, (size_t)c->n_tiles * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        uint64_t sum = 0;
+        for (uint32_t v : tot) sum += v;
+        dev[0] = (uint32_t)sum;
+    }
     // accepted exons = the chunks the classification kernel placed itself (cursor) + the ones k_gather_accepted placed
     c->h_totals[0] = dev[0]; c->h_totals[1] = dev[1] + dev[5]; c->h_totals[2] = dev[2] + dev[4];
     if (!(c->want & L2R_WANT_ACCEPTED)) c->h_totals[1] = c->h_totals[2] = 0;
@@ -975,7 +1021,20 @@ int l2r_download(l2r_ctx *c, l2r_result *res)
     if (res->n_reads < N || res->ex_cap < X) return fail(-3, "[l2r_download] buffers too small: need %lld reads, %lld exons", (long long)N, (long long)X);
     std::vector<uint32_t> off((size_t)N);
     const int32_t *xs = c->ex_start.p, *xe = c->ex_end.p; const uint8_t *xf = c->ex_flag.p;
-    if (c->fused && X) {
+    if (c->fused && c->slab && X) {
+        // the slab pipeline (l2r_slab.hip.h): read order = running sum of the exon counts, made on the device; k_linearize_slab
+        // gathers every read's column into its place (HBM speed, ahead of the PCIe copy)
+        if (c->lin_dest.ensure((size_t)N + 1) || c->lin_start.ensure((size_t)X) || c->lin_end.ensure((size_t)X) || c->lin_flag.ensure((size_t)X)) return -2;
+        const unsigned gN = (unsigned)((N + TILE_THREADS - 1) / TILE_THREADS);
+        hipLaunchKernelGGL(k_exon_counts, dim3(gN), dim3(TILE_THREADS), 0, c->stream, N, (const uint32_t *)c->info.p, c->lin_dest.p);
+        ScanJobs jobs; jobs.job[0] = ScanJob{c->lin_dest.p, N, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, jobs);
+        hipLaunchKernelGGL(k_linearize_slab, dim3(gN), dim3(TILE_THREADS), 0, c->stream, N, (const uint32_t *)c->ex_off.p, (const uint32_t *)c->info.p,
+                           (const uint32_t *)c->lin_dest.p, (const int32_t *)c->ex_start.p, (const int32_t *)c->ex_end.p, (const uint8_t *)c->ex_flag.p,
+                           c->lin_start.p, c->lin_end.p, c->lin_flag.p);
+        HIP_TRY(hipGetLastError());
+        xs = c->lin_start.p; xe = c->lin_end.p; xf = c->lin_flag.p;
+    } else if (c->fused && X) {
         // the one-walk pipeline leaves the exon arrays as one chunk per tile, chunks in the order an atomic cursor handed
         // them out (l2r_fused.hip.h): k_linearize copies them into read order on the device (HBM speed, ahead of the PCIe copy)
         const size_t T = (size_t)c->n_tiles;

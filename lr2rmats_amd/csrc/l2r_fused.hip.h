@@ -36,9 +36,16 @@ __device__ __forceinline__ uint32_t exon_bound(uint32_t c, int min_exon)
 __global__ __launch_bounds__(TILE_THREADS)
 void k_order(const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ tile_first, DevParams p,
              uint8_t *__restrict__ order_out, uint16_t *__restrict__ lub_out, uint32_t *__restrict__ tile_ub,
-             uint32_t *__restrict__ redo_count /* [3]: redo list, chunk cursor of the accepted list */, unsigned long long *__restrict__ ex_cursor)
+             uint32_t *__restrict__ redo_count /* [3]: redo list, chunk cursor of the accepted list */, unsigned long long *__restrict__ ex_cursor,
+             int32_t *__restrict__ tile_thi /* slab pipeline: the tile's largest read end (atomicMax of k_walk_slab), else null */,
+             unsigned long long *__restrict__ ovf_cursor /* slab pipeline: dense area of the outliers */,
+             uint32_t *__restrict__ tile_total /* slab pipeline: exon count per tile (atomicAdd of k_walk_slab), else null */)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { redo_count[0] = 0u; redo_count[1] = 0u; redo_count[2] = 0u; *ex_cursor = 0ull; }    // the kernels that use them run after this one
+    if (blockIdx.x == 0 && threadIdx.x == 0) {       // the kernels that use these run after this one
+        redo_count[0] = 0u; redo_count[1] = 0u; redo_count[2] = 0u; *ex_cursor = 0ull;
+        if (ovf_cursor) *ovf_cursor = 0ull;
+    }
+    if (tile_thi && threadIdx.x == 0) { tile_thi[blockIdx.x] = INT32_MIN; tile_total[blockIdx.x] = 0u; }
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_hist[WAVE];
     if (threadIdx.x < WAVE) s_hist[threadIdx.x] = 0u;
@@ -221,7 +228,6 @@ __device__ __forceinline__ SiteMasks map_exons_se(const TileLds &L, const int2 *
     if (mapping) { const int2 x = SE[local]; s = x.x; e = x.y; }
     const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
     const int k_max = wave_max(mapping ? (int)n : 0);
-#pragma unroll 2
     for (int k = 0; k < k_max; ++k) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
         const uint32_t is = min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none);

@@ -92,6 +92,16 @@ struct TileDesc {
     uint32_t en_r0, en_nk;     // END entries
     uint32_t flags, n_win;     // n_win: transcripts in the tile's window (win_hdr[tile * WIN_TX + 0 .. n_win))
 };
+// Exon addressing of the kernels behind the classification.  Dense result arrays (classic / fused pipelines): exon k of a read
+// at ex_off + k.  Slab pipeline (l2r_slab.hip.h, ex_stride = 256): at ex_off + k * 256, except outliers whose ex_off carries
+// the DENSE flag (bit 31) and which lie at stride 1.
+constexpr uint32_t EX_DENSE_FLAG = 0x80000000u;
+struct ExRun { uint32_t off, stride; };
+__device__ __forceinline__ ExRun ex_run(uint32_t raw_off, uint32_t ex_stride)
+{
+    if (ex_stride != 1u && (raw_off & EX_DENSE_FLAG)) return ExRun{raw_off & ~EX_DENSE_FLAG, 1u};
+    return ExRun{raw_off, ex_stride};
+}
 constexpr uint32_t CHUNK_DEFERRED = 0xffffffffu;   // tile_chunk: the tile's accepted exons are compacted by k_gather_accepted
 constexpr uint32_t TD_FAST = 1;    // exons fit the LDS tile, dictionary slices fit DIR_CAP / KEY_CAP, window fits WIN_TX
 constexpr uint32_t TD_WALKED = 4;  // long-CIGAR input: pass A has left the tile's exons in `walked` (tile * LDS_EXON_CAP + in-tile offset)
@@ -690,7 +700,7 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
                         const uint32_t *__restrict__ ex_off, const int32_t *__restrict__ ex_start, const int32_t *__restrict__ ex_end,
                         uint8_t *__restrict__ ex_flag, uint32_t *__restrict__ info_io, int32_t *__restrict__ ref_out,
                         uint32_t *__restrict__ tile_acc, uint32_t *__restrict__ tile_acc_ex, const uint32_t *__restrict__ tile_first, int n_tiles,
-                        CursorDir cd /* used when j0_arr is null: the one-walk pipeline keeps no per-read cursor values */)
+                        CursorDir cd /* used when j0_arr is null: the one-walk pipeline keeps no per-read cursor values */, uint32_t ex_stride)
 {
     __shared__ int g_S[GEN_WAVES][GEN_CAP];
     __shared__ int g_E[GEN_WAVES][GEN_CAP];
@@ -703,19 +713,21 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
     for (uint32_t i = blockIdx.x * GEN_WAVES + wv; i < cnt; i += gridDim.x * GEN_WAVES) {
         const uint32_t r = redo[i];
         const int n = (int)(info_io[r] >> 8);
-        const uint32_t off = ex_off[r];
+        const ExRun xr = ex_run(ex_off[r], ex_stride);
+        const uint32_t off = xr.off, st = xr.stride;
         const int tid = r_tid[r];
         const int j0 = j0_arr ? j0_arr[r] : cursor_value(cd, tid, ex_start[off]);        // (the first exon starts at pos + 1)
         const bool rev = r_rev[r] != 0;
         Verdict v{0u, -1};
         if (n > GEN_CAP) {
+            // (a read this long is dense in every layout: the slab pipeline stores reads beyond SLAB_ROWS exons at stride 1)
             if (lane == 0) v = sweep_literal(ex_start + off, ex_end + off, ex_flag + off, n, tid, rev, j0, hdr, anno_ex, p);
         } else {
             for (int k = lane; k < n; k += WAVE) {
-                S[k] = ex_start[off + k]; E[k] = ex_end[off + k];
+                S[k] = ex_start[off + (uint32_t)k * st]; E[k] = ex_end[off + (uint32_t)k * st];
                 F[k] = (k + 1 < n) ? (uint32_t)(F_EXON | F_DON | F_ACC | F_JUNC) : (uint32_t)F_EXON;
             }
-            const ReadEnds re{ex_start[off], ex_end[off], ex_start[off + n - 1], ex_end[off + n - 1]};
+            const ReadEnds re{ex_start[off], ex_end[off], ex_start[off + (uint32_t)(n - 1) * st], ex_end[off + (uint32_t)(n - 1) * st]};
             const int r_start = re.s0, r_end = re.el, dis = p.ss_dis, level = p.full_level;
             bool lfull = false, rfull = false, lnoth = true, rnoth = true, known = false, ksite = false;
             int ref = -1, ref_rev = 0;
@@ -802,7 +814,7 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
             if (full_decision(level, lfull, lnoth, rfull, rnoth)) info |= I_FULL;
             if (out_rev) info |= I_REV;
             v = Verdict{finish_info(info, n, p), ref};
-            for (int k = lane; k < n; k += WAVE) ex_flag[off + k] = (uint8_t)F[k];
+            for (int k = lane; k < n; k += WAVE) ex_flag[off + (uint32_t)k * st] = (uint8_t)F[k];
         }
         if (lane == 0) {
             info_io[r] = v.info;
@@ -1193,7 +1205,7 @@ __device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc 
 }
 
 // Known / known site / reference transcript / full-length / flag bytes of one read from its masks.
-template <int LEVEL>
+template <int LEVEL, int STRIDE = 1>             // STRIDE: elements between the work words of consecutive exons (slab pipeline: 256)
 __device__ __forceinline__ Verdict decide(const TileLds &L, const TileDesc &d, uint32_t local, uint32_t n, const ReadEnds &re,
                                           const VisitMasks &vm, const SiteMasks &sm, bool rev_in)
 {
@@ -1239,10 +1251,10 @@ __device__ __forceinline__ Verdict decide(const TileLds &L, const TileDesc &d, u
     const uint32_t site_bits = known ? 0u : (uint32_t)(F_DON | F_ACC);         // bits 12, 13 of a work word: the site is in V' (F_DON = 2, F_ACC = 4)
     if (n > 1) {
         for (int k = 0; k < (int)n; ++k) {
-            const uint32_t w = W[k];
+            const uint32_t w = W[k * STRIDE];
             uint32_t f = ((w & 63u) > lim ? (uint32_t)F_EXON : 0u) | (((w >> 6) & 63u) > lim ? (uint32_t)F_JUNC : 0u) | ((~w >> 11) & site_bits);
             f &= (k + 1 == (int)n) ? (uint32_t)F_EXON : 0xffu;                   // the last exon has no junction behind it
-            W[k] = (uint16_t)f;
+            W[k * STRIDE] = (uint16_t)f;
         }
     } else W[0] = (uint16_t)F_EXON;
     int ref = -1;
@@ -1631,15 +1643,16 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
                    const int64_t *__restrict__ sj_key, const int32_t *__restrict__ sj_cursor,
                    const int32_t *__restrict__ sj_tid, const int32_t *__restrict__ sj_don, const int32_t *__restrict__ sj_acc,
                    const int32_t *__restrict__ sj_uniq, const int32_t *__restrict__ sj_multi, DevParams p,
-                   uint32_t *__restrict__ info_io)
+                   uint32_t *__restrict__ info_io, uint32_t ex_stride)
 {
     const int64_t r = (int64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
     if (r >= n_reads) return;
     uint32_t info = info_io[r];
     if ((info & (I_FULL | I_KNOWN | I_KSITE)) != (I_FULL | I_KSITE)) return;
     const int n = (int)(info >> 8), tid = r_tid[r];
-    const uint32_t off = ex_off[r];
-    const int r_start = ex_start[off], r_end = ex_end[off + n - 1];
+    const ExRun xr = ex_run(ex_off[r], ex_stride);
+    const uint32_t off = xr.off, st = xr.stride;
+    const int r_start = ex_start[off], r_end = ex_end[off + (uint32_t)(n - 1) * st];
     const int from = sj_cursor ? sj_cursor[r] : first_key_above(sj_key, p.n_sj, pack_key(tid, r_start));
     bool ok = false;
     if (from < p.n_sj) {
@@ -1648,10 +1661,10 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
         if (!(t > tid || (t == tid && sj_don[from] >= r_end))) {
             ok = true;
             for (int j = 0; j + 1 < n; ++j) {
-                const uint8_t f = ex_flag[off + j];
+                const uint8_t f = ex_flag[off + (uint32_t)j * st];
                 if ((f & F_JUNC) &&
-                    !junction_supported(tid, ex_end[off + j] + 1, ex_start[off + j + 1] - 1, from, sj_tid, sj_don, sj_acc, sj_uniq, sj_multi, p)) {
-                    ex_flag[off + j] = f | F_UNREL;
+                    !junction_supported(tid, ex_end[off + (uint32_t)j * st] + 1, ex_start[off + (uint32_t)(j + 1) * st] - 1, from, sj_tid, sj_don, sj_acc, sj_uniq, sj_multi, p)) {
+                    ex_flag[off + (uint32_t)j * st] = f | F_UNREL;
                     ok = false;
                 }
             }
@@ -1704,7 +1717,8 @@ void k_gather_accepted(const uint32_t *__restrict__ tile_first, int64_t first_re
                        const uint8_t *__restrict__ ex_flag, const uint32_t *__restrict__ tile_reads, const uint32_t *__restrict__ tile_exons,
                        uint32_t *__restrict__ tile_chunk, uint32_t *__restrict__ tile_rchunk, const uint32_t *__restrict__ chunk_cursor /* {exons, records} */,
                        AccRec *__restrict__ rec, uint32_t *__restrict__ acc_ex_off, int32_t *__restrict__ acc_start,
-                       int32_t *__restrict__ acc_end, uint8_t *__restrict__ acc_flag)
+                       int32_t *__restrict__ acc_end, uint8_t *__restrict__ acc_flag,
+                       const uint32_t *__restrict__ tile_sbase /* slab pipeline: first element of the tile's slab, else null */, uint32_t ex_stride)
 {
     __shared__ uint32_t s_wcnt[4], s_wex[4];
     __shared__ uint16_t s_map[LDS_EXON_CAP];
@@ -1726,24 +1740,25 @@ void k_gather_accepted(const uint32_t *__restrict__ tile_first, int64_t first_re
     if (threadIdx.x == 0) { tile_chunk[blockIdx.x] = ebase0; tile_rchunk[blockIdx.x] = cbase0; }
     uint32_t cb = 0, eb = 0;
     for (int k = 0; k < wv; ++k) { cb += s_wcnt[k]; eb += s_wex[k]; }
-    const uint32_t src0 = n_act ? ex_off[r0] : 0u;                            // first exon of the tile
+    const uint32_t src0 = tile_sbase ? tile_sbase[blockIdx.x] : (n_act ? ex_off[r0] : 0u);      // first exon of the tile / first element of its slab
     const uint32_t e_loc = eb + inc - nex;                                    // tile-local compacted exon offset
     const bool mapped = e_tot <= (uint32_t)LDS_EXON_CAP;
     if (acc) {
-        const uint32_t src = ex_off[r];
+        const ExRun xr = ex_run(ex_off[r], ex_stride);
+        const uint32_t src = xr.off, st = xr.stride;
         const uint32_t slot = cbase0 + cb + rank_w;
         const uint64_t gidx = (uint64_t)(first_read + r);
         AccRec a; a.read_lo = (uint32_t)gidx; a.read_hi = (uint32_t)(gidx >> 32); a.info = w; a.ref_tx = ref_tx[r];
         rec[slot] = a;
         acc_ex_off[slot] = ebase0 + e_loc;
-        if (mapped && src - src0 + nex < MAP_DIRECT) {
-            for (uint32_t k = 0; k < nex; ++k) s_map[e_loc + k] = (uint16_t)(src - src0 + k);
+        if (mapped && src >= src0 && (uint64_t)(src - src0) + (uint64_t)nex * st < MAP_DIRECT) {
+            for (uint32_t k = 0; k < nex; ++k) s_map[e_loc + k] = (uint16_t)(src - src0 + k * st);
         } else {
             for (uint32_t k = 0; k < nex; ++k) {
                 if (mapped) s_map[e_loc + k] = (uint16_t)MAP_DIRECT;
-                acc_start[ebase0 + e_loc + k] = ex_start[src + k];
-                acc_end[ebase0 + e_loc + k] = ex_end[src + k];
-                acc_flag[ebase0 + e_loc + k] = ex_flag[src + k];
+                acc_start[ebase0 + e_loc + k] = ex_start[src + k * st];
+                acc_end[ebase0 + e_loc + k] = ex_end[src + k * st];
+                acc_flag[ebase0 + e_loc + k] = ex_flag[src + k * st];
             }
         }
     }

@@ -1,0 +1,320 @@
+// l2r_slab.hip.h -- the one-walk pipeline as TWO light kernels that both run at (nearly) full occupancy (gfx950).
+//
+// Measured on MI355X (profiles/r02): one wave issues an instruction every 13-18 cycles in these kernels whatever is done to
+// its instruction count -- they are bound by the latency of a wave's dependent instruction chains -- and a SIMD's issue
+// rate grows with its resident waves up to 8 (ubench_valu_issue.txt).  k_classify_fast / k_fused keep a tile's exons in
+// LDS (10 bytes each, 40 KB per workgroup): 4 waves per SIMD.  Here the exons go through HBM in a layout that both
+// sides touch with full 256- / 512-byte rows, and neither kernel needs them in LDS:
+//
+//   k_order (l2r_fused.hip.h)   the tile's reads by falling CIGAR length = the SLOT of every read (lane order of both kernels)
+//   k_walk_slab     one lane per read, CIGAR words in registers, ONE walk; exon k of the read in slot s goes to
+//                   element k * 256 + s of the tile's SLAB of the result arrays (row k = exon k of all reads of the
+//                   tile: a wave stores whole rows); read ends -> the tile's span.  No LDS, no barrier.
+//   k_probe_slab    per tile: one wave makes the descriptor and window (make_descriptor), the dictionary slices are
+//                   staged in LDS (21 KB with the per-exon work words: 7 workgroups per CU, <= 64 VGPRs); every lane
+//                   reads its exons back row by row (coalesced), window pass, probes, verdicts with the device functions
+//                   of the classic kernel; flag bytes go to the slab of ex_flag.
+//
+// The result arrays are slabs: ex_off[r] = element of exon 0, exon k at ex_off[r] + k * 256.  A tile's slab has as many rows
+// as its longest read can have exons (upper bound from the CIGAR lengths, at most SLAB_ROWS); reads beyond that bound
+// ("outliers") are walked literally into a dense area behind the slabs (ex_off | EXOFF_DENSE, stride 1) and classified
+// by the generic kernel.  l2r_download() turns slabs into read order (k_linearize_slab).
+// HBM traffic: CIGAR once, exons written once and read once.
+#pragma once
+#include "l2r_fused.hip.h"
+
+namespace l2r {
+
+constexpr int SLAB_ROWS = 24;                            // rows of a tile's slab at most (exons of its longest read it can hold)
+constexpr uint32_t SLAB_STRIDE = TILE_THREADS;           // elements between exon k and exon k + 1 of a read
+constexpr uint32_t EXOFF_DENSE = EX_DENSE_FLAG;          // ex_off flag (slab pipeline only): exons at stride 1
+constexpr uint32_t I_PRE_INSANE = I_UNREL;               // k_walk_slab -> k_probe_slab, in info[]: first or last exon empty
+constexpr uint32_t I_PRE_DIRECT = I_SJCHK;               // ... an outlier: its exons are in the dense area, the generic kernel classifies it
+
+// c ops -> is the read an outlier of the slab layout?  (exon_bound with min_exon >= 1, the only case this pipeline takes)
+__host__ __device__ __forceinline__ uint32_t slab_rows_of(uint32_t c) { return (c + 3u) >> 1; }
+
+struct SlabArgs {
+    FusedArgs g;
+    const uint32_t *tile_sbase;                          // first element of every tile's slab
+    const uint32_t *tile_rows;                           // rows of every tile's slab
+    int32_t *tile_thi;                                   // largest read end of every tile (k_walk_slab, atomicMax)
+    unsigned long long *ovf_cursor; uint32_t ovf_base;   // dense area behind the slabs for outliers
+};
+typedef const __attribute__((address_space(4))) SlabArgs *SlabArgsK;
+__device__ __forceinline__ SlabArgsK slab_args()
+{
+    SlabArgsK q = (SlabArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return q;
+}
+
+__global__ __launch_bounds__(TILE_THREADS, 8)
+void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint8_t *__restrict__ u_order,
+                 const int32_t *__restrict__ u_tid, const uint32_t *__restrict__ u_tile_sbase)
+{
+    (void)kernarg_block;
+    const SlabArgsK sa = slab_args();
+    const FusedArgsK a = fused_args();
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t t = blockIdx.x;
+    FusedTile T;
+    T.r0 = u_tile_first[t]; T.n_act = u_tile_first[t + 1u] - T.r0;
+    T.tid0 = T.n_act ? u_tid[T.r0] : 0; T.pos0 = 0; T.in_lds = true;
+    const uint32_t sbase = u_tile_sbase[t];
+    const int32_t src = threadIdx.x < T.n_act ? (int32_t)ld32(u_order, T.r0 + threadIdx.x) : -1;
+    FusedRead v;
+    fused_load_fields(a, T, src, v);
+    fused_load_words(a, v);
+    fused_mask_words(v);
+    const bool active = src >= 0;
+    const uint32_t r = T.r0 + (uint32_t)max(src, 0);
+    DevParams p;
+    p.min_exon = a->f.p.min_exon; p.min_intron = a->f.p.min_intron; p.max_delet = a->f.p.max_delet;
+    const uint32_t t3 = ((uint32_t)p.min_intron << 4) | 3u, t2 = ((uint32_t)(p.max_delet + 1) << 4) | 2u;
+    const bool outlier = slab_rows_of(v.n_cig) > (uint32_t)SLAB_ROWS;
+    const int c_max = wave_max((active && !outlier) ? (int)min(v.n_cig, (uint32_t)FUSED_HEAD) : 0);
+    int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end;
+    uint32_t n = 0u, off = 0u;
+    int el = INT32_MIN;
+    bool sane = true;
+    if (active && !outlier) {
+        // one lane per read; exon k lands in row k of the tile's slab, at the read's slot
+        off = sbase + threadIdx.x;
+        int start = v.pos + 1, end = v.pos;
+        int s0 = 0, e0 = 0;
+        bool first = true;
+        auto step = [&](uint32_t c) {
+            const uint32_t op = c & 0xfu;
+            const int len = (int)(c >> 4);
+            const bool cut = ((op == 3u) & (c >= t3)) | ((op == 2u) & (c >= t2));
+            const bool keep = cut & (first | (end - start >= p.min_exon - 1));
+            if (keep) {
+                st32(xs, off + n * SLAB_STRIDE, start); st32(xe, off + n * SLAB_STRIDE, end);
+                if (first) { s0 = start; e0 = end; }
+                first = false; ++n;
+            }
+            start = cut ? end + len + 1 : start;
+            end += len & __builtin_amdgcn_sbfe(0x18d, op, 1u);
+        };
+#pragma unroll
+        for (int q = 0; q < FUSED_HEAD_VEC; ++q)
+            if (4 * q < c_max) { step(v.cg[4 * q]); step(v.cg[4 * q + 1]); step(v.cg[4 * q + 2]); step(v.cg[4 * q + 3]); }       // (wave-uniform)
+        if (v.n_cig > (uint32_t)FUSED_HEAD) {
+            const uint32_t *const words = a->f.cig + v.c_lo;
+            for (uint32_t i = FUSED_HEAD; i < v.n_cig; ++i) step(words[i]);
+        }
+        st32(xs, off + n * SLAB_STRIDE, start); st32(xe, off + n * SLAB_STRIDE, end);
+        if (first) { s0 = start; e0 = end; }
+        ++n;
+        el = end;
+        // kept inner exons are at least min_exon >= 1 long; the first and the last one are kept whatever their length
+        sane = s0 <= e0 && start <= end;
+    } else if (active) {
+        // an outlier: the literal walk (l2r_kernels.hip.h), twice -- count, take a run of the dense area, store
+        const uint32_t *const words = a->f.cig + v.c_lo;
+        {
+            WalkState w{v.pos + 1, v.pos, 0};
+            auto none = [&](int, int, int) {};
+            walk_ops<false>(w, words, 0, (int)v.n_cig, p, none);
+            n = (uint32_t)w.n + 1u;
+        }
+        const uint32_t at = sa->ovf_base + (uint32_t)atomicAdd(sa->ovf_cursor, (unsigned long long)n);
+        WalkState w{v.pos + 1, v.pos, 0};
+        auto put = [&](int k, int s, int e) { xs[at + (uint32_t)k] = s; xe[at + (uint32_t)k] = e; sane = sane & (s <= e); el = e; };
+        walk_ops<false>(w, words, 0, (int)v.n_cig, p, put);
+        put(w.n, w.start, w.end);
+        off = at | EXOFF_DENSE;
+    }
+    if (active) {
+        a->f.ex_off[r] = off;
+        a->f.info[r] = (n << 8) | (sane ? 0u : I_PRE_INSANE) | (outlier ? I_PRE_DIRECT : 0u);
+    }
+    const int m = wave_max((active && v.tid == T.tid0) ? el : INT32_MIN);
+    const uint32_t wsum = wave_sum(active ? n : 0u);
+    if (lane == 0) {
+        if (m != INT32_MIN) atomicMax(sa->tile_thi + t, m);
+        if (wsum) atomicAdd(a->tile_total + t, wsum);                         // the tile's exon count (one word per tile: a single counter would serialise 156 k waves)
+    }
+}
+
+// map_exons (l2r_kernels.hip.h) with the read's exons streamed from its slab column: row k at off + k * 256, the same row
+// for the whole wave = coalesced; three rows in flight.  Work words at W[k * 256].
+__device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const TileDesc &d, bool mapping, const int32_t *__restrict__ xs,
+                                                    const int32_t *__restrict__ xe, uint32_t off, uint32_t n, uint32_t vpre)
+{
+    SiteMasks m{0xffffffffu, 0u, 0u, 0u};
+    uint16_t *W = L.W + threadIdx.x;
+    const uint32_t last = mapping ? n - 1u : 0u;
+    int s = 0, e = 0, s1 = 0, e1 = 0, s2n = 0, e2n = 0;
+    if (mapping) {
+        s = ld32(xs, off); e = ld32(xe, off);
+        const uint32_t i1 = off + min(1u, last) * SLAB_STRIDE, i2 = off + min(2u, last) * SLAB_STRIDE;
+        s1 = ld32(xs, i1); e1 = ld32(xe, i1); s2n = ld32(xs, i2); e2n = ld32(xe, i2);
+    }
+    const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
+    const int k_max = wave_max(mapping ? (int)n : 0);
+    for (int k = 0; k < k_max; ++k) {
+        const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
+        int s3 = 0, e3 = 0;
+        if (mapping) { const uint32_t i3 = off + min((uint32_t)k + 3u, last) * SLAB_STRIDE; s3 = ld32(xs, i3); e3 = ld32(xe, i3); }     // in flight during this round
+        const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
+        const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
+        const int s2 = s1;
+        const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
+        const v4i_t qs0 = lds_entry(L.ent0, ls);
+        const v4i_t qe0 = lds_entry(L.ent1, le), qe1 = lds_entry(L.ent1, le + 1u);
+        uint32_t xm, am, jm, dm;
+        {   const bool m0 = ls < hs && qs0.x == s;
+            am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
+        probe2(qe0, qe1, le, he, e, s2, jm, dm);
+        if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(L.ent0, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + 2u, he, e, s2, jm, dm, 0u); }
+        const uint32_t amj = junc ? am : 0u;
+        uint32_t word = first_member(xm & vpre);
+        word |= first_member(jm & vpre) << 6;
+        word |= nonzero(dm & vpre) << 12;
+        word |= nonzero(amj & vpre) << 13;
+        m.kand &= junc ? (am & dm) : 0xffffffffu;     // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
+        m.kor |= amj | dm;
+        if (k == 0) m.dm_first = dm;
+        m.am_last = (live && !junc) ? am : m.am_last;
+        if (live) W[(uint32_t)k * SLAB_STRIDE] = (uint16_t)word;
+        s = s1; e = e1; s1 = s2n; e1 = e2n; s2n = s3; e2n = e3;
+    }
+    return m;
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(TILE_THREADS, 7)
+void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint8_t *__restrict__ u_order,
+                  const int32_t *__restrict__ u_tid, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_rows,
+                  const int32_t *__restrict__ u_tile_thi)
+{
+    constexpr int DIR_BYTES = FAST_DIR_BYTES;
+    __shared__ __attribute__((aligned(16))) uint16_t s_W[SLAB_ROWS * TILE_THREADS];
+    __shared__ __attribute__((aligned(16))) v4i_t s_ent[2 * FUSED_KEY_CAP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_dir[3 * DIR_BYTES];
+    __shared__ __attribute__((aligned(16))) TileWin s_tw;
+    __shared__ int s_wide;
+    (void)kernarg_block;
+    const FusedArgsK a = fused_args();
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x;
+    const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
+    v4i_t *const s_ent0 = s_ent, *const s_ent1 = s_ent + FUSED_KEY_CAP;
+    uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
+    // ---- the tile's descriptor and window, by the last wave; meanwhile the others fetch their reads
+    if (wv == TILE_THREADS / WAVE - 1) {
+        const int32_t tid0 = n_act ? u_tid[r0] : 0, pos0 = n_act ? u_pos[r0] : 0;
+        make_descriptor(a, lane, tid0, pos0 + 1, u_tile_thi[t], u_tile_rows[t] <= (uint32_t)SLAB_ROWS, &s_tw);
+    }
+    if (threadIdx.x == 0) s_wide = 0;
+    const int32_t src = threadIdx.x < n_act ? (int32_t)ld32(u_order, r0 + threadIdx.x) : -1;
+    const bool active = src >= 0;
+    const uint32_t r = r0 + (uint32_t)max(src, 0);
+    uint32_t off = 0u, pre = 0u;
+    int32_t tid = 0; bool rev_in = false;
+    if (active) { off = ld32(a->f.ex_off, r); pre = ld32(a->f.info, r); tid = ld32(a->f.r_tid, r); rev_in = ld32(a->f.r_rev, r) != 0; }
+    const uint32_t n = pre >> 8;
+    const bool outlier = (pre & I_PRE_DIRECT) != 0u;
+    ReadEnds re{0, 0, 0, 0};
+    const int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end;
+    if (active && !outlier) {
+        re.s0 = ld32(xs, off); re.e0 = ld32(xe, off);
+        re.sl = ld32(xs, off + (n - 1u) * SLAB_STRIDE); re.el = ld32(xe, off + (n - 1u) * SLAB_STRIDE);
+    }
+    __syncthreads();
+    const TileDesc d = s_tw.d;
+    const bool fast = (d.flags & TD_FAST) != 0;
+    const int w_n = fast ? (int)d.n_win : 0;
+    // ---- stage the dictionary slices, re-based to the tile's window
+    int my_wide = 0;
+    if (fast) {
+        const FusedDict dv = fused_load_dict(a, d);
+        if ((int)threadIdx.x < FUSED_KEY_CAP) {
+            const bool has_st = threadIdx.x < d.st_nk, has_en = threadIdx.x < d.en_nk;
+            v4i_t e0, e1;
+            e0.x = dv.xa.x; e0.y = dv.xa.y; e1.x = dv.xc.x; e1.y = dv.xc.y;
+            if (d.flags & TD_CONTIG) {
+                e0.z = (int)rebase_mask((uint32_t)dv.xb.x, (uint32_t)dv.xb.y, dv.xa.z - d.j_lo);
+                e0.w = (int)rebase_mask((uint32_t)dv.xb.z, (uint32_t)dv.xb.w, dv.xa.z - d.j_lo);
+                e1.z = (int)rebase_mask((uint32_t)dv.xd.x, (uint32_t)dv.xd.y, dv.xc.z - d.j_lo);
+                e1.w = (int)rebase_mask((uint32_t)dv.xd.z, (uint32_t)dv.xd.w, dv.xc.z - d.j_lo);
+            } else {
+                e0.z = (int)rebase_gaps(s_tw.win, w_n, (uint32_t)dv.xb.x, (uint32_t)dv.xb.y, dv.xa.z);
+                e0.w = (int)rebase_gaps(s_tw.win, w_n, (uint32_t)dv.xb.z, (uint32_t)dv.xb.w, dv.xa.z);
+                e1.z = (int)rebase_gaps(s_tw.win, w_n, (uint32_t)dv.xd.x, (uint32_t)dv.xd.y, dv.xc.z);
+                e1.w = (int)rebase_gaps(s_tw.win, w_n, (uint32_t)dv.xd.z, (uint32_t)dv.xd.w, dv.xc.z);
+            }
+            if (has_st) { s_ent0[threadIdx.x] = e0; if (dv.xa.w & SE_WIDE) my_wide = 1; }
+            if (has_en) { s_ent1[threadIdx.x] = e1; if (dv.xc.w & SE_WIDE) my_wide = 1; }
+        }
+        if (d.nbk > 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = (int)threadIdx.x + q * TILE_THREADS;
+                if (i <= d.nbk) {
+                    s_dir0[i] = (uint8_t)(dv.dd[0][q] - d.st_r0); s_dir1[i] = (uint8_t)(dv.dd[1][q] - d.en_r0);
+                    s_rdir[i] = (uint8_t)(dv.dd[2][q] - d.st_r0);
+                }
+            }
+        }
+        if (threadIdx.x < 3u && (threadIdx.x > 0u || d.nbk == 0)) {
+            s_dir0[d.nbk + (int)threadIdx.x] = (uint8_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint8_t)d.en_nk;
+        }
+    }
+    if (my_wide) s_wide = 1;
+    __syncthreads();
+    const int any_wide = s_wide;
+    // ---- classification (device functions of the classic kernel)
+    uint32_t info = n << 8; int ref = -1;
+    bool redo = active && (!fast || outlier || any_wide != 0 || tid != d.tid || (n > 1 && (pre & I_PRE_INSANE) != 0u));
+    const bool work = active && !redo;
+    const TileLds L{nullptr, nullptr, s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
+    const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, s_tw.mask);
+    redo = redo || vm.redo;
+    const SiteMasks sm = map_exons_slab(L, d, work && !redo && n > 1, xs, xe, off, n, vm.vpre);
+    uint8_t *const xf = a->f.ex_flag;
+    if (work && !redo) {
+        const Verdict vd = decide<LEVEL, (int)SLAB_STRIDE>(L, d, threadIdx.x, n, re, vm, sm, rev_in);
+        info = vd.info; ref = vd.ref;
+        for (uint32_t k = 0; k < n; ++k) st32(xf, off + k * SLAB_STRIDE, (uint8_t)s_W[k * SLAB_STRIDE + threadIdx.x]);       // (rows: coalesced)
+    } else if (active && !outlier) {
+        for (uint32_t k = 0; k < n; ++k) st32(xf, off + k * SLAB_STRIDE, (uint8_t)0);
+    }
+    redo = redo && active;
+    {
+        const unsigned long long m = __ballot(redo);
+        if (m) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(a->f.redo_count, (uint32_t)__popcll(m));
+            at = __shfl(at, 0, WAVE);
+            if (redo) a->f.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+        }
+    }
+    if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; }
+}
+
+__global__ __launch_bounds__(TILE_THREADS)
+void k_exon_counts(int64_t n_reads, const uint32_t *__restrict__ info, uint32_t *__restrict__ out)
+{
+    const int64_t r = (int64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
+    if (r < n_reads) out[r] = info[r] >> 8;
+}
+
+// Slabs -> read order (l2r_download): one thread per read, dest[r] = running sum of the exon counts in read order.
+__global__ __launch_bounds__(TILE_THREADS)
+void k_linearize_slab(int64_t n_reads, const uint32_t *__restrict__ ex_off, const uint32_t *__restrict__ info, const uint32_t *__restrict__ dest,
+                      const int32_t *__restrict__ xs, const int32_t *__restrict__ xe, const uint8_t *__restrict__ xf,
+                      int32_t *__restrict__ os, int32_t *__restrict__ oe, uint8_t *__restrict__ of)
+{
+    const int64_t r = (int64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
+    if (r >= n_reads) return;
+    uint32_t off = ex_off[r];
+    const uint32_t n = info[r] >> 8, to = dest[r];
+    const uint32_t st = (off & EXOFF_DENSE) ? 1u : SLAB_STRIDE;
+    off &= ~EXOFF_DENSE;
+    for (uint32_t k = 0; k < n; ++k) { os[to + k] = xs[off + k * st]; oe[to + k] = xe[off + k * st]; of[to + k] = xf[off + k * st]; }
+}
+
+}  // namespace l2r
