@@ -65,8 +65,11 @@ struct l2r_ctx {
     bool fused = false;                     // the current upload runs a one-walk pipeline: sorted input, short CIGARs
     bool slab_ok = false;                   // ... and its slab layout fits (l2r_slab.hip.h); slab = the last launch used it
     bool slab = false;
-    DevBuf<uint32_t> tile_sbase, tile_rows, lin_dest;
-    DevBuf<int32_t> tile_thi;
+    DevBuf<uint32_t> tile_sbase, lin_dest, s_clo, s_pre;
+    DevBuf<uint16_t> s_ncig;
+    DevBuf<int32_t> s_pos;
+    DevBuf<uint8_t> s_rev;
+    DevBuf<TileWin> tw;
     DevBuf<unsigned long long> ovf_cursor;
     uint32_t ovf_base = 0;
     DevBuf<uint16_t> lub;                   // k_order: first LDS slot of every read
@@ -216,7 +219,8 @@ void l2r_destroy(l2r_ctx *c)
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->lub.release(); c->tile_ub.release(); c->tile_start.release(); c->tile_total.release(); c->tile_dest.release();
     c->lin_start.release(); c->lin_end.release(); c->lin_flag.release();
-    c->tile_sbase.release(); c->tile_rows.release(); c->lin_dest.release(); c->tile_thi.release(); c->ovf_cursor.release();
+    c->tile_sbase.release(); c->lin_dest.release(); c->ovf_cursor.release();
+    c->s_clo.release(); c->s_pre.release(); c->s_ncig.release(); c->s_pos.release(); c->s_rev.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -635,11 +639,11 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         }
         if (total + ovf < 0x7ffffff0ULL) {
             c->slab_ok = true; c->ovf_base = (uint32_t)total;
-            if (c->tile_sbase.ensure(T + 1) || c->tile_rows.ensure(T + 1) || c->tile_thi.ensure(T + 1) || c->ovf_cursor.ensure(1) ||
+            if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) ||
+                c->s_clo.ensure((size_t)N + 1) || c->s_pre.ensure((size_t)N + 1) || c->s_ncig.ensure((size_t)N + 1) || c->s_pos.ensure((size_t)N + 1) || c->s_rev.ensure((size_t)N + 1) ||
                 c->ex_start.ensure(std::max<size_t>(exb, total + ovf)) || c->ex_end.ensure(std::max<size_t>(exb, total + ovf)) ||
                 c->ex_flag.ensure(std::max<size_t>(exb, total + ovf))) return -2;
             HIP_TRY(hipMemcpyAsync(c->tile_sbase.p, sbase.data(), (T + 1) * 4, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(c->tile_rows.p, rows.data(), (T + 1) * 4, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));       // (locals)
         }
     }
@@ -769,21 +773,22 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         c->slab = c->slab_ok && p.min_exon >= 1 && p.min_intron >= 0 && p.min_intron < (1 << 28) && p.max_delet >= -1 && p.max_delet < (1 << 28) - 1;
         hipLaunchKernelGGL(k_order, dim3(gt), dim3(TILE_THREADS), 0, s, (const int64_t *)c->cig_off.p, (const uint32_t *)c->tile_first.p, p,
                            c->order.p, c->lub.p, c->tile_ub.p, c->totals.p + 3, ex_cursor,
-                           (c->slab ? c->tile_thi.p : (int32_t *)nullptr), (c->slab ? c->ovf_cursor.p : (unsigned long long *)nullptr),
-                           (c->slab ? c->tile_total.p : (uint32_t *)nullptr));
+                           (int32_t *)nullptr, (c->slab ? c->ovf_cursor.p : (unsigned long long *)nullptr),
+                           (c->slab ? c->tile_total.p : (uint32_t *)nullptr), (const int32_t *)c->r_pos.p, (const uint8_t *)c->r_rev.p,
+                           (c->slab ? c->s_clo.p : (uint32_t *)nullptr), c->s_ncig.p, c->s_pos.p, c->s_rev.p);
         MARK(ST_SCAN1);
         FusedArgs ga;
         ga.f = fa; ga.cd = cd; ga.tid_base = c->tid_base.p; ga.n_tid_dir = c->n_tid_dir; ga.lub = c->lub.p; ga.tile_ub = c->tile_ub.p;
         ga.tile_start = c->tile_start.p; ga.tile_total = c->tile_total.p; ga.ex_cursor = ex_cursor;
         if (c->slab) {
             // ---- two light kernels at high occupancy: the walk (exons into the tiles' slabs), then the probes (l2r_slab.hip.h)
-            SlabArgs sa; sa.g = ga; sa.tile_sbase = c->tile_sbase.p; sa.tile_rows = c->tile_rows.p; sa.tile_thi = c->tile_thi.p;
-            sa.ovf_cursor = c->ovf_cursor.p; sa.ovf_base = c->ovf_base;
+            SlabArgs sa; sa.g = ga; sa.tile_sbase = c->tile_sbase.p; sa.ovf_cursor = c->ovf_cursor.p; sa.ovf_base = c->ovf_base;
+            sa.s_clo = c->s_clo.p; sa.s_ncig = c->s_ncig.p; sa.s_pos = c->s_pos.p; sa.s_rev = c->s_rev.p; sa.pre = c->s_pre.p; sa.tw = c->tw.p;
             hipLaunchKernelGGL(k_walk_slab, dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, (const uint8_t *)c->order.p,
-                               (const int32_t *)c->r_tid.p, (const uint32_t *)c->tile_sbase.p);
+                               (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
             MARK(ST_FAST);
 #define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L>), dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
-                (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_rows.p, (const int32_t *)c->tile_thi.p)
+                (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const uint32_t *)c->tile_sbase.p)
             switch (p.full_level) {
             case 1: launch_probe_level(1); break;
             case 2: launch_probe_level(2); break;

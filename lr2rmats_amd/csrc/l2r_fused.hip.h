@@ -39,13 +39,17 @@ void k_order(const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ t
              uint32_t *__restrict__ redo_count /* [3]: redo list, chunk cursor of the accepted list */, unsigned long long *__restrict__ ex_cursor,
              int32_t *__restrict__ tile_thi /* slab pipeline: the tile's largest read end (atomicMax of k_walk_slab), else null */,
              unsigned long long *__restrict__ ovf_cursor /* slab pipeline: dense area of the outliers */,
-             uint32_t *__restrict__ tile_total /* slab pipeline: exon count per tile (atomicAdd of k_walk_slab), else null */)
+             uint32_t *__restrict__ tile_total /* slab pipeline: exon count per tile (atomicAdd of k_walk_slab), else null */,
+             const int32_t *__restrict__ r_pos, const uint8_t *__restrict__ r_rev,
+             uint32_t *__restrict__ s_clo, uint16_t *__restrict__ s_ncig, int32_t *__restrict__ s_pos, uint8_t *__restrict__ s_rev
+             /* slab pipeline: the records' fields in SLOT order (tile start + slot), so that its kernels need no indirection; else null */)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {       // the kernels that use these run after this one
         redo_count[0] = 0u; redo_count[1] = 0u; redo_count[2] = 0u; *ex_cursor = 0ull;
         if (ovf_cursor) *ovf_cursor = 0ull;
     }
-    if (tile_thi && threadIdx.x == 0) { tile_thi[blockIdx.x] = INT32_MIN; tile_total[blockIdx.x] = 0u; }
+    if (tile_total && threadIdx.x == 0) tile_total[blockIdx.x] = 0u;
+    if (tile_thi && threadIdx.x == 0) tile_thi[blockIdx.x] = INT32_MIN;
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_hist[WAVE];
     if (threadIdx.x < WAVE) s_hist[threadIdx.x] = 0u;
@@ -67,7 +71,13 @@ void k_order(const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ t
     if (threadIdx.x < WAVE) { const uint32_t v = s_hist[threadIdx.x]; s_hist[threadIdx.x] = wave_inclusive_scan(v) - v; }
     __syncthreads();
     const uint32_t slot = s_hist[bin] + rank;
-    if (active) order_out[(int64_t)r0 + slot] = (uint8_t)threadIdx.x;
+    if (active) {
+        order_out[(int64_t)r0 + slot] = (uint8_t)threadIdx.x;
+        if (s_clo) {
+            const int64_t at = (int64_t)r0 + slot;
+            s_clo[at] = (uint32_t)cig_off[r]; s_ncig[at] = (uint16_t)min(c, 0xffffu); s_pos[at] = r_pos[r]; s_rev[at] = r_rev[r];
+        }
+    }
 }
 
 // What the fused kernel needs beyond FastArgs (appended to it, so that the device functions of the classic kernel

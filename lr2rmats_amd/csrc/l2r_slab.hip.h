@@ -37,9 +37,11 @@ __host__ __device__ __forceinline__ uint32_t slab_rows_of(uint32_t c) { return (
 struct SlabArgs {
     FusedArgs g;
     const uint32_t *tile_sbase;                          // first element of every tile's slab
-    const uint32_t *tile_rows;                           // rows of every tile's slab
-    int32_t *tile_thi;                                   // largest read end of every tile (k_walk_slab, atomicMax)
     unsigned long long *ovf_cursor; uint32_t ovf_base;   // dense area behind the slabs for outliers
+    // the records' fields in slot order (k_order): c_lo, number of ops (65535: more), pos, strand
+    const uint32_t *s_clo; const uint16_t *s_ncig; const int32_t *s_pos; const uint8_t *s_rev;
+    uint32_t *pre;                                       // k_walk_slab -> k_probe_slab, slot order: exon count << 8 | I_PRE_*
+    TileWin *tw;                                         // k_walk_slab -> k_probe_slab: descriptor + window per tile
 };
 typedef const __attribute__((address_space(4))) SlabArgs *SlabArgsK;
 __device__ __forceinline__ SlabArgsK slab_args()
@@ -48,27 +50,37 @@ __device__ __forceinline__ SlabArgsK slab_args()
     asm volatile("" : "+s"(q));
     return q;
 }
+constexpr int SLAB_TW_VECS = (int)(sizeof(TileWin) / 16);
+static_assert(sizeof(TileWin) % 16 == 0, "TileWin is copied in 16-byte pieces");
 
+// Both kernels are laid out for SHORT dependent load chains (they are latency bound: a tile's time is the sum of its
+// dependent round trips): everything a lane needs sits at "tile start + slot".
 __global__ __launch_bounds__(TILE_THREADS, 8)
 void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint8_t *__restrict__ u_order,
-                 const int32_t *__restrict__ u_tid, const uint32_t *__restrict__ u_tile_sbase)
+                 const int32_t *__restrict__ u_tid, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase)
 {
+    __shared__ int s_wmax[TILE_THREADS / WAVE];
+    __shared__ __attribute__((aligned(16))) TileWin s_tw;
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const FusedArgsK a = fused_args();
-    const int lane = threadIdx.x & (WAVE - 1);
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     const uint32_t t = blockIdx.x;
-    FusedTile T;
-    T.r0 = u_tile_first[t]; T.n_act = u_tile_first[t + 1u] - T.r0;
-    T.tid0 = T.n_act ? u_tid[T.r0] : 0; T.pos0 = 0; T.in_lds = true;
+    const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
+    const int32_t tid0 = n_act ? u_tid[r0] : 0, pos0 = n_act ? u_pos[r0] : 0;
     const uint32_t sbase = u_tile_sbase[t];
-    const int32_t src = threadIdx.x < T.n_act ? (int32_t)ld32(u_order, T.r0 + threadIdx.x) : -1;
+    const bool active = threadIdx.x < n_act;
+    const uint32_t at = r0 + (active ? threadIdx.x : 0u);
+    // ---- the read in this slot and the head of its CIGAR
     FusedRead v;
-    fused_load_fields(a, T, src, v);
-    fused_load_words(a, v);
+    v.src = active ? 0 : -1; v.c_lo = 0u; v.n_cig = 0u; v.lub = 0u; v.pos = 0; v.tid = tid0; v.rev = 0u;
+    uint32_t r = r0;
+    if (active) {
+        v.c_lo = ld32(sa->s_clo, at); v.n_cig = v.c_lo + (uint32_t)ld32(sa->s_ncig, at); v.pos = ld32(sa->s_pos, at);
+        r = r0 + (uint32_t)ld32(u_order, at);
+    }
+    fused_load_words(a, v);                       // (n_cig = number of ops from here on; 65535 stands for "more")
     fused_mask_words(v);
-    const bool active = src >= 0;
-    const uint32_t r = T.r0 + (uint32_t)max(src, 0);
     DevParams p;
     p.min_exon = a->f.p.min_exon; p.min_intron = a->f.p.min_intron; p.max_delet = a->f.p.max_delet;
     const uint32_t t3 = ((uint32_t)p.min_intron << 4) | 3u, t2 = ((uint32_t)(p.max_delet + 1) << 4) | 2u;
@@ -112,30 +124,39 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
         sane = s0 <= e0 && start <= end;
     } else if (active) {
         // an outlier: the literal walk (l2r_kernels.hip.h), twice -- count, take a run of the dense area, store
+        const int64_t *const p_off = a->f.cig_off;
+        const uint32_t n_ops = (uint32_t)(ld32(p_off, r + 1u) - ld32(p_off, r));
         const uint32_t *const words = a->f.cig + v.c_lo;
         {
             WalkState w{v.pos + 1, v.pos, 0};
             auto none = [&](int, int, int) {};
-            walk_ops<false>(w, words, 0, (int)v.n_cig, p, none);
+            walk_ops<false>(w, words, 0, (int)n_ops, p, none);
             n = (uint32_t)w.n + 1u;
         }
-        const uint32_t at = sa->ovf_base + (uint32_t)atomicAdd(sa->ovf_cursor, (unsigned long long)n);
+        const uint32_t run = sa->ovf_base + (uint32_t)atomicAdd(sa->ovf_cursor, (unsigned long long)n);
         WalkState w{v.pos + 1, v.pos, 0};
-        auto put = [&](int k, int s, int e) { xs[at + (uint32_t)k] = s; xe[at + (uint32_t)k] = e; sane = sane & (s <= e); el = e; };
-        walk_ops<false>(w, words, 0, (int)v.n_cig, p, put);
+        auto put = [&](int k, int s, int e) { xs[run + (uint32_t)k] = s; xe[run + (uint32_t)k] = e; sane = sane & (s <= e); el = e; };
+        walk_ops<false>(w, words, 0, (int)n_ops, p, put);
         put(w.n, w.start, w.end);
-        off = at | EXOFF_DENSE;
+        off = run | EXOFF_DENSE;
     }
     if (active) {
+        const uint32_t pre = (n << 8) | (sane ? 0u : I_PRE_INSANE) | (outlier ? I_PRE_DIRECT : 0u);
+        sa->pre[at] = pre;
         a->f.ex_off[r] = off;
-        a->f.info[r] = (n << 8) | (sane ? 0u : I_PRE_INSANE) | (outlier ? I_PRE_DIRECT : 0u);
+        a->f.info[r] = pre;                          // (the exon count is what l2r_result_sizes / the generic kernel read; k_probe_slab writes the verdict)
     }
-    const int m = wave_max((active && v.tid == T.tid0) ? el : INT32_MIN);
+    const int m = wave_max(active ? el : INT32_MIN);
     const uint32_t wsum = wave_sum(active ? n : 0u);
     if (lane == 0) {
-        if (m != INT32_MIN) atomicMax(sa->tile_thi + t, m);
+        s_wmax[wv] = m;
         if (wsum) atomicAdd(a->tile_total + t, wsum);                         // the tile's exon count (one word per tile: a single counter would serialise 156 k waves)
     }
+    __syncthreads();
+    // ---- the tile's descriptor and window, by the last wave alone (the others are done): nobody waits for its load chain
+    if (wv != TILE_THREADS / WAVE - 1) return;
+    make_descriptor(a, lane, tid0, pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), true, &s_tw);
+    for (int i = lane; i < SLAB_TW_VECS; i += WAVE) reinterpret_cast<int4 *>(sa->tw + t)[i] = reinterpret_cast<const int4 *>(&s_tw)[i];
 }
 
 // map_exons (l2r_kernels.hip.h) with the read's exons streamed from its slab column: row k at off + k * 256, the same row
@@ -187,8 +208,7 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, 7)
 void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint8_t *__restrict__ u_order,
-                  const int32_t *__restrict__ u_tid, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_rows,
-                  const int32_t *__restrict__ u_tile_thi)
+                  const int32_t *__restrict__ u_tid, const uint32_t *__restrict__ u_tile_sbase)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
     __shared__ __attribute__((aligned(16))) uint16_t s_W[SLAB_ROWS * TILE_THREADS];
@@ -197,32 +217,34 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     __shared__ __attribute__((aligned(16))) TileWin s_tw;
     __shared__ int s_wide;
     (void)kernarg_block;
+    const SlabArgsK sa = slab_args();
     const FusedArgsK a = fused_args();
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t t = blockIdx.x;
     const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
+    const int32_t tid0 = n_act ? u_tid[r0] : 0;
+    const uint32_t sbase = u_tile_sbase[t];
     v4i_t *const s_ent0 = s_ent, *const s_ent1 = s_ent + FUSED_KEY_CAP;
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
-    // ---- the tile's descriptor and window, by the last wave; meanwhile the others fetch their reads
-    if (wv == TILE_THREADS / WAVE - 1) {
-        const int32_t tid0 = n_act ? u_tid[r0] : 0, pos0 = n_act ? u_pos[r0] : 0;
-        make_descriptor(a, lane, tid0, pos0 + 1, u_tile_thi[t], u_tile_rows[t] <= (uint32_t)SLAB_ROWS, &s_tw);
-    }
+    // ---- one round trip: the tile's descriptor and window (k_walk_slab), the slot's read, the first rows of its exons
+    if ((int)threadIdx.x < SLAB_TW_VECS)
+        reinterpret_cast<int4 *>(&s_tw)[threadIdx.x] = reinterpret_cast<const int4 *>(sa->tw + t)[threadIdx.x];
     if (threadIdx.x == 0) s_wide = 0;
-    const int32_t src = threadIdx.x < n_act ? (int32_t)ld32(u_order, r0 + threadIdx.x) : -1;
-    const bool active = src >= 0;
-    const uint32_t r = r0 + (uint32_t)max(src, 0);
-    uint32_t off = 0u, pre = 0u;
-    int32_t tid = 0; bool rev_in = false;
-    if (active) { off = ld32(a->f.ex_off, r); pre = ld32(a->f.info, r); tid = ld32(a->f.r_tid, r); rev_in = ld32(a->f.r_rev, r) != 0; }
+    const bool active = threadIdx.x < n_act;
+    const uint32_t at = r0 + (active ? threadIdx.x : 0u);
+    uint32_t pre = 0u, r = r0;
+    bool rev_in = false;
+    const int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end;
+    uint32_t off = sbase + threadIdx.x;
+    ReadEnds re{0, 0, 0, 0};
+    if (active) {
+        pre = ld32(sa->pre, at); r = r0 + (uint32_t)ld32(u_order, at); rev_in = ld32(sa->s_rev, at) != 0;
+        re.s0 = ld32(xs, off); re.e0 = ld32(xe, off);               // (an outlier's slab column holds nothing: read, not used)
+    }
     const uint32_t n = pre >> 8;
     const bool outlier = (pre & I_PRE_DIRECT) != 0u;
-    ReadEnds re{0, 0, 0, 0};
-    const int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end;
-    if (active && !outlier) {
-        re.s0 = ld32(xs, off); re.e0 = ld32(xe, off);
-        re.sl = ld32(xs, off + (n - 1u) * SLAB_STRIDE); re.el = ld32(xe, off + (n - 1u) * SLAB_STRIDE);
-    }
+    const int32_t tid = tid0;                                       // (sorted input: a tile is of one chromosome)
+    if (active && !outlier) { re.sl = ld32(xs, off + (n - 1u) * SLAB_STRIDE); re.el = ld32(xe, off + (n - 1u) * SLAB_STRIDE); }
     __syncthreads();
     const TileDesc d = s_tw.d;
     const bool fast = (d.flags & TD_FAST) != 0;
