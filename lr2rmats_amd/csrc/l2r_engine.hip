@@ -72,6 +72,7 @@ struct l2r_ctx {
     DevBuf<TileWin> tw;
     DevBuf<unsigned long long> ovf_cursor;
     uint32_t ovf_base = 0;
+    bool slab_ordered = false;              // k_order has run for this upload (slab pipeline: its outputs depend on the records only)
     DevBuf<uint16_t> lub;                   // k_order: first LDS slot of every read
     DevBuf<uint32_t> tile_ub, tile_start, tile_total, tile_dest;
     DevBuf<int32_t> lin_start, lin_end;     // l2r_download of a fused run: the exon arrays in read order (k_linearize)
@@ -620,7 +621,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb) || (c->wide_cigar && c->walked.ensure((size_t)(c->n_tiles + 1) * LDS_EXON_CAP))) return -2;
     c->ex_cap = (int64_t)exb;
     c->fused = c->want_pipeline > 0 && sorted && !c->wide_cigar;
-    c->slab_ok = false; c->slab = false;
+    c->slab_ok = false; c->slab = false; c->slab_ordered = false;
     if (c->fused && c->want_pipeline == 2) {
         // the slab layout (l2r_slab.hip.h): per tile as many rows of 256 elements as its longest read can have exons (bound from
         // the CIGAR lengths); reads beyond SLAB_ROWS rows are outliers and get a run of the dense area behind the slabs
@@ -771,11 +772,21 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         unsigned long long *const ex_cursor = (unsigned long long *)(c->totals.p + 6);
         // the slab form wants the straight-line walk: min_exon >= 1 and thresholds that fit a CIGAR word (else: k_fused)
         c->slab = c->slab_ok && p.min_exon >= 1 && p.min_intron >= 0 && p.min_intron < (1 << 28) && p.max_delet >= -1 && p.max_delet < (1 << 28) - 1;
+        if (c->slab) {
+            // the lane order of a tile and the slot-ordered record fields are a LAYOUT of the input (nothing of them depends on
+            // the parameters): made once per upload; a run only clears its counters
+            if (!c->slab_ordered) {
+                hipLaunchKernelGGL(k_order, dim3(gt), dim3(TILE_THREADS), 0, s, (const int64_t *)c->cig_off.p, (const uint32_t *)c->tile_first.p, p,
+                                   c->order.p, c->lub.p, c->tile_ub.p, c->totals.p + 3, ex_cursor, (int32_t *)nullptr, c->ovf_cursor.p, c->tile_total.p,
+                                   (const int32_t *)c->r_pos.p, (const uint8_t *)c->r_rev.p, c->s_clo.p, c->s_ncig.p, c->s_pos.p, c->s_rev.p);
+                c->slab_ordered = true;
+            }
+            // (the run's counters are cleared by the kernels themselves: l2r_slab.hip.h)
+        } else
         hipLaunchKernelGGL(k_order, dim3(gt), dim3(TILE_THREADS), 0, s, (const int64_t *)c->cig_off.p, (const uint32_t *)c->tile_first.p, p,
-                           c->order.p, c->lub.p, c->tile_ub.p, c->totals.p + 3, ex_cursor,
-                           (int32_t *)nullptr, (c->slab ? c->ovf_cursor.p : (unsigned long long *)nullptr),
-                           (c->slab ? c->tile_total.p : (uint32_t *)nullptr), (const int32_t *)c->r_pos.p, (const uint8_t *)c->r_rev.p,
-                           (c->slab ? c->s_clo.p : (uint32_t *)nullptr), c->s_ncig.p, c->s_pos.p, c->s_rev.p);
+                           c->order.p, c->lub.p, c->tile_ub.p, c->totals.p + 3, ex_cursor, (int32_t *)nullptr, (unsigned long long *)nullptr,
+                           (uint32_t *)nullptr, (const int32_t *)c->r_pos.p, (const uint8_t *)c->r_rev.p,
+                           (uint32_t *)nullptr, c->s_ncig.p, c->s_pos.p, c->s_rev.p);
         MARK(ST_SCAN1);
         FusedArgs ga;
         ga.f = fa; ga.cd = cd; ga.tid_base = c->tid_base.p; ga.n_tid_dir = c->n_tid_dir; ga.lub = c->lub.p; ga.tile_ub = c->tile_ub.p;

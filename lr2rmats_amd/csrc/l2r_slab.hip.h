@@ -60,6 +60,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
                  const int32_t *__restrict__ u_tid, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase)
 {
     __shared__ int s_wmax[TILE_THREADS / WAVE];
+    __shared__ uint32_t s_wsum[TILE_THREADS / WAVE];
     __shared__ __attribute__((aligned(16))) TileWin s_tw;
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
@@ -143,18 +144,21 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     if (active) {
         const uint32_t pre = (n << 8) | (sane ? 0u : I_PRE_INSANE) | (outlier ? I_PRE_DIRECT : 0u);
         sa->pre[at] = pre;
-        a->f.ex_off[r] = off;
-        a->f.info[r] = pre;                          // (the exon count is what l2r_result_sizes / the generic kernel read; k_probe_slab writes the verdict)
+        a->f.ex_off[r] = off;                        // (info[r] is written by k_probe_slab: exon count + verdict)
     }
     const int m = wave_max(active ? el : INT32_MIN);
     const uint32_t wsum = wave_sum(active ? n : 0u);
-    if (lane == 0) {
-        s_wmax[wv] = m;
-        if (wsum) atomicAdd(a->tile_total + t, wsum);                         // the tile's exon count (one word per tile: a single counter would serialise 156 k waves)
+    if (lane == 0) { s_wmax[wv] = m; s_wsum[wv] = wsum; }
+    if (t == 0u && threadIdx.x == 0) {
+        // the run's counters (this kernel is the first of a run, k_probe_slab the first to count): redo list, chunk cursor
+        // of the accepted list, exon cursor.  (The cursor of the outlier area is cleared by k_probe_slab for the next run.)
+        uint32_t *const cnt = a->f.redo_count;
+        cnt[0] = 0u; cnt[1] = 0u; cnt[2] = 0u; cnt[3] = 0u; cnt[4] = 0u;
     }
     __syncthreads();
     // ---- the tile's descriptor and window, by the last wave alone (the others are done): nobody waits for its load chain
     if (wv != TILE_THREADS / WAVE - 1) return;
+    if (lane == 0) a->tile_total[t] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];   // (one word per tile: a single counter would serialise 156 k waves)
     make_descriptor(a, lane, tid0, pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), true, &s_tw);
     for (int i = lane; i < SLAB_TW_VECS; i += WAVE) reinterpret_cast<int4 *>(sa->tw + t)[i] = reinterpret_cast<const int4 *>(&s_tw)[i];
 }
@@ -229,7 +233,7 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     // ---- one round trip: the tile's descriptor and window (k_walk_slab), the slot's read, the first rows of its exons
     if ((int)threadIdx.x < SLAB_TW_VECS)
         reinterpret_cast<int4 *>(&s_tw)[threadIdx.x] = reinterpret_cast<const int4 *>(sa->tw + t)[threadIdx.x];
-    if (threadIdx.x == 0) s_wide = 0;
+    if (threadIdx.x == 0) { s_wide = 0; if (t == 0u) *sa->ovf_cursor = 0ull; }   // (k_walk_slab is done with the outlier area)
     const bool active = threadIdx.x < n_act;
     const uint32_t at = r0 + (active ? threadIdx.x : 0u);
     uint32_t pre = 0u, r = r0;
