@@ -639,6 +639,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             if (total + ovf >= 0x7ffffff0ULL) break;
         }
         if (total + ovf < 0x7ffffff0ULL) {
+            sbase[T] = (uint32_t)total;                     // (k_probe_slab: rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true; c->ovf_base = (uint32_t)total;
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) ||
                 c->s_clo.ensure((size_t)N + 1) || c->s_pre.ensure((size_t)N + 1) || c->s_ncig.ensure((size_t)N + 1) || c->s_pos.ensure((size_t)N + 1) || c->s_rev.ensure((size_t)N + 1) ||
@@ -798,8 +799,10 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             hipLaunchKernelGGL(k_walk_slab, dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, (const uint8_t *)c->order.p,
                                (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
             MARK(ST_FAST);
+            // (tried: the run cut into chunks of tiles, the probes of chunk i on a second stream beside the walk of chunk i + 1 --
+            //  no gain, 0.71 -> 0.72 .. 0.82 ms with 2 .. 16 chunks: profiles/r02/README.md)
 #define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L>), dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
-                (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const uint32_t *)c->tile_sbase.p)
+                (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p)
             switch (p.full_level) {
             case 1: launch_probe_level(1); break;
             case 2: launch_probe_level(2); break;

@@ -119,7 +119,8 @@ struct TileWin {
 // The tile's dictionary slices and transcript window from its span [tlo, thi] on chromosome tid0 -- the descriptor
 // k_pass_a leaves in HBM, made by ONE WAVE of the workgroup (everything is wave-uniform but `lane`).  The window's
 // member headers go straight into LDS.
-__device__ __forceinline__ void make_descriptor(FusedArgsK a, int lane, int32_t tid0, int32_t tlo, int32_t thi, bool in_lds, TileWin *W)
+__device__ __forceinline__ void make_descriptor(FusedArgsK a, int lane, int32_t tid0, int32_t tlo, int32_t thi, bool in_lds, TileWin *W,
+                                                uint32_t key_cap = (uint32_t)FUSED_KEY_CAP)
 {
     const TxHdr *const hdr = a->f.hdr;
     const int32_t n_tx = a->f.p.n_tx;
@@ -184,7 +185,7 @@ __device__ __forceinline__ void make_descriptor(FusedArgsK a, int lane, int32_t 
         d.b_off = -lo; d.nb = nb; d.b0 = tb + lo; d.nbk = hi - lo + 1;
         d.st_r0 = sd_r0; d.st_nk = sd_r1 - sd_r0;
         d.en_r0 = ed_r0; d.en_nk = ed_r1 - ed_r0;
-        if (fast && (d.st_nk > (uint32_t)FUSED_KEY_CAP || d.en_nk > (uint32_t)FUSED_KEY_CAP)) { fast = false; why = 3u; }
+        if (fast && (d.st_nk > key_cap || d.en_nk > key_cap)) { fast = false; why = 3u; }
     }
     d.flags = (fast ? TD_FAST : 0u) | (contig ? TD_CONTIG : 0u) | (why << 8);
     // the members' headers (the wave's own LDS writes above are visible to it: same wave, in order)

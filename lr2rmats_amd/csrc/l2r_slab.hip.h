@@ -51,6 +51,7 @@ __device__ __forceinline__ SlabArgsK slab_args()
     return q;
 }
 constexpr int SLAB_TW_VECS = (int)(sizeof(TileWin) / 16);
+constexpr int SLAB_KEY_CAP = 168;                        // dictionary entries staged per dictionary and tile (k_probe_slab's LDS: 20 KB = 8 workgroups per CU)
 static_assert(sizeof(TileWin) % 16 == 0, "TileWin is copied in 16-byte pieces");
 
 // Both kernels are laid out for SHORT dependent load chains (they are latency bound: a tile's time is the sum of its
@@ -159,30 +160,28 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     // ---- the tile's descriptor and window, by the last wave alone (the others are done): nobody waits for its load chain
     if (wv != TILE_THREADS / WAVE - 1) return;
     if (lane == 0) a->tile_total[t] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];   // (one word per tile: a single counter would serialise 156 k waves)
-    make_descriptor(a, lane, tid0, pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), true, &s_tw);
+    make_descriptor(a, lane, tid0, pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), true, &s_tw, (uint32_t)SLAB_KEY_CAP);
     for (int i = lane; i < SLAB_TW_VECS; i += WAVE) reinterpret_cast<int4 *>(sa->tw + t)[i] = reinterpret_cast<const int4 *>(&s_tw)[i];
 }
 
 // map_exons (l2r_kernels.hip.h) with the read's exons streamed from its slab column: row k at off + k * 256, the same row
-// for the whole wave = coalesced; three rows in flight.  Work words at W[k * 256].
+// for the whole wave = coalesced.  Rows 0..3 come preloaded (SlabRows: the kernel asks for them with its first loads, before
+// it knows the read), row k + 4 is asked for in round k.  Rows at and behind the read's exon count hold anything: not used.
+// Work words at W[k * 256].
+struct SlabRows { int s[4], e[4]; };
 __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const TileDesc &d, bool mapping, const int32_t *__restrict__ xs,
-                                                    const int32_t *__restrict__ xe, uint32_t off, uint32_t n, uint32_t vpre)
+                                                    const int32_t *__restrict__ xe, uint32_t off, uint32_t n, uint32_t vpre,
+                                                    const SlabRows &q, uint32_t row_max)
 {
     SiteMasks m{0xffffffffu, 0u, 0u, 0u};
     uint16_t *W = L.W + threadIdx.x;
-    const uint32_t last = mapping ? n - 1u : 0u;
-    int s = 0, e = 0, s1 = 0, e1 = 0, s2n = 0, e2n = 0;
-    if (mapping) {
-        s = ld32(xs, off); e = ld32(xe, off);
-        const uint32_t i1 = off + min(1u, last) * SLAB_STRIDE, i2 = off + min(2u, last) * SLAB_STRIDE;
-        s1 = ld32(xs, i1); e1 = ld32(xe, i1); s2n = ld32(xs, i2); e2n = ld32(xe, i2);
-    }
+    int s = q.s[0], e = q.e[0], s1 = q.s[1], e1 = q.e[1], s2n = q.s[2], e2n = q.e[2], s3n = q.s[3], e3n = q.e[3];
     const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
     const int k_max = wave_max(mapping ? (int)n : 0);
     for (int k = 0; k < k_max; ++k) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
-        int s3 = 0, e3 = 0;
-        if (mapping) { const uint32_t i3 = off + min((uint32_t)k + 3u, last) * SLAB_STRIDE; s3 = ld32(xs, i3); e3 = ld32(xe, i3); }     // in flight during this round
+        int s4 = 0, e4 = 0;
+        if (mapping) { const uint32_t i4 = off + min((uint32_t)k + 4u, row_max) * SLAB_STRIDE; s4 = ld32(xs, i4); e4 = ld32(xe, i4); }   // four rows in flight
         const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
         const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
         const int s2 = s1;
@@ -204,22 +203,21 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         if (k == 0) m.dm_first = dm;
         m.am_last = (live && !junc) ? am : m.am_last;
         if (live) W[(uint32_t)k * SLAB_STRIDE] = (uint16_t)word;
-        s = s1; e = e1; s1 = s2n; e1 = e2n; s2n = s3; e2n = e3;
+        s = s1; e = e1; s1 = s2n; e1 = e2n; s2n = s3n; e2n = e3n; s3n = s4; e3n = e4;
     }
     return m;
 }
 
 template <int LEVEL>
-__global__ __launch_bounds__(TILE_THREADS, 7)
+__global__ __launch_bounds__(TILE_THREADS, 8)
 void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint8_t *__restrict__ u_order,
-                  const int32_t *__restrict__ u_tid, const uint32_t *__restrict__ u_tile_sbase)
+                  const int32_t *__restrict__ u_tid, const uint32_t *__restrict__ u_tile_sbase, const TileWin *__restrict__ u_tw)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
     __shared__ __attribute__((aligned(16))) uint16_t s_W[SLAB_ROWS * TILE_THREADS];
-    __shared__ __attribute__((aligned(16))) v4i_t s_ent[2 * FUSED_KEY_CAP];
+    __shared__ __attribute__((aligned(16))) v4i_t s_ent[2 * SLAB_KEY_CAP];
     __shared__ __attribute__((aligned(16))) uint8_t s_dir[3 * DIR_BYTES];
     __shared__ __attribute__((aligned(16))) TileWin s_tw;
-    __shared__ int s_wide;
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const FusedArgsK a = fused_args();
@@ -228,36 +226,45 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
     const int32_t tid0 = n_act ? u_tid[r0] : 0;
     const uint32_t sbase = u_tile_sbase[t];
-    v4i_t *const s_ent0 = s_ent, *const s_ent1 = s_ent + FUSED_KEY_CAP;
+    v4i_t *const s_ent0 = s_ent, *const s_ent1 = s_ent + SLAB_KEY_CAP;
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
-    // ---- one round trip: the tile's descriptor and window (k_walk_slab), the slot's read, the first rows of its exons
-    if ((int)threadIdx.x < SLAB_TW_VECS)
-        reinterpret_cast<int4 *>(&s_tw)[threadIdx.x] = reinterpret_cast<const int4 *>(sa->tw + t)[threadIdx.x];
-    if (threadIdx.x == 0) { s_wide = 0; if (t == 0u) *sa->ovf_cursor = 0ull; }   // (k_walk_slab is done with the outlier area)
+    // ---- one round trip behind the descriptor (scalar loads: uniform address): the tile's dictionary slices, its window
+    //      (k_walk_slab), the slot's read and the first four rows of its column -- all asked for before anything is looked at
+    const TileDesc d = u_tw[t].d;
+    const bool fast = (d.flags & TD_FAST) != 0;
+    const int w_n = fast ? (int)d.n_win : 0;
+    const uint32_t row_max = max((u_tile_sbase[t + 1u] - sbase) / SLAB_STRIDE, 1u) - 1u;     // last row of the tile's slab
+    const FusedDict dv = fused_load_dict(a, d);
+    int4 twv = make_int4(0, 0, 0, 0);
+    if ((int)threadIdx.x < SLAB_TW_VECS) twv = reinterpret_cast<const int4 *>(u_tw + t)[threadIdx.x];
     const bool active = threadIdx.x < n_act;
     const uint32_t at = r0 + (active ? threadIdx.x : 0u);
     uint32_t pre = 0u, r = r0;
     bool rev_in = false;
     const int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end;
-    uint32_t off = sbase + threadIdx.x;
-    ReadEnds re{0, 0, 0, 0};
+    const uint32_t off = sbase + threadIdx.x;
+    SlabRows q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { q.s[i] = 0; q.e[i] = 0; }
     if (active) {
         pre = ld32(sa->pre, at); r = r0 + (uint32_t)ld32(u_order, at); rev_in = ld32(sa->s_rev, at) != 0;
-        re.s0 = ld32(xs, off); re.e0 = ld32(xe, off);               // (an outlier's slab column holds nothing: read, not used)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {               // (an outlier's slab column holds nothing: read, not used)
+            const uint32_t ix = off + min((uint32_t)i, row_max) * SLAB_STRIDE;
+            q.s[i] = ld32(xs, ix); q.e[i] = ld32(xe, ix);
+        }
     }
+    if (threadIdx.x == 0 && t == 0u) *sa->ovf_cursor = 0ull;        // (k_walk_slab is done with the outlier area)
     const uint32_t n = pre >> 8;
     const bool outlier = (pre & I_PRE_DIRECT) != 0u;
     const int32_t tid = tid0;                                       // (sorted input: a tile is of one chromosome)
+    ReadEnds re{q.s[0], q.e[0], 0, 0};
     if (active && !outlier) { re.sl = ld32(xs, off + (n - 1u) * SLAB_STRIDE); re.el = ld32(xe, off + (n - 1u) * SLAB_STRIDE); }
-    __syncthreads();
-    const TileDesc d = s_tw.d;
-    const bool fast = (d.flags & TD_FAST) != 0;
-    const int w_n = fast ? (int)d.n_win : 0;
-    // ---- stage the dictionary slices, re-based to the tile's window
+    // ---- stage window and dictionary slices, re-based to the tile's window
+    if ((int)threadIdx.x < SLAB_TW_VECS) reinterpret_cast<int4 *>(&s_tw)[threadIdx.x] = twv;
     int my_wide = 0;
     if (fast) {
-        const FusedDict dv = fused_load_dict(a, d);
-        if ((int)threadIdx.x < FUSED_KEY_CAP) {
+        if ((int)threadIdx.x < SLAB_KEY_CAP) {
             const bool has_st = threadIdx.x < d.st_nk, has_en = threadIdx.x < d.en_nk;
             v4i_t e0, e1;
             e0.x = dv.xa.x; e0.y = dv.xa.y; e1.x = dv.xc.x; e1.y = dv.xc.y;
@@ -267,21 +274,23 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
                 e1.z = (int)rebase_mask((uint32_t)dv.xd.x, (uint32_t)dv.xd.y, dv.xc.z - d.j_lo);
                 e1.w = (int)rebase_mask((uint32_t)dv.xd.z, (uint32_t)dv.xd.w, dv.xc.z - d.j_lo);
             } else {
-                e0.z = (int)rebase_gaps(s_tw.win, w_n, (uint32_t)dv.xb.x, (uint32_t)dv.xb.y, dv.xa.z);
-                e0.w = (int)rebase_gaps(s_tw.win, w_n, (uint32_t)dv.xb.z, (uint32_t)dv.xb.w, dv.xa.z);
-                e1.z = (int)rebase_gaps(s_tw.win, w_n, (uint32_t)dv.xd.x, (uint32_t)dv.xd.y, dv.xc.z);
-                e1.w = (int)rebase_gaps(s_tw.win, w_n, (uint32_t)dv.xd.z, (uint32_t)dv.xd.w, dv.xc.z);
+                // (the window's transcript numbers: straight from the loaded vectors' home, they are not in LDS yet)
+                const int *const win = reinterpret_cast<const int *>(u_tw[t].win);
+                e0.z = (int)rebase_gaps(win, w_n, (uint32_t)dv.xb.x, (uint32_t)dv.xb.y, dv.xa.z);
+                e0.w = (int)rebase_gaps(win, w_n, (uint32_t)dv.xb.z, (uint32_t)dv.xb.w, dv.xa.z);
+                e1.z = (int)rebase_gaps(win, w_n, (uint32_t)dv.xd.x, (uint32_t)dv.xd.y, dv.xc.z);
+                e1.w = (int)rebase_gaps(win, w_n, (uint32_t)dv.xd.z, (uint32_t)dv.xd.w, dv.xc.z);
             }
             if (has_st) { s_ent0[threadIdx.x] = e0; if (dv.xa.w & SE_WIDE) my_wide = 1; }
             if (has_en) { s_ent1[threadIdx.x] = e1; if (dv.xc.w & SE_WIDE) my_wide = 1; }
         }
         if (d.nbk > 0) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int i = (int)threadIdx.x + q * TILE_THREADS;
+            for (int qq = 0; qq < 2; ++qq) {
+                const int i = (int)threadIdx.x + qq * TILE_THREADS;
                 if (i <= d.nbk) {
-                    s_dir0[i] = (uint8_t)(dv.dd[0][q] - d.st_r0); s_dir1[i] = (uint8_t)(dv.dd[1][q] - d.en_r0);
-                    s_rdir[i] = (uint8_t)(dv.dd[2][q] - d.st_r0);
+                    s_dir0[i] = (uint8_t)(dv.dd[0][qq] - d.st_r0); s_dir1[i] = (uint8_t)(dv.dd[1][qq] - d.en_r0);
+                    s_rdir[i] = (uint8_t)(dv.dd[2][qq] - d.st_r0);
                 }
             }
         }
@@ -289,9 +298,7 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
             s_dir0[d.nbk + (int)threadIdx.x] = (uint8_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint8_t)d.en_nk;
         }
     }
-    if (my_wide) s_wide = 1;
-    __syncthreads();
-    const int any_wide = s_wide;
+    const int any_wide = __syncthreads_or(my_wide);
     // ---- classification (device functions of the classic kernel)
     uint32_t info = n << 8; int ref = -1;
     bool redo = active && (!fast || outlier || any_wide != 0 || tid != d.tid || (n > 1 && (pre & I_PRE_INSANE) != 0u));
@@ -299,7 +306,7 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     const TileLds L{nullptr, nullptr, s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
     const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, s_tw.mask);
     redo = redo || vm.redo;
-    const SiteMasks sm = map_exons_slab(L, d, work && !redo && n > 1, xs, xe, off, n, vm.vpre);
+    const SiteMasks sm = map_exons_slab(L, d, work && !redo && n > 1, xs, xe, off, n, vm.vpre, q, row_max);
     uint8_t *const xf = a->f.ex_flag;
     if (work && !redo) {
         const Verdict vd = decide<LEVEL, (int)SLAB_STRIDE>(L, d, threadIdx.x, n, re, vm, sm, rev_in);
