@@ -150,13 +150,18 @@ typedef struct {
     const uint8_t *acc_ex_flag;
 } l2r_device_view;
 
-/* Average device time per kernel of the last l2r_run_timed(), milliseconds. */
+/* Average device time per kernel of the last l2r_run_timed(), milliseconds.  Stages 0..2 are the three kernels of the
+ * pipeline the engine chose for the uploaded records (l2r_stage_kernel() names them):
+ *     slab    (coordinate-sorted records, short CIGARs; default)  0 k_order, first run of an upload only (a layout of
+ *             the records: lane order of every tile, record fields in that order)  1 k_walk_slab (CIGAR -> exons, tile
+ *             descriptors)  2 k_probe_slab (annotation window, site probes, verdicts)
+ *     fused   (L2R_PIPELINE=fused)   0 k_order  1 -  2 k_fused
+ *     classic (unsorted records, long CIGARs, L2R_PIPELINE=classic)  0 k_pass_a  1 k_scan_tiles  2 k_classify_fast */
 #define L2R_N_STAGES 8
 typedef struct {
-    float stage_ms[L2R_N_STAGES];   /* 0 pass_a (exon counts, cursors, tile descriptors) 1 scan 2 classify_fast
-                                       3 classify_generic (redo list) 4 validate_junctions (+ recount)
+    float stage_ms[L2R_N_STAGES];   /* 0..2 see above  3 classify_generic (redo list) 4 validate_junctions (+ recount)
                                        5 scan of accepted counts 6 gather_accepted (records; exons of the tiles
-                                       classify_fast did not compact itself) 7 reserved */
+                                       the classification did not compact itself) 7 reserved */
     float total_ms;                 /* first launch -> last completion, per iteration */
     int32_t iters;
 } l2r_timing;
@@ -188,6 +193,7 @@ int          l2r_run(l2r_ctx *ctx);
 int          l2r_sync(l2r_ctx *ctx);
 /* `iters` back-to-back runs bracketed by HIP events on the context stream. */
 int          l2r_run_timed(l2r_ctx *ctx, int iters, l2r_timing *out);
+const char  *l2r_stage_kernel(l2r_ctx *ctx, int stage);                 /* kernel behind stage_ms[stage] ("" = none) */
 
 int          l2r_result_sizes(l2r_ctx *ctx, int64_t *n_reads, int64_t *n_exons,
                               int64_t *n_accepted, int64_t *n_accepted_exons);

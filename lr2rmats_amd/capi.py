@@ -28,6 +28,7 @@ EXPORTS = [
     "l2r_abi_version", "l2r_last_error", "l2r_device_count", "l2r_create", "l2r_destroy", "l2r_set_params",
     "l2r_set_outputs", "l2r_set_annotation", "l2r_set_junctions", "l2r_upload_reads", "l2r_run", "l2r_sync", "l2r_run_timed",
     "l2r_result_sizes", "l2r_download", "l2r_download_accepted", "l2r_device_view_get", "l2r_stream", "l2r_classify",
+    "l2r_stage_kernel",
 ]
 
 _i32p, _i64p, _u8p, _u32p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
@@ -110,6 +111,8 @@ def load_library():
         lib.l2r_run_timed.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.l2r_result_sizes.argtypes = [C.c_void_p, _i64p, _i64p, _i64p, _i64p]
         lib.l2r_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.l2r_stage_kernel.restype = C.c_char_p
+        lib.l2r_stage_kernel.argtypes = [C.c_void_p, C.c_int]
         _lib = lib
     return _lib
 
@@ -211,7 +214,10 @@ class Engine:
         t = CTiming()
         self._chk(self.lib.l2r_run_timed(self.ctx, iters, C.byref(t)))
         return {"total_ms": float(t.total_ms), "iters": int(t.iters),
-                "stage_ms": {STAGE_NAMES[i]: float(t.stage_ms[i]) for i in range(N_STAGES - 1)}}
+                "stage_ms": {STAGE_NAMES[i]: float(t.stage_ms[i]) for i in range(N_STAGES - 1)},
+                # the kernel behind every stage for the pipeline the engine chose for these records (slab / fused / classic)
+                "kernel_ms": {(self.lib.l2r_stage_kernel(self.ctx, i) or b"").decode(): float(t.stage_ms[i])
+                              for i in range(N_STAGES - 1) if self.lib.l2r_stage_kernel(self.ctx, i)}}
 
     def sizes(self):
         v = [C.c_int64(0) for _ in range(4)]

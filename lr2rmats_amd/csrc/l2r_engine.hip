@@ -917,14 +917,31 @@ int l2r_debug_counters(l2r_ctx *c, long long *out, int n)
     uint32_t redo = 0;
     if (c->totals.p) { HIP_TRY(hipMemcpyAsync(&redo, c->totals.p + 3, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     out[0] = redo; out[1] = c->n_wide; out[2] = c->n_compact; out[3] = c->n_tiles;
-    if (n >= 12 && c->desc.p && c->n_tiles > 0) {          // out[4 + k]: tiles that are not fast for reason k (k_pass_a), k = 0: fast
+    if (n >= 12) for (int k = 0; k < 8; ++k) out[4 + k] = 0;
+    if (n >= 12 && c->slab && c->ran && c->tw.p && c->n_tiles > 0) {     // slab pipeline: the descriptors k_walk_slab made
+        std::vector<TileWin> w((size_t)c->n_tiles);
+        HIP_TRY(hipMemcpyAsync(w.data(), c->tw.p, w.size() * sizeof(TileWin), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (const TileWin &t : w) out[4 + ((t.d.flags >> 8) & 7u)]++;
+    } else if (n >= 12 && !c->fused && c->desc.p && c->n_tiles > 0) {     // out[4 + k]: tiles that are not fast for reason k (k_pass_a), k = 0: fast
         std::vector<TileDesc> d((size_t)c->n_tiles);
         HIP_TRY(hipMemcpyAsync(d.data(), c->desc.p, d.size() * sizeof(TileDesc), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        for (int k = 0; k < 8; ++k) out[4 + k] = 0;
         for (const TileDesc &t : d) out[4 + ((t.flags >> 8) & 7u)]++;
     }
     return 0;
+}
+
+/* Which kernel(s) stand behind stage_ms[stage] of l2r_timing for the inputs and parameters now set (the pipeline is
+   chosen per upload: slab / fused for coordinate-sorted records with short CIGARs, classic otherwise). */
+const char *l2r_stage_kernel(l2r_ctx *c, int stage)
+{
+    if (!c || stage < 0 || stage >= L2R_N_STAGES) return "";
+    static const char *const classic[L2R_N_STAGES] = {"k_pass_a", "k_scan_tiles", "k_classify_fast", "k_classify_generic",
+                                                      "k_validate_sj", "k_scan_accepted", "k_gather_accepted", ""};
+    if (stage >= 3 || !c->fused) return classic[stage];
+    if (c->slab) return stage == 0 ? "k_order (first run of an upload only)" : stage == 1 ? "k_walk_slab" : "k_probe_slab";
+    return stage == 0 ? "k_order" : stage == 1 ? "" : "k_fused";
 }
 
 int l2r_run(l2r_ctx *c)
