@@ -113,7 +113,7 @@ struct TileWin {
     int win[WIN_TX];             // window member -> annotation index
     TileDesc d;
     uint32_t mask[2];            // members with one exon / without TX_COMPACT
-    uint32_t pad[2];
+    uint32_t pad[2];             // slab pipeline, pad[0]: byte w = largest exon count among the reads of wave w (k_walk_slab)
 };
 
 // The tile's dictionary slices and transcript window from its span [tlo, thi] on chromosome tid0 -- the descriptor

@@ -61,7 +61,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
                  const int32_t *__restrict__ u_tid, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase)
 {
     __shared__ int s_wmax[TILE_THREADS / WAVE];
-    __shared__ uint32_t s_wsum[TILE_THREADS / WAVE];
+    __shared__ uint32_t s_wsum[TILE_THREADS / WAVE], s_wn[TILE_THREADS / WAVE];
     __shared__ __attribute__((aligned(16))) TileWin s_tw;
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
@@ -149,7 +149,8 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     }
     const int m = wave_max(active ? el : INT32_MIN);
     const uint32_t wsum = wave_sum(active ? n : 0u);
-    if (lane == 0) { s_wmax[wv] = m; s_wsum[wv] = wsum; }
+    const int wn = wave_max((active && !outlier) ? (int)n : 0);
+    if (lane == 0) { s_wmax[wv] = m; s_wsum[wv] = wsum; s_wn[wv] = (uint32_t)min(wn, 255); }
     if (t == 0u && threadIdx.x == 0) {
         // the run's counters (this kernel is the first of a run, k_probe_slab the first to count): redo list, chunk cursor
         // of the accepted list, exon cursor.  (The cursor of the outlier area is cleared by k_probe_slab for the next run.)
@@ -161,6 +162,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     if (wv != TILE_THREADS / WAVE - 1) return;
     if (lane == 0) a->tile_total[t] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];   // (one word per tile: a single counter would serialise 156 k waves)
     make_descriptor(a, lane, tid0, pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), true, &s_tw, (uint32_t)SLAB_KEY_CAP);
+    if (lane == 0) s_tw.pad[0] = s_wn[0] | (s_wn[1] << 8) | (s_wn[2] << 16) | (s_wn[3] << 24);     // rows each wave of k_probe_slab has to look at
     for (int i = lane; i < SLAB_TW_VECS; i += WAVE) reinterpret_cast<int4 *>(sa->tw + t)[i] = reinterpret_cast<const int4 *>(&s_tw)[i];
 }
 
@@ -171,7 +173,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
 struct SlabRows { int s[4], e[4]; };
 __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const TileDesc &d, bool mapping, const int32_t *__restrict__ xs,
                                                     const int32_t *__restrict__ xe, uint32_t off, uint32_t n, uint32_t vpre,
-                                                    const SlabRows &q, uint32_t row_max)
+                                                    const SlabRows &q)
 {
     SiteMasks m{0xffffffffu, 0u, 0u, 0u};
     uint16_t *W = L.W + threadIdx.x;
@@ -181,7 +183,7 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
     for (int k = 0; k < k_max; ++k) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
         int s4 = 0, e4 = 0;
-        if (mapping) { const uint32_t i4 = off + min((uint32_t)k + 4u, row_max) * SLAB_STRIDE; s4 = ld32(xs, i4); e4 = ld32(xe, i4); }   // four rows in flight
+        if (mapping) { const uint32_t i4 = off + min((uint32_t)k + 4u, n - 1u) * SLAB_STRIDE; s4 = ld32(xs, i4); e4 = ld32(xe, i4); }   // four rows in flight
         const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
         const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
         const int s2 = s1;
@@ -233,7 +235,8 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     const TileDesc d = u_tw[t].d;
     const bool fast = (d.flags & TD_FAST) != 0;
     const int w_n = fast ? (int)d.n_win : 0;
-    const uint32_t row_max = max((u_tile_sbase[t + 1u] - sbase) / SLAB_STRIDE, 1u) - 1u;     // last row of the tile's slab
+    // the last row any read of this wave has (k_walk_slab): rows behind it are not asked for
+    const uint32_t row_max = max((u_tw[t].pad[0] >> (8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))) & 0xffu, 1u) - 1u;
     const FusedDict dv = fused_load_dict(a, d);
     int4 twv = make_int4(0, 0, 0, 0);
     if ((int)threadIdx.x < SLAB_TW_VECS) twv = reinterpret_cast<const int4 *>(u_tw + t)[threadIdx.x];
@@ -306,7 +309,7 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     const TileLds L{nullptr, nullptr, s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
     const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, s_tw.mask);
     redo = redo || vm.redo;
-    const SiteMasks sm = map_exons_slab(L, d, work && !redo && n > 1, xs, xe, off, n, vm.vpre, q, row_max);
+    const SiteMasks sm = map_exons_slab(L, d, work && !redo && n > 1, xs, xe, off, n, vm.vpre, q);
     uint8_t *const xf = a->f.ex_flag;
     if (work && !redo) {
         const Verdict vd = decide<LEVEL, (int)SLAB_STRIDE>(L, d, threadIdx.x, n, re, vm, sm, rev_in);
