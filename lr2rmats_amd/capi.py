@@ -75,6 +75,16 @@ class CTiming(C.Structure):
     _fields_ = [("stage_ms", C.c_float * N_STAGES), ("total_ms", C.c_float), ("iters", C.c_int32)]
 
 
+def accepted_mask(info: np.ndarray, has_sj: bool, split: bool) -> np.ndarray:
+    """Which reads check_trans() hands to novel_T / merge_trans (src/update_gtf.c:943-960), from the other info bits:
+    full, not known, has a known site; with a junction table additionally the junction check passed, or -s is set
+    (the read then goes on as split pieces).  The engine stores this as INFO_ACCEPTED."""
+    cand = (info & (INFO_FULL | INFO_KNOWN | INFO_KNOWN_SITE)) == (INFO_FULL | INFO_KNOWN_SITE)
+    if not has_sj:
+        return cand
+    return cand & (((info & INFO_SJ_PASS) != 0) | bool(split))
+
+
 ACC_REC_DTYPE = np.dtype([("read_lo", "<u4"), ("read_hi", "<u4"), ("info", "<u4"), ("ref_tx", "<i4")])
 
 

@@ -72,6 +72,7 @@ struct l2r_ctx {
     DevBuf<TileWin> tw;
     DevBuf<unsigned long long> ovf_cursor;
     uint32_t ovf_base = 0;
+    bool lin_valid = false;                 // lin_* hold the read-order exon arrays of the last run (read_order_arrays)
     bool slab_ordered = false;              // k_order has run for this upload (slab pipeline: its outputs depend on the records only)
     DevBuf<uint16_t> lub;                   // k_order: first LDS slot of every read
     DevBuf<uint32_t> tile_ub, tile_start, tile_total, tile_dest;
@@ -658,7 +659,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     c->n_reads = N; c->n_cigar = r->n_cigar; c->first_read = r->first_read_index;
-    c->ran = false; c->totals_valid = false; drop_graph(c);
+    c->ran = false; c->totals_valid = false; c->lin_valid = false; drop_graph(c);
     if (sorted) {
         // the annotation cursor after a sorted prefix is the prefix function of its last record
         if (N) {
@@ -967,7 +968,7 @@ int l2r_run(l2r_ctx *c)
     }
     if (graphable && c->graph_valid) HIP_TRY(hipGraphLaunch(c->graph, c->stream));
     else { rc = launch_all(c, nullptr); if (rc) return rc; }
-    c->ran = true; c->totals_valid = false;
+    c->ran = true; c->totals_valid = false; c->lin_valid = false;
     return 0;
 }
 
@@ -1030,7 +1031,7 @@ int l2r_run_timed(l2r_ctx *c, int iters, l2r_timing *out)
         for (int i = 0; i < ST_N; ++i) { float d = 0; HIP_TRY(hipEventElapsedTime(&d, ev[i], ev[i + 1])); out->stage_ms[i] += d / (float)iters; }
     }
     out->iters = iters;
-    c->ran = true; c->totals_valid = false;
+    c->ran = true; c->totals_valid = false; c->lin_valid = false;
     return 0;
 }
 
@@ -1047,6 +1048,48 @@ int l2r_result_sizes(l2r_ctx *c, int64_t *n_reads, int64_t *n_exons, int64_t *n_
     return 0;
 }
 
+/* The exon arrays of the last run in READ ORDER on the device (exon k of read i at off[i] + k, off = running sum of the
+   exon counts).  The classic pipeline writes them that way; the slab / fused pipelines keep their own layouts
+   (l2r_slab.hip.h, l2r_fused.hip.h) and are copied into place here, at HBM speed, once per run. */
+static int read_order_arrays(l2r_ctx *c, const uint32_t **off, const int32_t **xs, const int32_t **xe, const uint8_t **xf)
+{
+    const int64_t N = c->n_reads, X = c->h_totals[0];
+    if (!c->fused) { *off = c->ex_off.p; *xs = c->ex_start.p; *xe = c->ex_end.p; *xf = c->ex_flag.p; return 0; }
+    if (!c->lin_valid) {
+        if (c->lin_dest.ensure((size_t)N + 1) || c->lin_start.ensure((size_t)X + 1) || c->lin_end.ensure((size_t)X + 1) || c->lin_flag.ensure((size_t)X + 1)) return -2;
+        const unsigned gN = (unsigned)((N + TILE_THREADS - 1) / TILE_THREADS);
+        if (N) {
+            hipLaunchKernelGGL(k_exon_counts, dim3(gN), dim3(TILE_THREADS), 0, c->stream, N, (const uint32_t *)c->info.p, c->lin_dest.p);
+            ScanJobs jobs; jobs.job[0] = ScanJob{c->lin_dest.p, N, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
+            hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, jobs);
+        }
+        if (c->slab && X) {
+            // slabs: k_linearize_slab gathers every read's column into its place
+            hipLaunchKernelGGL(k_linearize_slab, dim3(gN), dim3(TILE_THREADS), 0, c->stream, N, (const uint32_t *)c->ex_off.p, (const uint32_t *)c->info.p,
+                               (const uint32_t *)c->lin_dest.p, (const int32_t *)c->ex_start.p, (const int32_t *)c->ex_end.p, (const uint8_t *)c->ex_flag.p,
+                               c->lin_start.p, c->lin_end.p, c->lin_flag.p);
+        } else if (X) {
+            // one chunk per tile, chunks in the order an atomic cursor handed them out: k_linearize moves the chunks
+            const size_t T = (size_t)c->n_tiles;
+            std::vector<uint32_t> tot(T), dest(T);
+            HIP_TRY(hipMemcpyAsync(tot.data(), c->tile_total.p, T * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            uint64_t run = 0;
+            for (size_t t = 0; t < T; ++t) { dest[t] = (uint32_t)run; run += tot[t]; }
+            if ((int64_t)run != X) return fail(-5, "[l2r_download] tile totals (%llu) do not add up to the exon count (%lld)", (unsigned long long)run, (long long)X);
+            HIP_TRY(hipMemcpyAsync(c->tile_dest.p, dest.data(), T * 4, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_linearize, dim3((unsigned)T), dim3(TILE_THREADS), 0, c->stream, (const uint32_t *)c->tile_start.p, (const uint32_t *)c->tile_dest.p,
+                               (const uint32_t *)c->tile_total.p, (const int32_t *)c->ex_start.p, (const int32_t *)c->ex_end.p, (const uint8_t *)c->ex_flag.p,
+                               c->lin_start.p, c->lin_end.p, c->lin_flag.p);
+            HIP_TRY(hipStreamSynchronize(c->stream));          // (dest is a local)
+        }
+        HIP_TRY(hipGetLastError());
+        c->lin_valid = true;
+    }
+    *off = c->lin_dest.p; *xs = c->lin_start.p; *xe = c->lin_end.p; *xf = c->lin_flag.p;
+    return 0;
+}
+
 int l2r_download(l2r_ctx *c, l2r_result *res)
 {
     if (!c || !res) return fail(-1, "[l2r_download] null argument");
@@ -1056,41 +1099,10 @@ int l2r_download(l2r_ctx *c, l2r_result *res)
     const int64_t N = c->n_reads, X = c->h_totals[0];
     if (res->n_reads < N || res->ex_cap < X) return fail(-3, "[l2r_download] buffers too small: need %lld reads, %lld exons", (long long)N, (long long)X);
     std::vector<uint32_t> off((size_t)N);
-    const int32_t *xs = c->ex_start.p, *xe = c->ex_end.p; const uint8_t *xf = c->ex_flag.p;
-    if (c->fused && c->slab && X) {
-        // the slab pipeline (l2r_slab.hip.h): read order = running sum of the exon counts, made on the device; k_linearize_slab
-        // gathers every read's column into its place (HBM speed, ahead of the PCIe copy)
-        if (c->lin_dest.ensure((size_t)N + 1) || c->lin_start.ensure((size_t)X) || c->lin_end.ensure((size_t)X) || c->lin_flag.ensure((size_t)X)) return -2;
-        const unsigned gN = (unsigned)((N + TILE_THREADS - 1) / TILE_THREADS);
-        hipLaunchKernelGGL(k_exon_counts, dim3(gN), dim3(TILE_THREADS), 0, c->stream, N, (const uint32_t *)c->info.p, c->lin_dest.p);
-        ScanJobs jobs; jobs.job[0] = ScanJob{c->lin_dest.p, N, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
-        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, jobs);
-        hipLaunchKernelGGL(k_linearize_slab, dim3(gN), dim3(TILE_THREADS), 0, c->stream, N, (const uint32_t *)c->ex_off.p, (const uint32_t *)c->info.p,
-                           (const uint32_t *)c->lin_dest.p, (const int32_t *)c->ex_start.p, (const int32_t *)c->ex_end.p, (const uint8_t *)c->ex_flag.p,
-                           c->lin_start.p, c->lin_end.p, c->lin_flag.p);
-        HIP_TRY(hipGetLastError());
-        xs = c->lin_start.p; xe = c->lin_end.p; xf = c->lin_flag.p;
-    } else if (c->fused && X) {
-        // the one-walk pipeline leaves the exon arrays as one chunk per tile, chunks in the order an atomic cursor handed
-        // them out (l2r_fused.hip.h): k_linearize copies them into read order on the device (HBM speed, ahead of the PCIe copy)
-        const size_t T = (size_t)c->n_tiles;
-        std::vector<uint32_t> tot(T), dest(T);
-        HIP_TRY(hipMemcpyAsync(tot.data(), c->tile_total.p, T * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        uint64_t run = 0;
-        for (size_t t = 0; t < T; ++t) { dest[t] = (uint32_t)run; run += tot[t]; }
-        if ((int64_t)run != X) return fail(-5, "[l2r_download] tile totals (%llu) do not add up to the exon count (%lld)", (unsigned long long)run, (long long)X);
-        if (c->lin_start.ensure((size_t)X) || c->lin_end.ensure((size_t)X) || c->lin_flag.ensure((size_t)X)) return -2;
-        HIP_TRY(hipMemcpyAsync(c->tile_dest.p, dest.data(), T * 4, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_linearize, dim3((unsigned)T), dim3(TILE_THREADS), 0, c->stream, (const uint32_t *)c->tile_start.p, (const uint32_t *)c->tile_dest.p,
-                           (const uint32_t *)c->tile_total.p, (const int32_t *)c->ex_start.p, (const int32_t *)c->ex_end.p, (const uint8_t *)c->ex_flag.p,
-                           c->lin_start.p, c->lin_end.p, c->lin_flag.p);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(c->stream));          // (dest is a local)
-        xs = c->lin_start.p; xe = c->lin_end.p; xf = c->lin_flag.p;
-    }
+    const int32_t *xs = nullptr, *xe = nullptr; const uint8_t *xf = nullptr; const uint32_t *d_off = nullptr;
+    if ((rc = read_order_arrays(c, &d_off, &xs, &xe, &xf))) return rc;
     if (N) {
-        if (!c->fused) HIP_TRY(hipMemcpyAsync(off.data(), c->ex_off.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+        if (!c->fused) HIP_TRY(hipMemcpyAsync(off.data(), d_off, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(res->info, c->info.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(res->ref_tx, c->ref_tx.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
     }
@@ -1176,7 +1188,11 @@ int l2r_device_view_get(l2r_ctx *c, l2r_device_view *v)
     int rc = fetch_totals(c);
     if (rc) return rc;
     v->n_reads = c->n_reads; v->n_exons = c->h_totals[0]; v->n_accepted = c->h_totals[1]; v->n_accepted_exons = c->h_totals[2];
-    v->ex_off = c->ex_off.p; v->ex_start = c->ex_start.p; v->ex_end = c->ex_end.p; v->ex_flag = c->ex_flag.p;
+    v->ex_off = nullptr; v->ex_start = nullptr; v->ex_end = nullptr; v->ex_flag = nullptr;
+    if (c->want & L2R_WANT_RESULTS) {
+        if ((rc = read_order_arrays(c, &v->ex_off, &v->ex_start, &v->ex_end, &v->ex_flag))) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));          // the caller reads them on streams of its own
+    }
     v->info = c->info.p; v->ref_tx = c->ref_tx.p;
     v->acc_rec = (const l2r_accepted_read *)c->acc_rec.p; v->acc_ex_off = c->acc_ex_off.p;
     v->acc_ex_start = c->acc_start.p; v->acc_ex_end = c->acc_end.p; v->acc_ex_flag = c->acc_flag.p;

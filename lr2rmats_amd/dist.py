@@ -7,13 +7,20 @@ Every rank parses the inputs with the C host library, takes a contiguous shard o
 (balanced by bytes per read; annotation and junction table replicated) and runs the gfx950 engine on
 its shard.  Then one of two routes gives the output files of the single-GPU run:
 
-* **partitioned** (reads grouped by chromosome, no ``-s`` with a junction table): the shards are cut at
+* **partitioned** (reads coordinate sorted, no ``-s`` with a junction table): the shards are cut at
   chromosome boundaries.  The order-dependent tail never looks across chromosomes (``merge_trans`` stops
   at a smaller tid, ``src/update_gtf.c:147``; the novel-exon / site / gene lists likewise), so every rank
   runs split / merge / writers on its own shard in parallel; the only collective is an all-gather of the 16
   summary counters, and rank 0 concatenates the part files in shard order.
-* **gathered** (anything else): the per-read result arrays are all-gathered (padded ``all_gather_into_tensor``,
-  rank order = read order) and rank 0 runs the tail once.
+* **gathered** (anything else): what the ranks' engines left in HBM is all-gathered from there (padded
+  ``all_gather_into_tensor``, no host copy on the way in) and rank 0 runs the tail once.  When no output lists
+  every read (``update-gtf ... > new.gtf``, ``-v``, ``-E``: the pipeline's first pass) the message is the engine's
+  compacted accepted list (16-byte records + their exons); otherwise it is the per-read result arrays.
+
+Records that are NOT coordinate sorted are classified by rank 0 alone: the annotation / junction cursors of the
+reference (``last_anno_i`` / ``last_sj_i``, ``src/update_gtf.c:938``) then depend on every earlier record, which a
+shard that starts in the middle does not have (the engine replays that history on the host, one context, one
+stream of uploads).  The other ranks idle; the output is the single-process output.
 """
 from __future__ import annotations
 
@@ -26,23 +33,115 @@ import numpy as np
 from . import capi, hostlib, workload
 
 
+def records_sorted(tid: np.ndarray, pos: np.ndarray) -> bool:
+    """The engine's criterion (l2r_upload_reads): (tid, pos) never decreases."""
+    if tid.shape[0] < 2:
+        return True
+    t0, t1, p0, p1 = tid[:-1], tid[1:], pos[:-1], pos[1:]
+    return not bool(np.any((t1 < t0) | ((t1 == t0) & (p1 < p0))))
+
+
+class HostShard:
+    """Results of a shard in host memory (the CPU classifier the gloo tests plug in)."""
+
+    def __init__(self, res: capi.Result, lo: int, has_sj: bool = False, split: bool = False):
+        self.res, self.lo, self.has_sj, self.split = res, lo, has_sj, split
+
+    def _t(self, arr, device):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()).to(device)
+
+    def full(self, device):
+        r = self.res
+        return {k: self._t(getattr(r, k), device) for k in ("info", "ref_tx", "ex_start", "ex_end", "ex_flag")}
+
+    def accepted(self, device):
+        r = self.res
+        idx = np.nonzero(capi.accepted_mask(r.info, self.has_sj, self.split))[0]
+        lens = (r.info[idx] >> 8).astype(np.int64)
+        g = workload.ragged_gather_index(r.ex_off[idx], lens)
+        rec = np.zeros(idx.shape[0], capi.ACC_REC_DTYPE)
+        gi = idx.astype(np.uint64) + np.uint64(self.lo)
+        rec["read_lo"] = (gi & np.uint64(0xffffffff)).astype(np.uint32); rec["read_hi"] = (gi >> np.uint64(32)).astype(np.uint32)
+        rec["info"] = r.info[idx] | capi.INFO_ACCEPTED; rec["ref_tx"] = r.ref_tx[idx]
+        off = np.zeros(idx.shape[0], np.uint32)
+        if idx.shape[0] > 1:
+            np.cumsum(lens[:-1], out=off[1:])
+        return {"rec": self._t(rec, device), "ex_off": self._t(off, device), "ex_start": self._t(r.ex_start[g], device),
+                "ex_end": self._t(r.ex_end[g], device), "ex_flag": self._t(r.ex_flag[g], device)}
+
+    def download(self) -> capi.Result:
+        return self.res
+
+
+class DeviceShard:
+    """Results of a shard where the engine left them: views of its HBM buffers (zero copy)."""
+
+    def __init__(self, eng: capi.Engine):
+        self.eng = eng
+
+    def full(self, device):
+        v = self.eng.device_view()
+        n, x = int(v.n_reads), int(v.n_exons)
+        b = workload.device_bytes
+        return {"info": b(v.info, 4 * n, device), "ref_tx": b(v.ref_tx, 4 * n, device), "ex_start": b(v.ex_start, 4 * x, device),
+                "ex_end": b(v.ex_end, 4 * x, device), "ex_flag": b(v.ex_flag, x, device)}
+
+    def accepted(self, device):
+        v = self.eng.device_view()
+        m, x = int(v.n_accepted), int(v.n_accepted_exons)
+        b = workload.device_bytes
+        return {"rec": b(v.acc_rec, 16 * m, device), "ex_off": b(v.acc_ex_off, 4 * m, device), "ex_start": b(v.acc_ex_start, 4 * x, device),
+                "ex_end": b(v.acc_ex_end, 4 * x, device), "ex_flag": b(v.acc_ex_flag, x, device)}
+
+    def download(self) -> capi.Result:
+        return self.eng.download()
+
+
 def _engine_classify(device_index: int):
-    """Default shard classifier: the HIP engine on this rank's GPU.  Returns device views when possible."""
+    """Default shard classifier: the HIP engine on this rank's GPU; the results stay in HBM."""
     eng = capi.Engine(device_index)
 
-    def run(job: hostlib.Job, lo: int, hi: int):
+    def run(job: hostlib.Job, lo: int, hi: int, want: int = capi.WANT_RESULTS):
         a = job.annotation_arrays()
         r = job.read_arrays()
         eng.set_params(job.prm)
+        eng.set_outputs(want)
         eng.set_annotation(a["tx_tid"], a["tx_start"], a["tx_end"], a["tx_rev"], a["tx_ex_off"], a["ex_start"], a["ex_end"])
         eng.set_junctions(job.junction_arrays())
         c0, c1 = int(r["cig_off"][lo]), int(r["cig_off"][hi])
         eng.upload_reads(r["tid"][lo:hi], r["pos"][lo:hi], r["rev"][lo:hi], r["cig_off"][lo:hi + 1] - c0, r["cig"][c0:c1], first_read_index=lo)
         eng.run()
         eng.sync()
-        return eng.download()
+        return DeviceShard(eng)
     run.engine = eng
     return run
+
+
+def assemble_accepted(parts):
+    """Rank 0 of the gathered route: the ranks' accepted lists (dicts of numpy byte arrays, rank order) -> one list in
+    input order.  A rank's list is made of per-tile chunks in the order its kernels handed them out
+    (include/lr2rmats_hip.h, l2r_device_view): the records are sorted by their 64-bit read index and the exons laid
+    out record by record.  Returns (read_idx, capi.Result of the accepted rows)."""
+    recs, offs, base = [], [], 0
+    for p in parts:
+        rec = p["rec"].view(capi.ACC_REC_DTYPE)
+        recs.append(rec)
+        offs.append(p["ex_off"].view(np.uint32).astype(np.int64) + base)
+        base += p["ex_start"].view(np.int32).shape[0]
+    rec = np.concatenate(recs) if recs else np.zeros(0, capi.ACC_REC_DTYPE)
+    off = np.concatenate(offs) if offs else np.zeros(0, np.int64)
+    xs = np.concatenate([p["ex_start"].view(np.int32) for p in parts]) if parts else np.zeros(0, np.int32)
+    xe = np.concatenate([p["ex_end"].view(np.int32) for p in parts]) if parts else np.zeros(0, np.int32)
+    xf = np.concatenate([p["ex_flag"].view(np.uint8) for p in parts]) if parts else np.zeros(0, np.uint8)
+    idx = rec["read_lo"].astype(np.int64) | (rec["read_hi"].astype(np.int64) << 32)
+    order = np.argsort(idx, kind="stable")
+    rec, off, idx = rec[order], off[order], idx[order]
+    lens = (rec["info"] >> 8).astype(np.int64)
+    g = workload.ragged_gather_index(off, lens)
+    new_off = np.zeros(rec.shape[0] + 1, np.int64)
+    np.cumsum(lens, out=new_off[1:])
+    return idx, capi.Result(new_off, xs[g], xe[g], xf[g], rec["info"].copy(), rec["ref_tx"].copy())
 
 
 def run(argv, classify: Optional[Callable] = None, backend: Optional[str] = None) -> int:
@@ -67,7 +166,8 @@ def run(argv, classify: Optional[Callable] = None, backend: Optional[str] = None
         torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+        # (L2R_DIST_BACKEND=gloo: tests that put several ranks on one GPU, which RCCL does not allow)
+        dist.init_process_group(backend or os.environ.get("L2R_DIST_BACKEND") or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
 
     job = hostlib.Job(list(argv), open_outputs=False)
     gtf_tmp = None
@@ -99,19 +199,37 @@ def run(argv, classify: Optional[Callable] = None, backend: Optional[str] = None
     weights = 4.0 * np.diff(r["cig_off"]) + 64.0           # ~ bytes a read costs (4c + 21n + 12)
     sj = job.junction_arrays()
     aligned = None
-    if world > 1 and not (job.prm.split_trans and sj is not None) and os.environ.get("L2R_DIST_GATHER") != "1":
+    in_order = records_sorted(r["tid"], r["pos"])
+    if world > 1 and in_order and not (job.prm.split_trans and sj is not None) and os.environ.get("L2R_DIST_GATHER") != "1":
         aligned = workload.aligned_shard_bounds(r["tid"], world, weights)
-    bounds = aligned if aligned is not None else workload.shard_bounds(n, world, weights)
+    if aligned is not None:
+        bounds = aligned
+    elif world > 1 and not in_order:
+        bounds = [(0, n)] + [(n, n)] * (world - 1)         # cursor history: one rank, one stream of records (see the module text)
+        if rank == 0:
+            print("[lr2rmats_amd.dist] records are not coordinate sorted: rank 0 classifies all of them", file=sys.stderr)
+    else:
+        bounds = workload.shard_bounds(n, world, weights)
     lo, hi = bounds[rank]
+    accepted_only = aligned is None and world > 1 and not job.needs_all_reads()
+    if rank == 0 and os.environ.get("L2R_DIST_TRACE"):      # tests: which route ran
+        with open(os.environ["L2R_DIST_TRACE"], "w") as fh:
+            fh.write(("partitioned" if aligned is not None else ("one rank, " if (world > 1 and not in_order) else "") + "gathered " +
+                      ("accepted" if accepted_only else "full")) + "\n")
     if classify is None:
         classify = _engine_classify(local_rank)
+    z = np.zeros(0, np.int32)
+    empty = HostShard(capi.Result(np.zeros(1, np.int64), z, z, np.zeros(0, np.uint8), np.zeros(0, np.uint32), z), lo)
     if hi > lo:
-        res = classify(job, lo, hi)
+        # (the engine is told which output to make; a plugged-in classifier returns a capi.Result of its shard)
+        shard = classify(job, lo, hi, capi.WANT_ACCEPTED) if (accepted_only and hasattr(classify, "engine")) else classify(job, lo, hi)
+        if isinstance(shard, capi.Result):
+            shard = HostShard(shard, lo, sj is not None, bool(job.prm.split_trans))
     else:
-        z = np.zeros(0, np.int32)
-        res = capi.Result(np.zeros(1, np.int64), z, z, np.zeros(0, np.uint8), np.zeros(0, np.uint32), z)
+        shard = empty
 
     if world == 1:
+        res = shard.download()
         job.open_outputs()
         rc = job.finish(res.ex_off, res.ex_start, res.ex_end, res.ex_flag, res.info, res.ref_tx)
         job.close()
@@ -121,8 +239,9 @@ def run(argv, classify: Optional[Callable] = None, backend: Optional[str] = None
     if aligned is not None:
         # partitioned route: every rank writes its part, rank 0 concatenates
         suffix = ".part%03d" % rank
+        res = shard.download()
         cnt = job.finish_part(lo, hi, res.ex_off, res.ex_start, res.ex_end, res.ex_flag, res.info, res.ref_tx, suffix, "", rank == 0)
-        t = torch.from_numpy(cnt).to(device)
+        t = torch.from_numpy(cnt).to(device if dist.get_backend() == "nccl" else "cpu")
         allc = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allc, t)
         dist.barrier()
@@ -151,23 +270,31 @@ def run(argv, classify: Optional[Callable] = None, backend: Optional[str] = None
 
     if rank == 0:                                           # gathered route: rank 0 owns the output files
         job.open_outputs()
-    # all-gatherv of the shard results, rank order = read order
-    def gather(arr: np.ndarray):
-        t = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)).to(device)
-        outs, _ = workload.all_gatherv(t)
-        return [o.cpu().numpy() for o in outs]
+    # all-gatherv of what the shards left on the device, rank order = read order; one host copy on rank 0
+    def gather(tensors: dict):
+        out = []
+        for k in sorted(tensors):
+            parts, _ = workload.all_gatherv(tensors[k])
+            out.append((k, [p.cpu().numpy() for p in parts] if rank == 0 else None))
+        return [{k: parts[w] for k, parts in out} for w in range(world)] if rank == 0 else None
 
-    parts = {k: gather(getattr(res, k)) for k in ("ex_start", "ex_end", "ex_flag", "info", "ref_tx")}
     rc = 0
-    if rank == 0:
-        info = np.concatenate([p.view(np.uint32) for p in parts["info"]])
-        ref = np.concatenate([p.view(np.int32) for p in parts["ref_tx"]])
-        xs = np.concatenate([p.view(np.int32) for p in parts["ex_start"]])
-        xe = np.concatenate([p.view(np.int32) for p in parts["ex_end"]])
-        xf = np.concatenate(parts["ex_flag"])
-        off = np.zeros(info.shape[0] + 1, np.int64)
-        np.cumsum(info >> 8, out=off[1:])
-        rc = job.finish(off, xs, xe, xf, info, ref)
+    if accepted_only:
+        parts = gather(shard.accepted(device))
+        if rank == 0:
+            idx, res = assemble_accepted(parts)
+            rc = job.finish_accepted(idx, res.ex_off, res.ex_start, res.ex_end, res.ex_flag, res.info, res.ref_tx)
+    else:
+        parts = gather(shard.full(device))
+        if rank == 0:
+            info = np.concatenate([p["info"].view(np.uint32) for p in parts])
+            ref = np.concatenate([p["ref_tx"].view(np.int32) for p in parts])
+            xs = np.concatenate([p["ex_start"].view(np.int32) for p in parts])
+            xe = np.concatenate([p["ex_end"].view(np.int32) for p in parts])
+            xf = np.concatenate([p["ex_flag"].view(np.uint8) for p in parts])
+            off = np.zeros(info.shape[0] + 1, np.int64)
+            np.cumsum(info >> 8, out=off[1:])
+            rc = job.finish(off, xs, xe, xf, info, ref)
     dist.barrier()
     job.close()
     emit_stdout()

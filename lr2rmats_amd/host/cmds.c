@@ -508,6 +508,33 @@ static int needs_all_reads(const h_job *j)
     return j->o.bam_gtf || j->o.bam_detail || j->o.known_gtf || j->o.unrecog_gtf || j->o.summary ||
            j->out_path[2] || j->out_path[3] || j->out_path[4] || j->out_path[6] || j->out_path[7];
 }
+int h_job_needs_all_reads(const h_job *j) { return needs_all_reads(j); }
+
+/* The tail over the accepted reads alone: `res` = their rows in input order, read_idx[k] = input index of row k.  The
+ * tail sees a view of the input records that keeps just them (routing, split, merge and the writers of the updated GTF /
+ * novel GTF / exon bed only ever look at the reads check_trans() accepted, update_gtf.c:946-960). */
+int h_job_finish_accepted(h_job *j, const l2r_result *res, const int64_t *read_idx)
+{
+    if (needs_all_reads(j)) h_fatal("update_gtf", "an output of this run needs every read: the accepted reads alone do not do");
+    h_reads *rd = &j->reads;
+    const int64_t m = res->n_reads;
+    int32_t *tid = (int32_t *)h_malloc((size_t)(m + 1) * 4), *pos = (int32_t *)h_malloc((size_t)(m + 1) * 4);
+    uint8_t *rev = (uint8_t *)h_malloc((size_t)m + 1);
+    uint32_t *qn = (uint32_t *)h_malloc((size_t)(m + 1) * 4), *tn = rd->tid_name ? (uint32_t *)h_malloc((size_t)(m + 1) * 4) : NULL;
+    for (int64_t k = 0; k < m; ++k) {
+        const int64_t i = read_idx[k];
+        if (i < 0 || i >= rd->n) h_fatal("update_gtf", "accepted record %lld points at read %lld of %lld", (long long)k, (long long)i, (long long)rd->n);
+        if (k && i <= read_idx[k - 1]) h_fatal("update_gtf", "accepted records are not in input order at row %lld", (long long)k);
+        tid[k] = rd->tid[i]; pos[k] = rd->pos[i]; rev[k] = rd->rev[i]; qn[k] = rd->qname[i];
+        if (tn) tn[k] = rd->tid_name[i];
+    }
+    int32_t *o_tid = rd->tid, *o_pos = rd->pos; uint8_t *o_rev = rd->rev; uint32_t *o_qn = rd->qname, *o_tn = rd->tid_name; const int64_t o_n = rd->n;
+    rd->tid = tid; rd->pos = pos; rd->rev = rev; rd->qname = qn; rd->tid_name = tn; rd->n = m;      /* (cig_off is not read by the tail) */
+    const int rc = h_job_finish(j, res);
+    rd->tid = o_tid; rd->pos = o_pos; rd->rev = o_rev; rd->qname = o_qn; rd->tid_name = o_tn; rd->n = o_n;
+    free(tid); free(pos); free(rev); free(qn); free(tn);
+    return rc;
+}
 
 int h_cmd_update_gtf(int argc, char **argv)
 {
@@ -524,26 +551,11 @@ int h_cmd_update_gtf(int argc, char **argv)
         l2r_result res = { out.n, out.n_ex, out.n_ex, out.ex_off, out.ex_start, out.ex_end, out.ex_flag, out.info, out.ref_tx };
         rc = h_job_finish(j, &res);
     } else {
-        /* the tail runs over the accepted reads alone: a view of the input records that keeps just them */
         int64_t *idx = NULL;
         run_engine("update_gtf", &prm, &a, &s, &r, &out, &idx);
-        h_reads *rd = &j->reads;
-        const int64_t m = out.n;
-        int32_t *tid = (int32_t *)h_malloc((size_t)(m + 1) * 4), *pos = (int32_t *)h_malloc((size_t)(m + 1) * 4);
-        uint8_t *rev = (uint8_t *)h_malloc((size_t)m + 1);
-        uint32_t *qn = (uint32_t *)h_malloc((size_t)(m + 1) * 4), *tn = rd->tid_name ? (uint32_t *)h_malloc((size_t)(m + 1) * 4) : NULL;
-        for (int64_t k = 0; k < m; ++k) {
-            const int64_t i = idx[k];
-            if (i < 0 || i >= rd->n) h_fatal("update_gtf", "accepted record %lld points at read %lld of %lld", (long long)k, (long long)i, (long long)rd->n);
-            tid[k] = rd->tid[i]; pos[k] = rd->pos[i]; rev[k] = rd->rev[i]; qn[k] = rd->qname[i];
-            if (tn) tn[k] = rd->tid_name[i];
-        }
-        int32_t *o_tid = rd->tid, *o_pos = rd->pos; uint8_t *o_rev = rd->rev; uint32_t *o_qn = rd->qname, *o_tn = rd->tid_name; const int64_t o_n = rd->n;
-        rd->tid = tid; rd->pos = pos; rd->rev = rev; rd->qname = qn; rd->tid_name = tn; rd->n = m;      /* (cig_off is not read by the tail) */
         l2r_result res = { out.n, out.n_ex, out.n_ex, out.ex_off, out.ex_start, out.ex_end, out.ex_flag, out.info, out.ref_tx };
-        rc = h_job_finish(j, &res);
-        rd->tid = o_tid; rd->pos = o_pos; rd->rev = o_rev; rd->qname = o_qn; rd->tid_name = o_tn; rd->n = o_n;
-        free(tid); free(pos); free(rev); free(qn); free(tn); free(idx);
+        rc = h_job_finish_accepted(j, &res, idx);
+        free(idx);
     }
     h_stage_time("merge + writers");
     h_result_free(&out);

@@ -117,6 +117,12 @@ h_job *h_job_open2(int argc, char **argv, int *exit_code, int open_outputs);   /
 void   h_job_views(h_job *j, l2r_params *prm, l2r_annotation *anno, l2r_junctions *sj, l2r_reads *reads);
 int    h_job_finish(h_job *j, const l2r_result *res);
 void   h_job_free(h_job *j);
+/* 1: an output of this run lists every read (detail.txt, -a / -k / -u, summary.txt); 0: the accepted reads are all the
+ * tail needs (`update-gtf ... > new.gtf`, -v, -E) and h_job_finish_accepted() may be used */
+int    h_job_needs_all_reads(const h_job *j);
+/* finish with the rows of the accepted reads only (l2r_download_accepted, or the records gathered from several GPUs):
+ * res->n_reads rows in input order, read_idx[k] = input index of row k */
+int    h_job_finish_accepted(h_job *j, const l2r_result *res, const int64_t *read_idx);
 
 /* Partitioned form (one-process-per-GPU runs whose read shards are cut at chromosome boundaries: the order-dependent
  * tail never looks across chromosomes -- merge_trans stops at a smaller tid, src/update_gtf.c:147, the novel-exon

@@ -37,6 +37,10 @@ def load_library():
         lib.h_job_finish.argtypes = [C.c_void_p, C.c_void_p]
         lib.h_job_finish.restype = C.c_int
         lib.h_job_free.argtypes = [C.c_void_p]
+        lib.h_job_needs_all_reads.argtypes = [C.c_void_p]
+        lib.h_job_needs_all_reads.restype = C.c_int
+        lib.h_job_finish_accepted.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        lib.h_job_finish_accepted.restype = C.c_int
         lib.h_job_finish_part.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]
         lib.h_job_finish_part.restype = C.c_int
         lib.h_job_out_path.argtypes = [C.c_void_p, C.c_int]
@@ -102,6 +106,20 @@ class Job:
         res = capi.CResult(n, x, x, keep[0].ctypes.data_as(capi._i64p), keep[1].ctypes.data_as(capi._i32p), keep[2].ctypes.data_as(capi._i32p),
                            keep[3].ctypes.data_as(capi._u8p), keep[4].ctypes.data_as(capi._u32p), keep[5].ctypes.data_as(capi._i32p))
         return self.lib.h_job_finish(self.h, C.byref(res))
+
+    def needs_all_reads(self) -> bool:
+        """An output of this run lists every read (detail.txt, -a / -k / -u, summary.txt)."""
+        return bool(self.lib.h_job_needs_all_reads(self.h))
+
+    def finish_accepted(self, read_idx, ex_off, ex_start, ex_end, ex_flag, info, ref_tx) -> int:
+        """Tail + writers with the rows of the accepted reads only (input order; read_idx[k] = input index of row k)."""
+        n, x = int(info.shape[0]), int(ex_start.shape[0])
+        keep = [np.ascontiguousarray(ex_off, np.int64), np.ascontiguousarray(ex_start, np.int32), np.ascontiguousarray(ex_end, np.int32),
+                np.ascontiguousarray(ex_flag, np.uint8), np.ascontiguousarray(info, np.uint32), np.ascontiguousarray(ref_tx, np.int32)]
+        idx = np.ascontiguousarray(read_idx, np.int64)
+        res = capi.CResult(n, x, x, keep[0].ctypes.data_as(capi._i64p), keep[1].ctypes.data_as(capi._i32p), keep[2].ctypes.data_as(capi._i32p),
+                           keep[3].ctypes.data_as(capi._u8p), keep[4].ctypes.data_as(capi._u32p), keep[5].ctypes.data_as(capi._i32p))
+        return self.lib.h_job_finish_accepted(self.h, C.byref(res), idx.ctypes.data_as(C.POINTER(C.c_int64)))
 
     # ---- partitioned tail (shards cut at chromosome boundaries; see l2r_host.h h_job_finish_part)
     N_SUMMARY = 16

@@ -96,6 +96,11 @@ def device_bytes(ptr: int, nbytes: int, device):
     return torch.as_tensor(_DevArray(ptr, nbytes), device=device)
 
 
+def ragged_gather_index(starts: np.ndarray, lens: np.ndarray) -> np.ndarray:
+    """Flat indices for concatenating the slices [starts[i], starts[i] + lens[i])."""
+    return synth._ragged_gather_index(np.asarray(starts), np.asarray(lens))
+
+
 def all_gatherv(t, group=None, counts=None):
     """All-gather of 1-D uint8 tensors of different lengths, rank order preserved.
 
@@ -106,6 +111,8 @@ def all_gatherv(t, group=None, counts=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        t = t.cpu()             # a CPU transport (gloo: tests that put two ranks on one GPU) -- staged through the host
     if counts is None:
         n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
         allc = [torch.zeros_like(n) for _ in range(world)]

@@ -117,6 +117,68 @@ def test_split_with_junctions_takes_the_gathered_route_and_stdout(oracle, tmp_pa
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("extra", [(), ("-s",)])
+def test_gathered_route_sends_only_the_accepted_reads_when_no_output_lists_every_read(oracle, tmp_path, inputs, extra):
+    # `update-gtf ... -o new.gtf -v novel.gtf -E bed`: the message of the all-gatherv is the accepted list (records + exons),
+    # rank 0 sorts the chunks into input order and runs the tail over those reads alone
+    d, anno, reads, sam, gtf = inputs
+    from tests import util
+    af = anno.in_file_order()
+    sj_args = []
+    if extra:
+        base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3))
+        j, _ = util.junction_table(af, reads, base, 52, cover=0.6)
+        tab = str(tmp_path / "SJ.out.tab")
+        j.write(tab)
+        sj_args = ["-s", "-J", "1", "-j", tab]
+    names = ("gtf", "novel", "bed")
+    single = {k: str(tmp_path / ("s." + k)) for k in names}
+    multi = {k: str(tmp_path / ("m." + k)) for k in names}
+    args = lambda o: ["update-gtf", "-l", "3"] + sj_args + ["-v", o["novel"], "-E", o["bed"], "-o", o["gtf"], sam, gtf]
+    assert oracle.run_cli(args(single)) == 0
+    _run_ranks(3, args(multi), {"L2R_DIST_GATHER": "1", "L2R_DIST_TRACE": str(tmp_path / "trace")})
+    for k in names:
+        assert filecmp.cmp(single[k], multi[k], shallow=False), k
+    assert os.path.getsize(single["gtf"]) > 10000
+    assert open(str(tmp_path / "trace")).read().strip() == "gathered accepted"
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("grouped", [True, False])
+def test_unsorted_records_are_classified_by_one_rank(oracle, tmp_path, inputs, grouped):
+    # records that are not coordinate sorted: the reference's cursors depend on every earlier record, so a shard that
+    # starts in the middle would classify differently -- rank 0 takes them all; files = single process
+    d, anno, reads, sam, gtf = inputs
+    rng = np.random.default_rng(7)
+    lines = open(sam).read().splitlines(keepends=True)
+    hdr = [l for l in lines if l.startswith("@")]
+    body = [l for l in lines if not l.startswith("@")]
+    if grouped:         # chromosome blocks stay together, order inside a block is shuffled
+        by = {}
+        for l in body:
+            by.setdefault(l.split("\t")[2], []).append(l)
+        body = []
+        for k in by:
+            body += [by[k][i] for i in rng.permutation(len(by[k]))]
+    else:
+        body = [body[i] for i in rng.permutation(len(body))]
+    usam = str(tmp_path / "u.sam")
+    open(usam, "w").write("".join(hdr + body))
+    single = {k: str(tmp_path / ("s." + k)) for k in KEYS}
+    multi = {k: str(tmp_path / ("m." + k)) for k in KEYS}
+    assert oracle.run_cli(_args(single, usam, gtf)) == 0
+    _run_ranks(2, _args(multi, usam, gtf), {"L2R_DIST_TRACE": str(tmp_path / "trace")})
+    for k in KEYS:
+        assert filecmp.cmp(single[k], multi[k], shallow=False), k
+    assert open(str(tmp_path / "trace")).read().strip() == "one rank, gathered full"
+    # and the sorted run of the same records is a different classification for some reads: the test would not notice
+    # a wrong route otherwise
+    s2 = {k: str(tmp_path / ("t." + k)) for k in KEYS}
+    assert oracle.run_cli(_args(s2, sam, gtf)) == 0
+    assert not filecmp.cmp(single["summary"], s2["summary"], shallow=False) or not filecmp.cmp(single["known"], s2["known"], shallow=False)
+
+
+@pytest.mark.timeout(300)
 def test_partitioned_route_to_stdout(oracle, tmp_path, inputs):
     d, anno, reads, sam, gtf = inputs
     a, b = str(tmp_path / "s.gtf"), str(tmp_path / "m.gtf")

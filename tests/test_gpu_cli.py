@@ -182,3 +182,50 @@ def test_accepted_route_writes_the_same_files(oracle, tmp_path, files, extra):
         for k in want:
             assert filecmp.cmp(want[k], got[k], shallow=False), (tag, k)
         assert os.path.getsize(got["gtf"]) > 1000
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("route", ["partitioned", "gathered_full", "gathered_accepted", "unsorted"])
+def test_ranks_on_the_engine_write_the_single_gpu_files(oracle, tmp_path, files, route):
+    """`python -m lr2rmats_amd.dist` with the real engine behind every rank: three ranks share GPU 0 (gloo as the
+    transport: RCCL wants one GPU per rank, the driver's 8-GPU run covers that); the shard results are read from the
+    engines' HBM buffers (l2r_device_view_get), gathered, and the files equal the ones of the one-process CLI."""
+    import subprocess
+    import sys
+    d, anno, reads, sam, bam, gtf = files
+    aln = bam
+    if route == "unsorted":
+        aln = str(tmp_path / "u.bam")
+        synth.write_bam(synth.make_reads(anno, 20000, 5, 45, unsorted=True), aln)
+    if route == "gathered_accepted":
+        names = ("gtf", "bed", "novel")
+        args = lambda o: ["update-gtf", "-l", "3", "-E", o["bed"], "-v", o["novel"], "-o", o["gtf"], aln, gtf]
+    else:
+        names = OUTS
+        args = lambda o: _args(["-l", "3"], o, aln, gtf)
+    one = {k: str(tmp_path / ("one." + k)) for k in names}
+    many = {k: str(tmp_path / ("many." + k)) for k in names}
+    r = hostlib.run_cli(args(one))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    world, port, procs = 3, _free_port(), []
+    trace = str(tmp_path / "trace")
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   L2R_DIST_BACKEND="gloo", L2R_DIST_TRACE=trace, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if route.startswith("gathered"):
+            env["L2R_DIST_GATHER"] = "1"
+        procs.append(subprocess.Popen([sys.executable, "-m", "lr2rmats_amd.dist"] + args(many), env=env, stderr=subprocess.PIPE,
+                                      stdout=subprocess.DEVNULL, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    for p in procs:
+        _, err = p.communicate(timeout=500)
+        assert p.returncode == 0, err.decode()[-3000:]
+    for k in names:
+        assert filecmp.cmp(one[k], many[k], shallow=False), (route, k)
+    want = {"partitioned": "partitioned", "gathered_full": "gathered full", "gathered_accepted": "gathered accepted",
+            "unsorted": "one rank, gathered full"}[route]
+    assert open(trace).read().strip() == want
