@@ -241,6 +241,13 @@ def run(argv, classify: Optional[Callable] = None, backend: Optional[str] = None
         suffix = ".part%03d" % rank
         res = shard.download()
         cnt = job.finish_part(lo, hi, res.ex_off, res.ex_start, res.ex_end, res.ex_flag, res.info, res.ref_tx, suffix, "", rank == 0)
+        # gene lists: an id equal to the last entry of the parts before this one is not counted again (hostlib.Job.part_last_genes)
+        lasts = [None] * world
+        dist.all_gather_object(lasts, job.part_last_genes())
+        for q in range(2):
+            before = [l[q] for l in lasts[:rank] if l[q] is not None]
+            if before and job.part_has_first_gene(q, before[-1]):
+                cnt[job.GENE_COUNTERS[q]] -= 1
         t = torch.from_numpy(cnt).to(device if dist.get_backend() == "nccl" else "cpu")
         allc = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allc, t)

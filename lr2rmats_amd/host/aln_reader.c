@@ -63,6 +63,11 @@ static void *bgzf_worker(void *arg)
             z.next_out = jb->out + b->out_off; z.avail_out = (uInt)b->out_len;
             const int rc = inflate(&z, Z_FINISH);
             if (rc != Z_STREAM_END || z.avail_out != 0) { jb->failed = 1; break; }
+            /* the block's CRC32 of the inflated bytes sits before ISIZE (htslib checks it too: a damaged block that still
+               inflates to ISIZE bytes must not pass) */
+            const uint8_t *t = jb->in + b->in_off + b->in_len;
+            const uLong want = (uLong)t[0] | ((uLong)t[1] << 8) | ((uLong)t[2] << 16) | ((uLong)t[3] << 24);
+            if (crc32(crc32(0L, Z_NULL, 0), jb->out + b->out_off, (uInt)b->out_len) != want) { jb->failed = 2; break; }
         }
     }
     inflateEnd(&z);
@@ -112,7 +117,7 @@ static blob slurp(const char *fn, const char *who)
     bgzf_worker(&jb);
     for (long k = 1; k < n_thr; ++k) pthread_join(th[k], NULL);
     pthread_mutex_destroy(&jb.mu);
-    if (jb.failed) h_fatal(who, "corrupt BGZF block in \"%s\"", fn);
+    if (jb.failed) h_fatal(who, jb.failed == 2 ? "CRC32 mismatch in a BGZF block of \"%s\"" : "corrupt BGZF block in \"%s\"", fn);
     free(blk); free(raw);
     return b;
 }

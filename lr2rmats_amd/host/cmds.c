@@ -27,6 +27,7 @@ struct h_job {
     int mode;
     l2r_params engine_prm;       /* what the engine gets: o.prm, except that `-m g` input passes its exons through unchanged */
     char *out_path[8];           /* 0 updated gtf (NULL = stdout), 1 exon bed, 2 bam gtf, 3 detail, 4 known, 5 novel, 6 unrecog, 7 summary */
+    h_part_genes part_genes;     /* of the part h_job_finish_part last ran */
 };
 
 static int g_open_outputs = 1;
@@ -279,6 +280,7 @@ int h_job_finish_part(h_job *j, int64_t lo, int64_t hi, const l2r_result *res, c
     o.exon_bed = open_part(j->out_path[1], suffix); o.bam_gtf = open_part(j->out_path[2], suffix); o.bam_detail = open_part(j->out_path[3], suffix);
     o.known_gtf = open_part(j->out_path[4], suffix); o.novel_gtf = open_part(j->out_path[5], suffix); o.unrecog_gtf = open_part(j->out_path[6], suffix);
     o.summary = NULL; o.summary_counts = counters; o.no_detail_header = !first_part;
+    h_part_genes_free(&j->part_genes); o.part_genes = &j->part_genes;
     if (!o.out_gtf) h_fatal("update_gtf", "a partitioned run needs -o or a base path for the updated GTF");
     h_reads part = j->reads;                                   /* a view: per-read arrays shifted, string table shared */
     part.n = hi - lo; part.tid += lo; part.pos += lo; part.rev += lo; part.qname += lo; part.cig_off += lo;
@@ -301,6 +303,7 @@ int h_job_finish_part(h_job *j, int64_t lo, int64_t hi, const l2r_result *res, c
 typedef struct {
     h_job *j; const l2r_result *res; int64_t lo, hi; int first;
     char *buf[7]; size_t len[7]; int64_t cnt[H_N_SUMMARY];
+    h_part_genes genes;
 } tail_part;
 
 static void *tail_part_main(void *arg)
@@ -316,7 +319,7 @@ static void *tail_part_main(void *arg)
         if (want[k] && !fs[k]) h_fatal("update_gtf", "open_memstream failed");
     }
     o.out_gtf = fs[0]; o.exon_bed = fs[1]; o.bam_gtf = fs[2]; o.bam_detail = fs[3]; o.known_gtf = fs[4]; o.novel_gtf = fs[5]; o.unrecog_gtf = fs[6];
-    o.summary = NULL; o.summary_counts = t->cnt; o.no_detail_header = !t->first;
+    o.summary = NULL; o.summary_counts = t->cnt; o.no_detail_header = !t->first; o.part_genes = &t->genes;
     h_reads part = j->reads;
     part.n = t->hi - t->lo; part.tid += t->lo; part.pos += t->lo; part.rev += t->lo; part.qname += t->lo; part.cig_off += t->lo;
     if (part.tid_name) part.tid_name += t->lo;
@@ -371,12 +374,19 @@ static int finish_threaded(h_job *j, const l2r_result *res, int n_thr)
     }
     int64_t total[H_N_SUMMARY]; memset(total, 0, sizeof total);
     FILE *outs[7] = {j->o.out_gtf, j->o.exon_bed, j->o.bam_gtf, j->o.bam_detail, j->o.known_gtf, j->o.novel_gtf, j->o.unrecog_gtf};
+    const char *last_gene[2] = {NULL, NULL};                /* gene_id of the last entry of the two gene lists so far (h_part_genes) */
+    static const int gene_cnt[2] = {H_CNT_UPDATED_GENES, H_CNT_KNOWN_GENES};
     for (int k = 0; k < n_thr; ++k) {
         pthread_join(th[k], NULL);
         for (int q = 0; q < 7; ++q) if (outs[q] && parts[k].len[q]) fwrite(parts[k].buf[q], 1, parts[k].len[q], outs[q]);
         for (int q = 0; q < 7; ++q) free(parts[k].buf[q]);
         for (int q = 0; q < H_N_SUMMARY; ++q) total[q] += parts[k].cnt[q];
+        for (int q = 0; q < 2; ++q) {
+            if (h_part_genes_has_first(&parts[k].genes, q, last_gene[q])) total[gene_cnt[q]] -= 1;       /* the sequential list would not have taken it */
+            if (parts[k].genes.last_gid[q]) last_gene[q] = parts[k].genes.last_gid[q];
+        }
     }
+    for (int k = 0; k < n_thr; ++k) h_part_genes_free(&parts[k].genes);
     if (j->o.summary) h_write_summary_text(j->o.summary, j->anno.gene_n, (int)j->anno.n_tx, total);
     free(parts); free(th); free(cut);
     return 0;
@@ -391,9 +401,13 @@ int h_job_write_summary(h_job *j, const int64_t counters[H_N_SUMMARY], const cha
     return 0;
 }
 
+const char *h_job_part_last_gene(const h_job *j, int list) { return (j && list >= 0 && list < 2) ? j->part_genes.last_gid[list] : NULL; }
+int h_job_part_has_first_gene(const h_job *j, int list, const char *gid) { return j ? h_part_genes_has_first(&j->part_genes, list, gid) : 0; }
+
 void h_job_free(h_job *j)
 {
     if (!j) return;
+    h_part_genes_free(&j->part_genes);
     for (int k = 0; k < 8; ++k) free(j->out_path[k]);
     if (j->sj_fp) fclose(j->sj_fp);
     h_reads_free(&j->reads); h_gtf_free(&j->anno); h_sj_free(&j->sj); h_chroms_free(&j->chr);

@@ -82,12 +82,27 @@ void h_result_free(h_result *r);
 
 /* ---- the sequential tail + writers */
 #define H_N_SUMMARY 16            /* counters of summary.txt, see tail.c summary_and_bed */
+#define H_CNT_UPDATED_GENES 0
+#define H_CNT_KNOWN_GENES   7
+/* What a chromosome-aligned PART of the reads leaves behind for the one place where the reference's lists do look across
+ * a chromosome boundary: merge_gene (src/update_gtf.c:181-189) compares the gene_id with the list's last entry BEFORE
+ * it tests the tid break, so a gene whose id equals the last entry of the previous chromosome is not counted again.
+ * List 0: genes of the updated transcripts, list 1: genes of the known reads.  A part starts with empty lists; with
+ * L = gene_id of the last entry of the parts before it, the part counted one gene too many iff L is among the ids it
+ * added under the tid of its own first entry (h_part_genes_fix does the bookkeeping over the parts in order). */
+typedef struct {
+    char *last_gid[2];            /* gene_id of the list's last entry, NULL: the part added nothing */
+    char **first_gids[2]; int n_first[2];      /* ids added under the tid of the list's first entry */
+} h_part_genes;
+void h_part_genes_free(h_part_genes *g);
+int  h_part_genes_has_first(const h_part_genes *g, int list, const char *gid);
 typedef struct {
     l2r_params prm;
     FILE *out_gtf, *exon_bed, *bam_gtf, *bam_detail, *known_gtf, *novel_gtf, *unrecog_gtf, *summary;
     char source[1024];
     int no_detail_header;        /* parts after the first of a partitioned run: detail.txt without its column line */
     int64_t *summary_counts;     /* non-NULL: the summary counters go here (H_N_SUMMARY values) instead of being printed */
+    h_part_genes *part_genes;    /* non-NULL (parts of a partitioned run): filled for the caller's fix-up of the gene counters */
 } h_update_opts;
 
 /* Everything update_gtf() does after check_with_anno_trans/check_with_short_sj:
@@ -133,6 +148,10 @@ int    h_job_finish_accepted(h_job *j, const l2r_result *res, const int64_t *rea
 int    h_job_finish_part(h_job *j, int64_t lo, int64_t hi, const l2r_result *res, const char *suffix, const char *stdout_base,
                          int first_part, int64_t counters[H_N_SUMMARY]);
 /* which: 0 updated gtf (NULL = stdout), 1 exon bed, 2 bam gtf, 3 detail, 4 known, 5 novel, 6 unrecog, 7 summary */
+/* the gene lists of the part h_job_finish_part() last ran (see h_part_genes): gene_id of list `list`'s last entry (NULL: none
+ * added), and whether `gid` is among the ids the part added under the tid of its first entry */
+const char *h_job_part_last_gene(const h_job *j, int list);
+int         h_job_part_has_first_gene(const h_job *j, int list, const char *gid);
 const char *h_job_out_path(const h_job *j, int which);
 void   h_job_set_out_path(h_job *j, int which, const char *path);
 void   h_job_open_outputs(h_job *j);                       /* open the output files of a job that was opened without them */

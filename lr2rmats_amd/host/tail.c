@@ -326,6 +326,35 @@ static void add_gene(s_gene **G, int *n, int *cap, int32_t tid, const char *gid)
     S_GROW(*G, *n, *cap, s_gene); (*G)[*n].tid = tid; (*G)[*n].gid = gid; ++*n;
 }
 
+void h_part_genes_free(h_part_genes *g)
+{
+    for (int q = 0; q < 2; ++q) {
+        free(g->last_gid[q]);
+        for (int k = 0; k < g->n_first[q]; ++k) free(g->first_gids[q][k]);
+        free(g->first_gids[q]);
+    }
+    memset(g, 0, sizeof *g);
+}
+
+int h_part_genes_has_first(const h_part_genes *g, int list, const char *gid)
+{
+    if (!gid || list < 0 || list > 1) return 0;
+    for (int k = 0; k < g->n_first[list]; ++k) if (strcmp(g->first_gids[list][k], gid) == 0) return 1;
+    return 0;
+}
+
+static void part_genes_take(h_part_genes *g, int list, const s_gene *G, int n)
+{
+    g->last_gid[list] = NULL; g->first_gids[list] = NULL; g->n_first[list] = 0;
+    if (n <= 0) return;
+    g->last_gid[list] = strdup(G[n - 1].gid);
+    int m = 0;
+    while (m < n && G[m].tid == G[0].tid) ++m;
+    g->first_gids[list] = (char **)h_malloc((size_t)m * sizeof(char *));
+    for (int k = 0; k < m; ++k) g->first_gids[list][k] = strdup(G[k].gid);
+    g->n_first[list] = m;
+}
+
 void h_write_summary_text(FILE *s, int anno_genes, int anno_tx, const int64_t *k)
 {
     /* src/update_gtf.c:530-569; k = the counters in the order summary_and_bed fills them */
@@ -395,6 +424,7 @@ static void summary_and_bed(const tail_ctx *c, const m_list *U)
             if (!hit) { S_GROW(J, j_n, j_cap, s_junc); J[j_n].tid = t->tid; J[j_n].don = xe[j]; J[j_n].acc = xs[j + 1]; ++j_n; }
         }
     }
+    if (c->o->part_genes) { memset(c->o->part_genes, 0, sizeof *c->o->part_genes); part_genes_take(c->o->part_genes, 0, G, upd_genes); }
     if (c->o->summary || c->o->summary_counts) {
         /* :496-528: classes of every input read + unique counts through merge_trans on fresh lists */
         int n_known = 0, n_rel = 0, n_unrel = 0, n_unrec = 0;
@@ -408,6 +438,7 @@ static void summary_and_bed(const tail_ctx *c, const m_list *U)
             else { ++n_unrec; dst = &un; }
             if (!m_merge(&t, dst, p)) m_push(dst, &t);
         }
+        if (c->o->part_genes) part_genes_take(c->o->part_genes, 1, G, known_genes);
         int64_t cnt[H_N_SUMMARY] = { upd_genes, U->n, partial, e_n, (int64_t)d_n + a_n, j_n, n_known, known_genes, uk.n,
                                      n_rel, n_unrel, ur.n, uu.n, n_unrec, un.n, 0 };
         if (c->o->summary_counts) memcpy(c->o->summary_counts, cnt, sizeof cnt);

@@ -37,6 +37,10 @@ def load_library():
         lib.h_job_finish.argtypes = [C.c_void_p, C.c_void_p]
         lib.h_job_finish.restype = C.c_int
         lib.h_job_free.argtypes = [C.c_void_p]
+        lib.h_job_part_last_gene.argtypes = [C.c_void_p, C.c_int]
+        lib.h_job_part_last_gene.restype = C.c_char_p
+        lib.h_job_part_has_first_gene.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+        lib.h_job_part_has_first_gene.restype = C.c_int
         lib.h_job_needs_all_reads.argtypes = [C.c_void_p]
         lib.h_job_needs_all_reads.restype = C.c_int
         lib.h_job_finish_accepted.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
@@ -147,6 +151,21 @@ class Job:
         self.lib.h_job_finish_part(self.h, lo, hi, C.byref(res), suffix.encode(), stdout_base.encode(), 1 if first_part else 0,
                                    cnt.ctypes.data_as(C.POINTER(C.c_int64)))
         return cnt
+
+    # The two gene lists of summary.txt (genes of the updated transcripts, genes of the known reads) are the one place where
+    # the reference looks across a chromosome boundary: the last entry's gene_id is compared before the tid break
+    # (l2r_host.h h_part_genes).  After finish_part(): the part's last ids, and whether an id was added under its first tid.
+    GENE_COUNTERS = (0, 7)
+
+    def part_last_genes(self):
+        out = []
+        for q in range(2):
+            g = self.lib.h_job_part_last_gene(self.h, q)
+            out.append(g.decode() if g is not None else None)
+        return out
+
+    def part_has_first_gene(self, which: int, gid) -> bool:
+        return gid is not None and bool(self.lib.h_job_part_has_first_gene(self.h, which, gid.encode()))
 
     def write_summary(self, counters: np.ndarray, path: str) -> None:
         c = np.ascontiguousarray(counters, np.int64)

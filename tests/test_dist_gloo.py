@@ -179,6 +179,26 @@ def test_unsorted_records_are_classified_by_one_rank(oracle, tmp_path, inputs, g
 
 
 @pytest.mark.timeout(300)
+def test_partitioned_route_counts_a_gene_id_that_spans_chromosomes_once(oracle, tmp_path, inputs):
+    # merge_gene compares the gene_id with the list's last entry before its tid break (src/update_gtf.c:181-189): with one
+    # gene_id on every chromosome the sequential summary says 1 gene; the ranks exchange their lists' last ids to agree
+    import re
+    d, anno, reads, sam, gtf = inputs
+    gtf1 = str(tmp_path / "one_gene.gtf")
+    with open(gtf) as fi, open(gtf1, "w") as fo:
+        for l in fi:
+            fo.write(re.sub(r'gene_id "[^"]*"', 'gene_id "GX"', l))
+    single = {k: str(tmp_path / ("s." + k)) for k in KEYS}
+    multi = {k: str(tmp_path / ("m." + k)) for k in KEYS}
+    assert oracle.run_cli(_args(single, sam, gtf1)) == 0
+    _run_ranks(3, _args(multi, sam, gtf1), {"L2R_DIST_TRACE": str(tmp_path / "trace")})
+    assert open(str(tmp_path / "trace")).read().strip() == "partitioned"
+    for k in KEYS:
+        assert filecmp.cmp(single[k], multi[k], shallow=False), k
+    assert "Updated_Genes\t1\n" in open(single["summary"]).read()
+
+
+@pytest.mark.timeout(300)
 def test_partitioned_route_to_stdout(oracle, tmp_path, inputs):
     d, anno, reads, sam, gtf = inputs
     a, b = str(tmp_path / "s.gtf"), str(tmp_path / "m.gtf")

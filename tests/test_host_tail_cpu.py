@@ -187,6 +187,28 @@ def test_threaded_tail_is_byte_identical(oracle, tmp_path, threads):
     assert os.path.getsize(oo["detail"]) > 100000
 
 
+def test_threaded_tail_counts_a_gene_on_two_chromosomes_like_the_sequential_run(oracle, tmp_path):
+    """merge_gene (src/update_gtf.c:181-189) compares the gene_id with the list's last entry before the tid break: a gene
+    id that continues on the next chromosome is counted once.  Every gene of this annotation carries the same id, so the
+    sequential run counts 1 updated / 1 known gene; parts that start with empty lists would count one per part."""
+    anno = synth.make_annotation(4000, 62, nchr=4)
+    reads = synth.make_reads(anno, 24000, 5, 62)
+    sam, gtf, gtf1 = str(tmp_path / "r.sam"), str(tmp_path / "a.gtf"), str(tmp_path / "one_gene.gtf")
+    reads.write_sam(sam)
+    anno.write_gtf(gtf)
+    import re
+    with open(gtf) as fi, open(gtf1, "w") as fo:
+        for l in fi:
+            fo.write(re.sub(r'gene_id "[^"]*"', 'gene_id "GX"', l))
+    oo, ho = _paths(tmp_path, "g.o"), _paths(tmp_path, "g.h")
+    assert oracle.run_cli(_args(["-l", "3"], oo, sam, gtf1)) == 0
+    assert _host_with_oracle_results(_args(["-l", "3"], ho, sam, gtf1), env=dict(os.environ, L2R_THREADS="4")) == 0
+    for k in OUTS:
+        assert filecmp.cmp(oo[k], ho[k], shallow=False), k
+    summ = dict(l.rstrip("\n").split("\t") for l in open(oo["summary"]) if "\t" in l)
+    assert summ["Updated_Genes"] == "1" and summ["Genes_of_Known_Transcripts_from_BAM"] == "1", summ
+
+
 def test_bgzf_blocks_inflated_on_several_threads(tmp_path):
     """A BAM of a few hundred BGZF blocks read with 1 and with 5 inflate threads gives the generator's arrays; a
     gzip-compressed SAM (one gzip member, not BGZF) still goes through the sequential route."""
@@ -219,6 +241,14 @@ np.savez(sys.argv[3], **a)
         np.testing.assert_array_equal(z["rev"], reads.rev)
         np.testing.assert_array_equal(z["cig_off"], reads.cig_off)
         np.testing.assert_array_equal(z["cig"], reads.cig)
+    # a block whose stored CRC32 does not match its inflated bytes is refused (htslib refuses it too)
+    raw = bytearray(open(bam, "rb").read())
+    bsize = (raw[16] | (raw[17] << 8)) + 1                  # first block; its CRC32 sits 8 bytes before the block's end
+    raw[bsize - 8] ^= 0x5a
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(raw))
+    r = subprocess.run([sys.executable, "-c", code, bad, gtf, str(tmp_path / "bad.npz")], stderr=subprocess.PIPE, env=dict(os.environ, L2R_THREADS="3"))
+    assert r.returncode != 0 and b"CRC32 mismatch" in r.stderr
 
 
 def test_gtf_input_mode(oracle, tmp_path):
