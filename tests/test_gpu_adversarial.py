@@ -1,0 +1,159 @@
+"""GPU: inputs built to break the fast path's assumptions -- against the oracle, bit exact, on every kernel pipeline.
+
+    annotation rows on chromosomes the BAM header does not have (tid -1) between the others
+    a locus of 300 isoforms (windows far wider than the 32-bit membership masks: the redo list carries the load)
+    duplicated transcripts, duplicated and overlapping exons inside a transcript
+    reads that touch a transcript / an exon by exactly one base, at every -l level
+    -d 2 with a junction table on ONT-like reads (long CIGARs, micro-exons), with and without -s
+and what share of the reads the redo list (k_classify_generic) takes on each of them.
+"""
+import numpy as np
+import pytest
+
+from lr2rmats_amd import synth
+from tests import util
+from tests.test_gpu_edges import _anno, _chain, _reads, _run, pipeline  # noqa: F401  (pipeline: autouse fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _sorted_rows(rows):
+    return sorted(rows, key=lambda r: (r[0], r[1]))
+
+
+def test_annotation_rows_without_a_chromosome_in_the_header(oracle):
+    # read_anno_trans() keeps transcripts of unknown chromosomes with tid -1 (src/gtf.c:468-521); they sit between the
+    # others in file order and can never match, but the sweep cursor walks over them
+    rng = np.random.default_rng(3)
+    txs = []
+    for g in range(120):
+        base = 5_000 + g * 4_000
+        ex = [(base + 300 * k, base + 300 * k + 120) for k in range(int(rng.integers(2, 7)))]
+        txs.append((0 if g < 80 else 1, g & 1, ex))
+        if g % 3 == 0:
+            txs.append((-1, 0, [(base + 10, base + 90), (base + 400, base + 520)]))      # same coordinates, no chromosome
+    af = _anno(txs)
+    rows = []
+    for i in range(2500):
+        t = txs[int(rng.integers(len(txs)))]
+        if t[0] < 0:
+            continue
+        ex = [list(x) for x in t[2]]
+        if i % 4 == 0:
+            ex[0][0] += int(rng.integers(0, 30))
+        if i % 5 == 0 and len(ex) > 2:
+            del ex[1]
+        p, ops = _chain([tuple(x) for x in ex])
+        rows.append((t[0], p, i & 1, ops))
+    cnt = [0, 0, 0, 0]
+    got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=3)
+    # (chains that begin with a transcript's first exon are never "known": Q1 -- they count as "has a known site")
+    assert ((want.info & 2) != 0).sum() > 200 and (want.ref_tx >= 0).sum() > 500
+    assert not np.isin(want.ref_tx[want.ref_tx >= 0], np.nonzero(af.tx_tid < 0)[0]).any()
+
+
+@pytest.mark.parametrize("level", [3, 5])
+def test_locus_of_300_isoforms(oracle, level, pipeline):
+    # every tile of this locus sees ~300 overlapping transcripts: the window does not fit the 32-bit masks and the
+    # reads go to the redo list (wave per read).  Results stay exact; the share is reported by the counters.
+    rng = np.random.default_rng(9)
+    pool = [(20_000 + 600 * k, 20_000 + 600 * k + 140) for k in range(30)]
+    txs = []
+    for t in range(300):
+        keep = sorted(set([0, 29] + list(rng.choice(np.arange(1, 29), size=int(rng.integers(6, 20)), replace=False))))
+        ex = [pool[k] for k in keep]
+        if t % 5 == 0:
+            ex[1] = (ex[1][0] - int(rng.integers(1, 30)), ex[1][1])
+        txs.append((0, t & 1, ex))
+    # a quiet neighbour locus on the same chromosome: its tiles must stay on the fast path
+    for g in range(200):
+        base = 400_000 + g * 3_000
+        txs.append((0, 0, [(base, base + 100), (base + 500, base + 650), (base + 1200, base + 1300)]))
+    af = _anno(txs)
+    rows = []
+    for i in range(6000):
+        t = txs[int(rng.integers(300))][2]
+        a = int(rng.integers(0, len(t) - 2))
+        ex = [list(x) for x in t[a:a + int(rng.integers(2, 9))]]
+        if i % 3 == 0:
+            ex[-1][1] -= int(rng.integers(0, 50))
+        p, ops = _chain([tuple(x) for x in ex])
+        rows.append((0, p, i & 1, ops))
+    for i in range(6000):
+        t = txs[300 + int(rng.integers(200))][2]
+        p, ops = _chain(t if i % 2 else t[:2])
+        rows.append((0, p, 0, ops))
+    cnt = [0, 0, 0, 0]
+    reads = _reads(_sorted_rows(rows))
+    got, want = _run(oracle, af, reads, counters=cnt, full_level=level)
+    assert ((want.info & 1) != 0).sum() > 1000
+    # the crowded locus is the redo list's, the quiet one is not (one tile may straddle the two)
+    assert 5000 <= cnt[0] <= 6000 + 256, cnt
+
+
+def test_duplicated_transcripts_and_overlapping_exons(oracle):
+    # the same transcript three times in a row; transcripts whose exons repeat or overlap each other (the reference
+    # sorts a transcript's exons by (start, end) and keeps all of them, src/gtf.c:468-521); a transcript that is one
+    # exon of another
+    a = [(1_000, 1_200), (2_000, 2_150), (3_000, 3_300)]
+    txs = [(0, 0, a), (0, 0, a), (0, 0, a),
+           (0, 0, [(1_000, 1_200), (1_000, 1_200), (2_000, 2_150)]),                  # duplicated exon
+           (0, 0, [(1_000, 1_200), (1_100, 1_400), (2_000, 2_150), (2_100, 2_300)]),  # overlapping exons
+           (0, 1, [(2_000, 2_150)]),                                                  # an exon of the others, other strand
+           (0, 0, [(5_000, 5_100), (5_050, 5_400), (5_300, 5_350), (6_000, 6_100)])]
+    af = _anno(txs)
+    chains = [a, a[:2], a[1:], [(1_100, 1_400), (2_000, 2_150)], [(1_000, 1_200), (2_100, 2_300)], [(1_050, 1_200), (2_000, 2_100)],
+              [(2_000, 2_150)], [(2_010, 2_140)], [(5_000, 5_100), (6_000, 6_100)], [(5_050, 5_400), (6_000, 6_100)],
+              [(5_300, 5_350), (6_000, 6_100)], [(5_000, 5_400), (6_000, 6_100)], [(1_000, 1_400), (2_000, 2_300)]]
+    rows = []
+    for k, ex in enumerate(chains * 20):
+        p, ops = _chain(ex)
+        rows.append((0, p, k & 1, ops))
+    for level in (1, 2, 3, 4, 5):
+        got, want = _run(oracle, af, _reads(_sorted_rows(rows)), full_level=level)
+    assert ((want.info & 1) != 0).any() and ((want.info & 1) == 0).any()
+    assert len(set(want.ref_tx.tolist())) >= 4
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5])
+def test_one_base_contacts_at_every_level(oracle, level):
+    # reads whose first / last exon meets a transcript's exon by exactly one base, misses it by one, or overlaps by
+    # two; and reads that touch the transcript's span by one base (Q5) -- check_full()'s comparisons are all <= / < on
+    # these (src/update_gtf.c:629-681), one level after the other
+    tx = [(10_000, 10_200), (11_000, 11_100), (12_000, 12_300), (13_000, 13_050)]
+    af = _anno([(0, 0, tx), (0, 1, [(20_000, 20_100)]), (0, 0, [tx[0], tx[2], tx[3]])])
+    rows = []
+    for d in (-2, -1, 0, 1, 2):
+        # left end around the first exon's END, right end around the last exon's START
+        rows.append((0, *_chain([(10_200 + d, 10_260 + max(d, 0)), (11_000, 11_100)])))
+        rows.append((0, *_chain([(11_000, 11_100), (12_000, 12_300), (12_940 + d, 13_000 + d)])))
+        # ends around exon boundaries of INNER exons
+        rows.append((0, *_chain([(11_100 + d, 11_180 + max(d, 0)), (12_000, 12_300)])))
+        rows.append((0, *_chain([(10_000, 10_200), (10_940 + d, 11_000 + d)])))
+        # single-exon reads around the single-exon transcript
+        rows.append((0, *_chain([(19_900, 20_000 + d)])))
+        rows.append((0, *_chain([(20_100 + d, 20_250)])))
+        # exact chain whose ends move by d
+        rows.append((0, *_chain([(10_000 + d, 10_200), (11_000, 11_100), (12_000, 12_300), (13_000, 13_050 + d)])))
+    rows = [(r[0], r[1], 0, r[2]) for r in rows]
+    got, want = _run(oracle, af, _reads(_sorted_rows(rows)), full_level=level)
+    assert ((want.info & 4) != 0).any() and (level == 5 or ((want.info & 4) == 0).any())       # (-l 5: every read counts as full length)
+
+
+@pytest.mark.parametrize("split", [0, 1])
+def test_splice_distance_with_junction_table_on_ont_like_reads(oracle, split):
+    # -d 2 moves every site comparison to a +-2 neighbourhood, the junction table decides acceptance (and with -s the
+    # split), the records are ONT-like: ~50 CIGAR operations per read, micro-exons, XS tags that disagree with the flag
+    anno, af, reads = util.make_case(23, n_reads=12000, n_exons=6, anno_exons=12000, ont=True, micro=3, xs=0.03)
+    base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3, ss_dis=2))
+    j, sj = util.junction_table(af, reads, base, 23, cover=0.6)
+    got, want = _run(oracle, af, reads, sj=sj, full_level=3, ss_dis=2, split_trans=split, min_sj_cnt=2)
+    assert ((want.info & 32) != 0).sum() > 100 and ((want.info & 64) != 0).sum() > 10 and ((want.ex_flag & 16) != 0).sum() > 10
+
+
+def test_redo_share_of_the_benchmark_workload_shape(oracle, pipeline):
+    # the shape bench.py measures (BASELINE configs[2], smaller): (almost) nothing may leave the fast path
+    anno, af, reads = util.make_case(29, n_reads=200000, n_exons=8, anno_exons=150000)
+    cnt = [0, 0, 0, 0]
+    got, want = _run(oracle, af, reads, counters=cnt, full_level=3)
+    assert cnt[0] <= reads.n // 200, cnt

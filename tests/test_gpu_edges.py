@@ -48,11 +48,20 @@ def _chain(exons):
     return exons[0][0] - 1, ops
 
 
-def _run(oracle, af, reads, counters=None, **kw):
-    want = util.oracle_run(oracle, af, reads, oracle.default_params(**kw))
+@pytest.fixture(autouse=True, params=["slab", "fused", "classic"])
+def pipeline(request, monkeypatch):
+    """Every case runs on each of the engine's three kernel pipelines (l2r_engine.hip: L2R_PIPELINE is read by l2r_create;
+    records the chosen pipeline cannot take -- unsorted, long CIGARs -- fall to the classic one by themselves)."""
+    monkeypatch.setenv("L2R_PIPELINE", request.param)
+    return request.param
+
+
+def _run(oracle, af, reads, counters=None, sj=None, **kw):
+    want = util.oracle_run(oracle, af, reads, oracle.default_params(**kw), sj)
     eng = capi.Engine(0)
     try:
         eng.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
+        eng.set_junctions(sj)
         got = eng.classify(reads, capi.default_params(**kw))
         # the accepted list (chunks placed by the classification kernel and by k_gather_accepted, mixed) == the
         # accepted reads of the full result, in read order
@@ -74,7 +83,7 @@ def _run(oracle, af, reads, counters=None, **kw):
             counters[:] = list(cnt)
     finally:
         eng.close()
-    util.assert_same_result(got, want, 0, 0)
+    util.assert_same_result(got, want, 0 if sj is None else len(sj[0]), kw.get("split_trans", 0))
     return got, want
 
 

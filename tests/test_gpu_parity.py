@@ -8,9 +8,19 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def engine():
-    e = capi.Engine(0)
+@pytest.fixture(scope="module", params=["slab", "fused", "classic"])
+def engine(request):
+    """One engine per kernel pipeline (l2r_create reads L2R_PIPELINE): every case of this file runs on all three."""
+    import os
+    old = os.environ.get("L2R_PIPELINE")
+    os.environ["L2R_PIPELINE"] = request.param
+    try:
+        e = capi.Engine(0)
+    finally:
+        if old is None:
+            del os.environ["L2R_PIPELINE"]
+        else:
+            os.environ["L2R_PIPELINE"] = old
     yield e
     e.close()
 
