@@ -182,6 +182,15 @@ int          l2r_set_params(l2r_ctx *ctx, const l2r_params *prm);
 #define L2R_WANT_ACCEPTED 2u
 int          l2r_set_outputs(l2r_ctx *ctx, unsigned want);
 int          l2r_set_annotation(l2r_ctx *ctx, const l2r_annotation *anno);
+/* The tables l2r_set_annotation derives from the annotation (transcript headers, cursor keys, the two site dictionaries and
+ * their bucket directories: two sorts of ~1.5 M rows each and the dictionary build for a GENCODE-size GTF) can be kept
+ * on disk between runs: `dir` (or the environment variable L2R_ANNO_CACHE when no call is made; NULL / "" = off, the
+ * default) holds one file per annotation, named by a hash of the arrays passed in.  A hit replaces the build by one
+ * read; a file that does not match in any respect is ignored and rewritten.  l2r_annotation_cache_state(): what the last
+ * l2r_set_annotation did -- 0 no cache, 1 built and stored, 2 read from the cache.  (The reference re-reads and re-sorts
+ * the GTF on every invocation, src/gtf.c:468-521; the pipeline calls update-gtf twice per sample on one GTF.) */
+int          l2r_set_annotation_cache(l2r_ctx *ctx, const char *dir);
+int          l2r_annotation_cache_state(l2r_ctx *ctx);
 int          l2r_set_junctions(l2r_ctx *ctx, const l2r_junctions *sj);   /* NULL or n == 0: no -j file */
 
 /* host -> HBM; detects whether the records are coordinate sorted and, if not,

@@ -28,7 +28,7 @@ EXPORTS = [
     "l2r_abi_version", "l2r_last_error", "l2r_device_count", "l2r_create", "l2r_destroy", "l2r_set_params",
     "l2r_set_outputs", "l2r_set_annotation", "l2r_set_junctions", "l2r_upload_reads", "l2r_run", "l2r_sync", "l2r_run_timed",
     "l2r_result_sizes", "l2r_download", "l2r_download_accepted", "l2r_device_view_get", "l2r_stream", "l2r_classify",
-    "l2r_stage_kernel",
+    "l2r_stage_kernel", "l2r_set_annotation_cache", "l2r_annotation_cache_state",
 ]
 
 _i32p, _i64p, _u8p, _u32p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
@@ -121,6 +121,8 @@ def load_library():
         lib.l2r_run_timed.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.l2r_result_sizes.argtypes = [C.c_void_p, _i64p, _i64p, _i64p, _i64p]
         lib.l2r_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.l2r_set_annotation_cache.argtypes = [C.c_void_p, C.c_char_p]
+        lib.l2r_annotation_cache_state.argtypes = [C.c_void_p]
         lib.l2r_stage_kernel.restype = C.c_char_p
         lib.l2r_stage_kernel.argtypes = [C.c_void_p, C.c_int]
         _lib = lib
@@ -206,6 +208,14 @@ class Engine:
         a = [np.ascontiguousarray(x, np.int32) for x in sj]
         cj = CJunctions(len(a[0]), *[_ptr(x, _i32p) for x in a])
         self._chk(self.lib.l2r_set_junctions(self.ctx, C.byref(cj)))
+
+    def set_annotation_cache(self, directory) -> None:
+        """Keep the annotation tables on disk under ``directory`` (None: off); see include/lr2rmats_hip.h."""
+        self._chk(self.lib.l2r_set_annotation_cache(self.ctx, directory.encode() if directory else None))
+
+    def annotation_cache_state(self) -> int:
+        """0 no cache, 1 built and stored, 2 read from the cache (last set_annotation)."""
+        return int(self.lib.l2r_annotation_cache_state(self.ctx))
 
     def upload_reads(self, tid, pos, rev, cig_off, cig, first_read_index: int = 0):
         a = [np.ascontiguousarray(tid, np.int32), np.ascontiguousarray(pos, np.int32), np.ascontiguousarray(rev, np.uint8),

@@ -7,7 +7,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -72,6 +75,8 @@ struct l2r_ctx {
     DevBuf<TileWin> tw;
     DevBuf<unsigned long long> ovf_cursor;
     uint32_t ovf_base = 0;
+    std::string anno_cache_dir;             // L2R_ANNO_CACHE / l2r_set_annotation_cache: where the annotation tables are kept between runs
+    int anno_cache_state = 0;               // last l2r_set_annotation: 0 no cache, 1 built + stored, 2 read from the cache
     bool lin_valid = false;                 // lin_* hold the read-order exon arrays of the last run (read_order_arrays)
     bool slab_ordered = false;              // k_order has run for this upload (slab pipeline: its outputs depend on the records only)
     DevBuf<uint16_t> lub;                   // k_order: first LDS slot of every read
@@ -201,6 +206,8 @@ l2r_ctx *l2r_create(int device)
         if (e && atoi(e) > 0) c->fast_grid = atoi(e);
         e = getenv("L2R_ABLATE");
         c->ablate = e ? atoi(e) : 0;
+        e = getenv("L2R_ANNO_CACHE");
+        if (e && *e) c->anno_cache_dir = e;
         e = getenv("L2R_PIPELINE");
         if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : !strcmp(e, "fused") ? 1 : 2;
     }
@@ -265,15 +272,28 @@ struct SiteTx {
     }
 };
 
+// Everything l2r_set_annotation derives from the annotation, on the host: what is uploaded, and what the cache file holds.
+struct AnnoTables {
+    std::vector<TxHdr> hdr;
+    std::vector<int64_t> key, key_raw;                 // cursor keys: prefix maximum / per transcript
+    std::vector<int2> ex;
+    std::vector<SiteEnt> st_ent, en_ent;               // START / END dictionaries
+    std::vector<uint32_t> st_dir, st_rdir, en_dir;     // their bucket directories (START: + reach-back directory)
+    std::vector<int32_t> tid_base, kb_base;
+    std::vector<uint32_t> key_dir;
+    int64_t n_wide = 0, n_compact = 0;
+    int32_t n_tid_dir = 0, n_tid_key = 0;
+};
+
 // Entries of one dictionary + its bucket directory.  `pairs`: sorted (tid, k1, k2, tx) rows of the pair kind
 // (exons for START, junctions for END); `singles`: sorted (tid, k1, 0, tx) rows of the single kind (acceptors /
 // donors).  An entry's masks are relative to the smallest member transcript of either kind.
-static int upload_dict(l2r_ctx *c, const std::vector<SiteTx> &pairs, const std::vector<SiteTx> &singles, const std::vector<int32_t> &tid_base,
-                       DevBuf<SiteEnt> &kbuf, DevBuf<uint32_t> &dbuf, DevBuf<uint32_t> *rbuf, int64_t &n_wide)
+static void build_dict(const std::vector<SiteTx> &pairs, const std::vector<SiteTx> &singles, const std::vector<int32_t> &tid_base,
+                       std::vector<SiteEnt> &ent, std::vector<uint32_t> &dir, std::vector<uint32_t> *rdir_out, int64_t &n_wide)
 {
     const size_t nb = (size_t)tid_base.back();
-    std::vector<uint32_t> dir(nb + 1, 0);                 // dir[b] = number of entries whose bucket id is < b
-    std::vector<SiteEnt> ent;
+    dir.assign(nb + 1, 0);                                // dir[b] = number of entries whose bucket id is < b
+    ent.clear();
     ent.reserve(pairs.size());
     size_t si = 0;                                        // walks `singles` in step (both sorted by (tid, k1))
     for (size_t i = 0; i < pairs.size();) {
@@ -303,9 +323,10 @@ static int upload_dict(l2r_ctx *c, const std::vector<SiteTx> &pairs, const std::
         i = j;                                             // `si` stays: the next pair may share (tid, k1)
     }
     for (size_t b = 0; b < nb; ++b) dir[b + 1] += dir[b];
-    if (rbuf) {
+    if (rdir_out) {
         // reach-back directory (START: k1 = exon start, k2 = exon end): first entry whose exon reaches into the bucket
-        std::vector<uint32_t> rdir(dir);
+        std::vector<uint32_t> &rdir = *rdir_out;
+        rdir = dir;
         size_t i = 0;
         for (size_t q = 0; q < pairs.size();) {           // entry i <-> the q-th distinct pair
             size_t j = q;
@@ -317,26 +338,17 @@ static int upload_dict(l2r_ctx *c, const std::vector<SiteTx> &pairs, const std::
             for (size_t b = sb + 1; b <= eb; ++b) if (rdir[t0 + b] > (uint32_t)i) rdir[t0 + b] = (uint32_t)i;
             ++i; q = j;
         }
-        if (rbuf->ensure(rdir.size())) return -2;
-        HIP_TRY(hipMemcpyAsync(rbuf->p, rdir.data(), rdir.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    if (kbuf.ensure(ent.size()) || dbuf.ensure(dir.size())) return -2;
-    if (!ent.empty()) HIP_TRY(hipMemcpyAsync(kbuf.p, ent.data(), ent.size() * sizeof(SiteEnt), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dbuf.p, dir.data(), dir.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
 }
 
-int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
+static int build_tables(const l2r_annotation *a, AnnoTables &o)
 {
-    if (!c || !a) return fail(-1, "[l2r_set_annotation] null argument");
-    if (a->n_tx < 0 || a->n_tx > 0x7ffffff0LL || a->n_exon < 0 || a->n_exon > 0x7ffffff0LL) return fail(-1, "[l2r_set_annotation] size out of range");
-    HIP_TRY(hipSetDevice(c->device));
     const int64_t T = a->n_tx;
-    std::vector<TxHdr> h((size_t)T);
-    std::vector<int64_t> key((size_t)T);
-    c->h_anno_key_raw.assign((size_t)T, 0);
+    std::vector<TxHdr> &h = o.hdr;
+    std::vector<int64_t> &key = o.key;
+    h.assign((size_t)T, TxHdr());
+    key.assign((size_t)T, 0);
+    o.key_raw.assign((size_t)T, 0);
     int64_t run = INT64_MIN;
     // headers, cursor keys, and the (site, transcript) rows of every kind
     std::vector<SiteTx> kd, ka, kx, kj;
@@ -370,14 +382,12 @@ int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
         // The sequential cursor equals the longest prefix that is entirely before the read = first index
         // whose running maximum of (tid,end) exceeds (read.tid, read.start)  (SURVEY.md 3.3).
         const int64_t k = host_key(t.tid, t.end);
-        c->h_anno_key_raw[(size_t)i] = k;
+        o.key_raw[(size_t)i] = k;
         if (k > run) run = k;
         key[(size_t)i] = run;
     }
-    c->h_anno_key_pm = key;
-    c->seq = l2r_ctx::Stream();
     std::sort(kd.begin(), kd.end()); std::sort(ka.begin(), ka.end()); std::sort(kx.begin(), kx.end()); std::sort(kj.begin(), kj.end());
-    c->n_compact = n_compact;
+    o.n_compact = n_compact;
     {   // one bucket grid for the four kinds: per tid, enough 512-bp buckets for its largest site coordinate
         int32_t n_tid = 0;
         for (const auto *v : {&kd, &ka, &kx, &kj}) if (!v->empty()) n_tid = std::max(n_tid, v->back().tid + 1);
@@ -386,30 +396,31 @@ int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
         // ... and for the last exon END of every chromosome: the full-length evidence looks for exons that reach into
         // the bucket of a read's terminal exon (rdir), so the grid has to cover exon ends, not only the probe keys
         for (const SiteTx &k : kx) mx[(size_t)k.tid] = std::max<int64_t>(mx[(size_t)k.tid], k.k2);
-        std::vector<int32_t> tb((size_t)n_tid + 1, 0);
+        std::vector<int32_t> &tb = o.tid_base;
+        tb.assign((size_t)n_tid + 1, 0);
         int64_t acc = 0;
         for (int32_t t = 0; t < n_tid; ++t) { tb[(size_t)t] = (int32_t)acc; acc += mx[(size_t)t] < 0 ? 0 : (mx[(size_t)t] >> SITE_SHIFT) + 1; }
         if (acc > 0x7ffffff0LL) return fail(-1, "[l2r_set_annotation] site directory too large");
         tb[(size_t)n_tid] = (int32_t)acc;
         // START: exons + the transcripts in which their start is an acceptor; END: junctions + donors
-        c->n_wide = 0;
-        if (upload_dict(c, kx, ka, tb, c->sk_st, c->sd_st, &c->sr_st, c->n_wide) || upload_dict(c, kj, kd, tb, c->sk_en, c->sd_en, nullptr, c->n_wide)) return -2;
-        if (c->tid_base.ensure(tb.size())) return -2;
-        HIP_TRY(hipMemcpyAsync(c->tid_base.p, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->n_tid_dir = n_tid;
+        o.n_wide = 0;
+        build_dict(kx, ka, tb, o.st_ent, o.st_dir, &o.st_rdir, o.n_wide);
+        build_dict(kj, kd, tb, o.en_ent, o.en_dir, nullptr, o.n_wide);
+        o.n_tid_dir = n_tid;
     }
     {   // cursor directory over the prefix-max keys: dir[kb_base[tid] + c] = first j with key_j >= (tid, c << 9)
         int32_t n_tid = 0;
         for (int64_t i = 0; i < T; ++i) n_tid = std::max(n_tid, h[(size_t)i].tid + 1);
         std::vector<int64_t> mxe((size_t)n_tid, -1);
         for (int64_t i = 0; i < T; ++i) if (h[(size_t)i].tid >= 0) mxe[(size_t)h[(size_t)i].tid] = std::max<int64_t>(mxe[(size_t)h[(size_t)i].tid], std::max(h[(size_t)i].end, 0));
-        std::vector<int32_t> kb((size_t)n_tid + 1, 0);
+        std::vector<int32_t> &kb = o.kb_base;
+        kb.assign((size_t)n_tid + 1, 0);
         int64_t acc = 0;
         for (int32_t t = 0; t < n_tid; ++t) { kb[(size_t)t] = (int32_t)acc; acc += mxe[(size_t)t] < 0 ? 0 : (mxe[(size_t)t] >> SITE_SHIFT) + 1; }
         if (acc > 0x7ffffff0LL) return fail(-1, "[l2r_set_annotation] cursor directory too large");
         kb[(size_t)n_tid] = (int32_t)acc;
-        std::vector<uint32_t> dir((size_t)acc + 1);
+        std::vector<uint32_t> &dir = o.key_dir;
+        dir.assign((size_t)acc + 1, 0);
         size_t j = 0;
         for (int32_t t = 0; t < n_tid; ++t) {
             const int32_t nbk = kb[(size_t)t + 1] - kb[(size_t)t];
@@ -425,22 +436,168 @@ int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
             dir[(size_t)acc] = (uint32_t)j;
         }
         // words of chromosomes without buckets (no transcript): they share the next chromosome's first word
-        if (c->key_dir.ensure(dir.size()) || c->kb_base.ensure(kb.size())) return -2;
-        HIP_TRY(hipMemcpyAsync(c->key_dir.p, dir.data(), dir.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->kb_base.p, kb.data(), kb.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->n_tid_key = n_tid;
+        o.n_tid_key = n_tid;
     }
-    std::vector<int2> ex((size_t)a->n_exon);
-    for (int64_t k = 0; k < a->n_exon; ++k) ex[(size_t)k] = make_int2(a->ex_start[k], a->ex_end[k]);
-    if (c->hdr.ensure((size_t)T) || c->anno_ex.ensure((size_t)a->n_exon) || c->anno_key.ensure((size_t)T)) return -2;
-    if (T) {
-        HIP_TRY(hipMemcpyAsync(c->hdr.p, h.data(), (size_t)T * sizeof(TxHdr), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->anno_key.p, key.data(), (size_t)T * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    o.ex.resize((size_t)a->n_exon);
+    for (int64_t k = 0; k < a->n_exon; ++k) o.ex[(size_t)k] = make_int2(a->ex_start[k], a->ex_end[k]);
+    return 0;
+}
+
+// ---- the tables on disk (L2R_ANNO_CACHE=<directory>, or l2r_set_annotation_cache): one file per annotation, named by a
+// hash of the arrays l2r_set_annotation was given + the layout constants; a hit replaces the sorts and the dictionary build
+// by one read.  The file is written to a temporary name and renamed, so a reader never sees a partial file; anything that
+// does not match (length, magic, hash, sizes) is ignored and rebuilt.
+static uint64_t mix64(uint64_t h, const void *p, size_t n)
+{
+    const uint8_t *b = (const uint8_t *)p;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 0x9E3779B97F4A7C15ULL; h ^= h >> 29; }
+    uint64_t w = 0;
+    if (i < n) { memcpy(&w, b + i, n - i); h = (h ^ w) * 0x9E3779B97F4A7C15ULL; h ^= h >> 29; }
+    return (h ^ n) * 0xD6E8FEB86659FD93ULL;
+}
+
+static uint64_t annotation_hash(const l2r_annotation *a)
+{
+    const uint64_t consts[] = {0x4c3252414e4e4f32ULL /* format */, (uint64_t)SITE_SHIFT, sizeof(TxHdr), sizeof(SiteEnt), (uint64_t)a->n_tx, (uint64_t)a->n_exon};
+    uint64_t h = mix64(0x1234567ULL, consts, sizeof consts);
+    const size_t T = (size_t)a->n_tx, X = (size_t)a->n_exon;
+    h = mix64(h, a->tx_tid, T * 4); h = mix64(h, a->tx_start, T * 4); h = mix64(h, a->tx_end, T * 4); h = mix64(h, a->tx_rev, T);
+    h = mix64(h, a->tx_ex_off, (T + 1) * 8); h = mix64(h, a->ex_start, X * 4); h = mix64(h, a->ex_end, X * 4);
+    return h;
+}
+
+struct CacheHead { char magic[8]; uint64_t hash; uint64_t n[12]; int64_t n_wide, n_compact; int32_t n_tid_dir, n_tid_key; uint64_t sum; };
+
+static uint64_t tables_sum(const AnnoTables &t)
+{
+    uint64_t h = 0x7ab1e5;
+    h = mix64(h, t.hdr.data(), t.hdr.size() * sizeof(TxHdr)); h = mix64(h, t.key.data(), t.key.size() * 8); h = mix64(h, t.key_raw.data(), t.key_raw.size() * 8);
+    h = mix64(h, t.ex.data(), t.ex.size() * sizeof(int2)); h = mix64(h, t.st_ent.data(), t.st_ent.size() * sizeof(SiteEnt));
+    h = mix64(h, t.en_ent.data(), t.en_ent.size() * sizeof(SiteEnt)); h = mix64(h, t.st_dir.data(), t.st_dir.size() * 4);
+    h = mix64(h, t.st_rdir.data(), t.st_rdir.size() * 4); h = mix64(h, t.en_dir.data(), t.en_dir.size() * 4);
+    h = mix64(h, t.tid_base.data(), t.tid_base.size() * 4); h = mix64(h, t.kb_base.data(), t.kb_base.size() * 4);
+    return mix64(h, t.key_dir.data(), t.key_dir.size() * 4);
+}
+
+extern "C++" {
+template <typename T> static bool put_vec(FILE *f, const std::vector<T> &v) { return v.empty() || fwrite(v.data(), sizeof(T), v.size(), f) == v.size(); }
+template <typename T> static bool get_vec(FILE *f, std::vector<T> &v, uint64_t n) { v.resize((size_t)n); return n == 0 || fread(v.data(), sizeof(T), (size_t)n, f) == (size_t)n; }
+}
+
+static std::string cache_path(const std::string &dir, uint64_t hash)
+{
+    char name[64];
+    snprintf(name, sizeof name, "/l2r_anno_%016llx.tables", (unsigned long long)hash);
+    return dir + name;
+}
+
+static bool cache_load(const std::string &path, uint64_t hash, int64_t n_tx, int64_t n_exon, AnnoTables &t)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    CacheHead hd;
+    bool ok = fread(&hd, sizeof hd, 1, f) == 1 && memcmp(hd.magic, "L2RANNO2", 8) == 0 && hd.hash == hash &&
+              hd.n[0] == (uint64_t)n_tx && hd.n[1] == (uint64_t)n_tx && hd.n[2] == (uint64_t)n_tx && hd.n[3] == (uint64_t)n_exon;
+    if (ok) {
+        // the lengths must add up to the file's length before anything is allocated from them
+        const uint64_t sz[12] = {sizeof(TxHdr), 8, 8, sizeof(int2), sizeof(SiteEnt), sizeof(SiteEnt), 4, 4, 4, 4, 4, 4};
+        uint64_t want = sizeof hd;
+        for (int k = 0; k < 12; ++k) { if (hd.n[k] > 0x7ffffff0ULL) ok = false; want += hd.n[k] * sz[k]; }
+        fseek(f, 0, SEEK_END);
+        ok = ok && (uint64_t)ftell(f) == want;
+        fseek(f, (long)sizeof hd, SEEK_SET);
     }
-    if (a->n_exon) HIP_TRY(hipMemcpyAsync(c->anno_ex.p, ex.data(), (size_t)a->n_exon * sizeof(int2), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->n_tx = T; c->n_anno_exon = a->n_exon;
+    ok = ok && get_vec(f, t.hdr, hd.n[0]) && get_vec(f, t.key, hd.n[1]) && get_vec(f, t.key_raw, hd.n[2]) && get_vec(f, t.ex, hd.n[3]) &&
+         get_vec(f, t.st_ent, hd.n[4]) && get_vec(f, t.en_ent, hd.n[5]) && get_vec(f, t.st_dir, hd.n[6]) && get_vec(f, t.st_rdir, hd.n[7]) &&
+         get_vec(f, t.en_dir, hd.n[8]) && get_vec(f, t.tid_base, hd.n[9]) && get_vec(f, t.kb_base, hd.n[10]) && get_vec(f, t.key_dir, hd.n[11]);
+    fclose(f);
+    if (ok) { t.n_wide = hd.n_wide; t.n_compact = hd.n_compact; t.n_tid_dir = hd.n_tid_dir; t.n_tid_key = hd.n_tid_key; }
+    // the payload is what was written, and the directories index the entries: nothing else may reach the kernels
+    ok = ok && tables_sum(t) == hd.sum;
+    ok = ok && t.tid_base.size() == (size_t)t.n_tid_dir + 1 && t.kb_base.size() == (size_t)t.n_tid_key + 1 &&
+         t.st_dir.size() == t.st_rdir.size() && t.st_dir.size() == t.en_dir.size() && !t.st_dir.empty() &&
+         t.st_dir.back() == t.st_ent.size() && t.en_dir.back() == t.en_ent.size() &&
+         (int64_t)t.st_dir.size() == (int64_t)t.tid_base.back() + 1 && (int64_t)t.key_dir.size() == (int64_t)t.kb_base.back() + 1;
+    return ok;
+}
+
+static void cache_store(const std::string &path, uint64_t hash, const AnnoTables &t)
+{
+    char tmp_suffix[48];
+    snprintf(tmp_suffix, sizeof tmp_suffix, ".tmp.%ld", (long)getpid());
+    const std::string tmp = path + tmp_suffix;
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;                                        // a cache that cannot be written is no error
+    CacheHead hd;
+    memset(&hd, 0, sizeof hd);
+    memcpy(hd.magic, "L2RANNO2", 8); hd.hash = hash;
+    const uint64_t n[12] = {t.hdr.size(), t.key.size(), t.key_raw.size(), t.ex.size(), t.st_ent.size(), t.en_ent.size(), t.st_dir.size(),
+                            t.st_rdir.size(), t.en_dir.size(), t.tid_base.size(), t.kb_base.size(), t.key_dir.size()};
+    memcpy(hd.n, n, sizeof n);
+    hd.n_wide = t.n_wide; hd.n_compact = t.n_compact; hd.n_tid_dir = t.n_tid_dir; hd.n_tid_key = t.n_tid_key;
+    hd.sum = tables_sum(t);
+    bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && put_vec(f, t.hdr) && put_vec(f, t.key) && put_vec(f, t.key_raw) && put_vec(f, t.ex) &&
+              put_vec(f, t.st_ent) && put_vec(f, t.en_ent) && put_vec(f, t.st_dir) && put_vec(f, t.st_rdir) && put_vec(f, t.en_dir) &&
+              put_vec(f, t.tid_base) && put_vec(f, t.kb_base) && put_vec(f, t.key_dir);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
+}
+
+extern "C++" {
+template <typename T> static int put_dev(l2r_ctx *c, DevBuf<T> &b, const std::vector<T> &v)
+{
+    if (b.ensure(v.size() ? v.size() : 1)) return -2;
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+}
+
+int l2r_set_annotation_cache(l2r_ctx *c, const char *dir)
+{
+    if (!c) return fail(-1, "[l2r_set_annotation_cache] null context");
+    c->anno_cache_dir = dir ? dir : "";
+    return 0;
+}
+
+int l2r_annotation_cache_state(l2r_ctx *c) { return c ? c->anno_cache_state : -1; }
+
+int l2r_set_annotation(l2r_ctx *c, const l2r_annotation *a)
+{
+    if (!c || !a) return fail(-1, "[l2r_set_annotation] null argument");
+    if (a->n_tx < 0 || a->n_tx > 0x7ffffff0LL || a->n_exon < 0 || a->n_exon > 0x7ffffff0LL) return fail(-1, "[l2r_set_annotation] size out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    AnnoTables t;
+    bool hit = false;
+    std::string path;
+    c->anno_cache_state = 0;
+    if (!c->anno_cache_dir.empty()) {
+        const uint64_t hash = annotation_hash(a);
+        path = cache_path(c->anno_cache_dir, hash);
+        hit = cache_load(path, hash, a->n_tx, a->n_exon, t);
+        if (!hit) {
+            t = AnnoTables();
+            int rc = build_tables(a, t);
+            if (rc) return rc;
+            (void)mkdir(c->anno_cache_dir.c_str(), 0777);
+            cache_store(path, hash, t);
+        }
+        c->anno_cache_state = hit ? 2 : 1;
+    } else {
+        int rc = build_tables(a, t);
+        if (rc) return rc;
+    }
+    int rc = 0;
+    if ((rc = put_dev(c, c->sk_st, t.st_ent)) || (rc = put_dev(c, c->sd_st, t.st_dir)) || (rc = put_dev(c, c->sr_st, t.st_rdir)) ||
+        (rc = put_dev(c, c->sk_en, t.en_ent)) || (rc = put_dev(c, c->sd_en, t.en_dir)) || (rc = put_dev(c, c->tid_base, t.tid_base)) ||
+        (rc = put_dev(c, c->key_dir, t.key_dir)) || (rc = put_dev(c, c->kb_base, t.kb_base)) || (rc = put_dev(c, c->hdr, t.hdr)) ||
+        (rc = put_dev(c, c->anno_key, t.key)) || (rc = put_dev(c, c->anno_ex, t.ex))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));              // (t is a local)
+    c->h_anno_key_raw.swap(t.key_raw);
+    c->h_anno_key_pm.swap(t.key);
+    c->seq = l2r_ctx::Stream();
+    c->n_compact = t.n_compact; c->n_wide = t.n_wide; c->n_tid_dir = t.n_tid_dir; c->n_tid_key = t.n_tid_key;
+    c->n_tx = a->n_tx; c->n_anno_exon = a->n_exon;
     c->have_win = false; c->ran = false; drop_graph(c);
     return 0;
 }

@@ -132,7 +132,7 @@ static uint32_t add_name(h_gtf *g, const char *s, const char *who)
     return h_str_add(&g->names, s);
 }
 
-void h_read_gtf(const char *fn, const h_chroms *chr, h_gtf *g, int as_reads)
+static void parse_gtf(const char *fn, const h_chroms *chr, h_gtf *g, int as_reads)
 {
     const char *who = as_reads ? "read_gtf_trans" : "read_anno_trans";
     memset(g, 0, sizeof *g);
@@ -197,6 +197,129 @@ void h_read_gtf(const char *fn, const h_chroms *chr, h_gtf *g, int as_reads)
     flush_tx(&b);
     free(b.ex); free(st);
     if (buf) munmap(buf, len);
+}
+
+/* ---- the parsed GTF on disk (L2R_ANNO_CACHE=<directory>): the transcript arrays and the name table of one GTF as read
+ * against one BAM header, keyed by the file's path, size and modification time, the header's chromosome names and the
+ * reading mode.  The reference parses the GTF anew on every invocation (src/gtf.c:468-521), the pipeline runs update-gtf
+ * twice per sample on the same file.  A file that does not match in any respect is ignored and rewritten. */
+static uint64_t fnv64(uint64_t h, const void *p, size_t n)
+{
+    const uint8_t *b = (const uint8_t *)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ULL; }
+    return h;
+}
+
+/* (8 bytes a step: the payload checksum runs over ~30 MB for a GENCODE-size GTF) */
+static uint64_t mix64(uint64_t h, const void *p, size_t n)
+{
+    const uint8_t *b = (const uint8_t *)p;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 0x9E3779B97F4A7C15ULL; h ^= h >> 29; }
+    uint64_t w = 0;
+    if (i < n) { memcpy(&w, b + i, n - i); h = (h ^ w) * 0x9E3779B97F4A7C15ULL; h ^= h >> 29; }
+    return (h ^ n) * 0xD6E8FEB86659FD93ULL;
+}
+
+typedef struct { char magic[8]; uint64_t key; int64_t n_tx, n_ex, names_len; int32_t gene_n, pad; uint64_t sum; } gtf_cache_head;
+
+static uint64_t gtf_payload_sum(const h_gtf *g)
+{
+    const size_t T = (size_t)g->n_tx, X = (size_t)g->n_ex;
+    uint64_t h = 0x51ed270b;
+    h = mix64(h, g->tid, T * 4); h = mix64(h, g->start, T * 4); h = mix64(h, g->end, T * 4); h = mix64(h, g->rev, T);
+    h = mix64(h, g->ex_off, (T + 1) * 8); h = mix64(h, g->ex_start, X * 4); h = mix64(h, g->ex_end, X * 4);
+    h = mix64(h, g->gid, T * 4); h = mix64(h, g->gname, T * 4); h = mix64(h, g->tids, T * 4); h = mix64(h, g->tname, T * 4);
+    return mix64(h, g->names.buf, g->names.len);
+}
+
+static char *gtf_cache_path(const char *fn, const h_chroms *chr, int as_reads, uint64_t *key_out)
+{
+    const char *dir = getenv("L2R_ANNO_CACHE");
+    if (!dir || !*dir) return NULL;
+    struct stat sb;
+    if (stat(fn, &sb) != 0) return NULL;
+    char *real = realpath(fn, NULL);
+    uint64_t h = 0xcbf29ce484222325ULL;
+    h = fnv64(h, real ? real : fn, strlen(real ? real : fn));
+    free(real);
+    const int64_t meta[4] = {(int64_t)sb.st_size, (int64_t)sb.st_mtim.tv_sec, (int64_t)sb.st_mtim.tv_nsec, as_reads};
+    h = fnv64(h, meta, sizeof meta);
+    for (int i = 0; i < chr->n_hdr; ++i) h = fnv64(h, chr->name[i], strlen(chr->name[i]) + 1);
+    *key_out = h;
+    char *path = (char *)h_malloc(strlen(dir) + 64);
+    sprintf(path, "%s/l2r_gtf_%016llx.parsed", dir, (unsigned long long)h);
+    return path;
+}
+
+static int gtf_cache_load(const char *path, uint64_t key, h_gtf *g)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return 0;
+    gtf_cache_head hd;
+    int ok = fread(&hd, sizeof hd, 1, f) == 1 && memcmp(hd.magic, "L2RGTF01", 8) == 0 && hd.key == key && hd.n_tx >= 0 && hd.n_ex >= 0 &&
+             hd.names_len >= 0 && hd.n_tx < (1LL << 31) && hd.n_ex < (1LL << 31) && hd.names_len < (1LL << 40);
+    if (ok) {
+        const int64_t want = (int64_t)sizeof hd + hd.n_tx * (4 * 3 + 1 + 4 * 4) + (hd.n_tx + 1) * 8 + hd.n_ex * 8 + hd.names_len;
+        fseek(f, 0, SEEK_END);
+        ok = ftell(f) == want;
+        fseek(f, (long)sizeof hd, SEEK_SET);
+    }
+    if (!ok) { fclose(f); return 0; }
+    memset(g, 0, sizeof *g);
+    const size_t T = (size_t)hd.n_tx, X = (size_t)hd.n_ex;
+    g->n_tx = g->cap_tx = hd.n_tx; g->n_ex = g->cap_ex = hd.n_ex; g->gene_n = hd.gene_n;
+    g->tid = (int32_t *)h_malloc(T * 4 + 4); g->start = (int32_t *)h_malloc(T * 4 + 4); g->end = (int32_t *)h_malloc(T * 4 + 4);
+    g->rev = (uint8_t *)h_malloc(T + 1); g->ex_off = (int64_t *)h_malloc((T + 1) * 8);
+    g->ex_start = (int32_t *)h_malloc(X * 4 + 4); g->ex_end = (int32_t *)h_malloc(X * 4 + 4);
+    g->gid = (uint32_t *)h_malloc(T * 4 + 4); g->gname = (uint32_t *)h_malloc(T * 4 + 4); g->tids = (uint32_t *)h_malloc(T * 4 + 4); g->tname = (uint32_t *)h_malloc(T * 4 + 4);
+    g->names.buf = (char *)h_malloc((size_t)hd.names_len + 1); g->names.len = g->names.cap = (size_t)hd.names_len;
+#define RD(p, sz, n) (ok = ok && ((n) == 0 || fread((p), (sz), (n), f) == (n)))
+    RD(g->tid, 4, T); RD(g->start, 4, T); RD(g->end, 4, T); RD(g->rev, 1, T); RD(g->ex_off, 8, T + 1);
+    RD(g->ex_start, 4, X); RD(g->ex_end, 4, X); RD(g->gid, 4, T); RD(g->gname, 4, T); RD(g->tids, 4, T); RD(g->tname, 4, T);
+    RD(g->names.buf, 1, (size_t)hd.names_len);
+#undef RD
+    fclose(f);
+    /* the payload is what was written; offsets and name ids stay inside their arrays */
+    ok = ok && gtf_payload_sum(g) == hd.sum;
+    ok = ok && g->ex_off[0] == 0 && g->ex_off[T] == (int64_t)X && (hd.names_len == 0 || g->names.buf[hd.names_len - 1] == 0);
+    for (size_t i = 0; ok && i < T; ++i)
+        ok = g->ex_off[i] <= g->ex_off[i + 1] && g->gid[i] < (uint64_t)hd.names_len && g->gname[i] < (uint64_t)hd.names_len &&
+             g->tids[i] < (uint64_t)hd.names_len && g->tname[i] < (uint64_t)hd.names_len;
+    if (!ok) { h_gtf_free(g); return 0; }
+    return 1;
+}
+
+static void gtf_cache_store(const char *path, uint64_t key, const h_gtf *g)
+{
+    const char *dir = getenv("L2R_ANNO_CACHE");
+    (void)mkdir(dir, 0777);
+    char *tmp = (char *)h_malloc(strlen(path) + 32);
+    sprintf(tmp, "%s.tmp.%ld", path, (long)getpid());
+    FILE *f = fopen(tmp, "wb");
+    if (!f) { free(tmp); return; }                         /* a cache that cannot be written is no error */
+    gtf_cache_head hd; memset(&hd, 0, sizeof hd);
+    memcpy(hd.magic, "L2RGTF01", 8); hd.key = key; hd.n_tx = g->n_tx; hd.n_ex = g->n_ex; hd.names_len = (int64_t)g->names.len; hd.gene_n = g->gene_n;
+    hd.sum = gtf_payload_sum(g);
+    const size_t T = (size_t)g->n_tx, X = (size_t)g->n_ex;
+    int ok = fwrite(&hd, sizeof hd, 1, f) == 1;
+#define WR(p, sz, n) (ok = ok && ((n) == 0 || fwrite((p), (sz), (n), f) == (n)))
+    WR(g->tid, 4, T); WR(g->start, 4, T); WR(g->end, 4, T); WR(g->rev, 1, T); WR(g->ex_off, 8, T + 1);
+    WR(g->ex_start, 4, X); WR(g->ex_end, 4, X); WR(g->gid, 4, T); WR(g->gname, 4, T); WR(g->tids, 4, T); WR(g->tname, 4, T);
+    WR(g->names.buf, 1, g->names.len);
+#undef WR
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp, path) != 0) remove(tmp);
+    free(tmp);
+}
+
+void h_read_gtf(const char *fn, const h_chroms *chr, h_gtf *g, int as_reads)
+{
+    uint64_t key = 0;
+    char *path = gtf_cache_path(fn, chr, as_reads, &key);
+    if (path && gtf_cache_load(path, key, g)) { free(path); return; }
+    parse_gtf(fn, chr, g, as_reads);
+    if (path) { gtf_cache_store(path, key, g); free(path); }
 }
 
 void h_gtf_free(h_gtf *g)

@@ -266,3 +266,44 @@ def test_config5_shard(engine, oracle):
     assert ((want2.info & 32) != 0).sum() > 1000 and ((want2.ex_flag & 16) != 0).sum() > 100
     _check_accepted_list(engine, got2, 0)
     engine.set_junctions(None)
+
+
+def test_annotation_table_cache(oracle, tmp_path):
+    """l2r_set_annotation_cache: the first engine builds the tables and stores them (state 1), the second reads them
+    (state 2) and classifies bit-exactly; another annotation gets a file of its own; a truncated file and one with a
+    flipped payload byte are ignored and rewritten (state 1)."""
+    import os
+    anno, af, reads = util.make_case(19, n_reads=20000, n_exons=5, anno_exons=15000, shuffle=True, long_tx=1)
+    op = oracle.default_params(full_level=3)
+    want = util.oracle_run(oracle, af, reads, op)
+    cache = tmp_path / "cache"
+
+    def run(af_, reads_, want_):
+        e = capi.Engine(0)
+        try:
+            e.set_annotation_cache(str(cache))
+            e.set_annotation(af_.tx_tid, af_.tx_start, af_.tx_end, af_.tx_rev, af_.tx_ex_off, af_.ex_start, af_.ex_end)
+            state = e.annotation_cache_state()
+            got = e.classify(reads_, util.to_engine_params(capi, op))
+        finally:
+            e.close()
+        util.assert_same_result(got, want_, 0, 0)
+        return state
+
+    assert run(af, reads, want) == 1
+    files = sorted(os.listdir(cache))
+    assert len(files) == 1 and files[0].endswith(".tables")
+    assert run(af, reads, want) == 2 and sorted(os.listdir(cache)) == files
+    anno2, af2, reads2 = util.make_case(20, n_reads=5000, n_exons=5, anno_exons=8000)
+    want2 = util.oracle_run(oracle, af2, reads2, op)
+    assert run(af2, reads2, want2) == 1 and len(os.listdir(cache)) == 2
+    assert run(af2, reads2, want2) == 2
+    path = cache / files[0]
+    raw = bytearray(open(path, "rb").read())
+    open(path, "wb").write(bytes(raw[: len(raw) - 1000]))
+    assert run(af, reads, want) == 1                       # truncated: rebuilt + rewritten
+    assert run(af, reads, want) == 2
+    raw[len(raw) // 2] ^= 0x10
+    open(path, "wb").write(bytes(raw))
+    assert run(af, reads, want) == 1                       # payload checksum
+    assert run(af, reads, want) == 2

@@ -251,6 +251,66 @@ np.savez(sys.argv[3], **a)
     assert r.returncode != 0 and b"CRC32 mismatch" in r.stderr
 
 
+def test_parsed_gtf_cache(tmp_path, synth_files):
+    """L2R_ANNO_CACHE: the second job over the same GTF + header reads the parsed arrays back (same arrays, same names);
+    a changed GTF (other size / mtime), another header or a damaged cache file is parsed anew."""
+    d, anno, reads, sam, gtf = synth_files[:5]
+    cache = tmp_path / "cache"
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from lr2rmats_amd import hostlib
+j = hostlib.Job(["update-gtf", "-o", sys.argv[4], sys.argv[1], sys.argv[2]], open_outputs=False)
+a = j.annotation_arrays()
+np.savez(sys.argv[3], **a)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def arrays(tag, gtf_file, env):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, sam, gtf_file, out, str(tmp_path / "o.gtf")], stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        return dict(np.load(out))
+
+    plain = arrays("plain", gtf, dict(os.environ))
+    env = dict(os.environ, L2R_ANNO_CACHE=str(cache))
+    first = arrays("first", gtf, env)
+    files = sorted(os.listdir(cache))
+    assert len(files) == 1 and files[0].startswith("l2r_gtf_") and files[0].endswith(".parsed")
+    stamp = os.path.getmtime(cache / files[0])
+    second = arrays("second", gtf, env)
+    assert os.path.getmtime(cache / files[0]) == stamp and sorted(os.listdir(cache)) == files       # read, not rewritten
+    for k in plain:
+        np.testing.assert_array_equal(plain[k], first[k])
+        np.testing.assert_array_equal(plain[k], second[k])
+    # the names come back too: the updated GTF written from cached arrays is the uncached one
+    outs = {}
+    for tag, e in (("n", dict(os.environ)), ("c", env)):
+        o = str(tmp_path / (tag + ".det"))
+        assert _host_with_oracle_results(["update-gtf", "-l", "3", "-a", o, "-o", str(tmp_path / (tag + ".gtf")), sam, gtf], env=e) == 0
+        outs[tag] = (o, str(tmp_path / (tag + ".gtf")))
+    assert filecmp.cmp(outs["n"][0], outs["c"][0], shallow=False) and filecmp.cmp(outs["n"][1], outs["c"][1], shallow=False)
+    # a GTF with one transcript less under the same name: other size -> other key
+    lines = open(gtf).read().splitlines(keepends=True)
+    gtf2 = str(tmp_path / "cut.gtf")
+    open(gtf2, "w").write("".join(lines[: len(lines) * 2 // 3]))
+    cut_plain, cut_cached = arrays("cp", gtf2, dict(os.environ)), arrays("cc", gtf2, env)
+    assert cut_plain["tx_tid"].shape[0] < plain["tx_tid"].shape[0]
+    for k in cut_plain:
+        np.testing.assert_array_equal(cut_plain[k], cut_cached[k])
+    assert len(os.listdir(cache)) == 2
+    # damage: a truncated file and one with a flipped offset are both ignored (and replaced)
+    path = cache / files[0]
+    raw = bytearray(open(path, "rb").read())
+    open(path, "wb").write(bytes(raw[: len(raw) // 2]))
+    again = arrays("again", gtf, env)
+    raw[64 + 8 * 3 + 100] ^= 0xff
+    open(path, "wb").write(bytes(raw))
+    again2 = arrays("again2", gtf, env)
+    for k in plain:
+        np.testing.assert_array_equal(plain[k], again[k])
+        np.testing.assert_array_equal(plain[k], again2[k])
+
+
 def test_gtf_input_mode(oracle, tmp_path):
     """`update-gtf -m g -b hdr.sam reads.gtf anno.gtf`: read-like transcripts from a GTF (here the reads' own bam2gtf
     output, trans_name != trans_id after editing) take the alignment records' place; files equal the oracle's."""
