@@ -214,6 +214,30 @@ void        *l2r_stream(l2r_ctx *ctx);                                  /* hipSt
 /* upload + run + sync + download in one call (the host CLI uses this). */
 int          l2r_classify(l2r_ctx *ctx, const l2r_reads *reads, l2r_result *res);
 
+/* ---- `filter` (src/bam_filter.c): the per-record test + score and the per-read choice of the best alignment.
+ * Replaces gtf_filter() :61-86 with remove_overlap() :48-59, and the selection loop of bam_filter() :128-154; reading the
+ * records and writing the BAM stay with the caller (host/filter.c). */
+typedef struct { float cov_rate, map_qual, sec_rat; int32_t min_intron_n; } l2r_filter_params;   /* -v 0.67  -q 0.75  -s 0.98  -i 0 */
+typedef struct {
+    int64_t n, n_cigar;
+    const uint16_t *flag;           /* FLAG */
+    const int32_t *tid, *pos;       /* core.tid, core.pos (0-based) */
+    const int32_t *l_qseq;          /* core.l_qseq */
+    const int32_t *nm;              /* bam_aux2i() of the NM tag: its value for the integer types, 0 for any other type */
+    const int64_t *cig_off;         /* n + 1 */
+    const uint32_t *cig;            /* len << 4 | op */
+} l2r_filter_records;
+/* transcripts of the -r GTF in FILE order, as read_anno_trans() leaves them (tid -1: chromosome not in the header) */
+typedef struct { int64_t n; const int32_t *tid, *start, *end; } l2r_filter_spans;
+/* drop[i] = gtf_filter() != 0; score[i] / intron_n[i] = its two outputs (score 0 for dropped records) */
+int          l2r_filter_score(l2r_ctx *ctx, const l2r_filter_records *recs, const l2r_filter_params *prm,
+                              const l2r_filter_spans *remove /* NULL: no -r */, uint8_t *drop, int32_t *score, int32_t *intron_n);
+/* Groups = runs of consecutive KEPT records with one read name (the dropped ones are invisible to bam_filter()'s loop);
+ * group g covers rows [group_off[g], group_off[g+1]) of score / intron_n (the kept records, in input order).
+ * winner[g] = row of the alignment that is written, or -1 when the read is not retained. */
+int          l2r_filter_select(l2r_ctx *ctx, int64_t n_groups, const int64_t *group_off, const int32_t *score,
+                               const int32_t *intron_n, const l2r_filter_params *prm, int64_t *winner);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ EXPORTS = [
     "l2r_abi_version", "l2r_last_error", "l2r_device_count", "l2r_create", "l2r_destroy", "l2r_set_params",
     "l2r_set_outputs", "l2r_set_annotation", "l2r_set_junctions", "l2r_upload_reads", "l2r_run", "l2r_sync", "l2r_run_timed",
     "l2r_result_sizes", "l2r_download", "l2r_download_accepted", "l2r_device_view_get", "l2r_stream", "l2r_classify",
-    "l2r_stage_kernel", "l2r_set_annotation_cache", "l2r_annotation_cache_state",
+    "l2r_stage_kernel", "l2r_set_annotation_cache", "l2r_annotation_cache_state", "l2r_filter_score", "l2r_filter_select",
 ]
 
 _i32p, _i64p, _u8p, _u32p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
@@ -69,6 +69,19 @@ class CDeviceView(C.Structure):
                 ("ex_off", C.c_void_p), ("ex_start", C.c_void_p), ("ex_end", C.c_void_p), ("ex_flag", C.c_void_p),
                 ("info", C.c_void_p), ("ref_tx", C.c_void_p), ("acc_rec", C.c_void_p), ("acc_ex_off", C.c_void_p),
                 ("acc_ex_start", C.c_void_p), ("acc_ex_end", C.c_void_p), ("acc_ex_flag", C.c_void_p)]
+
+
+class CFilterParams(C.Structure):
+    _fields_ = [("cov_rate", C.c_float), ("map_qual", C.c_float), ("sec_rat", C.c_float), ("min_intron_n", C.c_int32)]
+
+
+class CFilterRecords(C.Structure):
+    _fields_ = [("n", C.c_int64), ("n_cigar", C.c_int64), ("flag", C.c_void_p), ("tid", C.c_void_p), ("pos", C.c_void_p),
+                ("l_qseq", C.c_void_p), ("nm", C.c_void_p), ("cig_off", C.c_void_p), ("cig", C.c_void_p)]
+
+
+class CFilterSpans(C.Structure):
+    _fields_ = [("n", C.c_int64), ("tid", C.c_void_p), ("start", C.c_void_p), ("end", C.c_void_p)]
 
 
 class CTiming(C.Structure):
@@ -123,6 +136,8 @@ def load_library():
         lib.l2r_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.l2r_set_annotation_cache.argtypes = [C.c_void_p, C.c_char_p]
         lib.l2r_annotation_cache_state.argtypes = [C.c_void_p]
+        lib.l2r_filter_score.argtypes = [C.c_void_p] * 7
+        lib.l2r_filter_select.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
         lib.l2r_stage_kernel.restype = C.c_char_p
         lib.l2r_stage_kernel.argtypes = [C.c_void_p, C.c_int]
         _lib = lib
@@ -208,6 +223,30 @@ class Engine:
         a = [np.ascontiguousarray(x, np.int32) for x in sj]
         cj = CJunctions(len(a[0]), *[_ptr(x, _i32p) for x in a])
         self._chk(self.lib.l2r_set_junctions(self.ctx, C.byref(cj)))
+
+    # ---- `filter` (include/lr2rmats_hip.h: l2r_filter_score / l2r_filter_select)
+    def filter_score(self, flag, tid, pos, l_qseq, nm, cig_off, cig, prm: "CFilterParams", spans=None):
+        """(drop, score, intron_n) of every record; spans = (tid, start, end) of the -r transcripts in file order."""
+        a = [np.ascontiguousarray(flag, np.uint16), np.ascontiguousarray(tid, np.int32), np.ascontiguousarray(pos, np.int32),
+             np.ascontiguousarray(l_qseq, np.int32), np.ascontiguousarray(nm, np.int32), np.ascontiguousarray(cig_off, np.int64),
+             np.ascontiguousarray(cig, np.uint32)]
+        n = int(a[0].shape[0])
+        recs = CFilterRecords(n, int(a[6].shape[0]), *[x.ctypes.data for x in a])
+        sp = None
+        if spans is not None:
+            s = [np.ascontiguousarray(x, np.int32) for x in spans]
+            sp = CFilterSpans(int(s[0].shape[0]), *[x.ctypes.data for x in s])
+        drop = np.zeros(max(n, 1), np.uint8); score = np.zeros(max(n, 1), np.int32); intron = np.zeros(max(n, 1), np.int32)
+        self._chk(self.lib.l2r_filter_score(self.ctx, C.byref(recs), C.byref(prm), C.byref(sp) if sp is not None else None,
+                                            drop.ctypes.data, score.ctypes.data, intron.ctypes.data))
+        return drop[:n], score[:n], intron[:n]
+
+    def filter_select(self, group_off, score, intron_n, prm: "CFilterParams"):
+        g = np.ascontiguousarray(group_off, np.int64); s = np.ascontiguousarray(score, np.int32); i = np.ascontiguousarray(intron_n, np.int32)
+        ng = int(g.shape[0]) - 1
+        win = np.zeros(max(ng, 1), np.int64)
+        self._chk(self.lib.l2r_filter_select(self.ctx, ng, g.ctypes.data, s.ctypes.data, i.ctypes.data, C.byref(prm), win.ctypes.data))
+        return win[:ng]
 
     def set_annotation_cache(self, directory) -> None:
         """Keep the annotation tables on disk under ``directory`` (None: off); see include/lr2rmats_hip.h."""

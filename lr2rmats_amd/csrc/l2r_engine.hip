@@ -18,6 +18,7 @@
 #include "l2r_kernels.hip.h"
 #include "l2r_fused.hip.h"
 #include "l2r_slab.hip.h"
+#include "l2r_filter.hip.h"
 
 using namespace l2r;
 
@@ -1363,6 +1364,94 @@ int l2r_classify(l2r_ctx *c, const l2r_reads *reads, l2r_result *res)
     if ((rc = l2r_run(c))) return rc;
     if ((rc = l2r_sync(c))) return rc;
     return l2r_download(c, res);
+}
+
+// ---------------------------------------------------------------------------------------------- filter
+extern "C++" {
+template <typename T> static int to_dev(l2r_ctx *c, DevBuf<T> &b, const T *src, size_t n)
+{
+    if (b.ensure(n ? n : 1)) return -2;
+    if (n) HIP_TRY(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+}
+
+int l2r_filter_score(l2r_ctx *c, const l2r_filter_records *r, const l2r_filter_params *prm, const l2r_filter_spans *rm,
+                     uint8_t *drop, int32_t *score, int32_t *intron_n)
+{
+    if (!c || !r || !prm || !drop || !score || !intron_n) return fail(-1, "[l2r_filter_score] null argument");
+    if (r->n < 0 || r->n_cigar < 0) return fail(-1, "[l2r_filter_score] negative size");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t N = (size_t)r->n;
+    if (N && (r->cig_off[0] != 0 || r->cig_off[N] != r->n_cigar)) return fail(-1, "[l2r_filter_score] cig_off does not span the CIGAR array");
+    // the -r transcripts a record of every chromosome can meet (l2r_filter.hip.h FilterSpans), on the host
+    std::vector<int64_t> off; std::vector<int32_t> st, pe;
+    int32_t n_tid = 0;
+    if (rm && rm->n > 0) {
+        for (int64_t j = 0; j < rm->n; ++j) n_tid = std::max(n_tid, rm->tid[j] + 1);
+        // first_gt[v]: first transcript (file order) with tid > v = where remove_overlap() stops for a record of tid v
+        std::vector<int64_t> first_gt((size_t)n_tid, rm->n);
+        int32_t seen = -1;                                 // largest tid so far
+        for (int64_t j = 0; j < rm->n; ++j) if (rm->tid[j] > seen) { for (int32_t v = std::max(seen, 0); v < rm->tid[j]; ++v) first_gt[(size_t)v] = std::min(first_gt[(size_t)v], j); seen = rm->tid[j]; }
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> per((size_t)n_tid);
+        for (int64_t j = 0; j < rm->n; ++j) { const int32_t t = rm->tid[j]; if (t >= 0 && j < first_gt[(size_t)t]) per[(size_t)t].push_back({rm->start[j], rm->end[j]}); }
+        off.assign((size_t)n_tid + 1, 0);
+        for (int32_t t = 0; t < n_tid; ++t) {
+            auto &v = per[(size_t)t];
+            std::sort(v.begin(), v.end());
+            int32_t run = INT32_MIN;
+            for (auto &se : v) { run = std::max(run, se.second); st.push_back(se.first); pe.push_back(run); }
+            off[(size_t)t + 1] = (int64_t)st.size();
+        }
+    }
+    DevBuf<uint16_t> d_flag; DevBuf<int32_t> d_tid, d_pos, d_lq, d_nm, d_score, d_in, d_st, d_pe; DevBuf<int64_t> d_off, d_soff; DevBuf<uint32_t> d_cig; DevBuf<uint8_t> d_drop;
+    int rc = 0;
+    if ((rc = to_dev(c, d_flag, r->flag, N)) || (rc = to_dev(c, d_tid, r->tid, N)) || (rc = to_dev(c, d_pos, r->pos, N)) || (rc = to_dev(c, d_lq, r->l_qseq, N)) ||
+        (rc = to_dev(c, d_nm, r->nm, N)) || (rc = to_dev(c, d_off, r->cig_off, N + 1)) || (rc = to_dev(c, d_cig, r->cig, (size_t)r->n_cigar)) ||
+        (rc = to_dev(c, d_soff, off.data(), off.size())) || (rc = to_dev(c, d_st, st.data(), st.size())) || (rc = to_dev(c, d_pe, pe.data(), pe.size())) ||
+        d_drop.ensure(N ? N : 1) || d_score.ensure(N ? N : 1) || d_in.ensure(N ? N : 1)) { rc = rc ? rc : -2; }
+    if (!rc && N) {
+        const FilterPrm fp{prm->cov_rate, prm->map_qual, prm->sec_rat, prm->min_intron_n};
+        const FilterSpans sp{d_soff.p, d_st.p, d_pe.p, n_tid};
+        hipLaunchKernelGGL(k_filter_score, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (int64_t)N, (const uint16_t *)d_flag.p, (const int32_t *)d_tid.p,
+                           (const int32_t *)d_pos.p, (const int32_t *)d_lq.p, (const int32_t *)d_nm.p, (const int64_t *)d_off.p, (const uint32_t *)d_cig.p, fp, sp,
+                           d_drop.p, d_score.p, d_in.p);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(drop, d_drop.p, N, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(score, d_score.p, N * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(intron_n, d_in.p, N * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) rc = fail(-2, "[l2r_filter_score] %s", hipGetErrorString(e));
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);          // (the host vectors and the DevBufs above are locals)
+    if (!rc && e != hipSuccess) rc = fail(-2, "[l2r_filter_score] %s", hipGetErrorString(e));
+    d_flag.release(); d_tid.release(); d_pos.release(); d_lq.release(); d_nm.release(); d_score.release(); d_in.release(); d_st.release(); d_pe.release();
+    d_off.release(); d_soff.release(); d_cig.release(); d_drop.release();
+    return rc;
+}
+
+int l2r_filter_select(l2r_ctx *c, int64_t n_groups, const int64_t *group_off, const int32_t *score, const int32_t *intron_n,
+                      const l2r_filter_params *prm, int64_t *winner)
+{
+    if (!c || !prm || n_groups < 0 || (n_groups && (!group_off || !score || !intron_n || !winner))) return fail(-1, "[l2r_filter_select] bad argument");
+    if (n_groups == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t G = (size_t)n_groups, R = (size_t)group_off[G];
+    for (size_t g = 0; g < G; ++g) if (group_off[g + 1] <= group_off[g]) return fail(-1, "[l2r_filter_select] group %lld is empty", (long long)g);
+    DevBuf<int64_t> d_off, d_win; DevBuf<int32_t> d_score, d_in;
+    int rc = 0;
+    if ((rc = to_dev(c, d_off, group_off, G + 1)) || (rc = to_dev(c, d_score, score, R)) || (rc = to_dev(c, d_in, intron_n, R)) || d_win.ensure(G)) rc = rc ? rc : -2;
+    if (!rc) {
+        const FilterPrm fp{prm->cov_rate, prm->map_qual, prm->sec_rat, prm->min_intron_n};
+        hipLaunchKernelGGL(k_filter_select, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, c->stream, (int64_t)G, (const int64_t *)d_off.p, (const int32_t *)d_score.p,
+                           (const int32_t *)d_in.p, fp, d_win.p);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(winner, d_win.p, G * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) rc = fail(-2, "[l2r_filter_select] %s", hipGetErrorString(e));
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (!rc && e != hipSuccess) rc = fail(-2, "[l2r_filter_select] %s", hipGetErrorString(e));
+    d_off.release(); d_win.release(); d_score.release(); d_in.release();
+    return rc;
 }
 
 }  // extern "C"

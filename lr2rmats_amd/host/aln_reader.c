@@ -12,7 +12,7 @@
 #include <zlib.h>
 #include "l2r_host.h"
 
-typedef struct { uint8_t *p; size_t n; } blob;
+typedef h_blob blob;
 
 static blob slurp_gz(const char *fn, const char *who)
 {
@@ -75,7 +75,7 @@ static void *bgzf_worker(void *arg)
 }
 
 /* Whole file -> memory; BGZF is inflated block-parallel, anything else goes through gzread. */
-static blob slurp(const char *fn, const char *who)
+h_blob h_slurp(const char *fn, const char *who)
 {
     FILE *f = fopen(fn, "rb");
     if (!f) h_fatal(who, "Can not open \"%s\"\n", fn);
@@ -342,7 +342,7 @@ static void parse_bam(const blob *b, h_chroms *chr, h_reads *out, int skip_unmap
 
 static void read_any(const char *fn, h_chroms *chr, h_reads *out, int skip_unmapped, int header_only, const char *who)
 {
-    blob b = slurp(fn, who);
+    blob b = h_slurp(fn, who);
     h_reads tmp; memset(&tmp, 0, sizeof tmp);
     h_reads *dst = out ? out : &tmp;
     reads_reserve(dst, 1, 1);

@@ -706,7 +706,8 @@ int h_main(int argc, char **argv)
     if (strcmp(argv[0], "update-gtf") == 0) return h_cmd_update_gtf(argc, argv);
     if (strcmp(argv[0], "bam2gtf") == 0) return h_cmd_bam2gtf(argc, argv);
     if (strcmp(argv[0], "unique-gtf") == 0) return h_cmd_unique_gtf(argc, argv);
-    if (!strcmp(argv[0], "filter") || !strcmp(argv[0], "fusion") || !strcmp(argv[0], "bam2sj")) {
+    if (strcmp(argv[0], "filter") == 0) return h_cmd_filter(argc, argv);
+    if (!strcmp(argv[0], "fusion") || !strcmp(argv[0], "bam2sj")) {
         fprintf(stderr, "[main] command '%s' is outside the MI355X build (see DESIGN.md, scope)\n", argv[0]);
         return 1;
     }

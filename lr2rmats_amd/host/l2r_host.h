@@ -49,6 +49,25 @@ void h_read_alignments(const char *fn, h_chroms *chr, h_reads *out, int skip_unm
 void h_read_header_only(const char *fn, h_chroms *chr, const char *who);
 void h_reads_free(h_reads *r);
 
+/* ---- whole alignment records, BAM-encoded (`filter`: the kept ones are written out again) */
+typedef struct { uint8_t *p; size_t n; } h_blob;
+h_blob h_slurp(const char *fn, const char *who);             /* whole file, gzip / BGZF inflated (BGZF: on several threads) */
+typedef struct {
+    uint8_t *hdr; size_t hdr_len;          /* the BAM header block: magic, text, references */
+    uint8_t *buf; size_t buf_len;          /* records back to back, each behind its block_size word */
+    int64_t n, cap;
+    int64_t *rec_off;                      /* n + 1: record i = buf[rec_off[i], rec_off[i + 1]) */
+    /* what the tests of `filter` read (l2r_filter_records) */
+    uint16_t *flag; int32_t *tid, *pos, *l_qseq, *nm; uint8_t *nm_seen;
+    int64_t *cig_off; uint32_t *cig; int64_t n_cig, cap_cig;
+} h_records;
+void h_read_records(const char *fn, h_chroms *chr, h_records *out, const char *who);
+void h_records_free(h_records *r);
+/* header + the records keep[0..n_keep) (indices, ascending) as a BGZF-compressed BAM stream */
+int  h_write_bam(FILE *fp, const h_records *r, const int64_t *keep, int64_t n_keep);
+int  h_records_to_bam(const char *in_fn, const char *out_fn);
+int  h_filter_run(const char *in_fn, const char *remove_fn, const l2r_filter_params *prm, FILE *out, int64_t *n_written);
+
 /* ---- transcripts from a GTF (annotation, or read-like input of `-m g`) */
 typedef struct {
     int64_t n_tx, cap_tx, n_ex, cap_ex;
@@ -121,6 +140,7 @@ void h_unique_tail(const l2r_params *p, const char *source, FILE *out, int inter
 int h_cmd_update_gtf(int argc, char **argv);
 int h_cmd_bam2gtf(int argc, char **argv);
 int h_cmd_unique_gtf(int argc, char **argv);
+int h_cmd_filter(int argc, char **argv);
 int h_main(int argc, char **argv);
 
 /* ---- staged form of update-gtf, used by the CLI itself and by the one-process-per-GPU driver

@@ -41,6 +41,8 @@ def load_library():
         lib.h_job_part_last_gene.restype = C.c_char_p
         lib.h_job_part_has_first_gene.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
         lib.h_job_part_has_first_gene.restype = C.c_int
+        lib.h_records_to_bam.argtypes = [C.c_char_p, C.c_char_p]
+        lib.h_records_to_bam.restype = C.c_int
         lib.h_job_needs_all_reads.argtypes = [C.c_void_p]
         lib.h_job_needs_all_reads.restype = C.c_int
         lib.h_job_finish_accepted.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
@@ -175,6 +177,12 @@ class Job:
         if self.h:
             self.lib.h_job_free(self.h)
             self.h = None
+
+
+def records_to_bam(in_path: str, out_path: str) -> int:
+    """Every alignment record of ``in_path`` (SAM / gzip SAM / BAM) written as a BAM file: the reader, SAM->BAM encoder and
+    BGZF writer of ``lr2rmats filter`` without its tests (no GPU)."""
+    return load_library().h_records_to_bam(in_path.encode(), out_path.encode())
 
 
 def run_cli(args, stdout_path=None, cwd=None, env=None) -> subprocess.CompletedProcess:
