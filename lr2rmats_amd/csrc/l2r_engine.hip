@@ -959,7 +959,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
                                (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
             MARK(ST_FAST);
             // (tried: the run cut into chunks of tiles, the probes of chunk i on a second stream beside the walk of chunk i + 1 --
-            //  no gain, 0.71 -> 0.72 .. 0.82 ms with 2 .. 16 chunks: profiles/r02/README.md)
+            //  no gain, 0.71 -> 0.72 .. 0.82 ms with 2 .. 16 chunks; both halves in one persistent, software-pipelined kernel
+            //  with the exons read back out of L2 -- 0.86 ms and 4.2 GB of traffic (spills): DESIGN.md section 8)
 #define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L>), dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
                 (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p)
             switch (p.full_level) {

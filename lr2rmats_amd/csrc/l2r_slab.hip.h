@@ -56,21 +56,12 @@ static_assert(sizeof(TileWin) % 16 == 0, "TileWin is copied in 16-byte pieces");
 
 // Both kernels are laid out for SHORT dependent load chains (they are latency bound: a tile's time is the sum of its
 // dependent round trips): everything a lane needs sits at "tile start + slot".
-__global__ __launch_bounds__(TILE_THREADS, 8)
-void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint8_t *__restrict__ u_order,
-                 const int32_t *__restrict__ u_tid, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase)
+// The walk of one tile's reads, one lane per read (slot order): exon k of the read in slot s goes to row k of the tile's slab.
+// Writes the exon rows and ex_off[r]; returns what the rest of the tile's work needs.
+struct SlabWalk { uint32_t pre, r, n; int el; bool active, outlier; };
+__device__ __forceinline__ SlabWalk slab_walk(SlabArgsK sa, FusedArgsK a, uint32_t r0, uint32_t n_act, uint32_t sbase, int32_t tid0,
+                                              const uint8_t *__restrict__ u_order)
 {
-    __shared__ int s_wmax[TILE_THREADS / WAVE];
-    __shared__ uint32_t s_wsum[TILE_THREADS / WAVE], s_wn[TILE_THREADS / WAVE];
-    __shared__ __attribute__((aligned(16))) TileWin s_tw;
-    (void)kernarg_block;
-    const SlabArgsK sa = slab_args();
-    const FusedArgsK a = fused_args();
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    const uint32_t t = blockIdx.x;
-    const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
-    const int32_t tid0 = n_act ? u_tid[r0] : 0, pos0 = n_act ? u_pos[r0] : 0;
-    const uint32_t sbase = u_tile_sbase[t];
     const bool active = threadIdx.x < n_act;
     const uint32_t at = r0 + (active ? threadIdx.x : 0u);
     // ---- the read in this slot and the head of its CIGAR
@@ -142,11 +133,33 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
         put(w.n, w.start, w.end);
         off = run | EXOFF_DENSE;
     }
-    if (active) {
-        const uint32_t pre = (n << 8) | (sane ? 0u : I_PRE_INSANE) | (outlier ? I_PRE_DIRECT : 0u);
-        sa->pre[at] = pre;
-        a->f.ex_off[r] = off;                        // (info[r] is written by k_probe_slab: exon count + verdict)
-    }
+    SlabWalk o;
+    o.pre = (n << 8) | (sane ? 0u : I_PRE_INSANE) | (outlier ? I_PRE_DIRECT : 0u);
+    o.r = r; o.n = n; o.el = el; o.active = active; o.outlier = outlier;
+    if (active) a->f.ex_off[r] = off;              // (info[r] is written by the probe side: exon count + verdict)
+    return o;
+}
+
+__global__ __launch_bounds__(TILE_THREADS, 8)
+void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint8_t *__restrict__ u_order,
+                 const int32_t *__restrict__ u_tid, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase)
+{
+    __shared__ int s_wmax[TILE_THREADS / WAVE];
+    __shared__ uint32_t s_wsum[TILE_THREADS / WAVE], s_wn[TILE_THREADS / WAVE];
+    __shared__ __attribute__((aligned(16))) TileWin s_tw;
+    (void)kernarg_block;
+    const SlabArgsK sa = slab_args();
+    const FusedArgsK a = fused_args();
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x;
+    const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
+    const int32_t tid0 = n_act ? u_tid[r0] : 0, pos0 = n_act ? u_pos[r0] : 0;
+    const uint32_t sbase = u_tile_sbase[t];
+    const SlabWalk w = slab_walk(sa, a, r0, n_act, sbase, tid0, u_order);
+    const bool active = w.active, outlier = w.outlier;
+    const uint32_t n = w.n;
+    const int el = w.el;
+    if (active) sa->pre[r0 + threadIdx.x] = w.pre;
     const int m = wave_max(active ? el : INT32_MIN);
     const uint32_t wsum = wave_sum(active ? n : 0u);
     const int wn = wave_max((active && !outlier) ? (int)n : 0);
@@ -210,6 +223,95 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
     return m;
 }
 
+// The tile's dictionary slices into LDS, re-based to the tile's window (entries loaded by fused_load_dict: one START and one
+// END entry per thread, directory words two per thread).  `win`: the window's transcript numbers (gapped windows).
+struct SlabLds { uint16_t *W; v4i_t *ent0, *ent1; uint8_t *dir0, *dir1, *rdir; };
+__device__ __forceinline__ int slab_stage_dict(const TileDesc &d, const FusedDict &dv, const int *win, const SlabLds &S)
+{
+    const bool fast = (d.flags & TD_FAST) != 0;
+    const int w_n = fast ? (int)d.n_win : 0;
+    v4i_t *const s_ent0 = S.ent0, *const s_ent1 = S.ent1;
+    uint8_t *const s_dir0 = S.dir0, *const s_dir1 = S.dir1, *const s_rdir = S.rdir;
+    int my_wide = 0;
+    if (fast) {
+        if ((int)threadIdx.x < SLAB_KEY_CAP) {
+            const bool has_st = threadIdx.x < d.st_nk, has_en = threadIdx.x < d.en_nk;
+            v4i_t e0, e1;
+            e0.x = dv.xa.x; e0.y = dv.xa.y; e1.x = dv.xc.x; e1.y = dv.xc.y;
+            if (d.flags & TD_CONTIG) {
+                e0.z = (int)rebase_mask((uint32_t)dv.xb.x, (uint32_t)dv.xb.y, dv.xa.z - d.j_lo);
+                e0.w = (int)rebase_mask((uint32_t)dv.xb.z, (uint32_t)dv.xb.w, dv.xa.z - d.j_lo);
+                e1.z = (int)rebase_mask((uint32_t)dv.xd.x, (uint32_t)dv.xd.y, dv.xc.z - d.j_lo);
+                e1.w = (int)rebase_mask((uint32_t)dv.xd.z, (uint32_t)dv.xd.w, dv.xc.z - d.j_lo);
+            } else {
+                e0.z = (int)rebase_gaps(win, w_n, (uint32_t)dv.xb.x, (uint32_t)dv.xb.y, dv.xa.z);
+                e0.w = (int)rebase_gaps(win, w_n, (uint32_t)dv.xb.z, (uint32_t)dv.xb.w, dv.xa.z);
+                e1.z = (int)rebase_gaps(win, w_n, (uint32_t)dv.xd.x, (uint32_t)dv.xd.y, dv.xc.z);
+                e1.w = (int)rebase_gaps(win, w_n, (uint32_t)dv.xd.z, (uint32_t)dv.xd.w, dv.xc.z);
+            }
+            if (has_st) { s_ent0[threadIdx.x] = e0; if (dv.xa.w & SE_WIDE) my_wide = 1; }
+            if (has_en) { s_ent1[threadIdx.x] = e1; if (dv.xc.w & SE_WIDE) my_wide = 1; }
+        }
+        if (d.nbk > 0) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int i = (int)threadIdx.x + qq * TILE_THREADS;
+                if (i <= d.nbk) {
+                    s_dir0[i] = (uint8_t)(dv.dd[0][qq] - d.st_r0); s_dir1[i] = (uint8_t)(dv.dd[1][qq] - d.en_r0);
+                    s_rdir[i] = (uint8_t)(dv.dd[2][qq] - d.st_r0);
+                }
+            }
+        }
+        if (threadIdx.x < 3u && (threadIdx.x > 0u || d.nbk == 0)) {
+            s_dir0[d.nbk + (int)threadIdx.x] = (uint8_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint8_t)d.en_nk;
+        }
+    }
+    return my_wide;
+}
+
+// Verdicts of one tile's reads (slot order) from the staged window + dictionaries: the device functions of the classic kernel
+// on slab-resident exons; flags into the slab rows, info / ref_tx per read, redo list.
+template <int LEVEL>
+__device__ __forceinline__ void slab_classify(FusedArgsK a, const TileDesc &d, const SlabLds &S, const int4 *hk, const int4 *hx, const int *win,
+                                              const uint32_t *tilemask, bool active, uint32_t pre, uint32_t r, bool rev_in, int32_t tid,
+                                              uint32_t off, const SlabRows &q, const ReadEnds &re, int any_wide)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const bool fast = (d.flags & TD_FAST) != 0;
+    const int w_n = fast ? (int)d.n_win : 0;
+    const uint32_t n = pre >> 8;
+    const bool outlier = (pre & I_PRE_DIRECT) != 0u;
+    const int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end;
+    uint16_t *const s_W = S.W;
+    // ---- classification (device functions of the classic kernel)
+    uint32_t info = n << 8; int ref = -1;
+    bool redo = active && (!fast || outlier || any_wide != 0 || tid != d.tid || (n > 1 && (pre & I_PRE_INSANE) != 0u));
+    const bool work = active && !redo;
+    const TileLds L{nullptr, nullptr, s_W, S.ent0, S.ent1, S.dir0, S.dir1, S.rdir, hk, hx, win};
+    const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, tilemask);
+    redo = redo || vm.redo;
+    const SiteMasks sm = map_exons_slab(L, d, work && !redo && n > 1, xs, xe, off, n, vm.vpre, q);
+    uint8_t *const xf = a->f.ex_flag;
+    if (work && !redo) {
+        const Verdict vd = decide<LEVEL, (int)SLAB_STRIDE>(L, d, threadIdx.x, n, re, vm, sm, rev_in);
+        info = vd.info; ref = vd.ref;
+        for (uint32_t k = 0; k < n; ++k) st32(xf, off + k * SLAB_STRIDE, (uint8_t)s_W[k * SLAB_STRIDE + threadIdx.x]);       // (rows: coalesced)
+    } else if (active && !outlier) {
+        for (uint32_t k = 0; k < n; ++k) st32(xf, off + k * SLAB_STRIDE, (uint8_t)0);
+    }
+    redo = redo && active;
+    {
+        const unsigned long long m = __ballot(redo);
+        if (m) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(a->f.redo_count, (uint32_t)__popcll(m));
+            at = __shfl(at, 0, WAVE);
+            if (redo) a->f.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+        }
+    }
+    if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; }
+}
+
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, 8)
 void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint8_t *__restrict__ u_order,
@@ -223,7 +325,6 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const FusedArgsK a = fused_args();
-    const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t t = blockIdx.x;
     const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
     const int32_t tid0 = n_act ? u_tid[r0] : 0;
@@ -233,8 +334,6 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     // ---- one round trip behind the descriptor (scalar loads: uniform address): the tile's dictionary slices, its window
     //      (k_walk_slab), the slot's read and the first four rows of its column -- all asked for before anything is looked at
     const TileDesc d = u_tw[t].d;
-    const bool fast = (d.flags & TD_FAST) != 0;
-    const int w_n = fast ? (int)d.n_win : 0;
     // the last row any read of this wave has (k_walk_slab): rows behind it are not asked for
     const uint32_t row_max = max((u_tw[t].pad[0] >> (8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))) & 0xffu, 1u) - 1u;
     const FusedDict dv = fused_load_dict(a, d);
@@ -265,70 +364,11 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     if (active && !outlier) { re.sl = ld32(xs, off + (n - 1u) * SLAB_STRIDE); re.el = ld32(xe, off + (n - 1u) * SLAB_STRIDE); }
     // ---- stage window and dictionary slices, re-based to the tile's window
     if ((int)threadIdx.x < SLAB_TW_VECS) reinterpret_cast<int4 *>(&s_tw)[threadIdx.x] = twv;
-    int my_wide = 0;
-    if (fast) {
-        if ((int)threadIdx.x < SLAB_KEY_CAP) {
-            const bool has_st = threadIdx.x < d.st_nk, has_en = threadIdx.x < d.en_nk;
-            v4i_t e0, e1;
-            e0.x = dv.xa.x; e0.y = dv.xa.y; e1.x = dv.xc.x; e1.y = dv.xc.y;
-            if (d.flags & TD_CONTIG) {
-                e0.z = (int)rebase_mask((uint32_t)dv.xb.x, (uint32_t)dv.xb.y, dv.xa.z - d.j_lo);
-                e0.w = (int)rebase_mask((uint32_t)dv.xb.z, (uint32_t)dv.xb.w, dv.xa.z - d.j_lo);
-                e1.z = (int)rebase_mask((uint32_t)dv.xd.x, (uint32_t)dv.xd.y, dv.xc.z - d.j_lo);
-                e1.w = (int)rebase_mask((uint32_t)dv.xd.z, (uint32_t)dv.xd.w, dv.xc.z - d.j_lo);
-            } else {
-                // (the window's transcript numbers: straight from the loaded vectors' home, they are not in LDS yet)
-                const int *const win = reinterpret_cast<const int *>(u_tw[t].win);
-                e0.z = (int)rebase_gaps(win, w_n, (uint32_t)dv.xb.x, (uint32_t)dv.xb.y, dv.xa.z);
-                e0.w = (int)rebase_gaps(win, w_n, (uint32_t)dv.xb.z, (uint32_t)dv.xb.w, dv.xa.z);
-                e1.z = (int)rebase_gaps(win, w_n, (uint32_t)dv.xd.x, (uint32_t)dv.xd.y, dv.xc.z);
-                e1.w = (int)rebase_gaps(win, w_n, (uint32_t)dv.xd.z, (uint32_t)dv.xd.w, dv.xc.z);
-            }
-            if (has_st) { s_ent0[threadIdx.x] = e0; if (dv.xa.w & SE_WIDE) my_wide = 1; }
-            if (has_en) { s_ent1[threadIdx.x] = e1; if (dv.xc.w & SE_WIDE) my_wide = 1; }
-        }
-        if (d.nbk > 0) {
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const int i = (int)threadIdx.x + qq * TILE_THREADS;
-                if (i <= d.nbk) {
-                    s_dir0[i] = (uint8_t)(dv.dd[0][qq] - d.st_r0); s_dir1[i] = (uint8_t)(dv.dd[1][qq] - d.en_r0);
-                    s_rdir[i] = (uint8_t)(dv.dd[2][qq] - d.st_r0);
-                }
-            }
-        }
-        if (threadIdx.x < 3u && (threadIdx.x > 0u || d.nbk == 0)) {
-            s_dir0[d.nbk + (int)threadIdx.x] = (uint8_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint8_t)d.en_nk;
-        }
-    }
+    const SlabLds S{s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir};
+    // (the window's transcript numbers: straight from the loaded vectors' home, they are not in LDS yet)
+    const int my_wide = slab_stage_dict(d, dv, reinterpret_cast<const int *>(u_tw[t].win), S);
     const int any_wide = __syncthreads_or(my_wide);
-    // ---- classification (device functions of the classic kernel)
-    uint32_t info = n << 8; int ref = -1;
-    bool redo = active && (!fast || outlier || any_wide != 0 || tid != d.tid || (n > 1 && (pre & I_PRE_INSANE) != 0u));
-    const bool work = active && !redo;
-    const TileLds L{nullptr, nullptr, s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
-    const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, s_tw.mask);
-    redo = redo || vm.redo;
-    const SiteMasks sm = map_exons_slab(L, d, work && !redo && n > 1, xs, xe, off, n, vm.vpre, q);
-    uint8_t *const xf = a->f.ex_flag;
-    if (work && !redo) {
-        const Verdict vd = decide<LEVEL, (int)SLAB_STRIDE>(L, d, threadIdx.x, n, re, vm, sm, rev_in);
-        info = vd.info; ref = vd.ref;
-        for (uint32_t k = 0; k < n; ++k) st32(xf, off + k * SLAB_STRIDE, (uint8_t)s_W[k * SLAB_STRIDE + threadIdx.x]);       // (rows: coalesced)
-    } else if (active && !outlier) {
-        for (uint32_t k = 0; k < n; ++k) st32(xf, off + k * SLAB_STRIDE, (uint8_t)0);
-    }
-    redo = redo && active;
-    {
-        const unsigned long long m = __ballot(redo);
-        if (m) {
-            uint32_t at = 0;
-            if (lane == 0) at = atomicAdd(a->f.redo_count, (uint32_t)__popcll(m));
-            at = __shfl(at, 0, WAVE);
-            if (redo) a->f.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
-        }
-    }
-    if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; }
+    slab_classify<LEVEL>(a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, r, rev_in, tid, off, q, re, any_wide);
 }
 
 __global__ __launch_bounds__(TILE_THREADS)
