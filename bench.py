@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--accepted", action="store_true", help="also compact the accepted-novel list (always on with --exchange gathered)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0, help="diagnostics, one GPU: run the shard rank 0 would own in a strong-scaling run of this many GPUs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,10 +166,11 @@ def main():
     cfg = dict(workload.CONFIGS[args.config])
     if args.reads:
         cfg["n_reads"] = args.reads
+    w_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
     if args.scaling == "strong":
         # configs[3]: one read set of cfg["n_reads"] cut into `world` chromosome-aligned shards
-        cfg["n_reads"] = cfg["n_reads"] // world + (1 if rank < cfg["n_reads"] % world else 0)
-    af, reads = workload.make_rank_workload(cfg, rank, world)
+        cfg["n_reads"] = cfg["n_reads"] // w_world + (1 if rank < cfg["n_reads"] % w_world else 0)
+    af, reads = workload.make_rank_workload(cfg, rank, w_world)
 
     eng = capi.Engine(local_rank)
     eng.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
@@ -198,14 +200,19 @@ def main():
         return sum(c[0] for c in allc), sum(c[1] for c in allc)
 
     def step():
+        # One pass of the hot path over the resident batch: asynchronous launches on the engine's stream.  Passes are
+        # independent (each overwrites the results of the one before) and stream order keeps them apart, so the host does
+        # not wait between them: the timed region ends with one synchronisation of the engine's stream + device.  Only the
+        # gathered exchange needs the sizes of a pass on the host, and waits for them.
         eng.run()
-        eng.sync()
         if gather:
+            eng.sync()
             return exchange()
         return None
 
     for _ in range(args.warmup):
         step()
+    eng.sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -214,6 +221,7 @@ def main():
     last = None
     for _ in range(args.steps):
         last = step()
+    eng.sync()                      # (the engine launches on a stream of its own: torch.cuda.synchronize() alone would do, this says it)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
