@@ -18,6 +18,7 @@
 #include "l2r_kernels.hip.h"
 #include "l2r_fused.hip.h"
 #include "l2r_slab.hip.h"
+#include "l2r_wide.hip.h"
 #include "l2r_filter.hip.h"
 
 using namespace l2r;
@@ -74,6 +75,7 @@ struct l2r_ctx {
     DevBuf<int32_t> s_pos;
     DevBuf<uint8_t> s_rev;
     DevBuf<TileWin> tw;
+    DevBuf<TileWin64> tw64; DevBuf<uint32_t> wide_cnt, wide_tile; uint32_t wide_cap = 0;     // tiles with 33 .. 64 window members (l2r_wide.hip.h)
     DevBuf<unsigned long long> ovf_cursor;
     uint32_t ovf_base = 0;
     std::string anno_cache_dir;             // L2R_ANNO_CACHE / l2r_set_annotation_cache: where the annotation tables are kept between runs
@@ -229,7 +231,7 @@ void l2r_destroy(l2r_ctx *c)
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->lub.release(); c->tile_ub.release(); c->tile_start.release(); c->tile_total.release(); c->tile_dest.release();
     c->lin_start.release(); c->lin_end.release(); c->lin_flag.release();
-    c->tile_sbase.release(); c->lin_dest.release(); c->ovf_cursor.release();
+    c->tile_sbase.release(); c->lin_dest.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_cnt.release(); c->wide_tile.release();
     c->s_clo.release(); c->s_pre.release(); c->s_ncig.release(); c->s_pos.release(); c->s_rev.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -800,6 +802,9 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         if (total + ovf < 0x7ffffff0ULL) {
             sbase[T] = (uint32_t)total;                     // (k_probe_slab: rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true; c->ovf_base = (uint32_t)total;
+            c->wide_cap = (uint32_t)std::min<size_t>(T, 8192);
+            if (c->tw64.ensure(c->wide_cap) || c->wide_cnt.ensure(2) || c->wide_tile.ensure(c->wide_cap)) return -2;
+            HIP_TRY(hipMemsetAsync(c->wide_cnt.p, 0, 8, c->stream));
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) ||
                 c->s_clo.ensure((size_t)N + 1) || c->s_pre.ensure((size_t)N + 1) || c->s_ncig.ensure((size_t)N + 1) || c->s_pos.ensure((size_t)N + 1) || c->s_rev.ensure((size_t)N + 1) ||
                 c->ex_start.ensure(std::max<size_t>(exb, total + ovf)) || c->ex_end.ensure(std::max<size_t>(exb, total + ovf)) ||
@@ -955,6 +960,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             // ---- two light kernels at high occupancy: the walk (exons into the tiles' slabs), then the probes (l2r_slab.hip.h)
             SlabArgs sa; sa.g = ga; sa.tile_sbase = c->tile_sbase.p; sa.ovf_cursor = c->ovf_cursor.p; sa.ovf_base = c->ovf_base;
             sa.s_clo = c->s_clo.p; sa.s_ncig = c->s_ncig.p; sa.s_pos = c->s_pos.p; sa.s_rev = c->s_rev.p; sa.pre = c->s_pre.p; sa.tw = c->tw.p;
+            sa.wide_cnt = c->wide_cnt.p; sa.wide_tile = c->wide_tile.p; sa.tw64 = c->tw64.p; sa.wide_cap = c->wide_cap;
             hipLaunchKernelGGL(k_walk_slab, dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, (const uint8_t *)c->order.p,
                                (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
             MARK(ST_FAST);
@@ -972,6 +978,21 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             default: launch_probe_level(0); break;
             }
 #undef launch_probe_level
+            {   // the tiles with 33 .. 64 window members (none on most inputs: the grid finds an empty list and leaves)
+                const WideArgs wa{c->wide_cnt.p + 1, c->wide_tile.p, c->tw64.p};
+                const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, 1024);
+#define launch_wide_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_wide<L>), dim3(gw), dim3(TILE_THREADS), 0, s, sa, wa, (const uint32_t *)c->tile_first.p, \
+                    (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const uint32_t *)c->tile_sbase.p)
+                switch (p.full_level) {
+                case 1: launch_wide_level(1); break;
+                case 2: launch_wide_level(2); break;
+                case 3: launch_wide_level(3); break;
+                case 4: launch_wide_level(4); break;
+                case 5: launch_wide_level(5); break;
+                default: launch_wide_level(0); break;
+                }
+#undef launch_wide_level
+            }
         } else {
         MARK(ST_FAST);
 #define launch_fused_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused<L>), dim3(gp), dim3(TILE_THREADS), 0, s, ga, c->n_tiles, (const uint32_t *)c->tile_first.p, \
@@ -1069,7 +1090,7 @@ int l2r_debug_stamps(l2r_ctx *c, unsigned long long *out, int n)
 }
 
 /* diagnostics: [0] reads the last run sent to the generic kernel, [1] dictionary entries flagged wide,
-   [2] compact transcripts, [3] tiles */
+   [2] compact transcripts, [3] tiles, [4..11] tiles by the reason they are not fast, [12] tiles of k_probe_slab_wide */
 int l2r_debug_counters(l2r_ctx *c, long long *out, int n)
 {
     if (!c || !out || n < 4) return fail(-1, "[l2r_debug_counters] bad argument");
@@ -1078,6 +1099,11 @@ int l2r_debug_counters(l2r_ctx *c, long long *out, int n)
     if (c->totals.p) { HIP_TRY(hipMemcpyAsync(&redo, c->totals.p + 3, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     out[0] = redo; out[1] = c->n_wide; out[2] = c->n_compact; out[3] = c->n_tiles;
     if (n >= 12) for (int k = 0; k < 8; ++k) out[4 + k] = 0;
+    if (n >= 13) {                                          // out[12]: tiles the last run gave to k_probe_slab_wide (33 .. 64 window members)
+        uint32_t w = 0;
+        if (c->slab && c->ran && c->wide_cnt.p) { HIP_TRY(hipMemcpyAsync(&w, c->wide_cnt.p + 1, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+        out[12] = w;
+    }
     if (n >= 12 && c->slab && c->ran && c->tw.p && c->n_tiles > 0) {     // slab pipeline: the descriptors k_walk_slab made
         std::vector<TileWin> w((size_t)c->n_tiles);
         HIP_TRY(hipMemcpyAsync(w.data(), c->tw.p, w.size() * sizeof(TileWin), hipMemcpyDeviceToHost, c->stream));

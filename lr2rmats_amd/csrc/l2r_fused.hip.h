@@ -115,13 +115,26 @@ struct TileWin {
     uint32_t mask[2];            // members with one exon / without TX_COMPACT
     uint32_t pad[2];             // slab pipeline, pad[0]: byte w = largest exon count among the reads of wave w (k_walk_slab)
 };
+// A window of up to 64 members (l2r_wide.hip.h: tiles of loci with many isoforms); same fields, 64-bit member masks
+constexpr int WIDE_TX = 64;
+struct TileWin64 {
+    int4 hk[WIDE_TX];
+    int4 hx[WIDE_TX];
+    int win[WIDE_TX];
+    TileDesc d;
+    unsigned long long mask[2];
+};
 
 // The tile's dictionary slices and transcript window from its span [tlo, thi] on chromosome tid0 -- the descriptor
 // k_pass_a leaves in HBM, made by ONE WAVE of the workgroup (everything is wave-uniform but `lane`).  The window's
 // member headers go straight into LDS.
+// With W64 (slab pipeline): a window of 33 .. 64 members is collected into *W64 and the tile is flagged TD_WIDE instead of
+// TD_FAST (W then only carries the descriptor); up to 32 members everything is as without it.
 __device__ __forceinline__ void make_descriptor(FusedArgsK a, int lane, int32_t tid0, int32_t tlo, int32_t thi, bool in_lds, TileWin *W,
-                                                uint32_t key_cap = (uint32_t)FUSED_KEY_CAP)
+                                                uint32_t key_cap = (uint32_t)FUSED_KEY_CAP, TileWin64 *W64 = nullptr)
 {
+    const uint32_t win_cap = W64 ? (uint32_t)WIDE_TX : (uint32_t)WIN_TX;
+    int *const win_out = W64 ? W64->win : W->win;
     const TxHdr *const hdr = a->f.hdr;
     const int32_t n_tx = a->f.p.n_tx;
     int tb = 0, nb = 0;
@@ -164,7 +177,7 @@ __device__ __forceinline__ void make_descriptor(FusedArgsK a, int lane, int32_t 
             const unsigned long long mo = __ballot(ov) & (stop < WAVE ? (1ull << stop) - 1ull : ~0ull);
             if ((mo >> lane) & 1ull) {
                 const uint32_t rank = n_win + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull));
-                if (rank < (uint32_t)WIN_TX) W->win[rank] = j;
+                if (rank < win_cap) win_out[rank] = j;
             }
             if (mo) {
                 if (first < 0) first = base + __ffsll((long long)mo) - 1;
@@ -173,9 +186,9 @@ __device__ __forceinline__ void make_descriptor(FusedArgsK a, int lane, int32_t 
             n_win += (uint32_t)__popcll(mo);
             if (ma) break;
             base += WAVE;
-            if (n_win > (uint32_t)WIN_TX || trip == WIN_SCAN_TRIPS - 1) { fast = false; why = n_win > (uint32_t)WIN_TX ? 4u : 5u; break; }
+            if (n_win > win_cap || trip == WIN_SCAN_TRIPS - 1) { fast = false; why = n_win > win_cap ? 4u : 5u; break; }
         }
-        if (fast && n_win > (uint32_t)WIN_TX) { fast = false; why = 4u; }
+        if (fast && n_win > win_cap) { fast = false; why = 4u; }
         if (fast) {
             d.n_win = n_win;
             if (n_win) { d.j_lo = first; contig = (uint32_t)(last - first + 1) == n_win; }
@@ -187,7 +200,27 @@ __device__ __forceinline__ void make_descriptor(FusedArgsK a, int lane, int32_t 
         d.en_r0 = ed_r0; d.en_nk = ed_r1 - ed_r0;
         if (fast && (d.st_nk > key_cap || d.en_nk > key_cap)) { fast = false; why = 3u; }
     }
-    d.flags = (fast ? TD_FAST : 0u) | (contig ? TD_CONTIG : 0u) | (why << 8);
+    const bool wide = fast && d.n_win > (uint32_t)WIN_TX;                  // (only with W64)
+    d.flags = (fast ? (wide ? TD_WIDE : TD_FAST) : 0u) | (contig ? TD_CONTIG : 0u) | (why << 8);
+    if (wide) {
+        // all 64 lanes: one member each
+        bool single = false, loose = false;
+        if (lane < (int)d.n_win) {
+            const int j = W64->win[lane];
+            const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);
+            const int4 h0 = hp[0], h1 = hp[1], h2 = hp[2];
+            int st = h0.y, en = h0.z;
+            if (h0.x < tid0) { st = INT32_MIN; en = INT32_MIN; }
+            else if (h0.x > tid0) { st = INT32_MAX; en = INT32_MAX; }
+            W64->hk[lane] = make_int4(st, en, h1.x, (h1.z & 0xff) | (h1.y << 8));
+            W64->hx[lane] = h2;
+            single = h1.x == 1; loose = !((h1.z & 0xff) & TX_COMPACT);
+        }
+        const unsigned long long b1 = __ballot(single), b2 = __ballot(loose);
+        if (lane == 0) { W64->d = d; W64->mask[0] = b1; W64->mask[1] = b2; W->d = d; W->mask[0] = 0u; W->mask[1] = 0u; }
+        return;
+    }
+    if (W64 && lane < WIN_TX) W->win[lane] = W64->win[lane];                // (narrow after all: the members move to the 32-member record)
     // the members' headers (the wave's own LDS writes above are visible to it: same wave, in order)
     const int w_n = fast ? (int)d.n_win : 0;
     bool single = false, loose = false;
@@ -353,7 +386,7 @@ __device__ __forceinline__ FusedDict fused_load_dict(FusedArgsK a, const TileDes
 {
     FusedDict v;
     v.xa = v.xb = v.xc = v.xd = make_int4(0, 0, 0, 0);
-    const bool fast = (d.flags & TD_FAST) != 0;
+    const bool fast = (d.flags & (TD_FAST | TD_WIDE)) != 0;
     if (fast && threadIdx.x < d.st_nk) { const int4 *q = reinterpret_cast<const int4 *>(a->f.st.ent + d.st_r0 + threadIdx.x); v.xa = q[0]; v.xb = q[1]; }
     if (fast && threadIdx.x < d.en_nk) { const int4 *q = reinterpret_cast<const int4 *>(a->f.en.ent + d.en_r0 + threadIdx.x); v.xc = q[0]; v.xd = q[1]; }
 #pragma unroll

@@ -42,6 +42,9 @@ struct SlabArgs {
     const uint32_t *s_clo; const uint16_t *s_ncig; const int32_t *s_pos; const uint8_t *s_rev;
     uint32_t *pre;                                       // k_walk_slab -> k_probe_slab, slot order: exon count << 8 | I_PRE_*
     TileWin *tw;                                         // k_walk_slab -> k_probe_slab: descriptor + window per tile
+    // tiles whose window holds 33 .. 64 transcripts (l2r_wide.hip.h): wide_cnt[0] counts the appends of k_walk_slab, k_probe_slab
+    // moves the count to wide_cnt[1] (what k_probe_slab_wide reads) and clears [0] for the next run
+    uint32_t *wide_cnt; uint32_t *wide_tile; TileWin64 *tw64; uint32_t wide_cap;
 };
 typedef const __attribute__((address_space(4))) SlabArgs *SlabArgsK;
 __device__ __forceinline__ SlabArgsK slab_args()
@@ -147,6 +150,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     __shared__ int s_wmax[TILE_THREADS / WAVE];
     __shared__ uint32_t s_wsum[TILE_THREADS / WAVE], s_wn[TILE_THREADS / WAVE];
     __shared__ __attribute__((aligned(16))) TileWin s_tw;
+    __shared__ __attribute__((aligned(16))) TileWin64 s_tw64;
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const FusedArgsK a = fused_args();
@@ -174,7 +178,20 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     // ---- the tile's descriptor and window, by the last wave alone (the others are done): nobody waits for its load chain
     if (wv != TILE_THREADS / WAVE - 1) return;
     if (lane == 0) a->tile_total[t] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];   // (one word per tile: a single counter would serialise 156 k waves)
-    make_descriptor(a, lane, tid0, pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), true, &s_tw, (uint32_t)SLAB_KEY_CAP);
+    make_descriptor(a, lane, tid0, pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), true, &s_tw, (uint32_t)SLAB_KEY_CAP,
+                    sa->tw64 ? &s_tw64 : nullptr);
+    if (s_tw.d.flags & TD_WIDE) {
+        // a window of 33 .. 64 members: the tile joins the list of k_probe_slab_wide, its 64-member record goes along
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(sa->wide_cnt, 1u);
+        slot = __shfl(slot, 0, WAVE);
+        if (slot < sa->wide_cap) {
+            if (lane == 0) sa->wide_tile[slot] = t;
+            for (int i = lane; i < (int)(sizeof(TileWin64) / 16); i += WAVE) reinterpret_cast<int4 *>(sa->tw64 + slot)[i] = reinterpret_cast<const int4 *>(&s_tw64)[i];
+        } else if (lane == 0) {
+            s_tw.d.flags = (s_tw.d.flags & ~(TD_WIDE | (7u << 8))) | (4u << 8);     // list full: the tile takes the generic kernel ("window > 32")
+        }
+    }
     if (lane == 0) s_tw.pad[0] = s_wn[0] | (s_wn[1] << 8) | (s_wn[2] << 16) | (s_wn[3] << 24);     // rows each wave of k_probe_slab has to look at
     for (int i = lane; i < SLAB_TW_VECS; i += WAVE) reinterpret_cast<int4 *>(sa->tw + t)[i] = reinterpret_cast<const int4 *>(&s_tw)[i];
 }
@@ -334,6 +351,10 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     // ---- one round trip behind the descriptor (scalar loads: uniform address): the tile's dictionary slices, its window
     //      (k_walk_slab), the slot's read and the first four rows of its column -- all asked for before anything is looked at
     const TileDesc d = u_tw[t].d;
+    if (t == 0u && threadIdx.x == 0 && sa->wide_cnt) {          // (k_walk_slab is done: its count of wide tiles moves on, the counter is cleared for the next run)
+        sa->wide_cnt[1] = min(sa->wide_cnt[0], sa->wide_cap); sa->wide_cnt[0] = 0u;
+    }
+    if (d.flags & TD_WIDE) return;                               // k_probe_slab_wide takes the tile
     // the last row any read of this wave has (k_walk_slab): rows behind it are not asked for
     const uint32_t row_max = max((u_tw[t].pad[0] >> (8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))) & 0xffu, 1u) - 1u;
     const FusedDict dv = fused_load_dict(a, d);

@@ -1,0 +1,319 @@
+// l2r_wide.hip.h -- the slab pipeline's probe kernel for tiles whose window holds 33 .. 64 transcripts (WIDE tiles).
+//
+// The mask path of l2r_kernels.hip.h / l2r_slab.hip.h keeps one bit per window member in 32-bit words; a tile whose reads can
+// meet more than 32 annotation transcripts (a locus with many isoforms) went to the redo list, i.e. to k_classify_generic at
+// about 1/70 of the speed.  This file is the same formulation on 64-bit masks, for those tiles only:
+// k_walk_slab's last wave builds a 64-member window record (TileWin64) for them and appends the tile to a list;
+// k_probe_slab skips them; k_probe_slab_wide<LEVEL>, a small persistent grid, walks over the list.  Tiles beyond 64
+// members still take the generic kernel.
+//
+// Same semantics as visit_window / map_exons_slab / decide, line by line, with these differences:
+//   masks             unsigned long long; "first member" indices take 7 bits (127 = none), so a work word is 7 + 7 + 2 bits
+//   staged entries    {k1, k2, pair mask, single mask} = 24 bytes (two 8-byte key/mask reads) instead of one 16-byte vector
+#pragma once
+#include "l2r_slab.hip.h"
+
+namespace l2r {
+
+typedef unsigned long long m64_t;
+struct WEnt { int32_t k1, k2; m64_t pm, sm; };                  // staged dictionary entry, masks in the tile's window frame
+constexpr int WIDE_KEY_CAP = SLAB_KEY_CAP;
+constexpr int WIDE_TW_VECS = (int)(sizeof(TileWin64) / 16);
+
+struct VisitMasks64 { m64_t vpre, lmask, rmask, k1mask; bool redo; };
+struct SiteMasks64 { m64_t kand, kor, dm_first, am_last; };
+struct WideLds { uint16_t *W; const WEnt *ent0, *ent1; const uint8_t *dir0, *dir1, *rdir; const int4 *hk, *hx; const int *win; };
+
+__device__ __forceinline__ m64_t rebase64(m64_t m, int d)
+{
+    if (d >= 0) return d < 64 ? m << d : 0ull;
+    return -d < 64 ? m >> (-d) : 0ull;
+}
+__device__ __forceinline__ m64_t rebase_gaps64(const int *win, int w_n, m64_t m, int tx_base)
+{
+    m64_t out = 0ull;
+#pragma unroll 1
+    for (int j = 0; j < w_n; ++j) {
+        const uint32_t b = (uint32_t)(win[j] - tx_base);
+        out |= (b < 64u ? (m >> b) & 1ull : 0ull) << j;
+    }
+    return out;
+}
+__device__ __forceinline__ uint32_t first_member64(m64_t x) { return x ? (uint32_t)(__ffsll((long long)x) - 1) : 127u; }
+
+// visit_window (l2r_kernels.hip.h) on 64 members
+template <int LEVEL>
+__device__ __forceinline__ VisitMasks64 visit_window64(const WideLds &L, const TileDesc &d, int w_n, bool work, uint32_t n, int j0,
+                                                       const ReadEnds &re, const m64_t *tilemask)
+{
+    VisitMasks64 m{0ull, 0ull, 0ull, 0ull, false};
+    m64_t m_aft = 0ull, m_bef = 0ull;
+    for (int j = 0; j < w_n; ++j) {
+        const int4 hk = L.hk[j];
+        const m64_t bit = 1ull << j;
+        m_aft |= re.el <= hk.x ? bit : 0ull;                                 // comp_trans <= (Q5): the read lies before the member
+        m_bef |= hk.y <= re.s0 ? bit : 0ull;                                 // the member lies before the read
+        if (LEVEL >= 1 && LEVEL <= 4) {
+            const int4 hx = L.hx[j];
+            if (LEVEL == 1) {
+                m.lmask |= re.e0 == hx.y ? bit : 0ull;
+                m.rmask |= re.sl == hx.z ? bit : 0ull;
+            } else {
+                m.lmask |= closed_overlap(re.s0, re.e0, hx.x, hx.y) ? bit : 0ull;
+                if (LEVEL != 4) m.rmask |= closed_overlap(re.sl, re.el, hx.z, hx.w) ? bit : 0ull;
+            }
+        }
+    }
+    int jrel0 = j0 - d.j_lo;                       // first member the read's sweep reaches
+    if (!(d.flags & TD_CONTIG)) {
+        jrel0 = 0;
+        for (int j = 0; j < w_n; ++j) jrel0 += L.win[j] < j0 ? 1 : 0;
+    }
+    const m64_t reach = jrel0 <= 0 ? ~0ull : (jrel0 >= 64 ? 0ull : ~((1ull << jrel0) - 1ull));
+    const m64_t stop = m_aft & reach;                                        // the sweep ends at the lowest of these (:799-800)
+    const m64_t below = (stop & (0ull - stop)) - 1ull;                       // all ones when there is none
+    m.vpre = work ? (~m_bef & below & reach & (w_n >= 64 ? ~0ull : ((1ull << w_n) - 1ull))) : 0ull;
+    m.lmask &= m.vpre; m.rmask &= m.vpre;
+    const m64_t single = tilemask[0];
+    if (n == 1) {
+        m64_t c = m.vpre & single;
+        while (c) {
+            const int j = __ffsll((long long)c) - 1;
+            c &= c - 1ull;
+            const int4 hx = L.hx[j];
+            if (overlap_frac(re.s0, re.e0, hx.x, hx.y) >= fast_args()->p.frac) m.k1mask |= 1ull << j;
+        }
+    } else if (m.vpre & tilemask[1] & ~single) m.redo = true;
+    return m;
+}
+
+__device__ __forceinline__ void probe_all64(const WEnt *ent, uint32_t lo, uint32_t hi, int32_t k1, int32_t k2, m64_t &pm, m64_t &sm)
+{
+    pm = 0ull; sm = 0ull;
+    for (uint32_t r = lo; r < hi; ++r) {
+        const WEnt q = ent[r];
+        if (q.k1 == k1) { sm = q.sm; if (q.k2 == k2) pm = q.pm; }
+    }
+}
+
+__device__ __forceinline__ m64_t overlapping_exon_members64(const uint8_t *rdir, const uint8_t *dir, const WEnt *ent, int b_off, int nb, int s, int e)
+{
+    const int bs = s >> SITE_SHIFT;
+    if (bs >= nb) return 0ull;
+    const int be = min(e >> SITE_SHIFT, nb - 1);
+    m64_t m = 0ull;
+    const uint32_t i1 = dir[be + b_off + 1];
+    for (uint32_t i = rdir[bs + b_off]; i < i1; ++i) {
+        const WEnt q = ent[i];
+        if (q.k1 <= e && q.k2 >= s) m |= q.pm;
+    }
+    return m;
+}
+
+// map_exons_slab on 64-bit masks (rows streamed from the slab column, two rows in flight: these tiles are rare)
+__device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const TileDesc &d, bool mapping, const int32_t *__restrict__ xs,
+                                                        const int32_t *__restrict__ xe, uint32_t off, uint32_t n, m64_t vpre)
+{
+    SiteMasks64 m{~0ull, 0ull, 0ull, 0ull};
+    uint16_t *W = L.W + threadIdx.x;
+    int s = 0, e = 0, s1 = 0, e1 = 0;
+    if (mapping) {
+        s = ld32(xs, off); e = ld32(xe, off);
+        const uint32_t i1 = off + min(1u, n - 1u) * SLAB_STRIDE;
+        s1 = ld32(xs, i1); e1 = ld32(xe, i1);
+    }
+    const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
+    const int k_max = wave_max(mapping ? (int)n : 0);
+    for (int k = 0; k < k_max; ++k) {
+        const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
+        int s2n = 0, e2n = 0;
+        if (mapping) { const uint32_t i2 = off + min((uint32_t)k + 2u, n - 1u) * SLAB_STRIDE; s2n = ld32(xs, i2); e2n = ld32(xe, i2); }
+        const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
+        const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
+        const int s2 = s1;
+        const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
+        m64_t xm, am, jm, dm;
+        probe_all64(L.ent0, ls, hs, s, e, xm, am);
+        probe_all64(L.ent1, le, he, e, s2, jm, dm);
+        const m64_t amj = junc ? am : 0ull;
+        uint32_t word = first_member64(xm & vpre);
+        word |= first_member64(jm & vpre) << 7;
+        word |= ((dm & vpre) ? 1u : 0u) << 14;
+        word |= ((amj & vpre) ? 1u : 0u) << 15;
+        m.kand &= junc ? (am & dm) : ~0ull;            // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
+        m.kor |= amj | dm;
+        if (k == 0) m.dm_first = dm;
+        m.am_last = (live && !junc) ? am : m.am_last;
+        if (live) W[(uint32_t)k * SLAB_STRIDE] = (uint16_t)word;
+        s = s1; e = e1; s1 = s2n; e1 = e2n;
+    }
+    return m;
+}
+
+// decide (l2r_kernels.hip.h) on 64-bit masks; work words at W[k * 256]
+template <int LEVEL>
+__device__ __forceinline__ Verdict decide64(const WideLds &L, const TileDesc &d, uint32_t n, const ReadEnds &re,
+                                            const VisitMasks64 &vm, const SiteMasks64 &sm, bool rev_in)
+{
+    uint16_t *W = L.W + threadIdx.x;
+    int jstar = -1;
+    if (n > 1) {
+        m64_t c = sm.kand & vm.vpre;
+        while (c) {
+            const int j = __ffsll((long long)c) - 1;
+            c &= c - 1ull;
+            const int4 hk = L.hk[j];
+            if (hk.x <= re.e0 && re.sl <= hk.y) { jstar = j; break; }
+        }
+    } else if (vm.k1mask) jstar = __ffsll((long long)vm.k1mask) - 1;
+    const bool known = jstar >= 0;
+    const m64_t upto = jstar >= 63 ? ~0ull : ((2ull << (known ? jstar : 0)) - 1ull);
+    const m64_t V = known ? (vm.vpre & upto) : vm.vpre;
+    const m64_t ks = (n > 1) ? (sm.kor & V) : 0ull;
+    const bool ksite = (ks & ~(known ? (1ull << jstar) : 0ull)) != 0ull;
+    int jref = -1;
+    if (n > 1) { if (ks) jref = 63 - __clzll((long long)ks); }
+    else jref = jstar;
+    bool lfull = false, rfull = false, lnoth = true, rnoth = true;
+    if (LEVEL >= 1 && LEVEL <= 4) { lfull = (vm.lmask & V) != 0ull; rfull = (vm.rmask & V) != 0ull; }
+    if (LEVEL == 3 || LEVEL == 4) {
+        if (!lfull) {
+            if (sm.dm_first & V) lnoth = false;
+            else if (V) lnoth = (overlapping_exon_members64(L.rdir, L.dir0, L.ent0, d.b_off, d.nb, re.s0, re.e0) & V) == 0ull;
+        }
+        if (LEVEL == 3 && !rfull) {
+            if (sm.am_last & V) rnoth = false;
+            else if (V) rnoth = (overlapping_exon_members64(L.rdir, L.dir0, L.ent0, d.b_off, d.nb, re.sl, re.el) & V) == 0ull;
+        }
+    }
+    const uint32_t lim = known ? (uint32_t)jstar : 126u;
+    if (n > 1) {
+        for (int k = 0; k < (int)n; ++k) {
+            const uint32_t w = W[(uint32_t)k * SLAB_STRIDE];
+            uint32_t f = ((w & 127u) > lim ? (uint32_t)F_EXON : 0u) | (((w >> 7) & 127u) > lim ? (uint32_t)F_JUNC : 0u);
+            if (!known) f |= (((w >> 14) & 1u) ? 0u : (uint32_t)F_DON) | (((w >> 15) & 1u) ? 0u : (uint32_t)F_ACC);
+            f &= (k + 1 == (int)n) ? (uint32_t)F_EXON : 0xffu;                   // the last exon has no junction behind it
+            W[(uint32_t)k * SLAB_STRIDE] = (uint16_t)f;
+        }
+    } else W[0] = (uint16_t)F_EXON;
+    int ref = -1;
+    bool out_rev = rev_in;
+    if (jref >= 0) { ref = L.win[jref]; out_rev = ((L.hk[jref].w >> 8) & 1) != 0; }     // :825-831
+    uint32_t info = 0;
+    if (known) info |= I_KNOWN;
+    if (ksite) info |= I_KSITE;
+    if (full_decision(LEVEL, lfull, lnoth, rfull, rnoth)) info |= I_FULL;
+    if (out_rev) info |= I_REV;
+    if (fast_args()->p.n_sj == 0 && (info & (I_FULL | I_KNOWN | I_KSITE)) == (I_FULL | I_KSITE)) info |= I_ACCEPT;
+    return Verdict{info | (n << 8), ref};
+}
+
+// The list k_walk_slab leaves: wide_count tiles, entry i = {tile number, its 64-member window record}
+struct WideArgs { const uint32_t *wide_count; const uint32_t *wide_tile; const TileWin64 *tw64; };
+
+template <int LEVEL>
+__global__ __launch_bounds__(TILE_THREADS, 4)
+void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__restrict__ u_tile_first, const uint8_t *__restrict__ u_order,
+                       const int32_t *__restrict__ u_tid, const uint32_t *__restrict__ u_tile_sbase)
+{
+    constexpr int DIR_BYTES = FAST_DIR_BYTES;
+    __shared__ __attribute__((aligned(16))) uint16_t s_W[SLAB_ROWS * TILE_THREADS];
+    __shared__ __attribute__((aligned(16))) WEnt s_ent[2 * WIDE_KEY_CAP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_dir[3 * DIR_BYTES];
+    __shared__ __attribute__((aligned(16))) TileWin64 s_tw;
+    (void)kernarg_block;
+    const SlabArgsK sa = slab_args();
+    const FusedArgsK a = fused_args();
+    const int lane = threadIdx.x & (WAVE - 1);
+    WEnt *const s_ent0 = s_ent, *const s_ent1 = s_ent + WIDE_KEY_CAP;
+    uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
+    const uint32_t n_wide = *wa.wide_count;
+    for (uint32_t wi = blockIdx.x; wi < n_wide; wi += gridDim.x) {
+        const uint32_t t = wa.wide_tile[wi];
+        const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
+        const int32_t tid0 = n_act ? u_tid[r0] : 0;
+        const uint32_t sbase = u_tile_sbase[t];
+        for (int i = (int)threadIdx.x; i < WIDE_TW_VECS; i += TILE_THREADS)
+            reinterpret_cast<int4 *>(&s_tw)[i] = reinterpret_cast<const int4 *>(wa.tw64 + wi)[i];
+        const bool active = threadIdx.x < n_act;
+        const uint32_t at = r0 + (active ? threadIdx.x : 0u);
+        uint32_t pre = 0u, r = r0;
+        bool rev_in = false;
+        const int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end;
+        const uint32_t off = sbase + threadIdx.x;
+        ReadEnds re{0, 0, 0, 0};
+        if (active) { pre = ld32(sa->pre, at); r = r0 + (uint32_t)ld32(u_order, at); rev_in = ld32(sa->s_rev, at) != 0; }
+        const uint32_t n = pre >> 8;
+        const bool outlier = (pre & I_PRE_DIRECT) != 0u;
+        if (active && !outlier) {
+            re.s0 = ld32(xs, off); re.e0 = ld32(xe, off);
+            re.sl = ld32(xs, off + (n - 1u) * SLAB_STRIDE); re.el = ld32(xe, off + (n - 1u) * SLAB_STRIDE);
+        }
+        __syncthreads();
+        const TileDesc d = s_tw.d;
+        const int w_n = (int)d.n_win;
+        // ---- stage the dictionary slices, masks re-based to the tile's window (64-bit)
+        const FusedDict dv = fused_load_dict(a, d);
+        int my_wide = 0;
+        if ((int)threadIdx.x < WIDE_KEY_CAP) {
+            const bool has_st = threadIdx.x < d.st_nk, has_en = threadIdx.x < d.en_nk;
+            WEnt e0, e1;
+            e0.k1 = dv.xa.x; e0.k2 = dv.xa.y; e1.k1 = dv.xc.x; e1.k2 = dv.xc.y;
+            const m64_t pm0 = ((m64_t)(uint32_t)dv.xb.y << 32) | (uint32_t)dv.xb.x, sm0 = ((m64_t)(uint32_t)dv.xb.w << 32) | (uint32_t)dv.xb.z;
+            const m64_t pm1 = ((m64_t)(uint32_t)dv.xd.y << 32) | (uint32_t)dv.xd.x, sm1 = ((m64_t)(uint32_t)dv.xd.w << 32) | (uint32_t)dv.xd.z;
+            if (d.flags & TD_CONTIG) {
+                e0.pm = rebase64(pm0, dv.xa.z - d.j_lo); e0.sm = rebase64(sm0, dv.xa.z - d.j_lo);
+                e1.pm = rebase64(pm1, dv.xc.z - d.j_lo); e1.sm = rebase64(sm1, dv.xc.z - d.j_lo);
+            } else {
+                e0.pm = rebase_gaps64(s_tw.win, w_n, pm0, dv.xa.z); e0.sm = rebase_gaps64(s_tw.win, w_n, sm0, dv.xa.z);
+                e1.pm = rebase_gaps64(s_tw.win, w_n, pm1, dv.xc.z); e1.sm = rebase_gaps64(s_tw.win, w_n, sm1, dv.xc.z);
+            }
+            if (has_st) { s_ent0[threadIdx.x] = e0; if (dv.xa.w & SE_WIDE) my_wide = 1; }
+            if (has_en) { s_ent1[threadIdx.x] = e1; if (dv.xc.w & SE_WIDE) my_wide = 1; }
+        }
+        if (d.nbk > 0) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int i = (int)threadIdx.x + qq * TILE_THREADS;
+                if (i <= d.nbk) {
+                    s_dir0[i] = (uint8_t)(dv.dd[0][qq] - d.st_r0); s_dir1[i] = (uint8_t)(dv.dd[1][qq] - d.en_r0);
+                    s_rdir[i] = (uint8_t)(dv.dd[2][qq] - d.st_r0);
+                }
+            }
+        }
+        if (threadIdx.x < 3u && (threadIdx.x > 0u || d.nbk == 0)) {
+            s_dir0[d.nbk + (int)threadIdx.x] = (uint8_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint8_t)d.en_nk;
+        }
+        const int any_wide = __syncthreads_or(my_wide);
+        // ---- classification
+        uint32_t info = n << 8; int ref = -1;
+        bool redo = active && (outlier || any_wide != 0 || tid0 != d.tid || (n > 1 && (pre & I_PRE_INSANE) != 0u));
+        const bool work = active && !redo;
+        const WideLds L{s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
+        const VisitMasks64 vm = visit_window64<LEVEL>(L, d, w_n, work, n, d.j_lo, re, s_tw.mask);
+        redo = redo || vm.redo;
+        const SiteMasks64 sm = map_exons_slab64(L, d, work && !redo && n > 1, xs, xe, off, n, vm.vpre);
+        uint8_t *const xf = a->f.ex_flag;
+        if (work && !redo) {
+            const Verdict vd = decide64<LEVEL>(L, d, n, re, vm, sm, rev_in);
+            info = vd.info; ref = vd.ref;
+            for (uint32_t k = 0; k < n; ++k) st32(xf, off + k * SLAB_STRIDE, (uint8_t)s_W[k * SLAB_STRIDE + threadIdx.x]);
+        } else if (active && !outlier) {
+            for (uint32_t k = 0; k < n; ++k) st32(xf, off + k * SLAB_STRIDE, (uint8_t)0);
+        }
+        redo = redo && active;
+        {
+            const unsigned long long m = __ballot(redo);
+            if (m) {
+                uint32_t pos_r = 0;
+                if (lane == 0) pos_r = atomicAdd(a->f.redo_count, (uint32_t)__popcll(m));
+                pos_r = __shfl(pos_r, 0, WAVE);
+                if (redo) a->f.redo[pos_r + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+            }
+        }
+        if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; }
+        __syncthreads();                                        // (the next tile of this workgroup overwrites the LDS image)
+    }
+}
+
+}  // namespace l2r

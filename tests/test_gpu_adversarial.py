@@ -91,6 +91,54 @@ def test_locus_of_300_isoforms(oracle, level, pipeline):
     assert 5000 <= cnt[0] <= 6000 + 256, cnt
 
 
+@pytest.mark.parametrize("level", [1, 3, 5])
+@pytest.mark.parametrize("n_iso,gapped", [(40, False), (63, False), (44, True)])
+def test_locus_of_33_to_64_isoforms_stays_off_the_redo_list(oracle, level, n_iso, gapped, pipeline):
+    """Windows of 33 .. 64 transcripts: the slab pipeline classifies their tiles with the 64-bit-mask kernel
+    (l2r_wide.hip.h) instead of the redo list; results are exact on every pipeline.  `gapped`: unrelated transcripts of
+    a chromosome the header does not have (tid -1: skipped, not a stop) sit between the isoforms in file order, so the
+    window's members are not consecutive."""
+    rng = np.random.default_rng(100 + n_iso)
+    pool = [(50_000 + 500 * k, 50_000 + 500 * k + 120) for k in range(26)]
+    txs = []
+    for t in range(n_iso):
+        keep = sorted(set([0, 25] + list(rng.choice(np.arange(1, 25), size=int(rng.integers(5, 16)), replace=False))))
+        ex = [pool[k] for k in keep]
+        if t % 4 == 0:
+            ex[1] = (ex[1][0] - int(rng.integers(1, 25)), ex[1][1])
+        if t % 6 == 0:
+            ex[-2] = (ex[-2][0], ex[-2][1] + int(rng.integers(1, 25)))
+        txs.append((0, t & 1, ex))
+        if gapped and t % 3 == 0:
+            txs.append((-1, 0, [(1_000 + 50 * t, 1_020 + 50 * t), (9_000, 9_100)]))      # (a larger tid would END the sweep, :799)
+    if n_iso >= 60:                                   # one single-exon member as well
+        txs.append((0, 0, [(52_000, 56_000)]))
+    af = _anno(txs)
+    rows = []
+    iso = [t for t in txs if t[0] == 0]
+    for i in range(5000):
+        t = iso[int(rng.integers(len(iso)))][2]
+        if len(t) < 3:
+            ex = [list(t[0])]
+            ex[0][0] += int(rng.integers(0, 300)); ex[0][1] -= int(rng.integers(0, 300))
+        else:
+            a = int(rng.integers(0, len(t) - 2))
+            ex = [list(x) for x in t[a:a + int(rng.integers(2, 9))]]
+            if i % 3 == 0:
+                ex[-1][1] -= int(rng.integers(0, 40))
+            if i % 5 == 0:
+                ex[0][0] += int(rng.integers(0, 40))
+            if i % 11 == 0 and len(ex) > 2:
+                del ex[1]
+        p, ops = _chain([tuple(x) for x in ex])
+        rows.append((0, p, i & 1, ops))
+    cnt = [0, 0, 0, 0, 0]
+    got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=level)
+    assert ((want.info & 1) != 0).sum() > 100 and ((want.info & 2) != 0).sum() > 1000
+    if pipeline == "slab":
+        assert cnt[4] >= 15 and cnt[0] <= 300, cnt          # the locus's tiles took the 64-member kernel, (almost) nothing the redo list
+
+
 def test_duplicated_transcripts_and_overlapping_exons(oracle):
     # the same transcript three times in a row; transcripts whose exons repeat or overlap each other (the reference
     # sorts a transcript's exons by (start, end) and keeps all of them, src/gtf.c:468-521); a transcript that is one

@@ -77,10 +77,10 @@ def _run(oracle, af, reads, counters=None, sj=None, **kw):
         if counters is not None:            # [reads the generic kernel took, wide entries, compact transcripts, tiles]
             import ctypes as C
             lib = capi.load_library()
-            cnt = (C.c_longlong * 4)()
+            cnt = (C.c_longlong * 13)()
             lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-            lib.l2r_debug_counters(eng.ctx, cnt, 4)
-            counters[:] = list(cnt)
+            lib.l2r_debug_counters(eng.ctx, cnt, 13)
+            counters[:] = list(cnt)[:4] + [cnt[12]]      # (... , tiles the 64-member kernel took)
     finally:
         eng.close()
     util.assert_same_result(got, want, 0 if sj is None else len(sj[0]), kw.get("split_trans", 0))
