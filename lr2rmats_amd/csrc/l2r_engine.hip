@@ -802,7 +802,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         if (total + ovf < 0x7ffffff0ULL) {
             sbase[T] = (uint32_t)total;                     // (k_probe_slab: rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true; c->ovf_base = (uint32_t)total;
-            c->wide_cap = (uint32_t)std::min<size_t>(T, 8192);
+            c->wide_cap = (uint32_t)T;                      // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB per tile)
             if (c->tw64.ensure(c->wide_cap) || c->wide_cnt.ensure(2) || c->wide_tile.ensure(c->wide_cap)) return -2;
             HIP_TRY(hipMemsetAsync(c->wide_cnt.p, 0, 8, c->stream));
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) ||
@@ -960,7 +960,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             // ---- two light kernels at high occupancy: the walk (exons into the tiles' slabs), then the probes (l2r_slab.hip.h)
             SlabArgs sa; sa.g = ga; sa.tile_sbase = c->tile_sbase.p; sa.ovf_cursor = c->ovf_cursor.p; sa.ovf_base = c->ovf_base;
             sa.s_clo = c->s_clo.p; sa.s_ncig = c->s_ncig.p; sa.s_pos = c->s_pos.p; sa.s_rev = c->s_rev.p; sa.pre = c->s_pre.p; sa.tw = c->tw.p;
-            sa.wide_cnt = c->wide_cnt.p; sa.wide_tile = c->wide_tile.p; sa.tw64 = c->tw64.p; sa.wide_cap = c->wide_cap;
+            sa.wide_cnt = c->wide_cnt.p; sa.wide_tile = c->wide_tile.p; sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p; sa.wide_cap = c->wide_cap;      // (L2R_ABLATE bit 2: no 64-member windows)
             hipLaunchKernelGGL(k_walk_slab, dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, (const uint8_t *)c->order.p,
                                (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
             MARK(ST_FAST);
@@ -980,7 +980,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
 #undef launch_probe_level
             {   // the tiles with 33 .. 64 window members (none on most inputs: the grid finds an empty list and leaves)
                 const WideArgs wa{c->wide_cnt.p + 1, c->wide_tile.p, c->tw64.p};
-                const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, 1024);
+                const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 6);
 #define launch_wide_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_wide<L>), dim3(gw), dim3(TILE_THREADS), 0, s, sa, wa, (const uint32_t *)c->tile_first.p, \
                     (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const uint32_t *)c->tile_sbase.p)
                 switch (p.full_level) {

@@ -20,6 +20,9 @@ CONFIGS = {
     "cfg2": dict(n_reads=100_000, n_exons=5, anno_exons=50_000, seed=2, ont=False, micro=0, xs=0.0),
     "cfg3": dict(n_reads=10_000_000, n_exons=8, anno_exons=1_500_000, seed=3, ont=False, micro=0, xs=0.0),
     "cfg5": dict(n_reads=20_000_000, n_exons=12, anno_exons=2_000_000, seed=5, ont=True, micro=3, xs=0.02),
+    # cfg3 with 40 isoforms per gene instead of 5 (same exon count, an eighth of the genes): every tile's window holds 33 .. 64
+    # transcripts -- the shape of isoform-rich loci in a real annotation (diagnostics, not a BASELINE config)
+    "cfg3_iso40": dict(n_reads=10_000_000, n_exons=8, anno_exons=1_500_000, seed=3, ont=False, micro=0, xs=0.0, tx_per_gene=40),
 }
 
 
@@ -60,7 +63,7 @@ def make_rank_workload(cfg: dict, rank: int, world: int):
     """Weak-scaling workload: every rank gets ``cfg['n_reads']`` reads of the same mix, drawn from its own
     block of chromosomes, so that the concatenation over ranks is one coordinate-sorted read set of
     ``world * n_reads`` alignments against the one replicated annotation."""
-    anno = synth.make_annotation(cfg["anno_exons"], cfg["seed"], mean_tx_exons=cfg["n_exons"] + 1)
+    anno = synth.make_annotation(cfg["anno_exons"], cfg["seed"], mean_tx_exons=cfg["n_exons"] + 1, tx_per_gene=cfg.get("tx_per_gene", 5))
     af = anno.in_file_order()
     nchr = len(anno.chrom_names)
     lo_c, hi_c = (nchr * rank) // world, (nchr * (rank + 1)) // world

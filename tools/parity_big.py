@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 from lr2rmats_amd import capi, workload
 from oracle import pyoracle as po
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
-cfg = dict(workload.CONFIGS['cfg3']); cfg['n_reads'] = N
+cfg = dict(workload.CONFIGS[os.environ.get('L2R_CFG', 'cfg3')]); cfg['n_reads'] = N
 af, reads = workload.make_rank_workload(cfg, 0, 1)
 e = capi.Engine(0)
 e.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)

@@ -30,10 +30,10 @@ if os.environ.get("L2R_STAMPS"):
     print("  classic kernel: 0 CIGAR staging 7 walk 1 dictionary staging 2 window pass 3 probes 4 verdicts 5 counts 6 write-out")
     print("  one-walk kernel: 0 walk 1 staging 2 window pass + next span 3 probes + verdicts 4 offsets/map/write-out | 5 barrier waits of wave 0, 6 of the last wave, 7 descriptor work of the last wave (5-7 are not phases: compare with the sum of 0-4)")
     print("redo reasons [not fast, not in LDS, wide, other tid, not sane, window/compact]:", v[8:14])
-cnt = (C.c_longlong * 12)()
+cnt = (C.c_longlong * 13)()
 lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-lib.l2r_debug_counters(e.ctx, cnt, 12)
-print("redo reads %d, wide entries %d, compact tx %d, tiles %d" % tuple(cnt[:4]))
+lib.l2r_debug_counters(e.ctx, cnt, 13)
+print("redo reads %d, wide entries %d, compact tx %d, tiles %d" % tuple(cnt[:4]), "| tiles of the 64-member kernel:", cnt[12])
 print("tiles [fast, exons > LDS cap, bucket span, dictionary slice, window > 32, window scan, cursor behind window, off]:", list(cnt[4:12]))
 tm = e.run_timed(5)
 print(e.sizes(), tm)
