@@ -732,13 +732,28 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
             const int r_start = re.s0, r_end = re.el, dis = p.ss_dis, level = p.full_level;
             bool lfull = false, rfull = false, lnoth = true, rnoth = true, known = false, ksite = false;
             int ref = -1, ref_rev = 0;
-            for (int j = j0; j < p.n_tx; ++j) {
-                const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);
-                const int4 h0 = hp[0];
-                // src/update_gtf.c:786-790 comp_trans: <= (Q5)
-                if (tid < h0.x || (tid == h0.x && r_end <= h0.y)) break;                 // :799-800
-                if (h0.x < tid || (h0.x == tid && h0.z <= r_start)) continue;            // :801
-                const int4 h1 = hp[1], h2 = hp[2];
+            // The sweep in batches of 64 transcripts: every lane fetches one header (three 16-byte words, all in flight
+            // together), the stop (:799-800) and skip (:801) tests run on all 64 at once, and only the transcripts the
+            // reference would compare are visited, their header words read out of the lanes' registers.  (One header
+            // after the other cost a dependent round trip per transcript: a locus with 80 isoforms = 80 round trips.)
+            bool done = false;
+            for (int base = j0; base < p.n_tx && !done; base += WAVE) {
+              const int jl = base + lane;
+              int4 g0 = make_int4(INT32_MAX, 0, 0, 0), g1 = make_int4(0, 0, 0, 0), g2 = g1;     // (beyond the annotation: "the read lies before it")
+              if (jl < p.n_tx) { const int4 *gp = reinterpret_cast<const int4 *>(hdr + jl); g0 = gp[0]; g1 = gp[1]; g2 = gp[2]; }
+              // src/update_gtf.c:786-790 comp_trans: <= (Q5)
+              const bool brk = tid < g0.x || (tid == g0.x && r_end <= g0.y);              // :799-800
+              const bool skip = g0.x < tid || (g0.x == tid && g0.z <= r_start);            // :801
+              const unsigned long long mb = __ballot(brk);
+              unsigned long long mv = __ballot(!brk && !skip);
+              if (mb) { mv &= (mb & (0ull - mb)) - 1ull; done = true; }                   // nothing at or behind the first stop
+              while (mv) {
+                const int src = __ffsll((long long)mv) - 1;
+                mv &= mv - 1ull;
+                const int j = base + src;
+                const int4 h0 = make_int4(__shfl(g0.x, src, WAVE), __shfl(g0.y, src, WAVE), __shfl(g0.z, src, WAVE), __shfl(g0.w, src, WAVE));
+                const int4 h1 = make_int4(__shfl(g1.x, src, WAVE), __shfl(g1.y, src, WAVE), 0, 0);
+                const int4 h2 = make_int4(__shfl(g2.x, src, WAVE), __shfl(g2.y, src, WAVE), __shfl(g2.z, src, WAVE), __shfl(g2.w, src, WAVE));
                 const int a_start = h0.y, a_end = h0.z, m = h1.x;
                 const int2 *ax = anno_ex + h0.w;
                 // ---- check_full :629-681
@@ -805,7 +820,8 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
                     else if (same > 0) { vv = 2; ksite = true; }
                 }
                 if (vv) { ref = j; ref_rev = h1.y; }
-                if (vv == 1) break;                                                        // :810,816
+                if (vv == 1) { done = true; break; }                                       // :810,816
+              }
             }
             bool out_rev = rev;
             if (ref >= 0) out_rev = ref_rev != 0;               // :825-831 strand taken from the reference transcript
