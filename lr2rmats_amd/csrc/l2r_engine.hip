@@ -960,14 +960,16 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             // ---- two light kernels at high occupancy: the walk (exons into the tiles' slabs), then the probes (l2r_slab.hip.h)
             SlabArgs sa; sa.g = ga; sa.tile_sbase = c->tile_sbase.p; sa.ovf_cursor = c->ovf_cursor.p; sa.ovf_base = c->ovf_base;
             sa.s_clo = c->s_clo.p; sa.s_ncig = c->s_ncig.p; sa.s_pos = c->s_pos.p; sa.s_rev = c->s_rev.p; sa.pre = c->s_pre.p; sa.tw = c->tw.p;
+            sa.n_tiles = (uint32_t)c->n_tiles;
+            const unsigned gx = 8u * (unsigned)((c->n_tiles + 7) / 8);          // (l2r_slab.hip.h xcd_tile)
             sa.wide_cnt = c->wide_cnt.p; sa.wide_tile = c->wide_tile.p; sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p; sa.wide_cap = c->wide_cap;      // (L2R_ABLATE bit 2: no 64-member windows)
-            hipLaunchKernelGGL(k_walk_slab, dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, (const uint8_t *)c->order.p,
+            hipLaunchKernelGGL(k_walk_slab, dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, (const uint8_t *)c->order.p,
                                (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
             MARK(ST_FAST);
             // (tried: the run cut into chunks of tiles, the probes of chunk i on a second stream beside the walk of chunk i + 1 --
             //  no gain, 0.71 -> 0.72 .. 0.82 ms with 2 .. 16 chunks; both halves in one persistent, software-pipelined kernel
             //  with the exons read back out of L2 -- 0.86 ms and 4.2 GB of traffic (spills): DESIGN.md section 8)
-#define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L>), dim3(gt), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
+#define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
                 (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p)
             switch (p.full_level) {
             case 1: launch_probe_level(1); break;

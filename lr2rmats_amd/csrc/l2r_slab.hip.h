@@ -45,6 +45,7 @@ struct SlabArgs {
     // tiles whose window holds 33 .. 64 transcripts (l2r_wide.hip.h): wide_cnt[0] counts the appends of k_walk_slab, k_probe_slab
     // moves the count to wide_cnt[1] (what k_probe_slab_wide reads) and clears [0] for the next run
     uint32_t *wide_cnt; uint32_t *wide_tile; TileWin64 *tw64; uint32_t wide_cap;
+    uint32_t n_tiles;
 };
 typedef const __attribute__((address_space(4))) SlabArgs *SlabArgsK;
 __device__ __forceinline__ SlabArgsK slab_args()
@@ -54,6 +55,11 @@ __device__ __forceinline__ SlabArgsK slab_args()
     return q;
 }
 constexpr int SLAB_TW_VECS = (int)(sizeof(TileWin) / 16);
+// Workgroup -> tile.  Workgroups are handed to the 8 XCDs round robin (workgroup b runs on XCD b % 8), each XCD has an L2 of its
+// own: with this mapping an XCD works through ONE contiguous eighth of the tiles, so the dictionary slices of neighbouring
+// tiles (they overlap) are fetched into one L2 instead of all eight.
+// The grid is 8 * ceil(n_tiles / 8) workgroups; the few that land behind the last tile leave at once.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t grid) { return (b & 7u) * (grid >> 3) + (b >> 3); }
 constexpr int SLAB_KEY_CAP = 168;                        // dictionary entries staged per dictionary and tile (k_probe_slab's LDS: 20 KB = 8 workgroups per CU)
 static_assert(sizeof(TileWin) % 16 == 0, "TileWin is copied in 16-byte pieces");
 
@@ -155,7 +161,8 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     const SlabArgsK sa = slab_args();
     const FusedArgsK a = fused_args();
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    const uint32_t t = blockIdx.x;
+    const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
+    if (t >= sa->n_tiles) return;
     const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
     const int32_t tid0 = n_act ? u_tid[r0] : 0, pos0 = n_act ? u_pos[r0] : 0;
     const uint32_t sbase = u_tile_sbase[t];
@@ -342,7 +349,8 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const FusedArgsK a = fused_args();
-    const uint32_t t = blockIdx.x;
+    const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
+    if (t >= sa->n_tiles) return;
     const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
     const int32_t tid0 = n_act ? u_tid[r0] : 0;
     const uint32_t sbase = u_tile_sbase[t];
