@@ -37,7 +37,7 @@ static int g_open_outputs = 1;
 #include <stdint.h>
 static double h_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static double g_t_last = 0.0;
-static void h_stage_time(const char *what)
+void h_stage_time(const char *what)
 {
     if (!getenv("L2R_TIMING")) return;
     const double t = h_now();
@@ -376,9 +376,13 @@ static int finish_threaded(h_job *j, const l2r_result *res, int n_thr)
     FILE *outs[7] = {j->o.out_gtf, j->o.exon_bed, j->o.bam_gtf, j->o.bam_detail, j->o.known_gtf, j->o.novel_gtf, j->o.unrecog_gtf};
     const char *last_gene[2] = {NULL, NULL};                /* gene_id of the last entry of the two gene lists so far (h_part_genes) */
     static const int gene_cnt[2] = {H_CNT_UPDATED_GENES, H_CNT_KNOWN_GENES};
+    double t_join = 0.0, t_write = 0.0;
     for (int k = 0; k < n_thr; ++k) {
+        const double ta = h_now();
         pthread_join(th[k], NULL);
+        const double tb = h_now();
         for (int q = 0; q < 7; ++q) if (outs[q] && parts[k].len[q]) fwrite(parts[k].buf[q], 1, parts[k].len[q], outs[q]);
+        t_join += tb - ta; t_write += h_now() - tb;
         for (int q = 0; q < 7; ++q) free(parts[k].buf[q]);
         for (int q = 0; q < H_N_SUMMARY; ++q) total[q] += parts[k].cnt[q];
         for (int q = 0; q < 2; ++q) {
@@ -388,6 +392,10 @@ static int finish_threaded(h_job *j, const l2r_result *res, int n_thr)
     }
     for (int k = 0; k < n_thr; ++k) h_part_genes_free(&parts[k].genes);
     if (j->o.summary) h_write_summary_text(j->o.summary, j->anno.gene_n, (int)j->anno.n_tx, total);
+    /* (tried: detail.txt -- more than half of the bytes, rows independent -- in 64 parts of its own beside the chromosome-aligned
+     *  ones: slower, 2.2 -> 2.35 s on the 256-core GPU box; the tail is bound by page faults / stream growth of ~4 GB of fresh
+     *  memory in one process, not by formatting) */
+    if (getenv("L2R_TIMING")) fprintf(stderr, "[timing]   tail: %d parts, waiting for them %.3f s, copying their streams out %.3f s\n", n_thr, t_join, t_write);
     free(parts); free(th); free(cut);
     return 0;
 }

@@ -550,7 +550,9 @@ int h_filter_run(const char *in_fn, const char *remove_fn, const l2r_filter_para
 {
     h_chroms chr; memset(&chr, 0, sizeof chr);
     h_records r;
+    h_stage_time("start");
     h_read_records(in_fn, &chr, &r, "bam_filter");
+    h_stage_time("read + encode records");
     h_gtf g; memset(&g, 0, sizeof g);
     l2r_filter_spans spans = {0, NULL, NULL, NULL};
     if (remove_fn && remove_fn[0]) {
@@ -563,12 +565,15 @@ int h_filter_run(const char *in_fn, const char *remove_fn, const l2r_filter_para
      * a mapped record without it is the end of that run; here it is an error message */
     for (int64_t i = 0; i < r.n; ++i) if (!(r.flag[i] & 4) && !r.nm_seen[i])
         h_fatal("bam_filter", "alignment record %lld has no NM tag (the reference reads it unconditionally)", (long long)i);
+    h_stage_time("read -r annotation");
     l2r_ctx *ctx = l2r_create(0);
     if (!ctx) h_fatal("bam_filter", "%s", l2r_last_error());
+    h_stage_time("engine: create");
     uint8_t *drop = (uint8_t *)h_malloc((size_t)r.n + 1);
     int32_t *score = (int32_t *)h_malloc((size_t)(r.n + 1) * 4), *intron = (int32_t *)h_malloc((size_t)(r.n + 1) * 4);
     l2r_filter_records fr = { r.n, r.n_cig, r.flag, r.tid, r.pos, r.l_qseq, r.nm, r.cig_off, r.cig };
     if (l2r_filter_score(ctx, &fr, prm, spans.n ? &spans : NULL, drop, score, intron)) h_fatal("bam_filter", "%s", l2r_last_error());
+    h_stage_time("engine: score (upload, kernel, download)");
     /* kept records, and the runs of one read name among them */
     int64_t n_kept = 0;
     for (int64_t i = 0; i < r.n; ++i) n_kept += !drop[i];
@@ -583,8 +588,10 @@ int h_filter_run(const char *in_fn, const char *remove_fn, const l2r_filter_para
         last = name;
     }
     goff[n_groups] = m;
+    h_stage_time("groups of one read name");
     int64_t *winner = (int64_t *)h_malloc((size_t)(n_groups + 1) * 8);
     if (l2r_filter_select(ctx, n_groups, goff, k_score, k_intron, prm, winner)) h_fatal("bam_filter", "%s", l2r_last_error());
+    h_stage_time("engine: select (upload, kernel, download)");
     l2r_destroy(ctx);
     int64_t n_out = 0;
     for (int64_t gi = 0; gi < n_groups; ++gi) {
@@ -594,6 +601,7 @@ int h_filter_run(const char *in_fn, const char *remove_fn, const l2r_filter_para
     }
     int rc = h_write_bam(out, &r, kept, n_out);
     if (rc) h_fatal("bam_filter", "Error in writing SAM record\n");
+    h_stage_time("write BAM (BGZF)");
     if (n_written) *n_written = n_out;
     free(drop); free(score); free(intron); free(kept); free(goff); free(k_score); free(k_intron); free(winner);
     h_gtf_free(&g); h_records_free(&r); h_chroms_free(&chr);

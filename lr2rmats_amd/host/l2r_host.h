@@ -17,6 +17,7 @@
 /* ---- errors: reference exit behaviour (src/utils.c:91-111) */
 void h_fatal(const char *where, const char *fmt, ...);        /* "[where] msg" + exit(1) */
 void h_fatal_core(const char *where, const char *fmt, ...);   /* "[where] msg Abort!" + abort() */
+void h_stage_time(const char *what);                          /* L2R_TIMING=1: wall clock since the last call, on stderr */
 void *h_malloc(size_t n);
 void *h_realloc(void *p, size_t n);
 
