@@ -90,8 +90,26 @@ def e2e_leg(af, reads, level: int):
         cenv = dict(env, L2R_ANNO_CACHE=os.path.join(d, "anno_cache"))
         _, cold_wall, _ = one_run(cenv)
         rw, warm_wall, warm_stages = one_run(cenv)
+        # CPU side of the same command: the oracle's CLI (sequential C restatement with its own SAM / GTF readers and writers)
+        # on a bounded sample of the same reads, as SAM text (it reads no BAM) -- "port", end to end, one core
+        cpu_e2e = None
+        try:
+            from oracle import pyoracle as po
+            po.build()
+            n_s = min(reads.n, 500_000)
+            sam = os.path.join(d, "sample.sam")
+            reads.slice(0, n_s).write_sam(sam)
+            oo = {k: os.path.join(d, "cpu_" + k) for k in out}
+            t0 = time.perf_counter()
+            rc_o = po.run_cli(["update-gtf", "-l", str(level), "-A", oo["detail.txt"], "-y", oo["summary.txt"], "-E", oo["novel_exon.bed"],
+                               "-o", oo["updated.gtf"], sam, gtf])
+            cdt = time.perf_counter() - t0
+            cpu_e2e = {"wall_s": round(cdt, 2), "rc": rc_o, "reads": n_s, "reads_per_s": round(n_s / cdt, 1), "cores": 1, "kind": "port",
+                       "note": "oracle CLI, SAM text in (parses the whole GTF for the sample as well: the GTF stage does not shrink with the sample)"}
+        except Exception as e:                                # the baseline must not take the line down
+            cpu_e2e = {"error": str(e)[:200]}
         return {"wall_s": round(wall, 3), "rc": r.returncode, "reads": reads.n, "reads_per_s": round(reads.n / wall, 1),
-                "stages_s": stages,
+                "stages_s": stages, "cpu_port_same_command": cpu_e2e,
                 "with_annotation_cache": {"filling_run_wall_s": round(cold_wall, 3), "warm_run_wall_s": round(warm_wall, 3), "rc": rw.returncode,
                                           "warm_run_reads_per_s": round(reads.n / warm_wall, 1), "warm_run_stages_s": warm_stages},
                 "input_bytes": {"bam": os.path.getsize(bam), "gtf": os.path.getsize(gtf)},
