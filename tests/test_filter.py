@@ -184,6 +184,32 @@ def test_host_sam_to_bam_equals_the_independent_encoder(tmp_path):
     assert at == len(raw) and n_blocks > 5
 
 
+def test_host_encoder_long_cigar_goes_into_the_cg_tag(tmp_path):
+    """A CIGAR of more than 65535 operations does not fit the BAM record's 16-bit count: it is stored in CG:B,I behind a
+    <l_seq>S<ref len>N placeholder (SAMv1 4.2.2; htslib does this when it writes).  The host encoder and the independent one
+    agree on the bytes, and the record read back from that BAM scores with its REAL CIGAR (the reader swaps it back in)."""
+    rng = np.random.default_rng(3)
+    n_pairs = 33_000                                     # 66 000 operations: 1M 1I alternating, one intron in the middle
+    cigar = "1M1I" * (n_pairs // 2) + "500N" + "1M1I" * (n_pairs // 2)
+    qlen = 2 * n_pairs
+    sam = str(tmp_path / "long.sam")
+    with open(sam, "w") as fh:
+        fh.write(HDR)
+        fh.write(_line("long", 0, "chr1", 1000, cigar, _seq(rng, qlen), 7, ["AS:i:5"]))
+        fh.write(_line("short", 16, "chr2", 50, "20M", _seq(rng, 20), 0))
+    header, refs, recs = fo.parse_sam(sam)
+    idx = {name: i for i, (name, _) in enumerate(refs)}
+    want = fo.header_bytes(header, refs) + b"".join(fo.encode_record(r, idx) for r in recs)
+    assert b"CGBI" in want
+    out1, out2 = str(tmp_path / "a.bam"), str(tmp_path / "b.bam")
+    code = "import sys; sys.path.insert(0, %r); from lr2rmats_amd import hostlib; sys.exit(hostlib.records_to_bam(sys.argv[1], sys.argv[2]))" % \
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for src, dst in ((sam, out1), (out1, out2)):
+        r = subprocess.run([sys.executable, "-c", code, src, dst], stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert _inflate(dst) == want
+
+
 # ---------------------------------------------------------------------------------------------------- the HIP path (CLI)
 
 def _run_filter(args, stdout_path):
@@ -366,3 +392,46 @@ def test_c_abi_filter_score_and_select_at_size(tmp_path):
         assert (want >= 0).sum() > 1000
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_hip_filter_empty_and_header_only_inputs(tmp_path):
+    """No records at all, and records that all fail: the output is the header and the end-of-file block."""
+    out = str(tmp_path / "out.bam")
+    empty = str(tmp_path / "empty.sam")
+    open(empty, "w").write(HDR)
+    err = _run_filter([empty], out)
+    assert _inflate(out) == fo.expected_stream(empty)[0] and "Filtered alignments: 0" in err
+    rng = np.random.default_rng(6)
+    bad = str(tmp_path / "bad.sam")
+    with open(bad, "w") as fh:
+        fh.write(HDR)
+        fh.write(_line("a", 0, "chr1", 10, "60S40M", _seq(rng, 100), 0))          # coverage 0.4
+        fh.write(_line("b", 4, "*", 0, "*", _seq(rng, 30), None))                   # unmapped
+        fh.write(_line("c", 0, "chr1", 10, "100M", _seq(rng, 100), 60))             # identity 0.4
+    err = _run_filter([bad], out)
+    want, keep = fo.expected_stream(bad)
+    assert keep == [] and _inflate(out) == want and "Filtered alignments: 0" in err
+
+
+@pytest.mark.gpu
+def test_hip_filter_long_cigar_record(tmp_path):
+    """The 66 000-operation record through the whole sub-command, as SAM and as the BAM made from it (CG tag)."""
+    rng = np.random.default_rng(3)
+    n_pairs = 33_000
+    cigar = "1M1I" * (n_pairs // 2) + "500N" + "1M1I" * (n_pairs // 2)
+    sam, out = str(tmp_path / "long.sam"), str(tmp_path / "out.bam")
+    with open(sam, "w") as fh:
+        fh.write(HDR)
+        fh.write(_line("long", 0, "chr1", 1000, cigar, _seq(rng, 2 * n_pairs), 7))
+        fh.write(_line("long", 256, "chr2", 1000, "%dM" % (2 * n_pairs), _seq(rng, 2 * n_pairs), 40000))
+    want, keep = fo.expected_stream(sam, min_intron_n=1)
+    assert keep == [0]
+    _run_filter(["-i", "1", sam], out)
+    assert _inflate(out) == want
+    bam = str(tmp_path / "in.bam")
+    header, refs, recs = fo.parse_sam(sam)
+    idx = {name: i for i, (name, _) in enumerate(refs)}
+    open(bam, "wb").write(fo.bgzf_blocks(fo.header_bytes(header, refs) + b"".join(fo.encode_record(r, idx) for r in recs)))
+    _run_filter(["-i", "1", bam], out)
+    assert _inflate(out) == want
