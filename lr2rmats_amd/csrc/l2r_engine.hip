@@ -75,6 +75,7 @@ struct l2r_ctx {
     DevBuf<int32_t> s_pos;
     DevBuf<uint8_t> s_rev;
     DevBuf<TileWin> tw;
+    DevBuf<uint16_t> ex_len;                // slab pipeline: 16-bit lengths of the slab rows' exons (the rows hold no ends)
     DevBuf<TileWin64> tw64; DevBuf<uint32_t> wide_cnt, wide_tile; uint32_t wide_cap = 0;     // tiles with 33 .. 64 window members (l2r_wide.hip.h)
     DevBuf<unsigned long long> ovf_cursor;
     uint32_t ovf_base = 0;
@@ -231,7 +232,7 @@ void l2r_destroy(l2r_ctx *c)
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->lub.release(); c->tile_ub.release(); c->tile_start.release(); c->tile_total.release(); c->tile_dest.release();
     c->lin_start.release(); c->lin_end.release(); c->lin_flag.release();
-    c->tile_sbase.release(); c->lin_dest.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_cnt.release(); c->wide_tile.release();
+    c->tile_sbase.release(); c->lin_dest.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_cnt.release(); c->wide_tile.release(); c->ex_len.release();
     c->s_clo.release(); c->s_pre.release(); c->s_ncig.release(); c->s_pos.release(); c->s_rev.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -794,7 +795,10 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             for (uint32_t i = tile_first[t]; i < tile_first[t + 1]; ++i) {
                 const uint64_t cc = (uint64_t)(r->cig_off[i + 1] - r->cig_off[i]);
                 const uint64_t rw = (cc + 3u) >> 1;
-                if (rw > (uint64_t)SLAB_ROWS) ovf += cc + 1; else m = std::max<uint32_t>(m, (uint32_t)rw);
+                // (room in the dense area for EVERY read: besides the long CIGARs a read with an exon of 64 kb or more ends up
+                //  there, which only the walk finds out)
+                ovf += cc + 1;
+                if (rw <= (uint64_t)SLAB_ROWS) m = std::max<uint32_t>(m, (uint32_t)rw);
             }
             rows[t] = m; sbase[t] = (uint32_t)total; total += (uint64_t)m * SLAB_STRIDE;
             if (total + ovf >= 0x7ffffff0ULL) break;
@@ -808,7 +812,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) ||
                 c->s_clo.ensure((size_t)N + 1) || c->s_pre.ensure((size_t)N + 1) || c->s_ncig.ensure((size_t)N + 1) || c->s_pos.ensure((size_t)N + 1) || c->s_rev.ensure((size_t)N + 1) ||
                 c->ex_start.ensure(std::max<size_t>(exb, total + ovf)) || c->ex_end.ensure(std::max<size_t>(exb, total + ovf)) ||
-                c->ex_flag.ensure(std::max<size_t>(exb, total + ovf))) return -2;
+                c->ex_flag.ensure(std::max<size_t>(exb, total + ovf)) || c->ex_len.ensure((size_t)total + 1)) return -2;
             HIP_TRY(hipMemcpyAsync(c->tile_sbase.p, sbase.data(), (T + 1) * 4, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));       // (locals)
         }
@@ -925,6 +929,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     fa.walked = c->walked.p; fa.local = c->local.p; fa.order = c->order.p; fa.tile_base = c->tile_base.p; fa.j0 = j0; fa.desc = c->desc.p; fa.win_hdr = c->win_hdr.p;
     fa.hdr = c->hdr.p; fa.st = tabs.st; fa.en = tabs.en;
     fa.ex_off = c->ex_off.p; fa.ex_start = c->ex_start.p; fa.ex_end = c->ex_end.p; fa.ex_flag = c->ex_flag.p; fa.info = c->info.p; fa.ref_tx = c->ref_tx.p;
+    fa.ex_len = nullptr;                                   // (set where the slab pipeline is chosen)
     fa.tile_acc = c->tile_acc.p; fa.tile_acc_ex = c->tile_acc_ex.p; fa.redo_count = c->totals.p + 3; fa.redo = c->redo.p;
     fa.tile_chunk = c->tile_chunk.p; fa.tile_rchunk = c->tile_rchunk.p; fa.chunk_cursor = (unsigned long long *)(c->totals.p + 4);
     fa.acc_start = c->acc_start.p; fa.acc_end = c->acc_end.p; fa.acc_flag = c->acc_flag.p; fa.acc_rec = (AccRec *)c->acc_rec.p; fa.acc_ex_off = c->acc_ex_off.p; fa.first_read = c->first_read;
@@ -960,8 +965,9 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             // ---- two light kernels at high occupancy: the walk (exons into the tiles' slabs), then the probes (l2r_slab.hip.h)
             SlabArgs sa; sa.g = ga; sa.tile_sbase = c->tile_sbase.p; sa.ovf_cursor = c->ovf_cursor.p; sa.ovf_base = c->ovf_base;
             sa.s_clo = c->s_clo.p; sa.s_ncig = c->s_ncig.p; sa.s_pos = c->s_pos.p; sa.s_rev = c->s_rev.p; sa.pre = c->s_pre.p; sa.tw = c->tw.p;
+            sa.g.f.ex_len = c->ex_len.p;
             sa.n_tiles = (uint32_t)c->n_tiles;
-            const unsigned gx = 8u * (unsigned)((c->n_tiles + 7) / 8);          // (l2r_slab.hip.h xcd_tile)
+            const unsigned gx = 8u * (unsigned)std::max<int64_t>((c->n_tiles + 7) / 8, 1);      // (l2r_slab.hip.h xcd_tile; an empty upload still launches)
             sa.wide_cnt = c->wide_cnt.p; sa.wide_tile = c->wide_tile.p; sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p; sa.wide_cap = c->wide_cap;      // (L2R_ABLATE bit 2: no 64-member windows)
             hipLaunchKernelGGL(k_walk_slab, dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, (const uint8_t *)c->order.p,
                                (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
@@ -1040,20 +1046,21 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     }
     const bool slab_now = c->fused && c->slab;
     const uint32_t ex_stride = slab_now ? SLAB_STRIDE : 1u;
+    const uint16_t *const ex_len = slab_now ? (const uint16_t *)c->ex_len.p : (const uint16_t *)nullptr;
     MARK(ST_GENERIC);
     {
         const unsigned gg = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles * 4 : 1, 4096);      // one wave per listed read, grid-stride
         hipLaunchKernelGGL(k_classify_generic, dim3(gg), dim3(TILE_THREADS), 0, s, c->totals.p + 3, c->redo.p, c->r_tid.p, c->r_rev.p,
                            (c->fused ? (const int32_t *)nullptr : j0),
                            c->hdr.p, c->anno_ex.p, p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->info.p, c->ref_tx.p,
-                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles, cd, ex_stride);
+                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles, cd, ex_stride, ex_len);
     }
     MARK(ST_SJ);
     if (c->n_sj > 0) {
         if (!c->sorted) { int rc = prepare_unsorted_sj_cursor(c); if (rc) return rc; }
         hipLaunchKernelGGL(k_validate_sj, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p,
                            c->sj_key.p, (c->sorted ? (const int32_t *)nullptr : c->sj_cursor.p), c->sj_tid.p, c->sj_don.p, c->sj_acc.p,
-                           c->sj_uniq.p, c->sj_multi.p, p, c->info.p, ex_stride);
+                           c->sj_uniq.p, c->sj_multi.p, p, c->info.p, ex_stride, ex_len);
     }
     if ((c->n_sj > 0 || c->fused) && (c->want & L2R_WANT_ACCEPTED)) {
         // acceptance is decided by the junction check (and the one-walk pipeline counts nothing itself): count per tile
@@ -1069,7 +1076,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     hipLaunchKernelGGL(k_gather_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->first_read, c->info.p, c->ref_tx.p, c->ex_off.p,
                        c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->tile_acc.p, c->tile_acc_ex.p, c->tile_chunk.p, c->tile_rchunk.p, c->totals.p + 4,
                        c->acc_rec.p, c->acc_ex_off.p, c->acc_start.p, c->acc_end.p, c->acc_flag.p,
-                       (slab_now ? (const uint32_t *)c->tile_sbase.p : (const uint32_t *)nullptr), ex_stride);
+                       (slab_now ? (const uint32_t *)c->tile_sbase.p : (const uint32_t *)nullptr), ex_stride, ex_len);
     MARK(ST_N);
 #undef MARK
     HIP_TRY(hipGetLastError());
@@ -1254,7 +1261,7 @@ static int read_order_arrays(l2r_ctx *c, const uint32_t **off, const int32_t **x
             // slabs: k_linearize_slab gathers every read's column into its place
             hipLaunchKernelGGL(k_linearize_slab, dim3(gN), dim3(TILE_THREADS), 0, c->stream, N, (const uint32_t *)c->ex_off.p, (const uint32_t *)c->info.p,
                                (const uint32_t *)c->lin_dest.p, (const int32_t *)c->ex_start.p, (const int32_t *)c->ex_end.p, (const uint8_t *)c->ex_flag.p,
-                               c->lin_start.p, c->lin_end.p, c->lin_flag.p);
+                               c->lin_start.p, c->lin_end.p, c->lin_flag.p, (const uint16_t *)c->ex_len.p);
         } else if (X) {
             // one chunk per tile, chunks in the order an atomic cursor handed them out: k_linearize moves the chunks
             const size_t T = (size_t)c->n_tiles;

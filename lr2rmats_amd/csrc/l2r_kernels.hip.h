@@ -102,6 +102,12 @@ __device__ __forceinline__ ExRun ex_run(uint32_t raw_off, uint32_t ex_stride)
     if (ex_stride != 1u && (raw_off & EX_DENSE_FLAG)) return ExRun{raw_off & ~EX_DENSE_FLAG, 1u};
     return ExRun{raw_off, ex_stride};
 }
+// The slab pipeline keeps an exon of a slab row as {start, 16-bit length} (ex_len: 2 bytes instead of the 4 of an end; an
+// exon of 64 kb or more makes its read an outlier, stored densely with int32 ends).  ex_len == null: every layout has ends.
+__device__ __forceinline__ int ex_end_at(const int32_t *ex_start, const int32_t *ex_end, const uint16_t *ex_len, uint32_t idx, uint32_t stride)
+{
+    return (ex_len && stride != 1u) ? ex_start[idx] + (int)ex_len[idx] - 1 : ex_end[idx];
+}
 constexpr uint32_t CHUNK_DEFERRED = 0xffffffffu;   // tile_chunk: the tile's accepted exons are compacted by k_gather_accepted
 constexpr uint32_t TD_FAST = 1;    // exons fit the LDS tile, dictionary slices fit DIR_CAP / KEY_CAP, window fits WIN_TX
 constexpr uint32_t TD_WALKED = 4;  // long-CIGAR input: pass A has left the tile's exons in `walked` (tile * LDS_EXON_CAP + in-tile offset)
@@ -701,7 +707,8 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
                         const uint32_t *__restrict__ ex_off, const int32_t *__restrict__ ex_start, const int32_t *__restrict__ ex_end,
                         uint8_t *__restrict__ ex_flag, uint32_t *__restrict__ info_io, int32_t *__restrict__ ref_out,
                         uint32_t *__restrict__ tile_acc, uint32_t *__restrict__ tile_acc_ex, const uint32_t *__restrict__ tile_first, int n_tiles,
-                        CursorDir cd /* used when j0_arr is null: the one-walk pipeline keeps no per-read cursor values */, uint32_t ex_stride)
+                        CursorDir cd /* used when j0_arr is null: the one-walk pipeline keeps no per-read cursor values */, uint32_t ex_stride,
+                        const uint16_t *__restrict__ ex_len /* slab pipeline: lengths of the slab rows' exons, else null */)
 {
     __shared__ int g_S[GEN_WAVES][GEN_CAP];
     __shared__ int g_E[GEN_WAVES][GEN_CAP];
@@ -725,10 +732,11 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
             if (lane == 0) v = sweep_literal(ex_start + off, ex_end + off, ex_flag + off, n, tid, rev, j0, hdr, anno_ex, p);
         } else {
             for (int k = lane; k < n; k += WAVE) {
-                S[k] = ex_start[off + (uint32_t)k * st]; E[k] = ex_end[off + (uint32_t)k * st];
+                S[k] = ex_start[off + (uint32_t)k * st]; E[k] = ex_end_at(ex_start, ex_end, ex_len, off + (uint32_t)k * st, st);
                 F[k] = (k + 1 < n) ? (uint32_t)(F_EXON | F_DON | F_ACC | F_JUNC) : (uint32_t)F_EXON;
             }
-            const ReadEnds re{ex_start[off], ex_end[off], ex_start[off + (uint32_t)(n - 1) * st], ex_end[off + (uint32_t)(n - 1) * st]};
+            const ReadEnds re{ex_start[off], ex_end_at(ex_start, ex_end, ex_len, off, st), ex_start[off + (uint32_t)(n - 1) * st],
+                              ex_end_at(ex_start, ex_end, ex_len, off + (uint32_t)(n - 1) * st, st)};
             const int r_start = re.s0, r_end = re.el, dis = p.ss_dis, level = p.full_level;
             bool lfull = false, rfull = false, lnoth = true, rnoth = true, known = false, ksite = false;
             int ref = -1, ref_rev = 0;
@@ -879,6 +887,7 @@ struct FastArgs {
     const TxHdr *win_hdr;        // per tile WIN_TX header copies, the annotation index in the spare word (pass A)
     const TxHdr *hdr; SiteDict st, en;
     uint32_t *ex_off; int32_t *ex_start; int32_t *ex_end; uint8_t *ex_flag; uint32_t *info; int32_t *ref_tx;
+    uint16_t *ex_len;            // slab pipeline: the slab rows hold {start, this 16-bit length} instead of {start, end}
     uint32_t *tile_acc, *tile_acc_ex; uint32_t *redo_count, *redo;
     uint32_t *tile_chunk, *tile_rchunk;           // accepted list: first exon slot / first record slot of every tile's chunk
     unsigned long long *chunk_cursor;             // next free {record slot (high word), exon slot (low word)}
@@ -1660,7 +1669,7 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
                    const int64_t *__restrict__ sj_key, const int32_t *__restrict__ sj_cursor,
                    const int32_t *__restrict__ sj_tid, const int32_t *__restrict__ sj_don, const int32_t *__restrict__ sj_acc,
                    const int32_t *__restrict__ sj_uniq, const int32_t *__restrict__ sj_multi, DevParams p,
-                   uint32_t *__restrict__ info_io, uint32_t ex_stride)
+                   uint32_t *__restrict__ info_io, uint32_t ex_stride, const uint16_t *__restrict__ ex_len)
 {
     const int64_t r = (int64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
     if (r >= n_reads) return;
@@ -1669,7 +1678,7 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
     const int n = (int)(info >> 8), tid = r_tid[r];
     const ExRun xr = ex_run(ex_off[r], ex_stride);
     const uint32_t off = xr.off, st = xr.stride;
-    const int r_start = ex_start[off], r_end = ex_end[off + (uint32_t)(n - 1) * st];
+    const int r_start = ex_start[off], r_end = ex_end_at(ex_start, ex_end, ex_len, off + (uint32_t)(n - 1) * st, st);
     const int from = sj_cursor ? sj_cursor[r] : first_key_above(sj_key, p.n_sj, pack_key(tid, r_start));
     bool ok = false;
     if (from < p.n_sj) {
@@ -1680,7 +1689,7 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
             for (int j = 0; j + 1 < n; ++j) {
                 const uint8_t f = ex_flag[off + (uint32_t)j * st];
                 if ((f & F_JUNC) &&
-                    !junction_supported(tid, ex_end[off + (uint32_t)j * st] + 1, ex_start[off + (uint32_t)(j + 1) * st] - 1, from, sj_tid, sj_don, sj_acc, sj_uniq, sj_multi, p)) {
+                    !junction_supported(tid, ex_end_at(ex_start, ex_end, ex_len, off + (uint32_t)j * st, st) + 1, ex_start[off + (uint32_t)(j + 1) * st] - 1, from, sj_tid, sj_don, sj_acc, sj_uniq, sj_multi, p)) {
                     ex_flag[off + (uint32_t)j * st] = f | F_UNREL;
                     ok = false;
                 }
@@ -1735,7 +1744,8 @@ void k_gather_accepted(const uint32_t *__restrict__ tile_first, int64_t first_re
                        uint32_t *__restrict__ tile_chunk, uint32_t *__restrict__ tile_rchunk, const uint32_t *__restrict__ chunk_cursor /* {exons, records} */,
                        AccRec *__restrict__ rec, uint32_t *__restrict__ acc_ex_off, int32_t *__restrict__ acc_start,
                        int32_t *__restrict__ acc_end, uint8_t *__restrict__ acc_flag,
-                       const uint32_t *__restrict__ tile_sbase /* slab pipeline: first element of the tile's slab, else null */, uint32_t ex_stride)
+                       const uint32_t *__restrict__ tile_sbase /* slab pipeline: first element of the tile's slab, else null */, uint32_t ex_stride,
+                       const uint16_t *__restrict__ ex_len)
 {
     __shared__ uint32_t s_wcnt[4], s_wex[4];
     __shared__ uint16_t s_map[LDS_EXON_CAP];
@@ -1768,13 +1778,15 @@ void k_gather_accepted(const uint32_t *__restrict__ tile_first, int64_t first_re
         AccRec a; a.read_lo = (uint32_t)gidx; a.read_hi = (uint32_t)(gidx >> 32); a.info = w; a.ref_tx = ref_tx[r];
         rec[slot] = a;
         acc_ex_off[slot] = ebase0 + e_loc;
-        if (mapped && src >= src0 && (uint64_t)(src - src0) + (uint64_t)nex * st < MAP_DIRECT) {
+        // (slab pipeline: only slab rows go through the map -- a densely stored read next to the slabs would be read back in the
+        //  wrong format below)
+        if (mapped && (!ex_len || st != 1u) && src >= src0 && (uint64_t)(src - src0) + (uint64_t)nex * st < MAP_DIRECT) {
             for (uint32_t k = 0; k < nex; ++k) s_map[e_loc + k] = (uint16_t)(src - src0 + k * st);
         } else {
             for (uint32_t k = 0; k < nex; ++k) {
                 if (mapped) s_map[e_loc + k] = (uint16_t)MAP_DIRECT;
                 acc_start[ebase0 + e_loc + k] = ex_start[src + k * st];
-                acc_end[ebase0 + e_loc + k] = ex_end[src + k * st];
+                acc_end[ebase0 + e_loc + k] = ex_end_at(ex_start, ex_end, ex_len, src + k * st, st);
                 acc_flag[ebase0 + e_loc + k] = ex_flag[src + k * st];
             }
         }
@@ -1786,7 +1798,7 @@ void k_gather_accepted(const uint32_t *__restrict__ tile_first, int64_t first_re
         if (q == MAP_DIRECT) continue;
         const uint32_t sidx = src0 + q;
         acc_start[ebase0 + i] = ex_start[sidx];
-        acc_end[ebase0 + i] = ex_end[sidx];
+        acc_end[ebase0 + i] = ex_end_at(ex_start, ex_end, ex_len, sidx, ex_len ? 256u : 1u);      // (slab pipeline: mapped slots are slab elements)
         acc_flag[ebase0 + i] = ex_flag[sidx];
     }
 }

@@ -86,9 +86,10 @@ __device__ __forceinline__ SlabWalk slab_walk(SlabArgsK sa, FusedArgsK a, uint32
     DevParams p;
     p.min_exon = a->f.p.min_exon; p.min_intron = a->f.p.min_intron; p.max_delet = a->f.p.max_delet;
     const uint32_t t3 = ((uint32_t)p.min_intron << 4) | 3u, t2 = ((uint32_t)(p.max_delet + 1) << 4) | 2u;
-    const bool outlier = slab_rows_of(v.n_cig) > (uint32_t)SLAB_ROWS;
+    bool outlier = slab_rows_of(v.n_cig) > (uint32_t)SLAB_ROWS;
     const int c_max = wave_max((active && !outlier) ? (int)min(v.n_cig, (uint32_t)FUSED_HEAD) : 0);
     int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end;
+    uint16_t *const xl = a->f.ex_len;                   // slab rows: {start, 16-bit length}
     uint32_t n = 0u, off = 0u;
     int el = INT32_MIN;
     bool sane = true;
@@ -98,13 +99,16 @@ __device__ __forceinline__ SlabWalk slab_walk(SlabArgsK sa, FusedArgsK a, uint32
         int start = v.pos + 1, end = v.pos;
         int s0 = 0, e0 = 0;
         bool first = true;
+        uint32_t longest = 0u;
         auto step = [&](uint32_t c) {
             const uint32_t op = c & 0xfu;
             const int len = (int)(c >> 4);
             const bool cut = ((op == 3u) & (c >= t3)) | ((op == 2u) & (c >= t2));
             const bool keep = cut & (first | (end - start >= p.min_exon - 1));
             if (keep) {
-                st32(xs, off + n * SLAB_STRIDE, start); st32(xe, off + n * SLAB_STRIDE, end);
+                const uint32_t xlen = (uint32_t)(end - start + 1);
+                st32(xs, off + n * SLAB_STRIDE, start); st32(xl, off + n * SLAB_STRIDE, (uint16_t)xlen);
+                longest = max(longest, xlen);
                 if (first) { s0 = start; e0 = end; }
                 first = false; ++n;
             }
@@ -118,13 +122,18 @@ __device__ __forceinline__ SlabWalk slab_walk(SlabArgsK sa, FusedArgsK a, uint32
             const uint32_t *const words = a->f.cig + v.c_lo;
             for (uint32_t i = FUSED_HEAD; i < v.n_cig; ++i) step(words[i]);
         }
-        st32(xs, off + n * SLAB_STRIDE, start); st32(xe, off + n * SLAB_STRIDE, end);
+        {   const uint32_t xlen = (uint32_t)(end - start + 1);
+            st32(xs, off + n * SLAB_STRIDE, start); st32(xl, off + n * SLAB_STRIDE, (uint16_t)xlen);
+            longest = max(longest, xlen); }
         if (first) { s0 = start; e0 = end; }
         ++n;
         el = end;
         // kept inner exons are at least min_exon >= 1 long; the first and the last one are kept whatever their length
         sane = s0 <= e0 && start <= end;
-    } else if (active) {
+        // an exon of 64 kb or more does not fit the row format: the read is stored densely after all (below)
+        if (longest > 0xffffu) { outlier = true; n = 0u; sane = true; el = INT32_MIN; }
+    }
+    if (active && outlier) {
         // an outlier: the literal walk (l2r_kernels.hip.h), twice -- count, take a run of the dense area, store
         const int64_t *const p_off = a->f.cig_off;
         const uint32_t n_ops = (uint32_t)(ld32(p_off, r + 1u) - ld32(p_off, r));
@@ -209,7 +218,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
 // Work words at W[k * 256].
 struct SlabRows { int s[4], e[4]; };
 __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const TileDesc &d, bool mapping, const int32_t *__restrict__ xs,
-                                                    const int32_t *__restrict__ xe, uint32_t off, uint32_t n, uint32_t vpre,
+                                                    const uint16_t *__restrict__ xl, uint32_t off, uint32_t n, uint32_t vpre,
                                                     const SlabRows &q)
 {
     SiteMasks m{0xffffffffu, 0u, 0u, 0u};
@@ -220,7 +229,7 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
     for (int k = 0; k < k_max; ++k) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
         int s4 = 0, e4 = 0;
-        if (mapping) { const uint32_t i4 = off + min((uint32_t)k + 4u, n - 1u) * SLAB_STRIDE; s4 = ld32(xs, i4); e4 = ld32(xe, i4); }   // four rows in flight
+        if (mapping) { const uint32_t i4 = off + min((uint32_t)k + 4u, n - 1u) * SLAB_STRIDE; s4 = ld32(xs, i4); e4 = (int)ld32(xl, i4); }   // four rows in flight (e4: the length until the row is used)
         const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
         const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
         const int s2 = s1;
@@ -242,7 +251,7 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         if (k == 0) m.dm_first = dm;
         m.am_last = (live && !junc) ? am : m.am_last;
         if (live) W[(uint32_t)k * SLAB_STRIDE] = (uint16_t)word;
-        s = s1; e = e1; s1 = s2n; e1 = e2n; s2n = s3n; e2n = e3n; s3n = s4; e3n = e4;
+        s = s1; e = e1; s1 = s2n; e1 = e2n; s2n = s3n; e2n = e3n; s3n = s4; e3n = s4 + e4 - 1;
     }
     return m;
 }
@@ -305,7 +314,7 @@ __device__ __forceinline__ void slab_classify(FusedArgsK a, const TileDesc &d, c
     const int w_n = fast ? (int)d.n_win : 0;
     const uint32_t n = pre >> 8;
     const bool outlier = (pre & I_PRE_DIRECT) != 0u;
-    const int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end;
+    const int32_t *const xs = a->f.ex_start; const uint16_t *const xl = a->f.ex_len;
     uint16_t *const s_W = S.W;
     // ---- classification (device functions of the classic kernel)
     uint32_t info = n << 8; int ref = -1;
@@ -314,7 +323,7 @@ __device__ __forceinline__ void slab_classify(FusedArgsK a, const TileDesc &d, c
     const TileLds L{nullptr, nullptr, s_W, S.ent0, S.ent1, S.dir0, S.dir1, S.rdir, hk, hx, win};
     const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, tilemask);
     redo = redo || vm.redo;
-    const SiteMasks sm = map_exons_slab(L, d, work && !redo && n > 1, xs, xe, off, n, vm.vpre, q);
+    const SiteMasks sm = map_exons_slab(L, d, work && !redo && n > 1, xs, xl, off, n, vm.vpre, q);
     uint8_t *const xf = a->f.ex_flag;
     if (work && !redo) {
         const Verdict vd = decide<LEVEL, (int)SLAB_STRIDE>(L, d, threadIdx.x, n, re, vm, sm, rev_in);
@@ -372,7 +381,7 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     const uint32_t at = r0 + (active ? threadIdx.x : 0u);
     uint32_t pre = 0u, r = r0;
     bool rev_in = false;
-    const int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end;
+    const int32_t *const xs = a->f.ex_start; const uint16_t *const xl = a->f.ex_len;
     const uint32_t off = sbase + threadIdx.x;
     SlabRows q;
 #pragma unroll
@@ -382,15 +391,17 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
 #pragma unroll
         for (int i = 0; i < 4; ++i) {               // (an outlier's slab column holds nothing: read, not used)
             const uint32_t ix = off + min((uint32_t)i, row_max) * SLAB_STRIDE;
-            q.s[i] = ld32(xs, ix); q.e[i] = ld32(xe, ix);
+            q.s[i] = ld32(xs, ix); q.e[i] = (int)ld32(xl, ix);           // (the length: turned into the end below)
         }
     }
     if (threadIdx.x == 0 && t == 0u) *sa->ovf_cursor = 0ull;        // (k_walk_slab is done with the outlier area)
     const uint32_t n = pre >> 8;
     const bool outlier = (pre & I_PRE_DIRECT) != 0u;
     const int32_t tid = tid0;                                       // (sorted input: a tile is of one chromosome)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q.e[i] = q.s[i] + q.e[i] - 1;
     ReadEnds re{q.s[0], q.e[0], 0, 0};
-    if (active && !outlier) { re.sl = ld32(xs, off + (n - 1u) * SLAB_STRIDE); re.el = ld32(xe, off + (n - 1u) * SLAB_STRIDE); }
+    if (active && !outlier) { re.sl = ld32(xs, off + (n - 1u) * SLAB_STRIDE); re.el = re.sl + (int)ld32(xl, off + (n - 1u) * SLAB_STRIDE) - 1; }
     // ---- stage window and dictionary slices, re-based to the tile's window
     if ((int)threadIdx.x < SLAB_TW_VECS) reinterpret_cast<int4 *>(&s_tw)[threadIdx.x] = twv;
     const SlabLds S{s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir};
@@ -411,7 +422,7 @@ void k_exon_counts(int64_t n_reads, const uint32_t *__restrict__ info, uint32_t 
 __global__ __launch_bounds__(TILE_THREADS)
 void k_linearize_slab(int64_t n_reads, const uint32_t *__restrict__ ex_off, const uint32_t *__restrict__ info, const uint32_t *__restrict__ dest,
                       const int32_t *__restrict__ xs, const int32_t *__restrict__ xe, const uint8_t *__restrict__ xf,
-                      int32_t *__restrict__ os, int32_t *__restrict__ oe, uint8_t *__restrict__ of)
+                      int32_t *__restrict__ os, int32_t *__restrict__ oe, uint8_t *__restrict__ of, const uint16_t *__restrict__ xl)
 {
     const int64_t r = (int64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
     if (r >= n_reads) return;
@@ -419,7 +430,7 @@ void k_linearize_slab(int64_t n_reads, const uint32_t *__restrict__ ex_off, cons
     const uint32_t n = info[r] >> 8, to = dest[r];
     const uint32_t st = (off & EXOFF_DENSE) ? 1u : SLAB_STRIDE;
     off &= ~EXOFF_DENSE;
-    for (uint32_t k = 0; k < n; ++k) { os[to + k] = xs[off + k * st]; oe[to + k] = xe[off + k * st]; of[to + k] = xf[off + k * st]; }
+    for (uint32_t k = 0; k < n; ++k) { os[to + k] = xs[off + k * st]; oe[to + k] = ex_end_at(xs, xe, xl, off + k * st, st); of[to + k] = xf[off + k * st]; }
 }
 
 }  // namespace l2r

@@ -112,22 +112,22 @@ __device__ __forceinline__ m64_t overlapping_exon_members64(const uint8_t *rdir,
 
 // map_exons_slab on 64-bit masks (rows streamed from the slab column, two rows in flight: these tiles are rare)
 __device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const TileDesc &d, bool mapping, const int32_t *__restrict__ xs,
-                                                        const int32_t *__restrict__ xe, uint32_t off, uint32_t n, m64_t vpre)
+                                                        const uint16_t *__restrict__ xl, uint32_t off, uint32_t n, m64_t vpre)
 {
     SiteMasks64 m{~0ull, 0ull, 0ull, 0ull};
     uint16_t *W = L.W + threadIdx.x;
     int s = 0, e = 0, s1 = 0, e1 = 0;
     if (mapping) {
-        s = ld32(xs, off); e = ld32(xe, off);
+        s = ld32(xs, off); e = s + (int)ld32(xl, off) - 1;
         const uint32_t i1 = off + min(1u, n - 1u) * SLAB_STRIDE;
-        s1 = ld32(xs, i1); e1 = ld32(xe, i1);
+        s1 = ld32(xs, i1); e1 = s1 + (int)ld32(xl, i1) - 1;
     }
     const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
     const int k_max = wave_max(mapping ? (int)n : 0);
     for (int k = 0; k < k_max; ++k) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
         int s2n = 0, e2n = 0;
-        if (mapping) { const uint32_t i2 = off + min((uint32_t)k + 2u, n - 1u) * SLAB_STRIDE; s2n = ld32(xs, i2); e2n = ld32(xe, i2); }
+        if (mapping) { const uint32_t i2 = off + min((uint32_t)k + 2u, n - 1u) * SLAB_STRIDE; s2n = ld32(xs, i2); e2n = s2n + (int)ld32(xl, i2) - 1; }
         const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
         const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
         const int s2 = s1;
@@ -239,15 +239,15 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         const uint32_t at = r0 + (active ? threadIdx.x : 0u);
         uint32_t pre = 0u, r = r0;
         bool rev_in = false;
-        const int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end;
+        const int32_t *const xs = a->f.ex_start; const uint16_t *const xl = a->f.ex_len;
         const uint32_t off = sbase + threadIdx.x;
         ReadEnds re{0, 0, 0, 0};
         if (active) { pre = ld32(sa->pre, at); r = r0 + (uint32_t)ld32(u_order, at); rev_in = ld32(sa->s_rev, at) != 0; }
         const uint32_t n = pre >> 8;
         const bool outlier = (pre & I_PRE_DIRECT) != 0u;
         if (active && !outlier) {
-            re.s0 = ld32(xs, off); re.e0 = ld32(xe, off);
-            re.sl = ld32(xs, off + (n - 1u) * SLAB_STRIDE); re.el = ld32(xe, off + (n - 1u) * SLAB_STRIDE);
+            re.s0 = ld32(xs, off); re.e0 = re.s0 + (int)ld32(xl, off) - 1;
+            re.sl = ld32(xs, off + (n - 1u) * SLAB_STRIDE); re.el = re.sl + (int)ld32(xl, off + (n - 1u) * SLAB_STRIDE) - 1;
         }
         __syncthreads();
         const TileDesc d = s_tw.d;
@@ -292,7 +292,7 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         const WideLds L{s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
         const VisitMasks64 vm = visit_window64<LEVEL>(L, d, w_n, work, n, d.j_lo, re, s_tw.mask);
         redo = redo || vm.redo;
-        const SiteMasks64 sm = map_exons_slab64(L, d, work && !redo && n > 1, xs, xe, off, n, vm.vpre);
+        const SiteMasks64 sm = map_exons_slab64(L, d, work && !redo && n > 1, xs, xl, off, n, vm.vpre);
         uint8_t *const xf = a->f.ex_flag;
         if (work && !redo) {
             const Verdict vd = decide64<LEVEL>(L, d, n, re, vm, sm, rev_in);

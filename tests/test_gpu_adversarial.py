@@ -205,3 +205,28 @@ def test_redo_share_of_the_benchmark_workload_shape(oracle, pipeline):
     cnt = [0, 0, 0, 0]
     got, want = _run(oracle, af, reads, counters=cnt, full_level=3)
     assert cnt[0] <= reads.n // 200, cnt
+
+
+def test_exons_of_64_kb_and_more(oracle, pipeline):
+    """The slab rows keep an exon as {start, 16-bit length}: a read with an exon of 65 536 bases or more is stored densely
+    instead (found out by the walk itself) and classified by the generic kernel; lengths 65 534 .. 65 537 sit on both sides."""
+    txs = [(0, 0, [(1_000, 1_200), (2_000, 70_000), (80_000, 80_300)]),
+           (0, 1, [(100_000, 100_100), (100_500, 100_500 + 65_535), (200_000, 200_100)]),
+           (1, 0, [(5_000, 5_100), (6_000, 6_200)])]
+    af = _anno(txs)
+    rows = []
+    for L in (65_534, 65_535, 65_536, 65_537, 90_000):
+        rows.append((0, *_chain([(1_000, 1_200), (2_000, 2_000 + L - 1), (2_000 + L + 9_999, 2_000 + L + 10_299)])))
+        rows.append((0, *_chain([(100_000, 100_100), (100_500, 100_500 + L - 1), (200_000, 200_100)])))
+        rows.append((0, *_chain([(3_000, 3_000 + L - 1)])))                    # single long exon
+        rows.append((0, *_chain([(500, 600), (3_000, 3_000 + L - 1)])))        # long LAST exon
+    for k in range(300):                                                        # ordinary neighbours in the same tiles
+        rows.append((0, *_chain([(1_000 + k % 150, 1_200), (2_000, 2_300)])))
+        rows.append((1, *_chain([(5_000, 5_100), (6_000, 6_200 - (k % 7))])))
+    rows = [(r[0], r[1], 0, r[2]) for r in rows]
+    cnt = [0, 0, 0, 0, 0]
+    got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=3)
+    lens = (want.ex_end - want.ex_start + 1)
+    assert (lens >= 65_536).sum() >= 10 and (lens == 65_535).sum() >= 3
+    if pipeline == "slab":
+        assert 12 <= cnt[0] <= 80, cnt            # the reads with an exon of 65 536 bases or more (+ the tile a 200 kb span pushes off the fast path)
