@@ -216,26 +216,39 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
 // for the whole wave = coalesced.  Rows 0..3 come preloaded (SlabRows: the kernel asks for them with its first loads, before
 // it knows the read), row k + 4 is asked for in round k.  Rows at and behind the read's exon count hold anything: not used.
 // Work words at W[k * 256].
-struct SlabRows { int s[4], e[4]; };
+constexpr int SLAB_AHEAD = 4;                            // rows of a read's column in flight (6: no gain, measured)
+struct SlabRows { int s[SLAB_AHEAD], e[SLAB_AHEAD]; };
 __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const TileDesc &d, bool mapping, const int32_t *__restrict__ xs,
                                                     const uint16_t *__restrict__ xl, uint32_t off, uint32_t n, uint32_t vpre,
                                                     const SlabRows &q)
 {
     SiteMasks m{0xffffffffu, 0u, 0u, 0u};
     uint16_t *W = L.W + threadIdx.x;
-    int s = q.s[0], e = q.e[0], s1 = q.s[1], e1 = q.e[1], s2n = q.s[2], e2n = q.e[2], s3n = q.s[3], e3n = q.e[3];
+    int s = q.s[0], e = q.e[0], s1 = q.s[1], e1 = q.e[1];
+    int ps[SLAB_AHEAD - 2], pe[SLAB_AHEAD - 2];         // rows k + 2 .. k + SLAB_AHEAD - 1
+#pragma unroll
+    for (int i = 0; i < SLAB_AHEAD - 2; ++i) { ps[i] = q.s[i + 2]; pe[i] = q.e[i + 2]; }
     const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
     const int k_max = wave_max(mapping ? (int)n : 0);
+    // The bucket ranges of exon k + 1 are looked up while exon k's entries are compared (the directory bytes and the entries
+    // are two dependent LDS round trips: one of them per exon is taken off the chain).
+    auto buckets = [&](int k, int sv, int ev, uint32_t &ls, uint32_t &hs, uint32_t &le, uint32_t &he) {
+        const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
+        const uint32_t is = live ? min((uint32_t)((sv >> SITE_SHIFT) + d.b_off), none) : none;
+        const uint32_t ie = junc ? min((uint32_t)((ev >> SITE_SHIFT) + d.b_off), none) : none;
+        ls = L.dir0[is]; hs = L.dir0[is + 1u]; le = L.dir1[ie]; he = L.dir1[ie + 1u];
+    };
+    uint32_t ls, hs, le, he;
+    buckets(0, s, e, ls, hs, le, he);
     for (int k = 0; k < k_max; ++k) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
         int s4 = 0, e4 = 0;
-        if (mapping) { const uint32_t i4 = off + min((uint32_t)k + 4u, n - 1u) * SLAB_STRIDE; s4 = ld32(xs, i4); e4 = (int)ld32(xl, i4); }   // four rows in flight (e4: the length until the row is used)
-        const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
-        const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
+        if (mapping) { const uint32_t i4 = off + min((uint32_t)k + (uint32_t)SLAB_AHEAD, n - 1u) * SLAB_STRIDE; s4 = ld32(xs, i4); e4 = (int)ld32(xl, i4); }   // SLAB_AHEAD rows in flight (e4: the length until the row is used)
         const int s2 = s1;
-        const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
         const v4i_t qs0 = lds_entry(L.ent0, ls);
         const v4i_t qe0 = lds_entry(L.ent1, le), qe1 = lds_entry(L.ent1, le + 1u);
+        uint32_t ls_n, hs_n, le_n, he_n;
+        buckets(k + 1, s1, e1, ls_n, hs_n, le_n, he_n);
         uint32_t xm, am, jm, dm;
         {   const bool m0 = ls < hs && qs0.x == s;
             am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
@@ -251,7 +264,11 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         if (k == 0) m.dm_first = dm;
         m.am_last = (live && !junc) ? am : m.am_last;
         if (live) W[(uint32_t)k * SLAB_STRIDE] = (uint16_t)word;
-        s = s1; e = e1; s1 = s2n; e1 = e2n; s2n = s3n; e2n = e3n; s3n = s4; e3n = s4 + e4 - 1;
+        s = s1; e = e1; s1 = ps[0]; e1 = pe[0];
+#pragma unroll
+        for (int i = 0; i + 1 < SLAB_AHEAD - 2; ++i) { ps[i] = ps[i + 1]; pe[i] = pe[i + 1]; }
+        ps[SLAB_AHEAD - 3] = s4; pe[SLAB_AHEAD - 3] = s4 + e4 - 1;
+        ls = ls_n; hs = hs_n; le = le_n; he = he_n;
     }
     return m;
 }
@@ -385,11 +402,11 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     const uint32_t off = sbase + threadIdx.x;
     SlabRows q;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { q.s[i] = 0; q.e[i] = 0; }
+    for (int i = 0; i < SLAB_AHEAD; ++i) { q.s[i] = 0; q.e[i] = 0; }
     if (active) {
         pre = ld32(sa->pre, at); r = r0 + (uint32_t)ld32(u_order, at); rev_in = ld32(sa->s_rev, at) != 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {               // (an outlier's slab column holds nothing: read, not used)
+        for (int i = 0; i < SLAB_AHEAD; ++i) {      // (an outlier's slab column holds nothing: read, not used)
             const uint32_t ix = off + min((uint32_t)i, row_max) * SLAB_STRIDE;
             q.s[i] = ld32(xs, ix); q.e[i] = (int)ld32(xl, ix);           // (the length: turned into the end below)
         }
@@ -399,7 +416,7 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     const bool outlier = (pre & I_PRE_DIRECT) != 0u;
     const int32_t tid = tid0;                                       // (sorted input: a tile is of one chromosome)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q.e[i] = q.s[i] + q.e[i] - 1;
+    for (int i = 0; i < SLAB_AHEAD; ++i) q.e[i] = q.s[i] + q.e[i] - 1;
     ReadEnds re{q.s[0], q.e[0], 0, 0};
     if (active && !outlier) { re.sl = ld32(xs, off + (n - 1u) * SLAB_STRIDE); re.el = re.sl + (int)ld32(xl, off + (n - 1u) * SLAB_STRIDE) - 1; }
     // ---- stage window and dictionary slices, re-based to the tile's window
