@@ -151,6 +151,10 @@ struct l2r_ctx {
     bool ran = false;
     hipGraphExec_t graph = nullptr;         // the launch sequence of l2r_run, captured once per (inputs, parameters)
     bool graph_valid = false;
+    // slab pipeline: what the last synchronised run of THIS configuration left for the two list kernels (the redo list of
+    // k_classify_generic, the wide-tile list of k_probe_slab_wide).  Both counts are functions of the inputs and parameters: once
+    // they are known to be zero the two (empty) launches are left out until something changes (drop_graph is that hook).
+    bool tail_known = false; uint32_t tail_redo = 0, tail_wide = 0;
     DevBuf<unsigned long long> stamps;      // diagnostics, L2R_STAMPS=1
     uint32_t h_totals[3] = {0, 0, 0};
     bool totals_valid = false;
@@ -158,6 +162,7 @@ struct l2r_ctx {
 
 static void drop_graph(l2r_ctx *c)
 {
+    c->tail_known = false;
     if (c->graph) { (void)hipGraphExecDestroy(c->graph); c->graph = nullptr; }
     c->graph_valid = false;
 }
@@ -986,6 +991,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             default: launch_probe_level(0); break;
             }
 #undef launch_probe_level
+            if (!(c->tail_known && c->tail_wide == 0u))
             {   // the tiles with 33 .. 64 window members (none on most inputs: the grid finds an empty list and leaves)
                 const WideArgs wa{c->wide_cnt.p + 1, c->wide_tile.p, c->tw64.p};
                 const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 6);
@@ -1048,6 +1054,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     const uint32_t ex_stride = slab_now ? SLAB_STRIDE : 1u;
     const uint16_t *const ex_len = slab_now ? (const uint16_t *)c->ex_len.p : (const uint16_t *)nullptr;
     MARK(ST_GENERIC);
+    if (!(slab_now && c->tail_known && c->tail_redo == 0u))     // (a redo list known to be empty for these inputs and parameters)
     {
         const unsigned gg = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles * 4 : 1, 4096);      // one wave per listed read, grid-stride
         hipLaunchKernelGGL(k_classify_generic, dim3(gg), dim3(TILE_THREADS), 0, s, c->totals.p + 3, c->redo.p, c->r_tid.p, c->r_rev.p,
@@ -1171,6 +1178,13 @@ int l2r_sync(l2r_ctx *c)
     if (!c) return fail(-1, "[l2r_sync] null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->ran && c->fused && c->slab && !c->tail_known && c->wide_cnt.p) {
+        uint32_t redo = 0, wide = 0;
+        HIP_TRY(hipMemcpyAsync(&redo, c->totals.p + 3, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&wide, c->wide_cnt.p + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->tail_redo = redo; c->tail_wide = wide; c->tail_known = true;
+    }
     return 0;
 }
 
