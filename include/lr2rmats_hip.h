@@ -154,7 +154,8 @@ typedef struct {
  * pipeline the engine chose for the uploaded records (l2r_stage_kernel() names them):
  *     slab    (coordinate-sorted records, short CIGARs; default)  0 k_order, first run of an upload only (a layout of
  *             the records: lane order of every tile, record fields in that order)  1 k_walk_slab (CIGAR -> exons, tile
- *             descriptors)  2 k_probe_slab (annotation window, site probes, verdicts)
+ *             descriptors)  2 k_probe_slab (annotation window, site probes, verdicts) + k_probe_slab_wide (tiles whose
+ *             window holds 33 .. 64 transcripts)
  *     fused   (L2R_PIPELINE=fused)   0 k_order  1 -  2 k_fused
  *     classic (unsorted records, long CIGARs, L2R_PIPELINE=classic)  0 k_pass_a  1 k_scan_tiles  2 k_classify_fast */
 #define L2R_N_STAGES 8
