@@ -239,45 +239,13 @@ static void encode_aux(bytes *o, const char *a, const char *ae, const char *who)
     }
 }
 
-static void records_from_sam(const h_blob *b, h_chroms *chr, h_records *r, const char *who)
+/* The lines of [p, end) (whole lines) -> BAM-encoded records + their index, into a piece of its own (several pieces are made
+ * on several threads and joined by records_join) */
+static void encode_sam_lines(const char *p, const char *end, const h_chroms *chr, h_records *r, const char *who)
 {
-    const char *p = (const char *)b->p, *end = p + b->n;
-    /* header: the '@' lines verbatim are the BAM header text; the references come from the @SQ lines */
-    bytes text = {NULL, 0, 0}, refs = {NULL, 0, 0};
-    uint32_t n_ref = 0;
-    while (p < end && *p == '@') {
-        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-        const char *e = nl ? nl : end;
-        by_put(&text, p, (size_t)(e - p)); by_u8(&text, '\n');
-        const char *le = (e > p && e[-1] == '\r') ? e - 1 : e;
-        if (le - p > 3 && memcmp(p, "@SQ", 3) == 0) {
-            const char *sn = NULL, *sne = NULL; long long ln = 0;
-            for (const char *q = p; q < le;) {
-                const char *t = (const char *)memchr(q, '\t', (size_t)(le - q));
-                const char *fe = t ? t : le;
-                if (fe - q > 3 && memcmp(q, "SN:", 3) == 0) { sn = q + 3; sne = fe; }
-                if (fe - q > 3 && memcmp(q, "LN:", 3) == 0) ln = strtoll(q + 3, NULL, 10);
-                if (!t) break;
-                q = t + 1;
-            }
-            if (sn) {
-                char name[H_NAME_MAX];
-                if (sne - sn >= H_NAME_MAX) h_fatal(who, "reference name of 100 or more characters");
-                memcpy(name, sn, (size_t)(sne - sn)); name[sne - sn] = 0;
-                h_chrom_intern(chr, name);
-                by_u32(&refs, (uint32_t)(sne - sn) + 1); by_put(&refs, name, (size_t)(sne - sn) + 1); by_u32(&refs, (uint32_t)ln);
-                ++n_ref;
-            }
-        }
-        p = nl ? nl + 1 : end;
-    }
-    chr->n_hdr = chr->n;
-    r->hdr_len = 4 + 4 + text.n + 4 + refs.n;
-    r->hdr = (uint8_t *)h_malloc(r->hdr_len + 1);
-    memcpy(r->hdr, "BAM\1", 4); put32(r->hdr + 4, (uint32_t)text.n); memcpy(r->hdr + 8, text.p, text.n);
-    put32(r->hdr + 8 + text.n, n_ref); memcpy(r->hdr + 12 + text.n, refs.p, refs.n);
-    free(text.p); free(refs.p);
-
+    memset(r, 0, sizeof *r);
+    rec_reserve(r, 1);
+    r->cig_off[0] = 0; r->rec_off[0] = 0;
     bytes out = {NULL, 0, 0};
     int64_t *offs = NULL; int64_t n_off = 0, cap_off = 0;
     while (p < end) {
@@ -401,6 +369,105 @@ static void records_from_sam(const h_blob *b, h_chroms *chr, h_records *r, const
     r->buf = out.p; r->buf_len = out.n;
     for (int64_t k = 0; k < n_off; ++k) index_record(r, offs[k], who);
     free(offs);
+}
+
+typedef struct { const char *p, *end; const h_chroms *chr; h_records piece; const char *who; } sam_piece;
+static void *sam_piece_main(void *arg) { sam_piece *q = (sam_piece *)arg; encode_sam_lines(q->p, q->end, q->chr, &q->piece, q->who); return NULL; }
+
+/* pieces, in order -> one h_records (header fields of `r` are kept) */
+static void records_join(h_records *r, sam_piece *pc, int n_pc)
+{
+    int64_t n = 0, n_cig = 0; size_t bytes_total = 0;
+    for (int k = 0; k < n_pc; ++k) { n += pc[k].piece.n; n_cig += pc[k].piece.n_cig; bytes_total += pc[k].piece.buf_len; }
+    r->n = 0; r->cap = 0; r->n_cig = 0; r->cap_cig = 0;
+    r->rec_off = (int64_t *)h_malloc((size_t)(n + 2) * 8); r->cig_off = (int64_t *)h_malloc((size_t)(n + 2) * 8);
+    r->flag = (uint16_t *)h_malloc((size_t)(n + 1) * 2); r->tid = (int32_t *)h_malloc((size_t)(n + 1) * 4); r->pos = (int32_t *)h_malloc((size_t)(n + 1) * 4);
+    r->l_qseq = (int32_t *)h_malloc((size_t)(n + 1) * 4); r->nm = (int32_t *)h_malloc((size_t)(n + 1) * 4); r->nm_seen = (uint8_t *)h_malloc((size_t)n + 1);
+    r->cig = (uint32_t *)h_malloc((size_t)(n_cig + 1) * 4);
+    r->buf = (uint8_t *)h_malloc(bytes_total + 1); r->buf_len = bytes_total;
+    r->cap = n + 1; r->cap_cig = n_cig + 1;
+    int64_t at = 0, cat = 0; size_t bat = 0;
+    for (int k = 0; k < n_pc; ++k) {
+        h_records *q = &pc[k].piece;
+        memcpy(r->buf + bat, q->buf, q->buf_len);
+        for (int64_t i = 0; i < q->n; ++i) { r->rec_off[at + i] = q->rec_off[i] + (int64_t)bat; r->cig_off[at + i] = q->cig_off[i] + cat; }
+        memcpy(r->flag + at, q->flag, (size_t)q->n * 2); memcpy(r->tid + at, q->tid, (size_t)q->n * 4); memcpy(r->pos + at, q->pos, (size_t)q->n * 4);
+        memcpy(r->l_qseq + at, q->l_qseq, (size_t)q->n * 4); memcpy(r->nm + at, q->nm, (size_t)q->n * 4); memcpy(r->nm_seen + at, q->nm_seen, (size_t)q->n);
+        memcpy(r->cig + cat, q->cig, (size_t)q->n_cig * 4);
+        at += q->n; cat += q->n_cig; bat += q->buf_len;
+        uint8_t *hdr_keep = q->hdr; q->hdr = NULL; (void)hdr_keep;
+        h_records_free(q);
+    }
+    r->rec_off[at] = (int64_t)bat; r->cig_off[at] = cat;
+    r->n = at; r->n_cig = cat;
+}
+
+static void records_from_sam(const h_blob *b, h_chroms *chr, h_records *r, const char *who)
+{
+    const char *p = (const char *)b->p, *end = p + b->n;
+    /* header: the '@' lines verbatim are the BAM header text; the references come from the @SQ lines */
+    bytes text = {NULL, 0, 0}, refs = {NULL, 0, 0};
+    uint32_t n_ref = 0;
+    while (p < end && *p == '@') {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *e = nl ? nl : end;
+        by_put(&text, p, (size_t)(e - p)); by_u8(&text, '\n');
+        const char *le = (e > p && e[-1] == '\r') ? e - 1 : e;
+        if (le - p > 3 && memcmp(p, "@SQ", 3) == 0) {
+            const char *sn = NULL, *sne = NULL; long long ln = 0;
+            for (const char *q = p; q < le;) {
+                const char *t = (const char *)memchr(q, '\t', (size_t)(le - q));
+                const char *fe = t ? t : le;
+                if (fe - q > 3 && memcmp(q, "SN:", 3) == 0) { sn = q + 3; sne = fe; }
+                if (fe - q > 3 && memcmp(q, "LN:", 3) == 0) ln = strtoll(q + 3, NULL, 10);
+                if (!t) break;
+                q = t + 1;
+            }
+            if (sn) {
+                char name[H_NAME_MAX];
+                if (sne - sn >= H_NAME_MAX) h_fatal(who, "reference name of 100 or more characters");
+                memcpy(name, sn, (size_t)(sne - sn)); name[sne - sn] = 0;
+                h_chrom_intern(chr, name);
+                by_u32(&refs, (uint32_t)(sne - sn) + 1); by_put(&refs, name, (size_t)(sne - sn) + 1); by_u32(&refs, (uint32_t)ln);
+                ++n_ref;
+            }
+        }
+        p = nl ? nl + 1 : end;
+    }
+    chr->n_hdr = chr->n;
+    r->hdr_len = 4 + 4 + text.n + 4 + refs.n;
+    r->hdr = (uint8_t *)h_malloc(r->hdr_len + 1);
+    memcpy(r->hdr, "BAM\1", 4); put32(r->hdr + 4, (uint32_t)text.n); memcpy(r->hdr + 8, text.p, text.n);
+    put32(r->hdr + 8 + text.n, n_ref); memcpy(r->hdr + 12 + text.n, refs.p, refs.n);
+    free(text.p); free(refs.p);
+
+    /* the records: the text is cut at line ends into one piece per thread (L2R_THREADS, default = online CPUs up to 32; small
+     * inputs: one), every piece is encoded on its own, the pieces are joined in order */
+    {
+        const char *e = getenv("L2R_THREADS");
+        long n_thr = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+        if (n_thr > 32) n_thr = 32;
+        const size_t body = (size_t)(end - p);
+        if (n_thr < 1 || (!e && body < ((size_t)8 << 20))) n_thr = 1;
+        sam_piece pc[32];
+        int n_pc = 0;
+        const char *q = p;
+        for (long k = 0; k < n_thr && q < end; ++k) {
+            const char *stop = (k == n_thr - 1) ? end : p + body * (size_t)(k + 1) / (size_t)n_thr;
+            if (stop < q) stop = q;
+            if (stop < end) { const char *nl = (const char *)memchr(stop, '\n', (size_t)(end - stop)); stop = nl ? nl + 1 : end; }
+            pc[n_pc].p = q; pc[n_pc].end = stop; pc[n_pc].chr = chr; pc[n_pc].who = who; ++n_pc;
+            q = stop;
+        }
+        pthread_t th[32];
+        for (int k = 1; k < n_pc; ++k) if (pthread_create(&th[k], NULL, sam_piece_main, &pc[k])) h_fatal(who, "pthread_create failed");
+        if (n_pc) sam_piece_main(&pc[0]);
+        for (int k = 1; k < n_pc; ++k) pthread_join(th[k], NULL);
+        uint8_t *hdr = r->hdr; const size_t hdr_len = r->hdr_len;
+        free(r->rec_off); free(r->cig_off); free(r->flag); free(r->tid); free(r->pos); free(r->l_qseq); free(r->nm); free(r->nm_seen); free(r->cig);
+        records_join(r, pc, n_pc);
+        r->hdr = hdr; r->hdr_len = hdr_len;
+    }
 }
 
 void h_read_records(const char *fn, h_chroms *chr, h_records *r, const char *who)
