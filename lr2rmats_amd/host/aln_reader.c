@@ -285,28 +285,22 @@ static size_t aux_size(uint8_t type, const uint8_t *p, const uint8_t *end)
     }
 }
 
-static void parse_bam(const blob *b, h_chroms *chr, h_reads *out, int skip_unmapped, int header_only, const char *who)
+typedef struct {
+    const blob *b; const size_t *starts; size_t lo, hi; const h_chroms *chr; int skip_unmapped; const char *who; h_reads piece;
+    h_reads *dst; int64_t at, cat; size_t nat;               /* where the piece goes in the joined arrays */
+} bam_piece;
+
+static void *bam_piece_main(void *arg)
 {
-    const uint8_t *p = b->p, *end = p + b->n;
-    if (end - p < 12 || memcmp(p, "BAM\1", 4) != 0) h_fatal(who, "not a BAM stream");
-    uint32_t l_text = le32(p + 4);
-    p += 8 + l_text;
-    if (p + 4 > end) h_fatal(who, "truncated BAM header");
-    uint32_t n_ref = le32(p); p += 4;
-    for (uint32_t i = 0; i < n_ref; ++i) {
-        if (p + 4 > end) h_fatal(who, "truncated BAM header");
-        uint32_t l_name = le32(p); p += 4;
-        if (p + l_name + 4 > end) h_fatal(who, "truncated BAM header");
-        h_chrom_intern(chr, (const char *)p);            /* NUL terminated */
-        p += l_name + 4;
-    }
-    chr->n_hdr = chr->n;
-    if (header_only) return;
-    while (p + 4 <= end) {
-        uint32_t bs = le32(p); p += 4;
-        if (bs < 32 || p + bs > end) h_fatal(who, "truncated BAM record");
-        const uint8_t *rec = p, *rend = p + bs;
-        p = rend;
+    bam_piece *q = (bam_piece *)arg;
+    h_reads *out = &q->piece;
+    const h_chroms *chr = q->chr; const char *who = q->who; const int skip_unmapped = q->skip_unmapped;
+    reads_reserve(out, 1, 1);
+    out->cig_off[0] = 0;
+    for (size_t ri = q->lo; ri < q->hi; ++ri) {
+        const uint8_t *p = q->b->p + q->starts[ri];
+        const uint32_t bs = le32(p);
+        const uint8_t *rec = p + 4, *rend = rec + bs;
         int32_t refid = (int32_t)le32(rec), pos = (int32_t)le32(rec + 4);
         uint32_t l_read_name = rec[8], n_cig = le16(rec + 12), flag = le16(rec + 14), l_seq = le32(rec + 16);
         if (flag & 4) {
@@ -338,11 +332,87 @@ static void parse_bam(const blob *b, h_chroms *chr, h_reads *out, int skip_unmap
         out->n++;
         out->cig_off[out->n] = out->n_cig;
     }
+    return NULL;
+}
+
+static void *bam_join_main(void *arg)
+{
+    bam_piece *pc = (bam_piece *)arg;
+    h_reads *q = &pc->piece, *out = pc->dst;
+    const int64_t at = pc->at, cat = pc->cat; const size_t nat = pc->nat;
+    memcpy(out->tid + at, q->tid, (size_t)q->n * 4); memcpy(out->pos + at, q->pos, (size_t)q->n * 4); memcpy(out->rev + at, q->rev, (size_t)q->n);
+    for (int64_t i = 0; i < q->n; ++i) { out->cig_off[at + i] = q->cig_off[i] + cat; out->qname[at + i] = q->qname[i] + (uint32_t)nat; }
+    memcpy(out->cig + cat, q->cig, (size_t)q->n_cig * 4);
+    memcpy(out->names.buf + nat, q->names.buf, q->names.len);
+    h_reads_free(q);
+    return NULL;
+}
+
+static void parse_bam(const blob *b, h_chroms *chr, h_reads *out, int skip_unmapped, int header_only, const char *who)
+{
+    const uint8_t *p = b->p, *end = p + b->n;
+    if (end - p < 12 || memcmp(p, "BAM\1", 4) != 0) h_fatal(who, "not a BAM stream");
+    uint32_t l_text = le32(p + 4);
+    p += 8 + l_text;
+    if (p + 4 > end) h_fatal(who, "truncated BAM header");
+    uint32_t n_ref = le32(p); p += 4;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (p + 4 > end) h_fatal(who, "truncated BAM header");
+        uint32_t l_name = le32(p); p += 4;
+        if (p + l_name + 4 > end) h_fatal(who, "truncated BAM header");
+        h_chrom_intern(chr, (const char *)p);            /* NUL terminated */
+        p += l_name + 4;
+    }
+    chr->n_hdr = chr->n;
+    if (header_only) return;
+    /* the records' places (one cheap pass over the block_size words), then the field extraction on several threads: every
+     * thread fills a piece of its own, the pieces are joined in order (read names: ids are offsets into the joined table) */
+    size_t n_rec = 0, cap_rec = 1 << 16;
+    size_t *starts = (size_t *)h_malloc(cap_rec * sizeof *starts);
+    while (p + 4 <= end) {
+        const uint32_t bs = le32(p);
+        if (bs < 32 || p + 4 + bs > end) h_fatal(who, "truncated BAM record");
+        if (n_rec == cap_rec) { cap_rec *= 2; starts = (size_t *)h_realloc(starts, cap_rec * sizeof *starts); }
+        starts[n_rec++] = (size_t)(p - b->p);
+        p += 4 + bs;
+    }
+    const char *e = getenv("L2R_THREADS");
+    long n_thr = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    if (n_thr > 32) n_thr = 32;
+    if (n_thr < 1 || (!e && n_rec < 200000)) n_thr = 1;
+    if ((size_t)n_thr > n_rec) n_thr = n_rec ? (long)n_rec : 1;
+    bam_piece pc[32];
+    pthread_t th[32];
+    for (long k = 0; k < n_thr; ++k) {
+        pc[k].b = b; pc[k].starts = starts; pc[k].lo = n_rec * (size_t)k / (size_t)n_thr; pc[k].hi = n_rec * (size_t)(k + 1) / (size_t)n_thr;
+        pc[k].chr = chr; pc[k].skip_unmapped = skip_unmapped; pc[k].who = who;
+        memset(&pc[k].piece, 0, sizeof pc[k].piece);
+    }
+    for (long k = 1; k < n_thr; ++k) if (pthread_create(&th[k], NULL, bam_piece_main, &pc[k])) h_fatal(who, "pthread_create failed");
+    bam_piece_main(&pc[0]);
+    for (long k = 1; k < n_thr; ++k) pthread_join(th[k], NULL);
+    free(starts);
+    /* join */
+    int64_t n = 0, n_cig = 0; size_t names = 0;
+    for (long k = 0; k < n_thr; ++k) { n += pc[k].piece.n; n_cig += pc[k].piece.n_cig; names += pc[k].piece.names.len; }
+    if (names >= 0xffffffffu) h_fatal(who, "read names exceed 4 GiB");
+    reads_reserve(out, n, n_cig);
+    out->names.buf = (char *)h_realloc(out->names.buf, names + 1); out->names.cap = names + 1;
+    /* (every piece is copied into place by a thread of its own: the pages of the joined arrays are touched in parallel) */
+    for (long k = 0; k < n_thr; ++k) {
+        pc[k].dst = out; pc[k].at = out->n; pc[k].cat = out->n_cig; pc[k].nat = out->names.len;
+        out->n += pc[k].piece.n; out->n_cig += pc[k].piece.n_cig; out->names.len += pc[k].piece.names.len;
+    }
+    out->cig_off[out->n] = out->n_cig;
+    for (long k = 1; k < n_thr; ++k) if (pthread_create(&th[k], NULL, bam_join_main, &pc[k])) h_fatal(who, "pthread_create failed");
+    bam_join_main(&pc[0]);
+    for (long k = 1; k < n_thr; ++k) pthread_join(th[k], NULL);
 }
 
 static void read_any(const char *fn, h_chroms *chr, h_reads *out, int skip_unmapped, int header_only, const char *who)
 {
     blob b = h_slurp(fn, who);
+    if (!header_only) h_stage_time("  alignments: file read + inflate");
     h_reads tmp; memset(&tmp, 0, sizeof tmp);
     h_reads *dst = out ? out : &tmp;
     reads_reserve(dst, 1, 1);
