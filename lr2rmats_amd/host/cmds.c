@@ -394,7 +394,8 @@ static int finish_threaded(h_job *j, const l2r_result *res, int n_thr)
     if (j->o.summary) h_write_summary_text(j->o.summary, j->anno.gene_n, (int)j->anno.n_tx, total);
     /* (tried: detail.txt -- more than half of the bytes, rows independent -- in 64 parts of its own beside the chromosome-aligned
      *  ones: slower, 2.2 -> 2.35 s on the 256-core GPU box; the tail is bound by page faults / stream growth of ~4 GB of fresh
-     *  memory in one process, not by formatting) */
+     *  memory in one process, not by formatting; the three writer groups of a part -- lists | per-read files | summary -- side by side
+     *  on threads of their own: slower as well, 2.1 -> 2.46 s) */
     if (getenv("L2R_TIMING")) fprintf(stderr, "[timing]   tail: %d parts, waiting for them %.3f s, copying their streams out %.3f s\n", n_thr, t_join, t_write);
     free(parts); free(th); free(cut);
     return 0;
