@@ -315,8 +315,8 @@ static void *tail_part_main(void *arg)
     FILE *fs[7];
     for (int k = 0; k < 7; ++k) {
         t->buf[k] = NULL; t->len[k] = 0;
-        fs[k] = want[k] ? open_memstream(&t->buf[k], &t->len[k]) : NULL;
-        if (want[k] && !fs[k]) h_fatal("update_gtf", "open_memstream failed");
+        fs[k] = want[k] ? h_open_growbuf(&t->buf[k], &t->len[k]) : NULL;
+        if (want[k] && !fs[k]) h_fatal("update_gtf", "fopencookie failed");
     }
     o.out_gtf = fs[0]; o.exon_bed = fs[1]; o.bam_gtf = fs[2]; o.bam_detail = fs[3]; o.known_gtf = fs[4]; o.novel_gtf = fs[5]; o.unrecog_gtf = fs[6];
     o.summary = NULL; o.summary_counts = t->cnt; o.no_detail_header = !t->first; o.part_genes = &t->genes;

@@ -20,6 +20,7 @@ void h_fatal_core(const char *where, const char *fmt, ...);   /* "[where] msg Ab
 void h_stage_time(const char *what);                          /* L2R_TIMING=1: wall clock since the last call, on stderr */
 void *h_malloc(size_t n);
 void *h_realloc(void *p, size_t n);
+FILE *h_open_growbuf(char **buf, size_t *len);                /* like open_memstream, on h_realloc (huge pages); *buf, *len valid after fclose */
 
 /* ---- append-only string table: ids are byte offsets */
 typedef struct { char *buf; size_t len, cap; } h_strtab;

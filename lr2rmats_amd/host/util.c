@@ -1,7 +1,9 @@
 /* util.c -- errors, memory, string table, chromosome table. */
+#define _GNU_SOURCE
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include "l2r_host.h"
 
 void h_fatal(const char *where, const char *fmt, ...)
@@ -24,10 +26,25 @@ void h_fatal_core(const char *where, const char *fmt, ...)
     abort();
 }
 
+/* A 10 M-read run touches ~10 GB of fresh memory (inflated BAM, record arrays, results, 4 GB of output text): with 4 KB pages
+ * that is millions of page faults in one address space, and they -- not the parsing or formatting -- bound the host stages.
+ * Large blocks are therefore offered to the kernel as transparent huge pages (this box: THP mode "madvise"): 3.9 -> 2.7 s end to
+ * end for 10 M reads.  L2R_NO_THP=1 turns it off. */
+static void advise_huge(void *p, size_t n)
+{
+    static int off = -1;
+    if (off < 0) off = getenv("L2R_NO_THP") != NULL;
+    if (off || n < ((size_t)4 << 20)) return;
+    const size_t pg = 4096;
+    char *a = (char *)(((uintptr_t)p + pg - 1) & ~(uintptr_t)(pg - 1)), *e = (char *)(((uintptr_t)p + n) & ~(uintptr_t)(pg - 1));
+    if (e > a) (void)madvise(a, (size_t)(e - a), MADV_HUGEPAGE);
+}
+
 void *h_malloc(size_t n)
 {
     void *p = malloc(n ? n : 1);
     if (!p) h_fatal_core("h_malloc", "Malloc fail!\nSize: %lld\n", (long long)n);
+    advise_huge(p, n);
     return p;
 }
 
@@ -35,7 +52,35 @@ void *h_realloc(void *q, size_t n)
 {
     void *p = realloc(q, n ? n : 1);
     if (!p) h_fatal_core("h_realloc", "Realloc fail!\nSize: %lld\n", (long long)n);
+    advise_huge(p, n);
     return p;
+}
+
+/* A FILE that appends to a growing memory block made by h_realloc (open_memstream with the allocator above): *buf / *len are
+ * valid after fclose(). */
+typedef struct { char **buf; size_t *len; size_t cap; } growbuf;
+static ssize_t growbuf_write(void *ck, const char *data, size_t n)
+{
+    growbuf *g = (growbuf *)ck;
+    if (*g->len + n > g->cap) {
+        size_t c = g->cap ? g->cap : (size_t)1 << 20;
+        while (c < *g->len + n) c *= 2;
+        *g->buf = (char *)h_realloc(*g->buf, c); g->cap = c;
+    }
+    memcpy(*g->buf + *g->len, data, n);
+    *g->len += n;
+    return (ssize_t)n;
+}
+static int growbuf_close(void *ck) { free(ck); return 0; }
+FILE *h_open_growbuf(char **buf, size_t *len)
+{
+    growbuf *g = (growbuf *)h_malloc(sizeof *g);
+    *buf = NULL; *len = 0;
+    g->buf = buf; g->len = len; g->cap = 0;
+    cookie_io_functions_t io = { NULL, growbuf_write, NULL, growbuf_close };
+    FILE *f = fopencookie(g, "w", io);
+    if (f) setvbuf(f, NULL, _IOFBF, 1 << 16);
+    return f;
 }
 
 uint32_t h_str_add(h_strtab *t, const char *s)
