@@ -11,6 +11,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -395,7 +396,11 @@ static int build_tables(const l2r_annotation *a, AnnoTables &o)
         if (k > run) run = k;
         key[(size_t)i] = run;
     }
-    std::sort(kd.begin(), kd.end()); std::sort(ka.begin(), ka.end()); std::sort(kx.begin(), kx.end()); std::sort(kj.begin(), kj.end());
+    {   // the four row sets are independent: one thread each
+        std::thread t1([&] { std::sort(kd.begin(), kd.end()); }), t2([&] { std::sort(ka.begin(), ka.end()); }), t3([&] { std::sort(kx.begin(), kx.end()); });
+        std::sort(kj.begin(), kj.end());
+        t1.join(); t2.join(); t3.join();
+    }
     o.n_compact = n_compact;
     {   // one bucket grid for the four kinds: per tid, enough 512-bp buckets for its largest site coordinate
         int32_t n_tid = 0;
