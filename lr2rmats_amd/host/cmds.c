@@ -717,6 +717,8 @@ int h_main(int argc, char **argv)
     if (strcmp(argv[0], "bam2gtf") == 0) return h_cmd_bam2gtf(argc, argv);
     if (strcmp(argv[0], "unique-gtf") == 0) return h_cmd_unique_gtf(argc, argv);
     if (strcmp(argv[0], "filter") == 0) return h_cmd_filter(argc, argv);
+    /* (diagnostics, no GPU: every record of a SAM / BAM file written out as BAM -- reader, encoder and BGZF writer of `filter`) */
+    if (strcmp(argv[0], "records2bam") == 0 && argc == 3) return h_records_to_bam(argv[1], argv[2]) ? 1 : 0;
     if (!strcmp(argv[0], "fusion") || !strcmp(argv[0], "bam2sj")) {
         fprintf(stderr, "[main] command '%s' is outside the MI355X build (see DESIGN.md, scope)\n", argv[0]);
         return 1;
