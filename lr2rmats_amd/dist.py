@@ -8,7 +8,8 @@ Every rank parses the inputs with the C host library, takes a contiguous shard o
 its shard.  Then one of two routes gives the output files of the single-GPU run:
 
 * **partitioned** (reads coordinate sorted, no ``-s`` with a junction table): the shards are cut at
-  chromosome boundaries.  The order-dependent tail never looks across chromosomes (``merge_trans`` stops
+  chromosome boundaries.  For BAM input the host library makes the cut itself from the records' core fields and every rank
+  extracts names, strands and CIGARs of ITS shard only (``hostlib.Job(rank=, world=)``); SAM text is loaded whole and cut here.  The order-dependent tail never looks across chromosomes (``merge_trans`` stops
   at a smaller tid, ``src/update_gtf.c:147``; the novel-exon / site / gene lists likewise), so every rank
   runs split / merge / writers on its own shard in parallel; the only collective is an all-gather of the 16
   summary counters, and rank 0 concatenates the part files in shard order.
@@ -102,7 +103,7 @@ def _engine_classify(device_index: int):
     """Default shard classifier: the HIP engine on this rank's GPU; the results stay in HBM."""
     eng = capi.Engine(device_index)
 
-    def run(job: hostlib.Job, lo: int, hi: int, want: int = capi.WANT_RESULTS):
+    def run(job: hostlib.Job, lo: int, hi: int, want: int = capi.WANT_RESULTS, base: int = 0):
         a = job.annotation_arrays()
         r = job.read_arrays()
         eng.set_params(job.prm)
@@ -110,7 +111,7 @@ def _engine_classify(device_index: int):
         eng.set_annotation(a["tx_tid"], a["tx_start"], a["tx_end"], a["tx_rev"], a["tx_ex_off"], a["ex_start"], a["ex_end"])
         eng.set_junctions(job.junction_arrays())
         c0, c1 = int(r["cig_off"][lo]), int(r["cig_off"][hi])
-        eng.upload_reads(r["tid"][lo:hi], r["pos"][lo:hi], r["rev"][lo:hi], r["cig_off"][lo:hi + 1] - c0, r["cig"][c0:c1], first_read_index=lo)
+        eng.upload_reads(r["tid"][lo:hi], r["pos"][lo:hi], r["rev"][lo:hi], r["cig_off"][lo:hi + 1] - c0, r["cig"][c0:c1], first_read_index=base + lo)
         eng.run()
         eng.sync()
         return DeviceShard(eng)
@@ -169,7 +170,8 @@ def run(argv, classify: Optional[Callable] = None, backend: Optional[str] = None
         # (L2R_DIST_BACKEND=gloo: tests that put several ranks on one GPU, which RCCL does not allow)
         dist.init_process_group(backend or os.environ.get("L2R_DIST_BACKEND") or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
 
-    job = hostlib.Job(list(argv), open_outputs=False)
+    # (a rank of a multi-process run loads only its shard of a coordinate-sorted BAM: hostlib.Job.shard)
+    job = hostlib.Job(list(argv), open_outputs=False, rank=rank, world=world)
     gtf_tmp = None
     if job.out_path(0) is None:
         import tempfile
@@ -199,9 +201,18 @@ def run(argv, classify: Optional[Callable] = None, backend: Optional[str] = None
     weights = 4.0 * np.diff(r["cig_off"]) + 64.0           # ~ bytes a read costs (4c + 21n + 12)
     sj = job.junction_arrays()
     aligned = None
-    in_order = records_sorted(r["tid"], r["pos"])
-    if world > 1 and in_order and not (job.prm.split_trans and sj is not None) and os.environ.get("L2R_DIST_GATHER") != "1":
+    sharded, shard_lo, shard_hi, n_total = job.shard()
+    in_order = True if sharded else records_sorted(r["tid"], r["pos"])
+    if world > 1 and not sharded and in_order and not (job.prm.split_trans and sj is not None) and os.environ.get("L2R_DIST_GATHER") != "1":
         aligned = workload.aligned_shard_bounds(r["tid"], world, weights)
+    if os.environ.get("L2R_DIST_SHARD_TRACE"):                # tests: what this rank loaded
+        with open("%s.%d" % (os.environ["L2R_DIST_SHARD_TRACE"], rank), "w") as fh:
+            fh.write("%d %d %d %d\n" % (1 if sharded else 0, shard_lo, shard_hi, n_total))
+    base = 0
+    if sharded:
+        # the host library has cut the records already (same rule, chromosome-aligned): this rank holds [shard_lo, shard_hi) only
+        aligned = [(0, n)] * world
+        base = shard_lo
     if aligned is not None:
         bounds = aligned
     elif world > 1 and not in_order:
@@ -222,7 +233,10 @@ def run(argv, classify: Optional[Callable] = None, backend: Optional[str] = None
     empty = HostShard(capi.Result(np.zeros(1, np.int64), z, z, np.zeros(0, np.uint8), np.zeros(0, np.uint32), z), lo)
     if hi > lo:
         # (the engine is told which output to make; a plugged-in classifier returns a capi.Result of its shard)
-        shard = classify(job, lo, hi, capi.WANT_ACCEPTED) if (accepted_only and hasattr(classify, "engine")) else classify(job, lo, hi)
+        if hasattr(classify, "engine"):
+            shard = classify(job, lo, hi, capi.WANT_ACCEPTED if accepted_only else capi.WANT_RESULTS, base)
+        else:
+            shard = classify(job, lo, hi)
         if isinstance(shard, capi.Result):
             shard = HostShard(shard, lo, sj is not None, bool(job.prm.split_trans))
     else:

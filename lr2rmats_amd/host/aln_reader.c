@@ -348,6 +348,13 @@ static void *bam_join_main(void *arg)
     return NULL;
 }
 
+/* A one-process-per-GPU run (dist.py) asks every rank for ITS shard only: the ranks agree on the cuts from the records' core
+ * fields alone (chromosome, position, number of CIGAR operations: one cheap pass), and extract names / CIGARs / strands just for
+ * their own range.  The cuts are the ones of workload.aligned_shard_bounds: equal shares of 4 * ops + 64 bytes per record, moved to
+ * the nearest chromosome boundary.  Only coordinate-sorted BAM input is cut this way (anything else: every rank loads all). */
+typedef struct { int rank, world; int64_t lo, hi, n_total; int done; } shard_req;
+static shard_req *g_shard = NULL;
+
 static void parse_bam(const blob *b, h_chroms *chr, h_reads *out, int skip_unmapped, int header_only, const char *who)
 {
     const uint8_t *p = b->p, *end = p + b->n;
@@ -376,15 +383,60 @@ static void parse_bam(const blob *b, h_chroms *chr, h_reads *out, int skip_unmap
         starts[n_rec++] = (size_t)(p - b->p);
         p += 4 + bs;
     }
+    size_t r_lo = 0, r_hi = n_rec;
+    if (g_shard && g_shard->world > 1) {
+        shard_req *sq = g_shard;
+        sq->n_total = (int64_t)n_rec; sq->lo = 0; sq->hi = (int64_t)n_rec; sq->done = 0;
+        /* sorted by (tid, pos)?  weights; chromosome starts */
+        int sorted = 1;
+        double total_w = 0.0;
+        for (size_t i = 0; i < n_rec; ++i) {
+            const uint8_t *rec = b->p + starts[i] + 4;
+            const int32_t tid = (int32_t)le32(rec), pos = (int32_t)le32(rec + 4);
+            if (i) {
+                const uint8_t *pr = b->p + starts[i - 1] + 4;
+                const int32_t pt = (int32_t)le32(pr), pp = (int32_t)le32(pr + 4);
+                if (tid < pt || (tid == pt && pos < pp)) { sorted = 0; break; }
+            }
+            total_w += 4.0 * (double)le16(rec + 12) + 64.0;
+        }
+        if (sorted && n_rec) {
+            const int W = sq->world;
+            size_t *cut = (size_t *)h_malloc((size_t)(W + 1) * sizeof *cut);
+            /* ideal cuts: first record at which the running weight reaches k / W of the total */
+            size_t *ideal = (size_t *)h_malloc((size_t)(W + 1) * sizeof *ideal);
+            {   double run = 0.0; int k = 1; ideal[0] = 0;
+                for (size_t i = 0; i < n_rec && k < W; ++i) {
+                    while (k < W && run >= total_w * (double)k / (double)W) ideal[k++] = i;
+                    run += 4.0 * (double)le16(b->p + starts[i] + 4 + 12) + 64.0;
+                }
+                while (k <= W) ideal[k++] = n_rec; }
+            cut[0] = 0;
+            for (int k = 1; k < W; ++k) {
+                /* nearest chromosome boundary (0 and n_rec count as boundaries) */
+                size_t lo = ideal[k], hi = ideal[k];
+                while (lo > 0 && lo < n_rec && le32(b->p + starts[lo] + 4) == le32(b->p + starts[lo - 1] + 4)) --lo;
+                while (hi < n_rec && hi > 0 && le32(b->p + starts[hi] + 4) == le32(b->p + starts[hi - 1] + 4)) ++hi;
+                size_t c = (ideal[k] - lo <= hi - ideal[k]) ? lo : hi;
+                if (c < cut[k - 1]) c = cut[k - 1];
+                cut[k] = c;
+            }
+            cut[W] = n_rec;
+            r_lo = cut[sq->rank]; r_hi = cut[sq->rank + 1];
+            sq->lo = (int64_t)r_lo; sq->hi = (int64_t)r_hi; sq->done = 1;
+            free(cut); free(ideal);
+        }
+    }
+    const size_t n_mine = r_hi - r_lo;
     const char *e = getenv("L2R_THREADS");
     long n_thr = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
     if (n_thr > 32) n_thr = 32;
-    if (n_thr < 1 || (!e && n_rec < 200000)) n_thr = 1;
-    if ((size_t)n_thr > n_rec) n_thr = n_rec ? (long)n_rec : 1;
+    if (n_thr < 1 || (!e && n_mine < 200000)) n_thr = 1;
+    if ((size_t)n_thr > n_mine) n_thr = n_mine ? (long)n_mine : 1;
     bam_piece pc[32];
     pthread_t th[32];
     for (long k = 0; k < n_thr; ++k) {
-        pc[k].b = b; pc[k].starts = starts; pc[k].lo = n_rec * (size_t)k / (size_t)n_thr; pc[k].hi = n_rec * (size_t)(k + 1) / (size_t)n_thr;
+        pc[k].b = b; pc[k].starts = starts; pc[k].lo = r_lo + n_mine * (size_t)k / (size_t)n_thr; pc[k].hi = r_lo + n_mine * (size_t)(k + 1) / (size_t)n_thr;
         pc[k].chr = chr; pc[k].skip_unmapped = skip_unmapped; pc[k].who = who;
         memset(&pc[k].piece, 0, sizeof pc[k].piece);
     }
@@ -427,6 +479,21 @@ void h_read_alignments(const char *fn, h_chroms *chr, h_reads *out, int skip_unm
 {
     memset(out, 0, sizeof *out);
     read_any(fn, chr, out, skip_unmapped, 0, who);
+}
+
+/* h_read_alignments for one rank of `world` (see shard_req): *lo, *hi = the rank's record range, *n_total = records in the file;
+ * returns 1 when only that range was loaded, 0 when everything was (input that is not coordinate-sorted BAM). */
+int h_read_alignments_shard(const char *fn, h_chroms *chr, h_reads *out, int skip_unmapped, const char *who, int rank, int world,
+                            int64_t *lo, int64_t *hi, int64_t *n_total)
+{
+    shard_req sq = { rank, world, 0, 0, 0, 0 };
+    memset(out, 0, sizeof *out);
+    g_shard = &sq;
+    read_any(fn, chr, out, skip_unmapped, 0, who);
+    g_shard = NULL;
+    if (!sq.done) { sq.lo = 0; sq.hi = out->n; sq.n_total = out->n; }
+    *lo = sq.lo; *hi = sq.hi; *n_total = sq.n_total;
+    return sq.done;
 }
 
 void h_read_header_only(const char *fn, h_chroms *chr, const char *who)

@@ -26,6 +26,7 @@ struct h_job {
     FILE *sj_fp;
     int mode;
     l2r_params engine_prm;       /* what the engine gets: o.prm, except that `-m g` input passes its exons through unchanged */
+    int sharded; int64_t shard_lo, shard_hi, shard_total;       /* h_job_open_rank: only records [lo, hi) of `total` are loaded */
     char *out_path[8];           /* 0 updated gtf (NULL = stdout), 1 exon bed, 2 bam gtf, 3 detail, 4 known, 5 novel, 6 unrecog, 7 summary */
     h_part_genes part_genes;     /* of the part h_job_finish_part last ran */
 };
@@ -135,6 +136,20 @@ static void reads_from_gtf(const char *fn, const h_chroms *chr, h_reads *out)
     h_gtf_free(&g);
 }
 
+static int g_rank = 0, g_world = 1;
+h_job *h_job_open_rank(int argc, char **argv, int *exit_code, int open_outputs, int rank, int world)
+{
+    g_rank = rank; g_world = world;
+    h_job *j = h_job_open2(argc, argv, exit_code, open_outputs);
+    g_rank = 0; g_world = 1;
+    return j;
+}
+int h_job_shard(const h_job *j, int64_t *lo, int64_t *hi, int64_t *n_total)
+{
+    *lo = j->sharded ? j->shard_lo : 0; *hi = j->sharded ? j->shard_hi : j->reads.n; *n_total = j->sharded ? j->shard_total : j->reads.n;
+    return j->sharded;
+}
+
 h_job *h_job_open2(int argc, char **argv, int *exit_code, int open_outputs)
 {
     /* ranks other than the writer of a multi-process run parse the same command line without
@@ -194,7 +209,12 @@ h_job *h_job_open(int argc, char **argv, int *exit_code)
 
     h_stage_time("start");
     if (j->mode == 0) {
-        h_read_alignments(argv[optind], &j->chr, &j->reads, 0, "update_gtf");
+        /* a rank of a multi-process run loads its shard only -- unless the run needs the gathered route (split pieces are compared
+         * across chromosomes, Q2) or the caller forces it */
+        const char *fg = getenv("L2R_DIST_GATHER");
+        if (g_world > 1 && !(j->o.prm.split_trans && j->sj_fp) && !(fg && fg[0] == '1'))
+            j->sharded = h_read_alignments_shard(argv[optind], &j->chr, &j->reads, 0, "update_gtf", g_rank, g_world, &j->shard_lo, &j->shard_hi, &j->shard_total);
+        else h_read_alignments(argv[optind], &j->chr, &j->reads, 0, "update_gtf");
         h_stage_time("read alignments");
     } else {
         if (!hdr_file) h_fatal("update_gtf", "Couldn't read header of provided BAM file.\n");

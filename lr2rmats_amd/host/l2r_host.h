@@ -48,6 +48,8 @@ typedef struct {
 /* Reads every record of a SAM (text), gzip/BGZF-compressed SAM or BAM file.
  * skip_unmapped = 0: an unmapped record is the reference's abort (Q9). */
 void h_read_alignments(const char *fn, h_chroms *chr, h_reads *out, int skip_unmapped, const char *who);
+int  h_read_alignments_shard(const char *fn, h_chroms *chr, h_reads *out, int skip_unmapped, const char *who, int rank, int world,
+                             int64_t *lo, int64_t *hi, int64_t *n_total);
 void h_read_header_only(const char *fn, h_chroms *chr, const char *who);
 void h_reads_free(h_reads *r);
 
@@ -151,6 +153,11 @@ int h_main(int argc, char **argv);
 typedef struct h_job h_job;
 h_job *h_job_open(int argc, char **argv, int *exit_code);
 h_job *h_job_open2(int argc, char **argv, int *exit_code, int open_outputs);   /* 0: do not create output files */
+/* One rank of a one-process-per-GPU run: when the alignments are a coordinate-sorted BAM and the run can take the partitioned
+ * route (no -s with a junction table), only the rank's chromosome-aligned shard of the records is loaded -- h_job_shard() then
+ * gives its place: records [*lo, *hi) of *n_total, and returns 1; the job's read arrays hold just those (index 0 = record *lo). */
+h_job *h_job_open_rank(int argc, char **argv, int *exit_code, int open_outputs, int rank, int world);
+int    h_job_shard(const h_job *j, int64_t *lo, int64_t *hi, int64_t *n_total);
 void   h_job_views(h_job *j, l2r_params *prm, l2r_annotation *anno, l2r_junctions *sj, l2r_reads *reads);
 int    h_job_finish(h_job *j, const l2r_result *res);
 void   h_job_free(h_job *j);

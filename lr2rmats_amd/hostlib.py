@@ -33,6 +33,10 @@ def load_library():
         lib.h_job_open.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
         lib.h_job_open2.restype = C.c_void_p
         lib.h_job_open2.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int]
+        lib.h_job_open_rank.restype = C.c_void_p
+        lib.h_job_open_rank.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]
+        lib.h_job_shard.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.h_job_shard.restype = C.c_int
         lib.h_job_views.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.h_job_finish.argtypes = [C.c_void_p, C.c_void_p]
         lib.h_job_finish.restype = C.c_int
@@ -69,12 +73,17 @@ def _arr(ptr, n, dtype):
 class Job:
     """One ``update-gtf`` invocation: argv = ["update-gtf", options..., in.bam, old.gtf]."""
 
-    def __init__(self, argv: List[str], open_outputs: bool = True):
+    def __init__(self, argv: List[str], open_outputs: bool = True, rank: int = 0, world: int = 1):
+        """``rank`` / ``world`` > 1: a rank of a one-process-per-GPU run -- for a coordinate-sorted BAM on the partitioned
+        route only the rank's chromosome-aligned shard of the records is loaded (``shard()``)."""
         self.lib = load_library()
         args = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
         rc = C.c_int(0)
         self._argv_keep = args
-        self.h = self.lib.h_job_open2(len(argv), args, C.byref(rc), 1 if open_outputs else 0)
+        if world > 1:
+            self.h = self.lib.h_job_open_rank(len(argv), args, C.byref(rc), 1 if open_outputs else 0, rank, world)
+        else:
+            self.h = self.lib.h_job_open2(len(argv), args, C.byref(rc), 1 if open_outputs else 0)
         self.exit_code = rc.value
         if not self.h:
             raise SystemExit(self.exit_code or 1)
@@ -83,6 +92,12 @@ class Job:
         self.sj = capi.CJunctions()
         self.reads = capi.CReads()
         self.lib.h_job_views(self.h, C.byref(self.prm), C.byref(self.anno), C.byref(self.sj), C.byref(self.reads))
+
+    def shard(self):
+        """(sharded, lo, hi, n_total): with ``sharded`` the read arrays hold the records [lo, hi) of the file only."""
+        lo, hi, n = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        s = self.lib.h_job_shard(self.h, C.byref(lo), C.byref(hi), C.byref(n))
+        return bool(s), int(lo.value), int(hi.value), int(n.value)
 
     # numpy views (zero copy, valid until close())
     def annotation_arrays(self):

@@ -199,6 +199,31 @@ def test_partitioned_route_counts_a_gene_id_that_spans_chromosomes_once(oracle, 
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 5])
+def test_bam_input_is_loaded_shard_by_shard(oracle, tmp_path, inputs, world):
+    # coordinate-sorted BAM on the partitioned route: every rank extracts only its chromosome-aligned shard of the records
+    # (hostlib.Job(rank, world)); 5 ranks over 5 chromosomes, and 2; files = the single-process files
+    d, anno, reads, sam, gtf = inputs
+    bam = str(tmp_path / "r.bam")
+    synth.write_bam(reads, bam)
+    single = {k: str(tmp_path / ("s." + k)) for k in KEYS}
+    multi = {k: str(tmp_path / ("m." + k)) for k in KEYS}
+    assert oracle.run_cli(_args(single, sam, gtf)) == 0
+    _run_ranks(world, _args(multi, bam, gtf), {"L2R_DIST_TRACE": str(tmp_path / "trace"), "L2R_DIST_SHARD_TRACE": str(tmp_path / "shards")})
+    assert open(str(tmp_path / "trace")).read().strip() == "partitioned"
+    for k in KEYS:
+        assert filecmp.cmp(single[k], multi[k], shallow=False), (world, k)
+    # every rank reported a shard of its own: together they cover the file once, cut at chromosome boundaries
+    rows = sorted(tuple(int(x) for x in open(str(tmp_path / ("shards.%d" % r))).read().split()) for r in range(world))
+    assert all(r[3] == reads.n and r[0] == 1 for r in rows)
+    spans = sorted((r[1], r[2]) for r in rows)
+    assert spans[0][0] == 0 and spans[-1][1] == reads.n and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    for lo, hi in spans:
+        assert lo == hi or lo == 0 or reads.tid[lo - 1] != reads.tid[lo]
+    assert sum(1 for lo, hi in spans if hi > lo) >= 2
+
+
+@pytest.mark.timeout(300)
 def test_partitioned_route_to_stdout(oracle, tmp_path, inputs):
     d, anno, reads, sam, gtf = inputs
     a, b = str(tmp_path / "s.gtf"), str(tmp_path / "m.gtf")
