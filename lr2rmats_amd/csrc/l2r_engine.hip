@@ -152,6 +152,7 @@ struct l2r_ctx {
     bool ran = false;
     hipGraphExec_t graph = nullptr;         // the launch sequence of l2r_run, captured once per (inputs, parameters)
     bool graph_valid = false;
+    bool check_stages = false;              // L2R_CHECK
     // slab pipeline: what the last synchronised run of THIS configuration left for the two list kernels (the redo list of
     // k_classify_generic, the wide-tile list of k_probe_slab_wide).  Both counts are functions of the inputs and parameters: once
     // they are known to be zero the two (empty) launches are left out until something changes (drop_graph is that hook).
@@ -216,6 +217,7 @@ l2r_ctx *l2r_create(int device)
         if (e && atoi(e) > 0) c->fast_grid = atoi(e);
         e = getenv("L2R_ABLATE");
         c->ablate = e ? atoi(e) : 0;
+        c->check_stages = getenv("L2R_CHECK") != nullptr;
         e = getenv("L2R_ANNO_CACHE");
         if (e && *e) c->anno_cache_dir = e;
         e = getenv("L2R_PIPELINE");
@@ -930,7 +932,12 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     hipStream_t s = c->stream;
     const unsigned gt = (unsigned)(c->n_tiles ? c->n_tiles : 1), g256 = (unsigned)(c->n_tiles256 ? c->n_tiles256 : 1);
     const int32_t *j0 = c->sorted ? (const int32_t *)c->j0.p : (const int32_t *)c->win_start.p;
-#define MARK(i) do { if (ev) HIP_TRY(hipEventRecord(ev[i], s)); } while (0)
+    // L2R_CHECK=1 (diagnostics): wait for the device at every stage boundary, so that a kernel fault is reported with the stage it
+    // happened in instead of at the next synchronisation of the caller
+    static const char *const stage_name[ST_N + 1] = {"(start)", "pass A / order", "scan / walk", "classification", "generic", "junction check", "accepted scan", "accepted gather"};
+#define MARK(i) do { if (ev) HIP_TRY(hipEventRecord(ev[i], s)); \
+        if (c->check_stages) { const hipError_t e_ = hipStreamSynchronize(s); \
+            if (e_ != hipSuccess) return fail(-2, "[launch_all] device error behind stage \"%s\": %s", stage_name[(i) <= ST_N ? (i) : 0], hipGetErrorString(e_)); } } while (0)
     MARK(ST_PASS_A);
     const CursorDir cd{c->anno_key.p, c->key_dir.p, c->kb_base.p, c->n_tid_key, (int32_t)c->n_tx};
     const SiteTabs tabs{{c->sk_st.p, c->sd_st.p, c->sr_st.p}, {c->sk_en.p, c->sd_en.p, nullptr}, c->tid_base.p, c->n_tid_dir};
