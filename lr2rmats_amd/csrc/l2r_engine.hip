@@ -1285,7 +1285,8 @@ static int read_order_arrays(l2r_ctx *c, const uint32_t **off, const int32_t **x
         }
         if (c->slab && X) {
             // slabs: k_linearize_slab gathers every read's column into its place
-            hipLaunchKernelGGL(k_linearize_slab, dim3(gN), dim3(TILE_THREADS), 0, c->stream, N, (const uint32_t *)c->ex_off.p, (const uint32_t *)c->info.p,
+            hipLaunchKernelGGL(k_linearize_slab, dim3((unsigned)c->n_tiles), dim3(TILE_THREADS), 0, c->stream, (const uint32_t *)c->tile_first.p, (const uint32_t *)c->tile_sbase.p,
+                               (const uint8_t *)c->order.p, (const uint32_t *)c->s_pre.p, (const uint32_t *)c->ex_off.p, (const uint32_t *)c->info.p,
                                (const uint32_t *)c->lin_dest.p, (const int32_t *)c->ex_start.p, (const int32_t *)c->ex_end.p, (const uint8_t *)c->ex_flag.p,
                                c->lin_start.p, c->lin_end.p, c->lin_flag.p, (const uint16_t *)c->ex_len.p);
         } else if (X) {

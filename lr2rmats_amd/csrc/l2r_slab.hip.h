@@ -55,6 +55,15 @@ __device__ __forceinline__ SlabArgsK slab_args()
     return q;
 }
 constexpr int SLAB_TW_VECS = (int)(sizeof(TileWin) / 16);
+// Which 16-byte vectors of a window record carry something for a window of n_win members: the members' two header arrays, their
+// transcript numbers (four per vector), and the descriptor + masks at the end.  Only those travel from k_walk_slab to k_probe_slab.
+__device__ __forceinline__ bool tw_vec_used(int i, uint32_t n_win)
+{
+    if (i < WIN_TX) return (uint32_t)i < n_win;
+    if (i < 2 * WIN_TX) return (uint32_t)(i - WIN_TX) < n_win;
+    if (i < 2 * WIN_TX + WIN_TX / 4) return (uint32_t)(4 * (i - 2 * WIN_TX)) < n_win;
+    return true;
+}
 // Workgroup -> tile.  Workgroups are handed to the 8 XCDs round robin (workgroup b runs on XCD b % 8), each XCD has an L2 of its
 // own: with this mapping an XCD works through ONE contiguous eighth of the tiles, so the dictionary slices of neighbouring
 // tiles (they overlap) are fetched into one L2 instead of all eight.
@@ -154,7 +163,10 @@ __device__ __forceinline__ SlabWalk slab_walk(SlabArgsK sa, FusedArgsK a, uint32
     SlabWalk o;
     o.pre = (n << 8) | (sane ? 0u : I_PRE_INSANE) | (outlier ? I_PRE_DIRECT : 0u);
     o.r = r; o.n = n; o.el = el; o.active = active; o.outlier = outlier;
-    if (active) a->f.ex_off[r] = off;              // (info[r] is written by the probe side: exon count + verdict)
+    // ex_off[r]: a slab read sits at "its tile's slab + its slot", which the kernels behind the classification only need for the
+    // reads they touch -- every read with a junction table or an accepted list (k_validate_sj, k_gather_accepted), else only
+    // the redo list's (written by the probe side when it lists a read) and the densely stored reads (here).
+    if (active && (outlier || a->f.p.n_sj > 0 || (a->f.p.want & WANT_ACCEPTED))) a->f.ex_off[r] = off;
     return o;
 }
 
@@ -209,7 +221,8 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
         }
     }
     if (lane == 0) s_tw.pad[0] = s_wn[0] | (s_wn[1] << 8) | (s_wn[2] << 16) | (s_wn[3] << 24);     // rows each wave of k_probe_slab has to look at
-    for (int i = lane; i < SLAB_TW_VECS; i += WAVE) reinterpret_cast<int4 *>(sa->tw + t)[i] = reinterpret_cast<const int4 *>(&s_tw)[i];
+    {   const uint32_t n_win = (s_tw.d.flags & TD_FAST) ? s_tw.d.n_win : 0u;
+        for (int i = lane; i < SLAB_TW_VECS; i += WAVE) if (tw_vec_used(i, n_win)) reinterpret_cast<int4 *>(sa->tw + t)[i] = reinterpret_cast<const int4 *>(&s_tw)[i]; }
 }
 
 // map_exons (l2r_kernels.hip.h) with the read's exons streamed from its slab column: row k at off + k * 256, the same row
@@ -356,7 +369,7 @@ __device__ __forceinline__ void slab_classify(FusedArgsK a, const TileDesc &d, c
             uint32_t at = 0;
             if (lane == 0) at = atomicAdd(a->f.redo_count, (uint32_t)__popcll(m));
             at = __shfl(at, 0, WAVE);
-            if (redo) a->f.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+            if (redo) { a->f.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r; if (!outlier) a->f.ex_off[r] = off; }      // (see slab_walk)
         }
     }
     if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; }
@@ -393,7 +406,7 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     const uint32_t row_max = max((u_tw[t].pad[0] >> (8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))) & 0xffu, 1u) - 1u;
     const FusedDict dv = fused_load_dict(a, d);
     int4 twv = make_int4(0, 0, 0, 0);
-    if ((int)threadIdx.x < SLAB_TW_VECS) twv = reinterpret_cast<const int4 *>(u_tw + t)[threadIdx.x];
+    if ((int)threadIdx.x < SLAB_TW_VECS && tw_vec_used((int)threadIdx.x, (d.flags & TD_FAST) ? d.n_win : 0u)) twv = reinterpret_cast<const int4 *>(u_tw + t)[threadIdx.x];
     const bool active = threadIdx.x < n_act;
     const uint32_t at = r0 + (active ? threadIdx.x : 0u);
     uint32_t pre = 0u, r = r0;
@@ -437,16 +450,19 @@ void k_exon_counts(int64_t n_reads, const uint32_t *__restrict__ info, uint32_t 
 
 // Slabs -> read order (l2r_download): one thread per read, dest[r] = running sum of the exon counts in read order.
 __global__ __launch_bounds__(TILE_THREADS)
-void k_linearize_slab(int64_t n_reads, const uint32_t *__restrict__ ex_off, const uint32_t *__restrict__ info, const uint32_t *__restrict__ dest,
+void k_linearize_slab(const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_sbase, const uint8_t *__restrict__ order,
+                      const uint32_t *__restrict__ pre, const uint32_t *__restrict__ ex_off, const uint32_t *__restrict__ info, const uint32_t *__restrict__ dest,
                       const int32_t *__restrict__ xs, const int32_t *__restrict__ xe, const uint8_t *__restrict__ xf,
                       int32_t *__restrict__ os, int32_t *__restrict__ oe, uint8_t *__restrict__ of, const uint16_t *__restrict__ xl)
 {
-    const int64_t r = (int64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
-    if (r >= n_reads) return;
-    uint32_t off = ex_off[r];
+    // one workgroup per tile, one thread per slot: a slab read sits at its tile's slab + its slot, a densely stored one at ex_off
+    const uint32_t t = blockIdx.x, r0 = tile_first[t], n_act = tile_first[t + 1u] - r0;
+    if (threadIdx.x >= n_act) return;
+    const uint32_t at = r0 + threadIdx.x, r = r0 + order[at];
+    const bool dense = (pre[at] & I_PRE_DIRECT) != 0u;
+    uint32_t off = dense ? ex_off[r] & ~EXOFF_DENSE : tile_sbase[t] + threadIdx.x;
     const uint32_t n = info[r] >> 8, to = dest[r];
-    const uint32_t st = (off & EXOFF_DENSE) ? 1u : SLAB_STRIDE;
-    off &= ~EXOFF_DENSE;
+    const uint32_t st = dense ? 1u : SLAB_STRIDE;
     for (uint32_t k = 0; k < n; ++k) { os[to + k] = xs[off + k * st]; oe[to + k] = ex_end_at(xs, xe, xl, off + k * st, st); of[to + k] = xf[off + k * st]; }
 }
 

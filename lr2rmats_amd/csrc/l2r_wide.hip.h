@@ -308,7 +308,7 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
                 uint32_t pos_r = 0;
                 if (lane == 0) pos_r = atomicAdd(a->f.redo_count, (uint32_t)__popcll(m));
                 pos_r = __shfl(pos_r, 0, WAVE);
-                if (redo) a->f.redo[pos_r + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+                if (redo) { a->f.redo[pos_r + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r; if (!outlier) a->f.ex_off[r] = off; }   // (see slab_walk)
             }
         }
         if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; }
