@@ -800,23 +800,25 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
                         const int e = E[q], s2 = S[q + 1];
                         r_in += (e >= lo && e <= hi) + (s2 >= lo && s2 <= hi);
                     }
-                    for (int k = lane; k < m; k += WAVE) {                 // annotation exon k and its successor
+                    // one lane per (annotation exon k, read exon q) pair: m x n pairs over the 64 lanes (a lane per annotation
+                    // exon looping over the read's exons kept 9 lanes of 64 busy for a typical transcript)
+                    const int pairs = m * n;
+                    for (int idx = lane; idx < pairs; idx += WAVE) {
+                        const int k = idx / n, q = idx - k * n;
                         const bool has_next = k + 1 < m;
                         const int2 cur = ax[k], nxt = has_next ? ax[k + 1] : cur;
                         const bool don_in = has_next && cur.y >= lo && cur.y <= hi;
                         const bool acc_in = has_next && nxt.x >= lo && nxt.x <= hi;
-                        for (int q = 0; q < n; ++q) {
-                            const int sq = S[q], eq = E[q];
-                            const bool end_eq = near_eq(cur.y, eq, dis);
-                            uint32_t clr = 0;
-                            if (end_eq && near_eq(cur.x, sq, dis)) clr |= F_EXON;
-                            if (has_next && q + 1 < n) {
-                                if (don_in && end_eq) { ++same; clr |= F_DON; }
-                                if (acc_in && near_eq(nxt.x, sq, dis)) { ++same; clr |= F_ACC; }        // Q1: read exon q's own start
-                                if (end_eq && near_eq(nxt.x, S[q + 1], dis)) clr |= F_JUNC;
-                            }
-                            if (clr) atomicAnd(&F[q], ~clr);
+                        const int sq = S[q], eq = E[q];
+                        const bool end_eq = near_eq(cur.y, eq, dis);
+                        uint32_t clr = 0;
+                        if (end_eq && near_eq(cur.x, sq, dis)) clr |= F_EXON;
+                        if (has_next && q + 1 < n) {
+                            if (don_in && end_eq) { ++same; clr |= F_DON; }
+                            if (acc_in && near_eq(nxt.x, sq, dis)) { ++same; clr |= F_ACC; }        // Q1: read exon q's own start
+                            if (end_eq && near_eq(nxt.x, S[q + 1], dis)) clr |= F_JUNC;
                         }
+                        if (clr) atomicAnd(&F[q], ~clr);
                     }
                     // the two counters of check_splice_site are sums over the wave: LDS atomics instead of a shuffle tree
                     // (two dependent six-step ds_bpermute chains per candidate transcript otherwise)
