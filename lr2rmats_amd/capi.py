@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libl2r_hip.so")
+LIB_PATH = os.environ.get("L2R_HIP_LIB") or os.path.join(HERE, "lib", "libl2r_hip.so")      # (L2R_HIP_LIB: diagnostics, tools/ab.py compares builds)
 
 INFO_KNOWN, INFO_KNOWN_SITE, INFO_FULL, INFO_REV, INFO_UNREL, INFO_SJ_CHECKED, INFO_SJ_PASS, INFO_ACCEPTED = \
     1, 2, 4, 8, 16, 32, 64, 128
@@ -274,7 +274,7 @@ class Engine:
         self._chk(self.lib.l2r_run_timed(self.ctx, iters, C.byref(t)))
         return {"total_ms": float(t.total_ms), "iters": int(t.iters),
                 "stage_ms": {STAGE_NAMES[i]: float(t.stage_ms[i]) for i in range(N_STAGES - 1)},
-                # the kernel behind every stage for the pipeline the engine chose for these records (slab / fused / classic)
+                # the kernel behind every stage for the pipeline the engine chose for these records (slab / classic)
                 "kernel_ms": {(self.lib.l2r_stage_kernel(self.ctx, i) or b"").decode(): float(t.stage_ms[i])
                               for i in range(N_STAGES - 1) if self.lib.l2r_stage_kernel(self.ctx, i)}}
 

@@ -17,7 +17,7 @@
 
 #include "../../include/lr2rmats_hip.h"
 #include "l2r_kernels.hip.h"
-#include "l2r_fused.hip.h"
+#include "l2r_window.hip.h"
 #include "l2r_slab.hip.h"
 #include "l2r_wide.hip.h"
 #include "l2r_filter.hip.h"
@@ -67,27 +67,17 @@ struct l2r_ctx {
     bool wide_cigar = false;                // long CIGARs: the HBM walks fetch 16 words per lane and round (l2r_upload_reads decides)
     int n_cu = 256, wg_per_cu = 4;          // persistent grid of k_classify_fast (L2R_WG_PER_CU overrides)
     int ablate = 0;                         // diagnostics, L2R_ABLATE (read once, at l2r_create)
-    int want_pipeline = 2;                  // L2R_PIPELINE: classic (0: two walks), fused (1: l2r_fused.hip.h), slab (2, default: l2r_slab.hip.h)
-    bool fused = false;                     // the current upload runs a one-walk pipeline: sorted input, short CIGARs
-    bool slab_ok = false;                   // ... and its slab layout fits (l2r_slab.hip.h); slab = the last launch used it
-    bool slab = false;
-    DevBuf<uint32_t> tile_sbase, lin_dest, s_clo, s_pre;
-    DevBuf<uint16_t> s_ncig;
-    DevBuf<int32_t> s_pos;
-    DevBuf<uint8_t> s_rev;
+    int want_pipeline = 1;                  // L2R_PIPELINE: classic (0: l2r_kernels.hip.h, two walks), slab (1, default: l2r_slab.hip.h, one walk)
+    bool slab_ok = false;                   // the current upload can run the slab pipeline: coordinate-sorted records, short CIGARs, its slab layout fits
+    bool slab = false;                      // ... and the last launch did (the parameters have a say: launch_all)
+    DevBuf<uint32_t> tile_sbase, s_pre, s_loc, tile_total;
+    DevBuf<int32_t> slab_start, dense_start, dense_end;     // slab pipeline: the exon rows between its kernels, the outliers' dense area
+    DevBuf<uint16_t> slab_len;
     DevBuf<TileWin> tw;
-    DevBuf<uint16_t> ex_len;                // slab pipeline: 16-bit lengths of the slab rows' exons (the rows hold no ends)
     DevBuf<TileWin64> tw64; DevBuf<uint32_t> wide_cnt, wide_tile; uint32_t wide_cap = 0;     // tiles with 33 .. 64 window members (l2r_wide.hip.h)
     DevBuf<unsigned long long> ovf_cursor;
-    uint32_t ovf_base = 0;
     std::string anno_cache_dir;             // L2R_ANNO_CACHE / l2r_set_annotation_cache: where the annotation tables are kept between runs
     int anno_cache_state = 0;               // last l2r_set_annotation: 0 no cache, 1 built + stored, 2 read from the cache
-    bool lin_valid = false;                 // lin_* hold the read-order exon arrays of the last run (read_order_arrays)
-    bool slab_ordered = false;              // k_order has run for this upload (slab pipeline: its outputs depend on the records only)
-    DevBuf<uint16_t> lub;                   // k_order: first LDS slot of every read
-    DevBuf<uint32_t> tile_ub, tile_start, tile_total, tile_dest;
-    DevBuf<int32_t> lin_start, lin_end;     // l2r_download of a fused run: the exon arrays in read order (k_linearize)
-    DevBuf<uint8_t> lin_flag;
     unsigned want = L2R_WANT_RESULTS | L2R_WANT_ACCEPTED;      // l2r_set_outputs
     hipStream_t stream = nullptr;
     l2r_params prm;
@@ -153,10 +143,6 @@ struct l2r_ctx {
     hipGraphExec_t graph = nullptr;         // the launch sequence of l2r_run, captured once per (inputs, parameters)
     bool graph_valid = false;
     bool check_stages = false;              // L2R_CHECK
-    // slab pipeline: what the last synchronised run of THIS configuration left for the two list kernels (the redo list of
-    // k_classify_generic, the wide-tile list of k_probe_slab_wide).  Both counts are functions of the inputs and parameters: once
-    // they are known to be zero the two (empty) launches are left out until something changes (drop_graph is that hook).
-    bool tail_known = false; uint32_t tail_redo = 0, tail_wide = 0;
     DevBuf<unsigned long long> stamps;      // diagnostics, L2R_STAMPS=1
     uint32_t h_totals[3] = {0, 0, 0};
     bool totals_valid = false;
@@ -164,7 +150,6 @@ struct l2r_ctx {
 
 static void drop_graph(l2r_ctx *c)
 {
-    c->tail_known = false;
     if (c->graph) { (void)hipGraphExecDestroy(c->graph); c->graph = nullptr; }
     c->graph_valid = false;
 }
@@ -221,7 +206,7 @@ l2r_ctx *l2r_create(int device)
         e = getenv("L2R_ANNO_CACHE");
         if (e && *e) c->anno_cache_dir = e;
         e = getenv("L2R_PIPELINE");
-        if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : !strcmp(e, "fused") ? 1 : 2;
+        if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : 1;
     }
     return c;
 }
@@ -238,10 +223,8 @@ void l2r_destroy(l2r_ctx *c)
     c->win_start.release(); c->sj_cursor.release();
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
-    c->lub.release(); c->tile_ub.release(); c->tile_start.release(); c->tile_total.release(); c->tile_dest.release();
-    c->lin_start.release(); c->lin_end.release(); c->lin_flag.release();
-    c->tile_sbase.release(); c->lin_dest.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_cnt.release(); c->wide_tile.release(); c->ex_len.release();
-    c->s_clo.release(); c->s_pre.release(); c->s_ncig.release(); c->s_pos.release(); c->s_rev.release(); c->tw.release();
+    c->tile_total.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_cnt.release(); c->wide_tile.release();
+    c->slab_start.release(); c->slab_len.release(); c->dense_start.release(); c->dense_end.release(); c->s_pre.release(); c->s_loc.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -752,9 +735,15 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     // not on the chromosome of their tile's first read take the generic kernel).
     std::vector<uint32_t> tile_first;
     tile_first.reserve((size_t)(N / rpt + 64));
+    // (slab pipeline: a tile's exons are staged by position in LDS on their way out, l2r_slab.hip.h SLAB_POS_CAP: a tile also ends
+    //  where the exon bounds of its reads -- from the CIGAR lengths -- would exceed that, so no read of it is left outside)
+    const bool slab_tiles = c->want_pipeline > 0 && sorted && !c->wide_cigar;
+    uint64_t pos_sum = 0;
     for (int64_t i = 0, start = 0; i <= N; ++i) {
         if (i == N) { if (i > start) tile_first.push_back((uint32_t)start); break; }
-        if (i - start == rpt || (sorted && r->tid[i] != r->tid[start])) { tile_first.push_back((uint32_t)start); start = i; }
+        const uint64_t need = slab_tiles ? (uint64_t)slab_rows_of((uint32_t)std::min<int64_t>(r->cig_off[i + 1] - r->cig_off[i], 0x7ffffff0)) : 0u;
+        if (i - start == rpt || (sorted && r->tid[i] != r->tid[start]) || (i > start && pos_sum + need > (uint64_t)SLAB_POS_CAP)) { tile_first.push_back((uint32_t)start); start = i; pos_sum = 0; }
+        pos_sum += need;
     }
     c->n_tiles = (int64_t)tile_first.size();
     tile_first.push_back((uint32_t)N);
@@ -794,13 +783,12 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
         c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb) || (c->wide_cigar && c->walked.ensure((size_t)(c->n_tiles + 1) * LDS_EXON_CAP))) return -2;
     c->ex_cap = (int64_t)exb;
-    c->fused = c->want_pipeline > 0 && sorted && !c->wide_cigar;
-    c->slab_ok = false; c->slab = false; c->slab_ordered = false;
-    if (c->fused && c->want_pipeline == 2) {
+    c->slab_ok = false; c->slab = false;
+    if (c->want_pipeline > 0 && sorted && !c->wide_cigar) {
         // the slab layout (l2r_slab.hip.h): per tile as many rows of 256 elements as its longest read can have exons (bound from
-        // the CIGAR lengths); reads beyond SLAB_ROWS rows are outliers and get a run of the dense area behind the slabs
+        // the CIGAR lengths); reads beyond SLAB_ROWS rows are outliers and get a run of the dense area
         const size_t T = (size_t)c->n_tiles;
-        std::vector<uint32_t> rows(T + 1, 1u), sbase(T + 1, 0u);
+        std::vector<uint32_t> sbase(T + 1, 0u);
         uint64_t total = 0, ovf = 0;
         for (size_t t = 0; t < T; ++t) {
             uint32_t m = 1;
@@ -812,25 +800,24 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
                 ovf += cc + 1;
                 if (rw <= (uint64_t)SLAB_ROWS) m = std::max<uint32_t>(m, (uint32_t)rw);
             }
-            rows[t] = m; sbase[t] = (uint32_t)total; total += (uint64_t)m * SLAB_STRIDE;
-            if (total + ovf >= 0x7ffffff0ULL) break;
+            sbase[t] = (uint32_t)total; total += (uint64_t)m * SLAB_STRIDE;
+            if (total >= 0x7ffffff0ULL || ovf >= 0x7ffffff0ULL) break;
         }
-        if (total + ovf < 0x7ffffff0ULL) {
-            sbase[T] = (uint32_t)total;                     // (k_probe_slab: rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
-            c->slab_ok = true; c->ovf_base = (uint32_t)total;
+        if (total < 0x7ffffff0ULL && ovf < 0x7ffffff0ULL) {
+            sbase[T] = (uint32_t)total;                     // (rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
+            c->slab_ok = true;
             c->wide_cap = (uint32_t)T;                      // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB per tile)
             if (c->tw64.ensure(c->wide_cap) || c->wide_cnt.ensure(2) || c->wide_tile.ensure(c->wide_cap)) return -2;
             HIP_TRY(hipMemsetAsync(c->wide_cnt.p, 0, 8, c->stream));
-            if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) ||
-                c->s_clo.ensure((size_t)N + 1) || c->s_pre.ensure((size_t)N + 1) || c->s_ncig.ensure((size_t)N + 1) || c->s_pos.ensure((size_t)N + 1) || c->s_rev.ensure((size_t)N + 1) ||
-                c->ex_start.ensure(std::max<size_t>(exb, total + ovf)) || c->ex_end.ensure(std::max<size_t>(exb, total + ovf)) ||
-                c->ex_flag.ensure(std::max<size_t>(exb, total + ovf)) || c->ex_len.ensure((size_t)total + 1)) return -2;
+            if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) || c->tile_total.ensure(T + 2) ||
+                c->s_pre.ensure((size_t)N + 1) || c->s_loc.ensure((size_t)N + 1) ||
+                c->slab_start.ensure((size_t)total + 4) || c->slab_len.ensure((size_t)total + 4) ||       // (+ 4: the length of the last element is read as a 4-byte word)
+                c->dense_start.ensure((size_t)ovf + 1) || c->dense_end.ensure((size_t)ovf + 1)) return -2;
+            HIP_TRY(hipMemsetAsync(c->ovf_cursor.p, 0, 8, c->stream));
             HIP_TRY(hipMemcpyAsync(c->tile_sbase.p, sbase.data(), (T + 1) * 4, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));       // (locals)
         }
     }
-    if (c->fused && (c->lub.ensure((size_t)N + 1) || c->tile_ub.ensure((size_t)c->n_tiles + 1) || c->tile_start.ensure((size_t)c->n_tiles + 1) ||
-                     c->tile_total.ensure((size_t)c->n_tiles + 1) || c->tile_dest.ensure((size_t)c->n_tiles + 1))) return -2;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (getenv("L2R_STAMPS") && !c->stamps.p) {
         if (c->stamps.ensure(1024 * 8 + 16)) return -2;
@@ -838,7 +825,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     c->n_reads = N; c->n_cigar = r->n_cigar; c->first_read = r->first_read_index;
-    c->ran = false; c->totals_valid = false; c->lin_valid = false; drop_graph(c);
+    c->ran = false; c->totals_valid = false; drop_graph(c);
     if (sorted) {
         // the annotation cursor after a sorted prefix is the prefix function of its last record
         if (N) {
@@ -946,7 +933,6 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     fa.walked = c->walked.p; fa.local = c->local.p; fa.order = c->order.p; fa.tile_base = c->tile_base.p; fa.j0 = j0; fa.desc = c->desc.p; fa.win_hdr = c->win_hdr.p;
     fa.hdr = c->hdr.p; fa.st = tabs.st; fa.en = tabs.en;
     fa.ex_off = c->ex_off.p; fa.ex_start = c->ex_start.p; fa.ex_end = c->ex_end.p; fa.ex_flag = c->ex_flag.p; fa.info = c->info.p; fa.ref_tx = c->ref_tx.p;
-    fa.ex_len = nullptr;                                   // (set where the slab pipeline is chosen)
     fa.tile_acc = c->tile_acc.p; fa.tile_acc_ex = c->tile_acc_ex.p; fa.redo_count = c->totals.p + 3; fa.redo = c->redo.p;
     fa.tile_chunk = c->tile_chunk.p; fa.tile_rchunk = c->tile_rchunk.p; fa.chunk_cursor = (unsigned long long *)(c->totals.p + 4);
     fa.acc_start = c->acc_start.p; fa.acc_end = c->acc_end.p; fa.acc_flag = c->acc_flag.p; fa.acc_rec = (AccRec *)c->acc_rec.p; fa.acc_ex_off = c->acc_ex_off.p; fa.first_read = c->first_read;
@@ -954,84 +940,57 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     // persistent grid: a few workgroups per CU walk over the tiles (l2r_kernels.hip.h)
     unsigned gp = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * c->wg_per_cu);
     if (c->fast_grid > 0) gp = (unsigned)std::min<int64_t>(gp, c->fast_grid);           // L2R_FAST_GRID: tests force many tiles per workgroup
-    if (c->fused) {
-        // ---- the one-walk pipeline (l2r_fused.hip.h): k_order, then the persistent k_fused
-        unsigned long long *const ex_cursor = (unsigned long long *)(c->totals.p + 6);
-        // the slab form wants the straight-line walk: min_exon >= 1 and thresholds that fit a CIGAR word (else: k_fused)
-        c->slab = c->slab_ok && p.min_exon >= 1 && p.min_intron >= 0 && p.min_intron < (1 << 28) && p.max_delet >= -1 && p.max_delet < (1 << 28) - 1;
-        if (c->slab) {
-            // the lane order of a tile and the slot-ordered record fields are a LAYOUT of the input (nothing of them depends on
-            // the parameters): made once per upload; a run only clears its counters
-            if (!c->slab_ordered) {
-                hipLaunchKernelGGL(k_order, dim3(gt), dim3(TILE_THREADS), 0, s, (const int64_t *)c->cig_off.p, (const uint32_t *)c->tile_first.p, p,
-                                   c->order.p, c->lub.p, c->tile_ub.p, c->totals.p + 3, ex_cursor, (int32_t *)nullptr, c->ovf_cursor.p, c->tile_total.p,
-                                   (const int32_t *)c->r_pos.p, (const uint8_t *)c->r_rev.p, c->s_clo.p, c->s_ncig.p, c->s_pos.p, c->s_rev.p);
-                c->slab_ordered = true;
-            }
-            // (the run's counters are cleared by the kernels themselves: l2r_slab.hip.h)
-        } else
-        hipLaunchKernelGGL(k_order, dim3(gt), dim3(TILE_THREADS), 0, s, (const int64_t *)c->cig_off.p, (const uint32_t *)c->tile_first.p, p,
-                           c->order.p, c->lub.p, c->tile_ub.p, c->totals.p + 3, ex_cursor, (int32_t *)nullptr, (unsigned long long *)nullptr,
-                           (uint32_t *)nullptr, (const int32_t *)c->r_pos.p, (const uint8_t *)c->r_rev.p,
-                           (uint32_t *)nullptr, c->s_ncig.p, c->s_pos.p, c->s_rev.p);
-        MARK(ST_SCAN1);
-        FusedArgs ga;
-        ga.f = fa; ga.cd = cd; ga.tid_base = c->tid_base.p; ga.n_tid_dir = c->n_tid_dir; ga.lub = c->lub.p; ga.tile_ub = c->tile_ub.p;
-        ga.tile_start = c->tile_start.p; ga.tile_total = c->tile_total.p; ga.ex_cursor = ex_cursor;
-        if (c->slab) {
-            // ---- two light kernels at high occupancy: the walk (exons into the tiles' slabs), then the probes (l2r_slab.hip.h)
-            SlabArgs sa; sa.g = ga; sa.tile_sbase = c->tile_sbase.p; sa.ovf_cursor = c->ovf_cursor.p; sa.ovf_base = c->ovf_base;
-            sa.s_clo = c->s_clo.p; sa.s_ncig = c->s_ncig.p; sa.s_pos = c->s_pos.p; sa.s_rev = c->s_rev.p; sa.pre = c->s_pre.p; sa.tw = c->tw.p;
-            sa.g.f.ex_len = c->ex_len.p;
-            sa.n_tiles = (uint32_t)c->n_tiles;
-            const unsigned gx = 8u * (unsigned)std::max<int64_t>((c->n_tiles + 7) / 8, 1);      // (l2r_slab.hip.h xcd_tile; an empty upload still launches)
-            sa.wide_cnt = c->wide_cnt.p; sa.wide_tile = c->wide_tile.p; sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p; sa.wide_cap = c->wide_cap;      // (L2R_ABLATE bit 2: no 64-member windows)
-            hipLaunchKernelGGL(k_walk_slab, dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, (const uint8_t *)c->order.p,
+    // the slab pipeline wants the straight-line walk: thresholds that fit a CIGAR word (else: the classic kernels)
+    c->slab = c->slab_ok && p.min_intron >= 0 && p.min_intron < (1 << 28) && p.max_delet >= -1 && p.max_delet < (1 << 28) - 1;
+    if (c->slab) {
+        // ---- two light kernels at full occupancy: the walk (exons into the tiles' slabs, read-order places, descriptors), a scan of
+        //      the tiles' exon counts, then the probes, which write the read-order results (l2r_slab.hip.h).  Every launch does all
+        //      of it: nothing is kept from an earlier run of the same upload.
+        SlabArgs sa;
+        sa.g.f = fa; sa.g.cd = cd; sa.g.tid_base = c->tid_base.p; sa.g.n_tid_dir = c->n_tid_dir; sa.g.tile_total = c->tile_total.p;
+        sa.tile_sbase = c->tile_sbase.p; sa.slab_start = c->slab_start.p; sa.slab_len = c->slab_len.p;
+        sa.dense_start = c->dense_start.p; sa.dense_end = c->dense_end.p; sa.ovf_cursor = c->ovf_cursor.p;
+        sa.pre = c->s_pre.p; sa.loc = c->s_loc.p; sa.tw = c->tw.p;
+        sa.n_tiles = (uint32_t)c->n_tiles;
+        const unsigned gx = 8u * (unsigned)std::max<int64_t>((c->n_tiles + 7) / 8, 1);      // (l2r_slab.hip.h xcd_tile; an empty upload still launches)
+        sa.wide_cnt = c->wide_cnt.p; sa.wide_tile = c->wide_tile.p; sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p; sa.wide_cap = c->wide_cap;      // (L2R_ABLATE bit 2: no 64-member windows)
+        if (p.min_exon >= 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_slab<false>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p,
                                (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
-            MARK(ST_FAST);
-            // (tried: the run cut into chunks of tiles, the probes of chunk i on a second stream beside the walk of chunk i + 1 --
-            //  no gain, 0.71 -> 0.72 .. 0.82 ms with 2 .. 16 chunks; both halves in one persistent, software-pipelined kernel
-            //  with the exons read back out of L2 -- 0.86 ms and 4.2 GB of traffic (spills): DESIGN.md section 8)
-#define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
-                (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p)
-            switch (p.full_level) {
-            case 1: launch_probe_level(1); break;
-            case 2: launch_probe_level(2); break;
-            case 3: launch_probe_level(3); break;
-            case 4: launch_probe_level(4); break;
-            case 5: launch_probe_level(5); break;
-            default: launch_probe_level(0); break;
-            }
-#undef launch_probe_level
-            if (!(c->tail_known && c->tail_wide == 0u))
-            {   // the tiles with 33 .. 64 window members (none on most inputs: the grid finds an empty list and leaves)
-                const WideArgs wa{c->wide_cnt.p + 1, c->wide_tile.p, c->tw64.p};
-                const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 6);
-#define launch_wide_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_wide<L>), dim3(gw), dim3(TILE_THREADS), 0, s, sa, wa, (const uint32_t *)c->tile_first.p, \
-                    (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const uint32_t *)c->tile_sbase.p)
-                switch (p.full_level) {
-                case 1: launch_wide_level(1); break;
-                case 2: launch_wide_level(2); break;
-                case 3: launch_wide_level(3); break;
-                case 4: launch_wide_level(4); break;
-                case 5: launch_wide_level(5); break;
-                default: launch_wide_level(0); break;
-                }
-#undef launch_wide_level
-            }
-        } else {
-        MARK(ST_FAST);
-#define launch_fused_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused<L>), dim3(gp), dim3(TILE_THREADS), 0, s, ga, c->n_tiles, (const uint32_t *)c->tile_first.p, \
-            (const uint8_t *)c->order.p, (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_ub.p)
-        switch (p.full_level) {
-        case 1: launch_fused_level(1); break;
-        case 2: launch_fused_level(2); break;
-        case 3: launch_fused_level(3); break;
-        case 4: launch_fused_level(4); break;
-        case 5: launch_fused_level(5); break;
-        default: launch_fused_level(0); break;
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_slab<true>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p,
+                               (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
+        MARK(ST_SCAN1);
+        {   // the tiles' exon counts -> their first slots in the read-order result arrays (in place; the sum = the exon count)
+            ScanJobs jobs; jobs.job[0] = ScanJob{c->tile_total.p, c->n_tiles, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
+            hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, jobs);
         }
-#undef launch_fused_level
+        MARK(ST_FAST);
+#define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
+            (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_total.p)
+        switch (p.full_level) {
+        case 1: launch_probe_level(1); break;
+        case 2: launch_probe_level(2); break;
+        case 3: launch_probe_level(3); break;
+        case 4: launch_probe_level(4); break;
+        case 5: launch_probe_level(5); break;
+        default: launch_probe_level(0); break;
+        }
+#undef launch_probe_level
+        {   // the tiles with 33 .. 64 window members (none on most inputs: the grid finds an empty list and leaves)
+            const WideArgs wa{c->wide_cnt.p + 1, c->wide_tile.p, c->tw64.p};
+            const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 6);
+#define launch_wide_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_wide<L>), dim3(gw), dim3(TILE_THREADS), 0, s, sa, wa, (const uint32_t *)c->tile_first.p, \
+                (const uint32_t *)c->tile_sbase.p, (const uint32_t *)c->tile_total.p)
+            switch (p.full_level) {
+            case 1: launch_wide_level(1); break;
+            case 2: launch_wide_level(2); break;
+            case 3: launch_wide_level(3); break;
+            case 4: launch_wide_level(4); break;
+            case 5: launch_wide_level(5); break;
+            default: launch_wide_level(0); break;
+            }
+#undef launch_wide_level
         }
         // every tile's accepted reads are compacted by k_gather_accepted (nothing is fused into the classification here)
         if (c->want & L2R_WANT_ACCEPTED) HIP_TRY(hipMemsetAsync(c->tile_chunk.p, 0xff, (size_t)(c->n_tiles + 1) * 4, s));
@@ -1062,27 +1021,23 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         }
     }
     }
-    const bool slab_now = c->fused && c->slab;
-    const uint32_t ex_stride = slab_now ? SLAB_STRIDE : 1u;
-    const uint16_t *const ex_len = slab_now ? (const uint16_t *)c->ex_len.p : (const uint16_t *)nullptr;
     MARK(ST_GENERIC);
-    if (!(slab_now && c->tail_known && c->tail_redo == 0u))     // (a redo list known to be empty for these inputs and parameters)
     {
         const unsigned gg = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles * 4 : 1, 4096);      // one wave per listed read, grid-stride
         hipLaunchKernelGGL(k_classify_generic, dim3(gg), dim3(TILE_THREADS), 0, s, c->totals.p + 3, c->redo.p, c->r_tid.p, c->r_rev.p,
-                           (c->fused ? (const int32_t *)nullptr : j0),
+                           (c->slab ? (const int32_t *)nullptr : j0),
                            c->hdr.p, c->anno_ex.p, p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->info.p, c->ref_tx.p,
-                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles, cd, ex_stride, ex_len);
+                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles, cd);
     }
     MARK(ST_SJ);
     if (c->n_sj > 0) {
         if (!c->sorted) { int rc = prepare_unsorted_sj_cursor(c); if (rc) return rc; }
         hipLaunchKernelGGL(k_validate_sj, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p,
                            c->sj_key.p, (c->sorted ? (const int32_t *)nullptr : c->sj_cursor.p), c->sj_tid.p, c->sj_don.p, c->sj_acc.p,
-                           c->sj_uniq.p, c->sj_multi.p, p, c->info.p, ex_stride, ex_len);
+                           c->sj_uniq.p, c->sj_multi.p, p, c->info.p);
     }
-    if ((c->n_sj > 0 || c->fused) && (c->want & L2R_WANT_ACCEPTED)) {
-        // acceptance is decided by the junction check (and the one-walk pipeline counts nothing itself): count per tile
+    if ((c->n_sj > 0 || c->slab) && (c->want & L2R_WANT_ACCEPTED)) {
+        // acceptance is decided by the junction check (and the slab pipeline counts nothing itself): count per tile
             hipLaunchKernelGGL(k_count_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->info.p, c->tile_acc.p, c->tile_acc_ex.p);
     }
     MARK(ST_SCAN2);
@@ -1094,8 +1049,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     if (c->want & L2R_WANT_ACCEPTED)
     hipLaunchKernelGGL(k_gather_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->first_read, c->info.p, c->ref_tx.p, c->ex_off.p,
                        c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->tile_acc.p, c->tile_acc_ex.p, c->tile_chunk.p, c->tile_rchunk.p, c->totals.p + 4,
-                       c->acc_rec.p, c->acc_ex_off.p, c->acc_start.p, c->acc_end.p, c->acc_flag.p,
-                       (slab_now ? (const uint32_t *)c->tile_sbase.p : (const uint32_t *)nullptr), ex_stride, ex_len);
+                       c->acc_rec.p, c->acc_ex_off.p, c->acc_start.p, c->acc_end.p, c->acc_flag.p);
     MARK(ST_N);
 #undef MARK
     HIP_TRY(hipGetLastError());
@@ -1137,7 +1091,7 @@ int l2r_debug_counters(l2r_ctx *c, long long *out, int n)
         HIP_TRY(hipMemcpyAsync(w.data(), c->tw.p, w.size() * sizeof(TileWin), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         for (const TileWin &t : w) out[4 + ((t.d.flags >> 8) & 7u)]++;
-    } else if (n >= 12 && !c->fused && c->desc.p && c->n_tiles > 0) {     // out[4 + k]: tiles that are not fast for reason k (k_pass_a), k = 0: fast
+    } else if (n >= 12 && !c->slab && c->desc.p && c->n_tiles > 0) {     // out[4 + k]: tiles that are not fast for reason k (k_pass_a), k = 0: fast
         std::vector<TileDesc> d((size_t)c->n_tiles);
         HIP_TRY(hipMemcpyAsync(d.data(), c->desc.p, d.size() * sizeof(TileDesc), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1147,15 +1101,14 @@ int l2r_debug_counters(l2r_ctx *c, long long *out, int n)
 }
 
 /* Which kernel(s) stand behind stage_ms[stage] of l2r_timing for the inputs and parameters now set (the pipeline is
-   chosen per upload: slab / fused for coordinate-sorted records with short CIGARs, classic otherwise). */
+   chosen per launch: slab for coordinate-sorted records with short CIGARs, classic otherwise). */
 const char *l2r_stage_kernel(l2r_ctx *c, int stage)
 {
     if (!c || stage < 0 || stage >= L2R_N_STAGES) return "";
     static const char *const classic[L2R_N_STAGES] = {"k_pass_a", "k_scan_tiles", "k_classify_fast", "k_classify_generic",
                                                       "k_validate_sj", "k_scan_accepted", "k_gather_accepted", ""};
-    if (stage >= 3 || !c->fused) return classic[stage];
-    if (c->slab) return stage == 0 ? "k_order (first run of an upload only)" : stage == 1 ? "k_walk_slab" : "k_probe_slab";
-    return stage == 0 ? "k_order" : stage == 1 ? "" : "k_fused";
+    if (stage >= 3 || !c->slab) return classic[stage];
+    return stage == 0 ? "k_walk_slab" : stage == 1 ? "k_scan_tiles" : "k_probe_slab";
 }
 
 int l2r_run(l2r_ctx *c)
@@ -1181,7 +1134,7 @@ int l2r_run(l2r_ctx *c)
     }
     if (graphable && c->graph_valid) HIP_TRY(hipGraphLaunch(c->graph, c->stream));
     else { rc = launch_all(c, nullptr); if (rc) return rc; }
-    c->ran = true; c->totals_valid = false; c->lin_valid = false;
+    c->ran = true; c->totals_valid = false;
     return 0;
 }
 
@@ -1190,13 +1143,6 @@ int l2r_sync(l2r_ctx *c)
     if (!c) return fail(-1, "[l2r_sync] null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->ran && c->fused && c->slab && !c->tail_known && c->wide_cnt.p) {
-        uint32_t redo = 0, wide = 0;
-        HIP_TRY(hipMemcpyAsync(&redo, c->totals.p + 3, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&wide, c->wide_cnt.p + 1, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->tail_redo = redo; c->tail_wide = wide; c->tail_known = true;
-    }
     return 0;
 }
 
@@ -1207,15 +1153,6 @@ static int fetch_totals(l2r_ctx *c)
     uint32_t dev[8];
     HIP_TRY(hipMemcpyAsync(dev, c->totals.p, sizeof dev, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->fused) dev[0] = dev[6];                       // the one-walk pipeline's exon cursor (a shard has < 2^32 exons)
-    if (c->fused && c->slab) {                           // the slab pipeline counts per tile
-        std::vector<uint32_t> tot((size_t)c->n_tiles);
-        if (c->n_tiles) HIP_TRY(hipMemcpyAsync(tot.data(), c->tile_total.p, (size_t)c->n_tiles * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        uint64_t sum = 0;
-        for (uint32_t v : tot) sum += v;
-        dev[0] = (uint32_t)sum;
-    }
     // accepted exons = the chunks the classification kernel placed itself (cursor) + the ones k_gather_accepted placed
     c->h_totals[0] = dev[0]; c->h_totals[1] = dev[1] + dev[5]; c->h_totals[2] = dev[2] + dev[4];
     if (!(c->want & L2R_WANT_ACCEPTED)) c->h_totals[1] = c->h_totals[2] = 0;
@@ -1251,7 +1188,7 @@ int l2r_run_timed(l2r_ctx *c, int iters, l2r_timing *out)
         for (int i = 0; i < ST_N; ++i) { float d = 0; HIP_TRY(hipEventElapsedTime(&d, ev[i], ev[i + 1])); out->stage_ms[i] += d / (float)iters; }
     }
     out->iters = iters;
-    c->ran = true; c->totals_valid = false; c->lin_valid = false;
+    c->ran = true; c->totals_valid = false;
     return 0;
 }
 
@@ -1268,49 +1205,6 @@ int l2r_result_sizes(l2r_ctx *c, int64_t *n_reads, int64_t *n_exons, int64_t *n_
     return 0;
 }
 
-/* The exon arrays of the last run in READ ORDER on the device (exon k of read i at off[i] + k, off = running sum of the
-   exon counts).  The classic pipeline writes them that way; the slab / fused pipelines keep their own layouts
-   (l2r_slab.hip.h, l2r_fused.hip.h) and are copied into place here, at HBM speed, once per run. */
-static int read_order_arrays(l2r_ctx *c, const uint32_t **off, const int32_t **xs, const int32_t **xe, const uint8_t **xf)
-{
-    const int64_t N = c->n_reads, X = c->h_totals[0];
-    if (!c->fused) { *off = c->ex_off.p; *xs = c->ex_start.p; *xe = c->ex_end.p; *xf = c->ex_flag.p; return 0; }
-    if (!c->lin_valid) {
-        if (c->lin_dest.ensure((size_t)N + 1) || c->lin_start.ensure((size_t)X + 1) || c->lin_end.ensure((size_t)X + 1) || c->lin_flag.ensure((size_t)X + 1)) return -2;
-        const unsigned gN = (unsigned)((N + TILE_THREADS - 1) / TILE_THREADS);
-        if (N) {
-            hipLaunchKernelGGL(k_exon_counts, dim3(gN), dim3(TILE_THREADS), 0, c->stream, N, (const uint32_t *)c->info.p, c->lin_dest.p);
-            ScanJobs jobs; jobs.job[0] = ScanJob{c->lin_dest.p, N, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
-            hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, jobs);
-        }
-        if (c->slab && X) {
-            // slabs: k_linearize_slab gathers every read's column into its place
-            hipLaunchKernelGGL(k_linearize_slab, dim3((unsigned)c->n_tiles), dim3(TILE_THREADS), 0, c->stream, (const uint32_t *)c->tile_first.p, (const uint32_t *)c->tile_sbase.p,
-                               (const uint8_t *)c->order.p, (const uint32_t *)c->s_pre.p, (const uint32_t *)c->ex_off.p, (const uint32_t *)c->info.p,
-                               (const uint32_t *)c->lin_dest.p, (const int32_t *)c->ex_start.p, (const int32_t *)c->ex_end.p, (const uint8_t *)c->ex_flag.p,
-                               c->lin_start.p, c->lin_end.p, c->lin_flag.p, (const uint16_t *)c->ex_len.p);
-        } else if (X) {
-            // one chunk per tile, chunks in the order an atomic cursor handed them out: k_linearize moves the chunks
-            const size_t T = (size_t)c->n_tiles;
-            std::vector<uint32_t> tot(T), dest(T);
-            HIP_TRY(hipMemcpyAsync(tot.data(), c->tile_total.p, T * 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            uint64_t run = 0;
-            for (size_t t = 0; t < T; ++t) { dest[t] = (uint32_t)run; run += tot[t]; }
-            if ((int64_t)run != X) return fail(-5, "[l2r_download] tile totals (%llu) do not add up to the exon count (%lld)", (unsigned long long)run, (long long)X);
-            HIP_TRY(hipMemcpyAsync(c->tile_dest.p, dest.data(), T * 4, hipMemcpyHostToDevice, c->stream));
-            hipLaunchKernelGGL(k_linearize, dim3((unsigned)T), dim3(TILE_THREADS), 0, c->stream, (const uint32_t *)c->tile_start.p, (const uint32_t *)c->tile_dest.p,
-                               (const uint32_t *)c->tile_total.p, (const int32_t *)c->ex_start.p, (const int32_t *)c->ex_end.p, (const uint8_t *)c->ex_flag.p,
-                               c->lin_start.p, c->lin_end.p, c->lin_flag.p);
-            HIP_TRY(hipStreamSynchronize(c->stream));          // (dest is a local)
-        }
-        HIP_TRY(hipGetLastError());
-        c->lin_valid = true;
-    }
-    *off = c->lin_dest.p; *xs = c->lin_start.p; *xe = c->lin_end.p; *xf = c->lin_flag.p;
-    return 0;
-}
-
 int l2r_download(l2r_ctx *c, l2r_result *res)
 {
     if (!c || !res) return fail(-1, "[l2r_download] null argument");
@@ -1319,25 +1213,27 @@ int l2r_download(l2r_ctx *c, l2r_result *res)
     if (rc) return rc;
     const int64_t N = c->n_reads, X = c->h_totals[0];
     if (res->n_reads < N || res->ex_cap < X) return fail(-3, "[l2r_download] buffers too small: need %lld reads, %lld exons", (long long)N, (long long)X);
+    // both pipelines leave the results in read order: exon k of read i at ex_off[i] + k, offsets = the running sum of the exon counts
     std::vector<uint32_t> off((size_t)N);
-    const int32_t *xs = nullptr, *xe = nullptr; const uint8_t *xf = nullptr; const uint32_t *d_off = nullptr;
-    if ((rc = read_order_arrays(c, &d_off, &xs, &xe, &xf))) return rc;
     if (N) {
-        if (!c->fused) HIP_TRY(hipMemcpyAsync(off.data(), d_off, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(off.data(), c->ex_off.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(res->info, c->info.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(res->ref_tx, c->ref_tx.p, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
     }
     if (X) {
-        HIP_TRY(hipMemcpyAsync(res->ex_start, xs, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(res->ex_end, xe, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(res->ex_flag, xf, (size_t)X, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(res->ex_start, c->ex_start.p, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(res->ex_end, c->ex_end.p, (size_t)X * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(res->ex_flag, c->ex_flag.p, (size_t)X, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->fused) {                                        // read order: the offsets are the running sum of the exon counts
+    {
         int64_t at = 0;
-        for (int64_t i = 0; i < N; ++i) { res->ex_off[i] = at; at += (int64_t)(res->info[i] >> 8); }
+        for (int64_t i = 0; i < N; ++i) {
+            if ((int64_t)off[(size_t)i] != at) return fail(-5, "[l2r_download] exon offsets are not the running sum of the exon counts at read %lld (%u, expected %lld)", (long long)i, off[(size_t)i], (long long)at);
+            res->ex_off[i] = at; at += (int64_t)(res->info[i] >> 8);
+        }
         if (at != X) return fail(-5, "[l2r_download] exon counts (%lld) do not add up to the exon total (%lld)", (long long)at, (long long)X);
-    } else for (int64_t i = 0; i < N; ++i) res->ex_off[i] = off[(size_t)i];
+    }
     res->ex_off[N] = X;
     res->n_reads = N; res->n_exons = X;
     return 0;
@@ -1410,10 +1306,7 @@ int l2r_device_view_get(l2r_ctx *c, l2r_device_view *v)
     if (rc) return rc;
     v->n_reads = c->n_reads; v->n_exons = c->h_totals[0]; v->n_accepted = c->h_totals[1]; v->n_accepted_exons = c->h_totals[2];
     v->ex_off = nullptr; v->ex_start = nullptr; v->ex_end = nullptr; v->ex_flag = nullptr;
-    if (c->want & L2R_WANT_RESULTS) {
-        if ((rc = read_order_arrays(c, &v->ex_off, &v->ex_start, &v->ex_end, &v->ex_flag))) return rc;
-        HIP_TRY(hipStreamSynchronize(c->stream));          // the caller reads them on streams of its own
-    }
+    if (c->want & L2R_WANT_RESULTS) { v->ex_off = c->ex_off.p; v->ex_start = c->ex_start.p; v->ex_end = c->ex_end.p; v->ex_flag = c->ex_flag.p; }      // (read order, as the kernels left them; fetch_totals has waited for the stream)
     v->info = c->info.p; v->ref_tx = c->ref_tx.p;
     v->acc_rec = (const l2r_accepted_read *)c->acc_rec.p; v->acc_ex_off = c->acc_ex_off.p;
     v->acc_ex_start = c->acc_start.p; v->acc_ex_end = c->acc_end.p; v->acc_ex_flag = c->acc_flag.p;

@@ -92,22 +92,6 @@ struct TileDesc {
     uint32_t en_r0, en_nk;     // END entries
     uint32_t flags, n_win;     // n_win: transcripts in the tile's window (win_hdr[tile * WIN_TX + 0 .. n_win))
 };
-// Exon addressing of the kernels behind the classification.  Dense result arrays (classic / fused pipelines): exon k of a read
-// at ex_off + k.  Slab pipeline (l2r_slab.hip.h, ex_stride = 256): at ex_off + k * 256, except outliers whose ex_off carries
-// the DENSE flag (bit 31) and which lie at stride 1.
-constexpr uint32_t EX_DENSE_FLAG = 0x80000000u;
-struct ExRun { uint32_t off, stride; };
-__device__ __forceinline__ ExRun ex_run(uint32_t raw_off, uint32_t ex_stride)
-{
-    if (ex_stride != 1u && (raw_off & EX_DENSE_FLAG)) return ExRun{raw_off & ~EX_DENSE_FLAG, 1u};
-    return ExRun{raw_off, ex_stride};
-}
-// The slab pipeline keeps an exon of a slab row as {start, 16-bit length} (ex_len: 2 bytes instead of the 4 of an end; an
-// exon of 64 kb or more makes its read an outlier, stored densely with int32 ends).  ex_len == null: every layout has ends.
-__device__ __forceinline__ int ex_end_at(const int32_t *ex_start, const int32_t *ex_end, const uint16_t *ex_len, uint32_t idx, uint32_t stride)
-{
-    return (ex_len && stride != 1u) ? ex_start[idx] + (int)ex_len[idx] - 1 : ex_end[idx];
-}
 constexpr uint32_t CHUNK_DEFERRED = 0xffffffffu;   // tile_chunk: the tile's accepted exons are compacted by k_gather_accepted
 constexpr uint32_t TD_FAST = 1;    // exons fit the LDS tile, dictionary slices fit DIR_CAP / KEY_CAP, window fits WIN_TX
 constexpr uint32_t TD_WALKED = 4;  // long-CIGAR input: pass A has left the tile's exons in `walked` (tile * LDS_EXON_CAP + in-tile offset)
@@ -707,8 +691,7 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
                         const uint32_t *__restrict__ ex_off, const int32_t *__restrict__ ex_start, const int32_t *__restrict__ ex_end,
                         uint8_t *__restrict__ ex_flag, uint32_t *__restrict__ info_io, int32_t *__restrict__ ref_out,
                         uint32_t *__restrict__ tile_acc, uint32_t *__restrict__ tile_acc_ex, const uint32_t *__restrict__ tile_first, int n_tiles,
-                        CursorDir cd /* used when j0_arr is null: the one-walk pipeline keeps no per-read cursor values */, uint32_t ex_stride,
-                        const uint16_t *__restrict__ ex_len /* slab pipeline: lengths of the slab rows' exons, else null */)
+                        CursorDir cd /* used when j0_arr is null: the one-walk pipeline keeps no per-read cursor values */)
 {
     __shared__ int g_S[GEN_WAVES][GEN_CAP];
     __shared__ int g_E[GEN_WAVES][GEN_CAP];
@@ -721,22 +704,19 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
     for (uint32_t i = blockIdx.x * GEN_WAVES + wv; i < cnt; i += gridDim.x * GEN_WAVES) {
         const uint32_t r = redo[i];
         const int n = (int)(info_io[r] >> 8);
-        const ExRun xr = ex_run(ex_off[r], ex_stride);
-        const uint32_t off = xr.off, st = xr.stride;
+        const uint32_t off = ex_off[r];
         const int tid = r_tid[r];
         const int j0 = j0_arr ? j0_arr[r] : cursor_value(cd, tid, ex_start[off]);        // (the first exon starts at pos + 1)
         const bool rev = r_rev[r] != 0;
         Verdict v{0u, -1};
         if (n > GEN_CAP) {
-            // (a read this long is dense in every layout: the slab pipeline stores reads beyond SLAB_ROWS exons at stride 1)
             if (lane == 0) v = sweep_literal(ex_start + off, ex_end + off, ex_flag + off, n, tid, rev, j0, hdr, anno_ex, p);
         } else {
             for (int k = lane; k < n; k += WAVE) {
-                S[k] = ex_start[off + (uint32_t)k * st]; E[k] = ex_end_at(ex_start, ex_end, ex_len, off + (uint32_t)k * st, st);
+                S[k] = ex_start[off + (uint32_t)k]; E[k] = ex_end[off + (uint32_t)k];
                 F[k] = (k + 1 < n) ? (uint32_t)(F_EXON | F_DON | F_ACC | F_JUNC) : (uint32_t)F_EXON;
             }
-            const ReadEnds re{ex_start[off], ex_end_at(ex_start, ex_end, ex_len, off, st), ex_start[off + (uint32_t)(n - 1) * st],
-                              ex_end_at(ex_start, ex_end, ex_len, off + (uint32_t)(n - 1) * st, st)};
+            const ReadEnds re{ex_start[off], ex_end[off], ex_start[off + (uint32_t)(n - 1)], ex_end[off + (uint32_t)(n - 1)]};
             const int r_start = re.s0, r_end = re.el, dis = p.ss_dis, level = p.full_level;
             bool lfull = false, rfull = false, lnoth = true, rnoth = true, known = false, ksite = false;
             int ref = -1, ref_rev = 0;
@@ -841,7 +821,7 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
             if (full_decision(level, lfull, lnoth, rfull, rnoth)) info |= I_FULL;
             if (out_rev) info |= I_REV;
             v = Verdict{finish_info(info, n, p), ref};
-            for (int k = lane; k < n; k += WAVE) ex_flag[off + (uint32_t)k * st] = (uint8_t)F[k];
+            for (int k = lane; k < n; k += WAVE) ex_flag[off + (uint32_t)k] = (uint8_t)F[k];
         }
         if (lane == 0) {
             info_io[r] = v.info;
@@ -889,7 +869,6 @@ struct FastArgs {
     const TxHdr *win_hdr;        // per tile WIN_TX header copies, the annotation index in the spare word (pass A)
     const TxHdr *hdr; SiteDict st, en;
     uint32_t *ex_off; int32_t *ex_start; int32_t *ex_end; uint8_t *ex_flag; uint32_t *info; int32_t *ref_tx;
-    uint16_t *ex_len;            // slab pipeline: the slab rows hold {start, this 16-bit length} instead of {start, end}
     uint32_t *tile_acc, *tile_acc_ex; uint32_t *redo_count, *redo;
     uint32_t *tile_chunk, *tile_rchunk;           // accepted list: first exon slot / first record slot of every tile's chunk
     unsigned long long *chunk_cursor;             // next free {record slot (high word), exon slot (low word)}
@@ -1233,9 +1212,11 @@ __device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc 
 }
 
 // Known / known site / reference transcript / full-length / flag bytes of one read from its masks.
-template <int LEVEL, int STRIDE = 1>             // STRIDE: elements between the work words of consecutive exons (slab pipeline: 256)
+// STRIDE: elements between the work words of consecutive exons (slab pipeline: 256).  emit(k, flag byte) receives the exons' flags
+// (the classic kernel writes them back over the work words, the slab kernels store them straight into the result array).
+template <int LEVEL, int STRIDE = 1, typename Emit>
 __device__ __forceinline__ Verdict decide(const TileLds &L, const TileDesc &d, uint32_t local, uint32_t n, const ReadEnds &re,
-                                          const VisitMasks &vm, const SiteMasks &sm, bool rev_in)
+                                          const VisitMasks &vm, const SiteMasks &sm, bool rev_in, Emit emit)
 {
     uint16_t *W = L.W + local;
     // ---- first known transcript in visiting order
@@ -1282,9 +1263,9 @@ __device__ __forceinline__ Verdict decide(const TileLds &L, const TileDesc &d, u
             const uint32_t w = W[k * STRIDE];
             uint32_t f = ((w & 63u) > lim ? (uint32_t)F_EXON : 0u) | (((w >> 6) & 63u) > lim ? (uint32_t)F_JUNC : 0u) | ((~w >> 11) & site_bits);
             f &= (k + 1 == (int)n) ? (uint32_t)F_EXON : 0xffu;                   // the last exon has no junction behind it
-            W[k * STRIDE] = (uint16_t)f;
+            emit(k, f);
         }
-    } else W[0] = (uint16_t)F_EXON;
+    } else emit(0, (uint32_t)F_EXON);
     int ref = -1;
     bool out_rev = rev_in;
     if (jref >= 0) { ref = L.win[jref]; out_rev = ((L.hk[jref].w >> 8) & 1) != 0; }     // :825-831
@@ -1483,7 +1464,8 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         const SiteMasks sm = map_exons(L, d, work && !redo && n > 1, local, n, vm.vpre);
         L2R_STAMP(3);
         if (work && !redo) {
-            const Verdict vd = decide<LEVEL>(L, d, local, n, re, vm, sm, rev_in);
+            uint16_t *const Wr = s_W + local;
+            const Verdict vd = decide<LEVEL>(L, d, local, n, re, vm, sm, rev_in, [&](int k, uint32_t f) { Wr[k] = (uint16_t)f; });
             info = vd.info; ref = vd.ref;
         } else if (active && in_lds) {
             for (int k = 0; k < (int)n; ++k) s_W[local + k] = (uint16_t)0;
@@ -1671,16 +1653,15 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
                    const int64_t *__restrict__ sj_key, const int32_t *__restrict__ sj_cursor,
                    const int32_t *__restrict__ sj_tid, const int32_t *__restrict__ sj_don, const int32_t *__restrict__ sj_acc,
                    const int32_t *__restrict__ sj_uniq, const int32_t *__restrict__ sj_multi, DevParams p,
-                   uint32_t *__restrict__ info_io, uint32_t ex_stride, const uint16_t *__restrict__ ex_len)
+                   uint32_t *__restrict__ info_io)
 {
     const int64_t r = (int64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
     if (r >= n_reads) return;
     uint32_t info = info_io[r];
     if ((info & (I_FULL | I_KNOWN | I_KSITE)) != (I_FULL | I_KSITE)) return;
     const int n = (int)(info >> 8), tid = r_tid[r];
-    const ExRun xr = ex_run(ex_off[r], ex_stride);
-    const uint32_t off = xr.off, st = xr.stride;
-    const int r_start = ex_start[off], r_end = ex_end_at(ex_start, ex_end, ex_len, off + (uint32_t)(n - 1) * st, st);
+    const uint32_t off = ex_off[r];
+    const int r_start = ex_start[off], r_end = ex_end[off + (uint32_t)(n - 1)];
     const int from = sj_cursor ? sj_cursor[r] : first_key_above(sj_key, p.n_sj, pack_key(tid, r_start));
     bool ok = false;
     if (from < p.n_sj) {
@@ -1689,10 +1670,10 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
         if (!(t > tid || (t == tid && sj_don[from] >= r_end))) {
             ok = true;
             for (int j = 0; j + 1 < n; ++j) {
-                const uint8_t f = ex_flag[off + (uint32_t)j * st];
+                const uint8_t f = ex_flag[off + (uint32_t)j];
                 if ((f & F_JUNC) &&
-                    !junction_supported(tid, ex_end_at(ex_start, ex_end, ex_len, off + (uint32_t)j * st, st) + 1, ex_start[off + (uint32_t)(j + 1) * st] - 1, from, sj_tid, sj_don, sj_acc, sj_uniq, sj_multi, p)) {
-                    ex_flag[off + (uint32_t)j * st] = f | F_UNREL;
+                    !junction_supported(tid, ex_end[off + (uint32_t)j] + 1, ex_start[off + (uint32_t)(j + 1)] - 1, from, sj_tid, sj_don, sj_acc, sj_uniq, sj_multi, p)) {
+                    ex_flag[off + (uint32_t)j] = f | F_UNREL;
                     ok = false;
                 }
             }
@@ -1745,9 +1726,7 @@ void k_gather_accepted(const uint32_t *__restrict__ tile_first, int64_t first_re
                        const uint8_t *__restrict__ ex_flag, const uint32_t *__restrict__ tile_reads, const uint32_t *__restrict__ tile_exons,
                        uint32_t *__restrict__ tile_chunk, uint32_t *__restrict__ tile_rchunk, const uint32_t *__restrict__ chunk_cursor /* {exons, records} */,
                        AccRec *__restrict__ rec, uint32_t *__restrict__ acc_ex_off, int32_t *__restrict__ acc_start,
-                       int32_t *__restrict__ acc_end, uint8_t *__restrict__ acc_flag,
-                       const uint32_t *__restrict__ tile_sbase /* slab pipeline: first element of the tile's slab, else null */, uint32_t ex_stride,
-                       const uint16_t *__restrict__ ex_len)
+                       int32_t *__restrict__ acc_end, uint8_t *__restrict__ acc_flag)
 {
     __shared__ uint32_t s_wcnt[4], s_wex[4];
     __shared__ uint16_t s_map[LDS_EXON_CAP];
@@ -1769,27 +1748,24 @@ void k_gather_accepted(const uint32_t *__restrict__ tile_first, int64_t first_re
     if (threadIdx.x == 0) { tile_chunk[blockIdx.x] = ebase0; tile_rchunk[blockIdx.x] = cbase0; }
     uint32_t cb = 0, eb = 0;
     for (int k = 0; k < wv; ++k) { cb += s_wcnt[k]; eb += s_wex[k]; }
-    const uint32_t src0 = tile_sbase ? tile_sbase[blockIdx.x] : (n_act ? ex_off[r0] : 0u);      // first exon of the tile / first element of its slab
+    const uint32_t src0 = n_act ? ex_off[r0] : 0u;                            // first exon of the tile
     const uint32_t e_loc = eb + inc - nex;                                    // tile-local compacted exon offset
     const bool mapped = e_tot <= (uint32_t)LDS_EXON_CAP;
     if (acc) {
-        const ExRun xr = ex_run(ex_off[r], ex_stride);
-        const uint32_t src = xr.off, st = xr.stride;
+        const uint32_t src = ex_off[r];
         const uint32_t slot = cbase0 + cb + rank_w;
         const uint64_t gidx = (uint64_t)(first_read + r);
         AccRec a; a.read_lo = (uint32_t)gidx; a.read_hi = (uint32_t)(gidx >> 32); a.info = w; a.ref_tx = ref_tx[r];
         rec[slot] = a;
         acc_ex_off[slot] = ebase0 + e_loc;
-        // (slab pipeline: only slab rows go through the map -- a densely stored read next to the slabs would be read back in the
-        //  wrong format below)
-        if (mapped && (!ex_len || st != 1u) && src >= src0 && (uint64_t)(src - src0) + (uint64_t)nex * st < MAP_DIRECT) {
-            for (uint32_t k = 0; k < nex; ++k) s_map[e_loc + k] = (uint16_t)(src - src0 + k * st);
+        if (mapped && src >= src0 && (uint64_t)(src - src0) + (uint64_t)nex < MAP_DIRECT) {
+            for (uint32_t k = 0; k < nex; ++k) s_map[e_loc + k] = (uint16_t)(src - src0 + k);
         } else {
             for (uint32_t k = 0; k < nex; ++k) {
                 if (mapped) s_map[e_loc + k] = (uint16_t)MAP_DIRECT;
-                acc_start[ebase0 + e_loc + k] = ex_start[src + k * st];
-                acc_end[ebase0 + e_loc + k] = ex_end_at(ex_start, ex_end, ex_len, src + k * st, st);
-                acc_flag[ebase0 + e_loc + k] = ex_flag[src + k * st];
+                acc_start[ebase0 + e_loc + k] = ex_start[src + k];
+                acc_end[ebase0 + e_loc + k] = ex_end[src + k];
+                acc_flag[ebase0 + e_loc + k] = ex_flag[src + k];
             }
         }
     }
@@ -1800,7 +1776,7 @@ void k_gather_accepted(const uint32_t *__restrict__ tile_first, int64_t first_re
         if (q == MAP_DIRECT) continue;
         const uint32_t sidx = src0 + q;
         acc_start[ebase0 + i] = ex_start[sidx];
-        acc_end[ebase0 + i] = ex_end_at(ex_start, ex_end, ex_len, sidx, ex_len ? 256u : 1u);      // (slab pipeline: mapped slots are slab elements)
+        acc_end[ebase0 + i] = ex_end[sidx];
         acc_flag[ebase0 + i] = ex_flag[sidx];
     }
 }

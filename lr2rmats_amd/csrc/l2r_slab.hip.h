@@ -1,46 +1,59 @@
-// l2r_slab.hip.h -- the one-walk pipeline as TWO light kernels that both run at (nearly) full occupancy (gfx950).
+// l2r_slab.hip.h -- the one-walk pipeline for coordinate-sorted records with short CIGARs: TWO light kernels that both run at
+// full occupancy (8 waves per SIMD), with the exons handed over through HBM in a layout both sides touch with whole rows (gfx950).
 //
-// Measured on MI355X (profiles/r02): one wave issues an instruction every 13-18 cycles in these kernels whatever is done to
-// its instruction count -- they are bound by the latency of a wave's dependent instruction chains -- and a SIMD's issue
-// rate grows with its resident waves up to 8 (ubench_valu_issue.txt).  k_classify_fast / k_fused keep a tile's exons in
-// LDS (10 bytes each, 40 KB per workgroup): 4 waves per SIMD.  Here the exons go through HBM in a layout that both
-// sides touch with full 256- / 512-byte rows, and neither kernel needs them in LDS:
+// Measured on MI355X (profiles/r02): kernels of this path are bound by the latency of a wave's dependent chains, and a SIMD's
+// issue rate grows with its resident waves up to 8.  An LDS tile of exons (10 bytes each, 40 KB per workgroup: the classic
+// kernel) caps that at 4 waves per SIMD.  Here neither kernel keeps exons in LDS:
 //
-//   k_order (l2r_fused.hip.h)   the tile's reads by falling CIGAR length = the SLOT of every read (lane order of both kernels)
-//   k_walk_slab     one lane per read, CIGAR words in registers, ONE walk; exon k of the read in slot s goes to
-//                   element k * 256 + s of the tile's SLAB of the result arrays (row k = exon k of all reads of the
-//                   tile: a wave stores whole rows); read ends -> the tile's span.  No LDS, no barrier.
-//   k_probe_slab    per tile: one wave makes the descriptor and window (make_descriptor), the dictionary slices are
-//                   staged in LDS (21 KB with the per-exon work words: 7 workgroups per CU, <= 64 VGPRs); every lane
-//                   reads its exons back row by row (coalesced), window pass, probes, verdicts with the device functions
-//                   of the classic kernel; flag bytes go to the slab of ex_flag.
+//   k_walk_slab   per tile of up to 256 reads: the tile's reads by falling CIGAR length (a counting sort in LDS: the SLOT of a read =
+//                 its lane, so the lanes of a wave get similar trip counts); one lane per read, CIGAR words in registers, ONE walk;
+//                 exon k of the read in slot s goes to element row * 256 + s of the tile's SLAB (a row = the k-th exons of all reads of
+//                 the tile: a wave stores and loads whole rows).  Then every read's place in the READ-ORDER result arrays inside its
+//                 tile (`loc`: a scan of the exon counts in read order), the tile's exon count, and -- by the last wave alone, the
+//                 others have left -- the tile's descriptor and window (make_descriptor).
+//   k_scan_u32    exclusive scan of the tiles' exon counts: the first result slot of every tile (l2r_kernels.hip.h)
+//   k_probe_slab  per tile: dictionary slices and window staged in LDS (20 KB with the per-exon work words: 8 workgroups per CU,
+//                 <= 64 VGPRs); every lane streams its read's exons row by row (coalesced), window pass, probes, verdicts with the
+//                 device functions of the classic kernel, and writes the per-read results where their consumers read them:
+//                 ex_start / ex_end / ex_flag / ex_off in READ ORDER (exon k of read r at ex_off[r] + k), info, ref_tx.
+//                 Nothing is left in an intermediate layout: l2r_download / l2r_device_view_get hand out these arrays as they are.
+//   k_probe_slab_wide (l2r_wide.hip.h)   the same for tiles whose window holds 33 .. 64 transcripts.
 //
-// The result arrays are slabs: ex_off[r] = element of exon 0, exon k at ex_off[r] + k * 256.  A tile's slab has as many rows
-// as its longest read can have exons (upper bound from the CIGAR lengths, at most SLAB_ROWS); reads beyond that bound
-// ("outliers") are walked literally into a dense area behind the slabs (ex_off | EXOFF_DENSE, stride 1) and classified
-// by the generic kernel.  l2r_download() turns slabs into read order (k_linearize_slab).
-// HBM traffic: CIGAR once, exons written once and read once.
+// Slab rows hold {start (int32), length (uint16)}: 6 bytes per exon cross HBM between the kernels.  A read's LAST exon sits in
+// row 0 of its column and exon k < n - 1 in row k + 1: the probe side needs the first and the last exon before anything else, and
+// finds both at addresses that do not depend on the exon count (one dependent round trip less in front of its first barrier).
+// A tile's slab has as many rows as its longest read can have exons (bound from the CIGAR lengths at upload, at most SLAB_ROWS);
+// reads beyond that, and reads with an exon of 64 kb or more, are OUTLIERS: walked literally into a dense area
+// (dense_start / dense_end), copied into the result arrays by the probe side, classified by the generic kernel.
 #pragma once
-#include "l2r_fused.hip.h"
+#include "l2r_window.hip.h"
 
 namespace l2r {
 
 constexpr int SLAB_ROWS = 24;                            // rows of a tile's slab at most (exons of its longest read it can hold)
-constexpr uint32_t SLAB_STRIDE = TILE_THREADS;           // elements between exon k and exon k + 1 of a read
-constexpr uint32_t EXOFF_DENSE = EX_DENSE_FLAG;          // ex_off flag (slab pipeline only): exons at stride 1
-constexpr uint32_t I_PRE_INSANE = I_UNREL;               // k_walk_slab -> k_probe_slab, in info[]: first or last exon empty
-constexpr uint32_t I_PRE_DIRECT = I_SJCHK;               // ... an outlier: its exons are in the dense area, the generic kernel classifies it
+constexpr uint32_t SLAB_STRIDE = TILE_THREADS;           // elements between two rows of a column
+constexpr int SLAB_HEAD_VEC = 6;                         // 16-byte CIGAR vectors a lane holds: 24 ops; longer reads finish from memory
+constexpr int SLAB_HEAD = 4 * SLAB_HEAD_VEC;
+// k_walk_slab -> k_probe_slab, one word per slot: the read's index inside its tile (bits 0-7), its strand bit, two flags, its exon count
+constexpr uint32_t PRE_REV = 1u << 8;
+constexpr uint32_t PRE_INSANE = 1u << 9;                 // first or last exon empty (or, with -e < 1, any exon): the generic kernel decides
+constexpr uint32_t PRE_DENSE = 1u << 10;                 // an outlier: its exons are in the dense area (row 0 of its column holds the run's index)
+constexpr int PRE_N_SHIFT = 11;
 
-// c ops -> is the read an outlier of the slab layout?  (exon_bound with min_exon >= 1, the only case this pipeline takes)
+// c ops -> rows its read needs at most when every kept inner exon is at least one base long (min_exon >= 1): each kept exon but
+// the first and the last needs an op of its own next to its cut (src/bam2gtf.c:31-78), so n <= (c + 3) / 2.  With -e < 1 the walk
+// itself watches the rows (k_walk_slab<true>).
 __host__ __device__ __forceinline__ uint32_t slab_rows_of(uint32_t c) { return (c + 3u) >> 1; }
+// row of exon j of a read with n exons (the last exon in row 0)
+__device__ __forceinline__ uint32_t slab_row(uint32_t j, uint32_t n) { return j + 1u < n ? j + 1u : 0u; }
 
 struct SlabArgs {
-    FusedArgs g;
-    const uint32_t *tile_sbase;                          // first element of every tile's slab
-    unsigned long long *ovf_cursor; uint32_t ovf_base;   // dense area behind the slabs for outliers
-    // the records' fields in slot order (k_order): c_lo, number of ops (65535: more), pos, strand
-    const uint32_t *s_clo; const uint16_t *s_ncig; const int32_t *s_pos; const uint8_t *s_rev;
-    uint32_t *pre;                                       // k_walk_slab -> k_probe_slab, slot order: exon count << 8 | I_PRE_*
+    PipeArgs g;
+    const uint32_t *tile_sbase;                          // first element of every tile's slab (+ a closing entry)
+    int32_t *slab_start; uint16_t *slab_len;             // the slabs
+    int32_t *dense_start, *dense_end;                    // outliers: exon k of a run at run + k
+    unsigned long long *ovf_cursor;                      // next free element of the dense area
+    uint32_t *pre, *loc;                                 // k_walk_slab -> k_probe_slab, slot order: PRE_* word; exons of the tile's reads before this one (read order)
     TileWin *tw;                                         // k_walk_slab -> k_probe_slab: descriptor + window per tile
     // tiles whose window holds 33 .. 64 transcripts (l2r_wide.hip.h): wide_cnt[0] counts the appends of k_walk_slab, k_probe_slab
     // moves the count to wide_cnt[1] (what k_probe_slab_wide reads) and clears [0] for the next run
@@ -72,40 +85,84 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t grid) { return
 constexpr int SLAB_KEY_CAP = 168;                        // dictionary entries staged per dictionary and tile (k_probe_slab's LDS: 20 KB = 8 workgroups per CU)
 static_assert(sizeof(TileWin) % 16 == 0, "TileWin is copied in 16-byte pieces");
 
-// Both kernels are laid out for SHORT dependent load chains (they are latency bound: a tile's time is the sum of its
-// dependent round trips): everything a lane needs sits at "tile start + slot".
-// The walk of one tile's reads, one lane per read (slot order): exon k of the read in slot s goes to row k of the tile's slab.
-// Writes the exon rows and ex_off[r]; returns what the rest of the tile's work needs.
-struct SlabWalk { uint32_t pre, r, n; int el; bool active, outlier; };
-__device__ __forceinline__ SlabWalk slab_walk(SlabArgsK sa, FusedArgsK a, uint32_t r0, uint32_t n_act, uint32_t sbase, int32_t tid0,
-                                              const uint8_t *__restrict__ u_order)
+// ---------------------------------------------------------------------------------------------------------- k_walk_slab
+// GENERAL: -e < 1 (an inner exon may be empty: every exon's sanity is checked, and the read leaves the slab when it has more exons
+// than the tile's slab has rows -- with min_exon >= 1 the row bound from the CIGAR length makes that impossible).
+template <bool GENERAL>
+__global__ __launch_bounds__(TILE_THREADS, 8)
+void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const int32_t *__restrict__ u_tid,
+                 const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase)
 {
-    const bool active = threadIdx.x < n_act;
-    const uint32_t at = r0 + (active ? threadIdx.x : 0u);
-    // ---- the read in this slot and the head of its CIGAR
-    FusedRead v;
-    v.src = active ? 0 : -1; v.c_lo = 0u; v.n_cig = 0u; v.lub = 0u; v.pos = 0; v.tid = tid0; v.rev = 0u;
-    uint32_t r = r0;
-    if (active) {
-        v.c_lo = ld32(sa->s_clo, at); v.n_cig = v.c_lo + (uint32_t)ld32(sa->s_ncig, at); v.pos = ld32(sa->s_pos, at);
-        r = r0 + (uint32_t)ld32(u_order, at);
+    __shared__ uint32_t s_hist[WAVE];
+    __shared__ uint32_t s_x0[TILE_THREADS], s_x1[TILE_THREADS], s_x2[TILE_THREADS];       // the records' fields, slot order
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[TILE_THREADS], s_loc[TILE_THREADS];      // exon counts / their exclusive scan, READ order
+    __shared__ int s_wmax[TILE_THREADS / WAVE];
+    __shared__ uint32_t s_wn[TILE_THREADS / WAVE];
+    __shared__ __attribute__((aligned(16))) TileWin s_tw;
+    __shared__ __attribute__((aligned(16))) TileWin64 s_tw64;
+    (void)kernarg_block;
+    const SlabArgsK sa = slab_args();
+    const PipeArgsK a = pipe_args();
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
+    if (t >= sa->n_tiles) return;
+    const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
+    const int32_t tid0 = n_act ? u_tid[r0] : 0, pos0 = n_act ? u_pos[r0] : 0;
+    const uint32_t sbase = u_tile_sbase[t], rows_tile = (u_tile_sbase[t + 1u] - sbase) >> 8;
+    // ---- the tile's reads by falling CIGAR length (counting sort, 64 bins): thread i brings read i, slot s takes what landed there
+    {
+        const uint32_t i = threadIdx.x;
+        uint32_t c_lo = 0u, c = 0u, rev = 0u; int32_t pos = 0;
+        if (i < n_act) {
+            const int64_t *const p_off = a->f.cig_off;
+            c_lo = (uint32_t)ld32(p_off, r0 + i); c = (uint32_t)ld32(p_off, r0 + i + 1u) - c_lo;      // (a shard has < 2^32 words)
+            pos = ld32(a->f.r_pos, r0 + i); rev = ld32(a->f.r_rev, r0 + i) ? 1u : 0u;
+        }
+        if (i < (uint32_t)WAVE) s_hist[i] = 0u;
+        __syncthreads();
+        const uint32_t est = i < n_act ? max(1u, min((c + 1u) >> 1, (uint32_t)(WAVE - 1))) : 0u;      // threads without a read sort last
+        const uint32_t bin = (uint32_t)(WAVE - 1) - est;
+        const uint32_t rank = atomicAdd(&s_hist[bin], 1u);
+        __syncthreads();
+        if (i < (uint32_t)WAVE) { const uint32_t v = s_hist[i]; s_hist[i] = wave_inclusive_scan(v) - v; }
+        __syncthreads();
+        const uint32_t slot = s_hist[bin] + rank;
+        s_x0[slot] = c_lo; s_x1[slot] = (uint32_t)pos; s_x2[slot] = min(c, 0xffffu) | (rev << 16) | (i << 24);
+        __syncthreads();
     }
-    fused_load_words(a, v);                       // (n_cig = number of ops from here on; 65535 stands for "more")
-    fused_mask_words(v);
+    const bool active = threadIdx.x < n_act;
+    const uint32_t c_lo = s_x0[threadIdx.x], xw = s_x2[threadIdx.x];
+    const int32_t pos = (int32_t)s_x1[threadIdx.x];
+    const uint32_t n_cig = xw & 0xffffu, idx = xw >> 24;             // (n_cig 65535: that many or more)
+    // ---- the head of the read's CIGAR: six 16-byte vectors, all in flight at once; words behind the last op become "I, length 0"
+    uint32_t cg[SLAB_HEAD];
+#pragma unroll
+    for (int i = 0; i < SLAB_HEAD; ++i) cg[i] = 1u;
+    if (active) {
+        const uint32_t *const words = a->f.cig + c_lo;
+#pragma unroll
+        for (int q = 0; q < SLAB_HEAD_VEC; ++q)
+            if ((uint32_t)(4 * q) < n_cig) {
+                const v4i_a4 x = *reinterpret_cast<const v4i_a4 *>(words + 4 * q);
+                cg[4 * q] = (uint32_t)x.x; cg[4 * q + 1] = (uint32_t)x.y; cg[4 * q + 2] = (uint32_t)x.z; cg[4 * q + 3] = (uint32_t)x.w;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < SLAB_HEAD; ++i) cg[i] = (uint32_t)i < n_cig ? cg[i] : 1u;
     DevParams p;
     p.min_exon = a->f.p.min_exon; p.min_intron = a->f.p.min_intron; p.max_delet = a->f.p.max_delet;
-    const uint32_t t3 = ((uint32_t)p.min_intron << 4) | 3u, t2 = ((uint32_t)(p.max_delet + 1) << 4) | 2u;
-    bool outlier = slab_rows_of(v.n_cig) > (uint32_t)SLAB_ROWS;
-    const int c_max = wave_max((active && !outlier) ? (int)min(v.n_cig, (uint32_t)FUSED_HEAD) : 0);
-    int32_t *const xs = a->f.ex_start, *const xe = a->f.ex_end;
-    uint16_t *const xl = a->f.ex_len;                   // slab rows: {start, 16-bit length}
-    uint32_t n = 0u, off = 0u;
+    const uint32_t t3 = ((uint32_t)p.min_intron << 4) | 3u, t2 = ((uint32_t)(p.max_delet + 1) << 4) | 2u;      // op and length compare as one number
+    // beyond the rows a slab can have: an outlier from the start (-e < 1: only when the CIGAR cannot be walked out of the registers)
+    bool outlier = GENERAL ? n_cig > (uint32_t)SLAB_HEAD : slab_rows_of(n_cig) > (uint32_t)SLAB_ROWS;
+    const int c_max = wave_max((active && !outlier) ? (int)min(n_cig, (uint32_t)SLAB_HEAD) : 0);
+    int32_t *const xs = sa->slab_start; uint16_t *const xl = sa->slab_len;
+    const uint32_t off = sbase + threadIdx.x;
+    uint32_t n = 0u;
     int el = INT32_MIN;
     bool sane = true;
     if (active && !outlier) {
-        // one lane per read; exon k lands in row k of the tile's slab, at the read's slot
-        off = sbase + threadIdx.x;
-        int start = v.pos + 1, end = v.pos;
+        // one lane per read; kept exon k lands in row k + 1 of the read's column, the last exon in row 0
+        int start = pos + 1, end = pos;
         int s0 = 0, e0 = 0;
         bool first = true;
         uint32_t longest = 0u;
@@ -116,106 +173,91 @@ __device__ __forceinline__ SlabWalk slab_walk(SlabArgsK sa, FusedArgsK a, uint32
             const bool keep = cut & (first | (end - start >= p.min_exon - 1));
             if (keep) {
                 const uint32_t xlen = (uint32_t)(end - start + 1);
-                st32(xs, off + n * SLAB_STRIDE, start); st32(xl, off + n * SLAB_STRIDE, (uint16_t)xlen);
+                if (!GENERAL || n + 1u < rows_tile) { st32(xs, off + (n + 1u) * SLAB_STRIDE, start); st32(xl, off + (n + 1u) * SLAB_STRIDE, (uint16_t)xlen); }
                 longest = max(longest, xlen);
+                if (GENERAL) sane = sane & (start <= end);
                 if (first) { s0 = start; e0 = end; }
                 first = false; ++n;
             }
             start = cut ? end + len + 1 : start;
-            end += len & __builtin_amdgcn_sbfe(0x18d, op, 1u);
+            end += len & __builtin_amdgcn_sbfe(0x18d, op, 1u);         // ops 0 2 3 7 8 advance the reference
         };
 #pragma unroll
-        for (int q = 0; q < FUSED_HEAD_VEC; ++q)
-            if (4 * q < c_max) { step(v.cg[4 * q]); step(v.cg[4 * q + 1]); step(v.cg[4 * q + 2]); step(v.cg[4 * q + 3]); }       // (wave-uniform)
-        if (v.n_cig > (uint32_t)FUSED_HEAD) {
-            const uint32_t *const words = a->f.cig + v.c_lo;
-            for (uint32_t i = FUSED_HEAD; i < v.n_cig; ++i) step(words[i]);
+        for (int q = 0; q < SLAB_HEAD_VEC; ++q)
+            if (4 * q < c_max) { step(cg[4 * q]); step(cg[4 * q + 1]); step(cg[4 * q + 2]); step(cg[4 * q + 3]); }       // (wave-uniform)
+        if (!GENERAL && n_cig > (uint32_t)SLAB_HEAD) {
+            const uint32_t *const words = a->f.cig + c_lo;
+            for (uint32_t i = SLAB_HEAD; i < n_cig; ++i) step(words[i]);
         }
         {   const uint32_t xlen = (uint32_t)(end - start + 1);
-            st32(xs, off + n * SLAB_STRIDE, start); st32(xl, off + n * SLAB_STRIDE, (uint16_t)xlen);
+            st32(xs, off, start); st32(xl, off, (uint16_t)xlen);
             longest = max(longest, xlen); }
         if (first) { s0 = start; e0 = end; }
         ++n;
         el = end;
-        // kept inner exons are at least min_exon >= 1 long; the first and the last one are kept whatever their length
-        sane = s0 <= e0 && start <= end;
-        // an exon of 64 kb or more does not fit the row format: the read is stored densely after all (below)
-        if (longest > 0xffffu) { outlier = true; n = 0u; sane = true; el = INT32_MIN; }
+        // with min_exon >= 1 kept inner exons are at least one base long; the first and the last one are kept whatever their length
+        sane = GENERAL ? (sane & (start <= end)) : (s0 <= e0 && start <= end);
+        // an exon of 64 kb or more does not fit the row format, and (-e < 1 only) the read may have outgrown the tile's rows
+        if (longest > 0xffffu || (GENERAL && n > rows_tile)) { outlier = true; n = 0u; sane = true; el = INT32_MIN; }
     }
     if (active && outlier) {
         // an outlier: the literal walk (l2r_kernels.hip.h), twice -- count, take a run of the dense area, store
+        const uint32_t r = r0 + idx;
         const int64_t *const p_off = a->f.cig_off;
         const uint32_t n_ops = (uint32_t)(ld32(p_off, r + 1u) - ld32(p_off, r));
-        const uint32_t *const words = a->f.cig + v.c_lo;
+        const uint32_t *const words = a->f.cig + c_lo;
         {
-            WalkState w{v.pos + 1, v.pos, 0};
+            WalkState w{pos + 1, pos, 0};
             auto none = [&](int, int, int) {};
             walk_ops<false>(w, words, 0, (int)n_ops, p, none);
             n = (uint32_t)w.n + 1u;
         }
-        const uint32_t run = sa->ovf_base + (uint32_t)atomicAdd(sa->ovf_cursor, (unsigned long long)n);
-        WalkState w{v.pos + 1, v.pos, 0};
-        auto put = [&](int k, int s, int e) { xs[run + (uint32_t)k] = s; xe[run + (uint32_t)k] = e; sane = sane & (s <= e); el = e; };
+        const uint32_t run = (uint32_t)atomicAdd(sa->ovf_cursor, (unsigned long long)n);
+        int32_t *const ds = sa->dense_start, *const de = sa->dense_end;
+        WalkState w{pos + 1, pos, 0};
+        auto put = [&](int k, int s, int e) { ds[run + (uint32_t)k] = s; de[run + (uint32_t)k] = e; sane = sane & (s <= e); el = e; };
         walk_ops<false>(w, words, 0, (int)n_ops, p, put);
         put(w.n, w.start, w.end);
-        off = run | EXOFF_DENSE;
+        st32(xs, off, (int32_t)run);                     // (row 0 of the unused column: where the probe side finds the run)
     }
-    SlabWalk o;
-    o.pre = (n << 8) | (sane ? 0u : I_PRE_INSANE) | (outlier ? I_PRE_DIRECT : 0u);
-    o.r = r; o.n = n; o.el = el; o.active = active; o.outlier = outlier;
-    // ex_off[r]: a slab read sits at "its tile's slab + its slot", which the kernels behind the classification only need for the
-    // reads they touch -- every read with a junction table or an accepted list (k_validate_sj, k_gather_accepted), else only
-    // the redo list's (written by the probe side when it lists a read) and the densely stored reads (here).
-    if (active && (outlier || a->f.p.n_sj > 0 || (a->f.p.want & WANT_ACCEPTED))) a->f.ex_off[r] = off;
-    return o;
-}
-
-__global__ __launch_bounds__(TILE_THREADS, 8)
-void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint8_t *__restrict__ u_order,
-                 const int32_t *__restrict__ u_tid, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase)
-{
-    __shared__ int s_wmax[TILE_THREADS / WAVE];
-    __shared__ uint32_t s_wsum[TILE_THREADS / WAVE], s_wn[TILE_THREADS / WAVE];
-    __shared__ __attribute__((aligned(16))) TileWin s_tw;
-    __shared__ __attribute__((aligned(16))) TileWin64 s_tw64;
-    (void)kernarg_block;
-    const SlabArgsK sa = slab_args();
-    const FusedArgsK a = fused_args();
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
-    if (t >= sa->n_tiles) return;
-    const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
-    const int32_t tid0 = n_act ? u_tid[r0] : 0, pos0 = n_act ? u_pos[r0] : 0;
-    const uint32_t sbase = u_tile_sbase[t];
-    const SlabWalk w = slab_walk(sa, a, r0, n_act, sbase, tid0, u_order);
-    const bool active = w.active, outlier = w.outlier;
-    const uint32_t n = w.n;
-    const int el = w.el;
-    if (active) sa->pre[r0 + threadIdx.x] = w.pre;
+    s_cnt[idx] = active ? n : 0u;                        // (every entry is written: idx is a permutation of 0 .. 255)
     const int m = wave_max(active ? el : INT32_MIN);
-    const uint32_t wsum = wave_sum(active ? n : 0u);
     const int wn = wave_max((active && !outlier) ? (int)n : 0);
-    if (lane == 0) { s_wmax[wv] = m; s_wsum[wv] = wsum; s_wn[wv] = (uint32_t)min(wn, 255); }
+    if (lane == 0) { s_wmax[wv] = m; s_wn[wv] = (uint32_t)min(wn, 255); }
     if (t == 0u && threadIdx.x == 0) {
-        // the run's counters (this kernel is the first of a run, k_probe_slab the first to count): redo list, chunk cursor
-        // of the accepted list, exon cursor.  (The cursor of the outlier area is cleared by k_probe_slab for the next run.)
+        // the run's counters (this kernel is the first of a run): redo list, chunk cursor of the accepted list.
+        // (The cursor of the outlier area is cleared by k_probe_slab for the next run.)
         uint32_t *const cnt = a->f.redo_count;
-        cnt[0] = 0u; cnt[1] = 0u; cnt[2] = 0u; cnt[3] = 0u; cnt[4] = 0u;
+        cnt[0] = 0u; cnt[1] = 0u; cnt[2] = 0u;
     }
     __syncthreads();
+    // ---- every read's place among the tile's exons in READ order: each wave scans the 256 counts (four per lane) for itself
+    uint32_t total;
+    {
+        const uint4 c4 = reinterpret_cast<const uint4 *>(s_cnt)[lane];
+        const uint32_t sum = c4.x + c4.y + c4.z + c4.w;
+        const uint32_t inc = wave_inclusive_scan(sum), ex = inc - sum;
+        reinterpret_cast<uint4 *>(s_loc)[lane] = make_uint4(ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z);     // (the four waves write the same values)
+        total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+    }
+    if (active) {
+        const uint32_t at = r0 + threadIdx.x;
+        sa->pre[at] = idx | (((xw >> 16) & 1u) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (outlier ? PRE_DENSE : 0u) | (n << PRE_N_SHIFT);
+        sa->loc[at] = s_loc[idx];
+    }
     // ---- the tile's descriptor and window, by the last wave alone (the others are done): nobody waits for its load chain
     if (wv != TILE_THREADS / WAVE - 1) return;
-    if (lane == 0) a->tile_total[t] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];   // (one word per tile: a single counter would serialise 156 k waves)
+    if (lane == 0) a->tile_total[t] = total;             // (one word per tile, scanned by k_scan_u32: a single counter would serialise 156 k waves)
     make_descriptor(a, lane, tid0, pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), true, &s_tw, (uint32_t)SLAB_KEY_CAP,
                     sa->tw64 ? &s_tw64 : nullptr);
     if (s_tw.d.flags & TD_WIDE) {
         // a window of 33 .. 64 members: the tile joins the list of k_probe_slab_wide, its 64-member record goes along
-        uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(sa->wide_cnt, 1u);
-        slot = __shfl(slot, 0, WAVE);
-        if (slot < sa->wide_cap) {
-            if (lane == 0) sa->wide_tile[slot] = t;
-            for (int i = lane; i < (int)(sizeof(TileWin64) / 16); i += WAVE) reinterpret_cast<int4 *>(sa->tw64 + slot)[i] = reinterpret_cast<const int4 *>(&s_tw64)[i];
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(sa->wide_cnt, 1u);
+        at = __shfl(at, 0, WAVE);
+        if (at < sa->wide_cap) {
+            if (lane == 0) sa->wide_tile[at] = t;
+            for (int i = lane; i < (int)(sizeof(TileWin64) / 16); i += WAVE) reinterpret_cast<int4 *>(sa->tw64 + at)[i] = reinterpret_cast<const int4 *>(&s_tw64)[i];
         } else if (lane == 0) {
             s_tw.d.flags = (s_tw.d.flags & ~(TD_WIDE | (7u << 8))) | (4u << 8);     // list full: the tile takes the generic kernel ("window > 32")
         }
@@ -225,24 +267,55 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
         for (int i = lane; i < SLAB_TW_VECS; i += WAVE) if (tw_vec_used(i, n_win)) reinterpret_cast<int4 *>(sa->tw + t)[i] = reinterpret_cast<const int4 *>(&s_tw)[i]; }
 }
 
-// map_exons (l2r_kernels.hip.h) with the read's exons streamed from its slab column: row k at off + k * 256, the same row
-// for the whole wave = coalesced.  Rows 0..3 come preloaded (SlabRows: the kernel asks for them with its first loads, before
-// it knows the read), row k + 4 is asked for in round k.  Rows at and behind the read's exon count hold anything: not used.
-// Work words at W[k * 256].
-constexpr int SLAB_AHEAD = 4;                            // rows of a read's column in flight (6: no gain, measured)
-struct SlabRows { int s[SLAB_AHEAD], e[SLAB_AHEAD]; };
+// ---------------------------------------------------------------------------------------------------------- k_probe_slab
+// A row of a column as loaded: {start, length word}.  The 16-bit length is fetched as the low half of a 4-byte load at its 2-byte
+// boundary and masked where the row is READ: a 16-bit load is zero-extended by the compiler where it is issued, i.e. waited for there.
+struct SlabRow { int s; uint32_t l; };
+__device__ __forceinline__ SlabRow slab_load_row(const int32_t *__restrict__ xs, const uint16_t *__restrict__ xl, uint32_t i)
+{
+    SlabRow r;
+    r.s = ld32(xs, i);
+    r.l = *reinterpret_cast<const u32_a1 *>(reinterpret_cast<const char *>(xl) + (size_t)(i * 2u));
+    return r;
+}
+// end = start + (low half of the length word) - 1, as ONE opaque step: written in C the compiler folds the mask into the
+// loop's register hand-over, i.e. back to the place where the load is issued
+__device__ __forceinline__ int slab_row_end(const SlabRow &r)
+{
+    int e;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\tv_add_u32_e32 %0, -1, %0" : "=v"(e) : "v"(r.l), "v"(r.s));
+    return e;
+}
+constexpr int SLAB_AHEAD = 4;                            // exons of a read in flight (rows k .. k + 3 in registers)
+struct SlabRows { SlabRow last, x[SLAB_AHEAD]; };        // a column's row 0 (the last exon) and rows 1 .. 4 as loaded by the kernel's first loads
+
+// The tile's results on their way out: the lanes of k_probe_slab hold one READ each (slot order), the result arrays want the exons
+// in read order (exon k of a read at ex_off + k) -- written lane by lane that is one scattered 4-byte store per lane and exon
+// (measured: 3 x the whole kernel).  So every exon is left in LDS at its POSITION inside the tile (pos = exons of the tile's reads
+// before this one, in read order, + k): start in S[pos], and in LW[pos] the 16-bit length below the exon's work word (later its flag
+// byte).  After one barrier the tile's block of the result arrays is written with 16-byte stores, thread j positions 4j .. 4j + 3.
+// SLAB_POS_CAP positions fit (8 bytes each: with the dictionary slices 27 KB per workgroup, 6 workgroups per CU); a read whose
+// exons lie behind that (a tile of very long reads) is written directly and classified by the generic kernel.
+constexpr int SLAB_POS_CAP = 2416;
+constexpr uint32_t SLAB_POS_SKIP = 0x80000000u;          // LW of a position that was written directly
+struct SlabStage { int32_t *S; uint32_t *LW; uint32_t loc; bool fits; };          // loc: the lane's first position
+
+// map_exons (l2r_kernels.hip.h) with the read's exons streamed from its slab column: a row is the same exon number for the whole
+// wave = coalesced.  Exons k .. k + 3 sit in four register pairs with FIXED roles per unrolled round (no register rotation: a copy
+// of a loaded register is a wait for its load).  Round k reads exon k (current) and exon k + 1 (next) and, when it is done with
+// exon k, asks for exon k + 4 into exon k's registers: that load has three rounds to arrive.  Every round leaves its exon and
+// its work word at the exon's position in LDS (SlabStage).
 __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const TileDesc &d, bool mapping, const int32_t *__restrict__ xs,
                                                     const uint16_t *__restrict__ xl, uint32_t off, uint32_t n, uint32_t vpre,
-                                                    const SlabRows &q)
+                                                    const SlabRows &q, const SlabStage &st)
 {
     SiteMasks m{0xffffffffu, 0u, 0u, 0u};
-    uint16_t *W = L.W + threadIdx.x;
-    int s = q.s[0], e = q.e[0], s1 = q.s[1], e1 = q.e[1];
-    int ps[SLAB_AHEAD - 2], pe[SLAB_AHEAD - 2];         // rows k + 2 .. k + SLAB_AHEAD - 1
-#pragma unroll
-    for (int i = 0; i < SLAB_AHEAD - 2; ++i) { ps[i] = q.s[i + 2]; pe[i] = q.e[i + 2]; }
+    int32_t *const Sp = st.S + st.loc; uint32_t *const LWp = st.LW + st.loc;
+    // exon j of the read: row j + 1, the last one row 0
+    SlabRow R0 = n == 1u ? q.last : q.x[0], R1 = n == 2u ? q.last : q.x[1], R2 = n == 3u ? q.last : q.x[2], R3 = n == 4u ? q.last : q.x[3];
     const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
     const int k_max = wave_max(mapping ? (int)n : 0);
+    const uint32_t nm1 = mapping ? n - 1u : 0u;         // (lanes that map nothing keep loading their row 0: a valid address, no branch)
     // The bucket ranges of exon k + 1 are looked up while exon k's entries are compared (the directory bytes and the entries
     // are two dependent LDS round trips: one of them per exon is taken off the chain).
     auto buckets = [&](int k, int sv, int ev, uint32_t &ls, uint32_t &hs, uint32_t &le, uint32_t &he) {
@@ -252,21 +325,24 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         ls = L.dir0[is]; hs = L.dir0[is + 1u]; le = L.dir1[ie]; he = L.dir1[ie + 1u];
     };
     uint32_t ls, hs, le, he;
-    buckets(0, s, e, ls, hs, le, he);
-    for (int k = 0; k < k_max; ++k) {
+    buckets(0, R0.s, slab_row_end(R0), ls, hs, le, he);
+    auto round = [&](int k, SlabRow &cur, const SlabRow &nxt, bool reload) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
-        int s4 = 0, e4 = 0;
-        if (mapping) { const uint32_t i4 = off + min((uint32_t)k + (uint32_t)SLAB_AHEAD, n - 1u) * SLAB_STRIDE; s4 = ld32(xs, i4); e4 = (int)ld32(xl, i4); }   // SLAB_AHEAD rows in flight (e4: the length until the row is used)
-        const int s2 = s1;
+        const int s = cur.s, e = slab_row_end(cur), s2 = nxt.s, e2 = slab_row_end(nxt);
+        const uint32_t lw = cur.l;
         const v4i_t qs0 = lds_entry(L.ent0, ls);
         const v4i_t qe0 = lds_entry(L.ent1, le), qe1 = lds_entry(L.ent1, le + 1u);
         uint32_t ls_n, hs_n, le_n, he_n;
-        buckets(k + 1, s1, e1, ls_n, hs_n, le_n, he_n);
+        buckets(k + 1, s2, e2, ls_n, hs_n, le_n, he_n);
         uint32_t xm, am, jm, dm;
         {   const bool m0 = ls < hs && qs0.x == s;
             am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
         probe2(qe0, qe1, le, he, e, s2, jm, dm);
         if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(L.ent0, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + 2u, he, e, s2, jm, dm, 0u); }
+        if (reload) {                                   // exon k + 4 into the registers of exon k
+            const uint32_t j = (uint32_t)k + (uint32_t)SLAB_AHEAD;
+            cur = slab_load_row(xs, xl, off + (j < nm1 ? j + 1u : 0u) * SLAB_STRIDE);
+        }
         const uint32_t amj = junc ? am : 0u;
         uint32_t word = first_member(xm & vpre);
         word |= first_member(jm & vpre) << 6;
@@ -276,20 +352,30 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         m.kor |= amj | dm;
         if (k == 0) m.dm_first = dm;
         m.am_last = (live && !junc) ? am : m.am_last;
-        if (live) W[(uint32_t)k * SLAB_STRIDE] = (uint16_t)word;
-        s = s1; e = e1; s1 = ps[0]; e1 = pe[0];
-#pragma unroll
-        for (int i = 0; i + 1 < SLAB_AHEAD - 2; ++i) { ps[i] = ps[i + 1]; pe[i] = pe[i + 1]; }
-        ps[SLAB_AHEAD - 3] = s4; pe[SLAB_AHEAD - 3] = s4 + e4 - 1;
+        if (live) { Sp[k] = s; LWp[k] = (lw & 0xffffu) | (word << 16); }
         ls = ls_n; hs = hs_n; le = le_n; he = he_n;
+    };
+    static_assert(SLAB_AHEAD == 4, "the round loop is unrolled by the number of exons in flight");
+    // whole groups of four rounds (one back edge, no exit inside: the wait in front of a row then counts the loads behind it),
+    // then up to three more rounds that ask for nothing
+    int k = 0;
+    for (; k + SLAB_AHEAD <= k_max; k += SLAB_AHEAD) {
+        round(k, R0, R1, true); round(k + 1, R1, R2, true); round(k + 2, R2, R3, true); round(k + 3, R3, R0, true);
+    }
+    if (k < k_max) {
+        round(k, R0, R1, false);
+        if (k + 1 < k_max) {
+            round(k + 1, R1, R2, false);
+            if (k + 2 < k_max) round(k + 2, R2, R3, false);
+        }
     }
     return m;
 }
 
-// The tile's dictionary slices into LDS, re-based to the tile's window (entries loaded by fused_load_dict: one START and one
+// The tile's dictionary slices into LDS, re-based to the tile's window (entries loaded by load_dict_slices: one START and one
 // END entry per thread, directory words two per thread).  `win`: the window's transcript numbers (gapped windows).
 struct SlabLds { uint16_t *W; v4i_t *ent0, *ent1; uint8_t *dir0, *dir1, *rdir; };
-__device__ __forceinline__ int slab_stage_dict(const TileDesc &d, const FusedDict &dv, const int *win, const SlabLds &S)
+__device__ __forceinline__ int slab_stage_dict(const TileDesc &d, const DictRegs &dv, const int *win, const SlabLds &S)
 {
     const bool fast = (d.flags & TD_FAST) != 0;
     const int w_n = fast ? (int)d.n_win : 0;
@@ -332,36 +418,90 @@ __device__ __forceinline__ int slab_stage_dict(const TileDesc &d, const FusedDic
     return my_wide;
 }
 
+// diagnostics (L2R_STAMPS=1): cycles of wave 0 per phase of k_probe_slab summed over the tiles -- [0] loads until the staging,
+// [1] staging + barrier, [2] window pass, [3] probe rounds, [4] verdicts, [5] write-out -- and of the last wave: [6] whole kernel,
+// [7] probe rounds.  One lane of the two waves stamps; nothing is stamped (one uniform branch per phase) without the buffer.
+struct SlabStamp {
+    unsigned long long *p; unsigned long long t, t0; int who;       // who: 0 wave 0, 3 last wave, -1 nobody
+    __device__ __forceinline__ void start(unsigned long long *buf)
+    {
+        p = buf; who = -1;
+        if (buf && (threadIdx.x & (WAVE - 1)) == 0) { const int wv = threadIdx.x >> 6; who = wv == 0 ? 0 : (wv == TILE_THREADS / WAVE - 1 ? 3 : -1); }
+        t = t0 = buf ? __builtin_readcyclecounter() : 0ull;
+    }
+    __device__ __forceinline__ void mark(int phase)
+    {
+        if (!p) return;
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (who == 0) atomicAdd(&p[(blockIdx.x & 1023u) * 8u + (uint32_t)phase], now - t);
+        if (who == 3 && phase == 3) atomicAdd(&p[(blockIdx.x & 1023u) * 8u + 7u], now - t);
+        if (who == 3 && phase == 5) atomicAdd(&p[(blockIdx.x & 1023u) * 8u + 6u], now - t0);
+        t = now;
+    }
+};
+
+// Exons that no probe round has left in LDS: a slab read that maps nothing (one exon, a read for the generic kernel), or an outlier
+// (its exons wait in the dense area).  Into the staged positions when the read fits there, else straight into the result arrays.
+// Flags 0: the generic kernel writes them for the reads it takes, a one-exon read's flag follows from its verdict.
+struct SlabOut { int32_t *start, *end; uint8_t *flag; uint32_t dst; };     // the read-order arrays, exon k of the lane's read at dst + k
+__device__ __forceinline__ void slab_copy_exons(SlabArgsK sa, const SlabOut &out, const SlabStage &st, const SlabRows &q, uint32_t off, uint32_t n, bool dense)
+{
+    // (an outlier's exons may be 64 kb and longer, which the 16-bit length of a staged position cannot say: written directly, its
+    //  positions marked so that the tile's write-out leaves them alone)
+    auto put = [&](uint32_t k, int s, int e) {
+        if (st.fits && !dense) { st.S[st.loc + k] = s; st.LW[st.loc + k] = (uint32_t)(e - s + 1) & 0xffffu; }
+        else {
+            out.start[out.dst + k] = s; out.end[out.dst + k] = e; out.flag[out.dst + k] = 0;
+            if (st.fits) st.LW[st.loc + k] = SLAB_POS_SKIP;
+        }
+    };
+    if (dense) {
+        const uint32_t run = (uint32_t)q.last.s;
+        for (uint32_t k = 0; k < n; ++k) put(k, sa->dense_start[run + k], sa->dense_end[run + k]);
+    } else if (n == 1u) {
+        put(0u, q.last.s, slab_row_end(q.last));
+    } else {
+        for (uint32_t k = 0; k < n; ++k) {
+            const SlabRow r = slab_load_row(sa->slab_start, sa->slab_len, off + slab_row(k, n) * SLAB_STRIDE);
+            put(k, r.s, slab_row_end(r));
+        }
+    }
+}
+
 // Verdicts of one tile's reads (slot order) from the staged window + dictionaries: the device functions of the classic kernel
-// on slab-resident exons; flags into the slab rows, info / ref_tx per read, redo list.
+// on slab-resident exons; exons, work words and then flag bytes at their positions in LDS (or, for a read that does not fit
+// there, in the result arrays), info / ref_tx / ex_off per read, redo list.
 template <int LEVEL>
-__device__ __forceinline__ void slab_classify(FusedArgsK a, const TileDesc &d, const SlabLds &S, const int4 *hk, const int4 *hx, const int *win,
-                                              const uint32_t *tilemask, bool active, uint32_t pre, uint32_t r, bool rev_in, int32_t tid,
-                                              uint32_t off, const SlabRows &q, const ReadEnds &re, int any_wide)
+__device__ __forceinline__ void slab_classify(SlabArgsK sa, PipeArgsK a, const TileDesc &d, const SlabLds &S, const int4 *hk, const int4 *hx, const int *win,
+                                              const uint32_t *tilemask, bool active, uint32_t pre, uint32_t r, uint32_t off, const SlabRows &q,
+                                              const ReadEnds &re, const SlabOut &out, const SlabStage &st, int any_wide, SlabStamp &stamp)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const bool fast = (d.flags & TD_FAST) != 0;
     const int w_n = fast ? (int)d.n_win : 0;
-    const uint32_t n = pre >> 8;
-    const bool outlier = (pre & I_PRE_DIRECT) != 0u;
-    const int32_t *const xs = a->f.ex_start; const uint16_t *const xl = a->f.ex_len;
-    uint16_t *const s_W = S.W;
+    const uint32_t n = pre >> PRE_N_SHIFT;
+    const bool outlier = (pre & PRE_DENSE) != 0u, rev_in = (pre & PRE_REV) != 0u;
+    const int32_t *const xs = sa->slab_start; const uint16_t *const xl = sa->slab_len;
     // ---- classification (device functions of the classic kernel)
     uint32_t info = n << 8; int ref = -1;
-    bool redo = active && (!fast || outlier || any_wide != 0 || tid != d.tid || (n > 1 && (pre & I_PRE_INSANE) != 0u));
+    // (sorted input: a tile is of one chromosome, the descriptor's)
+    bool redo = active && (!fast || outlier || !st.fits || any_wide != 0 || (n > 1 && (pre & PRE_INSANE) != 0u));
     const bool work = active && !redo;
-    const TileLds L{nullptr, nullptr, s_W, S.ent0, S.ent1, S.dir0, S.dir1, S.rdir, hk, hx, win};
+    // work words: the upper halves of the read's LW words (16-bit elements 2 * loc + 1, + 3, ...)
+    const TileLds L{nullptr, nullptr, reinterpret_cast<uint16_t *>(st.LW), S.ent0, S.ent1, S.dir0, S.dir1, S.rdir, hk, hx, win};
     const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, tilemask);
     redo = redo || vm.redo;
-    const SiteMasks sm = map_exons_slab(L, d, work && !redo && n > 1, xs, xl, off, n, vm.vpre, q);
-    uint8_t *const xf = a->f.ex_flag;
+    stamp.mark(2);
+    const bool mapping = work && !redo && n > 1;
+    const SiteMasks sm = map_exons_slab(L, d, mapping, xs, xl, off, n, vm.vpre, q, st);
+    stamp.mark(3);
+    if (active && !mapping) slab_copy_exons(sa, out, st, q, off, n, outlier);
     if (work && !redo) {
-        const Verdict vd = decide<LEVEL, (int)SLAB_STRIDE>(L, d, threadIdx.x, n, re, vm, sm, rev_in);
+        uint16_t *const Wf = reinterpret_cast<uint16_t *>(st.LW) + 2u * st.loc + 1u;
+        const Verdict vd = decide<LEVEL, 2>(L, d, 2u * st.loc + 1u, n, re, vm, sm, rev_in, [&](int k, uint32_t f) { Wf[2 * k] = (uint16_t)f; });
         info = vd.info; ref = vd.ref;
-        for (uint32_t k = 0; k < n; ++k) st32(xf, off + k * SLAB_STRIDE, (uint8_t)s_W[k * SLAB_STRIDE + threadIdx.x]);       // (rows: coalesced)
-    } else if (active && !outlier) {
-        for (uint32_t k = 0; k < n; ++k) st32(xf, off + k * SLAB_STRIDE, (uint8_t)0);
     }
+    stamp.mark(4);
     redo = redo && active;
     {
         const unsigned long long m = __ballot(redo);
@@ -369,101 +509,116 @@ __device__ __forceinline__ void slab_classify(FusedArgsK a, const TileDesc &d, c
             uint32_t at = 0;
             if (lane == 0) at = atomicAdd(a->f.redo_count, (uint32_t)__popcll(m));
             at = __shfl(at, 0, WAVE);
-            if (redo) { a->f.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r; if (!outlier) a->f.ex_off[r] = off; }      // (see slab_walk)
+            if (redo) a->f.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
         }
     }
-    if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; }
+    if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; a->f.ex_off[r] = out.dst; }
+}
+
+// The staged positions [0, lim) of the tile -> the tile's block of the read-order result arrays (first slot xbase): 16-byte stores
+// of starts and ends, 4-byte stores of four flag bytes, at whatever alignment xbase has.
+__device__ __forceinline__ void slab_write_out(const SlabOut &out0 /* dst = xbase */, const int32_t *S, const uint32_t *LW, uint32_t lim)
+{
+    for (uint32_t p = threadIdx.x * 4u; p < lim; p += (uint32_t)TILE_THREADS * 4u) {
+        const v4i_t s4 = *reinterpret_cast<const v4i_t *>(S + p);
+        const v4i_t w4 = *reinterpret_cast<const v4i_t *>(LW + p);
+        v4i_t e4;
+        e4.x = s4.x + (int)((uint32_t)w4.x & 0xffffu) - 1; e4.y = s4.y + (int)((uint32_t)w4.y & 0xffffu) - 1;
+        e4.z = s4.z + (int)((uint32_t)w4.z & 0xffffu) - 1; e4.w = s4.w + (int)((uint32_t)w4.w & 0xffffu) - 1;
+        const uint32_t f4 = (((uint32_t)w4.x >> 16) & 0xffu) | ((((uint32_t)w4.y >> 16) & 0xffu) << 8) | ((((uint32_t)w4.z >> 16) & 0xffu) << 16) | (((uint32_t)w4.w >> 16) << 24);
+        const uint32_t at = out0.dst + p;
+        if (p + 4u <= lim && !(((uint32_t)w4.x | (uint32_t)w4.y | (uint32_t)w4.z | (uint32_t)w4.w) & SLAB_POS_SKIP)) {
+            *reinterpret_cast<v4i_a4 *>(out0.start + at) = s4;
+            *reinterpret_cast<v4i_a4 *>(out0.end + at) = e4;
+            *reinterpret_cast<u32_a1 *>(out0.flag + at) = f4;
+        } else {
+            const int sv[4] = {s4.x, s4.y, s4.z, s4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+            const uint32_t wv[4] = {(uint32_t)w4.x, (uint32_t)w4.y, (uint32_t)w4.z, (uint32_t)w4.w};
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i)
+                if (p + i < lim && !(wv[i] & SLAB_POS_SKIP)) { out0.start[at + i] = sv[i]; out0.end[at + i] = ev[i]; out0.flag[at + i] = (uint8_t)(wv[i] >> 16); }
+        }
+    }
 }
 
 template <int LEVEL>
-__global__ __launch_bounds__(TILE_THREADS, 8)
-void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint8_t *__restrict__ u_order,
-                  const int32_t *__restrict__ u_tid, const uint32_t *__restrict__ u_tile_sbase, const TileWin *__restrict__ u_tw)
+__global__ __launch_bounds__(TILE_THREADS, 6)
+void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint32_t *__restrict__ u_tile_sbase,
+                  const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase /* first result slot of every tile: the scanned exon counts (+ the total) */)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
-    __shared__ __attribute__((aligned(16))) uint16_t s_W[SLAB_ROWS * TILE_THREADS];
+    __shared__ __attribute__((aligned(16))) int32_t s_S[SLAB_POS_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_LW[SLAB_POS_CAP];
     __shared__ __attribute__((aligned(16))) v4i_t s_ent[2 * SLAB_KEY_CAP];
     __shared__ __attribute__((aligned(16))) uint8_t s_dir[3 * DIR_BYTES];
     __shared__ __attribute__((aligned(16))) TileWin s_tw;
+    __shared__ int s_widew[TILE_THREADS / WAVE];
+    __shared__ uint32_t s_lim;
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
-    const FusedArgsK a = fused_args();
+    const PipeArgsK a = pipe_args();
     const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
     if (t >= sa->n_tiles) return;
+    SlabStamp stamp; stamp.start(a->f.stamps);
     const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
-    const int32_t tid0 = n_act ? u_tid[r0] : 0;
-    const uint32_t sbase = u_tile_sbase[t];
+    const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t], total = u_xbase[t + 1u] - xbase;
     v4i_t *const s_ent0 = s_ent, *const s_ent1 = s_ent + SLAB_KEY_CAP;
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
     // ---- one round trip behind the descriptor (scalar loads: uniform address): the tile's dictionary slices, its window
-    //      (k_walk_slab), the slot's read and the first four rows of its column -- all asked for before anything is looked at
+    //      (k_walk_slab), the slot's words and rows 0 .. 4 of its column (the last exon and the first four) -- all asked for
+    //      before anything is looked at, and nothing of it at an address that depends on another load
     const TileDesc d = u_tw[t].d;
     if (t == 0u && threadIdx.x == 0 && sa->wide_cnt) {          // (k_walk_slab is done: its count of wide tiles moves on, the counter is cleared for the next run)
         sa->wide_cnt[1] = min(sa->wide_cnt[0], sa->wide_cap); sa->wide_cnt[0] = 0u;
     }
     if (d.flags & TD_WIDE) return;                               // k_probe_slab_wide takes the tile
-    // the last row any read of this wave has (k_walk_slab): rows behind it are not asked for
+    // the rows any read of this wave has (k_walk_slab): rows behind them are not asked for
     const uint32_t row_max = max((u_tw[t].pad[0] >> (8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))) & 0xffu, 1u) - 1u;
-    const FusedDict dv = fused_load_dict(a, d);
+    const DictRegs dv = load_dict_slices(a, d);
     int4 twv = make_int4(0, 0, 0, 0);
     if ((int)threadIdx.x < SLAB_TW_VECS && tw_vec_used((int)threadIdx.x, (d.flags & TD_FAST) ? d.n_win : 0u)) twv = reinterpret_cast<const int4 *>(u_tw + t)[threadIdx.x];
     const bool active = threadIdx.x < n_act;
     const uint32_t at = r0 + (active ? threadIdx.x : 0u);
-    uint32_t pre = 0u, r = r0;
-    bool rev_in = false;
-    const int32_t *const xs = a->f.ex_start; const uint16_t *const xl = a->f.ex_len;
+    uint32_t pre = 0u, loc = 0u;
+    const int32_t *const xs = sa->slab_start; const uint16_t *const xl = sa->slab_len;
     const uint32_t off = sbase + threadIdx.x;
     SlabRows q;
+    q.last = SlabRow{0, 0u};
 #pragma unroll
-    for (int i = 0; i < SLAB_AHEAD; ++i) { q.s[i] = 0; q.e[i] = 0; }
+    for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = SlabRow{0, 0u};
     if (active) {
-        pre = ld32(sa->pre, at); r = r0 + (uint32_t)ld32(u_order, at); rev_in = ld32(sa->s_rev, at) != 0;
+        pre = ld32(sa->pre, at); loc = ld32(sa->loc, at);
+        q.last = slab_load_row(xs, xl, off);
 #pragma unroll
-        for (int i = 0; i < SLAB_AHEAD; ++i) {      // (an outlier's slab column holds nothing: read, not used)
-            const uint32_t ix = off + min((uint32_t)i, row_max) * SLAB_STRIDE;
-            q.s[i] = ld32(xs, ix); q.e[i] = (int)ld32(xl, ix);           // (the length: turned into the end below)
-        }
+        for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = slab_load_row(xs, xl, off + min((uint32_t)i + 1u, row_max) * SLAB_STRIDE);      // (an outlier's column holds nothing: read, not used)
     }
-    if (threadIdx.x == 0 && t == 0u) *sa->ovf_cursor = 0ull;        // (k_walk_slab is done with the outlier area)
-    const uint32_t n = pre >> 8;
-    const bool outlier = (pre & I_PRE_DIRECT) != 0u;
-    const int32_t tid = tid0;                                       // (sorted input: a tile is of one chromosome)
-#pragma unroll
-    for (int i = 0; i < SLAB_AHEAD; ++i) q.e[i] = q.s[i] + q.e[i] - 1;
-    ReadEnds re{q.s[0], q.e[0], 0, 0};
-    if (active && !outlier) { re.sl = ld32(xs, off + (n - 1u) * SLAB_STRIDE); re.el = re.sl + (int)ld32(xl, off + (n - 1u) * SLAB_STRIDE) - 1; }
+    if (threadIdx.x == 0) { s_lim = min(total, (uint32_t)SLAB_POS_CAP); if (t == 0u) *sa->ovf_cursor = 0ull; }     // (k_walk_slab is done with the outlier area)
+    const uint32_t n = pre >> PRE_N_SHIFT;
+    const uint32_t r = r0 + (pre & 0xffu);
+    const SlabRow first = n == 1u ? q.last : q.x[0];
+    const ReadEnds re{first.s, slab_row_end(first), q.last.s, slab_row_end(q.last)};
+    const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
+    const SlabStage st{s_S, s_LW, loc, loc + n <= (uint32_t)SLAB_POS_CAP};
+    if (stamp.p) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp.mark(0);
     // ---- stage window and dictionary slices, re-based to the tile's window
     if ((int)threadIdx.x < SLAB_TW_VECS) reinterpret_cast<int4 *>(&s_tw)[threadIdx.x] = twv;
-    const SlabLds S{s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir};
+    const SlabLds S{nullptr, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir};
     // (the window's transcript numbers: straight from the loaded vectors' home, they are not in LDS yet)
     const int my_wide = slab_stage_dict(d, dv, reinterpret_cast<const int *>(u_tw[t].win), S);
-    const int any_wide = __syncthreads_or(my_wide);
-    slab_classify<LEVEL>(a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, r, rev_in, tid, off, q, re, any_wide);
-}
-
-__global__ __launch_bounds__(TILE_THREADS)
-void k_exon_counts(int64_t n_reads, const uint32_t *__restrict__ info, uint32_t *__restrict__ out)
-{
-    const int64_t r = (int64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
-    if (r < n_reads) out[r] = info[r] >> 8;
-}
-
-// Slabs -> read order (l2r_download): one thread per read, dest[r] = running sum of the exon counts in read order.
-__global__ __launch_bounds__(TILE_THREADS)
-void k_linearize_slab(const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_sbase, const uint8_t *__restrict__ order,
-                      const uint32_t *__restrict__ pre, const uint32_t *__restrict__ ex_off, const uint32_t *__restrict__ info, const uint32_t *__restrict__ dest,
-                      const int32_t *__restrict__ xs, const int32_t *__restrict__ xe, const uint8_t *__restrict__ xf,
-                      int32_t *__restrict__ os, int32_t *__restrict__ oe, uint8_t *__restrict__ of, const uint16_t *__restrict__ xl)
-{
-    // one workgroup per tile, one thread per slot: a slab read sits at its tile's slab + its slot, a densely stored one at ex_off
-    const uint32_t t = blockIdx.x, r0 = tile_first[t], n_act = tile_first[t + 1u] - r0;
-    if (threadIdx.x >= n_act) return;
-    const uint32_t at = r0 + threadIdx.x, r = r0 + order[at];
-    const bool dense = (pre[at] & I_PRE_DIRECT) != 0u;
-    uint32_t off = dense ? ex_off[r] & ~EXOFF_DENSE : tile_sbase[t] + threadIdx.x;
-    const uint32_t n = info[r] >> 8, to = dest[r];
-    const uint32_t st = dense ? 1u : SLAB_STRIDE;
-    for (uint32_t k = 0; k < n; ++k) { os[to + k] = xs[off + k * st]; oe[to + k] = ex_end_at(xs, xe, xl, off + k * st, st); of[to + k] = xf[off + k * st]; }
+    {   // one barrier: every wave leaves its "some entry has members beyond its 64-bit masks" word, all read the four
+        const int w_any = __any(my_wide) ? 1 : 0;
+        if ((threadIdx.x & (WAVE - 1)) == 0) s_widew[threadIdx.x >> 6] = w_any;
+    }
+    __syncthreads();
+    const int any_wide = s_widew[0] | s_widew[1] | s_widew[2] | s_widew[3];
+    // the first read that does not fit the staged positions ends the block that is written from LDS (reads are in read order there)
+    if (active && !st.fits) atomicMin(&s_lim, loc);
+    stamp.mark(1);
+    slab_classify<LEVEL>(sa, a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, r, off, q, re, out, st, any_wide, stamp);
+    __syncthreads();
+    slab_write_out(SlabOut{out.start, out.end, out.flag, xbase}, s_S, s_LW, s_lim);
+    stamp.mark(5);
 }
 
 }  // namespace l2r

@@ -110,24 +110,25 @@ __device__ __forceinline__ m64_t overlapping_exon_members64(const uint8_t *rdir,
     return m;
 }
 
-// map_exons_slab on 64-bit masks (rows streamed from the slab column, two rows in flight: these tiles are rare)
+// map_exons_slab on 64-bit masks (rows streamed from the slab column, two exons in flight: these tiles are rare); every round
+// stores its exon into the read-order result arrays
 __device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const TileDesc &d, bool mapping, const int32_t *__restrict__ xs,
-                                                        const uint16_t *__restrict__ xl, uint32_t off, uint32_t n, m64_t vpre)
+                                                        const uint16_t *__restrict__ xl, uint32_t off, uint32_t n, m64_t vpre, const SlabOut &out)
 {
     SiteMasks64 m{~0ull, 0ull, 0ull, 0ull};
     uint16_t *W = L.W + threadIdx.x;
+    auto exon = [&](uint32_t j, int &s, int &e) {        // exon min(j, n - 1) of the read (row j + 1, the last one row 0)
+        const SlabRow r = slab_load_row(xs, xl, off + slab_row(min(j, n - 1u), n) * SLAB_STRIDE);
+        s = r.s; e = slab_row_end(r);
+    };
     int s = 0, e = 0, s1 = 0, e1 = 0;
-    if (mapping) {
-        s = ld32(xs, off); e = s + (int)ld32(xl, off) - 1;
-        const uint32_t i1 = off + min(1u, n - 1u) * SLAB_STRIDE;
-        s1 = ld32(xs, i1); e1 = s1 + (int)ld32(xl, i1) - 1;
-    }
+    if (mapping) { exon(0u, s, e); exon(1u, s1, e1); }
     const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
     const int k_max = wave_max(mapping ? (int)n : 0);
     for (int k = 0; k < k_max; ++k) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
         int s2n = 0, e2n = 0;
-        if (mapping) { const uint32_t i2 = off + min((uint32_t)k + 2u, n - 1u) * SLAB_STRIDE; s2n = ld32(xs, i2); e2n = s2n + (int)ld32(xl, i2) - 1; }
+        if (mapping) exon((uint32_t)k + 2u, s2n, e2n);
         const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
         const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
         const int s2 = s1;
@@ -144,16 +145,19 @@ __device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const 
         m.kor |= amj | dm;
         if (k == 0) m.dm_first = dm;
         m.am_last = (live && !junc) ? am : m.am_last;
-        if (live) W[(uint32_t)k * SLAB_STRIDE] = (uint16_t)word;
+        if (live) {
+            W[(uint32_t)k * SLAB_STRIDE] = (uint16_t)word;
+            st32(out.start, out.dst + (uint32_t)k, s); st32(out.end, out.dst + (uint32_t)k, e);
+        }
         s = s1; e = e1; s1 = s2n; e1 = e2n;
     }
     return m;
 }
 
 // decide (l2r_kernels.hip.h) on 64-bit masks; work words at W[k * 256]
-template <int LEVEL>
+template <int LEVEL, typename Emit>
 __device__ __forceinline__ Verdict decide64(const WideLds &L, const TileDesc &d, uint32_t n, const ReadEnds &re,
-                                            const VisitMasks64 &vm, const SiteMasks64 &sm, bool rev_in)
+                                            const VisitMasks64 &vm, const SiteMasks64 &sm, bool rev_in, Emit emit)
 {
     uint16_t *W = L.W + threadIdx.x;
     int jstar = -1;
@@ -193,9 +197,9 @@ __device__ __forceinline__ Verdict decide64(const WideLds &L, const TileDesc &d,
             uint32_t f = ((w & 127u) > lim ? (uint32_t)F_EXON : 0u) | (((w >> 7) & 127u) > lim ? (uint32_t)F_JUNC : 0u);
             if (!known) f |= (((w >> 14) & 1u) ? 0u : (uint32_t)F_DON) | (((w >> 15) & 1u) ? 0u : (uint32_t)F_ACC);
             f &= (k + 1 == (int)n) ? (uint32_t)F_EXON : 0xffu;                   // the last exon has no junction behind it
-            W[(uint32_t)k * SLAB_STRIDE] = (uint16_t)f;
+            emit(k, f);
         }
-    } else W[0] = (uint16_t)F_EXON;
+    } else emit(0, (uint32_t)F_EXON);
     int ref = -1;
     bool out_rev = rev_in;
     if (jref >= 0) { ref = L.win[jref]; out_rev = ((L.hk[jref].w >> 8) & 1) != 0; }     // :825-831
@@ -213,8 +217,8 @@ struct WideArgs { const uint32_t *wide_count; const uint32_t *wide_tile; const T
 
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, 4)
-void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__restrict__ u_tile_first, const uint8_t *__restrict__ u_order,
-                       const int32_t *__restrict__ u_tid, const uint32_t *__restrict__ u_tile_sbase)
+void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__restrict__ u_tile_first, const uint32_t *__restrict__ u_tile_sbase,
+                       const uint32_t *__restrict__ u_xbase)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
     __shared__ __attribute__((aligned(16))) uint16_t s_W[SLAB_ROWS * TILE_THREADS];
@@ -223,7 +227,7 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
     __shared__ __attribute__((aligned(16))) TileWin64 s_tw;
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
-    const FusedArgsK a = fused_args();
+    const PipeArgsK a = pipe_args();
     const int lane = threadIdx.x & (WAVE - 1);
     WEnt *const s_ent0 = s_ent, *const s_ent1 = s_ent + WIDE_KEY_CAP;
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
@@ -231,29 +235,33 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
     for (uint32_t wi = blockIdx.x; wi < n_wide; wi += gridDim.x) {
         const uint32_t t = wa.wide_tile[wi];
         const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
-        const int32_t tid0 = n_act ? u_tid[r0] : 0;
-        const uint32_t sbase = u_tile_sbase[t];
+        const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t];
         for (int i = (int)threadIdx.x; i < WIDE_TW_VECS; i += TILE_THREADS)
             reinterpret_cast<int4 *>(&s_tw)[i] = reinterpret_cast<const int4 *>(wa.tw64 + wi)[i];
         const bool active = threadIdx.x < n_act;
         const uint32_t at = r0 + (active ? threadIdx.x : 0u);
-        uint32_t pre = 0u, r = r0;
-        bool rev_in = false;
-        const int32_t *const xs = a->f.ex_start; const uint16_t *const xl = a->f.ex_len;
+        uint32_t pre = 0u, loc = 0u;
+        const int32_t *const xs = sa->slab_start; const uint16_t *const xl = sa->slab_len;
         const uint32_t off = sbase + threadIdx.x;
         ReadEnds re{0, 0, 0, 0};
-        if (active) { pre = ld32(sa->pre, at); r = r0 + (uint32_t)ld32(u_order, at); rev_in = ld32(sa->s_rev, at) != 0; }
-        const uint32_t n = pre >> 8;
-        const bool outlier = (pre & I_PRE_DIRECT) != 0u;
+        SlabRows q;
+        q.last = SlabRow{0, 0u};
+#pragma unroll
+        for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = SlabRow{0, 0u};
+        if (active) { pre = ld32(sa->pre, at); loc = ld32(sa->loc, at); q.last = slab_load_row(xs, xl, off); }
+        const uint32_t n = pre >> PRE_N_SHIFT;
+        const uint32_t r = r0 + (pre & 0xffu);
+        const bool outlier = (pre & PRE_DENSE) != 0u, rev_in = (pre & PRE_REV) != 0u;
         if (active && !outlier) {
-            re.s0 = ld32(xs, off); re.e0 = re.s0 + (int)ld32(xl, off) - 1;
-            re.sl = ld32(xs, off + (n - 1u) * SLAB_STRIDE); re.el = re.sl + (int)ld32(xl, off + (n - 1u) * SLAB_STRIDE) - 1;
+            const SlabRow f = slab_load_row(xs, xl, off + slab_row(0u, n) * SLAB_STRIDE);
+            re.s0 = f.s; re.e0 = slab_row_end(f); re.sl = q.last.s; re.el = slab_row_end(q.last);
         }
+        const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
         __syncthreads();
         const TileDesc d = s_tw.d;
         const int w_n = (int)d.n_win;
         // ---- stage the dictionary slices, masks re-based to the tile's window (64-bit)
-        const FusedDict dv = fused_load_dict(a, d);
+        const DictRegs dv = load_dict_slices(a, d);
         int my_wide = 0;
         if ((int)threadIdx.x < WIDE_KEY_CAP) {
             const bool has_st = threadIdx.x < d.st_nk, has_en = threadIdx.x < d.en_nk;
@@ -287,19 +295,18 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         const int any_wide = __syncthreads_or(my_wide);
         // ---- classification
         uint32_t info = n << 8; int ref = -1;
-        bool redo = active && (outlier || any_wide != 0 || tid0 != d.tid || (n > 1 && (pre & I_PRE_INSANE) != 0u));
+        bool redo = active && (outlier || any_wide != 0 || (n > 1 && (pre & PRE_INSANE) != 0u));
         const bool work = active && !redo;
         const WideLds L{s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
         const VisitMasks64 vm = visit_window64<LEVEL>(L, d, w_n, work, n, d.j_lo, re, s_tw.mask);
         redo = redo || vm.redo;
-        const SiteMasks64 sm = map_exons_slab64(L, d, work && !redo && n > 1, xs, xl, off, n, vm.vpre);
-        uint8_t *const xf = a->f.ex_flag;
+        const bool mapping = work && !redo && n > 1;
+        const SiteMasks64 sm = map_exons_slab64(L, d, mapping, xs, xl, off, n, vm.vpre, out);
+        if (active && !mapping) slab_copy_exons(sa, out, SlabStage{nullptr, nullptr, 0u, false}, q, off, n, outlier);
         if (work && !redo) {
-            const Verdict vd = decide64<LEVEL>(L, d, n, re, vm, sm, rev_in);
+            uint8_t *const of = out.flag; const uint32_t dst = out.dst;
+            const Verdict vd = decide64<LEVEL>(L, d, n, re, vm, sm, rev_in, [&](int k, uint32_t f) { st32(of, dst + (uint32_t)k, (uint8_t)f); });
             info = vd.info; ref = vd.ref;
-            for (uint32_t k = 0; k < n; ++k) st32(xf, off + k * SLAB_STRIDE, (uint8_t)s_W[k * SLAB_STRIDE + threadIdx.x]);
-        } else if (active && !outlier) {
-            for (uint32_t k = 0; k < n; ++k) st32(xf, off + k * SLAB_STRIDE, (uint8_t)0);
         }
         redo = redo && active;
         {
@@ -308,10 +315,10 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
                 uint32_t pos_r = 0;
                 if (lane == 0) pos_r = atomicAdd(a->f.redo_count, (uint32_t)__popcll(m));
                 pos_r = __shfl(pos_r, 0, WAVE);
-                if (redo) { a->f.redo[pos_r + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r; if (!outlier) a->f.ex_off[r] = off; }   // (see slab_walk)
+                if (redo) a->f.redo[pos_r + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
             }
         }
-        if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; }
+        if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; a->f.ex_off[r] = out.dst; }
         __syncthreads();                                        // (the next tile of this workgroup overwrites the LDS image)
     }
 }

@@ -48,9 +48,9 @@ def _chain(exons):
     return exons[0][0] - 1, ops
 
 
-@pytest.fixture(autouse=True, params=["slab", "fused", "classic"])
+@pytest.fixture(autouse=True, params=["slab", "classic"])
 def pipeline(request, monkeypatch):
-    """Every case runs on each of the engine's three kernel pipelines (l2r_engine.hip: L2R_PIPELINE is read by l2r_create;
+    """Every case runs on each of the engine's two kernel pipelines (l2r_engine.hip: L2R_PIPELINE is read by l2r_create;
     records the chosen pipeline cannot take -- unsorted, long CIGARs -- fall to the classic one by themselves)."""
     monkeypatch.setenv("L2R_PIPELINE", request.param)
     return request.param

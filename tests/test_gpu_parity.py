@@ -8,9 +8,9 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["slab", "fused", "classic"])
+@pytest.fixture(scope="module", params=["slab", "classic"])
 def engine(request):
-    """One engine per kernel pipeline (l2r_create reads L2R_PIPELINE): every case of this file runs on all three."""
+    """One engine per kernel pipeline (l2r_create reads L2R_PIPELINE): every case of this file runs on both."""
     import os
     old = os.environ.get("L2R_PIPELINE")
     os.environ["L2R_PIPELINE"] = request.param

@@ -1,0 +1,33 @@
+"""Diagnostics on the GPU box: A/B timing of engine variants selected by L2R_ABLATE bits (read at l2r_create), all on ONE box and
+one workload: tools/ab.py <reads> <config> <ablate values ...>.  Prints the per-kernel milliseconds of l2r_run_timed per value,
+interleaved over several rounds so that clock drift hits every variant alike.  Not part of the product."""
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from lr2rmats_amd import capi, workload
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000000
+cfgname = sys.argv[2] if len(sys.argv) > 2 else 'cfg3'
+vals = [int(x) for x in sys.argv[3:]] or [0]
+rounds = int(os.environ.get("AB_ROUNDS", "3"))
+iters = int(os.environ.get("AB_ITERS", "20"))
+cfg = dict(workload.CONFIGS[cfgname]); cfg['n_reads'] = N
+af, reads = workload.make_rank_workload(cfg, 0, 1)
+engines = {}
+for v in vals:
+    os.environ["L2R_ABLATE"] = str(v)
+    e = capi.Engine(0)
+    e.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
+    e.set_params(capi.default_params(full_level=int(os.environ.get("L2R_LEVEL", "3"))))
+    e.set_outputs(int(os.environ.get("L2R_WANT", "1")))
+    e.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)
+    e.run(); e.sync()
+    engines[v] = e
+acc = {v: [] for v in vals}
+for _ in range(rounds):
+    for v in vals:
+        tm = engines[v].run_timed(iters)
+        acc[v].append(tm)
+for v in vals:
+    best = min(acc[v], key=lambda t: t["total_ms"])
+    ks = {k.split(" ")[0]: round(x, 4) for k, x in best["kernel_ms"].items() if x > 0.003}
+    print("ablate %3d: total %.4f ms (rounds: %s) %s" % (v, best["total_ms"], " ".join("%.4f" % t["total_ms"] for t in acc[v]), ks))
