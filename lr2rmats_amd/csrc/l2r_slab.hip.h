@@ -573,15 +573,19 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     }
     if (d.flags & TD_WIDE) return;                               // k_probe_slab_wide takes the tile
     // the rows any read of this wave has (k_walk_slab): rows behind them are not asked for
-    const uint32_t row_max = max((u_tw[t].pad[0] >> (8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))) & 0xffu, 1u) - 1u;
+    // thread -> slot: the slot groups (k_walk_slab: by falling CIGAR length, group 0 = the tile's longest reads) are rotated over
+    // the waves by a hash of the tile number (L2R_ABLATE bit 3: off)
+    const uint32_t rot = (a->f.p.ablate & 8) ? 0u : ((t ^ (t >> 3) ^ (t >> 7)) & 3u);
+    const uint32_t slot = (threadIdx.x + (rot << 6)) & (uint32_t)(TILE_THREADS - 1);
+    const uint32_t row_max = max((u_tw[t].pad[0] >> (8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot >> 6)))) & 0xffu, 1u) - 1u;
     const DictRegs dv = load_dict_slices(a, d);
     int4 twv = make_int4(0, 0, 0, 0);
     if ((int)threadIdx.x < SLAB_TW_VECS && tw_vec_used((int)threadIdx.x, (d.flags & TD_FAST) ? d.n_win : 0u)) twv = reinterpret_cast<const int4 *>(u_tw + t)[threadIdx.x];
-    const bool active = threadIdx.x < n_act;
-    const uint32_t at = r0 + (active ? threadIdx.x : 0u);
+    const bool active = slot < n_act;
+    const uint32_t at = r0 + (active ? slot : 0u);
     uint32_t pre = 0u, loc = 0u;
     const int32_t *const xs = sa->slab_start; const uint16_t *const xl = sa->slab_len;
-    const uint32_t off = sbase + threadIdx.x;
+    const uint32_t off = sbase + slot;
     SlabRows q;
     q.last = SlabRow{0, 0u};
 #pragma unroll
