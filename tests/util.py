@@ -48,3 +48,53 @@ def assert_same_result(got, want, n_sj, split):
     cand = ((w & 4) != 0) & ((w & 1) == 0) & ((w & 2) != 0)
     acc = cand & ((n_sj == 0) | ((w & 64) != 0) | bool(split))
     np.testing.assert_array_equal((got.info & 128) != 0, acc)
+
+
+# ---- seeded whole-file fixtures (tests/golden/seeds.sha256, made by tools/make_seed_hashes.py) ------------------------------
+SEED_FILES = ("updated.gtf", "detail.txt", "novel_exon.bed")
+SEED_SETS = ("first", "second")          # `-l 3` and `-s -l 3 -J 1 -j SJ.tab -A -E -y`
+SEEDS = (1, 2, 3, 4, 5)
+
+
+def seed_inputs(po, seed, d):
+    """BASELINE configs[1] with generator seed `seed` (100 k reads x 5 exons, 50 k-exon GTF) as files in directory `d`:
+    reads.sam, anno.gtf and the junction table of the pipeline's second pass (80 % of the novel junctions of the first pass,
+    from the ORACLE's first-pass classification: the inputs do not depend on the engine under test)."""
+    import os
+    anno = synth.make_annotation(50_000, seed)
+    reads = synth.make_reads(anno, 100_000, 5, seed)
+    af = anno.in_file_order()
+    sam, gtf, tab = os.path.join(d, "reads.sam"), os.path.join(d, "anno.gtf"), os.path.join(d, "SJ.out.tab")
+    reads.write_sam(sam)
+    anno.write_gtf(gtf)
+    base = oracle_run(po, af, reads, po.default_params(full_level=3))
+    j, _ = junction_table(af, reads, base, seed, cover=0.8)
+    j.write(tab)
+    return sam, gtf, tab
+
+
+def seed_args(which, sam, gtf, tab, out):
+    """argv of `update-gtf` for option set `which`; out = {file name: path} for SEED_FILES + summary.txt."""
+    extra = ["-l", "3"] if which == "first" else ["-s", "-l", "3", "-J", "1", "-j", tab]
+    return ["update-gtf"] + extra + ["-A", out["detail.txt"], "-E", out["novel_exon.bed"], "-y", out["summary.txt"], "-o", out["updated.gtf"], sam, gtf]
+
+
+def sha256_file(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for blk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def read_seed_hashes():
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seeds.sha256")
+    out = {}
+    with open(path) as fh:
+        for line in fh:
+            if line.strip() and not line.startswith("#"):
+                digest, name = line.split()
+                out[name] = digest
+    return out
