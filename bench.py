@@ -150,8 +150,9 @@ def pmc_traffic(kernels, config: str, n_reads: int):
     if t.get("config") != config or t.get("reads") != n_reads:
         return None, "PMC file is for another config / read count"
     out = {}
+    alias = {"k_scan_tiles": "k_scan_u32"}            # (stage name of l2r_stage_kernel -> kernel name in the profile)
     for k in kernels:
-        ent = t.get("kernels", {}).get(k)
+        ent = t.get("kernels", {}).get(alias.get(k, k))
         if ent is None:
             return None, "PMC file has no kernel %s" % k
         out[k] = ent["hbm_bytes_per_launch"]

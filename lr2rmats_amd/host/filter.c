@@ -629,9 +629,20 @@ int h_filter_run(const char *in_fn, const char *remove_fn, const l2r_filter_para
         spans.n = g.n_tx; spans.tid = g.tid; spans.start = g.start; spans.end = g.end;
     }
     /* the reference dereferences the NM tag without a test (bam_aux2i(bam_aux_get(b, "NM")), src/bam_filter.c:78-80):
-     * a mapped record without it is the end of that run; here it is an error message */
-    for (int64_t i = 0; i < r.n; ++i) if (!(r.flag[i] & 4) && !r.nm_seen[i])
-        h_fatal("bam_filter", "alignment record %lld has no NM tag (the reference reads it unconditionally)", (long long)i);
+     * a record without it that gets there is the end of that run; here it is an error message */
+    /* ... but only for a record that REACHES that read: gtf_filter() returns on an unmapped record and on one that fails the
+     * coverage test (src/bam_filter.c:63,77) before it looks for NM, so such a record is dropped without one */
+    for (int64_t i = 0; i < r.n; ++i) if (!(r.flag[i] & 4) && !r.nm_seen[i]) {
+        const int64_t c0 = r.cig_off[i], c1 = r.cig_off[i + 1];
+        int32_t qlen = r.l_qseq[i];
+        if (c1 > c0) {
+            const uint32_t w0 = r.cig[c0], w1 = r.cig[c1 - 1];
+            if ((w0 & 0xfu) == 4u || (w0 & 0xfu) == 5u) qlen -= (int32_t)(w0 >> 4);
+            if (c1 - c0 > 1 && ((w1 & 0xfu) == 4u || (w1 & 0xfu) == 5u)) qlen -= (int32_t)(w1 >> 4);
+        }
+        if (!(((double)qlen + 0.0) / (double)r.l_qseq[i] < (double)prm->cov_rate))
+            h_fatal("bam_filter", "alignment record %lld passes the coverage test and has no NM tag (the reference reads it there without a test)", (long long)i);
+    }
     h_stage_time("read -r annotation");
     l2r_ctx *ctx = l2r_create(0);
     if (!ctx) h_fatal("bam_filter", "%s", l2r_last_error());

@@ -100,7 +100,11 @@ uint32_t h_str_add(h_strtab *t, const char *s)
 
 int h_chrom_find(const h_chroms *c, const char *s, int limit)
 {
-    for (int i = 0; i < limit; ++i) if (strcmp(c->name[i], s) == 0) return i;
+    /* records and GTF lines come grouped by chromosome: the last hit of this thread is tried first (a hint only: it is checked
+       against the table it is used on), so an assembly with thousands of contigs does not cost a scan per record */
+    static __thread int last = 0;
+    if (last < limit && strcmp(c->name[last], s) == 0) return last;
+    for (int i = 0; i < limit; ++i) if (strcmp(c->name[i], s) == 0) { last = i; return i; }
     return -1;
 }
 

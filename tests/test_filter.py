@@ -435,3 +435,23 @@ def test_hip_filter_long_cigar_record(tmp_path):
     open(bam, "wb").write(fo.bgzf_blocks(fo.header_bytes(header, refs) + b"".join(fo.encode_record(r, idx) for r in recs)))
     _run_filter(["-i", "1", bam], out)
     assert _inflate(out) == want
+
+
+@pytest.mark.gpu
+def test_hip_filter_reads_nm_only_behind_the_coverage_test(tmp_path):
+    """gtf_filter() looks for the NM tag after the coverage test (src/bam_filter.c:77-80): a record that fails coverage is dropped
+    without one; a record that passes coverage without one ends the reference's run (a null pointer there, a message here)."""
+    rng = np.random.default_rng(7)
+    ok, out = str(tmp_path / "ok.sam"), str(tmp_path / "out.bam")
+    with open(ok, "w") as fh:
+        fh.write(HDR)
+        fh.write(_line("a", 0, "chr1", 10, "60S40M", _seq(rng, 100), None))       # coverage 0.4, no NM: dropped, no error
+        fh.write(_line("b", 0, "chr1", 10, "100M", _seq(rng, 100), 1))
+    err = _run_filter([ok], out)
+    assert "Filtered alignments: 1" in err
+    bad = str(tmp_path / "bad.sam")
+    with open(bad, "w") as fh:
+        fh.write(HDR)
+        fh.write(_line("a", 0, "chr1", 10, "100M", _seq(rng, 100), None))         # passes coverage, no NM
+    r = hostlib.run_cli(["filter", bad], stdout_path=out)
+    assert r.returncode == 1 and b"no NM tag" in r.stderr
