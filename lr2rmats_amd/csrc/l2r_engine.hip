@@ -754,7 +754,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     HIP_TRY(hipStreamSynchronize(c->stream));                              // (tile_first is a local)
 
     if (c->r_tid.ensure((size_t)N) || c->r_pos.ensure((size_t)N) || c->r_rev.ensure((size_t)N) ||
-        c->cig_off.ensure((size_t)N + 1) || c->cig.ensure((size_t)r->n_cigar + 4)) return -2;     // + 4: the tile staging reads whole 16-byte vectors
+        c->cig_off.ensure((size_t)N + 1) || c->cig.ensure((size_t)r->n_cigar + 8)) return -2;     // + 8: the kernels read whole 16-byte vectors (pass A: two per lane)
     if (N) {
         HIP_TRY(hipMemcpyAsync(c->r_tid.p, r->tid, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->r_pos.p, r->pos, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));

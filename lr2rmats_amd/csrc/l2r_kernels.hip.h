@@ -30,6 +30,10 @@
 
 namespace l2r {
 
+typedef int v4i_t __attribute__((ext_vector_type(4)));                    // (LDS copy of a dictionary entry {k1, k2, pm, sm}, masks in the tile frame)
+typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));       // a 16-byte access at any 4-byte boundary (global memory)
+typedef uint32_t u32_a1 __attribute__((aligned(1)));                      // a 4-byte access at any address (global memory)
+
 constexpr int TILE_THREADS = 256;
 constexpr int WAVE = 64;
 constexpr int LDS_EXON_CAP = 3072;      // exons of one tile staged in LDS (10 B each)
@@ -249,6 +253,82 @@ __device__ __forceinline__ int walk_cigar_headed(const CigarHead &h, const uint3
     return w.n + 1;
 }
 
+// ONE READ walked by ONE WAVE (long CIGARs: ONT-like reads, hundreds of ops): src/bam2gtf.c:31-78 as a scan over the op stream.
+// Lane L takes eight consecutive CIGAR words per round (two 16-byte loads; the wave reads 2 KB of the stream at a time, coalesced --
+// a lane per read fetches a 64-byte sector of its own per load).  A round:
+//   reference end before every op     = pos + sum of the reference-consuming lengths in front of it    (wave prefix sum + carry)
+//   a cut op (N >= min_intron, D > max_delet) closes the candidate exon [start behind the previous cut, end before this op];
+//   "start behind the previous cut"    = running maximum of end + len + 1 over the cut ops in front      (wave prefix max + carry)
+//   the candidate is kept iff it is the read's first or min_exon long (a dropped one is skipped, not merged: Q4), its exon
+//   number = kept candidates in front  (wave prefix sum + carry); the cut ops are found with a wave ballot.
+// emit(k, start, end) is called by the lane that holds the cut op.  The caller keeps the first round of the wave's NEXT read in
+// flight while this one is walked (wave_chunk_load / wave_chunk_walk): a wave on its own has one round trip to HBM per round.
+constexpr int WCHUNK = 8;                                // CIGAR words per lane and round
+struct WaveChunk { uint32_t w[WCHUNK]; };
+struct WaveWalk { int ref_end, cur_start; uint32_t n_kept; bool seen_cut; };    // (wave-uniform carries of one read)
+
+// words [base + 8 lane, + 8) of a read's CIGAR (the array is padded by 8 words: a lane that starts inside the read reads on)
+__device__ __forceinline__ WaveChunk wave_chunk_load(const uint32_t *__restrict__ cig, uint32_t n_cig, uint32_t base, int lane)
+{
+    WaveChunk k;
+#pragma unroll
+    for (int j = 0; j < WCHUNK; ++j) k.w[j] = 1u;
+    const uint32_t i0 = base + (uint32_t)WCHUNK * (uint32_t)lane;
+    if (i0 < n_cig) {
+        const v4i_a4 x = *reinterpret_cast<const v4i_a4 *>(cig + i0), y = *reinterpret_cast<const v4i_a4 *>(cig + i0 + 4u);
+        k.w[0] = (uint32_t)x.x; k.w[1] = (uint32_t)x.y; k.w[2] = (uint32_t)x.z; k.w[3] = (uint32_t)x.w;
+        k.w[4] = (uint32_t)y.x; k.w[5] = (uint32_t)y.y; k.w[6] = (uint32_t)y.z; k.w[7] = (uint32_t)y.w;
+    }
+    return k;
+}
+
+template <typename Emit>
+__device__ __forceinline__ void wave_chunk_walk(WaveWalk &st, const WaveChunk &ch, uint32_t n_cig, uint32_t base, const DevParams &p, int lane, Emit &emit)
+{
+    const uint32_t i0 = base + (uint32_t)WCHUNK * (uint32_t)lane;
+    int a[WCHUNK], len[WCHUNK]; bool c[WCHUNK];
+    int A = 0; bool any_c = false;
+#pragma unroll
+    for (int j = 0; j < WCHUNK; ++j) {
+        const uint32_t w = i0 + (uint32_t)j < n_cig ? ch.w[j] : 1u;          // behind the read's last op: "I, length 0"
+        const uint32_t op = w & 0xfu;
+        len[j] = (int)(w >> 4);
+        a[j] = len[j] & __builtin_amdgcn_sbfe(0x18d, op, 1u);                // ops 0 2 3 7 8 advance the reference
+        c[j] = ((op == 3u) & (len[j] >= p.min_intron)) | ((op == 2u) & (len[j] > p.max_delet));
+        A += a[j]; any_c = any_c | c[j];
+    }
+    const int incA = wave_scan<OpAdd>(A);
+    const unsigned long long cm = __ballot(any_c);
+    if (cm) {                                           // (wave-uniform)
+        int eb[WCHUNK], sa[WCHUNK];                     // reference end in front of op j; exon start behind it if it cuts
+        int run = st.ref_end + incA - A, my_last = INT32_MIN;
+#pragma unroll
+        for (int j = 0; j < WCHUNK; ++j) { eb[j] = run; sa[j] = run + len[j] + 1; my_last = c[j] ? sa[j] : my_last; run += a[j]; }
+        const int incM = wave_scan<OpMax>(my_last);
+        const int before = __builtin_amdgcn_update_dpp(INT32_MIN, incM, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        int S = max(before, st.cur_start);              // start of the candidate the lane's first cut closes
+        bool first = !st.seen_cut && lane == __ffsll((long long)cm) - 1;
+        bool k[WCHUNK]; int ks[WCHUNK];
+        uint32_t kept = 0u;
+#pragma unroll
+        for (int j = 0; j < WCHUNK; ++j) {
+            ks[j] = S;
+            k[j] = c[j] & (first | (eb[j] - S + 1 >= p.min_exon));
+            first = first & !c[j];
+            S = c[j] ? sa[j] : S;
+            kept += k[j] ? 1u : 0u;
+        }
+        const uint32_t incK = wave_inclusive_scan(kept);
+        uint32_t at = st.n_kept + incK - kept;
+#pragma unroll
+        for (int j = 0; j < WCHUNK; ++j) if (k[j]) { emit((int)at, ks[j], eb[j]); ++at; }
+        st.n_kept += (uint32_t)__builtin_amdgcn_readlane((int)incK, WAVE - 1);
+        st.cur_start = __builtin_amdgcn_readlane(incM, WAVE - 1);            // (the starts behind the cuts do not decrease)
+        st.seen_cut = true;
+    }
+    st.ref_end += __builtin_amdgcn_readlane(incA, WAVE - 1);
+}
+
 // dynamic LDS of k_pass_a<true> for tiles of up to `rpt` reads
 inline size_t pass_a_dynamic_lds(int rpt) { return (size_t)WALK_SLAB * rpt * 6 + (size_t)3 * WALK_OVF * 4 + (size_t)TILE_THREADS * 2; }
 
@@ -283,7 +363,7 @@ __device__ __forceinline__ int cursor_value(const CursorDir &cd, int32_t tid, in
 // Pass A.  j0_in != null: the cursor values were replayed on the host (unsorted input) and are only read here.
 // WIDE: the input has long CIGARs (the host decides per upload), see walk_cigar.
 template <bool WIDE>
-__global__ __launch_bounds__(TILE_THREADS)
+__global__ __launch_bounds__(TILE_THREADS, 8)
 void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t *__restrict__ r_pos,
               const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ cig, CursorDir cd, SiteTabs tabs, DevParams p,
               const int32_t *__restrict__ j0_in, int32_t *__restrict__ j0_out, uint32_t *__restrict__ local_out,
@@ -303,6 +383,7 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
     uint16_t *const s_slab_l = reinterpret_cast<uint16_t *>(s_ovf + 3 * WALK_OVF);      // ... and length (0: empty exon)
     uint16_t *const s_loc = s_slab_l + WALK_SLAB * slab_w;                   // in-tile exon offset of every thread's read
     __shared__ uint32_t s_ovf_n;
+    __shared__ int4 s_rd[WIDE ? TILE_THREADS : 1];                             // WIDE: {exon count, read end, not handed over} per read of the tile
     if (WIDE) { if (threadIdx.x == 0) s_ovf_n = 0u; __syncthreads(); }
     if (threadIdx.x < WAVE) s_hist[threadIdx.x] = 0u;
     // tile = reads [tile_first[b], tile_first[b + 1]): at most reads_per_tile of them, of one chromosome when the input is sorted
@@ -313,35 +394,73 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
     uint32_t n = 0;
     bool unwalked = false;
     int j0 = INT32_MAX, tid = 0, pos = 0, el = 0;
+    CigarHead head;
+    int n_cig_mine = 0;
+    const uint32_t *cig_mine = cig;
     if (active) {
-        const int64_t c_a = cig_off[r], c_b = cig_off[r + 1];
         pos = r_pos[r];
         tid = r_tid[r];
-        const CigarHead head = load_cigar_head(cig + c_a, (int)(c_b - c_a));      // in flight during the cursor lookup
+        if (!WIDE) {
+            const int64_t c_a = cig_off[r], c_b = cig_off[r + 1];
+            cig_mine = cig + c_a; n_cig_mine = (int)(c_b - c_a);
+            head = load_cigar_head(cig_mine, n_cig_mine);                   // in flight during the cursor lookup
+        }
         if (j0_in) j0 = j0_in[r];
         else { j0 = cursor_value(cd, tid, pos + 1); j0_out[r] = j0; }       // first exon always starts at pos + 1
         el = pos;
-        if (WIDE) {
-            // long CIGARs: the classification kernel shall not read them again (they are 10-50 times the bytes of the
-            // exons they describe).  A store per CIGAR step with the few lanes that cut there would cost more than the
-            // walk, and the place of an exon in the tile is not known before the scan below: the exons wait in LDS
-            // (exon-major, start + 16-bit length) and leave afterwards.  A read with more than WALK_SLAB exons or an exon
-            // of 64 kb and more: the classification kernel walks that read itself (its first slot says so).
-            n = (uint32_t)walk_cigar_headed<WIDE>(head, cig + c_a, (int)(c_b - c_a), pos, p, [&](int k, int s, int e) {
+    }
+    if (WIDE) {
+        // long CIGARs: the classification kernel shall not read them again (they are 10-50 times the bytes of the exons they
+        // describe), so the exons are handed over.  The reads of the tile are dealt to the four waves, ONE WAVE walks one read
+        // at a time (walk_read_wave: coalesced loads of the op stream, prefix sums over the wave).  The place of an exon in the
+        // tile is not known before the scan below: the exons wait in LDS (exon-major, start + 16-bit length) and leave afterwards.
+        // A read with more than WALK_SLAB exons or an exon of 64 kb and more: the classification kernel walks that read itself
+        // (its first slot says so).
+        const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+        // every read's {first word relative to the tile's, number of ops, pos}: thread i brings read i's, the waves pick them up in LDS
+        const int64_t c_tile = cig_off[r0];
+        if (active) { const int64_t c_a = cig_off[r], c_b = cig_off[r + 1]; s_rd[threadIdx.x] = make_int4((int)(c_a - c_tile), (int)min((int64_t)0x7fffffff, c_b - c_a), pos, 0); }
+        __syncthreads();
+        const uint32_t *const tile_cig = cig + c_tile;
+        constexpr uint32_t ROUND = (uint32_t)(WCHUNK * WAVE);
+        uint32_t q = (uint32_t)wv;
+        int4 meta = q < n_act ? s_rd[q] : make_int4(0, 0, 0, 0);
+        WaveChunk cur = wave_chunk_load(tile_cig + (uint32_t)meta.x, q < n_act ? (uint32_t)meta.y : 0u, 0u, lane);
+        for (; q < n_act; q += TILE_THREADS / WAVE) {
+            // the first round of the wave's next read is asked for before this read is walked
+            const uint32_t qn = q + TILE_THREADS / WAVE;
+            const int4 meta_n = qn < n_act ? s_rd[qn] : make_int4(0, 0, 0, 0);
+            const WaveChunk nxt = wave_chunk_load(tile_cig + (uint32_t)meta_n.x, qn < n_act ? (uint32_t)meta_n.y : 0u, 0u, lane);
+            const uint32_t *const words = tile_cig + (uint32_t)meta.x;
+            const uint32_t n_cig = (uint32_t)meta.y;
+            bool unw = false;
+            auto emit = [&](int k, int s, int e) {
                 const uint32_t len = (uint32_t)(e - s + 1);
                 if (k < WALK_SLAB) {
-                    s_slab_s[k * slab_w + (int)threadIdx.x] = s; s_slab_l[k * slab_w + (int)threadIdx.x] = (uint16_t)len;
-                    unwalked = unwalked | (len > 0xffffu);
+                    s_slab_s[k * slab_w + (int)q] = s; s_slab_l[k * slab_w + (int)q] = (uint16_t)len;
+                    unw = unw | (len > 0xffffu);
                 } else {
                     const uint32_t at = atomicAdd(&s_ovf_n, 1u);
-                    if (at < (uint32_t)WALK_OVF) { s_ovf[3 * at] = (int)threadIdx.x | (k << 8); s_ovf[3 * at + 1] = s; s_ovf[3 * at + 2] = e; }
-                    else unwalked = true;
+                    if (at < (uint32_t)WALK_OVF) { s_ovf[3 * at] = (int)q | (k << 8); s_ovf[3 * at + 1] = s; s_ovf[3 * at + 2] = e; }
+                    else unw = true;
                 }
-                el = e;
-            });
-        } else {
-            n = (uint32_t)walk_cigar_headed<WIDE>(head, cig + c_a, (int)(c_b - c_a), pos, p, [&](int, int, int e) { el = e; });
+            };
+            WaveWalk st{meta.z, meta.z + 1, 0u, false};
+            wave_chunk_walk(st, cur, n_cig, 0u, p, lane, emit);
+            for (uint32_t base = ROUND; base < n_cig; base += ROUND) {           // (reads beyond 512 ops: round by round)
+                const WaveChunk more = wave_chunk_load(words, n_cig, base, lane);
+                wave_chunk_walk(st, more, n_cig, base, p, lane, emit);
+            }
+            if (lane == 0) emit((int)st.n_kept, st.cur_start, st.ref_end);
+            const bool unw_any = __any(unw);
+            // (the read's own entry of s_rd is not read again: this wave was its only reader)
+            if (lane == 0) s_rd[q] = make_int4((int)st.n_kept + 1, st.ref_end, unw_any ? 1 : 0, 0);
+            meta = meta_n; cur = nxt;
         }
+        __syncthreads();
+        if (active) { const int4 v = s_rd[threadIdx.x]; n = (uint32_t)v.x; el = v.y; unwalked = v.z != 0; }
+    } else if (active) {
+        n = (uint32_t)walk_cigar_headed<WIDE>(head, cig_mine, n_cig_mine, pos, p, [&](int, int, int e) { el = e; });
     }
     if (threadIdx.x == 0) s_tid0 = active ? tid : INT32_MAX;          // (an empty launch has no first read: no chromosome matches)
     uint32_t total;
@@ -855,9 +974,6 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
 //   * the read's sweep ends inside the window (WIN_TX transcripts from the tile's smallest cursor value);
 //   * no dictionary entry of the tile's slices has members beyond 64 transcripts of its first.
 
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));       // a 16-byte access at any 4-byte boundary (global memory)
-typedef uint32_t u32_a1 __attribute__((aligned(1)));                      // a 4-byte access at any address (global memory)    // LDS copy of a dictionary entry {k1, k2, pm, sm}, masks in the tile frame
 
 struct AccRec { uint32_t read_lo, read_hi, info; int32_t ref_tx; };
 
