@@ -268,13 +268,14 @@ def main():
         dt = float(tt.item())
 
     n_r, n_x, n_acc, n_acc_x = eng.sizes()
+    per_rank = [[reads.n, n_x, n_acc, n_acc_x]]
     if world > 1:
-        # reads of all ranks (strong scaling: the shards differ by at most one read); outside the timed region
-        tr = torch.tensor([reads.n], dtype=torch.int64, device=device)
-        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
-        total_reads = int(tr.item())
-    else:
-        total_reads = reads.n
+        # reads / exons / accepted records of every rank (outside the timed region): the first hardware run explains itself
+        tr = torch.tensor(per_rank[0], dtype=torch.int64, device=device)
+        allr = [torch.zeros_like(tr) for _ in range(world)]
+        dist.all_gather(allr, tr)
+        per_rank = [t.tolist() for t in allr]
+    total_reads = sum(p[0] for p in per_rank)
     value = total_reads * args.steps / dt
 
     out = None
@@ -355,7 +356,11 @@ def main():
                            "partitioned: chromosome-aligned shards merge and write on their own rank; no collective inside a step"
                            if not gather else
                            "gathered: RCCL all-gatherv (padded all_gather_into_tensor) of %s accepted records / %s exons to every rank" % (last[0], last[1])),
-                       "parallelism": "reads sharded over %d GPU(s), annotation replicated" % world},
+                       "parallelism": "reads sharded over %d GPU(s), annotation replicated" % world,
+                       "rccl_world_size": world, "reads_per_rank": [p[0] for p in per_rank], "exons_per_rank": [p[1] for p in per_rank],
+                       # bytes a rank SENDS per step: the partitioned route exchanges nothing inside a step (16 summary counters once,
+                       # behind the timed region); the gathered route all-gathers its accepted records (16 + 4 bytes each) and their exons (9 bytes each)
+                       "exchange_bytes_per_rank_per_step": [0 if not gather else 20 * p[2] + 9 * p[3] for p in per_rank]},
             "roofline": roof,
             "with_accepted": with_accepted,
             "cpu_baseline": cpu,
