@@ -152,11 +152,10 @@ typedef struct {
 
 /* Average device time per kernel of the last l2r_run_timed(), milliseconds.  Stages 0..2 are the three kernels of the
  * pipeline the engine chose for the uploaded records (l2r_stage_kernel() names them):
- *     slab    (coordinate-sorted records, short CIGARs; default)  0 k_order, first run of an upload only (a layout of
- *             the records: lane order of every tile, record fields in that order)  1 k_walk_slab (CIGAR -> exons, tile
- *             descriptors)  2 k_probe_slab (annotation window, site probes, verdicts) + k_probe_slab_wide (tiles whose
- *             window holds 33 .. 64 transcripts)
- *     fused   (L2R_PIPELINE=fused)   0 k_order  1 -  2 k_fused
+ *     slab    (coordinate-sorted records, short CIGARs; default)  0 k_walk_slab (the tile's reads by CIGAR length, CIGAR -> exons,
+ *             read-order places, tile descriptors)  1 k_scan_u32 (the tiles' exon counts -> their first result slots)  2 k_probe_slab
+ *             (annotation window, site probes, verdicts, read-order results) + k_probe_slab_wide (tiles whose window holds 33 .. 64
+ *             transcripts).  Every run launches all of them: nothing is kept from an earlier run of the same records.
  *     classic (unsorted records, long CIGARs, L2R_PIPELINE=classic)  0 k_pass_a  1 k_scan_tiles  2 k_classify_fast */
 #define L2R_N_STAGES 8
 typedef struct {
@@ -199,7 +198,7 @@ int          l2r_set_junctions(l2r_ctx *ctx, const l2r_junctions *sj);   /* NULL
 int          l2r_upload_reads(l2r_ctx *ctx, const l2r_reads *reads);
 
 /* The hot path on resident inputs; asynchronous on the context stream. */
-int          l2r_run(l2r_ctx *ctx);
+int          l2r_run(l2r_ctx *ctx);          /* every kernel of the path, every call; results in read order in HBM */
 int          l2r_sync(l2r_ctx *ctx);
 /* `iters` back-to-back runs bracketed by HIP events on the context stream. */
 int          l2r_run_timed(l2r_ctx *ctx, int iters, l2r_timing *out);
