@@ -324,6 +324,7 @@ typedef struct {
     h_job *j; const l2r_result *res; int64_t lo, hi; int first;
     char *buf[7]; size_t len[7]; int64_t cnt[H_N_SUMMARY];
     h_part_genes genes;
+    int done;
 } tail_part;
 
 static void *tail_part_main(void *arg)
@@ -369,55 +370,112 @@ static int tail_threads(const h_job *j)
     return (int)n;
 }
 
+/* The parts of the threaded tail.  The order-dependent lists of the tail look backwards from their end and stop at the first entry
+ * that lies before the new one: merge_trans at `t->start > T->t[i].end` or a smaller tid (src/update_gtf.c:147), the novel exon /
+ * site / junction lists at a smaller tid, comparing coordinates (:181-222).  So the reads can be cut wherever a read starts behind the
+ * END OF EVERY READ in front of it on its chromosome (a gap in the coverage; chromosome boundaries are such places): no list entry made
+ * from the reads in front of the cut can stop short of, merge with or equal an entry made behind it.  Every part lies inside one
+ * chromosome; their outputs are concatenated and their counters added.  The one list that compares across a cut is the gene list
+ * (merge_gene, :181-189: equal gene_id anywhere on the chromosome, and with the list's last entry of a smaller tid): the parts report
+ * the ids they added and the join below counts an id once, as the sequential list would (gene_fix). */
+typedef struct {
+    int32_t cur_tid; const char **cur; int n_cur, cap_cur;       /* ids of the sequential list's entries under its last tid */
+    const char *lower;                                           /* id of its last entry with a smaller tid, NULL: none */
+    const char *last;                                            /* id of its last entry, NULL: empty */
+} gene_fix;
+
+/* ids `gids[0 .. n)` (in the order the part added them, all under `tid`) join the sequential list: returns how many of them it would
+ * NOT have taken (the part counted them, the total must not) */
+static int gene_fix_join(gene_fix *f, int32_t tid, char **gids, int n)
+{
+    if (n <= 0) return 0;
+    if (f->last == NULL || tid > f->cur_tid) { f->lower = f->last; f->n_cur = 0; f->cur_tid = tid; }
+    int dup = 0;
+    for (int k = 0; k < n; ++k) {
+        int hit = f->lower && strcmp(f->lower, gids[k]) == 0;
+        for (int q = f->n_cur - 1; !hit && q >= 0; --q) hit = strcmp(f->cur[q], gids[k]) == 0;
+        if (hit) { ++dup; continue; }
+        if (f->n_cur == f->cap_cur) { f->cap_cur = f->cap_cur ? f->cap_cur * 2 : 256; f->cur = (const char **)h_realloc((void *)f->cur, (size_t)f->cap_cur * sizeof(char *)); }
+        f->cur[f->n_cur++] = gids[k]; f->last = gids[k];
+    }
+    return dup;
+}
+
+typedef struct { tail_part *parts; int n_parts; int next; pthread_mutex_t mu; } tail_queue;
+static void *tail_queue_main(void *arg)
+{
+    tail_queue *q = (tail_queue *)arg;
+    for (;;) {
+        pthread_mutex_lock(&q->mu);
+        const int k = q->next < q->n_parts ? q->next++ : -1;
+        pthread_mutex_unlock(&q->mu);
+        if (k < 0) break;
+        tail_part_main(&q->parts[k]);
+        __atomic_store_n(&q->parts[k].done, 1, __ATOMIC_RELEASE);
+    }
+    return NULL;
+}
+
 static int finish_threaded(h_job *j, const l2r_result *res, int n_thr)
 {
-    /* cut points: chromosome boundaries nearest to the equal-count cuts */
     const int64_t N = j->reads.n;
-    int64_t *cut = (int64_t *)h_malloc((size_t)(n_thr + 1) * sizeof(int64_t));
-    cut[0] = 0;
-    for (int k = 1; k < n_thr; ++k) {
-        int64_t want = N * k / n_thr, lo = want, hi = want;
-        while (lo > cut[k - 1] && j->reads.tid[lo] == j->reads.tid[lo - 1]) --lo;           /* boundary at or below */
-        while (hi < N && j->reads.tid[hi] == j->reads.tid[hi - 1]) ++hi;                    /* boundary above */
-        int64_t c = (want - lo <= hi - want) ? lo : hi;
-        if (c < cut[k - 1]) c = cut[k - 1];
-        cut[k] = c;
+    /* cut points: coverage gaps (see above), a part of about N / (4 n_thr) reads ends at the next one; always at a new chromosome */
+    int64_t target = N / ((int64_t)n_thr * 4);
+    if (target < 5000) target = 5000;
+    {   const char *e = getenv("L2R_TAIL_PART_READS"); if (e && atoll(e) > 0) target = atoll(e); }      /* (tests force small parts) */
+    int64_t *cut = NULL; int n_cut = 0, cap_cut = 0;
+#define PUSH_CUT(v) do { if (n_cut == cap_cut) { cap_cut = cap_cut ? cap_cut * 2 : 256; cut = (int64_t *)h_realloc(cut, (size_t)cap_cut * sizeof(int64_t)); } cut[n_cut++] = (v); } while (0)
+    PUSH_CUT(0);
+    {
+        int32_t run_end = INT32_MIN;
+        for (int64_t i = 0; i < N; ++i) {
+            const int64_t x0 = res->ex_off[i], x1 = res->ex_off[i + 1];
+            const int32_t start = x1 > x0 ? res->ex_start[x0] : j->reads.pos[i] + 1, end = x1 > x0 ? res->ex_end[x1 - 1] : j->reads.pos[i];
+            if (i > 0) {
+                const int new_chrom = j->reads.tid[i] != j->reads.tid[i - 1];
+                if (new_chrom || (start > run_end && i - cut[n_cut - 1] >= target)) { PUSH_CUT(i); }
+                if (new_chrom) run_end = INT32_MIN;
+            }
+            if (end > run_end) run_end = end;
+        }
     }
-    cut[n_thr] = N;
-    tail_part *parts = (tail_part *)calloc((size_t)n_thr, sizeof *parts);
+    PUSH_CUT(N);
+#undef PUSH_CUT
+    const int n_parts = n_cut - 1;
+    tail_part *parts = (tail_part *)calloc((size_t)n_parts, sizeof *parts);
+    for (int k = 0; k < n_parts; ++k) { parts[k].j = j; parts[k].res = res; parts[k].lo = cut[k]; parts[k].hi = cut[k + 1]; parts[k].first = k == 0; }
+    tail_queue tq; tq.parts = parts; tq.n_parts = n_parts; tq.next = 0; pthread_mutex_init(&tq.mu, NULL);
+    if (n_thr > n_parts) n_thr = n_parts;
     pthread_t *th = (pthread_t *)calloc((size_t)n_thr, sizeof *th);
-    int first_nonempty = 1;
-    for (int k = 0; k < n_thr; ++k) {
-        parts[k].j = j; parts[k].res = res; parts[k].lo = cut[k]; parts[k].hi = cut[k + 1];
-        parts[k].first = first_nonempty && k == 0;
-        if (pthread_create(&th[k], NULL, tail_part_main, &parts[k])) h_fatal("update_gtf", "pthread_create failed");
-    }
+    for (int k = 0; k < n_thr; ++k) if (pthread_create(&th[k], NULL, tail_queue_main, &tq)) h_fatal("update_gtf", "pthread_create failed");
     int64_t total[H_N_SUMMARY]; memset(total, 0, sizeof total);
     FILE *outs[7] = {j->o.out_gtf, j->o.exon_bed, j->o.bam_gtf, j->o.bam_detail, j->o.known_gtf, j->o.novel_gtf, j->o.unrecog_gtf};
-    const char *last_gene[2] = {NULL, NULL};                /* gene_id of the last entry of the two gene lists so far (h_part_genes) */
+    gene_fix fix[2]; memset(fix, 0, sizeof fix);
     static const int gene_cnt[2] = {H_CNT_UPDATED_GENES, H_CNT_KNOWN_GENES};
     double t_join = 0.0, t_write = 0.0;
-    for (int k = 0; k < n_thr; ++k) {
+    for (int k = 0; k < n_parts; ++k) {
+        /* the parts are written in order as they finish (the queue hands them out in order, so the next one to write is among the first done) */
         const double ta = h_now();
-        pthread_join(th[k], NULL);
+        while (!__atomic_load_n(&parts[k].done, __ATOMIC_ACQUIRE)) usleep(200);
         const double tb = h_now();
         for (int q = 0; q < 7; ++q) if (outs[q] && parts[k].len[q]) fwrite(parts[k].buf[q], 1, parts[k].len[q], outs[q]);
         t_join += tb - ta; t_write += h_now() - tb;
-        for (int q = 0; q < 7; ++q) free(parts[k].buf[q]);
+        for (int q = 0; q < 7; ++q) { free(parts[k].buf[q]); parts[k].buf[q] = NULL; }
         for (int q = 0; q < H_N_SUMMARY; ++q) total[q] += parts[k].cnt[q];
-        for (int q = 0; q < 2; ++q) {
-            if (h_part_genes_has_first(&parts[k].genes, q, last_gene[q])) total[gene_cnt[q]] -= 1;       /* the sequential list would not have taken it */
-            if (parts[k].genes.last_gid[q]) last_gene[q] = parts[k].genes.last_gid[q];
-        }
+        const int32_t tid = parts[k].hi > parts[k].lo ? j->reads.tid[parts[k].lo] : 0;
+        for (int q = 0; q < 2; ++q) total[gene_cnt[q]] -= gene_fix_join(&fix[q], tid, parts[k].genes.first_gids[q], parts[k].genes.n_first[q]);
     }
-    for (int k = 0; k < n_thr; ++k) h_part_genes_free(&parts[k].genes);
+    for (int k = 0; k < n_thr; ++k) pthread_join(th[k], NULL);
+    pthread_mutex_destroy(&tq.mu);
+    for (int q = 0; q < 2; ++q) free((void *)fix[q].cur);
+    for (int k = 0; k < n_parts; ++k) h_part_genes_free(&parts[k].genes);
     if (j->o.summary) h_write_summary_text(j->o.summary, j->anno.gene_n, (int)j->anno.n_tx, total);
     /* (tried: detail.txt -- more than half of the bytes, rows independent -- in 64 parts of its own beside the chromosome-aligned
      *  ones: slower, 2.2 -> 2.35 s on the 256-core GPU box; the tail is bound by page faults / stream growth of ~4 GB of fresh
      *  memory in one process, not by formatting; the three writer groups of a part -- lists | per-read files | summary -- side by side
      *  on threads of their own: slower as well, 2.1 -> 2.46 s; the parts' streams written by 16 threads with pwrite at their offsets:
      *  0.40 -> 0.55 s, writes to one file serialise on its inode lock) */
-    if (getenv("L2R_TIMING")) fprintf(stderr, "[timing]   tail: %d parts, waiting for them %.3f s, copying their streams out %.3f s\n", n_thr, t_join, t_write);
+    if (getenv("L2R_TIMING")) fprintf(stderr, "[timing]   tail: %d parts on %d threads, waiting for them %.3f s, copying their streams out %.3f s\n", n_parts, n_thr, t_join, t_write);
     free(parts); free(th); free(cut);
     return 0;
 }

@@ -170,10 +170,12 @@ for k in a:
     j.close()
 
 
-@pytest.mark.parametrize("threads", ["3", "8"])
-def test_threaded_tail_is_byte_identical(oracle, tmp_path, threads):
-    """The tail on several host threads (chromosome-aligned parts into memory streams, written out in order) against the
-    oracle's single sequential pass; more threads than chromosomes leaves some parts empty."""
+@pytest.mark.parametrize("threads,part", [("3", ""), ("8", ""), ("5", "40"), ("2", "7")])
+def test_threaded_tail_is_byte_identical(oracle, tmp_path, threads, part):
+    """The tail on several host threads (parts cut at coverage gaps -- chromosome boundaries and, inside a chromosome, reads that
+    start behind the end of every read in front of them -- into memory streams, written out in order) against the oracle's single
+    sequential pass.  `part`: reads per part (L2R_TAIL_PART_READS): a few reads per part put a cut into nearly every gap between
+    two loci, and none between two reads that overlap (merge_trans across a would-be cut)."""
     anno = synth.make_annotation(6000, 61, nchr=5, shuffle_within_gene=True)
     reads = synth.make_reads(anno, 6000, 5, 61, xs_conflict_frac=0.02)
     sam, gtf = str(tmp_path / "r.sam"), str(tmp_path / "a.gtf")
@@ -181,9 +183,12 @@ def test_threaded_tail_is_byte_identical(oracle, tmp_path, threads):
     anno.write_gtf(gtf)
     oo, ho = _paths(tmp_path, "t.o"), _paths(tmp_path, "t.h")
     assert oracle.run_cli(_args(["-l", "3"], oo, sam, gtf)) == 0
-    assert _host_with_oracle_results(_args(["-l", "3"], ho, sam, gtf), env=dict(os.environ, L2R_THREADS=threads)) == 0
+    env = dict(os.environ, L2R_THREADS=threads)
+    if part:
+        env["L2R_TAIL_PART_READS"] = part
+    assert _host_with_oracle_results(_args(["-l", "3"], ho, sam, gtf), env=env) == 0
     for k in OUTS:
-        assert filecmp.cmp(oo[k], ho[k], shallow=False), (threads, k)
+        assert filecmp.cmp(oo[k], ho[k], shallow=False), (threads, part, k)
     assert os.path.getsize(oo["detail"]) > 100000
 
 
@@ -202,9 +207,10 @@ def test_threaded_tail_counts_a_gene_on_two_chromosomes_like_the_sequential_run(
             fo.write(re.sub(r'gene_id "[^"]*"', 'gene_id "GX"', l))
     oo, ho = _paths(tmp_path, "g.o"), _paths(tmp_path, "g.h")
     assert oracle.run_cli(_args(["-l", "3"], oo, sam, gtf1)) == 0
-    assert _host_with_oracle_results(_args(["-l", "3"], ho, sam, gtf1), env=dict(os.environ, L2R_THREADS="4")) == 0
-    for k in OUTS:
-        assert filecmp.cmp(oo[k], ho[k], shallow=False), k
+    for env in (dict(os.environ, L2R_THREADS="4"), dict(os.environ, L2R_THREADS="4", L2R_TAIL_PART_READS="25")):
+        assert _host_with_oracle_results(_args(["-l", "3"], ho, sam, gtf1), env=env) == 0
+        for k in OUTS:
+            assert filecmp.cmp(oo[k], ho[k], shallow=False), k
     summ = dict(l.rstrip("\n").split("\t") for l in open(oo["summary"]) if "\t" in l)
     assert summ["Updated_Genes"] == "1" and summ["Genes_of_Known_Transcripts_from_BAM"] == "1", summ
 
