@@ -348,6 +348,46 @@ static void *bam_join_main(void *arg)
     return NULL;
 }
 
+/* the fields of records starts[0 .. n_mine) of the inflated stream b, extracted on several threads (every thread fills a piece of
+ * its own) and APPENDED to *out in order (read names: ids are offsets into the joined table) */
+static void bam_extract(const blob *b, const size_t *starts, size_t n_mine, h_chroms *chr, h_reads *out, int skip_unmapped, const char *who)
+{
+    const char *e = getenv("L2R_THREADS");
+    long n_thr = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    if (n_thr > 32) n_thr = 32;
+    if (n_thr < 1 || (!e && n_mine < 200000)) n_thr = 1;
+    if ((size_t)n_thr > n_mine) n_thr = n_mine ? (long)n_mine : 1;
+    bam_piece pc[32];
+    pthread_t th[32];
+    for (long k = 0; k < n_thr; ++k) {
+        pc[k].b = b; pc[k].starts = starts; pc[k].lo = n_mine * (size_t)k / (size_t)n_thr; pc[k].hi = n_mine * (size_t)(k + 1) / (size_t)n_thr;
+        pc[k].chr = chr; pc[k].skip_unmapped = skip_unmapped; pc[k].who = who;
+        memset(&pc[k].piece, 0, sizeof pc[k].piece);
+    }
+    for (long k = 1; k < n_thr; ++k) if (pthread_create(&th[k], NULL, bam_piece_main, &pc[k])) h_fatal(who, "pthread_create failed");
+    bam_piece_main(&pc[0]);
+    for (long k = 1; k < n_thr; ++k) pthread_join(th[k], NULL);
+    /* join */
+    int64_t n = 0, n_cig = 0; size_t names = 0;
+    for (long k = 0; k < n_thr; ++k) { n += pc[k].piece.n; n_cig += pc[k].piece.n_cig; names += pc[k].piece.names.len; }
+    if (out->names.len + names >= 0xffffffffu) h_fatal(who, "read names exceed 4 GiB");
+    reads_reserve(out, n, n_cig);
+    if (out->names.len + names + 1 > out->names.cap) {
+        size_t c = out->names.cap ? out->names.cap : 1 << 20;
+        while (c < out->names.len + names + 1) c *= 2;
+        out->names.buf = (char *)h_realloc(out->names.buf, c); out->names.cap = c;
+    }
+    /* (every piece is copied into place by a thread of its own: the pages of the joined arrays are touched in parallel) */
+    for (long k = 0; k < n_thr; ++k) {
+        pc[k].dst = out; pc[k].at = out->n; pc[k].cat = out->n_cig; pc[k].nat = out->names.len;
+        out->n += pc[k].piece.n; out->n_cig += pc[k].piece.n_cig; out->names.len += pc[k].piece.names.len;
+    }
+    out->cig_off[out->n] = out->n_cig;
+    for (long k = 1; k < n_thr; ++k) if (pthread_create(&th[k], NULL, bam_join_main, &pc[k])) h_fatal(who, "pthread_create failed");
+    bam_join_main(&pc[0]);
+    for (long k = 1; k < n_thr; ++k) pthread_join(th[k], NULL);
+}
+
 /* A one-process-per-GPU run (dist.py) asks every rank for ITS shard only: the ranks agree on the cuts from the records' core
  * fields alone (chromosome, position, number of CIGAR operations: one cheap pass), and extract names / CIGARs / strands just for
  * their own range.  The cuts are the ones of workload.aligned_shard_bounds: equal shares of 4 * ops + 64 bytes per record, moved to
@@ -427,42 +467,171 @@ static void parse_bam(const blob *b, h_chroms *chr, h_reads *out, int skip_unmap
             free(cut); free(ideal);
         }
     }
-    const size_t n_mine = r_hi - r_lo;
+    bam_extract(b, starts + r_lo, r_hi - r_lo, chr, out, skip_unmapped, who);
+    free(starts);
+}
+
+/* ------------------------------------------------------------------ BAM in bounded memory
+ * The reference reads record by record (src/bam2gtf.c:150, src/update_gtf.c:1069).  Here a BGZF-compressed BAM goes through WINDOWS
+ * of whole BGZF blocks (64 MiB of the file at a time; L2R_READ_WINDOW overrides): read, inflated block-parallel, its complete
+ * records extracted on several threads and appended to the arrays; the bytes of a record that continues in the next window are
+ * carried over.  Neither the file nor the inflated stream is ever in memory as a whole: the peak is the record arrays (which the
+ * engine needs anyway) plus one window.  h_read_alignments() runs this to the end; bam2gtf consumes it batch by batch. */
+struct h_aln_stream {
+    FILE *f; const char *who; h_chroms *chr; int skip_unmapped;
+    uint8_t *carry; size_t carry_n;
+    int header_done, eof;
+    size_t window;
+};
+
+static int file_is_bgzf(FILE *f)
+{
+    uint8_t hd[18];
+    const size_t got = fread(hd, 1, sizeof hd, f);
+    fseek(f, 0, SEEK_SET);
+    return got == sizeof hd && hd[0] == 0x1f && hd[1] == 0x8b && hd[2] == 8 && (hd[3] & 4) && hd[12] == 'B' && hd[13] == 'C' &&
+           hd[14] == 2 && hd[15] == 0 && (hd[10] | (hd[11] << 8)) == 6;
+}
+
+/* one window: the next whole blocks of the file, inflated behind the carried bytes; returns the buffer (caller frees), *n_out its
+ * length; NULL at the end of the file (the carried bytes stay where they are) */
+static uint8_t *stream_window(h_aln_stream *s, size_t *n_out)
+{
+    *n_out = 0;
+    if (s->eof) return NULL;
+    uint8_t *raw = (uint8_t *)h_malloc(s->window + 1);
+    const size_t n_raw = fread(raw, 1, s->window, s->f);
+    if (n_raw == 0) { free(raw); s->eof = 1; return NULL; }
+    size_t n_blk = 0, cap = 1024, out_total = s->carry_n, p = 0;
+    bgzf_block *blk = (bgzf_block *)h_malloc(cap * sizeof *blk);
+    while (n_raw - p >= 18) {
+        if (raw[p] != 0x1f || raw[p + 1] != 0x8b || raw[p + 12] != 'B' || raw[p + 13] != 'C') h_fatal(s->who, "not a BGZF block where one was expected");
+        const size_t bsize = (size_t)(raw[p + 16] | (raw[p + 17] << 8)) + 1;
+        if (bsize < 28) h_fatal(s->who, "corrupt BGZF block");
+        if (p + bsize > n_raw) break;
+        const uint8_t *tail = raw + p + bsize - 4;
+        const size_t isize = (size_t)tail[0] | ((size_t)tail[1] << 8) | ((size_t)tail[2] << 16) | ((size_t)tail[3] << 24);
+        if (n_blk == cap) { cap *= 2; blk = (bgzf_block *)h_realloc(blk, cap * sizeof *blk); }
+        blk[n_blk].in_off = p + 18; blk[n_blk].in_len = bsize - 18 - 8; blk[n_blk].out_off = out_total; blk[n_blk].out_len = isize;
+        ++n_blk; out_total += isize; p += bsize;
+    }
+    if (n_blk == 0) h_fatal(s->who, n_raw < s->window ? "truncated BGZF block at the end of the file" : "BGZF block larger than the read window");
+    if (p < n_raw) fseek(s->f, -(long)(n_raw - p), SEEK_CUR);         /* the next window starts at the block that did not fit */
+    uint8_t *out = (uint8_t *)h_malloc(out_total + 1);
+    if (s->carry_n) memcpy(out, s->carry, s->carry_n);
+    free(s->carry); s->carry = NULL; s->carry_n = 0;
+    bgzf_job jb; memset(&jb, 0, sizeof jb);
+    jb.in = raw; jb.out = out; jb.blk = blk; jb.n_blk = n_blk; jb.next = 0; pthread_mutex_init(&jb.mu, NULL);
     const char *e = getenv("L2R_THREADS");
     long n_thr = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
     if (n_thr > 32) n_thr = 32;
-    if (n_thr < 1 || (!e && n_mine < 200000)) n_thr = 1;
-    if ((size_t)n_thr > n_mine) n_thr = n_mine ? (long)n_mine : 1;
-    bam_piece pc[32];
+    if (n_thr < 1 || n_blk < 8) n_thr = 1;
     pthread_t th[32];
-    for (long k = 0; k < n_thr; ++k) {
-        pc[k].b = b; pc[k].starts = starts; pc[k].lo = r_lo + n_mine * (size_t)k / (size_t)n_thr; pc[k].hi = r_lo + n_mine * (size_t)(k + 1) / (size_t)n_thr;
-        pc[k].chr = chr; pc[k].skip_unmapped = skip_unmapped; pc[k].who = who;
-        memset(&pc[k].piece, 0, sizeof pc[k].piece);
-    }
-    for (long k = 1; k < n_thr; ++k) if (pthread_create(&th[k], NULL, bam_piece_main, &pc[k])) h_fatal(who, "pthread_create failed");
-    bam_piece_main(&pc[0]);
+    for (long k = 1; k < n_thr; ++k) if (pthread_create(&th[k], NULL, bgzf_worker, &jb)) h_fatal(s->who, "pthread_create failed");
+    bgzf_worker(&jb);
     for (long k = 1; k < n_thr; ++k) pthread_join(th[k], NULL);
-    free(starts);
-    /* join */
-    int64_t n = 0, n_cig = 0; size_t names = 0;
-    for (long k = 0; k < n_thr; ++k) { n += pc[k].piece.n; n_cig += pc[k].piece.n_cig; names += pc[k].piece.names.len; }
-    if (names >= 0xffffffffu) h_fatal(who, "read names exceed 4 GiB");
-    reads_reserve(out, n, n_cig);
-    out->names.buf = (char *)h_realloc(out->names.buf, names + 1); out->names.cap = names + 1;
-    /* (every piece is copied into place by a thread of its own: the pages of the joined arrays are touched in parallel) */
-    for (long k = 0; k < n_thr; ++k) {
-        pc[k].dst = out; pc[k].at = out->n; pc[k].cat = out->n_cig; pc[k].nat = out->names.len;
-        out->n += pc[k].piece.n; out->n_cig += pc[k].piece.n_cig; out->names.len += pc[k].piece.names.len;
+    pthread_mutex_destroy(&jb.mu);
+    if (jb.failed) h_fatal(s->who, jb.failed == 2 ? "CRC32 mismatch in a BGZF block" : "corrupt BGZF block");
+    free(blk); free(raw);
+    *n_out = out_total;
+    return out;
+}
+
+/* NULL: not a BGZF-compressed BAM (SAM text, gzip, BGZF-compressed SAM): the caller reads the file as a whole */
+h_aln_stream *h_aln_stream_open(const char *fn, h_chroms *chr, int skip_unmapped, const char *who)
+{
+    FILE *f = fopen(fn, "rb");
+    if (!f) h_fatal(who, "Can not open \"%s\"\n", fn);
+    if (!file_is_bgzf(f)) { fclose(f); return NULL; }
+    h_aln_stream *s = (h_aln_stream *)calloc(1, sizeof *s);
+    s->f = f; s->who = who; s->chr = chr; s->skip_unmapped = skip_unmapped;
+    /* the stream's first block must start with the BAM magic */
+    s->window = 65536 + 64;
+    size_t n = 0;
+    uint8_t *w = stream_window(s, &n);
+    const int is_bam = w && n >= 4 && memcmp(w, "BAM\1", 4) == 0;
+    free(w);
+    if (!is_bam) { fclose(f); free(s); return NULL; }
+    fseek(f, 0, SEEK_SET); s->eof = 0;
+    s->window = (size_t)64 << 20;
+    const char *e = getenv("L2R_READ_WINDOW");
+    if (e && atoll(e) >= 65536 + 64) s->window = (size_t)atoll(e);
+    return s;
+}
+
+/* Appends the next batch of records to *out (an initialised h_reads); returns their number (0: a batch of skipped records), -1 at
+ * the end of the file.  The first batch also brings the header into chr. */
+int64_t h_aln_stream_next(h_aln_stream *s, h_reads *out)
+{
+    if (!out->cig_off) { reads_reserve(out, 1, 1); out->cig_off[0] = 0; }          /* (a zeroed h_reads) */
+    for (;;) {
+        size_t n = 0;
+        uint8_t *w = stream_window(s, &n);
+        if (!w) {
+            if (s->carry_n) h_fatal(s->who, s->header_done ? "truncated BAM record at the end of the file" : "truncated BAM header");
+            if (!s->header_done) h_fatal(s->who, "not a BAM stream");
+            return -1;
+        }
+        const uint8_t *p = w, *end = w + n;
+        if (!s->header_done) {
+            /* the header has to be complete in the buffer; if it is not, the buffer is carried into a longer one */
+            int ok = end - p >= 12 && memcmp(p, "BAM\1", 4) == 0;
+            if (end - p >= 4 && memcmp(p, "BAM\1", 4) != 0) h_fatal(s->who, "not a BAM stream");
+            uint32_t n_ref = 0;
+            const uint8_t *q = p;
+            if (ok) { ok = (size_t)(end - p) >= 12 + (size_t)le32(p + 4); if (ok) { q = p + 8 + le32(p + 4); n_ref = le32(q); q += 4; } }
+            for (uint32_t i = 0; ok && i < n_ref; ++i) {
+                ok = q + 4 <= end;
+                if (ok) { const uint32_t l_name = le32(q); ok = (size_t)(end - q) >= 8 + (size_t)l_name; if (ok) q += 8 + l_name; }
+            }
+            if (!ok) { s->carry = w; s->carry_n = n; continue; }
+            const uint8_t *h = p + 8 + le32(p + 4) + 4;
+            for (uint32_t i = 0; i < n_ref; ++i) { const uint32_t l_name = le32(h); h_chrom_intern(s->chr, (const char *)(h + 4)); h += 8 + l_name; }
+            s->chr->n_hdr = s->chr->n;
+            s->header_done = 1;
+            p = q;
+        }
+        /* the complete records of the buffer; what is left goes in front of the next window */
+        size_t n_rec = 0, cap_rec = 1 << 14;
+        size_t *starts = (size_t *)h_malloc(cap_rec * sizeof *starts);
+        while (p + 4 <= end) {
+            const uint32_t bs = le32(p);
+            if (bs < 32) h_fatal(s->who, "truncated BAM record");
+            if ((size_t)(end - p) < 4 + (size_t)bs) break;
+            if (n_rec == cap_rec) { cap_rec *= 2; starts = (size_t *)h_realloc(starts, cap_rec * sizeof *starts); }
+            starts[n_rec++] = (size_t)(p - w);
+            p += 4 + bs;
+        }
+        if (p < end) { s->carry_n = (size_t)(end - p); s->carry = (uint8_t *)h_malloc(s->carry_n); memcpy(s->carry, p, s->carry_n); }
+        const int64_t before = out->n;
+        if (n_rec) { const blob b = {w, n}; bam_extract(&b, starts, n_rec, s->chr, out, s->skip_unmapped, s->who); }
+        free(starts); free(w);
+        if (n_rec) return out->n - before;
+        /* (a window without a complete record -- one record longer than a window: read on) */
     }
-    out->cig_off[out->n] = out->n_cig;
-    for (long k = 1; k < n_thr; ++k) if (pthread_create(&th[k], NULL, bam_join_main, &pc[k])) h_fatal(who, "pthread_create failed");
-    bam_join_main(&pc[0]);
-    for (long k = 1; k < n_thr; ++k) pthread_join(th[k], NULL);
+}
+
+void h_aln_stream_close(h_aln_stream *s)
+{
+    if (!s) return;
+    if (s->f) fclose(s->f);
+    free(s->carry); free(s);
 }
 
 static void read_any(const char *fn, h_chroms *chr, h_reads *out, int skip_unmapped, int header_only, const char *who)
 {
+    if (out && !header_only && !(g_shard && g_shard->world > 1)) {
+        /* a BGZF-compressed BAM: window by window (bounded memory); anything else, and one rank's shard of a file, as a whole */
+        h_aln_stream *st = h_aln_stream_open(fn, chr, skip_unmapped, who);
+        if (st) {
+            reads_reserve(out, 1, 1);
+            out->cig_off[0] = 0;
+            while (h_aln_stream_next(st, out) >= 0) { }
+            h_aln_stream_close(st);
+            h_stage_time("  alignments: windows of BGZF blocks (read, inflate, extract)");
+            return;
+        }
+    }
     blob b = h_slurp(fn, who);
     if (!header_only) h_stage_time("  alignments: file read + inflate");
     h_reads tmp; memset(&tmp, 0, sizeof tmp);

@@ -686,6 +686,23 @@ static void exons_only(const char *who, const char *fn, const l2r_params *prm, h
     run_engine(who, prm, &a, &s, &r, out, NULL);
 }
 
+/* src/gtf.c:597-604 print_trans: gene_id + transcript_id only, exons always ascending */
+static void bam2gtf_print(const h_reads *reads, const h_result *out, const h_chroms *chr, const char *src)
+{
+    char line[512];
+    for (int64_t i = 0; i < out->n; ++i) {
+        const int64_t off = out->ex_off[i]; const int n = (int)L2R_INFO_NEXON(out->info[i]);
+        const char *q = h_str(&reads->names, reads->qname[i]), *cn = chr->name[reads->tid[i]];
+        const char st = "+-"[reads->rev[i] != 0];
+        snprintf(line, sizeof line, "%s\t%s\ttranscript\t%d\t%d\t.\t%c\t.\tgene_id \"%s\"; transcript_id \"%s\";\n", cn, src, out->ex_start[off], out->ex_end[off + n - 1], st, q, q);
+        fputs(line, stdout);
+        for (int k = 0; k < n; ++k) {
+            snprintf(line, sizeof line, "%s\t%s\texon\t%d\t%d\t.\t%c\t.\tgene_id \"%s\"; transcript_id \"%s\";\n", cn, src, out->ex_start[off + k], out->ex_end[off + k], st, q, q);
+            fputs(line, stdout);
+        }
+    }
+}
+
 int h_cmd_bam2gtf(int argc, char **argv)
 {
     static const struct option lopt[] = {{"exon-min", 1, 0, 'e'}, {"intron-len", 1, 0, 'i'}, {"source", 1, 0, 's'}, {0, 0, 0, 0}};
@@ -704,21 +721,43 @@ int h_cmd_bam2gtf(int argc, char **argv)
     }
     if (argc - optind != 1) return bam2gtf_usage();
     h_chroms chr; memset(&chr, 0, sizeof chr);
+    /* A BGZF-compressed BAM is converted window by window, as the reference converts record by record (src/bam2gtf.c:150): one
+     * engine, a batch of records uploaded, walked, downloaded and printed at a time; memory is bounded by the window, not by the file. */
+    h_aln_stream *st = h_aln_stream_open(argv[optind], &chr, 1, "bam2gtf");
+    if (st) {
+        l2r_ctx *ctx = l2r_create(0);
+        if (!ctx) engine_fail("bam2gtf");
+        l2r_annotation a; memset(&a, 0, sizeof a);
+        int64_t zero_off = 0; a.tx_ex_off = &zero_off;
+        if (l2r_set_params(ctx, &p) || l2r_set_outputs(ctx, L2R_WANT_RESULTS) || l2r_set_annotation(ctx, &a) || l2r_set_junctions(ctx, NULL)) engine_fail("bam2gtf");
+        for (;;) {
+            h_reads reads; memset(&reads, 0, sizeof reads);
+            const int64_t got = h_aln_stream_next(st, &reads);
+            if (got > 0) {
+                l2r_reads r = { reads.n, reads.n_cig, reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, 0 };
+                if (l2r_upload_reads(ctx, &r) || l2r_run(ctx) || l2r_sync(ctx)) engine_fail("bam2gtf");
+                int64_t nr = 0, nx = 0;
+                if (l2r_result_sizes(ctx, &nr, &nx, NULL, NULL)) engine_fail("bam2gtf");
+                h_result out; memset(&out, 0, sizeof out);
+                result_reserve(&out, nr, nx);
+                l2r_result res = { nr, nx, 0, out.ex_off, out.ex_start, out.ex_end, out.ex_flag, out.info, out.ref_tx };
+                if (l2r_download(ctx, &res)) engine_fail("bam2gtf");
+                out.n = nr; out.n_ex = nx;
+                bam2gtf_print(&reads, &out, &chr, src);
+                h_result_free(&out);
+            }
+            h_reads_free(&reads);
+            if (got < 0) break;
+        }
+        h_aln_stream_close(st);
+        l2r_destroy(ctx);
+        fflush(stdout);
+        h_chroms_free(&chr);
+        return 0;
+    }
     h_reads reads; h_result out;
     exons_only("bam2gtf", argv[optind], &p, &chr, &reads, &out, 1);
-    /* src/gtf.c:597-604 print_trans: gene_id + transcript_id only, exons always ascending */
-    char line[512];
-    for (int64_t i = 0; i < out.n; ++i) {
-        const int64_t off = out.ex_off[i]; const int n = (int)L2R_INFO_NEXON(out.info[i]);
-        const char *q = h_str(&reads.names, reads.qname[i]), *cn = chr.name[reads.tid[i]];
-        const char st = "+-"[reads.rev[i] != 0];
-        snprintf(line, sizeof line, "%s\t%s\ttranscript\t%d\t%d\t.\t%c\t.\tgene_id \"%s\"; transcript_id \"%s\";\n", cn, src, out.ex_start[off], out.ex_end[off + n - 1], st, q, q);
-        fputs(line, stdout);
-        for (int k = 0; k < n; ++k) {
-            snprintf(line, sizeof line, "%s\t%s\texon\t%d\t%d\t.\t%c\t.\tgene_id \"%s\"; transcript_id \"%s\";\n", cn, src, out.ex_start[off + k], out.ex_end[off + k], st, q, q);
-            fputs(line, stdout);
-        }
-    }
+    bam2gtf_print(&reads, &out, &chr, src);
     fflush(stdout);
     h_result_free(&out); h_reads_free(&reads); h_chroms_free(&chr);
     return 0;

@@ -51,6 +51,11 @@ void h_read_alignments(const char *fn, h_chroms *chr, h_reads *out, int skip_unm
 int  h_read_alignments_shard(const char *fn, h_chroms *chr, h_reads *out, int skip_unmapped, const char *who, int rank, int world,
                              int64_t *lo, int64_t *hi, int64_t *n_total);
 void h_read_header_only(const char *fn, h_chroms *chr, const char *who);
+/* a BGZF-compressed BAM window by window (aln_reader.c); open returns NULL for any other file */
+typedef struct h_aln_stream h_aln_stream;
+h_aln_stream *h_aln_stream_open(const char *fn, h_chroms *chr, int skip_unmapped, const char *who);
+int64_t h_aln_stream_next(h_aln_stream *s, h_reads *out);     /* appends a batch to *out; records appended, -1 at the end */
+void h_aln_stream_close(h_aln_stream *s);
 void h_reads_free(h_reads *r);
 
 /* ---- whole alignment records, BAM-encoded (`filter`: the kept ones are written out again) */

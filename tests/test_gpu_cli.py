@@ -102,6 +102,12 @@ def test_bam2gtf_and_unique_gtf(oracle, tmp_path, files):
         assert r.returncode == 0, r.stderr.decode()[-1000:]
         assert filecmp.cmp(a, b, shallow=False), (cmd, extra)
         assert os.path.getsize(a) > 10000
+    # bam2gtf converts a BAM window by window (aln_reader.c h_aln_stream): windows of one BGZF block = many engine batches
+    a, b = str(tmp_path / "o.out"), str(tmp_path / "hw.out")
+    assert oracle.run_cli(["bam2gtf", sam], stdout_path=a) == 0
+    r = hostlib.run_cli(["bam2gtf", bam], stdout_path=b, env={"L2R_READ_WINDOW": 65600})
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    assert filecmp.cmp(a, b, shallow=False)
 
 
 def test_gtf_input_mode(oracle, tmp_path, files):

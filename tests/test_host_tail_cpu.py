@@ -216,7 +216,7 @@ def test_threaded_tail_counts_a_gene_on_two_chromosomes_like_the_sequential_run(
 
 
 def test_bgzf_blocks_inflated_on_several_threads(tmp_path):
-    """A BAM of a few hundred BGZF blocks read with 1 and with 5 inflate threads gives the generator's arrays; a
+    """A BAM of a few hundred BGZF blocks read with 1 and with 5 inflate threads, and window by window, gives the generator's arrays; a
     gzip-compressed SAM (one gzip member, not BGZF) still goes through the sequential route."""
     import gzip
     anno = synth.make_annotation(8000, 71, nchr=3)
@@ -237,9 +237,14 @@ j = hostlib.Job(["update-gtf", sys.argv[1], sys.argv[2]])
 a = j.read_arrays()
 np.savez(sys.argv[3], **a)
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for tag, fn, thr in (("t1", bam, "1"), ("t5", bam, "5"), ("gz", samgz, "5")):
+    # (w1 / w3: the BAM in windows of one block and of about three: the records and the header cross window borders, every batch
+    #  is appended to the arrays of the batches before it -- aln_reader.c h_aln_stream)
+    for tag, fn, thr, win in (("t1", bam, "1", ""), ("t5", bam, "5", ""), ("gz", samgz, "5", ""), ("w1", bam, "3", "65600"), ("w3", bam, "2", "200000")):
         out = str(tmp_path / (tag + ".npz"))
-        r = subprocess.run([sys.executable, "-c", code, fn, gtf, out], stderr=subprocess.PIPE, env=dict(os.environ, L2R_THREADS=thr))
+        env = dict(os.environ, L2R_THREADS=thr)
+        if win:
+            env["L2R_READ_WINDOW"] = win
+        r = subprocess.run([sys.executable, "-c", code, fn, gtf, out], stderr=subprocess.PIPE, env=env)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         z = np.load(out)
         np.testing.assert_array_equal(z["tid"], reads.tid)
