@@ -242,8 +242,9 @@ void h_job_views(h_job *j, l2r_params *prm, l2r_annotation *a, l2r_junctions *s,
     r->cig_off = j->reads.cig_off; r->cig = j->reads.cig; r->first_read_index = 0;
 }
 
-static int tail_threads(const h_job *j);
-static int finish_threaded(h_job *j, const l2r_result *res, int n_thr);
+static int tail_threads(const h_job *j, const h_reads *reads);
+static int finish_threaded(h_job *j, const h_reads *reads, const h_update_opts *files, const l2r_result *res, int n_thr, int first_part,
+                           int64_t *counters_out, h_part_genes *genes_out);
 
 int h_job_finish(h_job *j, const l2r_result *res)
 {
@@ -251,8 +252,8 @@ int h_job_finish(h_job *j, const l2r_result *res)
     hr.n = res->n_reads; hr.n_ex = res->n_exons; hr.ex_off = res->ex_off; hr.ex_start = res->ex_start; hr.ex_end = res->ex_end;
     hr.ex_flag = res->ex_flag; hr.info = res->info; hr.ref_tx = res->ref_tx;
     if (hr.n != j->reads.n) h_fatal("update_gtf", "result covers %lld reads, input has %lld", (long long)hr.n, (long long)j->reads.n);
-    const int n_thr = tail_threads(j);
-    if (n_thr > 1) finish_threaded(j, res, n_thr);
+    const int n_thr = tail_threads(j, &j->reads);
+    if (n_thr > 1) finish_threaded(j, &j->reads, &j->o, res, n_thr, 1, NULL, NULL);
     else h_update_tail(&j->o, &j->chr, &j->reads, &j->anno, &hr, j->sj.n);
     FILE **fs[] = {&j->o.exon_bed, &j->o.bam_gtf, &j->o.bam_detail, &j->o.known_gtf, &j->o.novel_gtf, &j->o.unrecog_gtf, &j->o.summary};
     for (size_t k = 0; k < sizeof fs / sizeof fs[0]; ++k) if (*fs[k]) { fclose(*fs[k]); *fs[k] = NULL; }
@@ -309,7 +310,9 @@ int h_job_finish_part(h_job *j, int64_t lo, int64_t hi, const l2r_result *res, c
     hr.n = res->n_reads; hr.n_ex = res->n_exons; hr.ex_off = res->ex_off; hr.ex_start = res->ex_start; hr.ex_end = res->ex_end;
     hr.ex_flag = res->ex_flag; hr.info = res->info; hr.ref_tx = res->ref_tx;
     memset(counters, 0, H_N_SUMMARY * sizeof counters[0]);
-    h_update_tail(&o, &j->chr, &part, &j->anno, &hr, j->sj.n);
+    const int n_thr = tail_threads(j, &part);
+    if (n_thr > 1) { o.summary_counts = NULL; o.part_genes = NULL; finish_threaded(j, &part, &o, res, n_thr, first_part, counters, &j->part_genes); }
+    else h_update_tail(&o, &j->chr, &part, &j->anno, &hr, j->sj.n);
     FILE *fs[] = {o.out_gtf, o.exon_bed, o.bam_gtf, o.bam_detail, o.known_gtf, o.novel_gtf, o.unrecog_gtf};
     for (size_t k = 0; k < sizeof fs / sizeof fs[0]; ++k) if (fs[k]) fclose(fs[k]);
     return 0;
@@ -321,7 +324,7 @@ int h_job_finish_part(h_job *j, int64_t lo, int64_t hi, const l2r_result *res, c
 #include <pthread.h>
 #include <unistd.h>
 typedef struct {
-    h_job *j; const l2r_result *res; int64_t lo, hi; int first;
+    h_job *j; const h_reads *reads; const h_update_opts *files; const l2r_result *res; int64_t lo, hi; int first;
     char *buf[7]; size_t len[7]; int64_t cnt[H_N_SUMMARY];
     h_part_genes genes;
     int done;
@@ -331,8 +334,8 @@ static void *tail_part_main(void *arg)
 {
     tail_part *t = (tail_part *)arg;
     h_job *j = t->j;
-    h_update_opts o = j->o;
-    FILE *want[7] = {j->o.out_gtf, j->o.exon_bed, j->o.bam_gtf, j->o.bam_detail, j->o.known_gtf, j->o.novel_gtf, j->o.unrecog_gtf};
+    h_update_opts o = *t->files;
+    FILE *want[7] = {o.out_gtf, o.exon_bed, o.bam_gtf, o.bam_detail, o.known_gtf, o.novel_gtf, o.unrecog_gtf};
     FILE *fs[7];
     for (int k = 0; k < 7; ++k) {
         t->buf[k] = NULL; t->len[k] = 0;
@@ -341,7 +344,7 @@ static void *tail_part_main(void *arg)
     }
     o.out_gtf = fs[0]; o.exon_bed = fs[1]; o.bam_gtf = fs[2]; o.bam_detail = fs[3]; o.known_gtf = fs[4]; o.novel_gtf = fs[5]; o.unrecog_gtf = fs[6];
     o.summary = NULL; o.summary_counts = t->cnt; o.no_detail_header = !t->first; o.part_genes = &t->genes;
-    h_reads part = j->reads;
+    h_reads part = *t->reads;
     part.n = t->hi - t->lo; part.tid += t->lo; part.pos += t->lo; part.rev += t->lo; part.qname += t->lo; part.cig_off += t->lo;
     if (part.tid_name) part.tid_name += t->lo;
     const l2r_result *res = t->res;
@@ -359,21 +362,21 @@ static void *tail_part_main(void *arg)
 }
 
 /* number of tail threads: L2R_THREADS, else the online CPUs (at most 64); 1 when the partition argument does not hold */
-static int tail_threads(const h_job *j)
+static int tail_threads(const h_job *j, const h_reads *reads)
 {
     const char *e = getenv("L2R_THREADS");
     long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
     if (n > 64) n = 64;
-    if (n < 2 || (!e && j->reads.n < 20000)) return 1;                       /* small inputs: not worth the threads (unless asked for) */
+    if (n < 2 || (!e && reads->n < 20000)) return 1;                         /* small inputs: not worth the threads (unless asked for) */
     if (j->o.prm.split_trans && j->sj.n > 0) return 1;                      /* Q2: split pieces are compared across chromosomes */
-    for (int64_t i = 1; i < j->reads.n; ++i) if (j->reads.tid[i] < j->reads.tid[i - 1]) return 1;     /* not grouped by chromosome */
+    for (int64_t i = 1; i < reads->n; ++i) if (reads->tid[i] < reads->tid[i - 1]) return 1;     /* not grouped by chromosome */
     return (int)n;
 }
 
 /* The parts of the threaded tail.  The order-dependent lists of the tail look backwards from their end and stop at the first entry
  * that lies before the new one: merge_trans at `t->start > T->t[i].end` or a smaller tid (src/update_gtf.c:147), the novel exon /
- * site / junction lists at a smaller tid, comparing coordinates (:181-222).  So the reads can be cut wherever a read starts behind the
- * END OF EVERY READ in front of it on its chromosome (a gap in the coverage; chromosome boundaries are such places): no list entry made
+ * site / junction lists at a smaller tid, comparing coordinates (:181-222).  So the reads can be cut wherever every read from there on
+ * starts behind the END OF EVERY READ in front of the cut on its chromosome (a gap in the coverage; chromosome boundaries are such places): no list entry made
  * from the reads in front of the cut can stop short of, merge with or equal an entry made behind it.  Every part lies inside one
  * chromosome; their outputs are concatenated and their counters added.  The one list that compares across a cut is the gene list
  * (merge_gene, :181-189: equal gene_id anywhere on the chromosome, and with the list's last entry of a smaller tid): the parts report
@@ -382,13 +385,23 @@ typedef struct {
     int32_t cur_tid; const char **cur; int n_cur, cap_cur;       /* ids of the sequential list's entries under its last tid */
     const char *lower;                                           /* id of its last entry with a smaller tid, NULL: none */
     const char *last;                                            /* id of its last entry, NULL: empty */
+    const char **first; int n_first, first_done;                 /* ids of the entries under the list's FIRST tid (what a caller that joins whole shards needs) */
 } gene_fix;
+
+static void gene_fix_snapshot(gene_fix *f)
+{
+    if (f->first_done) return;
+    f->first = (const char **)h_malloc((size_t)(f->n_cur ? f->n_cur : 1) * sizeof(char *));
+    memcpy((void *)f->first, f->cur, (size_t)f->n_cur * sizeof(char *));
+    f->n_first = f->n_cur; f->first_done = 1;
+}
 
 /* ids `gids[0 .. n)` (in the order the part added them, all under `tid`) join the sequential list: returns how many of them it would
  * NOT have taken (the part counted them, the total must not) */
 static int gene_fix_join(gene_fix *f, int32_t tid, char **gids, int n)
 {
     if (n <= 0) return 0;
+    if (f->last != NULL && tid > f->cur_tid) gene_fix_snapshot(f);
     if (f->last == NULL || tid > f->cur_tid) { f->lower = f->last; f->n_cur = 0; f->cur_tid = tid; }
     int dup = 0;
     for (int k = 0; k < n; ++k) {
@@ -416,9 +429,10 @@ static void *tail_queue_main(void *arg)
     return NULL;
 }
 
-static int finish_threaded(h_job *j, const l2r_result *res, int n_thr)
+static int finish_threaded(h_job *j, const h_reads *reads, const h_update_opts *files, const l2r_result *res, int n_thr, int first_part,
+                           int64_t *counters_out, h_part_genes *genes_out)
 {
-    const int64_t N = j->reads.n;
+    const int64_t N = reads->n;
     /* cut points: coverage gaps (see above), a part of about N / (4 n_thr) reads ends at the next one; always at a new chromosome */
     int64_t target = N / ((int64_t)n_thr * 4);
     if (target < 5000) target = 5000;
@@ -427,29 +441,38 @@ static int finish_threaded(h_job *j, const l2r_result *res, int n_thr)
 #define PUSH_CUT(v) do { if (n_cut == cap_cut) { cap_cut = cap_cut ? cap_cut * 2 : 256; cut = (int64_t *)h_realloc(cut, (size_t)cap_cut * sizeof(int64_t)); } cut[n_cut++] = (v); } while (0)
     PUSH_CUT(0);
     {
+        /* a cut in front of read i is safe iff every read from i on (of its chromosome) starts behind the end of every read in front
+         * of i: suffix minimum of the starts against the running maximum of the ends (records need not be sorted inside a chromosome) */
+        int32_t *smin = (int32_t *)h_malloc((size_t)(N + 1) * sizeof(int32_t));
+        for (int64_t i = N - 1; i >= 0; --i) {
+            const int64_t x0 = res->ex_off[i], x1 = res->ex_off[i + 1];
+            const int32_t start = x1 > x0 ? res->ex_start[x0] : reads->pos[i] + 1;
+            smin[i] = (i + 1 < N && reads->tid[i + 1] == reads->tid[i] && smin[i + 1] < start) ? smin[i + 1] : start;
+        }
         int32_t run_end = INT32_MIN;
         for (int64_t i = 0; i < N; ++i) {
             const int64_t x0 = res->ex_off[i], x1 = res->ex_off[i + 1];
-            const int32_t start = x1 > x0 ? res->ex_start[x0] : j->reads.pos[i] + 1, end = x1 > x0 ? res->ex_end[x1 - 1] : j->reads.pos[i];
+            const int32_t end = x1 > x0 ? res->ex_end[x1 - 1] : reads->pos[i];
             if (i > 0) {
-                const int new_chrom = j->reads.tid[i] != j->reads.tid[i - 1];
-                if (new_chrom || (start > run_end && i - cut[n_cut - 1] >= target)) { PUSH_CUT(i); }
+                const int new_chrom = reads->tid[i] != reads->tid[i - 1];
+                if (new_chrom || (smin[i] > run_end && i - cut[n_cut - 1] >= target)) { PUSH_CUT(i); }
                 if (new_chrom) run_end = INT32_MIN;
             }
             if (end > run_end) run_end = end;
         }
+        free(smin);
     }
     PUSH_CUT(N);
 #undef PUSH_CUT
     const int n_parts = n_cut - 1;
     tail_part *parts = (tail_part *)calloc((size_t)n_parts, sizeof *parts);
-    for (int k = 0; k < n_parts; ++k) { parts[k].j = j; parts[k].res = res; parts[k].lo = cut[k]; parts[k].hi = cut[k + 1]; parts[k].first = k == 0; }
+    for (int k = 0; k < n_parts; ++k) { parts[k].j = j; parts[k].reads = reads; parts[k].files = files; parts[k].res = res; parts[k].lo = cut[k]; parts[k].hi = cut[k + 1]; parts[k].first = first_part && k == 0; }
     tail_queue tq; tq.parts = parts; tq.n_parts = n_parts; tq.next = 0; pthread_mutex_init(&tq.mu, NULL);
     if (n_thr > n_parts) n_thr = n_parts;
     pthread_t *th = (pthread_t *)calloc((size_t)n_thr, sizeof *th);
     for (int k = 0; k < n_thr; ++k) if (pthread_create(&th[k], NULL, tail_queue_main, &tq)) h_fatal("update_gtf", "pthread_create failed");
     int64_t total[H_N_SUMMARY]; memset(total, 0, sizeof total);
-    FILE *outs[7] = {j->o.out_gtf, j->o.exon_bed, j->o.bam_gtf, j->o.bam_detail, j->o.known_gtf, j->o.novel_gtf, j->o.unrecog_gtf};
+    FILE *outs[7] = {files->out_gtf, files->exon_bed, files->bam_gtf, files->bam_detail, files->known_gtf, files->novel_gtf, files->unrecog_gtf};
     gene_fix fix[2]; memset(fix, 0, sizeof fix);
     static const int gene_cnt[2] = {H_CNT_UPDATED_GENES, H_CNT_KNOWN_GENES};
     double t_join = 0.0, t_write = 0.0;
@@ -462,14 +485,25 @@ static int finish_threaded(h_job *j, const l2r_result *res, int n_thr)
         t_join += tb - ta; t_write += h_now() - tb;
         for (int q = 0; q < 7; ++q) { free(parts[k].buf[q]); parts[k].buf[q] = NULL; }
         for (int q = 0; q < H_N_SUMMARY; ++q) total[q] += parts[k].cnt[q];
-        const int32_t tid = parts[k].hi > parts[k].lo ? j->reads.tid[parts[k].lo] : 0;
+        const int32_t tid = parts[k].hi > parts[k].lo ? reads->tid[parts[k].lo] : 0;
         for (int q = 0; q < 2; ++q) total[gene_cnt[q]] -= gene_fix_join(&fix[q], tid, parts[k].genes.first_gids[q], parts[k].genes.n_first[q]);
     }
     for (int k = 0; k < n_thr; ++k) pthread_join(th[k], NULL);
     pthread_mutex_destroy(&tq.mu);
-    for (int q = 0; q < 2; ++q) free((void *)fix[q].cur);
+    if (genes_out) {                                        /* the whole range as ONE part of a caller that joins shards (h_part_genes) */
+        h_part_genes_free(genes_out);
+        for (int q = 0; q < 2; ++q) {
+            gene_fix_snapshot(&fix[q]);
+            genes_out->last_gid[q] = fix[q].last ? strdup(fix[q].last) : NULL;
+            genes_out->n_first[q] = fix[q].n_first;
+            genes_out->first_gids[q] = (char **)h_malloc((size_t)(fix[q].n_first ? fix[q].n_first : 1) * sizeof(char *));
+            for (int k = 0; k < fix[q].n_first; ++k) genes_out->first_gids[q][k] = strdup(fix[q].first[k]);
+        }
+    }
+    for (int q = 0; q < 2; ++q) { free((void *)fix[q].cur); free((void *)fix[q].first); }
     for (int k = 0; k < n_parts; ++k) h_part_genes_free(&parts[k].genes);
-    if (j->o.summary) h_write_summary_text(j->o.summary, j->anno.gene_n, (int)j->anno.n_tx, total);
+    if (counters_out) memcpy(counters_out, total, sizeof total);
+    else if (files->summary) h_write_summary_text(files->summary, j->anno.gene_n, (int)j->anno.n_tx, total);
     /* (tried: detail.txt -- more than half of the bytes, rows independent -- in 64 parts of its own beside the chromosome-aligned
      *  ones: slower, 2.2 -> 2.35 s on the 256-core GPU box; the tail is bound by page faults / stream growth of ~4 GB of fresh
      *  memory in one process, not by formatting; the three writer groups of a part -- lists | per-read files | summary -- side by side
