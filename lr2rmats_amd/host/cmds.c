@@ -575,10 +575,12 @@ static void result_reserve(h_result *r, int64_t reads_cap, int64_t ex_cap)
  *   acc_read != NULL: `out` = only the reads check_trans() hands to novel_T / merge_trans (update_gtf.c:946-960), in
  *                     input order, through the device-side compaction (l2r_download_accepted: about a third of the bytes
  *                     over PCIe and no host pass over the rest); *acc_read[k] = input index of row k. */
+static int g_device = 0;                                    /* the HIP device of this process (a child of the multi-GPU run: its own) */
+
 static void run_engine(const char *who, const l2r_params *prm, const l2r_annotation *a, const l2r_junctions *s,
                        const l2r_reads *r, h_result *out, int64_t **acc_read)
 {
-    l2r_ctx *ctx = l2r_create(0);
+    l2r_ctx *ctx = l2r_create(g_device);
     if (!ctx) engine_fail(who);
     h_stage_time("engine: create");
     if (l2r_set_params(ctx, prm) || l2r_set_outputs(ctx, acc_read ? L2R_WANT_ACCEPTED : L2R_WANT_RESULTS) ||
@@ -593,7 +595,7 @@ static void run_engine(const char *who, const l2r_params *prm, const l2r_annotat
         l2r_reads sub = *r;
         sub.n_reads = n; sub.n_cigar = r->cig_off[hi] - r->cig_off[lo];
         sub.tid = r->tid + lo; sub.pos = r->pos + lo; sub.rev = r->rev + lo; sub.cig = r->cig + r->cig_off[lo];
-        sub.first_read_index = lo;
+        sub.first_read_index = r->first_read_index + lo;
         if (lo > 0) {                                        /* the engine wants offsets that start at 0 */
             off_tmp = (int64_t *)h_realloc(off_tmp, (size_t)(n + 1) * 8);
             for (int64_t i = 0; i <= n; ++i) off_tmp[i] = r->cig_off[lo + i] - r->cig_off[lo];
@@ -672,11 +674,182 @@ int h_job_finish_accepted(h_job *j, const l2r_result *res, const int64_t *read_i
     return rc;
 }
 
+/* ---- several GPUs of one node, in C (L2R_GPUS=N) -------------------------------------------------------------------------
+ * The parent parses the inputs ONCE (the BAM is read and inflated once per node, the GTF parsed once) and, before anything has
+ * touched HIP, forks one child per device.  The children inherit the record and annotation arrays (copy on write: nothing is
+ * copied or re-read), take one chromosome-aligned shard each -- cut by bytes per read like workload.aligned_shard_bounds --,
+ * classify it on their GPU and run the order-dependent tail on it (h_job_finish_part: the partition argument of the threaded
+ * tail, no shard looks across a chromosome boundary) into part files; the parent concatenates the parts, adds the counters and
+ * counts a gene id that continues across a cut once.  No data-path collective: nothing of size O(reads) crosses xGMI.  The route
+ * that needs one (-s with a junction table: split pieces compare across chromosomes) and records that are not grouped by
+ * chromosome run on one GPU; `python -m lr2rmats_amd.dist` has the RCCL all-gatherv for them.
+ * L2R_GPU_MAP="0,0,0": device of every child (tests put several children on one GPU). */
+#include <sys/wait.h>
+static int multi_gpu_ok(const h_job *j)
+{
+    if (j->mode != 0 || (j->o.prm.split_trans && j->sj.n > 0)) return 0;
+    for (int64_t i = 1; i < j->reads.n; ++i)
+        if (j->reads.tid[i] < j->reads.tid[i - 1] || (j->reads.tid[i] == j->reads.tid[i - 1] && j->reads.pos[i] < j->reads.pos[i - 1])) return 0;
+    return 1;
+}
+
+static void meta_write(const char *path, const int64_t *cnt, const h_part_genes *g)
+{
+    FILE *f = fopen(path, "w");
+    if (!f) h_fatal("update_gtf", "Can not open \"%s\" for writing\n", path);
+    for (int k = 0; k < H_N_SUMMARY; ++k) fprintf(f, "%lld\n", (long long)cnt[k]);
+    for (int q = 0; q < 2; ++q) {
+        fprintf(f, "%d %d\n", g->last_gid[q] ? 1 : 0, g->n_first[q]);
+        if (g->last_gid[q]) fprintf(f, "%s\n", g->last_gid[q]);
+        for (int k = 0; k < g->n_first[q]; ++k) fprintf(f, "%s\n", g->first_gids[q][k]);
+    }
+    if (fclose(f) != 0) h_fatal("update_gtf", "write error on \"%s\"", path);
+}
+
+static void meta_read(const char *path, int64_t *cnt, h_part_genes *g)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) h_fatal("update_gtf", "a child of the multi-GPU run left no \"%s\"", path);
+    char line[2 * H_NAME_MAX + 64];
+    memset(g, 0, sizeof *g);
+    for (int k = 0; k < H_N_SUMMARY; ++k) { long long v = 0; if (!fgets(line, sizeof line, f) || sscanf(line, "%lld", &v) != 1) h_fatal("update_gtf", "bad \"%s\"", path); cnt[k] = v; }
+    for (int q = 0; q < 2; ++q) {
+        int has_last = 0, n = 0;
+        if (!fgets(line, sizeof line, f) || sscanf(line, "%d %d", &has_last, &n) != 2) h_fatal("update_gtf", "bad \"%s\"", path);
+        if (has_last) { if (!fgets(line, sizeof line, f)) h_fatal("update_gtf", "bad \"%s\"", path); line[strcspn(line, "\n")] = 0; g->last_gid[q] = strdup(line); }
+        g->first_gids[q] = (char **)h_malloc((size_t)(n ? n : 1) * sizeof(char *)); g->n_first[q] = n;
+        for (int k = 0; k < n; ++k) { if (!fgets(line, sizeof line, f)) h_fatal("update_gtf", "bad \"%s\"", path); line[strcspn(line, "\n")] = 0; g->first_gids[q][k] = strdup(line); }
+    }
+    fclose(f);
+}
+
+static int update_gtf_multi(h_job *j, int n_gpus)
+{
+    const int64_t N = j->reads.n;
+    /* chromosome-aligned cuts by bytes per read (4 per CIGAR op + 64): the nearest chromosome boundary to every ideal cut */
+    int64_t *cut = (int64_t *)h_malloc((size_t)(n_gpus + 1) * sizeof(int64_t));
+    {
+        double total = 0.0;
+        for (int64_t i = 0; i < N; ++i) total += 4.0 * (double)(j->reads.cig_off[i + 1] - j->reads.cig_off[i]) + 64.0;
+        double run = 0.0; int k = 1;
+        cut[0] = 0;
+        for (int64_t i = 0; i < N && k < n_gpus; ++i) {
+            while (k < n_gpus && run >= total * (double)k / (double)n_gpus) {
+                int64_t lo = i, hi = i;
+                while (lo > cut[k - 1] && j->reads.tid[lo] == j->reads.tid[lo - 1]) --lo;
+                while (hi < N && hi > 0 && j->reads.tid[hi] == j->reads.tid[hi - 1]) ++hi;
+                int64_t c = (i - lo <= hi - i) ? lo : hi;
+                if (c < cut[k - 1]) c = cut[k - 1];
+                cut[k++] = c;
+            }
+            run += 4.0 * (double)(j->reads.cig_off[i + 1] - j->reads.cig_off[i]) + 64.0;
+        }
+        while (k <= n_gpus) cut[k++] = N;
+    }
+    /* the part files sit next to the outputs; an updated GTF that goes to stdout is collected in a temporary file */
+    char tmp_base[1024] = "";
+    if (!j->out_path[0]) {
+        const char *td = getenv("TMPDIR");
+        snprintf(tmp_base, sizeof tmp_base, "%s/l2r_gtf_XXXXXX", td && td[0] ? td : "/tmp");
+        const int fd = mkstemp(tmp_base);
+        if (fd < 0) h_fatal("update_gtf", "mkstemp failed");
+        close(fd);
+    }
+    const char *map = getenv("L2R_GPU_MAP");
+    pid_t *pid = (pid_t *)calloc((size_t)n_gpus, sizeof *pid);
+    fflush(NULL);
+    for (int k = 0; k < n_gpus; ++k) {
+        int dev = k;
+        if (map) { const char *p = map; for (int q = 0; q < k && p; ++q) { p = strchr(p, ','); if (p) ++p; } if (p) dev = atoi(p); }
+        pid[k] = fork();
+        if (pid[k] < 0) h_fatal("update_gtf", "fork failed");
+        if (pid[k] == 0) {
+            /* ---- a child: its shard on its GPU (the first HIP call of this process is in here) */
+            g_device = dev;
+            const int64_t lo = cut[k], hi = cut[k + 1];
+            char suffix[32]; snprintf(suffix, sizeof suffix, ".part%03d", k);
+            int64_t cnt[H_N_SUMMARY]; memset(cnt, 0, sizeof cnt);
+            l2r_params prm; l2r_annotation a; l2r_junctions s; l2r_reads r;
+            h_job_views(j, &prm, &a, &s, &r);
+            h_result out; memset(&out, 0, sizeof out);
+            int64_t *off = NULL;
+            if (hi > lo) {
+                l2r_reads sub = r;
+                sub.n_reads = hi - lo; sub.n_cigar = r.cig_off[hi] - r.cig_off[lo];
+                sub.tid = r.tid + lo; sub.pos = r.pos + lo; sub.rev = r.rev + lo; sub.cig = r.cig + r.cig_off[lo];
+                off = (int64_t *)h_malloc((size_t)(hi - lo + 1) * 8);
+                for (int64_t i = 0; i <= hi - lo; ++i) off[i] = r.cig_off[lo + i] - r.cig_off[lo];
+                sub.cig_off = off; sub.first_read_index = lo;
+                run_engine("update_gtf", &prm, &a, &s, &sub, &out, NULL);
+            } else result_reserve(&out, 0, 0);
+            l2r_result res = { out.n, out.n_ex, out.n_ex, out.ex_off, out.ex_start, out.ex_end, out.ex_flag, out.info, out.ref_tx };
+            h_job_finish_part(j, lo, hi, &res, suffix, tmp_base, k == 0, cnt);
+            char meta[1200]; snprintf(meta, sizeof meta, "%s%s.meta", j->out_path[0] ? j->out_path[0] : tmp_base, suffix);
+            meta_write(meta, cnt, &j->part_genes);
+            fflush(NULL);
+            _exit(0);
+        }
+    }
+    int failed = 0;
+    for (int k = 0; k < n_gpus; ++k) { int st = 0; if (waitpid(pid[k], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) failed = 1; }
+    if (failed) h_fatal("update_gtf", "a child of the multi-GPU run failed");
+    h_stage_time("children: engine + tail on every shard");
+    /* ---- join: counters, gene lists (an id equal to the last entry of the parts before is not counted again, h_part_genes), files */
+    int64_t total[H_N_SUMMARY]; memset(total, 0, sizeof total);
+    static const int gene_cnt[2] = {H_CNT_UPDATED_GENES, H_CNT_KNOWN_GENES};
+    char *last_gene[2] = {NULL, NULL};
+    const char *base0 = j->out_path[0] ? j->out_path[0] : tmp_base;
+    for (int k = 0; k < n_gpus; ++k) {
+        char meta[1200]; snprintf(meta, sizeof meta, "%s.part%03d.meta", base0, k);
+        int64_t cnt[H_N_SUMMARY]; h_part_genes g;
+        meta_read(meta, cnt, &g);
+        remove(meta);
+        for (int q = 0; q < H_N_SUMMARY; ++q) total[q] += cnt[q];
+        for (int q = 0; q < 2; ++q) {
+            if (h_part_genes_has_first(&g, q, last_gene[q])) total[gene_cnt[q]] -= 1;
+            if (g.last_gid[q]) { free(last_gene[q]); last_gene[q] = strdup(g.last_gid[q]); }
+        }
+        h_part_genes_free(&g);
+    }
+    free(last_gene[0]); free(last_gene[1]);
+    FILE *outs[7] = {j->o.out_gtf, j->o.exon_bed, j->o.bam_gtf, j->o.bam_detail, j->o.known_gtf, j->o.novel_gtf, j->o.unrecog_gtf};
+    char *buf = (char *)h_malloc(1 << 24);
+    for (int w = 0; w < 7; ++w) {
+        const char *path = w == 0 ? base0 : j->out_path[w];
+        if (!path || !outs[w]) continue;
+        for (int k = 0; k < n_gpus; ++k) {
+            char part[1200]; snprintf(part, sizeof part, "%s.part%03d", path, k);
+            FILE *f = fopen(part, "rb");
+            if (!f) h_fatal("update_gtf", "a child of the multi-GPU run left no \"%s\"", part);
+            size_t got;
+            while ((got = fread(buf, 1, 1 << 24, f)) > 0) fwrite(buf, 1, got, outs[w]);
+            fclose(f); remove(part);
+        }
+    }
+    free(buf);
+    if (tmp_base[0]) remove(tmp_base);
+    if (j->o.summary) h_write_summary_text(j->o.summary, j->anno.gene_n, (int)j->anno.n_tx, total);
+    FILE **fs[] = {&j->o.exon_bed, &j->o.bam_gtf, &j->o.bam_detail, &j->o.known_gtf, &j->o.novel_gtf, &j->o.unrecog_gtf, &j->o.summary};
+    for (size_t k = 0; k < sizeof fs / sizeof fs[0]; ++k) if (*fs[k]) { fclose(*fs[k]); *fs[k] = NULL; }
+    if (j->o.out_gtf && j->o.out_gtf != stdout) { fclose(j->o.out_gtf); j->o.out_gtf = NULL; } else fflush(stdout);
+    free(pid); free(cut);
+    h_stage_time("join: parts -> files");
+    return 0;
+}
+
 int h_cmd_update_gtf(int argc, char **argv)
 {
     int rc = 0;
     h_job *j = h_job_open(argc, argv, &rc);
     if (!j) return rc;
+    {   /* L2R_GPUS=N: one child per GPU (update_gtf_multi) when the partition argument holds, else this process and one GPU */
+        const char *eg = getenv("L2R_GPUS");
+        const int n_gpus = eg ? atoi(eg) : 1;
+        if (n_gpus > 1) {
+            if (multi_gpu_ok(j)) { rc = update_gtf_multi(j, n_gpus); h_job_free(j); return rc; }
+            fprintf(stderr, "[update_gtf] L2R_GPUS=%d: this input / option set needs one stream of records (records not coordinate sorted, -m g, or -s with -j): running on one GPU\n", n_gpus);
+        }
+    }
     l2r_params prm; l2r_annotation a; l2r_junctions s; l2r_reads r;
     h_job_views(j, &prm, &a, &s, &r);
     h_result out;

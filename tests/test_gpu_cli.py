@@ -235,3 +235,31 @@ def test_ranks_on_the_engine_write_the_single_gpu_files(oracle, tmp_path, files,
     want = {"partitioned": "partitioned", "gathered_full": "gathered full", "gathered_accepted": "gathered accepted",
             "unsorted": "one rank, gathered full"}[route]
     assert open(trace).read().strip() == want
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("n_gpus,stdout", [(3, False), (5, True)])
+def test_c_cli_with_several_gpu_children_writes_the_single_gpu_files(tmp_path, files, n_gpus, stdout):
+    """`L2R_GPUS=N lr2rmats update-gtf ...` (host/cmds.c update_gtf_multi): the C binary parses the inputs once, forks one child per
+    device before any HIP call, every child classifies a chromosome-aligned shard and runs the tail on it, the parent joins the
+    parts.  Here the children share GPU 0 (L2R_GPU_MAP); more children than chromosomes leaves some shards empty.  Every file
+    equals the one-process run's, the updated GTF also when it goes to stdout."""
+    d, anno, reads, sam, bam, gtf = files
+    one, many = _paths(tmp_path, "one"), _paths(tmp_path, "many")
+    r = hostlib.run_cli(_args(["-l", "3"], one, bam, gtf))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    env = {"L2R_GPUS": n_gpus, "L2R_GPU_MAP": ",".join(["0"] * n_gpus), "L2R_THREADS": 3, "L2R_TAIL_PART_READS": 500}
+    args = _args(["-l", "3"], many, bam, gtf)
+    if stdout:
+        i = args.index("-o")
+        del args[i:i + 2]
+        r = hostlib.run_cli(args, stdout_path=many["gtf"], env=env)
+    else:
+        r = hostlib.run_cli(args, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    for k in OUTS:
+        assert filecmp.cmp(one[k], many[k], shallow=False), k
+    assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f]
+    # an option set that needs one stream of records says so and runs on one GPU
+    r = hostlib.run_cli(["update-gtf", "-m", "g", "-b", sam, "-l", "3", gtf, gtf], env={"L2R_GPUS": 2, "L2R_GPU_MAP": "0,0"})
+    assert r.returncode == 0 and b"running on one GPU" in r.stderr
