@@ -473,7 +473,7 @@ static void parse_bam(const blob *b, h_chroms *chr, h_reads *out, int skip_unmap
 
 /* ------------------------------------------------------------------ BAM in bounded memory
  * The reference reads record by record (src/bam2gtf.c:150, src/update_gtf.c:1069).  Here a BGZF-compressed BAM goes through WINDOWS
- * of whole BGZF blocks (64 MiB of the file at a time; L2R_READ_WINDOW overrides): read, inflated block-parallel, its complete
+ * of whole BGZF blocks (128 MiB of the file at a time; L2R_READ_WINDOW overrides): read, inflated block-parallel, its complete
  * records extracted on several threads and appended to the arrays; the bytes of a record that continues in the next window are
  * carried over.  Neither the file nor the inflated stream is ever in memory as a whole: the peak is the record arrays (which the
  * engine needs anyway) plus one window.  h_read_alignments() runs this to the end; bam2gtf consumes it batch by batch. */
@@ -553,7 +553,7 @@ h_aln_stream *h_aln_stream_open(const char *fn, h_chroms *chr, int skip_unmapped
     free(w);
     if (!is_bam) { fclose(f); free(s); return NULL; }
     fseek(f, 0, SEEK_SET); s->eof = 0;
-    s->window = (size_t)64 << 20;
+    s->window = (size_t)128 << 20;
     const char *e = getenv("L2R_READ_WINDOW");
     if (e && atoll(e) >= 65536 + 64) s->window = (size_t)atoll(e);
     return s;

@@ -253,11 +253,14 @@ int h_job_finish(h_job *j, const l2r_result *res)
     hr.ex_flag = res->ex_flag; hr.info = res->info; hr.ref_tx = res->ref_tx;
     if (hr.n != j->reads.n) h_fatal("update_gtf", "result covers %lld reads, input has %lld", (long long)hr.n, (long long)j->reads.n);
     const int n_thr = tail_threads(j, &j->reads);
+    h_stage_time("  tail: input checks");
     if (n_thr > 1) finish_threaded(j, &j->reads, &j->o, res, n_thr, 1, NULL, NULL);
     else h_update_tail(&j->o, &j->chr, &j->reads, &j->anno, &hr, j->sj.n);
+    h_stage_time("  tail: parts + writers");
     FILE **fs[] = {&j->o.exon_bed, &j->o.bam_gtf, &j->o.bam_detail, &j->o.known_gtf, &j->o.novel_gtf, &j->o.unrecog_gtf, &j->o.summary};
     for (size_t k = 0; k < sizeof fs / sizeof fs[0]; ++k) if (*fs[k]) { fclose(*fs[k]); *fs[k] = NULL; }
     if (j->o.out_gtf && j->o.out_gtf != stdout) { fclose(j->o.out_gtf); j->o.out_gtf = NULL; } else fflush(stdout);
+    h_stage_time("  tail: files closed");
     return 0;
 }
 
@@ -415,6 +418,19 @@ static int gene_fix_join(gene_fix *f, int32_t tid, char **gids, int n)
 }
 
 typedef struct { tail_part *parts; int n_parts; int next; pthread_mutex_t mu; } tail_queue;
+/* one writer per output file: the parts' streams of that file in order, each as soon as its part is done (the files are different
+ * inodes: the writers do not contend; pwrite of one file by many threads did, see below) */
+typedef struct { tail_part *parts; int n_parts; int which; FILE *out; } tail_writer;
+static void *tail_writer_main(void *arg)
+{
+    tail_writer *w = (tail_writer *)arg;
+    for (int k = 0; k < w->n_parts; ++k) {
+        while (!__atomic_load_n(&w->parts[k].done, __ATOMIC_ACQUIRE)) usleep(200);
+        if (w->parts[k].len[w->which]) fwrite(w->parts[k].buf[w->which], 1, w->parts[k].len[w->which], w->out);
+        free(w->parts[k].buf[w->which]); w->parts[k].buf[w->which] = NULL;
+    }
+    return NULL;
+}
 static void *tail_queue_main(void *arg)
 {
     tail_queue *q = (tail_queue *)arg;
@@ -464,6 +480,7 @@ static int finish_threaded(h_job *j, const h_reads *reads, const h_update_opts *
     }
     PUSH_CUT(N);
 #undef PUSH_CUT
+    h_stage_time("  tail: cut points");
     const int n_parts = n_cut - 1;
     tail_part *parts = (tail_part *)calloc((size_t)n_parts, sizeof *parts);
     for (int k = 0; k < n_parts; ++k) { parts[k].j = j; parts[k].reads = reads; parts[k].files = files; parts[k].res = res; parts[k].lo = cut[k]; parts[k].hi = cut[k + 1]; parts[k].first = first_part && k == 0; }
@@ -475,19 +492,22 @@ static int finish_threaded(h_job *j, const h_reads *reads, const h_update_opts *
     FILE *outs[7] = {files->out_gtf, files->exon_bed, files->bam_gtf, files->bam_detail, files->known_gtf, files->novel_gtf, files->unrecog_gtf};
     gene_fix fix[2]; memset(fix, 0, sizeof fix);
     static const int gene_cnt[2] = {H_CNT_UPDATED_GENES, H_CNT_KNOWN_GENES};
-    double t_join = 0.0, t_write = 0.0;
+    const double t_w0 = h_now();
+    tail_writer wr[7]; pthread_t wth[7]; int n_wr = 0;
+    for (int q = 0; q < 7; ++q) if (outs[q]) {
+        wr[n_wr].parts = parts; wr[n_wr].n_parts = n_parts; wr[n_wr].which = q; wr[n_wr].out = outs[q];
+        if (pthread_create(&wth[n_wr], NULL, tail_writer_main, &wr[n_wr])) h_fatal("update_gtf", "pthread_create failed");
+        ++n_wr;
+    }
     for (int k = 0; k < n_parts; ++k) {
-        /* the parts are written in order as they finish (the queue hands them out in order, so the next one to write is among the first done) */
-        const double ta = h_now();
         while (!__atomic_load_n(&parts[k].done, __ATOMIC_ACQUIRE)) usleep(200);
-        const double tb = h_now();
-        for (int q = 0; q < 7; ++q) if (outs[q] && parts[k].len[q]) fwrite(parts[k].buf[q], 1, parts[k].len[q], outs[q]);
-        t_join += tb - ta; t_write += h_now() - tb;
-        for (int q = 0; q < 7; ++q) { free(parts[k].buf[q]); parts[k].buf[q] = NULL; }
         for (int q = 0; q < H_N_SUMMARY; ++q) total[q] += parts[k].cnt[q];
         const int32_t tid = parts[k].hi > parts[k].lo ? reads->tid[parts[k].lo] : 0;
         for (int q = 0; q < 2; ++q) total[gene_cnt[q]] -= gene_fix_join(&fix[q], tid, parts[k].genes.first_gids[q], parts[k].genes.n_first[q]);
     }
+    const double t_join = h_now() - t_w0;
+    for (int q = 0; q < n_wr; ++q) pthread_join(wth[q], NULL);
+    const double t_write = h_now() - t_w0;
     for (int k = 0; k < n_thr; ++k) pthread_join(th[k], NULL);
     pthread_mutex_destroy(&tq.mu);
     if (genes_out) {                                        /* the whole range as ONE part of a caller that joins shards (h_part_genes) */
@@ -509,7 +529,7 @@ static int finish_threaded(h_job *j, const h_reads *reads, const h_update_opts *
      *  memory in one process, not by formatting; the three writer groups of a part -- lists | per-read files | summary -- side by side
      *  on threads of their own: slower as well, 2.1 -> 2.46 s; the parts' streams written by 16 threads with pwrite at their offsets:
      *  0.40 -> 0.55 s, writes to one file serialise on its inode lock) */
-    if (getenv("L2R_TIMING")) fprintf(stderr, "[timing]   tail: %d parts on %d threads, waiting for them %.3f s, copying their streams out %.3f s\n", n_parts, n_thr, t_join, t_write);
+    if (getenv("L2R_TIMING")) fprintf(stderr, "[timing]   tail: %d parts on %d threads done after %.3f s, their streams written (one writer per file) after %.3f s\n", n_parts, n_thr, t_join, t_write);
     free(parts); free(th); free(cut);
     return 0;
 }
