@@ -141,7 +141,7 @@ def pmc_traffic(kernels, config: str, n_reads: int):
     WRITE_SIZE need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots"; tools/profile.sh + tools/pmc_csv_summary.py
     make the file).  Only reported when the file was measured on these kernels, this config and this read count.
     Returns ({kernel: bytes}, note)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if config == "cfg3" else "pmc_traffic_%s.json" % config)
     try:
         with open(path) as fh:
             t = json.load(fh)
