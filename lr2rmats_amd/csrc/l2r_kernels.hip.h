@@ -1328,13 +1328,12 @@ __device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc 
 }
 
 // Known / known site / reference transcript / full-length / flag bytes of one read from its masks.
-// STRIDE: elements between the work words of consecutive exons (slab pipeline: 256).  emit(k, flag byte) receives the exons' flags
-// (the classic kernel writes them back over the work words, the slab kernels store them straight into the result array).
-template <int LEVEL, int STRIDE = 1, typename Emit>
-__device__ __forceinline__ Verdict decide(const TileLds &L, const TileDesc &d, uint32_t local, uint32_t n, const ReadEnds &re,
-                                          const VisitMasks &vm, const SiteMasks &sm, bool rev_in, Emit emit)
+// getw(k) = the work word map_exons left for exon k, emit(k, flag byte) receives the exons' flags (the classic kernel keeps both in its
+// 16-bit W array, the slab kernel in the upper bits of its staged positions).
+template <int LEVEL, typename GetW, typename Emit>
+__device__ __forceinline__ Verdict decide(const TileLds &L, const TileDesc &d, uint32_t n, const ReadEnds &re,
+                                          const VisitMasks &vm, const SiteMasks &sm, bool rev_in, GetW getw, Emit emit)
 {
-    uint16_t *W = L.W + local;
     // ---- first known transcript in visiting order
     int jstar = -1;
     if (n > 1) {
@@ -1376,7 +1375,7 @@ __device__ __forceinline__ Verdict decide(const TileLds &L, const TileDesc &d, u
     const uint32_t site_bits = known ? 0u : (uint32_t)(F_DON | F_ACC);         // bits 12, 13 of a work word: the site is in V' (F_DON = 2, F_ACC = 4)
     if (n > 1) {
         for (int k = 0; k < (int)n; ++k) {
-            const uint32_t w = W[k * STRIDE];
+            const uint32_t w = getw(k);
             uint32_t f = ((w & 63u) > lim ? (uint32_t)F_EXON : 0u) | (((w >> 6) & 63u) > lim ? (uint32_t)F_JUNC : 0u) | ((~w >> 11) & site_bits);
             f &= (k + 1 == (int)n) ? (uint32_t)F_EXON : 0xffu;                   // the last exon has no junction behind it
             emit(k, f);
@@ -1581,7 +1580,7 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         L2R_STAMP(3);
         if (work && !redo) {
             uint16_t *const Wr = s_W + local;
-            const Verdict vd = decide<LEVEL>(L, d, local, n, re, vm, sm, rev_in, [&](int k, uint32_t f) { Wr[k] = (uint16_t)f; });
+            const Verdict vd = decide<LEVEL>(L, d, n, re, vm, sm, rev_in, [&](int k) { return (uint32_t)Wr[k]; }, [&](int k, uint32_t f) { Wr[k] = (uint16_t)f; });
             info = vd.info; ref = vd.ref;
         } else if (active && in_lds) {
             for (int k = 0; k < (int)n; ++k) s_W[local + k] = (uint16_t)0;

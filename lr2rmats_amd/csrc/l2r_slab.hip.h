@@ -292,13 +292,16 @@ struct SlabRows { SlabRow last, x[SLAB_AHEAD]; };        // a column's row 0 (th
 // The tile's results on their way out: the lanes of k_probe_slab hold one READ each (slot order), the result arrays want the exons
 // in read order (exon k of a read at ex_off + k) -- written lane by lane that is one scattered 4-byte store per lane and exon
 // (measured: 3 x the whole kernel).  So every exon is left in LDS at its POSITION inside the tile (pos = exons of the tile's reads
-// before this one, in read order, + k): start in S[pos], and in LW[pos] the 16-bit length below the exon's work word (later its flag
-// byte).  After one barrier the tile's block of the result arrays is written with 16-byte stores, thread j positions 4j .. 4j + 3.
-// SLAB_POS_CAP positions fit (8 bytes each: with the dictionary slices 27 KB per workgroup, 6 workgroups per CU); a read whose
-// exons lie behind that (a tile of very long reads) is written directly and classified by the generic kernel.
-constexpr int SLAB_POS_CAP = 2416;
-constexpr uint32_t SLAB_POS_SKIP = 0x80000000u;          // LW of a position that was written directly
-struct SlabStage { int32_t *S; uint32_t *LW; uint32_t loc; bool fits; };          // loc: the lane's first position
+// before this one, in read order, + k), in 6 bytes: A[pos] = start relative to the tile's first read (18 bits: a fast tile spans
+// less than 384 buckets of 512 bases) below the exon's 14-bit work word (later its flag byte), L[pos] = the 16-bit length.  After
+// one barrier the tile's block of the result arrays is written with 16-byte stores, thread j positions 4j .. 4j + 3.
+// SLAB_POS_CAP positions fit (with the dictionary slices 22.3 KB per workgroup, 7 workgroups per CU); a read whose exons lie
+// behind that or further than 2^18 - 1 bases from the tile's start is written directly and classified by the generic kernel.
+constexpr int SLAB_POS_CAP = 2112;
+constexpr int SLAB_REL_BITS = 18;
+constexpr uint32_t SLAB_REL_MASK = (1u << SLAB_REL_BITS) - 1u;
+constexpr uint32_t SLAB_POS_SKIP = 0xffffffffu;          // A of a position that was written directly (a staged start is below 2^18 - 1)
+struct SlabStage { uint32_t *A; uint16_t *Ln; uint32_t loc; int32_t lo; bool fits; };          // loc: the lane's first position, lo: the tile's first start
 
 // map_exons (l2r_kernels.hip.h) with the read's exons streamed from its slab column: a row is the same exon number for the whole
 // wave = coalesced.  Exons k .. k + 3 sit in four register pairs with FIXED roles per unrolled round (no register rotation: a copy
@@ -310,7 +313,7 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
                                                     const SlabRows &q, const SlabStage &st)
 {
     SiteMasks m{0xffffffffu, 0u, 0u, 0u};
-    int32_t *const Sp = st.S + st.loc; uint32_t *const LWp = st.LW + st.loc;
+    uint32_t *const Ap = st.A + st.loc; uint16_t *const Lp = st.Ln + st.loc;
     // exon j of the read: row j + 1, the last one row 0
     SlabRow R0 = n == 1u ? q.last : q.x[0], R1 = n == 2u ? q.last : q.x[1], R2 = n == 3u ? q.last : q.x[2], R3 = n == 4u ? q.last : q.x[3];
     const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
@@ -352,7 +355,7 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         m.kor |= amj | dm;
         if (k == 0) m.dm_first = dm;
         m.am_last = (live && !junc) ? am : m.am_last;
-        if (live) { Sp[k] = s; LWp[k] = (lw & 0xffffu) | (word << 16); }
+        if (live) { Ap[k] = (uint32_t)(s - st.lo) | (word << SLAB_REL_BITS); Lp[k] = (uint16_t)lw; }
         ls = ls_n; hs = hs_n; le = le_n; he = he_n;
     };
     static_assert(SLAB_AHEAD == 4, "the round loop is unrolled by the number of exons in flight");
@@ -449,10 +452,10 @@ __device__ __forceinline__ void slab_copy_exons(SlabArgsK sa, const SlabOut &out
     // (an outlier's exons may be 64 kb and longer, which the 16-bit length of a staged position cannot say: written directly, its
     //  positions marked so that the tile's write-out leaves them alone)
     auto put = [&](uint32_t k, int s, int e) {
-        if (st.fits && !dense) { st.S[st.loc + k] = s; st.LW[st.loc + k] = (uint32_t)(e - s + 1) & 0xffffu; }
+        if (st.fits && !dense) { st.A[st.loc + k] = (uint32_t)(s - st.lo); st.Ln[st.loc + k] = (uint16_t)(e - s + 1); }
         else {
             out.start[out.dst + k] = s; out.end[out.dst + k] = e; out.flag[out.dst + k] = 0;
-            if (st.fits) st.LW[st.loc + k] = SLAB_POS_SKIP;
+            if (st.loc + k < (uint32_t)SLAB_POS_CAP) st.A[st.loc + k] = SLAB_POS_SKIP;
         }
     };
     if (dense) {
@@ -487,8 +490,7 @@ __device__ __forceinline__ void slab_classify(SlabArgsK sa, PipeArgsK a, const T
     // (sorted input: a tile is of one chromosome, the descriptor's)
     bool redo = active && (!fast || outlier || !st.fits || any_wide != 0 || (n > 1 && (pre & PRE_INSANE) != 0u));
     const bool work = active && !redo;
-    // work words: the upper halves of the read's LW words (16-bit elements 2 * loc + 1, + 3, ...)
-    const TileLds L{nullptr, nullptr, reinterpret_cast<uint16_t *>(st.LW), S.ent0, S.ent1, S.dir0, S.dir1, S.rdir, hk, hx, win};
+    const TileLds L{nullptr, nullptr, nullptr, S.ent0, S.ent1, S.dir0, S.dir1, S.rdir, hk, hx, win};
     const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, tilemask);
     redo = redo || vm.redo;
     stamp.mark(2);
@@ -497,8 +499,10 @@ __device__ __forceinline__ void slab_classify(SlabArgsK sa, PipeArgsK a, const T
     stamp.mark(3);
     if (active && !mapping) slab_copy_exons(sa, out, st, q, off, n, outlier);
     if (work && !redo) {
-        uint16_t *const Wf = reinterpret_cast<uint16_t *>(st.LW) + 2u * st.loc + 1u;
-        const Verdict vd = decide<LEVEL, 2>(L, d, 2u * st.loc + 1u, n, re, vm, sm, rev_in, [&](int k, uint32_t f) { Wf[2 * k] = (uint16_t)f; });
+        // work words: the upper 14 bits of the read's A words, replaced by the flag byte
+        uint32_t *const Ap = st.A + st.loc;
+        const Verdict vd = decide<LEVEL>(L, d, n, re, vm, sm, rev_in, [&](int k) { return Ap[k] >> SLAB_REL_BITS; },
+                                         [&](int k, uint32_t f) { Ap[k] = (Ap[k] & SLAB_REL_MASK) | (f << SLAB_REL_BITS); });
         info = vd.info; ref = vd.ref;
     }
     stamp.mark(4);
@@ -517,38 +521,41 @@ __device__ __forceinline__ void slab_classify(SlabArgsK sa, PipeArgsK a, const T
 
 // The staged positions [0, lim) of the tile -> the tile's block of the read-order result arrays (first slot xbase): 16-byte stores
 // of starts and ends, 4-byte stores of four flag bytes, at whatever alignment xbase has.
-__device__ __forceinline__ void slab_write_out(const SlabOut &out0 /* dst = xbase */, const int32_t *S, const uint32_t *LW, uint32_t lim)
+__device__ __forceinline__ void slab_write_out(const SlabOut &out0 /* dst = xbase */, const uint32_t *A, const uint16_t *Ln, int32_t lo, uint32_t lim)
 {
     for (uint32_t p = threadIdx.x * 4u; p < lim; p += (uint32_t)TILE_THREADS * 4u) {
-        const v4i_t s4 = *reinterpret_cast<const v4i_t *>(S + p);
-        const v4i_t w4 = *reinterpret_cast<const v4i_t *>(LW + p);
-        v4i_t e4;
-        e4.x = s4.x + (int)((uint32_t)w4.x & 0xffffu) - 1; e4.y = s4.y + (int)((uint32_t)w4.y & 0xffffu) - 1;
-        e4.z = s4.z + (int)((uint32_t)w4.z & 0xffffu) - 1; e4.w = s4.w + (int)((uint32_t)w4.w & 0xffffu) - 1;
-        const uint32_t f4 = (((uint32_t)w4.x >> 16) & 0xffu) | ((((uint32_t)w4.y >> 16) & 0xffu) << 8) | ((((uint32_t)w4.z >> 16) & 0xffu) << 16) | (((uint32_t)w4.w >> 16) << 24);
+        const v4i_t a4 = *reinterpret_cast<const v4i_t *>(A + p);
+        const uint2 l4 = *reinterpret_cast<const uint2 *>(Ln + p);
+        const uint32_t av[4] = {(uint32_t)a4.x, (uint32_t)a4.y, (uint32_t)a4.z, (uint32_t)a4.w};
+        const uint32_t lv[4] = {l4.x & 0xffffu, l4.x >> 16, l4.y & 0xffffu, l4.y >> 16};
+        v4i_t s4, e4;
+        s4.x = lo + (int)(av[0] & SLAB_REL_MASK); s4.y = lo + (int)(av[1] & SLAB_REL_MASK); s4.z = lo + (int)(av[2] & SLAB_REL_MASK); s4.w = lo + (int)(av[3] & SLAB_REL_MASK);
+        e4.x = s4.x + (int)lv[0] - 1; e4.y = s4.y + (int)lv[1] - 1; e4.z = s4.z + (int)lv[2] - 1; e4.w = s4.w + (int)lv[3] - 1;
+        const uint32_t f4 = ((av[0] >> SLAB_REL_BITS) & 0xffu) | (((av[1] >> SLAB_REL_BITS) & 0xffu) << 8) | (((av[2] >> SLAB_REL_BITS) & 0xffu) << 16) | ((av[3] >> SLAB_REL_BITS) << 24);
         const uint32_t at = out0.dst + p;
-        if (p + 4u <= lim && !(((uint32_t)w4.x | (uint32_t)w4.y | (uint32_t)w4.z | (uint32_t)w4.w) & SLAB_POS_SKIP)) {
+        const bool skip = av[0] == SLAB_POS_SKIP || av[1] == SLAB_POS_SKIP || av[2] == SLAB_POS_SKIP || av[3] == SLAB_POS_SKIP;
+        if (p + 4u <= lim && !skip) {
             *reinterpret_cast<v4i_a4 *>(out0.start + at) = s4;
             *reinterpret_cast<v4i_a4 *>(out0.end + at) = e4;
             *reinterpret_cast<u32_a1 *>(out0.flag + at) = f4;
         } else {
             const int sv[4] = {s4.x, s4.y, s4.z, s4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
-            const uint32_t wv[4] = {(uint32_t)w4.x, (uint32_t)w4.y, (uint32_t)w4.z, (uint32_t)w4.w};
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i)
-                if (p + i < lim && !(wv[i] & SLAB_POS_SKIP)) { out0.start[at + i] = sv[i]; out0.end[at + i] = ev[i]; out0.flag[at + i] = (uint8_t)(wv[i] >> 16); }
+                if (p + i < lim && av[i] != SLAB_POS_SKIP) { out0.start[at + i] = sv[i]; out0.end[at + i] = ev[i]; out0.flag[at + i] = (uint8_t)(av[i] >> SLAB_REL_BITS); }
         }
     }
 }
 
 template <int LEVEL>
-__global__ __launch_bounds__(TILE_THREADS, 6)
+__global__ __launch_bounds__(TILE_THREADS, 8)
 void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint32_t *__restrict__ u_tile_sbase,
                   const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase /* first result slot of every tile: the scanned exon counts (+ the total) */)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
-    __shared__ __attribute__((aligned(16))) int32_t s_S[SLAB_POS_CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t s_LW[SLAB_POS_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_A[SLAB_POS_CAP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_L[SLAB_POS_CAP];
+    __shared__ int32_t s_lo;
     __shared__ __attribute__((aligned(16))) v4i_t s_ent[2 * SLAB_KEY_CAP];
     __shared__ __attribute__((aligned(16))) uint8_t s_dir[3 * DIR_BYTES];
     __shared__ __attribute__((aligned(16))) TileWin s_tw;
@@ -602,7 +609,6 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     const SlabRow first = n == 1u ? q.last : q.x[0];
     const ReadEnds re{first.s, slab_row_end(first), q.last.s, slab_row_end(q.last)};
     const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
-    const SlabStage st{s_S, s_LW, loc, loc + n <= (uint32_t)SLAB_POS_CAP};
     if (stamp.p) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp.mark(0);
     // ---- stage window and dictionary slices, re-based to the tile's window
@@ -614,14 +620,18 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
         const int w_any = __any(my_wide) ? 1 : 0;
         if ((threadIdx.x & (WAVE - 1)) == 0) s_widew[threadIdx.x >> 6] = w_any;
     }
+    if (active && (pre & 0xffu) == 0u) s_lo = re.s0;             // the tile's first read has its smallest start (coordinate-sorted records)
     __syncthreads();
     const int any_wide = s_widew[0] | s_widew[1] | s_widew[2] | s_widew[3];
+    const int32_t tile_lo = s_lo;
+    // a read is staged when its positions fit and its last exon starts less than 2^18 - 1 bases behind the tile's first start
+    const SlabStage st{s_A, s_L, loc, tile_lo, loc + n <= (uint32_t)SLAB_POS_CAP && (uint32_t)(re.sl - tile_lo) < SLAB_REL_MASK && !(pre & PRE_DENSE)};
     // the first read that does not fit the staged positions ends the block that is written from LDS (reads are in read order there)
-    if (active && !st.fits) atomicMin(&s_lim, loc);
+    if (active && loc + n > (uint32_t)SLAB_POS_CAP) atomicMin(&s_lim, loc);      // (a read that is written directly for another reason marks its positions instead)
     stamp.mark(1);
     slab_classify<LEVEL>(sa, a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, r, off, q, re, out, st, any_wide, stamp);
     __syncthreads();
-    slab_write_out(SlabOut{out.start, out.end, out.flag, xbase}, s_S, s_LW, s_lim);
+    slab_write_out(SlabOut{out.start, out.end, out.flag, xbase}, s_A, s_L, tile_lo, s_lim);
     stamp.mark(5);
 }
 

@@ -302,7 +302,7 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         redo = redo || vm.redo;
         const bool mapping = work && !redo && n > 1;
         const SiteMasks64 sm = map_exons_slab64(L, d, mapping, xs, xl, off, n, vm.vpre, out);
-        if (active && !mapping) slab_copy_exons(sa, out, SlabStage{nullptr, nullptr, 0u, false}, q, off, n, outlier);
+        if (active && !mapping) slab_copy_exons(sa, out, SlabStage{nullptr, nullptr, (uint32_t)SLAB_POS_CAP, 0, false}, q, off, n, outlier);
         if (work && !redo) {
             uint8_t *const of = out.flag; const uint32_t dst = out.dst;
             const Verdict vd = decide64<LEVEL>(L, d, n, re, vm, sm, rev_in, [&](int k, uint32_t f) { st32(of, dst + (uint32_t)k, (uint8_t)f); });
