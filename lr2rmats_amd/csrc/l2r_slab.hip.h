@@ -297,7 +297,9 @@ struct SlabRows { SlabRow last, x[SLAB_AHEAD]; };        // a column's row 0 (th
 // one barrier the tile's block of the result arrays is written with 16-byte stores, thread j positions 4j .. 4j + 3.
 // SLAB_POS_CAP positions fit (with the dictionary slices 22.3 KB per workgroup, 7 workgroups per CU); a read whose exons lie
 // behind that or further than 2^18 - 1 bases from the tile's start is written directly and classified by the generic kernel.
-constexpr int SLAB_POS_CAP = 2112;
+// (Measured: 8 bytes per position at 6 workgroups per CU 0.474 ms, this form 0.462; 2112 positions at 8 workgroups per CU and
+// 64 VGPRs: 0.594 -- 17 spilled registers and 13 % more tiles.)
+constexpr int SLAB_POS_CAP = 2416;
 constexpr int SLAB_REL_BITS = 18;
 constexpr uint32_t SLAB_REL_MASK = (1u << SLAB_REL_BITS) - 1u;
 constexpr uint32_t SLAB_POS_SKIP = 0xffffffffu;          // A of a position that was written directly (a staged start is below 2^18 - 1)
@@ -548,7 +550,7 @@ __device__ __forceinline__ void slab_write_out(const SlabOut &out0 /* dst = xbas
 }
 
 template <int LEVEL>
-__global__ __launch_bounds__(TILE_THREADS, 8)
+__global__ __launch_bounds__(TILE_THREADS, 7)
 void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint32_t *__restrict__ u_tile_sbase,
                   const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase /* first result slot of every tile: the scanned exon counts (+ the total) */)
 {
