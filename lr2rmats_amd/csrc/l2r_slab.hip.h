@@ -325,15 +325,16 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
     // are two dependent LDS round trips: one of them per exon is taken off the chain).
     auto buckets = [&](int k, int sv, int ev, uint32_t &ls, uint32_t &hs, uint32_t &le, uint32_t &he) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
-        const uint32_t is = live ? min((uint32_t)((sv >> SITE_SHIFT) + d.b_off), none) : none;
+        const uint32_t is = live ? min((uint32_t)((sv >> SITE_SHIFT) + d.b_off), none) : none;      // (a lane without exon k must not open the long-bucket path)
         const uint32_t ie = junc ? min((uint32_t)((ev >> SITE_SHIFT) + d.b_off), none) : none;
         ls = L.dir0[is]; hs = L.dir0[is + 1u]; le = L.dir1[ie]; he = L.dir1[ie + 1u];
     };
     uint32_t ls, hs, le, he;
-    buckets(0, R0.s, slab_row_end(R0), ls, hs, le, he);
+    int e_cur = slab_row_end(R0);                       // (the end of the current exon: formed once, as the "next" of the round before)
+    buckets(0, R0.s, e_cur, ls, hs, le, he);
     auto round = [&](int k, SlabRow &cur, const SlabRow &nxt, bool reload) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
-        const int s = cur.s, e = slab_row_end(cur), s2 = nxt.s, e2 = slab_row_end(nxt);
+        const int s = cur.s, e = e_cur, s2 = nxt.s, e2 = slab_row_end(nxt);
         const uint32_t lw = cur.l;
         const v4i_t qs0 = lds_entry(L.ent0, ls);
         const v4i_t qe0 = lds_entry(L.ent1, le), qe1 = lds_entry(L.ent1, le + 1u);
@@ -358,7 +359,7 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         if (k == 0) m.dm_first = dm;
         m.am_last = (live && !junc) ? am : m.am_last;
         if (live) { Ap[k] = (uint32_t)(s - st.lo) | (word << SLAB_REL_BITS); Lp[k] = (uint16_t)lw; }
-        ls = ls_n; hs = hs_n; le = le_n; he = he_n;
+        ls = ls_n; hs = hs_n; le = le_n; he = he_n; e_cur = e2;
     };
     static_assert(SLAB_AHEAD == 4, "the round loop is unrolled by the number of exons in flight");
     // whole groups of four rounds (one back edge, no exit inside: the wait in front of a row then counts the loads behind it),
