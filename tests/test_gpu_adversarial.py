@@ -230,3 +230,56 @@ def test_exons_of_64_kb_and_more(oracle, pipeline):
     assert (lens >= 65_536).sum() >= 10 and (lens == 65_535).sum() >= 3
     if pipeline == "slab":
         assert 12 <= cnt[0] <= 80, cnt            # the reads with an exon of 65 536 bases or more (+ the tile a 200 kb span pushes off the fast path)
+
+
+def test_more_exons_than_staged_positions_with_empty_inner_exons(oracle, pipeline):
+    """`-e 0` keeps empty inner exons, so a read can have one exon per CIGAR op + 1 -- more than the bound the tiles were cut by
+    ((ops + 3) / 2): a tile of such reads has more exons than the probe kernel stages (l2r_slab.hip.h SLAB_POS_CAP).  The reads
+    behind the cap are written directly and classified by the generic kernel; everything is still the oracle's, bit for bit."""
+    txs = [(0, 0, [(1_000, 1_100), (1_200, 1_300), (1_400, 1_500), (1_600, 1_700)])]
+    af = _anno(txs)
+    M_, N_ = 0, 3
+    rows = []
+    for k in range(700):
+        # 10M then ten times (5N back to back 5N: an EMPTY exon between them) ... : 21 ops, 12 exons with -e 0, 2 + with -e 1
+        ops = [(10, M_)]
+        for _ in range(10):
+            ops += [(5, N_), (5, N_)]
+        ops = ops[:-1] + [(20, M_)]
+        rows.append((0, 900 + (k % 3), k & 1, ops))
+    for k in range(300):
+        rows.append((0, *_chain([(1_000 + k % 50, 1_100), (1_200, 1_300)])[0:1], 0, _chain([(1_000 + k % 50, 1_100), (1_200, 1_300)])[1]))
+    reads = _reads(_sorted_rows(rows))
+    cnt = [0, 0, 0, 0]
+    got, want = _run(oracle, af, reads, counters=cnt, full_level=3, min_exon=0)
+    assert int(np.diff(want.ex_off).max()) >= 12
+    if pipeline == "slab":
+        assert cnt[0] > 0, cnt                      # some reads did not fit the staged positions
+    _run(oracle, af, reads, full_level=3, min_exon=1)
+
+
+def test_reads_far_from_their_tiles_first_read_and_an_outlier_between_neighbours(oracle, pipeline):
+    """A staged position keeps an exon's start relative to the tile's first read in 18 bits: reads that start further away (sparse
+    input: one tile spans megabases) are written directly, as is a densely stored read (an exon of 64 kb or more) that sits BETWEEN
+    staged neighbours -- the write-out has to leave their positions alone."""
+    txs = []
+    for g in range(60):
+        base = 10_000 + g * 400_000
+        txs.append((0, g & 1, [(base, base + 100), (base + 300, base + 400), (base + 900, base + 1_000)]))
+    af = _anno(txs)
+    rows = []
+    for g in range(60):
+        base = 10_000 + g * 400_000
+        for k in range(5):                                                       # 300 reads over 24 Mb: ~1.2 tiles
+            rows.append((0, *_chain([(base + k, base + 100), (base + 300, base + 400), (base + 900, base + 1_000 - k)])))
+    # a dense locus with a long-exon read in the middle of its tile
+    for k in range(400):
+        rows.append((1, *_chain([(5_000 + k % 40, 5_100), (5_300, 5_400)])))
+        if k == 200:
+            rows.append((1, *_chain([(5_020, 5_100), (5_300, 5_300 + 70_000)])))
+    rows = [(r[0], r[1], 0, r[2]) for r in rows]
+    txs.append((1, 0, [(5_000, 5_100), (5_300, 5_400)]))
+    af = _anno(txs)
+    cnt = [0, 0, 0, 0]
+    got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=3)
+    assert ((want.info & 2) != 0).sum() > 100            # (chains that begin with a transcript's first exon are never "known": Q1)
