@@ -44,6 +44,11 @@ constexpr int PRE_N_SHIFT = 11;
 // the first and the last needs an op of its own next to its cut (src/bam2gtf.c:31-78), so n <= (c + 3) / 2.  With -e < 1 the walk
 // itself watches the rows (k_walk_slab<true>).
 __host__ __device__ __forceinline__ uint32_t slab_rows_of(uint32_t c) { return (c + 3u) >> 1; }
+// quarter (in read order) of the read with index idx in a tile of n reads: quarter k = reads [n k / 4, n (k + 1) / 4)
+__device__ __forceinline__ uint32_t slab_quarter(uint32_t idx, uint32_t n)
+{
+    return (idx >= (n * 2u) / 4u ? 2u : 0u) + (idx >= (idx >= (n * 2u) / 4u ? (n * 3u) / 4u : n / 4u) ? 1u : 0u);
+}
 // row of exon j of a read with n exons (the last exon in row 0)
 __device__ __forceinline__ uint32_t slab_row(uint32_t j, uint32_t n) { return j + 1u < n ? j + 1u : 0u; }
 
@@ -96,7 +101,8 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     __shared__ uint32_t s_hist[WAVE];
     __shared__ uint32_t s_x0[TILE_THREADS], s_x1[TILE_THREADS], s_x2[TILE_THREADS];       // the records' fields, slot order
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[TILE_THREADS], s_loc[TILE_THREADS];      // exon counts / their exclusive scan, READ order
-    __shared__ int s_wmax[TILE_THREADS / WAVE];
+    __shared__ int s_wmax[TILE_THREADS / WAVE], s_qmax[4][TILE_THREADS / WAVE];
+    __shared__ int s_qpos[4];
     __shared__ uint32_t s_wn[TILE_THREADS / WAVE];
     __shared__ __attribute__((aligned(16))) TileWin s_tw;
     __shared__ __attribute__((aligned(16))) TileWin64 s_tw64;
@@ -223,6 +229,16 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     s_cnt[idx] = active ? n : 0u;                        // (every entry is written: idx is a permutation of 0 .. 255)
     const int m = wave_max(active ? el : INT32_MIN);
     const int wn = wave_max((active && !outlier) ? (int)n : 0);
+    // (the QUARTERS of the tile in read order, for a tile whose window is beyond 64 members: see below)
+    {
+        const uint32_t qtr = slab_quarter(idx, n_act);
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const int mq = wave_max((active && qtr == k) ? el : INT32_MIN);
+            if (lane == 0) s_qmax[k][wv] = mq;
+        }
+        if (active && idx == (n_act * qtr) / 4u) s_qpos[qtr] = pos;            // (the quarter's first read: its smallest start)
+    }
     if (lane == 0) { s_wmax[wv] = m; s_wn[wv] = (uint32_t)min(wn, 255); }
     if (t == 0u && threadIdx.x == 0) {
         // the run's counters (this kernel is the first of a run): redo list, chunk cursor of the accepted list.
@@ -261,6 +277,39 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
         } else if (lane == 0) {
             s_tw.d.flags = (s_tw.d.flags & ~(TD_WIDE | (7u << 8))) | (4u << 8);     // list full: the tile takes the generic kernel ("window > 32")
         }
+    }
+    else if (sa->tw64 && (s_tw.d.flags & (TD_FAST | TD_WIDE)) == 0u && ((s_tw.d.flags >> 8) & 7u) == 4u && n_act >= 4u) {
+        // A window beyond 64 members: typically the tile straddles loci with many isoforms.  Its reads are in coordinate order, so a
+        // HALF of them (read order) sees about one locus: a window of its own per half, and per quarter where a half's is still
+        // beyond 64; every part goes on the list of k_probe_slab_wide (entry = tile | part code << 28; a part whose window is
+        // still too wide is sent to the generic kernel from there).
+        auto part_end = [&](uint32_t q0, uint32_t q1) {
+            int e = INT32_MIN;
+            for (uint32_t q = q0; q <= q1; ++q) e = max(e, max(max(s_qmax[q][0], s_qmax[q][1]), max(s_qmax[q][2], s_qmax[q][3])));
+            return e;
+        };
+        auto append = [&](uint32_t code) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(sa->wide_cnt, 1u);
+            at = __shfl(at, 0, WAVE);
+            if (at < sa->wide_cap) {
+                if (lane == 0) sa->wide_tile[at] = t | (code << 28);
+                for (int i = lane; i < (int)(sizeof(TileWin64) / 16); i += WAVE) reinterpret_cast<int4 *>(sa->tw64 + at)[i] = reinterpret_cast<const int4 *>(&s_tw64)[i];
+            }
+            return at < sa->wide_cap;
+        };
+        bool all_listed = true;
+        for (uint32_t h = 0; h < 2u; ++h) {
+            make_descriptor(a, lane, tid0, s_qpos[2u * h] + 1, part_end(2u * h, 2u * h + 1u), true, &s_tw, (uint32_t)SLAB_KEY_CAP, &s_tw64, true);
+            if (s_tw64.d.flags & TD_WIDE) { all_listed = append(1u + h) && all_listed; continue; }
+            for (uint32_t q = 2u * h; q < 2u * h + 2u; ++q) {
+                make_descriptor(a, lane, tid0, s_qpos[q] + 1, part_end(q, q), true, &s_tw, (uint32_t)SLAB_KEY_CAP, &s_tw64, true);
+                all_listed = append(3u + q) && all_listed;
+            }
+        }
+        // (k_probe_slab leaves the tile alone -- unless the list was full: then the tile's parts that made it onto the list are
+        //  classified twice with the same result, by k_probe_slab_wide and, through k_probe_slab's redo list, by the generic kernel)
+        if (all_listed && lane == 0) s_tw.d.flags = TD_WIDE | (4u << 8);
     }
     if (lane == 0) s_tw.pad[0] = s_wn[0] | (s_wn[1] << 8) | (s_wn[2] << 16) | (s_wn[3] << 24);     // rows each wave of k_probe_slab has to look at
     {   const uint32_t n_win = (s_tw.d.flags & TD_FAST) ? s_tw.d.n_win : 0u;

@@ -233,12 +233,14 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
     const uint32_t n_wide = *wa.wide_count;
     for (uint32_t wi = blockIdx.x; wi < n_wide; wi += gridDim.x) {
-        const uint32_t t = wa.wide_tile[wi];
+        // entry = tile | part code << 28: 0 the whole tile, 1 / 2 its first / second half in read order, 3 .. 6 its quarters (k_walk_slab:
+        // a tile whose window is beyond 64 members gets one window per half, per quarter where a half's is still too wide)
+        const uint32_t entry = wa.wide_tile[wi], t = entry & 0x0fffffffu, part = entry >> 28;
         const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
         const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t];
         for (int i = (int)threadIdx.x; i < WIDE_TW_VECS; i += TILE_THREADS)
             reinterpret_cast<int4 *>(&s_tw)[i] = reinterpret_cast<const int4 *>(wa.tw64 + wi)[i];
-        const bool active = threadIdx.x < n_act;
+        bool active = threadIdx.x < n_act;
         const uint32_t at = r0 + (active ? threadIdx.x : 0u);
         uint32_t pre = 0u, loc = 0u;
         const int32_t *const xs = sa->slab_start; const uint16_t *const xl = sa->slab_len;
@@ -249,6 +251,10 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
 #pragma unroll
         for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = SlabRow{0, 0u};
         if (active) { pre = ld32(sa->pre, at); loc = ld32(sa->loc, at); q.last = slab_load_row(xs, xl, off); }
+        if (part) {                                             // (the other lanes belong to the tile's other entries)
+            const uint32_t qtr = slab_quarter(pre & 0xffu, n_act);
+            active = active && (part <= 2u ? (qtr >> 1) == part - 1u : qtr == part - 3u);
+        }
         const uint32_t n = pre >> PRE_N_SHIFT;
         const uint32_t r = r0 + (pre & 0xffu);
         const bool outlier = (pre & PRE_DENSE) != 0u, rev_in = (pre & PRE_REV) != 0u;
@@ -295,7 +301,7 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         const int any_wide = __syncthreads_or(my_wide);
         // ---- classification
         uint32_t info = n << 8; int ref = -1;
-        bool redo = active && (outlier || any_wide != 0 || (n > 1 && (pre & PRE_INSANE) != 0u));
+        bool redo = active && (!(d.flags & TD_WIDE) || outlier || any_wide != 0 || (n > 1 && (pre & PRE_INSANE) != 0u));
         const bool work = active && !redo;
         const WideLds L{s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
         const VisitMasks64 vm = visit_window64<LEVEL>(L, d, w_n, work, n, d.j_lo, re, s_tw.mask);
