@@ -807,8 +807,8 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             sbase[T] = (uint32_t)total;                     // (rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true;
             c->wide_cap = (uint32_t)(4 * T + 4);            // (an isoform-rich annotation makes EVERY tile wide, a tile beyond 64 members takes up to four entries: 2.4 KB each)
-            if (c->tw64.ensure(c->wide_cap) || c->wide_cnt.ensure(2) || c->wide_tile.ensure(c->wide_cap)) return -2;
-            HIP_TRY(hipMemsetAsync(c->wide_cnt.p, 0, 8, c->stream));
+            if (c->tw64.ensure(c->wide_cap) || c->wide_cnt.ensure(4) || c->wide_tile.ensure(c->wide_cap)) return -2;
+            HIP_TRY(hipMemsetAsync(c->wide_cnt.p, 0, 16, c->stream));
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) || c->tile_total.ensure(T + 2) ||
                 c->s_pre.ensure((size_t)N + 1) || c->s_loc.ensure((size_t)N + 1) ||
                 c->slab_start.ensure((size_t)total + 4) || c->slab_len.ensure((size_t)total + 4) ||       // (+ 4: the length of the last element is read as a 4-byte word)

@@ -628,7 +628,7 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     //      before anything is looked at, and nothing of it at an address that depends on another load
     const TileDesc d = u_tw[t].d;
     if (t == 0u && threadIdx.x == 0 && sa->wide_cnt) {          // (k_walk_slab is done: its count of wide tiles moves on, the counter is cleared for the next run)
-        sa->wide_cnt[1] = min(sa->wide_cnt[0], sa->wide_cap); sa->wide_cnt[0] = 0u;
+        sa->wide_cnt[1] = min(sa->wide_cnt[0], sa->wide_cap); sa->wide_cnt[0] = 0u; sa->wide_cnt[2] = 0u;      // ([2]: k_probe_slab_wide's work cursor)
     }
     if (d.flags & TD_WIDE) return;                               // k_probe_slab_wide takes the tile
     // the rows any read of this wave has (k_walk_slab): rows behind them are not asked for

@@ -29,15 +29,23 @@ __device__ __forceinline__ m64_t rebase64(m64_t m, int d)
     if (d >= 0) return d < 64 ? m << d : 0ull;
     return -d < 64 ? m >> (-d) : 0ull;
 }
-__device__ __forceinline__ m64_t rebase_gaps64(const int *win, int w_n, m64_t m, int tx_base)
+// the masks of one START and one END entry (pair, single each) from their own frames (bit b = annotation transcript base + b) to
+// the window's (bit j = member j): one pass over the members for the four of them, the loads of win[] eight at a time
+__device__ __forceinline__ void rebase_gaps64(const int *win, int w_n, m64_t (&m)[4], int base_st, int base_en)
 {
-    m64_t out = 0ull;
-#pragma unroll 1
-    for (int j = 0; j < w_n; ++j) {
-        const uint32_t b = (uint32_t)(win[j] - tx_base);
-        out |= (b < 64u ? (m >> b) & 1ull : 0ull) << j;
+    m64_t out[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll 8
+    for (int j = 0; j < WIDE_TX; ++j) {
+        const int w = win[j];
+        const uint32_t b0 = (uint32_t)(w - base_st), b1 = (uint32_t)(w - base_en);
+        const uint32_t c0 = b0 < 64u ? b0 : 0u, c1 = b1 < 64u ? b1 : 0u;
+        const m64_t k0 = b0 < 64u ? 1ull : 0ull, k1 = b1 < 64u ? 1ull : 0ull;
+        out[0] |= ((m[0] >> c0) & k0) << j; out[1] |= ((m[1] >> c0) & k0) << j;
+        out[2] |= ((m[2] >> c1) & k1) << j; out[3] |= ((m[3] >> c1) & k1) << j;
     }
-    return out;
+    const m64_t keep = w_n >= 64 ? ~0ull : ((1ull << w_n) - 1ull);            // (win[] behind the members is not initialised)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = out[i] & keep;
 }
 __device__ __forceinline__ uint32_t first_member64(m64_t x) { return x ? (uint32_t)(__ffsll((long long)x) - 1) : 127u; }
 
@@ -48,6 +56,7 @@ __device__ __forceinline__ VisitMasks64 visit_window64(const WideLds &L, const T
 {
     VisitMasks64 m{0ull, 0ull, 0ull, 0ull, false};
     m64_t m_aft = 0ull, m_bef = 0ull;
+#pragma unroll 4
     for (int j = 0; j < w_n; ++j) {
         const int4 hk = L.hk[j];
         const m64_t bit = 1ull << j;
@@ -67,6 +76,7 @@ __device__ __forceinline__ VisitMasks64 visit_window64(const WideLds &L, const T
     int jrel0 = j0 - d.j_lo;                       // first member the read's sweep reaches
     if (!(d.flags & TD_CONTIG)) {
         jrel0 = 0;
+#pragma unroll 8
         for (int j = 0; j < w_n; ++j) jrel0 += L.win[j] < j0 ? 1 : 0;
     }
     const m64_t reach = jrel0 <= 0 ? ~0ull : (jrel0 >= 64 ? 0ull : ~((1ull << jrel0) - 1ull));
@@ -213,7 +223,7 @@ __device__ __forceinline__ Verdict decide64(const WideLds &L, const TileDesc &d,
 }
 
 // The list k_walk_slab leaves: wide_count tiles, entry i = {tile number, its 64-member window record}
-struct WideArgs { const uint32_t *wide_count; const uint32_t *wide_tile; const TileWin64 *tw64; };
+struct WideArgs { uint32_t *wide_count; const uint32_t *wide_tile; const TileWin64 *tw64; };     // wide_count[1]: the grid's work cursor
 
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, 4)
@@ -231,8 +241,15 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
     const int lane = threadIdx.x & (WAVE - 1);
     WEnt *const s_ent0 = s_ent, *const s_ent1 = s_ent + WIDE_KEY_CAP;
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
+    __shared__ uint32_t s_next;
     const uint32_t n_wide = *wa.wide_count;
-    for (uint32_t wi = blockIdx.x; wi < n_wide; wi += gridDim.x) {
+    for (;;) {
+        // (the entries differ a lot in cost -- a part whose window is still too wide only lists its reads for the generic kernel --
+        //  so the workgroups take them from a cursor; k_probe_slab cleared it)
+        if (threadIdx.x == 0) s_next = atomicAdd(wa.wide_count + 1, 1u);
+        __syncthreads();
+        const uint32_t wi = s_next;
+        if (wi >= n_wide) break;
         // entry = tile | part code << 28: 0 the whole tile, 1 / 2 its first / second half in read order, 3 .. 6 its quarters (k_walk_slab:
         // a tile whose window is beyond 64 members gets one window per half, per quarter where a half's is still too wide)
         const uint32_t entry = wa.wide_tile[wi], t = entry & 0x0fffffffu, part = entry >> 28;
@@ -279,8 +296,9 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
                 e0.pm = rebase64(pm0, dv.xa.z - d.j_lo); e0.sm = rebase64(sm0, dv.xa.z - d.j_lo);
                 e1.pm = rebase64(pm1, dv.xc.z - d.j_lo); e1.sm = rebase64(sm1, dv.xc.z - d.j_lo);
             } else {
-                e0.pm = rebase_gaps64(s_tw.win, w_n, pm0, dv.xa.z); e0.sm = rebase_gaps64(s_tw.win, w_n, sm0, dv.xa.z);
-                e1.pm = rebase_gaps64(s_tw.win, w_n, pm1, dv.xc.z); e1.sm = rebase_gaps64(s_tw.win, w_n, sm1, dv.xc.z);
+                m64_t mm[4] = {pm0, sm0, pm1, sm1};
+                rebase_gaps64(s_tw.win, w_n, mm, dv.xa.z, dv.xc.z);
+                e0.pm = mm[0]; e0.sm = mm[1]; e1.pm = mm[2]; e1.sm = mm[3];
             }
             if (has_st) { s_ent0[threadIdx.x] = e0; if (dv.xa.w & SE_WIDE) my_wide = 1; }
             if (has_en) { s_ent1[threadIdx.x] = e1; if (dv.xc.w & SE_WIDE) my_wide = 1; }
