@@ -74,7 +74,7 @@ struct l2r_ctx {
     DevBuf<int32_t> slab_start, dense_start, dense_end;     // slab pipeline: the exon rows between its kernels, the outliers' dense area
     DevBuf<uint16_t> slab_len;
     DevBuf<TileWin> tw;
-    DevBuf<TileWin64> tw64; DevBuf<uint32_t> wide_cnt, wide_tile; uint32_t wide_cap = 0;     // tiles with 33 .. 64 window members (l2r_wide.hip.h)
+    DevBuf<TileWin64> tw64; DevBuf<uint32_t> wide_cnt, wide_tile; uint32_t wide_cap = 0;     // tiles with 33 .. 63 window members (l2r_wide.hip.h)
     DevBuf<unsigned long long> ovf_cursor;
     std::string anno_cache_dir;             // L2R_ANNO_CACHE / l2r_set_annotation_cache: where the annotation tables are kept between runs
     int anno_cache_state = 0;               // last l2r_set_annotation: 0 no cache, 1 built + stored, 2 read from the cache
@@ -806,7 +806,8 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         if (total < 0x7ffffff0ULL && ovf < 0x7ffffff0ULL) {
             sbase[T] = (uint32_t)total;                     // (rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true;
-            c->wide_cap = (uint32_t)(4 * T + 4);            // (an isoform-rich annotation makes EVERY tile wide, a tile beyond 64 members takes up to four entries: 2.4 KB each)
+            c->wide_cap = (uint32_t)(2 * T + 8);            // (an isoform-rich annotation makes EVERY tile wide, a tile beyond 63 members takes up to eight entries, 2.4 KB each;
+                                                            //  a tile that finds the list full takes the generic kernel)
             if (c->tw64.ensure(c->wide_cap) || c->wide_cnt.ensure(4) || c->wide_tile.ensure(c->wide_cap)) return -2;
             HIP_TRY(hipMemsetAsync(c->wide_cnt.p, 0, 16, c->stream));
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) || c->tile_total.ensure(T + 2) ||
@@ -977,11 +978,11 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         default: launch_probe_level(0); break;
         }
 #undef launch_probe_level
-        {   // the tiles with 33 .. 64 window members (none on most inputs: the grid finds an empty list and leaves)
+        {   // the tiles with 33 .. 63 window members (none on most inputs: the grid finds an empty list and leaves)
             const WideArgs wa{c->wide_cnt.p + 1, c->wide_tile.p, c->tw64.p};
             const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 6);
 #define launch_wide_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_wide<L>), dim3(gw), dim3(TILE_THREADS), 0, s, sa, wa, (const uint32_t *)c->tile_first.p, \
-                (const uint32_t *)c->tile_sbase.p, (const uint32_t *)c->tile_total.p)
+                (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_total.p)
             switch (p.full_level) {
             case 1: launch_wide_level(1); break;
             case 2: launch_wide_level(2); break;
@@ -1081,7 +1082,7 @@ int l2r_debug_counters(l2r_ctx *c, long long *out, int n)
     if (c->totals.p) { HIP_TRY(hipMemcpyAsync(&redo, c->totals.p + 3, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     out[0] = redo; out[1] = c->n_wide; out[2] = c->n_compact; out[3] = c->n_tiles;
     if (n >= 12) for (int k = 0; k < 8; ++k) out[4 + k] = 0;
-    if (n >= 13) {                                          // out[12]: tiles the last run gave to k_probe_slab_wide (33 .. 64 window members)
+    if (n >= 13) {                                          // out[12]: tiles the last run gave to k_probe_slab_wide (33 .. 63 window members)
         uint32_t w = 0;
         if (c->slab && c->ran && c->wide_cnt.p) { HIP_TRY(hipMemcpyAsync(&w, c->wide_cnt.p + 1, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
         out[12] = w;

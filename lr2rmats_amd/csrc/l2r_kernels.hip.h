@@ -99,7 +99,7 @@ struct TileDesc {
 constexpr uint32_t CHUNK_DEFERRED = 0xffffffffu;   // tile_chunk: the tile's accepted exons are compacted by k_gather_accepted
 constexpr uint32_t TD_FAST = 1;    // exons fit the LDS tile, dictionary slices fit DIR_CAP / KEY_CAP, window fits WIN_TX
 constexpr uint32_t TD_WALKED = 4;  // long-CIGAR input: pass A has left the tile's exons in `walked` (tile * LDS_EXON_CAP + in-tile offset)
-constexpr uint32_t TD_WIDE = 8;    // slab pipeline: the window holds 33 .. 64 transcripts (l2r_wide.hip.h takes the tile), TD_FAST is not set
+constexpr uint32_t TD_WIDE = 8;    // slab pipeline: the window holds 33 .. 63 transcripts (l2r_wide.hip.h takes the tile), TD_FAST is not set
 constexpr uint32_t TD_CONTIG = 2;  // the window's transcripts are consecutive in the annotation: j_lo, j_lo + 1, ...
 constexpr int WIN_SCAN_TRIPS = 64; // pass A looks at up to 64 * WIN_SCAN_TRIPS transcripts for a tile's window
 

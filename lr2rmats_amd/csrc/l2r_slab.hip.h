@@ -17,7 +17,7 @@
 //                 device functions of the classic kernel, and writes the per-read results where their consumers read them:
 //                 ex_start / ex_end / ex_flag / ex_off in READ ORDER (exon k of read r at ex_off[r] + k), info, ref_tx.
 //                 Nothing is left in an intermediate layout: l2r_download / l2r_device_view_get hand out these arrays as they are.
-//   k_probe_slab_wide (l2r_wide.hip.h)   the same for tiles whose window holds 33 .. 64 transcripts.
+//   k_probe_slab_wide (l2r_wide.hip.h)   the same for tiles whose window holds 33 .. 63 transcripts.
 //
 // Slab rows hold {start (int32), length (uint16)}: 6 bytes per exon cross HBM between the kernels.  A read's LAST exon sits in
 // row 0 of its column and exon k < n - 1 in row k + 1: the probe side needs the first and the last exon before anything else, and
@@ -44,10 +44,14 @@ constexpr int PRE_N_SHIFT = 11;
 // the first and the last needs an op of its own next to its cut (src/bam2gtf.c:31-78), so n <= (c + 3) / 2.  With -e < 1 the walk
 // itself watches the rows (k_walk_slab<true>).
 __host__ __device__ __forceinline__ uint32_t slab_rows_of(uint32_t c) { return (c + 3u) >> 1; }
-// quarter (in read order) of the read with index idx in a tile of n reads: quarter k = reads [n k / 4, n (k + 1) / 4)
-__device__ __forceinline__ uint32_t slab_quarter(uint32_t idx, uint32_t n)
+// Parts of a tile (k_walk_slab: a tile whose window is too wide gets windows per part): level l cuts the tile's n reads, in read
+// order, into 2^l parts, part i = reads [n i >> l, n (i + 1) >> l); code 0 = the whole tile, 1 .. 2 halves, 3 .. 6 quarters, 7 .. 14 eighths
+constexpr int SLAB_PART_LEVELS = 3;
+__device__ __forceinline__ uint32_t slab_part_code(uint32_t level, uint32_t i) { return (1u << level) - 1u + i; }
+__device__ __forceinline__ void slab_part_range(uint32_t code, uint32_t n, uint32_t &i0, uint32_t &i1)
 {
-    return (idx >= (n * 2u) / 4u ? 2u : 0u) + (idx >= (idx >= (n * 2u) / 4u ? (n * 3u) / 4u : n / 4u) ? 1u : 0u);
+    const uint32_t level = code >= 7u ? 3u : (code >= 3u ? 2u : (code >= 1u ? 1u : 0u)), i = code - ((1u << level) - 1u);
+    i0 = (n * i) >> level; i1 = (n * (i + 1u)) >> level;
 }
 // row of exon j of a read with n exons (the last exon in row 0)
 __device__ __forceinline__ uint32_t slab_row(uint32_t j, uint32_t n) { return j + 1u < n ? j + 1u : 0u; }
@@ -60,7 +64,7 @@ struct SlabArgs {
     unsigned long long *ovf_cursor;                      // next free element of the dense area
     uint32_t *pre, *loc;                                 // k_walk_slab -> k_probe_slab, slot order: PRE_* word; exons of the tile's reads before this one (read order)
     TileWin *tw;                                         // k_walk_slab -> k_probe_slab: descriptor + window per tile
-    // tiles whose window holds 33 .. 64 transcripts (l2r_wide.hip.h): wide_cnt[0] counts the appends of k_walk_slab, k_probe_slab
+    // tiles whose window holds 33 .. 63 transcripts (l2r_wide.hip.h): wide_cnt[0] counts the appends of k_walk_slab, k_probe_slab
     // moves the count to wide_cnt[1] (what k_probe_slab_wide reads) and clears [0] for the next run
     uint32_t *wide_cnt; uint32_t *wide_tile; TileWin64 *tw64; uint32_t wide_cap;
     uint32_t n_tiles;
@@ -101,8 +105,8 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     __shared__ uint32_t s_hist[WAVE];
     __shared__ uint32_t s_x0[TILE_THREADS], s_x1[TILE_THREADS], s_x2[TILE_THREADS];       // the records' fields, slot order
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[TILE_THREADS], s_loc[TILE_THREADS];      // exon counts / their exclusive scan, READ order
-    __shared__ int s_wmax[TILE_THREADS / WAVE], s_qmax[4][TILE_THREADS / WAVE];
-    __shared__ int s_qpos[4];
+    __shared__ int s_wmax[TILE_THREADS / WAVE];
+    __shared__ int s_el[TILE_THREADS], s_rpos[TILE_THREADS];      // every read's last base and position, by read index (for the windows of PARTS of the tile)
     __shared__ uint32_t s_wn[TILE_THREADS / WAVE];
     __shared__ __attribute__((aligned(16))) TileWin s_tw;
     __shared__ __attribute__((aligned(16))) TileWin64 s_tw64;
@@ -229,16 +233,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     s_cnt[idx] = active ? n : 0u;                        // (every entry is written: idx is a permutation of 0 .. 255)
     const int m = wave_max(active ? el : INT32_MIN);
     const int wn = wave_max((active && !outlier) ? (int)n : 0);
-    // (the QUARTERS of the tile in read order, for a tile whose window is beyond 64 members: see below)
-    {
-        const uint32_t qtr = slab_quarter(idx, n_act);
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const int mq = wave_max((active && qtr == k) ? el : INT32_MIN);
-            if (lane == 0) s_qmax[k][wv] = mq;
-        }
-        if (active && idx == (n_act * qtr) / 4u) s_qpos[qtr] = pos;            // (the quarter's first read: its smallest start)
-    }
+    s_el[idx] = active ? el : INT32_MIN; s_rpos[idx] = pos;
     if (lane == 0) { s_wmax[wv] = m; s_wn[wv] = (uint32_t)min(wn, 255); }
     if (t == 0u && threadIdx.x == 0) {
         // the run's counters (this kernel is the first of a run): redo list, chunk cursor of the accepted list.
@@ -267,7 +262,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     make_descriptor(a, lane, tid0, pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), true, &s_tw, (uint32_t)SLAB_KEY_CAP,
                     sa->tw64 ? &s_tw64 : nullptr);
     if (s_tw.d.flags & TD_WIDE) {
-        // a window of 33 .. 64 members: the tile joins the list of k_probe_slab_wide, its 64-member record goes along
+        // a window of 33 .. 63 members: the tile joins the list of k_probe_slab_wide, its 64-member record goes along
         uint32_t at = 0;
         if (lane == 0) at = atomicAdd(sa->wide_cnt, 1u);
         at = __shfl(at, 0, WAVE);
@@ -278,33 +273,33 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
             s_tw.d.flags = (s_tw.d.flags & ~(TD_WIDE | (7u << 8))) | (4u << 8);     // list full: the tile takes the generic kernel ("window > 32")
         }
     }
-    else if (sa->tw64 && (s_tw.d.flags & (TD_FAST | TD_WIDE)) == 0u && ((s_tw.d.flags >> 8) & 7u) == 4u && n_act >= 4u) {
-        // A window beyond 64 members: typically the tile straddles loci with many isoforms.  Its reads are in coordinate order, so a
-        // HALF of them (read order) sees about one locus: a window of its own per half, and per quarter where a half's is still
-        // beyond 64; every part goes on the list of k_probe_slab_wide (entry = tile | part code << 28; a part whose window is
-        // still too wide is sent to the generic kernel from there).
-        auto part_end = [&](uint32_t q0, uint32_t q1) {
+    else if (sa->tw64 && (s_tw.d.flags & (TD_FAST | TD_WIDE)) == 0u && ((s_tw.d.flags >> 8) & 7u) == 4u && n_act >= (1u << SLAB_PART_LEVELS)) {
+        // A window beyond 63 members: typically the tile straddles loci with many isoforms.  Its reads are in coordinate order, so a
+        // HALF of them (read order) sees about one locus: a window of its own per half; per quarter where a half's is still too
+        // wide, per eighth where a quarter's is.  Every part goes on the list of k_probe_slab_wide (entry = tile | part code << 28,
+        // slab_part_code); an eighth whose window is still too wide is sent to the generic kernel from there.
+        bool all_listed = true;
+        auto part = [&](uint32_t level, uint32_t i) {
+            const uint32_t i0 = (n_act * i) >> level, i1 = (n_act * (i + 1u)) >> level;
             int e = INT32_MIN;
-            for (uint32_t q = q0; q <= q1; ++q) e = max(e, max(max(s_qmax[q][0], s_qmax[q][1]), max(s_qmax[q][2], s_qmax[q][3])));
-            return e;
-        };
-        auto append = [&](uint32_t code) {
+            for (uint32_t j = i0 + (uint32_t)lane; j < i1; j += WAVE) e = max(e, s_el[j]);
+            // (the part's first read has its smallest start)
+            make_descriptor(a, lane, tid0, s_rpos[i0] + 1, wave_max(e), true, &s_tw, (uint32_t)SLAB_KEY_CAP, &s_tw64, true);
+            if (!(s_tw64.d.flags & TD_WIDE) && level < (uint32_t)SLAB_PART_LEVELS) return false;
             uint32_t at = 0;
             if (lane == 0) at = atomicAdd(sa->wide_cnt, 1u);
             at = __shfl(at, 0, WAVE);
             if (at < sa->wide_cap) {
-                if (lane == 0) sa->wide_tile[at] = t | (code << 28);
-                for (int i = lane; i < (int)(sizeof(TileWin64) / 16); i += WAVE) reinterpret_cast<int4 *>(sa->tw64 + at)[i] = reinterpret_cast<const int4 *>(&s_tw64)[i];
-            }
-            return at < sa->wide_cap;
+                if (lane == 0) sa->wide_tile[at] = t | (slab_part_code(level, i) << 28);
+                for (int v = lane; v < (int)(sizeof(TileWin64) / 16); v += WAVE) reinterpret_cast<int4 *>(sa->tw64 + at)[v] = reinterpret_cast<const int4 *>(&s_tw64)[v];
+            } else all_listed = false;
+            return true;
         };
-        bool all_listed = true;
         for (uint32_t h = 0; h < 2u; ++h) {
-            make_descriptor(a, lane, tid0, s_qpos[2u * h] + 1, part_end(2u * h, 2u * h + 1u), true, &s_tw, (uint32_t)SLAB_KEY_CAP, &s_tw64, true);
-            if (s_tw64.d.flags & TD_WIDE) { all_listed = append(1u + h) && all_listed; continue; }
+            if (part(1u, h)) continue;
             for (uint32_t q = 2u * h; q < 2u * h + 2u; ++q) {
-                make_descriptor(a, lane, tid0, s_qpos[q] + 1, part_end(q, q), true, &s_tw, (uint32_t)SLAB_KEY_CAP, &s_tw64, true);
-                all_listed = append(3u + q) && all_listed;
+                if (part(2u, q)) continue;
+                part(3u, 2u * q); part(3u, 2u * q + 1u);
             }
         }
         // (k_probe_slab leaves the tile alone -- unless the list was full: then the tile's parts that made it onto the list are

@@ -1,14 +1,17 @@
-// l2r_wide.hip.h -- the slab pipeline's probe kernel for tiles whose window holds 33 .. 64 transcripts (WIDE tiles).
+// l2r_wide.hip.h -- the slab pipeline's probe kernel for tiles whose window holds 33 .. 63 transcripts (WIDE tiles).
 //
 // The mask path of l2r_kernels.hip.h / l2r_slab.hip.h keeps one bit per window member in 32-bit words; a tile whose reads can
 // meet more than 32 annotation transcripts (a locus with many isoforms) went to the redo list, i.e. to k_classify_generic at
 // about 1/70 of the speed.  This file is the same formulation on 64-bit masks, for those tiles only:
 // k_walk_slab's last wave builds a 64-member window record (TileWin64) for them and appends the tile to a list;
-// k_probe_slab skips them; k_probe_slab_wide<LEVEL>, a small persistent grid, walks over the list.  Tiles beyond 64
-// members still take the generic kernel.
+// k_probe_slab skips them; k_probe_slab_wide<LEVEL>, a persistent grid, walks over the list.  A tile beyond that gets one
+// such window per half / quarter of its reads (k_walk_slab), parts whose window is still too wide take the generic kernel.
+// With an isoform-rich annotation this is the kernel that classifies most reads, so it works like k_probe_slab: rows of the
+// slab four exons ahead, exons + work words + flags staged at their positions in LDS, one coalesced write-out per entry.
 //
 // Same semantics as visit_window / map_exons_slab / decide, line by line, with these differences:
-//   masks             unsigned long long; "first member" indices take 7 bits (127 = none), so a work word is 7 + 7 + 2 bits
+//   masks             unsigned long long; a window holds at most WIDE_MEMBERS = 63 transcripts, so that a "first member" index
+//                     still takes 6 bits (63 = none) and a work word 6 + 6 + 2 bits: the upper 14 bits of a staged position
 //   staged entries    {k1, k2, pair mask, single mask} = 24 bytes (two 8-byte key/mask reads) instead of one 16-byte vector
 #pragma once
 #include "l2r_slab.hip.h"
@@ -22,7 +25,7 @@ constexpr int WIDE_TW_VECS = (int)(sizeof(TileWin64) / 16);
 
 struct VisitMasks64 { m64_t vpre, lmask, rmask, k1mask; bool redo; };
 struct SiteMasks64 { m64_t kand, kor, dm_first, am_last; };
-struct WideLds { uint16_t *W; const WEnt *ent0, *ent1; const uint8_t *dir0, *dir1, *rdir; const int4 *hk, *hx; const int *win; };
+struct WideLds { const WEnt *ent0, *ent1; const uint8_t *dir0, *dir1, *rdir; const int4 *hk, *hx; const int *win; };
 
 __device__ __forceinline__ m64_t rebase64(m64_t m, int d)
 {
@@ -47,7 +50,7 @@ __device__ __forceinline__ void rebase_gaps64(const int *win, int w_n, m64_t (&m
 #pragma unroll
     for (int i = 0; i < 4; ++i) m[i] = out[i] & keep;
 }
-__device__ __forceinline__ uint32_t first_member64(m64_t x) { return x ? (uint32_t)(__ffsll((long long)x) - 1) : 127u; }
+__device__ __forceinline__ uint32_t first_member64(m64_t x) { return x ? (uint32_t)(__ffsll((long long)x) - 1) : 63u; }      // (members 0 .. 62)
 
 // visit_window (l2r_kernels.hip.h) on 64 members
 template <int LEVEL>
@@ -120,56 +123,65 @@ __device__ __forceinline__ m64_t overlapping_exon_members64(const uint8_t *rdir,
     return m;
 }
 
-// map_exons_slab on 64-bit masks (rows streamed from the slab column, two exons in flight: these tiles are rare); every round
-// stores its exon into the read-order result arrays
+// map_exons_slab on 64-bit masks: rows k .. k + 3 of the column in four register pairs with fixed roles, every round leaves its
+// exon and its work word at the exon's position in LDS (SlabStage)
 __device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const TileDesc &d, bool mapping, const int32_t *__restrict__ xs,
-                                                        const uint16_t *__restrict__ xl, uint32_t off, uint32_t n, m64_t vpre, const SlabOut &out)
+                                                        const uint16_t *__restrict__ xl, uint32_t off, uint32_t n, m64_t vpre,
+                                                        const SlabRows &q, const SlabStage &st)
 {
     SiteMasks64 m{~0ull, 0ull, 0ull, 0ull};
-    uint16_t *W = L.W + threadIdx.x;
-    auto exon = [&](uint32_t j, int &s, int &e) {        // exon min(j, n - 1) of the read (row j + 1, the last one row 0)
-        const SlabRow r = slab_load_row(xs, xl, off + slab_row(min(j, n - 1u), n) * SLAB_STRIDE);
-        s = r.s; e = slab_row_end(r);
-    };
-    int s = 0, e = 0, s1 = 0, e1 = 0;
-    if (mapping) { exon(0u, s, e); exon(1u, s1, e1); }
+    uint32_t *const Ap = st.A + st.loc; uint16_t *const Lp = st.Ln + st.loc;
+    SlabRow R0 = n == 1u ? q.last : q.x[0], R1 = n == 2u ? q.last : q.x[1], R2 = n == 3u ? q.last : q.x[2], R3 = n == 4u ? q.last : q.x[3];
     const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
     const int k_max = wave_max(mapping ? (int)n : 0);
-    for (int k = 0; k < k_max; ++k) {
+    const uint32_t nm1 = mapping ? n - 1u : 0u;
+    int e_cur = slab_row_end(R0);
+    auto round = [&](int k, SlabRow &cur, const SlabRow &nxt, bool reload) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
-        int s2n = 0, e2n = 0;
-        if (mapping) exon((uint32_t)k + 2u, s2n, e2n);
+        const int s = cur.s, e = e_cur, s2 = nxt.s, e2 = slab_row_end(nxt);
+        const uint32_t lw = cur.l;
         const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
         const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
-        const int s2 = s1;
         const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
         m64_t xm, am, jm, dm;
         probe_all64(L.ent0, ls, hs, s, e, xm, am);
         probe_all64(L.ent1, le, he, e, s2, jm, dm);
+        if (reload) {                                   // exon k + 4 into the registers of exon k
+            const uint32_t j = (uint32_t)k + (uint32_t)SLAB_AHEAD;
+            cur = slab_load_row(xs, xl, off + (j < nm1 ? j + 1u : 0u) * SLAB_STRIDE);
+        }
         const m64_t amj = junc ? am : 0ull;
         uint32_t word = first_member64(xm & vpre);
-        word |= first_member64(jm & vpre) << 7;
-        word |= ((dm & vpre) ? 1u : 0u) << 14;
-        word |= ((amj & vpre) ? 1u : 0u) << 15;
+        word |= first_member64(jm & vpre) << 6;
+        word |= ((dm & vpre) ? 1u : 0u) << 12;
+        word |= ((amj & vpre) ? 1u : 0u) << 13;
         m.kand &= junc ? (am & dm) : ~0ull;            // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
         m.kor |= amj | dm;
         if (k == 0) m.dm_first = dm;
         m.am_last = (live && !junc) ? am : m.am_last;
-        if (live) {
-            W[(uint32_t)k * SLAB_STRIDE] = (uint16_t)word;
-            st32(out.start, out.dst + (uint32_t)k, s); st32(out.end, out.dst + (uint32_t)k, e);
+        if (live) { Ap[k] = (uint32_t)(s - st.lo) | (word << SLAB_REL_BITS); Lp[k] = (uint16_t)lw; }
+        e_cur = e2;
+    };
+    static_assert(SLAB_AHEAD == 4, "the round loop is unrolled by the number of exons in flight");
+    int k = 0;
+    for (; k + SLAB_AHEAD <= k_max; k += SLAB_AHEAD) {
+        round(k, R0, R1, true); round(k + 1, R1, R2, true); round(k + 2, R2, R3, true); round(k + 3, R3, R0, true);
+    }
+    if (k < k_max) {
+        round(k, R0, R1, false);
+        if (k + 1 < k_max) {
+            round(k + 1, R1, R2, false);
+            if (k + 2 < k_max) round(k + 2, R2, R3, false);
         }
-        s = s1; e = e1; s1 = s2n; e1 = e2n;
     }
     return m;
 }
 
-// decide (l2r_kernels.hip.h) on 64-bit masks; work words at W[k * 256]
-template <int LEVEL, typename Emit>
+// decide (l2r_kernels.hip.h) on 64-bit masks; work words through getw(k), flag bytes through emit(k, f)
+template <int LEVEL, typename GetW, typename Emit>
 __device__ __forceinline__ Verdict decide64(const WideLds &L, const TileDesc &d, uint32_t n, const ReadEnds &re,
-                                            const VisitMasks64 &vm, const SiteMasks64 &sm, bool rev_in, Emit emit)
+                                            const VisitMasks64 &vm, const SiteMasks64 &sm, bool rev_in, GetW getw, Emit emit)
 {
-    uint16_t *W = L.W + threadIdx.x;
     int jstar = -1;
     if (n > 1) {
         m64_t c = sm.kand & vm.vpre;
@@ -200,12 +212,12 @@ __device__ __forceinline__ Verdict decide64(const WideLds &L, const TileDesc &d,
             else if (V) rnoth = (overlapping_exon_members64(L.rdir, L.dir0, L.ent0, d.b_off, d.nb, re.sl, re.el) & V) == 0ull;
         }
     }
-    const uint32_t lim = known ? (uint32_t)jstar : 126u;
+    const uint32_t lim = known ? (uint32_t)jstar : 62u;                        // (63 = no member)
     if (n > 1) {
         for (int k = 0; k < (int)n; ++k) {
-            const uint32_t w = W[(uint32_t)k * SLAB_STRIDE];
-            uint32_t f = ((w & 127u) > lim ? (uint32_t)F_EXON : 0u) | (((w >> 7) & 127u) > lim ? (uint32_t)F_JUNC : 0u);
-            if (!known) f |= (((w >> 14) & 1u) ? 0u : (uint32_t)F_DON) | (((w >> 15) & 1u) ? 0u : (uint32_t)F_ACC);
+            const uint32_t w = getw(k);
+            uint32_t f = ((w & 63u) > lim ? (uint32_t)F_EXON : 0u) | (((w >> 6) & 63u) > lim ? (uint32_t)F_JUNC : 0u);
+            if (!known) f |= (((w >> 12) & 1u) ? 0u : (uint32_t)F_DON) | (((w >> 13) & 1u) ? 0u : (uint32_t)F_ACC);
             f &= (k + 1 == (int)n) ? (uint32_t)F_EXON : 0xffu;                   // the last exon has no junction behind it
             emit(k, f);
         }
@@ -226,22 +238,24 @@ __device__ __forceinline__ Verdict decide64(const WideLds &L, const TileDesc &d,
 struct WideArgs { uint32_t *wide_count; const uint32_t *wide_tile; const TileWin64 *tw64; };     // wide_count[1]: the grid's work cursor
 
 template <int LEVEL>
-__global__ __launch_bounds__(TILE_THREADS, 4)
+__global__ __launch_bounds__(TILE_THREADS, 5)
 void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__restrict__ u_tile_first, const uint32_t *__restrict__ u_tile_sbase,
-                       const uint32_t *__restrict__ u_xbase)
+                       const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
-    __shared__ __attribute__((aligned(16))) uint16_t s_W[SLAB_ROWS * TILE_THREADS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_A[SLAB_POS_CAP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_L[SLAB_POS_CAP];
     __shared__ __attribute__((aligned(16))) WEnt s_ent[2 * WIDE_KEY_CAP];
     __shared__ __attribute__((aligned(16))) uint8_t s_dir[3 * DIR_BYTES];
     __shared__ __attribute__((aligned(16))) TileWin64 s_tw;
+    __shared__ uint32_t s_next, s_lim, s_p0, s_p1;
+    __shared__ int32_t s_lo;
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
     const int lane = threadIdx.x & (WAVE - 1);
     WEnt *const s_ent0 = s_ent, *const s_ent1 = s_ent + WIDE_KEY_CAP;
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
-    __shared__ uint32_t s_next;
     const uint32_t n_wide = *wa.wide_count;
     for (;;) {
         // (the entries differ a lot in cost -- a part whose window is still too wide only lists its reads for the generic kernel --
@@ -250,39 +264,48 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         __syncthreads();
         const uint32_t wi = s_next;
         if (wi >= n_wide) break;
-        // entry = tile | part code << 28: 0 the whole tile, 1 / 2 its first / second half in read order, 3 .. 6 its quarters (k_walk_slab:
-        // a tile whose window is beyond 64 members gets one window per half, per quarter where a half's is still too wide)
+        // entry = tile | part code << 28 (slab_part_code: the whole tile, or a half / quarter / eighth of it in read order)
         const uint32_t entry = wa.wide_tile[wi], t = entry & 0x0fffffffu, part = entry >> 28;
         const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
-        const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t];
+        const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t], total = u_xbase[t + 1u] - xbase;
         for (int i = (int)threadIdx.x; i < WIDE_TW_VECS; i += TILE_THREADS)
             reinterpret_cast<int4 *>(&s_tw)[i] = reinterpret_cast<const int4 *>(wa.tw64 + wi)[i];
+        // the part's reads [i0, i1) in read order: their exons are the tile's positions [p0, p1)
+        uint32_t i0, i1;
+        slab_part_range(part, n_act, i0, i1);
+        const uint32_t row_max = max((u_tw[t].pad[0] >> (8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))) & 0xffu, 1u) - 1u;
         bool active = threadIdx.x < n_act;
         const uint32_t at = r0 + (active ? threadIdx.x : 0u);
         uint32_t pre = 0u, loc = 0u;
         const int32_t *const xs = sa->slab_start; const uint16_t *const xl = sa->slab_len;
         const uint32_t off = sbase + threadIdx.x;
-        ReadEnds re{0, 0, 0, 0};
         SlabRows q;
         q.last = SlabRow{0, 0u};
 #pragma unroll
         for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = SlabRow{0, 0u};
-        if (active) { pre = ld32(sa->pre, at); loc = ld32(sa->loc, at); q.last = slab_load_row(xs, xl, off); }
-        if (part) {                                             // (the other lanes belong to the tile's other entries)
-            const uint32_t qtr = slab_quarter(pre & 0xffu, n_act);
-            active = active && (part <= 2u ? (qtr >> 1) == part - 1u : qtr == part - 3u);
+        if (active) {
+            pre = ld32(sa->pre, at); loc = ld32(sa->loc, at);
+            q.last = slab_load_row(xs, xl, off);
+#pragma unroll
+            for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = slab_load_row(xs, xl, off + min((uint32_t)i + 1u, row_max) * SLAB_STRIDE);      // (an outlier's column holds nothing: read, not used)
         }
+        if (threadIdx.x == 0) { s_p0 = 0u; s_p1 = total; }
+        __syncthreads();
+        const uint32_t idx = pre & 0xffu;
+        if (active && idx == i0) s_p0 = loc;                     // (i0 < n_act always; i1 == n_act: the tile's end)
+        if (active && idx == i1) s_p1 = loc;
+        active = active && idx >= i0 && idx < i1;               // (the other lanes belong to the tile's other entries)
         const uint32_t n = pre >> PRE_N_SHIFT;
-        const uint32_t r = r0 + (pre & 0xffu);
+        const uint32_t r = r0 + idx;
         const bool outlier = (pre & PRE_DENSE) != 0u, rev_in = (pre & PRE_REV) != 0u;
-        if (active && !outlier) {
-            const SlabRow f = slab_load_row(xs, xl, off + slab_row(0u, n) * SLAB_STRIDE);
-            re.s0 = f.s; re.e0 = slab_row_end(f); re.sl = q.last.s; re.el = slab_row_end(q.last);
-        }
-        const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
+        const SlabRow first = n == 1u ? q.last : q.x[0];
+        const ReadEnds re{first.s, slab_row_end(first), q.last.s, slab_row_end(q.last)};
+        if (active && idx == i0) s_lo = re.s0;                   // the part's first read has its smallest start (coordinate-sorted records)
         __syncthreads();
         const TileDesc d = s_tw.d;
         const int w_n = (int)d.n_win;
+        const uint32_t p0 = s_p0, p1 = s_p1;
+        const int32_t part_lo = s_lo;
         // ---- stage the dictionary slices, masks re-based to the tile's window (64-bit)
         const DictRegs dv = load_dict_slices(a, d);
         int my_wide = 0;
@@ -316,20 +339,28 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         if (threadIdx.x < 3u && (threadIdx.x > 0u || d.nbk == 0)) {
             s_dir0[d.nbk + (int)threadIdx.x] = (uint8_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint8_t)d.en_nk;
         }
+        if (threadIdx.x == 0) s_lim = min(p1 - p0, (uint32_t)SLAB_POS_CAP);
         const int any_wide = __syncthreads_or(my_wide);
+        // the part's positions are staged from 0: a read is staged when its positions fit and its last exon starts less than
+        // 2^18 - 1 bases behind the part's first start
+        const uint32_t ploc = loc - p0;
+        const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
+        const SlabStage st{s_A, s_L, ploc, part_lo, active && ploc + n <= (uint32_t)SLAB_POS_CAP && (uint32_t)(re.sl - part_lo) < SLAB_REL_MASK && !outlier};
+        if (active && ploc + n > (uint32_t)SLAB_POS_CAP) atomicMin(&s_lim, ploc);
         // ---- classification
         uint32_t info = n << 8; int ref = -1;
-        bool redo = active && (!(d.flags & TD_WIDE) || outlier || any_wide != 0 || (n > 1 && (pre & PRE_INSANE) != 0u));
+        bool redo = active && (!(d.flags & TD_WIDE) || outlier || !st.fits || any_wide != 0 || (n > 1 && (pre & PRE_INSANE) != 0u));
         const bool work = active && !redo;
-        const WideLds L{s_W, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
+        const WideLds L{s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
         const VisitMasks64 vm = visit_window64<LEVEL>(L, d, w_n, work, n, d.j_lo, re, s_tw.mask);
         redo = redo || vm.redo;
         const bool mapping = work && !redo && n > 1;
-        const SiteMasks64 sm = map_exons_slab64(L, d, mapping, xs, xl, off, n, vm.vpre, out);
-        if (active && !mapping) slab_copy_exons(sa, out, SlabStage{nullptr, nullptr, (uint32_t)SLAB_POS_CAP, 0, false}, q, off, n, outlier);
+        const SiteMasks64 sm = map_exons_slab64(L, d, mapping, xs, xl, off, n, vm.vpre, q, st);
+        if (active && !mapping) slab_copy_exons(sa, out, st, q, off, n, outlier);
         if (work && !redo) {
-            uint8_t *const of = out.flag; const uint32_t dst = out.dst;
-            const Verdict vd = decide64<LEVEL>(L, d, n, re, vm, sm, rev_in, [&](int k, uint32_t f) { st32(of, dst + (uint32_t)k, (uint8_t)f); });
+            uint32_t *const Ap = s_A + ploc;
+            const Verdict vd = decide64<LEVEL>(L, d, n, re, vm, sm, rev_in, [&](int k) { return Ap[k] >> SLAB_REL_BITS; },
+                                               [&](int k, uint32_t f) { Ap[k] = (Ap[k] & SLAB_REL_MASK) | (f << SLAB_REL_BITS); });
             info = vd.info; ref = vd.ref;
         }
         redo = redo && active;
@@ -343,7 +374,9 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
             }
         }
         if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; a->f.ex_off[r] = out.dst; }
-        __syncthreads();                                        // (the next tile of this workgroup overwrites the LDS image)
+        __syncthreads();
+        slab_write_out(SlabOut{out.start, out.end, out.flag, xbase + p0}, s_A, s_L, part_lo, s_lim);
+        __syncthreads();                                        // (the next entry of this workgroup overwrites the LDS image)
     }
 }
 

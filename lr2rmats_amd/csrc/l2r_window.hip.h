@@ -34,8 +34,9 @@ struct TileWin {
     uint32_t mask[2];            // members with one exon / without TX_COMPACT
     uint32_t pad[2];             // slab pipeline, pad[0]: byte w = largest exon count among the reads of wave w (k_walk_slab)
 };
-// A window of up to 64 members (l2r_wide.hip.h: tiles of loci with many isoforms); same fields, 64-bit member masks
+// A window of up to 63 members (WIDE_MEMBERS; l2r_wide.hip.h: tiles of loci with many isoforms); same fields, 64-bit member masks
 constexpr int WIDE_TX = 64;
+constexpr int WIDE_MEMBERS = 63;                          // members a 64-bit window may hold: 63 = "no member" in the 6-bit indices of a work word
 struct TileWin64 {
     int4 hk[WIDE_TX];
     int4 hx[WIDE_TX];
@@ -47,12 +48,12 @@ struct TileWin64 {
 // The tile's dictionary slices and transcript window from its span [tlo, thi] on chromosome tid0 -- the descriptor
 // k_pass_a leaves in HBM, made by ONE WAVE of the workgroup (everything is wave-uniform but `lane`).  The window's
 // member headers go straight into LDS.
-// With W64 (slab pipeline): a window of 33 .. 64 members is collected into *W64 and the tile is flagged TD_WIDE instead of
+// With W64 (slab pipeline): a window of 33 .. 63 members is collected into *W64 and the tile is flagged TD_WIDE instead of
 // TD_FAST (W then only carries the descriptor); up to 32 members everything is as without it.
 __device__ __forceinline__ void make_descriptor(PipeArgsK a, int lane, int32_t tid0, int32_t tlo, int32_t thi, bool in_lds, TileWin *W,
                                                 uint32_t key_cap = (uint32_t)PIPE_KEY_CAP, TileWin64 *W64 = nullptr, bool always_wide = false)
 {
-    const uint32_t win_cap = W64 ? (uint32_t)WIDE_TX : (uint32_t)WIN_TX;
+    const uint32_t win_cap = W64 ? (uint32_t)WIDE_MEMBERS : (uint32_t)WIN_TX;
     int *const win_out = W64 ? W64->win : W->win;
     const TxHdr *const hdr = a->f.hdr;
     const int32_t n_tx = a->f.p.n_tx;

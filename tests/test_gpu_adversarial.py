@@ -92,9 +92,9 @@ def test_locus_of_300_isoforms(oracle, level, pipeline):
 
 
 @pytest.mark.parametrize("level", [1, 3, 5])
-@pytest.mark.parametrize("n_iso,gapped", [(40, False), (63, False), (44, True)])
-def test_locus_of_33_to_64_isoforms_stays_off_the_redo_list(oracle, level, n_iso, gapped, pipeline):
-    """Windows of 33 .. 64 transcripts: the slab pipeline classifies their tiles with the 64-bit-mask kernel
+@pytest.mark.parametrize("n_iso,gapped", [(40, False), (62, False), (44, True)])
+def test_locus_of_33_to_63_isoforms_stays_off_the_redo_list(oracle, level, n_iso, gapped, pipeline):
+    """Windows of 33 .. 63 transcripts: the slab pipeline classifies their tiles with the 64-bit-mask kernel
     (l2r_wide.hip.h) instead of the redo list; results are exact on every pipeline.  `gapped`: unrelated transcripts of
     a chromosome the header does not have (tid -1: skipped, not a stop) sit between the isoforms in file order, so the
     window's members are not consecutive."""
