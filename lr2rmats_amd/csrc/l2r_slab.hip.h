@@ -47,6 +47,7 @@ __host__ __device__ __forceinline__ uint32_t slab_rows_of(uint32_t c) { return (
 // Parts of a tile (k_walk_slab: a tile whose window is too wide gets windows per part): level l cuts the tile's n reads, in read
 // order, into 2^l parts, part i = reads [n i >> l, n (i + 1) >> l); code 0 = the whole tile, 1 .. 2 halves, 3 .. 6 quarters, 7 .. 14 eighths
 constexpr int SLAB_PART_LEVELS = 3;
+constexpr uint32_t SLAB_PART_NONE = 0xffffffffu;         // a list entry nobody needs
 __device__ __forceinline__ uint32_t slab_part_code(uint32_t level, uint32_t i) { return (1u << level) - 1u + i; }
 __device__ __forceinline__ void slab_part_range(uint32_t code, uint32_t n, uint32_t &i0, uint32_t &i1)
 {
@@ -278,7 +279,12 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
         // HALF of them (read order) sees about one locus: a window of its own per half; per quarter where a half's is still too
         // wide, per eighth where a quarter's is.  Every part goes on the list of k_probe_slab_wide (entry = tile | part code << 28,
         // slab_part_code); an eighth whose window is still too wide is sent to the generic kernel from there.
-        bool all_listed = true;
+        // (the tile's entries are reserved at once, eight of them: a tile that finds the list full stays whole and takes the generic
+        //  kernel; entries it does not need are marked empty)
+        uint32_t base = 0, used = 0;
+        if (lane == 0) base = atomicAdd(sa->wide_cnt, 1u << SLAB_PART_LEVELS);
+        base = __shfl(base, 0, WAVE);
+        const bool listed = base + (1u << SLAB_PART_LEVELS) <= sa->wide_cap;
         auto part = [&](uint32_t level, uint32_t i) {
             const uint32_t i0 = (n_act * i) >> level, i1 = (n_act * (i + 1u)) >> level;
             int e = INT32_MIN;
@@ -286,25 +292,22 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
             // (the part's first read has its smallest start)
             make_descriptor(a, lane, tid0, s_rpos[i0] + 1, wave_max(e), true, &s_tw, (uint32_t)SLAB_KEY_CAP, &s_tw64, true);
             if (!(s_tw64.d.flags & TD_WIDE) && level < (uint32_t)SLAB_PART_LEVELS) return false;
-            uint32_t at = 0;
-            if (lane == 0) at = atomicAdd(sa->wide_cnt, 1u);
-            at = __shfl(at, 0, WAVE);
-            if (at < sa->wide_cap) {
-                if (lane == 0) sa->wide_tile[at] = t | (slab_part_code(level, i) << 28);
-                for (int v = lane; v < (int)(sizeof(TileWin64) / 16); v += WAVE) reinterpret_cast<int4 *>(sa->tw64 + at)[v] = reinterpret_cast<const int4 *>(&s_tw64)[v];
-            } else all_listed = false;
+            const uint32_t at = base + used++;
+            if (lane == 0) sa->wide_tile[at] = t | (slab_part_code(level, i) << 28);
+            for (int v = lane; v < (int)(sizeof(TileWin64) / 16); v += WAVE) reinterpret_cast<int4 *>(sa->tw64 + at)[v] = reinterpret_cast<const int4 *>(&s_tw64)[v];
             return true;
         };
-        for (uint32_t h = 0; h < 2u; ++h) {
-            if (part(1u, h)) continue;
-            for (uint32_t q = 2u * h; q < 2u * h + 2u; ++q) {
-                if (part(2u, q)) continue;
-                part(3u, 2u * q); part(3u, 2u * q + 1u);
+        if (listed) {
+            for (uint32_t h = 0; h < 2u; ++h) {
+                if (part(1u, h)) continue;
+                for (uint32_t q = 2u * h; q < 2u * h + 2u; ++q) {
+                    if (part(2u, q)) continue;
+                    part(3u, 2u * q); part(3u, 2u * q + 1u);
+                }
             }
+            if (lane == 0) s_tw.d.flags = TD_WIDE | (4u << 8);              // (k_probe_slab leaves the tile alone)
         }
-        // (k_probe_slab leaves the tile alone -- unless the list was full: then the tile's parts that made it onto the list are
-        //  classified twice with the same result, by k_probe_slab_wide and, through k_probe_slab's redo list, by the generic kernel)
-        if (all_listed && lane == 0) s_tw.d.flags = TD_WIDE | (4u << 8);
+        if (lane + (int)used < (1 << SLAB_PART_LEVELS) && base + used + (uint32_t)lane < sa->wide_cap) sa->wide_tile[base + used + (uint32_t)lane] = SLAB_PART_NONE;
     }
     if (lane == 0) s_tw.pad[0] = s_wn[0] | (s_wn[1] << 8) | (s_wn[2] << 16) | (s_wn[3] << 24);     // rows each wave of k_probe_slab has to look at
     {   const uint32_t n_win = (s_tw.d.flags & TD_FAST) ? s_tw.d.n_win : 0u;

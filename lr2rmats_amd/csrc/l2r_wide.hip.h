@@ -265,7 +265,9 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         const uint32_t wi = s_next;
         if (wi >= n_wide) break;
         // entry = tile | part code << 28 (slab_part_code: the whole tile, or a half / quarter / eighth of it in read order)
-        const uint32_t entry = wa.wide_tile[wi], t = entry & 0x0fffffffu, part = entry >> 28;
+        const uint32_t entry = wa.wide_tile[wi];
+        if (entry == SLAB_PART_NONE) { __syncthreads(); continue; }      // (the barrier: nobody takes the next entry while a wave still reads s_next)
+        const uint32_t t = entry & 0x0fffffffu, part = entry >> 28;
         const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
         const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t], total = u_xbase[t + 1u] - xbase;
         for (int i = (int)threadIdx.x; i < WIDE_TW_VECS; i += TILE_THREADS)
