@@ -71,8 +71,8 @@ struct l2r_ctx {
     bool slab_ok = false;                   // the current upload can run the slab pipeline: coordinate-sorted records, short CIGARs, its slab layout fits
     bool slab = false;                      // ... and the last launch did (the parameters have a say: launch_all)
     DevBuf<uint32_t> tile_sbase, s_pre, s_loc, tile_total;
-    DevBuf<int32_t> slab_start, dense_start, dense_end;     // slab pipeline: the exon rows between its kernels, the outliers' dense area
-    DevBuf<uint16_t> slab_len;
+    DevBuf<int32_t> dense_start, dense_end;                 // slab pipeline: the outliers' dense area
+    DevBuf<uint32_t> slab_row;                              //                the exon rows between its kernels (one word per exon)
     DevBuf<TileWin> tw;
     DevBuf<TileWin64> tw64; DevBuf<uint32_t> wide_cnt, wide_tile; uint32_t wide_cap = 0;     // tiles with 33 .. 63 window members (l2r_wide.hip.h)
     DevBuf<unsigned long long> ovf_cursor;
@@ -224,7 +224,7 @@ void l2r_destroy(l2r_ctx *c)
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->tile_total.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_cnt.release(); c->wide_tile.release();
-    c->slab_start.release(); c->slab_len.release(); c->dense_start.release(); c->dense_end.release(); c->s_pre.release(); c->s_loc.release(); c->tw.release();
+    c->slab_row.release(); c->dense_start.release(); c->dense_end.release(); c->s_pre.release(); c->s_loc.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -812,7 +812,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             HIP_TRY(hipMemsetAsync(c->wide_cnt.p, 0, 16, c->stream));
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) || c->tile_total.ensure(T + 2) ||
                 c->s_pre.ensure((size_t)N + 1) || c->s_loc.ensure((size_t)N + 1) ||
-                c->slab_start.ensure((size_t)total + 4) || c->slab_len.ensure((size_t)total + 4) ||       // (+ 4: the length of the last element is read as a 4-byte word)
+                c->slab_row.ensure((size_t)total + 4) ||
                 c->dense_start.ensure((size_t)ovf + 1) || c->dense_end.ensure((size_t)ovf + 1)) return -2;
             HIP_TRY(hipMemsetAsync(c->ovf_cursor.p, 0, 8, c->stream));
             HIP_TRY(hipMemcpyAsync(c->tile_sbase.p, sbase.data(), (T + 1) * 4, hipMemcpyHostToDevice, c->stream));
@@ -949,7 +949,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         //      of it: nothing is kept from an earlier run of the same upload.
         SlabArgs sa;
         sa.g.f = fa; sa.g.cd = cd; sa.g.tid_base = c->tid_base.p; sa.g.n_tid_dir = c->n_tid_dir; sa.g.tile_total = c->tile_total.p;
-        sa.tile_sbase = c->tile_sbase.p; sa.slab_start = c->slab_start.p; sa.slab_len = c->slab_len.p;
+        sa.tile_sbase = c->tile_sbase.p; sa.slab_row = c->slab_row.p;
         sa.dense_start = c->dense_start.p; sa.dense_end = c->dense_end.p; sa.ovf_cursor = c->ovf_cursor.p;
         sa.pre = c->s_pre.p; sa.loc = c->s_loc.p; sa.tw = c->tw.p;
         sa.n_tiles = (uint32_t)c->n_tiles;
@@ -968,7 +968,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         }
         MARK(ST_FAST);
 #define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
-            (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_total.p)
+            (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_total.p)
         switch (p.full_level) {
         case 1: launch_probe_level(1); break;
         case 2: launch_probe_level(2); break;
@@ -982,7 +982,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             const WideArgs wa{c->wide_cnt.p + 1, c->wide_tile.p, c->tw64.p};
             const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 6);
 #define launch_wide_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_wide<L>), dim3(gw), dim3(TILE_THREADS), 0, s, sa, wa, (const uint32_t *)c->tile_first.p, \
-                (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_total.p)
+                (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_total.p)
             switch (p.full_level) {
             case 1: launch_wide_level(1); break;
             case 2: launch_wide_level(2); break;

@@ -35,10 +35,19 @@ constexpr uint32_t SLAB_STRIDE = TILE_THREADS;           // elements between two
 constexpr int SLAB_HEAD_VEC = 6;                         // 16-byte CIGAR vectors a lane holds: 24 ops; longer reads finish from memory
 constexpr int SLAB_HEAD = 4 * SLAB_HEAD_VEC;
 // k_walk_slab -> k_probe_slab, one word per slot: the read's index inside its tile (bits 0-7), its strand bit, two flags, its exon count
+// A row word: the exon's start relative to a base in the low 18 bits, its length in the upper 14 (slab_pack).  The base is the
+// tile's first base (k_probe_slab stages exactly these 18 bits), for a PRE_FAR read its own.  A read with an exon that does not
+// fit -- 16 kb or longer, or starting 2^18 - 1 bases or more behind the base -- is an outlier (dense area).
+constexpr int SLAB_REL_BITS = 18;
+constexpr uint32_t SLAB_REL_MASK = (1u << SLAB_REL_BITS) - 1u;
+constexpr uint32_t SLAB_LEN_MAX = (1u << (32 - SLAB_REL_BITS)) - 1u;
+constexpr uint32_t SLAB_FAR_AT = 1u << (SLAB_REL_BITS - 1);
+__device__ __forceinline__ uint32_t slab_pack(int rel, uint32_t len) { return (uint32_t)rel | (len << SLAB_REL_BITS); }
 constexpr uint32_t PRE_REV = 1u << 8;
 constexpr uint32_t PRE_INSANE = 1u << 9;                 // first or last exon empty (or, with -e < 1, any exon): the generic kernel decides
+constexpr uint32_t PRE_FAR = 1u << 11;                   // rows relative to the read's OWN first base (its start lies 2^17 bases or more behind the tile's)
 constexpr uint32_t PRE_DENSE = 1u << 10;                 // an outlier: its exons are in the dense area (row 0 of its column holds the run's index)
-constexpr int PRE_N_SHIFT = 11;
+constexpr int PRE_N_SHIFT = 12;
 
 // c ops -> rows its read needs at most when every kept inner exon is at least one base long (min_exon >= 1): each kept exon but
 // the first and the last needs an op of its own next to its cut (src/bam2gtf.c:31-78), so n <= (c + 3) / 2.  With -e < 1 the walk
@@ -60,7 +69,7 @@ __device__ __forceinline__ uint32_t slab_row(uint32_t j, uint32_t n) { return j 
 struct SlabArgs {
     PipeArgs g;
     const uint32_t *tile_sbase;                          // first element of every tile's slab (+ a closing entry)
-    int32_t *slab_start; uint16_t *slab_len;             // the slabs
+    uint32_t *slab_row;                                  // the slabs: one word per exon (slab_pack)
     int32_t *dense_start, *dense_end;                    // outliers: exon k of a run at run + k
     unsigned long long *ovf_cursor;                      // next free element of the dense area
     uint32_t *pre, *loc;                                 // k_walk_slab -> k_probe_slab, slot order: PRE_* word; exons of the tile's reads before this one (read order)
@@ -166,8 +175,12 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     // beyond the rows a slab can have: an outlier from the start (-e < 1: only when the CIGAR cannot be walked out of the registers)
     bool outlier = GENERAL ? n_cig > (uint32_t)SLAB_HEAD : slab_rows_of(n_cig) > (uint32_t)SLAB_ROWS;
     const int c_max = wave_max((active && !outlier) ? (int)min(n_cig, (uint32_t)SLAB_HEAD) : 0);
-    int32_t *const xs = sa->slab_start; uint16_t *const xl = sa->slab_len;
+    uint32_t *const rows = sa->slab_row;
     const uint32_t off = sbase + threadIdx.x;
+    // a row word holds the exon's start relative to the tile's first base (sorted records: the first read's), or, for a read that
+    // begins 2^17 bases or more behind it, relative to the read's own first base
+    const bool far = active && (uint32_t)(pos - pos0) >= SLAB_FAR_AT;
+    const int32_t base = far ? pos + 1 : pos0 + 1;
     uint32_t n = 0u;
     int el = INT32_MIN;
     bool sane = true;
@@ -184,7 +197,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
             const bool keep = cut & (first | (end - start >= p.min_exon - 1));
             if (keep) {
                 const uint32_t xlen = (uint32_t)(end - start + 1);
-                if (!GENERAL || n + 1u < rows_tile) { st32(xs, off + (n + 1u) * SLAB_STRIDE, start); st32(xl, off + (n + 1u) * SLAB_STRIDE, (uint16_t)xlen); }
+                if (!GENERAL || n + 1u < rows_tile) st32(rows, off + (n + 1u) * SLAB_STRIDE, slab_pack(start - base, xlen));
                 longest = max(longest, xlen);
                 if (GENERAL) sane = sane & (start <= end);
                 if (first) { s0 = start; e0 = end; }
@@ -201,15 +214,18 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
             for (uint32_t i = SLAB_HEAD; i < n_cig; ++i) step(words[i]);
         }
         {   const uint32_t xlen = (uint32_t)(end - start + 1);
-            st32(xs, off, start); st32(xl, off, (uint16_t)xlen);
-            longest = max(longest, xlen); }
+            st32(rows, off, slab_pack(start - base, xlen));
+            longest = max(longest, xlen);
+            // (starts rise along the read: the last one is the furthest)
+            if ((uint32_t)(start - base) >= SLAB_REL_MASK) longest = 0xffffffffu; }
         if (first) { s0 = start; e0 = end; }
         ++n;
         el = end;
         // with min_exon >= 1 kept inner exons are at least one base long; the first and the last one are kept whatever their length
         sane = GENERAL ? (sane & (start <= end)) : (s0 <= e0 && start <= end);
-        // an exon of 64 kb or more does not fit the row format, and (-e < 1 only) the read may have outgrown the tile's rows
-        if (longest > 0xffffu || (GENERAL && n > rows_tile)) { outlier = true; n = 0u; sane = true; el = INT32_MIN; }
+        // an exon of 16 kb or more or one that starts 256 kb behind the base does not fit the row format, and (-e < 1 only) the read
+        // may have outgrown the tile's rows
+        if (longest > SLAB_LEN_MAX || (GENERAL && n > rows_tile)) { outlier = true; n = 0u; sane = true; el = INT32_MIN; }
     }
     if (active && outlier) {
         // an outlier: the literal walk (l2r_kernels.hip.h), twice -- count, take a run of the dense area, store
@@ -229,7 +245,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
         auto put = [&](int k, int s, int e) { ds[run + (uint32_t)k] = s; de[run + (uint32_t)k] = e; sane = sane & (s <= e); el = e; };
         walk_ops<false>(w, words, 0, (int)n_ops, p, put);
         put(w.n, w.start, w.end);
-        st32(xs, off, (int32_t)run);                     // (row 0 of the unused column: where the probe side finds the run)
+        st32(rows, off, run);                     // (row 0 of the unused column: where the probe side finds the run)
     }
     s_cnt[idx] = active ? n : 0u;                        // (every entry is written: idx is a permutation of 0 .. 255)
     const int m = wave_max(active ? el : INT32_MIN);
@@ -254,7 +270,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     }
     if (active) {
         const uint32_t at = r0 + threadIdx.x;
-        sa->pre[at] = idx | (((xw >> 16) & 1u) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (outlier ? PRE_DENSE : 0u) | (n << PRE_N_SHIFT);
+        sa->pre[at] = idx | (((xw >> 16) & 1u) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (outlier ? PRE_DENSE : (far ? PRE_FAR : 0u)) | (n << PRE_N_SHIFT);
         sa->loc[at] = s_loc[idx];
     }
     // ---- the tile's descriptor and window, by the last wave alone (the others are done): nobody waits for its load chain
@@ -317,22 +333,13 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
 // ---------------------------------------------------------------------------------------------------------- k_probe_slab
 // A row of a column as loaded: {start, length word}.  The 16-bit length is fetched as the low half of a 4-byte load at its 2-byte
 // boundary and masked where the row is READ: a 16-bit load is zero-extended by the compiler where it is issued, i.e. waited for there.
-struct SlabRow { int s; uint32_t l; };
-__device__ __forceinline__ SlabRow slab_load_row(const int32_t *__restrict__ xs, const uint16_t *__restrict__ xl, uint32_t i)
-{
-    SlabRow r;
-    r.s = ld32(xs, i);
-    r.l = *reinterpret_cast<const u32_a1 *>(reinterpret_cast<const char *>(xl) + (size_t)(i * 2u));
-    return r;
-}
-// end = start + (low half of the length word) - 1, as ONE opaque step: written in C the compiler folds the mask into the
-// loop's register hand-over, i.e. back to the place where the load is issued
-__device__ __forceinline__ int slab_row_end(const SlabRow &r)
-{
-    int e;
-    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\tv_add_u32_e32 %0, -1, %0" : "=v"(e) : "v"(r.l), "v"(r.s));
-    return e;
-}
+struct SlabRow { uint32_t w; };
+__device__ __forceinline__ SlabRow slab_load_row(const uint32_t *__restrict__ xw, uint32_t i) { return SlabRow{ld32(xw, i)}; }
+// (start / end are formed where they are used, from the word as loaded: anything done to a loaded register at the place of the
+//  load is a wait for that load)
+__device__ __forceinline__ int slab_row_start(const SlabRow &r, int32_t base) { return base + (int)(r.w & SLAB_REL_MASK); }
+__device__ __forceinline__ uint32_t slab_row_len(const SlabRow &r) { return r.w >> SLAB_REL_BITS; }
+__device__ __forceinline__ int slab_row_end(const SlabRow &r, int32_t base) { return slab_row_start(r, base) + (int)slab_row_len(r) - 1; }
 constexpr int SLAB_AHEAD = 4;                            // exons of a read in flight (rows k .. k + 3 in registers)
 struct SlabRows { SlabRow last, x[SLAB_AHEAD]; };        // a column's row 0 (the last exon) and rows 1 .. 4 as loaded by the kernel's first loads
 
@@ -347,8 +354,6 @@ struct SlabRows { SlabRow last, x[SLAB_AHEAD]; };        // a column's row 0 (th
 // (Measured: 8 bytes per position at 6 workgroups per CU 0.474 ms, this form 0.462; 2112 positions at 8 workgroups per CU and
 // 64 VGPRs: 0.594 -- 17 spilled registers and 13 % more tiles.)
 constexpr int SLAB_POS_CAP = 2416;
-constexpr int SLAB_REL_BITS = 18;
-constexpr uint32_t SLAB_REL_MASK = (1u << SLAB_REL_BITS) - 1u;
 constexpr uint32_t SLAB_POS_SKIP = 0xffffffffu;          // A of a position that was written directly (a staged start is below 2^18 - 1)
 struct SlabStage { uint32_t *A; uint16_t *Ln; uint32_t loc; int32_t lo; bool fits; };          // loc: the lane's first position, lo: the tile's first start
 
@@ -357,9 +362,8 @@ struct SlabStage { uint32_t *A; uint16_t *Ln; uint32_t loc; int32_t lo; bool fit
 // of a loaded register is a wait for its load).  Round k reads exon k (current) and exon k + 1 (next) and, when it is done with
 // exon k, asks for exon k + 4 into exon k's registers: that load has three rounds to arrive.  Every round leaves its exon and
 // its work word at the exon's position in LDS (SlabStage).
-__device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const TileDesc &d, bool mapping, const int32_t *__restrict__ xs,
-                                                    const uint16_t *__restrict__ xl, uint32_t off, uint32_t n, uint32_t vpre,
-                                                    const SlabRows &q, const SlabStage &st)
+__device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const TileDesc &d, bool mapping, const uint32_t *__restrict__ xw,
+                                                    uint32_t off, uint32_t n, uint32_t vpre, const SlabRows &q, const SlabStage &st)
 {
     SiteMasks m{0xffffffffu, 0u, 0u, 0u};
     uint32_t *const Ap = st.A + st.loc; uint16_t *const Lp = st.Ln + st.loc;
@@ -377,12 +381,12 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         ls = L.dir0[is]; hs = L.dir0[is + 1u]; le = L.dir1[ie]; he = L.dir1[ie + 1u];
     };
     uint32_t ls, hs, le, he;
-    int e_cur = slab_row_end(R0);                       // (the end of the current exon: formed once, as the "next" of the round before)
-    buckets(0, R0.s, e_cur, ls, hs, le, he);
+    int e_cur = slab_row_end(R0, st.lo);                // (the end of the current exon: formed once, as the "next" of the round before)
+    buckets(0, slab_row_start(R0, st.lo), e_cur, ls, hs, le, he);
     auto round = [&](int k, SlabRow &cur, const SlabRow &nxt, bool reload) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
-        const int s = cur.s, e = e_cur, s2 = nxt.s, e2 = slab_row_end(nxt);
-        const uint32_t lw = cur.l;
+        const int s = slab_row_start(cur, st.lo), e = e_cur, s2 = slab_row_start(nxt, st.lo), e2 = slab_row_end(nxt, st.lo);
+        const uint32_t cw = cur.w;
         const v4i_t qs0 = lds_entry(L.ent0, ls);
         const v4i_t qe0 = lds_entry(L.ent1, le), qe1 = lds_entry(L.ent1, le + 1u);
         uint32_t ls_n, hs_n, le_n, he_n;
@@ -394,7 +398,7 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(L.ent0, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + 2u, he, e, s2, jm, dm, 0u); }
         if (reload) {                                   // exon k + 4 into the registers of exon k
             const uint32_t j = (uint32_t)k + (uint32_t)SLAB_AHEAD;
-            cur = slab_load_row(xs, xl, off + (j < nm1 ? j + 1u : 0u) * SLAB_STRIDE);
+            cur = slab_load_row(xw, off + (j < nm1 ? j + 1u : 0u) * SLAB_STRIDE);
         }
         const uint32_t amj = junc ? am : 0u;
         uint32_t word = first_member(xm & vpre);
@@ -405,7 +409,7 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         m.kor |= amj | dm;
         if (k == 0) m.dm_first = dm;
         m.am_last = (live && !junc) ? am : m.am_last;
-        if (live) { Ap[k] = (uint32_t)(s - st.lo) | (word << SLAB_REL_BITS); Lp[k] = (uint16_t)lw; }
+        if (live) { Ap[k] = (cw & SLAB_REL_MASK) | (word << SLAB_REL_BITS); Lp[k] = (uint16_t)(cw >> SLAB_REL_BITS); }      // (a staged read's base is the tile's)
         ls = ls_n; hs = hs_n; le = le_n; he = he_n; e_cur = e2;
     };
     static_assert(SLAB_AHEAD == 4, "the round loop is unrolled by the number of exons in flight");
@@ -497,27 +501,30 @@ struct SlabStamp {
 // (its exons wait in the dense area).  Into the staged positions when the read fits there, else straight into the result arrays.
 // Flags 0: the generic kernel writes them for the reads it takes, a one-exon read's flag follows from its verdict.
 struct SlabOut { int32_t *start, *end; uint8_t *flag; uint32_t dst; };     // the read-order arrays, exon k of the lane's read at dst + k
-__device__ __forceinline__ void slab_copy_exons(SlabArgsK sa, const SlabOut &out, const SlabStage &st, const SlabRows &q, uint32_t off, uint32_t n, bool dense)
+__device__ __forceinline__ void slab_copy_exons(SlabArgsK sa, PipeArgsK a, const SlabOut &out, const SlabStage &st, const SlabRows &q, uint32_t off, uint32_t n,
+                                                uint32_t pre, uint32_t r)
 {
-    // (an outlier's exons may be 64 kb and longer, which the 16-bit length of a staged position cannot say: written directly, its
-    //  positions marked so that the tile's write-out leaves them alone)
+    // (an outlier's exons may be 16 kb and longer, which the length of a staged position cannot say: written directly, its
+    //  positions marked so that the tile's write-out leaves them alone; the same for a read whose rows have its own base)
+    const bool dense = (pre & PRE_DENSE) != 0u;
     auto put = [&](uint32_t k, int s, int e) {
-        if (st.fits && !dense) { st.A[st.loc + k] = (uint32_t)(s - st.lo); st.Ln[st.loc + k] = (uint16_t)(e - s + 1); }
+        if (st.fits) { st.A[st.loc + k] = (uint32_t)(s - st.lo); st.Ln[st.loc + k] = (uint16_t)(e - s + 1); }
         else {
             out.start[out.dst + k] = s; out.end[out.dst + k] = e; out.flag[out.dst + k] = 0;
             if (st.loc + k < (uint32_t)SLAB_POS_CAP) st.A[st.loc + k] = SLAB_POS_SKIP;
         }
     };
     if (dense) {
-        const uint32_t run = (uint32_t)q.last.s;
+        const uint32_t run = q.last.w;
         for (uint32_t k = 0; k < n; ++k) put(k, sa->dense_start[run + k], sa->dense_end[run + k]);
-    } else if (n == 1u) {
-        put(0u, q.last.s, slab_row_end(q.last));
     } else {
-        for (uint32_t k = 0; k < n; ++k) {
-            const SlabRow r = slab_load_row(sa->slab_start, sa->slab_len, off + slab_row(k, n) * SLAB_STRIDE);
-            put(k, r.s, slab_row_end(r));
-        }
+        const int32_t base = (pre & PRE_FAR) ? a->f.r_pos[r] + 1 : st.lo;
+        if (n == 1u) put(0u, slab_row_start(q.last, base), slab_row_end(q.last, base));
+        else
+            for (uint32_t k = 0; k < n; ++k) {
+                const SlabRow w = slab_load_row(sa->slab_row, off + slab_row(k, n) * SLAB_STRIDE);
+                put(k, slab_row_start(w, base), slab_row_end(w, base));
+            }
     }
 }
 
@@ -534,7 +541,7 @@ __device__ __forceinline__ void slab_classify(SlabArgsK sa, PipeArgsK a, const T
     const int w_n = fast ? (int)d.n_win : 0;
     const uint32_t n = pre >> PRE_N_SHIFT;
     const bool outlier = (pre & PRE_DENSE) != 0u, rev_in = (pre & PRE_REV) != 0u;
-    const int32_t *const xs = sa->slab_start; const uint16_t *const xl = sa->slab_len;
+    const uint32_t *const xw = sa->slab_row;
     // ---- classification (device functions of the classic kernel)
     uint32_t info = n << 8; int ref = -1;
     // (sorted input: a tile is of one chromosome, the descriptor's)
@@ -545,9 +552,9 @@ __device__ __forceinline__ void slab_classify(SlabArgsK sa, PipeArgsK a, const T
     redo = redo || vm.redo;
     stamp.mark(2);
     const bool mapping = work && !redo && n > 1;
-    const SiteMasks sm = map_exons_slab(L, d, mapping, xs, xl, off, n, vm.vpre, q, st);
+    const SiteMasks sm = map_exons_slab(L, d, mapping, xw, off, n, vm.vpre, q, st);
     stamp.mark(3);
-    if (active && !mapping) slab_copy_exons(sa, out, st, q, off, n, outlier);
+    if (active && !mapping) slab_copy_exons(sa, a, out, st, q, off, n, pre, r);
     if (work && !redo) {
         // work words: the upper 14 bits of the read's A words, replaced by the flag byte
         uint32_t *const Ap = st.A + st.loc;
@@ -599,13 +606,12 @@ __device__ __forceinline__ void slab_write_out(const SlabOut &out0 /* dst = xbas
 
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, 7)
-void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const uint32_t *__restrict__ u_tile_sbase,
+void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase,
                   const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase /* first result slot of every tile: the scanned exon counts (+ the total) */)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
     __shared__ __attribute__((aligned(16))) uint32_t s_A[SLAB_POS_CAP];
     __shared__ __attribute__((aligned(16))) uint16_t s_L[SLAB_POS_CAP];
-    __shared__ int32_t s_lo;
     __shared__ __attribute__((aligned(16))) v4i_t s_ent[2 * SLAB_KEY_CAP];
     __shared__ __attribute__((aligned(16))) uint8_t s_dir[3 * DIR_BYTES];
     __shared__ __attribute__((aligned(16))) TileWin s_tw;
@@ -619,6 +625,7 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     SlabStamp stamp; stamp.start(a->f.stamps);
     const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
     const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t], total = u_xbase[t + 1u] - xbase;
+    const int32_t tile_lo = u_pos[r0] + 1;                       // the base of the tile's row words: its first read's first base (coordinate-sorted records)
     v4i_t *const s_ent0 = s_ent, *const s_ent1 = s_ent + SLAB_KEY_CAP;
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
     // ---- one round trip behind the descriptor (scalar loads: uniform address): the tile's dictionary slices, its window
@@ -641,23 +648,23 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     const bool active = slot < n_act;
     const uint32_t at = r0 + (active ? slot : 0u);
     uint32_t pre = 0u, loc = 0u;
-    const int32_t *const xs = sa->slab_start; const uint16_t *const xl = sa->slab_len;
+    const uint32_t *const xw = sa->slab_row;
     const uint32_t off = sbase + slot;
     SlabRows q;
-    q.last = SlabRow{0, 0u};
+    q.last = SlabRow{0u};
 #pragma unroll
-    for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = SlabRow{0, 0u};
+    for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = SlabRow{0u};
     if (active) {
         pre = ld32(sa->pre, at); loc = ld32(sa->loc, at);
-        q.last = slab_load_row(xs, xl, off);
+        q.last = slab_load_row(xw, off);
 #pragma unroll
-        for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = slab_load_row(xs, xl, off + min((uint32_t)i + 1u, row_max) * SLAB_STRIDE);      // (an outlier's column holds nothing: read, not used)
+        for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = slab_load_row(xw, off + min((uint32_t)i + 1u, row_max) * SLAB_STRIDE);      // (an outlier's column holds nothing: read, not used)
     }
     if (threadIdx.x == 0) { s_lim = min(total, (uint32_t)SLAB_POS_CAP); if (t == 0u) *sa->ovf_cursor = 0ull; }     // (k_walk_slab is done with the outlier area)
     const uint32_t n = pre >> PRE_N_SHIFT;
     const uint32_t r = r0 + (pre & 0xffu);
     const SlabRow first = n == 1u ? q.last : q.x[0];
-    const ReadEnds re{first.s, slab_row_end(first), q.last.s, slab_row_end(q.last)};
+    const ReadEnds re{slab_row_start(first, tile_lo), slab_row_end(first, tile_lo), slab_row_start(q.last, tile_lo), slab_row_end(q.last, tile_lo)};      // (not of an outlier or a far read: those are not classified here)
     const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
     if (stamp.p) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp.mark(0);
@@ -670,12 +677,10 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
         const int w_any = __any(my_wide) ? 1 : 0;
         if ((threadIdx.x & (WAVE - 1)) == 0) s_widew[threadIdx.x >> 6] = w_any;
     }
-    if (active && (pre & 0xffu) == 0u) s_lo = re.s0;             // the tile's first read has its smallest start (coordinate-sorted records)
     __syncthreads();
     const int any_wide = s_widew[0] | s_widew[1] | s_widew[2] | s_widew[3];
-    const int32_t tile_lo = s_lo;
-    // a read is staged when its positions fit and its last exon starts less than 2^18 - 1 bases behind the tile's first start
-    const SlabStage st{s_A, s_L, loc, tile_lo, loc + n <= (uint32_t)SLAB_POS_CAP && (uint32_t)(re.sl - tile_lo) < SLAB_REL_MASK && !(pre & PRE_DENSE)};
+    // a read is staged when its positions fit and its rows have the tile's base
+    const SlabStage st{s_A, s_L, loc, tile_lo, loc + n <= (uint32_t)SLAB_POS_CAP && !(pre & (PRE_DENSE | PRE_FAR))};
     // the first read that does not fit the staged positions ends the block that is written from LDS (reads are in read order there)
     if (active && loc + n > (uint32_t)SLAB_POS_CAP) atomicMin(&s_lim, loc);      // (a read that is written directly for another reason marks its positions instead)
     stamp.mark(1);

@@ -125,9 +125,8 @@ __device__ __forceinline__ m64_t overlapping_exon_members64(const uint8_t *rdir,
 
 // map_exons_slab on 64-bit masks: rows k .. k + 3 of the column in four register pairs with fixed roles, every round leaves its
 // exon and its work word at the exon's position in LDS (SlabStage)
-__device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const TileDesc &d, bool mapping, const int32_t *__restrict__ xs,
-                                                        const uint16_t *__restrict__ xl, uint32_t off, uint32_t n, m64_t vpre,
-                                                        const SlabRows &q, const SlabStage &st)
+__device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const TileDesc &d, bool mapping, const uint32_t *__restrict__ xw,
+                                                        uint32_t off, uint32_t n, m64_t vpre, const SlabRows &q, const SlabStage &st)
 {
     SiteMasks64 m{~0ull, 0ull, 0ull, 0ull};
     uint32_t *const Ap = st.A + st.loc; uint16_t *const Lp = st.Ln + st.loc;
@@ -135,11 +134,11 @@ __device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const 
     const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
     const int k_max = wave_max(mapping ? (int)n : 0);
     const uint32_t nm1 = mapping ? n - 1u : 0u;
-    int e_cur = slab_row_end(R0);
+    int e_cur = slab_row_end(R0, st.lo);
     auto round = [&](int k, SlabRow &cur, const SlabRow &nxt, bool reload) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
-        const int s = cur.s, e = e_cur, s2 = nxt.s, e2 = slab_row_end(nxt);
-        const uint32_t lw = cur.l;
+        const int s = slab_row_start(cur, st.lo), e = e_cur, s2 = slab_row_start(nxt, st.lo), e2 = slab_row_end(nxt, st.lo);
+        const uint32_t cw = cur.w;
         const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
         const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
         const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
@@ -148,7 +147,7 @@ __device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const 
         probe_all64(L.ent1, le, he, e, s2, jm, dm);
         if (reload) {                                   // exon k + 4 into the registers of exon k
             const uint32_t j = (uint32_t)k + (uint32_t)SLAB_AHEAD;
-            cur = slab_load_row(xs, xl, off + (j < nm1 ? j + 1u : 0u) * SLAB_STRIDE);
+            cur = slab_load_row(xw, off + (j < nm1 ? j + 1u : 0u) * SLAB_STRIDE);
         }
         const m64_t amj = junc ? am : 0ull;
         uint32_t word = first_member64(xm & vpre);
@@ -159,7 +158,7 @@ __device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const 
         m.kor |= amj | dm;
         if (k == 0) m.dm_first = dm;
         m.am_last = (live && !junc) ? am : m.am_last;
-        if (live) { Ap[k] = (uint32_t)(s - st.lo) | (word << SLAB_REL_BITS); Lp[k] = (uint16_t)lw; }
+        if (live) { Ap[k] = (cw & SLAB_REL_MASK) | (word << SLAB_REL_BITS); Lp[k] = (uint16_t)(cw >> SLAB_REL_BITS); }
         e_cur = e2;
     };
     static_assert(SLAB_AHEAD == 4, "the round loop is unrolled by the number of exons in flight");
@@ -239,7 +238,7 @@ struct WideArgs { uint32_t *wide_count; const uint32_t *wide_tile; const TileWin
 
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, 5)
-void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__restrict__ u_tile_first, const uint32_t *__restrict__ u_tile_sbase,
+void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__restrict__ u_tile_first, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase,
                        const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
@@ -249,7 +248,6 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
     __shared__ __attribute__((aligned(16))) uint8_t s_dir[3 * DIR_BYTES];
     __shared__ __attribute__((aligned(16))) TileWin64 s_tw;
     __shared__ uint32_t s_next, s_lim, s_p0, s_p1;
-    __shared__ int32_t s_lo;
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
@@ -270,6 +268,7 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         const uint32_t t = entry & 0x0fffffffu, part = entry >> 28;
         const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
         const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t], total = u_xbase[t + 1u] - xbase;
+        const int32_t tile_lo = u_pos[r0] + 1;                   // the base of the tile's row words
         for (int i = (int)threadIdx.x; i < WIDE_TW_VECS; i += TILE_THREADS)
             reinterpret_cast<int4 *>(&s_tw)[i] = reinterpret_cast<const int4 *>(wa.tw64 + wi)[i];
         // the part's reads [i0, i1) in read order: their exons are the tile's positions [p0, p1)
@@ -279,17 +278,17 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         bool active = threadIdx.x < n_act;
         const uint32_t at = r0 + (active ? threadIdx.x : 0u);
         uint32_t pre = 0u, loc = 0u;
-        const int32_t *const xs = sa->slab_start; const uint16_t *const xl = sa->slab_len;
+        const uint32_t *const xw = sa->slab_row;
         const uint32_t off = sbase + threadIdx.x;
         SlabRows q;
-        q.last = SlabRow{0, 0u};
+        q.last = SlabRow{0u};
 #pragma unroll
-        for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = SlabRow{0, 0u};
+        for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = SlabRow{0u};
         if (active) {
             pre = ld32(sa->pre, at); loc = ld32(sa->loc, at);
-            q.last = slab_load_row(xs, xl, off);
+            q.last = slab_load_row(xw, off);
 #pragma unroll
-            for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = slab_load_row(xs, xl, off + min((uint32_t)i + 1u, row_max) * SLAB_STRIDE);      // (an outlier's column holds nothing: read, not used)
+            for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = slab_load_row(xw, off + min((uint32_t)i + 1u, row_max) * SLAB_STRIDE);      // (an outlier's column holds nothing: read, not used)
         }
         if (threadIdx.x == 0) { s_p0 = 0u; s_p1 = total; }
         __syncthreads();
@@ -301,13 +300,11 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         const uint32_t r = r0 + idx;
         const bool outlier = (pre & PRE_DENSE) != 0u, rev_in = (pre & PRE_REV) != 0u;
         const SlabRow first = n == 1u ? q.last : q.x[0];
-        const ReadEnds re{first.s, slab_row_end(first), q.last.s, slab_row_end(q.last)};
-        if (active && idx == i0) s_lo = re.s0;                   // the part's first read has its smallest start (coordinate-sorted records)
+        const ReadEnds re{slab_row_start(first, tile_lo), slab_row_end(first, tile_lo), slab_row_start(q.last, tile_lo), slab_row_end(q.last, tile_lo)};
         __syncthreads();
         const TileDesc d = s_tw.d;
         const int w_n = (int)d.n_win;
         const uint32_t p0 = s_p0, p1 = s_p1;
-        const int32_t part_lo = s_lo;
         // ---- stage the dictionary slices, masks re-based to the tile's window (64-bit)
         const DictRegs dv = load_dict_slices(a, d);
         int my_wide = 0;
@@ -343,11 +340,10 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         }
         if (threadIdx.x == 0) s_lim = min(p1 - p0, (uint32_t)SLAB_POS_CAP);
         const int any_wide = __syncthreads_or(my_wide);
-        // the part's positions are staged from 0: a read is staged when its positions fit and its last exon starts less than
-        // 2^18 - 1 bases behind the part's first start
+        // the part's positions are staged from 0: a read is staged when its positions fit and its rows have the tile's base
         const uint32_t ploc = loc - p0;
         const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
-        const SlabStage st{s_A, s_L, ploc, part_lo, active && ploc + n <= (uint32_t)SLAB_POS_CAP && (uint32_t)(re.sl - part_lo) < SLAB_REL_MASK && !outlier};
+        const SlabStage st{s_A, s_L, ploc, tile_lo, active && ploc + n <= (uint32_t)SLAB_POS_CAP && !(pre & (PRE_DENSE | PRE_FAR))};
         if (active && ploc + n > (uint32_t)SLAB_POS_CAP) atomicMin(&s_lim, ploc);
         // ---- classification
         uint32_t info = n << 8; int ref = -1;
@@ -357,8 +353,8 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         const VisitMasks64 vm = visit_window64<LEVEL>(L, d, w_n, work, n, d.j_lo, re, s_tw.mask);
         redo = redo || vm.redo;
         const bool mapping = work && !redo && n > 1;
-        const SiteMasks64 sm = map_exons_slab64(L, d, mapping, xs, xl, off, n, vm.vpre, q, st);
-        if (active && !mapping) slab_copy_exons(sa, out, st, q, off, n, outlier);
+        const SiteMasks64 sm = map_exons_slab64(L, d, mapping, xw, off, n, vm.vpre, q, st);
+        if (active && !mapping) slab_copy_exons(sa, a, out, st, q, off, n, pre, r);
         if (work && !redo) {
             uint32_t *const Ap = s_A + ploc;
             const Verdict vd = decide64<LEVEL>(L, d, n, re, vm, sm, rev_in, [&](int k) { return Ap[k] >> SLAB_REL_BITS; },
@@ -377,7 +373,7 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         }
         if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; a->f.ex_off[r] = out.dst; }
         __syncthreads();
-        slab_write_out(SlabOut{out.start, out.end, out.flag, xbase + p0}, s_A, s_L, part_lo, s_lim);
+        slab_write_out(SlabOut{out.start, out.end, out.flag, xbase + p0}, s_A, s_L, tile_lo, s_lim);
         __syncthreads();                                        // (the next entry of this workgroup overwrites the LDS image)
     }
 }
