@@ -340,7 +340,10 @@ __device__ __forceinline__ SlabRow slab_load_row(const uint32_t *__restrict__ xw
 __device__ __forceinline__ int slab_row_start(const SlabRow &r, int32_t base) { return base + (int)(r.w & SLAB_REL_MASK); }
 __device__ __forceinline__ uint32_t slab_row_len(const SlabRow &r) { return r.w >> SLAB_REL_BITS; }
 __device__ __forceinline__ int slab_row_end(const SlabRow &r, int32_t base) { return slab_row_start(r, base) + (int)slab_row_len(r) - 1; }
-constexpr int SLAB_AHEAD = 4;                            // exons of a read in flight (rows k .. k + 3 in registers)
+#ifndef L2R_SLAB_AHEAD
+#define L2R_SLAB_AHEAD 4
+#endif
+constexpr int SLAB_AHEAD = L2R_SLAB_AHEAD;               // exons of a read in flight (rows k .. k + SLAB_AHEAD - 1 in registers, one word each)
 struct SlabRows { SlabRow last, x[SLAB_AHEAD]; };        // a column's row 0 (the last exon) and rows 1 .. 4 as loaded by the kernel's first loads
 
 // The tile's results on their way out: the lanes of k_probe_slab hold one READ each (slot order), the result arrays want the exons
@@ -368,7 +371,9 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
     SiteMasks m{0xffffffffu, 0u, 0u, 0u};
     uint32_t *const Ap = st.A + st.loc; uint16_t *const Lp = st.Ln + st.loc;
     // exon j of the read: row j + 1, the last one row 0
-    SlabRow R0 = n == 1u ? q.last : q.x[0], R1 = n == 2u ? q.last : q.x[1], R2 = n == 3u ? q.last : q.x[2], R3 = n == 4u ? q.last : q.x[3];
+    SlabRow R[SLAB_AHEAD];
+#pragma unroll
+    for (int i = 0; i < SLAB_AHEAD; ++i) R[i] = n == (uint32_t)i + 1u ? q.last : q.x[i];
     const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
     const int k_max = wave_max(mapping ? (int)n : 0);
     const uint32_t nm1 = mapping ? n - 1u : 0u;         // (lanes that map nothing keep loading their row 0: a valid address, no branch)
@@ -381,8 +386,8 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         ls = L.dir0[is]; hs = L.dir0[is + 1u]; le = L.dir1[ie]; he = L.dir1[ie + 1u];
     };
     uint32_t ls, hs, le, he;
-    int e_cur = slab_row_end(R0, st.lo);                // (the end of the current exon: formed once, as the "next" of the round before)
-    buckets(0, slab_row_start(R0, st.lo), e_cur, ls, hs, le, he);
+    int e_cur = slab_row_end(R[0], st.lo);              // (the end of the current exon: formed once, as the "next" of the round before)
+    buckets(0, slab_row_start(R[0], st.lo), e_cur, ls, hs, le, he);
     auto round = [&](int k, SlabRow &cur, const SlabRow &nxt, bool reload) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
         const int s = slab_row_start(cur, st.lo), e = e_cur, s2 = slab_row_start(nxt, st.lo), e2 = slab_row_end(nxt, st.lo);
@@ -396,7 +401,7 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
             am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
         probe2(qe0, qe1, le, he, e, s2, jm, dm);
         if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(L.ent0, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + 2u, he, e, s2, jm, dm, 0u); }
-        if (reload) {                                   // exon k + 4 into the registers of exon k
+        if (reload) {                                   // exon k + SLAB_AHEAD into the registers of exon k
             const uint32_t j = (uint32_t)k + (uint32_t)SLAB_AHEAD;
             cur = slab_load_row(xw, off + (j < nm1 ? j + 1u : 0u) * SLAB_STRIDE);
         }
@@ -412,19 +417,17 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         if (live) { Ap[k] = (cw & SLAB_REL_MASK) | (word << SLAB_REL_BITS); Lp[k] = (uint16_t)(cw >> SLAB_REL_BITS); }      // (a staged read's base is the tile's)
         ls = ls_n; hs = hs_n; le = le_n; he = he_n; e_cur = e2;
     };
-    static_assert(SLAB_AHEAD == 4, "the round loop is unrolled by the number of exons in flight");
-    // whole groups of four rounds (one back edge, no exit inside: the wait in front of a row then counts the loads behind it),
-    // then up to three more rounds that ask for nothing
+    // whole groups of SLAB_AHEAD rounds (one back edge, no exit inside: the wait in front of a row then counts the loads behind
+    // it), then up to SLAB_AHEAD - 1 more rounds that ask for nothing
     int k = 0;
     for (; k + SLAB_AHEAD <= k_max; k += SLAB_AHEAD) {
-        round(k, R0, R1, true); round(k + 1, R1, R2, true); round(k + 2, R2, R3, true); round(k + 3, R3, R0, true);
+#pragma unroll
+        for (int i = 0; i < SLAB_AHEAD; ++i) round(k + i, R[i], R[(i + 1) % SLAB_AHEAD], true);
     }
-    if (k < k_max) {
-        round(k, R0, R1, false);
-        if (k + 1 < k_max) {
-            round(k + 1, R1, R2, false);
-            if (k + 2 < k_max) round(k + 2, R2, R3, false);
-        }
+#pragma unroll
+    for (int i = 0; i < SLAB_AHEAD - 1; ++i) {
+        if (k + i >= k_max) break;
+        round(k + i, R[i], R[i + 1], false);
     }
     return m;
 }
@@ -604,8 +607,13 @@ __device__ __forceinline__ void slab_write_out(const SlabOut &out0 /* dst = xbas
     }
 }
 
+// Workgroups per CU: a spilled register is a scratch access, and scratch accesses count on the same in-order counter as the row
+// loads (a reload inside the probe rounds waits for every row asked for before it): levels 3 and 4 need 74 .. 78 registers, so
+// they run at 6 workgroups per CU without scratch (measured at level 3: 0.418 ms against 0.435 at 7 with 32 bytes of scratch);
+// the other levels fit the 72 registers of 7.
+constexpr int slab_probe_wgs(int level) { return (level == 3 || level == 4) ? 6 : 7; }
 template <int LEVEL>
-__global__ __launch_bounds__(TILE_THREADS, 7)
+__global__ __launch_bounds__(TILE_THREADS, slab_probe_wgs(LEVEL))
 void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase,
                   const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase /* first result slot of every tile: the scanned exon counts (+ the total) */)
 {

@@ -130,11 +130,13 @@ __device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const 
 {
     SiteMasks64 m{~0ull, 0ull, 0ull, 0ull};
     uint32_t *const Ap = st.A + st.loc; uint16_t *const Lp = st.Ln + st.loc;
-    SlabRow R0 = n == 1u ? q.last : q.x[0], R1 = n == 2u ? q.last : q.x[1], R2 = n == 3u ? q.last : q.x[2], R3 = n == 4u ? q.last : q.x[3];
+    SlabRow R[SLAB_AHEAD];
+#pragma unroll
+    for (int i = 0; i < SLAB_AHEAD; ++i) R[i] = n == (uint32_t)i + 1u ? q.last : q.x[i];
     const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
     const int k_max = wave_max(mapping ? (int)n : 0);
     const uint32_t nm1 = mapping ? n - 1u : 0u;
-    int e_cur = slab_row_end(R0, st.lo);
+    int e_cur = slab_row_end(R[0], st.lo);
     auto round = [&](int k, SlabRow &cur, const SlabRow &nxt, bool reload) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
         const int s = slab_row_start(cur, st.lo), e = e_cur, s2 = slab_row_start(nxt, st.lo), e2 = slab_row_end(nxt, st.lo);
@@ -145,7 +147,7 @@ __device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const 
         m64_t xm, am, jm, dm;
         probe_all64(L.ent0, ls, hs, s, e, xm, am);
         probe_all64(L.ent1, le, he, e, s2, jm, dm);
-        if (reload) {                                   // exon k + 4 into the registers of exon k
+        if (reload) {                                   // exon k + SLAB_AHEAD into the registers of exon k
             const uint32_t j = (uint32_t)k + (uint32_t)SLAB_AHEAD;
             cur = slab_load_row(xw, off + (j < nm1 ? j + 1u : 0u) * SLAB_STRIDE);
         }
@@ -161,17 +163,17 @@ __device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const 
         if (live) { Ap[k] = (cw & SLAB_REL_MASK) | (word << SLAB_REL_BITS); Lp[k] = (uint16_t)(cw >> SLAB_REL_BITS); }
         e_cur = e2;
     };
-    static_assert(SLAB_AHEAD == 4, "the round loop is unrolled by the number of exons in flight");
+    // whole groups of SLAB_AHEAD rounds (one back edge, no exit inside: the wait in front of a row then counts the loads behind
+    // it), then up to SLAB_AHEAD - 1 more rounds that ask for nothing
     int k = 0;
     for (; k + SLAB_AHEAD <= k_max; k += SLAB_AHEAD) {
-        round(k, R0, R1, true); round(k + 1, R1, R2, true); round(k + 2, R2, R3, true); round(k + 3, R3, R0, true);
+#pragma unroll
+        for (int i = 0; i < SLAB_AHEAD; ++i) round(k + i, R[i], R[(i + 1) % SLAB_AHEAD], true);
     }
-    if (k < k_max) {
-        round(k, R0, R1, false);
-        if (k + 1 < k_max) {
-            round(k + 1, R1, R2, false);
-            if (k + 2 < k_max) round(k + 2, R2, R3, false);
-        }
+#pragma unroll
+    for (int i = 0; i < SLAB_AHEAD - 1; ++i) {
+        if (k + i >= k_max) break;
+        round(k + i, R[i], R[i + 1], false);
     }
     return m;
 }
