@@ -257,10 +257,12 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
     WEnt *const s_ent0 = s_ent, *const s_ent1 = s_ent + WIDE_KEY_CAP;
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
     const uint32_t n_wide = *wa.wide_count;
-    for (;;) {
+    for (bool own = true;; own = false) {
         // (the entries differ a lot in cost -- a part whose window is still too wide only lists its reads for the generic kernel --
-        //  so the workgroups take them from a cursor; k_probe_slab cleared it)
-        if (threadIdx.x == 0) s_next = atomicAdd(wa.wide_count + 1, 1u);
+        //  so the workgroups take them from a cursor, which k_probe_slab cleared; a workgroup's FIRST entry is its own number: an
+        //  empty list costs no atomic)
+        if (own && blockIdx.x >= n_wide) break;
+        if (threadIdx.x == 0) s_next = own ? blockIdx.x : gridDim.x + atomicAdd(wa.wide_count + 1, 1u);
         __syncthreads();
         const uint32_t wi = s_next;
         if (wi >= n_wide) break;
