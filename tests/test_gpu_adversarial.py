@@ -283,3 +283,34 @@ def test_reads_far_from_their_tiles_first_read_and_an_outlier_between_neighbours
     cnt = [0, 0, 0, 0]
     got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=3)
     assert ((want.info & 2) != 0).sum() > 100            # (chains that begin with a transcript's first exon are never "known": Q1)
+
+
+@pytest.mark.parametrize("level", [3, 5])
+def test_row_word_limits_of_the_slab(oracle, level, pipeline):
+    """A slab row is one word: the exon's start relative to the tile's first base in 18 bits, its length in 14.  Around every limit of
+    that format, inside one tile of staged neighbours: exons of 16383 / 16384 / 16385 bases (the last two leave the slab), reads that
+    begin just below / at / above 2^17 bases behind the tile's first read (the latter get their own base), reads whose last exon starts
+    at 2^18 - 2 / 2^18 - 1 / 2^18 bases behind the base -- of the tile and of the read itself."""
+    lo = 1_000_000
+    txs = [(0, 0, [(lo, lo + 100), (lo + 300, lo + 400), (lo + 900, lo + 1_000)]),
+           (0, 1, [(lo + 200, lo + 260), (lo + 20_000, lo + 20_100), (lo + 262_100, lo + 262_400)]),
+           (0, 0, [(lo + 131_000, lo + 131_200), (lo + 131_400, lo + 131_500), (lo + 140_000, lo + 140_100)])]
+    rows = []
+    for k in range(150):                                                         # the tile's staged majority, first read at lo
+        rows.append((0, *_chain([(lo + (k % 50), lo + 100), (lo + 300, lo + 400), (lo + 900, lo + 1_000 - (k % 7))])))
+    for ln in (16_382, 16_383, 16_384, 16_385, 40_000):                          # exon lengths around 2^14 - 1
+        rows.append((0, *_chain([(lo + 10, lo + 100), (lo + 300, lo + 300 + ln - 1)])))
+        rows.append((0, *_chain([(lo + 12, lo + 12 + ln - 1), (lo + 12 + ln + 200, lo + 12 + ln + 300)])))
+    for d in (131_070, 131_071, 131_072, 131_073, 131_400):                      # read starts around 2^17 behind the tile's first base
+        rows.append((0, *_chain([(lo + d, lo + d + 90), (lo + d + 300, lo + d + 380)])))
+        rows.append((0, *_chain([(lo + 131_000, lo + 131_200), (lo + 131_400, lo + 131_500), (lo + 140_000, lo + 140_100)])))
+    for d in (262_141, 262_142, 262_143, 262_144, 262_145):                      # last exon starts around 2^18 - 1 behind the TILE's base
+        rows.append((0, *_chain([(lo + 200, lo + 260), (lo + 20_000, lo + 20_100), (lo + d, lo + d + 250)])))
+    for d in (262_141, 262_142, 262_143, 262_144, 262_145):                      # ... and behind the READ's own base (a far read)
+        s = lo + 140_000
+        rows.append((0, *_chain([(s, s + 100), (s + 500, s + 600), (s + d, s + d + 80)])))
+    rows = [(r[0], r[1], i & 1, r[2]) for i, r in enumerate(rows)]
+    af = _anno(txs)
+    cnt = [0, 0, 0, 0]
+    got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=level)
+    assert ((want.info & 2) != 0).sum() > 100 and len(rows) <= 256              # one tile
