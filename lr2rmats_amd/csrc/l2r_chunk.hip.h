@@ -1,0 +1,369 @@
+// l2r_chunk.hip.h -- the slab pipeline's probe kernel for tiles whose window does not fit ANY mask width: k_probe_slab_chunked.
+//
+// A tile whose reads can meet more than 63 annotation transcripts (a locus with very many isoforms) has no window record.  This
+// kernel takes such a tile's window 63 members at a time, in annotation order -- CHUNKS -- and carries the sweep's state from chunk
+// to chunk per read, exactly as the sequential sweep of check_with_anno_trans (src/update_gtf.c:792-835) meets the transcripts:
+//
+//   per chunk   one wave scans the transcript headers on from where the last chunk ended and collects the next 63 members that
+//               overlap the tile's span (the scan of make_descriptor, resumable); the tile's dictionary slices are staged with
+//               their masks re-based to the chunk; visit_chunk64 / map_exons_lds64 give the chunk's masks and per-exon work words
+//   carried     known (the sweep's break: later chunks are not looked at), stopped (a member the read lies before ended the
+//               sweep), has-known-site, the reference transcript so far (the LAST member with an identical site), lfull / rfull /
+//               lnoth / rnoth (sticky, src/update_gtf.c:629-696), and per exon the novel flags still standing (LDS, one byte per
+//               staged position: a flag is cleared by the first chunk that has a member with the exon / junction / site no later
+//               than the break)
+//
+// The tile's exons are copied from the slab to their positions in LDS once; the probe rounds of every chunk read them there.
+// Entries: k_probe_slab appends the tiles it finds without a window ("window > 32" after k_walk_slab tried 64-bit records for the
+// tile and its parts) -- see l2r_slab.hip.h.  Same results as the one-window kernels, which the parity suites check.
+#pragma once
+#include "l2r_wide.hip.h"
+
+namespace l2r {
+
+struct ChunkArgs { uint32_t *count; const uint32_t *tile; };        // count[0]: entries, count[1]: the grid's work cursor
+constexpr int CHUNK_SCAN_TRIPS = 4096;                              // 64-transcript trips one chunk's scan may take (then: generic kernel)
+
+struct ChunkVisit { m64_t vpre, lmask, rmask, k1mask; bool redo, stopped; };
+
+// visit_window64 on one chunk; `stopped`: a member of the chunk lies behind the read (src/update_gtf.c:799-800 ends the sweep)
+template <int LEVEL>
+__device__ __forceinline__ ChunkVisit visit_chunk64(const WideLds &L, int w_n, bool work, uint32_t n, const ReadEnds &re, const m64_t *tilemask)
+{
+    ChunkVisit m{0ull, 0ull, 0ull, 0ull, false, false};
+    m64_t m_aft = 0ull, m_bef = 0ull;
+#pragma unroll 4
+    for (int j = 0; j < w_n; ++j) {
+        const int4 hk = L.hk[j];
+        const m64_t bit = 1ull << j;
+        m_aft |= re.el <= hk.x ? bit : 0ull;                                 // comp_trans <= (Q5): the read lies before the member
+        m_bef |= hk.y <= re.s0 ? bit : 0ull;                                 // the member lies before the read
+        if (LEVEL >= 1 && LEVEL <= 4) {
+            const int4 hx = L.hx[j];
+            if (LEVEL == 1) {
+                m.lmask |= re.e0 == hx.y ? bit : 0ull;
+                m.rmask |= re.sl == hx.z ? bit : 0ull;
+            } else {
+                m.lmask |= closed_overlap(re.s0, re.e0, hx.x, hx.y) ? bit : 0ull;
+                if (LEVEL != 4) m.rmask |= closed_overlap(re.sl, re.el, hx.z, hx.w) ? bit : 0ull;
+            }
+        }
+    }
+    const m64_t below = (m_aft & (0ull - m_aft)) - 1ull;                     // all ones when no member ends the sweep
+    m.vpre = work ? (~m_bef & below & (w_n >= 64 ? ~0ull : ((1ull << w_n) - 1ull))) : 0ull;
+    m.stopped = work && m_aft != 0ull;
+    m.lmask &= m.vpre; m.rmask &= m.vpre;
+    const m64_t single = tilemask[0];
+    if (n == 1) {
+        m64_t c = m.vpre & single;
+        while (c) {
+            const int j = __ffsll((long long)c) - 1;
+            c &= c - 1ull;
+            const int4 hx = L.hx[j];
+            if (overlap_frac(re.s0, re.e0, hx.x, hx.y) >= fast_args()->p.frac) m.k1mask |= 1ull << j;
+        }
+    } else if (m.vpre & tilemask[1] & ~single) m.redo = true;
+    return m;
+}
+
+// map_exons_slab64 with the read's exons at their staged positions in LDS (A: start relative to the tile's base, L: length); the
+// chunk's work word goes into the upper bits of A
+__device__ __forceinline__ SiteMasks64 map_exons_lds64(const WideLds &L, const TileDesc &d, bool mapping, uint32_t *Ap, const uint16_t *Lp,
+                                                       int32_t lo, uint32_t n, m64_t vpre)
+{
+    SiteMasks64 m{~0ull, 0ull, 0ull, 0ull};
+    const uint32_t none = (uint32_t)d.nbk + 1u;
+    const int k_max = wave_max(mapping ? (int)n : 0);
+    int s = 0, e = 0;
+    if (mapping) { s = lo + (int)(Ap[0] & SLAB_REL_MASK); e = s + (int)Lp[0] - 1; }
+    for (int k = 0; k < k_max; ++k) {
+        const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
+        int s2 = 0, e2 = 0;
+        if (junc) { s2 = lo + (int)(Ap[k + 1] & SLAB_REL_MASK); e2 = s2 + (int)Lp[k + 1] - 1; }
+        const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
+        const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
+        const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
+        m64_t xm, am, jm, dm;
+        probe_all64(L.ent0, ls, hs, s, e, xm, am);
+        probe_all64(L.ent1, le, he, e, s2, jm, dm);
+        const m64_t amj = junc ? am : 0ull;
+        uint32_t word = first_member64(xm & vpre);
+        word |= first_member64(jm & vpre) << 6;
+        word |= ((dm & vpre) ? 1u : 0u) << 12;
+        word |= ((amj & vpre) ? 1u : 0u) << 13;
+        m.kand &= junc ? (am & dm) : ~0ull;            // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
+        m.kor |= amj | dm;
+        if (k == 0) m.dm_first = dm;
+        m.am_last = (live && !junc) ? am : m.am_last;
+        if (live) Ap[k] = (uint32_t)(s - lo) | (word << SLAB_REL_BITS);
+        s = s2; e = e2;
+    }
+    return m;
+}
+
+// The next chunk of the tile's window: the scan of make_descriptor (l2r_window.hip.h) from transcript scan_j on, for up to
+// WIDE_MEMBERS members; ONE WAVE.  Leaves members, headers and masks in *W (W->d: n_win, j_lo = first member, TD_CONTIG) and
+// returns where the next chunk's scan begins (n_tx: the window is exhausted; -1: the scan took too long).
+__device__ __forceinline__ int chunk_window(PipeArgsK a, int lane, int32_t tid0, int32_t tlo, int32_t thi, int scan_j, TileWin64 *W)
+{
+    const TxHdr *const hdr = a->f.hdr;
+    const int32_t n_tx = a->f.p.n_tx;
+    uint32_t n_win = 0;
+    int first = -1, last = -1, next = n_tx;
+    int trip = 0;
+    for (int base = scan_j; base < n_tx; base += WAVE, ++trip) {
+        if (trip == CHUNK_SCAN_TRIPS) { next = -1; break; }
+        const int j = base + lane;
+        bool ov = false, aft = false;
+        if (j < n_tx) {
+            const int4 h0 = *reinterpret_cast<const int4 *>(hdr + j);                 // {tid, start, end, .}
+            aft = tid0 < h0.x || (tid0 == h0.x && thi <= h0.y);                       // comp_trans <= (Q5)
+            const bool bef = h0.x < tid0 || (h0.x == tid0 && h0.z <= tlo && h0.y < tlo);
+            ov = !aft && !bef;
+        }
+        const unsigned long long ma = __ballot(aft);
+        const int stop = ma ? __ffsll((long long)ma) - 1 : WAVE;
+        unsigned long long mo = __ballot(ov) & (stop < WAVE ? (1ull << stop) - 1ull : ~0ull);
+        const uint32_t room = (uint32_t)WIDE_MEMBERS - n_win;
+        bool full = false;
+        if ((uint32_t)__popcll(mo) > room) {
+            // the chunk ends inside this trip: keep its first `room` members, the next chunk begins at the first one left out
+            unsigned long long rest = mo;
+            for (uint32_t i = 0; i < room; ++i) rest &= rest - 1ull;
+            next = base + __ffsll((long long)rest) - 1;
+            mo &= ~rest;
+            full = true;
+        }
+        if ((mo >> lane) & 1ull) W->win[n_win + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull))] = j;
+        if (mo) {
+            if (first < 0) first = base + __ffsll((long long)mo) - 1;
+            last = base + 63 - __clzll((long long)mo);
+        }
+        n_win += (uint32_t)__popcll(mo);
+        if (full) break;
+        if (ma) break;                                   // (next stays n_tx: every read lies before what follows)
+    }
+    // the members' headers (the wave's own LDS writes above are visible to it: same wave, in order)
+    bool single = false, loose = false;
+    if (lane < (int)n_win) {
+        const int j = W->win[lane];
+        const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);
+        const int4 h0 = hp[0], h1 = hp[1], h2 = hp[2];
+        int st = h0.y, en = h0.z;
+        if (h0.x < tid0) { st = INT32_MIN; en = INT32_MIN; }            // another chromosome: before / after every read
+        else if (h0.x > tid0) { st = INT32_MAX; en = INT32_MAX; }
+        W->hk[lane] = make_int4(st, en, h1.x, (h1.z & 0xff) | (h1.y << 8));
+        W->hx[lane] = h2;
+        single = h1.x == 1; loose = !((h1.z & 0xff) & TX_COMPACT);
+    }
+    const unsigned long long b1 = __ballot(single), b2 = __ballot(loose);
+    if (lane == 0) {
+        W->d.n_win = n_win; W->d.j_lo = first < 0 ? scan_j : first;
+        W->d.flags = (n_win == 0u || (uint32_t)(last - first + 1) == n_win) ? TD_CONTIG : 0u;
+        W->mask[0] = b1; W->mask[1] = b2;
+    }
+    return next;
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(TILE_THREADS, 4)
+void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *__restrict__ u_tile_first, const int32_t *__restrict__ u_pos,
+                          const uint32_t *__restrict__ u_tile_sbase, const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase)
+{
+    constexpr int DIR_BYTES = FAST_DIR_BYTES;
+    constexpr uint32_t F_ALL = (uint32_t)(F_EXON | F_DON | F_ACC | F_JUNC);
+    __shared__ __attribute__((aligned(16))) uint32_t s_A[SLAB_POS_CAP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_L[SLAB_POS_CAP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_F[SLAB_POS_CAP];
+    __shared__ __attribute__((aligned(16))) WEnt s_ent[2 * WIDE_KEY_CAP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_dir[3 * DIR_BYTES];
+    __shared__ __attribute__((aligned(16))) TileWin64 s_tw;
+    __shared__ uint32_t s_next, s_lim;
+    __shared__ int s_scan;
+    (void)kernarg_block;
+    const SlabArgsK sa = slab_args();
+    const PipeArgsK a = pipe_args();
+    const int lane = threadIdx.x & (WAVE - 1);
+    WEnt *const s_ent0 = s_ent, *const s_ent1 = s_ent + WIDE_KEY_CAP;
+    uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
+    const uint32_t n_list = min(ca.count[0], (uint32_t)sa->n_tiles);
+    for (bool own = true;; own = false) {
+        if (own && blockIdx.x >= n_list) break;
+        if (threadIdx.x == 0) s_next = own ? blockIdx.x : gridDim.x + atomicAdd(ca.count + 1, 1u);
+        __syncthreads();
+        const uint32_t wi = s_next;
+        if (wi >= n_list) break;
+        const uint32_t t = ca.tile[wi];
+        const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
+        const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t], total = u_xbase[t + 1u] - xbase;
+        const int32_t tile_lo = u_pos[r0] + 1;
+        TileDesc d = u_tw[t].d;
+        const int32_t thi = (int32_t)u_tw[t].pad[1];            // the tile's last base (k_walk_slab)
+        // (the slices of the dictionaries are the tile's whatever the window: usable when they fit the staging)
+        const bool usable = d.nbk > 0 && d.st_nk <= (uint32_t)WIDE_KEY_CAP && d.en_nk <= (uint32_t)WIDE_KEY_CAP && a->f.p.ss_dis == 0;
+        d.flags = (d.flags & ~(TD_FAST | TD_WIDE)) | (usable ? TD_WIDE : 0u);       // (load_dict_slices loads for TD_FAST / TD_WIDE)
+        const bool active = threadIdx.x < n_act;
+        const uint32_t at = r0 + (active ? threadIdx.x : 0u);
+        uint32_t pre = 0u, loc = 0u;
+        const uint32_t *const xw = sa->slab_row;
+        const uint32_t off = sbase + threadIdx.x;
+        SlabRows q;
+        q.last = SlabRow{0u};
+#pragma unroll
+        for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = SlabRow{0u};
+        if (active) { pre = ld32(sa->pre, at); loc = ld32(sa->loc, at); q.last = slab_load_row(xw, off); }
+        const uint32_t n = pre >> PRE_N_SHIFT;
+        const uint32_t r = r0 + (pre & 0xffu);
+        const bool outlier = (pre & PRE_DENSE) != 0u, rev_in = (pre & PRE_REV) != 0u;
+        if (threadIdx.x == 0) { s_lim = min(total, (uint32_t)SLAB_POS_CAP); s_scan = d.j_lo; }
+        __syncthreads();
+        const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
+        const SlabStage st{s_A, s_L, loc, tile_lo, active && loc + n <= (uint32_t)SLAB_POS_CAP && !(pre & (PRE_DENSE | PRE_FAR))};
+        if (active && loc + n > (uint32_t)SLAB_POS_CAP) atomicMin(&s_lim, loc);
+        // ---- the tile's exons to their positions (a read that is not staged: straight into the result arrays)
+        if (active) slab_copy_exons(sa, a, out, st, q, off, n, pre, r);
+        uint32_t *const Ap = s_A + loc; const uint16_t *const Lp = s_L + loc; uint8_t *const Fp = s_F + loc;
+        bool redo = active && (!usable || outlier || !st.fits || (n > 1 && (pre & PRE_INSANE) != 0u));
+        const bool work0 = active && !redo;
+        ReadEnds re{0, 0, 0, 0};
+        if (work0) {
+            re.s0 = tile_lo + (int)(Ap[0] & SLAB_REL_MASK); re.e0 = re.s0 + (int)Lp[0] - 1;
+            re.sl = tile_lo + (int)(Ap[n - 1u] & SLAB_REL_MASK); re.el = re.sl + (int)Lp[n - 1u] - 1;
+            for (uint32_t k = 0; k < n; ++k) Fp[k] = (uint8_t)F_ALL;
+        }
+        // ---- the sweep's state, carried from chunk to chunk
+        bool known = false, stopped = false, ksite = false, lfull = false, rfull = false, lnoth = true, rnoth = true, out_rev = rev_in;
+        int ref = -1;
+        const WideLds L{s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
+        while (usable) {
+            if (threadIdx.x < (uint32_t)WAVE) {
+                const int nx = chunk_window(a, lane, d.tid, tile_lo, thi, s_scan, &s_tw);
+                if (lane == 0) s_scan = nx;
+            }
+            __syncthreads();
+            const int scan_next = s_scan;
+            const int w_n = (int)s_tw.d.n_win;
+            TileDesc dc = d;
+            dc.j_lo = s_tw.d.j_lo; dc.n_win = (uint32_t)w_n; dc.flags = (d.flags & ~TD_CONTIG) | (s_tw.d.flags & TD_CONTIG);
+            // ---- stage the dictionary slices, masks re-based to the chunk
+            const DictRegs dv = load_dict_slices(a, dc);
+            int my_wide = 0;
+            if ((int)threadIdx.x < WIDE_KEY_CAP) {
+                const bool has_st = threadIdx.x < d.st_nk, has_en = threadIdx.x < d.en_nk;
+                WEnt e0, e1;
+                e0.k1 = dv.xa.x; e0.k2 = dv.xa.y; e1.k1 = dv.xc.x; e1.k2 = dv.xc.y;
+                const m64_t pm0 = ((m64_t)(uint32_t)dv.xb.y << 32) | (uint32_t)dv.xb.x, sm0 = ((m64_t)(uint32_t)dv.xb.w << 32) | (uint32_t)dv.xb.z;
+                const m64_t pm1 = ((m64_t)(uint32_t)dv.xd.y << 32) | (uint32_t)dv.xd.x, sm1 = ((m64_t)(uint32_t)dv.xd.w << 32) | (uint32_t)dv.xd.z;
+                if (dc.flags & TD_CONTIG) {
+                    e0.pm = rebase64(pm0, dv.xa.z - dc.j_lo); e0.sm = rebase64(sm0, dv.xa.z - dc.j_lo);
+                    e1.pm = rebase64(pm1, dv.xc.z - dc.j_lo); e1.sm = rebase64(sm1, dv.xc.z - dc.j_lo);
+                } else {
+                    m64_t mm[4] = {pm0, sm0, pm1, sm1};
+                    rebase_gaps64(s_tw.win, w_n, mm, dv.xa.z, dv.xc.z);
+                    e0.pm = mm[0]; e0.sm = mm[1]; e1.pm = mm[2]; e1.sm = mm[3];
+                }
+                if (has_st) { s_ent0[threadIdx.x] = e0; if (dv.xa.w & SE_WIDE) my_wide = 1; }
+                if (has_en) { s_ent1[threadIdx.x] = e1; if (dv.xc.w & SE_WIDE) my_wide = 1; }
+            }
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int i = (int)threadIdx.x + qq * TILE_THREADS;
+                if (i <= d.nbk) {
+                    s_dir0[i] = (uint8_t)(dv.dd[0][qq] - d.st_r0); s_dir1[i] = (uint8_t)(dv.dd[1][qq] - d.en_r0);
+                    s_rdir[i] = (uint8_t)(dv.dd[2][qq] - d.st_r0);
+                }
+            }
+            if (threadIdx.x >= 1u && threadIdx.x < 3u) { s_dir0[d.nbk + (int)threadIdx.x] = (uint8_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint8_t)d.en_nk; }
+            const int any_wide = __syncthreads_or(my_wide);
+            const bool bad = any_wide != 0 || scan_next < 0;            // (an entry the masks cannot say, a scan without end: the generic kernel)
+            redo = redo || (active && bad);
+            // ---- this chunk's part of the sweep
+            const bool work = work0 && !redo && !known && !stopped;
+            const ChunkVisit vm = visit_chunk64<LEVEL>(L, w_n, work, n, re, s_tw.mask);
+            redo = redo || vm.redo;
+            const bool mapping = work && !vm.redo && n > 1;
+            const SiteMasks64 sm = map_exons_lds64(L, dc, mapping, Ap, Lp, tile_lo, n, vm.vpre);
+            if (work && !vm.redo) {
+                int jstar = -1;
+                if (n > 1) {
+                    m64_t c = sm.kand & vm.vpre;
+                    while (c) {
+                        const int j = __ffsll((long long)c) - 1;
+                        c &= c - 1ull;
+                        const int4 hk = L.hk[j];
+                        if (hk.x <= re.e0 && re.sl <= hk.y) { jstar = j; break; }
+                    }
+                } else if (vm.k1mask) jstar = __ffsll((long long)vm.k1mask) - 1;
+                const bool known_c = jstar >= 0;
+                const m64_t upto = jstar >= 63 ? ~0ull : ((2ull << (known_c ? jstar : 0)) - 1ull);
+                const m64_t V = known_c ? (vm.vpre & upto) : vm.vpre;
+                const m64_t ks = (n > 1) ? (sm.kor & V) : 0ull;
+                ksite = ksite || (ks & ~(known_c ? (1ull << jstar) : 0ull)) != 0ull;
+                int jref = -1;
+                if (n > 1) { if (ks) jref = 63 - __clzll((long long)ks); }
+                else jref = jstar;
+                if (jref >= 0) { ref = L.win[jref]; out_rev = ((L.hk[jref].w >> 8) & 1) != 0; }     // :825-831 (a later chunk's member is a later transcript)
+                if (LEVEL >= 1 && LEVEL <= 4) { lfull = lfull || (vm.lmask & V) != 0ull; rfull = rfull || (vm.rmask & V) != 0ull; }
+                if (LEVEL == 3 || LEVEL == 4) {
+                    if (lnoth) {
+                        if (sm.dm_first & V) lnoth = false;
+                        else if (V) lnoth = (overlapping_exon_members64(L.rdir, L.dir0, L.ent0, dc.b_off, dc.nb, re.s0, re.e0) & V) == 0ull;
+                    }
+                    if (LEVEL == 3 && rnoth) {
+                        if (sm.am_last & V) rnoth = false;
+                        else if (V) rnoth = (overlapping_exon_members64(L.rdir, L.dir0, L.ent0, dc.b_off, dc.nb, re.sl, re.el) & V) == 0ull;
+                    }
+                }
+                if (n > 1) {
+                    const uint32_t lim = known_c ? (uint32_t)jstar : 62u;                   // (63 = no member)
+                    for (int k = 0; k < (int)n; ++k) {
+                        const uint32_t w = Ap[k] >> SLAB_REL_BITS;
+                        uint32_t clr = ((w & 63u) <= lim ? (uint32_t)F_EXON : 0u) | (((w >> 6) & 63u) <= lim ? (uint32_t)F_JUNC : 0u);
+                        if (!known_c) clr |= (((w >> 12) & 1u) ? (uint32_t)F_DON : 0u) | (((w >> 13) & 1u) ? (uint32_t)F_ACC : 0u);
+                        Fp[k] = (uint8_t)(Fp[k] & ~clr);
+                    }
+                }
+                known = known_c;
+                stopped = vm.stopped;
+            }
+            __syncthreads();                                    // (the next chunk overwrites the window and the staged entries)
+            if (scan_next < 0 || scan_next >= a->f.p.n_tx || w_n == 0) break;
+        }
+        // ---- verdicts; flag bytes into the staged positions
+        uint32_t info = n << 8;
+        if (work0 && !redo) {
+            if (n > 1) {
+                for (int k = 0; k < (int)n; ++k) {
+                    uint32_t f = Fp[k];
+                    if (known) f &= ~(uint32_t)(F_DON | F_ACC);                             // (every site of a known read is its transcript's)
+                    f &= (k + 1 == (int)n) ? (uint32_t)F_EXON : 0xffu;                      // the last exon has no junction behind it
+                    Ap[k] = (Ap[k] & SLAB_REL_MASK) | (f << SLAB_REL_BITS);
+                }
+            } else Ap[0] = (Ap[0] & SLAB_REL_MASK) | ((uint32_t)F_EXON << SLAB_REL_BITS);
+            if (known) info |= I_KNOWN;
+            if (ksite) info |= I_KSITE;
+            if (full_decision(LEVEL, lfull, lnoth, rfull, rnoth)) info |= I_FULL;
+            if (out_rev) info |= I_REV;
+            if (fast_args()->p.n_sj == 0 && (info & (I_FULL | I_KNOWN | I_KSITE)) == (I_FULL | I_KSITE)) info |= I_ACCEPT;
+        } else {
+            ref = -1;
+            if (work0) for (uint32_t k = 0; k < n; ++k) Ap[k] &= SLAB_REL_MASK;             // (flags 0: the generic kernel writes them)
+        }
+        redo = redo && active;
+        {
+            const unsigned long long m = __ballot(redo);
+            if (m) {
+                uint32_t pos_r = 0;
+                if (lane == 0) pos_r = atomicAdd(a->f.redo_count, (uint32_t)__popcll(m));
+                pos_r = __shfl(pos_r, 0, WAVE);
+                if (redo) a->f.redo[pos_r + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+            }
+        }
+        if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; a->f.ex_off[r] = out.dst; }
+        __syncthreads();
+        slab_write_out(SlabOut{out.start, out.end, out.flag, xbase}, s_A, s_L, tile_lo, s_lim);
+        __syncthreads();                                        // (the next entry of this workgroup overwrites the LDS image)
+    }
+}
+
+}  // namespace l2r

@@ -19,7 +19,7 @@
 #include "l2r_kernels.hip.h"
 #include "l2r_window.hip.h"
 #include "l2r_slab.hip.h"
-#include "l2r_wide.hip.h"
+#include "l2r_chunk.hip.h"
 #include "l2r_filter.hip.h"
 
 using namespace l2r;
@@ -74,7 +74,7 @@ struct l2r_ctx {
     DevBuf<int32_t> dense_start, dense_end;                 // slab pipeline: the outliers' dense area
     DevBuf<uint32_t> slab_row;                              //                the exon rows between its kernels (one word per exon)
     DevBuf<TileWin> tw;
-    DevBuf<TileWin64> tw64; DevBuf<uint32_t> wide_cnt, wide_tile; uint32_t wide_cap = 0;     // tiles with 33 .. 63 window members (l2r_wide.hip.h)
+    DevBuf<TileWin64> tw64; DevBuf<uint32_t> wide_cnt, wide_tile, chunk_cnt, chunk_tile; uint32_t wide_cap = 0;     // tiles with 33 .. 63 window members (l2r_wide.hip.h)
     DevBuf<unsigned long long> ovf_cursor;
     std::string anno_cache_dir;             // L2R_ANNO_CACHE / l2r_set_annotation_cache: where the annotation tables are kept between runs
     int anno_cache_state = 0;               // last l2r_set_annotation: 0 no cache, 1 built + stored, 2 read from the cache
@@ -223,7 +223,7 @@ void l2r_destroy(l2r_ctx *c)
     c->win_start.release(); c->sj_cursor.release();
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
-    c->tile_total.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_cnt.release(); c->wide_tile.release();
+    c->tile_total.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_cnt.release(); c->wide_tile.release(); c->chunk_cnt.release(); c->chunk_tile.release();
     c->slab_row.release(); c->dense_start.release(); c->dense_end.release(); c->s_pre.release(); c->s_loc.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -806,10 +806,10 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         if (total < 0x7ffffff0ULL && ovf < 0x7ffffff0ULL) {
             sbase[T] = (uint32_t)total;                     // (rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true;
-            c->wide_cap = (uint32_t)(2 * T + 8);            // (an isoform-rich annotation makes EVERY tile wide, a tile beyond 63 members takes up to eight entries, 2.4 KB each;
-                                                            //  a tile that finds the list full takes the generic kernel)
-            if (c->tw64.ensure(c->wide_cap) || c->wide_cnt.ensure(4) || c->wide_tile.ensure(c->wide_cap)) return -2;
+            c->wide_cap = (uint32_t)(T + 1);                // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB each)
+            if (c->tw64.ensure(c->wide_cap) || c->wide_cnt.ensure(4) || c->wide_tile.ensure(c->wide_cap) || c->chunk_cnt.ensure(2) || c->chunk_tile.ensure(T + 1)) return -2;
             HIP_TRY(hipMemsetAsync(c->wide_cnt.p, 0, 16, c->stream));
+            HIP_TRY(hipMemsetAsync(c->chunk_cnt.p, 0, 8, c->stream));
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) || c->tile_total.ensure(T + 2) ||
                 c->s_pre.ensure((size_t)N + 1) || c->s_loc.ensure((size_t)N + 1) ||
                 c->slab_row.ensure((size_t)total + 4) ||
@@ -954,7 +954,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         sa.pre = c->s_pre.p; sa.loc = c->s_loc.p; sa.tw = c->tw.p;
         sa.n_tiles = (uint32_t)c->n_tiles;
         const unsigned gx = 8u * (unsigned)std::max<int64_t>((c->n_tiles + 7) / 8, 1);      // (l2r_slab.hip.h xcd_tile; an empty upload still launches)
-        sa.wide_cnt = c->wide_cnt.p; sa.wide_tile = c->wide_tile.p; sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p; sa.wide_cap = c->wide_cap;      // (L2R_ABLATE bit 2: no 64-member windows)
+        sa.wide_cnt = c->wide_cnt.p; sa.wide_tile = c->wide_tile.p; sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p; sa.wide_cap = c->wide_cap;
+        sa.chunk_cnt = (c->ablate & 32) ? nullptr : c->chunk_cnt.p; sa.chunk_tile = c->chunk_tile.p;      // (L2R_ABLATE bit 5: no chunked windows)      // (L2R_ABLATE bit 2: no 64-member windows)
         if (p.min_exon >= 1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_slab<false>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p,
                                (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
@@ -992,6 +993,21 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             default: launch_wide_level(0); break;
             }
 #undef launch_wide_level
+        }
+        if (sa.chunk_cnt) {   // the tiles without a window record (k_probe_slab's list: empty on most inputs)
+            const ChunkArgs ca{c->chunk_cnt.p, c->chunk_tile.p};
+            const unsigned gc = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 4);
+#define launch_chunk_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_chunked<L>), dim3(gc), dim3(TILE_THREADS), 0, s, sa, ca, (const uint32_t *)c->tile_first.p, \
+                (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_total.p)
+            switch (p.full_level) {
+            case 1: launch_chunk_level(1); break;
+            case 2: launch_chunk_level(2); break;
+            case 3: launch_chunk_level(3); break;
+            case 4: launch_chunk_level(4); break;
+            case 5: launch_chunk_level(5); break;
+            default: launch_chunk_level(0); break;
+            }
+#undef launch_chunk_level
         }
         // every tile's accepted reads are compacted by k_gather_accepted (nothing is fused into the classification here)
         if (c->want & L2R_WANT_ACCEPTED) HIP_TRY(hipMemsetAsync(c->tile_chunk.p, 0xff, (size_t)(c->n_tiles + 1) * 4, s));

@@ -53,16 +53,6 @@ constexpr int PRE_N_SHIFT = 12;
 // the first and the last needs an op of its own next to its cut (src/bam2gtf.c:31-78), so n <= (c + 3) / 2.  With -e < 1 the walk
 // itself watches the rows (k_walk_slab<true>).
 __host__ __device__ __forceinline__ uint32_t slab_rows_of(uint32_t c) { return (c + 3u) >> 1; }
-// Parts of a tile (k_walk_slab: a tile whose window is too wide gets windows per part): level l cuts the tile's n reads, in read
-// order, into 2^l parts, part i = reads [n i >> l, n (i + 1) >> l); code 0 = the whole tile, 1 .. 2 halves, 3 .. 6 quarters, 7 .. 14 eighths
-constexpr int SLAB_PART_LEVELS = 3;
-constexpr uint32_t SLAB_PART_NONE = 0xffffffffu;         // a list entry nobody needs
-__device__ __forceinline__ uint32_t slab_part_code(uint32_t level, uint32_t i) { return (1u << level) - 1u + i; }
-__device__ __forceinline__ void slab_part_range(uint32_t code, uint32_t n, uint32_t &i0, uint32_t &i1)
-{
-    const uint32_t level = code >= 7u ? 3u : (code >= 3u ? 2u : (code >= 1u ? 1u : 0u)), i = code - ((1u << level) - 1u);
-    i0 = (n * i) >> level; i1 = (n * (i + 1u)) >> level;
-}
 // row of exon j of a read with n exons (the last exon in row 0)
 __device__ __forceinline__ uint32_t slab_row(uint32_t j, uint32_t n) { return j + 1u < n ? j + 1u : 0u; }
 
@@ -77,6 +67,8 @@ struct SlabArgs {
     // tiles whose window holds 33 .. 63 transcripts (l2r_wide.hip.h): wide_cnt[0] counts the appends of k_walk_slab, k_probe_slab
     // moves the count to wide_cnt[1] (what k_probe_slab_wide reads) and clears [0] for the next run
     uint32_t *wide_cnt; uint32_t *wide_tile; TileWin64 *tw64; uint32_t wide_cap;
+    // tiles without a window record (l2r_chunk.hip.h): k_probe_slab appends them, chunk_cnt[0] = entries, [1] = k_probe_slab_chunked's work cursor
+    uint32_t *chunk_cnt; uint32_t *chunk_tile;
     uint32_t n_tiles;
 };
 typedef const __attribute__((address_space(4))) SlabArgs *SlabArgsK;
@@ -116,7 +108,6 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     __shared__ uint32_t s_x0[TILE_THREADS], s_x1[TILE_THREADS], s_x2[TILE_THREADS];       // the records' fields, slot order
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[TILE_THREADS], s_loc[TILE_THREADS];      // exon counts / their exclusive scan, READ order
     __shared__ int s_wmax[TILE_THREADS / WAVE];
-    __shared__ int s_el[TILE_THREADS], s_rpos[TILE_THREADS];      // every read's last base and position, by read index (for the windows of PARTS of the tile)
     __shared__ uint32_t s_wn[TILE_THREADS / WAVE];
     __shared__ __attribute__((aligned(16))) TileWin s_tw;
     __shared__ __attribute__((aligned(16))) TileWin64 s_tw64;
@@ -250,13 +241,13 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     s_cnt[idx] = active ? n : 0u;                        // (every entry is written: idx is a permutation of 0 .. 255)
     const int m = wave_max(active ? el : INT32_MIN);
     const int wn = wave_max((active && !outlier) ? (int)n : 0);
-    s_el[idx] = active ? el : INT32_MIN; s_rpos[idx] = pos;
     if (lane == 0) { s_wmax[wv] = m; s_wn[wv] = (uint32_t)min(wn, 255); }
     if (t == 0u && threadIdx.x == 0) {
         // the run's counters (this kernel is the first of a run): redo list, chunk cursor of the accepted list.
         // (The cursor of the outlier area is cleared by k_probe_slab for the next run.)
         uint32_t *const cnt = a->f.redo_count;
         cnt[0] = 0u; cnt[1] = 0u; cnt[2] = 0u;
+        if (sa->chunk_cnt) { sa->chunk_cnt[0] = 0u; sa->chunk_cnt[1] = 0u; }
     }
     __syncthreads();
     // ---- every read's place among the tile's exons in READ order: each wave scans the 256 counts (four per lane) for itself
@@ -276,8 +267,8 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     // ---- the tile's descriptor and window, by the last wave alone (the others are done): nobody waits for its load chain
     if (wv != TILE_THREADS / WAVE - 1) return;
     if (lane == 0) a->tile_total[t] = total;             // (one word per tile, scanned by k_scan_u32: a single counter would serialise 156 k waves)
-    make_descriptor(a, lane, tid0, pos0 + 1, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), true, &s_tw, (uint32_t)SLAB_KEY_CAP,
-                    sa->tw64 ? &s_tw64 : nullptr);
+    const int32_t tile_hi = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    make_descriptor(a, lane, tid0, pos0 + 1, tile_hi, true, &s_tw, (uint32_t)SLAB_KEY_CAP, sa->tw64 ? &s_tw64 : nullptr);
     if (s_tw.d.flags & TD_WIDE) {
         // a window of 33 .. 63 members: the tile joins the list of k_probe_slab_wide, its 64-member record goes along
         uint32_t at = 0;
@@ -290,41 +281,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
             s_tw.d.flags = (s_tw.d.flags & ~(TD_WIDE | (7u << 8))) | (4u << 8);     // list full: the tile takes the generic kernel ("window > 32")
         }
     }
-    else if (sa->tw64 && (s_tw.d.flags & (TD_FAST | TD_WIDE)) == 0u && ((s_tw.d.flags >> 8) & 7u) == 4u && n_act >= (1u << SLAB_PART_LEVELS)) {
-        // A window beyond 63 members: typically the tile straddles loci with many isoforms.  Its reads are in coordinate order, so a
-        // HALF of them (read order) sees about one locus: a window of its own per half; per quarter where a half's is still too
-        // wide, per eighth where a quarter's is.  Every part goes on the list of k_probe_slab_wide (entry = tile | part code << 28,
-        // slab_part_code); an eighth whose window is still too wide is sent to the generic kernel from there.
-        // (the tile's entries are reserved at once, eight of them: a tile that finds the list full stays whole and takes the generic
-        //  kernel; entries it does not need are marked empty)
-        uint32_t base = 0, used = 0;
-        if (lane == 0) base = atomicAdd(sa->wide_cnt, 1u << SLAB_PART_LEVELS);
-        base = __shfl(base, 0, WAVE);
-        const bool listed = base + (1u << SLAB_PART_LEVELS) <= sa->wide_cap;
-        auto part = [&](uint32_t level, uint32_t i) {
-            const uint32_t i0 = (n_act * i) >> level, i1 = (n_act * (i + 1u)) >> level;
-            int e = INT32_MIN;
-            for (uint32_t j = i0 + (uint32_t)lane; j < i1; j += WAVE) e = max(e, s_el[j]);
-            // (the part's first read has its smallest start)
-            make_descriptor(a, lane, tid0, s_rpos[i0] + 1, wave_max(e), true, &s_tw, (uint32_t)SLAB_KEY_CAP, &s_tw64, true);
-            if (!(s_tw64.d.flags & TD_WIDE) && level < (uint32_t)SLAB_PART_LEVELS) return false;
-            const uint32_t at = base + used++;
-            if (lane == 0) sa->wide_tile[at] = t | (slab_part_code(level, i) << 28);
-            for (int v = lane; v < (int)(sizeof(TileWin64) / 16); v += WAVE) reinterpret_cast<int4 *>(sa->tw64 + at)[v] = reinterpret_cast<const int4 *>(&s_tw64)[v];
-            return true;
-        };
-        if (listed) {
-            for (uint32_t h = 0; h < 2u; ++h) {
-                if (part(1u, h)) continue;
-                for (uint32_t q = 2u * h; q < 2u * h + 2u; ++q) {
-                    if (part(2u, q)) continue;
-                    part(3u, 2u * q); part(3u, 2u * q + 1u);
-                }
-            }
-            if (lane == 0) s_tw.d.flags = TD_WIDE | (4u << 8);              // (k_probe_slab leaves the tile alone)
-        }
-        if (lane + (int)used < (1 << SLAB_PART_LEVELS) && base + used + (uint32_t)lane < sa->wide_cap) sa->wide_tile[base + used + (uint32_t)lane] = SLAB_PART_NONE;
-    }
+    if (lane == 0) s_tw.pad[1] = (uint32_t)tile_hi;          // the tile's last base (k_probe_slab_chunked scans the window itself)
     if (lane == 0) s_tw.pad[0] = s_wn[0] | (s_wn[1] << 8) | (s_wn[2] << 16) | (s_wn[3] << 24);     // rows each wave of k_probe_slab has to look at
     {   const uint32_t n_win = (s_tw.d.flags & TD_FAST) ? s_tw.d.n_win : 0u;
         for (int i = lane; i < SLAB_TW_VECS; i += WAVE) if (tw_vec_used(i, n_win)) reinterpret_cast<int4 *>(sa->tw + t)[i] = reinterpret_cast<const int4 *>(&s_tw)[i]; }
@@ -640,10 +597,16 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     //      (k_walk_slab), the slot's words and rows 0 .. 4 of its column (the last exon and the first four) -- all asked for
     //      before anything is looked at, and nothing of it at an address that depends on another load
     const TileDesc d = u_tw[t].d;
-    if (t == 0u && threadIdx.x == 0 && sa->wide_cnt) {          // (k_walk_slab is done: its count of wide tiles moves on, the counter is cleared for the next run)
-        sa->wide_cnt[1] = min(sa->wide_cnt[0], sa->wide_cap); sa->wide_cnt[0] = 0u; sa->wide_cnt[2] = 0u;      // ([2]: k_probe_slab_wide's work cursor)
+    if (t == 0u && threadIdx.x == 0) {                           // (k_walk_slab is done: its count of wide tiles moves on, its counters are cleared for the next run)
+        if (sa->wide_cnt) { sa->wide_cnt[1] = min(sa->wide_cnt[0], sa->wide_cap); sa->wide_cnt[0] = 0u; sa->wide_cnt[2] = 0u; }      // ([2]: k_probe_slab_wide's work cursor)
+        *sa->ovf_cursor = 0ull;                                  // (the outlier area's)
     }
     if (d.flags & TD_WIDE) return;                               // k_probe_slab_wide takes the tile
+    if (sa->chunk_cnt && (d.flags & (TD_FAST | TD_WIDE)) == 0u && ((d.flags >> 8) & 7u) == 4u) {
+        // no window record fits the tile's window: k_probe_slab_chunked takes it, 63 members at a time
+        if (threadIdx.x == 0) sa->chunk_tile[atomicAdd(sa->chunk_cnt, 1u)] = t;
+        return;
+    }
     // the rows any read of this wave has (k_walk_slab): rows behind them are not asked for
     // thread -> slot: the slot groups (k_walk_slab: by falling CIGAR length, group 0 = the tile's longest reads) are rotated over
     // the waves by a hash of the tile number (L2R_ABLATE bit 3: off)
@@ -668,7 +631,7 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
 #pragma unroll
         for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = slab_load_row(xw, off + min((uint32_t)i + 1u, row_max) * SLAB_STRIDE);      // (an outlier's column holds nothing: read, not used)
     }
-    if (threadIdx.x == 0) { s_lim = min(total, (uint32_t)SLAB_POS_CAP); if (t == 0u) *sa->ovf_cursor = 0ull; }     // (k_walk_slab is done with the outlier area)
+    if (threadIdx.x == 0) s_lim = min(total, (uint32_t)SLAB_POS_CAP);
     const uint32_t n = pre >> PRE_N_SHIFT;
     const uint32_t r = r0 + (pre & 0xffu);
     const SlabRow first = n == 1u ? q.last : q.x[0];

@@ -4,8 +4,8 @@
 // meet more than 32 annotation transcripts (a locus with many isoforms) went to the redo list, i.e. to k_classify_generic at
 // about 1/70 of the speed.  This file is the same formulation on 64-bit masks, for those tiles only:
 // k_walk_slab's last wave builds a 64-member window record (TileWin64) for them and appends the tile to a list;
-// k_probe_slab skips them; k_probe_slab_wide<LEVEL>, a persistent grid, walks over the list.  A tile beyond that gets one
-// such window per half / quarter of its reads (k_walk_slab), parts whose window is still too wide take the generic kernel.
+// k_probe_slab skips them; k_probe_slab_wide<LEVEL>, a persistent grid, walks over the list.  A tile beyond 63 members has no
+// window record at all: k_probe_slab_chunked (l2r_chunk.hip.h) takes its window 63 members at a time.
 // With an isoform-rich annotation this is the kernel that classifies most reads, so it works like k_probe_slab: rows of the
 // slab four exons ahead, exons + work words + flags staged at their positions in LDS, one coalesced write-out per entry.
 //
@@ -249,7 +249,7 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
     __shared__ __attribute__((aligned(16))) WEnt s_ent[2 * WIDE_KEY_CAP];
     __shared__ __attribute__((aligned(16))) uint8_t s_dir[3 * DIR_BYTES];
     __shared__ __attribute__((aligned(16))) TileWin64 s_tw;
-    __shared__ uint32_t s_next, s_lim, s_p0, s_p1;
+    __shared__ uint32_t s_next, s_lim;
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
@@ -258,26 +258,19 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
     const uint32_t n_wide = *wa.wide_count;
     for (bool own = true;; own = false) {
-        // (the entries differ a lot in cost -- a part whose window is still too wide only lists its reads for the generic kernel --
-        //  so the workgroups take them from a cursor, which k_probe_slab cleared; a workgroup's FIRST entry is its own number: an
+        // (the workgroups take the entries from a cursor, which k_probe_slab cleared; a workgroup's FIRST entry is its own number: an
         //  empty list costs no atomic)
         if (own && blockIdx.x >= n_wide) break;
         if (threadIdx.x == 0) s_next = own ? blockIdx.x : gridDim.x + atomicAdd(wa.wide_count + 1, 1u);
         __syncthreads();
         const uint32_t wi = s_next;
         if (wi >= n_wide) break;
-        // entry = tile | part code << 28 (slab_part_code: the whole tile, or a half / quarter / eighth of it in read order)
-        const uint32_t entry = wa.wide_tile[wi];
-        if (entry == SLAB_PART_NONE) { __syncthreads(); continue; }      // (the barrier: nobody takes the next entry while a wave still reads s_next)
-        const uint32_t t = entry & 0x0fffffffu, part = entry >> 28;
+        const uint32_t t = wa.wide_tile[wi];
         const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
         const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t], total = u_xbase[t + 1u] - xbase;
         const int32_t tile_lo = u_pos[r0] + 1;                   // the base of the tile's row words
         for (int i = (int)threadIdx.x; i < WIDE_TW_VECS; i += TILE_THREADS)
             reinterpret_cast<int4 *>(&s_tw)[i] = reinterpret_cast<const int4 *>(wa.tw64 + wi)[i];
-        // the part's reads [i0, i1) in read order: their exons are the tile's positions [p0, p1)
-        uint32_t i0, i1;
-        slab_part_range(part, n_act, i0, i1);
         const uint32_t row_max = max((u_tw[t].pad[0] >> (8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))) & 0xffu, 1u) - 1u;
         bool active = threadIdx.x < n_act;
         const uint32_t at = r0 + (active ? threadIdx.x : 0u);
@@ -294,12 +287,7 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
 #pragma unroll
             for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = slab_load_row(xw, off + min((uint32_t)i + 1u, row_max) * SLAB_STRIDE);      // (an outlier's column holds nothing: read, not used)
         }
-        if (threadIdx.x == 0) { s_p0 = 0u; s_p1 = total; }
-        __syncthreads();
         const uint32_t idx = pre & 0xffu;
-        if (active && idx == i0) s_p0 = loc;                     // (i0 < n_act always; i1 == n_act: the tile's end)
-        if (active && idx == i1) s_p1 = loc;
-        active = active && idx >= i0 && idx < i1;               // (the other lanes belong to the tile's other entries)
         const uint32_t n = pre >> PRE_N_SHIFT;
         const uint32_t r = r0 + idx;
         const bool outlier = (pre & PRE_DENSE) != 0u, rev_in = (pre & PRE_REV) != 0u;
@@ -308,7 +296,6 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         __syncthreads();
         const TileDesc d = s_tw.d;
         const int w_n = (int)d.n_win;
-        const uint32_t p0 = s_p0, p1 = s_p1;
         // ---- stage the dictionary slices, masks re-based to the tile's window (64-bit)
         const DictRegs dv = load_dict_slices(a, d);
         int my_wide = 0;
@@ -342,13 +329,12 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         if (threadIdx.x < 3u && (threadIdx.x > 0u || d.nbk == 0)) {
             s_dir0[d.nbk + (int)threadIdx.x] = (uint8_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint8_t)d.en_nk;
         }
-        if (threadIdx.x == 0) s_lim = min(p1 - p0, (uint32_t)SLAB_POS_CAP);
+        if (threadIdx.x == 0) s_lim = min(total, (uint32_t)SLAB_POS_CAP);
         const int any_wide = __syncthreads_or(my_wide);
-        // the part's positions are staged from 0: a read is staged when its positions fit and its rows have the tile's base
-        const uint32_t ploc = loc - p0;
+        // a read is staged when its positions fit and its rows have the tile's base
         const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
-        const SlabStage st{s_A, s_L, ploc, tile_lo, active && ploc + n <= (uint32_t)SLAB_POS_CAP && !(pre & (PRE_DENSE | PRE_FAR))};
-        if (active && ploc + n > (uint32_t)SLAB_POS_CAP) atomicMin(&s_lim, ploc);
+        const SlabStage st{s_A, s_L, loc, tile_lo, active && loc + n <= (uint32_t)SLAB_POS_CAP && !(pre & (PRE_DENSE | PRE_FAR))};
+        if (active && loc + n > (uint32_t)SLAB_POS_CAP) atomicMin(&s_lim, loc);
         // ---- classification
         uint32_t info = n << 8; int ref = -1;
         bool redo = active && (!(d.flags & TD_WIDE) || outlier || !st.fits || any_wide != 0 || (n > 1 && (pre & PRE_INSANE) != 0u));
@@ -360,7 +346,7 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         const SiteMasks64 sm = map_exons_slab64(L, d, mapping, xw, off, n, vm.vpre, q, st);
         if (active && !mapping) slab_copy_exons(sa, a, out, st, q, off, n, pre, r);
         if (work && !redo) {
-            uint32_t *const Ap = s_A + ploc;
+            uint32_t *const Ap = s_A + loc;
             const Verdict vd = decide64<LEVEL>(L, d, n, re, vm, sm, rev_in, [&](int k) { return Ap[k] >> SLAB_REL_BITS; },
                                                [&](int k, uint32_t f) { Ap[k] = (Ap[k] & SLAB_REL_MASK) | (f << SLAB_REL_BITS); });
             info = vd.info; ref = vd.ref;
@@ -377,7 +363,7 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         }
         if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; a->f.ex_off[r] = out.dst; }
         __syncthreads();
-        slab_write_out(SlabOut{out.start, out.end, out.flag, xbase + p0}, s_A, s_L, tile_lo, s_lim);
+        slab_write_out(SlabOut{out.start, out.end, out.flag, xbase}, s_A, s_L, tile_lo, s_lim);
         __syncthreads();                                        // (the next entry of this workgroup overwrites the LDS image)
     }
 }
