@@ -14,21 +14,26 @@
 //               than the break)
 //
 // The tile's exons are copied from the slab to their positions in LDS once; the probe rounds of every chunk read them there.
-// Entries: k_probe_slab appends the tiles it finds without a window ("window > 32" after k_walk_slab tried 64-bit records for the
-// tile and its parts) -- see l2r_slab.hip.h.  Same results as the one-window kernels, which the parity suites check.
+// Entries: k_probe_slab appends the tiles it finds without a window ("window > 32" after k_walk_slab tried a 64-bit record), and it
+// and k_probe_slab_wide the tiles whose dictionary slices hold a key in several entries (SE_WIDE: the key's transcripts lie more
+// than 64 apart in the annotation, l2r_engine.hip build_dict) -- the probes here OR the parts of a key, each re-based to the chunk.
+// Up to CHUNK_KEY_CAP entries per dictionary are staged (16-bit directories); a tile beyond that takes the generic kernel.
+// Same results as the one-window kernels, which the parity suites check.
 #pragma once
 #include "l2r_wide.hip.h"
 
 namespace l2r {
 
 struct ChunkArgs { uint32_t *count; const uint32_t *tile; };        // count[0]: entries, count[1]: the grid's work cursor
+constexpr int CHUNK_KEY_CAP = 384;                                  // dictionary entries staged per dictionary and tile (40 KB of LDS per workgroup: 4 per CU)
+struct ChunkLds { const WEnt *ent0, *ent1; const uint16_t *dir0, *dir1, *rdir; const int4 *hk, *hx; const int *win; };
 constexpr int CHUNK_SCAN_TRIPS = 4096;                              // 64-transcript trips one chunk's scan may take (then: generic kernel)
 
 struct ChunkVisit { m64_t vpre, lmask, rmask, k1mask; bool redo, stopped; };
 
 // visit_window64 on one chunk; `stopped`: a member of the chunk lies behind the read (src/update_gtf.c:799-800 ends the sweep)
 template <int LEVEL>
-__device__ __forceinline__ ChunkVisit visit_chunk64(const WideLds &L, int w_n, bool work, uint32_t n, const ReadEnds &re, const m64_t *tilemask)
+__device__ __forceinline__ ChunkVisit visit_chunk64(const ChunkLds &L, int w_n, bool work, uint32_t n, const ReadEnds &re, const m64_t *tilemask)
 {
     ChunkVisit m{0ull, 0ull, 0ull, 0ull, false, false};
     m64_t m_aft = 0ull, m_bef = 0ull;
@@ -66,9 +71,19 @@ __device__ __forceinline__ ChunkVisit visit_chunk64(const WideLds &L, int w_n, b
     return m;
 }
 
+// probe_all64 for keys in several entries: the parts' masks are ORed
+__device__ __forceinline__ void probe_parts64(const WEnt *ent, uint32_t lo, uint32_t hi, int32_t k1, int32_t k2, m64_t &pm, m64_t &sm)
+{
+    pm = 0ull; sm = 0ull;
+    for (uint32_t r = lo; r < hi; ++r) {
+        const WEnt q = ent[r];
+        if (q.k1 == k1) { sm |= q.sm; if (q.k2 == k2) pm |= q.pm; }
+    }
+}
+
 // map_exons_slab64 with the read's exons at their staged positions in LDS (A: start relative to the tile's base, L: length); the
 // chunk's work word goes into the upper bits of A
-__device__ __forceinline__ SiteMasks64 map_exons_lds64(const WideLds &L, const TileDesc &d, bool mapping, uint32_t *Ap, const uint16_t *Lp,
+__device__ __forceinline__ SiteMasks64 map_exons_lds64(const ChunkLds &L, const TileDesc &d, bool mapping, uint32_t *Ap, const uint16_t *Lp,
                                                        int32_t lo, uint32_t n, m64_t vpre)
 {
     SiteMasks64 m{~0ull, 0ull, 0ull, 0ull};
@@ -84,8 +99,8 @@ __device__ __forceinline__ SiteMasks64 map_exons_lds64(const WideLds &L, const T
         const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
         const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
         m64_t xm, am, jm, dm;
-        probe_all64(L.ent0, ls, hs, s, e, xm, am);
-        probe_all64(L.ent1, le, he, e, s2, jm, dm);
+        probe_parts64(L.ent0, ls, hs, s, e, xm, am);
+        probe_parts64(L.ent1, le, he, e, s2, jm, dm);
         const m64_t amj = junc ? am : 0ull;
         uint32_t word = first_member64(xm & vpre);
         word |= first_member64(jm & vpre) << 6;
@@ -170,13 +185,13 @@ __global__ __launch_bounds__(TILE_THREADS, 4)
 void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *__restrict__ u_tile_first, const int32_t *__restrict__ u_pos,
                           const uint32_t *__restrict__ u_tile_sbase, const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase)
 {
-    constexpr int DIR_BYTES = FAST_DIR_BYTES;
+    constexpr int DIR_N = FAST_DIR_BYTES;                   // directory words per dictionary (16 bits each here)
     constexpr uint32_t F_ALL = (uint32_t)(F_EXON | F_DON | F_ACC | F_JUNC);
     __shared__ __attribute__((aligned(16))) uint32_t s_A[SLAB_POS_CAP];
     __shared__ __attribute__((aligned(16))) uint16_t s_L[SLAB_POS_CAP];
     __shared__ __attribute__((aligned(16))) uint8_t s_F[SLAB_POS_CAP];
-    __shared__ __attribute__((aligned(16))) WEnt s_ent[2 * WIDE_KEY_CAP];
-    __shared__ __attribute__((aligned(16))) uint8_t s_dir[3 * DIR_BYTES];
+    __shared__ __attribute__((aligned(16))) WEnt s_ent[2 * CHUNK_KEY_CAP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_dir[3 * DIR_N];
     __shared__ __attribute__((aligned(16))) TileWin64 s_tw;
     __shared__ uint32_t s_next, s_lim;
     __shared__ int s_scan;
@@ -184,8 +199,8 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
     const int lane = threadIdx.x & (WAVE - 1);
-    WEnt *const s_ent0 = s_ent, *const s_ent1 = s_ent + WIDE_KEY_CAP;
-    uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
+    WEnt *const s_ent0 = s_ent, *const s_ent1 = s_ent + CHUNK_KEY_CAP;
+    uint16_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_N, *const s_rdir = s_dir + 2 * DIR_N;
     const uint32_t n_list = min(ca.count[0], (uint32_t)sa->n_tiles);
     for (bool own = true;; own = false) {
         if (own && blockIdx.x >= n_list) break;
@@ -200,8 +215,7 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *
         TileDesc d = u_tw[t].d;
         const int32_t thi = (int32_t)u_tw[t].pad[1];            // the tile's last base (k_walk_slab)
         // (the slices of the dictionaries are the tile's whatever the window: usable when they fit the staging)
-        const bool usable = d.nbk > 0 && d.st_nk <= (uint32_t)WIDE_KEY_CAP && d.en_nk <= (uint32_t)WIDE_KEY_CAP && a->f.p.ss_dis == 0;
-        d.flags = (d.flags & ~(TD_FAST | TD_WIDE)) | (usable ? TD_WIDE : 0u);       // (load_dict_slices loads for TD_FAST / TD_WIDE)
+        const bool usable = d.nbk > 0 && d.st_nk <= (uint32_t)CHUNK_KEY_CAP && d.en_nk <= (uint32_t)CHUNK_KEY_CAP && a->f.p.ss_dis == 0;
         const bool active = threadIdx.x < n_act;
         const uint32_t at = r0 + (active ? threadIdx.x : 0u);
         uint32_t pre = 0u, loc = 0u;
@@ -234,7 +248,7 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *
         // ---- the sweep's state, carried from chunk to chunk
         bool known = false, stopped = false, ksite = false, lfull = false, rfull = false, lnoth = true, rnoth = true, out_rev = rev_in;
         int ref = -1;
-        const WideLds L{s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
+        const ChunkLds L{s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
         while (usable) {
             if (threadIdx.x < (uint32_t)WAVE) {
                 const int nx = chunk_window(a, lane, d.tid, tile_lo, thi, s_scan, &s_tw);
@@ -245,37 +259,35 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *
             const int w_n = (int)s_tw.d.n_win;
             TileDesc dc = d;
             dc.j_lo = s_tw.d.j_lo; dc.n_win = (uint32_t)w_n; dc.flags = (d.flags & ~TD_CONTIG) | (s_tw.d.flags & TD_CONTIG);
-            // ---- stage the dictionary slices, masks re-based to the chunk
-            const DictRegs dv = load_dict_slices(a, dc);
-            int my_wide = 0;
-            if ((int)threadIdx.x < WIDE_KEY_CAP) {
-                const bool has_st = threadIdx.x < d.st_nk, has_en = threadIdx.x < d.en_nk;
+            // ---- stage the dictionary slices, masks re-based to the chunk (the slices come out of L2 again for every chunk)
+            for (uint32_t i = threadIdx.x; i < max(d.st_nk, d.en_nk); i += (uint32_t)TILE_THREADS) {
+                const bool has_st = i < d.st_nk, has_en = i < d.en_nk;
+                int4 xa = make_int4(0, 0, 0, 0), xb = xa, xc = xa, xd = xa;
+                if (has_st) { const int4 *qv = reinterpret_cast<const int4 *>(a->f.st.ent + d.st_r0 + i); xa = qv[0]; xb = qv[1]; }
+                if (has_en) { const int4 *qv = reinterpret_cast<const int4 *>(a->f.en.ent + d.en_r0 + i); xc = qv[0]; xd = qv[1]; }
                 WEnt e0, e1;
-                e0.k1 = dv.xa.x; e0.k2 = dv.xa.y; e1.k1 = dv.xc.x; e1.k2 = dv.xc.y;
-                const m64_t pm0 = ((m64_t)(uint32_t)dv.xb.y << 32) | (uint32_t)dv.xb.x, sm0 = ((m64_t)(uint32_t)dv.xb.w << 32) | (uint32_t)dv.xb.z;
-                const m64_t pm1 = ((m64_t)(uint32_t)dv.xd.y << 32) | (uint32_t)dv.xd.x, sm1 = ((m64_t)(uint32_t)dv.xd.w << 32) | (uint32_t)dv.xd.z;
+                e0.k1 = xa.x; e0.k2 = xa.y; e1.k1 = xc.x; e1.k2 = xc.y;
+                const m64_t pm0 = ((m64_t)(uint32_t)xb.y << 32) | (uint32_t)xb.x, sm0 = ((m64_t)(uint32_t)xb.w << 32) | (uint32_t)xb.z;
+                const m64_t pm1 = ((m64_t)(uint32_t)xd.y << 32) | (uint32_t)xd.x, sm1 = ((m64_t)(uint32_t)xd.w << 32) | (uint32_t)xd.z;
                 if (dc.flags & TD_CONTIG) {
-                    e0.pm = rebase64(pm0, dv.xa.z - dc.j_lo); e0.sm = rebase64(sm0, dv.xa.z - dc.j_lo);
-                    e1.pm = rebase64(pm1, dv.xc.z - dc.j_lo); e1.sm = rebase64(sm1, dv.xc.z - dc.j_lo);
+                    e0.pm = rebase64(pm0, xa.z - dc.j_lo); e0.sm = rebase64(sm0, xa.z - dc.j_lo);
+                    e1.pm = rebase64(pm1, xc.z - dc.j_lo); e1.sm = rebase64(sm1, xc.z - dc.j_lo);
                 } else {
                     m64_t mm[4] = {pm0, sm0, pm1, sm1};
-                    rebase_gaps64(s_tw.win, w_n, mm, dv.xa.z, dv.xc.z);
+                    rebase_gaps64(s_tw.win, w_n, mm, xa.z, xc.z);
                     e0.pm = mm[0]; e0.sm = mm[1]; e1.pm = mm[2]; e1.sm = mm[3];
                 }
-                if (has_st) { s_ent0[threadIdx.x] = e0; if (dv.xa.w & SE_WIDE) my_wide = 1; }
-                if (has_en) { s_ent1[threadIdx.x] = e1; if (dv.xc.w & SE_WIDE) my_wide = 1; }
+                if (has_st) s_ent0[i] = e0;
+                if (has_en) s_ent1[i] = e1;
             }
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const int i = (int)threadIdx.x + qq * TILE_THREADS;
-                if (i <= d.nbk) {
-                    s_dir0[i] = (uint8_t)(dv.dd[0][qq] - d.st_r0); s_dir1[i] = (uint8_t)(dv.dd[1][qq] - d.en_r0);
-                    s_rdir[i] = (uint8_t)(dv.dd[2][qq] - d.st_r0);
-                }
+            for (int i = (int)threadIdx.x; i <= d.nbk; i += TILE_THREADS) {
+                const uint32_t b = (uint32_t)(d.b0 + i);
+                s_dir0[i] = (uint16_t)(ld32(a->f.st.dir, b) - d.st_r0); s_dir1[i] = (uint16_t)(ld32(a->f.en.dir, b) - d.en_r0);
+                s_rdir[i] = (uint16_t)(ld32(a->f.st.rdir, b) - d.st_r0);
             }
-            if (threadIdx.x >= 1u && threadIdx.x < 3u) { s_dir0[d.nbk + (int)threadIdx.x] = (uint8_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint8_t)d.en_nk; }
-            const int any_wide = __syncthreads_or(my_wide);
-            const bool bad = any_wide != 0 || scan_next < 0;            // (an entry the masks cannot say, a scan without end: the generic kernel)
+            if (threadIdx.x >= 1u && threadIdx.x < 3u) { s_dir0[d.nbk + (int)threadIdx.x] = (uint16_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint16_t)d.en_nk; }
+            __syncthreads();
+            const bool bad = scan_next < 0;                             // (a scan without end: the generic kernel)
             redo = redo || (active && bad);
             // ---- this chunk's part of the sweep
             const bool work = work0 && !redo && !known && !stopped;

@@ -282,7 +282,9 @@ struct AnnoTables {
 
 // Entries of one dictionary + its bucket directory.  `pairs`: sorted (tid, k1, k2, tx) rows of the pair kind
 // (exons for START, junctions for END); `singles`: sorted (tid, k1, 0, tx) rows of the single kind (acceptors /
-// donors).  An entry's masks are relative to the smallest member transcript of either kind.
+// donors).  An entry's masks are relative to its tx_base and say 64 transcripts; a key whose members (of either kind) lie further
+// apart gets SEVERAL entries in a row -- parts, same (k1, k2), rising tx_base, each flagged SE_WIDE: the 32- and 64-bit mask kernels
+// leave a tile with such an entry to k_probe_slab_chunked (slab pipeline; it ORs the parts) or to the generic kernel (classic).
 static void build_dict(const std::vector<SiteTx> &pairs, const std::vector<SiteTx> &singles, const std::vector<int32_t> &tid_base,
                        std::vector<SiteEnt> &ent, std::vector<uint32_t> &dir, std::vector<uint32_t> *rdir_out, int64_t &n_wide)
 {
@@ -290,6 +292,8 @@ static void build_dict(const std::vector<SiteTx> &pairs, const std::vector<SiteT
     dir.assign(nb + 1, 0);                                // dir[b] = number of entries whose bucket id is < b
     ent.clear();
     ent.reserve(pairs.size());
+    std::vector<uint32_t> parts;                          // entries per distinct pair (reach-back directory below)
+    parts.reserve(pairs.size());
     size_t si = 0;                                        // walks `singles` in step (both sorted by (tid, k1))
     for (size_t i = 0; i < pairs.size();) {
         size_t j = i;
@@ -298,23 +302,24 @@ static void build_dict(const std::vector<SiteTx> &pairs, const std::vector<SiteT
         while (si < singles.size() && (singles[si].tid < pairs[i].tid || (singles[si].tid == pairs[i].tid && singles[si].k1 < pairs[i].k1))) ++si;
         size_t sj = si;
         while (sj < singles.size() && singles[sj].tid == pairs[i].tid && singles[sj].k1 == pairs[i].k1) ++sj;
-        int32_t lo = pairs[i].tx;
-        if (sj > si) lo = std::min(lo, singles[si].tx);
-        SiteEnt e;
-        memset(&e, 0, sizeof e);
-        e.k1 = pairs[i].k1; e.k2 = pairs[i].k2; e.tx_base = lo;
-        for (size_t k = i; k < j; ++k) {
-            const int off = pairs[k].tx - lo;
-            if (off >= 64) e.flags |= SE_WIDE; else e.pm[off >> 5] |= 1u << (off & 31);
+        const size_t first_ent = ent.size();
+        size_t pk = i, sk = si;                            // (members of both kinds rise with tx)
+        while (pk < j || sk < sj) {
+            int32_t lo = INT32_MAX;
+            if (pk < j) lo = std::min(lo, pairs[pk].tx);
+            if (sk < sj) lo = std::min(lo, singles[sk].tx);
+            SiteEnt e;
+            memset(&e, 0, sizeof e);
+            e.k1 = pairs[i].k1; e.k2 = pairs[i].k2; e.tx_base = lo;
+            for (; pk < j && (int64_t)pairs[pk].tx - lo < 64; ++pk) { const int off = pairs[pk].tx - lo; e.pm[off >> 5] |= 1u << (off & 31); }
+            for (; sk < sj && (int64_t)singles[sk].tx - lo < 64; ++sk) { const int off = singles[sk].tx - lo; e.sm[off >> 5] |= 1u << (off & 31); }
+            ent.push_back(e);
         }
-        for (size_t k = si; k < sj; ++k) {
-            const int off = singles[k].tx - lo;
-            if (off >= 64) e.flags |= SE_WIDE; else e.sm[off >> 5] |= 1u << (off & 31);
-        }
-        if (e.flags & SE_WIDE) ++n_wide;
-        ent.push_back(e);
+        const uint32_t np = (uint32_t)(ent.size() - first_ent);
+        if (np > 1) { for (size_t q = first_ent; q < ent.size(); ++q) ent[q].flags |= SE_WIDE; ++n_wide; }
+        parts.push_back(np);
         const size_t b = (size_t)tid_base[(size_t)pairs[i].tid] + (size_t)(pairs[i].k1 >> SITE_SHIFT);
-        dir[b + 1]++;
+        dir[b + 1] += np;
         i = j;                                             // `si` stays: the next pair may share (tid, k1)
     }
     for (size_t b = 0; b < nb; ++b) dir[b + 1] += dir[b];
@@ -322,8 +327,8 @@ static void build_dict(const std::vector<SiteTx> &pairs, const std::vector<SiteT
         // reach-back directory (START: k1 = exon start, k2 = exon end): first entry whose exon reaches into the bucket
         std::vector<uint32_t> &rdir = *rdir_out;
         rdir = dir;
-        size_t i = 0;
-        for (size_t q = 0; q < pairs.size();) {           // entry i <-> the q-th distinct pair
+        size_t i = 0, u = 0;
+        for (size_t q = 0; q < pairs.size(); ++u) {       // entries [i, i + parts[u]) <-> the u-th distinct pair
             size_t j = q;
             while (j < pairs.size() && pairs[j].tid == pairs[q].tid && pairs[j].k1 == pairs[q].k1 && pairs[j].k2 == pairs[q].k2) ++j;
             const size_t t0 = (size_t)tid_base[(size_t)pairs[q].tid], nbt = (size_t)tid_base[(size_t)pairs[q].tid + 1] - t0;
@@ -331,7 +336,7 @@ static void build_dict(const std::vector<SiteTx> &pairs, const std::vector<SiteT
             size_t eb = pairs[q].k2 < 0 ? sb : (size_t)(pairs[q].k2 >> SITE_SHIFT);
             if (eb >= nbt) eb = nbt - 1;
             for (size_t b = sb + 1; b <= eb; ++b) if (rdir[t0 + b] > (uint32_t)i) rdir[t0 + b] = (uint32_t)i;
-            ++i; q = j;
+            i += parts[u]; q = j;
         }
     }
 }
@@ -496,7 +501,7 @@ static bool cache_load(const std::string &path, uint64_t hash, int64_t n_tx, int
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
     CacheHead hd;
-    bool ok = fread(&hd, sizeof hd, 1, f) == 1 && memcmp(hd.magic, "L2RANNO2", 8) == 0 && hd.hash == hash &&
+    bool ok = fread(&hd, sizeof hd, 1, f) == 1 && memcmp(hd.magic, "L2RANNO3", 8) == 0 && hd.hash == hash &&
               hd.n[0] == (uint64_t)n_tx && hd.n[1] == (uint64_t)n_tx && hd.n[2] == (uint64_t)n_tx && hd.n[3] == (uint64_t)n_exon;
     if (ok) {
         // the lengths must add up to the file's length before anything is allocated from them
@@ -530,7 +535,7 @@ static void cache_store(const std::string &path, uint64_t hash, const AnnoTables
     if (!f) return;                                        // a cache that cannot be written is no error
     CacheHead hd;
     memset(&hd, 0, sizeof hd);
-    memcpy(hd.magic, "L2RANNO2", 8); hd.hash = hash;
+    memcpy(hd.magic, "L2RANNO3", 8); hd.hash = hash;
     const uint64_t n[12] = {t.hdr.size(), t.key.size(), t.key_raw.size(), t.ex.size(), t.st_ent.size(), t.en_ent.size(), t.st_dir.size(),
                             t.st_rdir.size(), t.en_dir.size(), t.tid_base.size(), t.kb_base.size(), t.key_dir.size()};
     memcpy(hd.n, n, sizeof n);

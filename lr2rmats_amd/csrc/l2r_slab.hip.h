@@ -650,6 +650,11 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     }
     __syncthreads();
     const int any_wide = s_widew[0] | s_widew[1] | s_widew[2] | s_widew[3];
+    if (any_wide && sa->chunk_cnt) {
+        // a key of the staged slices has several entries (its transcripts lie more than 64 apart): k_probe_slab_chunked ORs them
+        if (threadIdx.x == 0) sa->chunk_tile[atomicAdd(sa->chunk_cnt, 1u)] = t;
+        return;
+    }
     // a read is staged when its positions fit and its rows have the tile's base
     const SlabStage st{s_A, s_L, loc, tile_lo, loc + n <= (uint32_t)SLAB_POS_CAP && !(pre & (PRE_DENSE | PRE_FAR))};
     // the first read that does not fit the staged positions ends the block that is written from LDS (reads are in read order there)

@@ -109,7 +109,8 @@ __device__ __forceinline__ void probe_all64(const WEnt *ent, uint32_t lo, uint32
     }
 }
 
-__device__ __forceinline__ m64_t overlapping_exon_members64(const uint8_t *rdir, const uint8_t *dir, const WEnt *ent, int b_off, int nb, int s, int e)
+template <typename DirT>
+__device__ __forceinline__ m64_t overlapping_exon_members64(const DirT *rdir, const DirT *dir, const WEnt *ent, int b_off, int nb, int s, int e)
 {
     const int bs = s >> SITE_SHIFT;
     if (bs >= nb) return 0ull;
@@ -331,6 +332,11 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         }
         if (threadIdx.x == 0) s_lim = min(total, (uint32_t)SLAB_POS_CAP);
         const int any_wide = __syncthreads_or(my_wide);
+        if (any_wide && sa->chunk_cnt) {                        // (a key with several entries: k_probe_slab_chunked ORs them)
+            if (threadIdx.x == 0) sa->chunk_tile[atomicAdd(sa->chunk_cnt, 1u)] = t;
+            __syncthreads();
+            continue;
+        }
         // a read is staged when its positions fit and its rows have the tile's base
         const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
         const SlabStage st{s_A, s_L, loc, tile_lo, active && loc + n <= (uint32_t)SLAB_POS_CAP && !(pre & (PRE_DENSE | PRE_FAR))};
