@@ -154,8 +154,9 @@ typedef struct {
  * pipeline the engine chose for the uploaded records (l2r_stage_kernel() names them):
  *     slab    (coordinate-sorted records, short CIGARs; default)  0 k_walk_slab (the tile's reads by CIGAR length, CIGAR -> exons,
  *             read-order places, tile descriptors)  1 k_scan_u32 (the tiles' exon counts -> their first result slots)  2 k_probe_slab
- *             (annotation window, site probes, verdicts, read-order results) + k_probe_slab_wide (tiles whose window holds 33 .. 64
- *             transcripts).  Every run launches all of them: nothing is kept from an earlier run of the same records.
+ *             (annotation window, site probes, verdicts, read-order results) + k_probe_slab_wide (tiles whose window holds 33 .. 63
+ *             transcripts) + k_probe_slab_chunked (tiles beyond that, or with a dictionary key in several entries: the window 63
+ *             members at a time).  Every run launches all of them: nothing is kept from an earlier run of the same records.
  *     classic (unsorted records, long CIGARs, L2R_PIPELINE=classic)  0 k_pass_a  1 k_scan_tiles  2 k_classify_fast */
 #define L2R_N_STAGES 8
 typedef struct {

@@ -278,7 +278,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
             if (lane == 0) sa->wide_tile[at] = t;
             for (int i = lane; i < (int)(sizeof(TileWin64) / 16); i += WAVE) reinterpret_cast<int4 *>(sa->tw64 + at)[i] = reinterpret_cast<const int4 *>(&s_tw64)[i];
         } else if (lane == 0) {
-            s_tw.d.flags = (s_tw.d.flags & ~(TD_WIDE | (7u << 8))) | (4u << 8);     // list full: the tile takes the generic kernel ("window > 32")
+            s_tw.d.flags = (s_tw.d.flags & ~(TD_WIDE | (7u << 8))) | (4u << 8);     // list full: the tile is treated like one without a window record ("window > 32")
         }
     }
     if (lane == 0) s_tw.pad[1] = (uint32_t)tile_hi;          // the tile's last base (k_probe_slab_chunked scans the window itself)

@@ -51,7 +51,7 @@ struct TileWin64 {
 // With W64 (slab pipeline): a window of 33 .. 63 members is collected into *W64 and the tile is flagged TD_WIDE instead of
 // TD_FAST (W then only carries the descriptor); up to 32 members everything is as without it.
 __device__ __forceinline__ void make_descriptor(PipeArgsK a, int lane, int32_t tid0, int32_t tlo, int32_t thi, bool in_lds, TileWin *W,
-                                                uint32_t key_cap = (uint32_t)PIPE_KEY_CAP, TileWin64 *W64 = nullptr, bool always_wide = false)
+                                                uint32_t key_cap = (uint32_t)PIPE_KEY_CAP, TileWin64 *W64 = nullptr)
 {
     const uint32_t win_cap = W64 ? (uint32_t)WIDE_MEMBERS : (uint32_t)WIN_TX;
     int *const win_out = W64 ? W64->win : W->win;
@@ -120,7 +120,7 @@ __device__ __forceinline__ void make_descriptor(PipeArgsK a, int lane, int32_t t
         d.en_r0 = ed_r0; d.en_nk = ed_r1 - ed_r0;
         if (fast && (d.st_nk > key_cap || d.en_nk > key_cap)) { fast = false; why = 3u; }
     }
-    const bool wide = fast && (d.n_win > (uint32_t)WIN_TX || (always_wide && W64));      // (only with W64; always_wide: the caller wants the 64-member record whatever the size)
+    const bool wide = fast && d.n_win > (uint32_t)WIN_TX;      // (only with W64)
     d.flags = (fast ? (wide ? TD_WIDE : TD_FAST) : 0u) | (contig ? TD_CONTIG : 0u) | (why << 8);
     if (wide) {
         // all 64 lanes: one member each
@@ -137,10 +137,9 @@ __device__ __forceinline__ void make_descriptor(PipeArgsK a, int lane, int32_t t
             single = h1.x == 1; loose = !((h1.z & 0xff) & TX_COMPACT);
         }
         const unsigned long long b1 = __ballot(single), b2 = __ballot(loose);
-        if (lane == 0) { W64->d = d; W64->mask[0] = b1; W64->mask[1] = b2; if (!always_wide) { W->d = d; W->mask[0] = 0u; W->mask[1] = 0u; } }
+        if (lane == 0) { W64->d = d; W64->mask[0] = b1; W64->mask[1] = b2; W->d = d; W->mask[0] = 0u; W->mask[1] = 0u; }
         return;
     }
-    if (always_wide && W64) { if (lane == 0) { W64->d = d; W64->mask[0] = 0ull; W64->mask[1] = 0ull; } return; }      // (not usable: the record only says so)
     if (W64 && lane < WIN_TX) W->win[lane] = W64->win[lane];                // (narrow after all: the members move to the 32-member record)
     // the members' headers (the wave's own LDS writes above are visible to it: same wave, in order)
     const int w_n = fast ? (int)d.n_win : 0;
