@@ -17,7 +17,9 @@
 // Entries: k_probe_slab appends the tiles it finds without a window ("window > 32" after k_walk_slab tried a 64-bit record), and it
 // and k_probe_slab_wide the tiles whose dictionary slices hold a key in several entries (SE_WIDE: the key's transcripts lie more
 // than 64 apart in the annotation, l2r_engine.hip build_dict) -- the probes here OR the parts of a key, each re-based to the chunk.
-// Up to CHUNK_KEY_CAP entries per dictionary are staged (16-bit directories); a tile beyond that takes the generic kernel.
+// Of a tile's dictionary slices a chunk stages only the entries that can say something about its 63 members (the others re-base to
+// nothing): a counting sort by bucket into up to CHUNK_KEY_CAP places per dictionary; a chunk beyond that sends the tile to the
+// generic kernel.
 // Same results as the one-window kernels, which the parity suites check.
 #pragma once
 #include "l2r_wide.hip.h"
@@ -25,8 +27,8 @@
 namespace l2r {
 
 struct ChunkArgs { uint32_t *count; const uint32_t *tile; };        // count[0]: entries, count[1]: the grid's work cursor
-constexpr int CHUNK_KEY_CAP = 384;                                  // dictionary entries staged per dictionary and tile (40 KB of LDS per workgroup: 4 per CU)
-struct ChunkLds { const WEnt *ent0, *ent1; const uint16_t *dir0, *dir1, *rdir; const int4 *hk, *hx; const int *win; };
+constexpr int CHUNK_KEY_CAP = 320;                                  // dictionary entries staged per dictionary and chunk (39.5 KB of LDS per workgroup: 4 per CU)
+struct ChunkLds { const WEnt *ent0, *ent1; const uint32_t *dir0, *dir1, *rdir; const int4 *hk, *hx; const int *win; };
 constexpr int CHUNK_SCAN_TRIPS = 4096;                              // 64-transcript trips one chunk's scan may take (then: generic kernel)
 
 struct ChunkVisit { m64_t vpre, lmask, rmask, k1mask; bool redo, stopped; };
@@ -117,9 +119,9 @@ __device__ __forceinline__ SiteMasks64 map_exons_lds64(const ChunkLds &L, const 
 }
 
 // The next chunk of the tile's window: the scan of make_descriptor (l2r_window.hip.h) from transcript scan_j on, for up to
-// WIDE_MEMBERS members; ONE WAVE.  Leaves members, headers and masks in *W (W->d: n_win, j_lo = first member, TD_CONTIG) and
+// max_members (<= WIDE_MEMBERS) members; ONE WAVE.  Leaves members, headers and masks in *W (W->d: n_win, j_lo = first member, TD_CONTIG) and
 // returns where the next chunk's scan begins (n_tx: the window is exhausted; -1: the scan took too long).
-__device__ __forceinline__ int chunk_window(PipeArgsK a, int lane, int32_t tid0, int32_t tlo, int32_t thi, int scan_j, TileWin64 *W)
+__device__ __forceinline__ int chunk_window(PipeArgsK a, int lane, int32_t tid0, int32_t tlo, int32_t thi, int scan_j, uint32_t max_members, TileWin64 *W)
 {
     const TxHdr *const hdr = a->f.hdr;
     const int32_t n_tx = a->f.p.n_tx;
@@ -139,7 +141,7 @@ __device__ __forceinline__ int chunk_window(PipeArgsK a, int lane, int32_t tid0,
         const unsigned long long ma = __ballot(aft);
         const int stop = ma ? __ffsll((long long)ma) - 1 : WAVE;
         unsigned long long mo = __ballot(ov) & (stop < WAVE ? (1ull << stop) - 1ull : ~0ull);
-        const uint32_t room = (uint32_t)WIDE_MEMBERS - n_win;
+        const uint32_t room = max_members - n_win;
         bool full = false;
         if ((uint32_t)__popcll(mo) > room) {
             // the chunk ends inside this trip: keep its first `room` members, the next chunk begins at the first one left out
@@ -185,13 +187,15 @@ __global__ __launch_bounds__(TILE_THREADS, 4)
 void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *__restrict__ u_tile_first, const int32_t *__restrict__ u_pos,
                           const uint32_t *__restrict__ u_tile_sbase, const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase)
 {
-    constexpr int DIR_N = FAST_DIR_BYTES;                   // directory words per dictionary (16 bits each here)
+    constexpr int DIR_N = FAST_DIR_BYTES;                   // directory words per dictionary (group 0 = the reach-back entries in front of the first bucket, bucket b = group b + 1, three closing words)
+    static_assert(DIR_N >= DIR_CAP + 4, "directory words");
     constexpr uint32_t F_ALL = (uint32_t)(F_EXON | F_DON | F_ACC | F_JUNC);
     __shared__ __attribute__((aligned(16))) uint32_t s_A[SLAB_POS_CAP];
     __shared__ __attribute__((aligned(16))) uint16_t s_L[SLAB_POS_CAP];
     __shared__ __attribute__((aligned(16))) uint8_t s_F[SLAB_POS_CAP];
     __shared__ __attribute__((aligned(16))) WEnt s_ent[2 * CHUNK_KEY_CAP];
-    __shared__ __attribute__((aligned(16))) uint16_t s_dir[3 * DIR_N];
+    __shared__ __attribute__((aligned(16))) uint32_t s_dir[3 * DIR_N];
+    __shared__ uint32_t s_kept[2];
     __shared__ __attribute__((aligned(16))) TileWin64 s_tw;
     __shared__ uint32_t s_next, s_lim;
     __shared__ int s_scan;
@@ -200,7 +204,7 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *
     const PipeArgsK a = pipe_args();
     const int lane = threadIdx.x & (WAVE - 1);
     WEnt *const s_ent0 = s_ent, *const s_ent1 = s_ent + CHUNK_KEY_CAP;
-    uint16_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_N, *const s_rdir = s_dir + 2 * DIR_N;
+    uint32_t *const X0 = s_dir, *const X1 = s_dir + DIR_N, *const XR = s_dir + 2 * DIR_N;
     const uint32_t n_list = min(ca.count[0], (uint32_t)sa->n_tiles);
     for (bool own = true;; own = false) {
         if (own && blockIdx.x >= n_list) break;
@@ -214,8 +218,8 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *
         const int32_t tile_lo = u_pos[r0] + 1;
         TileDesc d = u_tw[t].d;
         const int32_t thi = (int32_t)u_tw[t].pad[1];            // the tile's last base (k_walk_slab)
-        // (the slices of the dictionaries are the tile's whatever the window: usable when they fit the staging)
-        const bool usable = d.nbk > 0 && d.st_nk <= (uint32_t)CHUNK_KEY_CAP && d.en_nk <= (uint32_t)CHUNK_KEY_CAP && a->f.p.ss_dis == 0;
+        // (the slices of the dictionaries are the tile's whatever the window)
+        const bool usable = d.nbk > 0 && a->f.p.ss_dis == 0;
         const bool active = threadIdx.x < n_act;
         const uint32_t at = r0 + (active ? threadIdx.x : 0u);
         uint32_t pre = 0u, loc = 0u;
@@ -229,7 +233,7 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *
         const uint32_t n = pre >> PRE_N_SHIFT;
         const uint32_t r = r0 + (pre & 0xffu);
         const bool outlier = (pre & PRE_DENSE) != 0u, rev_in = (pre & PRE_REV) != 0u;
-        if (threadIdx.x == 0) { s_lim = min(total, (uint32_t)SLAB_POS_CAP); s_scan = d.j_lo; }
+        if (threadIdx.x == 0) s_lim = min(total, (uint32_t)SLAB_POS_CAP);
         __syncthreads();
         const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
         const SlabStage st{s_A, s_L, loc, tile_lo, active && loc + n <= (uint32_t)SLAB_POS_CAP && !(pre & (PRE_DENSE | PRE_FAR))};
@@ -248,10 +252,13 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *
         // ---- the sweep's state, carried from chunk to chunk
         bool known = false, stopped = false, ksite = false, lfull = false, rfull = false, lnoth = true, rnoth = true, out_rev = rev_in;
         int ref = -1;
-        const ChunkLds L{s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win};
+        const ChunkLds L{s_ent0, s_ent1, X0 + 1, X1 + 1, XR, s_tw.hk, s_tw.hx, s_tw.win};      // (dir[b] = first entry of bucket b = group b + 1)
+        // (members per chunk: halved, for the rest of the tile, when a chunk's members need more dictionary entries than are staged)
+        uint32_t chunk_members = (uint32_t)WIDE_MEMBERS;
+        int scan_from = d.j_lo;
         while (usable) {
             if (threadIdx.x < (uint32_t)WAVE) {
-                const int nx = chunk_window(a, lane, d.tid, tile_lo, thi, s_scan, &s_tw);
+                const int nx = chunk_window(a, lane, d.tid, tile_lo, thi, scan_from, chunk_members, &s_tw);
                 if (lane == 0) s_scan = nx;
             }
             __syncthreads();
@@ -259,36 +266,78 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *
             const int w_n = (int)s_tw.d.n_win;
             TileDesc dc = d;
             dc.j_lo = s_tw.d.j_lo; dc.n_win = (uint32_t)w_n; dc.flags = (d.flags & ~TD_CONTIG) | (s_tw.d.flags & TD_CONTIG);
-            // ---- stage the dictionary slices, masks re-based to the chunk (the slices come out of L2 again for every chunk)
-            for (uint32_t i = threadIdx.x; i < max(d.st_nk, d.en_nk); i += (uint32_t)TILE_THREADS) {
-                const bool has_st = i < d.st_nk, has_en = i < d.en_nk;
-                int4 xa = make_int4(0, 0, 0, 0), xb = xa, xc = xa, xd = xa;
-                if (has_st) { const int4 *qv = reinterpret_cast<const int4 *>(a->f.st.ent + d.st_r0 + i); xa = qv[0]; xb = qv[1]; }
-                if (has_en) { const int4 *qv = reinterpret_cast<const int4 *>(a->f.en.ent + d.en_r0 + i); xc = qv[0]; xd = qv[1]; }
-                WEnt e0, e1;
-                e0.k1 = xa.x; e0.k2 = xa.y; e1.k1 = xc.x; e1.k2 = xc.y;
-                const m64_t pm0 = ((m64_t)(uint32_t)xb.y << 32) | (uint32_t)xb.x, sm0 = ((m64_t)(uint32_t)xb.w << 32) | (uint32_t)xb.z;
-                const m64_t pm1 = ((m64_t)(uint32_t)xd.y << 32) | (uint32_t)xd.x, sm1 = ((m64_t)(uint32_t)xd.w << 32) | (uint32_t)xd.z;
-                if (dc.flags & TD_CONTIG) {
-                    e0.pm = rebase64(pm0, xa.z - dc.j_lo); e0.sm = rebase64(sm0, xa.z - dc.j_lo);
-                    e1.pm = rebase64(pm1, xc.z - dc.j_lo); e1.sm = rebase64(sm1, xc.z - dc.j_lo);
-                } else {
-                    m64_t mm[4] = {pm0, sm0, pm1, sm1};
-                    rebase_gaps64(s_tw.win, w_n, mm, xa.z, xc.z);
-                    e0.pm = mm[0]; e0.sm = mm[1]; e1.pm = mm[2]; e1.sm = mm[3];
-                }
-                if (has_st) s_ent0[i] = e0;
-                if (has_en) s_ent1[i] = e1;
-            }
-            for (int i = (int)threadIdx.x; i <= d.nbk; i += TILE_THREADS) {
-                const uint32_t b = (uint32_t)(d.b0 + i);
-                s_dir0[i] = (uint16_t)(ld32(a->f.st.dir, b) - d.st_r0); s_dir1[i] = (uint16_t)(ld32(a->f.en.dir, b) - d.en_r0);
-                s_rdir[i] = (uint16_t)(ld32(a->f.st.rdir, b) - d.st_r0);
-            }
-            if (threadIdx.x >= 1u && threadIdx.x < 3u) { s_dir0[d.nbk + (int)threadIdx.x] = (uint16_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint16_t)d.en_nk; }
+            // ---- stage the entries of the dictionary slices that can say something about this chunk's members, masks re-based to the
+            //      chunk: a counting sort by bucket (the order inside a bucket does not matter: the probes OR over it)
+            const int n_grp = d.nbk + 1;                                // groups 0 .. nbk
+            const int tx_lo = dc.j_lo, tx_hi = w_n > 0 ? s_tw.win[w_n - 1] : dc.j_lo - 1;
+            auto group_of = [&](int32_t k1) { return (uint32_t)(min(max((k1 >> SITE_SHIFT) + d.b_off, -1), d.nbk - 1) + 1); };
+            auto relevant = [&](int32_t tx_base) { return tx_base <= tx_hi && tx_base + 63 >= tx_lo; };
+            for (int i = (int)threadIdx.x; i < n_grp + 3; i += TILE_THREADS) { X0[i] = 0u; X1[i] = 0u; }
             __syncthreads();
-            const bool bad = scan_next < 0;                             // (a scan without end: the generic kernel)
+            for (uint32_t i = threadIdx.x; i < d.st_nk; i += (uint32_t)TILE_THREADS) {
+                const int4 xa = *reinterpret_cast<const int4 *>(a->f.st.ent + d.st_r0 + i);
+                if (relevant(xa.z)) atomicAdd(&X0[group_of(xa.x)], 1u);
+            }
+            for (uint32_t i = threadIdx.x; i < d.en_nk; i += (uint32_t)TILE_THREADS) {
+                const int4 xc = *reinterpret_cast<const int4 *>(a->f.en.ent + d.en_r0 + i);
+                if (relevant(xc.z)) atomicAdd(&X1[group_of(xc.x)], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x < 2u * (uint32_t)WAVE) {
+                // inclusive prefix sums over the groups (wave 0: START, wave 1: END): X[g] = end of group g, the closing words = total
+                uint32_t *const X = threadIdx.x < (uint32_t)WAVE ? X0 : X1;
+                constexpr int PER = (DIR_N + WAVE - 1) / WAVE;
+                uint32_t v[PER], sum = 0u;
+#pragma unroll
+                for (int u = 0; u < PER; ++u) { const int g = lane * PER + u; v[u] = g < n_grp + 3 ? X[g] : 0u; sum += v[u]; }
+                uint32_t run = wave_inclusive_scan(sum) - sum;
+#pragma unroll
+                for (int u = 0; u < PER; ++u) { const int g = lane * PER + u; run += v[u]; if (g < n_grp + 3) X[g] = run; }
+                if (lane == WAVE - 1) s_kept[threadIdx.x >> 6] = run;
+            }
+            __syncthreads();
+            const bool crowded = s_kept[0] > (uint32_t)CHUNK_KEY_CAP || s_kept[1] > (uint32_t)CHUNK_KEY_CAP;
+            if (crowded && scan_next >= 0 && chunk_members > 1u) {
+                chunk_members >>= 1;                                     // the same stretch of the window again, with half the members
+                __syncthreads();
+                continue;
+            }
+            const bool bad = scan_next < 0 || crowded;                  // (a scan without end, one transcript with too many entries: the generic kernel)
             redo = redo || (active && bad);
+            if (!bad) {
+                for (uint32_t i = threadIdx.x; i < max(d.st_nk, d.en_nk); i += (uint32_t)TILE_THREADS) {
+                    int4 xa = make_int4(0, 0, INT32_MIN / 2, 0), xb = make_int4(0, 0, 0, 0), xc = xa, xd = xb;
+                    if (i < d.st_nk) { const int4 *qv = reinterpret_cast<const int4 *>(a->f.st.ent + d.st_r0 + i); xa = qv[0]; xb = qv[1]; }
+                    if (i < d.en_nk) { const int4 *qv = reinterpret_cast<const int4 *>(a->f.en.ent + d.en_r0 + i); xc = qv[0]; xd = qv[1]; }
+                    const bool has_st = i < d.st_nk && relevant(xa.z), has_en = i < d.en_nk && relevant(xc.z);
+                    if (!has_st && !has_en) continue;
+                    WEnt e0, e1;
+                    e0.k1 = xa.x; e0.k2 = xa.y; e1.k1 = xc.x; e1.k2 = xc.y;
+                    const m64_t pm0 = ((m64_t)(uint32_t)xb.y << 32) | (uint32_t)xb.x, sm0 = ((m64_t)(uint32_t)xb.w << 32) | (uint32_t)xb.z;
+                    const m64_t pm1 = ((m64_t)(uint32_t)xd.y << 32) | (uint32_t)xd.x, sm1 = ((m64_t)(uint32_t)xd.w << 32) | (uint32_t)xd.z;
+                    if (dc.flags & TD_CONTIG) {
+                        e0.pm = rebase64(pm0, xa.z - dc.j_lo); e0.sm = rebase64(sm0, xa.z - dc.j_lo);
+                        e1.pm = rebase64(pm1, xc.z - dc.j_lo); e1.sm = rebase64(sm1, xc.z - dc.j_lo);
+                    } else {
+                        m64_t mm[4] = {pm0, sm0, pm1, sm1};
+                        rebase_gaps64(s_tw.win, w_n, mm, xa.z, xc.z);
+                        e0.pm = mm[0]; e0.sm = mm[1]; e1.pm = mm[2]; e1.sm = mm[3];
+                    }
+                    // (places are handed out from the end of the group downwards: afterwards X[g] is the group's FIRST entry)
+                    if (has_st) s_ent0[atomicSub(&X0[group_of(xa.x)], 1u) - 1u] = e0;
+                    if (has_en) s_ent1[atomicSub(&X1[group_of(xc.x)], 1u) - 1u] = e1;
+                }
+            }
+            __syncthreads();
+            // reach-back directory: the first staged entry of the GROUP that holds the bucket's first reaching entry (what is scanned
+            // from there on is filtered by the exon's own coordinates)
+            if (!bad) {
+                for (int i = (int)threadIdx.x; i < d.nbk; i += TILE_THREADS) {
+                    const uint32_t e = ld32(a->f.st.rdir, (uint32_t)(d.b0 + i));
+                    XR[i] = e < d.st_r0 + d.st_nk ? X0[group_of(a->f.st.ent[e].k1)] : X0[n_grp];
+                }
+            }
+            __syncthreads();
             // ---- this chunk's part of the sweep
             const bool work = work0 && !redo && !known && !stopped;
             const ChunkVisit vm = visit_chunk64<LEVEL>(L, w_n, work, n, re, s_tw.mask);
@@ -339,7 +388,8 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *
                 stopped = vm.stopped;
             }
             __syncthreads();                                    // (the next chunk overwrites the window and the staged entries)
-            if (scan_next < 0 || scan_next >= a->f.p.n_tx || w_n == 0) break;
+            if (bad || scan_next >= a->f.p.n_tx || w_n == 0) break;
+            scan_from = scan_next;
         }
         // ---- verdicts; flag bytes into the staged positions
         uint32_t info = n << 8;

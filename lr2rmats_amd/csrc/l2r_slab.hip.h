@@ -602,8 +602,9 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
         *sa->ovf_cursor = 0ull;                                  // (the outlier area's)
     }
     if (d.flags & TD_WIDE) return;                               // k_probe_slab_wide takes the tile
-    if (sa->chunk_cnt && (d.flags & (TD_FAST | TD_WIDE)) == 0u && ((d.flags >> 8) & 7u) == 4u) {
-        // no window record fits the tile's window: k_probe_slab_chunked takes it, 63 members at a time
+    if (sa->chunk_cnt && (d.flags & (TD_FAST | TD_WIDE)) == 0u && (((d.flags >> 8) & 7u) == 4u || ((d.flags >> 8) & 7u) == 3u)) {
+        // no window record fits the tile's window, or its dictionary slices do not fit the staging here: k_probe_slab_chunked takes it,
+        // 63 members at a time, with the entries that matter for them
         if (threadIdx.x == 0) sa->chunk_tile[atomicAdd(sa->chunk_cnt, 1u)] = t;
         return;
     }
