@@ -236,7 +236,7 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *
         if (threadIdx.x == 0) s_lim = min(total, (uint32_t)SLAB_POS_CAP);
         __syncthreads();
         const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
-        const SlabStage st{s_A, s_L, loc, tile_lo, active && loc + n <= (uint32_t)SLAB_POS_CAP && !(pre & (PRE_DENSE | PRE_FAR))};
+        const SlabStage st{s_A, s_L, loc, tile_lo, active && loc + n <= (uint32_t)SLAB_POS_CAP && !(pre & PRE_DENSE)};
         if (active && loc + n > (uint32_t)SLAB_POS_CAP) atomicMin(&s_lim, loc);
         // ---- the tile's exons to their positions (a read that is not staged: straight into the result arrays)
         if (active) slab_copy_exons(sa, a, out, st, q, off, n, pre, r);

@@ -35,19 +35,19 @@ constexpr uint32_t SLAB_STRIDE = TILE_THREADS;           // elements between two
 constexpr int SLAB_HEAD_VEC = 6;                         // 16-byte CIGAR vectors a lane holds: 24 ops; longer reads finish from memory
 constexpr int SLAB_HEAD = 4 * SLAB_HEAD_VEC;
 // k_walk_slab -> k_probe_slab, one word per slot: the read's index inside its tile (bits 0-7), its strand bit, two flags, its exon count
-// A row word: the exon's start relative to a base in the low 18 bits, its length in the upper 14 (slab_pack).  The base is the
-// tile's first base (k_probe_slab stages exactly these 18 bits), for a PRE_FAR read its own.  A read with an exon that does not
-// fit -- 16 kb or longer, or starting 2^18 - 1 bases or more behind the base -- is an outlier (dense area).
+// A row word: the exon's start relative to the tile's first base in the low 18 bits (k_probe_slab stages exactly these 18 bits), its
+// length in the upper 14 (slab_pack).  The upload cuts tiles so that their reads BEGIN less than SLAB_TILE_SPAN = 2^17 bases apart
+// (l2r_engine.hip); a read with an exon that does not fit -- 16 kb or longer, or starting 2^18 - 1 bases or more behind the tile's
+// first base -- is an outlier (dense area).
 constexpr int SLAB_REL_BITS = 18;
 constexpr uint32_t SLAB_REL_MASK = (1u << SLAB_REL_BITS) - 1u;
 constexpr uint32_t SLAB_LEN_MAX = (1u << (32 - SLAB_REL_BITS)) - 1u;
-constexpr uint32_t SLAB_FAR_AT = 1u << (SLAB_REL_BITS - 1);
+constexpr int32_t SLAB_TILE_SPAN = 1 << (SLAB_REL_BITS - 1);
 __device__ __forceinline__ uint32_t slab_pack(int rel, uint32_t len) { return (uint32_t)rel | (len << SLAB_REL_BITS); }
 constexpr uint32_t PRE_REV = 1u << 8;
 constexpr uint32_t PRE_INSANE = 1u << 9;                 // first or last exon empty (or, with -e < 1, any exon): the generic kernel decides
-constexpr uint32_t PRE_FAR = 1u << 11;                   // rows relative to the read's OWN first base (its start lies 2^17 bases or more behind the tile's)
 constexpr uint32_t PRE_DENSE = 1u << 10;                 // an outlier: its exons are in the dense area (row 0 of its column holds the run's index)
-constexpr int PRE_N_SHIFT = 12;
+constexpr int PRE_N_SHIFT = 11;
 
 // c ops -> rows its read needs at most when every kept inner exon is at least one base long (min_exon >= 1): each kept exon but
 // the first and the last needs an op of its own next to its cut (src/bam2gtf.c:31-78), so n <= (c + 3) / 2.  With -e < 1 the walk
@@ -168,10 +168,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     const int c_max = wave_max((active && !outlier) ? (int)min(n_cig, (uint32_t)SLAB_HEAD) : 0);
     uint32_t *const rows = sa->slab_row;
     const uint32_t off = sbase + threadIdx.x;
-    // a row word holds the exon's start relative to the tile's first base (sorted records: the first read's), or, for a read that
-    // begins 2^17 bases or more behind it, relative to the read's own first base
-    const bool far = active && (uint32_t)(pos - pos0) >= SLAB_FAR_AT;
-    const int32_t base = far ? pos + 1 : pos0 + 1;
+    const int32_t base = pos0 + 1;                           // the tile's first base (sorted records: the first read's)
     uint32_t n = 0u;
     int el = INT32_MIN;
     bool sane = true;
@@ -261,7 +258,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     }
     if (active) {
         const uint32_t at = r0 + threadIdx.x;
-        sa->pre[at] = idx | (((xw >> 16) & 1u) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (outlier ? PRE_DENSE : (far ? PRE_FAR : 0u)) | (n << PRE_N_SHIFT);
+        sa->pre[at] = idx | (((xw >> 16) & 1u) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (outlier ? PRE_DENSE : 0u) | (n << PRE_N_SHIFT);
         sa->loc[at] = s_loc[idx];
     }
     // ---- the tile's descriptor and window, by the last wave alone (the others are done): nobody waits for its load chain
@@ -465,7 +462,7 @@ __device__ __forceinline__ void slab_copy_exons(SlabArgsK sa, PipeArgsK a, const
                                                 uint32_t pre, uint32_t r)
 {
     // (an outlier's exons may be 16 kb and longer, which the length of a staged position cannot say: written directly, its
-    //  positions marked so that the tile's write-out leaves them alone; the same for a read whose rows have its own base)
+    //  positions marked so that the tile's write-out leaves them alone)
     const bool dense = (pre & PRE_DENSE) != 0u;
     auto put = [&](uint32_t k, int s, int e) {
         if (st.fits) { st.A[st.loc + k] = (uint32_t)(s - st.lo); st.Ln[st.loc + k] = (uint16_t)(e - s + 1); }
@@ -478,7 +475,7 @@ __device__ __forceinline__ void slab_copy_exons(SlabArgsK sa, PipeArgsK a, const
         const uint32_t run = q.last.w;
         for (uint32_t k = 0; k < n; ++k) put(k, sa->dense_start[run + k], sa->dense_end[run + k]);
     } else {
-        const int32_t base = (pre & PRE_FAR) ? a->f.r_pos[r] + 1 : st.lo;
+        const int32_t base = st.lo;
         if (n == 1u) put(0u, slab_row_start(q.last, base), slab_row_end(q.last, base));
         else
             for (uint32_t k = 0; k < n; ++k) {
@@ -636,7 +633,7 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     const uint32_t n = pre >> PRE_N_SHIFT;
     const uint32_t r = r0 + (pre & 0xffu);
     const SlabRow first = n == 1u ? q.last : q.x[0];
-    const ReadEnds re{slab_row_start(first, tile_lo), slab_row_end(first, tile_lo), slab_row_start(q.last, tile_lo), slab_row_end(q.last, tile_lo)};      // (not of an outlier or a far read: those are not classified here)
+    const ReadEnds re{slab_row_start(first, tile_lo), slab_row_end(first, tile_lo), slab_row_start(q.last, tile_lo), slab_row_end(q.last, tile_lo)};      // (not of an outlier: those are not classified here)
     const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
     if (stamp.p) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp.mark(0);
@@ -657,7 +654,7 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
         return;
     }
     // a read is staged when its positions fit and its rows have the tile's base
-    const SlabStage st{s_A, s_L, loc, tile_lo, loc + n <= (uint32_t)SLAB_POS_CAP && !(pre & (PRE_DENSE | PRE_FAR))};
+    const SlabStage st{s_A, s_L, loc, tile_lo, loc + n <= (uint32_t)SLAB_POS_CAP && !(pre & PRE_DENSE)};
     // the first read that does not fit the staged positions ends the block that is written from LDS (reads are in read order there)
     if (active && loc + n > (uint32_t)SLAB_POS_CAP) atomicMin(&s_lim, loc);      // (a read that is written directly for another reason marks its positions instead)
     stamp.mark(1);

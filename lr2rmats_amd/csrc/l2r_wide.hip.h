@@ -337,9 +337,9 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
             __syncthreads();
             continue;
         }
-        // a read is staged when its positions fit and its rows have the tile's base
+        // a read is staged when its positions fit and it is no outlier
         const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
-        const SlabStage st{s_A, s_L, loc, tile_lo, active && loc + n <= (uint32_t)SLAB_POS_CAP && !(pre & (PRE_DENSE | PRE_FAR))};
+        const SlabStage st{s_A, s_L, loc, tile_lo, active && loc + n <= (uint32_t)SLAB_POS_CAP && !(pre & PRE_DENSE)};
         if (active && loc + n > (uint32_t)SLAB_POS_CAP) atomicMin(&s_lim, loc);
         // ---- classification
         uint32_t info = n << 8; int ref = -1;
