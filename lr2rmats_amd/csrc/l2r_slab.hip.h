@@ -1,9 +1,10 @@
-// l2r_slab.hip.h -- the one-walk pipeline for coordinate-sorted records with short CIGARs: TWO light kernels that both run at
-// full occupancy (8 waves per SIMD), with the exons handed over through HBM in a layout both sides touch with whole rows (gfx950).
+// l2r_slab.hip.h -- the one-walk pipeline for coordinate-sorted records with short CIGARs: TWO light kernels at 6 .. 8 workgroups
+// per CU, with the exons handed over through HBM in a layout both sides touch with whole rows (gfx950).
 //
-// Measured on MI355X (profiles/r02): kernels of this path are bound by the latency of a wave's dependent chains, and a SIMD's
-// issue rate grows with its resident waves up to 8.  An LDS tile of exons (10 bytes each, 40 KB per workgroup: the classic
-// kernel) caps that at 4 waves per SIMD.  Here neither kernel keeps exons in LDS:
+// Measured on MI355X (profiles/r02, profiles/r03): kernels of this path are bound by the latency of a wave's dependent chains, and
+// a SIMD's issue rate grows with its resident waves up to 8.  An LDS tile of exons (10 bytes each, 40 KB per workgroup: the classic
+// kernel) caps that at 4 waves per SIMD.  Here the walk kernel keeps no exons in LDS, the probe kernel 6 bytes per exon (the tile's
+// results on their way into read order):
 //
 //   k_walk_slab   per tile of up to 256 reads: the tile's reads by falling CIGAR length (a counting sort in LDS: the SLOT of a read =
 //                 its lane, so the lanes of a wave get similar trip counts); one lane per read, CIGAR words in registers, ONE walk;
@@ -12,19 +13,23 @@
 //                 tile (`loc`: a scan of the exon counts in read order), the tile's exon count, and -- by the last wave alone, the
 //                 others have left -- the tile's descriptor and window (make_descriptor).
 //   k_scan_u32    exclusive scan of the tiles' exon counts: the first result slot of every tile (l2r_kernels.hip.h)
-//   k_probe_slab  per tile: dictionary slices and window staged in LDS (20 KB with the per-exon work words: 8 workgroups per CU,
-//                 <= 64 VGPRs); every lane streams its read's exons row by row (coalesced), window pass, probes, verdicts with the
-//                 device functions of the classic kernel, and writes the per-read results where their consumers read them:
-//                 ex_start / ex_end / ex_flag / ex_off in READ ORDER (exon k of read r at ex_off[r] + k), info, ref_tx.
-//                 Nothing is left in an intermediate layout: l2r_download / l2r_device_view_get hand out these arrays as they are.
-//   k_probe_slab_wide (l2r_wide.hip.h)   the same for tiles whose window holds 33 .. 63 transcripts.
+//   k_probe_slab  per tile: dictionary slices and window staged in LDS; every lane streams its read's exons row by row (coalesced),
+//                 window pass, probes, verdicts with the device functions of the classic kernel; exons, work words and flags wait at
+//                 their read-order POSITIONS in LDS (22 KB per workgroup: 6 or 7 workgroups per CU, no scratch), and the tile's block
+//                 of the result arrays is written coalesced: ex_start / ex_end / ex_flag / ex_off in READ ORDER (exon k of read r
+//                 at ex_off[r] + k), info, ref_tx.  Nothing is left in an intermediate layout: l2r_download / l2r_device_view_get
+//                 hand out these arrays as they are.
+//   k_probe_slab_wide (l2r_wide.hip.h)      the same for tiles whose window holds 33 .. 63 transcripts (64-bit masks).
+//   k_probe_slab_chunked (l2r_chunk.hip.h)  tiles beyond that, tiles with a dictionary key in several entries, tiles whose dictionary
+//                 slices do not fit the staging of the two above: the window 63 members at a time, the sweep's state carried per read.
 //
-// Slab rows hold {start (int32), length (uint16)}: 6 bytes per exon cross HBM between the kernels.  A read's LAST exon sits in
-// row 0 of its column and exon k < n - 1 in row k + 1: the probe side needs the first and the last exon before anything else, and
-// finds both at addresses that do not depend on the exon count (one dependent round trip less in front of its first barrier).
-// A tile's slab has as many rows as its longest read can have exons (bound from the CIGAR lengths at upload, at most SLAB_ROWS);
-// reads beyond that, and reads with an exon of 64 kb or more, are OUTLIERS: walked literally into a dense area
-// (dense_start / dense_end), copied into the result arrays by the probe side, classified by the generic kernel.
+// A slab row is one word per exon: start relative to the tile's first base (18 bits) | length (14 bits) -- 4 bytes per exon cross HBM
+// between the kernels.  A read's LAST exon sits in row 0 of its column and exon k < n - 1 in row k + 1: the probe side needs the
+// first and the last exon before anything else, and finds both at addresses that do not depend on the exon count (one dependent round
+// trip less in front of its first barrier).  A tile's slab has as many rows as its longest read can have exons (bound from the CIGAR
+// lengths at upload, at most SLAB_ROWS); reads beyond that, and reads with an exon the row word cannot say, are OUTLIERS: walked
+// literally into a dense area (dense_start / dense_end), copied into the result arrays by the probe side, classified by the generic
+// kernel.
 #pragma once
 #include "l2r_window.hip.h"
 
