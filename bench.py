@@ -295,7 +295,7 @@ def main():
         launched = [k for k in kern if k not in ("k_validate_sj", "k_scan_accepted", "k_gather_accepted") or args.accepted or gather]
         per_kernel, traffic_note = pmc_traffic(sorted(live), args.config, reads.n)
         traffic = None if per_kernel is None else int(sum(per_kernel.values()))
-        roof = {"bound": "hbm", "kernel": " + ".join(sorted(launched, key=lambda k: -kern[k])) + " (every kernel of a cold step; k_probe_slab includes the launch of k_probe_slab_wide)",
+        roof = {"bound": "hbm", "kernel": " + ".join(sorted(launched, key=lambda k: -kern[k])) + " (every kernel of a cold step; k_probe_slab includes the launches of k_probe_slab_wide and k_probe_slab_chunked)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_measured_copy_peak": round(ach / HBM_COPY_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_note,
