@@ -196,18 +196,54 @@ def run(argv, classify: Optional[Callable] = None, backend: Optional[str] = None
             os.remove(gtf_tmp)
         os.close(real_stdout)
 
+    sharded, shard_lo, shard_hi, n_total = job.shard()
+    inflated = (0, 0)
+    if world > 1:
+        # A rank that has inflated only the BGZF blocks of its own records (shard() == 2: host/aln_reader.c h_read_alignments_blocks) found
+        # its start without the records in front of it: the ranks compare notes.  Rank r's start must be rank r - 1's end (which that
+        # rank reached record by record), every rank's records must be coordinate sorted, and so must the ranks one after the other.
+        # If anything is off -- or some rank could not read the file that way -- those who did load it the other way (the whole file
+        # inflated, cut by the records' weights), like the others.
+        mine = {"mode": sharded}
+        if sharded == 2:
+            info = job.shard_blocks()
+            rr = job.read_arrays()
+            mine.update({"start": tuple(info[0:2]), "end": tuple(info[2:4]), "n": int(rr["tid"].shape[0]), "bytes": (info[4], info[5]),
+                         "sorted": records_sorted(rr["tid"], rr["pos"]),
+                         "first": (int(np.uint32(rr["tid"][0])), int(rr["pos"][0])) if rr["tid"].shape[0] else None,
+                         "last": (int(np.uint32(rr["tid"][-1])), int(rr["pos"][-1])) if rr["tid"].shape[0] else None})
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        if any(e["mode"] == 2 for e in every):
+            ok = all(e["mode"] == 2 for e in every)
+            ok = ok and all(e["sorted"] for e in every) and all(every[k]["end"] == every[k + 1]["start"] for k in range(world - 1))
+            keys = [e for e in every if ok and e["n"]]
+            ok = ok and all(keys[k]["last"] <= keys[k + 1]["first"] for k in range(len(keys) - 1))
+            if ok:
+                sharded = 1
+                shard_lo = sum(e["n"] for e in every[:rank]); shard_hi = shard_lo + mine["n"]; n_total = sum(e["n"] for e in every)
+                inflated = mine["bytes"]
+            else:
+                if rank == 0:
+                    print("[lr2rmats_amd.dist] the ranks' block ranges do not meet: every rank reads the whole file", file=sys.stderr)
+                os.environ["L2R_DIST_BLOCKS"] = "0"
+                if sharded == 2:
+                    job.close()
+                    job = hostlib.Job(list(argv), open_outputs=False, rank=rank, world=world)
+                    if gtf_tmp is not None:
+                        job.set_out_path(0, gtf_tmp)
+                    sharded, shard_lo, shard_hi, n_total = job.shard()
     r = job.read_arrays()
     n = int(r["tid"].shape[0])
     weights = 4.0 * np.diff(r["cig_off"]) + 64.0           # ~ bytes a read costs (4c + 21n + 12)
     sj = job.junction_arrays()
     aligned = None
-    sharded, shard_lo, shard_hi, n_total = job.shard()
     in_order = True if sharded else records_sorted(r["tid"], r["pos"])
     if world > 1 and not sharded and in_order and not (job.prm.split_trans and sj is not None) and os.environ.get("L2R_DIST_GATHER") != "1":
         aligned = workload.aligned_shard_bounds(r["tid"], world, weights)
     if os.environ.get("L2R_DIST_SHARD_TRACE"):                # tests: what this rank loaded
         with open("%s.%d" % (os.environ["L2R_DIST_SHARD_TRACE"], rank), "w") as fh:
-            fh.write("%d %d %d %d\n" % (1 if sharded else 0, shard_lo, shard_hi, n_total))
+            fh.write("%d %d %d %d %d %d\n" % (1 if sharded else 0, shard_lo, shard_hi, n_total, inflated[0], inflated[1]))      # (+ compressed bytes inflated / in the file: block ranges only)
     base = 0
     if sharded:
         # the host library has cut the records already (same rule, chromosome-aligned): this rank holds [shard_lo, shard_hi) only

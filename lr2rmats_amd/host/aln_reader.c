@@ -482,6 +482,7 @@ struct h_aln_stream {
     uint8_t *carry; size_t carry_n;
     int header_done, eof;
     size_t window;
+    int keep_blk; bgzf_block *blk; size_t n_blk;          /* keep_blk: the last window's block table stays (in_off relative to the window's first byte) */
 };
 
 static int file_is_bgzf(FILE *f)
@@ -532,7 +533,8 @@ static uint8_t *stream_window(h_aln_stream *s, size_t *n_out)
     for (long k = 1; k < n_thr; ++k) pthread_join(th[k], NULL);
     pthread_mutex_destroy(&jb.mu);
     if (jb.failed) h_fatal(s->who, jb.failed == 2 ? "CRC32 mismatch in a BGZF block" : "corrupt BGZF block");
-    free(blk); free(raw);
+    if (s->keep_blk) { free(s->blk); s->blk = blk; s->n_blk = n_blk; } else free(blk);
+    free(raw);
     *n_out = out_total;
     return out;
 }
@@ -616,6 +618,308 @@ void h_aln_stream_close(h_aln_stream *s)
     if (!s) return;
     if (s->f) fclose(s->f);
     free(s->carry); free(s);
+}
+
+/* ------------------------------------------------------------------ one rank's BLOCK RANGE of a coordinate-sorted BAM
+ * A rank of a multi-process run (dist.py) that inflates the whole file to find its shard spends what the ranks were meant to
+ * share.  Here rank r of W inflates only the BGZF blocks its records are in, plus the stretch it needs to find where they begin:
+ *
+ *   target(r)  = the first BGZF block that starts at or behind byte (file size * r / W)            (no inflation: block headers)
+ *   B(r)       = the first BAM record that starts at or behind the beginning of that block
+ *   S(r)       = the first record at or behind B(r) on ANOTHER chromosome than B(r)                 (S(0) = the first record)
+ *   the rank's records = [S(r), S(r + 1)),  S(W) = the end of the file
+ *
+ * so shards are cut at chromosome boundaries (what the partitioned tail needs: merge_trans never looks across one) and every
+ * rank finds both of its ends alone.  Its own end is exact: it streams there record by record.  Its start is found WITHOUT the
+ * records before it: B(r) is the first offset in the block at which a chain of eight plausible, coordinate-sorted records begins
+ * (block_size, refID, pos, name length, a printable NUL-terminated name, n_cigar, l_seq consistent with block_size).  dist.py
+ * compares every rank's start with its predecessor's (exact) end and falls back to loading the whole file everywhere when one pair
+ * differs.  info: [0,1] start (file offset of the block, offset inside its inflated bytes)  [2,3] end  [4] compressed bytes this
+ * rank inflated  [5] file size  [6] records kept.  Returns 1 = done, 0 = not a BGZF-compressed BAM / no boundary found (caller
+ * reads the file the other way). */
+typedef struct { int64_t coff; int64_t uoff; } vpos;
+
+static int bgzf_magic_at(const uint8_t *p, size_t n)
+{
+    return n >= 18 && p[0] == 0x1f && p[1] == 0x8b && p[2] == 8 && (p[3] & 4) && p[12] == 'B' && p[13] == 'C' && p[14] == 2 && p[15] == 0 &&
+           (p[10] | (p[11] << 8)) == 6 && (size_t)(p[16] | (p[17] << 8)) + 1 >= 28;
+}
+
+/* first block that starts at or behind `target` (fsz: none) */
+static int64_t bgzf_block_from(FILE *f, int64_t fsz, int64_t target)
+{
+    if (target <= 0) return 0;
+    if (target >= fsz) return fsz;
+    const size_t want = 4 * 65536 + 64;
+    uint8_t *buf = (uint8_t *)h_malloc(want);
+    fseek(f, (long)target, SEEK_SET);
+    const size_t n = fread(buf, 1, want, f);
+    int64_t found = fsz;
+    for (size_t p = 0; p + 18 <= n && p < 65536 + 18; ++p) {
+        if (!bgzf_magic_at(buf + p, n - p)) continue;
+        /* two more blocks (or the end of the file) must follow where this one says */
+        size_t q = p; int ok = 1;
+        for (int k = 0; k < 3 && ok; ++k) {
+            const size_t bs = (size_t)(buf[q + 16] | (buf[q + 17] << 8)) + 1;
+            q += bs;
+            if ((int64_t)(target + (int64_t)q) == fsz) break;
+            if (q + 18 > n) { ok = (int64_t)(target + (int64_t)q) < fsz; break; }
+            ok = bgzf_magic_at(buf + q, n - q);
+        }
+        if (ok) { found = target + (int64_t)p; break; }
+    }
+    free(buf);
+    return found;
+}
+
+/* one block at file offset coff, inflated behind buf[*n] (grown as needed); returns the block's size in the file, 0 at the end */
+static size_t bgzf_inflate_one(FILE *f, int64_t coff, uint8_t **buf, size_t *n, size_t *cap, const char *who)
+{
+    uint8_t raw[65536 + 64];
+    fseek(f, (long)coff, SEEK_SET);
+    const size_t got = fread(raw, 1, 18, f);
+    if (got == 0) return 0;
+    if (!bgzf_magic_at(raw, got)) h_fatal(who, "not a BGZF block where one was expected");
+    const size_t bsize = (size_t)(raw[16] | (raw[17] << 8)) + 1;
+    if (fread(raw + 18, 1, bsize - 18, f) != bsize - 18) h_fatal(who, "truncated BGZF block");
+    const uint8_t *tail = raw + bsize - 4;
+    const size_t isize = (size_t)tail[0] | ((size_t)tail[1] << 8) | ((size_t)tail[2] << 16) | ((size_t)tail[3] << 24);
+    if (*n + isize + 1 > *cap) { while (*n + isize + 1 > *cap) *cap = *cap ? *cap * 2 : 1 << 20; *buf = (uint8_t *)h_realloc(*buf, *cap); }
+    if (isize) {
+        z_stream z; memset(&z, 0, sizeof z);
+        if (inflateInit2(&z, -15) != Z_OK) h_fatal(who, "zlib");
+        z.next_in = raw + 18; z.avail_in = (uInt)(bsize - 18 - 8); z.next_out = *buf + *n; z.avail_out = (uInt)isize;
+        const int rc = inflate(&z, Z_FINISH);
+        inflateEnd(&z);
+        if (rc != Z_STREAM_END || z.avail_out != 0) h_fatal(who, "corrupt BGZF block");
+    }
+    *n += isize;
+    return bsize;
+}
+
+/* the BAM header at the beginning of the file -> chr; *after = where the first record begins */
+static int bam_header_light(FILE *f, h_chroms *chr, vpos *after, const char *who)
+{
+    uint8_t *buf = NULL; size_t n = 0, cap = 0;
+    int64_t coff = 0;
+    int64_t blk_off[4096]; size_t blk_out[4096]; size_t n_blk = 0;
+    for (;;) {
+        if (n_blk == 4096) { free(buf); return 0; }
+        blk_off[n_blk] = coff; blk_out[n_blk] = n;
+        const size_t bs = bgzf_inflate_one(f, coff, &buf, &n, &cap, who);
+        if (!bs) { free(buf); return 0; }
+        ++n_blk; coff += (int64_t)bs;
+        if (n < 12) continue;
+        if (memcmp(buf, "BAM\1", 4) != 0) { free(buf); return 0; }
+        const uint8_t *p = buf, *end = buf + n;
+        if ((size_t)(end - p) < 12 + (size_t)le32(p + 4)) continue;
+        const uint8_t *q = p + 8 + le32(p + 4);
+        const uint32_t n_ref = le32(q); q += 4;
+        int ok = 1;
+        for (uint32_t i = 0; ok && i < n_ref; ++i) {
+            ok = q + 4 <= end;
+            if (ok) { const uint32_t l_name = le32(q); ok = (size_t)(end - q) >= 8 + (size_t)l_name; if (ok) q += 8 + l_name; }
+        }
+        if (!ok) continue;
+        const uint8_t *h = p + 8 + le32(p + 4) + 4;
+        for (uint32_t i = 0; i < n_ref; ++i) { const uint32_t l_name = le32(h); h_chrom_intern(chr, (const char *)(h + 4)); h += 8 + l_name; }
+        chr->n_hdr = chr->n;
+        /* (the first record begins at offset q - buf: in the last block whose first byte is not behind it; at the very end of a
+         *  block it is the next block's first byte) */
+        const size_t at = (size_t)(q - buf);
+        size_t k = n_blk - 1;
+        while (k > 0 && blk_out[k] > at) --k;
+        after->coff = blk_off[k]; after->uoff = (int64_t)(at - blk_out[k]);
+        if (at == n) { after->coff = coff; after->uoff = 0; }
+        free(buf);
+        return 1;
+    }
+}
+
+static int bam_record_plausible(const uint8_t *p, const uint8_t *end, int32_t n_ref, int32_t *tid, int32_t *pos, uint32_t *bs_out)
+{
+    if (end - p < 36) return -1;                           /* (not enough bytes to say) */
+    const uint32_t bs = le32(p);
+    const int32_t ref = (int32_t)le32(p + 4), ps = (int32_t)le32(p + 8);
+    const uint32_t l_name = p[12], n_cig = le16(p + 16), l_seq = le32(p + 20);
+    const int32_t nref = (int32_t)le32(p + 24), npos = (int32_t)le32(p + 28);
+    if (bs < 32 || bs > (1u << 27) || ref < -1 || ref >= n_ref || ps < -1 || l_name < 1 || l_seq > (1u << 27) || nref < -1 || nref >= n_ref || npos < -1) return 0;
+    const uint64_t fixed = 32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1) / 2 + l_seq;
+    if (fixed > bs) return 0;
+    if ((size_t)(end - p) < 36 + (size_t)l_name) return -1;
+    const uint8_t *nm = p + 36;
+    if (nm[l_name - 1] != 0) return 0;
+    for (uint32_t i = 0; i + 1 < l_name; ++i) if (nm[i] < 33 || nm[i] > 126) return 0;
+    *tid = ref; *pos = ps; *bs_out = bs;
+    return 1;
+}
+
+/* sorted BAM order: unmapped records (refID -1) come last */
+static int bam_key_le(int32_t t0, int32_t p0, int32_t t1, int32_t p1)
+{
+    const uint32_t a = (uint32_t)t0, b = (uint32_t)t1;     /* -1 -> 0xffffffff */
+    return a < b || (a == b && p0 <= p1);
+}
+
+/* S(r) for r > 0 (see above): returns 1 and *S (coff == fsz: the end of the file), 0 when no record boundary was found;
+ * *inflated += compressed bytes inflated */
+static int bam_find_start(FILE *f, int64_t fsz, int64_t c0, int32_t n_ref, vpos *S, int64_t *inflated, const char *who)
+{
+    if (c0 >= fsz) { S->coff = fsz; S->uoff = 0; return 1; }
+    uint8_t *buf = NULL; size_t n = 0, cap = 0;
+    size_t cap_blk = 1024, n_blk = 0;
+    int64_t *blk_off = (int64_t *)h_malloc(cap_blk * sizeof *blk_off);
+    size_t *blk_out = (size_t *)h_malloc(cap_blk * sizeof *blk_out);
+    int64_t coff = c0;
+    int eof = 0;
+#define MORE() do { \
+        if (n_blk == cap_blk) { cap_blk *= 2; blk_off = (int64_t *)h_realloc(blk_off, cap_blk * sizeof *blk_off); blk_out = (size_t *)h_realloc(blk_out, cap_blk * sizeof *blk_out); } \
+        blk_off[n_blk] = coff; blk_out[n_blk] = n; \
+        const size_t bs_ = coff < fsz ? bgzf_inflate_one(f, coff, &buf, &n, &cap, who) : 0; \
+        if (!bs_) eof = 1; else { ++n_blk; coff += (int64_t)bs_; *inflated += (int64_t)bs_; } } while (0)
+    MORE();
+    const size_t first_len = n;                             /* B(r) begins inside the first block (or at a later block's first byte) */
+    size_t o = 0; int found = 0;
+    /* candidate offsets: every byte of the first block, then (an empty or tiny first block) on into the next ones, up to 1 MB */
+    for (; !found; ++o) {
+        while (!eof && n < o + (1u << 16)) MORE();
+        if (o >= n || o > (1u << 20)) break;
+        size_t q = o; int32_t pt = 0, pp = 0; int chain = 0, ok = 1;
+        while (chain < 8 && ok) {
+            int32_t t, ps; uint32_t bs;
+            int rc = bam_record_plausible(buf + q, buf + n, n_ref, &t, &ps, &bs);
+            while (rc < 0 && !eof) { MORE(); rc = bam_record_plausible(buf + q, buf + n, n_ref, &t, &ps, &bs); }
+            if (rc < 0) { ok = (q == n && chain > 0); break; }                 /* the file ends: a shorter chain that ends exactly there */
+            if (rc == 0 || (chain && !bam_key_le(pt, pp, t, ps))) { ok = 0; break; }
+            pt = t; pp = ps; ++chain;
+            while (!eof && n < q + 4 + (size_t)bs + 36) MORE();
+            q += 4 + (size_t)bs;
+            if (q > n) { ok = 0; break; }
+        }
+        if (ok && chain > 0) found = 1;
+        if (found) break;
+    }
+    (void)first_len;
+    if (!found) { free(buf); free(blk_off); free(blk_out); return 0; }
+    /* from B(r) on until the chromosome changes */
+    size_t q = o; int32_t tid0 = 0; int have = 0;
+    for (;;) {
+        while (!eof && n < q + 36) MORE();
+        if (q + 4 > n) { S->coff = fsz; S->uoff = 0; break; }                  /* no other chromosome behind B(r) */
+        const uint32_t bs = le32(buf + q);
+        const int32_t t = (int32_t)le32(buf + q + 4);
+        if (!have) { tid0 = t; have = 1; }
+        else if (t != tid0) {
+            size_t k = n_blk - 1;
+            while (k > 0 && blk_out[k] > q) --k;
+            S->coff = blk_off[k]; S->uoff = (int64_t)(q - blk_out[k]);
+            break;
+        }
+        while (!eof && n < q + 4 + (size_t)bs) MORE();
+        q += 4 + (size_t)bs;
+        if (q > n) { free(buf); free(blk_off); free(blk_out); return 0; }     /* truncated */
+        if (q > ((size_t)32 << 20)) {
+            /* (a chromosome can be long: what lies in front of the current record's block is dropped) */
+            size_t k = n_blk - 1;
+            while (k > 0 && blk_out[k] > q) --k;
+            const size_t shift = blk_out[k];
+            if (shift) {
+                memmove(buf, buf + shift, n - shift);
+                n -= shift; q -= shift;
+                for (size_t i = k; i < n_blk; ++i) { blk_off[i - k] = blk_off[i]; blk_out[i - k] = blk_out[i] - shift; }
+                n_blk -= k;
+            }
+        }
+    }
+#undef MORE
+    free(buf); free(blk_off); free(blk_out);
+    return 1;
+}
+
+int h_read_alignments_blocks(const char *fn, h_chroms *chr, h_reads *out, int skip_unmapped, const char *who, int rank, int world, int64_t info[8])
+{
+    memset(out, 0, sizeof *out);
+    memset(info, 0, 8 * sizeof info[0]);
+    FILE *f = fopen(fn, "rb");
+    if (!f) h_fatal(who, "Can not open \"%s\"\n", fn);
+    if (!file_is_bgzf(f)) { fclose(f); return 0; }
+    fseek(f, 0, SEEK_END);
+    const int64_t fsz = (int64_t)ftell(f);
+    fseek(f, 0, SEEK_SET);
+    vpos first;
+    if (!bam_header_light(f, chr, &first, who)) { fclose(f); return 0; }
+    const int32_t n_ref = (int32_t)chr->n_hdr;
+    int64_t inflated = 0;
+    vpos S = first;
+    if (rank > 0 && !bam_find_start(f, fsz, bgzf_block_from(f, fsz, fsz / world * rank), n_ref, &S, &inflated, who)) { fclose(f); return 0; }
+    const int64_t c1 = rank + 1 < world ? bgzf_block_from(f, fsz, fsz / world * (rank + 1)) : fsz;
+    info[0] = S.coff; info[1] = S.uoff; info[5] = fsz;
+    reads_reserve(out, 1, 1);
+    out->cig_off[0] = 0;
+    /* the rank's records: windows of whole blocks from S on (inflated block-parallel), until the first record at or behind block c1
+     * has been followed by a record of another chromosome */
+    vpos E; E.coff = fsz; E.uoff = 0;
+    if (S.coff < fsz) {
+        h_aln_stream st; memset(&st, 0, sizeof st);
+        st.f = f; st.who = who; st.chr = chr; st.skip_unmapped = skip_unmapped; st.header_done = 1;
+        size_t big = (size_t)64 << 20;
+        const char *e = getenv("L2R_READ_WINDOW");
+        if (e && atoll(e) >= 65536 + 64) big = (size_t)atoll(e);
+        st.keep_blk = 1;
+        fseek(f, (long)S.coff, SEEK_SET);
+        size_t skip = (size_t)S.uoff;
+        int phase = 0; int32_t tid_b = 0; int done = 0;
+        vpos carry_v = S;                                   /* where the carried bytes begin in the file */
+        while (!done) {
+            const int64_t win_off = (int64_t)ftell(f);
+            const size_t carried = st.carry_n;
+            size_t n = 0;
+            /* (large windows up to the next rank's target, small ones behind it: what is read past the rank's last record is wasted) */
+            st.window = win_off < c1 ? (size_t)(c1 - win_off) + 65536 + 64 : (size_t)2 * (65536 + 64);
+            if (st.window > big) st.window = big;
+            uint8_t *w = stream_window(&st, &n);
+            if (!w) { if (st.carry_n) h_fatal(who, "truncated BAM record at the end of the file"); break; }
+            info[4] += (int64_t)ftell(f) - win_off;
+            const uint8_t *p = w + skip, *end = w + n;
+            skip = 0;
+            size_t n_rec = 0, cap_rec = 1 << 14, kb = 0;
+            size_t *starts = (size_t *)h_malloc(cap_rec * sizeof *starts);
+            while (p + 4 <= end) {
+                const uint32_t bs = le32(p);
+                if (bs < 32) h_fatal(who, "truncated BAM record");
+                if ((size_t)(end - p) < 4 + (size_t)bs) break;
+                /* where the record begins in the file */
+                const size_t at = (size_t)(p - w);
+                vpos v;
+                if (at < carried) { v = carry_v; }
+                else {
+                    while (kb + 1 < st.n_blk && st.blk[kb + 1].out_off <= at) ++kb;
+                    v.coff = win_off + (int64_t)st.blk[kb].in_off - 18; v.uoff = (int64_t)(at - st.blk[kb].out_off);
+                }
+                const int32_t t = (int32_t)le32(p + 4);
+                if (phase == 0 && v.coff >= c1) { phase = 1; tid_b = t; }
+                else if (phase == 1 && t != tid_b) { E = v; done = 1; break; }
+                if (n_rec == cap_rec) { cap_rec *= 2; starts = (size_t *)h_realloc(starts, cap_rec * sizeof *starts); }
+                starts[n_rec++] = at;
+                p += 4 + bs;
+            }
+            if (!done && p < end) {
+                const size_t at = (size_t)(p - w);
+                if (at >= carried) {
+                    size_t k2 = 0;
+                    while (k2 + 1 < st.n_blk && st.blk[k2 + 1].out_off <= at) ++k2;
+                    carry_v.coff = win_off + (int64_t)st.blk[k2].in_off - 18; carry_v.uoff = (int64_t)(at - st.blk[k2].out_off);
+                }
+                st.carry_n = (size_t)(end - p); st.carry = (uint8_t *)h_malloc(st.carry_n); memcpy(st.carry, p, st.carry_n);
+            }
+            if (n_rec) { const blob b = {w, n}; bam_extract(&b, starts, n_rec, chr, out, skip_unmapped, who); }
+            free(starts); free(w);
+        }
+        free(st.carry); free(st.blk);
+    }
+    fclose(f);
+    info[2] = E.coff; info[3] = E.uoff; info[4] += inflated; info[6] = out->n;
+    return 1;
 }
 
 static void read_any(const char *fn, h_chroms *chr, h_reads *out, int skip_unmapped, int header_only, const char *who)

@@ -27,6 +27,7 @@ struct h_job {
     int mode;
     l2r_params engine_prm;       /* what the engine gets: o.prm, except that `-m g` input passes its exons through unchanged */
     int sharded; int64_t shard_lo, shard_hi, shard_total;       /* h_job_open_rank: only records [lo, hi) of `total` are loaded */
+    int64_t shard_blocks[8];                                     /* sharded == 2: the rank's block range (h_read_alignments_blocks); lo / hi / total are dist.py's to work out */
     char *out_path[8];           /* 0 updated gtf (NULL = stdout), 1 exon bed, 2 bam gtf, 3 detail, 4 known, 5 novel, 6 unrecog, 7 summary */
     h_part_genes part_genes;     /* of the part h_job_finish_part last ran */
 };
@@ -146,8 +147,12 @@ h_job *h_job_open_rank(int argc, char **argv, int *exit_code, int open_outputs, 
 }
 int h_job_shard(const h_job *j, int64_t *lo, int64_t *hi, int64_t *n_total)
 {
-    *lo = j->sharded ? j->shard_lo : 0; *hi = j->sharded ? j->shard_hi : j->reads.n; *n_total = j->sharded ? j->shard_total : j->reads.n;
+    *lo = j->sharded == 1 ? j->shard_lo : 0; *hi = j->sharded == 1 ? j->shard_hi : j->reads.n; *n_total = j->sharded == 1 ? j->shard_total : j->reads.n;
     return j->sharded;
+}
+void h_job_shard_blocks(const h_job *j, int64_t info[8])
+{
+    memcpy(info, j->shard_blocks, sizeof j->shard_blocks);
 }
 
 h_job *h_job_open2(int argc, char **argv, int *exit_code, int open_outputs)
@@ -212,9 +217,16 @@ h_job *h_job_open(int argc, char **argv, int *exit_code)
         /* a rank of a multi-process run loads its shard only -- unless the run needs the gathered route (split pieces are compared
          * across chromosomes, Q2) or the caller forces it */
         const char *fg = getenv("L2R_DIST_GATHER");
-        if (g_world > 1 && !(j->o.prm.split_trans && j->sj_fp) && !(fg && fg[0] == '1'))
-            j->sharded = h_read_alignments_shard(argv[optind], &j->chr, &j->reads, 0, "update_gtf", g_rank, g_world, &j->shard_lo, &j->shard_hi, &j->shard_total);
-        else h_read_alignments(argv[optind], &j->chr, &j->reads, 0, "update_gtf");
+        if (g_world > 1 && !(j->o.prm.split_trans && j->sj_fp) && !(fg && fg[0] == '1')) {
+            /* first choice: only the BGZF blocks of this rank's records are inflated (L2R_DIST_BLOCKS=0: every rank inflates the file
+             * and cuts it by the records' weights -- what dist.py falls back to when the ranks' block ranges do not meet) */
+            const char *fb = getenv("L2R_DIST_BLOCKS");
+            if (!(fb && fb[0] == '0') && h_read_alignments_blocks(argv[optind], &j->chr, &j->reads, 0, "update_gtf", g_rank, g_world, j->shard_blocks)) j->sharded = 2;
+            else {
+                if (j->reads.cig_off) h_reads_free(&j->reads);       /* (the header's names are interned again: same ids) */
+                j->sharded = h_read_alignments_shard(argv[optind], &j->chr, &j->reads, 0, "update_gtf", g_rank, g_world, &j->shard_lo, &j->shard_hi, &j->shard_total);
+            }
+        } else h_read_alignments(argv[optind], &j->chr, &j->reads, 0, "update_gtf");
         h_stage_time("read alignments");
     } else {
         if (!hdr_file) h_fatal("update_gtf", "Couldn't read header of provided BAM file.\n");

@@ -52,6 +52,8 @@ int  h_read_alignments_shard(const char *fn, h_chroms *chr, h_reads *out, int sk
                              int64_t *lo, int64_t *hi, int64_t *n_total);
 void h_read_header_only(const char *fn, h_chroms *chr, const char *who);
 /* a BGZF-compressed BAM window by window (aln_reader.c); open returns NULL for any other file */
+/* one rank's block range of a coordinate-sorted BGZF BAM (aln_reader.c); info[8]: start / end positions, bytes inflated, file size, records */
+int  h_read_alignments_blocks(const char *fn, h_chroms *chr, h_reads *out, int skip_unmapped, const char *who, int rank, int world, int64_t info[8]);
 typedef struct h_aln_stream h_aln_stream;
 h_aln_stream *h_aln_stream_open(const char *fn, h_chroms *chr, int skip_unmapped, const char *who);
 int64_t h_aln_stream_next(h_aln_stream *s, h_reads *out);     /* appends a batch to *out; records appended, -1 at the end */
@@ -163,6 +165,8 @@ h_job *h_job_open2(int argc, char **argv, int *exit_code, int open_outputs);   /
  * gives its place: records [*lo, *hi) of *n_total, and returns 1; the job's read arrays hold just those (index 0 = record *lo). */
 h_job *h_job_open_rank(int argc, char **argv, int *exit_code, int open_outputs, int rank, int world);
 int    h_job_shard(const h_job *j, int64_t *lo, int64_t *hi, int64_t *n_total);
+/* h_job_shard() == 2: the rank loaded the BGZF blocks of its own records only (h_read_alignments_blocks); info as there */
+void   h_job_shard_blocks(const h_job *j, int64_t info[8]);
 void   h_job_views(h_job *j, l2r_params *prm, l2r_annotation *anno, l2r_junctions *sj, l2r_reads *reads);
 int    h_job_finish(h_job *j, const l2r_result *res);
 void   h_job_free(h_job *j);

@@ -37,6 +37,8 @@ def load_library():
         lib.h_job_open_rank.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]
         lib.h_job_shard.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.h_job_shard.restype = C.c_int
+        lib.h_job_shard_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        lib.h_job_shard_blocks.restype = None
         lib.h_job_views.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.h_job_finish.argtypes = [C.c_void_p, C.c_void_p]
         lib.h_job_finish.restype = C.c_int
@@ -97,7 +99,14 @@ class Job:
         """(sharded, lo, hi, n_total): with ``sharded`` the read arrays hold the records [lo, hi) of the file only."""
         lo, hi, n = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         s = self.lib.h_job_shard(self.h, C.byref(lo), C.byref(hi), C.byref(n))
-        return bool(s), int(lo.value), int(hi.value), int(n.value)
+        return int(s), int(lo.value), int(hi.value), int(n.value)
+
+    def shard_blocks(self):
+        """shard()[0] == 2: [start block offset, offset in it, end block offset, offset in it, compressed bytes inflated, file size,
+        records] of the rank's block range (host/aln_reader.c h_read_alignments_blocks)."""
+        info = (C.c_int64 * 8)()
+        self.lib.h_job_shard_blocks(self.h, info)
+        return [int(x) for x in info[:7]]
 
     # numpy views (zero copy, valid until close())
     def annotation_arrays(self):

@@ -241,3 +241,66 @@ def test_aligned_shard_bounds():
     assert workload.aligned_shard_bounds(np.array([0, 1, 0], np.int32), 2) is None
     b = workload.aligned_shard_bounds(np.zeros(10, np.int32), 4)          # one chromosome, four ranks: three empty shards
     assert sum(hi - lo for lo, hi in b) == 10 and sum(1 for lo, hi in b if hi > lo) == 1
+
+
+@pytest.mark.timeout(600)
+def test_every_rank_inflates_only_its_block_range(oracle, tmp_path):
+    """A coordinate-sorted BGZF BAM on the partitioned route: rank r inflates the blocks from its byte target (file size * r / world) to
+    the end of its records -- its share of the file plus at most one chromosome and a block -- and finds its first record without the
+    records in front of it (host/aln_reader.c h_read_alignments_blocks); the ranks' ranges meet (dist.py checks that, the trace says
+    what each rank inflated) and the files are the single-process files."""
+    world, nchr = 3, 12
+    anno = synth.make_annotation(12000, 77, nchr=nchr, shuffle_within_gene=True)
+    reads = synth.make_reads(anno, 150000, 5, 77)
+    sam, gtf, bam = str(tmp_path / "r.sam"), str(tmp_path / "a.gtf"), str(tmp_path / "r.bam")
+    reads.write_sam(sam)
+    anno.write_gtf(gtf)
+    synth.write_bam(reads, bam)
+    single = {k: str(tmp_path / ("s." + k)) for k in KEYS}
+    multi = {k: str(tmp_path / ("m." + k)) for k in KEYS}
+    assert oracle.run_cli(_args(single, sam, gtf)) == 0
+    _run_ranks(world, _args(multi, bam, gtf), {"L2R_DIST_TRACE": str(tmp_path / "trace"), "L2R_DIST_SHARD_TRACE": str(tmp_path / "shards")})
+    assert open(str(tmp_path / "trace")).read().strip() == "partitioned"
+    for k in KEYS:
+        assert filecmp.cmp(single[k], multi[k], shallow=False), k
+    rows = [tuple(int(x) for x in open(str(tmp_path / ("shards.%d" % r))).read().split()) for r in range(world)]
+    fsz = os.path.getsize(bam)
+    assert fsz > 20 * 65536 // 4                                # enough blocks for the ranges to mean something
+    spans = [(r[1], r[2]) for r in rows]
+    assert spans[0][0] == 0 and spans[-1][1] == reads.n and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    for lo, hi in spans:
+        assert lo == hi or lo == 0 or reads.tid[lo - 1] != reads.tid[lo]
+    for r in rows:
+        assert r[0] == 1 and r[3] == reads.n and r[5] == fsz and r[4] > 0, r          # (r[4] == 0: the fallback ran, every rank inflated the file)
+        assert r[4] <= fsz * (1.0 / world + 1.5 / nchr) + 3 * 65536, (r, fsz)
+    assert sum(r[4] for r in rows) < 1.6 * fsz
+
+
+@pytest.mark.timeout(600)
+def test_block_ranges_that_cannot_be_trusted_fall_back(oracle, tmp_path):
+    """The second half of this BAM is not coordinate sorted: rank 0 reads its block range without noticing, rank 1 finds no chain of sorted
+    records to begin at and reads the file the other way.  The ranks compare notes (dist.py), rank 0 reloads, and the run takes the
+    route of unsorted input: one rank classifies everything; files = the single-process files of the same records."""
+    anno = synth.make_annotation(6000, 78, nchr=6, shuffle_within_gene=True)
+    reads = synth.make_reads(anno, 60000, 5, 78)
+    rng = np.random.default_rng(78)
+    perm = np.arange(reads.n)
+    half = reads.n // 2
+    perm[half:] = half + rng.permutation(reads.n - half)
+    lens = np.diff(reads.cig_off)[perm]
+    g = synth._ragged_gather_index(reads.cig_off[perm], lens)
+    off = np.zeros(reads.n + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    mixed = synth.Reads(reads.chrom_names, reads.tid[perm], reads.pos[perm], reads.rev[perm], reads.flag_rev[perm], reads.has_xs[perm], off, reads.cig[g],
+                        reads.name_base, reads.chrom_len, False)
+    sam, gtf, bam = str(tmp_path / "r.sam"), str(tmp_path / "a.gtf"), str(tmp_path / "r.bam")
+    mixed.write_sam(sam)
+    anno.write_gtf(gtf)
+    synth.write_bam(mixed, bam)
+    single = {k: str(tmp_path / ("s." + k)) for k in KEYS}
+    multi = {k: str(tmp_path / ("m." + k)) for k in KEYS}
+    assert oracle.run_cli(_args(single, sam, gtf)) == 0
+    _run_ranks(2, _args(multi, bam, gtf), {"L2R_DIST_TRACE": str(tmp_path / "trace")})
+    assert open(str(tmp_path / "trace")).read().strip() == "one rank, gathered full"
+    for k in KEYS:
+        assert filecmp.cmp(single[k], multi[k], shallow=False), k
