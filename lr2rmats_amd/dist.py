@@ -111,10 +111,39 @@ def _engine_classify(device_index: int):
         eng.set_annotation(a["tx_tid"], a["tx_start"], a["tx_end"], a["tx_rev"], a["tx_ex_off"], a["ex_start"], a["ex_end"])
         eng.set_junctions(job.junction_arrays())
         c0, c1 = int(r["cig_off"][lo]), int(r["cig_off"][hi])
-        eng.upload_reads(r["tid"][lo:hi], r["pos"][lo:hi], r["rev"][lo:hi], r["cig_off"][lo:hi + 1] - c0, r["cig"][c0:c1], first_read_index=base + lo)
-        eng.run()
-        eng.sync()
-        return DeviceShard(eng)
+        # One engine shard holds fewer than 2^32 reads + CIGAR operations (32-bit exon offsets on the device: host/cmds.c run_engine cuts
+        # the one-process CLI's input the same way).  A rank's shard beyond that is classified piece by piece -- consecutive uploads,
+        # first_read_index running on, so the engine carries its cursors from piece to piece -- and the results come back to the host
+        # (L2R_CHUNK_READS: reads per piece, tests force small pieces with it).
+        limit = int(os.environ.get("L2R_CHUNK_READS", "0") or 0)
+        max_units = 0xf0000000
+        if (hi - lo) + (c1 - c0) < max_units and not (limit and hi - lo > limit):
+            eng.upload_reads(r["tid"][lo:hi], r["pos"][lo:hi], r["rev"][lo:hi], r["cig_off"][lo:hi + 1] - c0, r["cig"][c0:c1], first_read_index=base + lo)
+            eng.run()
+            eng.sync()
+            return DeviceShard(eng)
+        eng.set_outputs(capi.WANT_RESULTS)                  # (the caller takes what it needs from the full results: HostShard)
+        parts, a = [], lo
+        while a < hi:
+            units = (r["cig_off"][a:hi + 1] - r["cig_off"][a]) + np.arange(hi - a + 1, dtype=np.int64)
+            b = a + max(1, int(np.searchsorted(units, max_units, side="left")) - 1)
+            if limit:
+                b = min(b, a + limit)
+            b = min(b, hi)
+            ca, cb = int(r["cig_off"][a]), int(r["cig_off"][b])
+            if (b - a) + (cb - ca) >= 0xfffffff0:
+                raise RuntimeError("record %d alone exceeds the engine's shard limit" % (base + a))
+            eng.upload_reads(r["tid"][a:b], r["pos"][a:b], r["rev"][a:b], r["cig_off"][a:b + 1] - ca, r["cig"][ca:cb], first_read_index=base + a)
+            eng.run()
+            eng.sync()
+            parts.append(eng.download())
+            a = b
+        offs, x = [np.zeros(1, np.int64)], 0
+        for q in parts:
+            offs.append(q.ex_off[1:] + x)
+            x += int(q.ex_off[-1])
+        return capi.Result(np.concatenate(offs), np.concatenate([q.ex_start for q in parts]), np.concatenate([q.ex_end for q in parts]),
+                           np.concatenate([q.ex_flag for q in parts]), np.concatenate([q.info for q in parts]), np.concatenate([q.ref_tx for q in parts]))
     run.engine = eng
     return run
 

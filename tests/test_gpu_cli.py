@@ -196,7 +196,7 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("route", ["partitioned", "gathered_full", "gathered_accepted", "unsorted"])
+@pytest.mark.parametrize("route", ["partitioned", "gathered_full", "gathered_accepted", "unsorted", "partitioned_in_pieces", "gathered_accepted_in_pieces"])
 def test_ranks_on_the_engine_write_the_single_gpu_files(oracle, tmp_path, files, route):
     """`python -m lr2rmats_amd.dist` with the real engine behind every rank: three ranks share GPU 0 (gloo as the
     transport: RCCL wants one GPU per rank, the driver's 8-GPU run covers that); the shard results are read from the
@@ -205,6 +205,8 @@ def test_ranks_on_the_engine_write_the_single_gpu_files(oracle, tmp_path, files,
     import sys
     d, anno, reads, sam, bam, gtf = files
     aln = bam
+    pieces = route.endswith("_in_pieces")               # a rank's shard beyond the engine's shard limit: several uploads per rank (dist.py)
+    route = route.replace("_in_pieces", "")
     if route == "unsorted":
         aln = str(tmp_path / "u.bam")
         synth.write_bam(synth.make_reads(anno, 20000, 5, 45, unsorted=True), aln)
@@ -225,6 +227,8 @@ def test_ranks_on_the_engine_write_the_single_gpu_files(oracle, tmp_path, files,
                    L2R_DIST_BACKEND="gloo", L2R_DIST_TRACE=trace, HSA_ENABLE_IPC_MODE_LEGACY="0")
         if route.startswith("gathered"):
             env["L2R_DIST_GATHER"] = "1"
+        if pieces:
+            env["L2R_CHUNK_READS"] = "1500"
         procs.append(subprocess.Popen([sys.executable, "-m", "lr2rmats_amd.dist"] + args(many), env=env, stderr=subprocess.PIPE,
                                       stdout=subprocess.DEVNULL, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     for p in procs:
