@@ -747,10 +747,11 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     for (int64_t i = 0, start = 0; i <= N; ++i) {
         if (i == N) { if (i > start) tile_first.push_back((uint32_t)start); break; }
         const uint64_t need = slab_tiles ? (uint64_t)slab_rows_of((uint32_t)std::min<int64_t>(r->cig_off[i + 1] - r->cig_off[i], 0x7ffffff0)) : 0u;
-        // (slab tiles also end where the reads would begin 2^17 bases apart: a tile's exons are kept relative to its first base, and
-        //  its dictionary slices cover 196 kb -- sparse stretches give small tiles instead of tiles for the generic kernel)
+        // (tiles of sorted records also end where the reads would begin 2^17 bases apart: a slab tile's exons are kept relative to its
+        //  first base, and any tile's dictionary slices cover 196 kb -- sparse stretches give small tiles instead of tiles for the
+        //  generic kernel; the classic pipeline, whose tiles own 24 KB of hand-over buffer each, keeps at least 8 reads per tile)
         if (i - start == rpt || (sorted && r->tid[i] != r->tid[start]) || (i > start && pos_sum + need > (uint64_t)SLAB_POS_CAP) ||
-            (slab_tiles && i > start && (int64_t)r->pos[i] - (int64_t)r->pos[start] >= (int64_t)SLAB_TILE_SPAN)) { tile_first.push_back((uint32_t)start); start = i; pos_sum = 0; }
+            (sorted && i > start && (int64_t)r->pos[i] - (int64_t)r->pos[start] >= (int64_t)SLAB_TILE_SPAN && (slab_tiles || i - start >= 8))) { tile_first.push_back((uint32_t)start); start = i; pos_sum = 0; }
         pos_sum += need;
     }
     c->n_tiles = (int64_t)tile_first.size();

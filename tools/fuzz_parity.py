@@ -1,0 +1,58 @@
+"""Diagnostics on the GPU box: the HIP path against the oracle on many small random workloads -- annotation shape (isoforms per
+gene from 1 to 160: windows of every size, dictionary keys in parts), exons per read, ONT-like CIGARs, every -l level, the CIGAR
+thresholds (-e / -i / -t), sparse and dense coverage.  tools/fuzz_parity.py [rounds] [seed]; prints the first differing case and
+exits 1.  Not part of the product."""
+import os
+import sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from lr2rmats_amd import capi, synth
+from oracle import pyoracle as po
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+po.build()
+bad = 0
+for it in range(rounds):
+    tpg = int(rng.choice([1, 3, 5, 12, 40, 70, 110, 160]))
+    n_ex = int(rng.integers(2, 15))
+    anno_exons = int(rng.choice([3000, 20000, 120000]))
+    n_reads = int(rng.choice([3000, 40000, 150000]))
+    ont = bool(rng.random() < 0.2)
+    seed = int(rng.integers(1, 1 << 30))
+    level = int(rng.integers(0, 6))
+    prm = dict(full_level=level, min_exon=int(rng.choice([3, 3, 3, 0, 1, 25])), min_intron=int(rng.choice([3, 3, 40])), max_delet=int(rng.choice([50, 50, 4])))
+    anno = synth.make_annotation(anno_exons, seed, mean_tx_exons=n_ex + 1, tx_per_gene=tpg)
+    af = anno.in_file_order()
+    reads = synth.make_reads(anno, n_reads, n_ex, seed + 7, ont=ont, micro_exons=3 if ont else 0, xs_conflict_frac=0.02 if ont else 0.0)
+    e = capi.Engine(0)
+    e.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
+    got = e.classify(reads, capi.default_params(**prm))
+    cnt = None
+    try:
+        import ctypes as C
+        lib = capi.load_library()
+        c = (C.c_longlong * 13)()
+        lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.l2r_debug_counters(e.ctx, c, 13)
+        cnt = (int(c[0]), int(c[1]), int(c[3]), int(c[12]))
+    except Exception:
+        pass
+    e.close()
+    want = po.classify_soa(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, af.tx_tid, af.tx_start, af.tx_end, af.tx_rev,
+                           af.tx_ex_off, af.ex_start, af.ex_end, params=po.default_params(**prm))
+    diffs = {}
+    for name in ("ex_off", "ex_start", "ex_end", "ex_flag", "ref_tx"):
+        a, b = getattr(got, name), getattr(want, name)
+        if len(a) != len(b) or np.any(a != b):
+            diffs[name] = int(np.sum(a[:min(len(a), len(b))] != b[:min(len(a), len(b))])) + abs(len(a) - len(b))
+    d = np.nonzero((got.info & 0x7f) != (want.info & 0x7f))[0]
+    if len(d):
+        diffs["info"] = (len(d), d[:5].tolist())
+    tag = "tpg %3d n_ex %2d anno %6d reads %6d ont %d seed %d %s (redo, keys in parts, tiles, wide list: %s)" % (tpg, n_ex, anno_exons, n_reads, ont, seed, prm, cnt)
+    print(("DIFF " if diffs else "ok   ") + tag, diffs if diffs else "", flush=True)
+    bad += 1 if diffs else 0
+    if diffs:
+        break
+print("fuzz_parity: %d rounds, %d with differences" % (it + 1, bad))
+sys.exit(1 if bad else 0)
