@@ -762,9 +762,11 @@ static int bam_key_le(int32_t t0, int32_t p0, int32_t t1, int32_t p1)
 }
 
 /* S(r) for r > 0 (see above): returns 1 and *S (coff == fsz: the end of the file), 0 when no record boundary was found;
- * *inflated += compressed bytes inflated */
-static int bam_find_start(FILE *f, int64_t fsz, int64_t c0, int32_t n_ref, vpos *S, int64_t *inflated, const char *who)
+ * *next_begins_before = 1 when a record between B(r) and S(r) already lies at or behind block c1, the next rank's first block: then
+ * B(r + 1) is on B(r)'s chromosome, S(r + 1) = S(r), and this rank has no records; *inflated += compressed bytes inflated */
+static int bam_find_start(FILE *f, int64_t fsz, int64_t c0, int64_t c1, int32_t n_ref, vpos *S, int *next_begins_before, int64_t *inflated, const char *who)
 {
+    *next_begins_before = 0;
     if (c0 >= fsz) { S->coff = fsz; S->uoff = 0; return 1; }
     uint8_t *buf = NULL; size_t n = 0, cap = 0;
     size_t cap_blk = 1024, n_blk = 0;
@@ -802,12 +804,14 @@ static int bam_find_start(FILE *f, int64_t fsz, int64_t c0, int32_t n_ref, vpos 
     (void)first_len;
     if (!found) { free(buf); free(blk_off); free(blk_out); return 0; }
     /* from B(r) on until the chromosome changes */
-    size_t q = o; int32_t tid0 = 0; int have = 0;
+    size_t q = o, kq = 0; int32_t tid0 = 0; int have = 0;
     for (;;) {
         while (!eof && n < q + 36) MORE();
-        if (q + 4 > n) { S->coff = fsz; S->uoff = 0; break; }                  /* no other chromosome behind B(r) */
+        if (q + 8 > n) { S->coff = fsz; S->uoff = 0; break; }                  /* no other chromosome behind B(r) */
         const uint32_t bs = le32(buf + q);
         const int32_t t = (int32_t)le32(buf + q + 4);
+        while (kq + 1 < n_blk && blk_out[kq + 1] <= q) ++kq;                    /* (the block the record begins in) */
+        if ((!have || t == tid0) && blk_off[kq] >= c1) *next_begins_before = 1;
         if (!have) { tid0 = t; have = 1; }
         else if (t != tid0) {
             size_t k = n_blk - 1;
@@ -827,7 +831,7 @@ static int bam_find_start(FILE *f, int64_t fsz, int64_t c0, int32_t n_ref, vpos 
                 memmove(buf, buf + shift, n - shift);
                 n -= shift; q -= shift;
                 for (size_t i = k; i < n_blk; ++i) { blk_off[i - k] = blk_off[i]; blk_out[i - k] = blk_out[i] - shift; }
-                n_blk -= k;
+                n_blk -= k; kq = 0;
             }
         }
     }
@@ -851,15 +855,17 @@ int h_read_alignments_blocks(const char *fn, h_chroms *chr, h_reads *out, int sk
     const int32_t n_ref = (int32_t)chr->n_hdr;
     int64_t inflated = 0;
     vpos S = first;
-    if (rank > 0 && !bam_find_start(f, fsz, bgzf_block_from(f, fsz, fsz / world * rank), n_ref, &S, &inflated, who)) { fclose(f); return 0; }
     const int64_t c1 = rank + 1 < world ? bgzf_block_from(f, fsz, fsz / world * (rank + 1)) : fsz;
+    int empty = 0;
+    if (rank > 0 && !bam_find_start(f, fsz, bgzf_block_from(f, fsz, fsz / world * rank), c1, n_ref, &S, &empty, &inflated, who)) { fclose(f); return 0; }
     info[0] = S.coff; info[1] = S.uoff; info[5] = fsz;
     reads_reserve(out, 1, 1);
     out->cig_off[0] = 0;
     /* the rank's records: windows of whole blocks from S on (inflated block-parallel), until the first record at or behind block c1
      * has been followed by a record of another chromosome */
     vpos E; E.coff = fsz; E.uoff = 0;
-    if (S.coff < fsz) {
+    if (empty) E = S;                                       /* (the next rank begins where this one does) */
+    if (S.coff < fsz && !empty) {
         h_aln_stream st; memset(&st, 0, sizeof st);
         st.f = f; st.who = who; st.chr = chr; st.skip_unmapped = skip_unmapped; st.header_done = 1;
         size_t big = (size_t)64 << 20;

@@ -1075,6 +1075,24 @@ int h_main(int argc, char **argv)
     if (strcmp(argv[0], "filter") == 0) return h_cmd_filter(argc, argv);
     /* (diagnostics, no GPU: every record of a SAM / BAM file written out as BAM -- reader, encoder and BGZF writer of `filter`) */
     if (strcmp(argv[0], "records2bam") == 0 && argc == 3) return h_records_to_bam(argv[1], argv[2]) ? 1 : 0;
+    /* (diagnostics, no GPU: the block ranges `world` ranks of a multi-process run would inflate of a BAM file, one line per rank:
+     *  rank, start and end (block offset : offset inside), compressed bytes inflated, records; last line: whether the ranges meet) */
+    if (strcmp(argv[0], "bam-shards") == 0 && argc == 3) {
+        const int world = atoi(argv[2]);
+        int64_t prev_end[2] = {0, 0}, total = 0; int ok = world >= 1;
+        for (int r = 0; r < world && ok; ++r) {
+            h_chroms chr; memset(&chr, 0, sizeof chr);
+            h_reads rd; int64_t info[8];
+            if (!h_read_alignments_blocks(argv[1], &chr, &rd, 0, "bam-shards", r, world, info)) { printf("rank %d: not readable by block ranges\n", r); ok = 0; break; }
+            printf("rank %d: %lld:%lld .. %lld:%lld, %lld of %lld bytes inflated, %lld records\n", r, (long long)info[0], (long long)info[1], (long long)info[2],
+                   (long long)info[3], (long long)info[4], (long long)info[5], (long long)info[6]);
+            if (r && (info[0] != prev_end[0] || info[1] != prev_end[1])) ok = 0;
+            prev_end[0] = info[2]; prev_end[1] = info[3]; total += info[6];
+            h_reads_free(&rd);
+        }
+        printf("%s, %lld records\n", ok ? "ranges meet" : "RANGES DO NOT MEET", (long long)total);
+        return ok ? 0 : 1;
+    }
     if (!strcmp(argv[0], "fusion") || !strcmp(argv[0], "bam2sj")) {
         fprintf(stderr, "[main] command '%s' is outside the MI355X build (see DESIGN.md, scope)\n", argv[0]);
         return 1;
