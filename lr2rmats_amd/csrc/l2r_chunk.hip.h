@@ -14,9 +14,11 @@
 //               than the break)
 //
 // The tile's exons are copied from the slab to their positions in LDS once; the probe rounds of every chunk read them there.
-// Entries: k_probe_slab appends the tiles it finds without a window ("window > 32" after k_walk_slab tried a 64-bit record), and it
-// and k_probe_slab_wide the tiles whose dictionary slices hold a key in several entries (SE_WIDE: the key's transcripts lie more
-// than 64 apart in the annotation, l2r_engine.hip build_dict) -- the probes here OR the parts of a key, each re-based to the chunk.
+// Its tiles (slab_tile_is_chunked, listed by TileLists between the walk and the probes): the ones k_walk_slab found no window record for ("window >
+// 32" after it tried a 64-bit record, or dictionary slices beyond the one-window kernels' staging), and the ones k_probe_slab or
+// k_probe_slab_wide flagged TD_CHUNK because their dictionary slices hold a key in several entries (SE_WIDE: the key's transcripts
+// lie more than 64 apart in the annotation, l2r_engine.hip build_dict) -- the probes here OR the parts of a key, each re-based to the
+// chunk.
 // Of a tile's dictionary slices a chunk stages only the entries that can say something about its 63 members (the others re-base to
 // nothing): a counting sort by bucket into up to CHUNK_KEY_CAP places per dictionary; a chunk beyond that sends the tile to the
 // generic kernel.
@@ -26,7 +28,6 @@
 
 namespace l2r {
 
-struct ChunkArgs { uint32_t *count; const uint32_t *tile; };        // count[0]: entries, count[1]: the grid's work cursor
 constexpr int CHUNK_KEY_CAP = 320;                                  // dictionary entries staged per dictionary and chunk (39.5 KB of LDS per workgroup: 4 per CU)
 struct ChunkLds { const WEnt *ent0, *ent1; const uint32_t *dir0, *dir1, *rdir; const int4 *hk, *hx; const int *win; };
 constexpr int CHUNK_SCAN_TRIPS = 4096;                              // 64-transcript trips one chunk's scan may take (then: generic kernel)
@@ -184,7 +185,7 @@ __device__ __forceinline__ int chunk_window(PipeArgsK a, int lane, int32_t tid0,
 
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, 4)
-void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *__restrict__ u_tile_first, const int32_t *__restrict__ u_pos,
+void k_probe_slab_chunked(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const int32_t *__restrict__ u_pos,
                           const uint32_t *__restrict__ u_tile_sbase, const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase)
 {
     constexpr int DIR_N = FAST_DIR_BYTES;                   // directory words per dictionary (group 0 = the reach-back entries in front of the first bucket, bucket b = group b + 1, three closing words)
@@ -205,14 +206,15 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, ChunkArgs ca, const uint32_t *
     const int lane = threadIdx.x & (WAVE - 1);
     WEnt *const s_ent0 = s_ent, *const s_ent1 = s_ent + CHUNK_KEY_CAP;
     uint32_t *const X0 = s_dir, *const X1 = s_dir + DIR_N, *const XR = s_dir + 2 * DIR_N;
-    const uint32_t n_list = min(ca.count[0], (uint32_t)sa->n_tiles);
+    // the tiles of this kernel: chunk_list (TileLists + what the one-window kernels appended), taken from a cursor
+    const uint32_t n_list = min(sa->list_cnt[1], (uint32_t)sa->n_tiles);
     for (bool own = true;; own = false) {
         if (own && blockIdx.x >= n_list) break;
-        if (threadIdx.x == 0) s_next = own ? blockIdx.x : gridDim.x + atomicAdd(ca.count + 1, 1u);
+        if (threadIdx.x == 0) s_next = own ? blockIdx.x : gridDim.x + atomicAdd(sa->list_cnt + 3, 1u);
         __syncthreads();
         const uint32_t wi = s_next;
         if (wi >= n_list) break;
-        const uint32_t t = ca.tile[wi];
+        const uint32_t t = sa->chunk_list[wi];
         const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
         const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t], total = u_xbase[t + 1u] - xbase;
         const int32_t tile_lo = u_pos[r0] + 1;

@@ -74,7 +74,7 @@ struct l2r_ctx {
     DevBuf<int32_t> dense_start, dense_end;                 // slab pipeline: the outliers' dense area
     DevBuf<uint32_t> slab_row;                              //                the exon rows between its kernels (one word per exon)
     DevBuf<TileWin> tw;
-    DevBuf<TileWin64> tw64; DevBuf<uint32_t> wide_cnt, wide_tile, chunk_cnt, chunk_tile; uint32_t wide_cap = 0;     // tiles with 33 .. 63 window members (l2r_wide.hip.h)
+    DevBuf<TileWin64> tw64; DevBuf<uint32_t> wide_list, chunk_list, list_cnt, tile_flags;     // tiles with 33 .. 63 window members (l2r_wide.hip.h)
     DevBuf<unsigned long long> ovf_cursor;
     std::string anno_cache_dir;             // L2R_ANNO_CACHE / l2r_set_annotation_cache: where the annotation tables are kept between runs
     int anno_cache_state = 0;               // last l2r_set_annotation: 0 no cache, 1 built + stored, 2 read from the cache
@@ -223,7 +223,7 @@ void l2r_destroy(l2r_ctx *c)
     c->win_start.release(); c->sj_cursor.release();
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
-    c->tile_total.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_cnt.release(); c->wide_tile.release(); c->chunk_cnt.release(); c->chunk_tile.release();
+    c->tile_total.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_list.release(); c->chunk_list.release(); c->list_cnt.release(); c->tile_flags.release();
     c->slab_row.release(); c->dense_start.release(); c->dense_end.release(); c->s_pre.release(); c->s_loc.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -815,10 +815,8 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         if (total < 0x7ffffff0ULL && ovf < 0x7ffffff0ULL) {
             sbase[T] = (uint32_t)total;                     // (rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true;
-            c->wide_cap = (uint32_t)(T + 1);                // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB each)
-            if (c->tw64.ensure(c->wide_cap) || c->wide_cnt.ensure(4) || c->wide_tile.ensure(c->wide_cap) || c->chunk_cnt.ensure(2) || c->chunk_tile.ensure(T + 1)) return -2;
-            HIP_TRY(hipMemsetAsync(c->wide_cnt.p, 0, 16, c->stream));
-            HIP_TRY(hipMemsetAsync(c->chunk_cnt.p, 0, 8, c->stream));
+            if (c->tw64.ensure(T + 1) || c->wide_list.ensure(T + 1) || c->chunk_list.ensure(T + 1) || c->list_cnt.ensure(4) || c->tile_flags.ensure(T + 8)) return -2;      // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB each)
+            HIP_TRY(hipMemsetAsync(c->list_cnt.p, 0, 16, c->stream));
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) || c->tile_total.ensure(T + 2) ||
                 c->s_pre.ensure((size_t)N + 1) || c->s_loc.ensure((size_t)N + 1) ||
                 c->slab_row.ensure((size_t)total + 4) ||
@@ -963,8 +961,9 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         sa.pre = c->s_pre.p; sa.loc = c->s_loc.p; sa.tw = c->tw.p;
         sa.n_tiles = (uint32_t)c->n_tiles;
         const unsigned gx = 8u * (unsigned)std::max<int64_t>((c->n_tiles + 7) / 8, 1);      // (l2r_slab.hip.h xcd_tile; an empty upload still launches)
-        sa.wide_cnt = c->wide_cnt.p; sa.wide_tile = c->wide_tile.p; sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p; sa.wide_cap = c->wide_cap;
-        sa.chunk_cnt = (c->ablate & 32) ? nullptr : c->chunk_cnt.p; sa.chunk_tile = c->chunk_tile.p;      // (L2R_ABLATE bit 5: no chunked windows)      // (L2R_ABLATE bit 2: no 64-member windows)
+        sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p;
+        sa.chunk_on = (c->ablate & 32) ? 0u : 1u;          // (L2R_ABLATE bit 2: no 64-member windows, bit 5: no chunked windows)
+        sa.wide_list = c->wide_list.p; sa.chunk_list = c->chunk_list.p; sa.list_cnt = c->list_cnt.p; sa.tile_flags = c->tile_flags.p;
         if (p.min_exon >= 1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_slab<false>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p,
                                (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
@@ -973,8 +972,10 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
                                (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
         MARK(ST_SCAN1);
         {   // the tiles' exon counts -> their first slots in the read-order result arrays (in place; the sum = the exon count)
-            ScanJobs jobs; jobs.job[0] = ScanJob{c->tile_total.p, c->n_tiles, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
-            hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, jobs);
+            // (block 1 of the same launch lists the tiles of the 64-bit-mask and the chunked kernel from the descriptors: TileLists)
+            ScanJobs jobs = {}; jobs.job[0] = ScanJob{c->tile_total.p, c->n_tiles, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
+            jobs.lists = TileLists{c->tile_flags.p, (uint32_t)c->n_tiles, sa.chunk_on, c->wide_list.p, c->chunk_list.p, c->list_cnt.p};
+            hipLaunchKernelGGL(k_scan_u32, dim3(2), dim3(1024), 0, s, jobs);
         }
         MARK(ST_FAST);
 #define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
@@ -989,8 +990,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         }
 #undef launch_probe_level
         {   // the tiles with 33 .. 63 window members (none on most inputs: the grid finds an empty list and leaves)
-            const WideArgs wa{c->wide_cnt.p + 1, c->wide_tile.p, c->tw64.p};
-            const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 6);
+            const WideArgs wa{c->tw64.p};
+            const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 5);
 #define launch_wide_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_wide<L>), dim3(gw), dim3(TILE_THREADS), 0, s, sa, wa, (const uint32_t *)c->tile_first.p, \
                 (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_total.p)
             switch (p.full_level) {
@@ -1003,10 +1004,9 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             }
 #undef launch_wide_level
         }
-        if (sa.chunk_cnt) {   // the tiles without a window record (k_probe_slab's list: empty on most inputs)
-            const ChunkArgs ca{c->chunk_cnt.p, c->chunk_tile.p};
+        if (sa.chunk_on) {   // the tiles without a window record, or with a dictionary key in several entries (none on most inputs)
             const unsigned gc = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 4);
-#define launch_chunk_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_chunked<L>), dim3(gc), dim3(TILE_THREADS), 0, s, sa, ca, (const uint32_t *)c->tile_first.p, \
+#define launch_chunk_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_chunked<L>), dim3(gc), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
                 (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_total.p)
             switch (p.full_level) {
             case 1: launch_chunk_level(1); break;
@@ -1032,7 +1032,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
                        c->totals.p + 3, (const TxHdr *)c->hdr.p, c->win_hdr.p, (const uint32_t *)c->tile_first.p, c->walked.p);
     MARK(ST_SCAN1);
     {
-        ScanJobs jobs; jobs.job[0] = ScanJob{c->tile_base.p, c->n_tiles, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
+        ScanJobs jobs = {}; jobs.job[0] = ScanJob{c->tile_base.p, c->n_tiles, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
         hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, jobs);
     }
     MARK(ST_FAST);
@@ -1068,7 +1068,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     }
     MARK(ST_SCAN2);
     if (c->want & L2R_WANT_ACCEPTED) {
-        ScanJobs jobs; jobs.job[0] = ScanJob{c->tile_acc.p, c->n_tiles, c->totals.p + 1}; jobs.job[1] = ScanJob{c->tile_acc_ex.p, c->n_tiles, c->totals.p + 2};
+        ScanJobs jobs = {}; jobs.job[0] = ScanJob{c->tile_acc.p, c->n_tiles, c->totals.p + 1}; jobs.job[1] = ScanJob{c->tile_acc_ex.p, c->n_tiles, c->totals.p + 2};
         hipLaunchKernelGGL(k_scan_u32, dim3(2), dim3(1024), 0, s, jobs);
     }
     MARK(ST_GATHER);
@@ -1107,16 +1107,15 @@ int l2r_debug_counters(l2r_ctx *c, long long *out, int n)
     if (c->totals.p) { HIP_TRY(hipMemcpyAsync(&redo, c->totals.p + 3, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     out[0] = redo; out[1] = c->n_wide; out[2] = c->n_compact; out[3] = c->n_tiles;
     if (n >= 12) for (int k = 0; k < 8; ++k) out[4 + k] = 0;
-    if (n >= 13) {                                          // out[12]: tiles the last run gave to k_probe_slab_wide (33 .. 63 window members)
-        uint32_t w = 0;
-        if (c->slab && c->ran && c->wide_cnt.p) { HIP_TRY(hipMemcpyAsync(&w, c->wide_cnt.p + 1, 4, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
-        out[12] = w;
-    }
-    if (n >= 12 && c->slab && c->ran && c->tw.p && c->n_tiles > 0) {     // slab pipeline: the descriptors k_walk_slab made
+    if (n >= 13) out[12] = 0;
+    if (n >= 12 && c->slab && c->ran && c->tw.p && c->n_tiles > 0) {     // slab pipeline: the descriptors k_walk_slab made (flags as the probe kernels left them)
         std::vector<TileWin> w((size_t)c->n_tiles);
         HIP_TRY(hipMemcpyAsync(w.data(), c->tw.p, w.size() * sizeof(TileWin), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        for (const TileWin &t : w) out[4 + ((t.d.flags >> 8) & 7u)]++;
+        for (const TileWin &t : w) {
+            out[4 + ((t.d.flags >> 8) & 7u)]++;
+            if (n >= 13 && (t.d.flags & TD_WIDE) && !(t.d.flags & TD_CHUNK)) out[12]++;     // out[12]: tiles k_probe_slab_wide classified (33 .. 63 window members)
+        }
     } else if (n >= 12 && !c->slab && c->desc.p && c->n_tiles > 0) {     // out[4 + k]: tiles that are not fast for reason k (k_pass_a), k = 0: fast
         std::vector<TileDesc> d((size_t)c->n_tiles);
         HIP_TRY(hipMemcpyAsync(d.data(), c->desc.p, d.size() * sizeof(TileDesc), hipMemcpyDeviceToHost, c->stream));

@@ -100,6 +100,7 @@ constexpr uint32_t CHUNK_DEFERRED = 0xffffffffu;   // tile_chunk: the tile's acc
 constexpr uint32_t TD_FAST = 1;    // exons fit the LDS tile, dictionary slices fit DIR_CAP / KEY_CAP, window fits WIN_TX
 constexpr uint32_t TD_WALKED = 4;  // long-CIGAR input: pass A has left the tile's exons in `walked` (tile * LDS_EXON_CAP + in-tile offset)
 constexpr uint32_t TD_WIDE = 8;    // slab pipeline: the window holds 33 .. 63 transcripts (l2r_wide.hip.h takes the tile), TD_FAST is not set
+constexpr uint32_t TD_CHUNK = 16;  // slab pipeline: set by k_probe_slab / k_probe_slab_wide on a tile that stages a dictionary key in several entries: k_probe_slab_chunked takes it
 constexpr uint32_t TD_CONTIG = 2;  // the window's transcripts are consecutive in the annotation: j_lo, j_lo + 1, ...
 constexpr int WIN_SCAN_TRIPS = 64; // pass A looks at up to 64 * WIN_SCAN_TRIPS transcripts for a tile's window
 
@@ -600,7 +601,19 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
 // 16-byte loads in flight together: the kernel is a chain of load -> scan -> store round trips, so fewer, wider rounds);
 // v[n] receives the sum (the array has n + 1 words) and so does *total.  blockIdx.x selects the array.
 struct ScanJob { uint32_t *v; int64_t n; uint32_t *total; };
-struct ScanJobs { ScanJob job[2]; };
+// lists: block 1 of a two-block launch (slab pipeline) does not scan: it lists the tiles of k_probe_slab_wide (TD_WIDE) and of
+// k_probe_slab_chunked (slab_tile_is_chunked) from the descriptors k_walk_slab left -- in tile order, beside the scan of the tiles' exon
+// counts, so the lists cost no launch and no tile appends to a shared counter (40 k appends to one address take 0.4 ms).
+// cnt[0] / cnt[1] = entries, cnt[2] / cnt[3] = the two kernels' work cursors (cleared here).
+struct TileLists { const uint32_t *flags0; uint32_t n_tiles, chunk_on; uint32_t *wide_list, *chunk_list, *cnt; };      // flags0: every tile's descriptor flags, densely (k_walk_slab)
+struct ScanJobs { ScanJob job[2]; TileLists lists; };
+// a tile k_probe_slab_chunked takes (l2r_chunk.hip.h): no window record (window beyond 63 members, dictionary slices beyond the
+// one-window kernels' staging) or flagged by a one-window kernel that found a dictionary key in several entries
+__device__ __forceinline__ bool slab_tile_is_chunked(uint32_t flags)
+{
+    const uint32_t why = (flags >> 8) & 7u;
+    return (flags & TD_CHUNK) != 0u || ((flags & (TD_FAST | TD_WIDE)) == 0u && (why == 4u || why == 3u));
+}
 constexpr int SCAN_PER_THREAD = 16;
 
 __global__ __launch_bounds__(1024)
@@ -608,6 +621,52 @@ void k_scan_u32(ScanJobs jobs)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
+    if (blockIdx.x == 1 && jobs.lists.flags0) {
+        // the tile lists, 16 tiles per thread and round like the scan below (four 16-byte loads in flight per thread): count, block
+        // scan of the counts, write in tile order behind what the rounds before have listed
+        __shared__ uint32_t s_w2[16];
+        __shared__ uint32_t s_base[2];
+        const TileLists L = jobs.lists;
+        const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+        if (threadIdx.x == 0) { s_base[0] = 0u; s_base[1] = 0u; }
+        __syncthreads();
+        for (uint32_t base = 0; base < L.n_tiles; base += 1024u * (uint32_t)SCAN_PER_THREAD) {
+            const uint32_t i = base + (uint32_t)SCAN_PER_THREAD * threadIdx.x;
+            uint32_t f[SCAN_PER_THREAD];
+            if (i + SCAN_PER_THREAD <= L.n_tiles) {
+#pragma unroll
+                for (int q = 0; q < SCAN_PER_THREAD / 4; ++q) {
+                    const uint4 t = *reinterpret_cast<const uint4 *>(L.flags0 + i + 4 * q);
+                    f[4 * q] = t.x; f[4 * q + 1] = t.y; f[4 * q + 2] = t.z; f[4 * q + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < SCAN_PER_THREAD; ++q) f[q] = i + q < L.n_tiles ? L.flags0[i + q] : TD_FAST;        // (behind the last tile: nobody's)
+            }
+            uint32_t nw = 0, nc = 0;
+#pragma unroll
+            for (int q = 0; q < SCAN_PER_THREAD; ++q) { nw += (f[q] & TD_WIDE) ? 1u : 0u; nc += (L.chunk_on && slab_tile_is_chunked(f[q])) ? 1u : 0u; }
+            const uint32_t iw = wave_inclusive_scan(nw), ic = wave_inclusive_scan(nc);
+            if (lane == WAVE - 1) { s_wave[w] = iw; s_w2[w] = ic; }
+            __syncthreads();
+            uint32_t bw = 0, bc = 0, tw_ = 0, tc_ = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { if (k < w) { bw += s_wave[k]; bc += s_w2[k]; } tw_ += s_wave[k]; tc_ += s_w2[k]; }
+            uint32_t aw = s_base[0] + bw + iw - nw, ac = s_base[1] + bc + ic - nc;
+            if (nw | nc) {
+#pragma unroll
+                for (int q = 0; q < SCAN_PER_THREAD; ++q) {
+                    if (f[q] & TD_WIDE) L.wide_list[aw++] = i + (uint32_t)q;
+                    if (L.chunk_on && slab_tile_is_chunked(f[q])) L.chunk_list[ac++] = i + (uint32_t)q;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) { s_base[0] += tw_; s_base[1] += tc_; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { L.cnt[0] = s_base[0]; L.cnt[1] = s_base[1]; L.cnt[2] = 0u; L.cnt[3] = 0u; }
+        return;
+    }
     uint32_t *__restrict__ v = jobs.job[blockIdx.x].v;
     const int64_t n = jobs.job[blockIdx.x].n;
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;

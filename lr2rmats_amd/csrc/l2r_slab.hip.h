@@ -69,11 +69,14 @@ struct SlabArgs {
     unsigned long long *ovf_cursor;                      // next free element of the dense area
     uint32_t *pre, *loc;                                 // k_walk_slab -> k_probe_slab, slot order: PRE_* word; exons of the tile's reads before this one (read order)
     TileWin *tw;                                         // k_walk_slab -> k_probe_slab: descriptor + window per tile
-    // tiles whose window holds 33 .. 63 transcripts (l2r_wide.hip.h): wide_cnt[0] counts the appends of k_walk_slab, k_probe_slab
-    // moves the count to wide_cnt[1] (what k_probe_slab_wide reads) and clears [0] for the next run
-    uint32_t *wide_cnt; uint32_t *wide_tile; TileWin64 *tw64; uint32_t wide_cap;
-    // tiles without a window record (l2r_chunk.hip.h): k_probe_slab appends them, chunk_cnt[0] = entries, [1] = k_probe_slab_chunked's work cursor
-    uint32_t *chunk_cnt; uint32_t *chunk_tile;
+    // tw64[tile]: the 64-member window record of a tile whose window holds 33 .. 63 transcripts (TD_WIDE).  The tiles of
+    // k_probe_slab_wide / k_probe_slab_chunked are listed by block 1 of the scan launch between the walk and the probes (TileLists,
+    // l2r_kernels.hip.h): wide_list / chunk_list, list_cnt[0] / [1] = entries, [2] / [3] = the kernels' work cursors.  A one-window
+    // kernel that finds a dictionary key in several entries appends its tile to chunk_list (rare).  chunk_on 0: no chunked windows.
+    TileWin64 *tw64;
+    uint32_t *wide_list, *chunk_list, *list_cnt;
+    uint32_t *tile_flags;                                // every tile's descriptor flags once more, densely (what TileLists reads)
+    uint32_t chunk_on;
     uint32_t n_tiles;
 };
 typedef const __attribute__((address_space(4))) SlabArgs *SlabArgsK;
@@ -249,7 +252,6 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
         // (The cursor of the outlier area is cleared by k_probe_slab for the next run.)
         uint32_t *const cnt = a->f.redo_count;
         cnt[0] = 0u; cnt[1] = 0u; cnt[2] = 0u;
-        if (sa->chunk_cnt) { sa->chunk_cnt[0] = 0u; sa->chunk_cnt[1] = 0u; }
     }
     __syncthreads();
     // ---- every read's place among the tile's exons in READ order: each wave scans the 256 counts (four per lane) for itself
@@ -272,18 +274,11 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     const int32_t tile_hi = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
     make_descriptor(a, lane, tid0, pos0 + 1, tile_hi, true, &s_tw, (uint32_t)SLAB_KEY_CAP, sa->tw64 ? &s_tw64 : nullptr);
     if (s_tw.d.flags & TD_WIDE) {
-        // a window of 33 .. 63 members: the tile joins the list of k_probe_slab_wide, its 64-member record goes along
-        uint32_t at = 0;
-        if (lane == 0) at = atomicAdd(sa->wide_cnt, 1u);
-        at = __shfl(at, 0, WAVE);
-        if (at < sa->wide_cap) {
-            if (lane == 0) sa->wide_tile[at] = t;
-            for (int i = lane; i < (int)(sizeof(TileWin64) / 16); i += WAVE) reinterpret_cast<int4 *>(sa->tw64 + at)[i] = reinterpret_cast<const int4 *>(&s_tw64)[i];
-        } else if (lane == 0) {
-            s_tw.d.flags = (s_tw.d.flags & ~(TD_WIDE | (7u << 8))) | (4u << 8);     // list full: the tile is treated like one without a window record ("window > 32")
-        }
+        // a window of 33 .. 63 members: its 64-member record goes to tw64[tile], k_probe_slab_wide finds the tile by its flags
+        for (int i = lane; i < (int)(sizeof(TileWin64) / 16); i += WAVE) reinterpret_cast<int4 *>(sa->tw64 + t)[i] = reinterpret_cast<const int4 *>(&s_tw64)[i];
     }
     if (lane == 0) s_tw.pad[1] = (uint32_t)tile_hi;          // the tile's last base (k_probe_slab_chunked scans the window itself)
+    if (lane == 0) sa->tile_flags[t] = s_tw.d.flags;
     if (lane == 0) s_tw.pad[0] = s_wn[0] | (s_wn[1] << 8) | (s_wn[2] << 16) | (s_wn[3] << 24);     // rows each wave of k_probe_slab has to look at
     {   const uint32_t n_win = (s_tw.d.flags & TD_FAST) ? s_tw.d.n_win : 0u;
         for (int i = lane; i < SLAB_TW_VECS; i += WAVE) if (tw_vec_used(i, n_win)) reinterpret_cast<int4 *>(sa->tw + t)[i] = reinterpret_cast<const int4 *>(&s_tw)[i]; }
@@ -599,17 +594,11 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     //      (k_walk_slab), the slot's words and rows 0 .. 4 of its column (the last exon and the first four) -- all asked for
     //      before anything is looked at, and nothing of it at an address that depends on another load
     const TileDesc d = u_tw[t].d;
-    if (t == 0u && threadIdx.x == 0) {                           // (k_walk_slab is done: its count of wide tiles moves on, its counters are cleared for the next run)
-        if (sa->wide_cnt) { sa->wide_cnt[1] = min(sa->wide_cnt[0], sa->wide_cap); sa->wide_cnt[0] = 0u; sa->wide_cnt[2] = 0u; }      // ([2]: k_probe_slab_wide's work cursor)
-        *sa->ovf_cursor = 0ull;                                  // (the outlier area's)
-    }
+    if (t == 0u && threadIdx.x == 0) *sa->ovf_cursor = 0ull;      // (k_walk_slab is done: the outlier area's cursor is cleared for the next run)
     if (d.flags & TD_WIDE) return;                               // k_probe_slab_wide takes the tile
-    if (sa->chunk_cnt && (d.flags & (TD_FAST | TD_WIDE)) == 0u && (((d.flags >> 8) & 7u) == 4u || ((d.flags >> 8) & 7u) == 3u)) {
-        // no window record fits the tile's window, or its dictionary slices do not fit the staging here: k_probe_slab_chunked takes it,
-        // 63 members at a time, with the entries that matter for them
-        if (threadIdx.x == 0) sa->chunk_tile[atomicAdd(sa->chunk_cnt, 1u)] = t;
-        return;
-    }
+    // no window record fits the tile's window, or its dictionary slices do not fit the staging here: k_probe_slab_chunked takes it,
+    // 63 members at a time, with the entries that matter for them (it finds the tile by these flags)
+    if (sa->chunk_on && slab_tile_is_chunked(d.flags)) return;
     // the rows any read of this wave has (k_walk_slab): rows behind them are not asked for
     // thread -> slot: the slot groups (k_walk_slab: by falling CIGAR length, group 0 = the tile's longest reads) are rotated over
     // the waves by a hash of the tile number (L2R_ABLATE bit 3: off)
@@ -653,9 +642,9 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     }
     __syncthreads();
     const int any_wide = s_widew[0] | s_widew[1] | s_widew[2] | s_widew[3];
-    if (any_wide && sa->chunk_cnt) {
+    if (any_wide && sa->chunk_on) {
         // a key of the staged slices has several entries (its transcripts lie more than 64 apart): k_probe_slab_chunked ORs them
-        if (threadIdx.x == 0) sa->chunk_tile[atomicAdd(sa->chunk_cnt, 1u)] = t;
+        if (threadIdx.x == 0) { sa->tw[t].d.flags = d.flags | TD_CHUNK; sa->chunk_list[atomicAdd(sa->list_cnt + 1, 1u)] = t; }
         return;
     }
     // a read is staged when its positions fit and its rows have the tile's base

@@ -236,8 +236,7 @@ __device__ __forceinline__ Verdict decide64(const WideLds &L, const TileDesc &d,
     return Verdict{info | (n << 8), ref};
 }
 
-// The list k_walk_slab leaves: wide_count tiles, entry i = {tile number, its 64-member window record}
-struct WideArgs { uint32_t *wide_count; const uint32_t *wide_tile; const TileWin64 *tw64; };     // wide_count[1]: the grid's work cursor
+struct WideArgs { const TileWin64 *tw64; };            // tw64[tile]: the 64-member window record k_walk_slab left for a TD_WIDE tile
 
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, 5)
@@ -257,21 +256,22 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
     const int lane = threadIdx.x & (WAVE - 1);
     WEnt *const s_ent0 = s_ent, *const s_ent1 = s_ent + WIDE_KEY_CAP;
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
-    const uint32_t n_wide = *wa.wide_count;
+    // the tiles of this kernel: wide_list (TileLists), taken from a cursor -- they differ in cost; a workgroup's FIRST entry is its
+    // own number: an empty list costs no atomic
+    const uint32_t n_wide = sa->list_cnt[0];
     for (bool own = true;; own = false) {
-        // (the workgroups take the entries from a cursor, which k_probe_slab cleared; a workgroup's FIRST entry is its own number: an
-        //  empty list costs no atomic)
         if (own && blockIdx.x >= n_wide) break;
-        if (threadIdx.x == 0) s_next = own ? blockIdx.x : gridDim.x + atomicAdd(wa.wide_count + 1, 1u);
+        if (threadIdx.x == 0) s_next = own ? blockIdx.x : gridDim.x + atomicAdd(sa->list_cnt + 2, 1u);
         __syncthreads();
         const uint32_t wi = s_next;
         if (wi >= n_wide) break;
-        const uint32_t t = wa.wide_tile[wi];
+        const uint32_t t = sa->wide_list[wi];
+        const uint32_t tflags = u_tw[t].d.flags;
         const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
         const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t], total = u_xbase[t + 1u] - xbase;
         const int32_t tile_lo = u_pos[r0] + 1;                   // the base of the tile's row words
         for (int i = (int)threadIdx.x; i < WIDE_TW_VECS; i += TILE_THREADS)
-            reinterpret_cast<int4 *>(&s_tw)[i] = reinterpret_cast<const int4 *>(wa.tw64 + wi)[i];
+            reinterpret_cast<int4 *>(&s_tw)[i] = reinterpret_cast<const int4 *>(wa.tw64 + t)[i];
         const uint32_t row_max = max((u_tw[t].pad[0] >> (8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))) & 0xffu, 1u) - 1u;
         bool active = threadIdx.x < n_act;
         const uint32_t at = r0 + (active ? threadIdx.x : 0u);
@@ -332,8 +332,8 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         }
         if (threadIdx.x == 0) s_lim = min(total, (uint32_t)SLAB_POS_CAP);
         const int any_wide = __syncthreads_or(my_wide);
-        if (any_wide && sa->chunk_cnt) {                        // (a key with several entries: k_probe_slab_chunked ORs them)
-            if (threadIdx.x == 0) sa->chunk_tile[atomicAdd(sa->chunk_cnt, 1u)] = t;
+        if (any_wide && sa->chunk_on) {                         // (a key with several entries: k_probe_slab_chunked ORs them)
+            if (threadIdx.x == 0) { sa->tw[t].d.flags = tflags | TD_CHUNK; sa->chunk_list[atomicAdd(sa->list_cnt + 1, 1u)] = t; }
             __syncthreads();
             continue;
         }
