@@ -515,7 +515,12 @@ __device__ __forceinline__ void slab_classify(SlabArgsK sa, PipeArgsK a, const T
     if (work && !redo) {
         // work words: the upper 14 bits of the read's A words, replaced by the flag byte
         uint32_t *const Ap = st.A + st.loc;
-        const Verdict vd = decide<LEVEL>(L, d, n, re, vm, sm, rev_in, [&](int k) { return Ap[k] >> SLAB_REL_BITS; },
+        // (the read's ends once more, from its staged exons: four registers that need not live through the probe rounds)
+        const uint16_t *const Lq = st.Ln + st.loc;
+        ReadEnds re2;
+        re2.s0 = st.lo + (int)(Ap[0] & SLAB_REL_MASK); re2.e0 = re2.s0 + (int)Lq[0] - 1;
+        re2.sl = st.lo + (int)(Ap[n - 1u] & SLAB_REL_MASK); re2.el = re2.sl + (int)Lq[n - 1u] - 1;
+        const Verdict vd = decide<LEVEL>(L, d, n, re2, vm, sm, rev_in, [&](int k) { return Ap[k] >> SLAB_REL_BITS; },
                                          [&](int k, uint32_t f) { Ap[k] = (Ap[k] & SLAB_REL_MASK) | (f << SLAB_REL_BITS); });
         info = vd.info; ref = vd.ref;
     }
@@ -562,10 +567,10 @@ __device__ __forceinline__ void slab_write_out(const SlabOut &out0 /* dst = xbas
 }
 
 // Workgroups per CU: a spilled register is a scratch access, and scratch accesses count on the same in-order counter as the row
-// loads (a reload inside the probe rounds waits for every row asked for before it): levels 3 and 4 need 74 .. 78 registers, so
-// they run at 6 workgroups per CU without scratch (measured at level 3: 0.418 ms against 0.435 at 7 with 32 bytes of scratch);
-// the other levels fit the 72 registers of 7.
-constexpr int slab_probe_wgs(int level) { return (level == 3 || level == 4) ? 6 : 7; }
+// loads (a reload inside the probe rounds waits for every row asked for before it): the kernel has to fit its registers.  Levels 3
+// and 4 needed 74 .. 78 and ran at 6 workgroups per CU (0.418 ms against 0.435 at 7 with 32 bytes of scratch) until the reads' ends
+// stopped living through the probe rounds (slab_classify reads them back from the staged exons): 72 registers, 7 per CU, 0.371 ms.
+constexpr int slab_probe_wgs(int) { return 7; }
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, slab_probe_wgs(LEVEL))
 void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase,

@@ -353,7 +353,12 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         if (active && !mapping) slab_copy_exons(sa, a, out, st, q, off, n, pre, r);
         if (work && !redo) {
             uint32_t *const Ap = s_A + loc;
-            const Verdict vd = decide64<LEVEL>(L, d, n, re, vm, sm, rev_in, [&](int k) { return Ap[k] >> SLAB_REL_BITS; },
+            // (the read's ends once more, from its staged exons: four registers that need not live through the probe rounds)
+            const uint16_t *const Lq = s_L + loc;
+            ReadEnds re2;
+            re2.s0 = tile_lo + (int)(Ap[0] & SLAB_REL_MASK); re2.e0 = re2.s0 + (int)Lq[0] - 1;
+            re2.sl = tile_lo + (int)(Ap[n - 1u] & SLAB_REL_MASK); re2.el = re2.sl + (int)Lq[n - 1u] - 1;
+            const Verdict vd = decide64<LEVEL>(L, d, n, re2, vm, sm, rev_in, [&](int k) { return Ap[k] >> SLAB_REL_BITS; },
                                                [&](int k, uint32_t f) { Ap[k] = (Ap[k] & SLAB_REL_MASK) | (f << SLAB_REL_BITS); });
             info = vd.info; ref = vd.ref;
         }
