@@ -363,8 +363,11 @@ __device__ __forceinline__ int cursor_value(const CursorDir &cd, int32_t tid, in
 
 // Pass A.  j0_in != null: the cursor values were replayed on the host (unsorted input) and are only read here.
 // WIDE: the input has long CIGARs (the host decides per upload), see walk_cigar.
+#ifndef L2R_PASSA_WGS
+#define L2R_PASSA_WGS 8
+#endif
 template <bool WIDE>
-__global__ __launch_bounds__(TILE_THREADS, 8)
+__global__ __launch_bounds__(TILE_THREADS, WIDE ? L2R_PASSA_WGS : 8)
 void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t *__restrict__ r_pos,
               const int64_t *__restrict__ cig_off, const uint32_t *__restrict__ cig, CursorDir cd, SiteTabs tabs, DevParams p,
               const int32_t *__restrict__ j0_in, int32_t *__restrict__ j0_out, uint32_t *__restrict__ local_out,
