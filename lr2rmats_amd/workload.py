@@ -20,7 +20,7 @@ CONFIGS = {
     "cfg2": dict(n_reads=100_000, n_exons=5, anno_exons=50_000, seed=2, ont=False, micro=0, xs=0.0),
     "cfg3": dict(n_reads=10_000_000, n_exons=8, anno_exons=1_500_000, seed=3, ont=False, micro=0, xs=0.0),
     "cfg5": dict(n_reads=20_000_000, n_exons=12, anno_exons=2_000_000, seed=5, ont=True, micro=3, xs=0.02),
-    # cfg3 with 40 isoforms per gene instead of 5 (same exon count, an eighth of the genes): every tile's window holds 33 .. 64
+    # cfg3 with 40 isoforms per gene instead of 5 (same exon count, an eighth of the genes): every tile's window holds 33 .. 63 (or, where a tile meets two genes, more)
     # transcripts -- the shape of isoform-rich loci in a real annotation (diagnostics, not a BASELINE config)
     "cfg3_iso40": dict(n_reads=10_000_000, n_exons=8, anno_exons=1_500_000, seed=3, ont=False, micro=0, xs=0.0, tx_per_gene=40),
     # ... and with 100: every window is beyond the 64-bit masks, most exons are shared by transcripts more than 64 apart in file order
