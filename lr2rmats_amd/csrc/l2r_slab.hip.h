@@ -166,6 +166,15 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
                 cg[4 * q] = (uint32_t)x.x; cg[4 * q + 1] = (uint32_t)x.y; cg[4 * q + 2] = (uint32_t)x.z; cg[4 * q + 3] = (uint32_t)x.w;
             }
     }
+    // The tile's cursor value (first transcript its sweep can reach: three dependent SCALAR loads, on their own counter) is looked up
+    // here, by the wave that will make the tile's descriptor, while the CIGAR vectors above are in flight -- not at the end, in front
+    // of the descriptor's own load chain.
+    int jl_early = INT32_MIN;
+    if (wv == TILE_THREADS / WAVE - 1 && n_act) {
+        CursorDir cd;
+        cd.key = a->cd.key; cd.dir = a->cd.dir; cd.kb_base = a->cd.kb_base; cd.n_tid = a->cd.n_tid; cd.n_tx = a->cd.n_tx;
+        jl_early = cursor_value(cd, tid0, pos0 + 1);
+    }
 #pragma unroll
     for (int i = 0; i < SLAB_HEAD; ++i) cg[i] = (uint32_t)i < n_cig ? cg[i] : 1u;
     DevParams p;
@@ -274,7 +283,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     if (wv != TILE_THREADS / WAVE - 1) return;
     if (lane == 0) a->tile_total[t] = total;             // (one word per tile, scanned by k_scan_u32: a single counter would serialise 156 k waves)
     const int32_t tile_hi = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-    make_descriptor(a, lane, tid0, pos0 + 1, tile_hi, true, &s_tw, (uint32_t)SLAB_KEY_CAP, sa->tw64 ? &s_tw64 : nullptr);
+    make_descriptor(a, lane, tid0, pos0 + 1, tile_hi, true, &s_tw, (uint32_t)SLAB_KEY_CAP, sa->tw64 ? &s_tw64 : nullptr, jl_early);
     if (s_tw.d.flags & TD_WIDE) {
         // a window of 33 .. 63 members: its 64-member record goes to tw64[tile], k_probe_slab_wide finds the tile by its flags
         for (int i = lane; i < (int)(sizeof(TileWin64) / 16); i += WAVE) reinterpret_cast<int4 *>(sa->tw64 + t)[i] = reinterpret_cast<const int4 *>(&s_tw64)[i];

@@ -51,7 +51,7 @@ struct TileWin64 {
 // With W64 (slab pipeline): a window of 33 .. 63 members is collected into *W64 and the tile is flagged TD_WIDE instead of
 // TD_FAST (W then only carries the descriptor); up to 32 members everything is as without it.
 __device__ __forceinline__ void make_descriptor(PipeArgsK a, int lane, int32_t tid0, int32_t tlo, int32_t thi, bool in_lds, TileWin *W,
-                                                uint32_t key_cap = (uint32_t)PIPE_KEY_CAP, TileWin64 *W64 = nullptr)
+                                                uint32_t key_cap = (uint32_t)PIPE_KEY_CAP, TileWin64 *W64 = nullptr, int jl_known = INT32_MIN /* the cursor value of (tid0, tlo), when the caller has looked it up already */)
 {
     const uint32_t win_cap = W64 ? (uint32_t)WIDE_MEMBERS : (uint32_t)WIN_TX;
     int *const win_out = W64 ? W64->win : W->win;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void make_descriptor(PipeArgsK a, int lane, int32_t t
     // its own: a member below a read's cursor value lies entirely before that read, which visit_window sees by itself
     CursorDir cd;
     cd.key = a->cd.key; cd.dir = a->cd.dir; cd.kb_base = a->cd.kb_base; cd.n_tid = a->cd.n_tid; cd.n_tx = a->cd.n_tx;
-    const int jl = cursor_value(cd, tid0, tlo);
+    const int jl = jl_known != INT32_MIN ? jl_known : cursor_value(cd, tid0, tlo);
     d.j_lo = jl;
     bool contig = true;
     uint32_t n_win = 0;
