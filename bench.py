@@ -150,13 +150,84 @@ def pmc_traffic(kernels, config: str, n_reads: int):
     if t.get("config") != config or t.get("reads") != n_reads:
         return None, "PMC file is for another config / read count"
     out = {}
-    alias = {"k_scan_tiles": "k_scan_u32"}            # (stage name of l2r_stage_kernel -> kernel name in the profile)
     for k in kernels:
-        ent = t.get("kernels", {}).get(alias.get(k, k))
+        ent = t.get("kernels", {}).get(k)
         if ent is None:
             return None, "PMC file has no kernel %s" % k
         out[k] = ent["hbm_bytes_per_launch"]
     return out, t.get("note", "profiles/pmc_traffic.json")
+
+
+def second_pass(eng, af, reads, got, args, capi, workload, n_x):
+    """The cold step under the pipeline's second option set: `-s -l 3 -J 1 -j SJ.tab` (the reference's junction
+    check src/update_gtf.c:589-627,698-709,946-960) with a junction table made like the generator's (every annotated junction +
+    the junctions of the reads, 80 % kept): k_validate_sj behind the classification, results + accepted list."""
+    import numpy as np
+    from lr2rmats_amd import synth
+    if got is None:
+        got = eng.download()
+    t0 = time.perf_counter()
+    sj = synth.make_junctions_fast(af, got.ex_off, got.ex_start, got.ex_end, reads.tid, seed=3, cover=0.8)
+    t_tab = time.perf_counter() - t0
+    eng.set_junctions((sj.tid, sj.don, sj.acc, sj.uniq, sj.multi))
+    eng.set_params(capi.default_params(full_level=args.level, split_trans=1, min_sj_cnt=1))
+    eng.set_outputs(capi.WANT_RESULTS | capi.WANT_ACCEPTED)
+    eng.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)
+    eng.run(); eng.sync()
+    tm = eng.run_timed(max(3, min(args.steps, 10)))
+    _, _, m_acc, x_acc = eng.sizes()
+    res = eng.download()
+    unrel = int(((res.info & 16) != 0).sum())
+    cand = int((((res.info & 4) != 0) & ((res.info & 1) == 0) & ((res.info & 2) != 0)).sum())
+    n_sj = int(len(sj.don))
+    abytes = workload.algorithmic_bytes(reads.n, int(reads.cig.shape[0]), n_x, af.n_tx, af.n_exons, n_sj)
+    out = {"options": "-s -l %d -J 1 -j SJ.tab (results + accepted list)" % args.level, "junction_rows": n_sj, "junction_table_s": round(t_tab, 1),
+           "ms_per_step": round(tm["total_ms"], 4), "reads_per_s": round(reads.n / (tm["total_ms"] * 1e-3), 1),
+           "algorithmic_bytes_per_launch": abytes, "accepted_list_bytes": 20 * m_acc + 9 * x_acc,
+           "frac_event_pass": round(abytes / (tm["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "candidates_checked": cand, "reads_with_unreliable_junction": unrel, "accepted_reads": m_acc, "accepted_exons": x_acc,
+           "kernel_ms": {k.split(" ")[0]: round(v, 4) for k, v in tm["kernel_ms"].items()}}
+    # back to the first option set (the e2e leg and anything behind this use their own engines, but leave this one as it was)
+    eng.set_junctions(None)
+    eng.set_params(capi.default_params(full_level=args.level))
+    eng.set_outputs(capi.WANT_RESULTS | (capi.WANT_ACCEPTED if args.accepted else 0))
+    eng.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)
+    return out
+
+
+def launcher_argv(args, port: int):
+    """The command `bench.py --gpus N` starts when no launcher has set WORLD_SIZE: the shape the driver uses itself."""
+    passed = [a for a in sys.argv[1:] if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + passed
+
+
+def self_launch(args) -> int:
+    import socket
+    import subprocess
+    with socket.socket() as so:                       # a free port for the rendezvous
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = launcher_argv(args, port)
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in r.stdout.decode(errors="replace").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    elif r.returncode == 0:
+        print("bench.py: the launcher returned 0 without a JSON line", file=sys.stderr)
+        return 4
+    return r.returncode
 
 
 def main():
@@ -174,15 +245,23 @@ def main():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--emulate-world", type=int, default=0, help="diagnostics, one GPU: run the shard rank 0 would own in a strong-scaling run of this many GPUs")
+    ap.add_argument("--no-second-pass", action="store_true", help="skip the pipeline's second option set (-s -l 3 -J 1 -j SJ.tab) at N=1")
+    ap.add_argument("--dry-launch", action="store_true", help="print the launcher command a plain `bench.py --gpus N` would start, and exit")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python3 bench.py --gpus N` without a launcher: start one process per GPU as a CHILD (nothing here has touched HIP yet,
+        # and nothing is exec'ed), relay rank 0's JSON line and the launcher's return code
+        sys.exit(self_launch(args))
+    if args.dry_launch:
+        print(json.dumps({"launch": None, "note": "one process: no launcher needed"}))
+        sys.exit(0)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs the torch.distributed.run launcher" % args.gpus, file=sys.stderr)
-            sys.exit(2)
+        print("bench.py: --gpus %d under WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
 
     import numpy as np
     import torch
@@ -192,11 +271,24 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # L2R_BENCH_DEVICES="0,0": ranks -> devices (tests put two ranks on one GPU; RCCL wants a GPU per rank, so such a run needs
+    # L2R_BENCH_BACKEND=gloo, whose collectives take host tensors)
+    dev_map = [int(x) for x in os.environ.get("L2R_BENCH_DEVICES", "").split(",") if x.strip() != ""]
+    dev_index = dev_map[local_rank % len(dev_map)] if dev_map else local_rank
+    backend = os.environ.get("L2R_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    coll_dev = device if backend == "nccl" else torch.device("cpu")      # where the small collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            print("bench.py: process group of %d ranks under --gpus %d" % (dist.get_world_size(), args.gpus), file=sys.stderr)
+            sys.exit(2)
+    rccl_world = dist.get_world_size() if world > 1 else 1
 
     cfg = dict(workload.CONFIGS[args.config])
     if args.reads:
@@ -207,12 +299,12 @@ def main():
         cfg["n_reads"] = cfg["n_reads"] // w_world + (1 if rank < cfg["n_reads"] % w_world else 0)
     af, reads = workload.make_rank_workload(cfg, rank, w_world)
 
-    eng = capi.Engine(local_rank)
+    eng = capi.Engine(dev_index)
     eng.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
     eng.set_params(capi.default_params(full_level=args.level))
     # the step produces the per-read results (SURVEY.md 8(d) bytes); the compacted accepted list only where the exchange sends it
-    gather = world > 1 and args.exchange == "gathered"
-    eng.set_outputs(capi.WANT_RESULTS | (capi.WANT_ACCEPTED if (gather or args.accepted) else 0))
+    gather_headline = world > 1 and args.exchange == "gathered"
+    eng.set_outputs(capi.WANT_RESULTS | (capi.WANT_ACCEPTED if (gather_headline or args.accepted) else 0))
     eng.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, first_read_index=rank * reads.n)
 
     gathered = {}
@@ -221,7 +313,7 @@ def main():
         # counts of (records, exons) per rank, then five padded all-gathers of engine-owned HBM (workload.all_gatherv)
         _, _, m, x = eng.sizes()
         v = eng.device_view()
-        cnt = torch.tensor([m, x], dtype=torch.int64, device=device)
+        cnt = torch.tensor([m, x], dtype=torch.int64, device=coll_dev)
         allc = [torch.zeros_like(cnt) for _ in range(world)]
         dist.all_gather(allc, cnt)
         allc = [c.tolist() for c in allc]
@@ -234,75 +326,102 @@ def main():
             gathered[name] = outs
         return sum(c[0] for c in allc), sum(c[1] for c in allc)
 
-    def step():
-        # One pass of the hot path over the resident batch: asynchronous launches on the engine's stream.  Passes are
-        # independent (each overwrites the results of the one before) and stream order keeps them apart, so the host does
-        # not wait between them: the timed region ends with one synchronisation of the engine's stream + device.  Only the
-        # gathered exchange needs the sizes of a pass on the host, and waits for them.
-        eng.run()
-        if gather:
-            eng.sync()
-            return exchange()
-        return None
+    def timed_region(steps: int, warmup: int, gather: bool):
+        """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; max over ranks.
+        One step = one pass of the hot path over the resident batch: asynchronous launches on the engine's stream.  Passes are
+        independent (each overwrites the results of the one before) and stream order keeps them apart, so the host does not
+        wait between them: the region ends with one synchronisation of the engine's stream + device.  Only the gathered
+        exchange needs the sizes of a pass on the host, and waits for them."""
+        def step():
+            eng.run()
+            if gather:
+                eng.sync()
+                return exchange()
+            return None
+        for _ in range(warmup):
+            step()
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(steps):
+            last = step()
+        eng.sync()                  # (the engine launches on a stream of its own: torch.cuda.synchronize() alone would do, this says it)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, last
 
-    for _ in range(args.warmup):
-        step()
-    eng.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step()
-    eng.sync()                      # (the engine launches on a stream of its own: torch.cuda.synchronize() alone would do, this says it)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, last = timed_region(args.steps, args.warmup, gather_headline)
 
     n_r, n_x, n_acc, n_acc_x = eng.sizes()
     per_rank = [[reads.n, n_x, n_acc, n_acc_x]]
     if world > 1:
         # reads / exons / accepted records of every rank (outside the timed region): the first hardware run explains itself
-        tr = torch.tensor(per_rank[0], dtype=torch.int64, device=device)
+        tr = torch.tensor(per_rank[0], dtype=torch.int64, device=coll_dev)
         allr = [torch.zeros_like(tr) for _ in range(world)]
         dist.all_gather(allr, tr)
         per_rank = [t.tolist() for t in allr]
     total_reads = sum(p[0] for p in per_rank)
     value = total_reads * args.steps / dt
 
+    # the OTHER route of dist.py in the same line (N > 1): a second, shorter timed region with the exchange the headline did not use,
+    # so that one scaling run reports both (partitioned: no collective in a step; gathered: compaction + RCCL all-gatherv of the accepted list)
+    other = None
+    if world > 1:
+        o_gather = not gather_headline
+        eng.set_outputs(capi.WANT_RESULTS | (capi.WANT_ACCEPTED if (o_gather or args.accepted) else 0))
+        o_steps = max(2, min(args.steps, 5))
+        o_dt, o_last = timed_region(o_steps, 1, o_gather)
+        _, _, o_acc, o_acc_x = eng.sizes()
+        tr = torch.tensor([o_acc, o_acc_x], dtype=torch.int64, device=coll_dev)
+        allr = [torch.zeros_like(tr) for _ in range(world)]
+        dist.all_gather(allr, tr)
+        o_per = [t.tolist() for t in allr]
+        other = {"exchange": "gathered" if o_gather else "partitioned", "steps": o_steps, "warmup": 1,
+                 "ms_per_step": round(o_dt / o_steps * 1e3, 4), "value": round(total_reads * o_steps / o_dt, 1), "unit": "reads/s",
+                 "exchange_bytes_per_rank_per_step": [0 if not o_gather else 20 * q[0] + 9 * q[1] for q in o_per],
+                 "gathered_records_exons": list(o_last) if o_last else None}
+        eng.set_outputs(capi.WANT_RESULTS | (capi.WANT_ACCEPTED if (gather_headline or args.accepted) else 0))
+
     out = None
     if rank == 0:
-        # Every kernel of a step, measured live with HIP events on the engine's stream (l2r_run_timed: back-to-back cold runs, then
-        # per-stage events).  The path is two kernels of comparable length (walk: CIGAR -> exons; probe: annotation window + site
-        # probes -> verdicts + the read-order write-out) with a scan between them and the redo list behind; no single one of them
-        # moves the path's algorithmic bytes.  `achieved` is therefore the path's algorithmic bytes over the time of ALL its
-        # kernels (first launch -> last completion); the longest kernel is given beside it.
+        # `achieved` = the path's algorithmic bytes (SURVEY.md 8(d)) over the time of one step OF THE TIMED REGION ABOVE -- the clock the
+        # headline value comes from (ADVICE r3).  The path is two kernels of comparable length (walk: CIGAR -> exons; probe: annotation
+        # window + site probes -> verdicts + the read-order write-out) with the redo list behind; no single one of them moves the path's
+        # algorithmic bytes.  A second pass with HIP events on the engine's stream (l2r_run_timed: back-to-back cold runs, then per-stage
+        # events) gives the kernels one by one; its own total is kept beside the headline as `frac_event_pass`.
         tm = eng.run_timed(max(3, min(args.steps, 10)))
         stage = tm["stage_ms"]
         kern = {k.split(" ")[0]: v for k, v in tm["kernel_ms"].items()}
         live = {k: v for k, v in kern.items() if v > 0.02 * tm["total_ms"]}
         dom = max(live, key=lambda k: live[k])
         abytes = workload.algorithmic_bytes(n_r, int(reads.cig.shape[0]), n_x, af.n_tx, af.n_exons, 0)
-        ach = abytes / (tm["total_ms"] * 1e-3) / 1e9
-        launched = [k for k in kern if k not in ("k_validate_sj", "k_scan_accepted", "k_gather_accepted") or args.accepted or gather]
+        step_s = dt / args.steps
+        ach = abytes / step_s / 1e9
+        ach_ev = abytes / (tm["total_ms"] * 1e-3) / 1e9
+        launched = [k for k in kern if k not in ("k_validate_sj", "k_scan_accepted", "k_gather_accepted") or args.accepted or gather_headline]
         per_kernel, traffic_note = pmc_traffic(sorted(live), args.config, reads.n)
         traffic = None if per_kernel is None else int(sum(per_kernel.values()))
-        roof = {"bound": "hbm", "kernel": " + ".join(sorted(launched, key=lambda k: -kern[k])) + " (every kernel of a cold step; k_probe_slab includes the launches of k_probe_slab_wide and k_probe_slab_chunked)",
+        roof = {"bound": "hbm", "kernel": " + ".join(sorted(launched, key=lambda k: -kern[k])) + " (every kernel of a cold step)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_measured_copy_peak": round(ach / HBM_COPY_GBS, 4),
+                "clock": "the timed region of this line: algorithmic bytes / ms_per_step",
+                "frac_event_pass": round(ach_ev / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_note,
                 "traffic_over_algorithmic": None if traffic is None else round(traffic / abytes, 3),
                 "algorithmic_bytes_per_launch": abytes,
                 "all_kernels_ms": round(tm["total_ms"], 4),
-                "all_kernels_achieved_GBs": round(ach, 1),
+                "all_kernels_achieved_GBs": round(ach_ev, 1),
                 "step_is_cold": True, "results_layout": "read order (ex_off / ex_start / ex_end / ex_flag / info / ref_tx as l2r_download copies them)",
                 "dominant_kernel": {"name": dom, "ms": round(live[dom], 4),
                                     "hbm_bytes_per_launch": None if per_kernel is None else per_kernel[dom],
@@ -324,6 +443,7 @@ def main():
             eng.set_outputs(capi.WANT_RESULTS | (capi.WANT_ACCEPTED if args.accepted else 0))
             eng.run(); eng.sync()
         cpu = None
+        got = None
         if world == 1 and not args.no_cpu:
             rate, sub, ores, cdt = cpu_baseline(af, reads, args.cpu_sample, args.level)
             # the same launch also serves as a parity spot check of the sample (bit exact)
@@ -339,6 +459,15 @@ def main():
                    # the reference itself cannot be built or shipped (htslib); its survey-time probe on a 2.1 GHz Xeon, BASELINE.md section 2
                    "reference_core_reads_per_s": 3.0e5, "reference_e2e_reads_per_s": 3.2e4,
                    "reference_note": "BASELINE.md section 2 (survey-time probe of the unmodified reference, other host; indicative only)"}
+        # the pipeline's SECOND option set (Snakefile:170): -s -l 3 -J 1 -j SJ.tab, i.e. the junction check
+        # (src/update_gtf.c:946-960) behind the classification, with the generator's 80 %-cover junction table, per-read results AND the
+        # accepted list (what -A / -E / -y and the GTF on stdout consume)
+        second = None
+        if world == 1 and not args.no_second_pass:
+            try:
+                second = second_pass(eng, af, reads, got, args, capi, workload, n_x)
+            except Exception as e:                                # (must not take the line down)
+                second = {"error": str(e)[:300]}
         e2e = None
         if world == 1 and not args.no_e2e:
             e2e = e2e_leg(af, reads, args.level)
@@ -354,15 +483,18 @@ def main():
                        "reads_per_gpu": reads.n, "total_reads": total_reads, "accepted_reads_rank0": n_acc,
                        "exchange": "none (1 GPU)" if world == 1 else (
                            "partitioned: chromosome-aligned shards merge and write on their own rank; no collective inside a step"
-                           if not gather else
+                           if not gather_headline else
                            "gathered: RCCL all-gatherv (padded all_gather_into_tensor) of %s accepted records / %s exons to every rank" % (last[0], last[1])),
                        "parallelism": "reads sharded over %d GPU(s), annotation replicated" % world,
-                       "rccl_world_size": world, "reads_per_rank": [p[0] for p in per_rank], "exons_per_rank": [p[1] for p in per_rank],
+                       "rccl_world_size": rccl_world, "collective_backend": backend if world > 1 else None,
+                       "reads_per_rank": [p[0] for p in per_rank], "exons_per_rank": [p[1] for p in per_rank],
                        # bytes a rank SENDS per step: the partitioned route exchanges nothing inside a step (16 summary counters once,
                        # behind the timed region); the gathered route all-gathers its accepted records (16 + 4 bytes each) and their exons (9 bytes each)
-                       "exchange_bytes_per_rank_per_step": [0 if not gather else 20 * p[2] + 9 * p[3] for p in per_rank]},
+                       "exchange_bytes_per_rank_per_step": [0 if not gather_headline else 20 * p[2] + 9 * p[3] for p in per_rank]},
             "roofline": roof,
+            "other_exchange": other,
             "with_accepted": with_accepted,
+            "second_pass": second,
             "cpu_baseline": cpu,
             "e2e": e2e,
         }

@@ -157,7 +157,7 @@ typedef struct {
  *             (annotation window, site probes, verdicts, read-order results) + k_probe_slab_wide (tiles whose window holds 33 .. 63
  *             transcripts) + k_probe_slab_chunked (tiles beyond that, or with a dictionary key in several entries: the window 63
  *             members at a time).  Every run launches all of them: nothing is kept from an earlier run of the same records.
- *     classic (unsorted records, long CIGARs, L2R_PIPELINE=classic)  0 k_pass_a  1 k_scan_tiles  2 k_classify_fast */
+ *     classic (unsorted records, long CIGARs, L2R_PIPELINE=classic)  0 k_pass_a  1 k_scan_u32 (tile sums)  2 k_classify_fast */
 #define L2R_N_STAGES 8
 typedef struct {
     float stage_ms[L2R_N_STAGES];   /* 0..2 see above  3 classify_generic (redo list) 4 validate_junctions (+ recount)

@@ -1130,10 +1130,11 @@ int l2r_debug_counters(l2r_ctx *c, long long *out, int n)
 const char *l2r_stage_kernel(l2r_ctx *c, int stage)
 {
     if (!c || stage < 0 || stage >= L2R_N_STAGES) return "";
-    static const char *const classic[L2R_N_STAGES] = {"k_pass_a", "k_scan_tiles", "k_classify_fast", "k_classify_generic",
-                                                      "k_validate_sj", "k_scan_accepted", "k_gather_accepted", ""};
+    // (the first word is the kernel's name as a profile lists it; both scans are launches of k_scan_u32)
+    static const char *const classic[L2R_N_STAGES] = {"k_pass_a", "k_scan_u32 (tile sums)", "k_classify_fast", "k_classify_generic",
+                                                      "k_validate_sj", "k_scan_accepted (k_scan_u32 of the accepted counts)", "k_gather_accepted", ""};
     if (stage >= 3 || !c->slab) return classic[stage];
-    return stage == 0 ? "k_walk_slab" : stage == 1 ? "k_scan_tiles" : "k_probe_slab";
+    return stage == 0 ? "k_walk_slab" : stage == 1 ? "k_scan_u32 (+ tile lists)" : "k_probe_slab (+ k_probe_slab_wide + k_probe_slab_chunked)";
 }
 
 int l2r_run(l2r_ctx *c)
