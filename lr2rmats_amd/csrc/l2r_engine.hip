@@ -70,7 +70,7 @@ struct l2r_ctx {
     int want_pipeline = 1;                  // L2R_PIPELINE: classic (0: l2r_kernels.hip.h, two walks), slab (1, default: l2r_slab.hip.h, one walk)
     bool slab_ok = false;                   // the current upload can run the slab pipeline: coordinate-sorted records, short CIGARs, its slab layout fits
     bool slab = false;                      // ... and the last launch did (the parameters have a say: launch_all)
-    DevBuf<uint32_t> tile_sbase, s_pre, s_loc, tile_total;
+    DevBuf<uint32_t> tile_sbase, s_pre, s_loc, tile_total, tile_xbase, tile_span;    // (tile_span: 16-byte TileSpan records, l2r_slab.hip.h)
     DevBuf<int32_t> dense_start, dense_end;                 // slab pipeline: the outliers' dense area
     DevBuf<uint32_t> slab_row;                              //                the exon rows between its kernels (one word per exon)
     DevBuf<TileWin> tw;
@@ -223,7 +223,7 @@ void l2r_destroy(l2r_ctx *c)
     c->win_start.release(); c->sj_cursor.release();
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
-    c->tile_total.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_list.release(); c->chunk_list.release(); c->list_cnt.release(); c->tile_flags.release();
+    c->tile_total.release(); c->tile_xbase.release(); c->tile_span.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_list.release(); c->chunk_list.release(); c->list_cnt.release(); c->tile_flags.release();
     c->slab_row.release(); c->dense_start.release(); c->dense_end.release(); c->s_pre.release(); c->s_loc.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -817,7 +817,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             c->slab_ok = true;
             if (c->tw64.ensure(T + 1) || c->wide_list.ensure(T + 1) || c->chunk_list.ensure(T + 1) || c->list_cnt.ensure(4) || c->tile_flags.ensure(T + 8)) return -2;      // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB each)
             HIP_TRY(hipMemsetAsync(c->list_cnt.p, 0, 16, c->stream));
-            if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) || c->tile_total.ensure(T + 2) ||
+            if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) || c->tile_total.ensure(T + 2) || c->tile_xbase.ensure(T + 2) || c->tile_span.ensure(12 * (T + 1)) ||
                 c->s_pre.ensure((size_t)N + 1) || c->s_loc.ensure((size_t)N + 1) ||
                 c->slab_row.ensure((size_t)total + 4) ||
                 c->dense_start.ensure((size_t)ovf + 1) || c->dense_end.ensure((size_t)ovf + 1)) return -2;
@@ -958,7 +958,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         sa.g.f = fa; sa.g.cd = cd; sa.g.tid_base = c->tid_base.p; sa.g.n_tid_dir = c->n_tid_dir; sa.g.tile_total = c->tile_total.p;
         sa.tile_sbase = c->tile_sbase.p; sa.slab_row = c->slab_row.p;
         sa.dense_start = c->dense_start.p; sa.dense_end = c->dense_end.p; sa.ovf_cursor = c->ovf_cursor.p;
-        sa.pre = c->s_pre.p; sa.loc = c->s_loc.p; sa.tw = c->tw.p;
+        sa.pre = c->s_pre.p; sa.loc = c->s_loc.p; sa.tw = c->tw.p; sa.span = (TileSpan *)c->tile_span.p;
         sa.n_tiles = (uint32_t)c->n_tiles;
         const unsigned gx = 8u * (unsigned)std::max<int64_t>((c->n_tiles + 7) / 8, 1);      // (l2r_slab.hip.h xcd_tile; an empty upload still launches)
         sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p;
@@ -971,15 +971,24 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_slab<true>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p,
                                (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
         MARK(ST_SCAN1);
-        {   // the tiles' exon counts -> their first slots in the read-order result arrays (in place; the sum = the exon count)
-            // (block 1 of the same launch lists the tiles of the 64-bit-mask and the chunked kernel from the descriptors: TileLists)
-            ScanJobs jobs = {}; jobs.job[0] = ScanJob{c->tile_total.p, c->n_tiles, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
-            jobs.lists = TileLists{c->tile_flags.p, (uint32_t)c->n_tiles, sa.chunk_on, c->wide_list.p, c->chunk_list.p, c->list_cnt.p};
-            hipLaunchKernelGGL(k_scan_u32, dim3(2), dim3(1024), 0, s, jobs);
+        {   // the tiles' exon counts -> their first slots in the read-order result arrays (tile_xbase; the sum = the exon count): the
+            // first workgroups of the launch, a segment each; the tiles' descriptors and windows, sixteen lanes per tile, and the lists
+            // of the 64-bit-mask and the chunked kernel: the workgroups behind them (l2r_slab.hip.h)
+            const DescribeScan job{c->tile_total.p, c->tile_xbase.p, c->totals.p + 0, c->n_tiles};
+            unsigned n_scan = (unsigned)std::max<int64_t>((c->n_tiles + DESCRIBE_SEG - 1) / DESCRIBE_SEG, 1);
+            if (c->n_tiles > DESCRIBE_SCAN_MAX) {
+                // (very large shards: one workgroup scans, in a launch of its own)
+                HIP_TRY(hipMemcpyAsync(c->tile_xbase.p, c->tile_total.p, (size_t)c->n_tiles * 4, hipMemcpyDeviceToDevice, s));
+                ScanJobs jobs = {}; jobs.job[0] = ScanJob{c->tile_xbase.p, c->n_tiles, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
+                hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, s, jobs);
+                n_scan = 0;
+            }
+            const unsigned gd = n_scan + (unsigned)std::max<int64_t>((c->n_tiles + DESCRIBE_TILES - 1) / DESCRIBE_TILES, 1);
+            hipLaunchKernelGGL(k_describe_scan, dim3(gd), dim3(TILE_THREADS), 0, s, sa, job, (uint32_t)n_scan);
         }
         MARK(ST_FAST);
-#define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
-            (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_total.p)
+#define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
+            (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p)
         switch (p.full_level) {
         case 1: launch_probe_level(1); break;
         case 2: launch_probe_level(2); break;
@@ -993,7 +1002,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             const WideArgs wa{c->tw64.p};
             const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 5);
 #define launch_wide_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_wide<L>), dim3(gw), dim3(TILE_THREADS), 0, s, sa, wa, (const uint32_t *)c->tile_first.p, \
-                (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_total.p)
+                (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p)
             switch (p.full_level) {
             case 1: launch_wide_level(1); break;
             case 2: launch_wide_level(2); break;
@@ -1007,7 +1016,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         if (sa.chunk_on) {   // the tiles without a window record, or with a dictionary key in several entries (none on most inputs)
             const unsigned gc = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 4);
 #define launch_chunk_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_chunked<L>), dim3(gc), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
-                (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_total.p)
+                (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p)
             switch (p.full_level) {
             case 1: launch_chunk_level(1); break;
             case 2: launch_chunk_level(2); break;
@@ -1134,7 +1143,7 @@ const char *l2r_stage_kernel(l2r_ctx *c, int stage)
     static const char *const classic[L2R_N_STAGES] = {"k_pass_a", "k_scan_u32 (tile sums)", "k_classify_fast", "k_classify_generic",
                                                       "k_validate_sj", "k_scan_accepted (k_scan_u32 of the accepted counts)", "k_gather_accepted", ""};
     if (stage >= 3 || !c->slab) return classic[stage];
-    return stage == 0 ? "k_walk_slab" : stage == 1 ? "k_scan_u32 (+ tile lists)" : "k_probe_slab (+ k_probe_slab_wide + k_probe_slab_chunked)";
+    return stage == 0 ? "k_walk_slab" : stage == 1 ? "k_describe_scan (tile descriptors + scan of the exon counts + tile lists)" : "k_probe_slab (+ k_probe_slab_wide + k_probe_slab_chunked)";
 }
 
 int l2r_run(l2r_ctx *c)

@@ -619,6 +619,53 @@ __device__ __forceinline__ bool slab_tile_is_chunked(uint32_t flags)
 }
 constexpr int SCAN_PER_THREAD = 16;
 
+// (one workgroup of 1024 threads; s_wave[16] and s_carry are the caller's)
+__device__ __forceinline__ void scan_block_u32(const ScanJob &job, uint32_t *s_wave, uint32_t &s_carry)
+{
+    uint32_t *__restrict__ v = job.v;
+    const int64_t n = job.n;
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024 * SCAN_PER_THREAD) {
+        const int64_t i = base + SCAN_PER_THREAD * (int64_t)threadIdx.x;
+        uint32_t x[SCAN_PER_THREAD];
+        if (i + SCAN_PER_THREAD <= n) {
+#pragma unroll
+            for (int q = 0; q < SCAN_PER_THREAD / 4; ++q) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(v + i + 4 * q);
+                x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < SCAN_PER_THREAD; ++q) x[q] = i + q < n ? v[i + q] : 0u;
+        }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < SCAN_PER_THREAD; ++q) { const uint32_t t = x[q]; x[q] = mine; mine += t; }      // x: exclusive inside the thread
+        const uint32_t inc = wave_inclusive_scan(mine);
+        if (lane == WAVE - 1) s_wave[w] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const uint32_t t = s_wave[k]; if (k < w) wbase += t; tot += t; }
+        const uint32_t carry = s_carry;
+        const uint32_t e0 = carry + wbase + inc - mine;
+        if (i + SCAN_PER_THREAD <= n) {
+#pragma unroll
+            for (int q = 0; q < SCAN_PER_THREAD / 4; ++q)
+                *reinterpret_cast<uint4 *>(v + i + 4 * q) = make_uint4(e0 + x[4 * q], e0 + x[4 * q + 1], e0 + x[4 * q + 2], e0 + x[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < SCAN_PER_THREAD; ++q) if (i + q < n) v[i + q] = e0 + x[q];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { v[n] = s_carry; *job.total = s_carry; }
+}
+
 __global__ __launch_bounds__(1024)
 void k_scan_u32(ScanJobs jobs)
 {
@@ -670,48 +717,7 @@ void k_scan_u32(ScanJobs jobs)
         if (threadIdx.x == 0) { L.cnt[0] = s_base[0]; L.cnt[1] = s_base[1]; L.cnt[2] = 0u; L.cnt[3] = 0u; }
         return;
     }
-    uint32_t *__restrict__ v = jobs.job[blockIdx.x].v;
-    const int64_t n = jobs.job[blockIdx.x].n;
-    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n; base += 1024 * SCAN_PER_THREAD) {
-        const int64_t i = base + SCAN_PER_THREAD * (int64_t)threadIdx.x;
-        uint32_t x[SCAN_PER_THREAD];
-        if (i + SCAN_PER_THREAD <= n) {
-#pragma unroll
-            for (int q = 0; q < SCAN_PER_THREAD / 4; ++q) {
-                const uint4 t = *reinterpret_cast<const uint4 *>(v + i + 4 * q);
-                x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < SCAN_PER_THREAD; ++q) x[q] = i + q < n ? v[i + q] : 0u;
-        }
-        uint32_t mine = 0;
-#pragma unroll
-        for (int q = 0; q < SCAN_PER_THREAD; ++q) { const uint32_t t = x[q]; x[q] = mine; mine += t; }      // x: exclusive inside the thread
-        const uint32_t inc = wave_inclusive_scan(mine);
-        if (lane == WAVE - 1) s_wave[w] = inc;
-        __syncthreads();
-        uint32_t wbase = 0, tot = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { const uint32_t t = s_wave[k]; if (k < w) wbase += t; tot += t; }
-        const uint32_t carry = s_carry;
-        const uint32_t e0 = carry + wbase + inc - mine;
-        if (i + SCAN_PER_THREAD <= n) {
-#pragma unroll
-            for (int q = 0; q < SCAN_PER_THREAD / 4; ++q)
-                *reinterpret_cast<uint4 *>(v + i + 4 * q) = make_uint4(e0 + x[4 * q], e0 + x[4 * q + 1], e0 + x[4 * q + 2], e0 + x[4 * q + 3]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < SCAN_PER_THREAD; ++q) if (i + q < n) v[i + q] = e0 + x[q];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { v[n] = s_carry; *jobs.job[blockIdx.x].total = s_carry; }
+    scan_block_u32(jobs.job[blockIdx.x], s_wave, s_carry);
 }
 
 // ------------------------------------------------------------------ comparison rules

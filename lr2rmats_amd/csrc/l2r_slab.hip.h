@@ -61,6 +61,12 @@ __host__ __device__ __forceinline__ uint32_t slab_rows_of(uint32_t c) { return (
 // row of exon j of a read with n exons (the last exon in row 0)
 __device__ __forceinline__ uint32_t slab_row(uint32_t j, uint32_t n) { return j + 1u < n ? j + 1u : 0u; }
 
+// k_walk_slab -> k_describe_scan, one 16-byte record per tile: chromosome, first and last base of the tile's reads, and (one byte per
+// wave of the probe kernels) the largest exon count among the reads of each slot group
+// ... and what of the descriptor's load chain does not need the tile's last base: the cursor value of its first read, its chromosome's
+// first bucket and bucket count (looked up by one wave of k_walk_slab while its CIGAR vectors are in flight)
+// ... and, for the probe kernels, the tile's reads and slab once more (one record instead of three arrays + the first read's position)
+struct TileSpan { int32_t tid, lo, hi; uint32_t rows; int32_t jl, tb, nb, pad; uint32_t r0, n_act, sbase, pad2; };
 struct SlabArgs {
     PipeArgs g;
     const uint32_t *tile_sbase;                          // first element of every tile's slab (+ a closing entry)
@@ -68,7 +74,8 @@ struct SlabArgs {
     int32_t *dense_start, *dense_end;                    // outliers: exon k of a run at run + k
     unsigned long long *ovf_cursor;                      // next free element of the dense area
     uint32_t *pre, *loc;                                 // k_walk_slab -> k_probe_slab, slot order: PRE_* word; exons of the tile's reads before this one (read order)
-    TileWin *tw;                                         // k_walk_slab -> k_probe_slab: descriptor + window per tile
+    TileWin *tw;                                         // k_describe_scan -> the probe kernels: descriptor + window per tile
+    TileSpan *span;                                      // k_walk_slab -> k_describe_scan: what a tile's descriptor is made from
     // tw64[tile]: the 64-member window record of a tile whose window holds 33 .. 63 transcripts (TD_WIDE).  The tiles of
     // k_probe_slab_wide / k_probe_slab_chunked are listed by block 1 of the scan launch between the walk and the probes (TileLists,
     // l2r_kernels.hip.h): wide_list / chunk_list, list_cnt[0] / [1] = entries, [2] / [3] = the kernels' work cursors.  A one-window
@@ -117,8 +124,6 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[TILE_THREADS], s_loc[TILE_THREADS];      // exon counts / their exclusive scan, READ order
     __shared__ int s_wmax[TILE_THREADS / WAVE];
     __shared__ uint32_t s_wn[TILE_THREADS / WAVE];
-    __shared__ __attribute__((aligned(16))) TileWin s_tw;
-    __shared__ __attribute__((aligned(16))) TileWin64 s_tw64;
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
@@ -166,14 +171,16 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
                 cg[4 * q] = (uint32_t)x.x; cg[4 * q + 1] = (uint32_t)x.y; cg[4 * q + 2] = (uint32_t)x.z; cg[4 * q + 3] = (uint32_t)x.w;
             }
     }
-    // The tile's cursor value (first transcript its sweep can reach: three dependent SCALAR loads, on their own counter) is looked up
-    // here, by the wave that will make the tile's descriptor, while the CIGAR vectors above are in flight -- not at the end, in front
-    // of the descriptor's own load chain.
-    int jl_early = INT32_MIN;
+    // The head of the tile descriptor's load chain (k_describe_scan): the cursor value of the tile's first read (first transcript its
+    // sweep can reach: three dependent SCALAR loads, on their own counter) and the chromosome's bucket range, by one wave, while the
+    // CIGAR vectors above are in flight.
     if (wv == TILE_THREADS / WAVE - 1 && n_act) {
         CursorDir cd;
         cd.key = a->cd.key; cd.dir = a->cd.dir; cd.kb_base = a->cd.kb_base; cd.n_tid = a->cd.n_tid; cd.n_tx = a->cd.n_tx;
-        jl_early = cursor_value(cd, tid0, pos0 + 1);
+        const int jl = cursor_value(cd, tid0, pos0 + 1);
+        int tb = 0, nb = 0;
+        if (tid0 >= 0 && tid0 < a->n_tid_dir) { tb = a->tid_base[tid0]; nb = a->tid_base[tid0 + 1] - tb; }
+        if (lane == 0) reinterpret_cast<int4 *>(sa->span + t)[1] = make_int4(jl, tb, nb, 0);
     }
 #pragma unroll
     for (int i = 0; i < SLAB_HEAD; ++i) cg[i] = (uint32_t)i < n_cig ? cg[i] : 1u;
@@ -261,6 +268,9 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
         // (The cursor of the outlier area is cleared by k_probe_slab for the next run.)
         uint32_t *const cnt = a->f.redo_count;
         cnt[0] = 0u; cnt[1] = 0u; cnt[2] = 0u;
+        // ... and the tile lists of k_probe_slab_wide / k_probe_slab_chunked with their work cursors (k_describe_scan appends)
+        uint32_t *const lc = sa->list_cnt;
+        lc[0] = 0u; lc[1] = 0u; lc[2] = 0u; lc[3] = 0u;
     }
     __syncthreads();
     // ---- every read's place among the tile's exons in READ order: each wave scans the 256 counts (four per lane) for itself
@@ -277,22 +287,125 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
         sa->pre[at] = idx | (((xw >> 16) & 1u) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (outlier ? PRE_DENSE : 0u) | (n << PRE_N_SHIFT);
         sa->loc[at] = s_loc[idx];
     }
-    // ---- the tile's descriptor and window, by the last wave alone (the others are done): nobody waits for its load chain
-    // (the last wave holds the tile's shortest CIGARs -- slots go by falling length -- and is done with its walk first; handing the
-    //  descriptor round the waves by tile number instead was measured: walk 0.256 -> 0.273 ms)
-    if (wv != TILE_THREADS / WAVE - 1) return;
-    if (lane == 0) a->tile_total[t] = total;             // (one word per tile, scanned by k_scan_u32: a single counter would serialise 156 k waves)
-    const int32_t tile_hi = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-    make_descriptor(a, lane, tid0, pos0 + 1, tile_hi, true, &s_tw, (uint32_t)SLAB_KEY_CAP, sa->tw64 ? &s_tw64 : nullptr, jl_early);
-    if (s_tw.d.flags & TD_WIDE) {
-        // a window of 33 .. 63 members: its 64-member record goes to tw64[tile], k_probe_slab_wide finds the tile by its flags
-        for (int i = lane; i < (int)(sizeof(TileWin64) / 16); i += WAVE) reinterpret_cast<int4 *>(sa->tw64 + t)[i] = reinterpret_cast<const int4 *>(&s_tw64)[i];
+    // ---- what the tile's descriptor is made from (k_describe_scan, one wave per tile, in the launch of the scan): its chromosome, its
+    //      first and last base, the rows each wave of the probe kernels has to look at; and its exon count
+    //      (Until round 4 the last wave of this workgroup made the descriptor itself, with the other three gone: its chain of five
+    //       dependent round trips kept the workgroup's LDS and wave slots for 0.047 of the kernel's 0.284 ms.)
+    if (threadIdx.x == 0) {
+        a->tile_total[t] = total;                        // (one word per tile, scanned by k_describe_scan: a single counter would serialise 156 k waves)
+        const int32_t tile_hi = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+        const uint32_t rows = s_wn[0] | (s_wn[1] << 8) | (s_wn[2] << 16) | (s_wn[3] << 24);
+        reinterpret_cast<int4 *>(sa->span + t)[0] = make_int4(tid0, pos0 + 1, tile_hi, (int)rows);
+        reinterpret_cast<int4 *>(sa->span + t)[2] = make_int4((int)r0, (int)n_act, (int)sbase, 0);
     }
-    if (lane == 0) s_tw.pad[1] = (uint32_t)tile_hi;          // the tile's last base (k_probe_slab_chunked scans the window itself)
-    if (lane == 0) sa->tile_flags[t] = s_tw.d.flags;
-    if (lane == 0) s_tw.pad[0] = s_wn[0] | (s_wn[1] << 8) | (s_wn[2] << 16) | (s_wn[3] << 24);     // rows each wave of k_probe_slab has to look at
-    {   const uint32_t n_win = (s_tw.d.flags & TD_FAST) ? s_tw.d.n_win : 0u;
-        for (int i = lane; i < SLAB_TW_VECS; i += WAVE) if (tw_vec_used(i, n_win)) reinterpret_cast<int4 *>(sa->tw + t)[i] = reinterpret_cast<const int4 *>(&s_tw)[i]; }
+}
+
+// ---------------------------------------------------------------------------------------------------------- k_describe_scan
+// The launch between the walk and the probes, 256-thread workgroups in two roles.
+//   Workgroups [0, n_scan): the exclusive scan of the tiles' exon counts (every tile's first slot in the read-order result arrays), a
+//       segment of DESCRIBE_SEG counts each.  A workgroup adds up the counts in front of its segment itself (a few 16-byte loads per
+//       thread, all in flight: the segments do not wait for each other) -- for the 39 k tiles of 10 M reads that is ten workgroups and
+//       about one round trip, where one workgroup took three dependent rounds (13 us).  Inputs beyond DESCRIBE_SCAN_MAX tiles scan
+//       with k_scan_u32 in a launch of its own (n_scan = 0).
+//   Workgroups [n_scan, ...): the tiles' descriptors and windows, SIXTEEN LANES PER TILE, four tiles per wave (make_descriptor:
+//       dictionary slice bounds, window scan from the cursor value k_walk_slab looked up, member headers, masks), written straight
+//       into tw[tile] (tw64[tile] for a window of 33 .. 63 members).  With a wave per tile the launch took 31 us for the 39 k tiles:
+//       each is a chain of three round trips, and only 8192 waves are resident at a time; with sixteen lanes per tile nearly all
+//       tiles are in flight at once.  A workgroup's 16 tiles that belong to k_probe_slab_wide / k_probe_slab_chunked are appended to
+//       those kernels' lists with ONE reservation per workgroup and list (no particular order; list_cnt is cleared by k_walk_slab).
+// in: the tiles' exon counts (n of them); out: their exclusive scan, n + 1 words (NOT in place: a workgroup reads the segments in front of
+// its own while their workgroups write); total: the sum once more (the engine's totals[0])
+struct DescribeScan { const uint32_t *in; uint32_t *out; uint32_t *total; int64_t n; };
+constexpr int DESCRIBE_G = 16;                           // lanes per tile
+constexpr int DESCRIBE_TILES = TILE_THREADS / DESCRIBE_G;       // tiles per workgroup
+constexpr int DESCRIBE_PER_THREAD = 16;
+constexpr int DESCRIBE_SEG = TILE_THREADS * DESCRIBE_PER_THREAD;     // counts per scanning workgroup
+constexpr int64_t DESCRIBE_SCAN_MAX = (int64_t)DESCRIBE_SEG * 64;    // (262 k tiles = 67 M reads: beyond that the summing in front costs more than it saves)
+__global__ __launch_bounds__(TILE_THREADS, 8)
+void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan)
+{
+    __shared__ int s_win[DESCRIBE_TILES][64];
+    __shared__ uint32_t s_flags[DESCRIBE_TILES];
+    __shared__ uint32_t s_part[2][TILE_THREADS / WAVE];
+    (void)kernarg_block;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    if (blockIdx.x < n_scan) {
+        // ---- scan role: segment blockIdx.x of the counts
+        const uint32_t *__restrict__ v = job.in;
+        const uint32_t n = (uint32_t)job.n, seg0 = blockIdx.x * (uint32_t)DESCRIBE_SEG;
+        const uint32_t i = seg0 + (uint32_t)DESCRIBE_PER_THREAD * threadIdx.x;
+        uint32_t x[DESCRIBE_PER_THREAD];
+        if (i + DESCRIBE_PER_THREAD <= n) {
+#pragma unroll
+            for (int q = 0; q < DESCRIBE_PER_THREAD / 4; ++q) {
+                const uint4 t4 = *reinterpret_cast<const uint4 *>(v + i + 4 * q);
+                x[4 * q] = t4.x; x[4 * q + 1] = t4.y; x[4 * q + 2] = t4.z; x[4 * q + 3] = t4.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < DESCRIBE_PER_THREAD; ++q) x[q] = i + q < n ? v[i + q] : 0u;
+        }
+        // everything in front of the segment (whole segments: 16 counts per thread each)
+        uint32_t before = 0u;
+#pragma unroll 2
+        for (uint32_t sgm = 0; sgm < blockIdx.x; ++sgm) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(v + sgm * (uint32_t)DESCRIBE_SEG + (uint32_t)DESCRIBE_PER_THREAD * threadIdx.x);
+            const uint4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
+            before += (a0.x + a0.y + a0.z + a0.w) + (a1.x + a1.y + a1.z + a1.w) + (a2.x + a2.y + a2.z + a2.w) + (a3.x + a3.y + a3.z + a3.w);
+        }
+        uint32_t mine = 0u;
+#pragma unroll
+        for (int q = 0; q < DESCRIBE_PER_THREAD; ++q) { const uint32_t tq = x[q]; x[q] = mine; mine += tq; }      // x: exclusive inside the thread
+        const uint32_t inc = wave_inclusive_scan(mine), bsum = wave_sum(before);
+        if (lane == WAVE - 1) s_part[0][wv] = inc;
+        if (lane == 0) s_part[1][wv] = bsum;
+        __syncthreads();
+        uint32_t wbase = 0u, tot = 0u, carry = 0u;
+#pragma unroll
+        for (int k = 0; k < TILE_THREADS / WAVE; ++k) { const uint32_t tk = s_part[0][k]; if (k < wv) wbase += tk; tot += tk; carry += s_part[1][k]; }
+        uint32_t *__restrict__ out = job.out;
+        const uint32_t e0 = carry + wbase + inc - mine;
+        if (i + DESCRIBE_PER_THREAD <= n) {
+#pragma unroll
+            for (int q = 0; q < DESCRIBE_PER_THREAD / 4; ++q)
+                *reinterpret_cast<uint4 *>(out + i + 4 * q) = make_uint4(e0 + x[4 * q], e0 + x[4 * q + 1], e0 + x[4 * q + 2], e0 + x[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < DESCRIBE_PER_THREAD; ++q) if (i + q < n) out[i + q] = e0 + x[q];
+        }
+        if (blockIdx.x == n_scan - 1u && threadIdx.x == 0) { out[n] = carry + tot; *job.total = carry + tot; }      // the sum = the run's exon count
+        return;
+    }
+    // ---- describe role
+    const SlabArgsK sa = slab_args();
+    const PipeArgsK a = pipe_args();
+    const int g = lane / DESCRIBE_G, gl = lane % DESCRIBE_G, slot = wv * (WAVE / DESCRIBE_G) + g;
+    const uint32_t t0 = (blockIdx.x - n_scan) * (uint32_t)DESCRIBE_TILES;
+    const uint32_t t = t0 + (uint32_t)slot;
+    uint32_t flags = TD_FAST;                            // (behind the last tile: nobody's)
+    if (t < sa->n_tiles) {
+        const int4 spv = reinterpret_cast<const int4 *>(sa->span + t)[0], spw = reinterpret_cast<const int4 *>(sa->span + t)[1];
+        flags = make_descriptor<DESCRIBE_G>(a, gl, g * DESCRIBE_G, spv.x, spv.y, spv.z, sa->tw + t, sa->tw64 ? sa->tw64 + t : nullptr, s_win[slot],
+                                            (uint32_t)SLAB_KEY_CAP, spw.x, spw.y, spw.z, (uint32_t)spv.w);
+        if (gl == 0) sa->tile_flags[t] = flags;
+    }
+    // ---- the workgroup's tiles for the 64-bit-mask and the chunked kernel
+    if (gl == 0) s_flags[slot] = flags;
+    __syncthreads();
+    if (wv == 0) {
+        const uint32_t f = lane < DESCRIBE_TILES ? s_flags[lane] : TD_FAST;
+        const uint32_t tl = t0 + (uint32_t)lane;
+        const bool is_w = (f & TD_WIDE) != 0u, is_c = sa->chunk_on && slab_tile_is_chunked(f);
+        const unsigned long long mw = __ballot(is_w), mc = __ballot(is_c);
+        if (mw | mc) {
+            uint32_t bw = 0u, bc = 0u;
+            if (lane == 0) { if (mw) bw = atomicAdd(sa->list_cnt + 0, (uint32_t)__popcll(mw)); if (mc) bc = atomicAdd(sa->list_cnt + 1, (uint32_t)__popcll(mc)); }
+            bw = (uint32_t)__builtin_amdgcn_readfirstlane((int)bw); bc = (uint32_t)__builtin_amdgcn_readfirstlane((int)bc);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (is_w) sa->wide_list[bw + (uint32_t)__popcll(mw & below)] = tl;
+            if (is_c) sa->chunk_list[bc + (uint32_t)__popcll(mc & below)] = tl;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------- k_probe_slab
@@ -584,8 +697,8 @@ __device__ __forceinline__ void slab_write_out(const SlabOut &out0 /* dst = xbas
 constexpr int slab_probe_wgs(int) { return 7; }
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, slab_probe_wgs(LEVEL))
-void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase,
-                  const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase /* first result slot of every tile: the scanned exon counts (+ the total) */)
+void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, const TileWin *__restrict__ u_tw,
+                  const uint32_t *__restrict__ u_xbase /* first result slot of every tile: the scanned exon counts (+ the total) */)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
     __shared__ __attribute__((aligned(16))) uint32_t s_A[SLAB_POS_CAP];
@@ -601,26 +714,30 @@ void k_probe_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fi
     const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
     if (t >= sa->n_tiles) return;
     SlabStamp stamp; stamp.start(a->f.stamps);
-    const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
-    const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t], total = u_xbase[t + 1u] - xbase;
-    const int32_t tile_lo = u_pos[r0] + 1;                       // the base of the tile's row words: its first read's first base (coordinate-sorted records)
+    // The tile's reads, slab and first base from ONE record of k_walk_slab, its descriptor, its first result slot: every scalar load
+    // of the prologue is asked for before the first one is waited for (the empty asm "uses" them all here: the compiler would sink
+    // some of them behind the early returns below, i.e. into a second and a third round trip).
+    const TileSpan sp = u_span[t];
+    const TileDesc d = u_tw[t].d;
+    const uint32_t xbase = u_xbase[t], xnext = u_xbase[t + 1u];
+    const uint32_t chunk_on = sa->chunk_on; const int32_t ablate = a->f.p.ablate;
+    asm volatile("" :: "s"(chunk_on), "s"(ablate), "s"(sp.lo), "s"(sp.rows), "s"(sp.r0), "s"(sp.n_act), "s"(sp.sbase), "s"(xbase), "s"(xnext),
+                       "s"(d.j_lo), "s"(d.b_off), "s"(d.nb), "s"(d.b0), "s"(d.nbk), "s"(d.st_r0), "s"(d.st_nk), "s"(d.en_r0), "s"(d.en_nk), "s"(d.flags), "s"(d.n_win));
+    const uint32_t r0 = sp.r0, n_act = sp.n_act, sbase = sp.sbase, total = xnext - xbase, rows_w = sp.rows;
+    const int32_t tile_lo = sp.lo;                               // the base of the tile's row words: its first read's first base (coordinate-sorted records)
     v4i_t *const s_ent0 = s_ent, *const s_ent1 = s_ent + SLAB_KEY_CAP;
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
-    // ---- one round trip behind the descriptor (scalar loads: uniform address): the tile's dictionary slices, its window
-    //      (k_walk_slab), the slot's words and rows 0 .. 4 of its column (the last exon and the first four) -- all asked for
-    //      before anything is looked at, and nothing of it at an address that depends on another load
-    const TileDesc d = u_tw[t].d;
     if (t == 0u && threadIdx.x == 0) *sa->ovf_cursor = 0ull;      // (k_walk_slab is done: the outlier area's cursor is cleared for the next run)
     if (d.flags & TD_WIDE) return;                               // k_probe_slab_wide takes the tile
     // no window record fits the tile's window, or its dictionary slices do not fit the staging here: k_probe_slab_chunked takes it,
     // 63 members at a time, with the entries that matter for them (it finds the tile by these flags)
-    if (sa->chunk_on && slab_tile_is_chunked(d.flags)) return;
+    if (chunk_on && slab_tile_is_chunked(d.flags)) return;
     // the rows any read of this wave has (k_walk_slab): rows behind them are not asked for
     // thread -> slot: the slot groups (k_walk_slab: by falling CIGAR length, group 0 = the tile's longest reads) are rotated over
     // the waves by a hash of the tile number (L2R_ABLATE bit 3: off)
-    const uint32_t rot = (a->f.p.ablate & 8) ? 0u : ((t ^ (t >> 3) ^ (t >> 7)) & 3u);
+    const uint32_t rot = (ablate & 8) ? 0u : ((t ^ (t >> 3) ^ (t >> 7)) & 3u);
     const uint32_t slot = (threadIdx.x + (rot << 6)) & (uint32_t)(TILE_THREADS - 1);
-    const uint32_t row_max = max((u_tw[t].pad[0] >> (8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot >> 6)))) & 0xffu, 1u) - 1u;
+    const uint32_t row_max = max((rows_w >> (8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot >> 6)))) & 0xffu, 1u) - 1u;
     const DictRegs dv = load_dict_slices(a, d);
     int4 twv = make_int4(0, 0, 0, 0);
     if ((int)threadIdx.x < SLAB_TW_VECS && tw_vec_used((int)threadIdx.x, (d.flags & TD_FAST) ? d.n_win : 0u)) twv = reinterpret_cast<const int4 *>(u_tw + t)[threadIdx.x];

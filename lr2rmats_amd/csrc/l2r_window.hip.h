@@ -3,6 +3,7 @@
 // makes it (make_descriptor), and the loads of a tile's dictionary slices.  The classic pipeline (l2r_kernels.hip.h) makes the
 // same descriptor inside k_pass_a.
 #pragma once
+#include <cstddef>
 #include "l2r_kernels.hip.h"
 
 namespace l2r {
@@ -45,39 +46,46 @@ struct TileWin64 {
     unsigned long long mask[2];
 };
 
-// The tile's dictionary slices and transcript window from its span [tlo, thi] on chromosome tid0 -- the descriptor
-// k_pass_a leaves in HBM, made by ONE WAVE of the workgroup (everything is wave-uniform but `lane`).  The window's
-// member headers go straight into LDS.
-// With W64 (slab pipeline): a window of 33 .. 63 members is collected into *W64 and the tile is flagged TD_WIDE instead of
-// TD_FAST (W then only carries the descriptor); up to 32 members everything is as without it.
-__device__ __forceinline__ void make_descriptor(PipeArgsK a, int lane, int32_t tid0, int32_t tlo, int32_t thi, bool in_lds, TileWin *W,
-                                                uint32_t key_cap = (uint32_t)PIPE_KEY_CAP, TileWin64 *W64 = nullptr, int jl_known = INT32_MIN /* the cursor value of (tid0, tlo), when the caller has looked it up already */)
+// A predicate's votes inside a GROUP of G consecutive lanes of the wave (G = 64: the wave), bit i = lane i of the group.
+// gshift = first lane of the group.  Lanes of other groups that have left a divergent loop simply do not vote.
+template <int G>
+__device__ __forceinline__ unsigned long long group_ballot(bool p, int gshift)
 {
-    const uint32_t win_cap = W64 ? (uint32_t)WIDE_MEMBERS : (uint32_t)WIN_TX;
-    int *const win_out = W64 ? W64->win : W->win;
+    const unsigned long long b = __ballot(p);
+    if (G == WAVE) return b;
+    return (b >> gshift) & ((1ull << (G & 63)) - 1ull);
+}
+
+// The tile's dictionary slices and transcript window from its span [tlo, thi] on chromosome tid0 -- the descriptor the probe
+// kernels start from -- made by ONE GROUP OF G LANES (k_describe_scan: four tiles per wave, 16 lanes each; everything here is
+// group-uniform but `lane`, the lane's number inside its group).  The record is written straight into its home in HBM (Wg; Wg64 for
+// a window of 33 .. 63 members, the tile then is flagged TD_WIDE instead of TD_FAST and Wg only carries the descriptor); only the
+// window's transcript numbers pass through LDS (win_s: 64 words per group), where the lanes that found them and the lanes that
+// fetch their headers meet.  Returns the descriptor's flags.
+// jl = the cursor value of (tid0, tlo); tb, nb = the chromosome's first bucket and bucket count (k_walk_slab has looked them up).
+template <int G>
+__device__ __forceinline__ uint32_t make_descriptor(PipeArgsK a, int lane, int gshift, int32_t tid0, int32_t tlo, int32_t thi, TileWin *Wg, TileWin64 *Wg64,
+                                                    int *win_s, uint32_t key_cap, int jl, int tb, int nb, uint32_t rows_word)
+{
+    const uint32_t win_cap = Wg64 ? (uint32_t)WIDE_MEMBERS : (uint32_t)WIN_TX;
     const TxHdr *const hdr = a->f.hdr;
     const int32_t n_tx = a->f.p.n_tx;
-    int tb = 0, nb = 0;
-    if (tid0 >= 0 && tid0 < a->n_tid_dir) { tb = a->tid_base[tid0]; nb = a->tid_base[tid0 + 1] - tb; }
     int lo = INT32_MAX, hi = -1;
     if (nb > 0) { lo = min(max(tlo, 0) >> SITE_SHIFT, nb - 1); hi = min(max(thi, 0) >> SITE_SHIFT, nb - 1); }
     TileDesc d;
     d.tid = tid0; d.b_off = 0; d.nb = 0; d.b0 = 0; d.nbk = 0;
     d.st_r0 = d.st_nk = d.en_r0 = d.en_nk = 0u; d.n_win = 0u;
-    bool fast = in_lds && a->f.p.ss_dis == 0 && !(a->f.p.ablate & 1);
-    uint32_t why = fast ? 0u : (!in_lds ? 1u : 7u);
+    bool fast = a->f.p.ss_dis == 0 && !(a->f.p.ablate & 1);
+    uint32_t why = fast ? 0u : 7u;
     uint32_t sd_r0 = 0u, sd_r1 = 0u, ed_r0 = 0u, ed_r1 = 0u;
     const bool sliced = fast && hi >= 0 && hi - lo + 1 <= DIR_CAP;
     if (fast && hi >= 0 && !sliced) { fast = false; why = 2u; }
     if (sliced) {
-        sd_r0 = a->f.st.rdir[tb + lo]; sd_r1 = a->f.st.dir[tb + hi + 1];
-        ed_r0 = a->f.en.dir[tb + lo]; ed_r1 = a->f.en.dir[tb + hi + 1];
+        sd_r0 = ld32(a->f.st.rdir, (uint32_t)(tb + lo)); sd_r1 = ld32(a->f.st.dir, (uint32_t)(tb + hi + 1));
+        ed_r0 = ld32(a->f.en.dir, (uint32_t)(tb + lo)); ed_r1 = ld32(a->f.en.dir, (uint32_t)(tb + hi + 1));
     }
     // sorted input: the smallest cursor value of the tile is the one of its first read, and no read needs
     // its own: a member below a read's cursor value lies entirely before that read, which visit_window sees by itself
-    CursorDir cd;
-    cd.key = a->cd.key; cd.dir = a->cd.dir; cd.kb_base = a->cd.kb_base; cd.n_tid = a->cd.n_tid; cd.n_tx = a->cd.n_tx;
-    const int jl = jl_known != INT32_MIN ? jl_known : cursor_value(cd, tid0, tlo);
     d.j_lo = jl;
     bool contig = true;
     uint32_t n_win = 0;
@@ -92,12 +100,12 @@ __device__ __forceinline__ void make_descriptor(PipeArgsK a, int lane, int32_t t
                 const bool bef = h0.x < tid0 || (h0.x == tid0 && h0.z <= tlo && h0.y < tlo);
                 ov = !aft && !bef;
             }
-            const unsigned long long ma = __ballot(aft);
-            const int stop = ma ? __ffsll((long long)ma) - 1 : WAVE;
-            const unsigned long long mo = __ballot(ov) & (stop < WAVE ? (1ull << stop) - 1ull : ~0ull);
+            const unsigned long long ma = group_ballot<G>(aft, gshift);
+            const int stop = ma ? __ffsll((long long)ma) - 1 : G;
+            const unsigned long long mo = group_ballot<G>(ov, gshift) & (stop < 64 ? (1ull << stop) - 1ull : ~0ull);
             if ((mo >> lane) & 1ull) {
                 const uint32_t rank = n_win + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull));
-                if (rank < win_cap) win_out[rank] = j;
+                if (rank < win_cap) win_s[rank] = j;
             }
             if (mo) {
                 if (first < 0) first = base + __ffsll((long long)mo) - 1;
@@ -105,8 +113,8 @@ __device__ __forceinline__ void make_descriptor(PipeArgsK a, int lane, int32_t t
             }
             n_win += (uint32_t)__popcll(mo);
             if (ma) break;
-            base += WAVE;
-            if (n_win > win_cap || trip == WIN_SCAN_TRIPS - 1) { fast = false; why = n_win > win_cap ? 4u : 5u; break; }
+            base += G;
+            if (n_win > win_cap || trip == WIN_SCAN_TRIPS * (WAVE / G) - 1) { fast = false; why = n_win > win_cap ? 4u : 5u; break; }
         }
         if (fast && n_win > win_cap) { fast = false; why = 4u; }
         if (fast) {
@@ -120,44 +128,49 @@ __device__ __forceinline__ void make_descriptor(PipeArgsK a, int lane, int32_t t
         d.en_r0 = ed_r0; d.en_nk = ed_r1 - ed_r0;
         if (fast && (d.st_nk > key_cap || d.en_nk > key_cap)) { fast = false; why = 3u; }
     }
-    const bool wide = fast && d.n_win > (uint32_t)WIN_TX;      // (only with W64)
+    const bool wide = fast && d.n_win > (uint32_t)WIN_TX;      // (only with Wg64)
     d.flags = (fast ? (wide ? TD_WIDE : TD_FAST) : 0u) | (contig ? TD_CONTIG : 0u) | (why << 8);
-    if (wide) {
-        // all 64 lanes: one member each
+    // the members' headers, G members per round (the group's own LDS writes above are visible to it: same wave, in order), straight
+    // into the record; masks of the members with one exon / without TX_COMPACT
+    const int w_n = fast ? (int)d.n_win : 0;
+    int4 *const hk_out = wide ? Wg64->hk : Wg->hk, *const hx_out = wide ? Wg64->hx : Wg->hx;
+    int *const win_out = wide ? Wg64->win : Wg->win;
+    unsigned long long b1 = 0ull, b2 = 0ull;
+    for (int m0 = 0; m0 < w_n; m0 += G) {
+        const int m = m0 + lane;
         bool single = false, loose = false;
-        if (lane < (int)d.n_win) {
-            const int j = W64->win[lane];
+        if (m < w_n) {
+            const int j = win_s[m];
             const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);
             const int4 h0 = hp[0], h1 = hp[1], h2 = hp[2];
             int st = h0.y, en = h0.z;
-            if (h0.x < tid0) { st = INT32_MIN; en = INT32_MIN; }
+            if (h0.x < tid0) { st = INT32_MIN; en = INT32_MIN; }            // another chromosome: before / after every read
             else if (h0.x > tid0) { st = INT32_MAX; en = INT32_MAX; }
-            W64->hk[lane] = make_int4(st, en, h1.x, (h1.z & 0xff) | (h1.y << 8));
-            W64->hx[lane] = h2;
+            hk_out[m] = make_int4(st, en, h1.x, (h1.z & 0xff) | (h1.y << 8));
+            hx_out[m] = h2;
+            win_out[m] = j;
             single = h1.x == 1; loose = !((h1.z & 0xff) & TX_COMPACT);
         }
-        const unsigned long long b1 = __ballot(single), b2 = __ballot(loose);
-        if (lane == 0) { W64->d = d; W64->mask[0] = b1; W64->mask[1] = b2; W->d = d; W->mask[0] = 0u; W->mask[1] = 0u; }
-        return;
+        b1 |= group_ballot<G>(single, gshift) << m0; b2 |= group_ballot<G>(loose, gshift) << m0;
     }
-    if (W64 && lane < WIN_TX) W->win[lane] = W64->win[lane];                // (narrow after all: the members move to the 32-member record)
-    // the members' headers (the wave's own LDS writes above are visible to it: same wave, in order)
-    const int w_n = fast ? (int)d.n_win : 0;
-    bool single = false, loose = false;
-    if (lane < w_n) {
-        const int j = W->win[lane];
-        const int4 *hp = reinterpret_cast<const int4 *>(hdr + j);
-        const int4 h0 = hp[0], h1 = hp[1], h2 = hp[2];
-        int st = h0.y, en = h0.z;
-        if (h0.x < tid0) { st = INT32_MIN; en = INT32_MIN; }            // another chromosome: before / after every read
-        else if (h0.x > tid0) { st = INT32_MAX; en = INT32_MAX; }
-        W->hk[lane] = make_int4(st, en, h1.x, (h1.z & 0xff) | (h1.y << 8));
-        W->hx[lane] = h2;
-        single = h1.x == 1; loose = !((h1.z & 0xff) & TX_COMPACT);
+    if (lane == 0) {
+        // descriptor + masks + {rows per wave of the probe kernels, the tile's last base}: the last 64 bytes of the record
+        int4 *const tail = reinterpret_cast<int4 *>(&Wg->d);
+        const int4 v0 = make_int4(d.j_lo, d.tid, d.b_off, d.nb), v1 = make_int4(d.b0, d.nbk, (int)d.st_r0, (int)d.st_nk),
+                   v2 = make_int4((int)d.en_r0, (int)d.en_nk, (int)d.flags, (int)d.n_win);
+        tail[0] = v0; tail[1] = v1; tail[2] = v2;
+        tail[3] = wide ? make_int4(0, 0, (int)rows_word, thi) : make_int4((int)(uint32_t)b1, (int)(uint32_t)b2, (int)rows_word, thi);
+        if (wide) {
+            int4 *const t64 = reinterpret_cast<int4 *>(&Wg64->d);
+            t64[0] = v0; t64[1] = v1; t64[2] = v2;
+            t64[3] = make_int4((int)(uint32_t)b1, (int)(uint32_t)(b1 >> 32), (int)(uint32_t)b2, (int)(uint32_t)(b2 >> 32));
+        }
     }
-    const unsigned long long b1 = __ballot(single), b2 = __ballot(loose);
-    if (lane == 0) { W->d = d; W->mask[0] = (uint32_t)b1; W->mask[1] = (uint32_t)b2; }
+    return d.flags;
 }
+static_assert(offsetof(TileWin, d) % 16 == 0 && sizeof(TileDesc) == 48 && offsetof(TileWin, mask) == offsetof(TileWin, d) + 48 && offsetof(TileWin, pad) == offsetof(TileWin, d) + 56,
+              "make_descriptor writes the tail of a TileWin as four 16-byte vectors");
+static_assert(offsetof(TileWin64, d) % 16 == 0 && offsetof(TileWin64, mask) == offsetof(TileWin64, d) + 48 && sizeof(TileWin64) == offsetof(TileWin64, d) + 64, "... and of a TileWin64");
 
 // base[idx] = v with a 32-bit byte offset (see ld32): one shift per lane instead of a 64-bit multiply-add
 template <typename T>
