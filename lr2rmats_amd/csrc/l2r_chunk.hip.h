@@ -231,7 +231,7 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, const uint32_t *__restrict__ u
         q.last = SlabRow{0u};
 #pragma unroll
         for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = SlabRow{0u};
-        if (active) { pre = ld32(sa->pre, at); loc = ld32(sa->loc, at); q.last = slab_load_row(xw, off); }
+        if (active) { slab_preloc(sa, t, at, pre, loc); q.last = slab_load_row(xw, off); }
         const uint32_t n = pre >> PRE_N_SHIFT;
         const uint32_t r = r0 + (pre & 0xffu);
         const bool outlier = (pre & PRE_DENSE) != 0u, rev_in = (pre & PRE_REV) != 0u;

@@ -70,7 +70,7 @@ struct l2r_ctx {
     int want_pipeline = 1;                  // L2R_PIPELINE: classic (0: l2r_kernels.hip.h, two walks), slab (1, default: l2r_slab.hip.h, one walk)
     bool slab_ok = false;                   // the current upload can run the slab pipeline: coordinate-sorted records, short CIGARs, its slab layout fits
     bool slab = false;                      // ... and the last launch did (the parameters have a say: launch_all)
-    DevBuf<uint32_t> tile_sbase, s_pre, s_loc, tile_total, tile_xbase, tile_span;    // (tile_span: 16-byte TileSpan records, l2r_slab.hip.h)
+    DevBuf<uint32_t> tile_sbase, s_pre, s_loc, s_pl, cig_off32, tile_rec, tile_total, tile_xbase, tile_span;    // (tile_span: 16-byte TileSpan records, l2r_slab.hip.h)
     DevBuf<int32_t> dense_start, dense_end;                 // slab pipeline: the outliers' dense area
     DevBuf<uint32_t> slab_row;                              //                the exon rows between its kernels (one word per exon)
     DevBuf<TileWin> tw;
@@ -223,7 +223,7 @@ void l2r_destroy(l2r_ctx *c)
     c->win_start.release(); c->sj_cursor.release();
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
-    c->tile_total.release(); c->tile_xbase.release(); c->tile_span.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_list.release(); c->chunk_list.release(); c->list_cnt.release(); c->tile_flags.release();
+    c->tile_total.release(); c->tile_xbase.release(); c->tile_rec.release(); c->cig_off32.release(); c->s_pl.release(); c->tile_span.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_list.release(); c->chunk_list.release(); c->list_cnt.release(); c->tile_flags.release();
     c->slab_row.release(); c->dense_start.release(); c->dense_end.release(); c->s_pre.release(); c->s_loc.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -823,6 +823,19 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
                 c->dense_start.ensure((size_t)ovf + 1) || c->dense_end.ensure((size_t)ovf + 1)) return -2;
             HIP_TRY(hipMemsetAsync(c->ovf_cursor.p, 0, 8, c->stream));
             HIP_TRY(hipMemcpyAsync(c->tile_sbase.p, sbase.data(), (T + 1) * 4, hipMemcpyHostToDevice, c->stream));
+            // the tiles' records for k_walk_slab (TileRec: reads, slab, chromosome and first base of the tile in one place) and the
+            // records' CIGAR offsets in 32 bits (the walk reads 4 bytes per record instead of 8 at a stride of 8)
+            std::vector<TileRec> rec(T ? T : 1);
+            for (size_t t = 0; t < T; ++t) {
+                TileRec &q = rec[t];
+                q.r0 = tile_first[t]; q.n_act = tile_first[t + 1] - tile_first[t]; q.sbase = sbase[t]; q.rows = (sbase[t + 1] - sbase[t]) >> 8;
+                q.tid0 = q.n_act ? r->tid[q.r0] : 0; q.lo = (q.n_act ? r->pos[q.r0] : 0) + 1; q.pad[0] = q.pad[1] = 0u;
+            }
+            std::vector<uint32_t> off32((size_t)N + 1);
+            for (int64_t i = 0; i <= N; ++i) off32[(size_t)i] = (uint32_t)r->cig_off[i];
+            if (c->tile_rec.ensure(8 * (T + 1)) || c->cig_off32.ensure((size_t)N + 2) || c->s_pl.ensure((size_t)N + 1)) return -2;
+            HIP_TRY(hipMemcpyAsync(c->tile_rec.p, rec.data(), rec.size() * sizeof(TileRec), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->cig_off32.p, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));       // (locals)
         }
     }
@@ -958,18 +971,16 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         sa.g.f = fa; sa.g.cd = cd; sa.g.tid_base = c->tid_base.p; sa.g.n_tid_dir = c->n_tid_dir; sa.g.tile_total = c->tile_total.p;
         sa.tile_sbase = c->tile_sbase.p; sa.slab_row = c->slab_row.p;
         sa.dense_start = c->dense_start.p; sa.dense_end = c->dense_end.p; sa.ovf_cursor = c->ovf_cursor.p;
-        sa.pre = c->s_pre.p; sa.loc = c->s_loc.p; sa.tw = c->tw.p; sa.span = (TileSpan *)c->tile_span.p;
+        sa.pl = c->s_pl.p; sa.pre_x = c->s_pre.p; sa.loc_x = c->s_loc.p; sa.cig_off32 = c->cig_off32.p; sa.tw = c->tw.p; sa.span = (TileSpan *)c->tile_span.p;
         sa.n_tiles = (uint32_t)c->n_tiles;
         const unsigned gx = 8u * (unsigned)std::max<int64_t>((c->n_tiles + 7) / 8, 1);      // (l2r_slab.hip.h xcd_tile; an empty upload still launches)
         sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p;
         sa.chunk_on = (c->ablate & 32) ? 0u : 1u;          // (L2R_ABLATE bit 2: no 64-member windows, bit 5: no chunked windows)
         sa.wide_list = c->wide_list.p; sa.chunk_list = c->chunk_list.p; sa.list_cnt = c->list_cnt.p; sa.tile_flags = c->tile_flags.p;
         if (p.min_exon >= 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_slab<false>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p,
-                               (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_slab<false>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const TileRec *)c->tile_rec.p);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_slab<true>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p,
-                               (const int32_t *)c->r_tid.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_slab<true>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const TileRec *)c->tile_rec.p);
         MARK(ST_SCAN1);
         {   // the tiles' exon counts -> their first slots in the read-order result arrays (tile_xbase; the sum = the exon count): the
             // first workgroups of the launch, a segment each; the tiles' descriptors and windows, sixteen lanes per tile, and the lists

@@ -53,6 +53,9 @@ constexpr uint32_t PRE_REV = 1u << 8;
 constexpr uint32_t PRE_INSANE = 1u << 9;                 // first or last exon empty (or, with -e < 1, any exon): the generic kernel decides
 constexpr uint32_t PRE_DENSE = 1u << 10;                 // an outlier: its exons are in the dense area (row 0 of its column holds the run's index)
 constexpr int PRE_N_SHIFT = 11;
+constexpr int PL_LOC_SHIFT = 19;                         // packed word: PRE_* bits and an 8-bit exon count below, `loc` (13 bits) above
+constexpr uint32_t PL_PRE_MASK = (1u << PL_LOC_SHIFT) - 1u;
+constexpr uint32_t PL_N_LIMIT = 1u << (PL_LOC_SHIFT - PRE_N_SHIFT), PL_LOC_LIMIT = 1u << (32 - PL_LOC_SHIFT);
 
 // c ops -> rows its read needs at most when every kept inner exon is at least one base long (min_exon >= 1): each kept exon but
 // the first and the last needs an op of its own next to its cut (src/bam2gtf.c:31-78), so n <= (c + 3) / 2.  With -e < 1 the walk
@@ -61,19 +64,26 @@ __host__ __device__ __forceinline__ uint32_t slab_rows_of(uint32_t c) { return (
 // row of exon j of a read with n exons (the last exon in row 0)
 __device__ __forceinline__ uint32_t slab_row(uint32_t j, uint32_t n) { return j + 1u < n ? j + 1u : 0u; }
 
+// What the upload knows of a tile, one 32-byte record (k_walk_slab starts from it: one scalar load instead of a chain of three):
+// its reads [r0, r0 + n_act), the first element of its slab and the rows it has, its chromosome and first base (its first read's).
+struct TileRec { uint32_t r0, n_act, sbase, rows; int32_t tid0, lo; uint32_t pad[2]; };
 // k_walk_slab -> k_describe_scan, one 16-byte record per tile: chromosome, first and last base of the tile's reads, and (one byte per
 // wave of the probe kernels) the largest exon count among the reads of each slot group
 // ... and what of the descriptor's load chain does not need the tile's last base: the cursor value of its first read, its chromosome's
 // first bucket and bucket count (looked up by one wave of k_walk_slab while its CIGAR vectors are in flight)
 // ... and, for the probe kernels, the tile's reads and slab once more (one record instead of three arrays + the first read's position)
-struct TileSpan { int32_t tid, lo, hi; uint32_t rows; int32_t jl, tb, nb, pad; uint32_t r0, n_act, sbase, pad2; };
+struct TileSpan { int32_t tid, lo, hi; uint32_t rows; int32_t jl, tb, nb, pad; uint32_t r0, n_act, sbase, fat; };     // fat: see SlabArgs::pl
 struct SlabArgs {
     PipeArgs g;
     const uint32_t *tile_sbase;                          // first element of every tile's slab (+ a closing entry)
     uint32_t *slab_row;                                  // the slabs: one word per exon (slab_pack)
     int32_t *dense_start, *dense_end;                    // outliers: exon k of a run at run + k
     unsigned long long *ovf_cursor;                      // next free element of the dense area
-    uint32_t *pre, *loc;                                 // k_walk_slab -> k_probe_slab, slot order: PRE_* word; exons of the tile's reads before this one (read order)
+    // k_walk_slab -> the probe kernels, slot order, ONE word per read (slab_preloc): the PRE_* word with the exon count in 8 bits below the
+    // exons of the tile's reads in front of this one (read order) in 13 bits.  A tile with a read of 256 exons or more or with 8192 exons
+    // or more (outliers make such tiles) is FAT: its reads' two words go to pre_x / loc_x instead, whole.
+    uint32_t *pl, *pre_x, *loc_x;
+    const uint32_t *cig_off32;                           // the records' CIGAR offsets once more, 32 bit (made at upload: a shard has < 2^32 words)
     TileWin *tw;                                         // k_describe_scan -> the probe kernels: descriptor + window per tile
     TileSpan *span;                                      // k_walk_slab -> k_describe_scan: what a tile's descriptor is made from
     // tw64[tile]: the 64-member window record of a tile whose window holds 33 .. 63 transcripts (TD_WIDE).  The tiles of
@@ -111,35 +121,44 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t grid) { return
 constexpr int SLAB_KEY_CAP = 168;                        // dictionary entries staged per dictionary and tile (k_probe_slab's LDS: 20 KB = 8 workgroups per CU)
 static_assert(sizeof(TileWin) % 16 == 0, "TileWin is copied in 16-byte pieces");
 
+// a read's PRE_* word and `loc` as k_walk_slab left them (the probe kernels behind k_probe_slab; that one spells it out around its loads)
+__device__ __forceinline__ void slab_preloc(SlabArgsK sa, uint32_t t, uint32_t at, uint32_t &pre, uint32_t &loc)
+{
+    if (sa->span[t].fat) { pre = ld32(sa->pre_x, at); loc = ld32(sa->loc_x, at); }
+    else { const uint32_t w = ld32(sa->pl, at); pre = w & PL_PRE_MASK; loc = w >> PL_LOC_SHIFT; }
+}
+
 // ---------------------------------------------------------------------------------------------------------- k_walk_slab
 // GENERAL: -e < 1 (an inner exon may be empty: every exon's sanity is checked, and the read leaves the slab when it has more exons
 // than the tile's slab has rows -- with min_exon >= 1 the row bound from the CIGAR length makes that impossible).
 template <bool GENERAL>
 __global__ __launch_bounds__(TILE_THREADS, 8)
-void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_first, const int32_t *__restrict__ u_tid,
-                 const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase)
+void k_walk_slab(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
 {
     __shared__ uint32_t s_hist[WAVE];
     __shared__ uint32_t s_x0[TILE_THREADS], s_x1[TILE_THREADS], s_x2[TILE_THREADS];       // the records' fields, slot order
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[TILE_THREADS], s_loc[TILE_THREADS];      // exon counts / their exclusive scan, READ order
     __shared__ int s_wmax[TILE_THREADS / WAVE];
-    __shared__ uint32_t s_wn[TILE_THREADS / WAVE];
+    __shared__ uint32_t s_wn[TILE_THREADS / WAVE], s_nmax[TILE_THREADS / WAVE];
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
     if (t >= sa->n_tiles) return;
-    const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
-    const int32_t tid0 = n_act ? u_tid[r0] : 0, pos0 = n_act ? u_pos[r0] : 0;
-    const uint32_t sbase = u_tile_sbase[t], rows_tile = (u_tile_sbase[t + 1u] - sbase) >> 8;
+    // (the tile's record from the upload: the vector loads below are the kernel's second round trip, not its fourth)
+    const TileRec rec = u_rec[t];
+    asm volatile("" :: "s"(rec.r0), "s"(rec.n_act), "s"(rec.sbase), "s"(rec.rows), "s"(rec.tid0), "s"(rec.lo));
+    const uint32_t r0 = rec.r0, n_act = rec.n_act;
+    const int32_t tid0 = rec.tid0, pos0 = rec.lo - 1;
+    const uint32_t sbase = rec.sbase, rows_tile = rec.rows;
     // ---- the tile's reads by falling CIGAR length (counting sort, 64 bins): thread i brings read i, slot s takes what landed there
     {
         const uint32_t i = threadIdx.x;
         uint32_t c_lo = 0u, c = 0u, rev = 0u; int32_t pos = 0;
         if (i < n_act) {
-            const int64_t *const p_off = a->f.cig_off;
-            c_lo = (uint32_t)ld32(p_off, r0 + i); c = (uint32_t)ld32(p_off, r0 + i + 1u) - c_lo;      // (a shard has < 2^32 words)
+            const uint32_t *const p_off = sa->cig_off32;
+            c_lo = ld32(p_off, r0 + i); c = ld32(p_off, r0 + i + 1u) - c_lo;
             pos = ld32(a->f.r_pos, r0 + i); rev = ld32(a->f.r_rev, r0 + i) ? 1u : 0u;
         }
         if (i < (uint32_t)WAVE) s_hist[i] = 0u;
@@ -242,8 +261,8 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     if (active && outlier) {
         // an outlier: the literal walk (l2r_kernels.hip.h), twice -- count, take a run of the dense area, store
         const uint32_t r = r0 + idx;
-        const int64_t *const p_off = a->f.cig_off;
-        const uint32_t n_ops = (uint32_t)(ld32(p_off, r + 1u) - ld32(p_off, r));
+        const uint32_t *const p_off = sa->cig_off32;
+        const uint32_t n_ops = ld32(p_off, r + 1u) - ld32(p_off, r);
         const uint32_t *const words = a->f.cig + c_lo;
         {
             WalkState w{pos + 1, pos, 0};
@@ -262,7 +281,8 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
     s_cnt[idx] = active ? n : 0u;                        // (every entry is written: idx is a permutation of 0 .. 255)
     const int m = wave_max(active ? el : INT32_MIN);
     const int wn = wave_max((active && !outlier) ? (int)n : 0);
-    if (lane == 0) { s_wmax[wv] = m; s_wn[wv] = (uint32_t)min(wn, 255); }
+    const int wn_all = wave_max(active ? (int)min(n, 0x7fffffffu) : 0);
+    if (lane == 0) { s_wmax[wv] = m; s_wn[wv] = (uint32_t)min(wn, 255); s_nmax[wv] = (uint32_t)wn_all; }
     if (t == 0u && threadIdx.x == 0) {
         // the run's counters (this kernel is the first of a run): redo list, chunk cursor of the accepted list.
         // (The cursor of the outlier area is cleared by k_probe_slab for the next run.)
@@ -282,10 +302,13 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
         reinterpret_cast<uint4 *>(s_loc)[lane] = make_uint4(ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z);     // (the four waves write the same values)
         total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
     }
+    // (a fat tile: some read's exon count or place does not fit the packed word -- only outliers make such tiles)
+    const bool fat = total >= PL_LOC_LIMIT || max(max(s_nmax[0], s_nmax[1]), max(s_nmax[2], s_nmax[3])) >= PL_N_LIMIT;
     if (active) {
         const uint32_t at = r0 + threadIdx.x;
-        sa->pre[at] = idx | (((xw >> 16) & 1u) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (outlier ? PRE_DENSE : 0u) | (n << PRE_N_SHIFT);
-        sa->loc[at] = s_loc[idx];
+        const uint32_t word = idx | (((xw >> 16) & 1u) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (outlier ? PRE_DENSE : 0u) | (n << PRE_N_SHIFT);
+        if (!fat) sa->pl[at] = word | (s_loc[idx] << PL_LOC_SHIFT);
+        else { sa->pl[at] = 0u; sa->pre_x[at] = word; sa->loc_x[at] = s_loc[idx]; }
     }
     // ---- what the tile's descriptor is made from (k_describe_scan, one wave per tile, in the launch of the scan): its chromosome, its
     //      first and last base, the rows each wave of the probe kernels has to look at; and its exon count
@@ -296,7 +319,7 @@ void k_walk_slab(SlabArgs kernarg_block, const uint32_t *__restrict__ u_tile_fir
         const int32_t tile_hi = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
         const uint32_t rows = s_wn[0] | (s_wn[1] << 8) | (s_wn[2] << 16) | (s_wn[3] << 24);
         reinterpret_cast<int4 *>(sa->span + t)[0] = make_int4(tid0, pos0 + 1, tile_hi, (int)rows);
-        reinterpret_cast<int4 *>(sa->span + t)[2] = make_int4((int)r0, (int)n_act, (int)sbase, 0);
+        reinterpret_cast<int4 *>(sa->span + t)[2] = make_int4((int)r0, (int)n_act, (int)sbase, fat ? 1 : 0);
     }
 }
 
@@ -721,7 +744,7 @@ void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, c
     const TileDesc d = u_tw[t].d;
     const uint32_t xbase = u_xbase[t], xnext = u_xbase[t + 1u];
     const uint32_t chunk_on = sa->chunk_on; const int32_t ablate = a->f.p.ablate;
-    asm volatile("" :: "s"(chunk_on), "s"(ablate), "s"(sp.lo), "s"(sp.rows), "s"(sp.r0), "s"(sp.n_act), "s"(sp.sbase), "s"(xbase), "s"(xnext),
+    asm volatile("" :: "s"(chunk_on), "s"(ablate), "s"(sp.lo), "s"(sp.rows), "s"(sp.r0), "s"(sp.n_act), "s"(sp.sbase), "s"(sp.fat), "s"(xbase), "s"(xnext),
                        "s"(d.j_lo), "s"(d.b_off), "s"(d.nb), "s"(d.b0), "s"(d.nbk), "s"(d.st_r0), "s"(d.st_nk), "s"(d.en_r0), "s"(d.en_nk), "s"(d.flags), "s"(d.n_win));
     const uint32_t r0 = sp.r0, n_act = sp.n_act, sbase = sp.sbase, total = xnext - xbase, rows_w = sp.rows;
     const int32_t tile_lo = sp.lo;                               // the base of the tile's row words: its first read's first base (coordinate-sorted records)
@@ -743,7 +766,7 @@ void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, c
     if ((int)threadIdx.x < SLAB_TW_VECS && tw_vec_used((int)threadIdx.x, (d.flags & TD_FAST) ? d.n_win : 0u)) twv = reinterpret_cast<const int4 *>(u_tw + t)[threadIdx.x];
     const bool active = slot < n_act;
     const uint32_t at = r0 + (active ? slot : 0u);
-    uint32_t pre = 0u, loc = 0u;
+    uint32_t pre = 0u, loc = 0u, plw = 0u;
     const uint32_t *const xw = sa->slab_row;
     const uint32_t off = sbase + slot;
     SlabRows q;
@@ -751,12 +774,14 @@ void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, c
 #pragma unroll
     for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = SlabRow{0u};
     if (active) {
-        pre = ld32(sa->pre, at); loc = ld32(sa->loc, at);
+        plw = ld32(sa->pl, at);
+        if (sp.fat) { pre = ld32(sa->pre_x, at); loc = ld32(sa->loc_x, at); }
         q.last = slab_load_row(xw, off);
 #pragma unroll
         for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = slab_load_row(xw, off + min((uint32_t)i + 1u, row_max) * SLAB_STRIDE);      // (an outlier's column holds nothing: read, not used)
     }
     if (threadIdx.x == 0) s_lim = min(total, (uint32_t)SLAB_POS_CAP);
+    if (!sp.fat) { pre = plw & PL_PRE_MASK; loc = plw >> PL_LOC_SHIFT; }
     const uint32_t n = pre >> PRE_N_SHIFT;
     const uint32_t r = r0 + (pre & 0xffu);
     const SlabRow first = n == 1u ? q.last : q.x[0];

@@ -283,7 +283,7 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
 #pragma unroll
         for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = SlabRow{0u};
         if (active) {
-            pre = ld32(sa->pre, at); loc = ld32(sa->loc, at);
+            slab_preloc(sa, t, at, pre, loc);
             q.last = slab_load_row(xw, off);
 #pragma unroll
             for (int i = 0; i < SLAB_AHEAD; ++i) q.x[i] = slab_load_row(xw, off + min((uint32_t)i + 1u, row_max) * SLAB_STRIDE);      // (an outlier's column holds nothing: read, not used)

@@ -368,3 +368,26 @@ def test_locus_beyond_the_mask_width_is_taken_in_chunks(oracle, level, n_iso, pi
     assert cnt[1] > 0                                                             # keys in several entries exist
     if pipeline == "slab":
         assert cnt[0] == 0, cnt                                                   # nothing left to the generic kernel
+
+
+def test_reads_of_300_and_9000_exons_between_ordinary_neighbours(oracle, pipeline):
+    """The walk hands a read's exon count and its place among its tile's exons to the probe kernels in ONE word (8 + 13 bits,
+    l2r_slab.hip.h SlabArgs::pl); a tile with a read of 256 exons or more, or with 8192 exons or more, is "fat" and uses the two
+    whole words instead.  Only outliers (reads beyond 24 slab rows) make such tiles: a 300-exon read and a 9000-exon read sit in
+    the middle of tiles of ordinary reads here, whose results must not move."""
+    txs = [(0, 0, [(1_000, 1_100), (1_300, 1_400), (1_600, 1_700)]), (1, 0, [(5_000, 5_100), (5_300, 5_400)])]
+    af = _anno(txs)
+    rows = []
+    for k in range(600):
+        rows.append((0, *_chain([(1_000 + k % 60, 1_100), (1_300, 1_400), (1_600, 1_700 - k % 5)])))
+        rows.append((1, *_chain([(5_000 + k % 30, 5_100), (5_300, 5_400)])))
+    rows.append((0, *_chain([(1_020 + 40 * j, 1_030 + 40 * j) for j in range(300)])))          # 300 exons: its count does not fit 8 bits
+    rows.append((1, *_chain([(5_010 + 30 * j, 5_020 + 30 * j) for j in range(9_000)])))        # 9000 exons: the places behind it do not fit 13 bits
+    rows = [(r[0], r[1], 0, r[2]) for r in rows]
+    cnt = [0, 0, 0, 0]
+    got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=3)
+    n_ex = np.diff(want.ex_off)
+    assert int((n_ex == 300).sum()) == 1 and int((n_ex == 9_000).sum()) == 1
+    assert ((want.info & 2) != 0).sum() > 500
+    if pipeline == "slab":
+        assert 2 <= cnt[0] <= 300, cnt                # the two long reads (and the reads of their tiles that no longer fit the staged positions)
