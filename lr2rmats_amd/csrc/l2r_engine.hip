@@ -998,8 +998,12 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             hipLaunchKernelGGL(k_describe_scan, dim3(gd), dim3(TILE_THREADS), 0, s, sa, job, (uint32_t)n_scan);
         }
         MARK(ST_FAST);
-#define launch_probe_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
-            (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p)
+        // (with the accepted list wanted and no junction table to decide later, the tiles leave their accepted chunks themselves)
+        const bool probe_acc = (c->want & L2R_WANT_ACCEPTED) && c->n_sj == 0;
+#define launch_probe_level(L) do { if (probe_acc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L, true>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
+            (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L, false>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
+            (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p); } while (0)
         switch (p.full_level) {
         case 1: launch_probe_level(1); break;
         case 2: launch_probe_level(2); break;
@@ -1038,8 +1042,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             }
 #undef launch_chunk_level
         }
-        // every tile's accepted reads are compacted by k_gather_accepted (nothing is fused into the classification here)
-        if (c->want & L2R_WANT_ACCEPTED) HIP_TRY(hipMemsetAsync(c->tile_chunk.p, 0xff, (size_t)(c->n_tiles + 1) * 4, s));
+        // (accepted list: k_describe_scan marks every tile CHUNK_DEFERRED, k_probe_slab<., true> takes that back for the tiles whose
+        //  chunk it has written itself; k_count_accepted / k_gather_accepted place the rest)
     } else {
     // sorted input: the cursor value of every read is computed on the device; unsorted input: it was replayed on the host
     if (c->wide_cigar)
@@ -1084,7 +1088,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     }
     if ((c->n_sj > 0 || c->slab) && (c->want & L2R_WANT_ACCEPTED)) {
         // acceptance is decided by the junction check (and the slab pipeline counts nothing itself): count per tile
-            hipLaunchKernelGGL(k_count_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->info.p, c->tile_acc.p, c->tile_acc_ex.p);
+            hipLaunchKernelGGL(k_count_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->info.p, (const uint32_t *)c->tile_chunk.p, c->tile_acc.p, c->tile_acc_ex.p);
     }
     MARK(ST_SCAN2);
     if (c->want & L2R_WANT_ACCEPTED) {

@@ -1872,10 +1872,12 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
 // Tiles are the classification tiles (reads_per_tile records, one workgroup).
 
 __global__ __launch_bounds__(TILE_THREADS)
-void k_count_accepted(const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ info, uint32_t *__restrict__ tile_reads,
-                      uint32_t *__restrict__ tile_exons)
+void k_count_accepted(const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ info, const uint32_t *__restrict__ tile_chunk,
+                      uint32_t *__restrict__ tile_reads, uint32_t *__restrict__ tile_exons)
 {
     __shared__ uint32_t s_cnt[4], s_ex[4];
+    // (a tile whose classification kernel has written its chunk itself has left zeros here: nothing of it is k_gather_accepted's)
+    if (tile_chunk[blockIdx.x] != CHUNK_DEFERRED) return;          // (workgroup-uniform)
     const uint32_t r0 = tile_first[blockIdx.x], n_act = tile_first[blockIdx.x + 1] - r0;
     const int64_t r = (int64_t)r0 + threadIdx.x;
     const uint32_t w = threadIdx.x < n_act ? info[r] : 0u;

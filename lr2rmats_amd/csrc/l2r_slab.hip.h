@@ -411,6 +411,8 @@ void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan)
         flags = make_descriptor<DESCRIBE_G>(a, gl, g * DESCRIBE_G, spv.x, spv.y, spv.z, sa->tw + t, sa->tw64 ? sa->tw64 + t : nullptr, s_win[slot],
                                             (uint32_t)SLAB_KEY_CAP, spw.x, spw.y, spw.z, (uint32_t)spv.w);
         if (gl == 0) sa->tile_flags[t] = flags;
+        // (accepted list: every tile's chunk is k_gather_accepted's until a probe kernel has left it itself)
+        if (gl == 0 && (a->f.p.want & WANT_ACCEPTED)) a->f.tile_chunk[t] = CHUNK_DEFERRED;
     }
     // ---- the workgroup's tiles for the 64-bit-mask and the chunked kernel
     if (gl == 0) s_flags[slot] = flags;
@@ -457,7 +459,7 @@ struct SlabRows { SlabRow last, x[SLAB_AHEAD]; };        // a column's row 0 (th
 // behind that or further than 2^18 - 1 bases from the tile's start is written directly and classified by the generic kernel.
 // (Measured: 8 bytes per position at 6 workgroups per CU 0.474 ms, this form 0.462; 2112 positions at 8 workgroups per CU and
 // 64 VGPRs: 0.594 -- 17 spilled registers and 13 % more tiles.)
-constexpr int SLAB_POS_CAP = 2544;                       // (k_probe_slab's LDS = 23040 bytes = 45 granules of 512: 7 workgroups per CU exactly; 2416 before: 1.1 % more tiles)
+constexpr int SLAB_POS_CAP = 2536;                       // (k_probe_slab's LDS = 23040 bytes = 45 granules of 512: 7 workgroups per CU exactly; 2416 before: 1.1 % more tiles)
 constexpr uint32_t SLAB_POS_SKIP = 0xffffffffu;          // A of a position that was written directly (a staged start is below 2^18 - 1)
 struct SlabStage { uint32_t *A; uint16_t *Ln; uint32_t loc; int32_t lo; bool fits; };          // loc: the lane's first position, lo: the tile's first start
 
@@ -635,8 +637,9 @@ __device__ __forceinline__ void slab_copy_exons(SlabArgsK sa, PipeArgsK a, const
 // Verdicts of one tile's reads (slot order) from the staged window + dictionaries: the device functions of the classic kernel
 // on slab-resident exons; exons, work words and then flag bytes at their positions in LDS (or, for a read that does not fit
 // there, in the result arrays), info / ref_tx / ex_off per read, redo list.
+struct SlabVerdict { uint32_t info; int ref; bool redo; };
 template <int LEVEL>
-__device__ __forceinline__ void slab_classify(SlabArgsK sa, PipeArgsK a, const TileDesc &d, const SlabLds &S, const int4 *hk, const int4 *hx, const int *win,
+__device__ __forceinline__ SlabVerdict slab_classify(SlabArgsK sa, PipeArgsK a, const TileDesc &d, const SlabLds &S, const int4 *hk, const int4 *hx, const int *win,
                                               const uint32_t *tilemask, bool active, uint32_t pre, uint32_t r, uint32_t off, const SlabRows &q,
                                               const ReadEnds &re, const SlabOut &out, const SlabStage &st, int any_wide, SlabStamp &stamp)
 {
@@ -683,6 +686,7 @@ __device__ __forceinline__ void slab_classify(SlabArgsK sa, PipeArgsK a, const T
         }
     }
     if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; a->f.ex_off[r] = out.dst; }
+    return SlabVerdict{info, ref, redo};
 }
 
 // The staged positions [0, lim) of the tile -> the tile's block of the read-order result arrays (first slot xbase): 16-byte stores
@@ -718,7 +722,16 @@ __device__ __forceinline__ void slab_write_out(const SlabOut &out0 /* dst = xbas
 // and 4 needed 74 .. 78 and ran at 6 workgroups per CU (0.418 ms against 0.435 at 7 with 32 bytes of scratch) until the reads' ends
 // stopped living through the probe rounds (slab_classify reads them back from the staged exons): 72 registers, 7 per CU, 0.371 ms.
 constexpr int slab_probe_wgs(int) { return 7; }
-template <int LEVEL>
+// ACC: the caller wants the compacted accepted-novel list and no junction table decides later (update_gtf.c:945-962 with sj_n == 0): a
+// tile whose verdicts are all final here (no read on the redo list) leaves its accepted chunk FROM ITS LDS IMAGE -- records in read
+// order, exons by position -- instead of k_gather_accepted reading the results back (0.72 GB read to write 0.72 GB on config 3).
+// The dictionary slices, directories and the window record are dead behind the classification: the per-read counts (by read number),
+// their scan and the slot -> position map of the accepted exons live there.
+constexpr int SLAB_DIR_BYTES = (3 * FAST_DIR_BYTES + 15) & ~15;
+constexpr int SLAB_AUX_BYTES = SLAB_DIR_BYTES + (int)sizeof(TileWin);
+static_assert(SLAB_AUX_BYTES >= 2 * TILE_THREADS * 4, "the accepted counts and their scan (one word per read each) reuse the directories + window record");
+static_assert(2 * SLAB_KEY_CAP * 16 >= SLAB_POS_CAP * 2, "the slot -> position map of a tile's accepted exons reuses the staged dictionary entries");
+template <int LEVEL, bool ACC>
 __global__ __launch_bounds__(TILE_THREADS, slab_probe_wgs(LEVEL))
 void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, const TileWin *__restrict__ u_tw,
                   const uint32_t *__restrict__ u_xbase /* first result slot of every tile: the scanned exon counts (+ the total) */)
@@ -727,10 +740,12 @@ void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, c
     __shared__ __attribute__((aligned(16))) uint32_t s_A[SLAB_POS_CAP];
     __shared__ __attribute__((aligned(16))) uint16_t s_L[SLAB_POS_CAP];
     __shared__ __attribute__((aligned(16))) v4i_t s_ent[2 * SLAB_KEY_CAP];
-    __shared__ __attribute__((aligned(16))) uint8_t s_dir[3 * DIR_BYTES];
-    __shared__ __attribute__((aligned(16))) TileWin s_tw;
+    __shared__ __attribute__((aligned(16))) uint8_t s_aux[SLAB_AUX_BYTES];       // directories, then the window record
     __shared__ int s_widew[TILE_THREADS / WAVE];
-    __shared__ uint32_t s_lim;
+    __shared__ uint32_t s_redow[TILE_THREADS / WAVE];
+    __shared__ uint32_t s_lim, s_chunk[2];
+    uint8_t *const s_dir = s_aux;
+    TileWin &s_tw = *reinterpret_cast<TileWin *>(s_aux + SLAB_DIR_BYTES);
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
@@ -810,10 +825,80 @@ void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, c
     // the first read that does not fit the staged positions ends the block that is written from LDS (reads are in read order there)
     if (active && loc + n > (uint32_t)SLAB_POS_CAP) atomicMin(&s_lim, loc);      // (a read that is written directly for another reason marks its positions instead)
     stamp.mark(1);
-    slab_classify<LEVEL>(sa, a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, r, off, q, re, out, st, any_wide, stamp);
+    const SlabVerdict vd = slab_classify<LEVEL>(sa, a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, r, off, q, re, out, st, any_wide, stamp);
+    if (ACC) { const int w_redo = __any(vd.redo) ? 1 : 0; if ((threadIdx.x & (WAVE - 1)) == 0) s_redow[threadIdx.x >> 6] = (uint32_t)w_redo; }
     __syncthreads();
+    if (!ACC) {
+        slab_write_out(SlabOut{out.start, out.end, out.flag, xbase}, s_A, s_L, tile_lo, s_lim);
+        stamp.mark(5);
+        return;
+    }
+    // ---- the tile's accepted chunk (see above).  Not fused: the tile stays CHUNK_DEFERRED (k_describe_scan) for k_gather_accepted.
+    const bool fused = (s_redow[0] | s_redow[1] | s_redow[2] | s_redow[3]) == 0u && !(ablate & 2);
+    if (!fused) { slab_write_out(SlabOut{out.start, out.end, out.flag, xbase}, s_A, s_L, tile_lo, s_lim); return; }
+    uint32_t *const s_racc = reinterpret_cast<uint32_t *>(s_aux), *const s_rscan = s_racc + TILE_THREADS;
+    uint16_t *const s_map = reinterpret_cast<uint16_t *>(s_ent);
+    const int lane = threadIdx.x & (WAVE - 1);
+    const bool acc = active && (vd.info & I_ACCEPT) != 0u;
+    // accepted reads (high half) and their exons (low half), by read number inside the tile
+    if (active) s_racc[pre & 0xffu] = acc ? ((1u << 16) | n) : 0u;
+    if (threadIdx.x >= n_act) s_racc[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t ca, cx;
+    {   // every wave scans the 256 words for itself (four per lane)
+        const uint4 c4 = reinterpret_cast<const uint4 *>(s_racc)[lane];
+        const uint32_t sum = c4.x + c4.y + c4.z + c4.w;
+        const uint32_t inc = wave_inclusive_scan(sum), ex = inc - sum;
+        reinterpret_cast<uint4 *>(s_rscan)[lane] = make_uint4(ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z);     // (the four waves write the same values)
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+        ca = tot >> 16; cx = tot & 0xffffu;
+    }
+    unsigned long long chunk = 0ull;                 // {first record slot, first exon slot} of the tile's chunk
+    if (threadIdx.x == 0) {
+        a->f.tile_acc[t] = 0u; a->f.tile_acc_ex[t] = 0u;            // nothing of this tile is left for k_gather_accepted
+        if (ca) chunk = atomicAdd(a->f.chunk_cursor, ((unsigned long long)ca << 32) | cx);      // (the answer travels during the write-out below)
+    }
+    const uint32_t mine = acc ? s_rscan[pre & 0xffu] : 0u;          // records / exons of the tile's accepted reads in front of this one
+    if (acc) for (uint32_t k = 0; k < n; ++k) s_map[(mine & 0xffffu) + k] = (uint16_t)(loc + k);
     slab_write_out(SlabOut{out.start, out.end, out.flag, xbase}, s_A, s_L, tile_lo, s_lim);
-    stamp.mark(5);
+    if (threadIdx.x == 0) {
+        s_chunk[0] = (uint32_t)chunk; s_chunk[1] = (uint32_t)(chunk >> 32);
+        a->f.tile_chunk[t] = (uint32_t)chunk; a->f.tile_rchunk[t] = (uint32_t)(chunk >> 32);
+    }
+    if (ca == 0u) return;
+    __syncthreads();
+    const uint32_t to = s_chunk[0], to_r = s_chunk[1];
+    if (acc) {                                      // the record of the thread's own read
+        const uint32_t rslot = to_r + (mine >> 16);
+        const uint64_t gidx = (uint64_t)(a->f.first_read + (int64_t)r);
+        AccRec rec; rec.read_lo = (uint32_t)gidx; rec.read_hi = (uint32_t)(gidx >> 32); rec.info = vd.info; rec.ref_tx = vd.ref;
+        a->f.acc_rec[rslot] = rec;
+        a->f.acc_ex_off[rslot] = to + (mine & 0xffffu);
+    }
+    {   // the chunk's exons: thread j takes slots 4j .. 4j + 3 (16-byte stores at whatever alignment the chunk has)
+        int32_t *const o_s = a->f.acc_start, *const o_e = a->f.acc_end; uint8_t *const o_f = a->f.acc_flag;
+        for (uint32_t p4 = threadIdx.x * 4u; p4 < cx; p4 += (uint32_t)TILE_THREADS * 4u) {
+            const uint2 m4 = *reinterpret_cast<const uint2 *>(s_map + p4);
+            const uint32_t src[4] = {m4.x & 0xffffu, m4.x >> 16, m4.y & 0xffffu, m4.y >> 16};
+            int sv[4], ev[4]; uint32_t fv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t q_ = p4 + (uint32_t)i < cx ? src[i] : 0u;      // (map entries behind the chunk are stale)
+                const uint32_t av = s_A[q_]; const uint32_t lv = s_L[q_];
+                sv[i] = tile_lo + (int)(av & SLAB_REL_MASK); ev[i] = sv[i] + (int)lv - 1; fv[i] = (av >> SLAB_REL_BITS) & 0xffu;
+            }
+            const uint32_t at_ = to + p4;
+            if (p4 + 4u <= cx) {
+                v4i_t s4, e4; s4.x = sv[0]; s4.y = sv[1]; s4.z = sv[2]; s4.w = sv[3]; e4.x = ev[0]; e4.y = ev[1]; e4.z = ev[2]; e4.w = ev[3];
+                *reinterpret_cast<v4i_a4 *>(o_s + at_) = s4;
+                *reinterpret_cast<v4i_a4 *>(o_e + at_) = e4;
+                *reinterpret_cast<u32_a1 *>(o_f + at_) = fv[0] | (fv[1] << 8) | (fv[2] << 16) | (fv[3] << 24);
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) if (p4 + i < cx) { o_s[at_ + i] = sv[i]; o_e[at_ + i] = ev[i]; o_f[at_ + i] = (uint8_t)fv[i]; }
+            }
+        }
+    }
 }
 
 }  // namespace l2r
