@@ -125,7 +125,7 @@ struct l2r_ctx {
     bool have_win = false;
     // work + results
     int64_t n_tiles = 0, n_tiles256 = 0;
-    DevBuf<uint32_t> local, tile_base, ex_off, info, tile_acc, tile_acc_ex, tile_chunk, tile_rchunk, totals;  // totals[0]=exons [1]=accepted [2]=accepted exons [3]=redo count [4],[5]=chunk cursor of the accepted list (one 64-bit word: exon slot low, record slot high)
+    DevBuf<uint32_t> local, tile_base, ex_off, info, tile_acc, tile_acc_ex, tile_acc_at, tile_acc_ex_at, tile_chunk, tile_rchunk, totals;  // totals[0]=exons [1]=accepted [2]=accepted exons [3]=redo count [4],[5]=chunk cursor of the accepted list (one 64-bit word: exon slot low, record slot high)
     DevBuf<uint32_t> redo;                  // reads the fast kernel hands to the generic one
     DevBuf<uint8_t> order;                  // per tile: reads by falling exon count (pass A)
     DevBuf<TileDesc> desc;
@@ -221,7 +221,7 @@ void l2r_destroy(l2r_ctx *c)
     c->sj_tid.release(); c->sj_don.release(); c->sj_acc.release(); c->sj_uniq.release(); c->sj_multi.release(); c->sj_key.release();
     c->r_tid.release(); c->r_pos.release(); c->r_rev.release(); c->cig_off.release(); c->cig.release();
     c->win_start.release(); c->sj_cursor.release();
-    c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
+    c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_acc_at.release(); c->tile_acc_ex_at.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->tile_total.release(); c->tile_xbase.release(); c->tile_rec.release(); c->cig_off32.release(); c->s_pl.release(); c->tile_span.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_list.release(); c->chunk_list.release(); c->list_cnt.release(); c->tile_flags.release();
     c->slab_row.release(); c->dense_start.release(); c->dense_end.release(); c->s_pre.release(); c->s_loc.release(); c->tw.release();
@@ -788,6 +788,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     if (c->j0.ensure((size_t)N) || c->local.ensure((size_t)N + 1) || c->ex_off.ensure((size_t)N) || c->info.ensure((size_t)N) || c->ref_tx.ensure((size_t)N) ||
         c->redo.ensure((size_t)N) || c->order.ensure((size_t)N + TILE_THREADS) || c->desc.ensure((size_t)c->n_tiles) || c->win_hdr.ensure((size_t)c->n_tiles * WIN_TX) ||
         c->tile_base.ensure((size_t)c->n_tiles + 1) || c->tile_acc.ensure((size_t)c->n_tiles + 1) || c->tile_acc_ex.ensure((size_t)c->n_tiles + 1) ||
+        c->tile_acc_at.ensure((size_t)c->n_tiles + 2) || c->tile_acc_ex_at.ensure((size_t)c->n_tiles + 2) ||
         c->totals.ensure(8) || c->tile_chunk.ensure((size_t)c->n_tiles + 1) || c->tile_rchunk.ensure((size_t)c->n_tiles + 1) || c->ex_start.ensure(exb) || c->ex_end.ensure(exb) || c->ex_flag.ensure(exb) ||
         c->acc_rec.ensure((size_t)N) || c->acc_ex_off.ensure((size_t)N) ||
         c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb) || (c->wide_cigar && c->walked.ensure((size_t)(c->n_tiles + 1) * LDS_EXON_CAP))) return -2;
@@ -1088,18 +1089,27 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     }
     if ((c->n_sj > 0 || c->slab) && (c->want & L2R_WANT_ACCEPTED)) {
         // acceptance is decided by the junction check (and the slab pipeline counts nothing itself): count per tile
-            hipLaunchKernelGGL(k_count_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->info.p, (const uint32_t *)c->tile_chunk.p, c->tile_acc.p, c->tile_acc_ex.p);
+            hipLaunchKernelGGL(k_count_accepted, dim3((gt + 3u) / 4u), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->info.p, (const uint32_t *)c->tile_chunk.p, c->tile_acc.p, c->tile_acc_ex.p, (uint32_t)c->n_tiles);
     }
     MARK(ST_SCAN2);
     if (c->want & L2R_WANT_ACCEPTED) {
-        ScanJobs jobs = {}; jobs.job[0] = ScanJob{c->tile_acc.p, c->n_tiles, c->totals.p + 1}; jobs.job[1] = ScanJob{c->tile_acc_ex.p, c->n_tiles, c->totals.p + 2};
-        hipLaunchKernelGGL(k_scan_u32, dim3(2), dim3(1024), 0, s, jobs);
+        // the deferred tiles' counts -> their places behind the fused chunks (tile_acc_at / tile_acc_ex_at; the sums = totals[1], [2])
+        if (c->n_tiles <= SEG_MAX) {
+            const unsigned n_seg = (unsigned)std::max<int64_t>((c->n_tiles + SEG_COUNT - 1) / SEG_COUNT, 1);
+            hipLaunchKernelGGL(k_scan_segments, dim3(2u * n_seg), dim3(TILE_THREADS), 0, s, SegScan{c->tile_acc.p, c->tile_acc_at.p, c->totals.p + 1, c->n_tiles},
+                               SegScan{c->tile_acc_ex.p, c->tile_acc_ex_at.p, c->totals.p + 2, c->n_tiles}, (uint32_t)n_seg);
+        } else {
+            HIP_TRY(hipMemcpyAsync(c->tile_acc_at.p, c->tile_acc.p, (size_t)c->n_tiles * 4, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(c->tile_acc_ex_at.p, c->tile_acc_ex.p, (size_t)c->n_tiles * 4, hipMemcpyDeviceToDevice, s));
+            ScanJobs jobs = {}; jobs.job[0] = ScanJob{c->tile_acc_at.p, c->n_tiles, c->totals.p + 1}; jobs.job[1] = ScanJob{c->tile_acc_ex_at.p, c->n_tiles, c->totals.p + 2};
+            hipLaunchKernelGGL(k_scan_u32, dim3(2), dim3(1024), 0, s, jobs);
+        }
     }
     MARK(ST_GATHER);
     if (c->want & L2R_WANT_ACCEPTED)
-    hipLaunchKernelGGL(k_gather_accepted, dim3(gt), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->first_read, c->info.p, c->ref_tx.p, c->ex_off.p,
-                       c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->tile_acc.p, c->tile_acc_ex.p, c->tile_chunk.p, c->tile_rchunk.p, c->totals.p + 4,
-                       c->acc_rec.p, c->acc_ex_off.p, c->acc_start.p, c->acc_end.p, c->acc_flag.p);
+    hipLaunchKernelGGL(k_gather_accepted, dim3((gt + GATHER_TILES - 1) / GATHER_TILES), dim3(TILE_THREADS), 0, s, (const uint32_t *)c->tile_first.p, c->first_read, c->info.p, c->ref_tx.p, c->ex_off.p,
+                       c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->tile_acc_at.p, c->tile_acc_ex_at.p, c->tile_chunk.p, c->tile_rchunk.p, c->totals.p + 4,
+                       c->acc_rec.p, c->acc_ex_off.p, c->acc_start.p, c->acc_end.p, c->acc_flag.p, (uint32_t)c->n_tiles);
     MARK(ST_N);
 #undef MARK
     HIP_TRY(hipGetLastError());

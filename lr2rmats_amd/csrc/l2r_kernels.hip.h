@@ -720,6 +720,71 @@ void k_scan_u32(ScanJobs jobs)
     scan_block_u32(jobs.job[blockIdx.x], s_wave, s_carry);
 }
 
+// Exclusive scan of n counts in SEGMENTS, one 256-thread workgroup per segment of SEG_COUNT counts, out of place: a workgroup adds up
+// the counts in front of its segment itself (a few 16-byte loads per thread, all in flight), so the segments do not wait for each
+// other -- for the 39 k tiles of 10 M reads that is ten workgroups and about one round trip, where one workgroup scanning in place
+// (k_scan_u32) takes three dependent rounds (13 us).  in: n counts; out: n + 1 words (the sum last), never `in` itself: a workgroup
+// reads the segments in front of its own while their workgroups write; total: the sum once more.  Worth it up to SEG_MAX counts.
+struct SegScan { const uint32_t *in; uint32_t *out; uint32_t *total; int64_t n; };
+constexpr int SEG_PER_THREAD = 16;
+constexpr int SEG_COUNT = TILE_THREADS * SEG_PER_THREAD;
+constexpr int64_t SEG_MAX = (int64_t)SEG_COUNT * 64;
+__device__ __forceinline__ void scan_segment(const SegScan &job, uint32_t seg, uint32_t n_seg, uint32_t (*s_part)[TILE_THREADS / WAVE] /* [2][4] */)
+{
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const uint32_t *__restrict__ v = job.in;
+    const uint32_t n = (uint32_t)job.n, seg0 = seg * (uint32_t)SEG_COUNT;
+    const uint32_t i = seg0 + (uint32_t)SEG_PER_THREAD * threadIdx.x;
+    uint32_t x[SEG_PER_THREAD];
+    if (i + SEG_PER_THREAD <= n) {
+#pragma unroll
+        for (int q = 0; q < SEG_PER_THREAD / 4; ++q) {
+            const uint4 t4 = *reinterpret_cast<const uint4 *>(v + i + 4 * q);
+            x[4 * q] = t4.x; x[4 * q + 1] = t4.y; x[4 * q + 2] = t4.z; x[4 * q + 3] = t4.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < SEG_PER_THREAD; ++q) x[q] = i + q < n ? v[i + q] : 0u;
+    }
+    // everything in front of the segment (whole segments: 16 counts per thread each)
+    uint32_t before = 0u;
+#pragma unroll 2
+    for (uint32_t sgm = 0; sgm < seg; ++sgm) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(v + sgm * (uint32_t)SEG_COUNT + (uint32_t)SEG_PER_THREAD * threadIdx.x);
+        const uint4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
+        before += (a0.x + a0.y + a0.z + a0.w) + (a1.x + a1.y + a1.z + a1.w) + (a2.x + a2.y + a2.z + a2.w) + (a3.x + a3.y + a3.z + a3.w);
+    }
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int q = 0; q < SEG_PER_THREAD; ++q) { const uint32_t tq = x[q]; x[q] = mine; mine += tq; }      // x: exclusive inside the thread
+    const uint32_t inc = wave_inclusive_scan(mine), bsum = wave_sum(before);
+    if (lane == WAVE - 1) s_part[0][wv] = inc;
+    if (lane == 0) s_part[1][wv] = bsum;
+    __syncthreads();
+    uint32_t wbase = 0u, tot = 0u, carry = 0u;
+#pragma unroll
+    for (int k = 0; k < TILE_THREADS / WAVE; ++k) { const uint32_t tk = s_part[0][k]; if (k < wv) wbase += tk; tot += tk; carry += s_part[1][k]; }
+    uint32_t *__restrict__ out = job.out;
+    const uint32_t e0 = carry + wbase + inc - mine;
+    if (i + SEG_PER_THREAD <= n) {
+#pragma unroll
+        for (int q = 0; q < SEG_PER_THREAD / 4; ++q)
+            *reinterpret_cast<uint4 *>(out + i + 4 * q) = make_uint4(e0 + x[4 * q], e0 + x[4 * q + 1], e0 + x[4 * q + 2], e0 + x[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < SEG_PER_THREAD; ++q) if (i + q < n) out[i + q] = e0 + x[q];
+    }
+    if (seg == n_seg - 1u && threadIdx.x == 0) { out[n] = carry + tot; *job.total = carry + tot; }
+}
+// two such scans in one launch: workgroups [0, n_seg) the first, [n_seg, 2 n_seg) the second
+__global__ __launch_bounds__(TILE_THREADS)
+void k_scan_segments(SegScan j0, SegScan j1, uint32_t n_seg)
+{
+    __shared__ uint32_t s_part[2][TILE_THREADS / WAVE];
+    if (blockIdx.x < n_seg) scan_segment(j0, blockIdx.x, n_seg, s_part);
+    else scan_segment(j1, blockIdx.x - n_seg, n_seg, s_part);
+}
+
 // ------------------------------------------------------------------ comparison rules
 
 __device__ __forceinline__ bool near_eq(int a, int b, int dis) { return __builtin_abs(a - b) <= dis; }
@@ -1871,26 +1936,24 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
 // ------------------------------------------------------------------ compaction of accepted reads
 // Tiles are the classification tiles (reads_per_tile records, one workgroup).
 
+// (one WAVE per tile, four tiles per workgroup: 39 k workgroups that find nothing to do cost 13 us of dispatch alone)
 __global__ __launch_bounds__(TILE_THREADS)
 void k_count_accepted(const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ info, const uint32_t *__restrict__ tile_chunk,
-                      uint32_t *__restrict__ tile_reads, uint32_t *__restrict__ tile_exons)
+                      uint32_t *__restrict__ tile_reads, uint32_t *__restrict__ tile_exons, uint32_t n_tiles)
 {
-    __shared__ uint32_t s_cnt[4], s_ex[4];
-    // (a tile whose classification kernel has written its chunk itself has left zeros here: nothing of it is k_gather_accepted's)
-    if (tile_chunk[blockIdx.x] != CHUNK_DEFERRED) return;          // (workgroup-uniform)
-    const uint32_t r0 = tile_first[blockIdx.x], n_act = tile_first[blockIdx.x + 1] - r0;
-    const int64_t r = (int64_t)r0 + threadIdx.x;
-    const uint32_t w = threadIdx.x < n_act ? info[r] : 0u;
-    const bool acc = (w & I_ACCEPT) != 0;
-    const unsigned long long m = __ballot(acc);
-    const uint32_t ex = wave_sum(acc ? (w >> 8) : 0u);
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    if (lane == 0) { s_cnt[wv] = (uint32_t)__popcll(m); s_ex[wv] = ex; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        tile_reads[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        tile_exons[blockIdx.x] = s_ex[0] + s_ex[1] + s_ex[2] + s_ex[3];
+    const uint32_t t = blockIdx.x * (uint32_t)(TILE_THREADS / WAVE) + (uint32_t)wv;
+    if (t >= n_tiles) return;
+    // (a tile whose classification kernel has written its chunk itself has left zeros here: nothing of it is k_gather_accepted's)
+    if (tile_chunk[t] != CHUNK_DEFERRED) return;          // (wave-uniform)
+    const uint32_t r0 = tile_first[t], n_act = tile_first[t + 1] - r0;
+    uint32_t cnt = 0u, ex = 0u;
+    for (uint32_t i = (uint32_t)lane; i < n_act; i += (uint32_t)WAVE) {
+        const uint32_t w = info[r0 + i];
+        if (w & I_ACCEPT) { ++cnt; ex += w >> 8; }
     }
+    cnt = wave_sum(cnt); ex = wave_sum(ex);
+    if (lane == 0) { tile_reads[t] = cnt; tile_exons[t] = ex; }
 }
 
 
@@ -1905,64 +1968,69 @@ void k_count_accepted(const uint32_t *__restrict__ tile_first, const uint32_t *_
 // the stores are contiguous and the loads run over contiguous pieces.
 constexpr uint32_t MAP_DIRECT = 0xffffu;      // map entry of an exon that its read has copied itself
 
+constexpr int GATHER_TILES = 4;               // tiles per workgroup, in turn (most are not deferred: 39 k workgroups that leave at once cost 13 us of dispatch)
 __global__ __launch_bounds__(TILE_THREADS)
 void k_gather_accepted(const uint32_t *__restrict__ tile_first, int64_t first_read, const uint32_t *__restrict__ info, const int32_t *__restrict__ ref_tx,
                        const uint32_t *__restrict__ ex_off, const int32_t *__restrict__ ex_start, const int32_t *__restrict__ ex_end,
                        const uint8_t *__restrict__ ex_flag, const uint32_t *__restrict__ tile_reads, const uint32_t *__restrict__ tile_exons,
                        uint32_t *__restrict__ tile_chunk, uint32_t *__restrict__ tile_rchunk, const uint32_t *__restrict__ chunk_cursor /* {exons, records} */,
                        AccRec *__restrict__ rec, uint32_t *__restrict__ acc_ex_off, int32_t *__restrict__ acc_start,
-                       int32_t *__restrict__ acc_end, uint8_t *__restrict__ acc_flag)
+                       int32_t *__restrict__ acc_end, uint8_t *__restrict__ acc_flag, uint32_t n_tiles)
 {
     __shared__ uint32_t s_wcnt[4], s_wex[4];
     __shared__ uint16_t s_map[LDS_EXON_CAP];
-    if (tile_chunk[blockIdx.x] != CHUNK_DEFERRED) return;          // (workgroup-uniform)
-    const uint32_t r0 = tile_first[blockIdx.x], n_act = tile_first[blockIdx.x + 1] - r0;
-    const int64_t r = (int64_t)r0 + threadIdx.x;
-    const bool active = threadIdx.x < n_act;
-    const uint32_t w = active ? info[r] : 0u;
-    const bool acc = (w & I_ACCEPT) != 0;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    const unsigned long long m = __ballot(acc);
-    const uint32_t rank_w = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    const uint32_t nex = acc ? (w >> 8) : 0u;
-    const uint32_t inc = wave_inclusive_scan(nex);
-    if (lane == WAVE - 1) { s_wcnt[wv] = (uint32_t)__popcll(m); s_wex[wv] = inc; }
-    const uint32_t ebase0 = chunk_cursor[0] + tile_exons[blockIdx.x], cbase0 = chunk_cursor[1] + tile_reads[blockIdx.x];
-    __syncthreads();
-    const uint32_t e_tot = s_wex[0] + s_wex[1] + s_wex[2] + s_wex[3];        // accepted exons of the tile
-    if (threadIdx.x == 0) { tile_chunk[blockIdx.x] = ebase0; tile_rchunk[blockIdx.x] = cbase0; }
-    uint32_t cb = 0, eb = 0;
-    for (int k = 0; k < wv; ++k) { cb += s_wcnt[k]; eb += s_wex[k]; }
-    const uint32_t src0 = n_act ? ex_off[r0] : 0u;                            // first exon of the tile
-    const uint32_t e_loc = eb + inc - nex;                                    // tile-local compacted exon offset
-    const bool mapped = e_tot <= (uint32_t)LDS_EXON_CAP;
-    if (acc) {
-        const uint32_t src = ex_off[r];
-        const uint32_t slot = cbase0 + cb + rank_w;
-        const uint64_t gidx = (uint64_t)(first_read + r);
-        AccRec a; a.read_lo = (uint32_t)gidx; a.read_hi = (uint32_t)(gidx >> 32); a.info = w; a.ref_tx = ref_tx[r];
-        rec[slot] = a;
-        acc_ex_off[slot] = ebase0 + e_loc;
-        if (mapped && src >= src0 && (uint64_t)(src - src0) + (uint64_t)nex < MAP_DIRECT) {
-            for (uint32_t k = 0; k < nex; ++k) s_map[e_loc + k] = (uint16_t)(src - src0 + k);
-        } else {
-            for (uint32_t k = 0; k < nex; ++k) {
-                if (mapped) s_map[e_loc + k] = (uint16_t)MAP_DIRECT;
-                acc_start[ebase0 + e_loc + k] = ex_start[src + k];
-                acc_end[ebase0 + e_loc + k] = ex_end[src + k];
-                acc_flag[ebase0 + e_loc + k] = ex_flag[src + k];
+    for (uint32_t t = blockIdx.x * (uint32_t)GATHER_TILES; t < min((blockIdx.x + 1u) * (uint32_t)GATHER_TILES, n_tiles); ++t) {
+        if (tile_chunk[t] != CHUNK_DEFERRED) continue;          // (workgroup-uniform)
+        const uint32_t r0 = tile_first[t], n_act = tile_first[t + 1] - r0;
+        const int64_t r = (int64_t)r0 + threadIdx.x;
+        const bool active = threadIdx.x < n_act;
+        const uint32_t w = active ? info[r] : 0u;
+        const bool acc = (w & I_ACCEPT) != 0;
+        const unsigned long long m = __ballot(acc);
+        const uint32_t rank_w = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t nex = acc ? (w >> 8) : 0u;
+        const uint32_t inc = wave_inclusive_scan(nex);
+        if (lane == WAVE - 1) { s_wcnt[wv] = (uint32_t)__popcll(m); s_wex[wv] = inc; }
+        const uint32_t ebase0 = chunk_cursor[0] + tile_exons[t], cbase0 = chunk_cursor[1] + tile_reads[t];
+        __syncthreads();
+        const uint32_t e_tot = s_wex[0] + s_wex[1] + s_wex[2] + s_wex[3];        // accepted exons of the tile
+        if (threadIdx.x == 0) { tile_chunk[t] = ebase0; tile_rchunk[t] = cbase0; }
+        uint32_t cb = 0, eb = 0;
+        for (int k = 0; k < wv; ++k) { cb += s_wcnt[k]; eb += s_wex[k]; }
+        const uint32_t src0 = n_act ? ex_off[r0] : 0u;                            // first exon of the tile
+        const uint32_t e_loc = eb + inc - nex;                                    // tile-local compacted exon offset
+        const bool mapped = e_tot <= (uint32_t)LDS_EXON_CAP;
+        if (acc) {
+            const uint32_t src = ex_off[r];
+            const uint32_t slot = cbase0 + cb + rank_w;
+            const uint64_t gidx = (uint64_t)(first_read + r);
+            AccRec a; a.read_lo = (uint32_t)gidx; a.read_hi = (uint32_t)(gidx >> 32); a.info = w; a.ref_tx = ref_tx[r];
+            rec[slot] = a;
+            acc_ex_off[slot] = ebase0 + e_loc;
+            if (mapped && src >= src0 && (uint64_t)(src - src0) + (uint64_t)nex < MAP_DIRECT) {
+                for (uint32_t k = 0; k < nex; ++k) s_map[e_loc + k] = (uint16_t)(src - src0 + k);
+            } else {
+                for (uint32_t k = 0; k < nex; ++k) {
+                    if (mapped) s_map[e_loc + k] = (uint16_t)MAP_DIRECT;
+                    acc_start[ebase0 + e_loc + k] = ex_start[src + k];
+                    acc_end[ebase0 + e_loc + k] = ex_end[src + k];
+                    acc_flag[ebase0 + e_loc + k] = ex_flag[src + k];
+                }
             }
         }
-    }
-    if (!mapped) return;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < e_tot; i += TILE_THREADS) {
-        const uint32_t q = s_map[i];
-        if (q == MAP_DIRECT) continue;
-        const uint32_t sidx = src0 + q;
-        acc_start[ebase0 + i] = ex_start[sidx];
-        acc_end[ebase0 + i] = ex_end[sidx];
-        acc_flag[ebase0 + i] = ex_flag[sidx];
+        __syncthreads();
+        if (mapped) {
+            for (uint32_t i = threadIdx.x; i < e_tot; i += TILE_THREADS) {
+                const uint32_t q = s_map[i];
+                if (q == MAP_DIRECT) continue;
+                const uint32_t sidx = src0 + q;
+                acc_start[ebase0 + i] = ex_start[sidx];
+                acc_end[ebase0 + i] = ex_end[sidx];
+                acc_flag[ebase0 + i] = ex_flag[sidx];
+            }
+        }
+        __syncthreads();                 // (the next tile of this workgroup overwrites the map and the wave counts)
     }
 }
 

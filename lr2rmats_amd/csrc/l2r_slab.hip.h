@@ -336,13 +336,10 @@ void k_walk_slab(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
 //       each is a chain of three round trips, and only 8192 waves are resident at a time; with sixteen lanes per tile nearly all
 //       tiles are in flight at once.  A workgroup's 16 tiles that belong to k_probe_slab_wide / k_probe_slab_chunked are appended to
 //       those kernels' lists with ONE reservation per workgroup and list (no particular order; list_cnt is cleared by k_walk_slab).
-// in: the tiles' exon counts (n of them); out: their exclusive scan, n + 1 words (NOT in place: a workgroup reads the segments in front of
-// its own while their workgroups write); total: the sum once more (the engine's totals[0])
-struct DescribeScan { const uint32_t *in; uint32_t *out; uint32_t *total; int64_t n; };
+typedef SegScan DescribeScan;
 constexpr int DESCRIBE_G = 16;                           // lanes per tile
 constexpr int DESCRIBE_TILES = TILE_THREADS / DESCRIBE_G;       // tiles per workgroup
-constexpr int DESCRIBE_PER_THREAD = 16;
-constexpr int DESCRIBE_SEG = TILE_THREADS * DESCRIBE_PER_THREAD;     // counts per scanning workgroup
+constexpr int DESCRIBE_SEG = SEG_COUNT;                 // counts per scanning workgroup
 constexpr int64_t DESCRIBE_SCAN_MAX = (int64_t)DESCRIBE_SEG * 64;    // (262 k tiles = 67 M reads: beyond that the summing in front costs more than it saves)
 __global__ __launch_bounds__(TILE_THREADS, 8)
 void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan)
@@ -351,57 +348,11 @@ void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan)
     __shared__ uint32_t s_flags[DESCRIBE_TILES];
     __shared__ uint32_t s_part[2][TILE_THREADS / WAVE];
     (void)kernarg_block;
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    if (blockIdx.x < n_scan) {
-        // ---- scan role: segment blockIdx.x of the counts
-        const uint32_t *__restrict__ v = job.in;
-        const uint32_t n = (uint32_t)job.n, seg0 = blockIdx.x * (uint32_t)DESCRIBE_SEG;
-        const uint32_t i = seg0 + (uint32_t)DESCRIBE_PER_THREAD * threadIdx.x;
-        uint32_t x[DESCRIBE_PER_THREAD];
-        if (i + DESCRIBE_PER_THREAD <= n) {
-#pragma unroll
-            for (int q = 0; q < DESCRIBE_PER_THREAD / 4; ++q) {
-                const uint4 t4 = *reinterpret_cast<const uint4 *>(v + i + 4 * q);
-                x[4 * q] = t4.x; x[4 * q + 1] = t4.y; x[4 * q + 2] = t4.z; x[4 * q + 3] = t4.w;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < DESCRIBE_PER_THREAD; ++q) x[q] = i + q < n ? v[i + q] : 0u;
-        }
-        // everything in front of the segment (whole segments: 16 counts per thread each)
-        uint32_t before = 0u;
-#pragma unroll 2
-        for (uint32_t sgm = 0; sgm < blockIdx.x; ++sgm) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(v + sgm * (uint32_t)DESCRIBE_SEG + (uint32_t)DESCRIBE_PER_THREAD * threadIdx.x);
-            const uint4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
-            before += (a0.x + a0.y + a0.z + a0.w) + (a1.x + a1.y + a1.z + a1.w) + (a2.x + a2.y + a2.z + a2.w) + (a3.x + a3.y + a3.z + a3.w);
-        }
-        uint32_t mine = 0u;
-#pragma unroll
-        for (int q = 0; q < DESCRIBE_PER_THREAD; ++q) { const uint32_t tq = x[q]; x[q] = mine; mine += tq; }      // x: exclusive inside the thread
-        const uint32_t inc = wave_inclusive_scan(mine), bsum = wave_sum(before);
-        if (lane == WAVE - 1) s_part[0][wv] = inc;
-        if (lane == 0) s_part[1][wv] = bsum;
-        __syncthreads();
-        uint32_t wbase = 0u, tot = 0u, carry = 0u;
-#pragma unroll
-        for (int k = 0; k < TILE_THREADS / WAVE; ++k) { const uint32_t tk = s_part[0][k]; if (k < wv) wbase += tk; tot += tk; carry += s_part[1][k]; }
-        uint32_t *__restrict__ out = job.out;
-        const uint32_t e0 = carry + wbase + inc - mine;
-        if (i + DESCRIBE_PER_THREAD <= n) {
-#pragma unroll
-            for (int q = 0; q < DESCRIBE_PER_THREAD / 4; ++q)
-                *reinterpret_cast<uint4 *>(out + i + 4 * q) = make_uint4(e0 + x[4 * q], e0 + x[4 * q + 1], e0 + x[4 * q + 2], e0 + x[4 * q + 3]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < DESCRIBE_PER_THREAD; ++q) if (i + q < n) out[i + q] = e0 + x[q];
-        }
-        if (blockIdx.x == n_scan - 1u && threadIdx.x == 0) { out[n] = carry + tot; *job.total = carry + tot; }      // the sum = the run's exon count
-        return;
-    }
+    if (blockIdx.x < n_scan) { scan_segment(job, blockIdx.x, n_scan, s_part); return; }      // ---- scan role: segment blockIdx.x of the counts
     // ---- describe role
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     const int g = lane / DESCRIBE_G, gl = lane % DESCRIBE_G, slot = wv * (WAVE / DESCRIBE_G) + g;
     const uint32_t t0 = (blockIdx.x - n_scan) * (uint32_t)DESCRIBE_TILES;
     const uint32_t t = t0 + (uint32_t)slot;
