@@ -98,6 +98,7 @@ struct l2r_ctx {
     int64_t n_sj = 0;
     DevBuf<int32_t> sj_tid, sj_don, sj_acc, sj_uniq, sj_multi;
     DevBuf<int64_t> sj_key;
+    DevBuf<int32_t> sj_cbase, sj_dbase; DevBuf<uint32_t> sj_cdir, sj_ddir; int32_t sj_ntid = 0;      // SjDir (l2r_kernels.hip.h)
     std::vector<int64_t> h_sj_key_raw;      // per row (tid,acc) key
     std::vector<int64_t> h_sj_key_pm;       // ... and its running maximum
     // reads
@@ -218,7 +219,7 @@ void l2r_destroy(l2r_ctx *c)
     c->hdr.release(); c->anno_ex.release(); c->anno_key.release();
     c->sk_st.release(); c->sk_en.release(); c->sd_st.release(); c->sd_en.release(); c->sr_st.release(); c->tid_base.release();
     c->key_dir.release(); c->kb_base.release(); c->j0.release();
-    c->sj_tid.release(); c->sj_don.release(); c->sj_acc.release(); c->sj_uniq.release(); c->sj_multi.release(); c->sj_key.release();
+    c->sj_tid.release(); c->sj_don.release(); c->sj_acc.release(); c->sj_uniq.release(); c->sj_multi.release(); c->sj_key.release(); c->sj_cbase.release(); c->sj_cdir.release(); c->sj_dbase.release(); c->sj_ddir.release();
     c->r_tid.release(); c->r_pos.release(); c->r_rev.release(); c->cig_off.release(); c->cig.release();
     c->win_start.release(); c->sj_cursor.release();
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_acc_at.release(); c->tile_acc_ex_at.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
@@ -341,6 +342,35 @@ static void build_dict(const std::vector<SiteTx> &pairs, const std::vector<SiteT
     }
 }
 
+// Directory over non-decreasing 64-bit keys host_key(tid, x): dir[base[tid] + c] = first j with key_j >= (tid, c << 9), one closing word
+// (first j with key_j >= (n_tid, 0)); mx[tid] = the largest x of the chromosome (-1: none, no buckets).  Used for the annotation cursor,
+// the junction cursor and the junction table's donors (cursor_value / sj_first_row in l2r_kernels.hip.h).
+static int build_key_dir(const int64_t *key, int64_t n, int32_t n_tid, const std::vector<int64_t> &mx, std::vector<int32_t> &base, std::vector<uint32_t> &dir)
+{
+    base.assign((size_t)n_tid + 1, 0);
+    int64_t acc = 0;
+    for (int32_t t = 0; t < n_tid; ++t) { base[(size_t)t] = (int32_t)acc; acc += mx[(size_t)t] < 0 ? 0 : (mx[(size_t)t] >> SITE_SHIFT) + 1; }
+    if (acc > 0x7ffffff0LL) return -1;
+    base[(size_t)n_tid] = (int32_t)acc;
+    dir.assign((size_t)acc + 1, 0);
+    size_t j = 0;
+    for (int32_t t = 0; t < n_tid; ++t) {
+        const int32_t nbk = base[(size_t)t + 1] - base[(size_t)t];
+        for (int32_t cb = 0; cb < nbk; ++cb) {
+            const int64_t q = host_key(t, cb << SITE_SHIFT);
+            while (j < (size_t)n && key[j] < q) ++j;
+            dir[(size_t)base[(size_t)t] + (size_t)cb] = (uint32_t)j;
+        }
+    }
+    {   // closing word: first j with key >= (n_tid, 0)
+        const int64_t q = host_key(n_tid, 0);
+        while (j < (size_t)n && key[j] < q) ++j;
+        dir[(size_t)acc] = (uint32_t)j;
+    }
+    // (words of chromosomes without buckets: they share the next chromosome's first word)
+    return 0;
+}
+
 static int build_tables(const l2r_annotation *a, AnnoTables &o)
 {
     const int64_t T = a->n_tx;
@@ -417,28 +447,7 @@ static int build_tables(const l2r_annotation *a, AnnoTables &o)
         for (int64_t i = 0; i < T; ++i) n_tid = std::max(n_tid, h[(size_t)i].tid + 1);
         std::vector<int64_t> mxe((size_t)n_tid, -1);
         for (int64_t i = 0; i < T; ++i) if (h[(size_t)i].tid >= 0) mxe[(size_t)h[(size_t)i].tid] = std::max<int64_t>(mxe[(size_t)h[(size_t)i].tid], std::max(h[(size_t)i].end, 0));
-        std::vector<int32_t> &kb = o.kb_base;
-        kb.assign((size_t)n_tid + 1, 0);
-        int64_t acc = 0;
-        for (int32_t t = 0; t < n_tid; ++t) { kb[(size_t)t] = (int32_t)acc; acc += mxe[(size_t)t] < 0 ? 0 : (mxe[(size_t)t] >> SITE_SHIFT) + 1; }
-        if (acc > 0x7ffffff0LL) return fail(-1, "[l2r_set_annotation] cursor directory too large");
-        kb[(size_t)n_tid] = (int32_t)acc;
-        std::vector<uint32_t> &dir = o.key_dir;
-        dir.assign((size_t)acc + 1, 0);
-        size_t j = 0;
-        for (int32_t t = 0; t < n_tid; ++t) {
-            const int32_t nbk = kb[(size_t)t + 1] - kb[(size_t)t];
-            for (int32_t cb = 0; cb < nbk; ++cb) {
-                const int64_t q = host_key(t, cb << SITE_SHIFT);
-                while (j < (size_t)T && key[j] < q) ++j;
-                dir[(size_t)kb[(size_t)t] + (size_t)cb] = (uint32_t)j;
-            }
-        }
-        {   // closing word: first j with key >= (n_tid, 0)
-            const int64_t q = host_key(n_tid, 0);
-            while (j < (size_t)T && key[j] < q) ++j;
-            dir[(size_t)acc] = (uint32_t)j;
-        }
+        if (build_key_dir(key.data(), T, n_tid, mxe, o.kb_base, o.key_dir)) return fail(-1, "[l2r_set_annotation] cursor directory too large");
         // words of chromosomes without buckets (no transcript): they share the next chromosome's first word
         o.n_tid_key = n_tid;
     }
@@ -627,8 +636,29 @@ int l2r_set_junctions(l2r_ctx *c, const l2r_junctions *s)
         if (k > run) run = k;
         key[(size_t)i] = run;
     }
+    // directories: the junction cursor (prefix-max keys of (tid, acc)) and the donors (rows are sorted by (tid, don, acc)): SjDir
+    std::vector<int32_t> cbase, dbase; std::vector<uint32_t> cdir, ddir;
+    int32_t sj_ntid = 0;
+    {
+        for (int64_t i = 0; i < n; ++i) sj_ntid = std::max(sj_ntid, s->tid[i] + 1);
+        std::vector<int64_t> mxa((size_t)sj_ntid, -1), mxd((size_t)sj_ntid, -1), dkey((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            dkey[(size_t)i] = host_key(s->tid[i], std::max(s->don[i], 0));
+            if (s->tid[i] < 0) continue;
+            mxa[(size_t)s->tid[i]] = std::max<int64_t>(mxa[(size_t)s->tid[i]], std::max(s->acc[i], 0));
+            mxd[(size_t)s->tid[i]] = std::max<int64_t>(mxd[(size_t)s->tid[i]], std::max(s->don[i], 0));
+        }
+        if (build_key_dir(key.data(), n, sj_ntid, mxa, cbase, cdir) || build_key_dir(dkey.data(), n, sj_ntid, mxd, dbase, ddir))
+            return fail(-1, "[l2r_set_junctions] junction directories too large");
+    }
     if (c->sj_tid.ensure((size_t)n) || c->sj_don.ensure((size_t)n) || c->sj_acc.ensure((size_t)n) ||
-        c->sj_uniq.ensure((size_t)n) || c->sj_multi.ensure((size_t)n) || c->sj_key.ensure((size_t)n)) return -2;
+        c->sj_uniq.ensure((size_t)n) || c->sj_multi.ensure((size_t)n) || c->sj_key.ensure((size_t)n) ||
+        c->sj_cbase.ensure(cbase.size()) || c->sj_cdir.ensure(cdir.size()) || c->sj_dbase.ensure(dbase.size()) || c->sj_ddir.ensure(ddir.size())) return -2;
+    HIP_TRY(hipMemcpyAsync(c->sj_cbase.p, cbase.data(), cbase.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->sj_cdir.p, cdir.data(), cdir.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->sj_dbase.p, dbase.data(), dbase.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->sj_ddir.p, ddir.data(), ddir.size() * 4, hipMemcpyHostToDevice, c->stream));
+    c->sj_ntid = sj_ntid;
     const size_t b = (size_t)n * 4;
     HIP_TRY(hipMemcpyAsync(c->sj_tid.p, s->tid, b, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->sj_don.p, s->don, b, hipMemcpyHostToDevice, c->stream));
@@ -1085,7 +1115,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         if (!c->sorted) { int rc = prepare_unsorted_sj_cursor(c); if (rc) return rc; }
         hipLaunchKernelGGL(k_validate_sj, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p,
                            c->sj_key.p, (c->sorted ? (const int32_t *)nullptr : c->sj_cursor.p), c->sj_tid.p, c->sj_don.p, c->sj_acc.p,
-                           c->sj_uniq.p, c->sj_multi.p, p, c->info.p);
+                           c->sj_uniq.p, c->sj_multi.p, p, c->info.p,
+                           SjDir{CursorDir{c->sj_key.p, c->sj_cdir.p, c->sj_cbase.p, c->sj_ntid, (int32_t)c->n_sj}, c->sj_ddir.p, c->sj_dbase.p, c->sj_ntid});
     }
     if ((c->n_sj > 0 || c->slab) && (c->want & L2R_WANT_ACCEPTED)) {
         // acceptance is decided by the junction check (and the slab pipeline counts nothing itself): count per tile
