@@ -1031,10 +1031,10 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         MARK(ST_FAST);
         // (with the accepted list wanted and no junction table to decide later, the tiles leave their accepted chunks themselves)
         const bool probe_acc = (c->want & L2R_WANT_ACCEPTED) && c->n_sj == 0;
-#define launch_probe_level(L) do { if (probe_acc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L, true>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
-            (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p); \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L, false>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
-            (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p); } while (0)
+#define launch_probe_k(L, A, D) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L, A, D>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
+            (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p)
+#define launch_probe_level(L) do { if (p.ss_dis > 0) { if (probe_acc) launch_probe_k(L, true, true); else launch_probe_k(L, false, true); } \
+                                   else { if (probe_acc) launch_probe_k(L, true, false); else launch_probe_k(L, false, false); } } while (0)
         switch (p.full_level) {
         case 1: launch_probe_level(1); break;
         case 2: launch_probe_level(2); break;

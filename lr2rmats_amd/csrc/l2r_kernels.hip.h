@@ -41,6 +41,7 @@ constexpr int DIR_CAP = 384;            // 512-bp buckets staged per tile (span 
 constexpr int KEY_CAP = 224;            // dictionary entries staged per dictionary and tile (threads 224..255 stage the headers)
 constexpr int WIN_TX = 32;              // annotation transcripts in a tile's window = bits of a tile-frame membership mask
 constexpr int SITE_SHIFT = 9;
+constexpr int DIS_MASK_MAX = 64;        // largest -d the mask kernels take (probe_near: a probe then looks at two 512-bp buckets at most)
 
 // One annotation transcript (file order), 48 B = three 16-byte loads.
 struct TxHdr {
@@ -508,8 +509,9 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
     int blo = INT32_MAX, bhi = -1;
     const bool mine = active && tid == tid0;
     if (mine && nb > 0) {             // bucket span of the read, clamped to the annotation's grid
-        blo = min(max(pos + 1, 0) >> SITE_SHIFT, nb - 1);
-        bhi = min(max(el, 0) >> SITE_SHIFT, nb - 1);
+        // (-d > 0: the probes look up to `dis` outside the read, probe_near)
+        blo = min(max(pos + 1 - max(p.ss_dis, 0), 0) >> SITE_SHIFT, nb - 1);
+        bhi = min(max(el + max(p.ss_dis, 0), 0) >> SITE_SHIFT, nb - 1);
     }
     {   // tile reductions: cursor range, bucket span, coordinate span
         const int a0 = wave_min(mine ? j0 : INT32_MAX), a1 = wave_max(mine ? j0 : -1), a3 = wave_min(blo), a4 = wave_max(bhi);
@@ -530,7 +532,7 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
         TileDesc d;
         d.j_lo = jl == INT32_MAX ? 0 : jl; d.tid = tid0; d.b_off = 0; d.nb = 0; d.b0 = 0; d.nbk = 0;
         d.st_r0 = d.st_nk = d.en_r0 = d.en_nk = 0u; d.n_win = 0u;
-        bool fast = total <= (uint32_t)LDS_EXON_CAP && p.ss_dis == 0 && !(p.ablate & 1);
+        bool fast = total <= (uint32_t)LDS_EXON_CAP && p.ss_dis >= 0 && p.ss_dis <= DIS_MASK_MAX && !(p.ablate & 1);
         uint32_t why = fast ? 0u : (total > (uint32_t)LDS_EXON_CAP ? 1u : 7u);       // diagnostics: why a tile is not fast (flags bits 8..11)
         // dictionary slices of the tile's bucket span: four directory words, used after the window scan below (the
         // loads and the scan's header loads are in flight together)
@@ -1169,6 +1171,39 @@ __device__ __forceinline__ void probe_rest(const v4i_t *ent, uint32_t lo, uint32
     }
 }
 
+// -d > 0 (src/update_gtf.c:717-779 with dis > 0): a read site matches EVERY annotation site within `dis` of it, and identical_site_n
+// counts the matching (annotation site, read site) PAIRS.  One probe of a staged slice with a tolerance: entries [lo, hi) are the
+// buckets of k1 - dis .. k1 + dis (at most two: dis < 512), sorted by (key 1, key 2).
+//   sm |= site members of every entry whose first key lies within dis of k1 AND inside the read's span [rs, re] -- an annotation site
+//         counts only inside the overlap span (:732,742); inside the transcript's own span it always is (TX_COMPACT);
+//   pm |= pair members of every entry with both keys within dis (the exon / junction flags know no overlap span, :753-768);
+//   amb |= members that have TWO different sites within dis of this one read site: for them the pair count is not the number of
+//         matched read sites, the masks cannot say whether the read is known -- such a read goes to the generic kernel (it takes a
+//         transcript with two donors or two acceptors less than 2 dis + 1 bases apart).
+__device__ __forceinline__ void probe_near(const v4i_t *ent, uint32_t lo, uint32_t hi, int32_t k1, int32_t k2, int dis, int rs, int re,
+                                           uint32_t &pm, uint32_t &sm, uint32_t &amb)
+{
+    pm = 0u; sm = 0u;
+    int last = INT32_MIN;
+    for (uint32_t r = lo; r < hi; ++r) {
+        const v4i_t q = lds_entry(ent, r);
+        if (q.x > k1 + dis) break;
+        if (q.x < k1 - dis) continue;
+        if (q.x >= rs && q.x <= re) {
+            if (q.x != last) { amb |= sm & (uint32_t)q.w; last = q.x; }
+            sm |= (uint32_t)q.w;
+        }
+        if (__builtin_abs(q.y - k2) <= dis) pm |= (uint32_t)q.z;
+    }
+}
+// the staged entries of the buckets of x - dis .. x + dis: [lo, hi)  (none: the empty bucket behind the staged ones)
+__device__ __forceinline__ void near_range(const uint8_t *dir, int b_off, uint32_t none, bool live, int x, int dis, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t i0 = live ? min((uint32_t)((max(x - dis, 0) >> SITE_SHIFT) + b_off), none) : none;
+    const uint32_t i1 = live ? min((uint32_t)(((x + dis) >> SITE_SHIFT) + b_off), none) : none;
+    lo = dir[i0]; hi = dir[i1 + 1u];
+}
+
 // Transcripts (tile frame) that have an exon overlapping [s, e]: union of the exon masks of the START entries
 // from the first one that reaches into the bucket of s up to the last one that starts in the bucket of e.
 __device__ __forceinline__ uint32_t overlapping_exon_members(const uint8_t *rdir, const uint8_t *dir, const v4i_t *ent,
@@ -1344,7 +1379,7 @@ struct TileLds {                 // the tile's LDS image (layout in k_classify_f
     const int *win;              // window member -> annotation index
 };
 struct VisitMasks { uint32_t vpre, lmask, rmask, k1mask; bool redo; };
-struct SiteMasks { uint32_t kand, kor, dm_first, am_last; };
+struct SiteMasks { uint32_t kand, kor, dm_first, am_last; uint32_t amb; };      // amb (-d > 0 only): members with TWO sites within the tolerance of one read site (probe_near)
 
 // V' = window transcripts j >= j0 up to the first one the read lies before (src/update_gtf.c:799-800), minus the ones
 // that lie before the read (:801); terminal-exon masks of check_full (:629-681); single-exon known candidates (:806-811).
@@ -1417,9 +1452,10 @@ __device__ __forceinline__ uint32_t nonzero(uint32_t x)
 // One START and one END probe per exon; the wave runs as many rounds as its longest read has exons.  Per round
 // {next exon, both bucket ranges} are read together, then the first entries of both buckets.  Leaves per exon in W:
 // first member of V' with the exon / the junction (6 bits each, 63: none), "donor / acceptor is in V'" (bits 12, 13).
-__device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc &d, bool mapping, uint32_t local, uint32_t n, uint32_t vpre)
+// dis > 0 (-d): every probe looks at the entries within the tolerance of its coordinate (probe_near); [rs, re] = the read's span.
+__device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc &d, bool mapping, uint32_t local, uint32_t n, uint32_t vpre, int dis, int rs, int re)
 {
-    SiteMasks m{0xffffffffu, 0u, 0u, 0u};
+    SiteMasks m{0xffffffffu, 0u, 0u, 0u, 0u};
     const int *S = L.S + local, *E = L.E + local;
     uint16_t *W = L.W + local;
     int s = 0, e = 0;
@@ -1434,16 +1470,23 @@ __device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc 
         const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
         const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
         const int s2 = L.S[inext], e2 = L.E[inext];
+        uint32_t xm, am, jm, dm;
+        if (dis > 0) {                                   // (wave-uniform)
+            uint32_t ls, hs, le, he;
+            near_range(L.dir0, d.b_off, none, live, s, dis, ls, hs); near_range(L.dir1, d.b_off, none, junc, e, dis, le, he);
+            probe_near(L.ent0, ls, hs, s, e, dis, rs, re, xm, am, m.amb);
+            probe_near(L.ent1, le, he, e, s2, dis, rs, re, jm, dm, m.amb);
+        } else {
         const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
         // START buckets mostly hold one exon, END buckets often several junctions of one donor.  (An index up to
         // KEY_CAP + 1 reads on into the arrays behind the slice; such an entry is never inside [ls, hs).)
         const v4i_t qs0 = lds_entry(L.ent0, ls);
         const v4i_t qe0 = lds_entry(L.ent1, le), qe1 = lds_entry(L.ent1, le + 1u);
-        uint32_t xm, am, jm, dm;
         {   const bool m0 = ls < hs && qs0.x == s;
             am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
         probe2(qe0, qe1, le, he, e, s2, jm, dm);
         if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(L.ent0, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + 2u, he, e, s2, jm, dm, 0u); }
+        }
         // without a junction jm = dm = 0 (empty bucket); the acceptor of the last exon is not a probed site (Q1)
         const uint32_t amj = junc ? am : 0u;
         uint32_t word = first_member(xm & vpre);
@@ -1452,8 +1495,9 @@ __device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc 
         word |= nonzero(amj & vpre) << 13;
         m.kand &= junc ? (am & dm) : 0xffffffffu;     // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
         m.kor |= amj | dm;
-        if (k == 0) m.dm_first = dm;
-        m.am_last = (live && !junc) ? am : m.am_last;  // transcripts in which the last exon's start begins a later exon
+        // (with a tolerance a shared donor / acceptor does not say that the exons overlap: the full-length evidence asks the START slice)
+        if (dis == 0) { if (k == 0) m.dm_first = dm;
+                        m.am_last = (live && !junc) ? am : m.am_last; } // transcripts in which the last exon's start begins a later exon
         if (live) W[k] = (uint16_t)word;
         s = s2; e = e2;
     }
@@ -1709,7 +1753,10 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, j0, re, s_tilemask);
         redo = redo || vm.redo;
         L2R_STAMP(2);
-        const SiteMasks sm = map_exons(L, d, work && !redo && n > 1, local, n, vm.vpre);
+        const int o_dis = fast_args()->p.ss_dis;
+        const SiteMasks sm = map_exons(L, d, work && !redo && n > 1, local, n, vm.vpre, o_dis, re.s0, re.el);
+        // (-d > 0: a visited member with two sites within the tolerance of one read site -- its pair count is the generic kernel's)
+        if (work && !redo && (sm.amb & vm.vpre) != 0u) redo = true;
         L2R_STAMP(3);
         if (work && !redo) {
             uint16_t *const Wr = s_W + local;

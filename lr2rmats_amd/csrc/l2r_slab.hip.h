@@ -419,10 +419,13 @@ struct SlabStage { uint32_t *A; uint16_t *Ln; uint32_t loc; int32_t lo; bool fit
 // of a loaded register is a wait for its load).  Round k reads exon k (current) and exon k + 1 (next) and, when it is done with
 // exon k, asks for exon k + 4 into exon k's registers: that load has three rounds to arrive.  Every round leaves its exon and
 // its work word at the exon's position in LDS (SlabStage).
+// DIS: -d > 0 -- every probe looks at the entries within the tolerance of its coordinate (probe_near), `dis` is the tolerance and [rs, re]
+// the read's span.
+template <bool DIS>
 __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const TileDesc &d, bool mapping, const uint32_t *__restrict__ xw,
-                                                    uint32_t off, uint32_t n, uint32_t vpre, const SlabRows &q, const SlabStage &st)
+                                                    uint32_t off, uint32_t n, uint32_t vpre, const SlabRows &q, const SlabStage &st, int dis = 0, int rs = 0, int re = 0)
 {
-    SiteMasks m{0xffffffffu, 0u, 0u, 0u};
+    SiteMasks m{0xffffffffu, 0u, 0u, 0u, 0u};
     uint32_t *const Ap = st.A + st.loc; uint16_t *const Lp = st.Ln + st.loc;
     // exon j of the read: row j + 1, the last one row 0
     SlabRow R[SLAB_AHEAD];
@@ -435,6 +438,7 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
     // are two dependent LDS round trips: one of them per exon is taken off the chain).
     auto buckets = [&](int k, int sv, int ev, uint32_t &ls, uint32_t &hs, uint32_t &le, uint32_t &he) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
+        if (DIS) { near_range(L.dir0, d.b_off, none, live, sv, dis, ls, hs); near_range(L.dir1, d.b_off, none, junc, ev, dis, le, he); return; }
         const uint32_t is = live ? min((uint32_t)((sv >> SITE_SHIFT) + d.b_off), none) : none;      // (a lane without exon k must not open the long-bucket path)
         const uint32_t ie = junc ? min((uint32_t)((ev >> SITE_SHIFT) + d.b_off), none) : none;
         ls = L.dir0[is]; hs = L.dir0[is + 1u]; le = L.dir1[ie]; he = L.dir1[ie + 1u];
@@ -446,15 +450,21 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
         const int s = slab_row_start(cur, st.lo), e = e_cur, s2 = slab_row_start(nxt, st.lo), e2 = slab_row_end(nxt, st.lo);
         const uint32_t cw = cur.w;
-        const v4i_t qs0 = lds_entry(L.ent0, ls);
-        const v4i_t qe0 = lds_entry(L.ent1, le), qe1 = lds_entry(L.ent1, le + 1u);
         uint32_t ls_n, hs_n, le_n, he_n;
-        buckets(k + 1, s2, e2, ls_n, hs_n, le_n, he_n);
         uint32_t xm, am, jm, dm;
-        {   const bool m0 = ls < hs && qs0.x == s;
-            am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
-        probe2(qe0, qe1, le, he, e, s2, jm, dm);
-        if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(L.ent0, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + 2u, he, e, s2, jm, dm, 0u); }
+        if (DIS) {
+            buckets(k + 1, s2, e2, ls_n, hs_n, le_n, he_n);
+            probe_near(L.ent0, ls, hs, s, e, dis, rs, re, xm, am, m.amb);
+            probe_near(L.ent1, le, he, e, s2, dis, rs, re, jm, dm, m.amb);
+        } else {
+            const v4i_t qs0 = lds_entry(L.ent0, ls);
+            const v4i_t qe0 = lds_entry(L.ent1, le), qe1 = lds_entry(L.ent1, le + 1u);
+            buckets(k + 1, s2, e2, ls_n, hs_n, le_n, he_n);
+            {   const bool m0 = ls < hs && qs0.x == s;
+                am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
+            probe2(qe0, qe1, le, he, e, s2, jm, dm);
+            if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(L.ent0, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + 2u, he, e, s2, jm, dm, 0u); }
+        }
         if (reload) {                                   // exon k + SLAB_AHEAD into the registers of exon k
             const uint32_t j = (uint32_t)k + (uint32_t)SLAB_AHEAD;
             cur = slab_load_row(xw, off + (j < nm1 ? j + 1u : 0u) * SLAB_STRIDE);
@@ -466,8 +476,9 @@ __device__ __forceinline__ SiteMasks map_exons_slab(const TileLds &L, const Tile
         word |= nonzero(amj & vpre) << 13;
         m.kand &= junc ? (am & dm) : 0xffffffffu;     // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
         m.kor |= amj | dm;
-        if (k == 0) m.dm_first = dm;
-        m.am_last = (live && !junc) ? am : m.am_last;
+        // (with a tolerance a shared donor / acceptor does not say that the exons overlap: the full-length evidence asks the START slice)
+        if (!DIS) { if (k == 0) m.dm_first = dm;
+                    m.am_last = (live && !junc) ? am : m.am_last; }
         if (live) { Ap[k] = (cw & SLAB_REL_MASK) | (word << SLAB_REL_BITS); Lp[k] = (uint16_t)(cw >> SLAB_REL_BITS); }      // (a staged read's base is the tile's)
         ls = ls_n; hs = hs_n; le = le_n; he = he_n; e_cur = e2;
     };
@@ -589,7 +600,7 @@ __device__ __forceinline__ void slab_copy_exons(SlabArgsK sa, PipeArgsK a, const
 // on slab-resident exons; exons, work words and then flag bytes at their positions in LDS (or, for a read that does not fit
 // there, in the result arrays), info / ref_tx / ex_off per read, redo list.
 struct SlabVerdict { uint32_t info; int ref; bool redo; };
-template <int LEVEL>
+template <int LEVEL, bool DIS>
 __device__ __forceinline__ SlabVerdict slab_classify(SlabArgsK sa, PipeArgsK a, const TileDesc &d, const SlabLds &S, const int4 *hk, const int4 *hx, const int *win,
                                               const uint32_t *tilemask, bool active, uint32_t pre, uint32_t r, uint32_t off, const SlabRows &q,
                                               const ReadEnds &re, const SlabOut &out, const SlabStage &st, int any_wide, SlabStamp &stamp)
@@ -610,9 +621,11 @@ __device__ __forceinline__ SlabVerdict slab_classify(SlabArgsK sa, PipeArgsK a, 
     redo = redo || vm.redo;
     stamp.mark(2);
     const bool mapping = work && !redo && n > 1;
-    const SiteMasks sm = map_exons_slab(L, d, mapping, xw, off, n, vm.vpre, q, st);
+    const SiteMasks sm = map_exons_slab<DIS>(L, d, mapping, xw, off, n, vm.vpre, q, st, DIS ? a->f.p.ss_dis : 0, re.s0, re.el);
     stamp.mark(3);
     if (active && !mapping) slab_copy_exons(sa, a, out, st, q, off, n, pre, r);
+    // (-d > 0: a visited member with two sites within the tolerance of one read site -- its pair count is the generic kernel's)
+    if (DIS && mapping && (sm.amb & vm.vpre) != 0u) redo = true;
     if (work && !redo) {
         // work words: the upper 14 bits of the read's A words, replaced by the flag byte
         uint32_t *const Ap = st.A + st.loc;
@@ -682,7 +695,7 @@ constexpr int SLAB_DIR_BYTES = (3 * FAST_DIR_BYTES + 15) & ~15;
 constexpr int SLAB_AUX_BYTES = SLAB_DIR_BYTES + (int)sizeof(TileWin);
 static_assert(SLAB_AUX_BYTES >= 2 * TILE_THREADS * 4, "the accepted counts and their scan (one word per read each) reuse the directories + window record");
 static_assert(2 * SLAB_KEY_CAP * 16 >= SLAB_POS_CAP * 2, "the slot -> position map of a tile's accepted exons reuses the staged dictionary entries");
-template <int LEVEL, bool ACC>
+template <int LEVEL, bool ACC, bool DIS>
 __global__ __launch_bounds__(TILE_THREADS, slab_probe_wgs(LEVEL))
 void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, const TileWin *__restrict__ u_tw,
                   const uint32_t *__restrict__ u_xbase /* first result slot of every tile: the scanned exon counts (+ the total) */)
@@ -776,7 +789,7 @@ void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, c
     // the first read that does not fit the staged positions ends the block that is written from LDS (reads are in read order there)
     if (active && loc + n > (uint32_t)SLAB_POS_CAP) atomicMin(&s_lim, loc);      // (a read that is written directly for another reason marks its positions instead)
     stamp.mark(1);
-    const SlabVerdict vd = slab_classify<LEVEL>(sa, a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, r, off, q, re, out, st, any_wide, stamp);
+    const SlabVerdict vd = slab_classify<LEVEL, DIS>(sa, a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, r, off, q, re, out, st, any_wide, stamp);
     if (ACC) { const int w_redo = __any(vd.redo) ? 1 : 0; if ((threadIdx.x & (WAVE - 1)) == 0) s_redow[threadIdx.x >> 6] = (uint32_t)w_redo; }
     __syncthreads();
     if (!ACC) {

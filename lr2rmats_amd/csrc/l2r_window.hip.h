@@ -70,12 +70,15 @@ __device__ __forceinline__ uint32_t make_descriptor(PipeArgsK a, int lane, int g
     const uint32_t win_cap = Wg64 ? (uint32_t)WIDE_MEMBERS : (uint32_t)WIN_TX;
     const TxHdr *const hdr = a->f.hdr;
     const int32_t n_tx = a->f.p.n_tx;
+    // -d > 0: the mask kernels probe within the tolerance (probe_near), up to DIS_MASK_MAX; the staged buckets then reach that much
+    // further on both sides (exon / junction flags look at annotation sites up to `dis` outside the reads' span)
+    const int dis = a->f.p.ss_dis;
     int lo = INT32_MAX, hi = -1;
-    if (nb > 0) { lo = min(max(tlo, 0) >> SITE_SHIFT, nb - 1); hi = min(max(thi, 0) >> SITE_SHIFT, nb - 1); }
+    if (nb > 0) { lo = min(max(tlo - max(dis, 0), 0) >> SITE_SHIFT, nb - 1); hi = min(max(thi + max(dis, 0), 0) >> SITE_SHIFT, nb - 1); }
     TileDesc d;
     d.tid = tid0; d.b_off = 0; d.nb = 0; d.b0 = 0; d.nbk = 0;
     d.st_r0 = d.st_nk = d.en_r0 = d.en_nk = 0u; d.n_win = 0u;
-    bool fast = a->f.p.ss_dis == 0 && !(a->f.p.ablate & 1);
+    bool fast = dis >= 0 && dis <= DIS_MASK_MAX && !(a->f.p.ablate & 1);
     uint32_t why = fast ? 0u : 7u;
     uint32_t sd_r0 = 0u, sd_r1 = 0u, ed_r0 = 0u, ed_r1 = 0u;
     const bool sliced = fast && hi >= 0 && hi - lo + 1 <= DIR_CAP;
@@ -117,6 +120,7 @@ __device__ __forceinline__ uint32_t make_descriptor(PipeArgsK a, int lane, int g
             if (n_win > win_cap || trip == WIN_SCAN_TRIPS * (WAVE / G) - 1) { fast = false; why = n_win > win_cap ? 4u : 5u; break; }
         }
         if (fast && n_win > win_cap) { fast = false; why = 4u; }
+        if (fast && dis > 0 && n_win > (uint32_t)WIN_TX) { fast = false; why = 7u; }      // (the 64-bit-mask kernels probe without a tolerance)
         if (fast) {
             d.n_win = n_win;
             if (n_win) { d.j_lo = first; contig = (uint32_t)(last - first + 1) == n_win; }

@@ -201,8 +201,11 @@ def test_splice_distance_with_junction_table_on_ont_like_reads(oracle, split):
     anno, af, reads = util.make_case(23, n_reads=12000, n_exons=6, anno_exons=12000, ont=True, micro=3, xs=0.03)
     base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3, ss_dis=2))
     j, sj = util.junction_table(af, reads, base, 23, cover=0.6)
-    got, want = _run(oracle, af, reads, sj=sj, full_level=3, ss_dis=2, split_trans=split, min_sj_cnt=2)
+    cnt = [0, 0, 0, 0]
+    got, want = _run(oracle, af, reads, sj=sj, counters=cnt, full_level=3, ss_dis=2, split_trans=split, min_sj_cnt=2)
     assert ((want.info & 32) != 0).sum() > 100 and ((want.info & 64) != 0).sum() > 10 and ((want.ex_flag & 16) != 0).sum() > 10
+    # the mask kernels take -d 2 themselves (probe_near): nothing of this input is the generic kernel's
+    assert cnt[0] == 0, cnt
 
 
 def test_redo_share_of_the_benchmark_workload_shape(oracle, pipeline):

@@ -340,3 +340,85 @@ def test_full_length_levels_known_answers(oracle):
     af, reads, expect = full_length_case()
     res = {l: _run(oracle, af, reads, full_level=l)[1] for l in (1, 2, 3, 4, 5)}
     check_full_length_outcomes(res, expect)
+
+
+@pytest.mark.parametrize("dis", [1, 2, 7, 20])
+@pytest.mark.parametrize("level", [1, 3, 5])
+def test_splice_distance_on_the_mask_path(oracle, dis, level, pipeline):
+    """-d > 0 (src/update_gtf.c:717-779 with dis > 0) on the mask kernels: every probe looks at the annotation sites within the
+    tolerance (probe_near).  Reads whose sites sit 0 .. dis + 1 bases off an annotation site on either side, exons that start /
+    end up to dis outside the first / last annotated base of their tile (the staged slices reach that far), annotation sites just
+    inside and just outside the read's own span (an annotation site only counts inside the overlap span, the flags know no span),
+    single-exon reads.  Nothing goes to the generic kernel: no transcript here has two sites within the tolerance of each other."""
+    rng = np.random.default_rng(40 + dis)
+    txs = []
+    for g in range(40):
+        base = 10_000 + g * 9_000
+        ex, x = [], base
+        for _ in range(int(rng.integers(3, 8))):
+            ln = int(rng.integers(60, 300))
+            ex.append((x, x + ln))
+            x += ln + int(rng.integers(120, 900))
+        txs.append((0 if g < 25 else 1, g & 1, ex))
+        if g % 3 == 0 and len(ex) > 3:                        # an isoform that skips an exon
+            txs.append((0 if g < 25 else 1, g & 1, ex[:1] + ex[2:]))
+    af = _anno(txs)
+    rows = []
+    for i in range(4000):
+        t = txs[int(rng.integers(len(txs)))]
+        ex = [list(x) for x in t[2]]
+        a = int(rng.integers(0, len(ex) - 1)); b = int(rng.integers(a + 1, len(ex))) + 1
+        ex = ex[a:b]
+        mode = i % 8
+        if mode == 1:                                            # every site jittered within the tolerance
+            for q in ex:
+                q[0] += int(rng.integers(-dis, dis + 1)); q[1] += int(rng.integers(-dis, dis + 1))
+        elif mode == 2:                                          # one site just outside it
+            q = ex[int(rng.integers(len(ex)))]
+            q[int(rng.integers(2))] += (dis + 1) * (1 if rng.integers(2) else -1)
+        elif mode == 3:                                          # the read ends right at / just inside / just outside a donor
+            ex[-1][1] = ex[-1][0] + int(rng.integers(0, 2 * dis + 3))
+        elif mode == 4:                                          # ... and begins around an acceptor
+            ex[0][0] = ex[0][1] - int(rng.integers(0, 2 * dis + 3))
+        elif mode == 5 and len(ex) > 2:                          # skipped exon with jitter
+            del ex[1]; ex[0][1] += int(rng.integers(-dis, dis + 1))
+        elif mode == 6:
+            ex = [ex[0]]                                         # single exon
+        elif mode == 7:
+            ex[0][0] -= int(rng.integers(0, dis + 2)); ex[-1][1] += int(rng.integers(0, dis + 2))
+        ex = [(max(1, x), max(max(1, x), y)) for x, y in ex]
+        ok = all(ex[k][1] + 3 < ex[k + 1][0] for k in range(len(ex) - 1))
+        if not ok:
+            continue
+        p, ops = _chain(ex)
+        rows.append((t[0], p, i & 1, ops))
+    rows.sort(key=lambda r: (r[0], r[1]))
+    cnt = [0, 0, 0, 0]
+    got, want = _run(oracle, af, _reads(rows), counters=cnt, full_level=level, ss_dis=dis)
+    k = (want.info & 1) != 0
+    assert k.sum() > 200 and (((want.info & 2) != 0) & ~k).sum() > 200
+    if pipeline == "slab":
+        assert cnt[0] == 0, cnt                                  # nothing for the generic kernel
+
+
+def test_splice_distance_with_two_annotation_sites_inside_the_tolerance(oracle, pipeline):
+    """identical_site_n counts (annotation site, read site) PAIRS (update_gtf.c:735-750): transcript A has donors at 1100 and 1104,
+    so at -d 3 a read donor at 1101 .. 1103 makes TWO pairs with it -- 3 pairs for the read's 2 sites: A is NOT "known" although every
+    read site matches one of its sites, and the sweep goes on to B (donor 1100 only), which is.  The masks cannot count pairs: a
+    read with such a member in its window goes to the generic kernel and comes out as the reference has it."""
+    txs = [(0, 0, [(500, 600), (1_000, 1_100), (1_102, 1_104), (1_400, 1_500)]),      # A: donors 600, 1100, 1104
+           (0, 0, [(500, 600), (1_000, 1_100), (1_400, 1_500)]),                      # B
+           (0, 1, [(4_500, 4_600), (5_000, 5_100), (5_300, 5_400)])]
+    af = _anno(txs)
+    rows = []
+    for k in range(300):
+        rows.append((0, *_chain([(1_000, 1_100 + (k % 6)), (1_400 - (k % 3), 1_500)])))
+        rows.append((0, *_chain([(5_000, 5_100 + (k % 5) - 2), (5_300, 5_400)])))
+    rows = [(r[0], r[1], 0, r[2]) for r in rows]
+    rows.sort(key=lambda r: (r[0], r[1]))
+    cnt = [0, 0, 0, 0]
+    got, want = _run(oracle, af, _reads(rows), counters=cnt, full_level=3, ss_dis=3)
+    known = (want.info & 1) != 0
+    assert known.sum() > 300 and (want.ref_tx[known] == 1).sum() >= 100 and (want.ref_tx[known] == 0).sum() >= 50      # B for the twin-donor reads, A for donor 1100 itself
+    if pipeline == "slab":
+        assert 0 < cnt[0] <= 300, cnt                            # the reads around the twin donors, nobody else

@@ -53,6 +53,13 @@ def test_splice_distance(engine, oracle, dis):
     anno, af, reads = util.make_case(12, n_reads=20000, n_exons=6, anno_exons=15000)
     _set_anno(engine, af)
     _check(engine, oracle, af, reads, oracle.default_params(full_level=3, ss_dis=dis))
+    # -d > 0 stays on the mask kernels (probe_near): a zero redo share
+    import ctypes as C
+    lib = capi.load_library()
+    cnt = (C.c_longlong * 13)()
+    lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.l2r_debug_counters(engine.ctx, cnt, 13)
+    assert cnt[0] == 0, list(cnt)
 
 
 @pytest.mark.parametrize("opts", [dict(min_exon=1), dict(min_exon=10, min_intron=200), dict(max_delet=3), dict(min_intron=0)])
