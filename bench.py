@@ -195,6 +195,56 @@ def second_pass(eng, af, reads, got, args, capi, workload, n_x):
     return out
 
 
+def gencode_leg(capi, workload, args):
+    """A second workload beside the headline: config 3's reads and exon count against an annotation whose isoforms per gene are drawn
+    heavy-tailed like a real one's (workload.CONFIGS["cfg3_gencode"]: log-normal, mean about 4.5, up to 200 -- most tiles on the 32-bit
+    masks, isoform-rich loci on the 64-bit-mask and the chunked kernel, and, because reads follow the isoforms, sparse stretches that
+    make small tiles).  The reference's sweep (src/update_gtf.c:796-822) has no such steps; this is where the mask kernels have theirs.
+    An engine of its own; a 1 M-read slice is compared with the oracle bit for bit."""
+    import ctypes as C
+    import numpy as np
+    cfg = dict(workload.CONFIGS["cfg3_gencode"])
+    if args.reads:
+        cfg["n_reads"] = args.reads
+    af, reads = workload.make_rank_workload(cfg, 0, 1)
+    eng = capi.Engine(0)
+    try:
+        eng.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
+        eng.set_params(capi.default_params(full_level=args.level))
+        eng.set_outputs(capi.WANT_RESULTS)
+        eng.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)
+        eng.run(); eng.sync()
+        tm = eng.run_timed(max(3, min(args.steps, 10)))
+        n_r, n_x, _, _ = eng.sizes()
+        lib = capi.load_library()
+        cnt = (C.c_longlong * 13)()
+        lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.l2r_debug_counters(eng.ctx, cnt, 13)
+        abytes = workload.algorithmic_bytes(n_r, int(reads.cig.shape[0]), n_x, af.n_tx, af.n_exons, 0)
+        out = {"workload": "cfg3_gencode: %d reads x %.2f exons/read, %d-exon / %d-transcript GTF with log-normal isoforms per gene (max %d), update-gtf -l %d" % (
+                   reads.n, n_x / max(n_r, 1), af.n_exons, af.n_tx, int(np.bincount(af.tx_gene).max()) if hasattr(af, "tx_gene") else -1, args.level),
+               "ms_per_step": round(tm["total_ms"], 4), "reads_per_s": round(reads.n / (tm["total_ms"] * 1e-3), 1),
+               "frac_event_pass": round(abytes / (tm["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "tiles": int(cnt[3]), "tiles_of_the_64_bit_mask_kernel": int(cnt[12]), "tiles_with_a_window_beyond_63_members": int(cnt[8]),
+               "reads_on_the_redo_list": int(cnt[0]),
+               "stage_ms": {k.split(" ")[0]: round(v, 4) for k, v in tm["kernel_ms"].items()}}
+        if not args.no_cpu:
+            from oracle import pyoracle as po
+            po.build()
+            sub = reads.slice(0, min(1_000_000, reads.n))
+            want = po.classify_soa(sub.tid, sub.pos, sub.rev, sub.cig_off, sub.cig, af.tx_tid, af.tx_start, af.tx_end, af.tx_rev,
+                                   af.tx_ex_off, af.ex_start, af.ex_end, params=po.default_params(full_level=args.level))
+            got = eng.download()
+            nx = int(want.ex_off[-1])
+            out["parity_on_slice"] = {"reads": sub.n, "identical": bool(
+                np.array_equal(got.ex_off[: sub.n + 1], want.ex_off) and np.array_equal(got.ex_start[:nx], want.ex_start)
+                and np.array_equal(got.ex_end[:nx], want.ex_end) and np.array_equal(got.ex_flag[:nx], want.ex_flag)
+                and np.array_equal(got.info[: sub.n] & 0x7f, want.info & 0x7f) and np.array_equal(got.ref_tx[: sub.n], want.ref_tx))}
+        return out
+    finally:
+        eng.close()
+
+
 def launcher_argv(args, port: int):
     """The command `bench.py --gpus N` starts when no launcher has set WORLD_SIZE: the shape the driver uses itself."""
     passed = [a for a in sys.argv[1:] if a != "--dry-launch"]
@@ -246,6 +296,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--emulate-world", type=int, default=0, help="diagnostics, one GPU: run the shard rank 0 would own in a strong-scaling run of this many GPUs")
     ap.add_argument("--no-second-pass", action="store_true", help="skip the pipeline's second option set (-s -l 3 -J 1 -j SJ.tab) at N=1")
+    ap.add_argument("--no-gencode", action="store_true", help="skip the second workload (heavy-tailed isoforms per gene) at N=1")
     ap.add_argument("--dry-launch", action="store_true", help="print the launcher command a plain `bench.py --gpus N` would start, and exit")
     args = ap.parse_args()
 
@@ -468,6 +519,12 @@ def main():
                 second = second_pass(eng, af, reads, got, args, capi, workload, n_x)
             except Exception as e:                                # (must not take the line down)
                 second = {"error": str(e)[:300]}
+        gencode = None
+        if world == 1 and not args.no_gencode:
+            try:
+                gencode = gencode_leg(capi, workload, args)
+            except Exception as e:                                # (must not take the line down)
+                gencode = {"error": str(e)[:300]}
         e2e = None
         if world == 1 and not args.no_e2e:
             e2e = e2e_leg(af, reads, args.level)
@@ -495,6 +552,7 @@ def main():
             "other_exchange": other,
             "with_accepted": with_accepted,
             "second_pass": second,
+            "isoform_rich": gencode,
             "cpu_baseline": cpu,
             "e2e": e2e,
         }

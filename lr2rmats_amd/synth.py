@@ -115,12 +115,22 @@ def _ragged_gather_index(starts: np.ndarray, lens: np.ndarray) -> np.ndarray:
     return np.arange(total, dtype=np.int64) - np.repeat(out_off, lens) + np.repeat(starts.astype(np.int64), lens)
 
 
-def make_annotation(n_exons: int, seed: int, nchr: int = 24, tx_per_gene: int = 5, pool: int = 16,
+def make_annotation(n_exons: int, seed: int, nchr: int = 24, tx_per_gene=5, pool: int = 16,
                     mean_tx_exons: int = 10, shuffle_within_gene: bool = False,
                     long_tx_per_chrom: int = 0, single_exon_tx_frac: float = 0.03) -> Annotation:
-    """About ``n_exons`` exon rows: genes = n_exons / (tx_per_gene * mean_tx_exons)."""
+    """About ``n_exons`` exon rows: genes = n_exons / (tx_per_gene * mean_tx_exons).
+    ``tx_per_gene="lognormal"``: isoforms per gene drawn heavy-tailed like a real annotation's (log-normal, mean about 4.5,
+    sigma 1.1, at most 200: about 1 % of the genes beyond 32 isoforms, 0.15 % beyond 64) -- reads sample transcripts
+    uniformly, so isoform-rich genes get reads in proportion."""
     rng = np.random.default_rng([seed, 0xA770])
-    n_genes = max(1, n_exons // (tx_per_gene * mean_tx_exons))
+    per_gene = None
+    if isinstance(tx_per_gene, str):
+        if tx_per_gene != "lognormal":
+            raise ValueError("tx_per_gene: an integer or 'lognormal'")
+        n_genes = max(1, int(n_exons / (4.5 * mean_tx_exons)))
+        per_gene = np.clip(np.rint(rng.lognormal(np.log(4.5) - 0.605, 1.1, size=n_genes)), 1, 200).astype(np.int64)
+    else:
+        n_genes = max(1, n_exons // (tx_per_gene * mean_tx_exons))
     per_chr = -(-n_genes // nchr)
     chrom_names = ["chr%d" % (i + 1) for i in range(nchr)]
     # pool exons per gene
@@ -134,8 +144,10 @@ def make_annotation(n_exons: int, seed: int, nchr: int = 24, tx_per_gene: int = 
     p_end = p_start + ex_len - 1
     gene_rev = rng.integers(0, 2, size=n_genes).astype(np.uint8)
 
-    n_tx = n_genes * tx_per_gene
-    tx_gene = np.repeat(np.arange(n_genes, dtype=np.int32), tx_per_gene)
+    if per_gene is None:
+        per_gene = np.full(n_genes, int(tx_per_gene), np.int64)
+    n_tx = int(per_gene.sum())
+    tx_gene = np.repeat(np.arange(n_genes, dtype=np.int32), per_gene)
     want = np.clip(mean_tx_exons + rng.integers(-3, 4, size=n_tx), 2, pool)
     single = rng.random(n_tx) < single_exon_tx_frac
     want[single] = 1

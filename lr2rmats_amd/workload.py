@@ -24,6 +24,9 @@ CONFIGS = {
     # transcripts -- the shape of isoform-rich loci in a real annotation (diagnostics, not a BASELINE config)
     "cfg3_iso40": dict(n_reads=10_000_000, n_exons=8, anno_exons=1_500_000, seed=3, ont=False, micro=0, xs=0.0, tx_per_gene=40),
     # ... and with 100: every window is beyond the 64-bit masks, most exons are shared by transcripts more than 64 apart in file order
+    # cfg3 with isoforms per gene drawn heavy-tailed (log-normal, mean about 4.5, up to 200) like a real annotation: most tiles on the
+    # 32-bit masks, the isoform-rich loci on the 64-bit-mask and the chunked kernel (bench.py reports it beside the headline)
+    "cfg3_gencode": dict(n_reads=10_000_000, n_exons=8, anno_exons=1_500_000, seed=3, ont=False, micro=0, xs=0.0, tx_per_gene="lognormal"),
     "cfg3_iso100": dict(n_reads=10_000_000, n_exons=8, anno_exons=1_500_000, seed=3, ont=False, micro=0, xs=0.0, tx_per_gene=100),
 }
 

@@ -16,6 +16,7 @@ def engine(request):
     os.environ["L2R_PIPELINE"] = request.param
     try:
         e = capi.Engine(0)
+        e.pipeline = request.param
     finally:
         if old is None:
             del os.environ["L2R_PIPELINE"]
@@ -236,6 +237,45 @@ def test_config3_full_size(engine, oracle):
     np.testing.assert_array_equal(got.ref_tx[lo:hi], sub.ref_tx)
     np.testing.assert_array_equal(got.ex_flag[a:b], sub.ex_flag)
     np.testing.assert_array_equal(got.ex_start[a:b], sub.ex_start)
+
+
+@pytest.mark.parametrize("cfgname,lo", [("cfg3_iso40", 4_200_000 + 77), ("cfg3_gencode", 6_100_000 + 131)])
+def test_isoform_rich_annotations_full_size(engine, oracle, cfgname, lo):
+    """Config 3's reads against isoform-rich annotations at FULL size (10 M reads): `cfg3_iso40` (40 isoforms per gene: every
+    window holds 33 .. 63 transcripts, k_probe_slab_wide and k_probe_slab_chunked classify nearly everything) and `cfg3_gencode`
+    (isoforms per gene log-normal, up to 200: all three probe kernels and small tiles).  Idempotence, the accepted list, a
+    1 M-read slice out of the middle bit-exact against the oracle and equal to the same reads of the whole run; nothing is left to
+    the generic kernel (src/update_gtf.c:796-822: the reference's sweep knows no window limit)."""
+    import ctypes as C
+    from lr2rmats_amd import workload
+    if engine.pipeline != "slab":
+        pytest.skip("the classic pipeline leaves windows beyond 32 transcripts to the generic kernel: covered at small size")
+    af, reads = workload.make_rank_workload(dict(workload.CONFIGS[cfgname]), 0, 1)
+    _set_anno(engine, af)
+    engine.set_junctions(None)
+    op = oracle.default_params(full_level=3)
+    prm = util.to_engine_params(capi, op)
+    got = engine.classify(reads, prm)
+    lib = capi.load_library()
+    cnt = (C.c_longlong * 13)()
+    lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.l2r_debug_counters(engine.ctx, cnt, 13)
+    redo_share = cnt[0] / reads.n
+    again = engine.classify(reads, prm)
+    for name in ("ex_off", "ex_start", "ex_end", "ex_flag", "info", "ref_tx"):
+        np.testing.assert_array_equal(getattr(got, name), getattr(again, name))
+    _check_accepted_list(engine, got, 0)
+    hi = lo + 1_000_000
+    part = reads.slice(lo, hi)
+    sub = engine.classify(part, prm, first_read_index=lo)
+    want = util.oracle_run(oracle, af, part, op)
+    util.assert_same_result(sub, want, 0, 0)
+    a, b = int(got.ex_off[lo]), int(got.ex_off[hi])
+    np.testing.assert_array_equal(got.info[lo:hi], sub.info)
+    np.testing.assert_array_equal(got.ref_tx[lo:hi], sub.ref_tx)
+    np.testing.assert_array_equal(got.ex_flag[a:b], sub.ex_flag)
+    np.testing.assert_array_equal(got.ex_start[a:b], sub.ex_start)
+    assert redo_share <= 1e-4, (cfgname, list(cnt))
 
 
 def test_config5_shard(engine, oracle):
