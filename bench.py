@@ -76,6 +76,11 @@ def e2e_leg(af, reads, level: int):
         cmd = [hostlib.CLI_PATH, "update-gtf", "-l", str(level), "-A", out["detail.txt"], "-y", out["summary.txt"], "-E", out["novel_exon.bed"],
                "-o", out["updated.gtf"], bam, gtf]
         def one_run(run_env):
+            # (every run writes NEW files: a run that overwrites the 3.9 GB of its predecessor pays 0.35-0.4 s when it closes them --
+            #  tools/e2e_time.py with E2E_RUNS=3 shows it on every run but the first, with or without the annotation caches)
+            for v in out.values():
+                if os.path.exists(v):
+                    os.remove(v)
             t0 = time.perf_counter()
             r = subprocess.run(cmd, env=run_env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
             wall = time.perf_counter() - t0

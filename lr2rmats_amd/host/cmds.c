@@ -138,6 +138,9 @@ static void reads_from_gtf(const char *fn, const h_chroms *chr, h_reads *out)
 }
 
 static int g_rank = 0, g_world = 1;
+static int g_want_early_engine = 0;        /* set by h_cmd_update_gtf around its h_job_open: see early_engine_start() */
+static void early_engine_start(void);
+
 h_job *h_job_open_rank(int argc, char **argv, int *exit_code, int open_outputs, int rank, int world)
 {
     g_rank = rank; g_world = world;
@@ -213,6 +216,7 @@ h_job *h_job_open(int argc, char **argv, int *exit_code)
     if (argc - optind != 2) { *exit_code = update_usage(); free(j); return NULL; }
 
     h_stage_time("start");
+    if (g_want_early_engine) early_engine_start();
     if (j->mode == 0) {
         /* a rank of a multi-process run loads its shard only -- unless the run needs the gathered route (split pieces are compared
          * across chromosomes, Q2) or the caller forces it */
@@ -609,11 +613,50 @@ static void result_reserve(h_result *r, int64_t reads_cap, int64_t ex_cap)
  *                     over PCIe and no host pass over the rest); *acc_read[k] = input index of row k. */
 static int g_device = 0;                                    /* the HIP device of this process (a child of the multi-GPU run: its own) */
 
+/* The engine's context (HIP runtime + device context: 0.1 - 0.2 s) can be made while the input files are read: a thread started
+ * by the command before it opens anything (never in front of the fork of the multi-GPU mode: nothing there may touch HIP).
+ * run_engine() takes the context over; a failure is reported there, where the one-thread order would have reported it. */
+static struct { pthread_t th; int started; l2r_ctx *ctx; char err[512]; } g_early;
+static void *early_engine_main(void *arg)
+{
+    (void)arg;
+    g_early.ctx = l2r_create(g_device);
+    if (!g_early.ctx) { snprintf(g_early.err, sizeof g_early.err, "%s", l2r_last_error()); }
+    return NULL;
+}
+static void early_engine_start(void)
+{
+    const char *off = getenv("L2R_EARLY_ENGINE");
+    if (g_early.started || (off && off[0] == '0')) return;
+    g_early.ctx = NULL; g_early.err[0] = 0;
+    if (pthread_create(&g_early.th, NULL, early_engine_main, NULL) == 0) g_early.started = 1;
+}
+/* the context of the early thread (NULL + its message when it failed), or a fresh one */
+static l2r_ctx *engine_take(const char *who)
+{
+    if (g_early.started) {
+        pthread_join(g_early.th, NULL);
+        g_early.started = 0;
+        if (!g_early.ctx) h_fatal(who, "%s", g_early.err);
+        l2r_ctx *c = g_early.ctx; g_early.ctx = NULL;
+        return c;
+    }
+    l2r_ctx *c = l2r_create(g_device);
+    if (!c) engine_fail(who);
+    return c;
+}
+static void early_engine_drop(void)
+{
+    if (!g_early.started) return;
+    pthread_join(g_early.th, NULL);
+    g_early.started = 0;
+    if (g_early.ctx) { l2r_destroy(g_early.ctx); g_early.ctx = NULL; }
+}
+
 static void run_engine(const char *who, const l2r_params *prm, const l2r_annotation *a, const l2r_junctions *s,
                        const l2r_reads *r, h_result *out, int64_t **acc_read)
 {
-    l2r_ctx *ctx = l2r_create(g_device);
-    if (!ctx) engine_fail(who);
+    l2r_ctx *ctx = engine_take(who);
     h_stage_time("engine: create");
     if (l2r_set_params(ctx, prm) || l2r_set_outputs(ctx, acc_read ? L2R_WANT_ACCEPTED : L2R_WANT_RESULTS) ||
         l2r_set_annotation(ctx, a) || l2r_set_junctions(ctx, s->n ? s : NULL)) engine_fail(who);
@@ -872,8 +915,14 @@ static int update_gtf_multi(h_job *j, int n_gpus)
 int h_cmd_update_gtf(int argc, char **argv)
 {
     int rc = 0;
+    {   /* one process, one GPU: its context is made while the files are read (the multi-GPU mode forks first); h_job_open starts
+         * the thread once the command line has been accepted */
+        const char *eg = getenv("L2R_GPUS");
+        g_want_early_engine = (eg ? atoi(eg) : 1) <= 1;
+    }
     h_job *j = h_job_open(argc, argv, &rc);
-    if (!j) return rc;
+    g_want_early_engine = 0;
+    if (!j) { early_engine_drop(); return rc; }
     {   /* L2R_GPUS=N: one child per GPU (update_gtf_multi) when the partition argument holds, else this process and one GPU */
         const char *eg = getenv("L2R_GPUS");
         const int n_gpus = eg ? atoi(eg) : 1;

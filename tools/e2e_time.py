@@ -12,10 +12,15 @@ t0 = time.time(); synth.write_bam(reads, bam); anno.write_gtf(gtf)
 print("inputs written in %.1f s: bam %.1f MB, gtf %.1f MB" % (time.time() - t0, os.path.getsize(bam) / 1e6, os.path.getsize(gtf) / 1e6), flush=True)
 out = {k: os.path.join(d, k) for k in ("gtf", "detail", "summary", "bed")}
 env = dict(os.environ); env["L2R_TIMING"] = "1"
-t0 = time.time()
-r = subprocess.run([hostlib.BIN_PATH if hasattr(hostlib, "BIN_PATH") else os.path.join(os.path.dirname(hostlib.__file__), "bin", "lr2rmats"),
-                    "update-gtf", "-l", "3", "-A", out["detail"], "-y", out["summary"], "-E", out["bed"], "-o", out["gtf"], bam, gtf],
-                   env=env, stderr=subprocess.PIPE)
-dt = time.time() - t0
-print(r.stderr.decode()[-1500:])
-print("rc", r.returncode, "wall %.2f s for %d reads; outputs:" % (dt, N), {k: round(os.path.getsize(v) / 1e6, 1) for k, v in out.items()})
+runs = int(os.environ.get("E2E_RUNS", "1"))
+for k in range(runs):
+    t0 = time.time()
+    r = subprocess.run([hostlib.BIN_PATH if hasattr(hostlib, "BIN_PATH") else os.path.join(os.path.dirname(hostlib.__file__), "bin", "lr2rmats"),
+                        "update-gtf", "-l", "3", "-A", out["detail"], "-y", out["summary"], "-E", out["bed"], "-o", out["gtf"], bam, gtf],
+                       env=env, stderr=subprocess.PIPE)
+    dt = time.time() - t0
+    if runs == 1:
+        print(r.stderr.decode()[-1500:])
+    else:
+        print("run", k, " | ".join(l[len("[timing]"):].strip() for l in r.stderr.decode().splitlines() if l.startswith("[timing]")))
+    print("rc", r.returncode, "wall %.2f s for %d reads; outputs:" % (dt, N), {k_: round(os.path.getsize(v) / 1e6, 1) for k_, v in out.items()}, flush=True)
