@@ -13,6 +13,7 @@
 #include <getopt.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include "l2r_host.h"
 
 static const char PROG[] = "lr2rmats";
@@ -140,6 +141,22 @@ static void reads_from_gtf(const char *fn, const h_chroms *chr, h_reads *out)
 static int g_rank = 0, g_world = 1;
 static int g_want_early_engine = 0;        /* set by h_cmd_update_gtf around its h_job_open: see early_engine_start() */
 static void early_engine_start(void);
+static void early_engine_annotation(const l2r_annotation *a);
+typedef struct { const char *fn; const h_chroms *chr; h_gtf *out; } gtf_thread_arg;
+static void *gtf_thread_main(void *p)
+{
+    gtf_thread_arg *a = (gtf_thread_arg *)p;
+    fprintf(stderr, "[read_anno_trans] reading transcript annotation from %s ...\n", a->fn);
+    h_read_gtf(a->fn, a->chr, a->out, 0);
+    fprintf(stderr, "[read_anno_trans] reading transcript annotation from %s done.\n", a->fn);
+    if (g_want_early_engine) {         /* (the command's own engine: its tables are built beside the record reader) */
+        l2r_annotation v;
+        v.n_tx = a->out->n_tx; v.n_exon = a->out->n_ex; v.tx_tid = a->out->tid; v.tx_start = a->out->start; v.tx_end = a->out->end;
+        v.tx_rev = a->out->rev; v.tx_ex_off = a->out->ex_off; v.ex_start = a->out->ex_start; v.ex_end = a->out->ex_end;
+        early_engine_annotation(&v);
+    }
+    return NULL;
+}
 
 h_job *h_job_open_rank(int argc, char **argv, int *exit_code, int open_outputs, int rank, int world)
 {
@@ -216,6 +233,7 @@ h_job *h_job_open(int argc, char **argv, int *exit_code)
     if (argc - optind != 2) { *exit_code = update_usage(); free(j); return NULL; }
 
     h_stage_time("start");
+    int anno_read = 0;
     if (g_want_early_engine) early_engine_start();
     if (j->mode == 0) {
         /* a rank of a multi-process run loads its shard only -- unless the run needs the gathered route (split pieces are compared
@@ -230,7 +248,20 @@ h_job *h_job_open(int argc, char **argv, int *exit_code)
                 if (j->reads.cig_off) h_reads_free(&j->reads);       /* (the header's names are interned again: same ids) */
                 j->sharded = h_read_alignments_shard(argv[optind], &j->chr, &j->reads, 0, "update_gtf", g_rank, g_world, &j->shard_lo, &j->shard_hi, &j->shard_total);
             }
-        } else h_read_alignments(argv[optind], &j->chr, &j->reads, 0, "update_gtf");
+        } else {
+            /* one process: the annotation is parsed on a thread of its own while the records are read -- it only LOOKS UP the header's
+             * chromosome names (h_read_gtf takes the table const), which are complete once the header has been read, and the record
+             * reader interns nothing behind the header (L2R_PARALLEL_READ=0: one after the other, as the reference does it) */
+            const char *pe = getenv("L2R_PARALLEL_READ");
+            pthread_t gt; int par = 0;
+            gtf_thread_arg ga = { argv[optind + 1], &j->chr, &j->anno };
+            if (!(pe && pe[0] == '0')) {
+                h_read_header_only(argv[optind], &j->chr, "update_gtf");
+                par = pthread_create(&gt, NULL, gtf_thread_main, &ga) == 0;
+            }
+            h_read_alignments(argv[optind], &j->chr, &j->reads, 0, "update_gtf");
+            if (par) { pthread_join(gt, NULL); anno_read = 1; }
+        }
         h_stage_time("read alignments");
     } else {
         if (!hdr_file) h_fatal("update_gtf", "Couldn't read header of provided BAM file.\n");
@@ -240,9 +271,11 @@ h_job *h_job_open(int argc, char **argv, int *exit_code)
     }
     j->engine_prm = j->o.prm;
     if (j->mode == 1) { j->engine_prm.min_exon = INT32_MIN; j->engine_prm.min_intron = 0; j->engine_prm.max_delet = INT32_MAX; }
-    fprintf(stderr, "[read_anno_trans] reading transcript annotation from %s ...\n", argv[optind + 1]);
-    h_read_gtf(argv[optind + 1], &j->chr, &j->anno, 0);
-    fprintf(stderr, "[read_anno_trans] reading transcript annotation from %s done.\n", argv[optind + 1]);
+    if (!anno_read) {
+        fprintf(stderr, "[read_anno_trans] reading transcript annotation from %s ...\n", argv[optind + 1]);
+        h_read_gtf(argv[optind + 1], &j->chr, &j->anno, 0);
+        fprintf(stderr, "[read_anno_trans] reading transcript annotation from %s done.\n", argv[optind + 1]);
+    }
     h_stage_time("read annotation");
     h_read_sj(j->sj_fp, &j->chr, &j->sj);
     return j;
@@ -616,29 +649,52 @@ static int g_device = 0;                                    /* the HIP device of
 /* The engine's context (HIP runtime + device context: 0.1 - 0.2 s) can be made while the input files are read: a thread started
  * by the command before it opens anything (never in front of the fork of the multi-GPU mode: nothing there may touch HIP).
  * run_engine() takes the context over; a failure is reported there, where the one-thread order would have reported it. */
-static struct { pthread_t th; int started; l2r_ctx *ctx; char err[512]; } g_early;
+static struct { pthread_t th; int started; l2r_ctx *ctx; char err[512];
+                pthread_mutex_t mu; pthread_cond_t cv; int anno_state;      /* 0: not parsed yet, 1: offered, 2: none will come */
+                l2r_annotation anno; int anno_set; } g_early = { .mu = PTHREAD_MUTEX_INITIALIZER, .cv = PTHREAD_COND_INITIALIZER };
 static void *early_engine_main(void *arg)
 {
     (void)arg;
     g_early.ctx = l2r_create(g_device);
     if (!g_early.ctx) { snprintf(g_early.err, sizeof g_early.err, "%s", l2r_last_error()); }
+    /* ... and its annotation tables (0.15 s for a GENCODE-size GTF) as soon as the GTF has been parsed, beside the record reader */
+    pthread_mutex_lock(&g_early.mu);
+    while (g_early.anno_state == 0) pthread_cond_wait(&g_early.cv, &g_early.mu);
+    const int have = g_early.anno_state == 1;
+    pthread_mutex_unlock(&g_early.mu);
+    if (have && g_early.ctx) {
+        if (l2r_set_annotation(g_early.ctx, &g_early.anno)) { snprintf(g_early.err, sizeof g_early.err, "%s", l2r_last_error()); l2r_destroy(g_early.ctx); g_early.ctx = NULL; }
+        else g_early.anno_set = 1;
+    }
     return NULL;
 }
 static void early_engine_start(void)
 {
     const char *off = getenv("L2R_EARLY_ENGINE");
     if (g_early.started || (off && off[0] == '0')) return;
-    g_early.ctx = NULL; g_early.err[0] = 0;
+    g_early.ctx = NULL; g_early.err[0] = 0; g_early.anno_state = 0; g_early.anno_set = 0;
     if (pthread_create(&g_early.th, NULL, early_engine_main, NULL) == 0) g_early.started = 1;
 }
-/* the context of the early thread (NULL + its message when it failed), or a fresh one */
-static l2r_ctx *engine_take(const char *who)
+/* the parsed annotation for the early thread (a: arrays that stay where they are until the engine has run), or NULL: none will come */
+static void early_engine_annotation(const l2r_annotation *a)
 {
+    if (!g_early.started) return;
+    pthread_mutex_lock(&g_early.mu);
+    if (g_early.anno_state == 0) { if (a) { g_early.anno = *a; g_early.anno_state = 1; } else g_early.anno_state = 2; }
+    pthread_cond_signal(&g_early.cv);
+    pthread_mutex_unlock(&g_early.mu);
+}
+/* the context of the early thread (its message when it failed), or a fresh one; *anno_set: its annotation tables are in place */
+static l2r_ctx *engine_take(const char *who, int *anno_set)
+{
+    *anno_set = 0;
     if (g_early.started) {
+        early_engine_annotation(NULL);
         pthread_join(g_early.th, NULL);
         g_early.started = 0;
         if (!g_early.ctx) h_fatal(who, "%s", g_early.err);
         l2r_ctx *c = g_early.ctx; g_early.ctx = NULL;
+        *anno_set = g_early.anno_set;
         return c;
     }
     l2r_ctx *c = l2r_create(g_device);
@@ -648,6 +704,7 @@ static l2r_ctx *engine_take(const char *who)
 static void early_engine_drop(void)
 {
     if (!g_early.started) return;
+    early_engine_annotation(NULL);
     pthread_join(g_early.th, NULL);
     g_early.started = 0;
     if (g_early.ctx) { l2r_destroy(g_early.ctx); g_early.ctx = NULL; }
@@ -656,10 +713,11 @@ static void early_engine_drop(void)
 static void run_engine(const char *who, const l2r_params *prm, const l2r_annotation *a, const l2r_junctions *s,
                        const l2r_reads *r, h_result *out, int64_t **acc_read)
 {
-    l2r_ctx *ctx = engine_take(who);
+    int anno_set = 0;
+    l2r_ctx *ctx = engine_take(who, &anno_set);
     h_stage_time("engine: create");
     if (l2r_set_params(ctx, prm) || l2r_set_outputs(ctx, acc_read ? L2R_WANT_ACCEPTED : L2R_WANT_RESULTS) ||
-        l2r_set_annotation(ctx, a) || l2r_set_junctions(ctx, s->n ? s : NULL)) engine_fail(who);
+        (!anno_set && l2r_set_annotation(ctx, a)) || l2r_set_junctions(ctx, s->n ? s : NULL)) engine_fail(who);
     h_stage_time("engine: annotation tables");
     memset(out, 0, sizeof *out);
     int64_t rows = 0, exons = 0, rows_cap = 0, ex_cap = 0, *idx = NULL, *off_tmp = NULL;
