@@ -98,7 +98,7 @@ struct l2r_ctx {
     int64_t n_sj = 0;
     DevBuf<int32_t> sj_tid, sj_don, sj_acc, sj_uniq, sj_multi;
     DevBuf<int64_t> sj_key;
-    DevBuf<int32_t> sj_cbase, sj_dbase; DevBuf<uint32_t> sj_cdir, sj_ddir; int32_t sj_ntid = 0;      // SjDir (l2r_kernels.hip.h)
+    DevBuf<int32_t> sj_cbase, sj_dbase; DevBuf<uint32_t> sj_cdir, sj_ddir; DevBuf<int4> sj_row; int32_t sj_ntid = 0;      // SjDir (l2r_kernels.hip.h)
     std::vector<int64_t> h_sj_key_raw;      // per row (tid,acc) key
     std::vector<int64_t> h_sj_key_pm;       // ... and its running maximum
     // reads
@@ -219,7 +219,7 @@ void l2r_destroy(l2r_ctx *c)
     c->hdr.release(); c->anno_ex.release(); c->anno_key.release();
     c->sk_st.release(); c->sk_en.release(); c->sd_st.release(); c->sd_en.release(); c->sr_st.release(); c->tid_base.release();
     c->key_dir.release(); c->kb_base.release(); c->j0.release();
-    c->sj_tid.release(); c->sj_don.release(); c->sj_acc.release(); c->sj_uniq.release(); c->sj_multi.release(); c->sj_key.release(); c->sj_cbase.release(); c->sj_cdir.release(); c->sj_dbase.release(); c->sj_ddir.release();
+    c->sj_tid.release(); c->sj_don.release(); c->sj_acc.release(); c->sj_uniq.release(); c->sj_multi.release(); c->sj_key.release(); c->sj_cbase.release(); c->sj_cdir.release(); c->sj_dbase.release(); c->sj_ddir.release(); c->sj_row.release();
     c->r_tid.release(); c->r_pos.release(); c->r_rev.release(); c->cig_off.release(); c->cig.release();
     c->win_start.release(); c->sj_cursor.release();
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_acc_at.release(); c->tile_acc_ex_at.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
@@ -653,7 +653,10 @@ int l2r_set_junctions(l2r_ctx *c, const l2r_junctions *s)
     }
     if (c->sj_tid.ensure((size_t)n) || c->sj_don.ensure((size_t)n) || c->sj_acc.ensure((size_t)n) ||
         c->sj_uniq.ensure((size_t)n) || c->sj_multi.ensure((size_t)n) || c->sj_key.ensure((size_t)n) ||
-        c->sj_cbase.ensure(cbase.size()) || c->sj_cdir.ensure(cdir.size()) || c->sj_dbase.ensure(dbase.size()) || c->sj_ddir.ensure(ddir.size())) return -2;
+        c->sj_cbase.ensure(cbase.size()) || c->sj_cdir.ensure(cdir.size()) || c->sj_dbase.ensure(dbase.size()) || c->sj_ddir.ensure(ddir.size()) || c->sj_row.ensure((size_t)n)) return -2;
+    std::vector<int4> rows((size_t)n);
+    for (int64_t i = 0; i < n; ++i) rows[(size_t)i] = make_int4(s->don[i], s->acc[i], s->uniq_c[i], s->multi_c[i]);
+    HIP_TRY(hipMemcpyAsync(c->sj_row.p, rows.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->sj_cbase.p, cbase.data(), cbase.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->sj_cdir.p, cdir.data(), cdir.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->sj_dbase.p, dbase.data(), dbase.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -1116,7 +1119,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         hipLaunchKernelGGL(k_validate_sj, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p,
                            c->sj_key.p, (c->sorted ? (const int32_t *)nullptr : c->sj_cursor.p), c->sj_tid.p, c->sj_don.p, c->sj_acc.p,
                            c->sj_uniq.p, c->sj_multi.p, p, c->info.p,
-                           SjDir{CursorDir{c->sj_key.p, c->sj_cdir.p, c->sj_cbase.p, c->sj_ntid, (int32_t)c->n_sj}, c->sj_ddir.p, c->sj_dbase.p, c->sj_ntid});
+                           SjDir{CursorDir{c->sj_key.p, c->sj_cdir.p, c->sj_cbase.p, c->sj_ntid, (int32_t)c->n_sj}, c->sj_ddir.p, c->sj_dbase.p, c->sj_ntid, c->sj_row.p});
     }
     if ((c->n_sj > 0 || c->slab) && (c->want & L2R_WANT_ACCEPTED)) {
         // acceptance is decided by the junction check (and the slab pipeline counts nothing itself): count per tile

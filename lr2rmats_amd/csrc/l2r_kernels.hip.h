@@ -1915,54 +1915,70 @@ __device__ __forceinline__ int first_key_above(const int64_t *__restrict__ key, 
 // (the same structure the annotation cursor uses: cursor_value), and a directory over 512-bp buckets of the donors:
 // ddir[dbase[tid] + (x >> 9)] = first row >= (tid, x << 9).  A lookup is one directory read and a few rows instead of a binary search
 // over the whole table (22 dependent loads for a STAR table of 4 M rows: k_validate_sj took 1.7 ms for the 7.4 M candidates of config 3).
-struct SjDir { CursorDir cur; const uint32_t *ddir; const int32_t *dbase; int32_t d_ntid; };
+struct SjDir { CursorDir cur; const uint32_t *ddir; const int32_t *dbase; int32_t d_ntid; const int4 *row; };      // row[i] = {don, acc, uniq, multi}: one 16-byte load per row
+// where a chromosome's rows are: first bucket, bucket count, first row behind them (rows are sorted by tid: every row from the
+// chromosome's first one up to `end` is its own)
+struct SjTid { int tid, db, nb, end; };
+__device__ __forceinline__ SjTid sj_tid_rows(const SjDir &sd, int tid, int n_sj)
+{
+    if (tid >= sd.d_ntid) return SjTid{tid, 0, 0, n_sj};
+    const int32_t db = sd.dbase[tid], nb = sd.dbase[tid + 1] - db;
+    return SjTid{tid, db, nb, (int)sd.ddir[db + nb]};
+}
 
 // first row >= (tid, want) of the table (rows sorted by (tid, don, acc))
-__device__ __forceinline__ int sj_first_row(const SjDir &sd, int tid, int want, int n_sj, const int32_t *__restrict__ sj_tid, const int32_t *__restrict__ sj_don)
+__device__ __forceinline__ int sj_first_row(const SjDir &sd, const SjTid &ti, int want)
 {
-    if (tid >= sd.d_ntid) return n_sj;
-    const int32_t db = sd.dbase[tid], nb = sd.dbase[tid + 1] - db;
+    if (ti.nb <= 0) return ti.end;
     const int b = max(want, 0) >> SITE_SHIFT;
-    if (b >= nb) return (int)sd.ddir[db + nb];                 // behind the chromosome's last donor: the next chromosome's first row
-    int lo = (int)sd.ddir[db + b], hi = (int)sd.ddir[db + b + 1];
+    if (b >= ti.nb) return ti.end;                             // behind the chromosome's last donor: the next chromosome's first row
+    int lo = (int)sd.ddir[ti.db + b], hi = min((int)sd.ddir[ti.db + b + 1], ti.end);
     if (hi - lo > 16) {                                        // a crowded bucket: lower bound inside it
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            const int t = sj_tid[mid];
-            if (t < tid || (t == tid && sj_don[mid] < want)) lo = mid + 1; else hi = mid;
+            if (sd.row[mid].x < want) lo = mid + 1; else hi = mid;
         }
         return lo;
     }
-    while (lo < hi && (sj_tid[lo] < tid || (sj_tid[lo] == tid && sj_don[lo] < want))) ++lo;
+    // (a bucket's rows are the chromosome's: only the donor is compared; the first two rows travel together)
+    if (lo + 1 < hi) { const int d0 = sd.row[lo].x, d1 = sd.row[lo + 1].x; if (d0 >= want) return lo; if (d1 >= want) return lo + 1; lo += 2; }
+    while (lo < hi && sd.row[lo].x < want) ++lo;
     return lo;
 }
 
 // src/update_gtf.c:589-603 check_short_sj1 with the linear scan from the cursor row replaced by a lower-bound on
 // (tid, don): rows below don-dis cannot match, and the reference stops at the first row with don >= acc (intron end).
-__device__ __forceinline__ bool junction_supported(int tid, int don, int acc, int from, const int32_t *__restrict__ sj_tid,
-                                                   const int32_t *__restrict__ sj_don, const int32_t *__restrict__ sj_acc,
-                                                   const int32_t *__restrict__ sj_uniq, const int32_t *__restrict__ sj_multi,
-                                                   const DevParams &p, const SjDir &sd)
+__device__ __forceinline__ bool junction_supported(const SjTid &ti, int don, int acc, int from, const DevParams &p, const SjDir &sd)
 {
     int lo = from;
     const int want = don - p.ss_dis;
     // (a degenerate intron with acc < don, or a negative -d, keeps the literal linear scan:
     //  only then could a skipped row have triggered the reference's early "don >= acc" stop)
-    if (!(acc < don || p.ss_dis < 0)) lo = max(from, sj_first_row(sd, tid, want, p.n_sj, sj_tid, sj_don));      // first row >= (tid, want) at or after `from`
-    for (int i = lo; i < p.n_sj; ++i) {
-        const int t = sj_tid[i], d = sj_don[i];
-        if (t > tid || (t == tid && d >= acc)) return false;
+    if (!(acc < don || p.ss_dis < 0)) lo = max(from, sj_first_row(sd, ti, want));      // first row >= (tid, want) at or after `from`
+    // (rows from `from` on are on the read's chromosome or behind it: the first row of a later chromosome ends the scan, :594)
+    for (int i = lo; i < ti.end; ++i) {
+        const int4 q = sd.row[i];
+        const int d = q.x;
+        if (d >= acc) return false;
         if (p.ss_dis >= 0 && d - don > p.ss_dis) return false;   // sorted by don: nothing further can match
-        if (near_eq(d, don, p.ss_dis) && near_eq(sj_acc[i], acc, p.ss_dis)) {
-            const int c = p.use_multi ? sj_uniq[i] + sj_multi[i] : sj_uniq[i];
+        if (near_eq(d, don, p.ss_dis) && near_eq(q.y, acc, p.ss_dis)) {
+            const int c = p.use_multi ? q.z + q.w : q.z;
             if (c >= p.min_sj_cnt) return true;
         }
     }
     return false;
 }
 
-// src/update_gtf.c:698-709 check_with_short_sj + :609-627 check_short_sj for every read that reaches it
-// (full, not known, has a known site), one thread per read.
+// src/update_gtf.c:698-709 check_with_short_sj + :609-627 check_short_sj for every read that reaches it (full, not known, has a
+// known site).  One workgroup per 256 consecutive reads, in three steps:
+//   1. thread i = read i: is it a candidate, its cursor row (:613-614) and the Q7 test on it; every exon position of the block learns
+//      its read (an LDS map over the block's exon run: the results are in read order, so the run is contiguous);
+//   2. the block's exon POSITIONS across the threads: flag bytes, exon ends and next starts are read coalesced, and the table lookups
+//      of the novel junctions of candidates are spread over all lanes -- one thread per read left most lanes idle behind the reads
+//      with the most novel junctions, each lookup a chain of dependent loads (0.86 ms for the 7.4 M candidates of config 3);
+//   3. thread i again: the read's verdict from what its junctions left in LDS.
+// A read whose exons do not lie in the mapped part of the run (a block of very long reads) checks its junctions itself, as before.
+constexpr int SJ_MAP_CAP = 6144;              // exon positions of a block that are mapped to their reads
 __global__ __launch_bounds__(TILE_THREADS)
 void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uint32_t *__restrict__ ex_off,
                    const int32_t *__restrict__ ex_start, const int32_t *__restrict__ ex_end, uint8_t *__restrict__ ex_flag,
@@ -1971,30 +1987,70 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
                    const int32_t *__restrict__ sj_uniq, const int32_t *__restrict__ sj_multi, DevParams p,
                    uint32_t *__restrict__ info_io, SjDir sd)
 {
+    __shared__ uint8_t s_owner[SJ_MAP_CAP];
+    __shared__ int s_from[TILE_THREADS];               // the read's cursor row, -1: its junctions are not looked up here
+    __shared__ int s_tid[TILE_THREADS];
+    __shared__ uint32_t s_bad[TILE_THREADS];
+    __shared__ uint32_t s_base, s_end;
     const int64_t r = (int64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
-    if (r >= n_reads) return;
-    uint32_t info = info_io[r];
-    if ((info & (I_FULL | I_KNOWN | I_KSITE)) != (I_FULL | I_KSITE)) return;
-    const int n = (int)(info >> 8), tid = r_tid[r];
-    const uint32_t off = ex_off[r];
-    const int r_start = ex_start[off], r_end = ex_end[off + (uint32_t)(n - 1)];
-    const int from = sj_cursor ? sj_cursor[r] : cursor_value(sd.cur, tid, r_start);      // (first row whose prefix-max key is above (tid, start): update_gtf.c:613-614)
-    bool ok = false;
-    if (from < p.n_sj) {
-        const int t = sj_tid[from];
-        // Q7: cursor row beyond the read -> unsupported, no unreliable flag
-        if (!(t > tid || (t == tid && sj_don[from] >= r_end))) {
-            ok = true;
-            for (int j = 0; j + 1 < n; ++j) {
-                const uint8_t f = ex_flag[off + (uint32_t)j];
-                if ((f & F_JUNC) &&
-                    !junction_supported(tid, ex_end[off + (uint32_t)j] + 1, ex_start[off + (uint32_t)(j + 1)] - 1, from, sj_tid, sj_don, sj_acc, sj_uniq, sj_multi, p, sd)) {
-                    ex_flag[off + (uint32_t)j] = f | F_UNREL;
-                    ok = false;
-                }
-            }
+    const bool have = r < n_reads;
+    uint32_t info = have ? info_io[r] : 0u;
+    const bool cand = have && (info & (I_FULL | I_KNOWN | I_KSITE)) == (I_FULL | I_KSITE);
+    const int n = (int)(info >> 8), tid = have ? r_tid[r] : 0;
+    const uint32_t off = have ? ex_off[r] : 0u;
+    // the rows of the block's chromosome (its first read's: wave-uniform loads), a read of another one looks its own up
+    const SjTid ti0 = sj_tid_rows(sd, r_tid[(int64_t)blockIdx.x * TILE_THREADS], p.n_sj);
+    if (threadIdx.x == 0) s_base = off;
+    // (the block's last read closes the run)
+    if (have && (threadIdx.x == TILE_THREADS - 1 || r == n_reads - 1)) s_end = off + (uint32_t)n;
+    int from = -1;
+    bool ok0 = false;
+    if (cand) {
+        const int r_start = ex_start[off], r_end = ex_end[off + (uint32_t)(n - 1)];
+        from = sj_cursor ? sj_cursor[r] : cursor_value(sd.cur, tid, r_start);      // (first row whose prefix-max key is above (tid, start): update_gtf.c:613-614)
+        if (from < p.n_sj) {
+            // Q7: cursor row beyond the read -> unsupported, no unreliable flag  (rows from the cursor on are on the read's chromosome or behind it)
+            const SjTid ti = tid == ti0.tid ? ti0 : sj_tid_rows(sd, tid, p.n_sj);
+            ok0 = !(from >= ti.end || sd.row[from].x >= r_end);
         }
     }
+    s_bad[threadIdx.x] = 0u;
+    s_tid[threadIdx.x] = tid;
+    __syncthreads();
+    const uint32_t base = s_base, total = min(s_end - base, (uint32_t)SJ_MAP_CAP);
+    // is the read's run inside the mapped positions?  (read order: it is, unless the block has more than SJ_MAP_CAP exons)
+    const bool mapped = have && off >= base && off - base + (uint32_t)n <= total;
+    s_from[threadIdx.x] = (cand && ok0 && mapped) ? from : -1;
+    if (mapped) for (int k = 0; k < n; ++k) s_owner[off - base + (uint32_t)k] = (uint8_t)threadIdx.x;
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < total; q += (uint32_t)TILE_THREADS) {
+        const uint8_t f = ex_flag[base + q];
+        if (!(f & F_JUNC)) continue;
+        const uint32_t who = s_owner[q];
+        const int fr = s_from[who];
+        if (fr < 0) continue;
+        // (a junction flag only stands on an exon that is not its read's last: position q + 1 is the same read's)
+        const int wt = s_tid[who];
+        const SjTid ti = wt == ti0.tid ? ti0 : sj_tid_rows(sd, wt, p.n_sj);
+        if (!junction_supported(ti, ex_end[base + q] + 1, ex_start[base + q + 1u] - 1, fr, p, sd)) {
+            ex_flag[base + q] = f | F_UNREL;
+            s_bad[who] = 1u;
+        }
+    }
+    __syncthreads();
+    if (!cand) return;
+    bool ok = ok0;
+    if (ok0 && !mapped) {
+        const SjTid ti = tid == ti0.tid ? ti0 : sj_tid_rows(sd, tid, p.n_sj);
+        for (int j = 0; j + 1 < n; ++j) {
+            const uint8_t f = ex_flag[off + (uint32_t)j];
+            if ((f & F_JUNC) &&
+                !junction_supported(ti, ex_end[off + (uint32_t)j] + 1, ex_start[off + (uint32_t)(j + 1)] - 1, from, p, sd)) {
+                ex_flag[off + (uint32_t)j] = f | F_UNREL;
+                ok = false;
+            }
+        }
+    } else if (ok0) ok = s_bad[threadIdx.x] == 0u;
     info |= I_SJCHK;
     if (ok) info |= I_SJPASS; else info |= I_UNREL;
     if (ok || p.split_trans) info |= I_ACCEPT;
