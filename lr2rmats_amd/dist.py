@@ -124,9 +124,11 @@ def _engine_classify(device_index: int):
             return DeviceShard(eng)
         eng.set_outputs(capi.WANT_RESULTS)                  # (the caller takes what it needs from the full results: HostShard)
         parts, a = [], lo
+        # reads + CIGAR operations in front of every record of the shard, computed ONCE (a piece's units = differences of it: the search
+        # per piece is a binary search, not two temporaries of the remaining shard's length -- ADVICE r3)
+        cum = r["cig_off"][lo:hi + 1].astype(np.int64) + np.arange(hi - lo + 1, dtype=np.int64)
         while a < hi:
-            units = (r["cig_off"][a:hi + 1] - r["cig_off"][a]) + np.arange(hi - a + 1, dtype=np.int64)
-            b = a + max(1, int(np.searchsorted(units, max_units, side="left")) - 1)
+            b = lo + max(a - lo + 1, int(np.searchsorted(cum, cum[a - lo] + max_units, side="left")) - 1)
             if limit:
                 b = min(b, a + limit)
             b = min(b, hi)

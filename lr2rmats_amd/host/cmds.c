@@ -890,10 +890,36 @@ static int update_gtf_multi(h_job *j, int n_gpus)
     }
     const char *map = getenv("L2R_GPU_MAP");
     pid_t *pid = (pid_t *)calloc((size_t)n_gpus, sizeof *pid);
-    fflush(NULL);
+    int *dev_of = (int *)calloc((size_t)n_gpus, sizeof *dev_of);
     for (int k = 0; k < n_gpus; ++k) {
         int dev = k;
         if (map) { const char *p = map; for (int q = 0; q < k && p; ++q) { p = strchr(p, ','); if (p) ++p; } if (p) dev = atoi(p); }
+        dev_of[k] = dev;
+    }
+    fflush(NULL);
+    {   /* how many devices are there?  Asked in a short-lived child: this process must not touch HIP in front of its forks.  A child per
+         * device that does not exist would fail in l2r_create only after the whole input has been parsed and cut. */
+        const pid_t pp = fork();
+        if (pp < 0) h_fatal("update_gtf", "fork failed");
+        if (pp == 0) { const int n = l2r_device_count(); _exit(n < 0 ? 0 : (n > 250 ? 250 : n)); }
+        int st = 0;
+        if (waitpid(pp, &st, 0) < 0 || !WIFEXITED(st)) h_fatal("update_gtf", "the device query of the multi-GPU run failed");
+        const int n_dev = WEXITSTATUS(st);
+        for (int k = 0; k < n_gpus; ++k)
+            if (dev_of[k] < 0 || dev_of[k] >= n_dev) {
+                if (tmp_base[0]) remove(tmp_base);
+                h_fatal("update_gtf", "L2R_GPUS=%d%s%s: child %d would run on device %d, this node has %d", n_gpus, map ? " with L2R_GPU_MAP=" : "", map ? map : "", k, dev_of[k], n_dev);
+            }
+    }
+    {   /* shards are whole chromosomes: say so when that leaves children without work or far out of balance */
+        int64_t mx = 0; int empty = 0;
+        for (int k = 0; k < n_gpus; ++k) { const int64_t n = cut[k + 1] - cut[k]; if (n == 0) ++empty; if (n > mx) mx = n; }
+        if (empty || (N > 0 && (double)mx * n_gpus > 2.0 * (double)N))
+            fprintf(stderr, "[update_gtf] L2R_GPUS=%d: shards are cut at chromosome boundaries -- %d of %d without records, the largest holds %lld of %lld\n",
+                    n_gpus, empty, n_gpus, (long long)mx, (long long)N);
+    }
+    for (int k = 0; k < n_gpus; ++k) {
+        const int dev = dev_of[k];
         pid[k] = fork();
         if (pid[k] < 0) h_fatal("update_gtf", "fork failed");
         if (pid[k] == 0) {
@@ -925,7 +951,21 @@ static int update_gtf_multi(h_job *j, int n_gpus)
     }
     int failed = 0;
     for (int k = 0; k < n_gpus; ++k) { int st = 0; if (waitpid(pid[k], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) failed = 1; }
-    if (failed) h_fatal("update_gtf", "a child of the multi-GPU run failed");
+    if (failed) {
+        /* nothing of a failed run stays behind: part files, their counters, the temporary GTF */
+        const char *b0 = j->out_path[0] ? j->out_path[0] : tmp_base;
+        for (int k = 0; k < n_gpus; ++k) {
+            char nm[1300];
+            snprintf(nm, sizeof nm, "%s.part%03d.meta", b0, k); remove(nm);
+            for (int w = 0; w < 8; ++w) {
+                const char *path = w == 0 ? b0 : j->out_path[w];
+                if (!path) continue;
+                snprintf(nm, sizeof nm, "%s.part%03d", path, k); remove(nm);
+            }
+        }
+        if (tmp_base[0]) remove(tmp_base);
+        h_fatal("update_gtf", "a child of the multi-GPU run failed");
+    }
     h_stage_time("children: engine + tail on every shard");
     /* ---- join: counters, gene lists (an id equal to the last entry of the parts before is not counted again, h_part_genes), files */
     int64_t total[H_N_SUMMARY]; memset(total, 0, sizeof total);
@@ -965,7 +1005,7 @@ static int update_gtf_multi(h_job *j, int n_gpus)
     FILE **fs[] = {&j->o.exon_bed, &j->o.bam_gtf, &j->o.bam_detail, &j->o.known_gtf, &j->o.novel_gtf, &j->o.unrecog_gtf, &j->o.summary};
     for (size_t k = 0; k < sizeof fs / sizeof fs[0]; ++k) if (*fs[k]) { fclose(*fs[k]); *fs[k] = NULL; }
     if (j->o.out_gtf && j->o.out_gtf != stdout) { fclose(j->o.out_gtf); j->o.out_gtf = NULL; } else fflush(stdout);
-    free(pid); free(cut);
+    free(pid); free(cut); free(dev_of);
     h_stage_time("join: parts -> files");
     return 0;
 }

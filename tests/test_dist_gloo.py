@@ -304,3 +304,22 @@ def test_block_ranges_that_cannot_be_trusted_fall_back(oracle, tmp_path):
     assert open(str(tmp_path / "trace")).read().strip() == "one rank, gathered full"
     for k in KEYS:
         assert filecmp.cmp(single[k], multi[k], shallow=False), k
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_bam_of_one_block_takes_the_fallback_of_the_block_ranges(oracle, tmp_path, world):
+    """A sorted BAM so small that it is ONE BGZF block (plus the end-of-file block): every rank's byte target lies in that block, the
+    block ranges cannot be told apart -- the ranks' notes do not meet (dist.py), every rank reopens its job with L2R_DIST_BLOCKS=0 and the
+    shards are cut from the records of the whole file.  Files = the single-process files (the branch had no test)."""
+    anno = synth.make_annotation(1500, 91, nchr=4)
+    reads = synth.make_reads(anno, 400, 4, 91)
+    sam, gtf, bam = str(tmp_path / "r.sam"), str(tmp_path / "a.gtf"), str(tmp_path / "r.bam")
+    reads.write_sam(sam)
+    anno.write_gtf(gtf)
+    synth.write_bam(reads, bam)
+    single = {k: str(tmp_path / ("s." + k)) for k in KEYS}
+    multi = {k: str(tmp_path / ("m." + k)) for k in KEYS}
+    assert oracle.run_cli(_args(single, sam, gtf)) == 0
+    _run_ranks(world, _args(multi, bam, gtf))
+    for k in KEYS:
+        assert filecmp.cmp(single[k], multi[k], shallow=False), k

@@ -267,3 +267,15 @@ def test_c_cli_with_several_gpu_children_writes_the_single_gpu_files(tmp_path, f
     # an option set that needs one stream of records says so and runs on one GPU
     r = hostlib.run_cli(["update-gtf", "-m", "g", "-b", sam, "-l", "3", gtf, gtf], env={"L2R_GPUS": 2, "L2R_GPU_MAP": "0,0"})
     assert r.returncode == 0 and b"running on one GPU" in r.stderr
+    if n_gpus == 5:
+        # more children than the input has chromosomes: some get no records -- said, not silent -- and the files are still the same
+        eleven = _paths(tmp_path, "eleven")
+        r = hostlib.run_cli(_args(["-l", "3"], eleven, bam, gtf), env={"L2R_GPUS": 11, "L2R_GPU_MAP": ",".join(["0"] * 11), "L2R_THREADS": 2})
+        assert r.returncode == 0 and b"without records" in r.stderr, r.stderr.decode()[-2000:]
+        for k in OUTS:
+            assert filecmp.cmp(one[k], eleven[k], shallow=False), k
+    # a child for a device the node does not have: refused before any child starts, nothing left behind
+    bad = _paths(tmp_path, "bad")
+    r = hostlib.run_cli(_args(["-l", "3"], bad, bam, gtf), env={"L2R_GPUS": 2, "L2R_GPU_MAP": "0,97"})
+    assert r.returncode != 0 and b"would run on device 97" in r.stderr
+    assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f or f.startswith("l2r_gtf_")]
