@@ -804,12 +804,22 @@ static int bam_find_start(FILE *f, int64_t fsz, int64_t c0, int64_t c1, int32_t 
     (void)first_len;
     if (!found) { free(buf); free(blk_off); free(blk_out); return 0; }
     /* from B(r) on until the chromosome changes */
-    size_t q = o, kq = 0; int32_t tid0 = 0; int have = 0;
+    size_t q = o, kq = 0; int32_t tid0 = 0, walk_t = 0, walk_p = 0; int have = 0;
     for (;;) {
         while (!eof && n < q + 36) MORE();
         if (q + 8 > n) { S->coff = fsz; S->uoff = 0; break; }                  /* no other chromosome behind B(r) */
-        const uint32_t bs = le32(buf + q);
-        const int32_t t = (int32_t)le32(buf + q + 4);
+        uint32_t bs = le32(buf + q);
+        int32_t t = (int32_t)le32(buf + q + 4);
+        {   /* every record of the walk has to look like one and keep the coordinate order: a start that only LOOKED like a chain of
+             * records (eight were checked) would otherwise send the walk after block sizes read from sequence bytes -- buffers of the
+             * file's inflated size before dist.py's cross-check rejects the range.  Not plausible: no start, the caller
+             * falls back to the whole-file cut. */
+            int32_t ps = 0; uint32_t bs2 = 0;
+            int rc = bam_record_plausible(buf + q, buf + n, n_ref, &t, &ps, &bs2);
+            while (rc < 0 && !eof) { MORE(); rc = bam_record_plausible(buf + q, buf + n, n_ref, &t, &ps, &bs2); }
+            if (rc == 0 || (rc > 0 && have && !bam_key_le(walk_t, walk_p, t, ps))) { free(buf); free(blk_off); free(blk_out); return 0; }
+            if (rc > 0) { bs = bs2; walk_t = t; walk_p = ps; }
+        }
         while (kq + 1 < n_blk && blk_out[kq + 1] <= q) ++kq;                    /* (the block the record begins in) */
         if ((!have || t == tid0) && blk_off[kq] >= c1) *next_begins_before = 1;
         if (!have) { tid0 = t; have = 1; }
