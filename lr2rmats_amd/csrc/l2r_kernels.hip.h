@@ -1449,11 +1449,44 @@ __device__ __forceinline__ uint32_t nonzero(uint32_t x)
     return r;
 }
 
+// -d > 0: the loop of map_exons (below) with every probe looking at the entries within the tolerance of its coordinate (probe_near); [rs, re] = the
+// read's span.  (A loop of its own: a wave-uniform branch inside the exact loop cost k_classify_fast 5 % on config 5's shard.)
+__device__ __forceinline__ SiteMasks map_exons_near(const TileLds &L, const TileDesc &d, bool mapping, uint32_t local, uint32_t n, uint32_t vpre, int dis, int rs, int re)
+{
+    SiteMasks m{0xffffffffu, 0u, 0u, 0u, 0u};
+    const int *S = L.S + local, *E = L.E + local;
+    uint16_t *W = L.W + local;
+    int s = 0, e = 0;
+    if (mapping) { s = S[0]; e = E[0]; }
+    const uint32_t none = (uint32_t)d.nbk + 1u;
+    const int k_max = wave_max(mapping ? (int)n : 0);
+    for (int k = 0; k < k_max; ++k) {
+        const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
+        const uint32_t inext = junc ? local + (uint32_t)k + 1u : 0u;
+        const int s2 = L.S[inext], e2 = L.E[inext];
+        uint32_t xm, am, jm, dm, ls, hs, le, he;
+        near_range(L.dir0, d.b_off, none, live, s, dis, ls, hs); near_range(L.dir1, d.b_off, none, junc, e, dis, le, he);
+        probe_near(L.ent0, ls, hs, s, e, dis, rs, re, xm, am, m.amb);
+        probe_near(L.ent1, le, he, e, s2, dis, rs, re, jm, dm, m.amb);
+        const uint32_t amj = junc ? am : 0u;
+        uint32_t word = first_member(xm & vpre);
+        word |= first_member(jm & vpre) << 6;
+        word |= nonzero(dm & vpre) << 12;
+        word |= nonzero(amj & vpre) << 13;
+        m.kand &= junc ? (am & dm) : 0xffffffffu;     // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
+        m.kor |= amj | dm;
+        // (with a tolerance a shared donor / acceptor does not say that the exons overlap: dm_first / am_last stay empty, the
+        //  full-length evidence asks the START slice)
+        if (live) W[k] = (uint16_t)word;
+        s = s2; e = e2;
+    }
+    return m;
+}
+
 // One START and one END probe per exon; the wave runs as many rounds as its longest read has exons.  Per round
 // {next exon, both bucket ranges} are read together, then the first entries of both buckets.  Leaves per exon in W:
 // first member of V' with the exon / the junction (6 bits each, 63: none), "donor / acceptor is in V'" (bits 12, 13).
-// dis > 0 (-d): every probe looks at the entries within the tolerance of its coordinate (probe_near); [rs, re] = the read's span.
-__device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc &d, bool mapping, uint32_t local, uint32_t n, uint32_t vpre, int dis, int rs, int re)
+__device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc &d, bool mapping, uint32_t local, uint32_t n, uint32_t vpre)
 {
     SiteMasks m{0xffffffffu, 0u, 0u, 0u, 0u};
     const int *S = L.S + local, *E = L.E + local;
@@ -1470,23 +1503,16 @@ __device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc 
         const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
         const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
         const int s2 = L.S[inext], e2 = L.E[inext];
-        uint32_t xm, am, jm, dm;
-        if (dis > 0) {                                   // (wave-uniform)
-            uint32_t ls, hs, le, he;
-            near_range(L.dir0, d.b_off, none, live, s, dis, ls, hs); near_range(L.dir1, d.b_off, none, junc, e, dis, le, he);
-            probe_near(L.ent0, ls, hs, s, e, dis, rs, re, xm, am, m.amb);
-            probe_near(L.ent1, le, he, e, s2, dis, rs, re, jm, dm, m.amb);
-        } else {
         const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
         // START buckets mostly hold one exon, END buckets often several junctions of one donor.  (An index up to
         // KEY_CAP + 1 reads on into the arrays behind the slice; such an entry is never inside [ls, hs).)
         const v4i_t qs0 = lds_entry(L.ent0, ls);
         const v4i_t qe0 = lds_entry(L.ent1, le), qe1 = lds_entry(L.ent1, le + 1u);
+        uint32_t xm, am, jm, dm;
         {   const bool m0 = ls < hs && qs0.x == s;
             am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
         probe2(qe0, qe1, le, he, e, s2, jm, dm);
         if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(L.ent0, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + 2u, he, e, s2, jm, dm, 0u); }
-        }
         // without a junction jm = dm = 0 (empty bucket); the acceptor of the last exon is not a probed site (Q1)
         const uint32_t amj = junc ? am : 0u;
         uint32_t word = first_member(xm & vpre);
@@ -1495,9 +1521,8 @@ __device__ __forceinline__ SiteMasks map_exons(const TileLds &L, const TileDesc 
         word |= nonzero(amj & vpre) << 13;
         m.kand &= junc ? (am & dm) : 0xffffffffu;     // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
         m.kor |= amj | dm;
-        // (with a tolerance a shared donor / acceptor does not say that the exons overlap: the full-length evidence asks the START slice)
-        if (dis == 0) { if (k == 0) m.dm_first = dm;
-                        m.am_last = (live && !junc) ? am : m.am_last; } // transcripts in which the last exon's start begins a later exon
+        if (k == 0) m.dm_first = dm;
+        m.am_last = (live && !junc) ? am : m.am_last;  // transcripts in which the last exon's start begins a later exon
         if (live) W[k] = (uint16_t)word;
         s = s2; e = e2;
     }
@@ -1754,7 +1779,8 @@ void k_classify_fast(FastArgs kernarg_block /* read through fast_args() */, int6
         redo = redo || vm.redo;
         L2R_STAMP(2);
         const int o_dis = fast_args()->p.ss_dis;
-        const SiteMasks sm = map_exons(L, d, work && !redo && n > 1, local, n, vm.vpre, o_dis, re.s0, re.el);
+        const SiteMasks sm = o_dis > 0 ? map_exons_near(L, d, work && !redo && n > 1, local, n, vm.vpre, o_dis, re.s0, re.el)
+                                       : map_exons(L, d, work && !redo && n > 1, local, n, vm.vpre);
         // (-d > 0: a visited member with two sites within the tolerance of one read site -- its pair count is the generic kernel's)
         if (work && !redo && (sm.amb & vm.vpre) != 0u) redo = true;
         L2R_STAMP(3);
