@@ -67,6 +67,7 @@ struct l2r_ctx {
     bool wide_cigar = false;                // long CIGARs: the HBM walks fetch 16 words per lane and round (l2r_upload_reads decides)
     int n_cu = 256, wg_per_cu = 4;          // persistent grid of k_classify_fast (L2R_WG_PER_CU overrides)
     int ablate = 0;                         // diagnostics, L2R_ABLATE (read once, at l2r_create)
+    int64_t seg_max = SEG_MAX;              // tiles up to which the segmented scans are used (l2r_kernels.hip.h); L2R_SEG_MAX
     int want_pipeline = 1;                  // L2R_PIPELINE: classic (0: l2r_kernels.hip.h, two walks), slab (1, default: l2r_slab.hip.h, one walk)
     bool slab_ok = false;                   // the current upload can run the slab pipeline: coordinate-sorted records, short CIGARs, its slab layout fits
     bool slab = false;                      // ... and the last launch did (the parameters have a say: launch_all)
@@ -204,6 +205,8 @@ l2r_ctx *l2r_create(int device)
         e = getenv("L2R_ABLATE");
         c->ablate = e ? atoi(e) : 0;
         c->check_stages = getenv("L2R_CHECK") != nullptr;
+        e = getenv("L2R_SEG_MAX");                       // diagnostics / tests: tiles beyond which the scans take k_scan_u32 in a launch of its own
+        if (e && atoll(e) >= 0) c->seg_max = atoll(e);
         e = getenv("L2R_ANNO_CACHE");
         if (e && *e) c->anno_cache_dir = e;
         e = getenv("L2R_PIPELINE");
@@ -1021,7 +1024,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             // of the 64-bit-mask and the chunked kernel: the workgroups behind them (l2r_slab.hip.h)
             const DescribeScan job{c->tile_total.p, c->tile_xbase.p, c->totals.p + 0, c->n_tiles};
             unsigned n_scan = (unsigned)std::max<int64_t>((c->n_tiles + DESCRIBE_SEG - 1) / DESCRIBE_SEG, 1);
-            if (c->n_tiles > DESCRIBE_SCAN_MAX) {
+            if (c->n_tiles > c->seg_max) {
                 // (very large shards: one workgroup scans, in a launch of its own)
                 HIP_TRY(hipMemcpyAsync(c->tile_xbase.p, c->tile_total.p, (size_t)c->n_tiles * 4, hipMemcpyDeviceToDevice, s));
                 ScanJobs jobs = {}; jobs.job[0] = ScanJob{c->tile_xbase.p, c->n_tiles, c->totals.p + 0}; jobs.job[1] = jobs.job[0];
@@ -1128,7 +1131,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     MARK(ST_SCAN2);
     if (c->want & L2R_WANT_ACCEPTED) {
         // the deferred tiles' counts -> their places behind the fused chunks (tile_acc_at / tile_acc_ex_at; the sums = totals[1], [2])
-        if (c->n_tiles <= SEG_MAX) {
+        if (c->n_tiles <= c->seg_max) {
             const unsigned n_seg = (unsigned)std::max<int64_t>((c->n_tiles + SEG_COUNT - 1) / SEG_COUNT, 1);
             hipLaunchKernelGGL(k_scan_segments, dim3(2u * n_seg), dim3(TILE_THREADS), 0, s, SegScan{c->tile_acc.p, c->tile_acc_at.p, c->totals.p + 1, c->n_tiles},
                                SegScan{c->tile_acc_ex.p, c->tile_acc_ex_at.p, c->totals.p + 2, c->n_tiles}, (uint32_t)n_seg);

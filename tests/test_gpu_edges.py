@@ -422,3 +422,16 @@ def test_splice_distance_with_two_annotation_sites_inside_the_tolerance(oracle, 
     assert known.sum() > 300 and (want.ref_tx[known] == 1).sum() >= 100 and (want.ref_tx[known] == 0).sum() >= 50      # B for the twin-donor reads, A for donor 1100 itself
     if pipeline == "slab":
         assert 0 < cnt[0] <= 300, cnt                            # the reads around the twin donors, nobody else
+
+
+def test_scans_in_launches_of_their_own(oracle, pipeline, monkeypatch):
+    """Shards beyond 262 k tiles (67 M reads) scan the tiles' exon counts and the deferred accepted counts with k_scan_u32 in launches of
+    their own instead of the segmented scans (l2r_kernels.hip.h SEG_MAX); L2R_SEG_MAX=0 takes that path on a small input: results and
+    accepted list as ever, with and without a junction table."""
+    monkeypatch.setenv("L2R_SEG_MAX", "0")
+    anno, af, reads = util.make_case(31, n_reads=30000, n_exons=6, anno_exons=20000)
+    got, want = _run(oracle, af, reads, full_level=3)
+    base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3))
+    j, sj = util.junction_table(af, reads, base, 31, cover=0.7)
+    _run(oracle, af, reads, sj=sj, full_level=3, split_trans=1, min_sj_cnt=1)
+    assert ((want.info & 7) == 6).sum() > 1000            # full, has a known site, not known: the reads the accepted list holds

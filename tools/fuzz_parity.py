@@ -1,6 +1,7 @@
 """Diagnostics on the GPU box: the HIP path against the oracle on many small random workloads -- annotation shape (isoforms per
 gene from 1 to 160: windows of every size, dictionary keys in parts), exons per read, ONT-like CIGARs, every -l level, the CIGAR
-thresholds (-e / -i / -t), sparse and dense coverage.  tools/fuzz_parity.py [rounds] [seed]; prints the first differing case and
+thresholds (-e / -i / -t), -d 0 .. 9, sparse and dense coverage; every case also checks the compacted accepted list against the
+accepted reads of the full result, and every fourth runs with L2R_SEG_MAX=0 (the scans in launches of their own).  tools/fuzz_parity.py [rounds] [seed]; prints the first differing case and
 exits 1.  Not part of the product."""
 import os
 import sys
@@ -21,13 +22,24 @@ for it in range(rounds):
     ont = bool(rng.random() < 0.2)
     seed = int(rng.integers(1, 1 << 30))
     level = int(rng.integers(0, 6))
-    prm = dict(full_level=level, min_exon=int(rng.choice([3, 3, 3, 0, 1, 25])), min_intron=int(rng.choice([3, 3, 40])), max_delet=int(rng.choice([50, 50, 4])))
+    prm = dict(full_level=level, min_exon=int(rng.choice([3, 3, 3, 0, 1, 25])), min_intron=int(rng.choice([3, 3, 40])), max_delet=int(rng.choice([50, 50, 4])),
+               ss_dis=int(rng.choice([0, 0, 1, 2, 5, 9])))
+    if it % 4 == 3:
+        os.environ["L2R_SEG_MAX"] = "0"
+    else:
+        os.environ.pop("L2R_SEG_MAX", None)
     anno = synth.make_annotation(anno_exons, seed, mean_tx_exons=n_ex + 1, tx_per_gene=tpg)
     af = anno.in_file_order()
     reads = synth.make_reads(anno, n_reads, n_ex, seed + 7, ont=ont, micro_exons=3 if ont else 0, xs_conflict_frac=0.02 if ont else 0.0)
     e = capi.Engine(0)
     e.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
     got = e.classify(reads, capi.default_params(**prm))
+    acc = e.download_accepted()
+    idx = np.nonzero((got.info & 128) != 0)[0]
+    lens = (got.info[idx] >> 8).astype(np.int64)
+    gidx = synth._ragged_gather_index(got.ex_off[idx], lens)
+    acc_ok = (np.array_equal(acc.read_index, idx) and np.array_equal(np.diff(acc.ex_off), lens) and np.array_equal(acc.ex_start, got.ex_start[gidx])
+              and np.array_equal(acc.ex_end, got.ex_end[gidx]) and np.array_equal(acc.ex_flag, got.ex_flag[gidx]))
     cnt = None
     try:
         import ctypes as C
@@ -41,7 +53,7 @@ for it in range(rounds):
     e.close()
     want = po.classify_soa(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, af.tx_tid, af.tx_start, af.tx_end, af.tx_rev,
                            af.tx_ex_off, af.ex_start, af.ex_end, params=po.default_params(**prm))
-    diffs = {}
+    diffs = {} if acc_ok else {"accepted_list": 1}
     for name in ("ex_off", "ex_start", "ex_end", "ex_flag", "ref_tx"):
         a, b = getattr(got, name), getattr(want, name)
         if len(a) != len(b) or np.any(a != b):
