@@ -732,7 +732,9 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             }
         }
         const double est = cuts / (double)sample + 1.0;
-        while (rpt > 32 && est * rpt * 1.25 > (double)LDS_EXON_CAP) rpt >>= 1;
+        // (long CIGARs on the slab pipeline: the probe kernels stage SLAB_POS_CAP positions per tile)
+        const bool slab_long = c->want_pipeline > 0 && sorted && (double)r->n_cigar / (double)N > 32.0 && !getenv("L2R_NO_SLAB_LONG");
+        while (rpt > 32 && est * rpt * 1.25 > (double)(slab_long ? SLAB_POS_CAP : LDS_EXON_CAP)) rpt >>= 1;
         // ... and keep the genomic span of a tile inside the staged bucket directory (DIR_CAP buckets of 512 bp):
         // sparse input (few reads per locus) makes 256 consecutive reads span many genes, and a tile that does not
         // fit goes to the generic kernel read by read (~30x the cost).  Sample windows of the sorted input, take for
@@ -778,6 +780,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     tile_first.reserve((size_t)(N / rpt + 64));
     // (slab pipeline: a tile's exons are staged by position in LDS on their way out, l2r_slab.hip.h SLAB_POS_CAP: a tile also ends
     //  where the exon bounds of its reads -- from the CIGAR lengths -- would exceed that, so no read of it is left outside)
+    const bool slab_long_tiles = c->want_pipeline > 0 && sorted && c->wide_cigar && !getenv("L2R_NO_SLAB_LONG");      // (k_walk_slab_long: tiles of rpt reads, cut by span like the slab's)
     const bool slab_tiles = c->want_pipeline > 0 && sorted && !c->wide_cigar;
     uint64_t pos_sum = 0;
     for (int64_t i = 0, start = 0; i <= N; ++i) {
@@ -787,7 +790,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         //  first base, and any tile's dictionary slices cover 196 kb -- sparse stretches give small tiles instead of tiles for the
         //  generic kernel; the classic pipeline, whose tiles own 24 KB of hand-over buffer each, keeps at least 8 reads per tile)
         if (i - start == rpt || (sorted && r->tid[i] != r->tid[start]) || (i > start && pos_sum + need > (uint64_t)SLAB_POS_CAP) ||
-            (sorted && i > start && (int64_t)r->pos[i] - (int64_t)r->pos[start] >= (int64_t)SLAB_TILE_SPAN && (slab_tiles || i - start >= 8))) { tile_first.push_back((uint32_t)start); start = i; pos_sum = 0; }
+            (sorted && i > start && (int64_t)r->pos[i] - (int64_t)r->pos[start] >= (int64_t)SLAB_TILE_SPAN && (slab_tiles || slab_long_tiles || i - start >= 8))) { tile_first.push_back((uint32_t)start); start = i; pos_sum = 0; }
         pos_sum += need;
     }
     c->n_tiles = (int64_t)tile_first.size();
@@ -830,7 +833,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb) || (c->wide_cigar && c->walked.ensure((size_t)(c->n_tiles + 1) * LDS_EXON_CAP))) return -2;
     c->ex_cap = (int64_t)exb;
     c->slab_ok = false; c->slab = false;
-    if (c->want_pipeline > 0 && sorted && !c->wide_cigar) {
+    if (c->want_pipeline > 0 && sorted && (!c->wide_cigar || !getenv("L2R_NO_SLAB_LONG"))) {
         // the slab layout (l2r_slab.hip.h): per tile as many rows of 256 elements as its longest read can have exons (bound from
         // the CIGAR lengths); reads beyond SLAB_ROWS rows are outliers and get a run of the dense area
         const size_t T = (size_t)c->n_tiles;
@@ -838,6 +841,11 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         uint64_t total = 0, ovf = 0;
         for (size_t t = 0; t < T; ++t) {
             uint32_t m = 1;
+            if (c->wide_cigar) {
+                // long CIGARs (k_walk_slab_long): the CIGAR length says nothing about the exons -- every tile has SLAB_ROWS rows, and
+                // the dense area has room for every exon of the shard (exb: reads + the operations that can cut)
+                m = (uint32_t)SLAB_ROWS;
+            } else
             for (uint32_t i = tile_first[t]; i < tile_first[t + 1]; ++i) {
                 const uint64_t cc = (uint64_t)(r->cig_off[i + 1] - r->cig_off[i]);
                 const uint64_t rw = (cc + 3u) >> 1;
@@ -849,6 +857,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             sbase[t] = (uint32_t)total; total += (uint64_t)m * SLAB_STRIDE;
             if (total >= 0x7ffffff0ULL || ovf >= 0x7ffffff0ULL) break;
         }
+        if (c->wide_cigar) ovf = (uint64_t)exb;
         if (total < 0x7ffffff0ULL && ovf < 0x7ffffff0ULL) {
             sbase[T] = (uint32_t)total;                     // (rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true;
@@ -999,7 +1008,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     unsigned gp = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * c->wg_per_cu);
     if (c->fast_grid > 0) gp = (unsigned)std::min<int64_t>(gp, c->fast_grid);           // L2R_FAST_GRID: tests force many tiles per workgroup
     // the slab pipeline wants the straight-line walk: thresholds that fit a CIGAR word (else: the classic kernels)
-    c->slab = c->slab_ok && p.min_intron >= 0 && p.min_intron < (1 << 28) && p.max_delet >= -1 && p.max_delet < (1 << 28) - 1;
+    c->slab = c->slab_ok && p.min_intron >= 0 && p.min_intron < (1 << 28) && p.max_delet >= -1 && p.max_delet < (1 << 28) - 1 &&
+              (!c->wide_cigar || p.min_exon >= 1);           // (k_walk_slab_long has no -e < 1 form: the classic kernels take that)
     if (c->slab) {
         // ---- two light kernels at full occupancy: the walk (exons into the tiles' slabs, read-order places, descriptors), a scan of
         //      the tiles' exon counts, then the probes, which write the read-order results (l2r_slab.hip.h).  Every launch does all
@@ -1014,7 +1024,9 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p;
         sa.chunk_on = (c->ablate & 32) ? 0u : 1u;          // (L2R_ABLATE bit 2: no 64-member windows, bit 5: no chunked windows)
         sa.wide_list = c->wide_list.p; sa.chunk_list = c->chunk_list.p; sa.list_cnt = c->list_cnt.p; sa.tile_flags = c->tile_flags.p;
-        if (p.min_exon >= 1)
+        if (c->wide_cigar)
+            hipLaunchKernelGGL(k_walk_slab_long, dim3(gx), dim3(TILE_THREADS), pass_a_dynamic_lds(c->reads_per_tile), s, sa, (const TileRec *)c->tile_rec.p);
+        else if (p.min_exon >= 1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_slab<false>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const TileRec *)c->tile_rec.p);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_slab<true>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const TileRec *)c->tile_rec.p);

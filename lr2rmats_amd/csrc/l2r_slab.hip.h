@@ -323,6 +323,200 @@ void k_walk_slab(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------- k_walk_slab_long
+// k_walk_slab for LONG CIGARs (ONT-like input: hundreds of operations per read; min_exon >= 1): the same outputs -- slab rows, the
+// reads' words, the tile's span record and exon count -- so that k_describe_scan and the probe kernels behind it do not know the
+// difference, with the walk of k_pass_a<true>: ONE WAVE walks one read at a time as a scan over its op stream (wave_chunk_walk:
+// eight words per lane and round, reference ends by prefix sum, exon starts by prefix maximum, kept cuts by ballot), the first round
+// of the wave's next read in flight meanwhile.  A read's first WALK_SLAB exons wait in an exon-major LDS slab, later ones in a list;
+// when every read of the tile has been walked, the reads get their slots (by falling exon count: counting sort) and their columns go
+// to the tile's slab with whole rows.  No per-read cursor value, no window here (k_pass_a makes both): the tile's descriptor is
+// k_describe_scan's.  Tiles are `reads_per_tile` reads (128 for ONT-like input: the upload cannot bound a read's exons by its CIGAR
+// length); a tile's slab has SLAB_ROWS rows.
+__global__ __launch_bounds__(TILE_THREADS, 8)
+void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
+{
+    __shared__ uint32_t s_hist[WAVE];
+    // per read, three words (8 workgroups per CU: 18.7 KB with the dynamic part): going into the walk {first CIGAR word, ops, pos}, coming out
+    // {., exon count | flags << 16, read end}; behind the walk s_ra holds the exon counts in read order and s_rc their exclusive scan
+    __shared__ __attribute__((aligned(16))) uint32_t s_ra[TILE_THREADS], s_rb[TILE_THREADS], s_rc[TILE_THREADS];
+    __shared__ uint8_t s_slot[TILE_THREADS];                                     // read -> slot
+    __shared__ uint8_t s_nslot[TILE_THREADS];                                    // slot -> exon count of a slab read (0: outlier / none)
+    __shared__ int s_wmax[TILE_THREADS / WAVE];
+    __shared__ uint32_t s_wn[TILE_THREADS / WAVE], s_nmax[TILE_THREADS / WAVE];
+    __shared__ uint32_t s_ovf_n;
+    uint32_t *const s_cnt = s_ra, *const s_loc = s_rc;
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+    (void)kernarg_block;
+    const SlabArgsK sa = slab_args();
+    const PipeArgsK a = pipe_args();
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
+    if (t >= sa->n_tiles) return;
+    const TileRec rec = u_rec[t];
+    asm volatile("" :: "s"(rec.r0), "s"(rec.n_act), "s"(rec.sbase), "s"(rec.rows), "s"(rec.tid0), "s"(rec.lo));
+    const uint32_t r0 = rec.r0, n_act = rec.n_act;
+    const int32_t tid0 = rec.tid0, pos0 = rec.lo - 1;
+    const uint32_t sbase = rec.sbase, rows_tile = rec.rows;
+    DevParams p;
+    p.min_exon = a->f.p.min_exon; p.min_intron = a->f.p.min_intron; p.max_delet = a->f.p.max_delet;
+    const int slab_w = a->f.p.reads_per_tile;                                    // reads per exon row of the LDS slab
+    int32_t *const s_slab_s = reinterpret_cast<int32_t *>(s_dyn);            // exon-major: start ...
+    int *const s_ovf = s_slab_s + WALK_SLAB * slab_w;                        // exons beyond the slab: {read | k << 8, start, end}
+    uint16_t *const s_slab_l = reinterpret_cast<uint16_t *>(s_ovf + 3 * WALK_OVF);      // ... and length
+    const bool active = threadIdx.x < n_act;
+    const uint32_t r = r0 + threadIdx.x;
+    uint32_t c_lo = 0u, rev = 0u; int32_t pos = 0;
+    if (active) {
+        const uint32_t *const p_off = sa->cig_off32;
+        c_lo = ld32(p_off, r); const uint32_t c = ld32(p_off, r + 1u) - c_lo;
+        pos = ld32(a->f.r_pos, r); rev = ld32(a->f.r_rev, r) ? 1u : 0u;
+        s_ra[threadIdx.x] = c_lo; s_rb[threadIdx.x] = min(c, 0x7fffffffu); s_rc[threadIdx.x] = (uint32_t)pos;
+    }
+    if (threadIdx.x == 0) s_ovf_n = 0u;
+    if (threadIdx.x < (uint32_t)WAVE) s_hist[threadIdx.x] = 0u;
+    // the head of the tile descriptor's load chain, by one wave, while the first chunks are on their way (see k_walk_slab)
+    if (wv == TILE_THREADS / WAVE - 1 && n_act) {
+        CursorDir cd;
+        cd.key = a->cd.key; cd.dir = a->cd.dir; cd.kb_base = a->cd.kb_base; cd.n_tid = a->cd.n_tid; cd.n_tx = a->cd.n_tx;
+        const int jl = cursor_value(cd, tid0, pos0 + 1);
+        int tb = 0, nb = 0;
+        if (tid0 >= 0 && tid0 < a->n_tid_dir) { tb = a->tid_base[tid0]; nb = a->tid_base[tid0 + 1] - tb; }
+        if (lane == 0) reinterpret_cast<int4 *>(sa->span + t)[1] = make_int4(jl, tb, nb, 0);
+    }
+    __syncthreads();
+    const int32_t base = pos0 + 1;                           // the tile's first base (sorted records: the first read's)
+    {   // ---- the walk: the reads of the tile are dealt to the four waves
+        const uint32_t *const cig = a->f.cig;
+        constexpr uint32_t ROUND = (uint32_t)(WCHUNK * WAVE);
+        uint32_t q = (uint32_t)wv;
+        auto meta_of = [&](uint32_t qq) { return qq < n_act ? make_int4((int)s_ra[qq], (int)s_rb[qq], (int)s_rc[qq], 0) : make_int4(0, 0, 0, 0); };
+        int4 meta = meta_of(q);
+        WaveChunk cur = wave_chunk_load(cig + (uint32_t)meta.x, q < n_act ? (uint32_t)meta.y : 0u, 0u, lane);
+        for (; q < n_act; q += TILE_THREADS / WAVE) {
+            // the first round of the wave's next read is asked for before this read is walked
+            const uint32_t qn = q + TILE_THREADS / WAVE;
+            const int4 meta_n = meta_of(qn);
+            const WaveChunk nxt = wave_chunk_load(cig + (uint32_t)meta_n.x, qn < n_act ? (uint32_t)meta_n.y : 0u, 0u, lane);
+            const uint32_t *const words = cig + (uint32_t)meta.x;
+            const uint32_t n_cig = (uint32_t)meta.y;
+            bool bad = false;                            // the read cannot live in the slab: an exon the row word cannot say, the list full
+            bool insane = false;                         // its first or last exon is empty
+            auto emit = [&](int k, int s_, int e_) {
+                const uint32_t len = (uint32_t)(e_ - s_ + 1);
+                bad = bad | (len > SLAB_LEN_MAX && s_ <= e_);
+                if (k == 0) insane = insane | (s_ > e_);
+                if (k < WALK_SLAB) { s_slab_s[k * slab_w + (int)q] = s_; s_slab_l[k * slab_w + (int)q] = (uint16_t)len; }
+                else {
+                    const uint32_t at = atomicAdd(&s_ovf_n, 1u);
+                    if (at < (uint32_t)WALK_OVF) { s_ovf[3 * at] = (int)q | (k << 8); s_ovf[3 * at + 1] = s_; s_ovf[3 * at + 2] = e_; }
+                    else bad = true;
+                }
+            };
+            WaveWalk st{meta.z, meta.z + 1, 0u, false};
+            wave_chunk_walk(st, cur, n_cig, 0u, p, lane, emit);
+            for (uint32_t b_ = ROUND; b_ < n_cig; b_ += ROUND) {                 // (reads beyond 512 ops: round by round)
+                const WaveChunk more = wave_chunk_load(words, n_cig, b_, lane);
+                wave_chunk_walk(st, more, n_cig, b_, p, lane, emit);
+            }
+            if (lane == 0) {
+                emit((int)st.n_kept, st.cur_start, st.ref_end);
+                insane = insane | (st.cur_start > st.ref_end);
+                // (starts rise along the read: the last one is the furthest from the tile's base)
+                bad = bad | ((uint32_t)(st.cur_start - base) >= SLAB_REL_MASK) | (st.n_kept + 1u > rows_tile);
+            }
+            const bool bad_any = __any(bad), insane_any = __any(insane);
+            // (the read's own words are not read again before the barrier: this wave was their only reader)
+            if (lane == 0) { s_rb[q] = (st.n_kept + 1u) | ((bad_any ? 1u : 0u) << 16) | ((insane_any ? 2u : 0u) << 16); s_rc[q] = (uint32_t)st.ref_end; }
+            meta = meta_n; cur = nxt;
+        }
+    }
+    __syncthreads();
+    uint32_t n = 0u; int el = INT32_MIN; bool outlier = false, sane = true;
+    if (active) { const uint32_t v = s_rb[threadIdx.x]; n = v & 0xffffu; el = (int)s_rc[threadIdx.x]; outlier = ((v >> 16) & 1u) != 0u; sane = ((v >> 16) & 2u) == 0u; }
+    uint32_t dense_run = 0u;
+    if (active && outlier) {
+        // an outlier: the literal walk by this lane alone into a run of the dense area (as in k_walk_slab; such reads are rare)
+        const uint32_t n_ops = ld32(sa->cig_off32, r + 1u) - c_lo;
+        const uint32_t *const words = a->f.cig + c_lo;
+        {   WalkState w{pos + 1, pos, 0};
+            auto none = [&](int, int, int) {};
+            walk_ops<true>(w, words, 0, (int)n_ops, p, none);
+            n = (uint32_t)w.n + 1u; }
+        dense_run = (uint32_t)atomicAdd(sa->ovf_cursor, (unsigned long long)n);
+        int32_t *const ds = sa->dense_start, *const de = sa->dense_end;
+        WalkState w{pos + 1, pos, 0};
+        sane = true;
+        auto put = [&](int k, int s_, int e_) { ds[dense_run + (uint32_t)k] = s_; de[dense_run + (uint32_t)k] = e_; sane = sane & (s_ <= e_); el = e_; };
+        walk_ops<true>(w, words, 0, (int)n_ops, p, put);
+        put(w.n, w.start, w.end);
+    }
+    // ---- slots: the tile's reads by falling exon count (outliers and threads without a read last)
+    const uint32_t key = (active && !outlier) ? min(n, (uint32_t)(WAVE - 2)) + 1u : (active ? 1u : 0u);
+    const uint32_t bin = (uint32_t)(WAVE - 1) - key;
+    const uint32_t rank = atomicAdd(&s_hist[bin], 1u);
+    s_cnt[threadIdx.x] = active ? n : 0u;
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)WAVE) { const uint32_t c = s_hist[threadIdx.x]; s_hist[threadIdx.x] = wave_inclusive_scan(c) - c; }
+    __syncthreads();
+    const uint32_t slot = s_hist[bin] + rank;
+    s_slot[threadIdx.x] = (uint8_t)slot;
+    s_nslot[slot] = (uint8_t)((active && !outlier) ? n : 0u);
+    {   const int m = wave_max(active ? el : INT32_MIN);
+        const int wn_all = wave_max(active ? (int)min(n, 0x7fffffffu) : 0);
+        if (lane == 0) { s_wmax[wv] = m; s_nmax[wv] = (uint32_t)wn_all; } }
+    if (t == 0u && threadIdx.x == 0) {
+        uint32_t *const cnt = a->f.redo_count;
+        cnt[0] = 0u; cnt[1] = 0u; cnt[2] = 0u;
+        uint32_t *const lc = sa->list_cnt;
+        lc[0] = 0u; lc[1] = 0u; lc[2] = 0u; lc[3] = 0u;
+    }
+    __syncthreads();
+    {   const int wn = wave_max((int)s_nslot[threadIdx.x]);            // (thread = slot here: the rows each wave of the probe kernels has to look at)
+        if (lane == 0) s_wn[wv] = (uint32_t)min(wn, 255); }
+    uint32_t total;
+    {
+        const uint4 c4 = reinterpret_cast<const uint4 *>(s_cnt)[lane];
+        const uint32_t sum = c4.x + c4.y + c4.z + c4.w;
+        const uint32_t inc = wave_inclusive_scan(sum), ex = inc - sum;
+        reinterpret_cast<uint4 *>(s_loc)[lane] = make_uint4(ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z);     // (the four waves write the same values)
+        total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+    }
+    // ---- the read's column: exon k to row k + 1 of its slot, the last one to row 0 (threads of a wave: neighbouring reads, slots all
+    //      over the tile's 256 -- every row store of the wave still lands in the row's 1 KB)
+    uint32_t *const rows = sa->slab_row;
+    const uint32_t off = sbase + slot;
+    if (active && !outlier) {
+        const int n_slab = min((int)n, WALK_SLAB);
+        for (int k = 0; k < n_slab; ++k) {
+            const int s0 = s_slab_s[k * slab_w + (int)threadIdx.x];
+            st32(rows, off + slab_row((uint32_t)k, n) * SLAB_STRIDE, slab_pack(s0 - base, (uint32_t)s_slab_l[k * slab_w + (int)threadIdx.x]));
+        }
+    } else if (active) st32(rows, off, dense_run);            // (row 0 of the unused column: where the probe side finds the run)
+    {   const uint32_t n_ovf = min(s_ovf_n, (uint32_t)WALK_OVF);
+        for (uint32_t i = threadIdx.x; i < n_ovf; i += TILE_THREADS) {
+            const uint32_t who = (uint32_t)s_ovf[3 * i] & 0xffu, k = (uint32_t)s_ovf[3 * i] >> 8;
+            const uint32_t v = s_rb[who];
+            if ((v >> 16) & 1u) continue;                     // (an outlier's exons are in the dense area)
+            st32(rows, sbase + (uint32_t)s_slot[who] + slab_row(k, v & 0xffffu) * SLAB_STRIDE, slab_pack(s_ovf[3 * i + 1] - base, (uint32_t)(s_ovf[3 * i + 2] - s_ovf[3 * i + 1] + 1)));
+        }
+    }
+    const bool fat = total >= PL_LOC_LIMIT || max(max(s_nmax[0], s_nmax[1]), max(s_nmax[2], s_nmax[3])) >= PL_N_LIMIT;
+    if (active) {
+        const uint32_t at = r0 + slot;
+        const uint32_t word = threadIdx.x | (rev ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (outlier ? PRE_DENSE : 0u) | (n << PRE_N_SHIFT);
+        if (!fat) sa->pl[at] = word | (s_loc[threadIdx.x] << PL_LOC_SHIFT);
+        else { sa->pl[at] = 0u; sa->pre_x[at] = word; sa->loc_x[at] = s_loc[threadIdx.x]; }
+    }
+    if (threadIdx.x == 0) {
+        a->tile_total[t] = total;
+        const int32_t tile_hi = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+        const uint32_t rw = s_wn[0] | (s_wn[1] << 8) | (s_wn[2] << 16) | (s_wn[3] << 24);
+        reinterpret_cast<int4 *>(sa->span + t)[0] = make_int4(tid0, pos0 + 1, tile_hi, (int)rw);
+        reinterpret_cast<int4 *>(sa->span + t)[2] = make_int4((int)r0, (int)n_act, (int)sbase, fat ? 1 : 0);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------- k_describe_scan
 // The launch between the walk and the probes, 256-thread workgroups in two roles.
 //   Workgroups [0, n_scan): the exclusive scan of the tiles' exon counts (every tile's first slot in the read-order result arrays), a
