@@ -152,13 +152,14 @@ typedef struct {
 
 /* Average device time per kernel of the last l2r_run_timed(), milliseconds.  Stages 0..2 are the three kernels of the
  * pipeline the engine chose for the uploaded records (l2r_stage_kernel() names them):
- *     slab    (coordinate-sorted records, short CIGARs; default)  0 k_walk_slab (the tile's reads by CIGAR length, CIGAR -> exons,
+ *     slab    (coordinate-sorted records; default)  0 k_walk_slab (the tile's reads by CIGAR length, CIGAR -> exons; long CIGARs:
+ *             k_walk_slab_long, one wave per read as a scan over the op stream,
  *             read-order places)  1 k_describe_scan (the tiles' descriptors and windows, one wave per tile; the tiles' exon counts -> their
  *             first result slots; the tile lists of the wide / chunked kernels)  2 k_probe_slab
  *             (annotation window, site probes, verdicts, read-order results) + k_probe_slab_wide (tiles whose window holds 33 .. 63
  *             transcripts) + k_probe_slab_chunked (tiles beyond that, or with a dictionary key in several entries: the window 63
  *             members at a time).  Every run launches all of them: nothing is kept from an earlier run of the same records.
- *     classic (unsorted records, long CIGARs, L2R_PIPELINE=classic)  0 k_pass_a  1 k_scan_u32 (tile sums)  2 k_classify_fast */
+ *     classic (unsorted records, long CIGARs with -e < 1, L2R_PIPELINE=classic)  0 k_pass_a  1 k_scan_u32 (tile sums)  2 k_classify_fast */
 #define L2R_N_STAGES 8
 typedef struct {
     float stage_ms[L2R_N_STAGES];   /* 0..2 see above  3 classify_generic (redo list) 4 validate_junctions (+ recount)
