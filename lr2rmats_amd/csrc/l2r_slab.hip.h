@@ -401,11 +401,9 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
             const uint32_t *const words = cig + (uint32_t)meta.x;
             const uint32_t n_cig = (uint32_t)meta.y;
             bool bad = false;                            // the read cannot live in the slab: an exon the row word cannot say, the list full
-            bool insane = false;                         // its first or last exon is empty
             auto emit = [&](int k, int s_, int e_) {
-                const uint32_t len = (uint32_t)(e_ - s_ + 1);
-                bad = bad | (len > SLAB_LEN_MAX && s_ <= e_);
-                if (k == 0) insane = insane | (s_ > e_);
+                const uint32_t len = (uint32_t)(e_ - s_ + 1);            // (0: an empty exon -- start = end + 1, never further apart)
+                bad = bad | (len > SLAB_LEN_MAX);
                 if (k < WALK_SLAB) { s_slab_s[k * slab_w + (int)q] = s_; s_slab_l[k * slab_w + (int)q] = (uint16_t)len; }
                 else {
                     const uint32_t at = atomicAdd(&s_ovf_n, 1u);
@@ -419,9 +417,10 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
                 const WaveChunk more = wave_chunk_load(words, n_cig, b_, lane);
                 wave_chunk_walk(st, more, n_cig, b_, p, lane, emit);
             }
+            bool insane = false;                         // the read's last exon is empty (its first one: looked at in the slab, below)
             if (lane == 0) {
                 emit((int)st.n_kept, st.cur_start, st.ref_end);
-                insane = insane | (st.cur_start > st.ref_end);
+                insane = st.cur_start > st.ref_end;
                 // (starts rise along the read: the last one is the furthest from the tile's base)
                 bad = bad | ((uint32_t)(st.cur_start - base) >= SLAB_REL_MASK) | (st.n_kept + 1u > rows_tile);
             }
@@ -433,7 +432,11 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
     }
     __syncthreads();
     uint32_t n = 0u; int el = INT32_MIN; bool outlier = false, sane = true;
-    if (active) { const uint32_t v = s_rb[threadIdx.x]; n = v & 0xffffu; el = (int)s_rc[threadIdx.x]; outlier = ((v >> 16) & 1u) != 0u; sane = ((v >> 16) & 2u) == 0u; }
+    if (active) {
+        const uint32_t v = s_rb[threadIdx.x]; n = v & 0xffffu; el = (int)s_rc[threadIdx.x]; outlier = ((v >> 16) & 1u) != 0u;
+        // first and last exon not empty (with min_exon >= 1 the kept inner ones never are): the first one's length waits in the slab's row 0
+        sane = ((v >> 16) & 2u) == 0u && s_slab_l[threadIdx.x] != 0;
+    }
     uint32_t dense_run = 0u;
     if (active && outlier) {
         // an outlier: the literal walk by this lane alone into a run of the dense area (as in k_walk_slab; such reads are rare)
