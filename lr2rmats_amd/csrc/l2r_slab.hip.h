@@ -401,11 +401,13 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
             const uint32_t *const words = cig + (uint32_t)meta.x;
             const uint32_t n_cig = (uint32_t)meta.y;
             bool bad = false;                            // the read cannot live in the slab: an exon the row word cannot say, the list full
+            // (inlined nine times into an issue-bound walk: every instruction here is paid nine times per read.  The slab keeps a length
+            //  saturated to 16 bits; whether it fits the row word is looked at once per read behind the walk.)
             auto emit = [&](int k, int s_, int e_) {
                 const uint32_t len = (uint32_t)(e_ - s_ + 1);            // (0: an empty exon -- start = end + 1, never further apart)
-                bad = bad | (len > SLAB_LEN_MAX);
-                if (k < WALK_SLAB) { s_slab_s[k * slab_w + (int)q] = s_; s_slab_l[k * slab_w + (int)q] = (uint16_t)len; }
+                if (k < WALK_SLAB) { s_slab_s[k * slab_w + (int)q] = s_; s_slab_l[k * slab_w + (int)q] = (uint16_t)min(len, 0xffffu); }
                 else {
+                    bad = bad | (len > SLAB_LEN_MAX);
                     const uint32_t at = atomicAdd(&s_ovf_n, 1u);
                     if (at < (uint32_t)WALK_OVF) { s_ovf[3 * at] = (int)q | (k << 8); s_ovf[3 * at + 1] = s_; s_ovf[3 * at + 2] = e_; }
                     else bad = true;
@@ -436,6 +438,11 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
         const uint32_t v = s_rb[threadIdx.x]; n = v & 0xffffu; el = (int)s_rc[threadIdx.x]; outlier = ((v >> 16) & 1u) != 0u;
         // first and last exon not empty (with min_exon >= 1 the kept inner ones never are): the first one's length waits in the slab's row 0
         sane = ((v >> 16) & 2u) == 0u && s_slab_l[threadIdx.x] != 0;
+        // an exon of 16 kb or more does not fit the row word: an outlier (the exons behind the LDS slab's rows were tested as they came)
+        const int n_chk = min((int)n, WALK_SLAB);
+        uint32_t longest = 0u;
+        for (int k = 0; k < n_chk; ++k) longest = max(longest, (uint32_t)s_slab_l[k * slab_w + (int)threadIdx.x]);
+        outlier = outlier || longest > SLAB_LEN_MAX;
     }
     uint32_t dense_run = 0u;
     if (active && outlier) {
