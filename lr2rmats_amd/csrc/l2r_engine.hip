@@ -69,6 +69,7 @@ struct l2r_ctx {
     int ablate = 0;                         // diagnostics, L2R_ABLATE (read once, at l2r_create)
     int64_t seg_max = SEG_MAX;              // tiles up to which the segmented scans are used (l2r_kernels.hip.h); L2R_SEG_MAX
     int want_pipeline = 1;                  // L2R_PIPELINE: classic (0: l2r_kernels.hip.h, two walks), slab (1, default: l2r_slab.hip.h, one walk)
+    bool many_exon_reads = false;           // the upload's sample: more than 0.5 % of the reads have more exons than a slab has rows
     bool slab_ok = false;                   // the current upload can run the slab pipeline: coordinate-sorted records, short CIGARs, its slab layout fits
     bool slab = false;                      // ... and the last launch did (the parameters have a say: launch_all)
     DevBuf<uint32_t> tile_sbase, s_pre, s_loc, s_pl, cig_off32, tile_rec, tile_total, tile_xbase, tile_span;    // (tile_span: 16-byte TileSpan records, l2r_slab.hip.h)
@@ -720,20 +721,27 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     // tile size: keep the expected exons of a tile inside the LDS staging area.
     // Estimate exons/read from a sample of the CIGARs (ops that can start an exon).
     int rpt = TILE_THREADS;
+    c->many_exon_reads = false;
     if (N) {
         const int64_t sample = N < 4096 ? N : 4096;
         const int64_t step = N / sample;
         double cuts = 0;
+        int64_t many = 0;                                  // sampled reads with more exons than a slab has rows
         for (int64_t s = 0; s < sample; ++s) {
             const int64_t i = s * step;
+            int64_t mine = 0;
             for (int64_t k = r->cig_off[i]; k < r->cig_off[i + 1]; ++k) {
                 const uint32_t op = r->cig[k] & 15u; const int len = (int)(r->cig[k] >> 4);
-                cuts += (op == 3u && len >= c->prm.min_intron) || (op == 2u && len > c->prm.max_delet);
+                mine += (op == 3u && len >= c->prm.min_intron) || (op == 2u && len > c->prm.max_delet);
             }
+            cuts += (double)mine; many += mine + 1 > (int64_t)SLAB_ROWS;
         }
+        // (k_walk_slab_long hands a read beyond SLAB_ROWS exons to the generic kernel, the classic kernels keep it on the mask path: an
+        //  input where such reads are more than a rarity stays with them)
+        c->many_exon_reads = many * 200 > sample;
         const double est = cuts / (double)sample + 1.0;
         // (long CIGARs on the slab pipeline: the probe kernels stage SLAB_POS_CAP positions per tile)
-        const bool slab_long = c->want_pipeline > 0 && sorted && (double)r->n_cigar / (double)N > 32.0 && !getenv("L2R_NO_SLAB_LONG");
+        const bool slab_long = c->want_pipeline > 0 && sorted && (double)r->n_cigar / (double)N > 32.0 && !getenv("L2R_NO_SLAB_LONG") && !c->many_exon_reads;
         while (rpt > 32 && est * rpt * 1.25 > (double)(slab_long ? SLAB_POS_CAP : LDS_EXON_CAP)) rpt >>= 1;
         // ... and keep the genomic span of a tile inside the staged bucket directory (DIR_CAP buckets of 512 bp):
         // sparse input (few reads per locus) makes 256 consecutive reads span many genes, and a tile that does not
@@ -780,7 +788,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
     tile_first.reserve((size_t)(N / rpt + 64));
     // (slab pipeline: a tile's exons are staged by position in LDS on their way out, l2r_slab.hip.h SLAB_POS_CAP: a tile also ends
     //  where the exon bounds of its reads -- from the CIGAR lengths -- would exceed that, so no read of it is left outside)
-    const bool slab_long_tiles = c->want_pipeline > 0 && sorted && c->wide_cigar && !getenv("L2R_NO_SLAB_LONG");      // (k_walk_slab_long: tiles of rpt reads, cut by span like the slab's)
+    const bool slab_long_tiles = c->want_pipeline > 0 && sorted && c->wide_cigar && !getenv("L2R_NO_SLAB_LONG") && !c->many_exon_reads;      // (k_walk_slab_long: tiles of rpt reads, cut by span like the slab's)
     const bool slab_tiles = c->want_pipeline > 0 && sorted && !c->wide_cigar;
     uint64_t pos_sum = 0;
     for (int64_t i = 0, start = 0; i <= N; ++i) {
@@ -833,7 +841,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         c->acc_start.ensure(exb) || c->acc_end.ensure(exb) || c->acc_flag.ensure(exb) || (c->wide_cigar && c->walked.ensure((size_t)(c->n_tiles + 1) * LDS_EXON_CAP))) return -2;
     c->ex_cap = (int64_t)exb;
     c->slab_ok = false; c->slab = false;
-    if (c->want_pipeline > 0 && sorted && (!c->wide_cigar || !getenv("L2R_NO_SLAB_LONG"))) {
+    if (c->want_pipeline > 0 && sorted && (!c->wide_cigar || (!getenv("L2R_NO_SLAB_LONG") && !c->many_exon_reads))) {
         // the slab layout (l2r_slab.hip.h): per tile as many rows of 256 elements as its longest read can have exons (bound from
         // the CIGAR lengths); reads beyond SLAB_ROWS rows are outliers and get a run of the dense area
         const size_t T = (size_t)c->n_tiles;

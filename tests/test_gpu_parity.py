@@ -68,6 +68,14 @@ def test_cigar_thresholds_ont(engine, oracle, opts):
     anno, af, reads = util.make_case(13, n_reads=8000, n_exons=6, anno_exons=15000, ont=True, micro=3, xs=0.02)
     _set_anno(engine, af)
     _check(engine, oracle, af, reads, oracle.default_params(full_level=3, **opts))
+    # whichever pipeline the upload chose (-t 3 cuts these reads into dozens of exons: more than a slab has rows, so long-CIGAR input
+    # of that kind stays with the classic kernels): the generic kernel is left with next to nothing
+    import ctypes as C
+    lib = capi.load_library()
+    cnt = (C.c_longlong * 13)()
+    lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.l2r_debug_counters(engine.ctx, cnt, 13)
+    assert cnt[0] <= reads.n // 50, list(cnt)
 
 
 def test_unsorted_gtf_and_long_transcripts(engine, oracle):
