@@ -1393,6 +1393,9 @@ __device__ __forceinline__ VisitMasks visit_window(const TileLds &L, const TileD
                                                    const ReadEnds &re, const uint32_t *tilemask)
 {
     VisitMasks m{0u, 0u, 0u, 0u, false};
+    // (a wave without a read to classify -- the upper waves of a tile of few reads -- has nothing to visit: the pass below would
+    //  still cost it a dozen instructions per member)
+    if (!__any(work)) return m;
     uint32_t m_aft = 0u, m_bef = 0u;
     for (int j = 0; j < w_n; ++j) {
         const int4 hk = L.hk[j];
