@@ -269,30 +269,40 @@ constexpr int WCHUNK = 8;                                // CIGAR words per lane
 struct WaveChunk { uint32_t w[WCHUNK]; };
 struct WaveWalk { int ref_end, cur_start; uint32_t n_kept; bool seen_cut; };    // (wave-uniform carries of one read)
 
-// words [base + 8 lane, + 8) of a read's CIGAR (the array is padded by 8 words: a lane that starts inside the read reads on)
-__device__ __forceinline__ WaveChunk wave_chunk_load(const uint32_t *__restrict__ cig, uint32_t n_cig, uint32_t base, int lane)
+// A read's CIGAR as a buffer of its own (the four descriptor words are wave-uniform: one wave walks one read): a word behind the
+// read's last op is outside the buffer and the hardware's range check loads it as 0 -- "M, length 0", an op that neither advances
+// the reference nor cuts -- so the walk needs neither a branch around the loads nor a mask per word.
+typedef uint32_t v4u_buf __attribute__((ext_vector_type(4)));
+struct CigarWindow { __amdgpu_buffer_rsrc_t rs; };
+__device__ __forceinline__ CigarWindow cigar_window(const uint32_t *__restrict__ cig, uint32_t first_word, uint32_t n_cig)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)first_word);
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(n_cig, 0x3fffffffu));
+    CigarWindow w;
+    w.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(cig + lo), (short)0, (int)(n * 4u), 0x00020000);
+    return w;
+}
+
+// words [base + 8 lane, + 8) of a read's CIGAR
+__device__ __forceinline__ WaveChunk wave_chunk_load(const CigarWindow &cw, uint32_t base, int lane)
 {
     WaveChunk k;
-#pragma unroll
-    for (int j = 0; j < WCHUNK; ++j) k.w[j] = 1u;
-    const uint32_t i0 = base + (uint32_t)WCHUNK * (uint32_t)lane;
-    if (i0 < n_cig) {
-        const v4i_a4 x = *reinterpret_cast<const v4i_a4 *>(cig + i0), y = *reinterpret_cast<const v4i_a4 *>(cig + i0 + 4u);
-        k.w[0] = (uint32_t)x.x; k.w[1] = (uint32_t)x.y; k.w[2] = (uint32_t)x.z; k.w[3] = (uint32_t)x.w;
-        k.w[4] = (uint32_t)y.x; k.w[5] = (uint32_t)y.y; k.w[6] = (uint32_t)y.z; k.w[7] = (uint32_t)y.w;
-    }
+    const int voff = WCHUNK * 4 * lane;
+    const v4u_buf x = __builtin_amdgcn_raw_buffer_load_b128(cw.rs, voff, (int)(base * 4u), 0);
+    const v4u_buf y = __builtin_amdgcn_raw_buffer_load_b128(cw.rs, voff + 16, (int)(base * 4u), 0);
+    k.w[0] = x.x; k.w[1] = x.y; k.w[2] = x.z; k.w[3] = x.w;
+    k.w[4] = y.x; k.w[5] = y.y; k.w[6] = y.z; k.w[7] = y.w;
     return k;
 }
 
 template <typename Emit>
-__device__ __forceinline__ void wave_chunk_walk(WaveWalk &st, const WaveChunk &ch, uint32_t n_cig, uint32_t base, const DevParams &p, int lane, Emit &emit)
+__device__ __forceinline__ void wave_chunk_walk(WaveWalk &st, const WaveChunk &ch, const DevParams &p, int lane, Emit &emit)
 {
-    const uint32_t i0 = base + (uint32_t)WCHUNK * (uint32_t)lane;
     int a[WCHUNK], len[WCHUNK]; bool c[WCHUNK];
     int A = 0; bool any_c = false;
 #pragma unroll
     for (int j = 0; j < WCHUNK; ++j) {
-        const uint32_t w = i0 + (uint32_t)j < n_cig ? ch.w[j] : 1u;          // behind the read's last op: "I, length 0"
+        const uint32_t w = ch.w[j];                                          // (behind the read's last op: 0, see cigar_window)
         const uint32_t op = w & 0xfu;
         len[j] = (int)(w >> 4);
         a[j] = len[j] & __builtin_amdgcn_sbfe(0x18d, op, 1u);                // ops 0 2 3 7 8 advance the reference
@@ -430,14 +440,15 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
         constexpr uint32_t ROUND = (uint32_t)(WCHUNK * WAVE);
         uint32_t q = (uint32_t)wv;
         int4 meta = q < n_act ? s_rd[q] : make_int4(0, 0, 0, 0);
-        WaveChunk cur = wave_chunk_load(tile_cig + (uint32_t)meta.x, q < n_act ? (uint32_t)meta.y : 0u, 0u, lane);
+        CigarWindow cw = cigar_window(tile_cig, (uint32_t)meta.x, (uint32_t)meta.y);
+        WaveChunk cur = wave_chunk_load(cw, 0u, lane);
         for (; q < n_act; q += TILE_THREADS / WAVE) {
             // the first round of the wave's next read is asked for before this read is walked
             const uint32_t qn = q + TILE_THREADS / WAVE;
             const int4 meta_n = qn < n_act ? s_rd[qn] : make_int4(0, 0, 0, 0);
-            const WaveChunk nxt = wave_chunk_load(tile_cig + (uint32_t)meta_n.x, qn < n_act ? (uint32_t)meta_n.y : 0u, 0u, lane);
-            const uint32_t *const words = tile_cig + (uint32_t)meta.x;
-            const uint32_t n_cig = (uint32_t)meta.y;
+            const CigarWindow cw_n = cigar_window(tile_cig, (uint32_t)meta_n.x, (uint32_t)meta_n.y);
+            const WaveChunk nxt = wave_chunk_load(cw_n, 0u, lane);
+            const uint32_t n_cig = (uint32_t)__builtin_amdgcn_readfirstlane(meta.y);
             bool unw = false;
             auto emit = [&](int k, int s, int e) {
                 const uint32_t len = (uint32_t)(e - s + 1);
@@ -451,16 +462,16 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
                 }
             };
             WaveWalk st{meta.z, meta.z + 1, 0u, false};
-            wave_chunk_walk(st, cur, n_cig, 0u, p, lane, emit);
+            wave_chunk_walk(st, cur, p, lane, emit);
             for (uint32_t base = ROUND; base < n_cig; base += ROUND) {           // (reads beyond 512 ops: round by round)
-                const WaveChunk more = wave_chunk_load(words, n_cig, base, lane);
-                wave_chunk_walk(st, more, n_cig, base, p, lane, emit);
+                const WaveChunk more = wave_chunk_load(cw, base, lane);
+                wave_chunk_walk(st, more, p, lane, emit);
             }
             if (lane == 0) emit((int)st.n_kept, st.cur_start, st.ref_end);
             const bool unw_any = __any(unw);
             // (the read's own entry of s_rd is not read again: this wave was its only reader)
             if (lane == 0) s_rd[q] = make_int4((int)st.n_kept + 1, st.ref_end, unw_any ? 1 : 0, 0);
-            meta = meta_n; cur = nxt;
+            meta = meta_n; cur = nxt; cw = cw_n;
         }
         __syncthreads();
         if (active) { const int4 v = s_rd[threadIdx.x]; n = (uint32_t)v.x; el = v.y; unwalked = v.z != 0; }

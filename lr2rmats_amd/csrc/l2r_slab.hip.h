@@ -392,14 +392,15 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
         uint32_t q = (uint32_t)wv;
         auto meta_of = [&](uint32_t qq) { return qq < n_act ? make_int4((int)s_ra[qq], (int)s_rb[qq], (int)s_rc[qq], 0) : make_int4(0, 0, 0, 0); };
         int4 meta = meta_of(q);
-        WaveChunk cur = wave_chunk_load(cig + (uint32_t)meta.x, q < n_act ? (uint32_t)meta.y : 0u, 0u, lane);
+        CigarWindow cw = cigar_window(cig, (uint32_t)meta.x, (uint32_t)meta.y);
+        WaveChunk cur = wave_chunk_load(cw, 0u, lane);
         for (; q < n_act; q += TILE_THREADS / WAVE) {
             // the first round of the wave's next read is asked for before this read is walked
             const uint32_t qn = q + TILE_THREADS / WAVE;
             const int4 meta_n = meta_of(qn);
-            const WaveChunk nxt = wave_chunk_load(cig + (uint32_t)meta_n.x, qn < n_act ? (uint32_t)meta_n.y : 0u, 0u, lane);
-            const uint32_t *const words = cig + (uint32_t)meta.x;
-            const uint32_t n_cig = (uint32_t)meta.y;
+            const CigarWindow cw_n = cigar_window(cig, (uint32_t)meta_n.x, (uint32_t)meta_n.y);
+            const WaveChunk nxt = wave_chunk_load(cw_n, 0u, lane);
+            const uint32_t n_cig = (uint32_t)__builtin_amdgcn_readfirstlane(meta.y);
             bool bad = false;                            // the read cannot live in the slab: an exon the row word cannot say, the list full
             // (inlined nine times into an issue-bound walk: every instruction here is paid nine times per read.  The slab keeps a length
             //  saturated to 16 bits; whether it fits the row word is looked at once per read behind the walk.)
@@ -414,10 +415,10 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
                 }
             };
             WaveWalk st{meta.z, meta.z + 1, 0u, false};
-            wave_chunk_walk(st, cur, n_cig, 0u, p, lane, emit);
+            wave_chunk_walk(st, cur, p, lane, emit);
             for (uint32_t b_ = ROUND; b_ < n_cig; b_ += ROUND) {                 // (reads beyond 512 ops: round by round)
-                const WaveChunk more = wave_chunk_load(words, n_cig, b_, lane);
-                wave_chunk_walk(st, more, n_cig, b_, p, lane, emit);
+                const WaveChunk more = wave_chunk_load(cw, b_, lane);
+                wave_chunk_walk(st, more, p, lane, emit);
             }
             bool insane = false;                         // the read's last exon is empty (its first one: looked at in the slab, below)
             if (lane == 0) {
@@ -429,7 +430,7 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
             const bool bad_any = __any(bad), insane_any = __any(insane);
             // (the read's own words are not read again before the barrier: this wave was their only reader)
             if (lane == 0) { s_rb[q] = (st.n_kept + 1u) | ((bad_any ? 1u : 0u) << 16) | ((insane_any ? 2u : 0u) << 16); s_rc[q] = (uint32_t)st.ref_end; }
-            meta = meta_n; cur = nxt;
+            meta = meta_n; cur = nxt; cw = cw_n;
         }
     }
     __syncthreads();
