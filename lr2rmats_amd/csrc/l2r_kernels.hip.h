@@ -283,11 +283,11 @@ __device__ __forceinline__ CigarWindow cigar_window(const uint32_t *__restrict__
     return w;
 }
 
-// words [base + 8 lane, + 8) of a read's CIGAR
-__device__ __forceinline__ WaveChunk wave_chunk_load(const CigarWindow &cw, uint32_t base, int lane)
+// words [base + W lane, + 8) of a read's CIGAR (a walk of W < 8 words per lane leaves the last ones alone: they are the next lane's)
+__device__ __forceinline__ WaveChunk wave_chunk_load(const CigarWindow &cw, uint32_t base, int lane, int W = WCHUNK)
 {
     WaveChunk k;
-    const int voff = WCHUNK * 4 * lane;
+    const int voff = W * 4 * lane;
     const v4u_buf x = __builtin_amdgcn_raw_buffer_load_b128(cw.rs, voff, (int)(base * 4u), 0);
     const v4u_buf y = __builtin_amdgcn_raw_buffer_load_b128(cw.rs, voff + 16, (int)(base * 4u), 0);
     k.w[0] = x.x; k.w[1] = x.y; k.w[2] = x.z; k.w[3] = x.w;
@@ -295,7 +295,9 @@ __device__ __forceinline__ WaveChunk wave_chunk_load(const CigarWindow &cw, uint
     return k;
 }
 
-template <typename Emit>
+// W words per lane: a read of up to 64 W ops is walked in one round, and every word less is a ninth of the round's instructions less
+constexpr int WCHUNK_SHORT = 6;
+template <int WCHUNK = l2r::WCHUNK, typename Emit>
 __device__ __forceinline__ void wave_chunk_walk(WaveWalk &st, const WaveChunk &ch, const DevParams &p, int lane, Emit &emit)
 {
     int a[WCHUNK], len[WCHUNK]; bool c[WCHUNK];

@@ -333,7 +333,10 @@ void k_walk_slab(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
 // to the tile's slab with whole rows.  No per-read cursor value, no window here (k_pass_a makes both): the tile's descriptor is
 // k_describe_scan's.  Tiles are `reads_per_tile` reads (128 for ONT-like input: the upload cannot bound a read's exons by its CIGAR
 // length); a tile's slab has SLAB_ROWS rows.
-__global__ __launch_bounds__(TILE_THREADS, 8)
+#ifndef L2R_WALKLONG_WGS
+#define L2R_WALKLONG_WGS 7
+#endif
+__global__ __launch_bounds__(TILE_THREADS, L2R_WALKLONG_WGS)
 void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
 {
     __shared__ uint32_t s_hist[WAVE];
@@ -392,14 +395,16 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
         uint32_t q = (uint32_t)wv;
         auto meta_of = [&](uint32_t qq) { return qq < n_act ? make_int4((int)s_ra[qq], (int)s_rb[qq], (int)s_rc[qq], 0) : make_int4(0, 0, 0, 0); };
         int4 meta = meta_of(q);
+        // (a read of up to 384 ops -- most ONT-like reads -- takes one round of six words per lane, longer ones rounds of eight)
+        auto words_per_lane = [](int n_ops) { return n_ops <= WCHUNK_SHORT * WAVE ? WCHUNK_SHORT : WCHUNK; };
         CigarWindow cw = cigar_window(cig, (uint32_t)meta.x, (uint32_t)meta.y);
-        WaveChunk cur = wave_chunk_load(cw, 0u, lane);
+        WaveChunk cur = wave_chunk_load(cw, 0u, lane, words_per_lane(__builtin_amdgcn_readfirstlane(meta.y)));
         for (; q < n_act; q += TILE_THREADS / WAVE) {
             // the first round of the wave's next read is asked for before this read is walked
             const uint32_t qn = q + TILE_THREADS / WAVE;
             const int4 meta_n = meta_of(qn);
             const CigarWindow cw_n = cigar_window(cig, (uint32_t)meta_n.x, (uint32_t)meta_n.y);
-            const WaveChunk nxt = wave_chunk_load(cw_n, 0u, lane);
+            const WaveChunk nxt = wave_chunk_load(cw_n, 0u, lane, words_per_lane(__builtin_amdgcn_readfirstlane(meta_n.y)));
             const uint32_t n_cig = (uint32_t)__builtin_amdgcn_readfirstlane(meta.y);
             bool bad = false;                            // the read cannot live in the slab: an exon the row word cannot say, the list full
             // (inlined nine times into an issue-bound walk: every instruction here is paid nine times per read.  The slab keeps a length
@@ -415,10 +420,13 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
                 }
             };
             WaveWalk st{meta.z, meta.z + 1, 0u, false};
-            wave_chunk_walk(st, cur, p, lane, emit);
-            for (uint32_t b_ = ROUND; b_ < n_cig; b_ += ROUND) {                 // (reads beyond 512 ops: round by round)
-                const WaveChunk more = wave_chunk_load(cw, b_, lane);
-                wave_chunk_walk(st, more, p, lane, emit);
+            if (n_cig <= (uint32_t)(WCHUNK_SHORT * WAVE)) wave_chunk_walk<WCHUNK_SHORT>(st, cur, p, lane, emit);
+            else {
+                wave_chunk_walk(st, cur, p, lane, emit);
+                for (uint32_t b_ = ROUND; b_ < n_cig; b_ += ROUND) {             // (reads beyond 512 ops: round by round)
+                    const WaveChunk more = wave_chunk_load(cw, b_, lane);
+                    wave_chunk_walk(st, more, p, lane, emit);
+                }
             }
             bool insane = false;                         // the read's last exon is empty (its first one: looked at in the slab, below)
             if (lane == 0) {
