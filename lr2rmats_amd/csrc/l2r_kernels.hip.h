@@ -297,50 +297,71 @@ __device__ __forceinline__ WaveChunk wave_chunk_load(const CigarWindow &cw, uint
 
 // W words per lane: a read of up to 64 W ops is walked in one round, and every word less is a ninth of the round's instructions less
 constexpr int WCHUNK_SHORT = 6;
-template <int WCHUNK = l2r::WCHUNK, typename Emit>
-__device__ __forceinline__ void wave_chunk_walk(WaveWalk &st, const WaveChunk &ch, const DevParams &p, int lane, Emit &emit)
+// One round.  A lane needs the first and the last cut op among its words only -- the reference bases in front of each and their
+// lengths, picked up word by word -- as long as no lane holds more than two (three take two micro-exons next to each other): no
+// per-word arrays, and the exon numbers come from two ballots.  Returns false, with `st` untouched, when a lane holds three.
+// (a lane's pick between two values by its bit of a wave-wide mask: the cut tests below are kept as masks in scalar registers, where
+//  "a second cut", "a third cut" are two scalar instructions per word; as per-lane booleans the compiler makes them vector arithmetic)
+__device__ __forceinline__ int pick(unsigned long long mask, int if_clear, int if_set)
 {
-    int a[WCHUNK], len[WCHUNK]; bool c[WCHUNK];
-    int A = 0; bool any_c = false;
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
+}
+
+template <int WCHUNK, typename Emit>
+__device__ __forceinline__ bool wave_chunk_try(WaveWalk &st, const WaveChunk &ch, const DevParams &p, int lane, Emit &emit)
+{
+    int A = 0, ab1 = 0, ab2 = 0, l1 = 0, l2 = 0;
+    unsigned long long any_c = 0ull, two = 0ull, three = 0ull;               // lanes with one, two, three cut ops so far
 #pragma unroll
     for (int j = 0; j < WCHUNK; ++j) {
         const uint32_t w = ch.w[j];                                          // (behind the read's last op: 0, see cigar_window)
         const uint32_t op = w & 0xfu;
-        len[j] = (int)(w >> 4);
-        a[j] = len[j] & __builtin_amdgcn_sbfe(0x18d, op, 1u);                // ops 0 2 3 7 8 advance the reference
-        c[j] = ((op == 3u) & (len[j] >= p.min_intron)) | ((op == 2u) & (len[j] > p.max_delet));
-        A += a[j]; any_c = any_c | c[j];
+        const int len = (int)(w >> 4);
+        const int a = len & __builtin_amdgcn_sbfe(0x18d, op, 1u);            // ops 0 2 3 7 8 advance the reference
+        const unsigned long long c = (__ballot(op == 3u) & __ballot(len >= p.min_intron)) | (__ballot(op == 2u) & __ballot(len > p.max_delet));
+        const unsigned long long f = c & ~any_c;
+        ab1 = pick(f, ab1, A); l1 = pick(f, l1, len);
+        ab2 = pick(c, ab2, A); l2 = pick(c, l2, len);
+        three |= c & two; two |= c & any_c; any_c |= c;
+        A += a;
     }
+    if (WCHUNK > 2 && three) return false;
     const int incA = wave_scan<OpAdd>(A);
-    const unsigned long long cm = __ballot(any_c);
-    if (cm) {                                           // (wave-uniform)
-        int eb[WCHUNK], sa[WCHUNK];                     // reference end in front of op j; exon start behind it if it cuts
-        int run = st.ref_end + incA - A, my_last = INT32_MIN;
-#pragma unroll
-        for (int j = 0; j < WCHUNK; ++j) { eb[j] = run; sa[j] = run + len[j] + 1; my_last = c[j] ? sa[j] : my_last; run += a[j]; }
-        const int incM = wave_scan<OpMax>(my_last);
+    if (any_c) {                                        // (wave-uniform)
+        const int run = st.ref_end + incA - A;          // reference end in front of the lane's first word
+        const int eb1 = run + ab1, sa1 = eb1 + l1 + 1, eb2 = run + ab2, sa2 = eb2 + l2 + 1;
+        const int incM = wave_scan<OpMax>(pick(any_c, INT32_MIN, sa2));
         const int before = __builtin_amdgcn_update_dpp(INT32_MIN, incM, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-        int S = max(before, st.cur_start);              // start of the candidate the lane's first cut closes
-        bool first = !st.seen_cut && lane == __ffsll((long long)cm) - 1;
-        bool k[WCHUNK]; int ks[WCHUNK];
-        uint32_t kept = 0u;
-#pragma unroll
-        for (int j = 0; j < WCHUNK; ++j) {
-            ks[j] = S;
-            k[j] = c[j] & (first | (eb[j] - S + 1 >= p.min_exon));
-            first = first & !c[j];
-            S = c[j] ? sa[j] : S;
-            kept += k[j] ? 1u : 0u;
-        }
-        const uint32_t incK = wave_inclusive_scan(kept);
-        uint32_t at = st.n_kept + incK - kept;
-#pragma unroll
-        for (int j = 0; j < WCHUNK; ++j) if (k[j]) { emit((int)at, ks[j], eb[j]); ++at; }
-        st.n_kept += (uint32_t)__builtin_amdgcn_readlane((int)incK, WAVE - 1);
+        const int s1 = max(before, st.cur_start);       // start of the candidate the lane's first cut closes
+        const unsigned long long first = st.seen_cut ? 0ull : any_c & (0ull - any_c);       // the read's first cut: kept whatever its length
+        const unsigned long long km1 = any_c & (first | __ballot(eb1 - s1 + 1 >= p.min_exon));
+        const unsigned long long km2 = two & __ballot(eb2 - sa1 + 1 >= p.min_exon);
+        const uint32_t in_front = __builtin_amdgcn_mbcnt_hi((uint32_t)(km1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km1, 0u))
+                                + __builtin_amdgcn_mbcnt_hi((uint32_t)(km2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km2, 0u));
+        const int at = (int)(st.n_kept + in_front);
+        const int k1 = pick(km1, 0, 1);
+        if (k1) emit(at, s1, eb1);
+        if (pick(km2, 0, 1)) emit(at + k1, sa1, eb2);
+        st.n_kept += (uint32_t)(__popcll(km1) + __popcll(km2));
         st.cur_start = __builtin_amdgcn_readlane(incM, WAVE - 1);            // (the starts behind the cuts do not decrease)
         st.seen_cut = true;
     }
     st.ref_end += __builtin_amdgcn_readlane(incA, WAVE - 1);
+    return true;
+}
+
+// the round of `ch` = words [base, base + 64 W) of the read behind `cw`; with three cuts in a lane, the same words two per lane
+template <int W = l2r::WCHUNK, typename Emit>
+__device__ __forceinline__ void wave_chunk_walk(WaveWalk &st, const CigarWindow &cw, const WaveChunk &ch, uint32_t base, const DevParams &p, int lane, Emit &emit)
+{
+    if (wave_chunk_try<W>(st, ch, p, lane, emit)) return;
+#pragma unroll 1
+    for (uint32_t b = base; b < base + (uint32_t)(W * WAVE); b += 2u * (uint32_t)WAVE) {
+        const WaveChunk part = wave_chunk_load(cw, b, lane, 2);
+        wave_chunk_try<2>(st, part, p, lane, emit);
+    }
 }
 
 // dynamic LDS of k_pass_a<true> for tiles of up to `rpt` reads
@@ -464,10 +485,10 @@ void k_pass_a(int64_t n_reads, const int32_t *__restrict__ r_tid, const int32_t 
                 }
             };
             WaveWalk st{meta.z, meta.z + 1, 0u, false};
-            wave_chunk_walk(st, cur, p, lane, emit);
+            wave_chunk_walk(st, cw, cur, 0u, p, lane, emit);
             for (uint32_t base = ROUND; base < n_cig; base += ROUND) {           // (reads beyond 512 ops: round by round)
                 const WaveChunk more = wave_chunk_load(cw, base, lane);
-                wave_chunk_walk(st, more, p, lane, emit);
+                wave_chunk_walk(st, cw, more, base, p, lane, emit);
             }
             if (lane == 0) emit((int)st.n_kept, st.cur_start, st.ref_end);
             const bool unw_any = __any(unw);

@@ -334,7 +334,10 @@ void k_walk_slab(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
 // k_describe_scan's.  Tiles are `reads_per_tile` reads (128 for ONT-like input: the upload cannot bound a read's exons by its CIGAR
 // length); a tile's slab has SLAB_ROWS rows.
 #ifndef L2R_WALKLONG_WGS
-#define L2R_WALKLONG_WGS 7
+#define L2R_WALKLONG_WGS 8
+#endif
+#ifndef L2R_WALK_MIXED
+#define L2R_WALK_MIXED 1
 #endif
 __global__ __launch_bounds__(TILE_THREADS, L2R_WALKLONG_WGS)
 void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
@@ -396,7 +399,7 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
         auto meta_of = [&](uint32_t qq) { return qq < n_act ? make_int4((int)s_ra[qq], (int)s_rb[qq], (int)s_rc[qq], 0) : make_int4(0, 0, 0, 0); };
         int4 meta = meta_of(q);
         // (a read of up to 384 ops -- most ONT-like reads -- takes one round of six words per lane, longer ones rounds of eight)
-        auto words_per_lane = [](int n_ops) { return n_ops <= WCHUNK_SHORT * WAVE ? WCHUNK_SHORT : WCHUNK; };
+        auto words_per_lane = [](int n_ops) { return L2R_WALK_MIXED && n_ops <= WCHUNK_SHORT * WAVE ? WCHUNK_SHORT : WCHUNK; };
         CigarWindow cw = cigar_window(cig, (uint32_t)meta.x, (uint32_t)meta.y);
         WaveChunk cur = wave_chunk_load(cw, 0u, lane, words_per_lane(__builtin_amdgcn_readfirstlane(meta.y)));
         for (; q < n_act; q += TILE_THREADS / WAVE) {
@@ -420,12 +423,21 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
                 }
             };
             WaveWalk st{meta.z, meta.z + 1, 0u, false};
-            if (n_cig <= (uint32_t)(WCHUNK_SHORT * WAVE)) wave_chunk_walk<WCHUNK_SHORT>(st, cur, p, lane, emit);
-            else {
-                wave_chunk_walk(st, cur, p, lane, emit);
+#if L2R_WALK_MIXED
+            if (n_cig <= (uint32_t)(WCHUNK_SHORT * WAVE)) {
+                // (the first six words of both rounds are the same arithmetic: kept apart, or the compiler computes them in front of the
+                //  branch and carries a dozen registers into both arms)
+                WaveChunk mine = cur;
+#pragma unroll
+                for (int j = 0; j < WCHUNK_SHORT; ++j) asm volatile("" : "+v"(mine.w[j]));
+                wave_chunk_walk<WCHUNK_SHORT>(st, cw, mine, 0u, p, lane, emit);
+            } else
+#endif
+            {
+                wave_chunk_walk(st, cw, cur, 0u, p, lane, emit);
                 for (uint32_t b_ = ROUND; b_ < n_cig; b_ += ROUND) {             // (reads beyond 512 ops: round by round)
                     const WaveChunk more = wave_chunk_load(cw, b_, lane);
-                    wave_chunk_walk(st, more, p, lane, emit);
+                    wave_chunk_walk(st, cw, more, b_, p, lane, emit);
                 }
             }
             bool insane = false;                         // the read's last exon is empty (its first one: looked at in the slab, below)
