@@ -747,7 +747,10 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         // sparse input (few reads per locus) makes 256 consecutive reads span many genes, and a tile that does not
         // fit goes to the generic kernel read by read (~30x the cost).  Sample windows of the sorted input, take for
         // every candidate size the share of windows that would not fit, and pick the cheapest size.
-        if (sorted && N >= 2 * TILE_THREADS) {
+        // (The slab pipeline's tiles are cut by span one by one, below: a sparse stretch makes ITS tiles small, not every tile of the
+        //  upload -- an annotation with a few isoform-rich loci and long sparse stretches got 128-read tiles throughout, twice the tiles.)
+        const bool span_cut_tiles = c->want_pipeline > 0 && sorted && ((double)r->n_cigar / (double)N <= 32.0 || slab_long);
+        if (sorted && N >= 2 * TILE_THREADS && !span_cut_tiles) {
             const int64_t n_win = std::min<int64_t>(N / TILE_THREADS, 384);
             const int64_t wstep = (N / TILE_THREADS) / n_win;
             const int64_t limit = (int64_t)(DIR_CAP - 8) << SITE_SHIFT;
