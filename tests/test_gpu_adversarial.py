@@ -394,3 +394,48 @@ def test_reads_of_300_and_9000_exons_between_ordinary_neighbours(oracle, pipelin
     assert ((want.info & 2) != 0).sum() > 500
     if pipeline == "slab":
         assert 2 <= cnt[0] <= 300, cnt                # the two long reads (and the reads of their tiles that no longer fit the staged positions)
+
+
+@pytest.mark.parametrize("min_exon", [1, 3])
+def test_long_cigars_with_cut_ops_crowded_into_a_few_words(oracle, min_exon, pipeline):
+    """The wave-cooperative walk of long CIGARs (l2r_kernels.hip.h wave_chunk_try) keeps a lane's FIRST and LAST cut op of its six or
+    eight CIGAR words; three cut ops in one lane's words re-walk the round two words per lane.  Reads with bursts of micro-exons
+    (N M N M N ... next to each other, with and without cutting deletions between them) at every place of the op stream -- inside
+    a lane, across lanes, across the 384- and 512-op rounds -- between stretches of M / I / D noise, of 40 to 1500 ops: one round
+    of six words, one of eight, several of eight, and the two-words-per-lane rounds in each of them."""
+    M_, I_, D_, N3 = 0, 1, 2, 3
+    rng = np.random.default_rng(77 + min_exon)
+    txs = [(0, 0, [(2_000 + 700 * k, 2_300 + 700 * k) for k in range(12)]), (0, 1, [(2_050, 2_300), (2_700, 3_000), (4_100, 4_400)])]
+    af = _anno(txs)
+    rows = []
+    for i in range(700):
+        target = int(rng.choice([40, 200, 370, 384, 390, 500, 512, 520, 700, 1_030, 1_500]))
+        ops = []
+        n_cuts = 0
+        burst_at = sorted(int(x) for x in rng.integers(0, max(target - 12, 1), size=int(rng.integers(1, 4))))
+        while len(ops) < target:
+            if burst_at and len(ops) >= burst_at[0] and n_cuts < 18:
+                burst_at.pop(0)
+                for _ in range(int(rng.integers(2, 5))):            # 2 .. 4 cut ops with 1 .. 6-base exons between them
+                    cut = (int(rng.integers(51, 90)), D_) if rng.random() < 0.3 else (int(rng.integers(3, 400)), N3)
+                    ops.append(cut)
+                    ops.append((int(rng.integers(1, 7)), M_))
+                    n_cuts += 1
+                continue
+            r = rng.random()
+            if r < 0.55 or not ops or ops[-1][1] != M_:
+                ops.append((int(rng.integers(1, 40)), M_))
+            elif r < 0.75:
+                ops.append((int(rng.integers(1, 4)), I_))
+            elif r < 0.97:
+                ops.append((int(rng.integers(1, 51)), D_))            # (up to max_delet: no cut)
+            elif n_cuts < 18:
+                ops.append((int(rng.integers(3, 2_000)), N3))
+                n_cuts += 1
+        if ops[-1][1] != M_:
+            ops.append((int(rng.integers(5, 40)), M_))
+        rows.append((0, 1_000 + int(rng.integers(0, 3_000)), i & 1, ops))
+    cnt = [0, 0, 0, 0]
+    got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=3, min_exon=min_exon)
+    n_ex = np.diff(want.ex_off)
+    assert n_ex.max() >= 8 and (n_ex >= 4).sum() > 300
