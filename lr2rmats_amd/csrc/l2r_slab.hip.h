@@ -397,17 +397,18 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
         constexpr uint32_t ROUND = (uint32_t)(WCHUNK * WAVE);
         uint32_t q = (uint32_t)wv;
         auto meta_of = [&](uint32_t qq) { return qq < n_act ? make_int4((int)s_ra[qq], (int)s_rb[qq], (int)s_rc[qq], 0) : make_int4(0, 0, 0, 0); };
-        int4 meta = meta_of(q);
         // (a read of up to 384 ops -- most ONT-like reads -- takes one round of six words per lane, longer ones rounds of eight)
         auto words_per_lane = [](int n_ops) { return L2R_WALK_MIXED && n_ops <= WCHUNK_SHORT * WAVE ? WCHUNK_SHORT : WCHUNK; };
-        CigarWindow cw = cigar_window(cig, (uint32_t)meta.x, (uint32_t)meta.y);
-        WaveChunk cur = wave_chunk_load(cw, 0u, lane, words_per_lane(__builtin_amdgcn_readfirstlane(meta.y)));
-        for (; q < n_act; q += TILE_THREADS / WAVE) {
-            // the first round of the wave's next read is asked for before this read is walked
-            const uint32_t qn = q + TILE_THREADS / WAVE;
-            const int4 meta_n = meta_of(qn);
-            const CigarWindow cw_n = cigar_window(cig, (uint32_t)meta_n.x, (uint32_t)meta_n.y);
-            const WaveChunk nxt = wave_chunk_load(cw_n, 0u, lane, words_per_lane(__builtin_amdgcn_readfirstlane(meta_n.y)));
+        // The first round of the wave's next read is asked for before this read is walked.  Two buffers with fixed registers take turns (the
+        // read loop is written out twice): handing the next read's chunk over to "the current one" would be eight register copies per read.
+        struct Ahead { int4 meta; CigarWindow cw; WaveChunk ch; };
+        auto fetch = [&](Ahead &b, uint32_t qq) {
+            b.meta = meta_of(qq);
+            b.cw = cigar_window(cig, (uint32_t)b.meta.x, (uint32_t)b.meta.y);
+            b.ch = wave_chunk_load(b.cw, 0u, lane, words_per_lane(__builtin_amdgcn_readfirstlane(b.meta.y)));
+        };
+        auto process = [&](const Ahead &mine) {
+            const int4 meta = mine.meta; const CigarWindow &cw = mine.cw; const WaveChunk &cur = mine.ch;
             const uint32_t n_cig = (uint32_t)__builtin_amdgcn_readfirstlane(meta.y);
             bool bad = false;                            // the read cannot live in the slab: an exon the row word cannot say, the list full
             // (inlined nine times into an issue-bound walk: every instruction here is paid nine times per read.  The slab keeps a length
@@ -450,7 +451,14 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
             const bool bad_any = __any(bad), insane_any = __any(insane);
             // (the read's own words are not read again before the barrier: this wave was their only reader)
             if (lane == 0) { s_rb[q] = (st.n_kept + 1u) | ((bad_any ? 1u : 0u) << 16) | ((insane_any ? 2u : 0u) << 16); s_rc[q] = (uint32_t)st.ref_end; }
-            meta = meta_n; cur = nxt; cw = cw_n;
+        };
+        Ahead b0, b1;
+        fetch(b0, q);
+        for (;;) {
+            if (q >= n_act) break;
+            fetch(b1, q + TILE_THREADS / WAVE); process(b0); q += TILE_THREADS / WAVE;
+            if (q >= n_act) break;
+            fetch(b0, q + TILE_THREADS / WAVE); process(b1); q += TILE_THREADS / WAVE;
         }
     }
     __syncthreads();
