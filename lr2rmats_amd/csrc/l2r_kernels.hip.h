@@ -341,9 +341,8 @@ __device__ __forceinline__ bool wave_chunk_try(WaveWalk &st, const WaveChunk &ch
         const uint32_t in_front = __builtin_amdgcn_mbcnt_hi((uint32_t)(km1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km1, 0u))
                                 + __builtin_amdgcn_mbcnt_hi((uint32_t)(km2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km2, 0u));
         const int at = (int)(st.n_kept + in_front);
-        const int k1 = pick(km1, 0, 1);
-        if (k1) emit(at, s1, eb1);
-        if (pick(km2, 0, 1)) emit(at + k1, sa1, eb2);
+        if (__builtin_amdgcn_inverse_ballot_w64(km1)) emit(at, s1, eb1);                 // (the mask is the branch's exec mask as it stands)
+        if (__builtin_amdgcn_inverse_ballot_w64(km2)) emit(at + pick(km1, 0, 1), sa1, eb2);
         st.n_kept += (uint32_t)(__popcll(km1) + __popcll(km2));
         st.cur_start = __builtin_amdgcn_readlane(incM, WAVE - 1);            // (the starts behind the cuts do not decrease)
         st.seen_cut = true;

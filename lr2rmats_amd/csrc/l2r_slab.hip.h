@@ -415,7 +415,7 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
             //  saturated to 16 bits; whether it fits the row word is looked at once per read behind the walk.)
             auto emit = [&](int k, int s_, int e_) {
                 const uint32_t len = (uint32_t)(e_ - s_ + 1);            // (0: an empty exon -- start = end + 1, never further apart)
-                if (k < WALK_SLAB) { s_slab_s[k * slab_w + (int)q] = s_; s_slab_l[k * slab_w + (int)q] = (uint16_t)min(len, 0xffffu); }
+                if (k < WALK_SLAB) { const int at_ = __mul24(k, slab_w) + (int)q; s_slab_s[at_] = s_; s_slab_l[at_] = (uint16_t)min(len, 0xffffu); }
                 else {
                     bad = bad | (len > SLAB_LEN_MAX);
                     const uint32_t at = atomicAdd(&s_ovf_n, 1u);
