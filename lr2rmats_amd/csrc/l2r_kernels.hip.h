@@ -287,9 +287,11 @@ __device__ __forceinline__ CigarWindow cigar_window(const uint32_t *__restrict__
 __device__ __forceinline__ WaveChunk wave_chunk_load(const CigarWindow &cw, uint32_t base, int lane, int W = WCHUNK)
 {
     WaveChunk k;
-    const int voff = W * 4 * lane;
-    const v4u_buf x = __builtin_amdgcn_raw_buffer_load_b128(cw.rs, voff, (int)(base * 4u), 0);
-    const v4u_buf y = __builtin_amdgcn_raw_buffer_load_b128(cw.rs, voff + 16, (int)(base * 4u), 0);
+    // (the round's first word goes into the per-lane offset, not into the instruction's scalar offset: the range check that zeroes the
+    //  words behind the read's last op is then the one of offset against num_records whatever the scalar offset's part in it is)
+    const int voff = W * 4 * lane + (int)(base * 4u);
+    const v4u_buf x = __builtin_amdgcn_raw_buffer_load_b128(cw.rs, voff, 0, 0);
+    const v4u_buf y = __builtin_amdgcn_raw_buffer_load_b128(cw.rs, voff + 16, 0, 0);
     k.w[0] = x.x; k.w[1] = x.y; k.w[2] = x.z; k.w[3] = x.w;
     k.w[4] = y.x; k.w[5] = y.y; k.w[6] = y.z; k.w[7] = y.w;
     return k;
