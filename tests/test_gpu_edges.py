@@ -435,3 +435,37 @@ def test_scans_in_launches_of_their_own(oracle, pipeline, monkeypatch):
     j, sj = util.junction_table(af, reads, base, 31, cover=0.7)
     _run(oracle, af, reads, sj=sj, full_level=3, split_trans=1, min_sj_cnt=1)
     assert ((want.info & 7) == 6).sum() > 1000            # full, has a known site, not known: the reads the accepted list holds
+
+
+def test_sparse_stretches_make_their_own_tiles_small_and_no_others(oracle, pipeline):
+    """Tiles of the slab pipeline are cut by span one by one (a tile's reads begin less than 2^17 bases apart): a sparse stretch of
+    the read set makes ITS tiles small.  The upload used to halve every tile of the read set when a sample of 256-read windows
+    held sparse ones (a rule the classic pipeline needs): twice the tiles on an annotation with busy loci between quiet stretches.
+    Ten busy loci of 3000 reads each, between them stretches of 600 reads one kb apart (256 of those span more than the staged
+    bucket directory, 128 do not: the old rule chose 128 for every tile -- 235 tiles for the busy loci instead of 120)."""
+    if pipeline != "slab":
+        pytest.skip("the classic pipeline keeps its rule")
+    exons = [(0, 300), (900, 1_200), (2_000, 2_400)]
+    txs, rows = [], []
+    rng = np.random.default_rng(11)
+
+    def locus(base, n_reads):
+        txs.append((0, 0, [(base + s, base + e) for s, e in exons]))
+        for _ in range(n_reads):
+            j = int(rng.integers(0, 40))
+            rows.append((0, *_chain([(base + exons[0][0] + j, base + exons[0][1]), (base + exons[1][0], base + exons[1][1]),
+                                     (base + exons[2][0], base + exons[2][1] - j)])))
+
+    at = 10_000
+    for k in range(10):
+        locus(at, 3_000)
+        at += 5_000
+        if k < 9:
+            for _ in range(600):
+                locus(at, 1)
+                at += 1_000
+    rows = sorted(((r[0], r[1], 0, r[2]) for r in rows), key=lambda r: (r[0], r[1]))
+    cnt = [0, 0, 0, 0]
+    _run(oracle, _anno(txs), _reads(rows), counters=cnt, full_level=3)
+    busy = 10 * -(-3_000 // 256)
+    assert busy <= cnt[3] <= busy + 9 * 7 + 10, cnt              # (a stretch of 600 kb: five to six tiles by span, plus the seams)
