@@ -396,7 +396,7 @@ def test_reads_of_300_and_9000_exons_between_ordinary_neighbours(oracle, pipelin
         assert 2 <= cnt[0] <= 300, cnt                # the two long reads (and the reads of their tiles that no longer fit the staged positions)
 
 
-@pytest.mark.parametrize("min_exon", [1, 3])
+@pytest.mark.parametrize("min_exon", [0, 1, 3])
 def test_long_cigars_with_cut_ops_crowded_into_a_few_words(oracle, min_exon, pipeline):
     """The wave-cooperative walk of long CIGARs (l2r_kernels.hip.h wave_chunk_try) keeps a lane's FIRST and LAST cut op of its six or
     eight CIGAR words; three cut ops in one lane's words re-walk the round two words per lane.  Reads with bursts of micro-exons
