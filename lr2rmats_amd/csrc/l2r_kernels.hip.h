@@ -256,13 +256,14 @@ __device__ __forceinline__ int walk_cigar_headed(const CigarHead &h, const uint3
 }
 
 // ONE READ walked by ONE WAVE (long CIGARs: ONT-like reads, hundreds of ops): src/bam2gtf.c:31-78 as a scan over the op stream.
-// Lane L takes eight consecutive CIGAR words per round (two 16-byte loads; the wave reads 2 KB of the stream at a time, coalesced --
-// a lane per read fetches a 64-byte sector of its own per load).  A round:
+// Lane L takes eight (six: a read of up to 384 ops, one round) consecutive CIGAR words per round (two 16-byte loads; the wave reads
+// 2 KB of the stream at a time, coalesced -- a lane per read fetches a 64-byte sector of its own per load).  A round:
 //   reference end before every op     = pos + sum of the reference-consuming lengths in front of it    (wave prefix sum + carry)
 //   a cut op (N >= min_intron, D > max_delet) closes the candidate exon [start behind the previous cut, end before this op];
 //   "start behind the previous cut"    = running maximum of end + len + 1 over the cut ops in front      (wave prefix max + carry)
 //   the candidate is kept iff it is the read's first or min_exon long (a dropped one is skipped, not merged: Q4), its exon
-//   number = kept candidates in front  (wave prefix sum + carry); the cut ops are found with a wave ballot.
+//   number = kept candidates in front  (two ballots + carry: a lane keeps the first and the last cut op of its words, see
+//   wave_chunk_try; a lane with three is walked again two words per lane); the cut ops are found with a wave ballot.
 // emit(k, start, end) is called by the lane that holds the cut op.  The caller keeps the first round of the wave's NEXT read in
 // flight while this one is walked (wave_chunk_load / wave_chunk_walk): a wave on its own has one round trip to HBM per round.
 constexpr int WCHUNK = 8;                                // CIGAR words per lane and round

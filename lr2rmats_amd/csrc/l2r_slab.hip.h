@@ -327,8 +327,8 @@ void k_walk_slab(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
 // k_walk_slab for LONG CIGARs (ONT-like input: hundreds of operations per read; min_exon >= 1): the same outputs -- slab rows, the
 // reads' words, the tile's span record and exon count -- so that k_describe_scan and the probe kernels behind it do not know the
 // difference, with the walk of k_pass_a<true>: ONE WAVE walks one read at a time as a scan over its op stream (wave_chunk_walk:
-// eight words per lane and round, reference ends by prefix sum, exon starts by prefix maximum, kept cuts by ballot), the first round
-// of the wave's next read in flight meanwhile.  A read's first WALK_SLAB exons wait in an exon-major LDS slab, later ones in a list;
+// six or eight words per lane and round, reference ends by prefix sum, exon starts by prefix maximum, kept cuts by ballot), the first
+// round of the wave's next read in flight meanwhile.  A read's first WALK_SLAB exons wait in an exon-major LDS slab, later ones in a list;
 // when every read of the tile has been walked, the reads get their slots (by falling exon count: counting sort) and their columns go
 // to the tile's slab with whole rows.  No per-read cursor value, no window here (k_pass_a makes both): the tile's descriptor is
 // k_describe_scan's.  Tiles are `reads_per_tile` reads (128 for ONT-like input: the upload cannot bound a read's exons by its CIGAR
