@@ -177,6 +177,19 @@ def assemble_accepted(parts):
 
 
 def run(argv, classify: Optional[Callable] = None, backend: Optional[str] = None) -> int:
+    """One rank of `update-gtf` (see the module's head).  A process group that this call brings up goes down with it: a rank that
+    leaves the interpreter with gloo's threads still running can abort in their teardown ("terminate called without an active
+    exception"), which turned a finished run into exit code -6 now and then."""
+    import torch.distributed as dist
+    had_group = dist.is_available() and dist.is_initialized()
+    try:
+        return _run(argv, classify, backend)
+    finally:
+        if not had_group and dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _run(argv, classify: Optional[Callable] = None, backend: Optional[str] = None) -> int:
     import torch
     import torch.distributed as dist
 
