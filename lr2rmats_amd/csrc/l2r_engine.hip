@@ -20,6 +20,7 @@
 #include "l2r_window.hip.h"
 #include "l2r_slab.hip.h"
 #include "l2r_chunk.hip.h"
+#include "l2r_tile.hip.h"
 #include "l2r_filter.hip.h"
 
 using namespace l2r;
@@ -68,10 +69,14 @@ struct l2r_ctx {
     int n_cu = 256, wg_per_cu = 4;          // persistent grid of k_classify_fast (L2R_WG_PER_CU overrides)
     int ablate = 0;                         // diagnostics, L2R_ABLATE (read once, at l2r_create)
     int64_t seg_max = SEG_MAX;              // tiles up to which the segmented scans are used (l2r_kernels.hip.h); L2R_SEG_MAX
-    int want_pipeline = 1;                  // L2R_PIPELINE: classic (0: l2r_kernels.hip.h, two walks), slab (1, default: l2r_slab.hip.h, one walk)
+    int want_pipeline = 2;                  // L2R_PIPELINE: classic (0: l2r_kernels.hip.h, two walks), slab (1: l2r_slab.hip.h, one walk, two kernels), tile (2, default: l2r_tile.hip.h, one kernel per tile where the input allows it, else slab)
     bool many_exon_reads = false;           // the upload's sample: more than 0.5 % of the reads have more exons than a slab has rows
     bool slab_ok = false;                   // the current upload can run the slab pipeline: coordinate-sorted records, short CIGARs, its slab layout fits
     bool slab = false;                      // ... and the last launch did (the parameters have a say: launch_all)
+    bool tile = false;                      // ... with the one-kernel tile path (l2r_tile.hip.h: short CIGARs, -e >= 1)
+    DevBuf<unsigned long long> lb_tile, lb_blk, lb_sup;     // one-kernel tile path: the tiles' exon counts on their way to the later tiles' first slots
+    DevBuf<uint32_t> fb_list;                               //                       the tiles it leaves to k_probe_slab
+    DevBuf<TileStat> tile_stat; std::vector<TileStat> h_tile_stat;      //                 the upload's index of the tiles' CIGAR operations (k_tile_index)
     DevBuf<uint32_t> tile_sbase, s_pre, s_loc, s_pl, cig_off32, tile_rec, tile_total, tile_xbase, tile_span;    // (tile_span: 16-byte TileSpan records, l2r_slab.hip.h)
     DevBuf<int32_t> dense_start, dense_end;                 // slab pipeline: the outliers' dense area
     DevBuf<uint32_t> slab_row;                              //                the exon rows between its kernels (one word per exon)
@@ -211,7 +216,7 @@ l2r_ctx *l2r_create(int device)
         e = getenv("L2R_ANNO_CACHE");
         if (e && *e) c->anno_cache_dir = e;
         e = getenv("L2R_PIPELINE");
-        if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : 1;
+        if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : !strcmp(e, "slab") ? 1 : 2;
     }
     return c;
 }
@@ -229,6 +234,7 @@ void l2r_destroy(l2r_ctx *c)
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_acc_at.release(); c->tile_acc_ex_at.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->tile_total.release(); c->tile_xbase.release(); c->tile_rec.release(); c->cig_off32.release(); c->s_pl.release(); c->tile_span.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_list.release(); c->chunk_list.release(); c->list_cnt.release(); c->tile_flags.release();
+    c->lb_tile.release(); c->lb_blk.release(); c->lb_sup.release(); c->fb_list.release(); c->tile_stat.release();
     c->slab_row.release(); c->dense_start.release(); c->dense_end.release(); c->s_pre.release(); c->s_loc.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -872,8 +878,10 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         if (total < 0x7ffffff0ULL && ovf < 0x7ffffff0ULL) {
             sbase[T] = (uint32_t)total;                     // (rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true;
-            if (c->tw64.ensure(T + 1) || c->wide_list.ensure(T + 1) || c->chunk_list.ensure(T + 1) || c->list_cnt.ensure(4) || c->tile_flags.ensure(T + 8)) return -2;      // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB each)
-            HIP_TRY(hipMemsetAsync(c->list_cnt.p, 0, 16, c->stream));
+            if (c->tw64.ensure(T + 1) || c->wide_list.ensure(T + 1) || c->chunk_list.ensure(T + 1) || c->list_cnt.ensure(8) || c->tile_flags.ensure(T + 8) ||
+                c->lb_tile.ensure(T + 64) || c->lb_blk.ensure(T / LB_BLK + 64) || c->lb_sup.ensure((T >> LB_SUP_SHIFT) + 64) || c->fb_list.ensure(T + 1) || c->tile_stat.ensure(T + 1)) return -2;
+            HIP_TRY(hipMemsetAsync(c->lb_sup.p, 0, ((T >> LB_SUP_SHIFT) + 64) * 8, c->stream));      // (from then on cleared behind every run, by k_classify_generic)      // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB each)
+            HIP_TRY(hipMemsetAsync(c->list_cnt.p, 0, 32, c->stream));
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) || c->tile_total.ensure(T + 2) || c->tile_xbase.ensure(T + 2) || c->tile_span.ensure(12 * (T + 1)) ||
                 c->s_pre.ensure((size_t)N + 1) || c->s_loc.ensure((size_t)N + 1) ||
                 c->slab_row.ensure((size_t)total + 4) ||
@@ -893,6 +901,15 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             if (c->tile_rec.ensure(8 * (T + 1)) || c->cig_off32.ensure((size_t)N + 2) || c->s_pl.ensure((size_t)N + 1)) return -2;
             HIP_TRY(hipMemcpyAsync(c->tile_rec.p, rec.data(), rec.size() * sizeof(TileRec), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemcpyAsync(c->cig_off32.p, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, c->stream));
+            // every tile's last base (the largest read end: CIGAR lengths only, no parameter has a say) into its record: the one-kernel
+            // tile path makes the tiles' windows from it in front of the walk (l2r_tile.hip.h)
+            // ... and an index of its CIGAR operations from which a run knows the tile's exon count unless a threshold is borderline in it
+            c->h_tile_stat.assign(T, TileStat{0, INT32_MAX, 0, INT32_MAX});
+            if (T && !c->wide_cigar) {
+                hipLaunchKernelGGL(k_tile_index, dim3((unsigned)std::min<size_t>(T, 8192)), dim3(TILE_THREADS), 0, c->stream, (TileRec *)c->tile_rec.p, c->tile_stat.p, (uint32_t)T,
+                                   (const uint32_t *)c->cig_off32.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->cig.p);
+                HIP_TRY(hipMemcpyAsync(c->h_tile_stat.data(), c->tile_stat.p, T * sizeof(TileStat), hipMemcpyDeviceToHost, c->stream));
+            }
             HIP_TRY(hipStreamSynchronize(c->stream));       // (locals)
         }
     }
@@ -1021,6 +1038,16 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     // the slab pipeline wants the straight-line walk: thresholds that fit a CIGAR word (else: the classic kernels)
     c->slab = c->slab_ok && p.min_intron >= 0 && p.min_intron < (1 << 28) && p.max_delet >= -1 && p.max_delet < (1 << 28) - 1 &&
               (!c->wide_cigar || p.min_exon >= 1);           // (k_walk_slab_long has no -e < 1 form: the classic kernels take that)
+    // the one-kernel tile path: short CIGARs whose exon counts the CIGAR lengths bound (-e >= 1)
+    c->tile = c->slab && c->want_pipeline >= 2 && !c->wide_cigar && p.min_exon >= 1;
+    if (c->tile) {
+        // A tile whose exon count the first kernel cannot derive from the upload's index (a threshold is borderline in it) publishes it
+        // from k_tile, and every later tile's write-out waits for it: fine for a few, a convoy for many (measured: 3 x the kernel when
+        // every tile does) -- such a run takes the two-kernel path.
+        int64_t inexact = 0;
+        for (const TileStat &st : c->h_tile_stat) inexact += tile_exact(st, p.min_exon, p.min_intron, p.max_delet) ? 0 : 1;
+        if (inexact * 50 > c->n_tiles + 800 && !getenv("L2R_TILE_ANYWAY")) c->tile = false;
+    }
     if (c->slab) {
         // ---- two light kernels at full occupancy: the walk (exons into the tiles' slabs, read-order places, descriptors), a scan of
         //      the tiles' exon counts, then the probes, which write the read-order results (l2r_slab.hip.h).  Every launch does all
@@ -1035,6 +1062,42 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p;
         sa.chunk_on = (c->ablate & 32) ? 0u : 1u;          // (L2R_ABLATE bit 2: no 64-member windows, bit 5: no chunked windows)
         sa.wide_list = c->wide_list.p; sa.chunk_list = c->chunk_list.p; sa.list_cnt = c->list_cnt.p; sa.tile_flags = c->tile_flags.p;
+        sa.lb_tile = c->lb_tile.p; sa.lb_blk = c->lb_blk.p; sa.lb_sup = c->lb_sup.p; sa.lb_err = c->totals.p + 6; sa.fb_list = c->fb_list.p; sa.exon_total = c->totals.p + 0; sa.tile_stat = c->tile_stat.p;
+        // (with the accepted list wanted and no junction table to decide later, the tiles leave their accepted chunks themselves)
+        const bool probe_acc = (c->want & L2R_WANT_ACCEPTED) && c->n_sj == 0;
+#define launch_probe_k(L, A, D, LIST, G) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L, A, D, LIST>), dim3(G), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
+            (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p, (const uint32_t *)c->fb_list.p)
+        // (the tiles k_tile left in slab form leave no accepted chunks themselves: they stay k_gather_accepted's -- half the instantiations)
+#define launch_probe_level(L, LIST, G) do { if (p.ss_dis > 0) { if (probe_acc && !LIST) launch_probe_k(L, !LIST, true, LIST, G); else launch_probe_k(L, false, true, LIST, G); } \
+                                   else { if (probe_acc && !LIST) launch_probe_k(L, !LIST, false, LIST, G); else launch_probe_k(L, false, false, LIST, G); } } while (0)
+#define launch_probe(LIST, G) do { switch (p.full_level) { \
+        case 1: launch_probe_level(1, LIST, G); break; case 2: launch_probe_level(2, LIST, G); break; case 3: launch_probe_level(3, LIST, G); break; \
+        case 4: launch_probe_level(4, LIST, G); break; case 5: launch_probe_level(5, LIST, G); break; default: launch_probe_level(0, LIST, G); break; } } while (0)
+        if (c->tile) {
+            // ---- ONE kernel per tile (l2r_tile.hip.h): the descriptors first (spans from the upload), then walk + probes + write-out in
+            //      one workgroup; k_probe_slab behind it for the few tiles that kept the slab form (none on most inputs)
+            const DescribeScan job{c->tile_total.p, c->tile_xbase.p, c->totals.p + 0, c->n_tiles};
+            const unsigned gd = (unsigned)std::max<int64_t>((c->n_tiles + DESCRIBE_TILES - 1) / DESCRIBE_TILES, 1);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_describe_scan<true>), dim3(gd), dim3(TILE_THREADS), 0, s, sa, job, 0u, (const TileRec *)c->tile_rec.p);
+            MARK(ST_SCAN1);
+            const unsigned gf = fused_grid(c->n_tiles);
+#define launch_tile_k(L, A, D) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile<L, A, D>), dim3(gf), dim3(TILE_THREADS), 0, s, sa, (const TileRec *)c->tile_rec.p, (const TileWin *)c->tw.p, (const TileStat *)c->tile_stat.p, c->tile_xbase.p)
+#define launch_tile_level(L) do { if (p.ss_dis > 0) { if (probe_acc) launch_tile_k(L, true, true); else launch_tile_k(L, false, true); } \
+                                  else { if (probe_acc) launch_tile_k(L, true, false); else launch_tile_k(L, false, false); } } while (0)
+            switch (p.full_level) {
+            case 1: launch_tile_level(1); break;
+            case 2: launch_tile_level(2); break;
+            case 3: launch_tile_level(3); break;
+            case 4: launch_tile_level(4); break;
+            case 5: launch_tile_level(5); break;
+            default: launch_tile_level(0); break;
+            }
+#undef launch_tile_level
+#undef launch_tile_k
+            MARK(ST_FAST);
+            const unsigned gl = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 2);
+            launch_probe(true, gl);
+        } else {
         if (c->wide_cigar)
             hipLaunchKernelGGL(k_walk_slab_long, dim3(gx), dim3(TILE_THREADS), pass_a_dynamic_lds(c->reads_per_tile), s, sa, (const TileRec *)c->tile_rec.p);
         else if (p.min_exon >= 1)
@@ -1055,24 +1118,14 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
                 n_scan = 0;
             }
             const unsigned gd = n_scan + (unsigned)std::max<int64_t>((c->n_tiles + DESCRIBE_TILES - 1) / DESCRIBE_TILES, 1);
-            hipLaunchKernelGGL(k_describe_scan, dim3(gd), dim3(TILE_THREADS), 0, s, sa, job, (uint32_t)n_scan);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_describe_scan<false>), dim3(gd), dim3(TILE_THREADS), 0, s, sa, job, (uint32_t)n_scan, (const TileRec *)nullptr);
         }
         MARK(ST_FAST);
-        // (with the accepted list wanted and no junction table to decide later, the tiles leave their accepted chunks themselves)
-        const bool probe_acc = (c->want & L2R_WANT_ACCEPTED) && c->n_sj == 0;
-#define launch_probe_k(L, A, D) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L, A, D>), dim3(gx), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
-            (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p)
-#define launch_probe_level(L) do { if (p.ss_dis > 0) { if (probe_acc) launch_probe_k(L, true, true); else launch_probe_k(L, false, true); } \
-                                   else { if (probe_acc) launch_probe_k(L, true, false); else launch_probe_k(L, false, false); } } while (0)
-        switch (p.full_level) {
-        case 1: launch_probe_level(1); break;
-        case 2: launch_probe_level(2); break;
-        case 3: launch_probe_level(3); break;
-        case 4: launch_probe_level(4); break;
-        case 5: launch_probe_level(5); break;
-        default: launch_probe_level(0); break;
+        launch_probe(false, gx);
         }
+#undef launch_probe
 #undef launch_probe_level
+#undef launch_probe_k
         {   // the tiles with 33 .. 63 window members (none on most inputs: the grid finds an empty list and leaves)
             const WideArgs wa{c->tw64.p};
             const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 5);
@@ -1137,7 +1190,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         hipLaunchKernelGGL(k_classify_generic, dim3(gg), dim3(TILE_THREADS), 0, s, c->totals.p + 3, c->redo.p, c->r_tid.p, c->r_rev.p,
                            (c->slab ? (const int32_t *)nullptr : j0),
                            c->hdr.p, c->anno_ex.p, p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->info.p, c->ref_tx.p,
-                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles, cd);
+                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles, cd, c->list_cnt.p,
+                           c->lb_sup.p, (uint32_t)(c->lb_sup.p ? (c->n_tiles >> LB_SUP_SHIFT) + 1 : 0));
     }
     MARK(ST_SJ);
     if (c->n_sj > 0) {
@@ -1191,6 +1245,23 @@ int l2r_debug_stamps(l2r_ctx *c, unsigned long long *out, int n)
     return 0;
 }
 
+/* diagnostics (L2R_STAMPS=1, one-kernel tile path): per tile four words -- the 100 MHz clock at its start << 3 | its XCD, the clock at the
+   publication of its exon count, at the begin and at the end of its wait for the counts of the tiles in front */
+int l2r_debug_tile_times(l2r_ctx *c, uint32_t *out, int64_t n_tiles)
+{
+    if (!c || !out) return fail(-1, "[l2r_debug_tile_times] null argument");
+    if (!c->tile || !c->ran || n_tiles > c->n_tiles) return fail(-1, "[l2r_debug_tile_times] no run of the one-kernel tile path to report");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t *src[4] = {c->tile_total.p, c->tile_acc.p, c->tile_acc_ex.p, c->tile_flags.p};
+    std::vector<uint32_t> h((size_t)n_tiles);
+    for (int k = 0; k < 4; ++k) {
+        HIP_TRY(hipMemcpyAsync(h.data(), src[k], (size_t)n_tiles * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int64_t i = 0; i < n_tiles; ++i) out[4 * i + k] = h[(size_t)i];
+    }
+    return 0;
+}
+
 /* diagnostics: [0] reads the last run sent to the generic kernel, [1] dictionary entries flagged wide,
    [2] compact transcripts, [3] tiles, [4..11] tiles by the reason they are not fast, [12] tiles of k_probe_slab_wide */
 int l2r_debug_counters(l2r_ctx *c, long long *out, int n)
@@ -1228,6 +1299,7 @@ const char *l2r_stage_kernel(l2r_ctx *c, int stage)
     static const char *const classic[L2R_N_STAGES] = {"k_pass_a", "k_scan_u32 (tile sums)", "k_classify_fast", "k_classify_generic",
                                                       "k_validate_sj", "k_scan_accepted (k_scan_u32 of the accepted counts)", "k_gather_accepted", ""};
     if (stage >= 3 || !c->slab) return classic[stage];
+    if (c->tile) return stage == 0 ? "k_describe_scan (tile descriptors + tile lists; first kernel of the run)" : stage == 1 ? "k_tile (walk + probes + write-out, one workgroup per tile)" : "k_probe_slab (tiles k_tile left in slab form) (+ k_probe_slab_wide + k_probe_slab_chunked)";
     return stage == 0 ? (c->wide_cigar ? "k_walk_slab_long" : "k_walk_slab") : stage == 1 ? "k_describe_scan (tile descriptors + scan of the exon counts + tile lists)" : "k_probe_slab (+ k_probe_slab_wide + k_probe_slab_chunked)";
 }
 
@@ -1274,6 +1346,7 @@ static int fetch_totals(l2r_ctx *c)
     HIP_TRY(hipMemcpyAsync(dev, c->totals.p, sizeof dev, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     // accepted exons = the chunks the classification kernel placed itself (cursor) + the ones k_gather_accepted placed
+    if (c->tile && dev[6] != 0u) return fail(-2, "[l2r] k_tile: a tile waited in vain for the exon counts of the tiles in front of it (L2R_PIPELINE=slab avoids the kernel)");
     c->h_totals[0] = dev[0]; c->h_totals[1] = dev[1] + dev[5]; c->h_totals[2] = dev[2] + dev[4];
     if (!(c->want & L2R_WANT_ACCEPTED)) c->h_totals[1] = c->h_totals[2] = 0;
     c->totals_valid = true;

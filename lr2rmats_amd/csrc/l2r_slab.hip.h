@@ -73,6 +73,22 @@ struct TileRec { uint32_t r0, n_act, sbase, rows; int32_t tid0, lo; uint32_t pad
 // first bucket and bucket count (looked up by one wave of k_walk_slab while its CIGAR vectors are in flight)
 // ... and, for the probe kernels, the tile's reads and slab once more (one record instead of three arrays + the first read's position)
 struct TileSpan { int32_t tid, lo, hi; uint32_t rows; int32_t jl, tb, nb, pad; uint32_t r0, n_act, sbase, fat; };     // fat: see SlabArgs::pl
+// What the upload knows of a tile's CIGAR operations whatever the parameters (k_tile_index, l2r_tile.hip.h): the N operations of its
+// reads, the shortest of them, the longest D operation, and the shortest stretch of reference bases between two N operations of one
+// read.  With them a run knows the tile's EXON COUNT without its CIGARs whenever no threshold is borderline inside the tile: every N is
+// an intron (-i <= the shortest N), no D cuts (-t >= the longest D), no inner exon is dropped (-e <= the shortest stretch) => exons =
+// reads + N operations (src/bam2gtf.c:41-74).
+struct TileStat { int32_t n_ops_n, min_n, max_d, min_seg; };
+__host__ __device__ __forceinline__ bool tile_exact(const TileStat &st, int min_exon, int min_intron, int max_delet)
+{
+    return st.min_n >= min_intron && st.max_d <= max_delet && st.min_seg >= min_exon;
+}
+// One-kernel tile path: the words a tile's exon count travels through to the later tiles (SlabArgs::lb_tile / lb_blk / lb_sup): a sum
+// in bits 0-39, from bit 40 on the number of counts it holds.  A block = the 16 tiles of one k_describe_scan workgroup (and of one XCD
+// group of k_tile), a super-block = 64 blocks.
+constexpr int LB_SHIFT = 40;
+constexpr unsigned long long LB_SUM_MASK = (1ull << LB_SHIFT) - 1ull;
+constexpr int LB_BLK_SHIFT = 4, LB_BLK = 1 << LB_BLK_SHIFT, LB_SUP_SHIFT = 10;
 struct SlabArgs {
     PipeArgs g;
     const uint32_t *tile_sbase;                          // first element of every tile's slab (+ a closing entry)
@@ -95,6 +111,15 @@ struct SlabArgs {
     uint32_t *tile_flags;                                // every tile's descriptor flags once more, densely (what TileLists reads)
     uint32_t chunk_on;
     uint32_t n_tiles;
+    // one-kernel tile path (l2r_tile.hip.h): the tiles' exon counts on their way to every later tile's first result slot -- lb_tile[t]
+    // (one word per tile), lb_blk[t >> 4] and lb_sup[t >> 10] (sums over 16 tiles / 64 blocks), LB_* above.  k_describe_scan<true> writes
+    // the words of the tiles and blocks (with the counts it knows from tile_stat: all of them unless a threshold is borderline) and adds
+    // the complete blocks to lb_sup, which k_classify_generic clears behind a run.  lb_err: set by a tile that waited in vain
+    // (diagnostics; never seen).  fb_list: the tiles k_tile left in slab form for k_probe_slab (list_cnt[4] entries).
+    unsigned long long *lb_tile, *lb_blk, *lb_sup;
+    const TileStat *tile_stat;
+    uint32_t *lb_err, *fb_list;
+    uint32_t *exon_total;                                // the run's exon count (k_tile: written by the last tile)
 };
 typedef const __attribute__((address_space(4))) SlabArgs *SlabArgsK;
 __device__ __forceinline__ SlabArgsK slab_args()
@@ -128,81 +153,20 @@ __device__ __forceinline__ void slab_preloc(SlabArgsK sa, uint32_t t, uint32_t a
     else { const uint32_t w = ld32(sa->pl, at); pre = w & PL_PRE_MASK; loc = w >> PL_LOC_SHIFT; }
 }
 
-// ---------------------------------------------------------------------------------------------------------- k_walk_slab
-// GENERAL: -e < 1 (an inner exon may be empty: every exon's sanity is checked, and the read leaves the slab when it has more exons
-// than the tile's slab has rows -- with min_exon >= 1 the row bound from the CIGAR length makes that impossible).
-template <bool GENERAL>
-__global__ __launch_bounds__(TILE_THREADS, 8)
-void k_walk_slab(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
+// ---------------------------------------------------------------------------------------------------------- slab_walk_tile
+// What k_walk_slab does with a tile once every slot holds its read's record and the head of its CIGAR (cg: SLAB_HEAD words in registers,
+// words behind the read's last op = "I, length 0"): the walk into the tile's slab, the outliers' literal walk into the dense area, the
+// reads' places in read order, their words (pl), the tile's span record and exon count.  A device function because the one-kernel tile
+// path (l2r_tile.hip.h) hands the tiles it cannot finish itself -- windows beyond 32 members, outliers, fat tiles -- over in exactly this
+// form.  `slot`: the thread's slot (the column of the slab and the place of its word; k_walk_slab: its thread number); W: 2 x 256 + 12 words
+// of LDS.  FIRST: this kernel is the first of a run (clears the run's counters).  Returns the tile's exon count (every thread).
+struct WalkLds { uint32_t *cnt, *loc; int *wmax; uint32_t *wn, *nmax; };
+template <bool GENERAL, bool FIRST>
+__device__ __forceinline__ uint32_t slab_walk_tile(SlabArgsK sa, PipeArgsK a, uint32_t t, uint32_t r0, uint32_t n_act, uint32_t sbase, uint32_t rows_tile, int32_t tid0, int32_t pos0,
+                                                   uint32_t slot, bool active, uint32_t c_lo, int32_t pos, uint32_t xw, uint32_t (&cg)[SLAB_HEAD], const WalkLds &W)
 {
-    __shared__ uint32_t s_hist[WAVE];
-    __shared__ uint32_t s_x0[TILE_THREADS], s_x1[TILE_THREADS], s_x2[TILE_THREADS];       // the records' fields, slot order
-    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[TILE_THREADS], s_loc[TILE_THREADS];      // exon counts / their exclusive scan, READ order
-    __shared__ int s_wmax[TILE_THREADS / WAVE];
-    __shared__ uint32_t s_wn[TILE_THREADS / WAVE], s_nmax[TILE_THREADS / WAVE];
-    (void)kernarg_block;
-    const SlabArgsK sa = slab_args();
-    const PipeArgsK a = pipe_args();
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
-    if (t >= sa->n_tiles) return;
-    // (the tile's record from the upload: the vector loads below are the kernel's second round trip, not its fourth)
-    const TileRec rec = u_rec[t];
-    asm volatile("" :: "s"(rec.r0), "s"(rec.n_act), "s"(rec.sbase), "s"(rec.rows), "s"(rec.tid0), "s"(rec.lo));
-    const uint32_t r0 = rec.r0, n_act = rec.n_act;
-    const int32_t tid0 = rec.tid0, pos0 = rec.lo - 1;
-    const uint32_t sbase = rec.sbase, rows_tile = rec.rows;
-    // ---- the tile's reads by falling CIGAR length (counting sort, 64 bins): thread i brings read i, slot s takes what landed there
-    {
-        const uint32_t i = threadIdx.x;
-        uint32_t c_lo = 0u, c = 0u, rev = 0u; int32_t pos = 0;
-        if (i < n_act) {
-            const uint32_t *const p_off = sa->cig_off32;
-            c_lo = ld32(p_off, r0 + i); c = ld32(p_off, r0 + i + 1u) - c_lo;
-            pos = ld32(a->f.r_pos, r0 + i); rev = ld32(a->f.r_rev, r0 + i) ? 1u : 0u;
-        }
-        if (i < (uint32_t)WAVE) s_hist[i] = 0u;
-        __syncthreads();
-        const uint32_t est = i < n_act ? max(1u, min((c + 1u) >> 1, (uint32_t)(WAVE - 1))) : 0u;      // threads without a read sort last
-        const uint32_t bin = (uint32_t)(WAVE - 1) - est;
-        const uint32_t rank = atomicAdd(&s_hist[bin], 1u);
-        __syncthreads();
-        if (i < (uint32_t)WAVE) { const uint32_t v = s_hist[i]; s_hist[i] = wave_inclusive_scan(v) - v; }
-        __syncthreads();
-        const uint32_t slot = s_hist[bin] + rank;
-        s_x0[slot] = c_lo; s_x1[slot] = (uint32_t)pos; s_x2[slot] = min(c, 0xffffu) | (rev << 16) | (i << 24);
-        __syncthreads();
-    }
-    const bool active = threadIdx.x < n_act;
-    const uint32_t c_lo = s_x0[threadIdx.x], xw = s_x2[threadIdx.x];
-    const int32_t pos = (int32_t)s_x1[threadIdx.x];
     const uint32_t n_cig = xw & 0xffffu, idx = xw >> 24;             // (n_cig 65535: that many or more)
-    // ---- the head of the read's CIGAR: six 16-byte vectors, all in flight at once; words behind the last op become "I, length 0"
-    uint32_t cg[SLAB_HEAD];
-#pragma unroll
-    for (int i = 0; i < SLAB_HEAD; ++i) cg[i] = 1u;
-    if (active) {
-        const uint32_t *const words = a->f.cig + c_lo;
-#pragma unroll
-        for (int q = 0; q < SLAB_HEAD_VEC; ++q)
-            if ((uint32_t)(4 * q) < n_cig) {
-                const v4i_a4 x = *reinterpret_cast<const v4i_a4 *>(words + 4 * q);
-                cg[4 * q] = (uint32_t)x.x; cg[4 * q + 1] = (uint32_t)x.y; cg[4 * q + 2] = (uint32_t)x.z; cg[4 * q + 3] = (uint32_t)x.w;
-            }
-    }
-    // The head of the tile descriptor's load chain (k_describe_scan): the cursor value of the tile's first read (first transcript its
-    // sweep can reach: three dependent SCALAR loads, on their own counter) and the chromosome's bucket range, by one wave, while the
-    // CIGAR vectors above are in flight.
-    if (wv == TILE_THREADS / WAVE - 1 && n_act) {
-        CursorDir cd;
-        cd.key = a->cd.key; cd.dir = a->cd.dir; cd.kb_base = a->cd.kb_base; cd.n_tid = a->cd.n_tid; cd.n_tx = a->cd.n_tx;
-        const int jl = cursor_value(cd, tid0, pos0 + 1);
-        int tb = 0, nb = 0;
-        if (tid0 >= 0 && tid0 < a->n_tid_dir) { tb = a->tid_base[tid0]; nb = a->tid_base[tid0 + 1] - tb; }
-        if (lane == 0) reinterpret_cast<int4 *>(sa->span + t)[1] = make_int4(jl, tb, nb, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < SLAB_HEAD; ++i) cg[i] = (uint32_t)i < n_cig ? cg[i] : 1u;
     DevParams p;
     p.min_exon = a->f.p.min_exon; p.min_intron = a->f.p.min_intron; p.max_delet = a->f.p.max_delet;
     const uint32_t t3 = ((uint32_t)p.min_intron << 4) | 3u, t2 = ((uint32_t)(p.max_delet + 1) << 4) | 2u;      // op and length compare as one number
@@ -210,7 +174,7 @@ void k_walk_slab(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
     bool outlier = GENERAL ? n_cig > (uint32_t)SLAB_HEAD : slab_rows_of(n_cig) > (uint32_t)SLAB_ROWS;
     const int c_max = wave_max((active && !outlier) ? (int)min(n_cig, (uint32_t)SLAB_HEAD) : 0);
     uint32_t *const rows = sa->slab_row;
-    const uint32_t off = sbase + threadIdx.x;
+    const uint32_t off = sbase + slot;
     const int32_t base = pos0 + 1;                           // the tile's first base (sorted records: the first read's)
     uint32_t n = 0u;
     int el = INT32_MIN;
@@ -278,12 +242,12 @@ void k_walk_slab(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
         put(w.n, w.start, w.end);
         st32(rows, off, run);                     // (row 0 of the unused column: where the probe side finds the run)
     }
-    s_cnt[idx] = active ? n : 0u;                        // (every entry is written: idx is a permutation of 0 .. 255)
+    W.cnt[idx] = active ? n : 0u;                        // (every entry is written: idx is a permutation of 0 .. 255)
     const int m = wave_max(active ? el : INT32_MIN);
     const int wn = wave_max((active && !outlier) ? (int)n : 0);
     const int wn_all = wave_max(active ? (int)min(n, 0x7fffffffu) : 0);
-    if (lane == 0) { s_wmax[wv] = m; s_wn[wv] = (uint32_t)min(wn, 255); s_nmax[wv] = (uint32_t)wn_all; }
-    if (t == 0u && threadIdx.x == 0) {
+    if (lane == 0) { W.wmax[wv] = m; W.wn[wv] = (uint32_t)min(wn, 255); W.nmax[wv] = (uint32_t)wn_all; }
+    if (FIRST && t == 0u && threadIdx.x == 0) {
         // the run's counters (this kernel is the first of a run): redo list, chunk cursor of the accepted list.
         // (The cursor of the outlier area is cleared by k_probe_slab for the next run.)
         uint32_t *const cnt = a->f.redo_count;
@@ -296,19 +260,19 @@ void k_walk_slab(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
     // ---- every read's place among the tile's exons in READ order: each wave scans the 256 counts (four per lane) for itself
     uint32_t total;
     {
-        const uint4 c4 = reinterpret_cast<const uint4 *>(s_cnt)[lane];
+        const uint4 c4 = reinterpret_cast<const uint4 *>(W.cnt)[lane];
         const uint32_t sum = c4.x + c4.y + c4.z + c4.w;
         const uint32_t inc = wave_inclusive_scan(sum), ex = inc - sum;
-        reinterpret_cast<uint4 *>(s_loc)[lane] = make_uint4(ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z);     // (the four waves write the same values)
+        reinterpret_cast<uint4 *>(W.loc)[lane] = make_uint4(ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z);     // (the four waves write the same values)
         total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
     }
     // (a fat tile: some read's exon count or place does not fit the packed word -- only outliers make such tiles)
-    const bool fat = total >= PL_LOC_LIMIT || max(max(s_nmax[0], s_nmax[1]), max(s_nmax[2], s_nmax[3])) >= PL_N_LIMIT;
+    const bool fat = total >= PL_LOC_LIMIT || max(max(W.nmax[0], W.nmax[1]), max(W.nmax[2], W.nmax[3])) >= PL_N_LIMIT;
     if (active) {
-        const uint32_t at = r0 + threadIdx.x;
+        const uint32_t at = r0 + slot;
         const uint32_t word = idx | (((xw >> 16) & 1u) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (outlier ? PRE_DENSE : 0u) | (n << PRE_N_SHIFT);
-        if (!fat) sa->pl[at] = word | (s_loc[idx] << PL_LOC_SHIFT);
-        else { sa->pl[at] = 0u; sa->pre_x[at] = word; sa->loc_x[at] = s_loc[idx]; }
+        if (!fat) sa->pl[at] = word | (W.loc[idx] << PL_LOC_SHIFT);
+        else { sa->pl[at] = 0u; sa->pre_x[at] = word; sa->loc_x[at] = W.loc[idx]; }
     }
     // ---- what the tile's descriptor is made from (k_describe_scan, one wave per tile, in the launch of the scan): its chromosome, its
     //      first and last base, the rows each wave of the probe kernels has to look at; and its exon count
@@ -316,11 +280,91 @@ void k_walk_slab(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
     //       dependent round trips kept the workgroup's LDS and wave slots for 0.047 of the kernel's 0.284 ms.)
     if (threadIdx.x == 0) {
         a->tile_total[t] = total;                        // (one word per tile, scanned by k_describe_scan: a single counter would serialise 156 k waves)
-        const int32_t tile_hi = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-        const uint32_t rows = s_wn[0] | (s_wn[1] << 8) | (s_wn[2] << 16) | (s_wn[3] << 24);
+        const int32_t tile_hi = max(max(W.wmax[0], W.wmax[1]), max(W.wmax[2], W.wmax[3]));
+        const uint32_t rows = W.wn[0] | (W.wn[1] << 8) | (W.wn[2] << 16) | (W.wn[3] << 24);
         reinterpret_cast<int4 *>(sa->span + t)[0] = make_int4(tid0, pos0 + 1, tile_hi, (int)rows);
         reinterpret_cast<int4 *>(sa->span + t)[2] = make_int4((int)r0, (int)n_act, (int)sbase, fat ? 1 : 0);
     }
+    return total;
+}
+
+// ---------------------------------------------------------------------------------------------------------- k_walk_slab
+// GENERAL: -e < 1 (an inner exon may be empty: every exon's sanity is checked, and the read leaves the slab when it has more exons
+// than the tile's slab has rows -- with min_exon >= 1 the row bound from the CIGAR length makes that impossible).
+template <bool GENERAL>
+__global__ __launch_bounds__(TILE_THREADS, 8)
+void k_walk_slab(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
+{
+    __shared__ uint32_t s_hist[WAVE];
+    __shared__ uint32_t s_x0[TILE_THREADS], s_x1[TILE_THREADS], s_x2[TILE_THREADS];       // the records' fields, slot order
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[TILE_THREADS], s_loc[TILE_THREADS];      // exon counts / their exclusive scan, READ order
+    __shared__ int s_wmax[TILE_THREADS / WAVE];
+    __shared__ uint32_t s_wn[TILE_THREADS / WAVE], s_nmax[TILE_THREADS / WAVE];
+    (void)kernarg_block;
+    const SlabArgsK sa = slab_args();
+    const PipeArgsK a = pipe_args();
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
+    if (t >= sa->n_tiles) return;
+    // (the tile's record from the upload: the vector loads below are the kernel's second round trip, not its fourth)
+    const TileRec rec = u_rec[t];
+    asm volatile("" :: "s"(rec.r0), "s"(rec.n_act), "s"(rec.sbase), "s"(rec.rows), "s"(rec.tid0), "s"(rec.lo));
+    const uint32_t r0 = rec.r0, n_act = rec.n_act;
+    const int32_t tid0 = rec.tid0, pos0 = rec.lo - 1;
+    const uint32_t sbase = rec.sbase, rows_tile = rec.rows;
+    // ---- the tile's reads by falling CIGAR length (counting sort, 64 bins): thread i brings read i, slot s takes what landed there
+    {
+        const uint32_t i = threadIdx.x;
+        uint32_t c_lo = 0u, c = 0u, rev = 0u; int32_t pos = 0;
+        if (i < n_act) {
+            const uint32_t *const p_off = sa->cig_off32;
+            c_lo = ld32(p_off, r0 + i); c = ld32(p_off, r0 + i + 1u) - c_lo;
+            pos = ld32(a->f.r_pos, r0 + i); rev = ld32(a->f.r_rev, r0 + i) ? 1u : 0u;
+        }
+        if (i < (uint32_t)WAVE) s_hist[i] = 0u;
+        __syncthreads();
+        const uint32_t est = i < n_act ? max(1u, min((c + 1u) >> 1, (uint32_t)(WAVE - 1))) : 0u;      // threads without a read sort last
+        const uint32_t bin = (uint32_t)(WAVE - 1) - est;
+        const uint32_t rank = atomicAdd(&s_hist[bin], 1u);
+        __syncthreads();
+        if (i < (uint32_t)WAVE) { const uint32_t v = s_hist[i]; s_hist[i] = wave_inclusive_scan(v) - v; }
+        __syncthreads();
+        const uint32_t slot = s_hist[bin] + rank;
+        s_x0[slot] = c_lo; s_x1[slot] = (uint32_t)pos; s_x2[slot] = min(c, 0xffffu) | (rev << 16) | (i << 24);
+        __syncthreads();
+    }
+    const bool active = threadIdx.x < n_act;
+    const uint32_t c_lo = s_x0[threadIdx.x], xw = s_x2[threadIdx.x];
+    const int32_t pos = (int32_t)s_x1[threadIdx.x];
+    const uint32_t n_cig = xw & 0xffffu;                            // (65535: that many or more)
+    // ---- the head of the read's CIGAR: six 16-byte vectors, all in flight at once; words behind the last op become "I, length 0"
+    uint32_t cg[SLAB_HEAD];
+#pragma unroll
+    for (int i = 0; i < SLAB_HEAD; ++i) cg[i] = 1u;
+    if (active) {
+        const uint32_t *const words = a->f.cig + c_lo;
+#pragma unroll
+        for (int q = 0; q < SLAB_HEAD_VEC; ++q)
+            if ((uint32_t)(4 * q) < n_cig) {
+                const v4i_a4 x = *reinterpret_cast<const v4i_a4 *>(words + 4 * q);
+                cg[4 * q] = (uint32_t)x.x; cg[4 * q + 1] = (uint32_t)x.y; cg[4 * q + 2] = (uint32_t)x.z; cg[4 * q + 3] = (uint32_t)x.w;
+            }
+    }
+    // The head of the tile descriptor's load chain (k_describe_scan): the cursor value of the tile's first read (first transcript its
+    // sweep can reach: three dependent SCALAR loads, on their own counter) and the chromosome's bucket range, by one wave, while the
+    // CIGAR vectors above are in flight.
+    if (wv == TILE_THREADS / WAVE - 1 && n_act) {
+        CursorDir cd;
+        cd.key = a->cd.key; cd.dir = a->cd.dir; cd.kb_base = a->cd.kb_base; cd.n_tid = a->cd.n_tid; cd.n_tx = a->cd.n_tx;
+        const int jl = cursor_value(cd, tid0, pos0 + 1);
+        int tb = 0, nb = 0;
+        if (tid0 >= 0 && tid0 < a->n_tid_dir) { tb = a->tid_base[tid0]; nb = a->tid_base[tid0 + 1] - tb; }
+        if (lane == 0) reinterpret_cast<int4 *>(sa->span + t)[1] = make_int4(jl, tb, nb, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < SLAB_HEAD; ++i) cg[i] = (uint32_t)i < n_cig ? cg[i] : 1u;
+    const WalkLds W{s_cnt, s_loc, s_wmax, s_wn, s_nmax};
+    (void)slab_walk_tile<GENERAL, true>(sa, a, t, r0, n_act, sbase, rows_tile, tid0, pos0, threadIdx.x, active, c_lo, pos, xw, cg, W);
 }
 
 // ---------------------------------------------------------------------------------------------------------- k_walk_slab_long
@@ -574,24 +618,60 @@ constexpr int DESCRIBE_G = 16;                           // lanes per tile
 constexpr int DESCRIBE_TILES = TILE_THREADS / DESCRIBE_G;       // tiles per workgroup
 constexpr int DESCRIBE_SEG = SEG_COUNT;                 // counts per scanning workgroup
 constexpr int64_t DESCRIBE_SCAN_MAX = (int64_t)DESCRIBE_SEG * 64;    // (262 k tiles = 67 M reads: beyond that the summing in front costs more than it saves)
+// FIRST (the one-kernel tile path, l2r_tile.hip.h): this launch is the FIRST kernel of a run -- a tile's span comes from the record the
+// upload made (u_rec: chromosome, first base, and the largest read end, which no parameter changes), the head of the descriptor's load
+// chain (cursor value, bucket range) is looked up here, the words k_tile's exon counts travel through are cleared, and so are the
+// run's counters; no scan role (n_scan = 0: k_tile finds the tiles' first slots itself).
+template <bool FIRST>
 __global__ __launch_bounds__(TILE_THREADS, 8)
-void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan)
+void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan, const TileRec *__restrict__ u_rec)
 {
     __shared__ int s_win[DESCRIBE_TILES][64];
     __shared__ uint32_t s_flags[DESCRIBE_TILES];
+    __shared__ uint32_t s_tot[DESCRIBE_TILES][2];
     __shared__ uint32_t s_part[2][TILE_THREADS / WAVE];
+    static_assert(DESCRIBE_TILES == LB_BLK, "a workgroup's tiles are one block of the exon counts' words");
     (void)kernarg_block;
-    if (blockIdx.x < n_scan) { scan_segment(job, blockIdx.x, n_scan, s_part); return; }      // ---- scan role: segment blockIdx.x of the counts
+    if (!FIRST && blockIdx.x < n_scan) { scan_segment(job, blockIdx.x, n_scan, s_part); return; }      // ---- scan role: segment blockIdx.x of the counts
     // ---- describe role
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     const int g = lane / DESCRIBE_G, gl = lane % DESCRIBE_G, slot = wv * (WAVE / DESCRIBE_G) + g;
-    const uint32_t t0 = (blockIdx.x - n_scan) * (uint32_t)DESCRIBE_TILES;
+    const uint32_t t0 = (blockIdx.x - (FIRST ? 0u : n_scan)) * (uint32_t)DESCRIBE_TILES;
     const uint32_t t = t0 + (uint32_t)slot;
     uint32_t flags = TD_FAST;                            // (behind the last tile: nobody's)
+    unsigned long long my_total = 0ull;                  // FIRST, lane 0 of a tile's group: {1, its exon count} where it is known here
+    if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) {
+        // the run's counters: redo list, chunk cursor of the accepted list, the outlier area's cursor, the work cursors of the list-driven
+        // kernels and k_probe_slab's list.  (The lists of the 64-bit-mask / chunked kernel are appended to by THIS launch: their
+        // counts are cleared behind their readers, by k_classify_generic.)
+        uint32_t *const cnt = a->f.redo_count;
+        cnt[0] = 0u; cnt[1] = 0u; cnt[2] = 0u;
+        *sa->ovf_cursor = 0ull; *sa->lb_err = 0u;
+        uint32_t *const lc = sa->list_cnt;
+        lc[2] = 0u; lc[3] = 0u; lc[4] = 0u; lc[5] = 0u;
+    }
     if (t < sa->n_tiles) {
-        const int4 spv = reinterpret_cast<const int4 *>(sa->span + t)[0], spw = reinterpret_cast<const int4 *>(sa->span + t)[1];
+        int4 spv, spw;
+        if (FIRST) {
+            const int4 rv = reinterpret_cast<const int4 *>(u_rec + t)[1];          // {tid0, lo, hi, .}
+            CursorDir cd;
+            cd.key = a->cd.key; cd.dir = a->cd.dir; cd.kb_base = a->cd.kb_base; cd.n_tid = a->cd.n_tid; cd.n_tx = a->cd.n_tx;
+            const int jl = cursor_value(cd, rv.x, rv.y);
+            int tb = 0, nb = 0;
+            if (rv.x >= 0 && rv.x < a->n_tid_dir) { tb = a->tid_base[rv.x]; nb = a->tid_base[rv.x + 1] - tb; }
+            spv = make_int4(rv.x, rv.y, rv.z, 0); spw = make_int4(jl, tb, nb, 0);
+            // the tile's exon count, where no threshold is borderline inside it: known to every later tile from here on
+            if (gl == 0) {
+                const int4 r0v = reinterpret_cast<const int4 *>(u_rec + t)[0];         // {r0, n_act, sbase, rows}
+                const int4 sv = *reinterpret_cast<const int4 *>(sa->tile_stat + t);
+                const TileStat st{sv.x, sv.y, sv.z, sv.w};
+                const bool exact = tile_exact(st, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet) && !(a->f.p.ablate & 256);
+                my_total = exact ? (1ull << LB_SHIFT) | (unsigned long long)(uint32_t)(r0v.y + st.n_ops_n) : 0ull;
+                sa->lb_tile[t] = my_total;
+            }
+        } else { spv = reinterpret_cast<const int4 *>(sa->span + t)[0]; spw = reinterpret_cast<const int4 *>(sa->span + t)[1]; }
         flags = make_descriptor<DESCRIBE_G>(a, gl, g * DESCRIBE_G, spv.x, spv.y, spv.z, sa->tw + t, sa->tw64 ? sa->tw64 + t : nullptr, s_win[slot],
                                             (uint32_t)SLAB_KEY_CAP, spw.x, spw.y, spw.z, (uint32_t)spv.w);
         if (gl == 0) sa->tile_flags[t] = flags;
@@ -600,7 +680,16 @@ void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan)
     }
     // ---- the workgroup's tiles for the 64-bit-mask and the chunked kernel
     if (gl == 0) s_flags[slot] = flags;
+    if (FIRST && gl == 0) { s_tot[slot][0] = (uint32_t)my_total; s_tot[slot][1] = (uint32_t)(my_total >> 32); }
     __syncthreads();
+    if (FIRST && threadIdx.x == 0 && t0 < sa->n_tiles) {
+        // the block's word: the sum of the counts known here (k_tile adds the others); a block that is complete goes to its super-block
+        unsigned long long sum = 0ull;
+        for (int i = 0; i < DESCRIBE_TILES; ++i) sum += ((unsigned long long)s_tot[i][1] << 32) | s_tot[i][0];
+        sa->lb_blk[t0 >> LB_BLK_SHIFT] = sum;
+        const uint32_t in_blk = min((uint32_t)LB_BLK, sa->n_tiles - t0);
+        if ((uint32_t)(sum >> LB_SHIFT) == in_blk) atomicAdd(sa->lb_sup + (t0 >> LB_SUP_SHIFT), (1ull << LB_SHIFT) | (sum & LB_SUM_MASK));
+    }
     if (wv == 0) {
         const uint32_t f = lane < DESCRIBE_TILES ? s_flags[lane] : TD_FAST;
         const uint32_t tl = t0 + (uint32_t)lane;
@@ -643,7 +732,7 @@ struct SlabRows { SlabRow last, x[SLAB_AHEAD]; };        // a column's row 0 (th
 // behind that or further than 2^18 - 1 bases from the tile's start is written directly and classified by the generic kernel.
 // (Measured: 8 bytes per position at 6 workgroups per CU 0.474 ms, this form 0.462; 2112 positions at 8 workgroups per CU and
 // 64 VGPRs: 0.594 -- 17 spilled registers and 13 % more tiles.)
-constexpr int SLAB_POS_CAP = 2536;                       // (k_probe_slab's LDS = 23040 bytes = 45 granules of 512: 7 workgroups per CU exactly; 2416 before: 1.1 % more tiles)
+constexpr int SLAB_POS_CAP = 2400;                       // (k_tile's LDS = 23040 bytes = 45 granules of 512: 7 workgroups per CU exactly; k_probe_slab alone could hold 2536)
 constexpr uint32_t SLAB_POS_SKIP = 0xffffffffu;          // A of a position that was written directly (a staged start is below 2^18 - 1)
 struct SlabStage { uint32_t *A; uint16_t *Ln; uint32_t loc; int32_t lo; bool fits; };          // loc: the lane's first position, lo: the tile's first start
 
@@ -928,10 +1017,13 @@ constexpr int SLAB_DIR_BYTES = (3 * FAST_DIR_BYTES + 15) & ~15;
 constexpr int SLAB_AUX_BYTES = SLAB_DIR_BYTES + (int)sizeof(TileWin);
 static_assert(SLAB_AUX_BYTES >= 2 * TILE_THREADS * 4, "the accepted counts and their scan (one word per read each) reuse the directories + window record");
 static_assert(2 * SLAB_KEY_CAP * 16 >= SLAB_POS_CAP * 2, "the slot -> position map of a tile's accepted exons reuses the staged dictionary entries");
-template <int LEVEL, bool ACC, bool DIS>
+// LIST (behind k_tile, l2r_tile.hip.h): the workgroups share the list_cnt[4] tiles of u_list -- the tiles k_tile left in slab form, few or none;
+// else workgroup b takes tile xcd_tile(b).  (A template parameter: as a run-time choice the loop cost the hot form 12 spilled registers.)
+template <int LEVEL, bool ACC, bool DIS, bool LIST = false>
 __global__ __launch_bounds__(TILE_THREADS, slab_probe_wgs(LEVEL))
 void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, const TileWin *__restrict__ u_tw,
-                  const uint32_t *__restrict__ u_xbase /* first result slot of every tile: the scanned exon counts (+ the total) */)
+                  const uint32_t *__restrict__ u_xbase /* first result slot of every tile: the scanned exon counts (+ the total) */,
+                  const uint32_t *__restrict__ u_list /* LIST only */)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
     __shared__ __attribute__((aligned(16))) uint32_t s_A[SLAB_POS_CAP];
@@ -946,8 +1038,7 @@ void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, c
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
-    const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
-    if (t >= sa->n_tiles) return;
+    auto one_tile = [&](const uint32_t t) {
     SlabStamp stamp; stamp.start(a->f.stamps);
     // The tile's reads, slab and first base from ONE record of k_walk_slab, its descriptor, its first result slot: every scalar load
     // of the prologue is asked for before the first one is waited for (the empty asm "uses" them all here: the compiler would sink
@@ -962,7 +1053,7 @@ void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, c
     const int32_t tile_lo = sp.lo;                               // the base of the tile's row words: its first read's first base (coordinate-sorted records)
     v4i_t *const s_ent0 = s_ent, *const s_ent1 = s_ent + SLAB_KEY_CAP;
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
-    if (t == 0u && threadIdx.x == 0) *sa->ovf_cursor = 0ull;      // (k_walk_slab is done: the outlier area's cursor is cleared for the next run)
+    if (!LIST && t == 0u && threadIdx.x == 0) *sa->ovf_cursor = 0ull;      // (k_walk_slab is done: the outlier area's cursor is cleared for the next run)
     if (d.flags & TD_WIDE) return;                               // k_probe_slab_wide takes the tile
     // no window record fits the tile's window, or its dictionary slices do not fit the staging here: k_probe_slab_chunked takes it,
     // 63 members at a time, with the entries that matter for them (it finds the tile by these flags)
@@ -1094,6 +1185,17 @@ void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, c
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) if (p4 + i < cx) { o_s[at_ + i] = sv[i]; o_e[at_ + i] = ev[i]; o_f[at_ + i] = (uint8_t)fv[i]; }
             }
+        }
+    }
+    };
+    if (!LIST) {
+        const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
+        if (t < sa->n_tiles) one_tile(t);
+    } else {
+        const uint32_t n_list = sa->list_cnt[4];
+        for (uint32_t wi = blockIdx.x; wi < n_list; wi += gridDim.x) {
+            one_tile(u_list[wi]);
+            __syncthreads();                             // (the next tile of this workgroup overwrites the LDS image)
         }
     }
 }

@@ -1,0 +1,691 @@
+// l2r_tile.hip.h -- the ONE-KERNEL tile path for coordinate-sorted records with short CIGARs (gfx950): what k_walk_slab hands to
+// k_probe_slab through HBM (4 bytes per exon each way, a word per read each way: 0.64 GB of the two-kernel step's 2.47 GB on 10 M
+// reads) stays inside one workgroup.
+//
+//   k_describe_scan<true>   first kernel of a run: the tiles' descriptors and windows from the spans the UPLOAD recorded (a tile's last
+//                           base = the largest read end: a sum of CIGAR lengths, independent of every parameter), the tile lists of the
+//                           64-bit-mask / chunked kernels, and the run's counters cleared (l2r_slab.hip.h)
+//   k_tile                  per tile: records -> slots (counting sort by CIGAR length), CIGAR heads into registers, dictionary slices
+//                           and window into LDS, then the CIGAR registers are walked TWICE: once to COUNT the read's exons (the counts
+//                           -> every read's place among the tile's exons in read order, one barrier + a wave scan), once to PLACE the
+//                           exons as row words at their read-order positions in LDS -- the image k_probe_slab builds from slab rows.
+//                           Window pass, probes, verdicts and the coalesced write-out as there (same device functions).  Registers
+//                           are max(walk, probe), not the sum: the 24 CIGAR words are dead before the probe rounds begin.
+//   the tile's first result slot: every tile PUBLISHES its exon count as soon as it knows it (a third of the way into its life) and
+//                           adds it to the sums of its block of 64 tiles / super-block of 64 blocks; just before its write-out it reads
+//                           the counts of the tiles in front of it inside its block, the sums of the blocks in front of it inside its
+//                           super-block and the sums of the super-blocks in front (three 64-lane loads, one per wave, agent-scope
+//                           atomics on both sides: no fence).  Nothing waits on a SPECIFIC predecessor's completion, only on counts
+//                           that tiles dispatched before this one publish early; workgroup -> tile is blocked-cyclic over the XCDs
+//                           (fused_tile: 16 consecutive tiles per XCD share their dictionary slices in one L2, and a tile's
+//                           predecessors are at most 128 workgroups behind it in dispatch order).  A tile that waits in vain
+//                           (2^22 polls) sets lb_err and leaves: the run then reports an error instead of hanging the device.
+//   tiles this kernel does not finish: windows of 33 .. 63 members / beyond (k_probe_slab_wide / _chunked: on their lists already),
+//                           a dictionary key in several entries, a read of 255 exons or more, more exons than the staged positions
+//                           hold (only outliers make such tiles).  For those the workgroup runs k_walk_slab's tile body instead
+//                           (slab_walk_tile: slab rows, reads' words, span record) and lists the tile for k_probe_slab (fb_list).
+//
+// -e < 1 and long CIGARs keep the two-kernel path (l2r_slab.hip.h).
+#pragma once
+#include "l2r_chunk.hip.h"
+
+namespace l2r {
+
+#ifndef L2R_TILE_GROUP_SHIFT
+#define L2R_TILE_GROUP_SHIFT 4
+#endif
+constexpr uint32_t TILE_GROUP = 1u << L2R_TILE_GROUP_SHIFT;      // consecutive tiles per XCD
+// Workgroup -> tile, blocked-cyclic: workgroup b runs on XCD b % 8 (observed placement: for speed only), so XCD x takes the tile groups
+// x, x + 8, x + 16, ...  The grid is a whole number of rounds of 8 groups; workgroups behind the last tile leave at once.
+__device__ __forceinline__ uint32_t fused_tile(uint32_t b)
+{
+    const uint32_t x = b & 7u, i = b >> 3;
+    return ((((i >> L2R_TILE_GROUP_SHIFT) << 3) + x) << L2R_TILE_GROUP_SHIFT) + (i & (TILE_GROUP - 1u));
+}
+inline unsigned fused_grid(int64_t n_tiles)
+{
+    const int64_t per = 8 * (int64_t)TILE_GROUP;
+    return (unsigned)(std::max<int64_t>((n_tiles + per - 1) / per, 1) * per);
+}
+
+// Upload time, once per read set: an index of every tile's CIGAR operations that no parameter has a say in.
+//   TileRec::pad[0]  the tile's LAST base = the largest end among its reads = pos + the reference bases of the CIGAR (ops M D N = X),
+//                    whatever the parameters cut or keep (src/bam2gtf.c:41-74: `end` only ever grows by these lengths):
+//                    k_describe_scan<true> makes the tile's window from it before any CIGAR has been walked;
+//   TileStat         how many N operations the tile's reads have, the shortest of them, the longest D operation, and the shortest
+//                    stretch of reference bases between two N operations of one read.  With them a run knows a tile's EXON COUNT
+//                    without its CIGARs whenever no threshold is borderline inside the tile (tile_exact): every N is an intron
+//                    (-i <= the shortest N), no D cuts (-t >= the longest D), no inner exon is dropped (-e <= the shortest
+//                    stretch) => exons = reads + N operations (src/bam2gtf.c:41-74).  Tiles for which that does not hold count in k_tile.
+__global__ __launch_bounds__(TILE_THREADS)
+void k_tile_index(TileRec *__restrict__ rec, TileStat *__restrict__ stat, uint32_t n_tiles, const uint32_t *__restrict__ cig_off32, const int32_t *__restrict__ r_pos,
+                  const uint32_t *__restrict__ cig)
+{
+    __shared__ int s_m[5][TILE_THREADS / WAVE];
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t r0 = rec[t].r0, n_act = rec[t].n_act;
+        int end = INT32_MIN, n_n = 0, min_n = INT32_MAX, max_d = 0, min_seg = INT32_MAX;
+        if (threadIdx.x < n_act) {
+            const uint32_t r = r0 + threadIdx.x;
+            end = r_pos[r];
+            int seg = 0; bool first = true;
+            for (uint32_t k = cig_off32[r]; k < cig_off32[r + 1u]; ++k) {
+                const uint32_t c = cig[k], op = c & 0xfu; const int len = (int)(c >> 4);
+                if (op == 3u) {
+                    ++n_n; min_n = min(min_n, len);
+                    if (!first) min_seg = min(min_seg, seg);      // (the first exon is kept whatever its length)
+                    first = false; seg = 0;
+                } else {
+                    if (op == 2u) max_d = max(max_d, len);
+                    seg += len & __builtin_amdgcn_sbfe(0x18d, op, 1u);
+                }
+                end += len & __builtin_amdgcn_sbfe(0x18d, op, 1u);
+            }
+        }
+        const int v[5] = {wave_max(end), (int)wave_sum((uint32_t)n_n), wave_min(min_n), wave_max(max_d), wave_min(min_seg)};
+        if ((threadIdx.x & (WAVE - 1)) == 0) for (int k = 0; k < 5; ++k) s_m[k][threadIdx.x >> 6] = v[k];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            rec[t].pad[0] = (uint32_t)max(max(s_m[0][0], s_m[0][1]), max(s_m[0][2], s_m[0][3]));
+            TileStat st;
+            st.n_ops_n = s_m[1][0] + s_m[1][1] + s_m[1][2] + s_m[1][3];
+            st.min_n = min(min(s_m[2][0], s_m[2][1]), min(s_m[2][2], s_m[2][3]));
+            st.max_d = max(max(s_m[3][0], s_m[3][1]), max(s_m[3][2], s_m[3][3]));
+            st.min_seg = min(min(s_m[4][0], s_m[4][1]), min(s_m[4][2], s_m[4][3]));
+            stat[t] = st;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- the tiles' exon counts -> first result slots (see the head of this file; the words' layout: l2r_slab.hip.h LB_*)
+constexpr uint32_t LB_POLLS = 1u << 19;                  // (2^19 polls, 3.4 us apart in the end: two seconds)
+__device__ __forceinline__ unsigned long long lb_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// thread 0 of a tile whose exon count k_describe_scan could not know (tile_exact), once the tile has counted
+__device__ __forceinline__ void lb_publish(SlabArgsK sa, uint32_t t, uint32_t total)
+{
+    const unsigned long long one = 1ull << LB_SHIFT;
+    __hip_atomic_store(sa->lb_tile + t, one | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t b = t >> LB_BLK_SHIFT, in_blk = min((uint32_t)LB_BLK, sa->n_tiles - (b << LB_BLK_SHIFT));
+    const unsigned long long old = __hip_atomic_fetch_add(sa->lb_blk + b, one | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the block's last count: its sum goes to the super-block)
+    if ((uint32_t)(old >> LB_SHIFT) + 1u == in_blk)
+        (void)__hip_atomic_fetch_add(sa->lb_sup + (t >> LB_SUP_SHIFT), one | ((old & LB_SUM_MASK) + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Waves 0 .. 2 of a tile: the words of one level in front of tile t -- wave 0 the tiles of its block, wave 1 the blocks of its super-block,
+// wave 2 the super-blocks.  lb_words: the level's first word, how many of them, and the number of counts a complete one holds.
+struct LbLevel { const unsigned long long *p; uint32_t cnt, want; };
+__device__ __forceinline__ LbLevel lb_level(SlabArgsK sa, uint32_t t, int wv)
+{
+    if (wv == 0) return LbLevel{sa->lb_tile + (t & ~(uint32_t)(LB_BLK - 1)), t & (uint32_t)(LB_BLK - 1), 1u};
+    if (wv == 1) return LbLevel{sa->lb_blk + ((t >> LB_SUP_SHIFT) << (LB_SUP_SHIFT - LB_BLK_SHIFT)), (t >> LB_BLK_SHIFT) & (uint32_t)((1 << (LB_SUP_SHIFT - LB_BLK_SHIFT)) - 1), (uint32_t)LB_BLK};
+    return LbLevel{sa->lb_sup, t >> LB_SUP_SHIFT, 1u << (LB_SUP_SHIFT - LB_BLK_SHIFT)};
+}
+// The wave's share of the tile's first result slot = the sum of its level's words, every one of them complete; a word that is not yet
+// is polled.  (Wave-uniform result; a shard's exon count is below 2^32, so the low 32 bits of every partial sum are exact.)
+// TRY: one look, no poll -- `done` says whether every word was complete (the tile's first look, at its start: with every count in front
+// known since k_describe_scan it is the only one).
+template <bool TRY>
+__device__ __forceinline__ uint32_t lb_share(SlabArgsK sa, uint32_t t, int wv, int lane, bool &done, uint32_t &n_polls)
+{
+    const LbLevel L = lb_level(sa, t, wv);
+    n_polls = 0u; done = true;
+    uint32_t sum = 0u;
+    for (uint32_t base = 0u; base < L.cnt; base += (uint32_t)WAVE) {
+        const uint32_t i = base + (uint32_t)lane;
+        unsigned long long v = 0ull;
+        bool ok = i >= L.cnt;
+        // A poll is one load instruction of the lanes whose word is not complete yet; between polls the wave sleeps, longer every time
+        // (thousands of waves that poll back to back take the memory system from the tiles they are waiting for).
+        for (uint32_t polls = 0u;; ++polls) {
+            if (!ok) { v = lb_load(L.p + i); ok = (uint32_t)(v >> LB_SHIFT) == L.want; }
+            if (__all(ok)) break;
+            if (TRY) { done = false; break; }
+            ++n_polls;
+            if (polls == LB_POLLS) { if (lane == 0) atomicOr(sa->lb_err, 1u); break; }
+            if (polls < 2u) __builtin_amdgcn_s_sleep(16); else if (polls < 6u) __builtin_amdgcn_s_sleep(48); else __builtin_amdgcn_s_sleep(127);
+        }
+        sum += i < L.cnt ? (uint32_t)v : 0u;
+    }
+    return wave_sum(sum);
+}
+
+// map_exons_slab (l2r_slab.hip.h) with the read's exons at their read-order positions in LDS (A[loc + j]: the row word the place walk
+// left) instead of in slab rows: exon k + AHEAD is read into exon k's register when round k is done with it, every round leaves
+// {start | work word, length} at the exon's position.  Positions of other lanes are never touched; a lane's reads behind its last exon
+// re-read that one (clipped index), live or rewritten: not used.
+#ifndef L2R_TILE_AHEAD
+#define L2R_TILE_AHEAD 2
+#endif
+constexpr int TILE_AHEAD = L2R_TILE_AHEAD;
+template <bool DIS>
+__device__ __forceinline__ SiteMasks map_exons_lds(const TileLds &L, const TileDesc &d, bool mapping, uint32_t n, uint32_t vpre, const SlabStage &st, int dis = 0, int rs = 0, int re = 0)
+{
+    SiteMasks m{0xffffffffu, 0u, 0u, 0u, 0u};
+    uint32_t *const Ap = st.A + st.loc; uint16_t *const Lp = st.Ln + st.loc;
+    const uint32_t nm1 = mapping ? n - 1u : 0u;
+    SlabRow R[TILE_AHEAD];
+#pragma unroll
+    for (int i = 0; i < TILE_AHEAD; ++i) R[i] = SlabRow{Ap[min((uint32_t)i, nm1)]};
+    const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
+    const int k_max = wave_max(mapping ? (int)n : 0);
+    auto buckets = [&](int k, int sv, int ev, uint32_t &ls, uint32_t &hs, uint32_t &le, uint32_t &he) {
+        const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
+        if (DIS) { near_range(L.dir0, d.b_off, none, live, sv, dis, ls, hs); near_range(L.dir1, d.b_off, none, junc, ev, dis, le, he); return; }
+        const uint32_t is = live ? min((uint32_t)((sv >> SITE_SHIFT) + d.b_off), none) : none;      // (a lane without exon k must not open the long-bucket path)
+        const uint32_t ie = junc ? min((uint32_t)((ev >> SITE_SHIFT) + d.b_off), none) : none;
+        ls = L.dir0[is]; hs = L.dir0[is + 1u]; le = L.dir1[ie]; he = L.dir1[ie + 1u];
+    };
+    uint32_t ls, hs, le, he;
+    int e_cur = slab_row_end(R[0], st.lo);
+    buckets(0, slab_row_start(R[0], st.lo), e_cur, ls, hs, le, he);
+    auto round = [&](int k, SlabRow &cur, const SlabRow &nxt, bool reload) {
+        const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
+        const int s = slab_row_start(cur, st.lo), e = e_cur, s2 = slab_row_start(nxt, st.lo), e2 = slab_row_end(nxt, st.lo);
+        const uint32_t cw = cur.w;
+        uint32_t ls_n, hs_n, le_n, he_n;
+        uint32_t xm, am, jm, dm;
+        if (DIS) {
+            buckets(k + 1, s2, e2, ls_n, hs_n, le_n, he_n);
+            probe_near(L.ent0, ls, hs, s, e, dis, rs, re, xm, am, m.amb);
+            probe_near(L.ent1, le, he, e, s2, dis, rs, re, jm, dm, m.amb);
+        } else {
+            const v4i_t qs0 = lds_entry(L.ent0, ls);
+            const v4i_t qe0 = lds_entry(L.ent1, le), qe1 = lds_entry(L.ent1, le + 1u);
+            buckets(k + 1, s2, e2, ls_n, hs_n, le_n, he_n);
+            {   const bool m0 = ls < hs && qs0.x == s;
+                am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
+            probe2(qe0, qe1, le, he, e, s2, jm, dm);
+            if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(L.ent0, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + 2u, he, e, s2, jm, dm, 0u); }
+        }
+        if (reload) cur = SlabRow{Ap[min((uint32_t)k + (uint32_t)TILE_AHEAD, nm1)]};      // exon k + TILE_AHEAD into the register of exon k
+        const uint32_t amj = junc ? am : 0u;
+        uint32_t word = first_member(xm & vpre);
+        word |= first_member(jm & vpre) << 6;
+        word |= nonzero(dm & vpre) << 12;
+        word |= nonzero(amj & vpre) << 13;
+        m.kand &= junc ? (am & dm) : 0xffffffffu;     // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
+        m.kor |= amj | dm;
+        if (!DIS) { if (k == 0) m.dm_first = dm;
+                    m.am_last = (live && !junc) ? am : m.am_last; }
+        if (live) { Ap[k] = (cw & SLAB_REL_MASK) | (word << SLAB_REL_BITS); Lp[k] = (uint16_t)(cw >> SLAB_REL_BITS); }
+        ls = ls_n; hs = hs_n; le = le_n; he = he_n; e_cur = e2;
+    };
+    int k = 0;
+    for (; k + TILE_AHEAD <= k_max; k += TILE_AHEAD) {
+#pragma unroll
+        for (int i = 0; i < TILE_AHEAD; ++i) round(k + i, R[i], R[(i + 1) % TILE_AHEAD], true);
+    }
+#pragma unroll
+    for (int i = 0; i < TILE_AHEAD - 1; ++i) {
+        if (k + i >= k_max) break;
+        round(k + i, R[i], R[i + 1], false);
+    }
+    return m;
+}
+
+// Verdicts of the tile's reads from the staged window + dictionaries (slab_classify with the exons in LDS).  big: the read has an exon
+// the row word cannot say (16 kb or longer, or 2^18 - 1 bases or more behind the tile's first base): the generic kernel classifies it,
+// its exons are written from a literal walk once the tile's first slot is known, its positions are marked.
+template <int LEVEL, bool DIS>
+__device__ __forceinline__ SlabVerdict tile_classify(PipeArgsK a, const TileDesc &d, const SlabLds &S, const int4 *hk, const int4 *hx, const int *win, const uint32_t *tilemask,
+                                                    bool active, uint32_t pre, bool big, uint32_t r, const ReadEnds &re, const SlabStage &st, int any_wide, SlabStamp &stamp)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const bool fast = (d.flags & TD_FAST) != 0;
+    const int w_n = fast ? (int)d.n_win : 0;
+    const uint32_t n = pre >> PRE_N_SHIFT;
+    const bool rev_in = (pre & PRE_REV) != 0u;
+    uint32_t info = n << 8; int ref = -1;
+    bool redo = active && (!fast || big || any_wide != 0 || (n > 1 && (pre & PRE_INSANE) != 0u));
+    const bool work = active && !redo;
+    const TileLds L{nullptr, nullptr, nullptr, S.ent0, S.ent1, S.dir0, S.dir1, S.rdir, hk, hx, win};
+    const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, tilemask);
+    redo = redo || vm.redo;
+    stamp.mark(2);
+    const bool mapping = work && !redo && n > 1;
+    const SiteMasks sm = map_exons_lds<DIS>(L, d, mapping, n, vm.vpre, st, DIS ? a->f.p.ss_dis : 0, re.s0, re.el);
+    stamp.mark(3);
+    if (active && !mapping) {
+        // no probe round has rewritten this read's row words: {start, flags 0} and the length apart, as the write-out reads them
+        uint32_t *const Ap = st.A + st.loc; uint16_t *const Lp = st.Ln + st.loc;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t w = Ap[k];
+            Ap[k] = big ? SLAB_POS_SKIP : (w & SLAB_REL_MASK); Lp[k] = (uint16_t)(w >> SLAB_REL_BITS);
+        }
+    }
+    // (-d > 0: a visited member with two sites within the tolerance of one read site -- its pair count is the generic kernel's)
+    if (DIS && mapping && (sm.amb & vm.vpre) != 0u) redo = true;
+    if (work && !redo) {
+        uint32_t *const Ap = st.A + st.loc;
+        // (the read's ends once more, from its staged exons: four registers that need not live through the probe rounds)
+        const uint16_t *const Lq = st.Ln + st.loc;
+        ReadEnds re2;
+        re2.s0 = st.lo + (int)(Ap[0] & SLAB_REL_MASK); re2.e0 = re2.s0 + (int)Lq[0] - 1;
+        re2.sl = st.lo + (int)(Ap[n - 1u] & SLAB_REL_MASK); re2.el = re2.sl + (int)Lq[n - 1u] - 1;
+        const Verdict vd = decide<LEVEL>(L, d, n, re2, vm, sm, rev_in, [&](int k) { return Ap[k] >> SLAB_REL_BITS; },
+                                         [&](int k, uint32_t f) { Ap[k] = (Ap[k] & SLAB_REL_MASK) | (f << SLAB_REL_BITS); });
+        info = vd.info; ref = vd.ref;
+    }
+    stamp.mark(4);
+    redo = redo && active;
+    {
+        const unsigned long long m = __ballot(redo);
+        if (m) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(a->f.redo_count, (uint32_t)__popcll(m));
+            at = __shfl(at, 0, WAVE);
+            if (redo) a->f.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+        }
+    }
+    if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; }
+    return SlabVerdict{info, ref, redo};
+}
+
+// LDS of k_tile beside the staged positions, dictionary slices, directories and window record of k_probe_slab: the reads' exon counts
+// (one byte each, read order) and their exclusive scan (16 bit).
+constexpr int TILE_LDS_BYTES = SLAB_POS_CAP * 6 + 2 * SLAB_KEY_CAP * 16 + SLAB_AUX_BYTES + TILE_THREADS * 3 + 16 * 4 + 4 * 4;
+static_assert(TILE_LDS_BYTES <= 23040, "k_tile: 7 workgroups per CU need 45 allocation granules of 512 bytes at most");
+static_assert(SLAB_POS_CAP >= 64 + 5 * TILE_THREADS + 16, "the sort's arrays (and slab_walk_tile's) live in the staged positions until the place walk");
+static_assert(SLAB_POS_CAP < 65536 && SLAB_POS_CAP % 8 == 0, "16-bit places; 16-byte aligned arrays");
+
+template <int LEVEL, bool ACC, bool DIS>
+__global__ __launch_bounds__(TILE_THREADS, 7)
+void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const TileWin *__restrict__ u_tw, const TileStat *__restrict__ u_stat, uint32_t *__restrict__ u_xbase)
+{
+    constexpr int DIR_BYTES = FAST_DIR_BYTES;
+    __shared__ __attribute__((aligned(16))) uint32_t s_A[SLAB_POS_CAP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_L[SLAB_POS_CAP];
+    __shared__ __attribute__((aligned(16))) v4i_t s_ent[2 * SLAB_KEY_CAP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_aux[SLAB_AUX_BYTES];       // directories, then the window record
+    __shared__ __attribute__((aligned(16))) uint8_t s_cnt[TILE_THREADS];        // exon counts, read order (255: that many or more)
+    __shared__ __attribute__((aligned(16))) uint16_t s_loc[TILE_THREADS];       // ... and their exclusive scan
+    __shared__ uint32_t s_flagw[TILE_THREADS / WAVE], s_redow[TILE_THREADS / WAVE];
+    __shared__ uint32_t s_lb[4], s_lbok[4];
+    __shared__ uint32_t s_chunk[2];
+    // (until the place walk the staged positions hold the sort's arrays; in a tile that keeps the slab form, slab_walk_tile's)
+    uint32_t *const s_hist = s_A, *const s_x0 = s_A + WAVE, *const s_x1 = s_x0 + TILE_THREADS, *const s_x2 = s_x1 + TILE_THREADS;
+    uint8_t *const s_dir = s_aux;
+    TileWin &s_tw = *reinterpret_cast<TileWin *>(s_aux + SLAB_DIR_BYTES);
+    (void)kernarg_block;
+    const SlabArgsK sa = slab_args();
+    const PipeArgsK a = pipe_args();
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const uint32_t t = fused_tile(blockIdx.x);
+    if (t >= sa->n_tiles) return;
+    // diagnostics (L2R_STAMPS=1), wave 0: [0] records, sort, CIGAR heads asked for, staging  [1] count walk + barrier  [6] scan, count
+    // published, place walk  [2] window pass  [3] probe rounds  [4] verdicts  [7] the tile's first slot (exon counts in front)  [5] write-out
+    SlabStamp stamp; stamp.start(a->f.stamps); if (stamp.who == 3) stamp.who = -1;
+    const uint32_t clk0 = stamp.p ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
+    // The tile's record from the upload and its descriptor from k_describe_scan: every scalar load of the prologue leaves before the
+    // first one is waited for (see k_probe_slab).
+    const TileRec rec = u_rec[t];
+    const TileDesc d0 = u_tw[t].d;
+    const TileStat tst = u_stat[t];
+    const uint32_t chunk_on = sa->chunk_on; const int32_t ablate = a->f.p.ablate;
+    const uint32_t n_tiles = sa->n_tiles;
+    asm volatile("" :: "s"(tst.n_ops_n), "s"(tst.min_n), "s"(tst.max_d), "s"(tst.min_seg), "s"(chunk_on), "s"(ablate), "s"(n_tiles), "s"(rec.r0), "s"(rec.n_act), "s"(rec.sbase), "s"(rec.rows), "s"(rec.tid0), "s"(rec.lo),
+                       "s"(d0.j_lo), "s"(d0.b_off), "s"(d0.nb), "s"(d0.b0), "s"(d0.nbk), "s"(d0.st_r0), "s"(d0.st_nk), "s"(d0.en_r0), "s"(d0.en_nk), "s"(d0.flags), "s"(d0.n_win));
+    // (diagnostics, per tile, for l2r_debug_tile_times: the 100 MHz clock at the tile's start | the XCD's number; further down at its
+    //  count's publication, at the begin and the end of its wait for the counts in front.  Behind the scalar loads above: a store in
+    //  front of them turns every one into a vector load.)
+    if (stamp.p && threadIdx.x == 0) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a->tile_total[t] = (clk0 << 3) | (xcc & 7u);
+    }
+    const uint32_t r0 = rec.r0, n_act = rec.n_act;
+    const int32_t tid0 = rec.tid0, pos0 = rec.lo - 1;
+    const int32_t tile_lo = rec.lo;                              // the base of the tile's row words: its first read's first base
+    // a tile of the 64-bit-mask or the chunked kernel (on their lists since k_describe_scan): slab form, nothing is staged here
+    const bool pre_slab = (d0.flags & TD_WIDE) != 0u || (chunk_on && slab_tile_is_chunked(d0.flags));
+    // the tile's exon count is known to the later tiles since k_describe_scan (no threshold is borderline in it): nothing to publish here
+    const bool counted = tile_exact(tst, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet) && !(ablate & 256);
+    TileDesc d = d0;
+    if (pre_slab) d.flags = 0u;
+    v4i_t *const s_ent0 = s_ent, *const s_ent1 = s_ent + SLAB_KEY_CAP;
+    uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
+    // thread -> slot: the slot groups (by falling CIGAR length, group 0 = the tile's longest reads) are rotated over the waves by a
+    // hash of the tile number (L2R_ABLATE bit 3: off)
+    const uint32_t rot = (ablate & 8) ? 0u : ((t ^ (t >> 3) ^ (t >> 7)) & 3u);
+    const uint32_t slot = (threadIdx.x + (rot << 6)) & (uint32_t)(TILE_THREADS - 1);
+    // ---- the tile's reads by falling CIGAR length (counting sort, 64 bins): thread i brings read i, the thread of slot s takes what
+    //      landed there.  The dictionary slices and the window record are asked for behind the records: they travel during the sort.
+    DictRegs dv;
+    int4 twv = make_int4(0, 0, 0, 0);
+    LbLevel lv{nullptr, 0u, 0u};
+    unsigned long long ev = 0ull;
+    {
+        const uint32_t i = threadIdx.x;
+        uint32_t c_lo = 0u, c = 0u, rev = 0u; int32_t pos = 0;
+        if (i < n_act) {
+            const uint32_t *const p_off = sa->cig_off32;
+            c_lo = ld32(p_off, r0 + i); c = ld32(p_off, r0 + i + 1u) - c_lo;
+            pos = ld32(a->f.r_pos, r0 + i); rev = ld32(a->f.r_rev, r0 + i) ? 1u : 0u;
+        }
+        // A first look at the exon counts in front of the tile (waves 0 .. 2, one level each): asked for here, looked at behind the sort.
+        // PLAIN loads: what k_describe_scan wrote (the launch in front) is visible to them, and a word is complete only once -- a stale
+        // copy of a word that a tile of this launch is still adding to merely looks incomplete, and the second look (agent-scope loads,
+        // behind the probe rounds) takes over.
+        if (wv < 3 && !pre_slab) { lv = lb_level(sa, t, wv); if ((uint32_t)lane < lv.cnt) ev = lv.p[lane]; }
+        dv = load_dict_slices(a, d);
+        if ((int)threadIdx.x < SLAB_TW_VECS && tw_vec_used((int)threadIdx.x, (d.flags & TD_FAST) ? d.n_win : 0u)) twv = reinterpret_cast<const int4 *>(u_tw + t)[threadIdx.x];
+        if (i < (uint32_t)WAVE) s_hist[i] = 0u;
+        __syncthreads();
+        const uint32_t est = i < n_act ? max(1u, min((c + 1u) >> 1, (uint32_t)(WAVE - 1))) : 0u;      // threads without a read sort last
+        const uint32_t bin = (uint32_t)(WAVE - 1) - est;
+        const uint32_t rank = atomicAdd(&s_hist[bin], 1u);
+        __syncthreads();
+        if (i < (uint32_t)WAVE) { const uint32_t v = s_hist[i]; s_hist[i] = wave_inclusive_scan(v) - v; }
+        __syncthreads();
+        const uint32_t at = (s_hist[bin] + rank - (rot << 6)) & (uint32_t)(TILE_THREADS - 1);      // the thread of that slot
+        s_x0[at] = c_lo; s_x1[at] = (uint32_t)pos; s_x2[at] = min(c, 0xffffu) | (rev << 16) | (i << 24);
+        __syncthreads();
+    }
+    if (wv < 3 && !pre_slab) {
+        // (complete words only; a level of more than 64 words -- beyond 65 k tiles -- is left to the second look)
+        const bool in = (uint32_t)lane < lv.cnt;
+        const bool ok = __all(!in || (uint32_t)(ev >> LB_SHIFT) == lv.want) && lv.cnt <= (uint32_t)WAVE;
+        const uint32_t w_sum = wave_sum(in ? (uint32_t)ev : 0u);
+        if (lane == 0) { s_lb[wv] = w_sum; s_lbok[wv] = ok ? 1u : 0u; }
+    }
+    // (the window record goes to LDS before the CIGAR heads are asked for: four registers less beside the 24 words and the dictionary entries)
+    if (!pre_slab && (int)threadIdx.x < SLAB_TW_VECS) reinterpret_cast<int4 *>(&s_tw)[threadIdx.x] = twv;
+    const bool active = slot < n_act;                            // (reads without a thread sort last: the slots behind the tile's reads)
+    const uint32_t c_lo = s_x0[threadIdx.x], xw = s_x2[threadIdx.x];
+    const int32_t pos = (int32_t)s_x1[threadIdx.x];
+    const uint32_t n_cig = xw & 0xffffu, idx = xw >> 24;         // (n_cig 65535: that many or more)
+    // ---- the head of the read's CIGAR: six 16-byte vectors, all in flight at once; words behind the last op become "I, length 0"
+    uint32_t cg[SLAB_HEAD];
+#pragma unroll
+    for (int i = 0; i < SLAB_HEAD; ++i) cg[i] = 1u;
+    if (active) {
+        const uint32_t *const words = a->f.cig + c_lo;
+#pragma unroll
+        for (int q = 0; q < SLAB_HEAD_VEC; ++q)
+            if ((uint32_t)(4 * q) < n_cig) {
+                const v4i_a4 x = *reinterpret_cast<const v4i_a4 *>(words + 4 * q);
+                cg[4 * q] = (uint32_t)x.x; cg[4 * q + 1] = (uint32_t)x.y; cg[4 * q + 2] = (uint32_t)x.z; cg[4 * q + 3] = (uint32_t)x.w;
+            }
+    }
+    // ---- window and dictionary slices into LDS, re-based to the tile's window (they arrived during the sort; the CIGAR words travel)
+    const SlabLds S{nullptr, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir};
+    int my_wide = 0;
+    if (!pre_slab) my_wide = slab_stage_dict(d, dv, reinterpret_cast<const int *>(u_tw[t].win), S);
+    stamp.mark(0);
+#pragma unroll
+    for (int i = 0; i < SLAB_HEAD; ++i) cg[i] = (uint32_t)i < n_cig ? cg[i] : 1u;
+    DevParams p;
+    p.min_exon = a->f.p.min_exon; p.min_intron = a->f.p.min_intron; p.max_delet = a->f.p.max_delet;
+    const uint32_t t3 = ((uint32_t)p.min_intron << 4) | 3u, t2 = ((uint32_t)(p.max_delet + 1) << 4) | 2u;      // op and length compare as one number
+    const int c_max = wave_max(active ? (int)min(n_cig, (uint32_t)SLAB_HEAD) : 0);
+    // ---- first walk: COUNT the read's exons (src/bam2gtf.c:31-78 with nothing stored)
+    uint32_t n = 0u;
+    if (!pre_slab) {
+        if (active) {
+            int start = pos + 1, end = pos;
+            bool first = true;
+            auto step = [&](uint32_t c) {
+                const uint32_t op = c & 0xfu;
+                const int len = (int)(c >> 4);
+                const bool cut = ((op == 3u) & (c >= t3)) | ((op == 2u) & (c >= t2));
+                const bool keep = cut & (first | (end - start >= p.min_exon - 1));
+                n += keep ? 1u : 0u;
+                first = first & !keep;
+                start = cut ? end + len + 1 : start;
+                end += len & __builtin_amdgcn_sbfe(0x18d, op, 1u);         // ops 0 2 3 7 8 advance the reference
+            };
+#pragma unroll
+            for (int q = 0; q < SLAB_HEAD_VEC; ++q)
+                if (4 * q < c_max) { step(cg[4 * q]); step(cg[4 * q + 1]); step(cg[4 * q + 2]); step(cg[4 * q + 3]); }       // (wave-uniform)
+            if (n_cig > (uint32_t)SLAB_HEAD) {
+                const uint32_t n_ops = ld32(sa->cig_off32, r0 + idx + 1u) - c_lo;
+                const uint32_t *const words = a->f.cig + c_lo;
+                for (uint32_t i = SLAB_HEAD; i < n_ops; ++i) step(words[i]);
+            }
+            ++n;
+        }
+        s_cnt[idx] = (uint8_t)min(n, 255u);                 // (every entry is written: idx is a permutation of 0 .. 255)
+        // (what the staged positions cannot hold: a read of 255 exons or more -- bit 0; a dictionary key in several entries -- bit 1)
+        const uint32_t fw = (__any(n >= 255u) ? 1u : 0u) | (__any(my_wide != 0) ? 2u : 0u);
+        if (lane == 0) s_flagw[wv] = fw;
+        __syncthreads();
+    }
+    stamp.mark(1);
+    // ---- every read's place among the tile's exons in READ order: each wave scans the 256 counts (four per lane) for itself
+    uint32_t total = 0u, loc = 0u;
+    bool late_slab = false, wide_key = false, first_look = false;
+    int any_wide = 0;
+    if (!pre_slab) {
+        const uint32_t c4 = reinterpret_cast<const uint32_t *>(s_cnt)[lane];
+        const uint32_t b0 = c4 & 0xffu, b1 = (c4 >> 8) & 0xffu, b2 = (c4 >> 16) & 0xffu, b3 = c4 >> 24;
+        const uint32_t sum = b0 + b1 + b2 + b3;
+        const uint32_t inc = wave_inclusive_scan(sum), ex = inc - sum;
+        reinterpret_cast<uint2 *>(s_loc)[lane] = make_uint2(ex | ((ex + b0) << 16), (ex + b0 + b1) | ((ex + b0 + b1 + b2) << 16));     // (the four waves write the same values)
+        total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+        // (wave-uniform for the compiler too: a branch it takes for divergent keeps the CIGAR registers alive through the probe rounds)
+        const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_flagw[0] | s_flagw[1] | s_flagw[2] | s_flagw[3]));
+        first_look = __builtin_amdgcn_readfirstlane((int)(s_lbok[0] & s_lbok[1] & s_lbok[2])) != 0;
+        // a dictionary key in several entries: k_probe_slab_chunked ORs them (the tile keeps the slab form); with chunked windows off
+        // the tile's reads take the generic kernel
+        late_slab = total > (uint32_t)SLAB_POS_CAP || (fl & 1u) != 0u || ((fl & 2u) != 0u && chunk_on != 0u);
+        wide_key = (fl & 2u) != 0u;
+        any_wide = (wide_key && !late_slab) ? 1 : 0;
+        loc = s_loc[idx];
+    }
+    // (the staged form first in the source, the slab form behind it: see the note at the end of the kernel)
+    auto staged_form = [&]() {
+    // ---- the tile's exon count is known: published for every later tile's first slot
+    if (threadIdx.x == 0 && !counted && !(ablate & 128)) lb_publish(sa, t, total);
+    if (stamp.p && threadIdx.x == 0) a->f.tile_acc[t] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    // ---- second walk: PLACE the exons as row words at their positions in LDS
+    const SlabStage st{s_A, s_L, loc, tile_lo, true};
+    ReadEnds re{0, 0, 0, 0};
+    bool sane = true, big = false;
+    n = 0u;
+    if (active) {
+        uint32_t *const Ap = s_A + loc;
+        int start = pos + 1, end = pos;
+        int s0 = 0, e0 = 0;
+        bool first = true;
+        uint32_t longest = 0u;
+        auto step = [&](uint32_t c) {
+            const uint32_t op = c & 0xfu;
+            const int len = (int)(c >> 4);
+            const bool cut = ((op == 3u) & (c >= t3)) | ((op == 2u) & (c >= t2));
+            const bool keep = cut & (first | (end - start >= p.min_exon - 1));
+            if (keep) {
+                const uint32_t xlen = (uint32_t)(end - start + 1);
+                Ap[n] = slab_pack(start - tile_lo, xlen);
+                longest = max(longest, xlen);
+                if (first) { s0 = start; e0 = end; }
+                first = false; ++n;
+            }
+            start = cut ? end + len + 1 : start;
+            end += len & __builtin_amdgcn_sbfe(0x18d, op, 1u);
+        };
+#pragma unroll
+        for (int q = 0; q < SLAB_HEAD_VEC; ++q)
+            if (4 * q < c_max) { step(cg[4 * q]); step(cg[4 * q + 1]); step(cg[4 * q + 2]); step(cg[4 * q + 3]); }       // (wave-uniform)
+        if (n_cig > (uint32_t)SLAB_HEAD) {
+            const uint32_t n_ops = ld32(sa->cig_off32, r0 + idx + 1u) - c_lo;
+            const uint32_t *const words = a->f.cig + c_lo;
+            for (uint32_t i = SLAB_HEAD; i < n_ops; ++i) step(words[i]);
+        }
+        {   const uint32_t xlen = (uint32_t)(end - start + 1);
+            Ap[n] = slab_pack(start - tile_lo, xlen);
+            longest = max(longest, xlen);
+            // (starts rise along the read: the last one is the furthest)
+            if ((uint32_t)(start - tile_lo) >= SLAB_REL_MASK) longest = 0xffffffffu; }
+        if (first) { s0 = start; e0 = end; }
+        ++n;
+        // with min_exon >= 1 kept inner exons are at least one base long; the first and the last one are kept whatever their length
+        sane = s0 <= e0 && start <= end;
+        big = longest > SLAB_LEN_MAX;
+        re = ReadEnds{s0, e0, start, end};
+    }
+    stamp.mark(6);
+    const uint32_t pre = idx | (((xw >> 16) & 1u) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (n << PRE_N_SHIFT);
+    const uint32_t r = r0 + idx;
+    // ---- classification (no barrier: a lane probes the positions it has placed itself; the dictionary slices were staged in front
+    //      of the barrier behind the count)
+    const SlabVerdict vd = tile_classify<LEVEL, DIS>(a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, big, r, re, st, any_wide, stamp);
+    if (ACC) { const int w_redo = __any(vd.redo) ? 1 : 0; if (lane == 0) s_redow[wv] = (uint32_t)w_redo; }
+    // ---- the tile's first result slot
+    {
+        uint32_t share = 0u;
+        uint32_t n_polls = 0u;
+        bool done;
+        if (stamp.p && threadIdx.x == 0) a->f.tile_acc_ex[t] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        // (the first look found every count in front: nothing to do here -- the rule unless a threshold is borderline somewhere)
+        if (!first_look || (ablate & 64)) {
+            if (wv < 3 && !(ablate & 64)) share = lb_share<false>(sa, t, wv, lane, done, n_polls);
+            if (stamp.p && lane == 0 && wv < 3) { atomicAdd(&stamp.p[8192 + wv], (unsigned long long)n_polls); atomicAdd(&stamp.p[8192 + 3 + wv], n_polls ? 1ull : 0ull); }
+            // (L2R_ABLATE bit 6, timing diagnostics only: no look at the counts in front -- the results land at made-up slots)
+            if (ablate & 64) share = wv == 0 ? t * (uint32_t)SLAB_POS_CAP : 0u;
+            if (lane == 0 && wv < 3) s_lb[wv] = share;
+        }
+    }
+    __syncthreads();
+    if (stamp.p && threadIdx.x == 0) sa->tile_flags[t] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    stamp.mark(7);
+    const uint32_t xbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_lb[0] + s_lb[1] + s_lb[2]));
+    if (threadIdx.x == 0) {
+        u_xbase[t] = xbase;
+        if (t + 1u == n_tiles) { u_xbase[n_tiles] = xbase + total; *sa->exon_total = xbase + total; }
+    }
+    const SlabOut out{a->f.ex_start, a->f.ex_end, a->f.ex_flag, xbase + loc};
+    if (active) a->f.ex_off[r] = out.dst;
+    if (active && big) {
+        // an exon the row word cannot say: the literal walk (l2r_kernels.hip.h) straight into the result arrays (flags: the generic kernel's)
+        const uint32_t n_ops = ld32(sa->cig_off32, r + 1u) - c_lo;
+        const uint32_t *const words = a->f.cig + c_lo;
+        WalkState w{pos + 1, pos, 0};
+        auto put = [&](int k, int s_, int e_) { out.start[out.dst + (uint32_t)k] = s_; out.end[out.dst + (uint32_t)k] = e_; out.flag[out.dst + (uint32_t)k] = 0; };
+        walk_ops<false>(w, words, 0, (int)n_ops, p, put);
+        put(w.n, w.start, w.end);
+    }
+    if (!ACC) {
+        slab_write_out(SlabOut{out.start, out.end, out.flag, xbase}, s_A, s_L, tile_lo, total);
+        stamp.mark(5);
+        return;
+    }
+    // ---- the tile's accepted chunk (k_probe_slab).  Not fused: the tile stays CHUNK_DEFERRED (k_describe_scan) for k_gather_accepted.
+    const bool fused = __builtin_amdgcn_readfirstlane((int)(s_redow[0] | s_redow[1] | s_redow[2] | s_redow[3])) == 0 && !(ablate & 2);
+    if (!fused) { slab_write_out(SlabOut{out.start, out.end, out.flag, xbase}, s_A, s_L, tile_lo, total); return; }
+    uint32_t *const s_racc = reinterpret_cast<uint32_t *>(s_aux), *const s_rscan = s_racc + TILE_THREADS;
+    uint16_t *const s_map = reinterpret_cast<uint16_t *>(s_ent);
+    const bool acc = active && (vd.info & I_ACCEPT) != 0u;
+    // accepted reads (high half) and their exons (low half), by read number inside the tile
+    s_racc[idx] = acc ? ((1u << 16) | n) : 0u;                  // (every entry is written: idx is a permutation of 0 .. 255)
+    __syncthreads();
+    uint32_t ca, cx;
+    {   // every wave scans the 256 words for itself (four per lane)
+        const uint4 c4 = reinterpret_cast<const uint4 *>(s_racc)[lane];
+        const uint32_t sum = c4.x + c4.y + c4.z + c4.w;
+        const uint32_t inc = wave_inclusive_scan(sum), ex = inc - sum;
+        reinterpret_cast<uint4 *>(s_rscan)[lane] = make_uint4(ex, ex + c4.x, ex + c4.x + c4.y, ex + c4.x + c4.y + c4.z);     // (the four waves write the same values)
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+        ca = tot >> 16; cx = tot & 0xffffu;
+    }
+    unsigned long long chunk = 0ull;                 // {first record slot, first exon slot} of the tile's chunk
+    if (threadIdx.x == 0) {
+        a->f.tile_acc[t] = 0u; a->f.tile_acc_ex[t] = 0u;            // nothing of this tile is left for k_gather_accepted
+        if (ca) chunk = atomicAdd(a->f.chunk_cursor, ((unsigned long long)ca << 32) | cx);      // (the answer travels during the write-out below)
+    }
+    const uint32_t mine = acc ? s_rscan[idx] : 0u;                  // records / exons of the tile's accepted reads in front of this one
+    if (acc) for (uint32_t k = 0; k < n; ++k) s_map[(mine & 0xffffu) + k] = (uint16_t)(loc + k);
+    slab_write_out(SlabOut{out.start, out.end, out.flag, xbase}, s_A, s_L, tile_lo, total);
+    if (threadIdx.x == 0) {
+        s_chunk[0] = (uint32_t)chunk; s_chunk[1] = (uint32_t)(chunk >> 32);
+        a->f.tile_chunk[t] = (uint32_t)chunk; a->f.tile_rchunk[t] = (uint32_t)(chunk >> 32);
+    }
+    if (ca == 0u) return;
+    __syncthreads();
+    const uint32_t to = s_chunk[0], to_r = s_chunk[1];
+    if (acc) {                                      // the record of the thread's own read
+        const uint32_t rslot = to_r + (mine >> 16);
+        const uint64_t gidx = (uint64_t)(a->f.first_read + (int64_t)r);
+        AccRec rc; rc.read_lo = (uint32_t)gidx; rc.read_hi = (uint32_t)(gidx >> 32); rc.info = vd.info; rc.ref_tx = vd.ref;
+        a->f.acc_rec[rslot] = rc;
+        a->f.acc_ex_off[rslot] = to + (mine & 0xffffu);
+    }
+    {   // the chunk's exons: thread j takes slots 4j .. 4j + 3 (16-byte stores at whatever alignment the chunk has)
+        int32_t *const o_s = a->f.acc_start, *const o_e = a->f.acc_end; uint8_t *const o_f = a->f.acc_flag;
+        for (uint32_t p4 = threadIdx.x * 4u; p4 < cx; p4 += (uint32_t)TILE_THREADS * 4u) {
+            const uint2 m4 = *reinterpret_cast<const uint2 *>(s_map + p4);
+            const uint32_t src[4] = {m4.x & 0xffffu, m4.x >> 16, m4.y & 0xffffu, m4.y >> 16};
+            int sv[4], ev[4]; uint32_t fv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t q_ = p4 + (uint32_t)i < cx ? src[i] : 0u;      // (map entries behind the chunk are stale)
+                const uint32_t av = s_A[q_]; const uint32_t lv = s_L[q_];
+                sv[i] = tile_lo + (int)(av & SLAB_REL_MASK); ev[i] = sv[i] + (int)lv - 1; fv[i] = (av >> SLAB_REL_BITS) & 0xffu;
+            }
+            const uint32_t at_ = to + p4;
+            if (p4 + 4u <= cx) {
+                v4i_t s4, e4; s4.x = sv[0]; s4.y = sv[1]; s4.z = sv[2]; s4.w = sv[3]; e4.x = ev[0]; e4.y = ev[1]; e4.z = ev[2]; e4.w = ev[3];
+                *reinterpret_cast<v4i_a4 *>(o_s + at_) = s4;
+                *reinterpret_cast<v4i_a4 *>(o_e + at_) = e4;
+                *reinterpret_cast<u32_a1 *>(o_f + at_) = fv[0] | (fv[1] << 8) | (fv[2] << 16) | (fv[3] << 24);
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) if (p4 + i < cx) { o_s[at_ + i] = sv[i]; o_e[at_ + i] = ev[i]; o_f[at_ + i] = (uint8_t)fv[i]; }
+            }
+        }
+    }
+
+    };
+    // (For its register allocation the compiler lays the two forms of a tile out one behind the other -- "the staged form, then, if a flag
+    //  says so, the slab form" -- whatever the order here: what the slab form needs is alive through the staged form's probe rounds.)
+    if (!(pre_slab || late_slab)) { staged_form(); return; }
+    // ---- the tile keeps the slab form: k_walk_slab's body on the CIGAR registers (its LDS words behind the sort's arrays, which a
+    //      slower wave may still be reading), then the tile's first slot and the list of the kernel that takes it
+    // (the thread's slot once more, from a tile number the compiler cannot recognise: kept from above it would be spilled through the staged form)
+    uint32_t t_again = t;
+    asm volatile("" : "+s"(t_again));
+    const uint32_t slot_s = (threadIdx.x + (((ablate & 8) ? 0u : ((t_again ^ (t_again >> 3) ^ (t_again >> 7)) & 3u)) << 6)) & (uint32_t)(TILE_THREADS - 1);
+    const bool active_s = slot_s < n_act;
+    uint32_t *const w0 = s_x2 + TILE_THREADS;
+    const WalkLds W{w0, w0 + TILE_THREADS, reinterpret_cast<int *>(w0 + 2 * TILE_THREADS), w0 + 2 * TILE_THREADS + 4, w0 + 2 * TILE_THREADS + 8};
+    // (the CIGAR heads are fetched once more: for the compiler this form FOLLOWS the staged one -- see below -- and words kept for it
+    //  would be alive, i.e. spilled, through the probe rounds of every tile; these tiles are rare)
+    uint32_t cgs[SLAB_HEAD];
+#pragma unroll
+    for (int i = 0; i < SLAB_HEAD; ++i) cgs[i] = 1u;
+    if (active_s) {
+        const uint32_t *const words = a->f.cig + c_lo;
+#pragma unroll
+        for (int q = 0; q < SLAB_HEAD_VEC; ++q)
+            if ((uint32_t)(4 * q) < n_cig) {
+                const v4i_a4 x = *reinterpret_cast<const v4i_a4 *>(words + 4 * q);
+                cgs[4 * q] = (uint32_t)x.x; cgs[4 * q + 1] = (uint32_t)x.y; cgs[4 * q + 2] = (uint32_t)x.z; cgs[4 * q + 3] = (uint32_t)x.w;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < SLAB_HEAD; ++i) cgs[i] = (uint32_t)i < n_cig ? cgs[i] : 1u;
+    const uint32_t tot = slab_walk_tile<false, false>(sa, a, t, r0, n_act, rec.sbase, rec.rows, tid0, pos0, slot_s, active_s, c_lo, pos, xw, cgs, W);
+    if (threadIdx.x == 0 && !counted) lb_publish(sa, t, tot);
+    uint32_t share = 0u;
+    uint32_t n_polls_s = 0u;
+    bool done_s;
+    if (wv < 3) share = lb_share<false>(sa, t, wv, lane, done_s, n_polls_s);
+    if (lane == 0 && wv < 3) s_lb[wv] = share;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t xbase = s_lb[0] + s_lb[1] + s_lb[2];
+        u_xbase[t] = xbase;
+        if (t + 1u == n_tiles) { u_xbase[n_tiles] = xbase + tot; *sa->exon_total = xbase + tot; }
+        // the rows each wave of the probe kernels has to look at (k_describe_scan could not know them)
+        sa->tw[t].pad[0] = W.wn[0] | (W.wn[1] << 8) | (W.wn[2] << 16) | (W.wn[3] << 24);
+        // which kernel takes the tile: the 64-bit-mask and the chunked kernel have theirs on their lists (k_describe_scan); a key in
+        // several entries makes it k_probe_slab_chunked's (as k_probe_slab decides), anything else k_probe_slab's
+        if (!pre_slab) {
+            if (wide_key && chunk_on) { sa->tw[t].d.flags = d0.flags | TD_CHUNK; sa->chunk_list[atomicAdd(sa->list_cnt + 1, 1u)] = t; }
+            else sa->fb_list[atomicAdd(sa->list_cnt + 4, 1u)] = t;
+        }
+    }
+
+}
+
+}  // namespace l2r

@@ -48,7 +48,7 @@ def _chain(exons):
     return exons[0][0] - 1, ops
 
 
-@pytest.fixture(autouse=True, params=["slab", "classic"])
+@pytest.fixture(autouse=True, params=["tile", "slab", "classic"])
 def pipeline(request, monkeypatch):
     """Every case runs on each of the engine's two kernel pipelines (l2r_engine.hip: L2R_PIPELINE is read by l2r_create;
     records the chosen pipeline cannot take -- unsorted, long CIGARs -- fall to the classic one by themselves)."""
@@ -397,7 +397,7 @@ def test_splice_distance_on_the_mask_path(oracle, dis, level, pipeline):
     got, want = _run(oracle, af, _reads(rows), counters=cnt, full_level=level, ss_dis=dis)
     k = (want.info & 1) != 0
     assert k.sum() > 200 and (((want.info & 2) != 0) & ~k).sum() > 200
-    if pipeline == "slab":
+    if pipeline in ("tile", "slab"):
         assert cnt[0] == 0, cnt                                  # nothing for the generic kernel
 
 
@@ -420,7 +420,7 @@ def test_splice_distance_with_two_annotation_sites_inside_the_tolerance(oracle, 
     got, want = _run(oracle, af, _reads(rows), counters=cnt, full_level=3, ss_dis=3)
     known = (want.info & 1) != 0
     assert known.sum() > 300 and (want.ref_tx[known] == 1).sum() >= 100 and (want.ref_tx[known] == 0).sum() >= 50      # B for the twin-donor reads, A for donor 1100 itself
-    if pipeline == "slab":
+    if pipeline in ("tile", "slab"):
         assert 0 < cnt[0] <= 300, cnt                            # the reads around the twin donors, nobody else
 
 
@@ -443,7 +443,7 @@ def test_sparse_stretches_make_their_own_tiles_small_and_no_others(oracle, pipel
     held sparse ones (a rule the classic pipeline needs): twice the tiles on an annotation with busy loci between quiet stretches.
     Ten busy loci of 3000 reads each, between them stretches of 600 reads one kb apart (256 of those span more than the staged
     bucket directory, 128 do not: the old rule chose 128 for every tile -- 235 tiles for the busy loci instead of 120)."""
-    if pipeline != "slab":
+    if pipeline not in ("tile", "slab"):
         pytest.skip("the classic pipeline keeps its rule")
     exons = [(0, 300), (900, 1_200), (2_000, 2_400)]
     txs, rows = [], []

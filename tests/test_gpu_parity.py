@@ -8,7 +8,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["slab", "classic"])
+@pytest.fixture(scope="module", params=["tile", "slab", "classic"])
 def engine(request):
     """One engine per kernel pipeline (l2r_create reads L2R_PIPELINE): every case of this file runs on both."""
     import os
@@ -256,7 +256,7 @@ def test_isoform_rich_annotations_full_size(engine, oracle, cfgname, lo):
     the generic kernel (src/update_gtf.c:796-822: the reference's sweep knows no window limit)."""
     import ctypes as C
     from lr2rmats_amd import workload
-    if engine.pipeline != "slab":
+    if engine.pipeline not in ("tile", "slab"):
         pytest.skip("the classic pipeline leaves windows beyond 32 transcripts to the generic kernel: covered at small size")
     af, reads = workload.make_rank_workload(dict(workload.CONFIGS[cfgname]), 0, 1)
     _set_anno(engine, af)

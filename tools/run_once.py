@@ -28,6 +28,7 @@ if os.environ.get("L2R_STAMPS"):
     tot = sum(v[:8]) or 1
     print("stamps (cycles of thread 0 summed over tiles):", [(i, x, round(100.0 * x / tot, 1)) for i, x in enumerate(v[:8]) if x])
     print("  slab pipeline (k_probe_slab, wave 0): 0 loads 1 staging + barrier 2 window pass 3 probe rounds 4 verdicts 5 write-out | last wave: 6 whole kernel 7 probe rounds; per tile:", [round(x / max(1, int(os.environ.get("L2R_TILES", "39074")))) for x in v[:8]])
+    print("  one-kernel tile path (k_tile, wave 0): 0 records + sort + CIGAR heads asked for + staging 1 count walk + barrier 6 scan + publish + place walk 2 window pass 3 probe rounds 4 verdicts 7 first slot (counts in front) 5 write-out; per tile:", [round(x / max(1, int(os.environ.get("L2R_TILES", "39074")))) for x in v[:8]])
     print("  classic kernel: 0 CIGAR staging 7 walk 1 dictionary staging 2 window pass 3 probes 4 verdicts 5 counts 6 write-out")
     print("  one-walk kernel: 0 walk 1 staging 2 window pass + next span 3 probes + verdicts 4 offsets/map/write-out | 5 barrier waits of wave 0, 6 of the last wave, 7 descriptor work of the last wave (5-7 are not phases: compare with the sum of 0-4)")
     print("redo reasons [not fast, not in LDS, wide, other tid, not sane, window/compact]:", v[8:14])
