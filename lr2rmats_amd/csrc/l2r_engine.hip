@@ -76,6 +76,7 @@ struct l2r_ctx {
     bool tile = false;                      // ... with the one-kernel tile path (l2r_tile.hip.h: short CIGARs, -e >= 1)
     DevBuf<unsigned long long> lb_tile, lb_blk, lb_sup;     // one-kernel tile path: the tiles' exon counts on their way to the later tiles' first slots
     DevBuf<uint32_t> fb_list;                               //                       the tiles it leaves to k_probe_slab
+    DevBuf<SlotRec> slot_rec;                               //                       the upload's slot records (k_tile_index)
     DevBuf<TileStat> tile_stat; std::vector<TileStat> h_tile_stat;      //                 the upload's index of the tiles' CIGAR operations (k_tile_index)
     DevBuf<uint32_t> tile_sbase, s_pre, s_loc, s_pl, cig_off32, tile_rec, tile_total, tile_xbase, tile_span;    // (tile_span: 16-byte TileSpan records, l2r_slab.hip.h)
     DevBuf<int32_t> dense_start, dense_end;                 // slab pipeline: the outliers' dense area
@@ -234,7 +235,7 @@ void l2r_destroy(l2r_ctx *c)
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_acc_at.release(); c->tile_acc_ex_at.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->tile_total.release(); c->tile_xbase.release(); c->tile_rec.release(); c->cig_off32.release(); c->s_pl.release(); c->tile_span.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_list.release(); c->chunk_list.release(); c->list_cnt.release(); c->tile_flags.release();
-    c->lb_tile.release(); c->lb_blk.release(); c->lb_sup.release(); c->fb_list.release(); c->tile_stat.release();
+    c->lb_tile.release(); c->lb_blk.release(); c->lb_sup.release(); c->fb_list.release(); c->tile_stat.release(); c->slot_rec.release();
     c->slab_row.release(); c->dense_start.release(); c->dense_end.release(); c->s_pre.release(); c->s_loc.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -879,7 +880,8 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             sbase[T] = (uint32_t)total;                     // (rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true;
             if (c->tw64.ensure(T + 1) || c->wide_list.ensure(T + 1) || c->chunk_list.ensure(T + 1) || c->list_cnt.ensure(8) || c->tile_flags.ensure(T + 8) ||
-                c->lb_tile.ensure(T + 64) || c->lb_blk.ensure(T / LB_BLK + 64) || c->lb_sup.ensure((T >> LB_SUP_SHIFT) + 64) || c->fb_list.ensure(T + 1) || c->tile_stat.ensure(T + 1)) return -2;
+                c->lb_tile.ensure(T + 64) || c->lb_blk.ensure(T / LB_BLK + 64) || c->lb_sup.ensure((T >> LB_SUP_SHIFT) + 64) || c->fb_list.ensure(T + 1) || c->tile_stat.ensure(T + 1) ||
+                (!c->wide_cigar && c->slot_rec.ensure((T + 1) * TILE_THREADS))) return -2;
             HIP_TRY(hipMemsetAsync(c->lb_sup.p, 0, ((T >> LB_SUP_SHIFT) + 64) * 8, c->stream));      // (from then on cleared behind every run, by k_classify_generic)      // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB each)
             HIP_TRY(hipMemsetAsync(c->list_cnt.p, 0, 32, c->stream));
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) || c->tile_total.ensure(T + 2) || c->tile_xbase.ensure(T + 2) || c->tile_span.ensure(12 * (T + 1)) ||
@@ -906,8 +908,8 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             // ... and an index of its CIGAR operations from which a run knows the tile's exon count unless a threshold is borderline in it
             c->h_tile_stat.assign(T, TileStat{0, INT32_MAX, 0, INT32_MAX});
             if (T && !c->wide_cigar) {
-                hipLaunchKernelGGL(k_tile_index, dim3((unsigned)std::min<size_t>(T, 8192)), dim3(TILE_THREADS), 0, c->stream, (TileRec *)c->tile_rec.p, c->tile_stat.p, (uint32_t)T,
-                                   (const uint32_t *)c->cig_off32.p, (const int32_t *)c->r_pos.p, (const uint32_t *)c->cig.p);
+                hipLaunchKernelGGL(k_tile_index, dim3((unsigned)std::min<size_t>(T, 8192)), dim3(TILE_THREADS), 0, c->stream, (TileRec *)c->tile_rec.p, c->tile_stat.p, c->slot_rec.p, (uint32_t)T,
+                                   (const uint32_t *)c->cig_off32.p, (const int32_t *)c->r_pos.p, (const uint8_t *)c->r_rev.p, (const uint32_t *)c->cig.p);
                 HIP_TRY(hipMemcpyAsync(c->h_tile_stat.data(), c->tile_stat.p, T * sizeof(TileStat), hipMemcpyDeviceToHost, c->stream));
             }
             HIP_TRY(hipStreamSynchronize(c->stream));       // (locals)
@@ -1062,7 +1064,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p;
         sa.chunk_on = (c->ablate & 32) ? 0u : 1u;          // (L2R_ABLATE bit 2: no 64-member windows, bit 5: no chunked windows)
         sa.wide_list = c->wide_list.p; sa.chunk_list = c->chunk_list.p; sa.list_cnt = c->list_cnt.p; sa.tile_flags = c->tile_flags.p;
-        sa.lb_tile = c->lb_tile.p; sa.lb_blk = c->lb_blk.p; sa.lb_sup = c->lb_sup.p; sa.lb_err = c->totals.p + 6; sa.fb_list = c->fb_list.p; sa.exon_total = c->totals.p + 0; sa.tile_stat = c->tile_stat.p;
+        sa.lb_tile = c->lb_tile.p; sa.lb_blk = c->lb_blk.p; sa.lb_sup = c->lb_sup.p; sa.lb_err = c->totals.p + 6; sa.fb_list = c->fb_list.p; sa.exon_total = c->totals.p + 0; sa.tile_stat = c->tile_stat.p; sa.has_wide_keys = c->n_wide > 0 ? 1u : 0u;
         // (with the accepted list wanted and no junction table to decide later, the tiles leave their accepted chunks themselves)
         const bool probe_acc = (c->want & L2R_WANT_ACCEPTED) && c->n_sj == 0;
 #define launch_probe_k(L, A, D, LIST, G) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L, A, D, LIST>), dim3(G), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
@@ -1081,7 +1083,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_describe_scan<true>), dim3(gd), dim3(TILE_THREADS), 0, s, sa, job, 0u, (const TileRec *)c->tile_rec.p);
             MARK(ST_SCAN1);
             const unsigned gf = fused_grid(c->n_tiles);
-#define launch_tile_k(L, A, D) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile<L, A, D>), dim3(gf), dim3(TILE_THREADS), 0, s, sa, (const TileRec *)c->tile_rec.p, (const TileWin *)c->tw.p, (const TileStat *)c->tile_stat.p, c->tile_xbase.p)
+#define launch_tile_k(L, A, D) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile<L, A, D>), dim3(gf), dim3(TILE_THREADS), 0, s, sa, (const TileRec *)c->tile_rec.p, (const TileWin *)c->tw.p, (const TileStat *)c->tile_stat.p, (const SlotRec *)c->slot_rec.p, c->tile_xbase.p)
 #define launch_tile_level(L) do { if (p.ss_dis > 0) { if (probe_acc) launch_tile_k(L, true, true); else launch_tile_k(L, false, true); } \
                                   else { if (probe_acc) launch_tile_k(L, true, false); else launch_tile_k(L, false, false); } } while (0)
             switch (p.full_level) {

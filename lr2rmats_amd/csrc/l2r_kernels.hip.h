@@ -32,6 +32,7 @@ namespace l2r {
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));                    // (LDS copy of a dictionary entry {k1, k2, pm, sm}, masks in the tile frame)
 typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));       // a 16-byte access at any 4-byte boundary (global memory)
+typedef uint32_t v3u_a4 __attribute__((ext_vector_type(3), aligned(4)));   // a 12-byte access at any 4-byte boundary (global memory)
 typedef uint32_t u32_a1 __attribute__((aligned(1)));                      // a 4-byte access at any address (global memory)
 
 constexpr int TILE_THREADS = 256;

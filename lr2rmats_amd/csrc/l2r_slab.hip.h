@@ -119,6 +119,7 @@ struct SlabArgs {
     unsigned long long *lb_tile, *lb_blk, *lb_sup;
     const TileStat *tile_stat;
     uint32_t *lb_err, *fb_list;
+    uint32_t has_wide_keys;                              // the annotation has dictionary keys in several entries (SE_WIDE)
     uint32_t *exon_total;                                // the run's exon count (k_tile: written by the last tile)
 };
 typedef const __attribute__((address_space(4))) SlabArgs *SlabArgsK;
@@ -246,7 +247,8 @@ __device__ __forceinline__ uint32_t slab_walk_tile(SlabArgsK sa, PipeArgsK a, ui
     const int m = wave_max(active ? el : INT32_MIN);
     const int wn = wave_max((active && !outlier) ? (int)n : 0);
     const int wn_all = wave_max(active ? (int)min(n, 0x7fffffffu) : 0);
-    if (lane == 0) { W.wmax[wv] = m; W.wn[wv] = (uint32_t)min(wn, 255); W.nmax[wv] = (uint32_t)wn_all; }
+    // (wn: by SLOT group -- the probe kernels ask "which rows do the slots of my wave have"; k_tile's waves hold rotated slot groups)
+    if (lane == 0) { W.wmax[wv] = m; W.wn[slot >> 6] = (uint32_t)min(wn, 255); W.nmax[wv] = (uint32_t)wn_all; }
     if (FIRST && t == 0u && threadIdx.x == 0) {
         // the run's counters (this kernel is the first of a run): redo list, chunk cursor of the accepted list.
         // (The cursor of the outlier area is cleared by k_probe_slab for the next run.)
@@ -649,13 +651,18 @@ void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan, 
         uint32_t *const cnt = a->f.redo_count;
         cnt[0] = 0u; cnt[1] = 0u; cnt[2] = 0u;
         *sa->ovf_cursor = 0ull; *sa->lb_err = 0u;
+        *sa->exon_total = 0u;                            // (k_tile's last tile writes the run's exon count: an upload without reads has none)
         uint32_t *const lc = sa->list_cnt;
         lc[2] = 0u; lc[3] = 0u; lc[4] = 0u; lc[5] = 0u;
     }
     if (t < sa->n_tiles) {
         int4 spv, spw;
         if (FIRST) {
-            const int4 rv = reinterpret_cast<const int4 *>(u_rec + t)[1];          // {tid0, lo, hi, .}
+            // (every load that needs nothing but the tile number leaves together, in front of the cursor's chain of three)
+            const int4 r0v = reinterpret_cast<const int4 *>(u_rec + t)[0];             // {r0, n_act, sbase, rows}
+            const int4 rv = reinterpret_cast<const int4 *>(u_rec + t)[1];              // {tid0, lo, hi, .}
+            const int4 sv = *reinterpret_cast<const int4 *>(sa->tile_stat + t);
+            asm volatile("" :: "v"(r0v.y), "v"(rv.x), "v"(sv.x));
             CursorDir cd;
             cd.key = a->cd.key; cd.dir = a->cd.dir; cd.kb_base = a->cd.kb_base; cd.n_tid = a->cd.n_tid; cd.n_tx = a->cd.n_tx;
             const int jl = cursor_value(cd, rv.x, rv.y);
@@ -664,8 +671,6 @@ void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan, 
             spv = make_int4(rv.x, rv.y, rv.z, 0); spw = make_int4(jl, tb, nb, 0);
             // the tile's exon count, where no threshold is borderline inside it: known to every later tile from here on
             if (gl == 0) {
-                const int4 r0v = reinterpret_cast<const int4 *>(u_rec + t)[0];         // {r0, n_act, sbase, rows}
-                const int4 sv = *reinterpret_cast<const int4 *>(sa->tile_stat + t);
                 const TileStat st{sv.x, sv.y, sv.z, sv.w};
                 const bool exact = tile_exact(st, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet) && !(a->f.p.ablate & 256);
                 my_total = exact ? (1ull << LB_SHIFT) | (unsigned long long)(uint32_t)(r0v.y + st.n_ops_n) : 0ull;
@@ -682,13 +687,15 @@ void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan, 
     if (gl == 0) s_flags[slot] = flags;
     if (FIRST && gl == 0) { s_tot[slot][0] = (uint32_t)my_total; s_tot[slot][1] = (uint32_t)(my_total >> 32); }
     __syncthreads();
-    if (FIRST && threadIdx.x == 0 && t0 < sa->n_tiles) {
+    if (FIRST && wv == 1 && t0 < sa->n_tiles) {
         // the block's word: the sum of the counts known here (k_tile adds the others); a block that is complete goes to its super-block
-        unsigned long long sum = 0ull;
-        for (int i = 0; i < DESCRIBE_TILES; ++i) sum += ((unsigned long long)s_tot[i][1] << 32) | s_tot[i][0];
-        sa->lb_blk[t0 >> LB_BLK_SHIFT] = sum;
-        const uint32_t in_blk = min((uint32_t)LB_BLK, sa->n_tiles - t0);
-        if ((uint32_t)(sum >> LB_SHIFT) == in_blk) atomicAdd(sa->lb_sup + (t0 >> LB_SUP_SHIFT), (1ull << LB_SHIFT) | (sum & LB_SUM_MASK));
+        const uint32_t lo = lane < DESCRIBE_TILES ? s_tot[lane][0] : 0u, hi = lane < DESCRIBE_TILES ? s_tot[lane][1] : 0u;
+        const unsigned long long sum = ((unsigned long long)wave_sum(hi) << 32) + (unsigned long long)wave_sum(lo);      // (an exact tile has fewer than 4096 exons: no carry out of the low words)
+        if (lane == 0) {
+            sa->lb_blk[t0 >> LB_BLK_SHIFT] = sum;
+            const uint32_t in_blk = min((uint32_t)LB_BLK, sa->n_tiles - t0);
+            if ((uint32_t)(sum >> LB_SHIFT) == in_blk) atomicAdd(sa->lb_sup + (t0 >> LB_SUP_SHIFT), (1ull << LB_SHIFT) | (sum & LB_SUM_MASK));
+        }
     }
     if (wv == 0) {
         const uint32_t f = lane < DESCRIBE_TILES ? s_flags[lane] : TD_FAST;

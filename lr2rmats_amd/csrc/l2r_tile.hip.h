@@ -57,20 +57,38 @@ inline unsigned fused_grid(int64_t n_tiles)
 //                    without its CIGARs whenever no threshold is borderline inside the tile (tile_exact): every N is an intron
 //                    (-i <= the shortest N), no D cuts (-t >= the longest D), no inner exon is dropped (-e <= the shortest
 //                    stretch) => exons = reads + N operations (src/bam2gtf.c:41-74).  Tiles for which that does not hold count in k_tile.
+//   slot records     the tile's reads by falling CIGAR length (the counting sort k_walk_slab does per run: CIGAR lengths only), one
+//                    12-byte record per SLOT at a fixed place -- tile t, thread p: u_slot[t * 256 + p] -- so k_tile asks for them with
+//                    nothing but its tile number, beside its scalar loads, and the CIGAR heads are its second round trip.  Thread p
+//                    holds slot (p + 64 rot) & 255, rot = a hash of the tile number: the slot groups (group 0 = the longest reads)
+//                    are rotated over the waves.  A record also says where the read's exons begin among the tile's exons in read order
+//                    IF the tile is exact (`loc`: the sum of 1 + N operations over the tile's reads in front of it): an exact tile
+//                    needs neither a count walk nor a scan.
+struct SlotRec { uint32_t c_lo; int32_t pos; uint32_t xw; };      // xw: SLOT_* fields
+// xw: CIGAR length in bits 0-7 (255: that many or more), strand bit 8, "a read" bit 9, read number inside the tile bits 10-17, loc bits 18-29
+constexpr uint32_t SLOT_REV = 1u << 8, SLOT_VALID = 1u << 9;
+constexpr int SLOT_IDX_SHIFT = 10, SLOT_LOC_SHIFT = 18;
+constexpr uint32_t SLOT_LOC_LIMIT = 1u << 12;
+__device__ __forceinline__ uint32_t tile_rot(uint32_t t) { return (t ^ (t >> 3) ^ (t >> 7)) & 3u; }
 __global__ __launch_bounds__(TILE_THREADS)
-void k_tile_index(TileRec *__restrict__ rec, TileStat *__restrict__ stat, uint32_t n_tiles, const uint32_t *__restrict__ cig_off32, const int32_t *__restrict__ r_pos,
-                  const uint32_t *__restrict__ cig)
+void k_tile_index(TileRec *__restrict__ rec, TileStat *__restrict__ stat, SlotRec *__restrict__ slot_rec, uint32_t n_tiles,
+                  const uint32_t *__restrict__ cig_off32, const int32_t *__restrict__ r_pos, const uint8_t *__restrict__ r_rev, const uint32_t *__restrict__ cig)
 {
     __shared__ int s_m[5][TILE_THREADS / WAVE];
+    __shared__ uint32_t s_hist[WAVE], s_wave[TILE_THREADS / WAVE];
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint32_t r0 = rec[t].r0, n_act = rec[t].n_act;
+        const uint32_t i = threadIdx.x;
+        const bool active = i < n_act;
         int end = INT32_MIN, n_n = 0, min_n = INT32_MAX, max_d = 0, min_seg = INT32_MAX;
-        if (threadIdx.x < n_act) {
-            const uint32_t r = r0 + threadIdx.x;
-            end = r_pos[r];
+        uint32_t c_lo = 0u, c = 0u, rev = 0u; int32_t pos = 0;
+        if (active) {
+            const uint32_t r = r0 + i;
+            c_lo = cig_off32[r]; c = cig_off32[r + 1u] - c_lo; pos = r_pos[r]; rev = r_rev[r] ? 1u : 0u;
+            end = pos;
             int seg = 0; bool first = true;
-            for (uint32_t k = cig_off32[r]; k < cig_off32[r + 1u]; ++k) {
-                const uint32_t c = cig[k], op = c & 0xfu; const int len = (int)(c >> 4);
+            for (uint32_t k = c_lo; k < c_lo + c; ++k) {
+                const uint32_t w = cig[k], op = w & 0xfu; const int len = (int)(w >> 4);
                 if (op == 3u) {
                     ++n_n; min_n = min(min_n, len);
                     if (!first) min_seg = min(min_seg, seg);      // (the first exon is kept whatever its length)
@@ -82,6 +100,22 @@ void k_tile_index(TileRec *__restrict__ rec, TileStat *__restrict__ stat, uint32
                 end += len & __builtin_amdgcn_sbfe(0x18d, op, 1u);
             }
         }
+        // the read's place among the tile's exons in read order if every N operation is an intron and nothing is dropped
+        uint32_t tot_x;
+        const uint32_t loc = block_exclusive_scan(active ? (uint32_t)n_n + 1u : 0u, s_wave, tot_x);
+        if (tot_x >= SLOT_LOC_LIMIT) min_seg = INT32_MIN;         // (places the record cannot say: the tile counts in k_tile -- it keeps the slab form anyway)
+        // the counting sort of k_walk_slab (64 bins by CIGAR length, threads without a read last)
+        if (i < (uint32_t)WAVE) s_hist[i] = 0u;
+        __syncthreads();
+        const uint32_t est = active ? max(1u, min((c + 1u) >> 1, (uint32_t)(WAVE - 1))) : 0u;
+        const uint32_t bin = (uint32_t)(WAVE - 1) - est;
+        const uint32_t rank = atomicAdd(&s_hist[bin], 1u);
+        __syncthreads();
+        if (i < (uint32_t)WAVE) { const uint32_t v = s_hist[i]; s_hist[i] = wave_inclusive_scan(v) - v; }
+        __syncthreads();
+        const uint32_t at = (s_hist[bin] + rank - (tile_rot(t) << 6)) & (uint32_t)(TILE_THREADS - 1);      // the thread of that slot
+        slot_rec[(size_t)t * TILE_THREADS + at] = SlotRec{c_lo, pos, min(c, 255u) | (rev ? SLOT_REV : 0u) | (active ? SLOT_VALID : 0u) | (i << SLOT_IDX_SHIFT) |
+                                                                         (min(loc, SLOT_LOC_LIMIT - 1u) << SLOT_LOC_SHIFT)};
         const int v[5] = {wave_max(end), (int)wave_sum((uint32_t)n_n), wave_min(min_n), wave_max(max_d), wave_min(min_seg)};
         if ((threadIdx.x & (WAVE - 1)) == 0) for (int k = 0; k < 5; ++k) s_m[k][threadIdx.x >> 6] = v[k];
         __syncthreads();
@@ -286,12 +320,13 @@ __device__ __forceinline__ SlabVerdict tile_classify(PipeArgsK a, const TileDesc
 // (one byte each, read order) and their exclusive scan (16 bit).
 constexpr int TILE_LDS_BYTES = SLAB_POS_CAP * 6 + 2 * SLAB_KEY_CAP * 16 + SLAB_AUX_BYTES + TILE_THREADS * 3 + 16 * 4 + 4 * 4;
 static_assert(TILE_LDS_BYTES <= 23040, "k_tile: 7 workgroups per CU need 45 allocation granules of 512 bytes at most");
-static_assert(SLAB_POS_CAP >= 64 + 5 * TILE_THREADS + 16, "the sort's arrays (and slab_walk_tile's) live in the staged positions until the place walk");
+static_assert(SLAB_POS_CAP >= 2 * TILE_THREADS + 16, "slab_walk_tile's words live in the staged positions");
 static_assert(SLAB_POS_CAP < 65536 && SLAB_POS_CAP % 8 == 0, "16-bit places; 16-byte aligned arrays");
 
 template <int LEVEL, bool ACC, bool DIS>
 __global__ __launch_bounds__(TILE_THREADS, 7)
-void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const TileWin *__restrict__ u_tw, const TileStat *__restrict__ u_stat, uint32_t *__restrict__ u_xbase)
+void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const TileWin *__restrict__ u_tw, const TileStat *__restrict__ u_stat, const SlotRec *__restrict__ u_slot,
+            uint32_t *__restrict__ u_xbase)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
     __shared__ __attribute__((aligned(16))) uint32_t s_A[SLAB_POS_CAP];
@@ -301,10 +336,9 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     __shared__ __attribute__((aligned(16))) uint8_t s_cnt[TILE_THREADS];        // exon counts, read order (255: that many or more)
     __shared__ __attribute__((aligned(16))) uint16_t s_loc[TILE_THREADS];       // ... and their exclusive scan
     __shared__ uint32_t s_flagw[TILE_THREADS / WAVE], s_redow[TILE_THREADS / WAVE];
-    __shared__ uint32_t s_lb[4], s_lbok[4];
+    __shared__ uint32_t s_lb[4];
     __shared__ uint32_t s_chunk[2];
-    // (until the place walk the staged positions hold the sort's arrays; in a tile that keeps the slab form, slab_walk_tile's)
-    uint32_t *const s_hist = s_A, *const s_x0 = s_A + WAVE, *const s_x1 = s_x0 + TILE_THREADS, *const s_x2 = s_x1 + TILE_THREADS;
+    // (in a tile that keeps the slab form the staged positions hold slab_walk_tile's words)
     uint8_t *const s_dir = s_aux;
     TileWin &s_tw = *reinterpret_cast<TileWin *>(s_aux + SLAB_DIR_BYTES);
     (void)kernarg_block;
@@ -313,10 +347,12 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     const uint32_t t = fused_tile(blockIdx.x);
     if (t >= sa->n_tiles) return;
-    // diagnostics (L2R_STAMPS=1), wave 0: [0] records, sort, CIGAR heads asked for, staging  [1] count walk + barrier  [6] scan, count
+    // diagnostics (L2R_STAMPS=1), wave 0: [0] records, CIGAR heads asked for, staging  [1] (count walk + barrier)  [6] scan, count
     // published, place walk  [2] window pass  [3] probe rounds  [4] verdicts  [7] the tile's first slot (exon counts in front)  [5] write-out
     SlabStamp stamp; stamp.start(a->f.stamps); if (stamp.who == 3) stamp.who = -1;
     const uint32_t clk0 = stamp.p ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
+    // The thread's slot record lies at a place the tile number alone says (k_tile_index): asked for beside the scalar loads below.
+    const v3u_a4 srec = *reinterpret_cast<const v3u_a4 *>(u_slot + ((size_t)t * TILE_THREADS + threadIdx.x));
     // The tile's record from the upload and its descriptor from k_describe_scan: every scalar load of the prologue leaves before the
     // first one is waited for (see k_probe_slab).
     const TileRec rec = u_rec[t];
@@ -326,76 +362,35 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     const uint32_t n_tiles = sa->n_tiles;
     asm volatile("" :: "s"(tst.n_ops_n), "s"(tst.min_n), "s"(tst.max_d), "s"(tst.min_seg), "s"(chunk_on), "s"(ablate), "s"(n_tiles), "s"(rec.r0), "s"(rec.n_act), "s"(rec.sbase), "s"(rec.rows), "s"(rec.tid0), "s"(rec.lo),
                        "s"(d0.j_lo), "s"(d0.b_off), "s"(d0.nb), "s"(d0.b0), "s"(d0.nbk), "s"(d0.st_r0), "s"(d0.st_nk), "s"(d0.en_r0), "s"(d0.en_nk), "s"(d0.flags), "s"(d0.n_win));
-    // (diagnostics, per tile, for l2r_debug_tile_times: the 100 MHz clock at the tile's start | the XCD's number; further down at its
-    //  count's publication, at the begin and the end of its wait for the counts in front.  Behind the scalar loads above: a store in
-    //  front of them turns every one into a vector load.)
-    if (stamp.p && threadIdx.x == 0) {
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        a->tile_total[t] = (clk0 << 3) | (xcc & 7u);
-    }
     const uint32_t r0 = rec.r0, n_act = rec.n_act;
     const int32_t tid0 = rec.tid0, pos0 = rec.lo - 1;
     const int32_t tile_lo = rec.lo;                              // the base of the tile's row words: its first read's first base
     // a tile of the 64-bit-mask or the chunked kernel (on their lists since k_describe_scan): slab form, nothing is staged here
     const bool pre_slab = (d0.flags & TD_WIDE) != 0u || (chunk_on && slab_tile_is_chunked(d0.flags));
-    // the tile's exon count is known to the later tiles since k_describe_scan (no threshold is borderline in it): nothing to publish here
+    // The tile is EXACT: no threshold is borderline in it, so a read's exon count is 1 + its N operations (the upload's read_n) and
+    // the tile's count is known to the later tiles since k_describe_scan -- no count walk, nothing to publish.
     const bool counted = tile_exact(tst, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet) && !(ablate & 256);
     TileDesc d = d0;
     if (pre_slab) d.flags = 0u;
     v4i_t *const s_ent0 = s_ent, *const s_ent1 = s_ent + SLAB_KEY_CAP;
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
-    // thread -> slot: the slot groups (by falling CIGAR length, group 0 = the tile's longest reads) are rotated over the waves by a
-    // hash of the tile number (L2R_ABLATE bit 3: off)
-    const uint32_t rot = (ablate & 8) ? 0u : ((t ^ (t >> 3) ^ (t >> 7)) & 3u);
-    const uint32_t slot = (threadIdx.x + (rot << 6)) & (uint32_t)(TILE_THREADS - 1);
-    // ---- the tile's reads by falling CIGAR length (counting sort, 64 bins): thread i brings read i, the thread of slot s takes what
-    //      landed there.  The dictionary slices and the window record are asked for behind the records: they travel during the sort.
-    DictRegs dv;
-    int4 twv = make_int4(0, 0, 0, 0);
+    // A first look at the exon counts in front of the tile (waves 0 .. 2, one level each): asked for here, looked at further down.
+    // PLAIN loads: what k_describe_scan wrote (the launch in front) is visible to them, and a word is complete only once -- a stale
+    // copy of a word that a tile of this launch is still adding to merely looks incomplete, and the second look (agent-scope loads,
+    // behind the probe rounds) takes over.
     LbLevel lv{nullptr, 0u, 0u};
     unsigned long long ev = 0ull;
-    {
-        const uint32_t i = threadIdx.x;
-        uint32_t c_lo = 0u, c = 0u, rev = 0u; int32_t pos = 0;
-        if (i < n_act) {
-            const uint32_t *const p_off = sa->cig_off32;
-            c_lo = ld32(p_off, r0 + i); c = ld32(p_off, r0 + i + 1u) - c_lo;
-            pos = ld32(a->f.r_pos, r0 + i); rev = ld32(a->f.r_rev, r0 + i) ? 1u : 0u;
-        }
-        // A first look at the exon counts in front of the tile (waves 0 .. 2, one level each): asked for here, looked at behind the sort.
-        // PLAIN loads: what k_describe_scan wrote (the launch in front) is visible to them, and a word is complete only once -- a stale
-        // copy of a word that a tile of this launch is still adding to merely looks incomplete, and the second look (agent-scope loads,
-        // behind the probe rounds) takes over.
-        if (wv < 3 && !pre_slab) { lv = lb_level(sa, t, wv); if ((uint32_t)lane < lv.cnt) ev = lv.p[lane]; }
-        dv = load_dict_slices(a, d);
-        if ((int)threadIdx.x < SLAB_TW_VECS && tw_vec_used((int)threadIdx.x, (d.flags & TD_FAST) ? d.n_win : 0u)) twv = reinterpret_cast<const int4 *>(u_tw + t)[threadIdx.x];
-        if (i < (uint32_t)WAVE) s_hist[i] = 0u;
-        __syncthreads();
-        const uint32_t est = i < n_act ? max(1u, min((c + 1u) >> 1, (uint32_t)(WAVE - 1))) : 0u;      // threads without a read sort last
-        const uint32_t bin = (uint32_t)(WAVE - 1) - est;
-        const uint32_t rank = atomicAdd(&s_hist[bin], 1u);
-        __syncthreads();
-        if (i < (uint32_t)WAVE) { const uint32_t v = s_hist[i]; s_hist[i] = wave_inclusive_scan(v) - v; }
-        __syncthreads();
-        const uint32_t at = (s_hist[bin] + rank - (rot << 6)) & (uint32_t)(TILE_THREADS - 1);      // the thread of that slot
-        s_x0[at] = c_lo; s_x1[at] = (uint32_t)pos; s_x2[at] = min(c, 0xffffu) | (rev << 16) | (i << 24);
-        __syncthreads();
-    }
-    if (wv < 3 && !pre_slab) {
-        // (complete words only; a level of more than 64 words -- beyond 65 k tiles -- is left to the second look)
-        const bool in = (uint32_t)lane < lv.cnt;
-        const bool ok = __all(!in || (uint32_t)(ev >> LB_SHIFT) == lv.want) && lv.cnt <= (uint32_t)WAVE;
-        const uint32_t w_sum = wave_sum(in ? (uint32_t)ev : 0u);
-        if (lane == 0) { s_lb[wv] = w_sum; s_lbok[wv] = ok ? 1u : 0u; }
-    }
-    // (the window record goes to LDS before the CIGAR heads are asked for: four registers less beside the 24 words and the dictionary entries)
-    if (!pre_slab && (int)threadIdx.x < SLAB_TW_VECS) reinterpret_cast<int4 *>(&s_tw)[threadIdx.x] = twv;
-    const bool active = slot < n_act;                            // (reads without a thread sort last: the slots behind the tile's reads)
-    const uint32_t c_lo = s_x0[threadIdx.x], xw = s_x2[threadIdx.x];
-    const int32_t pos = (int32_t)s_x1[threadIdx.x];
-    const uint32_t n_cig = xw & 0xffffu, idx = xw >> 24;         // (n_cig 65535: that many or more)
-    // ---- the head of the read's CIGAR: six 16-byte vectors, all in flight at once; words behind the last op become "I, length 0"
+    if (wv < 3 && !pre_slab) { lv = lb_level(sa, t, wv); if ((uint32_t)lane < lv.cnt) ev = lv.p[lane]; }
+    // the dictionary slices and the window record: they travel while the CIGAR heads are asked for
+    const DictRegs dv = load_dict_slices(a, d);
+    int4 twv = make_int4(0, 0, 0, 0);
+    if ((int)threadIdx.x < SLAB_TW_VECS && tw_vec_used((int)threadIdx.x, (d.flags & TD_FAST) ? d.n_win : 0u)) twv = reinterpret_cast<const int4 *>(u_tw + t)[threadIdx.x];
+    // ---- the thread's slot record (asked for at the top of the kernel) and the head of its read's CIGAR: six 16-byte vectors, all in
+    //      flight at once; words behind the last op become "I, length 0"
+    const uint32_t c_lo = srec.x, xs = srec.z;
+    const int32_t pos = (int32_t)srec.y;
+    const bool active = (xs & SLOT_VALID) != 0u;
+    const uint32_t n_cig = xs & 0xffu, idx = (xs >> SLOT_IDX_SHIFT) & 0xffu;         // (n_cig 255: that many or more)
     uint32_t cg[SLAB_HEAD];
 #pragma unroll
     for (int i = 0; i < SLAB_HEAD; ++i) cg[i] = 1u;
@@ -408,7 +403,16 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
                 cg[4 * q] = (uint32_t)x.x; cg[4 * q + 1] = (uint32_t)x.y; cg[4 * q + 2] = (uint32_t)x.z; cg[4 * q + 3] = (uint32_t)x.w;
             }
     }
-    // ---- window and dictionary slices into LDS, re-based to the tile's window (they arrived during the sort; the CIGAR words travel)
+    // the first look: complete words only (a level of more than 64 words -- beyond 65 k tiles -- is left to the second look)
+    bool first_look = false;                                     // (of this wave's level)
+    uint32_t first_share = 0u;
+    if (wv < 3 && !pre_slab) {
+        const bool in = (uint32_t)lane < lv.cnt;
+        first_look = __all(!in || (uint32_t)(ev >> LB_SHIFT) == lv.want) && lv.cnt <= (uint32_t)WAVE;
+        first_share = wave_sum(in ? (uint32_t)ev : 0u);
+    }
+    // ---- window and dictionary slices into LDS, re-based to the tile's window (the CIGAR words travel)
+    if (!pre_slab && (int)threadIdx.x < SLAB_TW_VECS) reinterpret_cast<int4 *>(&s_tw)[threadIdx.x] = twv;
     const SlabLds S{nullptr, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir};
     int my_wide = 0;
     if (!pre_slab) my_wide = slab_stage_dict(d, dv, reinterpret_cast<const int *>(u_tw[t].win), S);
@@ -419,9 +423,13 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     p.min_exon = a->f.p.min_exon; p.min_intron = a->f.p.min_intron; p.max_delet = a->f.p.max_delet;
     const uint32_t t3 = ((uint32_t)p.min_intron << 4) | 3u, t2 = ((uint32_t)(p.max_delet + 1) << 4) | 2u;      // op and length compare as one number
     const int c_max = wave_max(active ? (int)min(n_cig, (uint32_t)SLAB_HEAD) : 0);
-    // ---- first walk: COUNT the read's exons (src/bam2gtf.c:31-78 with nothing stored)
+    // ---- the reads' places among the tile's exons in read order: an exact tile has them in its records; else the first of two walks
+    //      COUNTS (src/bam2gtf.c:31-78 with nothing stored), the waves meet and every wave scans the counts.  They also meet when the
+    //      annotation has dictionary keys in several entries (rare: a site shared by transcripts more than 64 apart): whether this
+    //      tile staged one is every wave's business.
     uint32_t n = 0u;
-    if (!pre_slab) {
+    const bool meet = !pre_slab && (!counted || sa->has_wide_keys != 0u);       // (else the waves meet behind the place walk: the staged slices must be whole before the probes)
+    if (!pre_slab && !counted) {
         if (active) {
             int start = pos + 1, end = pos;
             bool first = true;
@@ -446,38 +454,42 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
             ++n;
         }
         s_cnt[idx] = (uint8_t)min(n, 255u);                 // (every entry is written: idx is a permutation of 0 .. 255)
+    }
+    if (meet) {
         // (what the staged positions cannot hold: a read of 255 exons or more -- bit 0; a dictionary key in several entries -- bit 1)
         const uint32_t fw = (__any(n >= 255u) ? 1u : 0u) | (__any(my_wide != 0) ? 2u : 0u);
         if (lane == 0) s_flagw[wv] = fw;
         __syncthreads();
     }
     stamp.mark(1);
-    // ---- every read's place among the tile's exons in READ order: each wave scans the 256 counts (four per lane) for itself
     uint32_t total = 0u, loc = 0u;
-    bool late_slab = false, wide_key = false, first_look = false;
+    bool late_slab = false, wide_key = false;
     int any_wide = 0;
     if (!pre_slab) {
-        const uint32_t c4 = reinterpret_cast<const uint32_t *>(s_cnt)[lane];
-        const uint32_t b0 = c4 & 0xffu, b1 = (c4 >> 8) & 0xffu, b2 = (c4 >> 16) & 0xffu, b3 = c4 >> 24;
-        const uint32_t sum = b0 + b1 + b2 + b3;
-        const uint32_t inc = wave_inclusive_scan(sum), ex = inc - sum;
-        reinterpret_cast<uint2 *>(s_loc)[lane] = make_uint2(ex | ((ex + b0) << 16), (ex + b0 + b1) | ((ex + b0 + b1 + b2) << 16));     // (the four waves write the same values)
-        total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+        if (counted) { total = n_act + (uint32_t)tst.n_ops_n; loc = (xs >> SLOT_LOC_SHIFT) & (SLOT_LOC_LIMIT - 1u); }
+        else {
+            // each wave scans the 256 counts (four per lane) for itself
+            const uint32_t c4 = reinterpret_cast<const uint32_t *>(s_cnt)[lane];
+            const uint32_t b0 = c4 & 0xffu, b1 = (c4 >> 8) & 0xffu, b2 = (c4 >> 16) & 0xffu, b3 = c4 >> 24;
+            const uint32_t sum = b0 + b1 + b2 + b3;
+            const uint32_t inc = wave_inclusive_scan(sum), ex = inc - sum;
+            reinterpret_cast<uint2 *>(s_loc)[lane] = make_uint2(ex | ((ex + b0) << 16), (ex + b0 + b1) | ((ex + b0 + b1 + b2) << 16));     // (the four waves write the same values)
+            total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+            loc = s_loc[idx];
+        }
         // (wave-uniform for the compiler too: a branch it takes for divergent keeps the CIGAR registers alive through the probe rounds)
-        const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_flagw[0] | s_flagw[1] | s_flagw[2] | s_flagw[3]));
-        first_look = __builtin_amdgcn_readfirstlane((int)(s_lbok[0] & s_lbok[1] & s_lbok[2])) != 0;
+        const uint32_t fl = meet ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_flagw[0] | s_flagw[1] | s_flagw[2] | s_flagw[3])) : 0u;
         // a dictionary key in several entries: k_probe_slab_chunked ORs them (the tile keeps the slab form); with chunked windows off
         // the tile's reads take the generic kernel
         late_slab = total > (uint32_t)SLAB_POS_CAP || (fl & 1u) != 0u || ((fl & 2u) != 0u && chunk_on != 0u);
         wide_key = (fl & 2u) != 0u;
         any_wide = (wide_key && !late_slab) ? 1 : 0;
-        loc = s_loc[idx];
     }
     // (the staged form first in the source, the slab form behind it: see the note at the end of the kernel)
     auto staged_form = [&]() {
     // ---- the tile's exon count is known: published for every later tile's first slot
     if (threadIdx.x == 0 && !counted && !(ablate & 128)) lb_publish(sa, t, total);
-    if (stamp.p && threadIdx.x == 0) a->f.tile_acc[t] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    const uint32_t clk1 = stamp.p ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
     // ---- second walk: PLACE the exons as row words at their positions in LDS
     const SlabStage st{s_A, s_L, loc, tile_lo, true};
     ReadEnds re{0, 0, 0, 0};
@@ -524,30 +536,38 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
         big = longest > SLAB_LEN_MAX;
         re = ReadEnds{s0, e0, start, end};
     }
+    if (!meet) __syncthreads();                                  // (the dictionary slices and the window record are whole)
     stamp.mark(6);
-    const uint32_t pre = idx | (((xw >> 16) & 1u) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (n << PRE_N_SHIFT);
+    const uint32_t pre = idx | ((xs & SLOT_REV) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (n << PRE_N_SHIFT);
     const uint32_t r = r0 + idx;
-    // ---- classification (no barrier: a lane probes the positions it has placed itself; the dictionary slices were staged in front
-    //      of the barrier behind the count)
+    // ---- classification (a lane probes the positions it has placed itself; the dictionary slices were whole at the barrier above)
     const SlabVerdict vd = tile_classify<LEVEL, DIS>(a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, big, r, re, st, any_wide, stamp);
     if (ACC) { const int w_redo = __any(vd.redo) ? 1 : 0; if (lane == 0) s_redow[wv] = (uint32_t)w_redo; }
     // ---- the tile's first result slot
+    uint32_t clk2 = 0u;
     {
-        uint32_t share = 0u;
+        uint32_t share = first_share;
         uint32_t n_polls = 0u;
         bool done;
-        if (stamp.p && threadIdx.x == 0) a->f.tile_acc_ex[t] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-        // (the first look found every count in front: nothing to do here -- the rule unless a threshold is borderline somewhere)
-        if (!first_look || (ablate & 64)) {
-            if (wv < 3 && !(ablate & 64)) share = lb_share<false>(sa, t, wv, lane, done, n_polls);
-            if (stamp.p && lane == 0 && wv < 3) { atomicAdd(&stamp.p[8192 + wv], (unsigned long long)n_polls); atomicAdd(&stamp.p[8192 + 3 + wv], n_polls ? 1ull : 0ull); }
-            // (L2R_ABLATE bit 6, timing diagnostics only: no look at the counts in front -- the results land at made-up slots)
-            if (ablate & 64) share = wv == 0 ? t * (uint32_t)SLAB_POS_CAP : 0u;
-            if (lane == 0 && wv < 3) s_lb[wv] = share;
-        }
+        clk2 = stamp.p ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
+        // (a wave whose first look found every count of its level in front has nothing to do here: the rule -- a tile in front that is
+        //  not exact publishes its count from this launch, and the waves that need it look again, with agent-scope loads)
+        if (wv < 3 && !first_look && !(ablate & 64)) share = lb_share<false>(sa, t, wv, lane, done, n_polls);
+        if (stamp.p && lane == 0 && wv < 3) { atomicAdd(&stamp.p[8192 + wv], (unsigned long long)n_polls); atomicAdd(&stamp.p[8192 + 3 + wv], n_polls ? 1ull : 0ull); }
+        // (L2R_ABLATE bit 6, timing diagnostics only: no look at the counts in front -- the results land at made-up slots)
+        if (ablate & 64) share = wv == 0 ? t * (uint32_t)SLAB_POS_CAP : 0u;
+        if (lane == 0 && wv < 3) s_lb[wv] = share;
     }
     __syncthreads();
-    if (stamp.p && threadIdx.x == 0) sa->tile_flags[t] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    // (diagnostics, per tile, for l2r_debug_tile_times: the 100 MHz clock at the tile's start | the XCD's number, at its count's
+    //  publication, at the begin and the end of its wait for the counts in front.  Stored here: a store in front of the prologue's scalar
+    //  loads turns every one of them into a vector load.)
+    if (stamp.p && threadIdx.x == 0) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a->tile_total[t] = (clk0 << 3) | (xcc & 7u); a->f.tile_acc[t] = clk1; a->f.tile_acc_ex[t] = clk2;
+        sa->tile_flags[t] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    }
     stamp.mark(7);
     const uint32_t xbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_lb[0] + s_lb[1] + s_lb[2]));
     if (threadIdx.x == 0) {
@@ -644,9 +664,9 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     // (the thread's slot once more, from a tile number the compiler cannot recognise: kept from above it would be spilled through the staged form)
     uint32_t t_again = t;
     asm volatile("" : "+s"(t_again));
-    const uint32_t slot_s = (threadIdx.x + (((ablate & 8) ? 0u : ((t_again ^ (t_again >> 3) ^ (t_again >> 7)) & 3u)) << 6)) & (uint32_t)(TILE_THREADS - 1);
-    const bool active_s = slot_s < n_act;
-    uint32_t *const w0 = s_x2 + TILE_THREADS;
+    const uint32_t slot_s = (threadIdx.x + (tile_rot(t_again) << 6)) & (uint32_t)(TILE_THREADS - 1);
+    const bool active_s = active;
+    uint32_t *const w0 = s_A;
     const WalkLds W{w0, w0 + TILE_THREADS, reinterpret_cast<int *>(w0 + 2 * TILE_THREADS), w0 + 2 * TILE_THREADS + 4, w0 + 2 * TILE_THREADS + 8};
     // (the CIGAR heads are fetched once more: for the compiler this form FOLLOWS the staged one -- see below -- and words kept for it
     //  would be alive, i.e. spilled, through the probe rounds of every tile; these tiles are rare)
@@ -664,7 +684,8 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     }
 #pragma unroll
     for (int i = 0; i < SLAB_HEAD; ++i) cgs[i] = (uint32_t)i < n_cig ? cgs[i] : 1u;
-    const uint32_t tot = slab_walk_tile<false, false>(sa, a, t, r0, n_act, rec.sbase, rec.rows, tid0, pos0, slot_s, active_s, c_lo, pos, xw, cgs, W);
+    const uint32_t tot = slab_walk_tile<false, false>(sa, a, t, r0, n_act, rec.sbase, rec.rows, tid0, pos0, slot_s, active_s, c_lo, pos,
+                                                      n_cig | ((xs & SLOT_REV) ? 1u << 16 : 0u) | (idx << 24) /* k_walk_slab's record word */, cgs, W);
     if (threadIdx.x == 0 && !counted) lb_publish(sa, t, tot);
     uint32_t share = 0u;
     uint32_t n_polls_s = 0u;

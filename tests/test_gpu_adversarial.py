@@ -392,8 +392,10 @@ def test_reads_of_300_and_9000_exons_between_ordinary_neighbours(oracle, pipelin
     n_ex = np.diff(want.ex_off)
     assert int((n_ex == 300).sum()) == 1 and int((n_ex == 9_000).sum()) == 1
     assert ((want.info & 2) != 0).sum() > 500
-    if pipeline in ("tile", "slab"):
+    if pipeline == "slab":
         assert 2 <= cnt[0] <= 300, cnt                # the two long reads (and the reads of their tiles that no longer fit the staged positions)
+    if pipeline == "tile":
+        assert 1 <= cnt[0] <= 300, cnt                # k_tile has no rows to outgrow: the 300-exon read is classified on the mask path; the 9000-exon read's tile keeps the slab form
 
 
 @pytest.mark.parametrize("min_exon", [0, 1, 3])
