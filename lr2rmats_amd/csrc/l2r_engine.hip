@@ -73,10 +73,12 @@ struct l2r_ctx {
     bool many_exon_reads = false;           // the upload's sample: more than 0.5 % of the reads have more exons than a slab has rows
     bool slab_ok = false;                   // the current upload can run the slab pipeline: coordinate-sorted records, short CIGARs, its slab layout fits
     bool slab = false;                      // ... and the last launch did (the parameters have a say: launch_all)
+    bool lists_known = false, lists_empty = false;      // one-kernel tile path: a completed run of these inputs and parameters left nothing to k_probe_slab / _wide / _chunked (l2r_sync looks): their launches are skipped until something changes
     bool tile = false;                      // ... with the one-kernel tile path (l2r_tile.hip.h: short CIGARs, -e >= 1)
     DevBuf<unsigned long long> lb_tile, lb_blk, lb_sup;     // one-kernel tile path: the tiles' exon counts on their way to the later tiles' first slots
     DevBuf<uint32_t> fb_list;                               //                       the tiles it leaves to k_probe_slab
     DevBuf<SlotRec> slot_rec;                               //                       the upload's slot records (k_tile_index)
+    DevBuf<TileStat> sup_stat;                              //                       ... summed up per super-block of 1024 tiles
     DevBuf<TileStat> tile_stat; std::vector<TileStat> h_tile_stat;      //                 the upload's index of the tiles' CIGAR operations (k_tile_index)
     DevBuf<uint32_t> tile_sbase, s_pre, s_loc, s_pl, cig_off32, tile_rec, tile_total, tile_xbase, tile_span;    // (tile_span: 16-byte TileSpan records, l2r_slab.hip.h)
     DevBuf<int32_t> dense_start, dense_end;                 // slab pipeline: the outliers' dense area
@@ -159,6 +161,7 @@ struct l2r_ctx {
 
 static void drop_graph(l2r_ctx *c)
 {
+    c->lists_known = false; c->lists_empty = false;     // (called wherever inputs, parameters or outputs change)
     if (c->graph) { (void)hipGraphExecDestroy(c->graph); c->graph = nullptr; }
     c->graph_valid = false;
 }
@@ -235,7 +238,7 @@ void l2r_destroy(l2r_ctx *c)
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_acc_at.release(); c->tile_acc_ex_at.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->tile_total.release(); c->tile_xbase.release(); c->tile_rec.release(); c->cig_off32.release(); c->s_pl.release(); c->tile_span.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_list.release(); c->chunk_list.release(); c->list_cnt.release(); c->tile_flags.release();
-    c->lb_tile.release(); c->lb_blk.release(); c->lb_sup.release(); c->fb_list.release(); c->tile_stat.release(); c->slot_rec.release();
+    c->lb_tile.release(); c->lb_blk.release(); c->lb_sup.release(); c->fb_list.release(); c->tile_stat.release(); c->sup_stat.release(); c->slot_rec.release();
     c->slab_row.release(); c->dense_start.release(); c->dense_end.release(); c->s_pre.release(); c->s_loc.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -880,7 +883,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             sbase[T] = (uint32_t)total;                     // (rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true;
             if (c->tw64.ensure(T + 1) || c->wide_list.ensure(T + 1) || c->chunk_list.ensure(T + 1) || c->list_cnt.ensure(8) || c->tile_flags.ensure(T + 8) ||
-                c->lb_tile.ensure(T + 64) || c->lb_blk.ensure(T / LB_BLK + 64) || c->lb_sup.ensure((T >> LB_SUP_SHIFT) + 64) || c->fb_list.ensure(T + 1) || c->tile_stat.ensure(T + 1) ||
+                c->lb_tile.ensure(T + 64) || c->lb_blk.ensure(T / LB_BLK + 64) || c->lb_sup.ensure((T >> LB_SUP_SHIFT) + 64) || c->fb_list.ensure(T + 1) || c->tile_stat.ensure(T + 1) || c->sup_stat.ensure((T >> LB_SUP_SHIFT) + 2) ||
                 (!c->wide_cigar && c->slot_rec.ensure((T + 1) * TILE_THREADS))) return -2;
             HIP_TRY(hipMemsetAsync(c->lb_sup.p, 0, ((T >> LB_SUP_SHIFT) + 64) * 8, c->stream));      // (from then on cleared behind every run, by k_classify_generic)      // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB each)
             HIP_TRY(hipMemsetAsync(c->list_cnt.p, 0, 32, c->stream));
@@ -913,6 +916,15 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
                 HIP_TRY(hipMemcpyAsync(c->h_tile_stat.data(), c->tile_stat.p, T * sizeof(TileStat), hipMemcpyDeviceToHost, c->stream));
             }
             HIP_TRY(hipStreamSynchronize(c->stream));       // (locals)
+            {   // the index once more per super-block (l2r_slab.hip.h SlabArgs::sup_stat)
+                std::vector<TileStat> sup((T >> LB_SUP_SHIFT) + 1, TileStat{0, INT32_MAX, 0, INT32_MAX});
+                for (size_t t = 0; t < T; ++t) {
+                    TileStat &q = sup[t >> LB_SUP_SHIFT]; const TileStat &st = c->h_tile_stat[t];
+                    q.n_ops_n += st.n_ops_n + (int32_t)rec[t].n_act; q.min_n = std::min(q.min_n, st.min_n); q.max_d = std::max(q.max_d, st.max_d); q.min_seg = std::min(q.min_seg, st.min_seg);
+                }
+                HIP_TRY(hipMemcpyAsync(c->sup_stat.p, sup.data(), sup.size() * sizeof(TileStat), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1054,6 +1066,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         // ---- two light kernels at full occupancy: the walk (exons into the tiles' slabs, read-order places, descriptors), a scan of
         //      the tiles' exon counts, then the probes, which write the read-order results (l2r_slab.hip.h).  Every launch does all
         //      of it: nothing is kept from an earlier run of the same upload.
+        bool skip_lists = false;
         SlabArgs sa;
         sa.g.f = fa; sa.g.cd = cd; sa.g.tid_base = c->tid_base.p; sa.g.n_tid_dir = c->n_tid_dir; sa.g.tile_total = c->tile_total.p;
         sa.tile_sbase = c->tile_sbase.p; sa.slab_row = c->slab_row.p;
@@ -1064,7 +1077,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p;
         sa.chunk_on = (c->ablate & 32) ? 0u : 1u;          // (L2R_ABLATE bit 2: no 64-member windows, bit 5: no chunked windows)
         sa.wide_list = c->wide_list.p; sa.chunk_list = c->chunk_list.p; sa.list_cnt = c->list_cnt.p; sa.tile_flags = c->tile_flags.p;
-        sa.lb_tile = c->lb_tile.p; sa.lb_blk = c->lb_blk.p; sa.lb_sup = c->lb_sup.p; sa.lb_err = c->totals.p + 6; sa.fb_list = c->fb_list.p; sa.exon_total = c->totals.p + 0; sa.tile_stat = c->tile_stat.p; sa.has_wide_keys = c->n_wide > 0 ? 1u : 0u;
+        sa.lb_tile = c->lb_tile.p; sa.lb_blk = c->lb_blk.p; sa.lb_sup = c->lb_sup.p; sa.lb_err = c->totals.p + 6; sa.fb_list = c->fb_list.p; sa.exon_total = c->totals.p + 0; sa.tile_stat = c->tile_stat.p; sa.sup_stat = c->sup_stat.p; sa.has_wide_keys = c->n_wide > 0 ? 1u : 0u;
         // (with the accepted list wanted and no junction table to decide later, the tiles leave their accepted chunks themselves)
         const bool probe_acc = (c->want & L2R_WANT_ACCEPTED) && c->n_sj == 0;
 #define launch_probe_k(L, A, D, LIST, G) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L, A, D, LIST>), dim3(G), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
@@ -1097,8 +1110,11 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
 #undef launch_tile_level
 #undef launch_tile_k
             MARK(ST_FAST);
+            // (the three list-driven kernels behind k_tile: not launched once a completed run of the same inputs and parameters has shown
+            //  their lists empty -- what ends up on them does not depend on anything else)
+            skip_lists = c->lists_known && c->lists_empty && !getenv("L2R_LAUNCH_ALL");
             const unsigned gl = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 2);
-            launch_probe(true, gl);
+            if (!skip_lists) launch_probe(true, gl);
         } else {
         if (c->wide_cigar)
             hipLaunchKernelGGL(k_walk_slab_long, dim3(gx), dim3(TILE_THREADS), pass_a_dynamic_lds(c->reads_per_tile), s, sa, (const TileRec *)c->tile_rec.p);
@@ -1128,6 +1144,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
 #undef launch_probe
 #undef launch_probe_level
 #undef launch_probe_k
+        if (!skip_lists)
         {   // the tiles with 33 .. 63 window members (none on most inputs: the grid finds an empty list and leaves)
             const WideArgs wa{c->tw64.p};
             const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 5);
@@ -1143,7 +1160,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             }
 #undef launch_wide_level
         }
-        if (sa.chunk_on) {   // the tiles without a window record, or with a dictionary key in several entries (none on most inputs)
+        if (sa.chunk_on && !skip_lists) {   // the tiles without a window record, or with a dictionary key in several entries (none on most inputs)
             const unsigned gc = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 4);
 #define launch_chunk_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_chunked<L>), dim3(gc), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
                 (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p)
@@ -1337,6 +1354,15 @@ int l2r_sync(l2r_ctx *c)
     if (!c) return fail(-1, "[l2r_sync] null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->ran && c->tile && !c->lists_known && c->list_cnt.p) {
+        // what the run left on the lists of the kernels behind k_tile (k_classify_generic keeps the counts of the 64-bit-mask and the
+        // chunked kernel's lists in words 6, 7 when it clears them; word 4: k_probe_slab's)
+        uint32_t lc[8];
+        HIP_TRY(hipMemcpyAsync(lc, c->list_cnt.p, sizeof lc, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->lists_empty = lc[4] == 0u && lc[6] == 0u && lc[7] == 0u;
+        c->lists_known = true;
+    }
     return 0;
 }
 

@@ -992,7 +992,7 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
     __shared__ int g_E[GEN_WAVES][GEN_CAP];
     __shared__ uint32_t g_F[GEN_WAVES][GEN_CAP];
     __shared__ uint32_t g_cnt[GEN_WAVES][2];
-    if (list_cnt && blockIdx.x == 0 && threadIdx.x == 0) { list_cnt[0] = 0u; list_cnt[1] = 0u; }
+    if (list_cnt && blockIdx.x == 0 && threadIdx.x == 0) { list_cnt[6] = list_cnt[0]; list_cnt[7] = list_cnt[1]; list_cnt[0] = 0u; list_cnt[1] = 0u; }
     if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < n_sup; i += TILE_THREADS) lb_sup[i] = 0ull;
     const uint32_t cnt = *redo_count;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
@@ -2063,7 +2063,7 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
     __shared__ int s_from[TILE_THREADS];               // the read's cursor row, -1: its junctions are not looked up here
     __shared__ int s_tid[TILE_THREADS];
     __shared__ uint32_t s_bad[TILE_THREADS];
-    __shared__ uint32_t s_base, s_end;
+    __shared__ uint32_t s_base, s_end, s_owned;
     const int64_t r = (int64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
     const bool have = r < n_reads;
     uint32_t info = have ? info_io[r] : 0u;
@@ -2072,7 +2072,7 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
     const uint32_t off = have ? ex_off[r] : 0u;
     // the rows of the block's chromosome (its first read's: wave-uniform loads), a read of another one looks its own up
     const SjTid ti0 = sj_tid_rows(sd, r_tid[(int64_t)blockIdx.x * TILE_THREADS], p.n_sj);
-    if (threadIdx.x == 0) s_base = off;
+    if (threadIdx.x == 0) { s_base = off; s_owned = 0u; }
     // (the block's last read closes the run)
     if (have && (threadIdx.x == TILE_THREADS - 1 || r == n_reads - 1)) s_end = off + (uint32_t)n;
     int from = -1;
@@ -2094,8 +2094,14 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
     const bool mapped = have && off >= base && off - base + (uint32_t)n <= total;
     s_from[threadIdx.x] = (cand && ok0 && mapped) ? from : -1;
     if (mapped) for (int k = 0; k < n; ++k) s_owner[off - base + (uint32_t)k] = (uint8_t)threadIdx.x;
+    // The mapped reads are a prefix of the block's reads (read order: behind the first one that does not fit, none does), so the positions
+    // up to the end of the last mapped read all have an owner; the ones behind it -- of the read that straddles position SJ_MAP_CAP, in
+    // a block with more exons than that -- hold whatever an earlier workgroup left there and are not looked at here (their reads take
+    // the per-read loop below).
+    if (mapped && n > 0) atomicMax(&s_owned, off - base + (uint32_t)n);
     __syncthreads();
-    for (uint32_t q = threadIdx.x; q < total; q += (uint32_t)TILE_THREADS) {
+    const uint32_t owned = s_owned;
+    for (uint32_t q = threadIdx.x; q < owned; q += (uint32_t)TILE_THREADS) {
         const uint8_t f = ex_flag[base + q];
         if (!(f & F_JUNC)) continue;
         const uint32_t who = s_owner[q];

@@ -118,6 +118,9 @@ struct SlabArgs {
     // (diagnostics; never seen).  fb_list: the tiles k_tile left in slab form for k_probe_slab (list_cnt[4] entries).
     unsigned long long *lb_tile, *lb_blk, *lb_sup;
     const TileStat *tile_stat;
+    // per super-block of 1024 tiles (made with tile_stat): n_ops_n = its exon count if every tile in it is exact (reads + N operations),
+    // the other three fields the extremes over its tiles -- tile_exact(sup_stat[s], ...) says "every tile of s is exact"
+    const TileStat *sup_stat;
     uint32_t *lb_err, *fb_list;
     uint32_t has_wide_keys;                              // the annotation has dictionary keys in several entries (SE_WIDE)
     uint32_t *exon_total;                                // the run's exon count (k_tile: written by the last tile)
@@ -693,8 +696,18 @@ void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan, 
         const unsigned long long sum = ((unsigned long long)wave_sum(hi) << 32) + (unsigned long long)wave_sum(lo);      // (an exact tile has fewer than 4096 exons: no carry out of the low words)
         if (lane == 0) {
             sa->lb_blk[t0 >> LB_BLK_SHIFT] = sum;
+            // A super-block whose tiles are ALL exact (the upload's sup_stat says so for these thresholds) is written whole by the workgroup
+            // of its first block; in any other, every complete block adds itself (64 adds to one word: 8 us of this launch when every
+            // block did that).
+            const int4 qv = *reinterpret_cast<const int4 *>(sa->sup_stat + (t0 >> LB_SUP_SHIFT));
+            const TileStat q{qv.x, qv.y, qv.z, qv.w};
+            const bool whole = tile_exact(q, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet) && !(a->f.p.ablate & 256) &&
+                               ((t0 >> LB_SUP_SHIFT) + 1u) << LB_SUP_SHIFT <= sa->n_tiles;       // (the last, partial super-block is nobody's "front")
             const uint32_t in_blk = min((uint32_t)LB_BLK, sa->n_tiles - t0);
-            if ((uint32_t)(sum >> LB_SHIFT) == in_blk) atomicAdd(sa->lb_sup + (t0 >> LB_SUP_SHIFT), (1ull << LB_SHIFT) | (sum & LB_SUM_MASK));
+            if (whole) {
+                if ((t0 & ((1u << LB_SUP_SHIFT) - 1u)) == 0u)
+                    sa->lb_sup[t0 >> LB_SUP_SHIFT] = ((unsigned long long)(1u << (LB_SUP_SHIFT - LB_BLK_SHIFT)) << LB_SHIFT) | (unsigned long long)(uint32_t)q.n_ops_n;
+            } else if ((uint32_t)(sum >> LB_SHIFT) == in_blk) atomicAdd(sa->lb_sup + (t0 >> LB_SUP_SHIFT), (1ull << LB_SHIFT) | (sum & LB_SUM_MASK));
         }
     }
     if (wv == 0) {

@@ -176,7 +176,9 @@ __device__ __forceinline__ uint32_t lb_share(SlabArgsK sa, uint32_t t, int wv, i
             if (__all(ok)) break;
             if (TRY) { done = false; break; }
             ++n_polls;
+            // (a tile that has waited in vain says so; the others stop waiting when they see that: a broken run ends in seconds)
             if (polls == LB_POLLS) { if (lane == 0) atomicOr(sa->lb_err, 1u); break; }
+            if ((polls & 63u) == 63u && __hip_atomic_load(sa->lb_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
             if (polls < 2u) __builtin_amdgcn_s_sleep(16); else if (polls < 6u) __builtin_amdgcn_s_sleep(48); else __builtin_amdgcn_s_sleep(127);
         }
         sum += i < L.cnt ? (uint32_t)v : 0u;

@@ -441,3 +441,36 @@ def test_long_cigars_with_cut_ops_crowded_into_a_few_words(oracle, min_exon, pip
     got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=3, min_exon=min_exon)
     n_ex = np.diff(want.ex_off)
     assert n_ex.max() >= 8 and (n_ex >= 4).sum() > 300
+
+
+@pytest.mark.parametrize("split", [0, 1])
+def test_junction_check_in_blocks_of_more_exons_than_the_mapped_positions(oracle, split, pipeline):
+    """k_validate_sj maps the exon positions of a block of 256 reads to their reads (6144 positions, l2r_kernels.hip.h SJ_MAP_CAP) and
+    spreads the junction lookups over the positions; a block of full-length reads of a 30 .. 40-exon gene has more exons than that,
+    and the read that straddles position 6144 is not mapped: its positions have no owner (they were looked at all the
+    same, with whatever an earlier workgroup had left in LDS).  Reads with skipped exons (novel junctions) sit all over such blocks,
+    the straddling ones included; the junction table supports some of the novel junctions and not others."""
+    rng = np.random.default_rng(77)
+    gene = [(10_000 + 400 * k, 10_000 + 400 * k + 150) for k in range(40)]
+    txs = [(0, 0, gene), (0, 1, gene[:12] + [(gene[12][0], gene[12][1] + 40)]), (1, 0, [(5_000, 5_100), (5_300, 5_400)])]
+    af = _anno(txs)
+    rows = []
+    for i in range(900):
+        n = int(rng.integers(30, 41))
+        ex = [list(x) for x in gene[:n]]
+        ex[0][0] += int(rng.integers(0, 100))                       # sorted input with varied starts
+        if i % 3 == 0:
+            del ex[int(rng.integers(2, n - 2))]                     # a skipped exon: one novel junction
+        if i % 7 == 0:
+            del ex[int(rng.integers(2, len(ex) - 2))]
+        if i % 5 == 0:
+            ex[-1][1] -= int(rng.integers(0, 30))
+        rows.append((0, *_chain([tuple(x) for x in ex])))
+    rows = [(r[0], r[1], i & 1, r[2]) for i, r in enumerate(rows)]
+    reads = _reads(_sorted_rows(rows))
+    base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3))
+    assert int(np.diff(base.ex_off).reshape(-1)[:256].sum()) > 6144 + 40          # the first block alone is beyond the mapped positions
+    j, sj = util.junction_table(af, reads, base, 77, cover=0.5)
+    for _ in range(3):                                              # (stale LDS: what the positions hold differs from launch to launch)
+        got, want = _run(oracle, af, reads, sj=sj, full_level=3, split_trans=split, min_sj_cnt=1)
+    assert ((want.info & 32) != 0).sum() > 200 and ((want.info & 16) != 0).sum() > 20 and ((want.info & 64) != 0).sum() > 20
