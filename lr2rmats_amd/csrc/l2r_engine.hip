@@ -73,6 +73,7 @@ struct l2r_ctx {
     bool many_exon_reads = false;           // the upload's sample: more than 0.5 % of the reads have more exons than a slab has rows
     bool slab_ok = false;                   // the current upload can run the slab pipeline: coordinate-sorted records, short CIGARs, its slab layout fits
     bool slab = false;                      // ... and the last launch did (the parameters have a say: launch_all)
+    bool redo_empty = false;                            // ... and nothing to the generic kernel either: every read had its junction check in k_tile, k_validate_sj has nothing to do
     bool lists_known = false, lists_empty = false;      // one-kernel tile path: a completed run of these inputs and parameters left nothing to k_probe_slab / _wide / _chunked (l2r_sync looks): their launches are skipped until something changes
     bool tile = false;                      // ... with the one-kernel tile path (l2r_tile.hip.h: short CIGARs, -e >= 1)
     DevBuf<unsigned long long> lb_tile, lb_blk, lb_sup;     // one-kernel tile path: the tiles' exon counts on their way to the later tiles' first slots
@@ -161,7 +162,7 @@ struct l2r_ctx {
 
 static void drop_graph(l2r_ctx *c)
 {
-    c->lists_known = false; c->lists_empty = false;     // (called wherever inputs, parameters or outputs change)
+    c->lists_known = false; c->lists_empty = false; c->redo_empty = false;     // (called wherever inputs, parameters or outputs change)
     if (c->graph) { (void)hipGraphExecDestroy(c->graph); c->graph = nullptr; }
     c->graph_valid = false;
 }
@@ -1077,9 +1078,11 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p;
         sa.chunk_on = (c->ablate & 32) ? 0u : 1u;          // (L2R_ABLATE bit 2: no 64-member windows, bit 5: no chunked windows)
         sa.wide_list = c->wide_list.p; sa.chunk_list = c->chunk_list.p; sa.list_cnt = c->list_cnt.p; sa.tile_flags = c->tile_flags.p;
-        sa.lb_tile = c->lb_tile.p; sa.lb_blk = c->lb_blk.p; sa.lb_sup = c->lb_sup.p; sa.lb_err = c->totals.p + 6; sa.fb_list = c->fb_list.p; sa.exon_total = c->totals.p + 0; sa.tile_stat = c->tile_stat.p; sa.sup_stat = c->sup_stat.p; sa.has_wide_keys = c->n_wide > 0 ? 1u : 0u;
+        sa.lb_tile = c->lb_tile.p; sa.lb_blk = c->lb_blk.p; sa.lb_sup = c->lb_sup.p; sa.lb_err = c->totals.p + 6; sa.fb_list = c->fb_list.p; sa.exon_total = c->totals.p + 0; sa.tile_stat = c->tile_stat.p; sa.sup_stat = c->sup_stat.p;
+        sa.sj = SjDir{CursorDir{c->sj_key.p, c->sj_cdir.p, c->sj_cbase.p, c->sj_ntid, (int32_t)c->n_sj}, c->sj_ddir.p, c->sj_dbase.p, c->sj_ntid, c->sj_row.p};
+        sa.has_wide_keys = c->n_wide > 0 ? 1u : 0u;
         // (with the accepted list wanted and no junction table to decide later, the tiles leave their accepted chunks themselves)
-        const bool probe_acc = (c->want & L2R_WANT_ACCEPTED) && c->n_sj == 0;
+        const bool probe_acc = (c->want & L2R_WANT_ACCEPTED) && (c->n_sj == 0 || c->tile);      // (k_tile decides acceptance itself, junction table or not)
 #define launch_probe_k(L, A, D, LIST, G) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L, A, D, LIST>), dim3(G), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
             (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p, (const uint32_t *)c->fb_list.p)
         // (the tiles k_tile left in slab form leave no accepted chunks themselves: they stay k_gather_accepted's -- half the instantiations)
@@ -1213,7 +1216,10 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
                            c->lb_sup.p, (uint32_t)(c->lb_sup.p ? (c->n_tiles >> LB_SUP_SHIFT) + 1 : 0));
     }
     MARK(ST_SJ);
-    if (c->n_sj > 0) {
+    // (one-kernel tile path: k_tile has checked every read whose verdict it made; with nothing on the redo list and nothing left to the
+    //  list-driven kernels -- seen by a completed run of the same inputs and parameters -- no read is left for this launch)
+    const bool sj_all_in_tile = c->tile && c->lists_known && c->lists_empty && c->redo_empty && !getenv("L2R_LAUNCH_ALL");
+    if (c->n_sj > 0 && !sj_all_in_tile) {
         if (!c->sorted) { int rc = prepare_unsorted_sj_cursor(c); if (rc) return rc; }
         hipLaunchKernelGGL(k_validate_sj, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p,
                            c->sj_key.p, (c->sorted ? (const int32_t *)nullptr : c->sj_cursor.p), c->sj_tid.p, c->sj_don.p, c->sj_acc.p,
@@ -1360,7 +1366,11 @@ int l2r_sync(l2r_ctx *c)
         uint32_t lc[8];
         HIP_TRY(hipMemcpyAsync(lc, c->list_cnt.p, sizeof lc, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        uint32_t redo_n = 1u;
+        HIP_TRY(hipMemcpyAsync(&redo_n, c->totals.p + 3, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
         c->lists_empty = lc[4] == 0u && lc[6] == 0u && lc[7] == 0u;
+        c->redo_empty = redo_n == 0u;
         c->lists_known = true;
     }
     return 0;

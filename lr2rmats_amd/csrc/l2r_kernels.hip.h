@@ -2067,7 +2067,8 @@ void k_validate_sj(int64_t n_reads, const int32_t *__restrict__ r_tid, const uin
     const int64_t r = (int64_t)blockIdx.x * TILE_THREADS + threadIdx.x;
     const bool have = r < n_reads;
     uint32_t info = have ? info_io[r] : 0u;
-    const bool cand = have && (info & (I_FULL | I_KNOWN | I_KSITE)) == (I_FULL | I_KSITE);
+    // (a read k_tile has checked on its tile's LDS image carries I_SJCHK already: l2r_tile.hip.h)
+    const bool cand = have && (info & (I_FULL | I_KNOWN | I_KSITE | I_SJCHK)) == (I_FULL | I_KSITE);
     const int n = (int)(info >> 8), tid = have ? r_tid[r] : 0;
     const uint32_t off = have ? ex_off[r] : 0u;
     // the rows of the block's chromosome (its first read's: wave-uniform loads), a read of another one looks its own up

@@ -122,6 +122,7 @@ struct SlabArgs {
     // the other three fields the extremes over its tiles -- tile_exact(sup_stat[s], ...) says "every tile of s is exact"
     const TileStat *sup_stat;
     uint32_t *lb_err, *fb_list;
+    SjDir sj;                                            // the junction table's directories and rows (k_tile's junction check)
     uint32_t has_wide_keys;                              // the annotation has dictionary keys in several entries (SE_WIDE)
     uint32_t *exon_total;                                // the run's exon count (k_tile: written by the last tile)
 };

@@ -314,7 +314,7 @@ __device__ __forceinline__ SlabVerdict tile_classify(PipeArgsK a, const TileDesc
             if (redo) a->f.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
         }
     }
-    if (active) { a->f.info[r] = info; a->f.ref_tx[r] = ref; }
+    if (active) a->f.ref_tx[r] = ref;                           // (info: by the caller, behind the junction check)
     return SlabVerdict{info, ref, redo};
 }
 
@@ -543,8 +543,60 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     const uint32_t pre = idx | ((xs & SLOT_REV) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (n << PRE_N_SHIFT);
     const uint32_t r = r0 + idx;
     // ---- classification (a lane probes the positions it has placed itself; the dictionary slices were whole at the barrier above)
-    const SlabVerdict vd = tile_classify<LEVEL, DIS>(a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, big, r, re, st, any_wide, stamp);
+    SlabVerdict vd = tile_classify<LEVEL, DIS>(a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, big, r, re, st, any_wide, stamp);
     if (ACC) { const int w_redo = __any(vd.redo) ? 1 : 0; if (lane == 0) s_redow[wv] = (uint32_t)w_redo; }
+    // ---- short-read junction support (-j: src/update_gtf.c:698-709 check_with_short_sj, :609-627 check_short_sj) for the reads whose
+    //      verdict is final here, on the tile's LDS image: k_validate_sj's three steps without its passes over the results in HBM.
+    //      (1) thread = read: is it a candidate (full, not known, has a known site), its cursor row (:613-614) and the Q7 test on it;
+    //      every position of the tile learns its read; (2) the tile's exon POSITIONS across the threads: the table lookups of the
+    //      candidates' novel junctions, spread over all lanes; (3) the read's verdict.  A read on the redo list gets its verdict from
+    //      the generic kernel and its junction check from k_validate_sj behind that (which skips the reads checked here).
+    if (a->f.p.n_sj > 0) {
+        __syncthreads();                                        // (the dictionary slices, directories and window record are dead: the maps below live there)
+        uint8_t *const s_owner = reinterpret_cast<uint8_t *>(s_ent);
+        int *const s_sjfrom = reinterpret_cast<int *>(s_aux);
+        uint8_t *const s_bad = s_aux + TILE_THREADS * 4;
+        static_assert(2 * SLAB_KEY_CAP * 16 >= SLAB_POS_CAP && SLAB_AUX_BYTES >= TILE_THREADS * 5, "the junction check's maps fit the dead dictionary slices / directories");
+        SjDir sd;
+        sd.cur.key = sa->sj.cur.key; sd.cur.dir = sa->sj.cur.dir; sd.cur.kb_base = sa->sj.cur.kb_base; sd.cur.n_tid = sa->sj.cur.n_tid; sd.cur.n_tx = sa->sj.cur.n_tx;
+        sd.ddir = sa->sj.ddir; sd.dbase = sa->sj.dbase; sd.d_ntid = sa->sj.d_ntid; sd.row = sa->sj.row;
+        const int n_sj = a->f.p.n_sj;
+        DevParams pj;
+        pj.ss_dis = a->f.p.ss_dis; pj.use_multi = a->f.p.use_multi; pj.min_sj_cnt = a->f.p.min_sj_cnt; pj.n_sj = n_sj;
+        const SjTid ti0 = sj_tid_rows(sd, tid0, n_sj);         // (a tile is of one chromosome)
+        const bool cand = active && !vd.redo && (vd.info & (I_FULL | I_KNOWN | I_KSITE)) == (I_FULL | I_KSITE);
+        int from = -1;
+        bool ok0 = false;
+        if (cand) {
+            // (the read's first start and last end from its staged exons: registers that need not live through the probe rounds)
+            const int r_start = tile_lo + (int)(s_A[loc] & SLAB_REL_MASK);
+            const int r_end = tile_lo + (int)(s_A[loc + n - 1u] & SLAB_REL_MASK) + (int)s_L[loc + n - 1u] - 1;
+            from = cursor_value(sd.cur, tid0, r_start);        // (first row whose prefix-max key is above (tid, start))
+            // Q7: cursor row beyond the read -> unsupported, no unreliable flag
+            if (from < n_sj) ok0 = !(from >= ti0.end || sd.row[from].x >= r_end);
+        }
+        s_sjfrom[threadIdx.x] = (cand && ok0) ? from : -1;
+        s_bad[threadIdx.x] = 0;
+        if (active) for (uint32_t k = 0; k < n; ++k) s_owner[loc + k] = (uint8_t)threadIdx.x;
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < total; q += (uint32_t)TILE_THREADS) {
+            const uint32_t av = s_A[q];
+            if (av == SLAB_POS_SKIP || !((av >> SLAB_REL_BITS) & F_JUNC)) continue;
+            const uint32_t who = s_owner[q];
+            const int fr = s_sjfrom[who];
+            if (fr < 0) continue;
+            // (a junction flag only stands on an exon that is not its read's last: position q + 1 is the same read's)
+            const int don = tile_lo + (int)(av & SLAB_REL_MASK) + (int)s_L[q], acc = tile_lo + (int)(s_A[q + 1u] & SLAB_REL_MASK) - 1;
+            if (!junction_supported(ti0, don, acc, fr, pj, sd)) { s_A[q] = av | ((uint32_t)F_UNREL << SLAB_REL_BITS); s_bad[who] = 1; }
+        }
+        __syncthreads();
+        if (cand) {
+            const bool ok = ok0 && s_bad[threadIdx.x] == 0;
+            vd.info |= I_SJCHK | (ok ? I_SJPASS : I_UNREL);
+            if (ok || a->f.p.split_trans) vd.info |= I_ACCEPT;
+        }
+    }
+    if (active) a->f.info[r] = vd.info;
     // ---- the tile's first result slot
     uint32_t clk2 = 0u;
     {
