@@ -325,6 +325,9 @@ static_assert(TILE_LDS_BYTES <= 23040, "k_tile: 7 workgroups per CU need 45 allo
 static_assert(SLAB_POS_CAP >= 2 * TILE_THREADS + 16, "slab_walk_tile's words live in the staged positions");
 static_assert(SLAB_POS_CAP < 65536 && SLAB_POS_CAP % 8 == 0, "16-bit places; 16-byte aligned arrays");
 
+constexpr int SJ_STAGE = 2 * SLAB_KEY_CAP * 16 / 12;    // junction rows k_tile stages per tile: {donor, acceptor, running maximum of the acceptors} over the dead dictionary slices
+static_assert(SLAB_AUX_BYTES >= (SJ_STAGE / 32 + 2 * 4 + 2) * 4 && SLAB_AUX_BYTES >= TILE_THREADS * 5 && 2 * SLAB_KEY_CAP * 16 >= SLAB_POS_CAP,
+              "the junction check's arrays fit the dead dictionary slices / directories");
 template <int LEVEL, bool ACC, bool DIS>
 __global__ __launch_bounds__(TILE_THREADS, 7)
 void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const TileWin *__restrict__ u_tw, const TileStat *__restrict__ u_stat, const SlotRec *__restrict__ u_slot,
@@ -552,11 +555,7 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     //      candidates' novel junctions, spread over all lanes; (3) the read's verdict.  A read on the redo list gets its verdict from
     //      the generic kernel and its junction check from k_validate_sj behind that (which skips the reads checked here).
     if (a->f.p.n_sj > 0) {
-        __syncthreads();                                        // (the dictionary slices, directories and window record are dead: the maps below live there)
-        uint8_t *const s_owner = reinterpret_cast<uint8_t *>(s_ent);
-        int *const s_sjfrom = reinterpret_cast<int *>(s_aux);
-        uint8_t *const s_bad = s_aux + TILE_THREADS * 4;
-        static_assert(2 * SLAB_KEY_CAP * 16 >= SLAB_POS_CAP && SLAB_AUX_BYTES >= TILE_THREADS * 5, "the junction check's maps fit the dead dictionary slices / directories");
+        __syncthreads();                                        // (the dictionary slices, directories and window record are dead: what follows lives there)
         SjDir sd;
         sd.cur.key = sa->sj.cur.key; sd.cur.dir = sa->sj.cur.dir; sd.cur.kb_base = sa->sj.cur.kb_base; sd.cur.n_tid = sa->sj.cur.n_tid; sd.cur.n_tx = sa->sj.cur.n_tx;
         sd.ddir = sa->sj.ddir; sd.dbase = sa->sj.dbase; sd.d_ntid = sa->sj.d_ntid; sd.row = sa->sj.row;
@@ -565,35 +564,104 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
         pj.ss_dis = a->f.p.ss_dis; pj.use_multi = a->f.p.use_multi; pj.min_sj_cnt = a->f.p.min_sj_cnt; pj.n_sj = n_sj;
         const SjTid ti0 = sj_tid_rows(sd, tid0, n_sj);         // (a tile is of one chromosome)
         const bool cand = active && !vd.redo && (vd.info & (I_FULL | I_KNOWN | I_KSITE)) == (I_FULL | I_KSITE);
-        int from = -1;
-        bool ok0 = false;
-        if (cand) {
-            // (the read's first start and last end from its staged exons: registers that need not live through the probe rounds)
-            const int r_start = tile_lo + (int)(s_A[loc] & SLAB_REL_MASK);
-            const int r_end = tile_lo + (int)(s_A[loc + n - 1u] & SLAB_REL_MASK) + (int)s_L[loc + n - 1u] - 1;
-            from = cursor_value(sd.cur, tid0, r_start);        // (first row whose prefix-max key is above (tid, start))
-            // Q7: cursor row beyond the read -> unsupported, no unreliable flag
-            if (from < n_sj) ok0 = !(from >= ti0.end || sd.row[from].x >= r_end);
+        // The table's rows whose donor lies in the tile's span (+- the tolerance), whole 512-bp buckets of the donor directory, and the
+        // row in front of them: [rlo - 1, rhi).  Every lookup of the tile's reads ends inside them -- a junction's donor is a base of
+        // its read -- and so does every read's cursor row unless it lies in front (the first row whose running maximum of the acceptors
+        // is above the read's start has a donor in front of the read's start or is that row).  Up to SJ_STAGE rows are staged.
+        const int dis_j = max(pj.ss_dis, 0);
+        int rlo = ti0.end, rhi = ti0.end, c0 = ti0.end;
+        if (ti0.nb > 0) {
+            const int b_lo = max(tile_lo - dis_j, 0) >> SITE_SHIFT, b_hi = max((int)rec.pad[0] + dis_j, 0) >> SITE_SHIFT;
+            c0 = (int)sd.ddir[ti0.db];
+            if (b_lo < ti0.nb) rlo = min((int)sd.ddir[ti0.db + b_lo], ti0.end);
+            if (b_hi + 1 < ti0.nb) rhi = min((int)sd.ddir[ti0.db + b_hi + 1], ti0.end);
         }
-        s_sjfrom[threadIdx.x] = (cand && ok0) ? from : -1;
-        s_bad[threadIdx.x] = 0;
-        if (active) for (uint32_t k = 0; k < n; ++k) s_owner[loc + k] = (uint8_t)threadIdx.x;
-        __syncthreads();
-        for (uint32_t q = threadIdx.x; q < total; q += (uint32_t)TILE_THREADS) {
-            const uint32_t av = s_A[q];
-            if (av == SLAB_POS_SKIP || !((av >> SLAB_REL_BITS) & F_JUNC)) continue;
-            const uint32_t who = s_owner[q];
-            const int fr = s_sjfrom[who];
-            if (fr < 0) continue;
-            // (a junction flag only stands on an exon that is not its read's last: position q + 1 is the same read's)
-            const int don = tile_lo + (int)(av & SLAB_REL_MASK) + (int)s_L[q], acc = tile_lo + (int)(s_A[q + 1u] & SLAB_REL_MASK) - 1;
-            if (!junction_supported(ti0, don, acc, fr, pj, sd)) { s_A[q] = av | ((uint32_t)F_UNREL << SLAB_REL_BITS); s_bad[who] = 1; }
-        }
-        __syncthreads();
-        if (cand) {
-            const bool ok = ok0 && s_bad[threadIdx.x] == 0;
-            vd.info |= I_SJCHK | (ok ? I_SJPASS : I_UNREL);
-            if (ok || a->f.p.split_trans) vd.info |= I_ACCEPT;
+        const bool have_prev = rlo > c0;                        // (the chromosome has a row in front of the staged ones)
+        const int m = rhi - rlo + 1;                            // staged entries: index 0 = the row in front (if any), 1 .. m - 1 = rows rlo .. rhi - 1
+        // (-d < 0 and introns of no length -- -i < 1: a junction's acceptor may lie in front of its donor -- keep the literal scan from the cursor row)
+        if (m <= SJ_STAGE && pj.ss_dis >= 0 && a->f.p.min_intron >= 1) {
+            int *const s_don = reinterpret_cast<int *>(s_ent), *const s_acc = s_don + SJ_STAGE, *const s_pm = s_acc + SJ_STAGE;
+            uint32_t *const s_okb = reinterpret_cast<uint32_t *>(s_aux);          // bit i: row i's read count reaches -J
+            for (int i0 = 0; i0 < m; i0 += TILE_THREADS) {
+                const int i = i0 + (int)threadIdx.x;
+                bool okc = false;
+                if (i < m && (i > 0 || have_prev)) {
+                    const int4 q = sd.row[rlo - 1 + i];
+                    s_don[i] = q.x; s_acc[i] = q.y; s_pm[i] = (int)(uint32_t)sd.cur.key[rlo - 1 + i];      // (low word of the key: the running maximum of the chromosome's acceptors)
+                    okc = (pj.use_multi ? q.z + q.w : q.z) >= pj.min_sj_cnt;
+                } else if (i == 0) { s_don[0] = INT32_MIN; s_acc[0] = INT32_MIN; s_pm[0] = INT32_MIN; }
+                const unsigned long long mb = __ballot(okc);
+                if (lane == 0) { s_okb[(i0 >> 5) + 2 * wv] = (uint32_t)mb; s_okb[(i0 >> 5) + 2 * wv + 1] = (uint32_t)(mb >> 32); }
+            }
+            __syncthreads();
+            if (cand) {
+                const int r_start = tile_lo + (int)(s_A[loc] & SLAB_REL_MASK);
+                const int r_end = tile_lo + (int)(s_A[loc + n - 1u] & SLAB_REL_MASK) + (int)s_L[loc + n - 1u] - 1;
+                // the cursor row (:613-614), clipped to the staged rows: first entry >= 1 whose running maximum is above the read's start
+                int lo = 1, hi = m;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pm[mid] > r_start) hi = mid; else lo = mid + 1; }
+                const int fi = lo;                              // (m: the row behind the staged ones -- its donor lies behind every read of the tile)
+                // Q7: the cursor row lies behind the read (or there is none) -> unsupported, no unreliable flag.  A cursor row in front of
+                // the staged ones (the running maximum in front of entry 1 is above the start already) has its donor in front of the read;
+                // one behind them (fi = m) has its donor behind every read of the tile.
+                const bool exact = fi > 1 || s_pm[0] <= r_start;
+                bool ok = !exact || (fi < m && s_don[fi] < r_end);
+                if (ok) {
+                    for (uint32_t k = 0; k + 1u < n; ++k) {
+                        const uint32_t av = s_A[loc + k];
+                        if (!((av >> SLAB_REL_BITS) & F_JUNC)) continue;
+                        const int don = tile_lo + (int)(av & SLAB_REL_MASK) + (int)s_L[loc + k], acc = tile_lo + (int)(s_A[loc + k + 1u] & SLAB_REL_MASK) - 1;
+                        // src/update_gtf.c:589-603 from the later of the cursor row and the first row with a donor >= don - dis
+                        int l2 = fi, h2 = m;
+                        const int want = don - dis_j;
+                        while (l2 < h2) { const int mid = (l2 + h2) >> 1; if (s_don[mid] < want) l2 = mid + 1; else h2 = mid; }
+                        bool sup = false;
+                        for (int i = l2; i < m; ++i) {
+                            const int dd = s_don[i];
+                            if (dd >= acc || dd - don > dis_j) break;
+                            if (__builtin_abs(dd - don) <= dis_j && __builtin_abs(s_acc[i] - acc) <= dis_j && ((s_okb[i >> 5] >> (i & 31)) & 1u)) { sup = true; break; }
+                        }
+                        if (!sup) { s_A[loc + k] = av | ((uint32_t)F_UNREL << SLAB_REL_BITS); ok = false; }
+                    }
+                }
+                vd.info |= I_SJCHK | (ok ? I_SJPASS : I_UNREL);
+                if (ok || a->f.p.split_trans) vd.info |= I_ACCEPT;
+            }
+        } else {
+            // (more rows than the staging holds, or a negative -d: the lookups go to the table in HBM -- k_validate_sj's three steps)
+            uint8_t *const s_owner = reinterpret_cast<uint8_t *>(s_ent);
+            int *const s_sjfrom = reinterpret_cast<int *>(s_aux);
+            uint8_t *const s_bad = s_aux + TILE_THREADS * 4;
+            int from = -1;
+            bool ok0 = false;
+            if (cand) {
+                // (the read's first start and last end from its staged exons: registers that need not live through the probe rounds)
+                const int r_start = tile_lo + (int)(s_A[loc] & SLAB_REL_MASK);
+                const int r_end = tile_lo + (int)(s_A[loc + n - 1u] & SLAB_REL_MASK) + (int)s_L[loc + n - 1u] - 1;
+                from = cursor_value(sd.cur, tid0, r_start);        // (first row whose prefix-max key is above (tid, start))
+                // Q7: cursor row beyond the read -> unsupported, no unreliable flag
+                if (from < n_sj) ok0 = !(from >= ti0.end || sd.row[from].x >= r_end);
+            }
+            s_sjfrom[threadIdx.x] = (cand && ok0) ? from : -1;
+            s_bad[threadIdx.x] = 0;
+            if (active) for (uint32_t k = 0; k < n; ++k) s_owner[loc + k] = (uint8_t)threadIdx.x;
+            __syncthreads();
+            for (uint32_t q = threadIdx.x; q < total; q += (uint32_t)TILE_THREADS) {
+                const uint32_t av = s_A[q];
+                if (av == SLAB_POS_SKIP || !((av >> SLAB_REL_BITS) & F_JUNC)) continue;
+                const uint32_t who = s_owner[q];
+                const int fr = s_sjfrom[who];
+                if (fr < 0) continue;
+                // (a junction flag only stands on an exon that is not its read's last: position q + 1 is the same read's)
+                const int don = tile_lo + (int)(av & SLAB_REL_MASK) + (int)s_L[q], acc = tile_lo + (int)(s_A[q + 1u] & SLAB_REL_MASK) - 1;
+                if (!junction_supported(ti0, don, acc, fr, pj, sd)) { s_A[q] = av | ((uint32_t)F_UNREL << SLAB_REL_BITS); s_bad[who] = 1; }
+            }
+            __syncthreads();
+            if (cand) {
+                const bool ok = ok0 && s_bad[threadIdx.x] == 0;
+                vd.info |= I_SJCHK | (ok ? I_SJPASS : I_UNREL);
+                if (ok || a->f.p.split_trans) vd.info |= I_ACCEPT;
+            }
         }
     }
     if (active) a->f.info[r] = vd.info;
