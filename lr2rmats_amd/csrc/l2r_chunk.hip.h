@@ -84,12 +84,40 @@ __device__ __forceinline__ void probe_parts64(const WEnt *ent, uint32_t lo, uint
     }
 }
 
+// probe_parts64 with a tolerance (-d > 0, src/update_gtf.c:717-779: see probe_near, l2r_kernels.hip.h): entries [lo, hi) = the staged
+// entries of the buckets of k1 - dis .. k1 + dis, in NO particular order inside a bucket (the chunk's counting sort), a key possibly in
+// several of them (parts: same keys, masks of different transcripts).  amb: members with two DIFFERENT sites within the tolerance.
+__device__ __forceinline__ void probe_near_parts64(const WEnt *ent, uint32_t lo, uint32_t hi, int32_t k1, int32_t k2, int dis, int rs, int re, m64_t &pm, m64_t &sm, m64_t &amb)
+{
+    pm = 0ull; sm = 0ull;
+    int first = INT32_MIN; bool several = false;
+    for (uint32_t r = lo; r < hi; ++r) {
+        const WEnt q = ent[r];
+        if (__builtin_abs(q.k1 - k1) > dis) continue;
+        if (q.k1 >= rs && q.k1 <= re) {
+            if (first == INT32_MIN) first = q.k1; else several = several || q.k1 != first;
+            sm |= q.sm;
+        }
+        if (__builtin_abs(q.k2 - k2) <= dis) pm |= q.pm;
+    }
+    if (several)                                             // (rare: two annotation sites within 2 dis + 1 bases -- which members have both?)
+        for (uint32_t r = lo; r < hi; ++r) {
+            const WEnt q = ent[r];
+            if (__builtin_abs(q.k1 - k1) > dis || q.k1 < rs || q.k1 > re) continue;
+            for (uint32_t u = r + 1u; u < hi; ++u) {
+                const WEnt w = ent[u];
+                if (__builtin_abs(w.k1 - k1) > dis || w.k1 < rs || w.k1 > re || w.k1 == q.k1) continue;
+                amb |= q.sm & w.sm;
+            }
+        }
+}
+
 // map_exons_slab64 with the read's exons at their staged positions in LDS (A: start relative to the tile's base, L: length); the
 // chunk's work word goes into the upper bits of A
 __device__ __forceinline__ SiteMasks64 map_exons_lds64(const ChunkLds &L, const TileDesc &d, bool mapping, uint32_t *Ap, const uint16_t *Lp,
-                                                       int32_t lo, uint32_t n, m64_t vpre)
+                                                       int32_t lo, uint32_t n, m64_t vpre, int dis = 0, int rs = 0, int re = 0)
 {
-    SiteMasks64 m{~0ull, 0ull, 0ull, 0ull};
+    SiteMasks64 m{~0ull, 0ull, 0ull, 0ull, 0ull};
     const uint32_t none = (uint32_t)d.nbk + 1u;
     const int k_max = wave_max(mapping ? (int)n : 0);
     int s = 0, e = 0;
@@ -98,12 +126,24 @@ __device__ __forceinline__ SiteMasks64 map_exons_lds64(const ChunkLds &L, const 
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
         int s2 = 0, e2 = 0;
         if (junc) { s2 = lo + (int)(Ap[k + 1] & SLAB_REL_MASK); e2 = s2 + (int)Lp[k + 1] - 1; }
-        const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
-        const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
-        const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
         m64_t xm, am, jm, dm;
-        probe_parts64(L.ent0, ls, hs, s, e, xm, am);
-        probe_parts64(L.ent1, le, he, e, s2, jm, dm);
+        if (dis > 0) {                                  // (wave-uniform: -d)
+            auto range = [&](const uint32_t *dir, bool on, int x, uint32_t &l_, uint32_t &h_) {
+                const uint32_t i0 = on ? min((uint32_t)((max(x - dis, 0) >> SITE_SHIFT) + d.b_off), none) : none;
+                const uint32_t i1 = on ? min((uint32_t)(((x + dis) >> SITE_SHIFT) + d.b_off), none) : none;
+                l_ = dir[i0]; h_ = dir[i1 + 1u];
+            };
+            uint32_t ls, hs, le, he;
+            range(L.dir0, live, s, ls, hs); range(L.dir1, junc, e, le, he);
+            probe_near_parts64(L.ent0, ls, hs, s, e, dis, rs, re, xm, am, m.amb);
+            probe_near_parts64(L.ent1, le, he, e, s2, dis, rs, re, jm, dm, m.amb);
+        } else {
+            const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
+            const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
+            const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
+            probe_parts64(L.ent0, ls, hs, s, e, xm, am);
+            probe_parts64(L.ent1, le, he, e, s2, jm, dm);
+        }
         const m64_t amj = junc ? am : 0ull;
         uint32_t word = first_member64(xm & vpre);
         word |= first_member64(jm & vpre) << 6;
@@ -111,8 +151,9 @@ __device__ __forceinline__ SiteMasks64 map_exons_lds64(const ChunkLds &L, const 
         word |= ((amj & vpre) ? 1u : 0u) << 13;
         m.kand &= junc ? (am & dm) : ~0ull;            // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
         m.kor |= amj | dm;
-        if (k == 0) m.dm_first = dm;
-        m.am_last = (live && !junc) ? am : m.am_last;
+        // (with a tolerance a shared donor / acceptor does not say that the exons overlap: the full-length evidence asks the START slice)
+        if (dis <= 0) { if (k == 0) m.dm_first = dm;
+                        m.am_last = (live && !junc) ? am : m.am_last; }
         if (live) Ap[k] = (uint32_t)(s - lo) | (word << SLAB_REL_BITS);
         s = s2; e = e2;
     }
@@ -221,7 +262,8 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, const uint32_t *__restrict__ u
         TileDesc d = u_tw[t].d;
         const int32_t thi = (int32_t)u_tw[t].pad[1];            // the tile's last base (k_walk_slab)
         // (the slices of the dictionaries are the tile's whatever the window)
-        const bool usable = d.nbk > 0 && a->f.p.ss_dis == 0;
+        const int dis = a->f.p.ss_dis;
+        const bool usable = d.nbk > 0 && dis >= 0 && dis <= DIS_MASK_MAX;
         const bool active = threadIdx.x < n_act;
         const uint32_t at = r0 + (active ? threadIdx.x : 0u);
         uint32_t pre = 0u, loc = 0u;
@@ -345,8 +387,11 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, const uint32_t *__restrict__ u
             const ChunkVisit vm = visit_chunk64<LEVEL>(L, w_n, work, n, re, s_tw.mask);
             redo = redo || vm.redo;
             const bool mapping = work && !vm.redo && n > 1;
-            const SiteMasks64 sm = map_exons_lds64(L, dc, mapping, Ap, Lp, tile_lo, n, vm.vpre);
-            if (work && !vm.redo) {
+            const SiteMasks64 sm = map_exons_lds64(L, dc, mapping, Ap, Lp, tile_lo, n, vm.vpre, dis, re.s0, re.el);
+            // (-d > 0: a visited member with two sites within the tolerance of one read site -- its pair count is the generic kernel's)
+            const bool amb = dis > 0 && mapping && (sm.amb & vm.vpre) != 0ull;
+            redo = redo || amb;
+            if (work && !vm.redo && !amb) {
                 int jstar = -1;
                 if (n > 1) {
                     m64_t c = sm.kand & vm.vpre;

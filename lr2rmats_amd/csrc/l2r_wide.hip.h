@@ -24,7 +24,7 @@ constexpr int WIDE_KEY_CAP = SLAB_KEY_CAP;
 constexpr int WIDE_TW_VECS = (int)(sizeof(TileWin64) / 16);
 
 struct VisitMasks64 { m64_t vpre, lmask, rmask, k1mask; bool redo; };
-struct SiteMasks64 { m64_t kand, kor, dm_first, am_last; };
+struct SiteMasks64 { m64_t kand, kor, dm_first, am_last, amb; };      // amb (-d > 0 only): members with TWO sites within the tolerance of one read site (probe_near64)
 struct WideLds { const WEnt *ent0, *ent1; const uint8_t *dir0, *dir1, *rdir; const int4 *hk, *hx; const int *win; };
 
 __device__ __forceinline__ m64_t rebase64(m64_t m, int d)
@@ -109,6 +109,24 @@ __device__ __forceinline__ void probe_all64(const WEnt *ent, uint32_t lo, uint32
     }
 }
 
+// probe_near (l2r_kernels.hip.h: -d > 0, src/update_gtf.c:717-779 with dis > 0) on 64-bit masks; entries [lo, hi) = the staged entries of
+// the buckets of k1 - dis .. k1 + dis, sorted by (key 1, key 2)
+__device__ __forceinline__ void probe_near64(const WEnt *ent, uint32_t lo, uint32_t hi, int32_t k1, int32_t k2, int dis, int rs, int re, m64_t &pm, m64_t &sm, m64_t &amb)
+{
+    pm = 0ull; sm = 0ull;
+    int last = INT32_MIN;
+    for (uint32_t r = lo; r < hi; ++r) {
+        const WEnt q = ent[r];
+        if (q.k1 > k1 + dis) break;
+        if (q.k1 < k1 - dis) continue;
+        if (q.k1 >= rs && q.k1 <= re) {
+            if (q.k1 != last) { amb |= sm & q.sm; last = q.k1; }
+            sm |= q.sm;
+        }
+        if (__builtin_abs(q.k2 - k2) <= dis) pm |= q.pm;
+    }
+}
+
 template <typename DirT>
 __device__ __forceinline__ m64_t overlapping_exon_members64(const DirT *rdir, const DirT *dir, const WEnt *ent, int b_off, int nb, int s, int e)
 {
@@ -127,9 +145,9 @@ __device__ __forceinline__ m64_t overlapping_exon_members64(const DirT *rdir, co
 // map_exons_slab on 64-bit masks: rows k .. k + 3 of the column in four register pairs with fixed roles, every round leaves its
 // exon and its work word at the exon's position in LDS (SlabStage)
 __device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const TileDesc &d, bool mapping, const uint32_t *__restrict__ xw,
-                                                        uint32_t off, uint32_t n, m64_t vpre, const SlabRows &q, const SlabStage &st)
+                                                        uint32_t off, uint32_t n, m64_t vpre, const SlabRows &q, const SlabStage &st, int dis = 0, int rs = 0, int re = 0)
 {
-    SiteMasks64 m{~0ull, 0ull, 0ull, 0ull};
+    SiteMasks64 m{~0ull, 0ull, 0ull, 0ull, 0ull};
     uint32_t *const Ap = st.A + st.loc; uint16_t *const Lp = st.Ln + st.loc;
     SlabRow R[SLAB_AHEAD];
 #pragma unroll
@@ -142,12 +160,19 @@ __device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const 
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
         const int s = slab_row_start(cur, st.lo), e = e_cur, s2 = slab_row_start(nxt, st.lo), e2 = slab_row_end(nxt, st.lo);
         const uint32_t cw = cur.w;
-        const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
-        const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
-        const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
         m64_t xm, am, jm, dm;
-        probe_all64(L.ent0, ls, hs, s, e, xm, am);
-        probe_all64(L.ent1, le, he, e, s2, jm, dm);
+        if (dis > 0) {                                  // (wave-uniform: -d)
+            uint32_t ls, hs, le, he;
+            near_range(L.dir0, d.b_off, none, live, s, dis, ls, hs); near_range(L.dir1, d.b_off, none, junc, e, dis, le, he);
+            probe_near64(L.ent0, ls, hs, s, e, dis, rs, re, xm, am, m.amb);
+            probe_near64(L.ent1, le, he, e, s2, dis, rs, re, jm, dm, m.amb);
+        } else {
+            const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
+            const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
+            const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
+            probe_all64(L.ent0, ls, hs, s, e, xm, am);
+            probe_all64(L.ent1, le, he, e, s2, jm, dm);
+        }
         if (reload) {                                   // exon k + SLAB_AHEAD into the registers of exon k
             const uint32_t j = (uint32_t)k + (uint32_t)SLAB_AHEAD;
             cur = slab_load_row(xw, off + (j < nm1 ? j + 1u : 0u) * SLAB_STRIDE);
@@ -159,8 +184,9 @@ __device__ __forceinline__ SiteMasks64 map_exons_slab64(const WideLds &L, const 
         word |= ((amj & vpre) ? 1u : 0u) << 13;
         m.kand &= junc ? (am & dm) : ~0ull;            // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
         m.kor |= amj | dm;
-        if (k == 0) m.dm_first = dm;
-        m.am_last = (live && !junc) ? am : m.am_last;
+        // (with a tolerance a shared donor / acceptor does not say that the exons overlap: the full-length evidence asks the START slice)
+        if (dis <= 0) { if (k == 0) m.dm_first = dm;
+                        m.am_last = (live && !junc) ? am : m.am_last; }
         if (live) { Ap[k] = (cw & SLAB_REL_MASK) | (word << SLAB_REL_BITS); Lp[k] = (uint16_t)(cw >> SLAB_REL_BITS); }
         e_cur = e2;
     };
@@ -349,8 +375,11 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         const VisitMasks64 vm = visit_window64<LEVEL>(L, d, w_n, work, n, d.j_lo, re, s_tw.mask);
         redo = redo || vm.redo;
         const bool mapping = work && !redo && n > 1;
-        const SiteMasks64 sm = map_exons_slab64(L, d, mapping, xw, off, n, vm.vpre, q, st);
+        const int dis = a->f.p.ss_dis;
+        const SiteMasks64 sm = map_exons_slab64(L, d, mapping, xw, off, n, vm.vpre, q, st, dis, re.s0, re.el);
         if (active && !mapping) slab_copy_exons(sa, a, out, st, q, off, n, pre, r);
+        // (-d > 0: a visited member with two sites within the tolerance of one read site -- its pair count is the generic kernel's)
+        if (dis > 0 && mapping && (sm.amb & vm.vpre) != 0ull) redo = true;
         if (work && !redo) {
             uint32_t *const Ap = s_A + loc;
             // (the read's ends once more, from its staged exons: four registers that need not live through the probe rounds)

@@ -120,7 +120,6 @@ __device__ __forceinline__ uint32_t make_descriptor(PipeArgsK a, int lane, int g
             if (n_win > win_cap || trip == WIN_SCAN_TRIPS * (WAVE / G) - 1) { fast = false; why = n_win > win_cap ? 4u : 5u; break; }
         }
         if (fast && n_win > win_cap) { fast = false; why = 4u; }
-        if (fast && dis > 0 && n_win > (uint32_t)WIN_TX) { fast = false; why = 7u; }      // (the 64-bit-mask kernels probe without a tolerance)
         if (fast) {
             d.n_win = n_win;
             if (n_win) { d.j_lo = first; contig = (uint32_t)(last - first + 1) == n_win; }

@@ -97,13 +97,15 @@ def test_locus_of_300_isoforms(oracle, level, pipeline):
         assert 5000 <= cnt[0] <= 6000 + 256, cnt
 
 
+@pytest.mark.parametrize("ss_dis", [0, 2, 7])
 @pytest.mark.parametrize("level", [1, 3, 5])
 @pytest.mark.parametrize("n_iso,gapped", [(40, False), (62, False), (44, True)])
-def test_locus_of_33_to_63_isoforms_stays_off_the_redo_list(oracle, level, n_iso, gapped, pipeline):
+def test_locus_of_33_to_63_isoforms_stays_off_the_redo_list(oracle, level, n_iso, gapped, ss_dis, pipeline):
     """Windows of 33 .. 63 transcripts: the slab pipeline classifies their tiles with the 64-bit-mask kernel
     (l2r_wide.hip.h) instead of the redo list; results are exact on every pipeline.  `gapped`: unrelated transcripts of
     a chromosome the header does not have (tid -1: skipped, not a stop) sit between the isoforms in file order, so the
-    window's members are not consecutive."""
+    window's members are not consecutive.  `ss_dis`: -d, the splice-site tolerance (src/update_gtf.c:717-779) -- the 64-bit-mask
+    kernel probes within it like the 32-bit one (probe_near64)."""
     rng = np.random.default_rng(100 + n_iso)
     pool = [(50_000 + 500 * k, 50_000 + 500 * k + 120) for k in range(26)]
     txs = []
@@ -139,7 +141,7 @@ def test_locus_of_33_to_63_isoforms_stays_off_the_redo_list(oracle, level, n_iso
         p, ops = _chain([tuple(x) for x in ex])
         rows.append((0, p, i & 1, ops))
     cnt = [0, 0, 0, 0, 0]
-    got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=level)
+    got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=level, ss_dis=ss_dis)
     assert ((want.info & 1) != 0).sum() > 100 and ((want.info & 2) != 0).sum() > 1000
     if pipeline in ("tile", "slab"):
         assert cnt[4] >= 15 and cnt[0] <= 300, cnt          # the locus's tiles took the 64-member kernel, (almost) nothing the redo list
@@ -328,9 +330,10 @@ def test_row_word_limits_of_the_slab(oracle, level, pipeline):
     assert ((want.info & 2) != 0).sum() > 100 and len(rows) <= 256
 
 
+@pytest.mark.parametrize("ss_dis", [0, 2, 7])
 @pytest.mark.parametrize("level", [1, 3, 5])
 @pytest.mark.parametrize("n_iso", [70, 150])
-def test_locus_beyond_the_mask_width_is_taken_in_chunks(oracle, level, n_iso, pipeline):
+def test_locus_beyond_the_mask_width_is_taken_in_chunks(oracle, level, n_iso, ss_dis, pipeline):
     """More overlapping transcripts than a 64-bit window holds, and exons shared by transcripts that lie more than 64 apart in the
     annotation (dictionary keys in several entries): the slab pipeline takes the tile's window 63 members at a time
     (k_probe_slab_chunked) and leaves nothing of it to the generic kernel; results are exact on every pipeline.  The known break,
@@ -366,7 +369,7 @@ def test_locus_beyond_the_mask_width_is_taken_in_chunks(oracle, level, n_iso, pi
         p, ops = _chain([tuple(x) for x in ex])
         rows.append((0, p, i & 1, ops))
     cnt = [0, 0, 0, 0, 0]
-    got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=level)
+    got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=level, ss_dis=ss_dis)
     assert ((want.info & 1) != 0).sum() > 100 and ((want.info & 2) != 0).sum() > 1000 and len(np.unique(want.ref_tx)) > 15
     assert cnt[1] > 0                                                             # keys in several entries exist
     if pipeline in ("tile", "slab"):

@@ -247,13 +247,14 @@ def test_config3_full_size(engine, oracle):
     np.testing.assert_array_equal(got.ex_start[a:b], sub.ex_start)
 
 
-@pytest.mark.parametrize("cfgname,lo", [("cfg3_iso40", 4_200_000 + 77), ("cfg3_gencode", 6_100_000 + 131)])
-def test_isoform_rich_annotations_full_size(engine, oracle, cfgname, lo):
+@pytest.mark.parametrize("cfgname,lo,ss_dis", [("cfg3_iso40", 4_200_000 + 77, 0), ("cfg3_gencode", 6_100_000 + 131, 0), ("cfg3_gencode", 2_300_000 + 19, 2)])
+def test_isoform_rich_annotations_full_size(engine, oracle, cfgname, lo, ss_dis):
     """Config 3's reads against isoform-rich annotations at FULL size (10 M reads): `cfg3_iso40` (40 isoforms per gene: every
     window holds 33 .. 63 transcripts, k_probe_slab_wide and k_probe_slab_chunked classify nearly everything) and `cfg3_gencode`
     (isoforms per gene log-normal, up to 200: all three probe kernels and small tiles).  Idempotence, the accepted list, a
     1 M-read slice out of the middle bit-exact against the oracle and equal to the same reads of the whole run; nothing is left to
-    the generic kernel (src/update_gtf.c:796-822: the reference's sweep knows no window limit)."""
+    the generic kernel (src/update_gtf.c:796-822: the reference's sweep knows no window limit).  `ss_dis` 2: the same with a splice-site
+    tolerance (-d 2, src/update_gtf.c:717-779) -- all three probe kernels look within it."""
     import ctypes as C
     from lr2rmats_amd import workload
     if engine.pipeline not in ("tile", "slab"):
@@ -261,7 +262,7 @@ def test_isoform_rich_annotations_full_size(engine, oracle, cfgname, lo):
     af, reads = workload.make_rank_workload(dict(workload.CONFIGS[cfgname]), 0, 1)
     _set_anno(engine, af)
     engine.set_junctions(None)
-    op = oracle.default_params(full_level=3)
+    op = oracle.default_params(full_level=3, ss_dis=ss_dis)
     prm = util.to_engine_params(capi, op)
     got = engine.classify(reads, prm)
     lib = capi.load_library()
