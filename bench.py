@@ -245,9 +245,92 @@ def gencode_leg(capi, workload, args):
                 np.array_equal(got.ex_off[: sub.n + 1], want.ex_off) and np.array_equal(got.ex_start[:nx], want.ex_start)
                 and np.array_equal(got.ex_end[:nx], want.ex_end) and np.array_equal(got.ex_flag[:nx], want.ex_flag)
                 and np.array_equal(got.info[: sub.n] & 0x7f, want.info & 0x7f) and np.array_equal(got.ref_tx[: sub.n], want.ref_tx))}
+        # ... and with a splice-site tolerance (-d 2): the 64-bit-mask and the chunked kernel probe within it as well
+        eng.set_params(capi.default_params(full_level=args.level, ss_dis=2))
+        eng.run(); eng.sync()
+        tm2 = eng.run_timed(max(3, min(args.steps, 10)))
+        lib.l2r_debug_counters(eng.ctx, cnt, 13)
+        out["dis2"] = {"options": "-l %d -d 2" % args.level, "ms_per_step": round(tm2["total_ms"], 4), "over_the_d0_step": round(tm2["total_ms"] / tm["total_ms"], 3),
+                       "reads_on_the_redo_list": int(cnt[0]), "stage_ms": {k.split(" ")[0]: round(v, 4) for k, v in tm2["kernel_ms"].items()}}
         return out
     finally:
         eng.close()
+
+
+def _same(np, got, want, n_r):
+    nx = int(want.ex_off[-1])
+    return bool(np.array_equal(got.ex_off[: n_r + 1], want.ex_off) and np.array_equal(got.ex_start[:nx], want.ex_start)
+                and np.array_equal(got.ex_end[:nx], want.ex_end) and np.array_equal(got.ex_flag[:nx], want.ex_flag)
+                and np.array_equal(got.info[: n_r] & 0x7f, want.info & 0x7f) and np.array_equal(got.ref_tx[: n_r], want.ref_tx))
+
+
+def ont_leg(capi, workload, args):
+    """BASELINE configs[4] as ONE of its 8 GPUs sees it: rank 0's shard of the ONT-error-profile workload (2.5 M reads of ~330 CIGAR
+    operations and ~14 exons, 3 micro-exons per read, against the 2 M-exon GTF) -- the long-CIGAR kernels (k_walk_slab_long + k_probe_slab).
+    An engine of its own; a 150 k-read slice is compared with the oracle bit for bit."""
+    import ctypes as C
+    import numpy as np
+    cfg = dict(workload.CONFIGS["cfg5"])
+    cfg["n_reads"] = cfg["n_reads"] // 8
+    af, reads = workload.make_rank_workload(cfg, 0, 8)
+    eng = capi.Engine(0)
+    try:
+        eng.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
+        eng.set_params(capi.default_params(full_level=args.level))
+        eng.set_outputs(capi.WANT_RESULTS)
+        eng.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)
+        eng.run(); eng.sync()
+        tm = eng.run_timed(max(3, min(args.steps, 10)))
+        n_r, n_x, _, _ = eng.sizes()
+        lib = capi.load_library()
+        cnt = (C.c_longlong * 13)()
+        lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.l2r_debug_counters(eng.ctx, cnt, 13)
+        abytes = workload.algorithmic_bytes(n_r, int(reads.cig.shape[0]), n_x, af.n_tx, af.n_exons, 0)
+        out = {"workload": "BASELINE configs[4], rank 0 of 8: %d ONT-like reads x %.2f exons/read (%.1f CIGAR ops/read), %d-exon / %d-transcript GTF, update-gtf -l %d" % (
+                   reads.n, n_x / max(n_r, 1), reads.cig.shape[0] / max(n_r, 1), af.n_exons, af.n_tx, args.level),
+               "ms_per_step": round(tm["total_ms"], 4), "reads_per_s": round(reads.n / (tm["total_ms"] * 1e-3), 1),
+               "algorithmic_bytes_per_launch": abytes,
+               "frac_event_pass": round(abytes / (tm["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "reads_on_the_redo_list": int(cnt[0]), "tiles": int(cnt[3]),
+               "kernel_ms": {k.split(" ")[0]: round(v, 4) for k, v in tm["kernel_ms"].items()}}
+        if not args.no_cpu:
+            from oracle import pyoracle as po
+            po.build()
+            sub = reads.slice(0, min(150_000, reads.n))
+            want = po.classify_soa(sub.tid, sub.pos, sub.rev, sub.cig_off, sub.cig, af.tx_tid, af.tx_start, af.tx_end, af.tx_rev,
+                                   af.tx_ex_off, af.ex_start, af.ex_end, params=po.default_params(full_level=args.level))
+            out["parity_on_slice"] = {"reads": sub.n, "identical": _same(np, eng.download(), want, sub.n)}
+        return out
+    finally:
+        eng.close()
+
+
+def dis_leg(eng, af, reads, args, capi, workload, n_x, base_ms):
+    """The headline workload with a splice-site tolerance: `-d 2` (src/update_gtf.c:717-779 with dis > 0; every mask kernel probes
+    within the tolerance).  Same engine, same resident reads; a 150 k-read slice against the oracle."""
+    import ctypes as C
+    import numpy as np
+    eng.set_params(capi.default_params(full_level=args.level, ss_dis=2))
+    eng.run(); eng.sync()
+    tm = eng.run_timed(max(3, min(args.steps, 10)))
+    lib = capi.load_library()
+    cnt = (C.c_longlong * 13)()
+    lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.l2r_debug_counters(eng.ctx, cnt, 13)
+    out = {"options": "-l %d -d 2" % args.level, "ms_per_step": round(tm["total_ms"], 4), "over_the_d0_step": round(tm["total_ms"] / base_ms, 3),
+           "reads_on_the_redo_list": int(cnt[0]), "redo_share": round(cnt[0] / max(reads.n, 1), 6),
+           "kernel_ms": {k.split(" ")[0]: round(v, 4) for k, v in tm["kernel_ms"].items()}}
+    if not args.no_cpu:
+        from oracle import pyoracle as po
+        po.build()
+        sub = reads.slice(0, min(150_000, reads.n))
+        want = po.classify_soa(sub.tid, sub.pos, sub.rev, sub.cig_off, sub.cig, af.tx_tid, af.tx_start, af.tx_end, af.tx_rev,
+                               af.tx_ex_off, af.ex_start, af.ex_end, params=po.default_params(full_level=args.level, ss_dis=2))
+        out["parity_on_slice"] = {"reads": sub.n, "identical": _same(np, eng.download(), want, sub.n)}
+    eng.set_params(capi.default_params(full_level=args.level))
+    eng.run(); eng.sync()
+    return out
 
 
 def launcher_argv(args, port: int):
@@ -302,6 +385,8 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0, help="diagnostics, one GPU: run the shard rank 0 would own in a strong-scaling run of this many GPUs")
     ap.add_argument("--no-second-pass", action="store_true", help="skip the pipeline's second option set (-s -l 3 -J 1 -j SJ.tab) at N=1")
     ap.add_argument("--no-gencode", action="store_true", help="skip the second workload (heavy-tailed isoforms per gene) at N=1")
+    ap.add_argument("--no-ont", action="store_true", help="skip the ONT shard (BASELINE configs[4], rank 0 of 8) at N=1")
+    ap.add_argument("--no-dis", action="store_true", help="skip the -d 2 leg at N=1")
     ap.add_argument("--dry-launch", action="store_true", help="print the launcher command a plain `bench.py --gpus N` would start, and exit")
     args = ap.parse_args()
 
@@ -531,6 +616,18 @@ def main():
                 second = second_pass(eng, af, reads, got, args, capi, workload, n_x)
             except Exception as e:                                # (must not take the line down)
                 second = {"error": str(e)[:300]}
+        dis2 = None
+        if world == 1 and not args.no_dis and args.config == "cfg3":
+            try:
+                dis2 = dis_leg(eng, af, reads, args, capi, workload, n_x, tm["total_ms"])
+            except Exception as e:                                # (must not take the line down)
+                dis2 = {"error": str(e)[:300]}
+        ont = None
+        if world == 1 and not args.no_ont and args.config == "cfg3":
+            try:
+                ont = ont_leg(capi, workload, args)
+            except Exception as e:                                # (must not take the line down)
+                ont = {"error": str(e)[:300]}
         gencode = None
         if world == 1 and not args.no_gencode:
             try:
@@ -543,6 +640,8 @@ def main():
         out = {
             "metric": "long-read alignments classified/sec; achieved HBM GB/s vs roofline",
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # (the line's value / ms_per_step / roofline.frac come from the SECOND of two identical W + K regions: roofline.cold_start is the first)
+            "headline_region": 2, "warmup_effective_steps": 2 * args.warmup + args.steps,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: synthetic %d long reads (%d per GPU) x %.2f exons/read (%.1f CIGAR ops/read), "
@@ -565,6 +664,8 @@ def main():
             "with_accepted": with_accepted,
             "second_pass": second,
             "isoform_rich": gencode,
+            "dis2": dis2,
+            "ont_shard": ont,
             "cpu_baseline": cpu,
             "e2e": e2e,
         }

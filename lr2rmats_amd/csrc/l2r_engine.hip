@@ -811,7 +811,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         // (tiles of sorted records also end where the reads would begin 2^17 bases apart: a slab tile's exons are kept relative to its
         //  first base, and any tile's dictionary slices cover 196 kb -- sparse stretches give small tiles instead of tiles for the
         //  generic kernel; the classic pipeline, whose tiles own 24 KB of hand-over buffer each, keeps at least 8 reads per tile)
-        if (i - start == rpt || (sorted && r->tid[i] != r->tid[start]) || (i > start && pos_sum + need > (uint64_t)SLAB_POS_CAP) ||
+        if (i - start == rpt || (sorted && r->tid[i] != r->tid[start]) || (i > start && pos_sum + need > (uint64_t)TILE_POS_CAP) ||
             (sorted && i > start && (int64_t)r->pos[i] - (int64_t)r->pos[start] >= (int64_t)SLAB_TILE_SPAN && (slab_tiles || slab_long_tiles || i - start >= 8))) { tile_first.push_back((uint32_t)start); start = i; pos_sum = 0; }
         pos_sum += need;
     }

@@ -753,7 +753,8 @@ struct SlabRows { SlabRow last, x[SLAB_AHEAD]; };        // a column's row 0 (th
 // behind that or further than 2^18 - 1 bases from the tile's start is written directly and classified by the generic kernel.
 // (Measured: 8 bytes per position at 6 workgroups per CU 0.474 ms, this form 0.462; 2112 positions at 8 workgroups per CU and
 // 64 VGPRs: 0.594 -- 17 spilled registers and 13 % more tiles.)
-constexpr int SLAB_POS_CAP = 2400;                       // (k_tile's LDS = 23040 bytes = 45 granules of 512: 7 workgroups per CU exactly; k_probe_slab alone could hold 2536)
+constexpr int SLAB_POS_CAP = 2536;                       // (k_probe_slab's LDS = 23040 bytes = 45 granules of 512: 7 workgroups per CU exactly; 2416 before: 1.1 % more tiles)
+constexpr int TILE_POS_CAP = 2400;                       // ... of k_tile (l2r_tile.hip.h), which also keeps the reads' counts and places there: what the upload cuts the tiles of short CIGARs by
 constexpr uint32_t SLAB_POS_SKIP = 0xffffffffu;          // A of a position that was written directly (a staged start is below 2^18 - 1)
 struct SlabStage { uint32_t *A; uint16_t *Ln; uint32_t loc; int32_t lo; bool fits; };          // loc: the lane's first position, lo: the tile's first start
 

@@ -320,13 +320,13 @@ __device__ __forceinline__ SlabVerdict tile_classify(PipeArgsK a, const TileDesc
 
 // LDS of k_tile beside the staged positions, dictionary slices, directories and window record of k_probe_slab: the reads' exon counts
 // (one byte each, read order) and their exclusive scan (16 bit).
-constexpr int TILE_LDS_BYTES = SLAB_POS_CAP * 6 + 2 * SLAB_KEY_CAP * 16 + SLAB_AUX_BYTES + TILE_THREADS * 3 + 16 * 4 + 4 * 4;
+constexpr int TILE_LDS_BYTES = TILE_POS_CAP * 6 + 2 * SLAB_KEY_CAP * 16 + SLAB_AUX_BYTES + TILE_THREADS * 3 + 16 * 4 + 4 * 4;
 static_assert(TILE_LDS_BYTES <= 23040, "k_tile: 7 workgroups per CU need 45 allocation granules of 512 bytes at most");
-static_assert(SLAB_POS_CAP >= 2 * TILE_THREADS + 16, "slab_walk_tile's words live in the staged positions");
-static_assert(SLAB_POS_CAP < 65536 && SLAB_POS_CAP % 8 == 0, "16-bit places; 16-byte aligned arrays");
+static_assert(TILE_POS_CAP >= 2 * TILE_THREADS + 16, "slab_walk_tile's words live in the staged positions");
+static_assert(TILE_POS_CAP < 65536 && TILE_POS_CAP % 8 == 0, "16-bit places; 16-byte aligned arrays");
 
 constexpr int SJ_STAGE = 2 * SLAB_KEY_CAP * 16 / 12;    // junction rows k_tile stages per tile: {donor, acceptor, running maximum of the acceptors} over the dead dictionary slices
-static_assert(SLAB_AUX_BYTES >= (SJ_STAGE / 32 + 2 * 4 + 2) * 4 && SLAB_AUX_BYTES >= TILE_THREADS * 5 && 2 * SLAB_KEY_CAP * 16 >= SLAB_POS_CAP,
+static_assert(SLAB_AUX_BYTES >= (SJ_STAGE / 32 + 2 * 4 + 2) * 4 && SLAB_AUX_BYTES >= TILE_THREADS * 5 && 2 * SLAB_KEY_CAP * 16 >= TILE_POS_CAP,
               "the junction check's arrays fit the dead dictionary slices / directories");
 template <int LEVEL, bool ACC, bool DIS>
 __global__ __launch_bounds__(TILE_THREADS, 7)
@@ -334,8 +334,8 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
             uint32_t *__restrict__ u_xbase)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
-    __shared__ __attribute__((aligned(16))) uint32_t s_A[SLAB_POS_CAP];
-    __shared__ __attribute__((aligned(16))) uint16_t s_L[SLAB_POS_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_A[TILE_POS_CAP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_L[TILE_POS_CAP];
     __shared__ __attribute__((aligned(16))) v4i_t s_ent[2 * SLAB_KEY_CAP];
     __shared__ __attribute__((aligned(16))) uint8_t s_aux[SLAB_AUX_BYTES];       // directories, then the window record
     __shared__ __attribute__((aligned(16))) uint8_t s_cnt[TILE_THREADS];        // exon counts, read order (255: that many or more)
@@ -486,7 +486,7 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
         const uint32_t fl = meet ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_flagw[0] | s_flagw[1] | s_flagw[2] | s_flagw[3])) : 0u;
         // a dictionary key in several entries: k_probe_slab_chunked ORs them (the tile keeps the slab form); with chunked windows off
         // the tile's reads take the generic kernel
-        late_slab = total > (uint32_t)SLAB_POS_CAP || (fl & 1u) != 0u || ((fl & 2u) != 0u && chunk_on != 0u);
+        late_slab = total > (uint32_t)TILE_POS_CAP || (fl & 1u) != 0u || ((fl & 2u) != 0u && chunk_on != 0u);
         wide_key = (fl & 2u) != 0u;
         any_wide = (wide_key && !late_slab) ? 1 : 0;
     }
@@ -677,7 +677,7 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
         if (wv < 3 && !first_look && !(ablate & 64)) share = lb_share<false>(sa, t, wv, lane, done, n_polls);
         if (stamp.p && lane == 0 && wv < 3) { atomicAdd(&stamp.p[8192 + wv], (unsigned long long)n_polls); atomicAdd(&stamp.p[8192 + 3 + wv], n_polls ? 1ull : 0ull); }
         // (L2R_ABLATE bit 6, timing diagnostics only: no look at the counts in front -- the results land at made-up slots)
-        if (ablate & 64) share = wv == 0 ? t * (uint32_t)SLAB_POS_CAP : 0u;
+        if (ablate & 64) share = wv == 0 ? t * (uint32_t)TILE_POS_CAP : 0u;
         if (lane == 0 && wv < 3) s_lb[wv] = share;
     }
     __syncthreads();
