@@ -987,5 +987,15 @@ int h_read_alignments_shard(const char *fn, h_chroms *chr, h_reads *out, int ski
 
 void h_read_header_only(const char *fn, h_chroms *chr, const char *who)
 {
+    /* a BGZF-compressed BAM: the blocks the header lies in and nothing else (the whole file used to be read and inflated
+     * here, in front of the reader that streams it again); anything else -- SAM text, gzip -- as a whole */
+    FILE *f = fopen(fn, "rb");
+    if (!f) h_fatal(who, "Can not open \"%s\"\n", fn);
+    if (file_is_bgzf(f)) {
+        fseek(f, 0, SEEK_SET);
+        vpos first;
+        if (bam_header_light(f, chr, &first, who)) { fclose(f); return; }
+    }
+    fclose(f);
     read_any(fn, chr, NULL, 1, 1, who);
 }

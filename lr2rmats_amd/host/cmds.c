@@ -668,12 +668,21 @@ static void *early_engine_main(void *arg)
     }
     return NULL;
 }
+/* h_fatal on another thread (a missing input, a malformed GTF) while this one may be inside hipInit / l2r_create: exit() must not
+ * tear the runtime down under it -- tell the thread that no annotation will come and wait for it (not from the thread itself) */
+static void early_engine_before_exit(void)
+{
+    if (!g_early.started || pthread_equal(pthread_self(), g_early.th)) return;
+    early_engine_annotation(NULL);
+    pthread_join(g_early.th, NULL);
+    g_early.started = 0;
+}
 static void early_engine_start(void)
 {
     const char *off = getenv("L2R_EARLY_ENGINE");
     if (g_early.started || (off && off[0] == '0')) return;
     g_early.ctx = NULL; g_early.err[0] = 0; g_early.anno_state = 0; g_early.anno_set = 0;
-    if (pthread_create(&g_early.th, NULL, early_engine_main, NULL) == 0) g_early.started = 1;
+    if (pthread_create(&g_early.th, NULL, early_engine_main, NULL) == 0) { g_early.started = 1; h_before_exit = early_engine_before_exit; }
 }
 /* the parsed annotation for the early thread (a: arrays that stay where they are until the engine has run), or NULL: none will come */
 static void early_engine_annotation(const l2r_annotation *a)

@@ -15,6 +15,7 @@
 #define H_NAME_MAX 100          /* reference name buffers are char[100] (src/gtf.h:44-45) */
 
 /* ---- errors: reference exit behaviour (src/utils.c:91-111) */
+extern void (*h_before_exit)(void);            /* called by h_fatal in front of exit(): a thread that is starting the HIP runtime is waited for */
 void h_fatal(const char *where, const char *fmt, ...);        /* "[where] msg" + exit(1) */
 void h_fatal_core(const char *where, const char *fmt, ...);   /* "[where] msg Abort!" + abort() */
 void h_stage_time(const char *what);                          /* L2R_TIMING=1: wall clock since the last call, on stderr */

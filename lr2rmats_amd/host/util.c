@@ -6,6 +6,8 @@
 #include <sys/mman.h>
 #include "l2r_host.h"
 
+void (*h_before_exit)(void) = 0;
+
 void h_fatal(const char *where, const char *fmt, ...)
 {
     /* reference src/utils.c:91-100 err_fatal: message on stderr, exit status 1 */
@@ -13,6 +15,9 @@ void h_fatal(const char *where, const char *fmt, ...)
     fprintf(stderr, "[%s] ", where);
     va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap);
     fprintf(stderr, "\n");
+    /* A helper thread may be inside the HIP runtime's start-up (cmds.c early_engine_start: the engine's context is made beside the
+     * readers); exit() would run the runtime's teardown against it.  The registered hook waits for that thread first. */
+    if (h_before_exit) h_before_exit();
     exit(EXIT_FAILURE);
 }
 

@@ -37,5 +37,6 @@ lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 lib.l2r_debug_counters(e.ctx, cnt, 13)
 print("redo reads %d, wide entries %d, compact tx %d, tiles %d" % tuple(cnt[:4]), "| tiles of the 64-member kernel:", cnt[12])
 print("tiles [fast, exons > LDS cap, bucket span, dictionary slice, window > 32, window scan, cursor behind window, off]:", list(cnt[4:12]))
-tm = e.run_timed(5)
+# (a profile's per-kernel averages: enough back-to-back steps for the chip's clock to settle -- it rises over the first ~25, tools/ramp.py)
+tm = e.run_timed(int(os.environ.get("L2R_ONCE_ITERS", "30")))
 print(e.sizes(), tm)
