@@ -159,6 +159,10 @@ typedef struct {
  *             (annotation window, site probes, verdicts, read-order results) + k_probe_slab_wide (tiles whose window holds 33 .. 63
  *             transcripts) + k_probe_slab_chunked (tiles beyond that, or with a dictionary key in several entries: the window 63
  *             members at a time).  Every run launches all of them: nothing is kept from an earlier run of the same records.
+ *     tile    (coordinate-sorted records with short CIGARs, -e >= 1; default where it applies)  0 k_describe_scan (the tiles' descriptors
+ *             and windows from the spans the upload recorded; first kernel of the run)  1 k_tile (CIGAR -> exons, window, probes, verdicts,
+ *             junction check, read-order results: one workgroup per tile, nothing handed over through HBM)  2 k_probe_slab for the few
+ *             tiles k_tile left in slab form + k_probe_slab_wide + k_probe_slab_chunked (not launched once a run has shown their lists empty)
  *     classic (unsorted records, long CIGARs with -e < 1, L2R_PIPELINE=classic)  0 k_pass_a  1 k_scan_u32 (tile sums)  2 k_classify_fast */
 #define L2R_N_STAGES 8
 typedef struct {
@@ -213,6 +217,18 @@ int          l2r_download(l2r_ctx *ctx, l2r_result *res);               /* HBM -
 int          l2r_download_accepted(l2r_ctx *ctx, l2r_accepted *acc);
 int          l2r_device_view_get(l2r_ctx *ctx, l2r_device_view *view);
 void        *l2r_stream(l2r_ctx *ctx);                                  /* hipStream_t */
+
+/* ---- diagnostics (tools/, bench.py and the tests read them; no product path does).
+ * l2r_debug_counters: out[0] reads the last run left to the generic kernel (the redo list), [1] dictionary entries whose key has
+ *   several entries, [2] annotation transcripts the mask kernels take, [3] tiles, [4..11] tiles by the reason their descriptor
+ *   is not on the 32-bit masks (0 = it is), [12] tiles of the 64-bit-mask kernel; n = words of out (4, 12 or 13).
+ * l2r_debug_stamps: with L2R_STAMPS=1 in the environment at l2r_upload_reads, per-phase cycle sums of the classification kernel
+ *   (and clears them); zeros otherwise.
+ * l2r_debug_tile_times: with L2R_STAMPS=1, one-kernel tile path: four words per tile -- the chip's 100 MHz clock at the tile's start
+ *   << 3 | its XCD, at the publication of its exon count, at the begin and the end of its wait for the counts in front. */
+int          l2r_debug_counters(l2r_ctx *ctx, long long *out, int n);
+int          l2r_debug_stamps(l2r_ctx *ctx, unsigned long long *out, int n);
+int          l2r_debug_tile_times(l2r_ctx *ctx, uint32_t *out, int64_t n_tiles);
 
 /* upload + run + sync + download in one call (the host CLI uses this). */
 int          l2r_classify(l2r_ctx *ctx, const l2r_reads *reads, l2r_result *res);

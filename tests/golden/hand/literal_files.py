@@ -234,8 +234,60 @@ SPLIT_BED = [bed("chrA", 2500, 2600, "I", 2, "+"), bed("chrB", 20050, 20100, "T"
              bed("chrB", 20960, 20980, "T", 1, "+")]
 SPLIT_SUMMARY = summary(7, 7, 2, 4, 1, 4, 7, 3, 0, 0, 0, 3, 3, 2, 2, 0, 0)
 
+# --------------------------------------------------------------------------------------------------
+# Case "dis": update-gtf -l 5 -d 2 (and -d 0 beside it) on an annotation with TWO donors inside one read donor's tolerance.
+# README.md section 4.  check_splice_site (update_gtf.c:717-779) counts identical_site_n per (annotation site, read site) PAIR.
+DIS_ANNO = gtf_rows("chrA", "+", "GD", "gd", "TD1", "td1", [(500, 600), (1000, 1100), (1102, 1103), (2000, 2100)])
+DIS_SAM = SAM_HEADER + [
+    sam("rd1", 0, "chrA", 1000, "102M898N101M"),      # exons (1000,1101) (2000,2100): its donor 1101 is within 2 of the donors 1100 AND 1103
+    sam("rd2", 0, "chrA", 1000, "101M899N101M"),      # exons (1000,1100) (2000,2100): its donor 1100 is within 2 of 1100 only
+]
+# -d 2: rd1 -- acceptor pair (1000, its own first start: Q1) + donor pairs (1100,1101) and (1103,1101) = 3 pairs for 2 read sites: NOT known
+# (:770), has a known site; every novel flag is cleared (exon 0 within 2 of (1000,1100), junction within 2 of (1103,2000)).
+# rd2 -- pairs (1000,1000) and (1100,1100), donor 1103 is 3 away: 2 pairs = 2 sites = known; its junction (1100,2000) is no
+# annotated junction within 2 ((1100,1102) and (1103,2000) both miss one end), so that flag stays.
+DIS2_DETAIL = [
+    DETAIL_HEADER,
+    detail("rd1", "chrA", "+", 1, "GD", "gd", [1000, 2000], [1101, 2100], [], [], [], []),
+    detail("rd2", "chrA", "+", 0, "GD", "gd", [1000, 2000], [1100, 2100], [], [], [0], []),
+]
+# -d 0: rd1's donor 1101 matches nothing (site 0, exon 0 and junction 0 stay novel), its acceptor pair still makes it "has known site"
+DIS0_DETAIL = [
+    DETAIL_HEADER,
+    detail("rd1", "chrA", "+", 1, "GD", "gd", [1000, 2000], [1101, 2100], [0], [0], [0], []),
+    detail("rd2", "chrA", "+", 0, "GD", "gd", [1000, 2000], [1100, 2100], [], [], [0], []),
+]
+DIS_GTF = gtf_block("chrA", 1000, 2100, "+", "GD", "gd", "rd1", 1, "chrA", "+", [(1000, 1101), (2000, 2100)])      # rd2 is known: not in the updated list
+
+# --------------------------------------------------------------------------------------------------
+# Case "ends": update-gtf -l 1 / -l 2 / -l 4: the full-length rules (check_full / set_full, update_gtf.c:629-696) seen through the
+# updated GTF (only full-length reads are routed, :943).  README.md section 5.
+ENDS_ANNO = gtf_rows("chrA", "+", "GE", "ge", "TE1", "te1", [(1000, 1100), (2000, 2100), (3000, 3100)])
+ENDS_SAM = SAM_HEADER + [
+    sam("e4", 0, "chrA", 1020, "71M909N101M899N101M"),     # (1020,1090) (2000,2100) (3000,3100): first exons overlap, first ends differ
+    sam("e1", 0, "chrA", 1050, "51M899N101M899N51M"),      # (1050,1100) (2000,2100) (3000,3050): first end and last start are the annotation's
+    sam("e2", 0, "chrA", 1150, "101M749N101M899N101M"),    # (1150,1250) ...: the first exon overlaps NO annotation exon
+    sam("e3", 0, "chrA", 2050, "51M899N101M"),             # (2050,2100) (3000,3100): the first exon overlaps the annotation's SECOND exon
+]
+ENDS_DETAIL = [
+    DETAIL_HEADER,
+    detail("e4", "chrA", "+", 1, "GE", "ge", [1020, 2000, 3000], [1090, 2100, 3100], [0], [0, 1], [0], []),
+    detail("e1", "chrA", "+", 1, "GE", "ge", [1050, 2000, 3000], [1100, 2100, 3050], [0, 2], [1], [], []),
+    detail("e2", "chrA", "+", 1, "GE", "ge", [1150, 2000, 3000], [1250, 2100, 3100], [0], [0, 1], [0], []),
+    detail("e3", "chrA", "+", 1, "GE", "ge", [2050, 3000], [2100, 3100], [0], [1], [], []),
+]
+_E4 = gtf_block("chrA", 1020, 3100, "+", "GE", "ge", "e4", 1, "chrA", "+", [(1020, 1090), (2000, 2100), (3000, 3100)])
+_E1 = gtf_block("chrA", 1050, 3050, "+", "GE", "ge", "e1", 1, "chrA", "+", [(1050, 1100), (2000, 2100), (3000, 3050)])
+_E2 = gtf_block("chrA", 1150, 3100, "+", "GE", "ge", "e2", 1, "chrA", "+", [(1150, 1250), (2000, 2100), (3000, 3100)])
+ENDS_GTF_L1 = _E1                     # -l 1: first END and last START must be the annotation's: e1 alone
+ENDS_GTF_L2 = _E4 + _E1               # -l 2: terminal exons must overlap the annotation's terminal exons: e4 too
+ENDS_GTF_L4 = _E4 + _E1 + _E2         # -l 4: left side only, and a first exon that overlaps NO annotation exon counts (lnoth): e2 too; e3's overlaps an inner one
+
 FILES = {
     "anno.gtf": ANNO,
+    "dis_anno.gtf": DIS_ANNO, "dis.sam": DIS_SAM, "dis2.detail.txt": DIS2_DETAIL, "dis0.detail.txt": DIS0_DETAIL, "dis.updated.gtf": DIS_GTF,
+    "ends_anno.gtf": ENDS_ANNO, "ends.sam": ENDS_SAM, "ends.detail.txt": ENDS_DETAIL,
+    "ends_l1.updated.gtf": ENDS_GTF_L1, "ends_l2.updated.gtf": ENDS_GTF_L2, "ends_l4.updated.gtf": ENDS_GTF_L4,
     "upd.sam": UPD_SAM, "upd.detail.txt": UPD_DETAIL, "upd.updated.gtf": UPD_GTF, "upd.novel_exon.bed": UPD_BED, "upd.summary.txt": UPD_SUMMARY,
     "upd_c.updated.gtf": UPD_GTF_C, "upd_c.novel_exon.bed": UPD_BED_C, "upd_c.summary.txt": UPD_SUMMARY_C,
     "uniq.sam": UNIQ_SAM, "uniq.unique.gtf": UNIQ_GTF, "uniq_s.unique.gtf": UNIQ_GTF_S,

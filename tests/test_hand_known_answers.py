@@ -17,6 +17,12 @@ CASES = {
               {"gtf": "upd_c.updated.gtf", "detail": "upd.detail.txt", "summary": "upd_c.summary.txt", "bed": "upd_c.novel_exon.bed"}),
     "split": (["update-gtf", "-s", "-l", "5", "-J", "1", "-j", os.path.join(H, "split_sj.tab")], "split.sam", True,
               {"gtf": "split.updated.gtf", "detail": "split.detail.txt", "summary": "split.summary.txt", "bed": "split.novel_exon.bed"}),
+    # -d: two annotation donors inside one read donor's tolerance (pair counting, update_gtf.c:736-752,770); -l 1 / 2 / 4 end rules (:629-696)
+    "dis2": (["update-gtf", "-l", "5", "-d", "2"], "dis.sam", "dis_anno.gtf", {"gtf": "dis.updated.gtf", "detail": "dis2.detail.txt"}),
+    "dis0": (["update-gtf", "-l", "5", "-d", "0"], "dis.sam", "dis_anno.gtf", {"gtf": "dis.updated.gtf", "detail": "dis0.detail.txt"}),
+    "ends_l1": (["update-gtf", "-l", "1"], "ends.sam", "ends_anno.gtf", {"gtf": "ends_l1.updated.gtf", "detail": "ends.detail.txt"}),
+    "ends_l2": (["update-gtf", "-l", "2"], "ends.sam", "ends_anno.gtf", {"gtf": "ends_l2.updated.gtf", "detail": "ends.detail.txt"}),
+    "ends_l4": (["update-gtf", "-l", "4"], "ends.sam", "ends_anno.gtf", {"gtf": "ends_l4.updated.gtf", "detail": "ends.detail.txt"}),
     "uniq": (["unique-gtf"], "uniq.sam", False, {"gtf": "uniq.unique.gtf"}),
     "uniq_s": (["unique-gtf", "-s"], "uniq.sam", False, {"gtf": "uniq_s.unique.gtf"}),
 }
@@ -24,13 +30,13 @@ CASES = {
 
 def _argv(case, tmp_path):
     cmd, inp, with_anno, expect = CASES[case]
-    out = {k: str(tmp_path / ("%s.%s" % (case, k))) for k in expect}
+    out = {k: str(tmp_path / ("%s.%s" % (case, k))) for k in ("gtf", "detail", "summary", "bed")}
     args = list(cmd)
     if with_anno:
         args += ["-A", out["detail"], "-y", out["summary"], "-E", out["bed"]]
     args += [os.path.join(H, inp)]
     if with_anno:
-        args += [os.path.join(H, "anno.gtf")]
+        args += [os.path.join(H, with_anno if isinstance(with_anno, str) else "anno.gtf")]
     return args, out, expect
 
 
