@@ -218,6 +218,20 @@ int          l2r_download_accepted(l2r_ctx *ctx, l2r_accepted *acc);
 int          l2r_device_view_get(l2r_ctx *ctx, l2r_device_view *view);
 void        *l2r_stream(l2r_ctx *ctx);                                  /* hipStream_t */
 
+/* ---- several GPUs of one node, one process (rank) per GPU: the gathered route's exchange over RCCL (xGMI).
+ * Inputs that cannot be cut into independent shards (-s with a junction table: split pieces are compared across chromosomes,
+ * src/update_gtf.c:837-913,946-960) are classified shard by shard and their per-read results gathered on rank 0, which runs the
+ * order-dependent tail once over the whole read-order set.  Rank 0 makes the id (l2r_xchg_unique_id: l2r_xchg_id_bytes() bytes) and
+ * the caller carries it to the other ranks; every rank then creates its end (collective) and, behind l2r_run + l2r_sync, calls
+ * l2r_xchg_gather_results (collective): `res` (rank 0 only; capacities as for l2r_download, for the reads / exons of ALL ranks)
+ * receives the results of every rank as one set with global exon offsets; counts_out (may be NULL) gets {reads, exons} per rank. */
+typedef struct l2r_xchg l2r_xchg;
+int          l2r_xchg_id_bytes(void);
+int          l2r_xchg_unique_id(void *id_out);
+l2r_xchg    *l2r_xchg_create(l2r_ctx *ctx, int rank, int world, const void *id);
+int          l2r_xchg_gather_results(l2r_xchg *x, l2r_result *res, int64_t *counts_out);
+void         l2r_xchg_destroy(l2r_xchg *x);
+
 /* ---- diagnostics (tools/, bench.py and the tests read them; no product path does).
  * l2r_debug_counters: out[0] reads the last run left to the generic kernel (the redo list), [1] dictionary entries whose key has
  *   several entries, [2] annotation transcripts the mask kernels take, [3] tiles, [4..11] tiles by the reason their descriptor

@@ -1646,3 +1646,5 @@ int l2r_filter_select(l2r_ctx *c, int64_t n_groups, const int64_t *group_off, co
 static_assert(sizeof(AccRec) == sizeof(l2r_accepted_read), "accepted record layout");
 static_assert(sizeof(TxHdr) == 48, "TxHdr must be three int4");
 static_assert(sizeof(SiteEnt) == 32 && sizeof(TileDesc) == 48, "dictionary entry / tile descriptor layout");
+
+#include "l2r_xchg.hip.h"

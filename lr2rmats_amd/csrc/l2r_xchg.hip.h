@@ -1,0 +1,134 @@
+// l2r_xchg.hip.h -- the gathered route's exchange in the engine library: the per-read results of the ranks of one node, left in HBM by
+// their engines, travel over RCCL (xGMI) to rank 0, which hands them to the order-dependent host tail as ONE read-order result set.
+// (The reference merges in read order -- src/update_gtf.c:946-960 -- and with -s and a junction table its split pieces are compared
+// across chromosomes, Q2: that input cannot be cut into independent shards, so its shards' results are gathered instead.)
+// One process per GPU; the caller forks / launches the ranks and carries the 128-byte id from rank 0 to the others
+// (host/cmds.c: through memory shared before the fork; lr2rmats_amd/dist.py does the same job through torch.distributed).
+// Included at the end of l2r_engine.hip (it needs l2r_ctx).
+#pragma once
+#include <rccl/rccl.h>
+
+struct l2r_xchg {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    l2r_ctx *ctx = nullptr;
+};
+
+#define NCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess) return fail(-3, "[%s] %s: %s", __func__, #expr, ncclGetErrorString(r_));  \
+    } while (0)
+
+extern "C" {
+
+int l2r_xchg_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
+
+int l2r_xchg_unique_id(void *id_out)
+{
+    if (!id_out) return fail(-1, "[l2r_xchg_unique_id] null argument");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return 0;
+}
+
+l2r_xchg *l2r_xchg_create(l2r_ctx *c, int rank, int world, const void *id_in)
+{
+    if (!c || !id_in || world < 1 || rank < 0 || rank >= world) { fail(-1, "[l2r_xchg_create] bad argument"); return nullptr; }
+    if (hipSetDevice(c->device) != hipSuccess) { fail(-2, "[l2r_xchg_create] hipSetDevice failed"); return nullptr; }
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof id);
+    l2r_xchg *x = new l2r_xchg();
+    x->rank = rank; x->world = world; x->ctx = c;
+    const ncclResult_t r = ncclCommInitRank(&x->comm, world, id, rank);
+    if (r != ncclSuccess) { fail(-3, "[l2r_xchg_create] ncclCommInitRank (rank %d of %d): %s", rank, world, ncclGetErrorString(r)); delete x; return nullptr; }
+    return x;
+}
+
+void l2r_xchg_destroy(l2r_xchg *x)
+{
+    if (!x) return;
+    if (x->comm) (void)ncclCommDestroy(x->comm);
+    delete x;
+}
+
+/* Every rank calls this behind its l2r_run + l2r_sync.  The ranks' {reads, exons} are all-gathered; then every array of the per-read
+ * results goes from the engines' HBM to rank 0's (ncclSend / ncclRecv inside one group: a gatherv, each rank's part at the place its
+ * shard has in read order), and rank 0 copies them to the host: res (rank 0 only; capacities as for l2r_download) receives the
+ * results of ALL ranks as one read-order set -- ex_off[0 .. total reads] with global exon offsets.  counts_out: world x 2 (any rank). */
+int l2r_xchg_gather_results(l2r_xchg *x, l2r_result *res, int64_t *counts_out)
+{
+    if (!x || !x->ctx) return fail(-1, "[l2r_xchg_gather_results] null argument");
+    l2r_ctx *c = x->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = fetch_totals(c);
+    if (rc) return rc;
+    if (!(c->want & L2R_WANT_RESULTS)) return fail(-1, "[l2r_xchg_gather_results] the run did not produce the per-read results (l2r_set_outputs)");
+    const int W = x->world;
+    hipStream_t s = c->stream;
+    // ---- sizes
+    DevBuf<long long> d_cnt;
+    if (d_cnt.ensure((size_t)2 * (W + 1))) return -2;
+    const long long mine[2] = {(long long)c->n_reads, (long long)c->h_totals[0]};
+    HIP_TRY(hipMemcpyAsync(d_cnt.p + 2 * W, mine, sizeof mine, hipMemcpyHostToDevice, s));
+    NCCL_TRY(ncclAllGather(d_cnt.p + 2 * W, d_cnt.p, 2, ncclInt64, x->comm, s));
+    std::vector<long long> cnt((size_t)2 * W);
+    HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt.p, cnt.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    d_cnt.release();
+    std::vector<long long> r_at((size_t)W + 1, 0), x_at((size_t)W + 1, 0);
+    for (int k = 0; k < W; ++k) { r_at[k + 1] = r_at[k] + cnt[2 * k]; x_at[k + 1] = x_at[k] + cnt[2 * k + 1]; }
+    if (counts_out) for (int k = 0; k < 2 * W; ++k) counts_out[k] = cnt[k];
+    const long long R = r_at[W], X = x_at[W];
+    // ---- the arrays: {device pointer of this rank, bytes per element, per-read (0) or per-exon (1)}
+    struct Part { const void *src; size_t width; int per_exon; };
+    const Part parts[6] = {{c->ex_off.p, 4, 0}, {c->info.p, 4, 0}, {c->ref_tx.p, 4, 0}, {c->ex_start.p, 4, 1}, {c->ex_end.p, 4, 1}, {c->ex_flag.p, 1, 1}};
+    DevBuf<uint8_t> g[6];
+    if (x->rank == 0) {
+        if (!res) return fail(-1, "[l2r_xchg_gather_results] rank 0 needs a result to fill");
+        if (res->n_reads < R || res->ex_cap < X) return fail(-4, "[l2r_xchg_gather_results] result buffers too small (%lld reads, %lld exons)", R, X);
+        for (int a = 0; a < 6; ++a) if (g[a].ensure((size_t)(parts[a].per_exon ? X : R) * parts[a].width + 16)) return -2;
+    }
+    NCCL_TRY(ncclGroupStart());
+    for (int a = 0; a < 6; ++a) {
+        const std::vector<long long> &at = parts[a].per_exon ? x_at : r_at;
+        if (x->rank == 0) {
+            for (int k = 1; k < W; ++k) {
+                const size_t n = (size_t)(at[k + 1] - at[k]) * parts[a].width;
+                if (n) NCCL_TRY(ncclRecv(g[a].p + (size_t)at[k] * parts[a].width, n, ncclUint8, k, x->comm, s));
+            }
+        } else {
+            const size_t n = (size_t)(at[x->rank + 1] - at[x->rank]) * parts[a].width;
+            if (n) NCCL_TRY(ncclSend(parts[a].src, n, ncclUint8, 0, x->comm, s));
+        }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    if (x->rank == 0) {
+        // (rank 0's own part: the head of every array)
+        for (int a = 0; a < 6; ++a) {
+            const size_t n = (size_t)((parts[a].per_exon ? x_at[1] : r_at[1])) * parts[a].width;
+            if (n) HIP_TRY(hipMemcpyAsync(g[a].p, parts[a].src, n, hipMemcpyDeviceToDevice, s));
+        }
+        std::vector<uint32_t> off((size_t)R + 1);
+        HIP_TRY(hipMemcpyAsync(off.data(), g[0].p, (size_t)R * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(res->info, g[1].p, (size_t)R * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(res->ref_tx, g[2].p, (size_t)R * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(res->ex_start, g[3].p, (size_t)X * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(res->ex_end, g[4].p, (size_t)X * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(res->ex_flag, g[5].p, (size_t)X, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        // shard-local exclusive offsets -> global ones
+        for (int k = 0; k < W; ++k)
+            for (long long i = r_at[k]; i < r_at[k + 1]; ++i) res->ex_off[i] = (int64_t)off[(size_t)i] + x_at[k];
+        res->ex_off[R] = X;
+        res->n_reads = R; res->n_exons = X;
+        // what the totals say against what the reads say (l2r_download checks the same)
+        for (long long i = 0; i < R; ++i)
+            if (res->ex_off[i] + (int64_t)(res->info[i] >> 8) != res->ex_off[i + 1]) return fail(-5, "[l2r_xchg_gather_results] exon counts do not add up at read %lld", i);
+    } else HIP_TRY(hipStreamSynchronize(s));
+    for (int a = 0; a < 6; ++a) g[a].release();
+    return 0;
+}
+
+}  // extern "C"

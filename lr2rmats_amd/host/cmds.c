@@ -827,12 +827,52 @@ int h_job_finish_accepted(h_job *j, const l2r_result *res, const int64_t *read_i
  * chromosome run on one GPU; `python -m lr2rmats_amd.dist` has the RCCL all-gatherv for them.
  * L2R_GPU_MAP="0,0,0": device of every child (tests put several children on one GPU). */
 #include <sys/wait.h>
+/* 1: the partitioned route (every child merges and writes its own chromosome-aligned shard); 2: the gathered route (-s with a
+ * junction table: split pieces are compared across chromosomes, Q2 -- the children classify, their results are gathered on child 0,
+ * which runs the tail once); 0: one stream of records is needed (records not coordinate sorted, -m g): one GPU */
 static int multi_gpu_ok(const h_job *j)
 {
-    if (j->mode != 0 || (j->o.prm.split_trans && j->sj.n > 0)) return 0;
+    if (j->mode != 0) return 0;
     for (int64_t i = 1; i < j->reads.n; ++i)
         if (j->reads.tid[i] < j->reads.tid[i - 1] || (j->reads.tid[i] == j->reads.tid[i - 1] && j->reads.pos[i] < j->reads.pos[i - 1])) return 0;
+    const char *force = getenv("L2R_MULTI_ROUTE");          /* diagnostics / tests: "gathered" */
+    if ((j->o.prm.split_trans && j->sj.n > 0) || (force && !strcmp(force, "gathered"))) return 2;
     return 1;
+}
+
+/* ---- the gathered route's exchange (one node): the children's per-read results -> child 0.
+ * rccl: from the engines' HBM over RCCL / xGMI (l2r_xchg_*: ncclSend / ncclRecv inside one group), one GPU per child;
+ * shm:  every child downloads into memory shared since before the fork -- the same interface where RCCL cannot run (several
+ *       children on one GPU: the tests' L2R_GPU_MAP="0,0,0").
+ * What the children share (mapped before the fork; the parent never touches HIP): */
+#include <sys/mman.h>
+#include <signal.h>
+typedef struct {
+    pthread_barrier_t bar;
+    volatile int id_ready;
+    char id[256];
+    int64_t counts[256][2];                                  /* {reads, exons} per child */
+    /* shm transport: the result arrays of the whole input (upper bounds; pages are touched by whoever writes them) */
+    int64_t *ex_off; uint32_t *info; int32_t *ref_tx, *ex_start, *ex_end; uint8_t *ex_flag;
+} gather_shared;
+
+static void *shared_pages(size_t bytes)
+{
+    void *p = mmap(NULL, bytes ? bytes : 1, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) h_fatal("update_gtf", "mmap of %zu shared bytes failed", bytes);
+    return p;
+}
+
+/* One child's shard classified, its results left in HBM: the engine is returned alive */
+static l2r_ctx *classify_keep(const char *who, const l2r_params *prm, const l2r_annotation *a, const l2r_junctions *s, const l2r_reads *r)
+{
+    int anno_set = 0;
+    l2r_ctx *ctx = engine_take(who, &anno_set);
+    if (l2r_set_params(ctx, prm) || l2r_set_outputs(ctx, L2R_WANT_RESULTS) || (!anno_set && l2r_set_annotation(ctx, a)) ||
+        l2r_set_junctions(ctx, s->n ? s : NULL)) engine_fail(who);
+    if (shard_end(r, 0) != r->n_reads) h_fatal(who, "a child's shard is too large for one upload (%lld reads): use more GPUs", (long long)r->n_reads);
+    if (l2r_upload_reads(ctx, r) || l2r_run(ctx) || l2r_sync(ctx)) engine_fail(who);
+    return ctx;
 }
 
 static void meta_write(const char *path, const int64_t *cnt, const h_part_genes *g)
@@ -865,9 +905,10 @@ static void meta_read(const char *path, int64_t *cnt, h_part_genes *g)
     fclose(f);
 }
 
-static int update_gtf_multi(h_job *j, int n_gpus)
+static int update_gtf_multi(h_job *j, int n_gpus, int gathered)
 {
     const int64_t N = j->reads.n;
+    if (n_gpus > 256) h_fatal("update_gtf", "L2R_GPUS=%d: at most 256", n_gpus);
     /* chromosome-aligned cuts by bytes per read (4 per CIGAR op + 64): the nearest chromosome boundary to every ideal cut */
     int64_t *cut = (int64_t *)h_malloc((size_t)(n_gpus + 1) * sizeof(int64_t));
     {
@@ -878,8 +919,9 @@ static int update_gtf_multi(h_job *j, int n_gpus)
         for (int64_t i = 0; i < N && k < n_gpus; ++i) {
             while (k < n_gpus && run >= total * (double)k / (double)n_gpus) {
                 int64_t lo = i, hi = i;
-                while (lo > cut[k - 1] && j->reads.tid[lo] == j->reads.tid[lo - 1]) --lo;
-                while (hi < N && hi > 0 && j->reads.tid[hi] == j->reads.tid[hi - 1]) ++hi;
+                /* (the gathered route cuts anywhere: its tail runs once, over everything) */
+                while (!gathered && lo > cut[k - 1] && j->reads.tid[lo] == j->reads.tid[lo - 1]) --lo;
+                while (!gathered && hi < N && hi > 0 && j->reads.tid[hi] == j->reads.tid[hi - 1]) ++hi;
                 int64_t c = (i - lo <= hi - i) ? lo : hi;
                 if (c < cut[k - 1]) c = cut[k - 1];
                 cut[k++] = c;
@@ -890,7 +932,7 @@ static int update_gtf_multi(h_job *j, int n_gpus)
     }
     /* the part files sit next to the outputs; an updated GTF that goes to stdout is collected in a temporary file */
     char tmp_base[1024] = "";
-    if (!j->out_path[0]) {
+    if (!j->out_path[0] && !gathered) {
         const char *td = getenv("TMPDIR");
         snprintf(tmp_base, sizeof tmp_base, "%s/l2r_gtf_XXXXXX", td && td[0] ? td : "/tmp");
         const int fd = mkstemp(tmp_base);
@@ -920,6 +962,29 @@ static int update_gtf_multi(h_job *j, int n_gpus)
                 h_fatal("update_gtf", "L2R_GPUS=%d%s%s: child %d would run on device %d, this node has %d", n_gpus, map ? " with L2R_GPU_MAP=" : "", map ? map : "", k, dev_of[k], n_dev);
             }
     }
+    /* ---- the gathered route: the exchange's shared block, and which transport */
+    gather_shared *sh = NULL;
+    int use_rccl = 0;
+    if (gathered) {
+        sh = (gather_shared *)shared_pages(sizeof *sh);
+        memset(sh, 0, sizeof *sh);
+        pthread_barrierattr_t ba; pthread_barrierattr_init(&ba); pthread_barrierattr_setpshared(&ba, PTHREAD_PROCESS_SHARED);
+        pthread_barrier_init(&sh->bar, &ba, (unsigned)n_gpus);
+        use_rccl = 1;
+        for (int k = 0; k < n_gpus; ++k) for (int q = 0; q < k; ++q) if (dev_of[q] == dev_of[k]) use_rccl = 0;      /* RCCL wants a GPU per rank */
+        const char *xe = getenv("L2R_XCHG");
+        if (xe && !strcmp(xe, "shm")) use_rccl = 0;
+        if (xe && !strcmp(xe, "rccl")) use_rccl = 1;
+        if (!use_rccl) {
+            const size_t xb = (size_t)(j->reads.cig_off[N] + N) + 1;         /* n_exon(read) <= ops(read) + 1 */
+            sh->ex_off = (int64_t *)shared_pages((size_t)(N + n_gpus + 1) * 8); sh->info = (uint32_t *)shared_pages((size_t)(N + 1) * 4);
+            sh->ref_tx = (int32_t *)shared_pages((size_t)(N + 1) * 4);
+            sh->ex_start = (int32_t *)shared_pages(xb * 4); sh->ex_end = (int32_t *)shared_pages(xb * 4); sh->ex_flag = (uint8_t *)shared_pages(xb);
+        }
+        fprintf(stderr, "[update_gtf] L2R_GPUS=%d: gathered route (-s with a junction table): %d children classify, child 0 merges and writes; exchange: %s\n",
+                n_gpus, n_gpus, use_rccl ? "RCCL (ncclSend / ncclRecv to rank 0)" : "shared memory");
+    }
+    if (!gathered)
     {   /* shards are whole chromosomes: say so when that leaves children without work or far out of balance */
         int64_t mx = 0; int empty = 0;
         for (int k = 0; k < n_gpus; ++k) { const int64_t n = cut[k + 1] - cut[k]; if (n == 0) ++empty; if (n > mx) mx = n; }
@@ -935,6 +1000,70 @@ static int update_gtf_multi(h_job *j, int n_gpus)
             /* ---- a child: its shard on its GPU (the first HIP call of this process is in here) */
             g_device = dev;
             const int64_t lo = cut[k], hi = cut[k + 1];
+            if (gathered) {
+                l2r_params prm; l2r_annotation a; l2r_junctions s; l2r_reads r;
+                h_job_views(j, &prm, &a, &s, &r);
+                l2r_reads sub = r;
+                sub.n_reads = hi - lo; sub.n_cigar = r.cig_off[hi] - r.cig_off[lo];
+                sub.tid = r.tid + lo; sub.pos = r.pos + lo; sub.rev = r.rev + lo; sub.cig = r.cig + r.cig_off[lo];
+                int64_t *off = (int64_t *)h_malloc((size_t)(hi - lo + 1) * 8);
+                for (int64_t i = 0; i <= hi - lo; ++i) off[i] = r.cig_off[lo + i] - r.cig_off[lo];
+                sub.cig_off = off; sub.first_read_index = lo;
+                l2r_ctx *ctx = classify_keep("update_gtf", &prm, &a, &s, &sub);
+                int rc_c = 0;
+                h_result out; memset(&out, 0, sizeof out);
+                if (use_rccl) {
+                    /* rank 0 makes the id BEHIND the fork and hands it on through the shared block */
+                    if (k == 0) {
+                        if (l2r_xchg_id_bytes() > (int)sizeof sh->id || l2r_xchg_unique_id(sh->id)) engine_fail("update_gtf");
+                        __sync_synchronize(); sh->id_ready = 1;
+                    }
+                    pthread_barrier_wait(&sh->bar);
+                    if (!sh->id_ready) h_fatal("update_gtf", "child 0 left no RCCL id");
+                    l2r_xchg *x = l2r_xchg_create(ctx, k, n_gpus, sh->id);
+                    if (!x) engine_fail("update_gtf");
+                    l2r_result res; memset(&res, 0, sizeof res);
+                    if (k == 0) {
+                        const int64_t xb = j->reads.cig_off[N] + N;
+                        result_reserve(&out, N, xb);
+                        res.n_reads = N; res.ex_cap = xb; res.ex_off = out.ex_off; res.ex_start = out.ex_start; res.ex_end = out.ex_end;
+                        res.ex_flag = out.ex_flag; res.info = out.info; res.ref_tx = out.ref_tx;
+                    }
+                    if (l2r_xchg_gather_results(x, k == 0 ? &res : NULL, NULL)) engine_fail("update_gtf");
+                    l2r_xchg_destroy(x);
+                    if (k == 0) { out.n = res.n_reads; out.n_ex = res.n_exons; }
+                } else {
+                    int64_t nr = 0, nx = 0;
+                    if (l2r_result_sizes(ctx, &nr, &nx, NULL, NULL)) engine_fail("update_gtf");
+                    sh->counts[k][0] = nr; sh->counts[k][1] = nx;
+                    pthread_barrier_wait(&sh->bar);
+                    int64_t x_at = 0;
+                    for (int q = 0; q < k; ++q) x_at += sh->counts[q][1];
+                    /* (a shard's offsets have one entry more than it has reads: every child writes lo + k .. hi + k, child 0 closes the gaps) */
+                    l2r_result res = { nr, nx, 0, sh->ex_off + lo + k, sh->ex_start + x_at, sh->ex_end + x_at, sh->ex_flag + x_at, sh->info + lo, sh->ref_tx + lo };
+                    if (l2r_download(ctx, &res)) engine_fail("update_gtf");
+                    pthread_barrier_wait(&sh->bar);
+                    if (k == 0) {
+                        int64_t xs = 0;
+                        for (int q = 0; q < n_gpus; ++q) {
+                            for (int64_t i = cut[q]; i < cut[q + 1]; ++i) sh->ex_off[i] = sh->ex_off[i + q] + xs;      /* (q = 0: in place; later ones move down) */
+                            xs += sh->counts[q][1];
+                        }
+                        sh->ex_off[N] = xs;
+                        out.n = N; out.n_ex = xs; out.ex_off = sh->ex_off; out.ex_start = sh->ex_start; out.ex_end = sh->ex_end;
+                        out.ex_flag = sh->ex_flag; out.info = sh->info; out.ref_tx = sh->ref_tx;
+                    }
+                }
+                l2r_destroy(ctx);
+                if (k == 0) {
+                    h_stage_time("children: engines, exchange");
+                    l2r_result res = { out.n, out.n_ex, out.n_ex, out.ex_off, out.ex_start, out.ex_end, out.ex_flag, out.info, out.ref_tx };
+                    rc_c = h_job_finish(j, &res);
+                    h_stage_time("child 0: merge + writers");
+                }
+                fflush(NULL);
+                _exit(rc_c ? 1 : 0);
+            }
             char suffix[32]; snprintf(suffix, sizeof suffix, ".part%03d", k);
             int64_t cnt[H_N_SUMMARY]; memset(cnt, 0, sizeof cnt);
             l2r_params prm; l2r_annotation a; l2r_junctions s; l2r_reads r;
@@ -959,6 +1088,28 @@ static int update_gtf_multi(h_job *j, int n_gpus)
         }
     }
     int failed = 0;
+    if (gathered) {
+        /* (the children wait for each other at barriers: one that dies takes the others with it) */
+        for (int left = n_gpus; left > 0; --left) {
+            int st = 0;
+            const pid_t w = waitpid(-1, &st, 0);
+            if (w < 0) { failed = 1; break; }
+            if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+                failed = 1;
+                for (int k = 0; k < n_gpus; ++k) if (pid[k] != w) kill(pid[k], SIGKILL);
+                for (int k = 0; k < n_gpus; ++k) if (pid[k] != w) (void)waitpid(pid[k], NULL, 0);
+                break;
+            }
+        }
+        if (failed) h_fatal("update_gtf", "a child of the multi-GPU run failed");
+        /* child 0 has written every output through the streams it inherited (flushed before the fork: nothing of them is left here) */
+        FILE **fs[] = {&j->o.exon_bed, &j->o.bam_gtf, &j->o.bam_detail, &j->o.known_gtf, &j->o.novel_gtf, &j->o.unrecog_gtf, &j->o.summary};
+        for (size_t k = 0; k < sizeof fs / sizeof fs[0]; ++k) if (*fs[k]) { fclose(*fs[k]); *fs[k] = NULL; }
+        if (j->o.out_gtf && j->o.out_gtf != stdout) { fclose(j->o.out_gtf); j->o.out_gtf = NULL; }
+        free(pid); free(cut); free(dev_of);
+        h_stage_time("children: engines, exchange, child 0's tail");
+        return 0;
+    }
     for (int k = 0; k < n_gpus; ++k) { int st = 0; if (waitpid(pid[k], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) failed = 1; }
     if (failed) {
         /* nothing of a failed run stays behind: part files, their counters, the temporary GTF */
@@ -1025,7 +1176,7 @@ int h_cmd_update_gtf(int argc, char **argv)
     {   /* one process, one GPU: its context is made while the files are read (the multi-GPU mode forks first); h_job_open starts
          * the thread once the command line has been accepted */
         const char *eg = getenv("L2R_GPUS");
-        g_want_early_engine = (eg ? atoi(eg) : 1) <= 1;
+        g_want_early_engine = (eg ? atoi(eg) : 1) <= 1 && !getenv("L2R_MULTI_ROUTE");       /* (the multi-GPU mode forks first: nothing may touch HIP in front of that) */
     }
     h_job *j = h_job_open(argc, argv, &rc);
     g_want_early_engine = 0;
@@ -1033,9 +1184,10 @@ int h_cmd_update_gtf(int argc, char **argv)
     {   /* L2R_GPUS=N: one child per GPU (update_gtf_multi) when the partition argument holds, else this process and one GPU */
         const char *eg = getenv("L2R_GPUS");
         const int n_gpus = eg ? atoi(eg) : 1;
-        if (n_gpus > 1) {
-            if (multi_gpu_ok(j)) { rc = update_gtf_multi(j, n_gpus); h_job_free(j); return rc; }
-            fprintf(stderr, "[update_gtf] L2R_GPUS=%d: this input / option set needs one stream of records (records not coordinate sorted, -m g, or -s with -j): running on one GPU\n", n_gpus);
+        if (n_gpus > 1 || (n_gpus == 1 && getenv("L2R_MULTI_ROUTE"))) {      /* (one child: diagnostics / tests -- RCCL with a world of one) */
+            const int route = multi_gpu_ok(j);
+            if (route) { rc = update_gtf_multi(j, n_gpus, route == 2); h_job_free(j); return rc; }
+            fprintf(stderr, "[update_gtf] L2R_GPUS=%d: this input needs one stream of records (records not coordinate sorted, or -m g): running on one GPU\n", n_gpus);
         }
     }
     l2r_params prm; l2r_annotation a; l2r_junctions s; l2r_reads r;

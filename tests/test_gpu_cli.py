@@ -279,3 +279,47 @@ def test_c_cli_with_several_gpu_children_writes_the_single_gpu_files(tmp_path, f
     r = hostlib.run_cli(_args(["-l", "3"], bad, bam, gtf), env={"L2R_GPUS": 2, "L2R_GPU_MAP": "0,97"})
     assert r.returncode != 0 and b"would run on device 97" in r.stderr
     assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f or f.startswith("l2r_gtf_")]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n_gpus,xchg", [(3, "shm"), (5, "shm"), (1, "rccl")])
+def test_c_cli_gathered_route_over_several_children(oracle, tmp_path, files, n_gpus, xchg):
+    """The pipeline's second command on several GPUs FROM C (Snakefile:170: `update-gtf -s -l 3 -J 1 -j SJ.out.tab ...`): -s with a
+    junction table cannot be cut into independent shards (split pieces are compared across chromosomes, src/update_gtf.c:837-913, Q2),
+    so `L2R_GPUS=N lr2rmats update-gtf` forks one child per device, the children classify shards cut ANYWHERE (not at chromosome
+    boundaries), their per-read results are gathered on child 0 -- over RCCL from the engines' HBM (l2r_xchg_*: ncclSend / ncclRecv to
+    rank 0), or through memory shared since before the fork where RCCL cannot run -- and child 0 runs the order-dependent tail once.
+    Here: 3 and 5 children on GPU 0 with the shared-memory transport, and a world of ONE through real RCCL (id from rank 0,
+    ncclCommInitRank, the counts' all-gather, the gather itself).  Every file equals the one-process run's."""
+    d, anno, reads, sam, bam, gtf = files
+    af = anno.in_file_order()
+    base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3))
+    j, _ = util.junction_table(af, reads, base, 41, cover=0.7)
+    tab = str(tmp_path / "SJ.out.tab")
+    j.write(tab)
+    extra = ["-s", "-l", "3", "-J", "1", "-j", tab]
+    one, many = _paths(tmp_path, "one"), _paths(tmp_path, "many")
+    r = hostlib.run_cli(_args(extra, one, bam, gtf))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    env = {"L2R_GPUS": n_gpus, "L2R_GPU_MAP": ",".join(["0"] * n_gpus), "L2R_THREADS": 3, "L2R_XCHG": xchg}
+    if n_gpus == 1:
+        env["L2R_MULTI_ROUTE"] = "gathered"
+    r = hostlib.run_cli(_args(extra, many, bam, gtf), env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert b"gathered route" in r.stderr and (b"RCCL" if xchg == "rccl" else b"shared memory") in r.stderr
+    for k in OUTS:
+        assert filecmp.cmp(one[k], many[k], shallow=False), (n_gpus, xchg, k)
+    assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f]
+    if n_gpus == 3:
+        # the same route when the updated GTF goes to stdout, and forced on an option set that could be partitioned
+        so = _paths(tmp_path, "so")
+        args = _args(["-l", "3"], so, bam, gtf)
+        i = args.index("-o")
+        del args[i:i + 2]
+        r = hostlib.run_cli(args, stdout_path=so["gtf"], env=dict(env, L2R_MULTI_ROUTE="gathered"))
+        assert r.returncode == 0 and b"gathered route" in r.stderr, r.stderr.decode()[-2000:]
+        ref = _paths(tmp_path, "ref")
+        r = hostlib.run_cli(_args(["-l", "3"], ref, bam, gtf))
+        assert r.returncode == 0
+        for k in OUTS:
+            assert filecmp.cmp(ref[k], so[k], shallow=False), ("stdout", k)
