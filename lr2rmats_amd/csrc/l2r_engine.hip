@@ -73,6 +73,7 @@ struct l2r_ctx {
     bool many_exon_reads = false;           // the upload's sample: more than 0.5 % of the reads have more exons than a slab has rows
     bool slab_ok = false;                   // the current upload can run the slab pipeline: coordinate-sorted records, short CIGARs, its slab layout fits
     bool slab = false;                      // ... and the last launch did (the parameters have a say: launch_all)
+    bool lists_heavy = false;                           // ... or most tiles went to them (an isoform-rich annotation): k_tile would only walk for them, which k_walk_slab does faster -- later runs take the slab pipeline
     bool redo_empty = false;                            // ... and nothing to the generic kernel either: every read had its junction check in k_tile, k_validate_sj has nothing to do
     bool lists_known = false, lists_empty = false;      // one-kernel tile path: a completed run of these inputs and parameters left nothing to k_probe_slab / _wide / _chunked (l2r_sync looks): their launches are skipped until something changes
     bool tile = false;                      // ... with the one-kernel tile path (l2r_tile.hip.h: short CIGARs, -e >= 1)
@@ -162,7 +163,7 @@ struct l2r_ctx {
 
 static void drop_graph(l2r_ctx *c)
 {
-    c->lists_known = false; c->lists_empty = false; c->redo_empty = false;     // (called wherever inputs, parameters or outputs change)
+    c->lists_known = false; c->lists_empty = false; c->redo_empty = false; c->lists_heavy = false;     // (called wherever inputs, parameters or outputs change)
     if (c->graph) { (void)hipGraphExecDestroy(c->graph); c->graph = nullptr; }
     c->graph_valid = false;
 }
@@ -1062,6 +1063,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         int64_t inexact = 0;
         for (const TileStat &st : c->h_tile_stat) inexact += tile_exact(st, p.min_exon, p.min_intron, p.max_delet) ? 0 : 1;
         if (inexact * 50 > c->n_tiles + 800 && !getenv("L2R_TILE_ANYWAY")) c->tile = false;
+        // (measured: cfg3_iso40 -- every tile wide or chunked -- 1.34 ms on this path against 1.26 on the slab pipeline)
+        if (c->lists_known && c->lists_heavy && !getenv("L2R_TILE_ANYWAY")) c->tile = false;
     }
     if (c->slab) {
         // ---- two light kernels at full occupancy: the walk (exons into the tiles' slabs, read-order places, descriptors), a scan of
@@ -1370,6 +1373,7 @@ int l2r_sync(l2r_ctx *c)
         HIP_TRY(hipMemcpyAsync(&redo_n, c->totals.p + 3, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->lists_empty = lc[4] == 0u && lc[6] == 0u && lc[7] == 0u;
+        c->lists_heavy = 2ull * ((unsigned long long)lc[4] + lc[6] + lc[7]) > (unsigned long long)c->n_tiles;
         c->redo_empty = redo_n == 0u;
         c->lists_known = true;
     }

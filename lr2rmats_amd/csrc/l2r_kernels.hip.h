@@ -1216,13 +1216,16 @@ __device__ __forceinline__ void probe_rest(const v4i_t *ent, uint32_t lo, uint32
 
 // -d > 0 (src/update_gtf.c:717-779 with dis > 0): a read site matches EVERY annotation site within `dis` of it, and identical_site_n
 // counts the matching (annotation site, read site) PAIRS.  One probe of a staged slice with a tolerance: entries [lo, hi) are the
-// buckets of k1 - dis .. k1 + dis (at most two: dis < 512), sorted by (key 1, key 2).
+// buckets of k1 - dis .. k1 + dis (one or two of them: 2 dis + 1 <= 129 bases with dis <= DIS_MASK_MAX; the range arithmetic of
+// near_range would take more -- lo = the first bucket's first entry, hi = the last bucket's end), sorted by (key 1, key 2).  The staged
+// directories are bytes: a slice holds at most SLAB_KEY_CAP / KEY_CAP (< 256) entries whatever the tolerance adds to its span.
 //   sm |= site members of every entry whose first key lies within dis of k1 AND inside the read's span [rs, re] -- an annotation site
 //         counts only inside the overlap span (:732,742); inside the transcript's own span it always is (TX_COMPACT);
 //   pm |= pair members of every entry with both keys within dis (the exon / junction flags know no overlap span, :753-768);
 //   amb |= members that have TWO different sites within dis of this one read site: for them the pair count is not the number of
 //         matched read sites, the masks cannot say whether the read is known -- such a read goes to the generic kernel (it takes a
 //         transcript with two donors or two acceptors less than 2 dis + 1 bases apart).
+static_assert(2 * DIS_MASK_MAX + 1 <= (1 << SITE_SHIFT) && KEY_CAP < 256, "a tolerance window spans two buckets at most; byte directories");
 __device__ __forceinline__ void probe_near(const v4i_t *ent, uint32_t lo, uint32_t hi, int32_t k1, int32_t k2, int dis, int rs, int re,
                                            uint32_t &pm, uint32_t &sm, uint32_t &amb)
 {

@@ -342,7 +342,7 @@ def test_full_length_levels_known_answers(oracle):
     check_full_length_outcomes(res, expect)
 
 
-@pytest.mark.parametrize("dis", [1, 2, 7, 20])
+@pytest.mark.parametrize("dis", [1, 2, 7, 20, 64])          # (64 = DIS_MASK_MAX: tolerance windows of 129 bases straddle the 512-bp buckets everywhere)
 @pytest.mark.parametrize("level", [1, 3, 5])
 def test_splice_distance_on_the_mask_path(oracle, dis, level, pipeline):
     """-d > 0 (src/update_gtf.c:717-779 with dis > 0) on the mask kernels: every probe looks at the annotation sites within the
