@@ -31,8 +31,19 @@ for it in range(rounds):
     anno = synth.make_annotation(anno_exons, seed, mean_tx_exons=n_ex + 1, tx_per_gene=tpg)
     af = anno.in_file_order()
     reads = synth.make_reads(anno, n_reads, n_ex, seed + 7, ont=ont, micro_exons=3 if ont else 0, xs_conflict_frac=0.02 if ont else 0.0)
+    # every third case with a junction table (-j): made from the oracle's first pass over the same reads like the generator's (a share of
+    # the annotated junctions + of the reads' own), with -J 1 .. 3, -M and -s drawn -- the junction check inside k_tile (rows staged in LDS or
+    # looked up in HBM), k_validate_sj behind the other kernels
+    sj = None
+    if it % 3 == 1 and not ont:
+        base = po.classify_soa(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, af.tx_tid, af.tx_start, af.tx_end, af.tx_rev,
+                               af.tx_ex_off, af.ex_start, af.ex_end, params=po.default_params(**prm))
+        j = synth.make_junctions(af, base.ex_off, base.ex_start, base.ex_end, reads.tid, seed + 11, cover=float(rng.choice([0.3, 0.7, 0.95])))
+        sj = (j.tid, j.don, j.acc, j.uniq, j.multi)
+        prm.update(split_trans=int(rng.integers(0, 2)), min_sj_cnt=int(rng.integers(1, 4)), use_multi=int(rng.integers(0, 2)))
     e = capi.Engine(0)
     e.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
+    e.set_junctions(sj)
     got = e.classify(reads, capi.default_params(**prm))
     acc = e.download_accepted()
     idx = np.nonzero((got.info & 128) != 0)[0]
@@ -52,7 +63,7 @@ for it in range(rounds):
         pass
     e.close()
     want = po.classify_soa(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, af.tx_tid, af.tx_start, af.tx_end, af.tx_rev,
-                           af.tx_ex_off, af.ex_start, af.ex_end, params=po.default_params(**prm))
+                           af.tx_ex_off, af.ex_start, af.ex_end, sj=sj, params=po.default_params(**prm))
     diffs = {} if acc_ok else {"accepted_list": 1}
     for name in ("ex_off", "ex_start", "ex_end", "ex_flag", "ref_tx"):
         a, b = getattr(got, name), getattr(want, name)
@@ -61,7 +72,7 @@ for it in range(rounds):
     d = np.nonzero((got.info & 0x7f) != (want.info & 0x7f))[0]
     if len(d):
         diffs["info"] = (len(d), d[:5].tolist())
-    tag = "tpg %3d n_ex %2d anno %6d reads %6d ont %d seed %d %s (redo, keys in parts, tiles, wide list: %s)" % (tpg, n_ex, anno_exons, n_reads, ont, seed, prm, cnt)
+    tag = "tpg %3d n_ex %2d anno %6d reads %6d ont %d sj %d seed %d %s (redo, keys in parts, tiles, wide list: %s)" % (tpg, n_ex, anno_exons, n_reads, ont, 0 if sj is None else len(sj[0]), seed, prm, cnt)
     print(("DIFF " if diffs else "ok   ") + tag, diffs if diffs else "", flush=True)
     bad += 1 if diffs else 0
     if diffs:
