@@ -1231,16 +1231,22 @@ __device__ __forceinline__ void probe_near(const v4i_t *ent, uint32_t lo, uint32
 {
     pm = 0u; sm = 0u;
     int last = INT32_MIN;
-    for (uint32_t r = lo; r < hi; ++r) {
-        const v4i_t q = lds_entry(ent, r);
-        if (q.x > k1 + dis) break;
-        if (q.x < k1 - dis) continue;
-        if (q.x >= rs && q.x <= re) {
-            if (q.x != last) { amb |= sm & (uint32_t)q.w; last = q.x; }
-            sm |= (uint32_t)q.w;
-        }
-        if (__builtin_abs(q.y - k2) <= dis) pm |= (uint32_t)q.z;
-    }
+    const uint32_t span = 2u * (uint32_t)dis, b1 = (uint32_t)k1 - (uint32_t)dis, b2 = (uint32_t)k2 - (uint32_t)dis;
+    // (no branch per entry: selects; an entry outside the tolerance adds nothing, sorted or not)
+    auto one = [&](const v4i_t q, bool on) {
+        const bool in = on && (uint32_t)q.x - b1 <= span;
+        const bool sp = in && q.x >= rs && q.x <= re;
+        const uint32_t w = sp ? (uint32_t)q.w : 0u;
+        amb |= q.x != last ? (sm & w) : 0u;
+        last = sp ? q.x : last;
+        sm |= w;
+        pm |= (in && (uint32_t)q.y - b2 <= span) ? (uint32_t)q.z : 0u;
+    };
+    // the first NEAR_FIRST entries without a loop (most tolerance windows hold no more), the others only where some lane has them
+    const v4i_t q0 = lds_entry(ent, lo), q1 = lds_entry(ent, lo + 1u);
+    one(q0, lo < hi); one(q1, lo + 1u < hi);
+    if (__any(hi > lo + 2u))
+        for (uint32_t r = lo + 2u; r < hi; ++r) one(lds_entry(ent, r), true);
 }
 // the staged entries of the buckets of x - dis .. x + dis: [lo, hi)  (none: the empty bucket behind the staged ones)
 __device__ __forceinline__ void near_range(const uint8_t *dir, int b_off, uint32_t none, bool live, int x, int dis, uint32_t &lo, uint32_t &hi)

@@ -17,7 +17,7 @@ for v in vals:
     os.environ["L2R_ABLATE"] = str(v)
     e = capi.Engine(0)
     e.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
-    e.set_params(capi.default_params(full_level=int(os.environ.get("L2R_LEVEL", "3"))))
+    e.set_params(capi.default_params(full_level=int(os.environ.get("L2R_LEVEL", "3")), ss_dis=int(os.environ.get("L2R_DIS", "0"))))
     e.set_outputs(int(os.environ.get("L2R_WANT", "1")))
     e.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)
     e.run(); e.sync()
