@@ -194,6 +194,13 @@ __device__ __forceinline__ uint32_t lb_share(SlabArgsK sa, uint32_t t, int wv, i
 #define L2R_TILE_AHEAD 2
 #endif
 constexpr int TILE_AHEAD = L2R_TILE_AHEAD;
+#ifndef L2R_TILE_NS
+#define L2R_TILE_NS 1
+#endif
+#ifndef L2R_TILE_NE
+#define L2R_TILE_NE 2
+#endif
+constexpr int TILE_NS = L2R_TILE_NS, TILE_NE = L2R_TILE_NE;      // entries of a START / END bucket every probe round looks at without a loop
 template <bool DIS>
 __device__ __forceinline__ SiteMasks map_exons_lds(const TileLds &L, const TileDesc &d, bool mapping, uint32_t n, uint32_t vpre, const SlabStage &st, int dis = 0, int rs = 0, int re = 0)
 {
@@ -226,13 +233,24 @@ __device__ __forceinline__ SiteMasks map_exons_lds(const TileLds &L, const TileD
             probe_near(L.ent0, ls, hs, s, e, dis, rs, re, xm, am, m.amb);
             probe_near(L.ent1, le, he, e, s2, dis, rs, re, jm, dm, m.amb);
         } else {
-            const v4i_t qs0 = lds_entry(L.ent0, ls);
-            const v4i_t qe0 = lds_entry(L.ent1, le), qe1 = lds_entry(L.ent1, le + 1u);
+            v4i_t qs[TILE_NS], qe[TILE_NE];
+#pragma unroll
+            for (int i = 0; i < TILE_NS; ++i) qs[i] = lds_entry(L.ent0, ls + (uint32_t)i);
+#pragma unroll
+            for (int i = 0; i < TILE_NE; ++i) qe[i] = lds_entry(L.ent1, le + (uint32_t)i);
             buckets(k + 1, s2, e2, ls_n, hs_n, le_n, he_n);
-            {   const bool m0 = ls < hs && qs0.x == s;
-                am = m0 ? (uint32_t)qs0.w : 0u; xm = (m0 && qs0.y == e) ? (uint32_t)qs0.z : 0u; }
-            probe2(qe0, qe1, le, he, e, s2, jm, dm);
-            if (__any(hs > ls + 1u || he > le + 2u)) { probe_rest(L.ent0, ls + 1u, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + 2u, he, e, s2, jm, dm, 0u); }
+            am = 0u; xm = 0u; jm = 0u; dm = 0u;
+#pragma unroll
+            for (int i = 0; i < TILE_NS; ++i) {
+                const bool mi = ls + (uint32_t)i < hs && qs[i].x == s;
+                am = mi ? (uint32_t)qs[i].w : am; xm = (mi && qs[i].y == e) ? (uint32_t)qs[i].z : xm;
+            }
+#pragma unroll
+            for (int i = 0; i < TILE_NE; ++i) {
+                const bool mi = le + (uint32_t)i < he && qe[i].x == e;
+                dm = mi ? (uint32_t)qe[i].w : dm; jm = (mi && qe[i].y == s2) ? (uint32_t)qe[i].z : jm;
+            }
+            if (__any(hs > ls + (uint32_t)TILE_NS || he > le + (uint32_t)TILE_NE)) { probe_rest(L.ent0, ls + (uint32_t)TILE_NS, hs, s, e, xm, am, 0u); probe_rest(L.ent1, le + (uint32_t)TILE_NE, he, e, s2, jm, dm, 0u); }
         }
         if (reload) cur = SlabRow{Ap[min((uint32_t)k + (uint32_t)TILE_AHEAD, nm1)]};      // exon k + TILE_AHEAD into the register of exon k
         const uint32_t amj = junc ? am : 0u;
