@@ -75,6 +75,7 @@ struct l2r_ctx {
     bool slab = false;                      // ... and the last launch did (the parameters have a say: launch_all)
     bool lists_heavy = false;                           // ... or most tiles went to them (an isoform-rich annotation): k_tile would only walk for them, which k_walk_slab does faster -- later runs take the slab pipeline
     bool redo_empty = false;                            // ... and nothing to the generic kernel either: every read had its junction check in k_tile, k_validate_sj has nothing to do
+    uint32_t lb_flip = 0;                               // which of the two lb_sup arrays the next run of the tile path uses (l2r_slab.hip.h SlabArgs::lb_sup)
     bool lists_known = false, lists_empty = false;      // one-kernel tile path: a completed run of these inputs and parameters left nothing to k_probe_slab / _wide / _chunked (l2r_sync looks): their launches are skipped until something changes
     bool tile = false;                      // ... with the one-kernel tile path (l2r_tile.hip.h: short CIGARs, -e >= 1)
     DevBuf<unsigned long long> lb_tile, lb_blk, lb_sup;     // one-kernel tile path: the tiles' exon counts on their way to the later tiles' first slots
@@ -885,9 +886,9 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             sbase[T] = (uint32_t)total;                     // (rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true;
             if (c->tw64.ensure(T + 1) || c->wide_list.ensure(T + 1) || c->chunk_list.ensure(T + 1) || c->list_cnt.ensure(8) || c->tile_flags.ensure(T + 8) ||
-                c->lb_tile.ensure(T + 64) || c->lb_blk.ensure(T / LB_BLK + 64) || c->lb_sup.ensure((T >> LB_SUP_SHIFT) + 64) || c->fb_list.ensure(T + 1) || c->tile_stat.ensure(T + 1) || c->sup_stat.ensure((T >> LB_SUP_SHIFT) + 2) ||
+                c->lb_tile.ensure(T + 64) || c->lb_blk.ensure(T / LB_BLK + 64) || c->lb_sup.ensure(2 * ((T >> LB_SUP_SHIFT) + 64)) || c->fb_list.ensure(T + 1) || c->tile_stat.ensure(T + 1) || c->sup_stat.ensure((T >> LB_SUP_SHIFT) + 2) ||
                 (!c->wide_cigar && c->slot_rec.ensure((T + 1) * TILE_THREADS))) return -2;
-            HIP_TRY(hipMemsetAsync(c->lb_sup.p, 0, ((T >> LB_SUP_SHIFT) + 64) * 8, c->stream));      // (from then on cleared behind every run, by k_classify_generic)      // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB each)
+            HIP_TRY(hipMemsetAsync(c->lb_sup.p, 0, 2 * ((T >> LB_SUP_SHIFT) + 64) * 8, c->stream)); c->lb_flip = 0;      // (two arrays taking turns; from then on each is cleared by the run in front of its own)      // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB each)
             HIP_TRY(hipMemsetAsync(c->list_cnt.p, 0, 32, c->stream));
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) || c->tile_total.ensure(T + 2) || c->tile_xbase.ensure(T + 2) || c->tile_span.ensure(12 * (T + 1)) ||
                 c->s_pre.ensure((size_t)N + 1) || c->s_loc.ensure((size_t)N + 1) ||
@@ -1081,7 +1082,11 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p;
         sa.chunk_on = (c->ablate & 32) ? 0u : 1u;          // (L2R_ABLATE bit 2: no 64-member windows, bit 5: no chunked windows)
         sa.wide_list = c->wide_list.p; sa.chunk_list = c->chunk_list.p; sa.list_cnt = c->list_cnt.p; sa.tile_flags = c->tile_flags.p;
-        sa.lb_tile = c->lb_tile.p; sa.lb_blk = c->lb_blk.p; sa.lb_sup = c->lb_sup.p; sa.lb_err = c->totals.p + 6; sa.fb_list = c->fb_list.p; sa.exon_total = c->totals.p + 0; sa.tile_stat = c->tile_stat.p; sa.sup_stat = c->sup_stat.p;
+        {   const size_t sup_words = (size_t)(c->n_tiles >> LB_SUP_SHIFT) + 64;
+            sa.lb_sup = c->lb_sup.p ? c->lb_sup.p + (c->lb_flip ? sup_words : 0) : nullptr;
+            sa.lb_sup_next = c->lb_sup.p ? c->lb_sup.p + (c->lb_flip ? 0 : sup_words) : nullptr;
+            sa.n_sup = (uint32_t)(c->n_tiles >> LB_SUP_SHIFT) + 1u; }
+        sa.lb_tile = c->lb_tile.p; sa.lb_blk = c->lb_blk.p; sa.lb_err = c->totals.p + 6; sa.fb_list = c->fb_list.p; sa.exon_total = c->totals.p + 0; sa.tile_stat = c->tile_stat.p; sa.sup_stat = c->sup_stat.p;
         sa.sj = SjDir{CursorDir{c->sj_key.p, c->sj_cdir.p, c->sj_cbase.p, c->sj_ntid, (int32_t)c->n_sj}, c->sj_ddir.p, c->sj_dbase.p, c->sj_ntid, c->sj_row.p};
         sa.has_wide_keys = c->n_wide > 0 ? 1u : 0u;
         // (with the accepted list wanted and no junction table to decide later, the tiles leave their accepted chunks themselves)
@@ -1210,18 +1215,21 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     }
     }
     MARK(ST_GENERIC);
-    {
+    // (one-kernel tile path: a completed run of the same inputs and parameters has left nothing on the redo list and nothing to the
+    //  list-driven kernels -- no read is left for the generic kernel, and what it used to clear for the next run is cleared in front)
+    const bool nothing_left = c->tile && c->lists_known && c->lists_empty && c->redo_empty && !getenv("L2R_LAUNCH_ALL");
+    if (c->tile) c->lb_flip ^= 1u;
+    if (!nothing_left) {
         const unsigned gg = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles * 4 : 1, 4096);      // one wave per listed read, grid-stride
         hipLaunchKernelGGL(k_classify_generic, dim3(gg), dim3(TILE_THREADS), 0, s, c->totals.p + 3, c->redo.p, c->r_tid.p, c->r_rev.p,
                            (c->slab ? (const int32_t *)nullptr : j0),
                            c->hdr.p, c->anno_ex.p, p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->info.p, c->ref_tx.p,
-                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles, cd, c->list_cnt.p,
-                           c->lb_sup.p, (uint32_t)(c->lb_sup.p ? (c->n_tiles >> LB_SUP_SHIFT) + 1 : 0));
+                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles, cd, c->list_cnt.p);
     }
     MARK(ST_SJ);
     // (one-kernel tile path: k_tile has checked every read whose verdict it made; with nothing on the redo list and nothing left to the
     //  list-driven kernels -- seen by a completed run of the same inputs and parameters -- no read is left for this launch)
-    const bool sj_all_in_tile = c->tile && c->lists_known && c->lists_empty && c->redo_empty && !getenv("L2R_LAUNCH_ALL");
+    const bool sj_all_in_tile = nothing_left;
     if (c->n_sj > 0 && !sj_all_in_tile) {
         if (!c->sorted) { int rc = prepare_unsorted_sj_cursor(c); if (rc) return rc; }
         hipLaunchKernelGGL(k_validate_sj, dim3(g256), dim3(TILE_THREADS), 0, s, N, c->r_tid.p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p,

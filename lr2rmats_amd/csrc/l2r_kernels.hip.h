@@ -984,16 +984,13 @@ void k_classify_generic(const uint32_t *__restrict__ redo_count, const uint32_t 
                         uint32_t *__restrict__ tile_acc, uint32_t *__restrict__ tile_acc_ex, const uint32_t *__restrict__ tile_first, int n_tiles,
                         CursorDir cd /* used when j0_arr is null: the one-walk pipeline keeps no per-read cursor values */,
                         uint32_t *__restrict__ list_cnt /* slab pipelines: the entry counts of the list-driven probe kernels in front of this launch,
-                                                           cleared here for the next run (its FIRST kernel appends to them); else null */,
-                        unsigned long long *__restrict__ lb_sup, uint32_t n_sup /* one-kernel tile path: the super-block sums of the tiles' exon counts,
-                                                                                    cleared here for the next run (l2r_slab.hip.h SlabArgs::lb_sup) */)
+                                                           cleared here for the next run (its FIRST kernel appends to them); else null */)
 {
     __shared__ int g_S[GEN_WAVES][GEN_CAP];
     __shared__ int g_E[GEN_WAVES][GEN_CAP];
     __shared__ uint32_t g_F[GEN_WAVES][GEN_CAP];
     __shared__ uint32_t g_cnt[GEN_WAVES][2];
     if (list_cnt && blockIdx.x == 0 && threadIdx.x == 0) { list_cnt[6] = list_cnt[0]; list_cnt[7] = list_cnt[1]; list_cnt[0] = 0u; list_cnt[1] = 0u; }
-    if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < n_sup; i += TILE_THREADS) lb_sup[i] = 0ull;
     const uint32_t cnt = *redo_count;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     int *S = g_S[wv], *E = g_E[wv];

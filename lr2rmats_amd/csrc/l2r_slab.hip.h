@@ -114,9 +114,12 @@ struct SlabArgs {
     // one-kernel tile path (l2r_tile.hip.h): the tiles' exon counts on their way to every later tile's first result slot -- lb_tile[t]
     // (one word per tile), lb_blk[t >> 4] and lb_sup[t >> 10] (sums over 16 tiles / 64 blocks), LB_* above.  k_describe_scan<true> writes
     // the words of the tiles and blocks (with the counts it knows from tile_stat: all of them unless a threshold is borderline) and adds
-    // the complete blocks to lb_sup, which k_classify_generic clears behind a run.  lb_err: set by a tile that waited in vain
+    // the complete blocks to lb_sup.  lb_sup is one of TWO arrays that take turns run by run: the words add up during a run, so they
+    // have to start from zero -- this run's k_describe_scan<true> clears the other array (lb_sup_next, n_sup words), which nobody
+    // touches meanwhile, for the next run; no launch behind k_tile is needed for that.  lb_err: set by a tile that waited in vain
     // (diagnostics; never seen).  fb_list: the tiles k_tile left in slab form for k_probe_slab (list_cnt[4] entries).
-    unsigned long long *lb_tile, *lb_blk, *lb_sup;
+    unsigned long long *lb_tile, *lb_blk, *lb_sup, *lb_sup_next;
+    uint32_t n_sup;
     const TileStat *tile_stat;
     // per super-block of 1024 tiles (made with tile_stat): n_ops_n = its exon count if every tile in it is exact (reads + N operations),
     // the other three fields the extremes over its tiles -- tile_exact(sup_stat[s], ...) says "every tile of s is exact"
@@ -659,6 +662,7 @@ void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan, 
         uint32_t *const lc = sa->list_cnt;
         lc[2] = 0u; lc[3] = 0u; lc[4] = 0u; lc[5] = 0u;
     }
+    if (FIRST && blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < sa->n_sup; i += TILE_THREADS) sa->lb_sup_next[i] = 0ull;      // (the next run's super-block words)
     if (t < sa->n_tiles) {
         int4 spv, spw;
         if (FIRST) {

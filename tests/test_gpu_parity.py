@@ -161,6 +161,28 @@ def test_single_exon_fraction_float_compare(engine, oracle):
         _check(engine, oracle, af, reads, oracle.default_params(full_level=5, single_exon_ovlp_frac=f))
 
 
+@pytest.mark.parametrize("n_reads,ablate", [(600000, None), (70000, "256")])
+def test_runs_in_a_row_on_one_upload(engine, oracle, monkeypatch, n_reads, ablate):
+    """From the second run on the launches a completed run has shown to be empty are skipped (k_probe_slab's lists, the generic kernel),
+    and the words the tiles' exon counts add up in take turns run by run: five runs in a row, the same results.  600 k reads: two whole
+    super-blocks of 1024 tiles and a partial one; L2R_ABLATE=256: no tile's exon count is known ahead, every tile adds its own inside the run."""
+    anno, af, reads = util.make_case(21, n_reads=n_reads, n_exons=6, anno_exons=20000)
+    _set_anno(engine, af)
+    op = oracle.default_params(full_level=3)
+    want = util.oracle_run(oracle, af, reads, op)
+    if ablate:
+        monkeypatch.setenv("L2R_ABLATE", ablate)
+    engine.set_junctions(None)
+    engine.set_params(util.to_engine_params(capi, op))
+    engine.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)
+    for _ in range(5):
+        engine.run(); engine.sync()
+        util.assert_same_result(engine.download(), want, 0, 0)
+    if ablate:
+        monkeypatch.delenv("L2R_ABLATE")
+        engine.set_params(util.to_engine_params(capi, op))
+
+
 def _check_accepted_list(engine, got, first):
     """The accepted list of the last launch == the accepted reads of its full result, in read order."""
     acc = engine.download_accepted()
