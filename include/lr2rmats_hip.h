@@ -224,12 +224,16 @@ void        *l2r_stream(l2r_ctx *ctx);                                  /* hipSt
  * order-dependent tail once over the whole read-order set.  Rank 0 makes the id (l2r_xchg_unique_id: l2r_xchg_id_bytes() bytes) and
  * the caller carries it to the other ranks; every rank then creates its end (collective) and, behind l2r_run + l2r_sync, calls
  * l2r_xchg_gather_results (collective): `res` (rank 0 only; capacities as for l2r_download, for the reads / exons of ALL ranks)
- * receives the results of every rank as one set with global exon offsets; counts_out (may be NULL) gets {reads, exons} per rank. */
+ * receives the results of every rank as one set with global exon offsets; counts_out (may be NULL) gets {reads, exons} per rank.
+ * l2r_xchg_gather_accepted (collective; L2R_WANT_ACCEPTED): the accepted-novel records alone -- SURVEY 8(e)'s all-gatherv message -- of
+ * every rank to rank 0 in read order (`acc`, rank 0 only, capacities for all ranks; read indices are the global ones the uploads'
+ * first_read_index gave): all the order-dependent merge needs when no output wants every read; 16 + 9 n bytes per accepted read. */
 typedef struct l2r_xchg l2r_xchg;
 int          l2r_xchg_id_bytes(void);
 int          l2r_xchg_unique_id(void *id_out);
 l2r_xchg    *l2r_xchg_create(l2r_ctx *ctx, int rank, int world, const void *id);
 int          l2r_xchg_gather_results(l2r_xchg *x, l2r_result *res, int64_t *counts_out);
+int          l2r_xchg_gather_accepted(l2r_xchg *x, l2r_accepted *acc, int64_t *counts_out);
 void         l2r_xchg_destroy(l2r_xchg *x);
 
 /* ---- diagnostics (tools/, bench.py and the tests read them; no product path does).

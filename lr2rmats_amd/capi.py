@@ -30,7 +30,7 @@ EXPORTS = [
     "l2r_result_sizes", "l2r_download", "l2r_download_accepted", "l2r_device_view_get", "l2r_stream", "l2r_classify",
     "l2r_stage_kernel", "l2r_set_annotation_cache", "l2r_annotation_cache_state", "l2r_filter_score", "l2r_filter_select",
     "l2r_debug_counters", "l2r_debug_stamps", "l2r_debug_tile_times",
-    "l2r_xchg_id_bytes", "l2r_xchg_unique_id", "l2r_xchg_create", "l2r_xchg_gather_results", "l2r_xchg_destroy",
+    "l2r_xchg_id_bytes", "l2r_xchg_unique_id", "l2r_xchg_create", "l2r_xchg_gather_results", "l2r_xchg_gather_accepted", "l2r_xchg_destroy",
 ]
 
 _i32p, _i64p, _u8p, _u32p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)

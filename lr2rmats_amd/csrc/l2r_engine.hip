@@ -1482,6 +1482,41 @@ int l2r_download(l2r_ctx *c, l2r_result *res)
     return 0;
 }
 
+// The accepted list of one engine as it lies in HBM (per-tile chunks in the order they were handed out, see k_gather_accepted) -> read
+// order, appended to `a` at record at_r / exon at: the chunks are told apart by the first-record slots the tiles left (starts), each is
+// in read order inside, and the exons are laid out record by record, so that ex_off is the running sum.
+static int order_accepted(const AccRec *rec, const uint32_t *off, std::vector<uint32_t> starts, const int32_t *xs, const int32_t *xe, const uint8_t *xf,
+                          int64_t M, int64_t X, l2r_accepted *a, int64_t &at_r, int64_t &at)
+{
+    if (!M) return 0;
+    const int64_t r_end = at_r + M, x_base = at;
+    // (a tile without accepted reads leaves the slot of some other chunk, 0 or M: duplicates and M drop out)
+    starts.push_back(0u);
+    std::sort(starts.begin(), starts.end());
+    starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
+    while (!starts.empty() && (int64_t)starts.back() >= M) starts.pop_back();
+    std::vector<std::pair<uint64_t, std::pair<uint32_t, uint32_t>>> chunks;        // first read index -> [from, to)
+    for (size_t k = 0; k < starts.size(); ++k) {
+        const uint32_t from = starts[k], to = k + 1 < starts.size() ? starts[k + 1] : (uint32_t)M;
+        chunks.push_back({((uint64_t)rec[from].read_hi << 32) | rec[from].read_lo, {from, to}});
+    }
+    std::sort(chunks.begin(), chunks.end());
+    for (const auto &ch : chunks) {
+        for (uint32_t i = ch.second.first; i < ch.second.second; ++i) {
+            const int64_t n = (int64_t)(rec[i].info >> 8), from = off[i];
+            if (from + n > X || at - x_base + n > X || at_r >= r_end) return fail(-5, "[l2r_download_accepted] inconsistent accepted list");
+            memcpy(&a->rec[at_r], &rec[i], sizeof(AccRec));
+            a->ex_off[at_r] = at;
+            memcpy(a->ex_start + at, xs + from, (size_t)n * 4);
+            memcpy(a->ex_end + at, xe + from, (size_t)n * 4);
+            memcpy(a->ex_flag + at, xf + from, (size_t)n);
+            at += n; ++at_r;
+        }
+    }
+    if (at_r != r_end) return fail(-5, "[l2r_download_accepted] inconsistent accepted list (%lld of %lld records)", (long long)(at_r - (r_end - M)), (long long)M);
+    return 0;
+}
+
 int l2r_download_accepted(l2r_ctx *c, l2r_accepted *a)
 {
     if (!c || !a) return fail(-1, "[l2r_download_accepted] null argument");
@@ -1510,32 +1545,8 @@ int l2r_download_accepted(l2r_ctx *c, l2r_accepted *a)
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     int64_t at_r = 0, at = 0;
-    if (M) {
-        // (a tile without accepted reads leaves the slot of some other chunk, 0 or M: duplicates and M drop out)
-        starts.push_back(0u);
-        std::sort(starts.begin(), starts.end());
-        starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
-        while (!starts.empty() && (int64_t)starts.back() >= M) starts.pop_back();
-        std::vector<std::pair<uint64_t, std::pair<uint32_t, uint32_t>>> chunks;        // first read index -> [from, to)
-        for (size_t k = 0; k < starts.size(); ++k) {
-            const uint32_t from = starts[k], to = k + 1 < starts.size() ? starts[k + 1] : (uint32_t)M;
-            chunks.push_back({((uint64_t)rec[from].read_hi << 32) | rec[from].read_lo, {from, to}});
-        }
-        std::sort(chunks.begin(), chunks.end());
-        for (const auto &ch : chunks) {
-            for (uint32_t i = ch.second.first; i < ch.second.second; ++i) {
-                const int64_t n = (int64_t)(rec[i].info >> 8), from = off[i];
-                if (from + n > X || at + n > X || at_r >= M) return fail(-5, "[l2r_download_accepted] inconsistent accepted list");
-                memcpy(&a->rec[at_r], &rec[i], sizeof(AccRec));
-                a->ex_off[at_r] = at;
-                memcpy(a->ex_start + at, xs.data() + from, (size_t)n * 4);
-                memcpy(a->ex_end + at, xe.data() + from, (size_t)n * 4);
-                memcpy(a->ex_flag + at, xf.data() + from, (size_t)n);
-                at += n; ++at_r;
-            }
-        }
-        if (at_r != M) return fail(-5, "[l2r_download_accepted] inconsistent accepted list (%lld of %lld records)", (long long)at_r, (long long)M);
-    }
+    rc = order_accepted(rec.data(), off.data(), starts, xs.data(), xe.data(), xf.data(), M, X, a, at_r, at);
+    if (rc) return rc;
     a->ex_off[M] = at;
     a->n_reads = M; a->n_exons = X;
     return 0;

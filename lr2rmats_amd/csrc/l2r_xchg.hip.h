@@ -131,4 +131,98 @@ int l2r_xchg_gather_results(l2r_xchg *x, l2r_result *res, int64_t *counts_out)
     return 0;
 }
 
+/* The accepted-novel records alone (all that the order-dependent merge needs when no output wants every read): every
+ * rank calls this behind its l2r_run + l2r_sync with L2R_WANT_ACCEPTED set.  The ranks' {records, exons, tiles} are all-gathered; the
+ * five arrays of every rank's list and its tiles' first-record slots go from HBM to rank 0 (ncclSend / ncclRecv in one group), which
+ * puts each rank's chunks into read order (order_accepted) one rank behind the other: acc (rank 0 only; capacities for the records /
+ * exons of ALL ranks) = the accepted reads of the whole input in read order, read indices global (first_read_index of the uploads).
+ * counts_out: world x 2 {records, exons} (any rank; may be NULL). */
+int l2r_xchg_gather_accepted(l2r_xchg *x, l2r_accepted *acc, int64_t *counts_out)
+{
+    if (!x || !x->ctx) return fail(-1, "[l2r_xchg_gather_accepted] null argument");
+    l2r_ctx *c = x->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = fetch_totals(c);
+    if (rc) return rc;
+    if (!(c->want & L2R_WANT_ACCEPTED)) return fail(-1, "[l2r_xchg_gather_accepted] the accepted list was not requested (l2r_set_outputs)");
+    const int W = x->world;
+    hipStream_t s = c->stream;
+    DevBuf<long long> d_cnt;
+    if (d_cnt.ensure((size_t)3 * (W + 1))) return -2;
+    const long long mine[3] = {(long long)c->h_totals[1], (long long)c->h_totals[2], (long long)c->n_tiles};
+    HIP_TRY(hipMemcpyAsync(d_cnt.p + 3 * W, mine, sizeof mine, hipMemcpyHostToDevice, s));
+    NCCL_TRY(ncclAllGather(d_cnt.p + 3 * W, d_cnt.p, 3, ncclInt64, x->comm, s));
+    std::vector<long long> cnt((size_t)3 * W);
+    HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt.p, cnt.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    d_cnt.release();
+    std::vector<long long> m_at((size_t)W + 1, 0), x_at((size_t)W + 1, 0), t_at((size_t)W + 1, 0);
+    for (int k = 0; k < W; ++k) { m_at[k + 1] = m_at[k] + cnt[3 * k]; x_at[k + 1] = x_at[k] + cnt[3 * k + 1]; t_at[k + 1] = t_at[k] + cnt[3 * k + 2]; }
+    if (counts_out) for (int k = 0; k < W; ++k) { counts_out[2 * k] = cnt[3 * k]; counts_out[2 * k + 1] = cnt[3 * k + 1]; }
+    const long long M = m_at[W], X = x_at[W], T = t_at[W];
+    // {device pointer of this rank, bytes per element, counted by records (0) / exons (1) / tiles (2)}
+    struct Part { const void *src; size_t width; int by; };
+    const Part parts[6] = {{c->acc_rec.p, sizeof(AccRec), 0}, {c->acc_ex_off.p, 4, 0}, {c->tile_rchunk.p, 4, 2}, {c->acc_start.p, 4, 1}, {c->acc_end.p, 4, 1}, {c->acc_flag.p, 1, 1}};
+    auto at_of = [&](int by) -> const std::vector<long long> & { return by == 0 ? m_at : (by == 1 ? x_at : t_at); };
+    DevBuf<uint8_t> g[6];
+    if (x->rank == 0) {
+        if (!acc) return fail(-1, "[l2r_xchg_gather_accepted] rank 0 needs a list to fill");
+        if (acc->n_reads < M || acc->ex_cap < X) return fail(-4, "[l2r_xchg_gather_accepted] buffers too small (%lld records, %lld exons)", M, X);
+        for (int a = 0; a < 6; ++a) if (g[a].ensure((size_t)at_of(parts[a].by)[W] * parts[a].width + 16)) return -2;
+    }
+    NCCL_TRY(ncclGroupStart());
+    for (int a = 0; a < 6; ++a) {
+        const std::vector<long long> &at = at_of(parts[a].by);
+        // (a rank without accepted reads has not made the arrays: its tiles' slots do not matter either)
+        if (x->rank == 0) {
+            for (int k = 1; k < W; ++k) {
+                const size_t n = cnt[3 * k] ? (size_t)(at[k + 1] - at[k]) * parts[a].width : 0;
+                if (n) NCCL_TRY(ncclRecv(g[a].p + (size_t)at[k] * parts[a].width, n, ncclUint8, k, x->comm, s));
+            }
+        } else {
+            const size_t n = cnt[3 * x->rank] ? (size_t)(at[x->rank + 1] - at[x->rank]) * parts[a].width : 0;
+            if (n) NCCL_TRY(ncclSend(parts[a].src, n, ncclUint8, 0, x->comm, s));
+        }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    if (x->rank == 0) {
+        for (int a = 0; a < 6; ++a) {
+            const size_t n = cnt[0] ? (size_t)at_of(parts[a].by)[1] * parts[a].width : 0;
+            if (n) HIP_TRY(hipMemcpyAsync(g[a].p, parts[a].src, n, hipMemcpyDeviceToDevice, s));
+        }
+        std::vector<AccRec> rec((size_t)M);
+        std::vector<uint32_t> off((size_t)M), starts((size_t)T);
+        std::vector<int32_t> xs((size_t)X), xe((size_t)X);
+        std::vector<uint8_t> xf((size_t)X);
+        if (M) {
+            HIP_TRY(hipMemcpyAsync(rec.data(), g[0].p, (size_t)M * sizeof(AccRec), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(off.data(), g[1].p, (size_t)M * 4, hipMemcpyDeviceToHost, s));
+            if (T) HIP_TRY(hipMemcpyAsync(starts.data(), g[2].p, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+        }
+        if (X) {
+            HIP_TRY(hipMemcpyAsync(xs.data(), g[3].p, (size_t)X * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(xe.data(), g[4].p, (size_t)X * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(xf.data(), g[5].p, (size_t)X, hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        int64_t at_r = 0, at = 0;
+        for (int k = 0; k < W; ++k) {
+            const long long Mk = cnt[3 * k], Xk = cnt[3 * k + 1];
+            if (!Mk) continue;
+            std::vector<uint32_t> st(starts.begin() + t_at[k], starts.begin() + t_at[k + 1]);
+            rc = order_accepted(rec.data() + m_at[k], off.data() + m_at[k], st, xs.data() + x_at[k], xe.data() + x_at[k], xf.data() + x_at[k], Mk, Xk, acc, at_r, at);
+            if (rc) return rc;
+        }
+        acc->ex_off[M] = at;
+        acc->n_reads = M; acc->n_exons = X;
+        // the shards follow each other in read order: so do the global read indices
+        for (long long i = 1; i < M; ++i) {
+            const uint64_t a0 = ((uint64_t)acc->rec[i - 1].read_hi << 32) | acc->rec[i - 1].read_lo, a1 = ((uint64_t)acc->rec[i].read_hi << 32) | acc->rec[i].read_lo;
+            if (a1 <= a0) return fail(-5, "[l2r_xchg_gather_accepted] records out of read order at %lld (do the uploads say their first_read_index?)", i);
+        }
+    } else HIP_TRY(hipStreamSynchronize(s));
+    for (int a = 0; a < 6; ++a) g[a].release();
+    return 0;
+}
+
 }  // extern "C"

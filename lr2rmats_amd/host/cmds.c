@@ -854,6 +854,8 @@ typedef struct {
     int64_t counts[256][2];                                  /* {reads, exons} per child */
     /* shm transport: the result arrays of the whole input (upper bounds; pages are touched by whoever writes them) */
     int64_t *ex_off; uint32_t *info; int32_t *ref_tx, *ex_start, *ex_end; uint8_t *ex_flag;
+    /* ... or, when no output wants every read, of the accepted reads alone (+ their records: global read index, info, ref_tx) */
+    l2r_accepted_read *rec;
 } gather_shared;
 
 static void *shared_pages(size_t bytes)
@@ -864,11 +866,11 @@ static void *shared_pages(size_t bytes)
 }
 
 /* One child's shard classified, its results left in HBM: the engine is returned alive */
-static l2r_ctx *classify_keep(const char *who, const l2r_params *prm, const l2r_annotation *a, const l2r_junctions *s, const l2r_reads *r)
+static l2r_ctx *classify_keep(const char *who, const l2r_params *prm, const l2r_annotation *a, const l2r_junctions *s, const l2r_reads *r, unsigned want)
 {
     int anno_set = 0;
     l2r_ctx *ctx = engine_take(who, &anno_set);
-    if (l2r_set_params(ctx, prm) || l2r_set_outputs(ctx, L2R_WANT_RESULTS) || (!anno_set && l2r_set_annotation(ctx, a)) ||
+    if (l2r_set_params(ctx, prm) || l2r_set_outputs(ctx, want) || (!anno_set && l2r_set_annotation(ctx, a)) ||
         l2r_set_junctions(ctx, s->n ? s : NULL)) engine_fail(who);
     if (shard_end(r, 0) != r->n_reads) h_fatal(who, "a child's shard is too large for one upload (%lld reads): use more GPUs", (long long)r->n_reads);
     if (l2r_upload_reads(ctx, r) || l2r_run(ctx) || l2r_sync(ctx)) engine_fail(who);
@@ -965,6 +967,9 @@ static int update_gtf_multi(h_job *j, int n_gpus, int gathered)
     /* ---- the gathered route: the exchange's shared block, and which transport */
     gather_shared *sh = NULL;
     int use_rccl = 0;
+    /* what travels: the per-read results of every read (a detail table, the known / unrecognised lists, the summary want them), or --
+     * SURVEY 8(e)'s message -- the accepted-novel records alone, 16 + 9 n bytes each, which is all the order-dependent merge reads */
+    const int acc_only = gathered && !needs_all_reads(j) && !getenv("L2R_GATHER_ALL");
     if (gathered) {
         sh = (gather_shared *)shared_pages(sizeof *sh);
         memset(sh, 0, sizeof *sh);
@@ -977,12 +982,14 @@ static int update_gtf_multi(h_job *j, int n_gpus, int gathered)
         if (xe && !strcmp(xe, "rccl")) use_rccl = 1;
         if (!use_rccl) {
             const size_t xb = (size_t)(j->reads.cig_off[N] + N) + 1;         /* n_exon(read) <= ops(read) + 1 */
+            if (acc_only) sh->rec = (l2r_accepted_read *)shared_pages((size_t)(N + 1) * sizeof(l2r_accepted_read));
             sh->ex_off = (int64_t *)shared_pages((size_t)(N + n_gpus + 1) * 8); sh->info = (uint32_t *)shared_pages((size_t)(N + 1) * 4);
             sh->ref_tx = (int32_t *)shared_pages((size_t)(N + 1) * 4);
             sh->ex_start = (int32_t *)shared_pages(xb * 4); sh->ex_end = (int32_t *)shared_pages(xb * 4); sh->ex_flag = (uint8_t *)shared_pages(xb);
         }
-        fprintf(stderr, "[update_gtf] L2R_GPUS=%d: gathered route (-s with a junction table): %d children classify, child 0 merges and writes; exchange: %s\n",
-                n_gpus, n_gpus, use_rccl ? "RCCL (ncclSend / ncclRecv to rank 0)" : "shared memory");
+        fprintf(stderr, "[update_gtf] L2R_GPUS=%d: gathered route (-s with a junction table): %d children classify, child 0 merges and writes; exchange: %s, %s\n",
+                n_gpus, n_gpus, use_rccl ? "RCCL (ncclSend / ncclRecv to rank 0)" : "shared memory",
+                acc_only ? "the accepted reads alone (no output of this run wants every read)" : "the per-read results");
     }
     if (!gathered)
     {   /* shards are whole chromosomes: say so when that leaves children without work or far out of balance */
@@ -1009,9 +1016,65 @@ static int update_gtf_multi(h_job *j, int n_gpus, int gathered)
                 int64_t *off = (int64_t *)h_malloc((size_t)(hi - lo + 1) * 8);
                 for (int64_t i = 0; i <= hi - lo; ++i) off[i] = r.cig_off[lo + i] - r.cig_off[lo];
                 sub.cig_off = off; sub.first_read_index = lo;
-                l2r_ctx *ctx = classify_keep("update_gtf", &prm, &a, &s, &sub);
+                l2r_ctx *ctx = classify_keep("update_gtf", &prm, &a, &s, &sub, acc_only ? L2R_WANT_ACCEPTED : L2R_WANT_RESULTS);
                 int rc_c = 0;
                 h_result out; memset(&out, 0, sizeof out);
+                int64_t *acc_idx = NULL;                                  /* acc_only, child 0: input index of every gathered record */
+                if (acc_only) {
+                    /* ---- the accepted reads alone */
+                    l2r_accepted_read *rec = NULL;
+                    int64_t m_all = 0, x_all = 0;
+                    if (use_rccl) {
+                        if (k == 0) {
+                            if (l2r_xchg_id_bytes() > (int)sizeof sh->id || l2r_xchg_unique_id(sh->id)) engine_fail("update_gtf");
+                            __sync_synchronize(); sh->id_ready = 1;
+                        }
+                        pthread_barrier_wait(&sh->bar);
+                        if (!sh->id_ready) h_fatal("update_gtf", "child 0 left no RCCL id");
+                        l2r_xchg *x = l2r_xchg_create(ctx, k, n_gpus, sh->id);
+                        if (!x) engine_fail("update_gtf");
+                        l2r_accepted acc; memset(&acc, 0, sizeof acc);
+                        if (k == 0) {
+                            const int64_t xb = j->reads.cig_off[N] + N;
+                            result_reserve(&out, N, xb);
+                            rec = (l2r_accepted_read *)h_malloc((size_t)(N + 1) * sizeof *rec);
+                            acc.n_reads = N; acc.ex_cap = xb; acc.rec = rec; acc.ex_off = out.ex_off; acc.ex_start = out.ex_start; acc.ex_end = out.ex_end; acc.ex_flag = out.ex_flag;
+                        }
+                        if (l2r_xchg_gather_accepted(x, k == 0 ? &acc : NULL, NULL)) engine_fail("update_gtf");
+                        l2r_xchg_destroy(x);
+                        if (k == 0) { m_all = acc.n_reads; x_all = acc.n_exons; }
+                    } else {
+                        int64_t na = 0, nax = 0;
+                        if (l2r_result_sizes(ctx, NULL, NULL, &na, &nax)) engine_fail("update_gtf");
+                        sh->counts[k][0] = na; sh->counts[k][1] = nax;
+                        pthread_barrier_wait(&sh->bar);
+                        int64_t m_at = 0, x_at = 0;
+                        for (int q = 0; q < k; ++q) { m_at += sh->counts[q][0]; x_at += sh->counts[q][1]; }
+                        /* (offsets: one entry more than records, as above -- child q writes m_at + q .. ; child 0 closes the gaps) */
+                        l2r_accepted acc = { na, nax, 0, sh->rec + m_at, sh->ex_off + m_at + k, sh->ex_start + x_at, sh->ex_end + x_at, sh->ex_flag + x_at };
+                        if (l2r_download_accepted(ctx, &acc)) engine_fail("update_gtf");
+                        pthread_barrier_wait(&sh->bar);
+                        if (k == 0) {
+                            int64_t ms = 0, xs = 0;
+                            for (int q = 0; q < n_gpus; ++q) {
+                                for (int64_t i = 0; i < sh->counts[q][0]; ++i) sh->ex_off[ms + i] = sh->ex_off[ms + i + q] + xs;
+                                ms += sh->counts[q][0]; xs += sh->counts[q][1];
+                            }
+                            sh->ex_off[ms] = xs;
+                            m_all = ms; x_all = xs; rec = sh->rec;
+                            out.ex_off = sh->ex_off; out.ex_start = sh->ex_start; out.ex_end = sh->ex_end; out.ex_flag = sh->ex_flag;
+                            out.info = (uint32_t *)h_malloc((size_t)(ms + 1) * 4); out.ref_tx = (int32_t *)h_malloc((size_t)(ms + 1) * 4);
+                        }
+                    }
+                    if (k == 0) {
+                        acc_idx = (int64_t *)h_malloc((size_t)(m_all + 1) * 8);
+                        for (int64_t i = 0; i < m_all; ++i) {
+                            acc_idx[i] = (int64_t)(((uint64_t)rec[i].read_hi << 32) | rec[i].read_lo);
+                            out.info[i] = rec[i].info; out.ref_tx[i] = rec[i].ref_tx;
+                        }
+                        out.n = m_all; out.n_ex = x_all;
+                    }
+                } else
                 if (use_rccl) {
                     /* rank 0 makes the id BEHIND the fork and hands it on through the shared block */
                     if (k == 0) {
@@ -1058,7 +1121,7 @@ static int update_gtf_multi(h_job *j, int n_gpus, int gathered)
                 if (k == 0) {
                     h_stage_time("children: engines, exchange");
                     l2r_result res = { out.n, out.n_ex, out.n_ex, out.ex_off, out.ex_start, out.ex_end, out.ex_flag, out.info, out.ref_tx };
-                    rc_c = h_job_finish(j, &res);
+                    rc_c = acc_only ? h_job_finish_accepted(j, &res, acc_idx) : h_job_finish(j, &res);
                     h_stage_time("child 0: merge + writers");
                 }
                 fflush(NULL);

@@ -323,3 +323,37 @@ def test_c_cli_gathered_route_over_several_children(oracle, tmp_path, files, n_g
         assert r.returncode == 0
         for k in OUTS:
             assert filecmp.cmp(ref[k], so[k], shallow=False), ("stdout", k)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n_gpus,xchg", [(3, "shm"), (4, "shm"), (1, "rccl")])
+def test_c_cli_gathered_route_moves_the_accepted_reads_alone(oracle, tmp_path, files, n_gpus, xchg):
+    """SURVEY.md 8(e)'s message from C: when no output of the run wants every read (`update-gtf -s -l 3 -J 1 -j SJ.out.tab -v novel.gtf
+    -E novel_exon.bed -o updated.gtf`: no detail table, no known / unrecognised / all lists, no summary), the gathered route sends the
+    compacted accepted-novel records alone to child 0 (l2r_xchg_gather_accepted over RCCL, or shared memory) and the tail runs on them
+    (h_job_finish_accepted).  The three files equal the one-process run's; L2R_GATHER_ALL=1 sends the per-read results instead."""
+    d, anno, reads, sam, bam, gtf = files
+    af = anno.in_file_order()
+    base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3))
+    j, _ = util.junction_table(af, reads, base, 43, cover=0.7)
+    tab = str(tmp_path / "SJ.out.tab")
+    j.write(tab)
+
+    def args(o):
+        return ["update-gtf", "-s", "-l", "3", "-J", "1", "-j", tab, "-v", o["novel"], "-E", o["bed"], "-o", o["gtf"], bam, gtf]
+    one, many, full = _paths(tmp_path, "one"), _paths(tmp_path, "many"), _paths(tmp_path, "full")
+    r = hostlib.run_cli(args(one))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert os.path.getsize(one["gtf"]) > 10000 and os.path.getsize(one["bed"]) > 100
+    env = {"L2R_GPUS": n_gpus, "L2R_GPU_MAP": ",".join(["0"] * n_gpus), "L2R_THREADS": 3, "L2R_XCHG": xchg}
+    if n_gpus == 1:
+        env["L2R_MULTI_ROUTE"] = "gathered"
+    r = hostlib.run_cli(args(many), env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert b"gathered route" in r.stderr and b"the accepted reads alone" in r.stderr and (b"RCCL" if xchg == "rccl" else b"shared memory") in r.stderr
+    for k in ("gtf", "novel", "bed"):
+        assert filecmp.cmp(one[k], many[k], shallow=False), (n_gpus, xchg, k)
+    r = hostlib.run_cli(args(full), env=dict(env, L2R_GATHER_ALL="1"))
+    assert r.returncode == 0 and b"the per-read results" in r.stderr, r.stderr.decode()[-2000:]
+    for k in ("gtf", "novel", "bed"):
+        assert filecmp.cmp(one[k], full[k], shallow=False), ("all", n_gpus, xchg, k)
