@@ -1349,7 +1349,9 @@ int l2r_run(l2r_ctx *c)
     // replayed, one submission per pass instead of seven.  Off by default: measured on MI355X / ROCm 7.2 the replay is
     // 2-4 % slower than the seven direct launches (config 2: 0.093 vs 0.089 ms, config 3: 1.42 vs 1.40 ms per pass).
     // Not for unsorted input with a junction table (its cursor replay syncs).
-    const bool graphable = !(c->n_sj > 0 && !c->sorted) && getenv("L2R_GRAPH") != nullptr;
+    // Not for the one-kernel tile path either (two launches: nothing to gain, and its launch arguments change run by run -- the
+    // super-block words take turns, launches are dropped once a run has shown them empty).
+    const bool graphable = !(c->n_sj > 0 && !c->sorted) && c->want_pipeline < 2 && getenv("L2R_GRAPH") != nullptr;
     if (graphable && !c->graph_valid) {
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
