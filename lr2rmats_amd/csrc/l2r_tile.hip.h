@@ -631,6 +631,7 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
                     unsigned long long nov = 0ull;
                     const uint32_t nj = n - 1u, n64 = min(nj, 64u);
                     for (uint32_t k = 0; k < n64; ++k) nov |= (unsigned long long)(((s_A[loc + k] >> SLAB_REL_BITS) & (uint32_t)F_JUNC) ? 1u : 0u) << k;
+                    if (ablate & 2048) nov = 0ull;              // (timing diagnostics: no lookups)
                     uint32_t k_tail = 64u;                      // (a read of more than 65 exons: the ones behind, one by one)
                     while (nov != 0ull || k_tail < nj) {
                         uint32_t k;

@@ -1,6 +1,6 @@
 """Diagnostics on the GPU box: the second option set (-s -l 3 -J 1 -j SJ.tab, results + accepted list; bench.py's second_pass leg) under
-L2R_ABLATE values, alternating on one box: tools/ab_sj.py <reads> <config> <ablate values ...>.  Bits 512 / 1024 (k_tile): no read is a
-candidate of the junction check / the whole check is skipped -- timing only, the results are wrong.  Not part of the product."""
+L2R_ABLATE values, alternating on one box: tools/ab_sj.py <reads> <config> <ablate values ...>.  Bits 512 / 1024 / 2048 (k_tile): no read is a
+candidate of the junction check / the whole check is skipped / no table lookups (cursor row and Q7 only) -- timing only, the results are wrong.  Not part of the product."""
 import os
 import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
