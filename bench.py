@@ -333,6 +333,40 @@ def dis_leg(eng, af, reads, args, capi, workload, n_x, base_ms):
     return out
 
 
+def pipelines_leg(af, reads, args, capi, tile_ms):
+    """What the headline step leans on, said in the line: the one-kernel tile path reads per-tile slot records and op statistics that
+    l2r_upload_reads makes ONCE per read set (k_tile_index: a function of the records alone, no option changes it; 0.41 ms / 1.15 GB in
+    profiles/r05).  The same step WITHOUT that index -- the two-kernel slab pipeline (L2R_PIPELINE=slab), which sorts, counts and scans
+    inside every step -- is timed here on a second engine; the upload's wall time (H2D copies + index kernel) beside it."""
+    import os
+    old = os.environ.get("L2R_PIPELINE")
+    out = {}
+    try:
+        for name in ("slab", "tile"):
+            os.environ["L2R_PIPELINE"] = name
+            e = capi.Engine(0)
+            e.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
+            e.set_params(capi.default_params(full_level=args.level)); e.set_outputs(capi.WANT_RESULTS)
+            e.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)          # (first upload: allocations)
+            e.run(); e.sync()
+            t0 = time.perf_counter()
+            e.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)
+            e.run(); e.sync()                                                                   # (the upload is asynchronous: the run behind it closes it)
+            up = time.perf_counter() - t0
+            for _ in range(2):                                   # (like the headline: the second of two regions, the clock has settled)
+                tm = e.run_timed(args.warmup + args.steps)
+            out[name] = {"ms_per_step": round(tm["total_ms"], 4), "upload_plus_one_step_wall_ms": round(up * 1e3, 2)}
+            e.close()
+    finally:
+        if old is None:
+            os.environ.pop("L2R_PIPELINE", None)
+        else:
+            os.environ["L2R_PIPELINE"] = old
+    out["note"] = ("tile (the headline's path) reads an op index made at upload, once per read set and independent of every option "
+                   "(k_tile_index: 0.41 ms, 1.15 GB by rocprofv3, profiles/r05); slab makes everything inside the step")
+    return out
+
+
 def launcher_argv(args, port: int):
     """The command `bench.py --gpus N` starts when no launcher has set WORLD_SIZE: the shape the driver uses itself."""
     passed = [a for a in sys.argv[1:] if a != "--dry-launch"]
@@ -387,6 +421,7 @@ def main():
     ap.add_argument("--no-gencode", action="store_true", help="skip the second workload (heavy-tailed isoforms per gene) at N=1")
     ap.add_argument("--no-ont", action="store_true", help="skip the ONT shard (BASELINE configs[4], rank 0 of 8) at N=1")
     ap.add_argument("--no-dis", action="store_true", help="skip the -d 2 leg at N=1")
+    ap.add_argument("--no-pipelines", action="store_true", help="skip the tile / slab comparison (the step without the upload's op index) at N=1")
     ap.add_argument("--dry-launch", action="store_true", help="print the launcher command a plain `bench.py --gpus N` would start, and exit")
     args = ap.parse_args()
 
@@ -634,6 +669,12 @@ def main():
                 gencode = gencode_leg(capi, workload, args)
             except Exception as e:                                # (must not take the line down)
                 gencode = {"error": str(e)[:300]}
+        pipes = None
+        if world == 1 and args.config == "cfg3" and not args.no_pipelines:
+            try:
+                pipes = pipelines_leg(af, reads, args, capi, tm["total_ms"])
+            except Exception as e:                                # (must not take the line down)
+                pipes = {"error": str(e)[:300]}
         e2e = None
         if world == 1 and not args.no_e2e:
             e2e = e2e_leg(af, reads, args.level)
@@ -666,6 +707,7 @@ def main():
             "isoform_rich": gencode,
             "dis2": dis2,
             "ont_shard": ont,
+            "resident_input": pipes,
             "cpu_baseline": cpu,
             "e2e": e2e,
         }
