@@ -2,24 +2,28 @@
 // k_probe_slab through HBM (4 bytes per exon each way, a word per read each way: 0.64 GB of the two-kernel step's 2.47 GB on 10 M
 // reads) stays inside one workgroup.
 //
-//   k_describe_scan<true>   first kernel of a run: the tiles' descriptors and windows from the spans the UPLOAD recorded (a tile's last
-//                           base = the largest read end: a sum of CIGAR lengths, independent of every parameter), the tile lists of the
-//                           64-bit-mask / chunked kernels, and the run's counters cleared (l2r_slab.hip.h)
-//   k_tile                  per tile: records -> slots (counting sort by CIGAR length), CIGAR heads into registers, dictionary slices
-//                           and window into LDS, then the CIGAR registers are walked TWICE: once to COUNT the read's exons (the counts
-//                           -> every read's place among the tile's exons in read order, one barrier + a wave scan), once to PLACE the
-//                           exons as row words at their read-order positions in LDS -- the image k_probe_slab builds from slab rows.
-//                           Window pass, probes, verdicts and the coalesced write-out as there (same device functions).  Registers
-//                           are max(walk, probe), not the sum: the 24 CIGAR words are dead before the probe rounds begin.
-//   the tile's first result slot: every tile PUBLISHES its exon count as soon as it knows it (a third of the way into its life) and
-//                           adds it to the sums of its block of 64 tiles / super-block of 64 blocks; just before its write-out it reads
-//                           the counts of the tiles in front of it inside its block, the sums of the blocks in front of it inside its
-//                           super-block and the sums of the super-blocks in front (three 64-lane loads, one per wave, agent-scope
-//                           atomics on both sides: no fence).  Nothing waits on a SPECIFIC predecessor's completion, only on counts
-//                           that tiles dispatched before this one publish early; workgroup -> tile is blocked-cyclic over the XCDs
-//                           (fused_tile: 16 consecutive tiles per XCD share their dictionary slices in one L2, and a tile's
-//                           predecessors are at most 128 workgroups behind it in dispatch order).  A tile that waits in vain
-//                           (2^22 polls) sets lb_err and leaves: the run then reports an error instead of hanging the device.
+//   k_tile_index            at UPLOAD, once per read set (below): per tile the span, op statistics and slot records -- functions of the
+//                           records alone, no option has a say in them.
+//   k_describe_scan<true>   first kernel of a run: the tiles' descriptors and windows from the spans the upload recorded, the tile lists
+//                           of the 64-bit-mask / chunked kernels, the run's counters cleared, and -- for every tile whose exon count the
+//                           op statistics settle under this run's thresholds (tile_exact: nearly all) -- the count itself, written into
+//                           the words the later tiles read (lb_tile / lb_blk / lb_sup, l2r_slab.hip.h).
+//   k_tile                  per tile: the slot records (one load by tile number), CIGAR heads into registers, dictionary slices and
+//                           window into LDS; the CIGAR registers are walked once to PLACE the read's exons as row words at their
+//                           read-order positions in LDS -- the image k_probe_slab builds from slab rows (an exact tile knows every
+//                           read's place from its slot record; any other tile walks twice: once to COUNT, a scan, then to place).
+//                           Window pass, probes, verdicts, the junction check (-j: rows staged over the dead dictionary slices) and
+//                           the coalesced write-out (same device functions as the slab kernels).  Registers are max(walk, probe),
+//                           not the sum: the 24 CIGAR words are dead before the probe rounds begin.
+//   the tile's first result slot = the exon counts of all tiles in front: the counts of the tiles in front of it inside its block of
+//                           16, the sums of the blocks in front inside its super-block of 64 blocks, the sums of the super-blocks in
+//                           front (three 64-lane loads, one per wave).  Counts k_describe_scan wrote are complete for every reader
+//                           from its first instruction (plain loads at the top of the kernel, nothing to wait for).  A tile that is
+//                           not exact publishes its count from k_tile (agent-scope atomics on both sides, no fence) and later tiles
+//                           poll for it: fine for a few, a convoy for many (launch_all sends runs with more than 2 % of such tiles
+//                           to the two-kernel path).  Workgroup -> tile is blocked-cyclic over the XCDs (fused_tile: 16 consecutive
+//                           tiles per XCD share their dictionary slices in one L2).  A tile that waits in vain (LB_POLLS) sets lb_err,
+//                           which ends every other wait too: the run reports an error instead of hanging the device.
 //   tiles this kernel does not finish: windows of 33 .. 63 members / beyond (k_probe_slab_wide / _chunked: on their lists already),
 //                           a dictionary key in several entries, a read of 255 exons or more, more exons than the staged positions
 //                           hold (only outliers make such tiles).  For those the workgroup runs k_walk_slab's tile body instead
