@@ -42,8 +42,8 @@ ANNO += gtf_rows("chrB", "+", "GS", "gs", "TS1", "ts1", [(50000, 50099)])
 SAM_HEADER = ["@HD\tVN:1.0\tSO:coordinate", "@SQ\tSN:chrA\tLN:100000000", "@SQ\tSN:chrB\tLN:100000000"]
 
 
-def sam(name, flag, chrom, pos, cigar):
-    return T.join([name, str(flag), chrom, str(pos), "60", cigar, "*", "0", "0", "*", "*"])
+def sam(name, flag, chrom, pos, cigar, *tags):
+    return T.join([name, str(flag), chrom, str(pos), "60", cigar, "*", "0", "0", "*", "*"] + list(tags))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -283,8 +283,65 @@ ENDS_GTF_L1 = _E1                     # -l 1: first END and last START must be t
 ENDS_GTF_L2 = _E4 + _E1               # -l 2: terminal exons must overlap the annotation's terminal exons: e4 too
 ENDS_GTF_L4 = _E4 + _E1 + _E2         # -l 4: left side only, and a first exon that overlaps NO annotation exon counts (lnoth): e2 too; e3's overlaps an inner one
 
+# --------------------------------------------------------------------------------------------------
+# Case "cigar": CIGAR -> exons (gen_exon, bam2gtf.c:31-78) through `bam2gtf` and through `update-gtf -l 5 -A` with an annotation on
+# another chromosome, under the default thresholds (-e 3 -i 3 -t 50) and under -e 10 -i 100 -t 5.  README.md section 6.
+CIG_SAM = SAM_HEADER + [
+    sam("g1", 0, "chrA", 1000, "5S50M2I50M100N30M"),
+    sam("g2", 0, "chrA", 2000, "100M200N2M300N100M"),
+    sam("g3", 0, "chrA", 3000, "50M2N50M10N50M"),
+    sam("g4", 0, "chrA", 4000, "50M50D50M51D50M"),
+    sam("g5", 0, "chrA", 5000, "1M100N2M100N50M"),
+    sam("g6", 0, "chrA", 6000, "3H10=5X100N1M"),
+    sam("g7", 16, "chrA", 7000, "50M100N50M", "XS:A:+"),
+    sam("g8", 0, "chrA", 7500, "50M100N50M", "XS:A:-"),
+    sam("g11", 0, "chrA", 8000, "20M100N10M100N20M"),
+    sam("g12", 0, "chrA", 8500, "20M100N9M100N20M"),
+    sam("g9", 0, "chrA", 9000, "50M100N50M", "XS:i:5"),
+    sam("g10", 4, "*", 0, "*"),
+]
+CIG_SAM_MAPPED = CIG_SAM[:-1]          # (update-gtf: read_bam_trans does not skip an unmapped record -- it dies on it, bam2gtf.c:95,100)
+CIG_ANNO = gtf_rows("chrB", "+", "GX", "gx", "TX1", "tx1", [(1000, 1100), (2000, 2100)])
+
+
+def b2g(chrom, strand, name, exons):
+    """print_trans (gtf.c:597-604): transcript row + exon rows, gene_id and transcript_id only, always ascending."""
+    attr = 'gene_id "%s"; transcript_id "%s";' % (name, name)
+    rows = [T.join([chrom, "lr2rmats", "transcript", str(exons[0][0]), str(exons[-1][1]), ".", strand, ".", attr])]
+    return rows + [T.join([chrom, "lr2rmats", "exon", str(a), str(b), ".", strand, ".", attr]) for a, b in exons]
+
+
+# name -> (strand, exons under the defaults, exons under -e 10 -i 100 -t 5 where they differ)
+_CIG = [
+    ("g1", "+", [(1000, 1099), (1200, 1229)], None),
+    ("g2", "+", [(2000, 2099), (2602, 2701)], None),
+    ("g3", "+", [(3000, 3101), (3112, 3161)], [(3000, 3161)]),
+    ("g4", "+", [(4000, 4149), (4201, 4250)], [(4000, 4049), (4100, 4149), (4201, 4250)]),
+    ("g5", "+", [(5000, 5000), (5203, 5252)], None),
+    ("g6", "+", [(6000, 6014), (6115, 6115)], None),
+    ("g7", "+", [(7000, 7049), (7150, 7199)], None),
+    ("g8", "-", [(7500, 7549), (7650, 7699)], None),
+    ("g11", "+", [(8000, 8019), (8120, 8129), (8230, 8249)], None),
+    ("g12", "+", [(8500, 8519), (8620, 8628), (8729, 8748)], [(8500, 8519), (8729, 8748)]),
+    ("g9", "-", [(9000, 9049), (9150, 9199)], None),
+]
+CIG_B2G = sum((b2g("chrA", st, nm, ex) for nm, st, ex, _ in _CIG), [])
+CIG_B2G_T = sum((b2g("chrA", st, nm, alt or ex) for nm, st, ex, alt in _CIG), [])
+
+
+def _unrec(name, strand, exons):
+    n = len(exons)
+    return detail(name, "chrA", strand, 2, "NA", "NA", [a for a, _ in exons], [b for _, b in exons], list(range(n)), list(range(2 * (n - 1))), list(range(n - 1)), [])
+
+
+CIG_DETAIL = [DETAIL_HEADER] + [_unrec(nm, st, ex) for nm, st, ex, _ in _CIG]
+CIG_DETAIL_T = [DETAIL_HEADER] + [_unrec(nm, st, alt or ex) for nm, st, ex, alt in _CIG]
+
+
 FILES = {
     "anno.gtf": ANNO,
+    "cigar.sam": CIG_SAM, "cigar_m.sam": CIG_SAM_MAPPED, "cigar_anno.gtf": CIG_ANNO, "cigar.bam2gtf.gtf": CIG_B2G, "cigar_t.bam2gtf.gtf": CIG_B2G_T,
+    "cigar.detail.txt": CIG_DETAIL, "cigar_t.detail.txt": CIG_DETAIL_T,
     "dis_anno.gtf": DIS_ANNO, "dis.sam": DIS_SAM, "dis2.detail.txt": DIS2_DETAIL, "dis0.detail.txt": DIS0_DETAIL, "dis.updated.gtf": DIS_GTF,
     "ends_anno.gtf": ENDS_ANNO, "ends.sam": ENDS_SAM, "ends.detail.txt": ENDS_DETAIL,
     "ends_l1.updated.gtf": ENDS_GTF_L1, "ends_l2.updated.gtf": ENDS_GTF_L2, "ends_l4.updated.gtf": ENDS_GTF_L4,

@@ -23,6 +23,12 @@ CASES = {
     "ends_l1": (["update-gtf", "-l", "1"], "ends.sam", "ends_anno.gtf", {"gtf": "ends_l1.updated.gtf", "detail": "ends.detail.txt"}),
     "ends_l2": (["update-gtf", "-l", "2"], "ends.sam", "ends_anno.gtf", {"gtf": "ends_l2.updated.gtf", "detail": "ends.detail.txt"}),
     "ends_l4": (["update-gtf", "-l", "4"], "ends.sam", "ends_anno.gtf", {"gtf": "ends_l4.updated.gtf", "detail": "ends.detail.txt"}),
+    # CIGAR -> exons (gen_exon, bam2gtf.c:31-78: Q4 micro-exon drop and intron fusion, absorbed N / D, clips, =/X, XS strand, unmapped record)
+    # under two threshold sets, through bam2gtf and through update-gtf's classification kernels
+    "cigar_b2g": (["bam2gtf"], "cigar.sam", False, {"gtf": "cigar.bam2gtf.gtf"}),
+    "cigar_b2g_t": (["bam2gtf", "-e", "10", "-i", "100", "-t", "5"], "cigar.sam", False, {"gtf": "cigar_t.bam2gtf.gtf"}),
+    "cigar_upd": (["update-gtf", "-l", "5"], "cigar_m.sam", "cigar_anno.gtf", {"detail": "cigar.detail.txt"}),
+    "cigar_upd_t": (["update-gtf", "-l", "5", "-e", "10", "-i", "100", "-t", "5"], "cigar_m.sam", "cigar_anno.gtf", {"detail": "cigar_t.detail.txt"}),
     "uniq": (["unique-gtf"], "uniq.sam", False, {"gtf": "uniq.unique.gtf"}),
     "uniq_s": (["unique-gtf", "-s"], "uniq.sam", False, {"gtf": "uniq_s.unique.gtf"}),
 }
