@@ -283,6 +283,23 @@ ENDS_GTF_L1 = _E1                     # -l 1: first END and last START must be t
 ENDS_GTF_L2 = _E4 + _E1               # -l 2: terminal exons must overlap the annotation's terminal exons: e4 too
 ENDS_GTF_L4 = _E4 + _E1 + _E2         # -l 4: left side only, and a first exon that overlaps NO annotation exon counts (lnoth): e2 too; e3's overlaps an inner one
 
+# Case "ends3": the same annotation with two more reads in front -- -l 3 (both ends, README.md section 7) against -l 4 and -l 2, and what
+# merge_trans makes of reads whose junction chains contain each other once they are routed.
+ENDS3_SAM = SAM_HEADER + [
+    sam("e5", 0, "chrA", 1000, "101M899N51M"),             # (1000,1100) (2000,2050): the LAST exon overlaps the annotation's second exon only
+    sam("e6", 0, "chrA", 1000, "101M899N101M399N101M"),    # (1000,1100) (2000,2100) (2500,2600): the last exon overlaps NO annotation exon
+] + ENDS_SAM[len(SAM_HEADER):]
+ENDS3_DETAIL = [
+    DETAIL_HEADER,
+    detail("e5", "chrA", "+", 1, "GE", "ge", [1000, 2000], [1100, 2050], [1], [1], [], []),
+    detail("e6", "chrA", "+", 1, "GE", "ge", [1000, 2000, 2500], [1100, 2100, 2600], [2], [1], [1], []),
+] + ENDS_DETAIL[1:]
+_E5 = gtf_block("chrA", 1000, 2050, "+", "GE", "ge", "e5", 1, "chrA", "+", [(1000, 1100), (2000, 2050)])
+_E6 = gtf_block("chrA", 1000, 2600, "+", "GE", "ge", "e6", 1, "chrA", "+", [(1000, 1100), (2000, 2100), (2500, 2600)])
+ENDS3_GTF_L2 = _E4 + _E1               # e5, e6: their last exons do not overlap the annotation's last exon
+ENDS3_GTF_L3 = _E6 + _E4 + _E1 + _E2   # e6's last exon overlaps nothing (rnoth): full; e5's overlaps an inner exon: not; nothing merges
+ENDS3_GTF_L4 = _E5 + _E4 + _E2         # left side only: e5 is routed first, and e6 and e1 -- chains that BEGIN with e5's only junction -- vanish into it (Q8)
+
 # --------------------------------------------------------------------------------------------------
 # Case "cigar": CIGAR -> exons (gen_exon, bam2gtf.c:31-78) through `bam2gtf` and through `update-gtf -l 5 -A` with an annotation on
 # another chromosome, under the default thresholds (-e 3 -i 3 -t 50) and under -e 10 -i 100 -t 5.  README.md section 6.
@@ -344,6 +361,8 @@ FILES = {
     "cigar.detail.txt": CIG_DETAIL, "cigar_t.detail.txt": CIG_DETAIL_T,
     "dis_anno.gtf": DIS_ANNO, "dis.sam": DIS_SAM, "dis2.detail.txt": DIS2_DETAIL, "dis0.detail.txt": DIS0_DETAIL, "dis.updated.gtf": DIS_GTF,
     "ends_anno.gtf": ENDS_ANNO, "ends.sam": ENDS_SAM, "ends.detail.txt": ENDS_DETAIL,
+    "ends3.sam": ENDS3_SAM, "ends3.detail.txt": ENDS3_DETAIL, "ends3_l2.updated.gtf": ENDS3_GTF_L2, "ends3_l3.updated.gtf": ENDS3_GTF_L3,
+    "ends3_l4.updated.gtf": ENDS3_GTF_L4,
     "ends_l1.updated.gtf": ENDS_GTF_L1, "ends_l2.updated.gtf": ENDS_GTF_L2, "ends_l4.updated.gtf": ENDS_GTF_L4,
     "upd.sam": UPD_SAM, "upd.detail.txt": UPD_DETAIL, "upd.updated.gtf": UPD_GTF, "upd.novel_exon.bed": UPD_BED, "upd.summary.txt": UPD_SUMMARY,
     "upd_c.updated.gtf": UPD_GTF_C, "upd_c.novel_exon.bed": UPD_BED_C, "upd_c.summary.txt": UPD_SUMMARY_C,

@@ -23,6 +23,10 @@ CASES = {
     "ends_l1": (["update-gtf", "-l", "1"], "ends.sam", "ends_anno.gtf", {"gtf": "ends_l1.updated.gtf", "detail": "ends.detail.txt"}),
     "ends_l2": (["update-gtf", "-l", "2"], "ends.sam", "ends_anno.gtf", {"gtf": "ends_l2.updated.gtf", "detail": "ends.detail.txt"}),
     "ends_l4": (["update-gtf", "-l", "4"], "ends.sam", "ends_anno.gtf", {"gtf": "ends_l4.updated.gtf", "detail": "ends.detail.txt"}),
+    # -l 3 (both ends: overlap the terminal exon or overlap nothing) against -l 2 / -l 4, with reads whose chains contain each other (Q8)
+    "ends3_l2": (["update-gtf", "-l", "2"], "ends3.sam", "ends_anno.gtf", {"gtf": "ends3_l2.updated.gtf", "detail": "ends3.detail.txt"}),
+    "ends3_l3": (["update-gtf", "-l", "3"], "ends3.sam", "ends_anno.gtf", {"gtf": "ends3_l3.updated.gtf", "detail": "ends3.detail.txt"}),
+    "ends3_l4": (["update-gtf", "-l", "4"], "ends3.sam", "ends_anno.gtf", {"gtf": "ends3_l4.updated.gtf", "detail": "ends3.detail.txt"}),
     # CIGAR -> exons (gen_exon, bam2gtf.c:31-78: Q4 micro-exon drop and intron fusion, absorbed N / D, clips, =/X, XS strand, unmapped record)
     # under two threshold sets, through bam2gtf and through update-gtf's classification kernels
     "cigar_b2g": (["bam2gtf"], "cigar.sam", False, {"gtf": "cigar.bam2gtf.gtf"}),
