@@ -355,12 +355,48 @@ CIG_DETAIL = [DETAIL_HEADER] + [_unrec(nm, st, ex) for nm, st, ex, _ in _CIG]
 CIG_DETAIL_T = [DETAIL_HEADER] + [_unrec(nm, st, alt or ex) for nm, st, ex, alt in _CIG]
 
 
+# --------------------------------------------------------------------------------------------------
+# Case "sj": update-gtf -l 5 -J 3 -j sj.tab without -s, and the same with -M.  README.md section 8.
+SJ_ANNO = (gtf_rows("chrA", "+", "GJ1", "gj1", "TJ1", "tj1", [(1000, 1100), (2000, 2100), (3000, 3100)])
+           + gtf_rows("chrA", "+", "GJ2", "gj2", "TJ2", "tj2", [(5000, 5100), (6000, 6100)])
+           + gtf_rows("chrA", "+", "GJ3", "gj3", "TJ3", "tj3", [(6900, 7000), (9000, 9100)]))
+SJ_SAM = SAM_HEADER + [
+    sam("j1", 0, "chrA", 1000, "101M899N101M399N101M399N101M"),
+    sam("j2", 0, "chrA", 5000, "101M399N101M"),
+    sam("j3", 0, "chrA", 6900, "101M999N101M"),
+]
+SJ_TAB = [T.join(r) for r in [
+    ("chrA", "2101", "2499", "1", "1", "0", "2", "2", "30"),
+    ("chrA", "2601", "2999", "1", "1", "0", "5", "0", "30"),
+    ("chrA", "7001", "7999", "1", "1", "0", "3", "0", "30"),
+]]
+
+
+def _sj_detail(j1_unrel):
+    return [
+        DETAIL_HEADER,
+        detail("j1", "chrA", "+", 1, "GJ1", "gj1", [1000, 2000, 2500, 3000], [1100, 2100, 2600, 3100], [2], [1, 4, 5], [1, 2], j1_unrel),
+        detail("j2", "chrA", "+", 1, "GJ2", "gj2", [5000, 5500], [5100, 5600], [1], [1], [0], []),
+        detail("j3", "chrA", "+", 1, "GJ3", "gj3", [6900, 8000], [7000, 8100], [1], [1], [0], []),
+    ]
+
+
+SJ_DETAIL = _sj_detail([1])            # -J 3: the row of junction 1 has 2 unique reads
+SJ_DETAIL_M = _sj_detail([])           # -M: 2 unique + 2 multi
+_J1 = gtf_block("chrA", 1000, 3100, "+", "GJ1", "gj1", "j1", 1, "chrA", "+", [(1000, 1100), (2000, 2100), (2500, 2600), (3000, 3100)])
+_J3 = gtf_block("chrA", 6900, 8100, "+", "GJ3", "gj3", "j3", 1, "chrA", "+", [(6900, 7000), (8000, 8100)])
+SJ_GTF = _J3                           # j1 has an unreliable junction, j2 is unsupported without one (Q7): neither is routed without -s
+SJ_GTF_M = _J1 + _J3
+
+
 FILES = {
     "anno.gtf": ANNO,
     "cigar.sam": CIG_SAM, "cigar_m.sam": CIG_SAM_MAPPED, "cigar_anno.gtf": CIG_ANNO, "cigar.bam2gtf.gtf": CIG_B2G, "cigar_t.bam2gtf.gtf": CIG_B2G_T,
     "cigar.detail.txt": CIG_DETAIL, "cigar_t.detail.txt": CIG_DETAIL_T,
     "dis_anno.gtf": DIS_ANNO, "dis.sam": DIS_SAM, "dis2.detail.txt": DIS2_DETAIL, "dis0.detail.txt": DIS0_DETAIL, "dis.updated.gtf": DIS_GTF,
     "ends_anno.gtf": ENDS_ANNO, "ends.sam": ENDS_SAM, "ends.detail.txt": ENDS_DETAIL,
+    "sj_anno.gtf": SJ_ANNO, "sj.sam": SJ_SAM, "sj.tab": SJ_TAB, "sj.detail.txt": SJ_DETAIL, "sj_m.detail.txt": SJ_DETAIL_M,
+    "sj.updated.gtf": SJ_GTF, "sj_m.updated.gtf": SJ_GTF_M,
     "ends3.sam": ENDS3_SAM, "ends3.detail.txt": ENDS3_DETAIL, "ends3_l2.updated.gtf": ENDS3_GTF_L2, "ends3_l3.updated.gtf": ENDS3_GTF_L3,
     "ends3_l4.updated.gtf": ENDS3_GTF_L4,
     "ends_l1.updated.gtf": ENDS_GTF_L1, "ends_l2.updated.gtf": ENDS_GTF_L2, "ends_l4.updated.gtf": ENDS_GTF_L4,

@@ -27,6 +27,11 @@ CASES = {
     "ends3_l2": (["update-gtf", "-l", "2"], "ends3.sam", "ends_anno.gtf", {"gtf": "ends3_l2.updated.gtf", "detail": "ends3.detail.txt"}),
     "ends3_l3": (["update-gtf", "-l", "3"], "ends3.sam", "ends_anno.gtf", {"gtf": "ends3_l3.updated.gtf", "detail": "ends3.detail.txt"}),
     "ends3_l4": (["update-gtf", "-l", "4"], "ends3.sam", "ends_anno.gtf", {"gtf": "ends3_l4.updated.gtf", "detail": "ends3.detail.txt"}),
+    # junction table without -s: a count below -J (with and without --use-multi; the SHORT option -M wants an argument, update_gtf.c:999),
+    # a cursor row beyond the read (Q7: unsupported, no flag)
+    "sj": (["update-gtf", "-l", "5", "-J", "3", "-j", os.path.join(H, "sj.tab")], "sj.sam", "sj_anno.gtf", {"gtf": "sj.updated.gtf", "detail": "sj.detail.txt"}),
+    "sj_m": (["update-gtf", "-l", "5", "-J", "3", "--use-multi", "-j", os.path.join(H, "sj.tab")], "sj.sam", "sj_anno.gtf",
+             {"gtf": "sj_m.updated.gtf", "detail": "sj_m.detail.txt"}),
     # CIGAR -> exons (gen_exon, bam2gtf.c:31-78: Q4 micro-exon drop and intron fusion, absorbed N / D, clips, =/X, XS strand, unmapped record)
     # under two threshold sets, through bam2gtf and through update-gtf's classification kernels
     "cigar_b2g": (["bam2gtf"], "cigar.sam", False, {"gtf": "cigar.bam2gtf.gtf"}),
