@@ -300,6 +300,20 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, const uint32_t *__restrict__ u
         // (members per chunk: halved, for the rest of the tile, when a chunk's members need more dictionary entries than are staged)
         uint32_t chunk_members = (uint32_t)WIDE_MEMBERS;
         int scan_from = d.j_lo;
+        // The first entry that reaches into each bucket (reach-back directory) and its key do not change from chunk to chunk -- only the
+        // staged place of its group does: two dependent round trips per chunk that are taken once per tile here (two buckets per thread).
+        constexpr int RB_PER = (DIR_CAP + TILE_THREADS - 1) / TILE_THREADS;
+        int32_t rb_k1[RB_PER]; bool rb_in[RB_PER];
+#pragma unroll
+        for (int u = 0; u < RB_PER; ++u) {
+            const int i = (int)threadIdx.x + u * TILE_THREADS;
+            rb_k1[u] = 0; rb_in[u] = false;
+            if (usable && i < d.nbk) {
+                const uint32_t e = ld32(a->f.st.rdir, (uint32_t)(d.b0 + i));
+                rb_in[u] = e < d.st_r0 + d.st_nk;
+                if (rb_in[u]) rb_k1[u] = a->f.st.ent[e].k1;
+            }
+        }
         while (usable) {
             if (threadIdx.x < (uint32_t)WAVE) {
                 const int nx = chunk_window(a, lane, d.tid, tile_lo, thi, scan_from, chunk_members, &s_tw);
@@ -376,9 +390,10 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, const uint32_t *__restrict__ u
             // reach-back directory: the first staged entry of the GROUP that holds the bucket's first reaching entry (what is scanned
             // from there on is filtered by the exon's own coordinates)
             if (!bad) {
-                for (int i = (int)threadIdx.x; i < d.nbk; i += TILE_THREADS) {
-                    const uint32_t e = ld32(a->f.st.rdir, (uint32_t)(d.b0 + i));
-                    XR[i] = e < d.st_r0 + d.st_nk ? X0[group_of(a->f.st.ent[e].k1)] : X0[n_grp];
+#pragma unroll
+                for (int u = 0; u < RB_PER; ++u) {
+                    const int i = (int)threadIdx.x + u * TILE_THREADS;
+                    if (i < d.nbk) XR[i] = rb_in[u] ? X0[group_of(rb_k1[u])] : X0[n_grp];
                 }
             }
             __syncthreads();
