@@ -399,9 +399,10 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, const uint32_t *__restrict__ u
             __syncthreads();
             // ---- this chunk's part of the sweep
             const bool work = work0 && !redo && !known && !stopped;
-            const ChunkVisit vm = visit_chunk64<LEVEL>(L, w_n, work, n, re, s_tw.mask);
+            const int abl = a->f.p.ablate;                     // (timing diagnostics: 8192 no member pass, 4096 no probe rounds -- results wrong)
+            const ChunkVisit vm = visit_chunk64<LEVEL>(L, (abl & 8192) ? 0 : w_n, work, n, re, s_tw.mask);
             redo = redo || vm.redo;
-            const bool mapping = work && !vm.redo && n > 1;
+            const bool mapping = work && !vm.redo && n > 1 && !(abl & 4096);
             const SiteMasks64 sm = map_exons_lds64(L, dc, mapping, Ap, Lp, tile_lo, n, vm.vpre, dis, re.s0, re.el);
             // (-d > 0: a visited member with two sites within the tolerance of one read site -- its pair count is the generic kernel's)
             const bool amb = dis > 0 && mapping && (sm.amb & vm.vpre) != 0ull;
