@@ -77,3 +77,31 @@ def test_self_launched_world_of_two_on_one_gpu():
     # both routes in one line: the headline is partitioned (no collective in a step), the other one gathers the accepted list
     assert d["other_exchange"]["exchange"] == "gathered" and d["other_exchange"]["value"] > 0
     assert sum(d["other_exchange"]["exchange_bytes_per_rank_per_step"]) > 0
+
+
+@pytest.mark.gpu
+def test_one_gpu_line_has_the_contract_fields():
+    """`bench.py` at N = 1 on a small configuration: ONE JSON line with the driver's fields, the roofline object (from the timed region) and the
+    CPU baseline object, parity of the timed path against the oracle on the sample."""
+    r = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--config", "cfg2", "--reads", "60000", "--cpu-sample", "60000",
+                        "--no-gencode", "--no-e2e"], env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "headline_region", "warmup_effective_steps"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "int32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 60000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-2            # (ms_per_step is rounded to four digits)
+    ro = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in ro, k
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and 0 < ro["frac"] < 1
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["parity_on_sample"] is True
+    assert d["second_pass"]["ms_per_step"] > 0 and d["with_accepted"]["ms_per_step"] > 0
