@@ -1066,6 +1066,7 @@ void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, c
     const PipeArgsK a = pipe_args();
     auto one_tile = [&](const uint32_t t) {
     SlabStamp stamp; stamp.start(a->f.stamps);
+    __builtin_amdgcn_s_setprio(1);                              // (issue priority above the waves that are in their classification: see k_tile, l2r_tile.hip.h)
     // The tile's reads, slab and first base from ONE record of k_walk_slab, its descriptor, its first result slot: every scalar load
     // of the prologue is asked for before the first one is waited for (the empty asm "uses" them all here: the compiler would sink
     // some of them behind the early returns below, i.e. into a second and a third round trip).
@@ -1139,7 +1140,9 @@ void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, c
     // the first read that does not fit the staged positions ends the block that is written from LDS (reads are in read order there)
     if (active && loc + n > (uint32_t)SLAB_POS_CAP) atomicMin(&s_lim, loc);      // (a read that is written directly for another reason marks its positions instead)
     stamp.mark(1);
+    __builtin_amdgcn_s_setprio(0);
     const SlabVerdict vd = slab_classify<LEVEL, DIS>(sa, a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, r, off, q, re, out, st, any_wide, stamp);
+    __builtin_amdgcn_s_setprio(1);
     if (ACC) { const int w_redo = __any(vd.redo) ? 1 : 0; if ((threadIdx.x & (WAVE - 1)) == 0) s_redow[threadIdx.x >> 6] = (uint32_t)w_redo; }
     __syncthreads();
     if (!ACC) {

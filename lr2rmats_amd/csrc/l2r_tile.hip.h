@@ -204,6 +204,10 @@ constexpr int TILE_AHEAD = L2R_TILE_AHEAD;
 #ifndef L2R_TILE_NE
 #define L2R_TILE_NE 2
 #endif
+#ifndef L2R_TILE_PRIO
+#define L2R_TILE_PRIO 1
+#endif
+constexpr int TILE_PRIO = L2R_TILE_PRIO;                // k_tile: a wave's issue priority outside its classification (0 inside)
 constexpr int TILE_NS = L2R_TILE_NS, TILE_NE = L2R_TILE_NE;      // entries of a START / END bucket every probe round looks at without a loop
 template <bool DIS>
 __device__ __forceinline__ SiteMasks map_exons_lds(const TileLds &L, const TileDesc &d, bool mapping, uint32_t n, uint32_t vpre, const SlabStage &st, int dis = 0, int rs = 0, int re = 0)
@@ -377,6 +381,12 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     // diagnostics (L2R_STAMPS=1), wave 0: [0] records, CIGAR heads asked for, staging  [1] (count walk + barrier)  [6] scan, count
     // published, place walk  [2] window pass  [3] probe rounds  [4] verdicts  [7] the tile's first slot (exon counts in front)  [5] write-out
     SlabStamp stamp; stamp.start(a->f.stamps); if (stamp.who == 3) stamp.who = -1;
+    // Issue priority: a wave is above the others everywhere but in its classification (window pass, probe rounds, verdicts: the part of a
+    // tile that is bound by vector and LDS issue).  The waves that are asking for their records and CIGARs, walking, waiting for the
+    // counts in front or writing out get their few instructions in first -- their round trips start earlier, the probing waves lose
+    // nothing they could use (measured: k_tile 0.484 -> 0.471 ms; priority 3 instead of 1 the same within noise; high only up to the
+    // end of the staging: 0.478).
+    __builtin_amdgcn_s_setprio(TILE_PRIO);
     const uint32_t clk0 = stamp.p ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
     // The thread's slot record lies at a place the tile number alone says (k_tile_index): asked for beside the scalar loads below.
     const v3u_a4 srec = *reinterpret_cast<const v3u_a4 *>(u_slot + ((size_t)t * TILE_THREADS + threadIdx.x));
@@ -568,7 +578,9 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     const uint32_t pre = idx | ((xs & SLOT_REV) ? PRE_REV : 0u) | (sane ? 0u : PRE_INSANE) | (n << PRE_N_SHIFT);
     const uint32_t r = r0 + idx;
     // ---- classification (a lane probes the positions it has placed itself; the dictionary slices were whole at the barrier above)
+    __builtin_amdgcn_s_setprio(0);
     SlabVerdict vd = tile_classify<LEVEL, DIS>(a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, big, r, re, st, any_wide, stamp);
+    __builtin_amdgcn_s_setprio(TILE_PRIO);
     if (ACC) { const int w_redo = __any(vd.redo) ? 1 : 0; if (lane == 0) s_redow[wv] = (uint32_t)w_redo; }
     // ---- short-read junction support (-j: src/update_gtf.c:698-709 check_with_short_sj, :609-627 check_short_sj) for the reads whose
     //      verdict is final here, on the tile's LDS image: k_validate_sj's three steps without its passes over the results in HBM.
