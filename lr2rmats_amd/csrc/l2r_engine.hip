@@ -75,6 +75,9 @@ struct l2r_ctx {
     bool slab = false;                      // ... and the last launch did (the parameters have a say: launch_all)
     bool lists_heavy = false;                           // ... or most tiles went to them (an isoform-rich annotation): k_tile would only walk for them, which k_walk_slab does faster -- later runs take the slab pipeline
     bool redo_empty = false;                            // ... and nothing to the generic kernel either: every read had its junction check in k_tile, k_validate_sj has nothing to do
+    bool wide_direct = true;                            // L2R_WIDE_DIRECT=0: the exact 64-bit-mask tiles keep the slab form and k_probe_slab_wide (k_tile's WIDE instance, l2r_tile.hip.h)
+    bool wide_rest_empty = false;                       // ... and none of them kept the slab form (list_cnt[5]): k_probe_slab_wide has nothing to do
+    uint32_t n_wide_tiles = 0;                          // ... entries of wide_list a completed run has left (l2r_sync): the WIDE instance's grid
     uint32_t lb_flip = 0;                               // which of the two lb_sup arrays the next run of the tile path uses (l2r_slab.hip.h SlabArgs::lb_sup)
     bool lists_known = false, lists_empty = false;      // one-kernel tile path: a completed run of these inputs and parameters left nothing to k_probe_slab / _wide / _chunked (l2r_sync looks): their launches are skipped until something changes
     bool tile = false;                      // ... with the one-kernel tile path (l2r_tile.hip.h: short CIGARs, -e >= 1)
@@ -222,6 +225,8 @@ l2r_ctx *l2r_create(int device)
         if (e && atoll(e) >= 0) c->seg_max = atoll(e);
         e = getenv("L2R_ANNO_CACHE");
         if (e && *e) c->anno_cache_dir = e;
+        e = getenv("L2R_WIDE_DIRECT");
+        if (e) c->wide_direct = atoi(e) != 0;
         e = getenv("L2R_PIPELINE");
         if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : !strcmp(e, "slab") ? 1 : 2;
     }
@@ -885,7 +890,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         if (total < 0x7ffffff0ULL && ovf < 0x7ffffff0ULL) {
             sbase[T] = (uint32_t)total;                     // (rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true;
-            if (c->tw64.ensure(T + 1) || c->wide_list.ensure(T + 1) || c->chunk_list.ensure(T + 1) || c->list_cnt.ensure(8) || c->tile_flags.ensure(T + 8) ||
+            if (c->tw64.ensure(T + 1) || c->wide_list.ensure(2 * (T + 1)) || c->chunk_list.ensure(T + 1) || c->list_cnt.ensure(8) || c->tile_flags.ensure(T + 8) ||
                 c->lb_tile.ensure(T + 64) || c->lb_blk.ensure(T / LB_BLK + 64) || c->lb_sup.ensure(2 * ((T >> LB_SUP_SHIFT) + 64)) || c->fb_list.ensure(T + 1) || c->tile_stat.ensure(T + 1) || c->sup_stat.ensure((T >> LB_SUP_SHIFT) + 2) ||
                 (!c->wide_cigar && c->slot_rec.ensure((T + 1) * TILE_THREADS))) return -2;
             HIP_TRY(hipMemsetAsync(c->lb_sup.p, 0, 2 * ((T >> LB_SUP_SHIFT) + 64) * 8, c->stream)); c->lb_flip = 0;      // (two arrays taking turns; from then on each is cleared by the run in front of its own)      // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB each)
@@ -1089,6 +1094,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         sa.lb_tile = c->lb_tile.p; sa.lb_blk = c->lb_blk.p; sa.lb_err = c->totals.p + 6; sa.fb_list = c->fb_list.p; sa.exon_total = c->totals.p + 0; sa.tile_stat = c->tile_stat.p; sa.sup_stat = c->sup_stat.p;
         sa.sj = SjDir{CursorDir{c->sj_key.p, c->sj_cdir.p, c->sj_cbase.p, c->sj_ntid, (int32_t)c->n_sj}, c->sj_ddir.p, c->sj_dbase.p, c->sj_ntid, c->sj_row.p};
         sa.has_wide_keys = c->n_wide > 0 ? 1u : 0u;
+        sa.wide_direct_on = (c->tile && c->wide_direct && c->tw64.p && !(c->ablate & 4)) ? 1u : 0u;
         // (with the accepted list wanted and no junction table to decide later, the tiles leave their accepted chunks themselves)
         const bool probe_acc = (c->want & L2R_WANT_ACCEPTED) && (c->n_sj == 0 || c->tile);      // (k_tile decides acceptance itself, junction table or not)
 #define launch_probe_k(L, A, D, LIST, G) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L, A, D, LIST>), dim3(G), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
@@ -1125,6 +1131,23 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             //  their lists empty -- what ends up on them does not depend on anything else)
             skip_lists = c->lists_known && c->lists_empty && !getenv("L2R_LAUNCH_ALL");
             const unsigned gl = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 2);
+            if (!skip_lists && sa.wide_direct_on) {
+                // the exact 64-bit-mask tiles straight from their CIGARs: k_tile's WIDE instance, a workgroup per entry of wide_list (the
+                // list's length is known to the host once a run has completed: until then a grid for every tile, most of which leave at once)
+                const unsigned gwd = c->lists_known ? std::max(c->n_wide_tiles, 1u) : (unsigned)std::max<int64_t>(c->n_tiles, 1);
+#define launch_tw_k(L, D) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile<L, false, D, true>), dim3(gwd), dim3(TILE_THREADS), 0, s, sa, (const TileRec *)c->tile_rec.p, (const TileWin *)c->tw.p, (const TileStat *)c->tile_stat.p, (const SlotRec *)c->slot_rec.p, c->tile_xbase.p)
+#define launch_tw_level(L) do { if (p.ss_dis > 0) launch_tw_k(L, true); else launch_tw_k(L, false); } while (0)
+                switch (p.full_level) {
+                case 1: launch_tw_level(1); break;
+                case 2: launch_tw_level(2); break;
+                case 3: launch_tw_level(3); break;
+                case 4: launch_tw_level(4); break;
+                case 5: launch_tw_level(5); break;
+                default: launch_tw_level(0); break;
+                }
+#undef launch_tw_level
+#undef launch_tw_k
+            }
             if (!skip_lists) launch_probe(true, gl);
         } else {
         if (c->wide_cigar)
@@ -1155,12 +1178,12 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
 #undef launch_probe
 #undef launch_probe_level
 #undef launch_probe_k
-        if (!skip_lists)
+        if (!skip_lists && !(c->tile && c->lists_known && c->wide_rest_empty && !getenv("L2R_LAUNCH_ALL")))
         {   // the tiles with 33 .. 63 window members (none on most inputs: the grid finds an empty list and leaves)
             const WideArgs wa{c->tw64.p};
             const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 5);
 #define launch_wide_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_wide<L>), dim3(gw), dim3(TILE_THREADS), 0, s, sa, wa, (const uint32_t *)c->tile_first.p, \
-                (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p)
+                (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p, (const TileStat *)(c->tile ? c->tile_stat.p : nullptr))
             switch (p.full_level) {
             case 1: launch_wide_level(1); break;
             case 2: launch_wide_level(2); break;
@@ -1383,7 +1406,9 @@ int l2r_sync(l2r_ctx *c)
         HIP_TRY(hipMemcpyAsync(&redo_n, c->totals.p + 3, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->lists_empty = lc[4] == 0u && lc[6] == 0u && lc[7] == 0u;
-        c->lists_heavy = 2ull * ((unsigned long long)lc[4] + lc[6] + lc[7]) > (unsigned long long)c->n_tiles;
+        // (with k_tile's WIDE instance the 64-bit-mask tiles are no burden of the tile path)
+        c->lists_heavy = 2ull * ((unsigned long long)lc[4] + (c->wide_direct ? 0u : lc[6]) + lc[7]) > (unsigned long long)c->n_tiles;
+        c->n_wide_tiles = lc[6]; c->wide_rest_empty = lc[5] == 0u;
         c->redo_empty = redo_n == 0u;
         c->lists_known = true;
     }

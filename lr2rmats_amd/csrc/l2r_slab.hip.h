@@ -127,6 +127,7 @@ struct SlabArgs {
     uint32_t *lb_err, *fb_list;
     SjDir sj;                                            // the junction table's directories and rows (k_tile's junction check)
     uint32_t has_wide_keys;                              // the annotation has dictionary keys in several entries (SE_WIDE)
+    uint32_t wide_direct_on;                             // one-kernel tile path: k_tile's WIDE instance takes the exact 64-bit-mask tiles straight from their CIGARs
     uint32_t *exon_total;                                // the run's exon count (k_tile: written by the last tile)
 };
 typedef const __attribute__((address_space(4))) SlabArgs *SlabArgsK;
@@ -759,6 +760,14 @@ struct SlabRows { SlabRow last, x[SLAB_AHEAD]; };        // a column's row 0 (th
 // 64 VGPRs: 0.594 -- 17 spilled registers and 13 % more tiles.)
 constexpr int SLAB_POS_CAP = 2536;                       // (k_probe_slab's LDS = 23040 bytes = 45 granules of 512: 7 workgroups per CU exactly; 2416 before: 1.1 % more tiles)
 constexpr int TILE_POS_CAP = 2400;                       // ... of k_tile (l2r_tile.hip.h), which also keeps the reads' counts and places there: what the upload cuts the tiles of short CIGARs by
+// One-kernel tile path: a tile of the 64-bit-mask kernel that k_tile's WIDE instance classifies straight from its CIGARs (the plain
+// instance returns at once for it, k_probe_slab_wide skips it): exact under the run's thresholds -- its reads' places are in their slot
+// records, its exon count is known since k_describe_scan -- and no more exons than the staged positions hold.
+__device__ __forceinline__ bool tile_wide_direct(uint32_t on, uint32_t flags, uint32_t chunk_on, const TileStat &st, uint32_t n_act, int min_exon, int min_intron, int max_delet, int ablate)
+{
+    return on != 0u && (flags & TD_WIDE) != 0u && !(chunk_on && slab_tile_is_chunked(flags)) && tile_exact(st, min_exon, min_intron, max_delet) && !(ablate & 256) &&
+           n_act + (uint32_t)st.n_ops_n <= (uint32_t)TILE_POS_CAP;
+}
 constexpr uint32_t SLAB_POS_SKIP = 0xffffffffu;          // A of a position that was written directly (a staged start is below 2^18 - 1)
 struct SlabStage { uint32_t *A; uint16_t *Ln; uint32_t loc; int32_t lo; bool fits; };          // loc: the lane's first position, lo: the tile's first start
 

@@ -31,6 +31,7 @@
 //
 // -e < 1 and long CIGARs keep the two-kernel path (l2r_slab.hip.h).
 #pragma once
+#include <type_traits>
 #include "l2r_chunk.hip.h"
 
 namespace l2r {
@@ -107,6 +108,7 @@ void k_tile_index(TileRec *__restrict__ rec, TileStat *__restrict__ stat, SlotRe
         // the read's place among the tile's exons in read order if every N operation is an intron and nothing is dropped
         uint32_t tot_x;
         const uint32_t loc = block_exclusive_scan(active ? (uint32_t)n_n + 1u : 0u, s_wave, tot_x);
+        if (__syncthreads_or(active && n_n + 1 >= 255)) min_seg = INT32_MIN;      // (a read of 255 exons or more: never an exact tile -- k_tile counts it and gives it the slab form)
         if (tot_x >= SLOT_LOC_LIMIT) min_seg = INT32_MIN;         // (places the record cannot say: the tile counts in k_tile -- it keeps the slab form anyway)
         // the counting sort of k_walk_slab (64 bins by CIGAR length, threads without a read last)
         if (i < (uint32_t)WAVE) s_hist[i] = 0u;
@@ -203,6 +205,9 @@ constexpr int TILE_AHEAD = L2R_TILE_AHEAD;
 #endif
 #ifndef L2R_TILE_NE
 #define L2R_TILE_NE 2
+#endif
+#ifndef L2R_WIDE_WGS
+#define L2R_WIDE_WGS 6
 #endif
 #ifndef L2R_TILE_PRIO
 #define L2R_TILE_PRIO 1
@@ -344,6 +349,149 @@ __device__ __forceinline__ SlabVerdict tile_classify(PipeArgsK a, const TileDesc
     return SlabVerdict{info, ref, redo};
 }
 
+// ---- the same for a tile whose window holds 33 .. 63 transcripts (k_tile<..., WIDE>): 64-bit masks, 24-byte entries
+// probe_all64 (l2r_wide.hip.h) for keys that may come in several entries (SE_WIDE: the key's transcripts lie more than 64 apart in the
+// annotation): the parts' masks are ORed, each re-based to the window -- a part that has nothing to say about it re-bases to nothing
+// (k_probe_slab_chunked's rule, probe_parts64); such a tile need not be handed on.
+__device__ __forceinline__ void probe_or64(const WEnt *ent, uint32_t lo, uint32_t hi, int32_t k1, int32_t k2, m64_t &pm, m64_t &sm)
+{
+    pm = 0ull; sm = 0ull;
+    for (uint32_t r = lo; r < hi; ++r) {
+        const WEnt q = ent[r];
+        if (q.k1 == k1) { sm |= q.sm; if (q.k2 == k2) pm |= q.pm; }
+    }
+}
+// map_exons_lds on 64-bit masks (map_exons_slab64 with the exons at their read-order positions in LDS)
+__device__ __forceinline__ SiteMasks64 map_exons_lds_wide(const WideLds &L, const TileDesc &d, bool mapping, uint32_t n, m64_t vpre, const SlabStage &st, int dis, int rs, int re)
+{
+    SiteMasks64 m{~0ull, 0ull, 0ull, 0ull, 0ull};
+    uint32_t *const Ap = st.A + st.loc; uint16_t *const Lp = st.Ln + st.loc;
+    const uint32_t none = (uint32_t)d.nbk + 1u;         // a bucket behind the staged ones: the staging leaves it empty
+    const int k_max = wave_max(mapping ? (int)n : 0);
+    const uint32_t nm1 = mapping ? n - 1u : 0u;
+    SlabRow cur{Ap[0]}, nxt{Ap[min(1u, nm1)]};
+    for (int k = 0; k < k_max; ++k) {
+        const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
+        const SlabRow nn{Ap[min((uint32_t)k + 2u, nm1)]};             // (behind the last exon: that one again -- live or rewritten, not used)
+        const int s = slab_row_start(cur, st.lo), e = slab_row_end(cur, st.lo), s2 = slab_row_start(nxt, st.lo);
+        const uint32_t cw = cur.w;
+        m64_t xm, am, jm, dm;
+        if (dis > 0) {                                  // (wave-uniform: -d)
+            uint32_t ls, hs, le, he;
+            near_range(L.dir0, d.b_off, none, live, s, dis, ls, hs); near_range(L.dir1, d.b_off, none, junc, e, dis, le, he);
+            probe_near64(L.ent0, ls, hs, s, e, dis, rs, re, xm, am, m.amb);
+            probe_near64(L.ent1, le, he, e, s2, dis, rs, re, jm, dm, m.amb);
+        } else {
+            const uint32_t is = live ? min((uint32_t)((s >> SITE_SHIFT) + d.b_off), none) : none;
+            const uint32_t ie = junc ? min((uint32_t)((e >> SITE_SHIFT) + d.b_off), none) : none;
+            const uint32_t ls = L.dir0[is], hs = L.dir0[is + 1u], le = L.dir1[ie], he = L.dir1[ie + 1u];
+            probe_or64(L.ent0, ls, hs, s, e, xm, am);
+            probe_or64(L.ent1, le, he, e, s2, jm, dm);
+        }
+        const m64_t amj = junc ? am : 0ull;
+        uint32_t word = first_member64(xm & vpre);
+        word |= first_member64(jm & vpre) << 6;
+        word |= ((dm & vpre) ? 1u : 0u) << 12;
+        word |= ((amj & vpre) ? 1u : 0u) << 13;
+        m.kand &= junc ? (am & dm) : ~0ull;            // Q1: the acceptor probed with exon k is ITS OWN start, k < n-1
+        m.kor |= amj | dm;
+        if (dis <= 0) { if (k == 0) m.dm_first = dm;
+                        m.am_last = (live && !junc) ? am : m.am_last; }
+        if (live) { Ap[k] = (cw & SLAB_REL_MASK) | (word << SLAB_REL_BITS); Lp[k] = (uint16_t)(cw >> SLAB_REL_BITS); }
+        cur = nxt; nxt = nn;
+    }
+    return m;
+}
+// slab_stage_dict on 64-bit masks (k_probe_slab_wide's staging): entries re-based to the tile's window, byte directories
+__device__ __forceinline__ void wide_stage_dict(const TileDesc &d, const DictRegs &dv, const int *win, WEnt *s_ent0, WEnt *s_ent1, uint8_t *s_dir0, uint8_t *s_dir1, uint8_t *s_rdir)
+{
+    const int w_n = (int)d.n_win;
+    if ((int)threadIdx.x < WIDE_KEY_CAP) {
+        const bool has_st = threadIdx.x < d.st_nk, has_en = threadIdx.x < d.en_nk;
+        WEnt e0, e1;
+        e0.k1 = dv.xa.x; e0.k2 = dv.xa.y; e1.k1 = dv.xc.x; e1.k2 = dv.xc.y;
+        const m64_t pm0 = ((m64_t)(uint32_t)dv.xb.y << 32) | (uint32_t)dv.xb.x, sm0 = ((m64_t)(uint32_t)dv.xb.w << 32) | (uint32_t)dv.xb.z;
+        const m64_t pm1 = ((m64_t)(uint32_t)dv.xd.y << 32) | (uint32_t)dv.xd.x, sm1 = ((m64_t)(uint32_t)dv.xd.w << 32) | (uint32_t)dv.xd.z;
+        if (d.flags & TD_CONTIG) {
+            e0.pm = rebase64(pm0, dv.xa.z - d.j_lo); e0.sm = rebase64(sm0, dv.xa.z - d.j_lo);
+            e1.pm = rebase64(pm1, dv.xc.z - d.j_lo); e1.sm = rebase64(sm1, dv.xc.z - d.j_lo);
+        } else {
+            m64_t mm[4] = {pm0, sm0, pm1, sm1};
+            rebase_gaps64(win, w_n, mm, dv.xa.z, dv.xc.z);
+            e0.pm = mm[0]; e0.sm = mm[1]; e1.pm = mm[2]; e1.sm = mm[3];
+        }
+        if (has_st) s_ent0[threadIdx.x] = e0;
+        if (has_en) s_ent1[threadIdx.x] = e1;
+    }
+    if (d.nbk > 0) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int i = (int)threadIdx.x + qq * TILE_THREADS;
+            if (i <= d.nbk) {
+                s_dir0[i] = (uint8_t)(dv.dd[0][qq] - d.st_r0); s_dir1[i] = (uint8_t)(dv.dd[1][qq] - d.en_r0);
+                s_rdir[i] = (uint8_t)(dv.dd[2][qq] - d.st_r0);
+            }
+        }
+    }
+    if (threadIdx.x < 3u && (threadIdx.x > 0u || d.nbk == 0)) {
+        s_dir0[d.nbk + (int)threadIdx.x] = (uint8_t)d.st_nk; s_dir1[d.nbk + (int)threadIdx.x] = (uint8_t)d.en_nk;
+    }
+}
+// tile_classify on 64-bit masks
+template <int LEVEL, bool DIS>
+__device__ __forceinline__ SlabVerdict tile_classify_wide(PipeArgsK a, const TileDesc &d, const WideLds &L, const m64_t *tilemask,
+                                                         bool active, uint32_t pre, bool big, uint32_t r, const ReadEnds &re, const SlabStage &st)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const bool fast = (d.flags & TD_WIDE) != 0;
+    const int w_n = fast ? (int)d.n_win : 0;
+    const uint32_t n = pre >> PRE_N_SHIFT;
+    const bool rev_in = (pre & PRE_REV) != 0u;
+    uint32_t info = n << 8; int ref = -1;
+    bool redo = active && (!fast || big || (n > 1 && (pre & PRE_INSANE) != 0u));
+    const bool work = active && !redo;
+    const VisitMasks64 vm = visit_window64<LEVEL>(L, d, w_n, work, n, d.j_lo, re, tilemask);
+    redo = redo || vm.redo;
+    const bool mapping = work && !redo && n > 1;
+    const int dis = DIS ? a->f.p.ss_dis : 0;
+    const SiteMasks64 sm = map_exons_lds_wide(L, d, mapping, n, vm.vpre, st, dis, re.s0, re.el);
+    if (active && !mapping) {
+        // no probe round has rewritten this read's row words: {start, flags 0} and the length apart, as the write-out reads them
+        uint32_t *const Ap = st.A + st.loc; uint16_t *const Lp = st.Ln + st.loc;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t w = Ap[k];
+            Ap[k] = big ? SLAB_POS_SKIP : (w & SLAB_REL_MASK); Lp[k] = (uint16_t)(w >> SLAB_REL_BITS);
+        }
+    }
+    if (DIS && mapping && (sm.amb & vm.vpre) != 0ull) redo = true;
+    if (work && !redo) {
+        uint32_t *const Ap = st.A + st.loc;
+        const uint16_t *const Lq = st.Ln + st.loc;
+        ReadEnds re2;
+        re2.s0 = st.lo + (int)(Ap[0] & SLAB_REL_MASK); re2.e0 = re2.s0 + (int)Lq[0] - 1;
+        re2.sl = st.lo + (int)(Ap[n - 1u] & SLAB_REL_MASK); re2.el = re2.sl + (int)Lq[n - 1u] - 1;
+        const Verdict vd = decide64<LEVEL>(L, d, n, re2, vm, sm, rev_in, [&](int k) { return Ap[k] >> SLAB_REL_BITS; },
+                                           [&](int k, uint32_t f) { Ap[k] = (Ap[k] & SLAB_REL_MASK) | (f << SLAB_REL_BITS); });
+        info = vd.info; ref = vd.ref;
+    } else if (work && mapping) {
+        // (probed, then found ambiguous: the work words go, flags 0 -- the generic kernel writes them)
+        uint32_t *const Ap = st.A + st.loc;
+        for (uint32_t k = 0; k < n; ++k) Ap[k] &= SLAB_REL_MASK;
+    }
+    redo = redo && active;
+    {
+        const unsigned long long m = __ballot(redo);
+        if (m) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(a->f.redo_count, (uint32_t)__popcll(m));
+            at = __shfl(at, 0, WAVE);
+            if (redo) a->f.redo[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+        }
+    }
+    if (active) a->f.ref_tx[r] = ref;                           // (info: by the caller, behind the junction check)
+    return SlabVerdict{info, ref, redo};
+}
+
 // LDS of k_tile beside the staged positions, dictionary slices, directories and window record of k_probe_slab: the reads' exon counts
 // (one byte each, read order) and their exclusive scan (16 bit).
 constexpr int TILE_LDS_BYTES = TILE_POS_CAP * 6 + 2 * SLAB_KEY_CAP * 16 + SLAB_AUX_BYTES + TILE_THREADS * 3 + 16 * 4 + 4 * 4;
@@ -354,16 +502,23 @@ static_assert(TILE_POS_CAP < 65536 && TILE_POS_CAP % 8 == 0, "16-bit places; 16-
 constexpr int SJ_STAGE = 2 * SLAB_KEY_CAP * 16 / 12;    // junction rows k_tile stages per tile: {donor, acceptor, running maximum of the acceptors} over the dead dictionary slices
 static_assert(SLAB_AUX_BYTES >= (SJ_STAGE / 32 + 2 * 4 + 2) * 4 && SLAB_AUX_BYTES >= TILE_THREADS * 5 && 2 * SLAB_KEY_CAP * 16 >= TILE_POS_CAP,
               "the junction check's arrays fit the dead dictionary slices / directories");
-template <int LEVEL, bool ACC, bool DIS>
-__global__ __launch_bounds__(TILE_THREADS, 7)
+// WIDE: the instance for the tiles of the 64-bit-mask kernel that tile_wide_direct (l2r_slab.hip.h) names -- launched behind the plain
+// instance over wide_list (one workgroup per entry): the same tile, with 64-bit masks, 24-byte entries, a 63-member window record, at 5
+// workgroups per CU.  The plain instance returns at once for those tiles instead of giving them the slab form.
+template <int LEVEL, bool ACC, bool DIS, bool WIDE = false>
+__global__ __launch_bounds__(TILE_THREADS, WIDE ? L2R_WIDE_WGS : 7)
 void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const TileWin *__restrict__ u_tw, const TileStat *__restrict__ u_stat, const SlotRec *__restrict__ u_slot,
             uint32_t *__restrict__ u_xbase)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
+    using WinT = typename std::conditional<WIDE, TileWin64, TileWin>::type;
+    using EntT = typename std::conditional<WIDE, WEnt, v4i_t>::type;
+    constexpr int AUX_BYTES = SLAB_DIR_BYTES + (int)sizeof(WinT);
+    static_assert(AUX_BYTES >= SLAB_AUX_BYTES && WIDE_KEY_CAP == SLAB_KEY_CAP, "the WIDE instance's arrays hold what the plain one's do");
     __shared__ __attribute__((aligned(16))) uint32_t s_A[TILE_POS_CAP];
     __shared__ __attribute__((aligned(16))) uint16_t s_L[TILE_POS_CAP];
-    __shared__ __attribute__((aligned(16))) v4i_t s_ent[2 * SLAB_KEY_CAP];
-    __shared__ __attribute__((aligned(16))) uint8_t s_aux[SLAB_AUX_BYTES];       // directories, then the window record
+    __shared__ __attribute__((aligned(16))) EntT s_ent[2 * SLAB_KEY_CAP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_aux[AUX_BYTES];            // directories, then the window record
     __shared__ __attribute__((aligned(16))) uint8_t s_cnt[TILE_THREADS];        // exon counts, read order (255: that many or more)
     __shared__ __attribute__((aligned(16))) uint16_t s_loc[TILE_THREADS];       // ... and their exclusive scan
     __shared__ uint32_t s_flagw[TILE_THREADS / WAVE], s_redow[TILE_THREADS / WAVE];
@@ -371,13 +526,14 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     __shared__ uint32_t s_chunk[2];
     // (in a tile that keeps the slab form the staged positions hold slab_walk_tile's words)
     uint8_t *const s_dir = s_aux;
-    TileWin &s_tw = *reinterpret_cast<TileWin *>(s_aux + SLAB_DIR_BYTES);
+    WinT &s_tw = *reinterpret_cast<WinT *>(s_aux + SLAB_DIR_BYTES);
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    const uint32_t t = fused_tile(blockIdx.x);
-    if (t >= sa->n_tiles) return;
+    uint32_t t;
+    if (WIDE) { if (blockIdx.x >= sa->list_cnt[0]) return; t = sa->wide_list[blockIdx.x]; }
+    else { t = fused_tile(blockIdx.x); if (t >= sa->n_tiles) return; }
     // diagnostics (L2R_STAMPS=1), wave 0: [0] records, CIGAR heads asked for, staging  [1] (count walk + barrier)  [6] scan, count
     // published, place walk  [2] window pass  [3] probe rounds  [4] verdicts  [7] the tile's first slot (exon counts in front)  [5] write-out
     SlabStamp stamp; stamp.start(a->f.stamps); if (stamp.who == 3) stamp.who = -1;
@@ -393,7 +549,7 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     // The tile's record from the upload and its descriptor from k_describe_scan: every scalar load of the prologue leaves before the
     // first one is waited for (see k_probe_slab).
     const TileRec rec = u_rec[t];
-    const TileDesc d0 = u_tw[t].d;
+    const TileDesc d0 = WIDE ? sa->tw64[t].d : u_tw[t].d;
     const TileStat tst = u_stat[t];
     const uint32_t chunk_on = sa->chunk_on; const int32_t ablate = a->f.p.ablate;
     const uint32_t n_tiles = sa->n_tiles;
@@ -403,13 +559,17 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     const int32_t tid0 = rec.tid0, pos0 = rec.lo - 1;
     const int32_t tile_lo = rec.lo;                              // the base of the tile's row words: its first read's first base
     // a tile of the 64-bit-mask or the chunked kernel (on their lists since k_describe_scan): slab form, nothing is staged here
-    const bool pre_slab = (d0.flags & TD_WIDE) != 0u || (chunk_on && slab_tile_is_chunked(d0.flags));
+    const bool pre_slab = !WIDE && ((d0.flags & TD_WIDE) != 0u || (chunk_on && slab_tile_is_chunked(d0.flags)));
     // The tile is EXACT: no threshold is borderline in it, so a read's exon count is 1 + its N operations (the upload's read_n) and
     // the tile's count is known to the later tiles since k_describe_scan -- no count walk, nothing to publish.
     const bool counted = tile_exact(tst, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet) && !(ablate & 256);
+    {   // (a wide tile that the WIDE instance takes whole, behind this launch: nothing of it happens in the plain one -- and the other way round)
+        const bool direct = tile_wide_direct(sa->wide_direct_on, d0.flags, chunk_on, tst, n_act, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet, ablate);
+        if (WIDE ? !direct : direct) return;
+    }
     TileDesc d = d0;
     if (pre_slab) d.flags = 0u;
-    v4i_t *const s_ent0 = s_ent, *const s_ent1 = s_ent + SLAB_KEY_CAP;
+    EntT *const s_ent0 = s_ent, *const s_ent1 = s_ent + SLAB_KEY_CAP;
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
     // A first look at the exon counts in front of the tile (waves 0 .. 2, one level each): asked for here, looked at further down.
     // PLAIN loads: what k_describe_scan wrote (the launch in front) is visible to them, and a word is complete only once -- a stale
@@ -421,7 +581,8 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     // the dictionary slices and the window record: they travel while the CIGAR heads are asked for
     const DictRegs dv = load_dict_slices(a, d);
     int4 twv = make_int4(0, 0, 0, 0);
-    if ((int)threadIdx.x < SLAB_TW_VECS && tw_vec_used((int)threadIdx.x, (d.flags & TD_FAST) ? d.n_win : 0u)) twv = reinterpret_cast<const int4 *>(u_tw + t)[threadIdx.x];
+    if (WIDE) { if ((int)threadIdx.x < WIDE_TW_VECS) twv = reinterpret_cast<const int4 *>(sa->tw64 + t)[threadIdx.x]; }
+    else if ((int)threadIdx.x < SLAB_TW_VECS && tw_vec_used((int)threadIdx.x, (d.flags & TD_FAST) ? d.n_win : 0u)) twv = reinterpret_cast<const int4 *>(u_tw + t)[threadIdx.x];
     // ---- the thread's slot record (asked for at the top of the kernel) and the head of its read's CIGAR: six 16-byte vectors, all in
     //      flight at once; words behind the last op become "I, length 0"
     const uint32_t c_lo = srec.x, xs = srec.z;
@@ -449,10 +610,10 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
         first_share = wave_sum(in ? (uint32_t)ev : 0u);
     }
     // ---- window and dictionary slices into LDS, re-based to the tile's window (the CIGAR words travel)
-    if (!pre_slab && (int)threadIdx.x < SLAB_TW_VECS) reinterpret_cast<int4 *>(&s_tw)[threadIdx.x] = twv;
-    const SlabLds S{nullptr, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir};
+    if (!pre_slab && (int)threadIdx.x < (WIDE ? WIDE_TW_VECS : SLAB_TW_VECS)) reinterpret_cast<int4 *>(&s_tw)[threadIdx.x] = twv;
     int my_wide = 0;
-    if (!pre_slab) my_wide = slab_stage_dict(d, dv, reinterpret_cast<const int *>(u_tw[t].win), S);
+    if constexpr (WIDE) wide_stage_dict(d, dv, reinterpret_cast<const int *>(sa->tw64[t].win), s_ent0, s_ent1, s_dir0, s_dir1, s_rdir);
+    else if (!pre_slab) my_wide = slab_stage_dict(d, dv, reinterpret_cast<const int *>(u_tw[t].win), SlabLds{nullptr, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir});
     stamp.mark(0);
 #pragma unroll
     for (int i = 0; i < SLAB_HEAD; ++i) cg[i] = (uint32_t)i < n_cig ? cg[i] : 1u;
@@ -465,7 +626,7 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     //      annotation has dictionary keys in several entries (rare: a site shared by transcripts more than 64 apart): whether this
     //      tile staged one is every wave's business.
     uint32_t n = 0u;
-    const bool meet = !pre_slab && (!counted || sa->has_wide_keys != 0u);       // (else the waves meet behind the place walk: the staged slices must be whole before the probes)
+    const bool meet = !WIDE && !pre_slab && (!counted || sa->has_wide_keys != 0u);       // (else the waves meet behind the place walk: the staged slices must be whole before the probes)
     if (!pre_slab && !counted) {
         if (active) {
             int start = pos + 1, end = pos;
@@ -579,7 +740,9 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     const uint32_t r = r0 + idx;
     // ---- classification (a lane probes the positions it has placed itself; the dictionary slices were whole at the barrier above)
     __builtin_amdgcn_s_setprio(0);
-    SlabVerdict vd = tile_classify<LEVEL, DIS>(a, d, S, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, big, r, re, st, any_wide, stamp);
+    SlabVerdict vd;
+    if constexpr (WIDE) vd = tile_classify_wide<LEVEL, DIS>(a, d, WideLds{s_ent0, s_ent1, s_dir0, s_dir1, s_rdir, s_tw.hk, s_tw.hx, s_tw.win}, s_tw.mask, active, pre, big, r, re, st);
+    else vd = tile_classify<LEVEL, DIS>(a, d, SlabLds{nullptr, s_ent0, s_ent1, s_dir0, s_dir1, s_rdir}, s_tw.hk, s_tw.hx, s_tw.win, s_tw.mask, active, pre, big, r, re, st, any_wide, stamp);
     __builtin_amdgcn_s_setprio(TILE_PRIO);
     if (ACC) { const int w_redo = __any(vd.redo) ? 1 : 0; if (lane == 0) s_redow[wv] = (uint32_t)w_redo; }
     // ---- short-read junction support (-j: src/update_gtf.c:698-709 check_with_short_sj, :609-627 check_short_sj) for the reads whose
@@ -824,7 +987,8 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     };
     // (For its register allocation the compiler lays the two forms of a tile out one behind the other -- "the staged form, then, if a flag
     //  says so, the slab form" -- whatever the order here: what the slab form needs is alive through the staged form's probe rounds.)
-    if (!(pre_slab || late_slab)) { staged_form(); return; }
+    if (WIDE || !(pre_slab || late_slab)) { staged_form(); return; }
+    if constexpr (!WIDE) {
     // ---- the tile keeps the slab form: k_walk_slab's body on the CIGAR registers (its LDS words behind the sort's arrays, which a
     //      slower wave may still be reading), then the tile's first slot and the list of the kernel that takes it
     // (the thread's slot once more, from a tile number the compiler cannot recognise: kept from above it would be spilled through the staged form)
@@ -870,7 +1034,8 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
         if (!pre_slab) {
             if (wide_key && chunk_on) { sa->tw[t].d.flags = d0.flags | TD_CHUNK; sa->chunk_list[atomicAdd(sa->list_cnt + 1, 1u)] = t; }
             else sa->fb_list[atomicAdd(sa->list_cnt + 4, 1u)] = t;
-        }
+        } else if (d0.flags & TD_WIDE) sa->wide_list[n_tiles + 1u + atomicAdd(sa->list_cnt + 5, 1u)] = t;      // (k_probe_slab_wide's, behind the WIDE instance's tiles)
+    }
     }
 
 }

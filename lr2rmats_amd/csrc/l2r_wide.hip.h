@@ -267,7 +267,7 @@ struct WideArgs { const TileWin64 *tw64; };            // tw64[tile]: the 64-mem
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, 5)
 void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__restrict__ u_tile_first, const int32_t *__restrict__ u_pos, const uint32_t *__restrict__ u_tile_sbase,
-                       const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase)
+                       const TileWin *__restrict__ u_tw, const uint32_t *__restrict__ u_xbase, const TileStat *__restrict__ u_stat /* one-kernel tile path, else null */)
 {
     constexpr int DIR_BYTES = FAST_DIR_BYTES;
     __shared__ __attribute__((aligned(16))) uint32_t s_A[SLAB_POS_CAP];
@@ -284,14 +284,17 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
     uint8_t *const s_dir0 = s_dir, *const s_dir1 = s_dir + DIR_BYTES, *const s_rdir = s_dir + 2 * DIR_BYTES;
     // the tiles of this kernel: wide_list (TileLists), taken from a cursor -- they differ in cost; a workgroup's FIRST entry is its
     // own number: an empty list costs no atomic
-    const uint32_t n_wide = sa->list_cnt[0];
+    // (one-kernel tile path: the wide tiles k_tile has given the slab form -- its list behind wide_list, list_cnt[5] entries; the others
+    //  are its WIDE instance's)
+    const uint32_t *const w_list = u_stat ? sa->wide_list + sa->n_tiles + 1u : sa->wide_list;
+    const uint32_t n_wide = u_stat ? sa->list_cnt[5] : sa->list_cnt[0];
     for (bool own = true;; own = false) {
         if (own && blockIdx.x >= n_wide) break;
         if (threadIdx.x == 0) s_next = own ? blockIdx.x : gridDim.x + atomicAdd(sa->list_cnt + 2, 1u);
         __syncthreads();
         const uint32_t wi = s_next;
         if (wi >= n_wide) break;
-        const uint32_t t = sa->wide_list[wi];
+        const uint32_t t = w_list[wi];
         const uint32_t tflags = u_tw[t].d.flags;
         const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
         const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t], total = u_xbase[t + 1u] - xbase;
