@@ -24,7 +24,10 @@
 //                           to the two-kernel path).  Workgroup -> tile is blocked-cyclic over the XCDs (fused_tile: 16 consecutive
 //                           tiles per XCD share their dictionary slices in one L2).  A tile that waits in vain (LB_POLLS) sets lb_err,
 //                           which ends every other wait too: the run reports an error instead of hanging the device.
-//   tiles this kernel does not finish: windows of 33 .. 63 members / beyond (k_probe_slab_wide / _chunked: on their lists already),
+//   k_tile<..., WIDE>       the same kernel with 64-bit masks, 24-byte entries and the 63-member window record, one workgroup per entry of
+//                           wide_list behind the plain instance: the windows of 33 .. 63 transcripts (tile_wide_direct, l2r_slab.hip.h: exact
+//                           tiles; the plain instance returns at once for them).
+//   tiles this kernel does not finish: windows beyond 63 members and the wide ones that are not exact (k_probe_slab_chunked / _wide),
 //                           a dictionary key in several entries, a read of 255 exons or more, more exons than the staged positions
 //                           hold (only outliers make such tiles).  For those the workgroup runs k_walk_slab's tile body instead
 //                           (slab_walk_tile: slab rows, reads' words, span record) and lists the tile for k_probe_slab (fb_list).
