@@ -477,3 +477,39 @@ def test_junction_check_in_blocks_of_more_exons_than_the_mapped_positions(oracle
     for _ in range(3):                                              # (stale LDS: what the positions hold differs from launch to launch)
         got, want = _run(oracle, af, reads, sj=sj, full_level=5, split_trans=split, min_sj_cnt=1)
     assert ((want.info & 32) != 0).sum() > 200 and ((want.info & 16) != 0).sum() > 20 and ((want.info & 64) != 0).sum() > 20
+
+
+@pytest.mark.parametrize("route", ["wide_instance", "slab_form", "inexact"])
+def test_wide_tiles_on_every_route_of_the_tile_path(oracle, monkeypatch, route):
+    """A locus of 40 isoforms on the one-kernel tile path: its tiles (windows of 33 .. 63 transcripts) are classified by k_tile's WIDE
+    instance straight from their CIGARs (default), by k_probe_slab_wide from the slab form k_tile gives them (L2R_WIDE_DIRECT=0), and --
+    with a threshold that is borderline inside the tiles (-i 450 against introns of 380 .. 24 500 bases: the tiles are not exact) -- by the
+    slab form again although the WIDE instance is on.  Exact on each."""
+    monkeypatch.setenv("L2R_PIPELINE", "tile")
+    if route == "slab_form":
+        monkeypatch.setenv("L2R_WIDE_DIRECT", "0")
+    rng = np.random.default_rng(4040)
+    pool = [(50_000 + 500 * k, 50_000 + 500 * k + 120) for k in range(26)]
+    txs = []
+    for t in range(40):
+        keep = sorted(set([0, 25] + list(rng.choice(np.arange(1, 25), size=int(rng.integers(5, 16)), replace=False))))
+        txs.append((0, t & 1, [pool[k] for k in keep]))
+    af = _anno(txs)
+    rows = []
+    for i in range(6000):
+        t = txs[int(rng.integers(len(txs)))][2]
+        a = int(rng.integers(0, len(t) - 2))
+        ex = [list(x) for x in t[a:a + int(rng.integers(2, 9))]]
+        if i % 3 == 0:
+            ex[-1][1] -= int(rng.integers(0, 40))
+        if i % 7 == 0 and len(ex) > 2:
+            del ex[1]
+        p, ops = _chain([tuple(x) for x in ex])
+        rows.append((0, p, i & 1, ops))
+    cnt = [0, 0, 0, 0, 0]
+    kw = dict(full_level=3)
+    if route == "inexact":
+        kw["min_intron"] = 450
+    got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, **kw)
+    assert ((want.info & 2) != 0).sum() > 1000
+    assert cnt[4] >= 15 and cnt[0] <= 300, cnt              # the locus's tiles are 64-bit-mask tiles, (almost) nothing on the redo list
