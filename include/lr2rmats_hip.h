@@ -162,7 +162,7 @@ typedef struct {
  *     tile    (coordinate-sorted records with short CIGARs, -e >= 1; default where it applies)  0 k_describe_scan (the tiles' descriptors
  *             and windows from the spans the upload recorded; first kernel of the run)  1 k_tile (CIGAR -> exons, window, probes, verdicts,
  *             junction check, read-order results: one workgroup per tile, nothing handed over through HBM)  2 k_probe_slab for the few
- *             tiles k_tile left in slab form + k_probe_slab_wide + k_probe_slab_chunked (not launched once a run has shown their lists empty)
+ *             tiles k_tile left in slab form + k_tile's WIDE instance (windows of 33 .. 63 transcripts) + k_probe_slab_wide + k_probe_slab_chunked (not launched once a run has shown their lists empty)
  *     classic (unsorted records, long CIGARs with -e < 1, L2R_PIPELINE=classic)  0 k_pass_a  1 k_scan_u32 (tile sums)  2 k_classify_fast */
 #define L2R_N_STAGES 8
 typedef struct {
