@@ -248,14 +248,18 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, const uint32_t *__restrict__ u
     WEnt *const s_ent0 = s_ent, *const s_ent1 = s_ent + CHUNK_KEY_CAP;
     uint32_t *const X0 = s_dir, *const X1 = s_dir + DIR_N, *const XR = s_dir + 2 * DIR_N;
     // the tiles of this kernel: chunk_list (TileLists + what the one-window kernels appended), taken from a cursor
-    const uint32_t n_list = min(sa->list_cnt[1], (uint32_t)sa->n_tiles);
+    // (... = the entries k_describe_scan / TileLists made, then the ones the one-window kernels appended late: chunk_list_append_late)
+    const uint32_t n_first = min(sa->list_cnt[1], (uint32_t)sa->n_tiles), n_list = n_first + min(sa->list_cnt[8], (uint32_t)sa->n_tiles);
     for (bool own = true;; own = false) {
         if (own && blockIdx.x >= n_list) break;
         if (threadIdx.x == 0) s_next = own ? blockIdx.x : gridDim.x + atomicAdd(sa->list_cnt + 3, 1u);
         __syncthreads();
         const uint32_t wi = s_next;
         if (wi >= n_list) break;
-        const uint32_t t = sa->chunk_list[wi];
+        const uint32_t t = wi < n_first ? sa->chunk_list[wi] : sa->chunk_list[sa->n_tiles + 1u + (wi - n_first)];
+        // (one-kernel tile path: k_tile_chunk, l2r_tchunk.hip.h, has taken the tile from its CIGARs -- the same test as there)
+        if (sa->chunk_direct_on && tile_chunk_direct(1u, sa->tile_flags[t], sa->chunk_on, u_tw[t].d, sa->tile_stat[t], u_tile_first[t + 1u] - u_tile_first[t],
+                                                     a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet, a->f.p.ss_dis, a->f.p.ablate)) { __syncthreads(); continue; }
         const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
         const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t], total = u_xbase[t + 1u] - xbase;
         const int32_t tile_lo = u_pos[r0] + 1;

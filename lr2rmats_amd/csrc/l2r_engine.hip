@@ -20,7 +20,7 @@
 #include "l2r_window.hip.h"
 #include "l2r_slab.hip.h"
 #include "l2r_chunk.hip.h"
-#include "l2r_tile.hip.h"
+#include "l2r_tchunk.hip.h"
 #include "l2r_filter.hip.h"
 
 using namespace l2r;
@@ -76,6 +76,9 @@ struct l2r_ctx {
     bool lists_heavy = false;                           // ... or most tiles went to them (an isoform-rich annotation): k_tile would only walk for them, which k_walk_slab does faster -- later runs take the slab pipeline
     bool redo_empty = false;                            // ... and nothing to the generic kernel either: every read had its junction check in k_tile, k_validate_sj has nothing to do
     bool wide_direct = true;                            // L2R_WIDE_DIRECT=0: the exact 64-bit-mask tiles keep the slab form and k_probe_slab_wide (k_tile's WIDE instance, l2r_tile.hip.h)
+    bool chunk_direct = true;                           // L2R_CHUNK_DIRECT=0: the exact tiles of the chunked kernel keep the slab form and k_probe_slab_chunked (k_tile_chunk, l2r_tchunk.hip.h)
+    bool chunk_rest_empty = false;                      // ... and k_tile_chunk declined none, nobody appended late (list_cnt[9], [8]): k_probe_slab_chunked has nothing to do
+    uint32_t n_chunk_tiles = 0;                         // ... entries of chunk_list a completed run has left: k_tile_chunk's grid
     bool wide_rest_empty = false;                       // ... and none of them kept the slab form (list_cnt[5]): k_probe_slab_wide has nothing to do
     uint32_t n_wide_tiles = 0;                          // ... entries of wide_list a completed run has left (l2r_sync): the WIDE instance's grid
     uint32_t lb_flip = 0;                               // which of the two lb_sup arrays the next run of the tile path uses (l2r_slab.hip.h SlabArgs::lb_sup)
@@ -96,6 +99,13 @@ struct l2r_ctx {
     int anno_cache_state = 0;               // last l2r_set_annotation: 0 no cache, 1 built + stored, 2 read from the cache
     unsigned want = L2R_WANT_RESULTS | L2R_WANT_ACCEPTED;      // l2r_set_outputs
     hipStream_t stream = nullptr;
+    // one-kernel tile path: the instances of k_tile that take the isoform-rich tiles (WIDE, CHUNK) need nothing of the plain instance --
+    // their tiles' first slots are known since k_describe_scan -- and run BESIDE it on streams of their own (forked behind
+    // k_describe_scan, joined in front of the list kernels): a few thousand long-lived workgroups fill in where the plain instance's
+    // short ones leave CUs, instead of costing a launch each with a tail of its own.  L2R_SIDE=0: one behind the other on `stream`.
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    bool side_on = true;
     l2r_params prm;
     // annotation
     int64_t n_tx = 0, n_anno_exon = 0;
@@ -209,6 +219,11 @@ l2r_ctx *l2r_create(int device)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         fail(-2, "[l2r_create] hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr;
     }
+    for (int k = 0; k < 2; ++k)
+        if ((e = hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming)) != hipSuccess) {
+            fail(-2, "[l2r_create] side stream: %s", hipGetErrorString(e)); l2r_destroy(c); return nullptr;
+        }
+    if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) { fail(-2, "[l2r_create] hipEventCreate: %s", hipGetErrorString(e)); l2r_destroy(c); return nullptr; }
     // src/update_gtf.c:24-35 defaults
     c->prm = l2r_params{3, 3, 50, 0, 0x7fffffff, 5, 0, 0, 1, 0, 0.80f};
     {
@@ -227,6 +242,10 @@ l2r_ctx *l2r_create(int device)
         if (e && *e) c->anno_cache_dir = e;
         e = getenv("L2R_WIDE_DIRECT");
         if (e) c->wide_direct = atoi(e) != 0;
+        e = getenv("L2R_CHUNK_DIRECT");
+        if (e) c->chunk_direct = atoi(e) != 0;
+        e = getenv("L2R_SIDE");
+        if (e) c->side_on = atoi(e) != 0;
         e = getenv("L2R_PIPELINE");
         if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : !strcmp(e, "slab") ? 1 : 2;
     }
@@ -250,6 +269,8 @@ void l2r_destroy(l2r_ctx *c)
     c->slab_row.release(); c->dense_start.release(); c->dense_end.release(); c->s_pre.release(); c->s_loc.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
+    for (int k = 0; k < 2; ++k) { if (c->side[k]) (void)hipStreamDestroy(c->side[k]); if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -890,11 +911,11 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         if (total < 0x7ffffff0ULL && ovf < 0x7ffffff0ULL) {
             sbase[T] = (uint32_t)total;                     // (rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true;
-            if (c->tw64.ensure(T + 1) || c->wide_list.ensure(2 * (T + 1)) || c->chunk_list.ensure(T + 1) || c->list_cnt.ensure(8) || c->tile_flags.ensure(T + 8) ||
+            if (c->tw64.ensure(T + 1) || c->wide_list.ensure(2 * (T + 1)) || c->chunk_list.ensure(2 * (T + 1)) || c->list_cnt.ensure(16) || c->tile_flags.ensure(T + 8) ||
                 c->lb_tile.ensure(T + 64) || c->lb_blk.ensure(T / LB_BLK + 64) || c->lb_sup.ensure(2 * ((T >> LB_SUP_SHIFT) + 64)) || c->fb_list.ensure(T + 1) || c->tile_stat.ensure(T + 1) || c->sup_stat.ensure((T >> LB_SUP_SHIFT) + 2) ||
                 (!c->wide_cigar && c->slot_rec.ensure((T + 1) * TILE_THREADS))) return -2;
             HIP_TRY(hipMemsetAsync(c->lb_sup.p, 0, 2 * ((T >> LB_SUP_SHIFT) + 64) * 8, c->stream)); c->lb_flip = 0;      // (two arrays taking turns; from then on each is cleared by the run in front of its own)      // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB each)
-            HIP_TRY(hipMemsetAsync(c->list_cnt.p, 0, 32, c->stream));
+            HIP_TRY(hipMemsetAsync(c->list_cnt.p, 0, 64, c->stream));
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) || c->tile_total.ensure(T + 2) || c->tile_xbase.ensure(T + 2) || c->tile_span.ensure(12 * (T + 1)) ||
                 c->s_pre.ensure((size_t)N + 1) || c->s_loc.ensure((size_t)N + 1) ||
                 c->slab_row.ensure((size_t)total + 4) ||
@@ -1095,6 +1116,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         sa.sj = SjDir{CursorDir{c->sj_key.p, c->sj_cdir.p, c->sj_cbase.p, c->sj_ntid, (int32_t)c->n_sj}, c->sj_ddir.p, c->sj_dbase.p, c->sj_ntid, c->sj_row.p};
         sa.has_wide_keys = c->n_wide > 0 ? 1u : 0u;
         sa.wide_direct_on = (c->tile && c->wide_direct && c->tw64.p && !(c->ablate & 4)) ? 1u : 0u;
+        sa.chunk_direct_on = (c->tile && c->chunk_direct && sa.chunk_on) ? 1u : 0u;
         // (with the accepted list wanted and no junction table to decide later, the tiles leave their accepted chunks themselves)
         const bool probe_acc = (c->want & L2R_WANT_ACCEPTED) && (c->n_sj == 0 || c->tile);      // (k_tile decides acceptance itself, junction table or not)
 #define launch_probe_k(L, A, D, LIST, G) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab<L, A, D, LIST>), dim3(G), dim3(TILE_THREADS), 0, s, sa, (const TileSpan *)c->tile_span.p, \
@@ -1112,6 +1134,51 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             const unsigned gd = (unsigned)std::max<int64_t>((c->n_tiles + DESCRIBE_TILES - 1) / DESCRIBE_TILES, 1);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_describe_scan<true>), dim3(gd), dim3(TILE_THREADS), 0, s, sa, job, 0u, (const TileRec *)c->tile_rec.p);
             MARK(ST_SCAN1);
+            // (the three list-driven kernels behind k_tile: not launched once a completed run of the same inputs and parameters has shown
+            //  their lists empty -- what ends up on them does not depend on anything else)
+            skip_lists = c->lists_known && c->lists_empty && !getenv("L2R_LAUNCH_ALL");
+            const unsigned gl = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 2);
+            // (the WIDE instance beside the plain one, on a stream of its own: see l2r_ctx::side; with per-stage events or L2R_CHECK one behind the other)
+            const bool wide_launch = !skip_lists && sa.wide_direct_on;
+            const bool beside = c->side_on && !ev && !c->check_stages;
+            hipStream_t sw = s;
+            if (wide_launch && beside) { sw = c->side[0]; HIP_TRY(hipEventRecord(c->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(sw, c->ev_fork, 0)); }
+            if (wide_launch) {
+                // the exact 64-bit-mask tiles straight from their CIGARs: k_tile's WIDE instance, a workgroup per entry of wide_list (the
+                // list's length is known to the host once a run has completed: until then a grid for every tile, most of which leave at once)
+                const unsigned gwd = c->lists_known ? std::max(c->n_wide_tiles, 1u) : (unsigned)std::max<int64_t>(c->n_tiles, 1);
+#define launch_tw_k(L, D) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile<L, false, D, true>), dim3(gwd), dim3(TILE_THREADS), 0, sw, sa, (const TileRec *)c->tile_rec.p, (const TileWin *)c->tw.p, (const TileStat *)c->tile_stat.p, (const SlotRec *)c->slot_rec.p, c->tile_xbase.p)
+#define launch_tw_level(L) do { if (p.ss_dis > 0) launch_tw_k(L, true); else launch_tw_k(L, false); } while (0)
+                switch (p.full_level) {
+                case 1: launch_tw_level(1); break;
+                case 2: launch_tw_level(2); break;
+                case 3: launch_tw_level(3); break;
+                case 4: launch_tw_level(4); break;
+                case 5: launch_tw_level(5); break;
+                default: launch_tw_level(0); break;
+                }
+#undef launch_tw_level
+#undef launch_tw_k
+            }
+            if (wide_launch && beside) HIP_TRY(hipEventRecord(c->ev_join[0], sw));
+            // ... and the exact tiles of the chunked kernel: k_tile_chunk (l2r_tchunk.hip.h), a workgroup per entry of chunk_list
+            const bool chunk_launch = !skip_lists && sa.chunk_direct_on && !(c->lists_known && c->n_chunk_tiles == 0u);
+            hipStream_t sc = s;
+            if (chunk_launch && beside) { sc = c->side[1]; if (!wide_launch) HIP_TRY(hipEventRecord(c->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(sc, c->ev_fork, 0)); }
+            auto launch_tchunk = [&]() {
+                const unsigned gcd = c->lists_known ? std::max(c->n_chunk_tiles, 1u) : (unsigned)std::max<int64_t>(c->n_tiles, 1);
+#define launch_tc_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_chunk<L>), dim3(gcd), dim3(TILE_THREADS), 0, sc, sa, (const TileRec *)c->tile_rec.p, (const TileWin *)c->tw.p, (const TileStat *)c->tile_stat.p, (const SlotRec *)c->slot_rec.p, c->tile_xbase.p)
+                switch (p.full_level) {
+                case 1: launch_tc_level(1); break;
+                case 2: launch_tc_level(2); break;
+                case 3: launch_tc_level(3); break;
+                case 4: launch_tc_level(4); break;
+                case 5: launch_tc_level(5); break;
+                default: launch_tc_level(0); break;
+                }
+#undef launch_tc_level
+            };
+            if (chunk_launch && beside) { launch_tchunk(); HIP_TRY(hipEventRecord(c->ev_join[1], sc)); }
             const unsigned gf = fused_grid(c->n_tiles);
 #define launch_tile_k(L, A, D) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile<L, A, D>), dim3(gf), dim3(TILE_THREADS), 0, s, sa, (const TileRec *)c->tile_rec.p, (const TileWin *)c->tw.p, (const TileStat *)c->tile_stat.p, (const SlotRec *)c->slot_rec.p, c->tile_xbase.p)
 #define launch_tile_level(L) do { if (p.ss_dis > 0) { if (probe_acc) launch_tile_k(L, true, true); else launch_tile_k(L, false, true); } \
@@ -1127,27 +1194,9 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
 #undef launch_tile_level
 #undef launch_tile_k
             MARK(ST_FAST);
-            // (the three list-driven kernels behind k_tile: not launched once a completed run of the same inputs and parameters has shown
-            //  their lists empty -- what ends up on them does not depend on anything else)
-            skip_lists = c->lists_known && c->lists_empty && !getenv("L2R_LAUNCH_ALL");
-            const unsigned gl = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 2);
-            if (!skip_lists && sa.wide_direct_on) {
-                // the exact 64-bit-mask tiles straight from their CIGARs: k_tile's WIDE instance, a workgroup per entry of wide_list (the
-                // list's length is known to the host once a run has completed: until then a grid for every tile, most of which leave at once)
-                const unsigned gwd = c->lists_known ? std::max(c->n_wide_tiles, 1u) : (unsigned)std::max<int64_t>(c->n_tiles, 1);
-#define launch_tw_k(L, D) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile<L, false, D, true>), dim3(gwd), dim3(TILE_THREADS), 0, s, sa, (const TileRec *)c->tile_rec.p, (const TileWin *)c->tw.p, (const TileStat *)c->tile_stat.p, (const SlotRec *)c->slot_rec.p, c->tile_xbase.p)
-#define launch_tw_level(L) do { if (p.ss_dis > 0) launch_tw_k(L, true); else launch_tw_k(L, false); } while (0)
-                switch (p.full_level) {
-                case 1: launch_tw_level(1); break;
-                case 2: launch_tw_level(2); break;
-                case 3: launch_tw_level(3); break;
-                case 4: launch_tw_level(4); break;
-                case 5: launch_tw_level(5); break;
-                default: launch_tw_level(0); break;
-                }
-#undef launch_tw_level
-#undef launch_tw_k
-            }
+            if (chunk_launch && !beside) launch_tchunk();
+            if (wide_launch && beside) HIP_TRY(hipStreamWaitEvent(s, c->ev_join[0], 0));
+            if (chunk_launch && beside) HIP_TRY(hipStreamWaitEvent(s, c->ev_join[1], 0));
             if (!skip_lists) launch_probe(true, gl);
         } else {
         if (c->wide_cigar)
@@ -1194,7 +1243,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             }
 #undef launch_wide_level
         }
-        if (sa.chunk_on && !skip_lists) {   // the tiles without a window record, or with a dictionary key in several entries (none on most inputs)
+        if (sa.chunk_on && !skip_lists && !(c->tile && c->lists_known && c->chunk_rest_empty && !getenv("L2R_LAUNCH_ALL"))) {   // the tiles without a window record, or with a dictionary key in several entries (none on most inputs)
             const unsigned gc = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 4);
 #define launch_chunk_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_chunked<L>), dim3(gc), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
                 (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p)
@@ -1399,16 +1448,20 @@ int l2r_sync(l2r_ctx *c)
     if (c->ran && c->tile && !c->lists_known && c->list_cnt.p) {
         // what the run left on the lists of the kernels behind k_tile (k_classify_generic keeps the counts of the 64-bit-mask and the
         // chunked kernel's lists in words 6, 7 when it clears them; word 4: k_probe_slab's)
-        uint32_t lc[8];
+        uint32_t lc[16];
         HIP_TRY(hipMemcpyAsync(lc, c->list_cnt.p, sizeof lc, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         uint32_t redo_n = 1u;
         HIP_TRY(hipMemcpyAsync(&redo_n, c->totals.p + 3, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        c->lists_empty = lc[4] == 0u && lc[6] == 0u && lc[7] == 0u;
-        // (with k_tile's WIDE instance the 64-bit-mask tiles are no burden of the tile path)
-        c->lists_heavy = 2ull * ((unsigned long long)lc[4] + (c->wide_direct ? 0u : lc[6]) + lc[7]) > (unsigned long long)c->n_tiles;
+        // (lc[8]: tiles a one-window kernel handed to the chunked kernel late; lc[9]: entries of chunk_list k_tile_chunk declined)
+        c->lists_empty = lc[4] == 0u && lc[6] == 0u && lc[7] == 0u && lc[8] == 0u;
+        const bool tchunk = c->chunk_direct && !(c->ablate & 32);
+        const unsigned long long chunk_rest = (unsigned long long)lc[8] + (tchunk ? lc[9] : lc[7]);
+        // (with k_tile's WIDE instance / k_tile_chunk the tiles they take are no burden of the tile path: what counts is what keeps the slab form)
+        c->lists_heavy = 2ull * ((unsigned long long)lc[4] + (c->wide_direct ? lc[5] : lc[6]) + chunk_rest) > (unsigned long long)c->n_tiles;
         c->n_wide_tiles = lc[6]; c->wide_rest_empty = lc[5] == 0u;
+        c->n_chunk_tiles = lc[7]; c->chunk_rest_empty = chunk_rest == 0ull;
         c->redo_empty = redo_n == 0u;
         c->lists_known = true;
     }

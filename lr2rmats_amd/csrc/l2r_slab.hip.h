@@ -127,6 +127,7 @@ struct SlabArgs {
     uint32_t *lb_err, *fb_list;
     SjDir sj;                                            // the junction table's directories and rows (k_tile's junction check)
     uint32_t has_wide_keys;                              // the annotation has dictionary keys in several entries (SE_WIDE)
+    uint32_t chunk_direct_on;                            // ... and k_tile_chunk (l2r_tchunk.hip.h) the exact tiles of the chunked kernel
     uint32_t wide_direct_on;                             // one-kernel tile path: k_tile's WIDE instance takes the exact 64-bit-mask tiles straight from their CIGARs
     uint32_t *exon_total;                                // the run's exon count (k_tile: written by the last tile)
 };
@@ -137,6 +138,11 @@ __device__ __forceinline__ SlabArgsK slab_args()
     asm volatile("" : "+s"(q));
     return q;
 }
+
+// A one-window kernel that finds a dictionary key in several entries hands its tile to k_probe_slab_chunked LATE: behind the entries
+// k_describe_scan / TileLists made (list_cnt[1] of them, which k_tile_chunk may be walking over beside the caller), in a region of its own:
+// chunk_list[n_tiles + 1 + i], i < list_cnt[8].
+__device__ __forceinline__ void chunk_list_append_late(SlabArgsK sa, uint32_t t) { sa->chunk_list[sa->n_tiles + 1u + atomicAdd(sa->list_cnt + 8, 1u)] = t; }
 constexpr int SLAB_TW_VECS = (int)(sizeof(TileWin) / 16);
 // Which 16-byte vectors of a window record carry something for a window of n_win members: the members' two header arrays, their
 // transcript numbers (four per vector), and the descriptor + masks at the end.  Only those travel from k_walk_slab to k_probe_slab.
@@ -264,7 +270,7 @@ __device__ __forceinline__ uint32_t slab_walk_tile(SlabArgsK sa, PipeArgsK a, ui
         cnt[0] = 0u; cnt[1] = 0u; cnt[2] = 0u;
         // ... and the tile lists of k_probe_slab_wide / k_probe_slab_chunked with their work cursors (k_describe_scan appends)
         uint32_t *const lc = sa->list_cnt;
-        lc[0] = 0u; lc[1] = 0u; lc[2] = 0u; lc[3] = 0u;
+        lc[0] = 0u; lc[1] = 0u; lc[2] = 0u; lc[3] = 0u; lc[8] = 0u; lc[9] = 0u;
     }
     __syncthreads();
     // ---- every read's place among the tile's exons in READ order: each wave scans the 256 counts (four per lane) for itself
@@ -562,7 +568,7 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
         uint32_t *const cnt = a->f.redo_count;
         cnt[0] = 0u; cnt[1] = 0u; cnt[2] = 0u;
         uint32_t *const lc = sa->list_cnt;
-        lc[0] = 0u; lc[1] = 0u; lc[2] = 0u; lc[3] = 0u;
+        lc[0] = 0u; lc[1] = 0u; lc[2] = 0u; lc[3] = 0u; lc[8] = 0u; lc[9] = 0u;
     }
     __syncthreads();
     {   const int wn = wave_max((int)s_nslot[threadIdx.x]);            // (thread = slot here: the rows each wave of the probe kernels has to look at)
@@ -661,7 +667,7 @@ void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan, 
         *sa->ovf_cursor = 0ull; *sa->lb_err = 0u;
         *sa->exon_total = 0u;                            // (k_tile's last tile writes the run's exon count: an upload without reads has none)
         uint32_t *const lc = sa->list_cnt;
-        lc[2] = 0u; lc[3] = 0u; lc[4] = 0u; lc[5] = 0u;
+        lc[2] = 0u; lc[3] = 0u; lc[4] = 0u; lc[5] = 0u; lc[8] = 0u; lc[9] = 0u;
     }
     if (FIRST && blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < sa->n_sup; i += TILE_THREADS) sa->lb_sup_next[i] = 0ull;      // (the next run's super-block words)
     if (t < sa->n_tiles) {
@@ -768,6 +774,16 @@ __device__ __forceinline__ bool tile_wide_direct(uint32_t on, uint32_t flags, ui
     return on != 0u && (flags & TD_WIDE) != 0u && !(chunk_on && slab_tile_is_chunked(flags)) && tile_exact(st, min_exon, min_intron, max_delet) && !(ablate & 256) &&
            n_act + (uint32_t)st.n_ops_n <= (uint32_t)TILE_POS_CAP;
 }
+constexpr int TC_ENT_POOL = 768;                         // k_tile_chunk (l2r_tchunk.hip.h): dictionary entries of a tile (START + END) whose keys it stages
+// The tile is taken by k_tile_chunk (the plain instance returns at once for it, k_probe_slab_chunked skips it).  flags: the tile's
+// descriptor flags as k_describe_scan left them (SlabArgs::tile_flags: nobody changes those).
+__device__ __forceinline__ bool tile_chunk_direct(uint32_t on, uint32_t flags, uint32_t chunk_on, const TileDesc &d, const TileStat &st, uint32_t n_act,
+                                                  int min_exon, int min_intron, int max_delet, int dis, int ablate)
+{
+    return on != 0u && chunk_on != 0u && slab_tile_is_chunked(flags) && !(flags & TD_CHUNK) && dis == 0 && d.nbk > 0 && d.st_nk + d.en_nk <= (uint32_t)TC_ENT_POOL &&
+           tile_exact(st, min_exon, min_intron, max_delet) && !(ablate & 256) && n_act + (uint32_t)st.n_ops_n <= (uint32_t)TILE_POS_CAP;
+}
+
 constexpr uint32_t SLAB_POS_SKIP = 0xffffffffu;          // A of a position that was written directly (a staged start is below 2^18 - 1)
 struct SlabStage { uint32_t *A; uint16_t *Ln; uint32_t loc; int32_t lo; bool fits; };          // loc: the lane's first position, lo: the tile's first start
 
@@ -1141,7 +1157,7 @@ void k_probe_slab(SlabArgs kernarg_block, const TileSpan *__restrict__ u_span, c
     const int any_wide = s_widew[0] | s_widew[1] | s_widew[2] | s_widew[3];
     if (any_wide && sa->chunk_on) {
         // a key of the staged slices has several entries (its transcripts lie more than 64 apart): k_probe_slab_chunked ORs them
-        if (threadIdx.x == 0) { sa->tw[t].d.flags = d.flags | TD_CHUNK; sa->chunk_list[atomicAdd(sa->list_cnt + 1, 1u)] = t; }
+        if (threadIdx.x == 0) { sa->tw[t].d.flags = d.flags | TD_CHUNK; chunk_list_append_late(sa, t); }
         return;
     }
     // a read is staged when its positions fit and its rows have the tile's base

@@ -569,6 +569,8 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     {   // (a wide tile that the WIDE instance takes whole, behind this launch: nothing of it happens in the plain one -- and the other way round)
         const bool direct = tile_wide_direct(sa->wide_direct_on, d0.flags, chunk_on, tst, n_act, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet, ablate);
         if (WIDE ? !direct : direct) return;
+        // (... or k_tile_chunk, l2r_tchunk.hip.h: an exact tile of the chunked kernel)
+        if (!WIDE && tile_chunk_direct(sa->chunk_direct_on, d0.flags, chunk_on, d0, tst, n_act, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet, a->f.p.ss_dis, ablate)) return;
     }
     TileDesc d = d0;
     if (pre_slab) d.flags = 0u;
@@ -1035,7 +1037,7 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
         // which kernel takes the tile: the 64-bit-mask and the chunked kernel have theirs on their lists (k_describe_scan); a key in
         // several entries makes it k_probe_slab_chunked's (as k_probe_slab decides), anything else k_probe_slab's
         if (!pre_slab) {
-            if (wide_key && chunk_on) { sa->tw[t].d.flags = d0.flags | TD_CHUNK; sa->chunk_list[atomicAdd(sa->list_cnt + 1, 1u)] = t; }
+            if (wide_key && chunk_on) { sa->tw[t].d.flags = d0.flags | TD_CHUNK; chunk_list_append_late(sa, t); }
             else sa->fb_list[atomicAdd(sa->list_cnt + 4, 1u)] = t;
         } else if (d0.flags & TD_WIDE) sa->wide_list[n_tiles + 1u + atomicAdd(sa->list_cnt + 5, 1u)] = t;      // (k_probe_slab_wide's, behind the WIDE instance's tiles)
     }

@@ -362,7 +362,7 @@ void k_probe_slab_wide(SlabArgs kernarg_block, WideArgs wa, const uint32_t *__re
         if (threadIdx.x == 0) s_lim = min(total, (uint32_t)SLAB_POS_CAP);
         const int any_wide = __syncthreads_or(my_wide);
         if (any_wide && sa->chunk_on) {                         // (a key with several entries: k_probe_slab_chunked ORs them)
-            if (threadIdx.x == 0) { sa->tw[t].d.flags = tflags | TD_CHUNK; sa->chunk_list[atomicAdd(sa->list_cnt + 1, 1u)] = t; }
+            if (threadIdx.x == 0) { sa->tw[t].d.flags = tflags | TD_CHUNK; chunk_list_append_late(sa, t); }
             __syncthreads();
             continue;
         }

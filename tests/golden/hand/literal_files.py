@@ -389,6 +389,59 @@ SJ_GTF = _J3                           # j1 has an unreliable junction, j2 is un
 SJ_GTF_M = _J1 + _J3
 
 
+# --------------------------------------------------------------------------------------------------
+# Case "gtfq": the annotation reader's quirks (read_anno_trans / gtf_add_info, gtf.c:317-326,468-521) seen through
+# update-gtf -l 5.  README.md section 9.  Rows are written out one by one here (no gtf_rows): their ORDER and their
+# attribute TEXT are the subject.
+def _exon_row(chrom, s, e, attr):
+    return T.join([chrom, "hand", "exon", str(s), str(e), ".", "+", ".", attr])
+
+
+_Q1_ATTR = 'ref_gene_id "RG1"; gene_id "G1"; transcript_id "T1"; gene_name "g1"; transcript_name "t1";'      # "gene_id" is first met inside "ref_gene_id"
+_QZ_ATTR = 'gene_id "GZ"; transcript_id "TZ"; gene_name "gz"; transcript_name "tz";'
+_Q2_ATTR = 'transcript_id "T2"; gene_name "g2";'                                                                 # no gene_id, no transcript_name
+_Q4_HEAD = 'gene_id "G4"; transcript_id "T4"; note "'
+_Q4_LONG = _Q4_HEAD + "aaaa " * 280 + '"; gene_name "late4"; transcript_name "latet4";'                          # 1 500 bytes of attributes: the names lie behind byte 1 023
+_Q4_ATTR = 'gene_id "G4"; transcript_id "T4"; gene_name "g4"; transcript_name "t4";'
+_Q5_ATTR = 'gene_id "G5"; transcript_id "T5"; gene_name "g5"; transcript_name "t5";'
+_Q5_HEAD = _exon_row("chrA", 21000, 21100, 'gene_id "G5"; transcript_id "T5"; note "')
+# the row is cut behind its 1 023rd byte (fgets(line, 1024), gtf.c:476): the second piece reads "bb cc exon dd ee..."
+_Q5_LONG = _Q5_HEAD + "b" * (1023 - len(_Q5_HEAD)) + 'bb cc exon dd ee"; gene_name "late5";'
+GTFQ_ANNO = [
+    _exon_row("chrA", 1000, 1100, _Q1_ATTR),
+    "#" + _exon_row("chrA", 1500, 1600, 'gene_id "GC"; transcript_id "TC";'),     # a comment (gtf.c:477); read as a row it would cut T1 in two
+    _exon_row("chrA", 2000, 2100, _Q1_ATTR),
+    _exon_row("chrZ", 1000, 1100, _QZ_ATTR),                                      # chrZ is not in the header: tid -1, before every read (gtf.c:481)
+    _exon_row("chrZ", 2000, 2100, _QZ_ATTR),
+    _exon_row("chrA", 5000, 5100, _Q2_ATTR),
+    _exon_row("chrA", 6000, 6100, _Q2_ATTR),
+    "",                                                                           # an empty line: sscanf assigns nothing, the row in front is taken again
+    _exon_row("chrA", 7000, 7100, _Q2_ATTR),
+    _exon_row("chrA", 10000, 10100, _Q4_LONG),
+    _exon_row("chrA", 11000, 11100, _Q4_ATTR),
+    _exon_row("chrA", 20000, 20100, _Q5_ATTR),
+    _Q5_LONG,
+    _exon_row("chrA", 22000, 22100, _Q5_ATTR),
+]
+GTFQ_SAM = SAM_HEADER + [
+    sam("q1", 0, "chrA", 1000, "101M899N101M"),
+    sam("q2", 0, "chrA", 6000, "101M899N101M"),
+    sam("q4", 0, "chrA", 10000, "101M899N101M"),
+    sam("q5", 0, "chrA", 21000, "101M899N101M"),
+]
+GTFQ_DETAIL = [
+    DETAIL_HEADER,
+    detail("q1", "chrA", "+", 1, "RG1", "g1", [1000, 2000], [1100, 2100], [], [1], [], []),
+    detail("q2", "chrA", "+", 1, "g2", "g2", [6000, 7000], [6100, 7100], [], [], [], []),
+    detail("q4", "chrA", "+", 1, "G4", "G4", [10000, 11000], [10100, 11100], [], [1], [], []),
+    detail("q5", "chrA", "+", 1, "G5", "g5", [21000, 22000], [21100, 22100], [], [], [], []),
+]
+GTFQ_GTF = (gtf_block("chrA", 1000, 2100, "+", "RG1", "g1", "q1", 1, "chrA", "+", [(1000, 1100), (2000, 2100)])
+            + gtf_block("chrA", 6000, 7100, "+", "g2", "g2", "q2", 1, "chrA", "+", [(6000, 6100), (7000, 7100)])
+            + gtf_block("chrA", 10000, 11100, "+", "G4", "G4", "q4", 1, "chrA", "+", [(10000, 10100), (11000, 11100)])
+            + gtf_block("chrA", 21000, 22100, "+", "G5", "g5", "q5", 1, "chrA", "+", [(21000, 21100), (22000, 22100)]))
+
+
 FILES = {
     "anno.gtf": ANNO,
     "cigar.sam": CIG_SAM, "cigar_m.sam": CIG_SAM_MAPPED, "cigar_anno.gtf": CIG_ANNO, "cigar.bam2gtf.gtf": CIG_B2G, "cigar_t.bam2gtf.gtf": CIG_B2G_T,
@@ -405,6 +458,7 @@ FILES = {
     "uniq.sam": UNIQ_SAM, "uniq.unique.gtf": UNIQ_GTF, "uniq_s.unique.gtf": UNIQ_GTF_S,
     "split.sam": SPLIT_SAM, "split_sj.tab": SPLIT_SJ, "split.detail.txt": SPLIT_DETAIL, "split.updated.gtf": SPLIT_GTF,
     "split.novel_exon.bed": SPLIT_BED, "split.summary.txt": SPLIT_SUMMARY,
+    "gtfq_anno.gtf": GTFQ_ANNO, "gtfq.sam": GTFQ_SAM, "gtfq.detail.txt": GTFQ_DETAIL, "gtfq.updated.gtf": GTFQ_GTF,
 }
 
 if __name__ == "__main__":

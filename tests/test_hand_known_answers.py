@@ -38,6 +38,9 @@ CASES = {
     "cigar_b2g_t": (["bam2gtf", "-e", "10", "-i", "100", "-t", "5"], "cigar.sam", False, {"gtf": "cigar_t.bam2gtf.gtf"}),
     "cigar_upd": (["update-gtf", "-l", "5"], "cigar_m.sam", "cigar_anno.gtf", {"detail": "cigar.detail.txt"}),
     "cigar_upd_t": (["update-gtf", "-l", "5", "-e", "10", "-i", "100", "-t", "5"], "cigar_m.sam", "cigar_anno.gtf", {"detail": "cigar_t.detail.txt"}),
+    # the annotation reader's quirks (gtf.c:317-326,468-521): tag found inside a longer tag, id / name fall-backs, a comment between a
+    # transcript's rows, a chromosome that is not in the header, an empty line, rows cut behind byte 1 023
+    "gtfq": (["update-gtf", "-l", "5"], "gtfq.sam", "gtfq_anno.gtf", {"gtf": "gtfq.updated.gtf", "detail": "gtfq.detail.txt"}),
     "uniq": (["unique-gtf"], "uniq.sam", False, {"gtf": "uniq.unique.gtf"}),
     "uniq_s": (["unique-gtf", "-s"], "uniq.sam", False, {"gtf": "uniq_s.unique.gtf"}),
 }
