@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define L2R_ABI_VERSION 2
+#define L2R_ABI_VERSION 3
 
 typedef struct l2r_ctx l2r_ctx;
 
@@ -80,6 +80,15 @@ typedef struct {
     const int64_t *cig_off;         /* n_reads + 1 */
     const uint32_t *cig;
     int64_t first_read_index;       /* global index of record 0 (read shards of a multi-GPU run) */
+    /* Optional (NULL: the engine walks every CIGAR once at upload to make it, k_tile_index): what a reader knows of a record's CIGAR
+     * while it converts it (host/aln_reader.c does for every input format; lr2rmats_amd/synth.py for synthetic reads), whatever the
+     * thresholds of a run -- three words per record:
+     *   [0] reference bases of the CIGAR (ops M D N = X): the record ends at pos + [0] (src/bam2gtf.c:41-74: `end` only grows by these);
+     *   [1] N operations | the shortest of them << 16;     [2] the longest D operation | the shortest stretch of reference bases
+     *       between two N operations << 16 -- each of the four saturated at 65535 (the shortest ones 65535 where there is none).
+     * With it a run knows a tile's exon count without a CIGAR walk wherever no threshold is borderline (exons = records + N operations
+     * while -i <= shortest N, -t >= longest D, -e <= shortest stretch), and the upload's index is a scan over 15 bytes per record. */
+    const uint32_t *cig_summary;
 } l2r_reads;
 
 /* bits of info[] : one word per read; bits 8..31 = exon count */
@@ -203,6 +212,13 @@ int          l2r_set_junctions(l2r_ctx *ctx, const l2r_junctions *sj);   /* NULL
 /* host -> HBM; detects whether the records are coordinate sorted and, if not,
  * prepares the history-dependent cursor values on the host. */
 int          l2r_upload_reads(l2r_ctx *ctx, const l2r_reads *reads);
+/* GPU time of the last upload's tile index (k_tile_index; 0 where the upload made none), by HIP events on the context stream: the part of
+ * an upload that is kernel work on the records -- bench.py adds it to a first run for the cost of ONE classification of fresh input. */
+float        l2r_upload_index_ms(l2r_ctx *ctx);
+/* on != 0: every following upload will be classified ONCE (what the CLI does: one l2r_run per l2r_upload_reads).  Such an upload makes
+ * no tile index and its run takes the two-kernel pipeline -- by total GPU time the cheaper way for a single run (l2r_classify does the
+ * same by itself); the one-kernel tile path is for uploads that are run again (parameter sweeps, the benchmark's resident steps). */
+int          l2r_hint_single_run(l2r_ctx *ctx, int on);
 
 /* The hot path on resident inputs; asynchronous on the context stream. */
 int          l2r_run(l2r_ctx *ctx);          /* every kernel of the path, every call; results in read order in HBM */

@@ -29,7 +29,7 @@ EXPORTS = [
     "l2r_set_outputs", "l2r_set_annotation", "l2r_set_junctions", "l2r_upload_reads", "l2r_run", "l2r_sync", "l2r_run_timed",
     "l2r_result_sizes", "l2r_download", "l2r_download_accepted", "l2r_device_view_get", "l2r_stream", "l2r_classify",
     "l2r_stage_kernel", "l2r_set_annotation_cache", "l2r_annotation_cache_state", "l2r_filter_score", "l2r_filter_select",
-    "l2r_debug_counters", "l2r_debug_stamps", "l2r_debug_tile_times",
+    "l2r_debug_counters", "l2r_debug_stamps", "l2r_debug_tile_times", "l2r_upload_index_ms", "l2r_hint_single_run",
     "l2r_xchg_id_bytes", "l2r_xchg_unique_id", "l2r_xchg_create", "l2r_xchg_gather_results", "l2r_xchg_gather_accepted", "l2r_xchg_destroy",
 ]
 
@@ -53,7 +53,7 @@ class CJunctions(C.Structure):
 
 class CReads(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("n_cigar", C.c_int64), ("tid", _i32p), ("pos", _i32p), ("rev", _u8p),
-                ("cig_off", _i64p), ("cig", _u32p), ("first_read_index", C.c_int64)]
+                ("cig_off", _i64p), ("cig", _u32p), ("first_read_index", C.c_int64), ("cig_summary", _u32p)]
 
 
 class CResult(C.Structure):
@@ -140,6 +140,9 @@ def load_library():
         lib.l2r_annotation_cache_state.argtypes = [C.c_void_p]
         lib.l2r_filter_score.argtypes = [C.c_void_p] * 7
         lib.l2r_filter_select.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+        lib.l2r_hint_single_run.argtypes = [C.c_void_p, C.c_int]
+        lib.l2r_upload_index_ms.restype = C.c_float
+        lib.l2r_upload_index_ms.argtypes = [C.c_void_p]
         lib.l2r_stage_kernel.restype = C.c_char_p
         lib.l2r_stage_kernel.argtypes = [C.c_void_p, C.c_int]
         _lib = lib
@@ -258,12 +261,20 @@ class Engine:
         """0 no cache, 1 built and stored, 2 read from the cache (last set_annotation)."""
         return int(self.lib.l2r_annotation_cache_state(self.ctx))
 
-    def upload_reads(self, tid, pos, rev, cig_off, cig, first_read_index: int = 0):
+    def upload_reads(self, tid, pos, rev, cig_off, cig, first_read_index: int = 0, cig_summary=None):
+        """``cig_summary``: the reader's per-record CIGAR summaries ([N, 3] uint32, ``synth.cigar_summary``; None: the engine walks the CIGARs)."""
         a = [np.ascontiguousarray(tid, np.int32), np.ascontiguousarray(pos, np.int32), np.ascontiguousarray(rev, np.uint8),
              np.ascontiguousarray(cig_off, np.int64), np.ascontiguousarray(cig, np.uint32)]
+        sm = None if cig_summary is None else np.ascontiguousarray(cig_summary, np.uint32)
+        if sm is not None and sm.shape != (len(a[0]), 3):
+            raise ValueError("cig_summary: expected shape (n_reads, 3)")
         cr = CReads(len(a[0]), len(a[4]), _ptr(a[0], _i32p), _ptr(a[1], _i32p), _ptr(a[2], _u8p), _ptr(a[3], _i64p),
-                    _ptr(a[4], _u32p), first_read_index)
+                    _ptr(a[4], _u32p), first_read_index, _ptr(sm, _u32p) if sm is not None else None)
         self._chk(self.lib.l2r_upload_reads(self.ctx, C.byref(cr)))
+
+    def upload_index_ms(self) -> float:
+        """GPU time of the last upload's tile index (k_tile_index), ms."""
+        return float(self.lib.l2r_upload_index_ms(self.ctx))
 
     def run(self):
         self._chk(self.lib.l2r_run(self.ctx))
@@ -311,7 +322,7 @@ class Engine:
         """upload + run + sync + download for a ``synth.Reads``-like object."""
         if params is not None:
             self.set_params(params)
-        self.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, first_read_index)
+        self.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, first_read_index, getattr(reads, "cig_summary", None))
         self.run()
         self.sync()
         return self.download()

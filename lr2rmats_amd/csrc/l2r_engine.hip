@@ -86,6 +86,10 @@ struct l2r_ctx {
     bool tile = false;                      // ... with the one-kernel tile path (l2r_tile.hip.h: short CIGARs, -e >= 1)
     DevBuf<unsigned long long> lb_tile, lb_blk, lb_sup;     // one-kernel tile path: the tiles' exon counts on their way to the later tiles' first slots
     DevBuf<uint32_t> fb_list;                               //                       the tiles it leaves to k_probe_slab
+    DevBuf<uint16_t> sum_nn;                                //                       the records' N operations (l2r_reads::cig_summary) for k_tile_index<true>
+    bool have_index = false;                                //                       the current upload has its tile index (slot records, op statistics)
+    bool one_shot_upload = false;                           //                       ONE run will follow the upload (l2r_classify, l2r_hint_single_run): see l2r_classify
+    float index_ms = 0.0f;                                  //                       GPU time of the last upload's k_tile_index (l2r_upload_index_ms)
     DevBuf<SlotRec> slot_rec;                               //                       the upload's slot records (k_tile_index)
     DevBuf<TileStat> sup_stat;                              //                       ... summed up per super-block of 1024 tiles
     DevBuf<TileStat> tile_stat; std::vector<TileStat> h_tile_stat;      //                 the upload's index of the tiles' CIGAR operations (k_tile_index)
@@ -265,7 +269,7 @@ void l2r_destroy(l2r_ctx *c)
     c->local.release(); c->order.release(); c->redo.release(); c->desc.release(); c->win_hdr.release(); c->tile_first.release(); c->walked.release(); c->stamps.release(); c->tile_base.release(); c->ex_off.release(); c->info.release(); c->tile_acc.release(); c->tile_acc_ex.release(); c->tile_acc_at.release(); c->tile_acc_ex_at.release(); c->tile_chunk.release(); c->tile_rchunk.release(); c->totals.release();
     c->ex_start.release(); c->ex_end.release(); c->ref_tx.release(); c->ex_flag.release();
     c->tile_total.release(); c->tile_xbase.release(); c->tile_rec.release(); c->cig_off32.release(); c->s_pl.release(); c->tile_span.release(); c->tile_sbase.release(); c->ovf_cursor.release(); c->tw64.release(); c->wide_list.release(); c->chunk_list.release(); c->list_cnt.release(); c->tile_flags.release();
-    c->lb_tile.release(); c->lb_blk.release(); c->lb_sup.release(); c->fb_list.release(); c->tile_stat.release(); c->sup_stat.release(); c->slot_rec.release();
+    c->lb_tile.release(); c->lb_blk.release(); c->lb_sup.release(); c->fb_list.release(); c->tile_stat.release(); c->sup_stat.release(); c->slot_rec.release(); c->sum_nn.release();
     c->slab_row.release(); c->dense_start.release(); c->dense_end.release(); c->s_pre.release(); c->s_loc.release(); c->tw.release();
     c->acc_rec.release(); c->acc_ex_off.release(); c->acc_start.release(); c->acc_end.release(); c->acc_flag.release();
     drop_graph(c);
@@ -276,6 +280,8 @@ void l2r_destroy(l2r_ctx *c)
 }
 
 void *l2r_stream(l2r_ctx *c) { return c ? (void *)c->stream : nullptr; }
+float l2r_upload_index_ms(l2r_ctx *c) { return c ? c->index_ms : 0.0f; }
+int l2r_hint_single_run(l2r_ctx *c, int on) { if (!c) return fail(-1, "[l2r_hint_single_run] null context"); c->one_shot_upload = on != 0; return 0; }
 
 int l2r_set_outputs(l2r_ctx *c, unsigned want)
 {
@@ -939,10 +945,51 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             // tile path makes the tiles' windows from it in front of the walk (l2r_tile.hip.h)
             // ... and an index of its CIGAR operations from which a run knows the tile's exon count unless a threshold is borderline in it
             c->h_tile_stat.assign(T, TileStat{0, INT32_MAX, 0, INT32_MAX});
-            if (T && !c->wide_cigar) {
-                hipLaunchKernelGGL(k_tile_index, dim3((unsigned)std::min<size_t>(T, 8192)), dim3(TILE_THREADS), 0, c->stream, (TileRec *)c->tile_rec.p, c->tile_stat.p, c->slot_rec.p, (uint32_t)T,
-                                   (const uint32_t *)c->cig_off32.p, (const int32_t *)c->r_pos.p, (const uint8_t *)c->r_rev.p, (const uint32_t *)c->cig.p);
-                HIP_TRY(hipMemcpyAsync(c->h_tile_stat.data(), c->tile_stat.p, T * sizeof(TileStat), hipMemcpyDeviceToHost, c->stream));
+            c->index_ms = 0.0f; c->have_index = false;
+            if (T && !c->wide_cigar && c->want_pipeline >= 2 && !(c->one_shot_upload && !getenv("L2R_TILE_ANYWAY"))) {
+                c->have_index = true;
+                struct Ev { hipEvent_t a = nullptr, b = nullptr; ~Ev() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev;
+                HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b));
+                const unsigned gi = (unsigned)std::min<size_t>(T, 8192);
+                if (r->cig_summary) {
+                    // the reader's per-record summaries: the tiles' statistics and last bases on the host (no parameter has a say in them), the
+                    // records' N operations as one 16-bit column for the kernel -- which then touches no CIGAR
+                    std::vector<uint16_t> nn((size_t)N);
+                    for (size_t t = 0; t < T; ++t) {
+                        TileStat st{0, INT32_MAX, 0, INT32_MAX};
+                        int64_t hi = INT32_MIN; uint32_t tot_x = 0u; bool many = false;
+                        for (uint32_t i = tile_first[t]; i < tile_first[t + 1]; ++i) {
+                            const uint32_t *q = r->cig_summary + 3 * (size_t)i;
+                            const uint32_t n_n = q[1] & 0xffffu, mn = q[1] >> 16, md = q[2] & 0xffffu, ms = q[2] >> 16;
+                            nn[i] = (uint16_t)n_n;
+                            st.n_ops_n += (int32_t)n_n; st.min_n = std::min(st.min_n, (int32_t)mn); st.min_seg = std::min(st.min_seg, (int32_t)ms);
+                            st.max_d = std::max(st.max_d, md == 0xffffu ? INT32_MAX : (int32_t)md);      // (65535: that long or longer)
+                            hi = std::max<int64_t>(hi, (int64_t)r->pos[i] + (int64_t)q[0]);
+                            tot_x += n_n + 1u; many = many || n_n + 1u >= 255u;
+                        }
+                        // (a read of 255 exons or more, places a slot record cannot say: never an exact tile -- as k_tile_index<false> rules)
+                        if (many || tot_x >= SLOT_LOC_LIMIT) st.min_seg = INT32_MIN;
+                        c->h_tile_stat[t] = st;
+                        rec[t].pad[0] = (uint32_t)std::min<int64_t>(std::max<int64_t>(hi, INT32_MIN), INT32_MAX);
+                    }
+                    if (c->sum_nn.ensure((size_t)N + 1)) return -2;
+                    HIP_TRY(hipMemcpyAsync(c->sum_nn.p, nn.data(), (size_t)N * 2, hipMemcpyHostToDevice, c->stream));
+                    HIP_TRY(hipMemcpyAsync(c->tile_rec.p, rec.data(), rec.size() * sizeof(TileRec), hipMemcpyHostToDevice, c->stream));
+                    HIP_TRY(hipMemcpyAsync(c->tile_stat.p, c->h_tile_stat.data(), T * sizeof(TileStat), hipMemcpyHostToDevice, c->stream));
+                    HIP_TRY(hipEventRecord(ev.a, c->stream));
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_index<true>), dim3(gi), dim3(TILE_THREADS), 0, c->stream, (TileRec *)c->tile_rec.p, c->tile_stat.p, c->slot_rec.p, (uint32_t)T,
+                                       (const uint32_t *)c->cig_off32.p, (const int32_t *)c->r_pos.p, (const uint8_t *)c->r_rev.p, (const uint32_t *)c->cig.p, (const uint16_t *)c->sum_nn.p);
+                    HIP_TRY(hipEventRecord(ev.b, c->stream));
+                    HIP_TRY(hipStreamSynchronize(c->stream));       // (nn, rec)
+                } else {
+                    HIP_TRY(hipEventRecord(ev.a, c->stream));
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_index<false>), dim3(gi), dim3(TILE_THREADS), 0, c->stream, (TileRec *)c->tile_rec.p, c->tile_stat.p, c->slot_rec.p, (uint32_t)T,
+                                       (const uint32_t *)c->cig_off32.p, (const int32_t *)c->r_pos.p, (const uint8_t *)c->r_rev.p, (const uint32_t *)c->cig.p, (const uint16_t *)nullptr);
+                    HIP_TRY(hipEventRecord(ev.b, c->stream));
+                    HIP_TRY(hipMemcpyAsync(c->h_tile_stat.data(), c->tile_stat.p, T * sizeof(TileStat), hipMemcpyDeviceToHost, c->stream));
+                }
+                HIP_TRY(hipEventSynchronize(ev.b));
+                HIP_TRY(hipEventElapsedTime(&c->index_ms, ev.a, ev.b));
             }
             HIP_TRY(hipStreamSynchronize(c->stream));       // (locals)
             {   // the index once more per super-block (l2r_slab.hip.h SlabArgs::sup_stat)
@@ -1082,7 +1129,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     c->slab = c->slab_ok && p.min_intron >= 0 && p.min_intron < (1 << 28) && p.max_delet >= -1 && p.max_delet < (1 << 28) - 1 &&
               (!c->wide_cigar || p.min_exon >= 1);           // (k_walk_slab_long has no -e < 1 form: the classic kernels take that)
     // the one-kernel tile path: short CIGARs whose exon counts the CIGAR lengths bound (-e >= 1)
-    c->tile = c->slab && c->want_pipeline >= 2 && !c->wide_cigar && p.min_exon >= 1;
+    c->tile = c->slab && c->want_pipeline >= 2 && !c->wide_cigar && p.min_exon >= 1 && (c->have_index || c->n_tiles == 0);
     if (c->tile) {
         // A tile whose exon count the first kernel cannot derive from the upload's index (a threshold is borderline in it) publishes it
         // from k_tile, and every later tile's write-out waits for it: fine for a few, a convoy for many (measured: 3 x the kernel when
@@ -1649,7 +1696,15 @@ int l2r_device_view_get(l2r_ctx *c, l2r_device_view *v)
 
 int l2r_classify(l2r_ctx *c, const l2r_reads *reads, l2r_result *res)
 {
+    if (!c) return fail(-1, "[l2r_classify] null context");
+    // ONE run follows this upload: by total GPU time the two-kernel (slab) pipeline wins that case -- measured on 10 M reads 0.62 ms against
+    // tile index + first run of the one-kernel path 0.68 ms (1.05 ms where the engine has to walk the CIGARs for the index itself); the
+    // one-kernel path pays off from the second run of an upload on (0.50 ms a run).  So this upload makes no tile index and its run takes
+    // the slab pipeline (L2R_TILE_ANYWAY=1: index + tile path all the same).
+    const bool was = c->one_shot_upload;
+    c->one_shot_upload = true;
     int rc = l2r_upload_reads(c, reads);
+    c->one_shot_upload = was;
     if (rc) return rc;
     if ((rc = l2r_run(c))) return rc;
     if ((rc = l2r_sync(c))) return rc;

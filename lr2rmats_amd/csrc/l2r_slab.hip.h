@@ -774,13 +774,13 @@ __device__ __forceinline__ bool tile_wide_direct(uint32_t on, uint32_t flags, ui
     return on != 0u && (flags & TD_WIDE) != 0u && !(chunk_on && slab_tile_is_chunked(flags)) && tile_exact(st, min_exon, min_intron, max_delet) && !(ablate & 256) &&
            n_act + (uint32_t)st.n_ops_n <= (uint32_t)TILE_POS_CAP;
 }
-constexpr int TC_ENT_POOL = 768;                         // k_tile_chunk (l2r_tchunk.hip.h): dictionary entries of a tile (START + END) whose keys it stages
+constexpr int TC_ST_CAP = 128, TC_EN_CAP = 512;          // k_tile_chunk (l2r_tchunk.hip.h): START / END dictionary entries of a tile it stages
 // The tile is taken by k_tile_chunk (the plain instance returns at once for it, k_probe_slab_chunked skips it).  flags: the tile's
 // descriptor flags as k_describe_scan left them (SlabArgs::tile_flags: nobody changes those).
 __device__ __forceinline__ bool tile_chunk_direct(uint32_t on, uint32_t flags, uint32_t chunk_on, const TileDesc &d, const TileStat &st, uint32_t n_act,
                                                   int min_exon, int min_intron, int max_delet, int dis, int ablate)
 {
-    return on != 0u && chunk_on != 0u && slab_tile_is_chunked(flags) && !(flags & TD_CHUNK) && dis == 0 && d.nbk > 0 && d.st_nk + d.en_nk <= (uint32_t)TC_ENT_POOL &&
+    return on != 0u && chunk_on != 0u && slab_tile_is_chunked(flags) && !(flags & TD_CHUNK) && dis == 0 && d.nbk > 0 && d.st_nk <= (uint32_t)TC_ST_CAP && d.en_nk <= (uint32_t)TC_EN_CAP &&
            tile_exact(st, min_exon, min_intron, max_delet) && !(ablate & 256) && n_act + (uint32_t)st.n_ops_n <= (uint32_t)TILE_POS_CAP;
 }
 

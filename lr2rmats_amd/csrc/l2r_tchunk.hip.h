@@ -26,46 +26,81 @@
 // before every read or behind every read, which the member pass sees per read like for any other member (m_bef / m_aft), so masks are
 // re-based by shifts alone (no gapped windows) and the chunk's window is its first transcript's number.
 // Not taken here (they keep the slab form and k_probe_slab_chunked): tiles that are not exact under the run's thresholds, -d > 0,
-// slices of more than TC_ENT_POOL entries, and the tiles a one-window kernel flags late (a key in several entries).
+// slices of more than TC_ST_CAP / TC_EN_CAP entries, and the tiles a one-window kernel flags late (a key in several entries).
 // Junction support (-j) is left to k_validate_sj, the accepted chunk to k_gather_accepted (as for every list-driven kernel).
 #pragma once
 #include "l2r_tile.hip.h"
 
 namespace l2r {
 
-constexpr int TC_PER_THREAD = TC_ENT_POOL / TILE_THREADS;         // (TC_ENT_POOL: l2r_slab.hip.h, beside tile_chunk_direct)
+constexpr int TC_ENT_POOL = TC_ST_CAP + TC_EN_CAP;                // (the caps: l2r_slab.hip.h, beside tile_chunk_direct)
+constexpr int TC_PER_THREAD = (TC_ENT_POOL + TILE_THREADS - 1) / TILE_THREADS;
 constexpr int TC_MEMBERS_PER = WIDE_MEMBERS;                     // transcripts per chunk: 63, so that a "first member" still takes 6 bits (63 = none)
 constexpr int TC_TRIPS = 256;                            // stretches of 63 transcripts the window scan may look at (16 k transcripts)
 constexpr int TC_CHUNKS = 64;                            // ... and the ones with members a tile may have (4 k members)
 constexpr int TC_DIR_N = DIR_CAP + 4;                    // directory words per dictionary (bucket b's first entry, two closing words)
-static_assert(TC_ENT_POOL % TILE_THREADS == 0 && TC_ENT_POOL <= 1024, "entries per thread; 10-bit entry numbers in a lookup word");
+static_assert(TC_ST_CAP <= 512 && TC_EN_CAP <= 512, "9-bit entry numbers in a lookup word");
+// A position's lookup word (s_R): START half in bits 0-13, END half in bits 14-27 -- first part (9 bits) | parts (4 bits) << 9 | "the pair
+// matches" << 13 --, the exon's novel flags still standing in bits 28-31 (F_EXON | F_DON | F_ACC | F_JUNC).
+constexpr int TC_HALF_BITS = 14, TC_F_SHIFT = 28;
+constexpr uint32_t TC_R_OVER = 1u << 13;                 // "the pair matches" without a part: a key of more than 15 parts (the read goes to the generic kernel)
+constexpr uint32_t TC_ROW_FIRST = 1u << 30, TC_ROW_LAST = 1u << 31;      // row word, until the first chunk's work words: the exon begins / ends its read
+constexpr uint32_t TC_HALF_MASK = (1u << TC_HALF_BITS) - 1u;
 
 struct TcMask { m64_t pm, sm; };                         // a staged entry's masks in the chunk's frame (bit j = transcript chunk base + j)
 struct TcLds { const int2 *key0, *key1; const TcMask *msk0, *msk1; const uint16_t *dir0, *dir1, *rdir; const int4 *hk, *hx; };
 
-// One lookup of the tile's key staging (once per exon and dictionary): the parts of the pair (k1, k2) if the dictionary has it, else the
-// parts of the first pair with key 1 (their single masks cover every transcript with that site: build_dict walks a pair's parts until
-// both member lists are through).  Word: first part (10 bits) | parts (5 bits) << 10 | "the pair matches" << 15; 0 = nothing.
-// over: more than 31 parts (the read goes to the generic kernel).
-__device__ __forceinline__ uint32_t tc_lookup(const int2 *key, const uint16_t *dir, int b_off, uint32_t none, bool on, int32_t k1, int32_t k2, bool &over)
+// The two lookups of one exon in the tile's key staging (once per tile): START key (start, end) and END key (end, next start).  Per
+// key: the parts of the pair (k1, k2) if the dictionary has it, else the parts of the first pair with key 1 (their single masks cover
+// every transcript with that site: build_dict walks a pair's parts until both member lists are through).  The entries of a bucket are
+// sorted by (key 1, key 2), a pair's parts lie side by side: lower bounds, BOTH dictionaries' in one loop (two independent LDS reads in
+// flight per step -- the kernel is bound by such dependent chains; a scan of the bucket took one read per entry), a second search only
+// where a pair is missing.  Half word: first part (9 bits) | parts (4 bits) << 9 | "the pair matches" << 13; 0 = nothing.
+// over: more than 15 parts (the read goes to the generic kernel).
+struct TcKey { const int2 *key; const uint16_t *dir; };
+__device__ __forceinline__ uint32_t tc_parts(const int2 *key, uint32_t base, uint32_t hi, bool found, bool pair, int2 kb, bool &over)
 {
-    const uint32_t ib = on ? min((uint32_t)((k1 >> SITE_SHIFT) + b_off), none) : none;
-    const uint32_t lo = dir[ib], hi = dir[ib + 1u];
-    uint32_t a0 = 0xffffu, x0 = 0xffffu;
-    for (uint32_t r = lo; r < hi; ++r) {
-        const int2 q = key[r];
-        const bool m1 = q.x == k1;
-        a0 = (m1 && a0 == 0xffffu) ? r : a0;
-        x0 = (m1 && q.y == k2 && x0 == 0xffffu) ? r : x0;
-    }
-    const bool pair = x0 != 0xffffu;
-    const uint32_t base = pair ? x0 : a0;
-    if (base == 0xffffu) return 0u;
-    const int2 kb = key[base];
+    if (!found) return 0u;
+    // the pair's parts: the entries behind it with its keys (three asked for at once; more is rare)
     uint32_t cnt = 1u;
-    for (uint32_t r = base + 1u; r < hi; ++r) { const int2 q = key[r]; if (q.x != kb.x || q.y != kb.y) break; ++cnt; }
-    if (cnt > 31u) { over = true; cnt = 31u; }
-    return base | (cnt << 10) | (pair ? 1u << 15 : 0u);
+    for (uint32_t r = base + 1u; r < hi; r += 3u) {
+        const int2 q0 = key[r], q1 = key[min(r + 1u, hi - 1u)], q2 = key[min(r + 2u, hi - 1u)];
+        const bool e0 = q0.x == kb.x && q0.y == kb.y, e1 = e0 && r + 1u < hi && q1.x == kb.x && q1.y == kb.y, e2 = e1 && r + 2u < hi && q2.x == kb.x && q2.y == kb.y;
+        cnt += (e0 ? 1u : 0u) + (e1 ? 1u : 0u) + (e2 ? 1u : 0u);
+        if (!e2) break;
+    }
+    if (cnt > 15u) { over = true; cnt = 15u; }
+    return base | (cnt << 9) | (pair ? 1u << 13 : 0u);
+}
+__device__ __forceinline__ uint32_t tc_lookup2(const TcKey &K0, const TcKey &K1, int b_off, uint32_t none, bool on0, bool on1, int32_t s, int32_t e, int32_t s2, bool &over)
+{
+    const uint32_t ib0 = on0 ? min((uint32_t)((s >> SITE_SHIFT) + b_off), none) : none, ib1 = on1 ? min((uint32_t)((e >> SITE_SHIFT) + b_off), none) : none;
+    const uint32_t lo0 = K0.dir[ib0], hi0 = K0.dir[ib0 + 1u], lo1 = K1.dir[ib1], hi1 = K1.dir[ib1 + 1u];
+    uint32_t l0 = lo0, h0 = hi0, l1 = lo1, h1 = hi1;
+    while (l0 < h0 || l1 < h1) {
+        const uint32_t m0 = (l0 + h0) >> 1, m1 = (l1 + h1) >> 1;
+        const int2 q0 = K0.key[m0], q1 = K1.key[m1];           // (an empty range reads an entry of the staging or the word behind it: not used)
+        const bool less0 = q0.x < s || (q0.x == s && q0.y < e), less1 = q1.x < e || (q1.x == e && q1.y < s2);
+        if (l0 < h0) { l0 = less0 ? m0 + 1u : l0; h0 = less0 ? h0 : m0; }
+        if (l1 < h1) { l1 = less1 ? m1 + 1u : l1; h1 = less1 ? h1 : m1; }
+    }
+    int2 kb0 = K0.key[l0], kb1 = K1.key[l1];
+    bool pair0 = l0 < hi0 && kb0.x == s && kb0.y == e, pair1 = l1 < hi1 && kb1.x == e && kb1.y == s2;
+    bool found0 = pair0, found1 = pair1;
+    uint32_t base0 = l0, base1 = l1;
+    if ((!pair0 && lo0 < hi0) || (!pair1 && lo1 < hi1)) {
+        // (the first entry with key 1: in front of the place the pair would have)
+        uint32_t a0 = lo0, b0 = pair0 ? lo0 : l0, a1 = lo1, b1 = pair1 ? lo1 : l1;
+        while (a0 < b0 || a1 < b1) {
+            const uint32_t m0 = (a0 + b0) >> 1, m1 = (a1 + b1) >> 1;
+            const bool less0 = K0.key[m0].x < s, less1 = K1.key[m1].x < e;
+            if (a0 < b0) { a0 = less0 ? m0 + 1u : a0; b0 = less0 ? b0 : m0; }
+            if (a1 < b1) { a1 = less1 ? m1 + 1u : a1; b1 = less1 ? b1 : m1; }
+        }
+        if (!pair0) { base0 = a0; kb0 = K0.key[a0]; found0 = a0 < hi0 && kb0.x == s; }
+        if (!pair1) { base1 = a1; kb1 = K1.key[a1]; found1 = a1 < hi1 && kb1.x == e; }
+    }
+    return tc_parts(K0.key, base0, hi0, found0, pair0, kb0, over) | (tc_parts(K1.key, base1, hi1, found1, pair1, kb1, over) << TC_HALF_BITS);
 }
 
 // overlapping_exon_members64 (l2r_wide.hip.h) on the split key / mask arrays
@@ -83,22 +118,92 @@ __device__ __forceinline__ m64_t tc_overlapping_exon_members(const TcLds &L, int
     return m;
 }
 
-// map_exons_lds64 (l2r_chunk.hip.h) with the lookups done: per exon the ORs over the parts its word names
+// visit_chunk64 (l2r_chunk.hip.h) for a chunk of 63 transcripts whose headers are all staged (a transcript behind the chunk's last or
+// behind the annotation: "behind every read").  The member pass is bound by vector issue (four waves per SIMD walk the same 63 headers):
+// members 0 .. 31 and 32 .. 62 are collected in two 32-bit words, highest member first, each predicate by ONE compare and ONE
+// add-with-carry (m = m + m + predicate) -- 10 vector instructions per member at level 3 where the 64-bit select-and-or form takes 24.
+__device__ __forceinline__ void tc_shift_in_le(uint32_t &m, int a, int b)          // m = m << 1 | (a <= b)
+{
+    asm volatile("v_cmp_le_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ void tc_shift_in_eq(uint32_t &m, int a, int b)          // m = m << 1 | (a == b)
+{
+    asm volatile("v_cmp_eq_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ void tc_shift_in_le2(uint32_t &m, int a, int b, int c, int d)      // m = m << 1 | (a <= b && c <= d)
+{
+    unsigned long long t;
+    asm volatile("v_cmp_le_i32 vcc, %2, %3\n\tv_cmp_le_i32 %1, %4, %5\n\ts_and_b64 vcc, vcc, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                 : "+v"(m), "=&s"(t) : "v"(a), "v"(b), "v"(c), "v"(d) : "vcc", "scc");
+}
+template <int LEVEL>
+__device__ __forceinline__ ChunkVisit tc_visit(const int2 *s_se, const int4 *s_hx, int w_n, bool work, uint32_t n, const ReadEnds &re, const m64_t *tilemask)
+{
+    ChunkVisit m{0ull, 0ull, 0ull, 0ull, false, false};
+    if (!__any(work) || w_n <= 0) return m;
+    uint32_t aft[2] = {0u, 0u}, bef[2] = {0u, 0u}, lm[2] = {0u, 0u}, rm[2] = {0u, 0u};
+#pragma unroll
+    for (int half = 1; half >= 0; --half) {
+        const int j_hi = half ? TC_MEMBERS_PER - 1 : 31, j_lo = half ? 32 : 0;
+#pragma unroll 4
+        for (int j = j_hi; j >= j_lo; --j) {
+            const int2 hk = s_se[j];                                         // {start, end}: 8 bytes of the 16 the verdicts' header word has
+            tc_shift_in_le(aft[half], re.el, hk.x);                          // comp_trans <= (Q5): the read lies before the member
+            tc_shift_in_le(bef[half], hk.y, re.s0);                          // the member lies before the read
+            if (LEVEL >= 1 && LEVEL <= 4) {
+                const int4 hx = s_hx[j];
+                if (LEVEL == 1) { tc_shift_in_eq(lm[half], re.e0, hx.y); tc_shift_in_eq(rm[half], re.sl, hx.z); }
+                else {
+                    tc_shift_in_le2(lm[half], re.s0, hx.y, hx.x, re.e0);     // closed_overlap(s0, e0, hx.x, hx.y)
+                    if (LEVEL != 4) tc_shift_in_le2(rm[half], re.sl, hx.w, hx.z, re.el);
+                }
+            }
+        }
+    }
+    const m64_t m_aft = ((m64_t)aft[1] << 32) | aft[0], m_bef = ((m64_t)bef[1] << 32) | bef[0];
+    m.lmask = ((m64_t)lm[1] << 32) | lm[0]; m.rmask = ((m64_t)rm[1] << 32) | rm[0];
+    const m64_t keep = w_n >= 64 ? ~0ull : ((1ull << w_n) - 1ull);
+    const m64_t stop = m_aft & keep;
+    const m64_t below = (stop & (0ull - stop)) - 1ull;                       // all ones when no member ends the sweep
+    m.vpre = work ? (~m_bef & below & keep) : 0ull;
+    m.stopped = work && stop != 0ull;
+    m.lmask &= m.vpre; m.rmask &= m.vpre;
+    const m64_t single = tilemask[0];
+    if (n == 1) {
+        m64_t c = m.vpre & single;
+        while (c) {
+            const int j = __ffsll((long long)c) - 1;
+            c &= c - 1ull;
+            const int4 hx = s_hx[j];
+            if (overlap_frac(re.s0, re.e0, hx.x, hx.y) >= fast_args()->p.frac) m.k1mask |= 1ull << j;
+        }
+    } else if (m.vpre & tilemask[1] & ~single) m.redo = true;
+    return m;
+}
+
+// map_exons_lds64 (l2r_chunk.hip.h) with the lookups done: per exon the ORs over the parts its word names.  The first two parts of both
+// keys are read without a loop (four independent 16-byte reads in flight; a part that is not there is read and not used), the next
+// exon's word is asked for before this exon's masks are looked at.
 __device__ __forceinline__ SiteMasks64 tc_map_exons(const TcLds &L, bool mapping, uint32_t *Ap, const uint32_t *Rp, uint32_t n, m64_t vpre)
 {
     SiteMasks64 m{~0ull, 0ull, 0ull, 0ull, 0ull};
     const int k_max = wave_max(mapping ? (int)n : 0);
+    const uint32_t nm1 = mapping ? n - 1u : 0u;
+    uint32_t R = mapping ? Rp[0] : 0u;
     for (int k = 0; k < k_max; ++k) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
-        const uint32_t R = live ? Rp[k] : 0u;
-        m64_t xm = 0ull, am = 0ull, jm = 0ull, dm = 0ull;
-        {   const uint32_t i0 = R & 1023u, c0 = (R >> 10) & 31u;
-            for (uint32_t c = 0; c < c0; ++c) { const TcMask q = L.msk0[i0 + c]; xm |= q.pm; am |= q.sm; }
-            if (!((R >> 15) & 1u)) xm = 0ull; }
-        {   const uint32_t R1 = junc ? R >> 16 : 0u;
-            const uint32_t i0 = R1 & 1023u, c0 = (R1 >> 10) & 31u;
-            for (uint32_t c = 0; c < c0; ++c) { const TcMask q = L.msk1[i0 + c]; jm |= q.pm; dm |= q.sm; }
-            if (!((R1 >> 15) & 1u)) jm = 0ull; }
+        const uint32_t R0 = live ? R & TC_HALF_MASK : 0u, R1 = junc ? (R >> TC_HALF_BITS) & TC_HALF_MASK : 0u;
+        const uint32_t i0 = R0 & 511u, c0 = (R0 >> 9) & 15u, i1 = R1 & 511u, c1 = (R1 >> 9) & 15u;
+        const TcMask a0 = L.msk0[i0], a1 = L.msk0[i0 + 1u], b0 = L.msk1[i1], b1 = L.msk1[i1 + 1u];
+        const uint32_t Rn = mapping ? Rp[min((uint32_t)k + 1u, nm1)] : 0u;
+        m64_t xm = c0 ? a0.pm : 0ull, am = c0 ? a0.sm : 0ull, jm = c1 ? b0.pm : 0ull, dm = c1 ? b0.sm : 0ull;
+        xm |= c0 > 1u ? a1.pm : 0ull; am |= c0 > 1u ? a1.sm : 0ull; jm |= c1 > 1u ? b1.pm : 0ull; dm |= c1 > 1u ? b1.sm : 0ull;
+        if (__any(c0 > 2u || c1 > 2u)) {
+            for (uint32_t c = 2u; c < c0; ++c) { const TcMask q = L.msk0[i0 + c]; xm |= q.pm; am |= q.sm; }
+            for (uint32_t c = 2u; c < c1; ++c) { const TcMask q = L.msk1[i1 + c]; jm |= q.pm; dm |= q.sm; }
+        }
+        if (!((R0 >> 13) & 1u)) xm = 0ull;
+        if (!((R1 >> 13) & 1u)) jm = 0ull;
         const m64_t amj = junc ? am : 0ull;
         uint32_t word = first_member64(xm & vpre);
         word |= first_member64(jm & vpre) << 6;
@@ -109,31 +214,35 @@ __device__ __forceinline__ SiteMasks64 tc_map_exons(const TcLds &L, bool mapping
         if (k == 0) m.dm_first = dm;
         m.am_last = (live && !junc) ? am : m.am_last;
         if (live) Ap[k] = (Ap[k] & SLAB_REL_MASK) | (word << SLAB_REL_BITS);
+        R = Rn;
     }
     return m;
 }
 
-constexpr int TC_LDS_BYTES = TILE_POS_CAP * (4 + 2 + 4 + 1) + TC_ENT_POOL * (8 + 16) + 3 * TC_DIR_N * 2 + 2 * 64 * 16 + TC_TRIPS + TC_CHUNKS * 2 + 128;
-static_assert(TC_LDS_BYTES <= 54272, "k_tile_chunk: 3 workgroups per CU need 106 allocation granules of 512 bytes at most");
+constexpr int TC_LDS_BYTES = TILE_POS_CAP * (4 + 2 + 4) + TC_ST_CAP * 8 + (TC_ENT_POOL + 2) * 16 + 3 * TC_DIR_N * 2 + 2 * 64 * 16 + 64 * 8 + TC_TRIPS + TC_CHUNKS * 2 + 64;
+static_assert(TC_LDS_BYTES <= 40960, "k_tile_chunk: 4 workgroups per CU need 80 allocation granules of 512 bytes at most");
 
 template <int LEVEL>
-__global__ __launch_bounds__(TILE_THREADS, 3)
+__global__ __launch_bounds__(TILE_THREADS, 4)
 void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const TileWin *__restrict__ u_tw, const TileStat *__restrict__ u_stat, const SlotRec *__restrict__ u_slot,
                   uint32_t *__restrict__ u_xbase)
 {
     constexpr uint32_t F_ALL = (uint32_t)(F_EXON | F_DON | F_ACC | F_JUNC);
     __shared__ __attribute__((aligned(16))) uint32_t s_A[TILE_POS_CAP];          // row words: start - base | the chunk's work word << 18 (at the end: | flag byte << 18)
     __shared__ __attribute__((aligned(16))) uint16_t s_L[TILE_POS_CAP];          // lengths
-    __shared__ __attribute__((aligned(16))) uint32_t s_R[TILE_POS_CAP];          // lookup words (tc_lookup): START | END << 16
-    __shared__ __attribute__((aligned(16))) uint8_t s_F[TILE_POS_CAP];           // novel flags still standing
-    __shared__ __attribute__((aligned(16))) int2 s_key[TC_ENT_POOL];
-    __shared__ __attribute__((aligned(16))) TcMask s_msk[TC_ENT_POOL];
+    __shared__ __attribute__((aligned(16))) uint32_t s_R[TILE_POS_CAP];          // lookup words (tc_lookup): START | END << 14 | novel flags still standing << 28
+    __shared__ __attribute__((aligned(16))) int2 s_key0[TC_ST_CAP];              // START keys (the full-length evidence asks them in every chunk)
+    // the entries' masks in the chunk's frame, START entries first; until the first chunk the END entries' KEYS live in the END part (the
+    // lookups are through before a mask is written); two entries more: a part that is not there may be read
+    __shared__ __attribute__((aligned(16))) TcMask s_msk[TC_ENT_POOL + 2];
     __shared__ __attribute__((aligned(16))) uint16_t s_dir[3 * TC_DIR_N];
     __shared__ __attribute__((aligned(16))) int4 s_hk[64], s_hx[64];
+    __shared__ __attribute__((aligned(16))) int2 s_se[64];                        // the members' {start, end} once more (the member pass is bound by its LDS reads)
     __shared__ __attribute__((aligned(16))) uint8_t s_trip[TC_TRIPS];                                         // per stretch: 1 has a member | 2 the sweeps end in it
     __shared__ uint16_t s_chunk[TC_CHUNKS];
     __shared__ m64_t s_mask[2];
     __shared__ uint32_t s_lb[4], s_nchunk, s_bad;
+    int2 *const s_key1 = reinterpret_cast<int2 *>(s_msk + TC_ST_CAP);
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
@@ -142,6 +251,9 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
     const uint32_t t = sa->chunk_list[blockIdx.x];
     const uint32_t n_tiles = sa->n_tiles;
     if (t >= n_tiles) return;
+    // diagnostics (L2R_STAMPS=1), wave 0: [0] records, loads asked for, window scan  [1] place walk + barrier  [2] chunk list, key lookups + barrier
+    // [3] per chunk: headers + masks staged, barrier  [4] member pass  [5] mask ORs  [6] carried state + barrier  [7] verdicts, first slot, write-out
+    SlabStamp stamp; stamp.start(a->f.stamps); if (stamp.who == 3) stamp.who = -1;
     __builtin_amdgcn_s_setprio(TILE_PRIO);
     const v3u_a4 srec = *reinterpret_cast<const v3u_a4 *>(u_slot + ((size_t)t * TILE_THREADS + threadIdx.x));
     const TileRec rec = u_rec[t];
@@ -187,7 +299,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
         if (e < n_ent) {
             const int4 *const qv = reinterpret_cast<const int4 *>(e < d.st_nk ? a->f.st.ent + d.st_r0 + e : a->f.en.ent + d.en_r0 + (e - d.st_nk));
             const int4 xa = qv[0], xb = qv[1];
-            s_key[e] = make_int2(xa.x, xa.y);
+            if (e < d.st_nk) s_key0[e] = make_int2(xa.x, xa.y); else s_key1[e - d.st_nk] = make_int2(xa.x, xa.y);
             e_base[u] = xa.z;
             e_pm[u] = ((m64_t)(uint32_t)xb.y << 32) | (uint32_t)xb.x; e_sm[u] = ((m64_t)(uint32_t)xb.w << 32) | (uint32_t)xb.z;
         }
@@ -226,6 +338,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
             if (last) break;
         }
     }
+    stamp.mark(0);
 #pragma unroll
     for (int i = 0; i < SLAB_HEAD; ++i) cg[i] = (uint32_t)i < n_cig ? cg[i] : 1u;
     DevParams p;
@@ -242,7 +355,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
         first_share = wave_sum(in ? (uint32_t)ev : 0u);
     }
     // ---- the place walk (k_tile's): the read's exons as row words at their read-order positions
-    uint32_t *const Ap = s_A + loc; uint16_t *const Lp = s_L + loc; uint32_t *const Rp = s_R + loc; uint8_t *const Fp = s_F + loc;
+    uint32_t *const Ap = s_A + loc; uint16_t *const Lp = s_L + loc; uint32_t *const Rp = s_R + loc;
     ReadEnds re{0, 0, 0, 0};
     bool sane = true, big = false;
     uint32_t n = 0u;
@@ -275,11 +388,12 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
             for (uint32_t i = SLAB_HEAD; i < n_ops; ++i) step(words[i]);
         }
         {   const uint32_t xlen = (uint32_t)(end - start + 1);
-            Ap[n] = (uint32_t)(start - tile_lo) & SLAB_REL_MASK; Lp[n] = (uint16_t)xlen;
+            Ap[n] = ((uint32_t)(start - tile_lo) & SLAB_REL_MASK) | TC_ROW_LAST; Lp[n] = (uint16_t)xlen;
             longest = max(longest, xlen);
             if ((uint32_t)(start - tile_lo) >= SLAB_REL_MASK) longest = 0xffffffffu; }
         if (first) { s0 = start; e0 = end; }
         ++n;
+        Ap[0] |= TC_ROW_FIRST;                                   // (until the first chunk's work words: which exons begin / end a read, for the lookups)
         sane = s0 <= e0 && start <= end;
         big = longest > SLAB_LEN_MAX;
         re = ReadEnds{s0, e0, start, end};
@@ -287,6 +401,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
     const uint32_t r = r0 + idx;
     const bool rev_in = (xs & SLOT_REV) != 0u;
     __syncthreads();                                         // (keys, directories, the stretches' words are whole)
+    stamp.mark(1);
     // ---- the chunk list (wave 0, four stretches per lane) while the other waves begin their lookups
     if (wv == 0) {
         const uint32_t f4 = reinterpret_cast<const uint32_t *>(s_trip)[lane];
@@ -305,35 +420,36 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
         const uint32_t nc = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
         if (lane == 0) { s_nchunk = nc; if (ms == 0ull || nc > (uint32_t)TC_CHUNKS) s_bad = 1u; }      // (no end in sight, too many chunks: the generic kernel)
     }
-    // ---- the key lookups, once per tile
+    // ---- the key lookups, once per tile, a POSITION per thread and round (every thread the same number of lookups, whatever its read's
+    //      exon count; an exon's successor is the next position unless it ends its read)
     bool redo = active && (big || (n > 1 && !sane));
     const bool work0 = active && !redo;
     const uint32_t none = (uint32_t)d.nbk + 1u;
-    const int2 *const key0 = s_key, *const key1 = s_key + d.st_nk;
-    if (work0) {
-        bool over = false;
-        int s = re.s0, e = re.e0;
-        for (uint32_t k = 0; k < n; ++k) {
-            const bool junc = k + 1u < n;
-            int s2 = 0, e2 = 0;
-            if (junc) { s2 = tile_lo + (int)Ap[k + 1u]; e2 = s2 + (int)Lp[k + 1u] - 1; }
-            const uint32_t w0 = (n > 1u && !(ablate & 16384)) ? tc_lookup(key0, s_dir0, d.b_off, none, true, s, e, over) : 0u;
-            const uint32_t w1 = (ablate & 16384) ? 0u : tc_lookup(key1, s_dir1, d.b_off, none, junc, e, s2, over);      // (bit 14, timing diagnostics: no lookups -- results wrong)
-            Rp[k] = w0 | (w1 << 16);
-            Fp[k] = (uint8_t)F_ALL;
-            s = s2; e = e2;
+    const int2 *const key0 = s_key0, *const key1 = s_key1;
+    {
+        const TcKey K0{key0, s_dir0}, K1{key1, s_dir1};
+        for (uint32_t q = threadIdx.x; q < total; q += (uint32_t)TILE_THREADS) {
+            const uint32_t aw = s_A[q];
+            const bool first_x = (aw & TC_ROW_FIRST) != 0u, last_x = (aw & TC_ROW_LAST) != 0u;
+            const int s = tile_lo + (int)(aw & SLAB_REL_MASK), e = s + (int)s_L[q] - 1;
+            const int s2 = last_x ? 0 : tile_lo + (int)(s_A[q + 1u] & SLAB_REL_MASK);
+            bool over = false;
+            uint32_t w = (ablate & 16384) ? 0u : tc_lookup2(K0, K1, d.b_off, none, !(first_x && last_x), !last_x, s, e, s2, over);      // (bit 14, timing diagnostics: no lookups -- results wrong)
+            if (over) w = TC_R_OVER;
+            s_R[q] = w | (F_ALL << TC_F_SHIFT);
         }
-        redo = over;
     }
     __syncthreads();                                         // (the chunk list)
+    stamp.mark(2);
     const uint32_t n_chunk = s_nchunk;
     const bool bad = s_bad != 0u;
     redo = redo || (active && bad);
+    if (work0) { bool over = false; for (uint32_t k = 0; k < n; ++k) over = over || (Rp[k] & ((1u << TC_F_SHIFT) - 1u)) == TC_R_OVER; redo = redo || over; }
     // ---- the sweep, chunk by chunk
     __builtin_amdgcn_s_setprio(0);
     bool known = false, stopped = false, ksite = false, lfull = false, rfull = false, lnoth = true, rnoth = true, out_rev = rev_in;
     int ref = -1;
-    const TcLds L{key0, key1, s_msk, s_msk + d.st_nk, s_dir0, s_dir1, s_rdir, s_hk, s_hx};
+    const TcLds L{key0, key1, s_msk, s_msk + TC_ST_CAP, s_dir0, s_dir1, s_rdir, s_hk, s_hx};
     const TxHdr *const hdr = a->f.hdr;
     // (the headers of the chunk's transcripts: thread j < 63 asks for transcript cb + j one chunk ahead)
     int4 h0 = make_int4(0, 0, 0, 0), h1 = h0, h2 = h0;
@@ -354,7 +470,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
                 int st = h0.y, en = h0.z;
                 if (h0.x < tid0) { st = INT32_MIN; en = INT32_MIN; }            // another chromosome: before / after every read
                 else if (h0.x > tid0) { st = INT32_MAX; en = INT32_MAX; }
-                s_hk[lane] = make_int4(st, en, h1.x, (h1.z & 0xff) | (h1.y << 8));
+                s_hk[lane] = make_int4(st, en, h1.x, (h1.z & 0xff) | (h1.y << 8)); s_se[lane] = make_int2(st, en);
                 s_hx[lane] = h2;
                 single = h1.x == 1 && lane < w_n; loose = !((h1.z & 0xff) & TX_COMPACT) && lane < w_n;
             }
@@ -369,17 +485,19 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
             if (e < n_ent) {
                 const int dd = e_base[u] - cb;
                 TcMask q; q.pm = rebase64(e_pm[u], dd) & keepm; q.sm = rebase64(e_sm[u], dd) & keepm;
-                s_msk[e] = q;
+                s_msk[e < d.st_nk ? e : e - d.st_nk + (uint32_t)TC_ST_CAP] = q;
             }
         }
         __syncthreads();
+        stamp.mark(3);
         ask_headers(ci + 1u);
         const bool work = work0 && !redo && !known && !stopped;
-        const ChunkLds CL{nullptr, nullptr, nullptr, nullptr, nullptr, s_hk, s_hx, nullptr};
-        const ChunkVisit vm = visit_chunk64<LEVEL>(CL, (ablate & 8192) ? 0 : w_n, work, n, re, s_mask);
+        const ChunkVisit vm = tc_visit<LEVEL>(s_se, s_hx, (ablate & 8192) ? 0 : w_n, work, n, re, s_mask);
         redo = redo || vm.redo;
+        stamp.mark(4);
         const bool mapping = work && !vm.redo && n > 1 && !(ablate & 4096);
         const SiteMasks64 sm = tc_map_exons(L, mapping, Ap, Rp, n, vm.vpre);
+        stamp.mark(5);
         if (work && !vm.redo) {
             int jstar = -1;
             if (n > 1) {
@@ -417,7 +535,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
                     const uint32_t w = Ap[k] >> SLAB_REL_BITS;
                     uint32_t clr = ((w & 63u) <= lim ? (uint32_t)F_EXON : 0u) | (((w >> 6) & 63u) <= lim ? (uint32_t)F_JUNC : 0u);
                     if (!known_c) clr |= (((w >> 12) & 1u) ? (uint32_t)F_DON : 0u) | (((w >> 13) & 1u) ? (uint32_t)F_ACC : 0u);
-                    Fp[k] = (uint8_t)(Fp[k] & ~clr);
+                    Rp[k] &= ~(clr << TC_F_SHIFT);
                 }
             }
             known = known_c;
@@ -425,7 +543,9 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
         }
         // (the next chunk overwrites headers and masks; nobody left who sweeps on: the loop ends for the whole workgroup)
         const bool on = work0 && !redo && !known && !stopped;
-        if (!__syncthreads_or(on ? 1 : 0)) break;
+        const int go_on = __syncthreads_or(on ? 1 : 0);
+        stamp.mark(6);
+        if (!go_on) break;
     }
     __builtin_amdgcn_s_setprio(TILE_PRIO);
     // ---- verdicts; flag bytes into the row words
@@ -433,7 +553,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
     if (work0 && !redo) {
         if (n > 1) {
             for (int k = 0; k < (int)n; ++k) {
-                uint32_t f = Fp[k];
+                uint32_t f = Rp[k] >> TC_F_SHIFT;
                 if (known) f &= ~(uint32_t)(F_DON | F_ACC);                             // (every site of a known read is its transcript's)
                 f &= (k + 1 == (int)n) ? (uint32_t)F_EXON : 0xffu;                      // the last exon has no junction behind it
                 Ap[k] = (Ap[k] & SLAB_REL_MASK) | (f << SLAB_REL_BITS);
@@ -483,6 +603,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
         put(w.n, w.start, w.end);
     }
     slab_write_out(SlabOut{out.start, out.end, out.flag, xbase}, s_A, s_L, tile_lo, total);
+    stamp.mark(7);
 }
 
 }  // namespace l2r

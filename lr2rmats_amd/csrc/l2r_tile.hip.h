@@ -78,9 +78,14 @@ constexpr uint32_t SLOT_REV = 1u << 8, SLOT_VALID = 1u << 9;
 constexpr int SLOT_IDX_SHIFT = 10, SLOT_LOC_SHIFT = 18;
 constexpr uint32_t SLOT_LOC_LIMIT = 1u << 12;
 __device__ __forceinline__ uint32_t tile_rot(uint32_t t) { return (t ^ (t >> 3) ^ (t >> 7)) & 3u; }
+// SUMMARY: the caller's per-record CIGAR summaries are there (l2r_reads::cig_summary) -- the host has made the tiles' statistics and last
+// bases from them, the records' N operations come as one 16-bit column (sum_nn): no CIGAR is touched, the kernel is the scan and the
+// counting sort over 15 bytes per record in, 12 out.
+template <bool SUMMARY>
 __global__ __launch_bounds__(TILE_THREADS)
 void k_tile_index(TileRec *__restrict__ rec, TileStat *__restrict__ stat, SlotRec *__restrict__ slot_rec, uint32_t n_tiles,
-                  const uint32_t *__restrict__ cig_off32, const int32_t *__restrict__ r_pos, const uint8_t *__restrict__ r_rev, const uint32_t *__restrict__ cig)
+                  const uint32_t *__restrict__ cig_off32, const int32_t *__restrict__ r_pos, const uint8_t *__restrict__ r_rev, const uint32_t *__restrict__ cig,
+                  const uint16_t *__restrict__ sum_nn)
 {
     __shared__ int s_m[5][TILE_THREADS / WAVE];
     __shared__ uint32_t s_hist[WAVE], s_wave[TILE_THREADS / WAVE];
@@ -95,6 +100,8 @@ void k_tile_index(TileRec *__restrict__ rec, TileStat *__restrict__ stat, SlotRe
             c_lo = cig_off32[r]; c = cig_off32[r + 1u] - c_lo; pos = r_pos[r]; rev = r_rev[r] ? 1u : 0u;
             end = pos;
             int seg = 0; bool first = true;
+            if (SUMMARY) n_n = (int)sum_nn[r];
+            else
             for (uint32_t k = c_lo; k < c_lo + c; ++k) {
                 const uint32_t w = cig[k], op = w & 0xfu; const int len = (int)(w >> 4);
                 if (op == 3u) {
@@ -111,8 +118,10 @@ void k_tile_index(TileRec *__restrict__ rec, TileStat *__restrict__ stat, SlotRe
         // the read's place among the tile's exons in read order if every N operation is an intron and nothing is dropped
         uint32_t tot_x;
         const uint32_t loc = block_exclusive_scan(active ? (uint32_t)n_n + 1u : 0u, s_wave, tot_x);
+        if (!SUMMARY) {      // (with summaries the host has applied both rules to the statistics it made)
         if (__syncthreads_or(active && n_n + 1 >= 255)) min_seg = INT32_MIN;      // (a read of 255 exons or more: never an exact tile -- k_tile counts it and gives it the slab form)
         if (tot_x >= SLOT_LOC_LIMIT) min_seg = INT32_MIN;         // (places the record cannot say: the tile counts in k_tile -- it keeps the slab form anyway)
+        }
         // the counting sort of k_walk_slab (64 bins by CIGAR length, threads without a read last)
         if (i < (uint32_t)WAVE) s_hist[i] = 0u;
         __syncthreads();
@@ -125,6 +134,7 @@ void k_tile_index(TileRec *__restrict__ rec, TileStat *__restrict__ stat, SlotRe
         const uint32_t at = (s_hist[bin] + rank - (tile_rot(t) << 6)) & (uint32_t)(TILE_THREADS - 1);      // the thread of that slot
         slot_rec[(size_t)t * TILE_THREADS + at] = SlotRec{c_lo, pos, min(c, 255u) | (rev ? SLOT_REV : 0u) | (active ? SLOT_VALID : 0u) | (i << SLOT_IDX_SHIFT) |
                                                                          (min(loc, SLOT_LOC_LIMIT - 1u) << SLOT_LOC_SHIFT)};
+        if (SUMMARY) continue;                                   // (statistics and last base: the host's, from the summaries)
         const int v[5] = {wave_max(end), (int)wave_sum((uint32_t)n_n), wave_min(min_n), wave_max(max_d), wave_min(min_seg)};
         if ((threadIdx.x & (WAVE - 1)) == 0) for (int k = 0; k < 5; ++k) s_m[k][threadIdx.x >> 6] = v[k];
         __syncthreads();

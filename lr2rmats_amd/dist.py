@@ -118,7 +118,8 @@ def _engine_classify(device_index: int):
         limit = int(os.environ.get("L2R_CHUNK_READS", "0") or 0)
         max_units = 0xf0000000
         if (hi - lo) + (c1 - c0) < max_units and not (limit and hi - lo > limit):
-            eng.upload_reads(r["tid"][lo:hi], r["pos"][lo:hi], r["rev"][lo:hi], r["cig_off"][lo:hi + 1] - c0, r["cig"][c0:c1], first_read_index=base + lo)
+            eng.upload_reads(r["tid"][lo:hi], r["pos"][lo:hi], r["rev"][lo:hi], r["cig_off"][lo:hi + 1] - c0, r["cig"][c0:c1], first_read_index=base + lo,
+                             cig_summary=None if r.get("cig_summary") is None else r["cig_summary"][lo:hi])
             eng.run()
             eng.sync()
             return DeviceShard(eng)
@@ -135,7 +136,8 @@ def _engine_classify(device_index: int):
             ca, cb = int(r["cig_off"][a]), int(r["cig_off"][b])
             if (b - a) + (cb - ca) >= 0xfffffff0:
                 raise RuntimeError("record %d alone exceeds the engine's shard limit" % (base + a))
-            eng.upload_reads(r["tid"][a:b], r["pos"][a:b], r["rev"][a:b], r["cig_off"][a:b + 1] - ca, r["cig"][ca:cb], first_read_index=base + a)
+            eng.upload_reads(r["tid"][a:b], r["pos"][a:b], r["rev"][a:b], r["cig_off"][a:b + 1] - ca, r["cig"][ca:cb], first_read_index=base + a,
+                             cig_summary=None if r.get("cig_summary") is None else r["cig_summary"][a:b])
             eng.run()
             eng.sync()
             parts.append(eng.download())

@@ -122,6 +122,42 @@ h_blob h_slurp(const char *fn, const char *who)
     return b;
 }
 
+/* What the engine's upload would otherwise walk every CIGAR for (include/lr2rmats_hip.h, l2r_reads::cig_summary): collected op by op
+ * where a record's CIGAR is converted anyway -- reference bases, N operations, the shortest N, the longest D, the shortest stretch of
+ * reference bases between two N operations (src/bam2gtf.c:41-74: what decides whether an N cuts, a D cuts, an inner exon is dropped). */
+typedef struct { uint64_t ref, seg; uint32_t nn, mn, md, ms; int first; } cigsum;
+static inline void cigsum_init(cigsum *a) { a->ref = 0; a->seg = 0; a->nn = 0; a->mn = 65535u; a->md = 0; a->ms = 65535u; a->first = 1; }
+static inline void cigsum_op(cigsum *a, uint32_t w)
+{
+    const uint32_t op = w & 15u, len = w >> 4;
+    const int adv = (0x18d >> op) & 1;                    /* ops M D N = X advance the reference */
+    if (op == 3u) {
+        a->nn++; if (len < a->mn) a->mn = len;
+        if (!a->first && a->seg < a->ms) a->ms = (uint32_t)a->seg;      /* (the stretch in front of the first N is the first exon: kept whatever its length) */
+        a->first = 0; a->seg = 0;
+    } else {
+        if (op == 2u && len > a->md) a->md = len;
+        if (adv) a->seg += len;
+    }
+    if (adv) a->ref += len;
+}
+static inline void cigsum_store(const cigsum *a, uint32_t *q)
+{
+    q[0] = a->ref > 0xffffffffull ? 0xffffffffu : (uint32_t)a->ref;
+    q[1] = (a->nn > 65535u ? 65535u : a->nn) | ((a->mn > 65535u ? 65535u : a->mn) << 16);
+    q[2] = (a->md > 65535u ? 65535u : a->md) | ((a->ms > 65535u ? 65535u : a->ms) << 16);
+}
+
+/* the same for records that are in memory already (synthetic reads, callers with their own reader): out[3 * n] */
+void h_cigar_summaries(int64_t n, const int64_t *cig_off, const uint32_t *cig, uint32_t *out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        cigsum cs; cigsum_init(&cs);
+        for (int64_t k = cig_off[i]; k < cig_off[i + 1]; ++k) cigsum_op(&cs, cig[k]);
+        cigsum_store(&cs, out + 3 * (size_t)i);
+    }
+}
+
 static void reads_reserve(h_reads *r, int64_t more_reads, int64_t more_cig)
 {
     if (r->n + more_reads + 1 > r->cap) {
@@ -130,6 +166,7 @@ static void reads_reserve(h_reads *r, int64_t more_reads, int64_t more_cig)
         r->tid = (int32_t *)h_realloc(r->tid, (size_t)c * 4); r->pos = (int32_t *)h_realloc(r->pos, (size_t)c * 4);
         r->rev = (uint8_t *)h_realloc(r->rev, (size_t)c); r->cig_off = (int64_t *)h_realloc(r->cig_off, (size_t)(c + 1) * 8);
         r->qname = (uint32_t *)h_realloc(r->qname, (size_t)c * 4);
+        r->cig_sum = (uint32_t *)h_realloc(r->cig_sum, (size_t)c * 12);
         r->cap = c;
     }
     if (r->n_cig + more_cig > r->cap_cig) {
@@ -141,7 +178,7 @@ static void reads_reserve(h_reads *r, int64_t more_reads, int64_t more_cig)
 
 void h_reads_free(h_reads *r)
 {
-    free(r->tid); free(r->pos); free(r->rev); free(r->cig_off); free(r->cig); free(r->qname); free(r->tid_name); free(r->names.buf);
+    free(r->tid); free(r->pos); free(r->rev); free(r->cig_off); free(r->cig); free(r->cig_sum); free(r->qname); free(r->tid_name); free(r->names.buf);
     memset(r, 0, sizeof *r);
 }
 
@@ -219,6 +256,7 @@ static void parse_sam(const blob *b, h_chroms *chr, h_reads *out, int skip_unmap
         out->pos[out->n] = atoi(f[3]) - 1;
         /* CIGAR */
         out->cig_off[out->n] = out->n_cig;
+        cigsum cs; cigsum_init(&cs);
         {
             const char *c = f[5], *ce = f[6] - 1;
             if (!(ce - c == 1 && *c == '*')) {
@@ -234,6 +272,7 @@ static void parse_sam(const blob *b, h_chroms *chr, h_reads *out, int skip_unmap
                     default: h_fatal(who, "bad CIGAR operator '%c'", *c); op = 0;
                     }
                     out->cig[out->n_cig++] = (len << 4) | op;
+                    cigsum_op(&cs, (len << 4) | op);
                     ++c;
                 }
             }
@@ -255,6 +294,7 @@ static void parse_sam(const blob *b, h_chroms *chr, h_reads *out, int skip_unmap
             }
             out->rev[out->n] = rev;
         }
+        cigsum_store(&cs, out->cig_sum + 3 * (size_t)out->n);
         out->n++;
         out->cig_off[out->n] = out->n_cig;
         p = e + 1;
@@ -328,7 +368,9 @@ static void *bam_piece_main(void *arg)
         add_qname(out, (const char *)name, strnlen((const char *)name, l_read_name), who);
         out->tid[out->n] = refid; out->pos[out->n] = pos; out->rev[out->n] = rev;
         out->cig_off[out->n] = out->n_cig;
-        for (uint32_t k = 0; k < cn; ++k) out->cig[out->n_cig++] = le32(cp + 4 * (size_t)k);
+        cigsum cs; cigsum_init(&cs);
+        for (uint32_t k = 0; k < cn; ++k) { const uint32_t w = le32(cp + 4 * (size_t)k); out->cig[out->n_cig++] = w; cigsum_op(&cs, w); }
+        cigsum_store(&cs, out->cig_sum + 3 * (size_t)out->n);
         out->n++;
         out->cig_off[out->n] = out->n_cig;
     }
@@ -343,6 +385,7 @@ static void *bam_join_main(void *arg)
     memcpy(out->tid + at, q->tid, (size_t)q->n * 4); memcpy(out->pos + at, q->pos, (size_t)q->n * 4); memcpy(out->rev + at, q->rev, (size_t)q->n);
     for (int64_t i = 0; i < q->n; ++i) { out->cig_off[at + i] = q->cig_off[i] + cat; out->qname[at + i] = q->qname[i] + (uint32_t)nat; }
     memcpy(out->cig + cat, q->cig, (size_t)q->n_cig * 4);
+    memcpy(out->cig_sum + 3 * (size_t)at, q->cig_sum, (size_t)q->n * 12);
     memcpy(out->names.buf + nat, q->names.buf, q->names.len);
     h_reads_free(q);
     return NULL;

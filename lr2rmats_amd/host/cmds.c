@@ -288,7 +288,7 @@ void h_job_views(h_job *j, l2r_params *prm, l2r_annotation *a, l2r_junctions *s,
     a->tx_rev = j->anno.rev; a->tx_ex_off = j->anno.ex_off; a->ex_start = j->anno.ex_start; a->ex_end = j->anno.ex_end;
     s->n = j->sj.n; s->tid = j->sj.tid; s->don = j->sj.don; s->acc = j->sj.acc; s->uniq_c = j->sj.uniq; s->multi_c = j->sj.multi;
     r->n_reads = j->reads.n; r->n_cigar = j->reads.n_cig; r->tid = j->reads.tid; r->pos = j->reads.pos; r->rev = j->reads.rev;
-    r->cig_off = j->reads.cig_off; r->cig = j->reads.cig; r->first_read_index = 0;
+    r->cig_off = j->reads.cig_off; r->cig = j->reads.cig; r->first_read_index = 0; r->cig_summary = j->reads.cig_sum;
 }
 
 static int tail_threads(const h_job *j, const h_reads *reads);
@@ -657,6 +657,7 @@ static void *early_engine_main(void *arg)
     (void)arg;
     g_early.ctx = l2r_create(g_device);
     if (!g_early.ctx) { snprintf(g_early.err, sizeof g_early.err, "%s", l2r_last_error()); }
+    else (void)l2r_hint_single_run(g_early.ctx, 1);            /* (this program classifies every upload once) */
     /* ... and its annotation tables (0.15 s for a GENCODE-size GTF) as soon as the GTF has been parsed, beside the record reader */
     pthread_mutex_lock(&g_early.mu);
     while (g_early.anno_state == 0) pthread_cond_wait(&g_early.cv, &g_early.mu);
@@ -708,6 +709,7 @@ static l2r_ctx *engine_take(const char *who, int *anno_set)
     }
     l2r_ctx *c = l2r_create(g_device);
     if (!c) engine_fail(who);
+    (void)l2r_hint_single_run(c, 1);
     return c;
 }
 static void early_engine_drop(void)
@@ -737,6 +739,7 @@ static void run_engine(const char *who, const l2r_params *prm, const l2r_annotat
         l2r_reads sub = *r;
         sub.n_reads = n; sub.n_cigar = r->cig_off[hi] - r->cig_off[lo];
         sub.tid = r->tid + lo; sub.pos = r->pos + lo; sub.rev = r->rev + lo; sub.cig = r->cig + r->cig_off[lo];
+        sub.cig_summary = r->cig_summary ? r->cig_summary + 3 * (size_t)lo : NULL;
         sub.first_read_index = r->first_read_index + lo;
         if (lo > 0) {                                        /* the engine wants offsets that start at 0 */
             off_tmp = (int64_t *)h_realloc(off_tmp, (size_t)(n + 1) * 8);
@@ -1013,6 +1016,7 @@ static int update_gtf_multi(h_job *j, int n_gpus, int gathered)
                 l2r_reads sub = r;
                 sub.n_reads = hi - lo; sub.n_cigar = r.cig_off[hi] - r.cig_off[lo];
                 sub.tid = r.tid + lo; sub.pos = r.pos + lo; sub.rev = r.rev + lo; sub.cig = r.cig + r.cig_off[lo];
+                sub.cig_summary = r.cig_summary ? r.cig_summary + 3 * (size_t)lo : NULL;
                 int64_t *off = (int64_t *)h_malloc((size_t)(hi - lo + 1) * 8);
                 for (int64_t i = 0; i <= hi - lo; ++i) off[i] = r.cig_off[lo + i] - r.cig_off[lo];
                 sub.cig_off = off; sub.first_read_index = lo;
@@ -1137,6 +1141,7 @@ static int update_gtf_multi(h_job *j, int n_gpus, int gathered)
                 l2r_reads sub = r;
                 sub.n_reads = hi - lo; sub.n_cigar = r.cig_off[hi] - r.cig_off[lo];
                 sub.tid = r.tid + lo; sub.pos = r.pos + lo; sub.rev = r.rev + lo; sub.cig = r.cig + r.cig_off[lo];
+                sub.cig_summary = r.cig_summary ? r.cig_summary + 3 * (size_t)lo : NULL;
                 off = (int64_t *)h_malloc((size_t)(hi - lo + 1) * 8);
                 for (int64_t i = 0; i <= hi - lo; ++i) off[i] = r.cig_off[lo + i] - r.cig_off[lo];
                 sub.cig_off = off; sub.first_read_index = lo;
@@ -1292,7 +1297,7 @@ static void exons_only(const char *who, const char *fn, const l2r_params *prm, h
     l2r_annotation a; memset(&a, 0, sizeof a);
     int64_t zero_off = 0; a.tx_ex_off = &zero_off;
     l2r_junctions s; memset(&s, 0, sizeof s);
-    l2r_reads r = { reads->n, reads->n_cig, reads->tid, reads->pos, reads->rev, reads->cig_off, reads->cig, 0 };
+    l2r_reads r = { reads->n, reads->n_cig, reads->tid, reads->pos, reads->rev, reads->cig_off, reads->cig, 0, reads->cig_sum };
     run_engine(who, prm, &a, &s, &r, out, NULL);
 }
 
@@ -1337,6 +1342,7 @@ int h_cmd_bam2gtf(int argc, char **argv)
     if (st) {
         l2r_ctx *ctx = l2r_create(0);
         if (!ctx) engine_fail("bam2gtf");
+        (void)l2r_hint_single_run(ctx, 1);
         l2r_annotation a; memset(&a, 0, sizeof a);
         int64_t zero_off = 0; a.tx_ex_off = &zero_off;
         if (l2r_set_params(ctx, &p) || l2r_set_outputs(ctx, L2R_WANT_RESULTS) || l2r_set_annotation(ctx, &a) || l2r_set_junctions(ctx, NULL)) engine_fail("bam2gtf");
@@ -1344,7 +1350,7 @@ int h_cmd_bam2gtf(int argc, char **argv)
             h_reads reads; memset(&reads, 0, sizeof reads);
             const int64_t got = h_aln_stream_next(st, &reads);
             if (got > 0) {
-                l2r_reads r = { reads.n, reads.n_cig, reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, 0 };
+                l2r_reads r = { reads.n, reads.n_cig, reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, 0, reads.cig_sum };
                 if (l2r_upload_reads(ctx, &r) || l2r_run(ctx) || l2r_sync(ctx)) engine_fail("bam2gtf");
                 int64_t nr = 0, nx = 0;
                 if (l2r_result_sizes(ctx, &nr, &nx, NULL, NULL)) engine_fail("bam2gtf");

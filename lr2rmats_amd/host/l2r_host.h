@@ -41,6 +41,7 @@ typedef struct {
     uint8_t *rev;
     int64_t *cig_off;
     uint32_t *cig; int64_t n_cig, cap_cig;
+    uint32_t *cig_sum;           /* alignments: three words per record, made while its CIGAR is converted (l2r_reads::cig_summary); NULL for `-m g` input */
     uint32_t *qname;             /* ids into names: QNAME = trans_name (and trans_id, unless tid_name is set) */
     uint32_t *tid_name;          /* `-m g` input only: transcript_id of the read-like transcript (NULL for alignments) */
     h_strtab names;
@@ -60,6 +61,8 @@ h_aln_stream *h_aln_stream_open(const char *fn, h_chroms *chr, int skip_unmapped
 int64_t h_aln_stream_next(h_aln_stream *s, h_reads *out);     /* appends a batch to *out; records appended, -1 at the end */
 void h_aln_stream_close(h_aln_stream *s);
 void h_reads_free(h_reads *r);
+/* per-record CIGAR summaries (l2r_reads::cig_summary, three words each) of records that are in memory already */
+void h_cigar_summaries(int64_t n, const int64_t *cig_off, const uint32_t *cig, uint32_t *out);
 
 /* ---- whole alignment records, BAM-encoded (`filter`: the kept ones are written out again) */
 typedef struct { uint8_t *p; size_t n; } h_blob;

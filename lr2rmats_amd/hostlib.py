@@ -61,6 +61,8 @@ def load_library():
         lib.h_job_write_summary.restype = C.c_int
         lib.h_job_open_outputs.argtypes = [C.c_void_p]
         lib.h_job_set_out_path.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+        lib.h_cigar_summaries.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.h_cigar_summaries.restype = None
         _lib = lib
     return _lib
 
@@ -71,6 +73,15 @@ def _arr(ptr, n, dtype):
     return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype) if False else np.frombuffer(
         (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(C.addressof(ptr.contents)), dtype=dtype, count=n)
 
+
+def cigar_summaries(cig_off, cig) -> np.ndarray:
+    """The reader's per-record CIGAR summaries (l2r_reads::cig_summary, [N, 3] uint32) of records that are in memory already: the C loop of
+    host/aln_reader.c (``synth.cigar_summary`` is the numpy form of the same rule, which the tests hold this to)."""
+    off = np.ascontiguousarray(cig_off, np.int64)
+    cg = np.ascontiguousarray(cig, np.uint32)
+    out = np.empty((len(off) - 1, 3), np.uint32)
+    load_library().h_cigar_summaries(len(off) - 1, off.ctypes.data, cg.ctypes.data, out.ctypes.data)
+    return out
 
 class Job:
     """One ``update-gtf`` invocation: argv = ["update-gtf", options..., in.bam, old.gtf]."""
@@ -124,8 +135,10 @@ class Job:
 
     def read_arrays(self):
         r = self.reads
+        # (cig_summary: the reader's per-record CIGAR summaries, l2r_reads::cig_summary; None for `-m g` input)
+        sm = _arr(r.cig_summary, 3 * r.n_reads, np.uint32).reshape(-1, 3) if r.cig_summary else None
         return dict(tid=_arr(r.tid, r.n_reads, np.int32), pos=_arr(r.pos, r.n_reads, np.int32), rev=_arr(r.rev, r.n_reads, np.uint8),
-                    cig_off=_arr(r.cig_off, r.n_reads + 1, np.int64), cig=_arr(r.cig, r.n_cigar, np.uint32))
+                    cig_off=_arr(r.cig_off, r.n_reads + 1, np.int64), cig=_arr(r.cig, r.n_cigar, np.uint32), cig_summary=sm)
 
     def finish(self, ex_off, ex_start, ex_end, ex_flag, info, ref_tx) -> int:
         """Sequential tail + writers.  Arrays as in ``capi.Result`` (info carries the exon count in bits 8..31)."""

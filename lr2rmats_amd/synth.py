@@ -115,6 +115,56 @@ def _ragged_gather_index(starts: np.ndarray, lens: np.ndarray) -> np.ndarray:
     return np.arange(total, dtype=np.int64) - np.repeat(out_off, lens) + np.repeat(starts.astype(np.int64), lens)
 
 
+def _segment_reduce(val: np.ndarray, off: np.ndarray, ufunc, identity: int) -> np.ndarray:
+    """ufunc-reduction of val[off[i]:off[i+1]] for every i (identity for empty segments)."""
+    n = len(off) - 1
+    out = np.full(n, identity, np.int64)
+    if n == 0 or len(val) == 0:
+        return out
+    full = off[1:] > off[:-1]
+    if full.any():
+        v = np.concatenate([val.astype(np.int64), [identity]])           # (a sentinel: trailing empty segments index it)
+        red = ufunc.reduceat(v, off[:-1].astype(np.int64))
+        out[full] = red[full]
+    return out
+
+
+def cigar_summary(cig_off: np.ndarray, cig: np.ndarray) -> np.ndarray:
+    """What a reader knows of every record's CIGAR while it converts it (include/lr2rmats_hip.h, l2r_reads::cig_summary): [N, 3] uint32 --
+    reference bases | N operations + the shortest of them << 16 | the longest D operation + the shortest stretch of reference bases
+    between two N operations << 16 (each of the four saturated at 65535; 65535 where there is no N / no such stretch).
+    host/aln_reader.c makes the same words for SAM / BAM input; this is the generator's (and the tests') form of it."""
+    off = np.asarray(cig_off, np.int64)
+    c = np.asarray(cig, np.uint32)
+    n = len(off) - 1
+    op = (c & 15).astype(np.int64)
+    ln = (c >> 4).astype(np.int64)
+    adv = np.isin(op, (0, 2, 3, 7, 8))
+    ref = np.where(adv, ln, 0)
+    cs = np.concatenate([[0], np.cumsum(ref)])
+    ref_len = cs[off[1:]] - cs[off[:-1]]
+    is_n = op == 3
+    cn = np.concatenate([[0], np.cumsum(is_n)])
+    n_n = cn[off[1:]] - cn[off[:-1]]
+    sat = 65535
+    min_n = _segment_reduce(np.where(is_n, np.minimum(ln, sat), sat), off, np.minimum, sat)
+    max_d = _segment_reduce(np.where(op == 2, np.minimum(ln, sat), 0), off, np.maximum, 0)
+    # stretches between two N operations of one record: reference bases of the other ops between them
+    cx = np.concatenate([[0], np.cumsum(np.where(is_n, 0, ref))])       # cx[k] = such bases in front of op k (all records, running)
+    idx = np.nonzero(is_n)[0]
+    seg = np.full(len(idx), sat, np.int64)
+    if len(idx) > 1:
+        rid = np.searchsorted(off, idx, side="right") - 1                # the record of every N operation
+        same = rid[1:] == rid[:-1]
+        seg[1:] = np.where(same, np.minimum(cx[idx[1:]] - cx[idx[:-1]], sat), sat)
+    min_seg = _segment_reduce(seg, cn[off], np.minimum, sat)
+    out = np.empty((n, 3), np.uint32)
+    out[:, 0] = np.minimum(ref_len, 0xffffffff).astype(np.uint32)
+    out[:, 1] = (np.minimum(n_n, sat) | (min_n << 16)).astype(np.uint32)
+    out[:, 2] = (max_d | (min_seg << 16)).astype(np.uint32)
+    return out
+
+
 def make_annotation(n_exons: int, seed: int, nchr: int = 24, tx_per_gene=5, pool: int = 16,
                     mean_tx_exons: int = 10, shuffle_within_gene: bool = False,
                     long_tx_per_chrom: int = 0, single_exon_tx_frac: float = 0.03) -> Annotation:

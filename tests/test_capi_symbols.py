@@ -24,11 +24,12 @@ def test_library_exports_every_symbol():
     for name in _declared():
         assert hasattr(lib, name), name
     lib.l2r_abi_version.restype = ctypes.c_int
-    assert lib.l2r_abi_version() == 2
+    assert lib.l2r_abi_version() == 3
 
 
 def test_struct_layouts():
     assert ctypes.sizeof(capi.Params) == 44
+    assert ctypes.sizeof(capi.CReads) == 72          # l2r_reads: + cig_summary (ABI 3)
     assert capi.ACC_REC_DTYPE.itemsize == 16
     assert ctypes.sizeof(capi.CTiming) == 4 * capi.N_STAGES + 8
 

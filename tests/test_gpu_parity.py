@@ -183,6 +183,27 @@ def test_runs_in_a_row_on_one_upload(engine, oracle, monkeypatch, n_reads, ablat
         engine.set_params(util.to_engine_params(capi, op))
 
 
+@pytest.mark.parametrize("opts", [dict(), dict(min_exon=40, min_intron=150, max_delet=2)])
+def test_upload_with_the_readers_cigar_summaries(engine, oracle, opts):
+    """l2r_reads::cig_summary (what a reader knows of a record's CIGAR while it converts it): the upload's tile index then touches no CIGAR
+    (k_tile_index<true>) -- same tiles, same statistics, same results as with the engine's own CIGAR walk, under default thresholds (every
+    tile exact) and under thresholds that are borderline in most tiles (counts published from k_tile / the slab pipeline)."""
+    from lr2rmats_amd import synth
+    anno, af, reads = util.make_case(33, n_reads=150000, n_exons=7, anno_exons=30000)
+    _set_anno(engine, af)
+    op = oracle.default_params(full_level=3, **opts)
+    want = util.oracle_run(oracle, af, reads, op)
+    engine.set_junctions(None)
+    engine.set_params(util.to_engine_params(capi, op))
+    sm = synth.cigar_summary(reads.cig_off, reads.cig)
+    for summary in (None, sm, None, sm):
+        engine.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, cig_summary=summary)
+        assert engine.upload_index_ms() >= 0.0          # (0 where the upload makes no tile index: the classic pipeline)
+        for _ in range(2):
+            engine.run(); engine.sync()
+            util.assert_same_result(engine.download(), want, 0, 0)
+
+
 def _check_accepted_list(engine, got, first):
     """The accepted list of the last launch == the accepted reads of its full result, in read order."""
     acc = engine.download_accepted()

@@ -167,6 +167,8 @@ for k in a:
     np.testing.assert_array_equal(ra["rev"], reads.rev)
     np.testing.assert_array_equal(ra["cig_off"], reads.cig_off)
     np.testing.assert_array_equal(ra["cig"], reads.cig)
+    # ... and the reader's per-record CIGAR summaries (l2r_reads::cig_summary) are what the numpy form of the rule gives
+    np.testing.assert_array_equal(ra["cig_summary"], synth.cigar_summary(reads.cig_off, reads.cig))
     j.close()
 
 
