@@ -221,7 +221,9 @@ float        l2r_upload_index_ms(l2r_ctx *ctx);
 int          l2r_hint_single_run(l2r_ctx *ctx, int on);
 
 /* The hot path on resident inputs; asynchronous on the context stream. */
-int          l2r_run(l2r_ctx *ctx);          /* every kernel of the path, every call; results in read order in HBM */
+int          l2r_run(l2r_ctx *ctx);          /* one pass of the path over the resident upload; results in read order in HBM.  (Launches that a
+                                              * completed run of the same upload and parameters has shown to be empty -- list kernels, the generic
+                                              * kernel -- are dropped from later runs; the one-kernel tile path reads the index the upload made.) */
 int          l2r_sync(l2r_ctx *ctx);
 /* `iters` back-to-back runs bracketed by HIP events on the context stream. */
 int          l2r_run_timed(l2r_ctx *ctx, int iters, l2r_timing *out);
@@ -255,7 +257,8 @@ void         l2r_xchg_destroy(l2r_xchg *x);
 /* ---- diagnostics (tools/, bench.py and the tests read them; no product path does).
  * l2r_debug_counters: out[0] reads the last run left to the generic kernel (the redo list), [1] dictionary entries whose key has
  *   several entries, [2] annotation transcripts the mask kernels take, [3] tiles, [4..11] tiles by the reason their descriptor
- *   is not on the 32-bit masks (0 = it is), [12] tiles of the 64-bit-mask kernel; n = words of out (4, 12 or 13).
+ *   is not on the 32-bit masks (0 = it is), [12] tiles of the 64-bit-mask kernel, [13] runs that l2r_sync did again on the slab pipeline
+ *   because a tile of k_tile had waited in vain for the exon counts in front of it; n = words of out (4, 12, 13 or 14).
  * l2r_debug_stamps: with L2R_STAMPS=1 in the environment at l2r_upload_reads, per-phase cycle sums of the classification kernel
  *   (and clears them); zeros otherwise.
  * l2r_debug_tile_times: with L2R_STAMPS=1, one-kernel tile path: four words per tile -- the chip's 100 MHz clock at the tile's start

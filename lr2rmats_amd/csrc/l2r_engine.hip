@@ -87,6 +87,8 @@ struct l2r_ctx {
     DevBuf<unsigned long long> lb_tile, lb_blk, lb_sup;     // one-kernel tile path: the tiles' exon counts on their way to the later tiles' first slots
     DevBuf<uint32_t> fb_list;                               //                       the tiles it leaves to k_probe_slab
     DevBuf<uint16_t> sum_nn;                                //                       the records' N operations (l2r_reads::cig_summary) for k_tile_index<true>
+    bool tile_starved = false;                              //                       a tile of k_tile has waited in vain for the counts in front of it (or the device cannot hold the workgroups its look-back needs): the slab pipeline from then on
+    int64_t n_lb_fallback = 0;                              //                       ... runs that were done again on the slab pipeline for that reason (l2r_debug_counters)
     bool have_index = false;                                //                       the current upload has its tile index (slot records, op statistics)
     bool one_shot_upload = false;                           //                       ONE run will follow the upload (l2r_classify, l2r_hint_single_run): see l2r_classify
     float index_ms = 0.0f;                                  //                       GPU time of the last upload's k_tile_index (l2r_upload_index_ms)
@@ -252,6 +254,13 @@ l2r_ctx *l2r_create(int device)
         if (e) c->side_on = atoi(e) != 0;
         e = getenv("L2R_PIPELINE");
         if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : !strcmp(e, "slab") ? 1 : 2;
+        {   // k_tile's look-back: a tile may wait for one whose workgroup comes up to 8 * TILE_GROUP - 1 block indices later (fused_tile), so
+            // that many workgroups + 1 have to be resident together -- guaranteed nowhere; checked here (small or partitioned devices, CU
+            // masks): a device that cannot hold them takes the slab pipeline from the start
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tile<3, false, false, false>, TILE_THREADS, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+            if ((int64_t)per_cu * c->n_cu < 8 * (int64_t)TILE_GROUP + 1 || getenv("L2R_TILE_STARVED")) c->tile_starved = true;
+        }
     }
     return c;
 }
@@ -1129,7 +1138,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     c->slab = c->slab_ok && p.min_intron >= 0 && p.min_intron < (1 << 28) && p.max_delet >= -1 && p.max_delet < (1 << 28) - 1 &&
               (!c->wide_cigar || p.min_exon >= 1);           // (k_walk_slab_long has no -e < 1 form: the classic kernels take that)
     // the one-kernel tile path: short CIGARs whose exon counts the CIGAR lengths bound (-e >= 1)
-    c->tile = c->slab && c->want_pipeline >= 2 && !c->wide_cigar && p.min_exon >= 1 && (c->have_index || c->n_tiles == 0);
+    c->tile = c->slab && c->want_pipeline >= 2 && !c->wide_cigar && p.min_exon >= 1 && (c->have_index || c->n_tiles == 0) && !c->tile_starved;
     if (c->tile) {
         // A tile whose exon count the first kernel cannot derive from the upload's index (a threshold is borderline in it) publishes it
         // from k_tile, and every later tile's write-out waits for it: fine for a few, a convoy for many (measured: 3 x the kernel when
@@ -1428,6 +1437,7 @@ int l2r_debug_counters(l2r_ctx *c, long long *out, int n)
     out[0] = redo; out[1] = c->n_wide; out[2] = c->n_compact; out[3] = c->n_tiles;
     if (n >= 12) for (int k = 0; k < 8; ++k) out[4 + k] = 0;
     if (n >= 13) out[12] = 0;
+    if (n >= 14) out[13] = c->n_lb_fallback;              // runs done again on the slab pipeline because k_tile's look-back starved
     if (n >= 12 && c->slab && c->ran && c->tw.p && c->n_tiles > 0) {     // slab pipeline: the descriptors k_walk_slab made (flags as the probe kernels left them)
         std::vector<TileWin> w((size_t)c->n_tiles);
         HIP_TRY(hipMemcpyAsync(w.data(), c->tw.p, w.size() * sizeof(TileWin), hipMemcpyDeviceToHost, c->stream));
@@ -1492,6 +1502,22 @@ int l2r_sync(l2r_ctx *c)
     if (!c) return fail(-1, "[l2r_sync] null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->ran && c->tile && c->totals.p) {
+        // a tile of k_tile waited in vain for the exon counts in front of it (its poll limit ended every wait: the run is complete but its
+        // result slots are not to be trusted): the SAME resident upload once more on the slab pipeline, which has no such wait -- and no
+        // later run of this context takes the tile path again (the cause is the device's occupancy, not this input)
+        uint32_t lb = 0u;
+        HIP_TRY(hipMemcpyAsync(&lb, c->totals.p + 6, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (lb != 0u) {
+            c->tile_starved = true; c->n_lb_fallback++;
+            c->lists_known = false; c->totals_valid = false;
+            int rc = launch_all(c, nullptr);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            snprintf(g_err, sizeof g_err, "[l2r_sync] note: k_tile's look-back starved; the run was done again on the slab pipeline (this context keeps to it)");
+        }
+    }
     if (c->ran && c->tile && !c->lists_known && c->list_cnt.p) {
         // what the run left on the lists of the kernels behind k_tile (k_classify_generic keeps the counts of the 64-bit-mask and the
         // chunked kernel's lists in words 6, 7 when it clears them; word 4: k_probe_slab's)
@@ -1523,7 +1549,7 @@ static int fetch_totals(l2r_ctx *c)
     HIP_TRY(hipMemcpyAsync(dev, c->totals.p, sizeof dev, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     // accepted exons = the chunks the classification kernel placed itself (cursor) + the ones k_gather_accepted placed
-    if (c->tile && dev[6] != 0u) return fail(-2, "[l2r] k_tile: a tile waited in vain for the exon counts of the tiles in front of it (L2R_PIPELINE=slab avoids the kernel)");
+    if (c->tile && dev[6] != 0u) return fail(-2, "[l2r] k_tile: a tile waited in vain for the exon counts of the tiles in front of it and l2r_sync was not called behind the run (it does the run again on the slab pipeline)");
     c->h_totals[0] = dev[0]; c->h_totals[1] = dev[1] + dev[5]; c->h_totals[2] = dev[2] + dev[4];
     if (!(c->want & L2R_WANT_ACCEPTED)) c->h_totals[1] = c->h_totals[2] = 0;
     c->totals_valid = true;

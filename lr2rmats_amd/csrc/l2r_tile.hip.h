@@ -701,7 +701,8 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
     // (the staged form first in the source, the slab form behind it: see the note at the end of the kernel)
     auto staged_form = [&]() {
     // ---- the tile's exon count is known: published for every later tile's first slot
-    if (threadIdx.x == 0 && !counted && !(ablate & 128)) lb_publish(sa, t, total);
+    // (L2R_ABLATE bit 15, tests: tile 3 never publishes its count -- the tiles behind it wait in vain, the engine falls back to the slab pipeline)
+    if (threadIdx.x == 0 && !counted && !(ablate & 128) && !((ablate & 32768) && t == 3u)) lb_publish(sa, t, total);
     const uint32_t clk1 = stamp.p ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
     // ---- second walk: PLACE the exons as row words at their positions in LDS
     const SlabStage st{s_A, s_L, loc, tile_lo, true};

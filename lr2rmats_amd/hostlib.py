@@ -17,7 +17,7 @@ import numpy as np
 from . import capi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libl2r_host.so")
+LIB_PATH = os.environ.get("L2R_HOST_LIB") or os.path.join(HERE, "lib", "libl2r_host.so")      # (L2R_HOST_LIB: the sanitizer tests load libl2r_host_asan.so)
 CLI_PATH = os.path.join(HERE, "bin", "lr2rmats")
 
 _lib = None

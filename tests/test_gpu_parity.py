@@ -204,6 +204,41 @@ def test_upload_with_the_readers_cigar_summaries(engine, oracle, opts):
             util.assert_same_result(engine.download(), want, 0, 0)
 
 
+@pytest.mark.parametrize("how", ["a_tile_never_publishes", "device_too_small"])
+def test_starved_look_back_falls_back_to_the_slab_pipeline(oracle, monkeypatch, how):
+    """k_tile's tiles wait for the exon counts of the tiles in front of them; a count that never comes (here: L2R_ABLATE bit 15 -- tile 3 does not
+    publish, with bit 8 -- no count is known ahead) ends every wait at the poll limit, and l2r_sync does the same resident upload again on the
+    slab pipeline: results bit exact, the counter says so, later runs stay there.  A device that cannot hold the workgroups the look-back
+    needs (L2R_TILE_STARVED stands in for the occupancy test of l2r_create) never takes the tile path."""
+    import ctypes as C
+    anno, af, reads = util.make_case(44, n_reads=40000, n_exons=6, anno_exons=20000)
+    op = oracle.default_params(full_level=3)
+    want = util.oracle_run(oracle, af, reads, op)
+    if how == "a_tile_never_publishes":
+        monkeypatch.setenv("L2R_ABLATE", str(256 + 32768))
+    else:
+        monkeypatch.setenv("L2R_TILE_STARVED", "1")
+    monkeypatch.setenv("L2R_PIPELINE", "tile")
+    eng = capi.Engine(0)
+    try:
+        eng.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
+        eng.set_junctions(None)
+        eng.set_params(util.to_engine_params(capi, op))
+        eng.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig)
+        lib = capi.load_library()
+        lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.l2r_stage_kernel.restype = C.c_char_p
+        for k in range(3):
+            eng.run(); eng.sync()
+            util.assert_same_result(eng.download(), want, 0, 0)
+            cnt = (C.c_longlong * 14)()
+            lib.l2r_debug_counters(eng.ctx, cnt, 14)
+            assert cnt[13] == (1 if how == "a_tile_never_publishes" else 0), list(cnt)
+            assert b"k_walk_slab" in lib.l2r_stage_kernel(eng.ctx, 0)          # (the last launch was the slab pipeline's)
+    finally:
+        eng.close()
+
+
 def _check_accepted_list(engine, got, first):
     """The accepted list of the last launch == the accepted reads of its full result, in read order."""
     acc = engine.download_accepted()
