@@ -6,7 +6,66 @@
 // (host/cmds.c: through memory shared before the fork; lr2rmats_amd/dist.py does the same job through torch.distributed).
 // Included at the end of l2r_engine.hip (it needs l2r_ctx).
 #pragma once
+#include <dlfcn.h>
 #include <rccl/rccl.h>
+
+// RCCL is resolved when the exchange is first used, not when libl2r_hip.so is loaded: a one-GPU run, bench.py and the Python binding
+// need no librccl at all, and a process that holds one already (torch ships its own) keeps using THAT copy -- two RCCLs in one process
+// is asking for trouble.  Order: a copy that is loaded already (RTLD_NOLOAD), then $L2R_RCCL_LIB, $ROCM_PATH/lib/librccl.so, the loader's path.
+struct RcclApi {
+    void *h = nullptr;
+    decltype(&::ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&::ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&::ncclCommCount) CommCount = nullptr;
+    decltype(&::ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&::ncclCommCuDevice) CommCuDevice = nullptr;
+    decltype(&::ncclAllGather) AllGather = nullptr;
+    decltype(&::ncclSend) Send = nullptr;
+    decltype(&::ncclRecv) Recv = nullptr;
+    decltype(&::ncclGroupStart) GroupStart = nullptr;
+    decltype(&::ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+};
+static RcclApi g_rccl;
+static const char *rccl_load()                              // nullptr: ready; else what went wrong
+{
+    if (g_rccl.h) return nullptr;
+    static char why[512];
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so"}) if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    if (!h) { const char *e = getenv("L2R_RCCL_LIB"); if (e && *e) h = dlopen(e, RTLD_NOW | RTLD_LOCAL); }
+    if (!h) {
+        const char *rp = getenv("ROCM_PATH");
+        char path[1024];
+        snprintf(path, sizeof path, "%s/lib/librccl.so", (rp && *rp) ? rp : "/opt/rocm");
+        h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    }
+    for (const char *name : {"librccl.so.1", "librccl.so"}) if (!h) h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { snprintf(why, sizeof why, "librccl.so not found (L2R_RCCL_LIB, $ROCM_PATH/lib, loader path): %s", dlerror()); return why; }
+    RcclApi a; a.h = h;
+#define L2R_RCCL_SYM(field, sym) do { a.field = (decltype(a.field))dlsym(h, #sym); if (!a.field) { snprintf(why, sizeof why, "%s is missing from librccl", #sym); return why; } } while (0)
+    L2R_RCCL_SYM(GetUniqueId, ncclGetUniqueId); L2R_RCCL_SYM(CommInitRank, ncclCommInitRank); L2R_RCCL_SYM(CommDestroy, ncclCommDestroy);
+    L2R_RCCL_SYM(CommCount, ncclCommCount); L2R_RCCL_SYM(CommUserRank, ncclCommUserRank); L2R_RCCL_SYM(CommCuDevice, ncclCommCuDevice);
+    L2R_RCCL_SYM(AllGather, ncclAllGather); L2R_RCCL_SYM(Send, ncclSend); L2R_RCCL_SYM(Recv, ncclRecv);
+    L2R_RCCL_SYM(GroupStart, ncclGroupStart); L2R_RCCL_SYM(GroupEnd, ncclGroupEnd); L2R_RCCL_SYM(GetErrorString, ncclGetErrorString);
+#undef L2R_RCCL_SYM
+    g_rccl = a;
+    return nullptr;
+}
+// (the calls below go through the table)
+#define ncclGetUniqueId g_rccl.GetUniqueId
+#define ncclCommInitRank g_rccl.CommInitRank
+#define ncclCommDestroy g_rccl.CommDestroy
+#define ncclCommCount g_rccl.CommCount
+#define ncclCommUserRank g_rccl.CommUserRank
+#define ncclCommCuDevice g_rccl.CommCuDevice
+#define ncclAllGather g_rccl.AllGather
+#define ncclSend g_rccl.Send
+#define ncclRecv g_rccl.Recv
+#define ncclGroupStart g_rccl.GroupStart
+#define ncclGroupEnd g_rccl.GroupEnd
+#define ncclGetErrorString g_rccl.GetErrorString
 
 struct l2r_xchg {
     ncclComm_t comm = nullptr;
@@ -27,6 +86,7 @@ int l2r_xchg_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
 int l2r_xchg_unique_id(void *id_out)
 {
     if (!id_out) return fail(-1, "[l2r_xchg_unique_id] null argument");
+    if (const char *why = rccl_load()) return fail(-3, "[l2r_xchg_unique_id] %s", why);
     ncclUniqueId id;
     NCCL_TRY(ncclGetUniqueId(&id));
     memcpy(id_out, &id, sizeof id);
@@ -37,19 +97,47 @@ l2r_xchg *l2r_xchg_create(l2r_ctx *c, int rank, int world, const void *id_in)
 {
     if (!c || !id_in || world < 1 || rank < 0 || rank >= world) { fail(-1, "[l2r_xchg_create] bad argument"); return nullptr; }
     if (hipSetDevice(c->device) != hipSuccess) { fail(-2, "[l2r_xchg_create] hipSetDevice failed"); return nullptr; }
+    if (const char *why = rccl_load()) { fail(-3, "[l2r_xchg_create] %s", why); return nullptr; }
     ncclUniqueId id;
     memcpy(&id, id_in, sizeof id);
     l2r_xchg *x = new l2r_xchg();
     x->rank = rank; x->world = world; x->ctx = c;
     const ncclResult_t r = ncclCommInitRank(&x->comm, world, id, rank);
     if (r != ncclSuccess) { fail(-3, "[l2r_xchg_create] ncclCommInitRank (rank %d of %d): %s", rank, world, ncclGetErrorString(r)); delete x; return nullptr; }
+    {   // what the communicator holds, said once per rank (the first run on several physical GPUs proves by it that RCCL had them all)
+        int n = -1, me = -1, dev = -1; char bus[32] = "?";
+        (void)ncclCommCount(x->comm, &n); (void)ncclCommUserRank(x->comm, &me); (void)ncclCommCuDevice(x->comm, &dev);
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, c->device) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof bus, "?"); }
+        fprintf(stderr, "[l2r_xchg_create] RCCL communicator: rank %d of %d, device %d (bus %s)\n", me, n, dev, bus);
+    }
     return x;
+}
+
+// Every rank says whether it can go on (0) before any of them enters a send / receive group: a rank that left alone -- rank 0 with
+// buffers too small -- would leave its peers blocked in ncclSend.  Returns the first non-zero status of the world (on every rank).
+static int xchg_agree(l2r_xchg *x, hipStream_t s, long long status, const char *who)
+{
+    const int W = x->world;
+    DevBuf<long long> d;
+    if (d.ensure((size_t)W + 1)) return -2;
+    HIP_TRY(hipMemcpyAsync(d.p + W, &status, 8, hipMemcpyHostToDevice, s));
+    NCCL_TRY(ncclAllGather(d.p + W, d.p, 1, ncclInt64, x->comm, s));
+    std::vector<long long> all((size_t)W);
+    HIP_TRY(hipMemcpyAsync(all.data(), d.p, (size_t)W * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    d.release();
+    for (int k = 0; k < W; ++k)
+        if (all[(size_t)k] != 0) {
+            if (k == x->rank) return (int)status;              // (its own message stands)
+            return fail((int)all[(size_t)k], "[%s] rank %d cannot take part (status %lld): nothing was exchanged", who, k, all[(size_t)k]);
+        }
+    return 0;
 }
 
 void l2r_xchg_destroy(l2r_xchg *x)
 {
     if (!x) return;
-    if (x->comm) (void)ncclCommDestroy(x->comm);
+    if (x->comm && g_rccl.h) (void)ncclCommDestroy(x->comm);
     delete x;
 }
 
@@ -85,11 +173,13 @@ int l2r_xchg_gather_results(l2r_xchg *x, l2r_result *res, int64_t *counts_out)
     struct Part { const void *src; size_t width; int per_exon; };
     const Part parts[6] = {{c->ex_off.p, 4, 0}, {c->info.p, 4, 0}, {c->ref_tx.p, 4, 0}, {c->ex_start.p, 4, 1}, {c->ex_end.p, 4, 1}, {c->ex_flag.p, 1, 1}};
     DevBuf<uint8_t> g[6];
+    long long status = 0;
     if (x->rank == 0) {
-        if (!res) return fail(-1, "[l2r_xchg_gather_results] rank 0 needs a result to fill");
-        if (res->n_reads < R || res->ex_cap < X) return fail(-4, "[l2r_xchg_gather_results] result buffers too small (%lld reads, %lld exons)", R, X);
-        for (int a = 0; a < 6; ++a) if (g[a].ensure((size_t)(parts[a].per_exon ? X : R) * parts[a].width + 16)) return -2;
+        if (!res) status = fail(-1, "[l2r_xchg_gather_results] rank 0 needs a result to fill");
+        else if (res->n_reads < R || res->ex_cap < X) status = fail(-4, "[l2r_xchg_gather_results] result buffers too small (%lld reads, %lld exons)", R, X);
+        else for (int a = 0; a < 6 && !status; ++a) if (g[a].ensure((size_t)(parts[a].per_exon ? X : R) * parts[a].width + 16)) status = -2;
     }
+    if ((rc = xchg_agree(x, s, status, "l2r_xchg_gather_results"))) { for (int a = 0; a < 6; ++a) g[a].release(); return rc; }
     NCCL_TRY(ncclGroupStart());
     for (int a = 0; a < 6; ++a) {
         const std::vector<long long> &at = parts[a].per_exon ? x_at : r_at;
@@ -165,11 +255,13 @@ int l2r_xchg_gather_accepted(l2r_xchg *x, l2r_accepted *acc, int64_t *counts_out
     const Part parts[6] = {{c->acc_rec.p, sizeof(AccRec), 0}, {c->acc_ex_off.p, 4, 0}, {c->tile_rchunk.p, 4, 2}, {c->acc_start.p, 4, 1}, {c->acc_end.p, 4, 1}, {c->acc_flag.p, 1, 1}};
     auto at_of = [&](int by) -> const std::vector<long long> & { return by == 0 ? m_at : (by == 1 ? x_at : t_at); };
     DevBuf<uint8_t> g[6];
+    long long status = 0;
     if (x->rank == 0) {
-        if (!acc) return fail(-1, "[l2r_xchg_gather_accepted] rank 0 needs a list to fill");
-        if (acc->n_reads < M || acc->ex_cap < X) return fail(-4, "[l2r_xchg_gather_accepted] buffers too small (%lld records, %lld exons)", M, X);
-        for (int a = 0; a < 6; ++a) if (g[a].ensure((size_t)at_of(parts[a].by)[W] * parts[a].width + 16)) return -2;
+        if (!acc) status = fail(-1, "[l2r_xchg_gather_accepted] rank 0 needs a list to fill");
+        else if (acc->n_reads < M || acc->ex_cap < X) status = fail(-4, "[l2r_xchg_gather_accepted] buffers too small (%lld records, %lld exons)", M, X);
+        else for (int a = 0; a < 6 && !status; ++a) if (g[a].ensure((size_t)at_of(parts[a].by)[W] * parts[a].width + 16)) status = -2;
     }
+    if ((rc = xchg_agree(x, s, status, "l2r_xchg_gather_accepted"))) { for (int a = 0; a < 6; ++a) g[a].release(); return rc; }
     NCCL_TRY(ncclGroupStart());
     for (int a = 0; a < 6; ++a) {
         const std::vector<long long> &at = at_of(parts[a].by);

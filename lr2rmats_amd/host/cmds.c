@@ -910,6 +910,7 @@ static void meta_read(const char *path, int64_t *cnt, h_part_genes *g)
     fclose(f);
 }
 
+#define H_MULTI_DECLINED (-77)                               /* update_gtf_multi: nothing was started, the caller takes the one-GPU path */
 static int update_gtf_multi(h_job *j, int n_gpus, int gathered)
 {
     const int64_t N = j->reads.n;
@@ -943,6 +944,15 @@ static int update_gtf_multi(h_job *j, int n_gpus, int gathered)
         const int fd = mkstemp(tmp_base);
         if (fd < 0) h_fatal("update_gtf", "mkstemp failed");
         close(fd);
+    }
+    if (gathered) {
+        /* a child of the gathered route classifies its shard in ONE upload (its results stay in HBM for the exchange): a shard beyond the
+         * engine's limit -- or beyond L2R_CHUNK_READS, which the tests set -- is the one-GPU path's (upload by upload), decided before
+         * anything is forked */
+        l2r_params prm; l2r_annotation a; l2r_junctions s; l2r_reads r;
+        h_job_views(j, &prm, &a, &s, &r);
+        for (int k = 0; k < n_gpus; ++k)
+            if (cut[k + 1] > cut[k] && shard_end(&r, cut[k]) < cut[k + 1]) { free(cut); return H_MULTI_DECLINED; }
     }
     const char *map = getenv("L2R_GPU_MAP");
     pid_t *pid = (pid_t *)calloc((size_t)n_gpus, sizeof *pid);
@@ -1005,7 +1015,12 @@ static int update_gtf_multi(h_job *j, int n_gpus, int gathered)
     for (int k = 0; k < n_gpus; ++k) {
         const int dev = dev_of[k];
         pid[k] = fork();
-        if (pid[k] < 0) h_fatal("update_gtf", "fork failed");
+        if (pid[k] < 0) {
+            /* (the children started so far wait for the others at a barrier: nobody else will end them) */
+            for (int q = 0; q < k; ++q) kill(pid[q], SIGKILL);
+            for (int q = 0; q < k; ++q) (void)waitpid(pid[q], NULL, 0);
+            h_fatal("update_gtf", "fork failed (child %d of %d)", k, n_gpus);
+        }
         if (pid[k] == 0) {
             /* ---- a child: its shard on its GPU (the first HIP call of this process is in here) */
             g_device = dev;
@@ -1161,7 +1176,12 @@ static int update_gtf_multi(h_job *j, int n_gpus, int gathered)
         for (int left = n_gpus; left > 0; --left) {
             int st = 0;
             const pid_t w = waitpid(-1, &st, 0);
-            if (w < 0) { failed = 1; break; }
+            if (w < 0) {
+                failed = 1;
+                for (int k = 0; k < n_gpus; ++k) kill(pid[k], SIGKILL);      /* (whoever is left sits at a barrier) */
+                for (int k = 0; k < n_gpus; ++k) (void)waitpid(pid[k], NULL, 0);
+                break;
+            }
             if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
                 failed = 1;
                 for (int k = 0; k < n_gpus; ++k) if (pid[k] != w) kill(pid[k], SIGKILL);
@@ -1254,7 +1274,11 @@ int h_cmd_update_gtf(int argc, char **argv)
         const int n_gpus = eg ? atoi(eg) : 1;
         if (n_gpus > 1 || (n_gpus == 1 && getenv("L2R_MULTI_ROUTE"))) {      /* (one child: diagnostics / tests -- RCCL with a world of one) */
             const int route = multi_gpu_ok(j);
-            if (route) { rc = update_gtf_multi(j, n_gpus, route == 2); h_job_free(j); return rc; }
+            if (route) {
+                rc = update_gtf_multi(j, n_gpus, route == 2);
+                if (rc != H_MULTI_DECLINED) { h_job_free(j); return rc; }
+                fprintf(stderr, "[update_gtf] L2R_GPUS=%d: a child's shard would not fit one upload: running on one GPU, upload by upload\n", n_gpus);
+            } else
             fprintf(stderr, "[update_gtf] L2R_GPUS=%d: this input needs one stream of records (records not coordinate sorted, or -m g): running on one GPU\n", n_gpus);
         }
     }
