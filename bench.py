@@ -393,6 +393,75 @@ def pipelines_leg(af, reads, args, capi, tile_ms, abytes):
     return out
 
 
+def c_route_leg(world: int, dev_map, args, capi, workload, dev_index: int):
+    """N > 1, rank 0, BEHIND the process group: the multi-GPU route of the C CLI itself (host/cmds.c, `L2R_GPUS=N lr2rmats update-gtf ...`: the
+    parent forks a child per GPU before any HIP call, the children classify shards of the records and -- for `-s` with a junction table --
+    gather their results on child 0 over RCCL / xGMI, l2r_xchg_*) on a bounded read set of the same configuration, as FRESH CHILD PROCESSES of
+    this rank (nothing is exec'ed in place of a rank): the pipeline's second command with every output (the per-read results travel) and with
+    `-o new.gtf -E bed` alone (the accepted reads travel, SURVEY 8(e)'s message), each against the one-GPU run of the same command, file by
+    file.  The torch.distributed route above and this one are two implementations of the same exchange; a scaling run exercises both."""
+    import filecmp
+    import shutil
+    import subprocess
+    import tempfile
+    from lr2rmats_amd import hostlib, synth
+    cfg = dict(workload.CONFIGS[args.config]); cfg["n_reads"] = args.c_route_reads
+    af, reads = workload.make_rank_workload(cfg, 0, 1)
+    d = tempfile.mkdtemp(prefix="l2r_croute_", dir=os.environ.get("TMPDIR", "/tmp"))
+    out = {"reads": reads.n, "children": world}
+    try:
+        bam, gtf, tab = os.path.join(d, "reads.bam"), os.path.join(d, "anno.gtf"), os.path.join(d, "SJ.out.tab")
+        synth.write_bam_fast(reads, bam)
+        af.write_gtf(gtf)
+        e = capi.Engine(dev_index)
+        e.set_annotation(af.tx_tid, af.tx_start, af.tx_end, af.tx_rev, af.tx_ex_off, af.ex_start, af.ex_end)
+        e.set_junctions(None)
+        res = e.classify(reads, capi.default_params(full_level=args.level))
+        n_x = int(res.ex_start.shape[0])
+        e.close()
+        sj = synth.make_junctions_fast(af, res.ex_off, res.ex_start, res.ex_end, reads.tid, 5, cover=0.8)
+        sj.write(tab)
+        base = ["update-gtf", "-s", "-l", str(args.level), "-J", "1", "-j", tab]
+        env_n = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID"):
+            env_n.pop(k, None)
+        env_n["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        env_1 = dict(env_n); env_1.pop("L2R_GPUS", None)
+        env_n["L2R_GPUS"] = str(world)
+        if dev_map:                                           # (tests: several ranks on one GPU -- the children share it too, RCCL cannot run there)
+            env_n["L2R_GPU_MAP"] = ",".join(str(dev_map[k % len(dev_map)]) for k in range(world))
+        for name, outs in (("per_read_results", ("updated.gtf", "detail.txt", "summary.txt", "novel_exon.bed")), ("accepted_reads_alone", ("updated.gtf", "novel_exon.bed"))):
+            def cmd(tag):
+                o = {k: os.path.join(d, "%s.%s.%s" % (name, tag, k)) for k in outs}
+                c = [hostlib.CLI_PATH] + base + ["-o", o["updated.gtf"], "-E", o["novel_exon.bed"]]
+                if "detail.txt" in o:
+                    c += ["-A", o["detail.txt"], "-y", o["summary.txt"]]
+                return c + [bam, gtf], o
+            c1, o1 = cmd("one")
+            r1 = subprocess.run(c1, env=env_1, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            cn, on = cmd("many")
+            t0 = time.perf_counter()
+            rn = subprocess.run(cn, env=env_n, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            wall = time.perf_counter() - t0
+            err = rn.stderr.decode(errors="replace")
+            for ln in err.splitlines():                          # what ncclCommInitRank saw on every rank: the first hardware run proves its world by it
+                if "RCCL communicator" in ln or "gathered route" in ln or "L2R_GPUS" in ln:
+                    print("bench.py c_route[%s]: %s" % (name, ln), file=sys.stderr)
+            same = r1.returncode == 0 and rn.returncode == 0 and all(os.path.exists(on[k]) and filecmp.cmp(o1[k], on[k], shallow=False) for k in outs)
+            ranks_seen = sorted({ln.split("rank ")[1].split(" ")[0] for ln in err.splitlines() if "RCCL communicator: rank " in ln})
+            n_acc = int(((res.info & 128) != 0).sum())
+            out[name] = {"wall_s": round(wall, 3), "rc": [r1.returncode, rn.returncode], "files_identical": bool(same),
+                         "exchange": "rccl" if "exchange: RCCL" in err else ("shm" if "exchange: shared memory" in err else "none (partitioned or one child)"),
+                         "rccl_ranks_reporting": ranks_seen,
+                         # an upper bound of what travels to child 0 (its own shard does not): 12 bytes per read + 9 per exon, or the accepted records alone
+                         "bytes_to_rank0_at_most": (12 * reads.n + 9 * n_x) if name == "per_read_results" else None,
+                         "stderr_tail": None if same else err[-600:]}
+        out["accepted_reads_before_the_junction_check"] = n_acc
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def launcher_argv(args, port: int):
     """The command `bench.py --gpus N` starts when no launcher has set WORLD_SIZE: the shape the driver uses itself."""
     passed = [a for a in sys.argv[1:] if a != "--dry-launch"]
@@ -448,6 +517,8 @@ def main():
     ap.add_argument("--no-ont", action="store_true", help="skip the ONT shard (BASELINE configs[4], rank 0 of 8) at N=1")
     ap.add_argument("--no-dis", action="store_true", help="skip the -d 2 leg at N=1")
     ap.add_argument("--no-pipelines", action="store_true", help="skip the tile / slab comparison (the step without the upload's op index) at N=1")
+    ap.add_argument("--no-c-route", action="store_true", help="N > 1: skip the C CLI's own multi-GPU run (L2R_GPUS=N) behind the process group")
+    ap.add_argument("--c-route-reads", type=int, default=1_000_000, help="N > 1: reads of the C route's leg")
     ap.add_argument("--dry-launch", action="store_true", help="print the launcher command a plain `bench.py --gpus N` would start, and exit")
     args = ap.parse_args()
 
@@ -754,6 +825,11 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if world > 1 and rank == 0 and out is not None and not args.no_c_route:
+        try:
+            out["c_route"] = c_route_leg(world, dev_map, args, capi, workload, dev_index)
+        except Exception as e:                                    # (must not take the line down)
+            out["c_route"] = {"error": str(e)[:300]}
     if out is not None:
         print(json.dumps(out))
 

@@ -87,6 +87,8 @@ struct l2r_ctx {
     DevBuf<unsigned long long> lb_tile, lb_blk, lb_sup;     // one-kernel tile path: the tiles' exon counts on their way to the later tiles' first slots
     DevBuf<uint32_t> fb_list;                               //                       the tiles it leaves to k_probe_slab
     DevBuf<uint16_t> sum_nn;                                //                       the records' N operations (l2r_reads::cig_summary) for k_tile_index<true>
+    bool env_tile_anyway = false, env_launch_all = false;   // L2R_TILE_ANYWAY / L2R_LAUNCH_ALL (diagnostics), read once at l2r_create
+    int64_t inexact_tiles = -1;                             //                       tiles that are not exact under the parameters now set (-1: not counted yet; drop_graph forgets it)
     bool tile_starved = false;                              //                       a tile of k_tile has waited in vain for the counts in front of it (or the device cannot hold the workgroups its look-back needs): the slab pipeline from then on
     int64_t n_lb_fallback = 0;                              //                       ... runs that were done again on the slab pipeline for that reason (l2r_debug_counters)
     bool have_index = false;                                //                       the current upload has its tile index (slot records, op statistics)
@@ -184,6 +186,7 @@ struct l2r_ctx {
 static void drop_graph(l2r_ctx *c)
 {
     c->lists_known = false; c->lists_empty = false; c->redo_empty = false; c->lists_heavy = false;     // (called wherever inputs, parameters or outputs change)
+    c->inexact_tiles = -1;
     if (c->graph) { (void)hipGraphExecDestroy(c->graph); c->graph = nullptr; }
     c->graph_valid = false;
 }
@@ -248,6 +251,7 @@ l2r_ctx *l2r_create(int device)
         if (e && *e) c->anno_cache_dir = e;
         e = getenv("L2R_WIDE_DIRECT");
         if (e) c->wide_direct = atoi(e) != 0;
+        c->env_tile_anyway = getenv("L2R_TILE_ANYWAY") != nullptr; c->env_launch_all = getenv("L2R_LAUNCH_ALL") != nullptr;
         e = getenv("L2R_CHUNK_DIRECT");
         if (e) c->chunk_direct = atoi(e) != 0;
         e = getenv("L2R_SIDE");
@@ -955,7 +959,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             // ... and an index of its CIGAR operations from which a run knows the tile's exon count unless a threshold is borderline in it
             c->h_tile_stat.assign(T, TileStat{0, INT32_MAX, 0, INT32_MAX});
             c->index_ms = 0.0f; c->have_index = false;
-            if (T && !c->wide_cigar && c->want_pipeline >= 2 && !(c->one_shot_upload && !getenv("L2R_TILE_ANYWAY"))) {
+            if (T && !c->wide_cigar && c->want_pipeline >= 2 && !(c->one_shot_upload && !c->env_tile_anyway)) {
                 c->have_index = true;
                 struct Ev { hipEvent_t a = nullptr, b = nullptr; ~Ev() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev;
                 HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b));
@@ -1143,11 +1147,14 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         // A tile whose exon count the first kernel cannot derive from the upload's index (a threshold is borderline in it) publishes it
         // from k_tile, and every later tile's write-out waits for it: fine for a few, a convoy for many (measured: 3 x the kernel when
         // every tile does) -- such a run takes the two-kernel path.
-        int64_t inexact = 0;
-        for (const TileStat &st : c->h_tile_stat) inexact += tile_exact(st, p.min_exon, p.min_intron, p.max_delet) ? 0 : 1;
-        if (inexact * 50 > c->n_tiles + 800 && !getenv("L2R_TILE_ANYWAY")) c->tile = false;
+        if (c->inexact_tiles < 0) {     // (depends on the upload and the parameters alone: counted once, forgotten with them -- drop_graph)
+            int64_t inexact = 0;
+            for (const TileStat &st : c->h_tile_stat) inexact += tile_exact(st, p.min_exon, p.min_intron, p.max_delet) ? 0 : 1;
+            c->inexact_tiles = inexact;
+        }
+        if (c->inexact_tiles * 50 > c->n_tiles + 800 && !c->env_tile_anyway) c->tile = false;
         // (measured: cfg3_iso40 -- every tile wide or chunked -- 1.34 ms on this path against 1.26 on the slab pipeline)
-        if (c->lists_known && c->lists_heavy && !getenv("L2R_TILE_ANYWAY")) c->tile = false;
+        if (c->lists_known && c->lists_heavy && !c->env_tile_anyway) c->tile = false;
     }
     if (c->slab) {
         // ---- two light kernels at full occupancy: the walk (exons into the tiles' slabs, read-order places, descriptors), a scan of
@@ -1192,7 +1199,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             MARK(ST_SCAN1);
             // (the three list-driven kernels behind k_tile: not launched once a completed run of the same inputs and parameters has shown
             //  their lists empty -- what ends up on them does not depend on anything else)
-            skip_lists = c->lists_known && c->lists_empty && !getenv("L2R_LAUNCH_ALL");
+            skip_lists = c->lists_known && c->lists_empty && !c->env_launch_all;
             const unsigned gl = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 2);
             // (the WIDE instance beside the plain one, on a stream of its own: see l2r_ctx::side; with per-stage events or L2R_CHECK one behind the other)
             const bool wide_launch = !skip_lists && sa.wide_direct_on;
@@ -1283,7 +1290,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
 #undef launch_probe
 #undef launch_probe_level
 #undef launch_probe_k
-        if (!skip_lists && !(c->tile && c->lists_known && c->wide_rest_empty && !getenv("L2R_LAUNCH_ALL")))
+        if (!skip_lists && !(c->tile && c->lists_known && c->wide_rest_empty && !c->env_launch_all))
         {   // the tiles with 33 .. 63 window members (none on most inputs: the grid finds an empty list and leaves)
             const WideArgs wa{c->tw64.p};
             const unsigned gw = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 5);
@@ -1299,7 +1306,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             }
 #undef launch_wide_level
         }
-        if (sa.chunk_on && !skip_lists && !(c->tile && c->lists_known && c->chunk_rest_empty && !getenv("L2R_LAUNCH_ALL"))) {   // the tiles without a window record, or with a dictionary key in several entries (none on most inputs)
+        if (sa.chunk_on && !skip_lists && !(c->tile && c->lists_known && c->chunk_rest_empty && !c->env_launch_all)) {   // the tiles without a window record, or with a dictionary key in several entries (none on most inputs)
             const unsigned gc = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 4);
 #define launch_chunk_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_slab_chunked<L>), dim3(gc), dim3(TILE_THREADS), 0, s, sa, (const uint32_t *)c->tile_first.p, \
                 (const int32_t *)c->r_pos.p, (const uint32_t *)c->tile_sbase.p, (const TileWin *)c->tw.p, (const uint32_t *)c->tile_xbase.p)
@@ -1345,7 +1352,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     MARK(ST_GENERIC);
     // (one-kernel tile path: a completed run of the same inputs and parameters has left nothing on the redo list and nothing to the
     //  list-driven kernels -- no read is left for the generic kernel, and what it used to clear for the next run is cleared in front)
-    const bool nothing_left = c->tile && c->lists_known && c->lists_empty && c->redo_empty && !getenv("L2R_LAUNCH_ALL");
+    const bool nothing_left = c->tile && c->lists_known && c->lists_empty && c->redo_empty && !c->env_launch_all;
     if (c->tile) c->lb_flip ^= 1u;
     if (!nothing_left) {
         const unsigned gg = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles * 4 : 1, 4096);      // one wave per listed read, grid-stride
@@ -1480,7 +1487,7 @@ int l2r_run(l2r_ctx *c)
     // Not for unsorted input with a junction table (its cursor replay syncs).
     // Not for the one-kernel tile path either (two launches: nothing to gain, and its launch arguments change run by run -- the
     // super-block words take turns, launches are dropped once a run has shown them empty).
-    const bool graphable = !(c->n_sj > 0 && !c->sorted) && c->want_pipeline < 2 && getenv("L2R_GRAPH") != nullptr;
+    const bool graphable = !(c->n_sj > 0 && !c->sorted) && (c->want_pipeline < 2 || (c->ran && !c->tile)) && getenv("L2R_GRAPH") != nullptr;
     if (graphable && !c->graph_valid) {
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {

@@ -65,7 +65,7 @@ def test_fast_junction_table_is_the_generators(oracle):
 def test_self_launched_world_of_two_on_one_gpu():
     env = _env()
     env["L2R_BENCH_DEVICES"] = "0,0"; env["L2R_BENCH_BACKEND"] = "gloo"
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "cfg2", "--reads", "60000"], env=env,
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "cfg2", "--reads", "60000", "--c-route-reads", "50000"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
@@ -77,6 +77,13 @@ def test_self_launched_world_of_two_on_one_gpu():
     # both routes in one line: the headline is partitioned (no collective in a step), the other one gathers the accepted list
     assert d["other_exchange"]["exchange"] == "gathered" and d["other_exchange"]["value"] > 0
     assert sum(d["other_exchange"]["exchange_bytes_per_rank_per_step"]) > 0
+    # ... and behind the process group the C CLI's own multi-GPU run (L2R_GPUS=2: here two children on GPU 0, shared-memory transport): both forms
+    # of the gathered route against the one-GPU run of the same command
+    cr = d["c_route"]
+    assert "error" not in cr, cr
+    assert cr["children"] == 2 and cr["reads"] == 50000
+    for form in ("per_read_results", "accepted_reads_alone"):
+        assert cr[form]["files_identical"] is True and cr[form]["exchange"] == "shm" and cr[form]["rc"] == [0, 0], cr[form]
 
 
 @pytest.mark.gpu

@@ -357,3 +357,63 @@ def test_c_cli_gathered_route_moves_the_accepted_reads_alone(oracle, tmp_path, f
     assert r.returncode == 0 and b"the per-read results" in r.stderr, r.stderr.decode()[-2000:]
     for k in ("gtf", "novel", "bed"):
         assert filecmp.cmp(one[k], full[k], shallow=False), ("all", n_gpus, xchg, k)
+
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("accepted_only", [False, True])
+def test_c_cli_gathered_route_over_rccl_between_two_gpus(oracle, tmp_path, files, accepted_only):
+    """The RCCL transport with PEERS (the other gathered-route tests reach it with a world of one, where no ncclSend / ncclRecv is issued):
+    L2R_GPUS=2, a GPU per child, both forms of the message -- the per-read results (offsets at[k] * width, exon offsets re-based on rank 0)
+    and the accepted reads alone (tile_rchunk gathered for order_accepted).  Needs two devices: skipped on the one-GPU boxes of the pool."""
+    if _n_devices() < 2:
+        pytest.skip("needs two GPUs")
+    d, anno, reads, sam, bam, gtf = files
+    af = anno.in_file_order()
+    base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3))
+    j, _ = util.junction_table(af, reads, base, 47, cover=0.7)
+    tab = str(tmp_path / "SJ.out.tab")
+    j.write(tab)
+    if accepted_only:
+        keys = ("gtf", "novel", "bed")
+
+        def args(o):
+            return ["update-gtf", "-s", "-l", "3", "-J", "1", "-j", tab, "-v", o["novel"], "-E", o["bed"], "-o", o["gtf"], bam, gtf]
+    else:
+        keys = OUTS
+
+        def args(o):
+            return _args(["-s", "-l", "3", "-J", "1", "-j", tab], o, bam, gtf)
+    one, many = _paths(tmp_path, "one"), _paths(tmp_path, "many")
+    r = hostlib.run_cli(args(one))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    r = hostlib.run_cli(args(many), env={"L2R_GPUS": 2, "L2R_THREADS": 3, "L2R_XCHG": "rccl"})
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert b"gathered route" in r.stderr and b"RCCL" in r.stderr
+    assert b"RCCL communicator: rank 0 of 2" in r.stderr and b"RCCL communicator: rank 1 of 2" in r.stderr      # (what ncclCommInitRank saw)
+    for k in keys:
+        assert filecmp.cmp(one[k], many[k], shallow=False), (accepted_only, k)
+
+
+def test_c_cli_gathered_shard_beyond_one_upload_runs_on_one_gpu(oracle, tmp_path, files):
+    """A child of the gathered route classifies its shard in ONE upload; where that does not fit (here: L2R_CHUNK_READS below the shard size)
+    the run is declined before anything is forked and takes the one-GPU path, upload by upload -- same files, and it says so."""
+    d, anno, reads, sam, bam, gtf = files
+    af = anno.in_file_order()
+    base = util.oracle_run(oracle, af, reads, oracle.default_params(full_level=3))
+    j, _ = util.junction_table(af, reads, base, 53, cover=0.7)
+    tab = str(tmp_path / "SJ.out.tab")
+    j.write(tab)
+    extra = ["-s", "-l", "3", "-J", "1", "-j", tab]
+    one, many = _paths(tmp_path, "one"), _paths(tmp_path, "many")
+    r = hostlib.run_cli(_args(extra, one, bam, gtf))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    r = hostlib.run_cli(_args(extra, many, bam, gtf), env={"L2R_GPUS": 3, "L2R_GPU_MAP": "0,0,0", "L2R_XCHG": "shm", "L2R_CHUNK_READS": 1500})
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert b"would not fit one upload: running on one GPU" in r.stderr and b"gathered route" not in r.stderr
+    for k in OUTS:
+        assert filecmp.cmp(one[k], many[k], shallow=False), k
