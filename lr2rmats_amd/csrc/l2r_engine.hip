@@ -76,11 +76,14 @@ struct l2r_ctx {
     bool lists_heavy = false;                           // ... or most tiles went to them (an isoform-rich annotation): k_tile would only walk for them, which k_walk_slab does faster -- later runs take the slab pipeline
     bool redo_empty = false;                            // ... and nothing to the generic kernel either: every read had its junction check in k_tile, k_validate_sj has nothing to do
     bool wide_direct = true;                            // L2R_WIDE_DIRECT=0: the exact 64-bit-mask tiles keep the slab form and k_probe_slab_wide (k_tile's WIDE instance, l2r_tile.hip.h)
+    bool fb_empty = false;                              // ... and k_tile left no tile in slab form for k_probe_slab (list_cnt[4])
     bool chunk_direct = true;                           // L2R_CHUNK_DIRECT=0: the exact tiles of the chunked kernel keep the slab form and k_probe_slab_chunked (k_tile_chunk, l2r_tchunk.hip.h)
     bool chunk_rest_empty = false;                      // ... and k_tile_chunk declined none, nobody appended late (list_cnt[9], [8]): k_probe_slab_chunked has nothing to do
     uint32_t n_chunk_tiles = 0;                         // ... entries of chunk_list a completed run has left: k_tile_chunk's grid
     bool wide_rest_empty = false;                       // ... and none of them kept the slab form (list_cnt[5]): k_probe_slab_wide has nothing to do
     uint32_t n_wide_tiles = 0;                          // ... entries of wide_list a completed run has left (l2r_sync): the WIDE instance's grid
+    bool prev_run_tile = false;                         // the last launch of this upload took the tile path (else the list counters are whatever a slab run left: cleared before the next tile run)
+    uint32_t lc_flip = 0;                               // ... and which of the two blocks of list counters (SlabArgs::list_cnt / list_cnt_next)
     uint32_t lb_flip = 0;                               // which of the two lb_sup arrays the next run of the tile path uses (l2r_slab.hip.h SlabArgs::lb_sup)
     bool lists_known = false, lists_empty = false;      // one-kernel tile path: a completed run of these inputs and parameters left nothing to k_probe_slab / _wide / _chunked (l2r_sync looks): their launches are skipped until something changes
     bool tile = false;                      // ... with the one-kernel tile path (l2r_tile.hip.h: short CIGARs, -e >= 1)
@@ -228,8 +231,12 @@ l2r_ctx *l2r_create(int device)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         fail(-2, "[l2r_create] hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr;
     }
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // (lowest, highest)
+    const char *sp = getenv("L2R_SIDE_PRIO");
+    const int side_prio = (sp && atoi(sp) == 0) ? 0 : prio_lo;      // the side streams' workgroups fill in behind the plain instance's: lowest priority (L2R_SIDE_PRIO=0: default priority)
     for (int k = 0; k < 2; ++k)
-        if ((e = hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming)) != hipSuccess) {
+        if ((e = hipStreamCreateWithPriority(&c->side[k], hipStreamNonBlocking, side_prio)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming)) != hipSuccess) {
             fail(-2, "[l2r_create] side stream: %s", hipGetErrorString(e)); l2r_destroy(c); return nullptr;
         }
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) { fail(-2, "[l2r_create] hipEventCreate: %s", hipGetErrorString(e)); l2r_destroy(c); return nullptr; }
@@ -930,11 +937,11 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
         if (total < 0x7ffffff0ULL && ovf < 0x7ffffff0ULL) {
             sbase[T] = (uint32_t)total;                     // (rows of tile t = (sbase[t + 1] - sbase[t]) / 256)
             c->slab_ok = true;
-            if (c->tw64.ensure(T + 1) || c->wide_list.ensure(2 * (T + 1)) || c->chunk_list.ensure(2 * (T + 1)) || c->list_cnt.ensure(16) || c->tile_flags.ensure(T + 8) ||
+            if (c->tw64.ensure(T + 1) || c->wide_list.ensure(2 * (T + 1)) || c->chunk_list.ensure(2 * (T + 1)) || c->list_cnt.ensure(32) || c->tile_flags.ensure(T + 8) ||
                 c->lb_tile.ensure(T + 64) || c->lb_blk.ensure(T / LB_BLK + 64) || c->lb_sup.ensure(2 * ((T >> LB_SUP_SHIFT) + 64)) || c->fb_list.ensure(T + 1) || c->tile_stat.ensure(T + 1) || c->sup_stat.ensure((T >> LB_SUP_SHIFT) + 2) ||
                 (!c->wide_cigar && c->slot_rec.ensure((T + 1) * TILE_THREADS))) return -2;
             HIP_TRY(hipMemsetAsync(c->lb_sup.p, 0, 2 * ((T >> LB_SUP_SHIFT) + 64) * 8, c->stream)); c->lb_flip = 0;      // (two arrays taking turns; from then on each is cleared by the run in front of its own)      // (an isoform-rich annotation makes EVERY tile wide: 2.4 KB each)
-            HIP_TRY(hipMemsetAsync(c->list_cnt.p, 0, 64, c->stream));
+            HIP_TRY(hipMemsetAsync(c->list_cnt.p, 0, 128, c->stream)); c->lc_flip = 0; c->prev_run_tile = false;
             if (c->tile_sbase.ensure(T + 1) || c->ovf_cursor.ensure(1) || c->tw.ensure(T + 1) || c->tile_total.ensure(T + 2) || c->tile_xbase.ensure(T + 2) || c->tile_span.ensure(12 * (T + 1)) ||
                 c->s_pre.ensure((size_t)N + 1) || c->s_loc.ensure((size_t)N + 1) ||
                 c->slab_row.ensure((size_t)total + 4) ||
@@ -1170,7 +1177,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         const unsigned gx = 8u * (unsigned)std::max<int64_t>((c->n_tiles + 7) / 8, 1);      // (l2r_slab.hip.h xcd_tile; an empty upload still launches)
         sa.tw64 = (c->ablate & 4) ? nullptr : c->tw64.p;
         sa.chunk_on = (c->ablate & 32) ? 0u : 1u;          // (L2R_ABLATE bit 2: no 64-member windows, bit 5: no chunked windows)
-        sa.wide_list = c->wide_list.p; sa.chunk_list = c->chunk_list.p; sa.list_cnt = c->list_cnt.p; sa.tile_flags = c->tile_flags.p;
+        sa.wide_list = c->wide_list.p; sa.chunk_list = c->chunk_list.p; sa.list_cnt = c->list_cnt.p; sa.list_cnt_next = nullptr; sa.tile_flags = c->tile_flags.p;
         {   const size_t sup_words = (size_t)(c->n_tiles >> LB_SUP_SHIFT) + 64;
             sa.lb_sup = c->lb_sup.p ? c->lb_sup.p + (c->lb_flip ? sup_words : 0) : nullptr;
             sa.lb_sup_next = c->lb_sup.p ? c->lb_sup.p + (c->lb_flip ? 0 : sup_words) : nullptr;
@@ -1191,6 +1198,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
         case 1: launch_probe_level(1, LIST, G); break; case 2: launch_probe_level(2, LIST, G); break; case 3: launch_probe_level(3, LIST, G); break; \
         case 4: launch_probe_level(4, LIST, G); break; case 5: launch_probe_level(5, LIST, G); break; default: launch_probe_level(0, LIST, G); break; } } while (0)
         if (c->tile) {
+            if (!c->prev_run_tile) { HIP_TRY(hipMemsetAsync(c->list_cnt.p, 0, 128, s)); c->lc_flip = 0; }
+            sa.list_cnt = c->list_cnt.p + 16 * (c->lc_flip & 1u); sa.list_cnt_next = c->list_cnt.p + 16 * ((c->lc_flip & 1u) ^ 1u);
             // ---- ONE kernel per tile (l2r_tile.hip.h): the descriptors first (spans from the upload), then walk + probes + write-out in
             //      one workgroup; k_probe_slab behind it for the few tiles that kept the slab form (none on most inputs)
             const DescribeScan job{c->tile_total.p, c->tile_xbase.p, c->totals.p + 0, c->n_tiles};
@@ -1260,7 +1269,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             if (chunk_launch && !beside) launch_tchunk();
             if (wide_launch && beside) HIP_TRY(hipStreamWaitEvent(s, c->ev_join[0], 0));
             if (chunk_launch && beside) HIP_TRY(hipStreamWaitEvent(s, c->ev_join[1], 0));
-            if (!skip_lists) launch_probe(true, gl);
+            if (!skip_lists && !(c->lists_known && c->fb_empty && !c->env_launch_all)) launch_probe(true, gl);
         } else {
         if (c->wide_cigar)
             hipLaunchKernelGGL(k_walk_slab_long, dim3(gx), dim3(TILE_THREADS), pass_a_dynamic_lds(c->reads_per_tile), s, sa, (const TileRec *)c->tile_rec.p);
@@ -1352,14 +1361,16 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
     MARK(ST_GENERIC);
     // (one-kernel tile path: a completed run of the same inputs and parameters has left nothing on the redo list and nothing to the
     //  list-driven kernels -- no read is left for the generic kernel, and what it used to clear for the next run is cleared in front)
-    const bool nothing_left = c->tile && c->lists_known && c->lists_empty && c->redo_empty && !c->env_launch_all;
-    if (c->tile) c->lb_flip ^= 1u;
+    // (... or nothing on the redo list: the list counters need no launch for their clearing, they take turns)
+    const bool nothing_left = c->tile && c->lists_known && c->redo_empty && (c->lists_empty || c->n_sj == 0) && !c->env_launch_all;
+    if (c->tile) { c->lb_flip ^= 1u; c->lc_flip ^= 1u; }
+    c->prev_run_tile = c->tile;
     if (!nothing_left) {
         const unsigned gg = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles * 4 : 1, 4096);      // one wave per listed read, grid-stride
         hipLaunchKernelGGL(k_classify_generic, dim3(gg), dim3(TILE_THREADS), 0, s, c->totals.p + 3, c->redo.p, c->r_tid.p, c->r_rev.p,
                            (c->slab ? (const int32_t *)nullptr : j0),
                            c->hdr.p, c->anno_ex.p, p, c->ex_off.p, c->ex_start.p, c->ex_end.p, c->ex_flag.p, c->info.p, c->ref_tx.p,
-                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles, cd, c->list_cnt.p);
+                           c->tile_acc.p, c->tile_acc_ex.p, (const uint32_t *)c->tile_first.p, (int)c->n_tiles, cd, (uint32_t *)nullptr);
     }
     MARK(ST_SJ);
     // (one-kernel tile path: k_tile has checked every read whose verdict it made; with nothing on the redo list and nothing left to the
@@ -1529,7 +1540,8 @@ int l2r_sync(l2r_ctx *c)
         // what the run left on the lists of the kernels behind k_tile (k_classify_generic keeps the counts of the 64-bit-mask and the
         // chunked kernel's lists in words 6, 7 when it clears them; word 4: k_probe_slab's)
         uint32_t lc[16];
-        HIP_TRY(hipMemcpyAsync(lc, c->list_cnt.p, sizeof lc, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(lc, c->list_cnt.p + 16 * ((c->lc_flip & 1u) ^ 1u), sizeof lc, hipMemcpyDeviceToHost, c->stream));      // (the block of the run that has just ended: launch_all has flipped already)
+        lc[6] = lc[0]; lc[7] = lc[1];                              // (entries of wide_list / chunk_list: nobody clears them behind their readers any more)
         HIP_TRY(hipStreamSynchronize(c->stream));
         uint32_t redo_n = 1u;
         HIP_TRY(hipMemcpyAsync(&redo_n, c->totals.p + 3, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1540,7 +1552,7 @@ int l2r_sync(l2r_ctx *c)
         const unsigned long long chunk_rest = (unsigned long long)lc[8] + (tchunk ? lc[9] : lc[7]);
         // (with k_tile's WIDE instance / k_tile_chunk the tiles they take are no burden of the tile path: what counts is what keeps the slab form)
         c->lists_heavy = 2ull * ((unsigned long long)lc[4] + (c->wide_direct ? lc[5] : lc[6]) + chunk_rest) > (unsigned long long)c->n_tiles;
-        c->n_wide_tiles = lc[6]; c->wide_rest_empty = lc[5] == 0u;
+        c->n_wide_tiles = lc[6]; c->wide_rest_empty = lc[5] == 0u; c->fb_empty = lc[4] == 0u;
         c->n_chunk_tiles = lc[7]; c->chunk_rest_empty = chunk_rest == 0ull;
         c->redo_empty = redo_n == 0u;
         c->lists_known = true;

@@ -108,6 +108,7 @@ struct SlabArgs {
     // kernel that finds a dictionary key in several entries appends its tile to chunk_list (rare).  chunk_on 0: no chunked windows.
     TileWin64 *tw64;
     uint32_t *wide_list, *chunk_list, *list_cnt;
+    uint32_t *list_cnt_next;                             // one-kernel tile path: the list counters take turns run by run like lb_sup (16 words each): this run's k_describe_scan<true> clears the entry counts of the NEXT run's block, so no launch behind the list kernels is needed for that
     uint32_t *tile_flags;                                // every tile's descriptor flags once more, densely (what TileLists reads)
     uint32_t chunk_on;
     uint32_t n_tiles;
@@ -668,6 +669,7 @@ void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan, 
         *sa->exon_total = 0u;                            // (k_tile's last tile writes the run's exon count: an upload without reads has none)
         uint32_t *const lc = sa->list_cnt;
         lc[2] = 0u; lc[3] = 0u; lc[4] = 0u; lc[5] = 0u; lc[8] = 0u; lc[9] = 0u;
+        if (sa->list_cnt_next) { sa->list_cnt_next[0] = 0u; sa->list_cnt_next[1] = 0u; }      // (the next run's entry counts: k_describe_scan appends to them from its first workgroup on)
     }
     if (FIRST && blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < sa->n_sup; i += TILE_THREADS) sa->lb_sup_next[i] = 0ull;      // (the next run's super-block words)
     if (t < sa->n_tiles) {
