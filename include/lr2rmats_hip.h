@@ -258,7 +258,9 @@ void         l2r_xchg_destroy(l2r_xchg *x);
  * l2r_debug_counters: out[0] reads the last run left to the generic kernel (the redo list), [1] dictionary entries whose key has
  *   several entries, [2] annotation transcripts the mask kernels take, [3] tiles, [4..11] tiles by the reason their descriptor
  *   is not on the 32-bit masks (0 = it is), [12] tiles of the 64-bit-mask kernel, [13] runs that l2r_sync did again on the slab pipeline
- *   because a tile of k_tile had waited in vain for the exon counts in front of it; n = words of out (4, 12, 13 or 14).
+ *   because a tile of k_tile had waited in vain for the exon counts in front of it, [14] entries of the chunked kernel's list that k_tile_chunk
+ *   declined in the last run (its staging caps), [15] tiles handed to the chunked kernel late (a key in several entries); n = words of out
+ *   (4, 12, 13, 14 or 16).
  * l2r_debug_stamps: with L2R_STAMPS=1 in the environment at l2r_upload_reads, per-phase cycle sums of the classification kernel
  *   (and clears them); zeros otherwise.
  * l2r_debug_tile_times: with L2R_STAMPS=1, one-kernel tile path: four words per tile -- the chip's 100 MHz clock at the tile's start

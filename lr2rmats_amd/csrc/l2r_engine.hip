@@ -79,6 +79,7 @@ struct l2r_ctx {
     bool fb_empty = false;                              // ... and k_tile left no tile in slab form for k_probe_slab (list_cnt[4])
     bool chunk_direct = true;                           // L2R_CHUNK_DIRECT=0: the exact tiles of the chunked kernel keep the slab form and k_probe_slab_chunked (k_tile_chunk, l2r_tchunk.hip.h)
     bool chunk_rest_empty = false;                      // ... and k_tile_chunk declined none, nobody appended late (list_cnt[9], [8]): k_probe_slab_chunked has nothing to do
+    uint32_t n_late_tiles = 0;                          // ... tiles a one-window kernel handed to the chunked kernel late (list_cnt[8]): the grid of k_tile_chunk's second launch
     uint32_t n_chunk_tiles = 0;                         // ... entries of chunk_list a completed run has left: k_tile_chunk's grid
     bool wide_rest_empty = false;                       // ... and none of them kept the slab form (list_cnt[5]): k_probe_slab_wide has nothing to do
     uint32_t n_wide_tiles = 0;                          // ... entries of wide_list a completed run has left (l2r_sync): the WIDE instance's grid
@@ -1237,9 +1238,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             const bool chunk_launch = !skip_lists && sa.chunk_direct_on && !(c->lists_known && c->n_chunk_tiles == 0u);
             hipStream_t sc = s;
             if (chunk_launch && beside) { sc = c->side[1]; if (!wide_launch) HIP_TRY(hipEventRecord(c->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(sc, c->ev_fork, 0)); }
-            auto launch_tchunk = [&]() {
-                const unsigned gcd = c->lists_known ? std::max(c->n_chunk_tiles, 1u) : (unsigned)std::max<int64_t>(c->n_tiles, 1);
-#define launch_tc_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_chunk<L>), dim3(gcd), dim3(TILE_THREADS), 0, sc, sa, (const TileRec *)c->tile_rec.p, (const TileWin *)c->tw.p, (const TileStat *)c->tile_stat.p, (const SlotRec *)c->slot_rec.p, c->tile_xbase.p)
+            auto launch_tchunk = [&](hipStream_t sc, unsigned gcd, uint32_t late) {
+#define launch_tc_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_chunk<L>), dim3(gcd), dim3(TILE_THREADS), 0, sc, sa, (const TileRec *)c->tile_rec.p, (const TileWin *)c->tw.p, (const TileStat *)c->tile_stat.p, (const SlotRec *)c->slot_rec.p, c->tile_xbase.p, late)
                 switch (p.full_level) {
                 case 1: launch_tc_level(1); break;
                 case 2: launch_tc_level(2); break;
@@ -1250,7 +1250,8 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
                 }
 #undef launch_tc_level
             };
-            if (chunk_launch && beside) { launch_tchunk(); HIP_TRY(hipEventRecord(c->ev_join[1], sc)); }
+            const unsigned gcd = c->lists_known ? std::max(c->n_chunk_tiles, 1u) : (unsigned)std::max<int64_t>(c->n_tiles, 1);
+            if (chunk_launch && beside) { launch_tchunk(sc, gcd, 0u); HIP_TRY(hipEventRecord(c->ev_join[1], sc)); }
             const unsigned gf = fused_grid(c->n_tiles);
 #define launch_tile_k(L, A, D) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile<L, A, D>), dim3(gf), dim3(TILE_THREADS), 0, s, sa, (const TileRec *)c->tile_rec.p, (const TileWin *)c->tw.p, (const TileStat *)c->tile_stat.p, (const SlotRec *)c->slot_rec.p, c->tile_xbase.p)
 #define launch_tile_level(L) do { if (p.ss_dis > 0) { if (probe_acc) launch_tile_k(L, true, true); else launch_tile_k(L, false, true); } \
@@ -1266,7 +1267,7 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
 #undef launch_tile_level
 #undef launch_tile_k
             MARK(ST_FAST);
-            if (chunk_launch && !beside) launch_tchunk();
+            if (chunk_launch && !beside) launch_tchunk(s, gcd, 0u);
             if (wide_launch && beside) HIP_TRY(hipStreamWaitEvent(s, c->ev_join[0], 0));
             if (chunk_launch && beside) HIP_TRY(hipStreamWaitEvent(s, c->ev_join[1], 0));
             if (!skip_lists && !(c->lists_known && c->fb_empty && !c->env_launch_all)) launch_probe(true, gl);
@@ -1314,6 +1315,23 @@ static int launch_all(l2r_ctx *c, hipEvent_t *ev /* ST_N + 1 events or null */)
             default: launch_wide_level(0); break;
             }
 #undef launch_wide_level
+        }
+        if (c->tile && sa.chunk_direct_on && !skip_lists && !(c->lists_known && c->n_late_tiles == 0u && !c->env_launch_all)) {
+            // the tiles a one-window kernel handed on late (a key in several entries): k_tile_chunk once more, over that list
+            const unsigned gl2 = c->lists_known ? std::max(c->n_late_tiles, 1u) : (unsigned)std::max<int64_t>(c->n_tiles, 1);      // (every entry needs its workgroup: k_probe_slab_chunked skips what this launch takes)
+            auto launch_late = [&]() {
+#define launch_tcl_level(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_chunk<L>), dim3(gl2), dim3(TILE_THREADS), 0, s, sa, (const TileRec *)c->tile_rec.p, (const TileWin *)c->tw.p, (const TileStat *)c->tile_stat.p, (const SlotRec *)c->slot_rec.p, c->tile_xbase.p, 1u)
+                switch (p.full_level) {
+                case 1: launch_tcl_level(1); break;
+                case 2: launch_tcl_level(2); break;
+                case 3: launch_tcl_level(3); break;
+                case 4: launch_tcl_level(4); break;
+                case 5: launch_tcl_level(5); break;
+                default: launch_tcl_level(0); break;
+                }
+#undef launch_tcl_level
+            };
+            launch_late();
         }
         if (sa.chunk_on && !skip_lists && !(c->tile && c->lists_known && c->chunk_rest_empty && !c->env_launch_all)) {   // the tiles without a window record, or with a dictionary key in several entries (none on most inputs)
             const unsigned gc = (unsigned)std::min<int64_t>(c->n_tiles ? c->n_tiles : 1, (int64_t)c->n_cu * 4);
@@ -1456,11 +1474,30 @@ int l2r_debug_counters(l2r_ctx *c, long long *out, int n)
     if (n >= 12) for (int k = 0; k < 8; ++k) out[4 + k] = 0;
     if (n >= 13) out[12] = 0;
     if (n >= 14) out[13] = c->n_lb_fallback;              // runs done again on the slab pipeline because k_tile's look-back starved
+    if (n >= 16) {                                        // one-kernel tile path, last run: entries of chunk_list k_tile_chunk declined, tiles handed to the chunked kernel late
+        out[14] = 0; out[15] = 0;
+        if (c->tile && c->ran && c->list_cnt.p) {
+            uint32_t lc[16];
+            HIP_TRY(hipMemcpyAsync(lc, c->list_cnt.p + 16 * ((c->lc_flip & 1u) ^ 1u), sizeof lc, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            out[14] = lc[9]; out[15] = lc[8];
+        }
+    }
     if (n >= 12 && c->slab && c->ran && c->tw.p && c->n_tiles > 0) {     // slab pipeline: the descriptors k_walk_slab made (flags as the probe kernels left them)
         std::vector<TileWin> w((size_t)c->n_tiles);
         HIP_TRY(hipMemcpyAsync(w.data(), c->tw.p, w.size() * sizeof(TileWin), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        if (n >= 24) for (int k = 16; k < 24; ++k) out[k] = 0;
         for (const TileWin &t : w) {
+            if (n >= 24) {                                  // tiles of the chunked kernel by the END entries of their dictionary slices (<= 256, 512, 768, 1024, more), START entries beyond 128 / 256, all of them
+                const uint32_t why = (t.d.flags >> 8) & 7u;
+                if ((t.d.flags & TD_CHUNK) || (!(t.d.flags & (TD_FAST | TD_WIDE)) && (why == 4u || why == 3u))) {
+                    out[16 + (t.d.en_nk <= 256u ? 0 : t.d.en_nk <= 512u ? 1 : t.d.en_nk <= 768u ? 2 : t.d.en_nk <= 1024u ? 3 : 4)]++;
+                    if (t.d.st_nk > 128u) out[21]++;
+                    if (t.d.st_nk > 256u) out[22]++;
+                    out[23]++;
+                }
+            }
             out[4 + ((t.d.flags >> 8) & 7u)]++;
             if (n >= 13 && (t.d.flags & TD_WIDE) && !(t.d.flags & TD_CHUNK)) out[12]++;     // out[12]: tiles k_probe_slab_wide classified (33 .. 63 window members)
         }
@@ -1549,7 +1586,9 @@ int l2r_sync(l2r_ctx *c)
         // (lc[8]: tiles a one-window kernel handed to the chunked kernel late; lc[9]: entries of chunk_list k_tile_chunk declined)
         c->lists_empty = lc[4] == 0u && lc[6] == 0u && lc[7] == 0u && lc[8] == 0u;
         const bool tchunk = c->chunk_direct && !(c->ablate & 32);
-        const unsigned long long chunk_rest = (unsigned long long)lc[8] + (tchunk ? lc[9] : lc[7]);
+        // (what is left to k_probe_slab_chunked: with k_tile_chunk the entries it declined in its two launches, else every entry)
+        const unsigned long long chunk_rest = tchunk ? (unsigned long long)lc[9] + lc[10] : (unsigned long long)lc[8] + lc[7];
+        c->n_late_tiles = lc[8];
         // (with k_tile's WIDE instance / k_tile_chunk the tiles they take are no burden of the tile path: what counts is what keeps the slab form)
         c->lists_heavy = 2ull * ((unsigned long long)lc[4] + (c->wide_direct ? lc[5] : lc[6]) + chunk_rest) > (unsigned long long)c->n_tiles;
         c->n_wide_tiles = lc[6]; c->wide_rest_empty = lc[5] == 0u; c->fb_empty = lc[4] == 0u;

@@ -668,7 +668,7 @@ void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan, 
         *sa->ovf_cursor = 0ull; *sa->lb_err = 0u;
         *sa->exon_total = 0u;                            // (k_tile's last tile writes the run's exon count: an upload without reads has none)
         uint32_t *const lc = sa->list_cnt;
-        lc[2] = 0u; lc[3] = 0u; lc[4] = 0u; lc[5] = 0u; lc[8] = 0u; lc[9] = 0u;
+        lc[2] = 0u; lc[3] = 0u; lc[4] = 0u; lc[5] = 0u; lc[8] = 0u; lc[9] = 0u; lc[10] = 0u;
         if (sa->list_cnt_next) { sa->list_cnt_next[0] = 0u; sa->list_cnt_next[1] = 0u; }      // (the next run's entry counts: k_describe_scan appends to them from its first workgroup on)
     }
     if (FIRST && blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < sa->n_sup; i += TILE_THREADS) sa->lb_sup_next[i] = 0ull;      // (the next run's super-block words)
@@ -779,10 +779,12 @@ __device__ __forceinline__ bool tile_wide_direct(uint32_t on, uint32_t flags, ui
 constexpr int TC_ST_CAP = 128, TC_EN_CAP = 512;          // k_tile_chunk (l2r_tchunk.hip.h): START / END dictionary entries of a tile it stages
 // The tile is taken by k_tile_chunk (the plain instance returns at once for it, k_probe_slab_chunked skips it).  flags: the tile's
 // descriptor flags as k_describe_scan left them (SlabArgs::tile_flags: nobody changes those).
+// late: the tile is one a one-window kernel handed on late (a key in several entries; chunk_list_append_late): k_tile_chunk's second
+// launch, behind the list kernels, takes those -- whatever their descriptor's flags said.
 __device__ __forceinline__ bool tile_chunk_direct(uint32_t on, uint32_t flags, uint32_t chunk_on, const TileDesc &d, const TileStat &st, uint32_t n_act,
-                                                  int min_exon, int min_intron, int max_delet, int dis, int ablate)
+                                                  int min_exon, int min_intron, int max_delet, int dis, int ablate, bool late = false)
 {
-    return on != 0u && chunk_on != 0u && slab_tile_is_chunked(flags) && !(flags & TD_CHUNK) && dis == 0 && d.nbk > 0 && d.st_nk <= (uint32_t)TC_ST_CAP && d.en_nk <= (uint32_t)TC_EN_CAP &&
+    return on != 0u && chunk_on != 0u && (late || (slab_tile_is_chunked(flags) && !(flags & TD_CHUNK))) && dis == 0 && d.nbk > 0 && d.st_nk <= (uint32_t)TC_ST_CAP && d.en_nk <= (uint32_t)TC_EN_CAP &&
            tile_exact(st, min_exon, min_intron, max_delet) && !(ablate & 256) && n_act + (uint32_t)st.n_ops_n <= (uint32_t)TILE_POS_CAP;
 }
 

@@ -225,7 +225,7 @@ static_assert(TC_LDS_BYTES <= 40960, "k_tile_chunk: 4 workgroups per CU need 80 
 template <int LEVEL>
 __global__ __launch_bounds__(TILE_THREADS, 4)
 void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const TileWin *__restrict__ u_tw, const TileStat *__restrict__ u_stat, const SlotRec *__restrict__ u_slot,
-                  uint32_t *__restrict__ u_xbase)
+                  uint32_t *__restrict__ u_xbase, uint32_t late /* 1: the launch behind the list kernels, over the tiles they handed on late */)
 {
     constexpr uint32_t F_ALL = (uint32_t)(F_EXON | F_DON | F_ACC | F_JUNC);
     __shared__ __attribute__((aligned(16))) uint32_t s_A[TILE_POS_CAP];          // row words: start - base | the chunk's work word << 18 (at the end: | flag byte << 18)
@@ -247,9 +247,9 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    if (blockIdx.x >= sa->list_cnt[1]) return;
-    const uint32_t t = sa->chunk_list[blockIdx.x];
     const uint32_t n_tiles = sa->n_tiles;
+    if (blockIdx.x >= sa->list_cnt[late ? 8 : 1]) return;
+    const uint32_t t = sa->chunk_list[late ? n_tiles + 1u + blockIdx.x : blockIdx.x];
     if (t >= n_tiles) return;
     // diagnostics (L2R_STAMPS=1), wave 0: [0] records, loads asked for, window scan  [1] place walk + barrier  [2] chunk list, key lookups + barrier
     // [3] per chunk: headers + masks staged, barrier  [4] member pass  [5] mask ORs  [6] carried state + barrier  [7] verdicts, first slot, write-out
@@ -264,8 +264,8 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
     const int32_t n_tx = a->f.p.n_tx;
     const uint32_t r0 = rec.r0, n_act = rec.n_act;
     const int32_t tid0 = rec.tid0, tile_lo = rec.lo, tile_hi = (int32_t)rec.pad[0];
-    if (!tile_chunk_direct(sa->chunk_direct_on, flags0, chunk_on, d, tst, n_act, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet, a->f.p.ss_dis, ablate)) {
-        if (threadIdx.x == 0) atomicAdd(sa->list_cnt + 9, 1u);            // (left to k_probe_slab_chunked: the host skips that launch while nobody counts here)
+    if (!tile_chunk_direct(sa->chunk_direct_on, flags0, chunk_on, d, tst, n_act, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet, a->f.p.ss_dis, ablate, late != 0u)) {
+        if (threadIdx.x == 0) atomicAdd(sa->list_cnt + (late ? 10 : 9), 1u);            // (left to k_probe_slab_chunked: the host skips that launch while nobody counts here)
         return;
     }
     // ---- the counts in front of the tile (waves 0 .. 2, one level each): plain loads, complete unless a tile in front is not exact

@@ -32,9 +32,11 @@ if os.environ.get("L2R_STAMPS"):
     print("  classic kernel: 0 CIGAR staging 7 walk 1 dictionary staging 2 window pass 3 probes 4 verdicts 5 counts 6 write-out")
     print("  one-walk kernel: 0 walk 1 staging 2 window pass + next span 3 probes + verdicts 4 offsets/map/write-out | 5 barrier waits of wave 0, 6 of the last wave, 7 descriptor work of the last wave (5-7 are not phases: compare with the sum of 0-4)")
     print("redo reasons [not fast, not in LDS, wide, other tid, not sane, window/compact]:", v[8:14])
-cnt = (C.c_longlong * 13)()
+cnt = (C.c_longlong * 24)()
 lib.l2r_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-lib.l2r_debug_counters(e.ctx, cnt, 13)
+lib.l2r_debug_counters(e.ctx, cnt, 24)
+print("runs done again on the slab pipeline %d | k_tile_chunk declined %d tiles, %d handed on late" % (cnt[13], cnt[14], cnt[15]))
+print("tiles of the chunked kernel by END entries [<=256, <=512, <=768, <=1024, more]:", list(cnt[16:21]), "| START entries > 128:", cnt[21], "> 256:", cnt[22], "| all:", cnt[23])
 print("redo reads %d, wide entries %d, compact tx %d, tiles %d" % tuple(cnt[:4]), "| tiles of the 64-member kernel:", cnt[12])
 print("tiles [fast, exons > LDS cap, bucket span, dictionary slice, window > 32, window scan, cursor behind window, off]:", list(cnt[4:12]))
 # (a profile's per-kernel averages: enough back-to-back steps for the chip's clock to settle -- it rises over the first ~25, tools/ramp.py)
