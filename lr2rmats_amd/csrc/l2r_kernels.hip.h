@@ -1427,6 +1427,22 @@ struct TileLds {                 // the tile's LDS image (layout in k_classify_f
     const int4 *hk, *hx;
     const int *win;              // window member -> annotation index
 };
+// m = m << 1 | predicate, as ONE compare and ONE add-with-carry (m + m + carry): the member passes collect their per-member predicates
+// highest member first -- the select-and-or form costs three vector instructions per predicate on 32-bit masks, five on 64-bit ones.
+__device__ __forceinline__ void shift_in_le(uint32_t &m, int a, int b)          // m = m << 1 | (a <= b)
+{
+    asm volatile("v_cmp_le_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ void shift_in_eq(uint32_t &m, int a, int b)          // m = m << 1 | (a == b)
+{
+    asm volatile("v_cmp_eq_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ void shift_in_le2(uint32_t &m, int a, int b, int c, int d)      // m = m << 1 | (a <= b && c <= d)
+{
+    unsigned long long t;
+    asm volatile("v_cmp_le_i32 vcc, %2, %3\n\tv_cmp_le_i32 %1, %4, %5\n\ts_and_b64 vcc, vcc, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                 : "+v"(m), "=&s"(t) : "v"(a), "v"(b), "v"(c), "v"(d) : "vcc", "scc");
+}
 struct VisitMasks { uint32_t vpre, lmask, rmask, k1mask; bool redo; };
 struct SiteMasks { uint32_t kand, kor, dm_first, am_last; uint32_t amb; };      // amb (-d > 0 only): members with TWO sites within the tolerance of one read site (probe_near)
 

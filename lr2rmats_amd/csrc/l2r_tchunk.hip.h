@@ -122,20 +122,6 @@ __device__ __forceinline__ m64_t tc_overlapping_exon_members(const TcLds &L, int
 // behind the annotation: "behind every read").  The member pass is bound by vector issue (four waves per SIMD walk the same 63 headers):
 // members 0 .. 31 and 32 .. 62 are collected in two 32-bit words, highest member first, each predicate by ONE compare and ONE
 // add-with-carry (m = m + m + predicate) -- 10 vector instructions per member at level 3 where the 64-bit select-and-or form takes 24.
-__device__ __forceinline__ void tc_shift_in_le(uint32_t &m, int a, int b)          // m = m << 1 | (a <= b)
-{
-    asm volatile("v_cmp_le_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a), "v"(b) : "vcc");
-}
-__device__ __forceinline__ void tc_shift_in_eq(uint32_t &m, int a, int b)          // m = m << 1 | (a == b)
-{
-    asm volatile("v_cmp_eq_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a), "v"(b) : "vcc");
-}
-__device__ __forceinline__ void tc_shift_in_le2(uint32_t &m, int a, int b, int c, int d)      // m = m << 1 | (a <= b && c <= d)
-{
-    unsigned long long t;
-    asm volatile("v_cmp_le_i32 vcc, %2, %3\n\tv_cmp_le_i32 %1, %4, %5\n\ts_and_b64 vcc, vcc, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                 : "+v"(m), "=&s"(t) : "v"(a), "v"(b), "v"(c), "v"(d) : "vcc", "scc");
-}
 template <int LEVEL>
 __device__ __forceinline__ ChunkVisit tc_visit(const int2 *s_se, const int4 *s_hx, int w_n, bool work, uint32_t n, const ReadEnds &re, const m64_t *tilemask)
 {
@@ -148,14 +134,14 @@ __device__ __forceinline__ ChunkVisit tc_visit(const int2 *s_se, const int4 *s_h
 #pragma unroll 4
         for (int j = j_hi; j >= j_lo; --j) {
             const int2 hk = s_se[j];                                         // {start, end}: 8 bytes of the 16 the verdicts' header word has
-            tc_shift_in_le(aft[half], re.el, hk.x);                          // comp_trans <= (Q5): the read lies before the member
-            tc_shift_in_le(bef[half], hk.y, re.s0);                          // the member lies before the read
+            shift_in_le(aft[half], re.el, hk.x);                          // comp_trans <= (Q5): the read lies before the member
+            shift_in_le(bef[half], hk.y, re.s0);                          // the member lies before the read
             if (LEVEL >= 1 && LEVEL <= 4) {
                 const int4 hx = s_hx[j];
-                if (LEVEL == 1) { tc_shift_in_eq(lm[half], re.e0, hx.y); tc_shift_in_eq(rm[half], re.sl, hx.z); }
+                if (LEVEL == 1) { shift_in_eq(lm[half], re.e0, hx.y); shift_in_eq(rm[half], re.sl, hx.z); }
                 else {
-                    tc_shift_in_le2(lm[half], re.s0, hx.y, hx.x, re.e0);     // closed_overlap(s0, e0, hx.x, hx.y)
-                    if (LEVEL != 4) tc_shift_in_le2(rm[half], re.sl, hx.w, hx.z, re.el);
+                    shift_in_le2(lm[half], re.s0, hx.y, hx.x, re.e0);     // closed_overlap(s0, e0, hx.x, hx.y)
+                    if (LEVEL != 4) shift_in_le2(rm[half], re.sl, hx.w, hx.z, re.el);
                 }
             }
         }
