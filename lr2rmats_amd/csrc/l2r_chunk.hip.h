@@ -258,8 +258,9 @@ void k_probe_slab_chunked(SlabArgs kernarg_block, const uint32_t *__restrict__ u
         if (wi >= n_list) break;
         const uint32_t t = wi < n_first ? sa->chunk_list[wi] : sa->chunk_list[sa->n_tiles + 1u + (wi - n_first)];
         // (one-kernel tile path: k_tile_chunk, l2r_tchunk.hip.h, has taken the tile from its CIGARs -- the same test as there)
-        if (sa->chunk_direct_on && tile_chunk_direct(1u, sa->tile_flags[t], sa->chunk_on, u_tw[t].d, sa->tile_stat[t], u_tile_first[t + 1u] - u_tile_first[t],
-                                                     a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet, a->f.p.ss_dis, a->f.p.ablate, wi >= n_first)) { __syncthreads(); continue; }
+        if (sa->chunk_direct_on && (wi < n_first ? (sa->tile_flags[t] & TD_CDIRECT) != 0u
+                                                 : tile_chunk_direct(1u, sa->tile_flags[t], sa->chunk_on, u_tw[t].d, sa->tile_stat[t], u_tile_first[t + 1u] - u_tile_first[t],
+                                                                     a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet, a->f.p.ss_dis, a->f.p.ablate, true))) { __syncthreads(); continue; }
         const uint32_t r0 = u_tile_first[t], n_act = u_tile_first[t + 1u] - r0;
         const uint32_t sbase = u_tile_sbase[t], xbase = u_xbase[t], total = u_xbase[t + 1u] - xbase;
         const int32_t tile_lo = u_pos[r0] + 1;

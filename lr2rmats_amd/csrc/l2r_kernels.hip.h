@@ -103,6 +103,7 @@ constexpr uint32_t TD_FAST = 1;    // exons fit the LDS tile, dictionary slices 
 constexpr uint32_t TD_WALKED = 4;  // long-CIGAR input: pass A has left the tile's exons in `walked` (tile * LDS_EXON_CAP + in-tile offset)
 constexpr uint32_t TD_WIDE = 8;    // slab pipeline: the window holds 33 .. 63 transcripts (l2r_wide.hip.h takes the tile), TD_FAST is not set
 constexpr uint32_t TD_CHUNK = 16;  // slab pipeline: set by k_probe_slab / k_probe_slab_wide on a tile that stages a dictionary key in several entries: k_probe_slab_chunked takes it
+constexpr uint32_t TD_CDIRECT = 32; // one-kernel tile path: k_tile_chunk (l2r_tchunk.hip.h) takes the tile from its CIGARs -- decided by k_describe_scan<true> (tile_chunk_direct), so that k_tile's plain instance only tests this bit
 constexpr uint32_t TD_CONTIG = 2;  // the window's transcripts are consecutive in the annotation: j_lo, j_lo + 1, ...
 constexpr int WIN_SCAN_TRIPS = 64; // pass A looks at up to 64 * WIN_SCAN_TRIPS transcripts for a tile's window
 

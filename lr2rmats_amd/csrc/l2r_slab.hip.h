@@ -630,6 +630,8 @@ void k_walk_slab_long(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec)
 //       each is a chain of three round trips, and only 8192 waves are resident at a time; with sixteen lanes per tile nearly all
 //       tiles are in flight at once.  A workgroup's 16 tiles that belong to k_probe_slab_wide / k_probe_slab_chunked are appended to
 //       those kernels' lists with ONE reservation per workgroup and list (no particular order; list_cnt is cleared by k_walk_slab).
+__device__ __forceinline__ bool tile_chunk_direct(uint32_t on, uint32_t flags, uint32_t chunk_on, const TileDesc &d, const TileStat &st, uint32_t n_act,
+                                                  int min_exon, int min_intron, int max_delet, int dis, int ablate, bool late = false);      // (below, beside tile_wide_direct)
 typedef SegScan DescribeScan;
 constexpr int DESCRIBE_G = 16;                           // lanes per tile
 constexpr int DESCRIBE_TILES = TILE_THREADS / DESCRIBE_G;       // tiles per workgroup
@@ -674,12 +676,14 @@ void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan, 
     if (FIRST && blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < sa->n_sup; i += TILE_THREADS) sa->lb_sup_next[i] = 0ull;      // (the next run's super-block words)
     if (t < sa->n_tiles) {
         int4 spv, spw;
+        TileStat st_first{0, 0, 0, 0}; uint32_t n_act_first = 0u;      // FIRST: the tile's op statistics and reads (tile_chunk_direct below)
         if (FIRST) {
             // (every load that needs nothing but the tile number leaves together, in front of the cursor's chain of three)
             const int4 r0v = reinterpret_cast<const int4 *>(u_rec + t)[0];             // {r0, n_act, sbase, rows}
             const int4 rv = reinterpret_cast<const int4 *>(u_rec + t)[1];              // {tid0, lo, hi, .}
             const int4 sv = *reinterpret_cast<const int4 *>(sa->tile_stat + t);
             asm volatile("" :: "v"(r0v.y), "v"(rv.x), "v"(sv.x));
+            st_first = TileStat{sv.x, sv.y, sv.z, sv.w}; n_act_first = (uint32_t)r0v.y;
             CursorDir cd;
             cd.key = a->cd.key; cd.dir = a->cd.dir; cd.kb_base = a->cd.kb_base; cd.n_tid = a->cd.n_tid; cd.n_tx = a->cd.n_tx;
             const int jl = cursor_value(cd, rv.x, rv.y);
@@ -696,6 +700,14 @@ void k_describe_scan(SlabArgs kernarg_block, DescribeScan job, uint32_t n_scan, 
         } else { spv = reinterpret_cast<const int4 *>(sa->span + t)[0]; spw = reinterpret_cast<const int4 *>(sa->span + t)[1]; }
         flags = make_descriptor<DESCRIBE_G>(a, gl, g * DESCRIBE_G, spv.x, spv.y, spv.z, sa->tw + t, sa->tw64 ? sa->tw64 + t : nullptr, s_win[slot],
                                             (uint32_t)SLAB_KEY_CAP, spw.x, spw.y, spw.z, (uint32_t)spv.w);
+        // (one-kernel tile path: is the tile k_tile_chunk's?  Said once, here, as a bit of the descriptor's flags: the kernels test the bit)
+        if (FIRST && gl == 0 && sa->chunk_direct_on != 0u) {
+            const TileDesc dd = sa->tw[t].d;                     // (this lane's own stores of a moment ago)
+            if (tile_chunk_direct(1u, flags, sa->chunk_on, dd, st_first, n_act_first, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet, a->f.p.ss_dis, a->f.p.ablate)) {
+                flags |= TD_CDIRECT;
+                sa->tw[t].d.flags = flags;
+            }
+        }
         if (gl == 0) sa->tile_flags[t] = flags;
         // (accepted list: every tile's chunk is k_gather_accepted's until a probe kernel has left it itself)
         if (gl == 0 && (a->f.p.want & WANT_ACCEPTED)) a->f.tile_chunk[t] = CHUNK_DEFERRED;
@@ -782,7 +794,7 @@ constexpr int TC_ST_CAP = 128, TC_EN_CAP = 512;          // k_tile_chunk (l2r_tc
 // late: the tile is one a one-window kernel handed on late (a key in several entries; chunk_list_append_late): k_tile_chunk's second
 // launch, behind the list kernels, takes those -- whatever their descriptor's flags said.
 __device__ __forceinline__ bool tile_chunk_direct(uint32_t on, uint32_t flags, uint32_t chunk_on, const TileDesc &d, const TileStat &st, uint32_t n_act,
-                                                  int min_exon, int min_intron, int max_delet, int dis, int ablate, bool late = false)
+                                                  int min_exon, int min_intron, int max_delet, int dis, int ablate, bool late)
 {
     return on != 0u && chunk_on != 0u && (late || (slab_tile_is_chunked(flags) && !(flags & TD_CHUNK))) && dis == 0 && d.nbk > 0 && d.st_nk <= (uint32_t)TC_ST_CAP && d.en_nk <= (uint32_t)TC_EN_CAP &&
            tile_exact(st, min_exon, min_intron, max_delet) && !(ablate & 256) && n_act + (uint32_t)st.n_ops_n <= (uint32_t)TILE_POS_CAP;

@@ -250,7 +250,9 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
     const int32_t n_tx = a->f.p.n_tx;
     const uint32_t r0 = rec.r0, n_act = rec.n_act;
     const int32_t tid0 = rec.tid0, tile_lo = rec.lo, tile_hi = (int32_t)rec.pad[0];
-    if (!tile_chunk_direct(sa->chunk_direct_on, flags0, chunk_on, d, tst, n_act, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet, a->f.p.ss_dis, ablate, late != 0u)) {
+    // (the tiles of the first launch carry k_describe_scan's verdict as a bit of their flags; the late ones are tested here)
+    if (late ? !tile_chunk_direct(sa->chunk_direct_on, flags0, chunk_on, d, tst, n_act, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet, a->f.p.ss_dis, ablate, true)
+             : (flags0 & TD_CDIRECT) == 0u) {
         if (threadIdx.x == 0) atomicAdd(sa->list_cnt + (late ? 10 : 9), 1u);            // (left to k_probe_slab_chunked: the host skips that launch while nobody counts here)
         return;
     }

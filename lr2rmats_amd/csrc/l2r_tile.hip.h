@@ -580,7 +580,7 @@ void k_tile(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, const Til
         const bool direct = tile_wide_direct(sa->wide_direct_on, d0.flags, chunk_on, tst, n_act, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet, ablate);
         if (WIDE ? !direct : direct) return;
         // (... or k_tile_chunk, l2r_tchunk.hip.h: an exact tile of the chunked kernel)
-        if (!WIDE && tile_chunk_direct(sa->chunk_direct_on, d0.flags, chunk_on, d0, tst, n_act, a->f.p.min_exon, a->f.p.min_intron, a->f.p.max_delet, a->f.p.ss_dis, ablate)) return;
+        if (!WIDE && (d0.flags & TD_CDIRECT) != 0u) return;
     }
     TileDesc d = d0;
     if (pre_slab) d.flags = 0u;
