@@ -441,20 +441,34 @@ def c_route_leg(world: int, dev_map, args, capi, workload, dev_index: int):
                 if "detail.txt" in o:
                     c += ["-A", o["detail.txt"], "-y", o["summary.txt"]]
                 return c + [bam, gtf], o
+            def run_bounded(argv, env, limit=240.0):
+                # (a child of its own session, ended with its whole group at the limit: a route that has never met two physical GPUs must not
+                #  be able to hold the line back)
+                import signal
+                pr = subprocess.Popen(argv, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+                try:
+                    _, e = pr.communicate(timeout=limit)
+                    return pr.returncode, e.decode(errors="replace")
+                except subprocess.TimeoutExpired:
+                    try:
+                        os.killpg(pr.pid, signal.SIGKILL)
+                    except OSError:
+                        pass
+                    _, e = pr.communicate()
+                    return -999, e.decode(errors="replace") + "\n[bench.py] ended after %.0f s" % limit
             c1, o1 = cmd("one")
-            r1 = subprocess.run(c1, env=env_1, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            rc1, _ = run_bounded(c1, env_1)
             cn, on = cmd("many")
             t0 = time.perf_counter()
-            rn = subprocess.run(cn, env=env_n, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            rcn, err = run_bounded(cn, env_n)
             wall = time.perf_counter() - t0
-            err = rn.stderr.decode(errors="replace")
             for ln in err.splitlines():                          # what ncclCommInitRank saw on every rank: the first hardware run proves its world by it
                 if "RCCL communicator" in ln or "gathered route" in ln or "L2R_GPUS" in ln:
                     print("bench.py c_route[%s]: %s" % (name, ln), file=sys.stderr)
-            same = r1.returncode == 0 and rn.returncode == 0 and all(os.path.exists(on[k]) and filecmp.cmp(o1[k], on[k], shallow=False) for k in outs)
+            same = rc1 == 0 and rcn == 0 and all(os.path.exists(on[k]) and filecmp.cmp(o1[k], on[k], shallow=False) for k in outs)
             ranks_seen = sorted({ln.split("rank ")[1].split(" ")[0] for ln in err.splitlines() if "RCCL communicator: rank " in ln})
             n_acc = int(((res.info & 128) != 0).sum())
-            out[name] = {"wall_s": round(wall, 3), "rc": [r1.returncode, rn.returncode], "files_identical": bool(same),
+            out[name] = {"wall_s": round(wall, 3), "rc": [rc1, rcn], "files_identical": bool(same),
                          "exchange": "rccl" if "exchange: RCCL" in err else ("shm" if "exchange: shared memory" in err else "none (partitioned or one child)"),
                          "rccl_ranks_reporting": ranks_seen,
                          # an upper bound of what travels to child 0 (its own shard does not): 12 bytes per read + 9 per exon, or the accepted records alone

@@ -272,6 +272,10 @@ class Engine:
                     _ptr(a[4], _u32p), first_read_index, _ptr(sm, _u32p) if sm is not None else None)
         self._chk(self.lib.l2r_upload_reads(self.ctx, C.byref(cr)))
 
+    def hint_single_run(self, on: bool = True):
+        """Every following upload will be classified once (l2r_hint_single_run): no tile index, the two-kernel pipeline."""
+        self._chk(self.lib.l2r_hint_single_run(self.ctx, 1 if on else 0))
+
     def upload_index_ms(self) -> float:
         """GPU time of the last upload's tile index (k_tile_index), ms."""
         return float(self.lib.l2r_upload_index_ms(self.ctx))

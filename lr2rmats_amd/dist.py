@@ -102,6 +102,7 @@ class DeviceShard:
 def _engine_classify(device_index: int):
     """Default shard classifier: the HIP engine on this rank's GPU; the results stay in HBM."""
     eng = capi.Engine(device_index)
+    eng.hint_single_run(True)               # (a shard is uploaded and classified once: no tile index, the two-kernel pipeline -- DESIGN.md section 7)
 
     def run(job: hostlib.Job, lo: int, hi: int, want: int = capi.WANT_RESULTS, base: int = 0):
         a = job.annotation_arrays()
