@@ -168,10 +168,13 @@ typedef struct {
  *             (annotation window, site probes, verdicts, read-order results) + k_probe_slab_wide (tiles whose window holds 33 .. 63
  *             transcripts) + k_probe_slab_chunked (tiles beyond that, or with a dictionary key in several entries: the window 63
  *             members at a time).  Every run launches all of them: nothing is kept from an earlier run of the same records.
- *     tile    (coordinate-sorted records with short CIGARs, -e >= 1; default where it applies)  0 k_describe_scan (the tiles' descriptors
+ *     tile    (coordinate-sorted records with short CIGARs, -e >= 1, an upload that carries the tile index -- i.e. not a single-run one,
+ *             l2r_hint_single_run / l2r_classify; default where it applies)  0 k_describe_scan (the tiles' descriptors
  *             and windows from the spans the upload recorded; first kernel of the run)  1 k_tile (CIGAR -> exons, window, probes, verdicts,
  *             junction check, read-order results: one workgroup per tile, nothing handed over through HBM)  2 k_probe_slab for the few
- *             tiles k_tile left in slab form + k_tile's WIDE instance (windows of 33 .. 63 transcripts) + k_probe_slab_wide + k_probe_slab_chunked (not launched once a run has shown their lists empty)
+ *             tiles k_tile left in slab form + k_tile's WIDE instance (windows of 33 .. 63 transcripts) + k_tile_chunk (windows beyond that) -- both launched beside
+ *             k_tile on streams of their own, so with per-stage events they count here and in stage 1 one behind the other -- + k_probe_slab_wide + k_probe_slab_chunked
+ *             (each not launched once a run has shown its list empty)
  *     classic (unsorted records, long CIGARs with -e < 1, L2R_PIPELINE=classic)  0 k_pass_a  1 k_scan_u32 (tile sums)  2 k_classify_fast */
 #define L2R_N_STAGES 8
 typedef struct {

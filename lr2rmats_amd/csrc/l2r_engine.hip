@@ -1521,7 +1521,7 @@ const char *l2r_stage_kernel(l2r_ctx *c, int stage)
     static const char *const classic[L2R_N_STAGES] = {"k_pass_a", "k_scan_u32 (tile sums)", "k_classify_fast", "k_classify_generic",
                                                       "k_validate_sj", "k_scan_accepted (k_scan_u32 of the accepted counts)", "k_gather_accepted", ""};
     if (stage >= 3 || !c->slab) return classic[stage];
-    if (c->tile) return stage == 0 ? "k_describe_scan (tile descriptors + tile lists; first kernel of the run)" : stage == 1 ? "k_tile (walk + probes + write-out, one workgroup per tile)" : "k_probe_slab (tiles k_tile left in slab form) (+ k_probe_slab_wide + k_probe_slab_chunked)";
+    if (c->tile) return stage == 0 ? "k_describe_scan (tile descriptors + tile lists; first kernel of the run)" : stage == 1 ? "k_tile (walk + probes + write-out, one workgroup per tile)" : "k_probe_slab (tiles k_tile left in slab form) (+ k_tile_chunk + k_probe_slab_wide + k_probe_slab_chunked)";
     return stage == 0 ? (c->wide_cigar ? "k_walk_slab_long" : "k_walk_slab") : stage == 1 ? "k_describe_scan (tile descriptors + scan of the exon counts + tile lists)" : "k_probe_slab (+ k_probe_slab_wide + k_probe_slab_chunked)";
 }
 

@@ -23,11 +23,13 @@
 //                           poll for it: fine for a few, a convoy for many (launch_all sends runs with more than 2 % of such tiles
 //                           to the two-kernel path).  Workgroup -> tile is blocked-cyclic over the XCDs (fused_tile: 16 consecutive
 //                           tiles per XCD share their dictionary slices in one L2).  A tile that waits in vain (LB_POLLS) sets lb_err,
-//                           which ends every other wait too: the run reports an error instead of hanging the device.
+//                           which ends every other wait too: l2r_sync then does the run again on the slab pipeline.
 //   k_tile<..., WIDE>       the same kernel with 64-bit masks, 24-byte entries and the 63-member window record, one workgroup per entry of
-//                           wide_list behind the plain instance: the windows of 33 .. 63 transcripts (tile_wide_direct, l2r_slab.hip.h: exact
-//                           tiles; the plain instance returns at once for them).
-//   tiles this kernel does not finish: windows beyond 63 members and the wide ones that are not exact (k_probe_slab_chunked / _wide),
+//                           wide_list, launched BESIDE the plain instance on a stream of its own: the windows of 33 .. 63 transcripts
+//                           (tile_wide_direct, l2r_slab.hip.h: exact tiles; the plain instance returns at once for them).
+//   k_tile_chunk            (l2r_tchunk.hip.h) the exact tiles with windows beyond 63 transcripts, likewise beside the plain instance, which
+//                           returns at once for them (TD_CDIRECT: k_describe_scan's verdict).
+//   tiles this kernel does not finish: windows beyond 32 members that are not exact (k_probe_slab_chunked / _wide),
 //                           a dictionary key in several entries, a read of 255 exons or more, more exons than the staged positions
 //                           hold (only outliers make such tiles).  For those the workgroup runs k_walk_slab's tile body instead
 //                           (slab_walk_tile: slab rows, reads' words, span record) and lists the tile for k_probe_slab (fb_list).
