@@ -442,6 +442,40 @@ GTFQ_GTF = (gtf_block("chrA", 1000, 2100, "+", "RG1", "g1", "q1", 1, "chrA", "+"
             + gtf_block("chrA", 21000, 22100, "+", "G5", "g5", "q5", 1, "chrA", "+", [(21000, 21100), (22000, 22100)]))
 
 
+# --------------------------------------------------------------------------------------------------
+# Case "uns": records that are NOT coordinate sorted -- the sweep's cursor only moves forward (check_with_anno_trans,
+# update_gtf.c:792-802: `if (*last_anno_i == i) ++(*last_anno_i)`).  README.md section 10.
+UNS_ANNO = (gtf_rows("chrA", "+", "GA", "ga", "TA", "ta", [(1000, 1100), (2000, 2100)])
+            + gtf_rows("chrA", "+", "GB", "gb", "TB", "tb", [(5000, 5100), (6000, 6100)]))
+UNS_SAM = ["@HD\tVN:1.0\tSO:unsorted", "@SQ\tSN:chrA\tLN:100000000", "@SQ\tSN:chrB\tLN:100000000",
+           sam("rB", 0, "chrA", 5000, "101M899N101M"),
+           sam("rA", 0, "chrA", 1000, "101M899N101M"),
+           sam("rC", 0, "chrA", 5000, "101M899N101M")]
+UNS_DETAIL = [
+    DETAIL_HEADER,
+    detail("rB", "chrA", "+", 1, "GB", "gb", [5000, 6000], [5100, 6100], [], [1], [], []),
+    detail("rA", "chrA", "+", 2, "NA", "NA", [1000, 2000], [1100, 2100], [0, 1], [0, 1], [0], []),      # the cursor has passed TA for good
+    detail("rC", "chrA", "+", 1, "GB", "gb", [5000, 6000], [5100, 6100], [], [1], [], []),
+]
+UNS_GTF = gtf_block("chrA", 5000, 6100, "+", "GB", "gb", "rB", 2, "chrA", "+", [(5000, 5100), (6000, 6100)])      # rC merges into rB's entry: cov 2
+
+
+# --------------------------------------------------------------------------------------------------
+# Case "mg": `update-gtf -m g -b uns.sam`: read-like transcripts from a GTF instead of alignments (read_gtf_trans, gtf.c:524-595).
+# README.md section 11.  Annotation: uns_anno.gtf.
+MG_READS = (gtf_rows("chrA", "-", "GX", "gx", "X1", "x1n", [(6000, 6100), (5000, 5100)])
+            + [T.join(["chrA", "hand", "exon", "50000", "50099", ".", "+", ".", 'transcript_id "X2"; gene_name "gz";'])])
+MG_DETAIL = [
+    DETAIL_HEADER,
+    detail("x1n", "chrA", "+", 1, "GB", "gb", [5000, 6000], [5100, 6100], [], [1], [], []),
+    detail("X2", "chrA", "+", 2, "NA", "NA", [50000], [50099], [0], [], [], []),
+]
+_MG_ATTR = 'gene_id "GB"; transcript_id "X1"; gene_name "gb"; transcript_name "x1n";'
+MG_GTF = [T.join(["chrA", "lr2rmats", "transcript", "5000", "6100", ".", "+", ".", _MG_ATTR + ' transcript_cov "1";']),
+          T.join(["chrA", "lr2rmats", "exon", "5000", "5100", ".", "+", ".", _MG_ATTR]),
+          T.join(["chrA", "lr2rmats", "exon", "6000", "6100", ".", "+", ".", _MG_ATTR])]
+
+
 FILES = {
     "anno.gtf": ANNO,
     "cigar.sam": CIG_SAM, "cigar_m.sam": CIG_SAM_MAPPED, "cigar_anno.gtf": CIG_ANNO, "cigar.bam2gtf.gtf": CIG_B2G, "cigar_t.bam2gtf.gtf": CIG_B2G_T,
@@ -458,6 +492,8 @@ FILES = {
     "uniq.sam": UNIQ_SAM, "uniq.unique.gtf": UNIQ_GTF, "uniq_s.unique.gtf": UNIQ_GTF_S,
     "split.sam": SPLIT_SAM, "split_sj.tab": SPLIT_SJ, "split.detail.txt": SPLIT_DETAIL, "split.updated.gtf": SPLIT_GTF,
     "split.novel_exon.bed": SPLIT_BED, "split.summary.txt": SPLIT_SUMMARY,
+    "mg_reads.gtf": MG_READS, "mg.detail.txt": MG_DETAIL, "mg.updated.gtf": MG_GTF,
+    "uns_anno.gtf": UNS_ANNO, "uns.sam": UNS_SAM, "uns.detail.txt": UNS_DETAIL, "uns.updated.gtf": UNS_GTF,
     "gtfq_anno.gtf": GTFQ_ANNO, "gtfq.sam": GTFQ_SAM, "gtfq.detail.txt": GTFQ_DETAIL, "gtfq.updated.gtf": GTFQ_GTF,
 }
 

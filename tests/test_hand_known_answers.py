@@ -41,6 +41,11 @@ CASES = {
     # the annotation reader's quirks (gtf.c:317-326,468-521): tag found inside a longer tag, id / name fall-backs, a comment between a
     # transcript's rows, a chromosome that is not in the header, an empty line, rows cut behind byte 1 023
     "gtfq": (["update-gtf", "-l", "5"], "gtfq.sam", "gtfq_anno.gtf", {"gtf": "gtfq.updated.gtf", "detail": "gtfq.detail.txt"}),
+    # records that are not coordinate sorted: the sweep's cursor only moves forward (update_gtf.c:792-802), a read in front of it finds nothing
+    "uns": (["update-gtf", "-l", "5"], "uns.sam", "uns_anno.gtf", {"gtf": "uns.updated.gtf", "detail": "uns.detail.txt"}),
+    # -m g: read-like transcripts from a GTF (read_gtf_trans, gtf.c:524-595): ids / names of the input kept, gene taken from the annotation, exons sorted,
+    # strand flipped to the reference transcript's
+    "mg": (["update-gtf", "-m", "g", "-b", os.path.join(H, "uns.sam"), "-l", "5"], "mg_reads.gtf", "uns_anno.gtf", {"gtf": "mg.updated.gtf", "detail": "mg.detail.txt"}),
     "uniq": (["unique-gtf"], "uniq.sam", False, {"gtf": "uniq.unique.gtf"}),
     "uniq_s": (["unique-gtf", "-s"], "uniq.sam", False, {"gtf": "uniq_s.unique.gtf"}),
 }
