@@ -513,3 +513,60 @@ def test_wide_tiles_on_every_route_of_the_tile_path(oracle, monkeypatch, route):
     got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, **kw)
     assert ((want.info & 2) != 0).sum() > 1000
     assert cnt[4] >= 15 and cnt[0] <= 300, cnt              # the locus's tiles are 64-bit-mask tiles, (almost) nothing on the redo list
+
+
+@pytest.mark.parametrize("shape", ["far_members", "chromosome_edge", "end_of_annotation", "many_chunks"])
+def test_chunk_lists_at_their_limits(oracle, shape, pipeline):
+    """k_tile_chunk (l2r_tchunk.hip.h) takes a window in stretches of 63 CONSECUTIVE transcripts of the annotation's file order:
+    far_members        a locus whose 150 isoforms are written in two halves with 20 000 transcripts of LOWER coordinates between them (file
+                       order is arbitrary, src/update_gtf.c:796-822 walks it as it is): more stretches than the window scan looks at -- the
+                       tile's reads are the generic kernel's, results exact;
+    chromosome_edge    the isoform-rich locus is the last of its chromosome, the stretch that ends its window runs into the next chromosome's
+                       transcripts (behind every read) and a quiet locus there must stay untouched;
+    end_of_annotation  ... and the last of the annotation: the last stretch is cut short by the annotation's end;
+    many_chunks        400 isoforms around one another: seven stretches, the sweep's state carried through all of them."""
+    rng = np.random.default_rng(17)
+    pool = [(50_000 + 700 * k, 50_000 + 700 * k + 160) for k in range(24)]
+
+    def isoform(t):
+        keep = sorted(set([0, 23] + list(rng.choice(np.arange(1, 23), size=int(rng.integers(5, 16)), replace=False))))
+        return (0, t & 1, [pool[k] for k in keep])
+    n_iso = 400 if shape == "many_chunks" else 150
+    iso = [isoform(t) for t in range(n_iso)]
+    # (transcripts in front of the locus: all of them end below 50 000)
+    if shape == "far_members":
+        quiet0 = [(0, 0, [(1_000 + 2 * g, 1_000 + 2 * g + 1)]) for g in range(20_000)]
+    else:
+        quiet0 = [(0, 0, [(1_000 + 40 * g, 1_000 + 40 * g + 10), (1_000 + 40 * g + 20, 1_000 + 40 * g + 30)]) for g in range(50)]
+    quiet1 = [(1, 0, [(5_000 + 3_000 * g, 5_000 + 3_000 * g + 100), (5_000 + 3_000 * g + 500, 5_000 + 3_000 * g + 650)]) for g in range(100)]
+    if shape == "far_members":
+        txs = iso[:75] + quiet0 + iso[75:] + quiet1
+    elif shape == "end_of_annotation":
+        txs = quiet0 + iso                                  # (nothing behind the locus)
+    else:
+        txs = quiet0 + iso + quiet1
+    af = _anno(txs)
+    rows = []
+    for i in range(5000):
+        t = iso[int(rng.integers(n_iso))][2]
+        a = int(rng.integers(0, len(t) - 2))
+        ex = [list(x) for x in t[a:a + int(rng.integers(2, 9))]]
+        if i % 4 == 0:
+            ex[-1][1] -= int(rng.integers(0, 60))
+        if i % 7 == 0:
+            ex[0][0] += int(rng.integers(0, 60))
+        p, ops = _chain([tuple(x) for x in ex])
+        rows.append((0, p, i & 1, ops))
+    if shape not in ("end_of_annotation",):
+        for i in range(2000):
+            t = quiet1[int(rng.integers(len(quiet1)))][2]
+            p, ops = _chain(t)
+            rows.append((1, p, 0, ops))
+    cnt = [0, 0, 0, 0]
+    for level in (3, 5):
+        got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=level)
+        assert ((want.info & 2) != 0).sum() > 500
+        if pipeline == "tile" and shape != "far_members":
+            assert cnt[0] <= 256, cnt                       # (the isoform-rich tiles stay off the redo list)
+        if pipeline == "tile" and shape == "far_members":
+            assert cnt[0] >= 4000, cnt                      # (the window scan gives up: the locus' reads are the generic kernel's)
