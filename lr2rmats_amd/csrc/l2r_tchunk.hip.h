@@ -128,22 +128,38 @@ __device__ __forceinline__ ChunkVisit tc_visit(const int2 *s_se, const int4 *s_h
     ChunkVisit m{0ull, 0ull, 0ull, 0ull, false, false};
     if (!__any(work) || w_n <= 0) return m;
     uint32_t aft[2] = {0u, 0u}, bef[2] = {0u, 0u}, lm[2] = {0u, 0u}, rm[2] = {0u, 0u};
+    // A few members' headers are asked for together: left to itself the compiler puts every
+    // LDS read right in front of its use and waits for it there -- two exposed LDS latencies per member (measured: 200 cycles per member
+    // and wave, all of the pass).  The empty asm statements name the loaded registers: the loads cannot sink below them.
+    constexpr bool LR = LEVEL >= 1 && LEVEL <= 4;
+    constexpr int MB = 3;                                                     // members per block (4: 128 registers and 5 spilled; the 63 members of a chunk are 21 blocks of 3)
+    auto ask = [&](int j_top, int2 (&se)[MB], int4 (&hx)[MB]) {              // members j_top, j_top - 1, .. (clipped to 0: read, not used)
+#pragma unroll
+        for (int u = 0; u < MB; ++u) { const int j = max(j_top - u, 0); se[u] = s_se[j]; if (LR) hx[u] = s_hx[j]; }
+    };
+    auto take = [&](int half, int j_top, int j_lo, const int2 (&se)[MB], const int4 (&hx)[MB]) {
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+            if (j_top - u < j_lo) break;                                     // (wave-uniform)
+            shift_in_le(aft[half], re.el, se[u].x);                          // comp_trans <= (Q5): the read lies before the member
+            shift_in_le(bef[half], se[u].y, re.s0);                          // the member lies before the read
+            if (LEVEL == 1) { shift_in_eq(lm[half], re.e0, hx[u].y); shift_in_eq(rm[half], re.sl, hx[u].z); }
+            else if (LR) {
+                shift_in_le2(lm[half], re.s0, hx[u].y, hx[u].x, re.e0);      // closed_overlap(s0, e0, hx.x, hx.y)
+                if (LEVEL != 4) shift_in_le2(rm[half], re.sl, hx[u].w, hx[u].z, re.el);
+            }
+        }
+    };
 #pragma unroll
     for (int half = 1; half >= 0; --half) {
         const int j_hi = half ? TC_MEMBERS_PER - 1 : 31, j_lo = half ? 32 : 0;
-#pragma unroll 4
-        for (int j = j_hi; j >= j_lo; --j) {
-            const int2 hk = s_se[j];                                         // {start, end}: 8 bytes of the 16 the verdicts' header word has
-            shift_in_le(aft[half], re.el, hk.x);                          // comp_trans <= (Q5): the read lies before the member
-            shift_in_le(bef[half], hk.y, re.s0);                          // the member lies before the read
-            if (LEVEL >= 1 && LEVEL <= 4) {
-                const int4 hx = s_hx[j];
-                if (LEVEL == 1) { shift_in_eq(lm[half], re.e0, hx.y); shift_in_eq(rm[half], re.sl, hx.z); }
-                else {
-                    shift_in_le2(lm[half], re.s0, hx.y, hx.x, re.e0);     // closed_overlap(s0, e0, hx.x, hx.y)
-                    if (LEVEL != 4) shift_in_le2(rm[half], re.sl, hx.w, hx.z, re.el);
-                }
-            }
+        int2 seA[MB]; int4 hxA[MB];
+#pragma unroll
+        for (int u = 0; u < MB; ++u) hxA[u] = make_int4(0, 0, 0, 0);
+        for (int j = j_hi; j >= j_lo; j -= MB) {
+            ask(j, seA, hxA);
+            asm volatile("" :: "v"(seA[0].x), "v"(seA[1].x), "v"(seA[2].x), "v"(hxA[0].x), "v"(hxA[1].x), "v"(hxA[2].x));
+            take(half, j, j_lo, seA, hxA);
         }
     }
     const m64_t m_aft = ((m64_t)aft[1] << 32) | aft[0], m_bef = ((m64_t)bef[1] << 32) | bef[0];
