@@ -239,7 +239,9 @@ l2r_ctx *l2r_create(int device)
     //  fill in -- measured on cfg3_gencode: lowest 0.665, default 0.660, highest 0.658 ms: the dispatcher hardly cares.  L2R_SIDE_PRIO: 0 default, < 0 lowest)
     const int side_prio = !sp ? prio_hi : (atoi(sp) == 0 ? 0 : (atoi(sp) > 0 ? prio_hi : prio_lo));
     for (int k = 0; k < 2; ++k)
-        if ((e = hipStreamCreateWithPriority(&c->side[k], hipStreamNonBlocking, side_prio)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming)) != hipSuccess) {
+        if (((e = hipStreamCreateWithPriority(&c->side[k], hipStreamNonBlocking, side_prio)) != hipSuccess &&
+             ((void)hipGetLastError(), e = hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking)) != hipSuccess) ||      // (a runtime without stream priorities: a plain stream does)
+            (e = hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming)) != hipSuccess) {
             fail(-2, "[l2r_create] side stream: %s", hipGetErrorString(e)); l2r_destroy(c); return nullptr;
         }
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) { fail(-2, "[l2r_create] hipEventCreate: %s", hipGetErrorString(e)); l2r_destroy(c); return nullptr; }
