@@ -1786,7 +1786,7 @@ int l2r_classify(l2r_ctx *c, const l2r_reads *reads, l2r_result *res)
 {
     if (!c) return fail(-1, "[l2r_classify] null context");
     // ONE run follows this upload: by total GPU time the two-kernel (slab) pipeline wins that case -- measured on 10 M reads 0.62 ms against
-    // tile index + first run of the one-kernel path 0.68 ms (1.05 ms where the engine has to walk the CIGARs for the index itself); the
+    // tile index + first run of the one-kernel path 0.68 ms (0.80 ms where the engine has to walk the CIGARs for the index itself); the
     // one-kernel path pays off from the second run of an upload on (0.50 ms a run).  So this upload makes no tile index and its run takes
     // the slab pipeline (L2R_TILE_ANYWAY=1: index + tile path all the same).
     const bool was = c->one_shot_upload;

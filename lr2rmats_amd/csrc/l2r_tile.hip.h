@@ -102,10 +102,8 @@ void k_tile_index(TileRec *__restrict__ rec, TileStat *__restrict__ stat, SlotRe
             c_lo = cig_off32[r]; c = cig_off32[r + 1u] - c_lo; pos = r_pos[r]; rev = r_rev[r] ? 1u : 0u;
             end = pos;
             int seg = 0; bool first = true;
-            if (SUMMARY) n_n = (int)sum_nn[r];
-            else
-            for (uint32_t k = c_lo; k < c_lo + c; ++k) {
-                const uint32_t w = cig[k], op = w & 0xfu; const int len = (int)(w >> 4);
+            auto step = [&](uint32_t w) {
+                const uint32_t op = w & 0xfu; const int len = (int)(w >> 4);
                 if (op == 3u) {
                     ++n_n; min_n = min(min_n, len);
                     if (!first) min_seg = min(min_seg, seg);      // (the first exon is kept whatever its length)
@@ -115,6 +113,24 @@ void k_tile_index(TileRec *__restrict__ rec, TileStat *__restrict__ stat, SlotRe
                     seg += len & __builtin_amdgcn_sbfe(0x18d, op, 1u);
                 }
                 end += len & __builtin_amdgcn_sbfe(0x18d, op, 1u);
+            };
+            if (SUMMARY) n_n = (int)sum_nn[r];
+            else {
+                // (the head of the CIGAR as k_tile fetches it: six 16-byte vectors in flight at once, words behind the last op = "I, length 0";
+                //  one 4-byte load per op in a serial loop had every thread wait for each word: 0.42 ms for 10 M reads)
+                const uint32_t *const words = cig + c_lo;
+                uint32_t cg[SLAB_HEAD];
+#pragma unroll
+                for (int k = 0; k < SLAB_HEAD; ++k) cg[k] = 1u;
+#pragma unroll
+                for (int q = 0; q < SLAB_HEAD_VEC; ++q)
+                    if ((uint32_t)(4 * q) < c) {
+                        const v4i_a4 x = *reinterpret_cast<const v4i_a4 *>(words + 4 * q);
+                        cg[4 * q] = (uint32_t)x.x; cg[4 * q + 1] = (uint32_t)x.y; cg[4 * q + 2] = (uint32_t)x.z; cg[4 * q + 3] = (uint32_t)x.w;
+                    }
+#pragma unroll
+                for (int k = 0; k < SLAB_HEAD; ++k) if ((uint32_t)k < c) step(cg[k]);
+                for (uint32_t k = SLAB_HEAD; k < c; ++k) step(words[k]);
             }
         }
         // the read's place among the tile's exons in read order if every N operation is an intron and nothing is dropped
