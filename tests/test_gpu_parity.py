@@ -441,3 +441,31 @@ def test_annotation_table_cache(oracle, tmp_path):
     open(path, "wb").write(bytes(raw))
     assert run(af, reads, want) == 1                       # payload checksum
     assert run(af, reads, want) == 2
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(min_intron=66000), dict(max_delet=69000), dict(min_intron=70001, max_delet=70000, min_exon=19)])
+def test_summaries_at_their_saturation_limits(engine, oracle, opts):
+    """Summary fields saturate at 65535: an N or a D operation of 70 000 bases with thresholds on either side of it, a stretch of 18 bases against
+    -e 19 -- the tiles' exactness must come out on the safe side (a tile that might not be exact counts in k_tile), results as the oracle's."""
+    from lr2rmats_amd import synth
+    from tests.test_gpu_edges import _anno, _reads
+    M, D, N = 0, 2, 3
+    rows = []
+    for i in range(600):
+        base = 10_000 + 37 * i
+        rows.append((0, base, i & 1, [(50, M), (70000, N), (10, M), (8, M), (300, N), (40, M), (70000, D), (25, M), (65535, N), (30, M)]))
+        rows.append((0, base + 5, 0, [(60, M), (500, N), (18, M), (400, N), (33, M)]))
+    rows.sort(key=lambda r: (r[0], r[1]))
+    reads = _reads(rows)
+    af = _anno([(0, 0, [(10_001, 10_050), (80_051, 80_068)]), (0, 1, [(10_100, 10_200), (10_701, 10_718), (11_119, 11_151)])]).in_file_order()
+    _set_anno(engine, af)
+    op = oracle.default_params(full_level=3, **opts)
+    want = util.oracle_run(oracle, af, reads, op)
+    engine.set_junctions(None)
+    engine.set_params(util.to_engine_params(capi, op))
+    sm = synth.cigar_summary(reads.cig_off, reads.cig)
+    for summary in (sm, None):
+        engine.upload_reads(reads.tid, reads.pos, reads.rev, reads.cig_off, reads.cig, cig_summary=summary)
+        for _ in range(2):
+            engine.run(); engine.sync()
+            util.assert_same_result(engine.download(), want, 0, 0)

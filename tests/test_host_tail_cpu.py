@@ -350,3 +350,35 @@ def test_gtf_input_mode(oracle, tmp_path):
     for k in OUTS:
         assert filecmp.cmp(oo[k], ho[k], shallow=False), k
     assert os.path.getsize(oo["detail"]) > 50000 and "N_" in open(oo["detail"]).read(4000)
+
+
+def test_cigar_summaries_saturate_and_match_the_numpy_form():
+    """l2r_reads::cig_summary as host/aln_reader.c makes it (h_cigar_summaries) against synth.cigar_summary (numpy) on hand-made CIGARs at the
+    fields' limits: no N at all, N / D / stretches of 65535 and more (16-bit fields saturate), an empty CIGAR, clips and insertions
+    (they advance nothing), a stretch made of several ops, and against literal words for three of them."""
+    M, I, D, N, S, H, EQ, X = 0, 1, 2, 3, 4, 5, 7, 8
+
+    def cig(ops):
+        return [(l << 4) | o for l, o in ops]
+    reads = [
+        cig([(100, M)]),                                                        # no N: shortest N / stretch = 65535
+        cig([(50, M), (70000, N), (10, EQ), (5, X), (3, D), (65535, N), (20, M)]),      # N beyond and at 65535; stretch 10 + 5 + 3 = 18
+        cig([(5, S), (30, M), (4, I), (70000, D), (200, N), (8, M), (120, N), (9, M), (2, H)]),     # D beyond 65535; first stretch not counted: 8
+        [],                                                                     # empty
+        cig([(1, M), (1, N), (70000, M), (1, N), (1, M)]),                      # stretch beyond 65535
+    ]
+    off = np.zeros(len(reads) + 1, np.int64)
+    np.cumsum([len(r) for r in reads], out=off[1:])
+    flat = np.array([w for r in reads for w in r], np.uint32)
+    a = hostlib.cigar_summaries(off, flat)
+    b = synth.cigar_summary(off, flat)
+    np.testing.assert_array_equal(a, b)
+    assert list(a[0]) == [100, 0 | (65535 << 16), 0 | (65535 << 16)]
+    assert list(a[1]) == [50 + 70000 + 10 + 5 + 3 + 65535 + 20, 2 | (65535 << 16), 3 | (18 << 16)]
+    assert list(a[2]) == [30 + 70000 + 200 + 8 + 120 + 9, 2 | (120 << 16), 65535 | (8 << 16)]
+    assert list(a[3]) == [0, 0 | (65535 << 16), 0 | (65535 << 16)]
+    assert list(a[4]) == [70004, 2 | (1 << 16), 0 | (65535 << 16)]
+    # and on random ONT-like records
+    anno = synth.make_annotation(3000, 5)
+    r = synth.make_reads(anno, 2000, 6, 5, ont=True, micro_exons=2)
+    np.testing.assert_array_equal(hostlib.cigar_summaries(r.cig_off, r.cig), synth.cigar_summary(r.cig_off, r.cig))
