@@ -186,7 +186,16 @@ __device__ __forceinline__ ChunkVisit tc_visit(const int2 *s_se, const int4 *s_h
 // map_exons_lds64 (l2r_chunk.hip.h) with the lookups done: per exon the ORs over the parts its word names.  The first two parts of both
 // keys are read without a loop (four independent 16-byte reads in flight; a part that is not there is read and not used), the next
 // exon's word is asked for before this exon's masks are looked at.
-__device__ __forceinline__ SiteMasks64 tc_map_exons(const TcLds &L, bool mapping, uint32_t *Ap, const uint32_t *Rp, uint32_t n, m64_t vpre)
+// pend: the read swept the chunk before this one and goes on (not known there): that chunk's work words, still in the row words, clear
+// the novel flags of the exons / junctions / sites one of its visited members had -- here, where both words pass by anyway (a loop
+// of its own behind the carried state cost 4% of the kernel).
+__device__ __forceinline__ uint32_t tc_flag_clears(uint32_t w, uint32_t lim, bool sites)
+{
+    uint32_t clr = ((w & 63u) <= lim ? (uint32_t)F_EXON : 0u) | (((w >> 6) & 63u) <= lim ? (uint32_t)F_JUNC : 0u);
+    if (sites) clr |= (((w >> 12) & 1u) ? (uint32_t)F_DON : 0u) | (((w >> 13) & 1u) ? (uint32_t)F_ACC : 0u);
+    return clr << TC_F_SHIFT;
+}
+__device__ __forceinline__ SiteMasks64 tc_map_exons(const TcLds &L, bool mapping, bool pend, uint32_t *Ap, uint32_t *Rp, uint32_t n, m64_t vpre)
 {
     SiteMasks64 m{~0ull, 0ull, 0ull, 0ull, 0ull};
     const int k_max = wave_max(mapping ? (int)n : 0);
@@ -215,7 +224,11 @@ __device__ __forceinline__ SiteMasks64 tc_map_exons(const TcLds &L, bool mapping
         m.kor |= amj | dm;
         if (k == 0) m.dm_first = dm;
         m.am_last = (live && !junc) ? am : m.am_last;
-        if (live) Ap[k] = (Ap[k] & SLAB_REL_MASK) | (word << SLAB_REL_BITS);
+        if (live) {
+            const uint32_t A = Ap[k];
+            if (pend) { const uint32_t clr = tc_flag_clears(A >> SLAB_REL_BITS, 62u, true); if (R & clr) Rp[k] = R & ~clr; }      // (63 = no member)
+            Ap[k] = (A & SLAB_REL_MASK) | (word << SLAB_REL_BITS);
+        }
         R = Rn;
     }
     return m;
@@ -453,6 +466,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
     __builtin_amdgcn_s_setprio(0);
     bool known = false, stopped = false, ksite = false, lfull = false, rfull = false, lnoth = true, rnoth = true, out_rev = rev_in;
     int ref = -1;
+    bool pend = false; uint32_t lim_last = 62u;
     const TcLds L{key0, key1, s_msk, s_msk + TC_ST_CAP, s_dir0, s_dir1, s_rdir, s_hk, s_hx};
     const TxHdr *const hdr = a->f.hdr;
     // (the headers of the chunk's transcripts: thread j < 63 asks for transcript cb + j one chunk ahead)
@@ -500,7 +514,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
         redo = redo || vm.redo;
         stamp.mark(4);
         const bool mapping = work && !vm.redo && n > 1 && !(ablate & 4096);
-        const SiteMasks64 sm = tc_map_exons(L, mapping, Ap, Rp, n, vm.vpre);
+        const SiteMasks64 sm = tc_map_exons(L, mapping, pend, Ap, Rp, n, vm.vpre);
         stamp.mark(5);
         if (work && !vm.redo) {
             int jstar = -1;
@@ -533,15 +547,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
                     else if (V) rnoth = (tc_overlapping_exon_members(L, d.b_off, d.nb, re.sl, re.el) & V) == 0ull;
                 }
             }
-            if (n > 1) {
-                const uint32_t lim = known_c ? (uint32_t)jstar : 62u;                   // (63 = no member)
-                for (int k = 0; k < (int)n; ++k) {
-                    const uint32_t w = Ap[k] >> SLAB_REL_BITS;
-                    uint32_t clr = ((w & 63u) <= lim ? (uint32_t)F_EXON : 0u) | (((w >> 6) & 63u) <= lim ? (uint32_t)F_JUNC : 0u);
-                    if (!known_c) clr |= (((w >> 12) & 1u) ? (uint32_t)F_DON : 0u) | (((w >> 13) & 1u) ? (uint32_t)F_ACC : 0u);
-                    Rp[k] &= ~(clr << TC_F_SHIFT);
-                }
-            }
+            pend = n > 1; lim_last = known_c ? (uint32_t)jstar : 62u;      // (this chunk's flag clears: tc_map_exons of the next chunk, or the verdicts)
             known = known_c;
             stopped = vm.stopped;
         }
@@ -557,7 +563,9 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
     if (work0 && !redo) {
         if (n > 1) {
             for (int k = 0; k < (int)n; ++k) {
-                uint32_t f = Rp[k] >> TC_F_SHIFT;
+                uint32_t f = Rp[k];
+                if (pend) f &= ~tc_flag_clears(Ap[k] >> SLAB_REL_BITS, lim_last, !known);       // (the last chunk this read swept)
+                f >>= TC_F_SHIFT;
                 if (known) f &= ~(uint32_t)(F_DON | F_ACC);                             // (every site of a known read is its transcript's)
                 f &= (k + 1 == (int)n) ? (uint32_t)F_EXON : 0xffu;                      // the last exon has no junction behind it
                 Ap[k] = (Ap[k] & SLAB_REL_MASK) | (f << SLAB_REL_BITS);
