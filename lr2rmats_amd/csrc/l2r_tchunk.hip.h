@@ -48,59 +48,61 @@ constexpr uint32_t TC_ROW_FIRST = 1u << 30, TC_ROW_LAST = 1u << 31;      // row 
 constexpr uint32_t TC_HALF_MASK = (1u << TC_HALF_BITS) - 1u;
 
 struct TcMask { m64_t pm, sm; };                         // a staged entry's masks in the chunk's frame (bit j = transcript chunk base + j)
-struct TcLds { const int2 *key0, *key1; const TcMask *msk0, *msk1; const uint16_t *dir0, *dir1, *rdir; const int4 *hk, *hx; };
+struct TcLds { const unsigned long long *key0, *key1; const TcMask *msk0, *msk1; const uint16_t *dir0, *dir1, *rdir; const int4 *hk, *hx; };
 
 // The two lookups of one exon in the tile's key staging (once per tile): START key (start, end) and END key (end, next start).  Per
 // key: the parts of the pair (k1, k2) if the dictionary has it, else the parts of the first pair with key 1 (their single masks cover
 // every transcript with that site: build_dict walks a pair's parts until both member lists are through).  The entries of a bucket are
-// sorted by (key 1, key 2), a pair's parts lie side by side: lower bounds, BOTH dictionaries' in one loop (two independent LDS reads in
-// flight per step -- the kernel is bound by such dependent chains; a scan of the bucket took one read per entry), a second search only
-// where a pair is missing.  Half word: first part (9 bits) | parts (4 bits) << 9 | "the pair matches" << 13; 0 = nothing.
-// over: more than 15 parts (the read goes to the generic kernel).
-struct TcKey { const int2 *key; const uint16_t *dir; };
-__device__ __forceinline__ uint32_t tc_parts(const int2 *key, uint32_t base, uint32_t hi, bool found, bool pair, int2 kb, bool &over)
+// sorted by (key 1, key 2), a pair's parts lie side by side.  The kernel is bound by its VECTOR INSTRUCTIONS (6.8 k per wave, four
+// waves per SIMD), so a staged key is ONE 64-bit word key 1 << 32 | key 2 (coordinates are not negative: l2r_set_annotation) and a
+// step of the lower bound one 64-bit compare; both dictionaries' searches run in one loop (two independent LDS reads in flight).
+// Behind the lower bound l, ONE round of six reads per dictionary says the rest: the entries l .. l+2 (the pair and its parts, or --
+// nothing in front with key 1 -- the first pair with key 1 behind it) and l-1 .. l-3 (the entries with key 1 and a smaller key 2: the
+// first of them is the first pair with key 1).  Longer runs take a loop (rare).  A second search for the first entry with key 1 cost
+// four more dependent steps for every wave in which one lane's pair was missing.
+// Half word: first part (9 bits) | parts (4 bits) << 9 | "the pair matches" << 13; 0 = nothing.  over: more than 15 parts (the read
+// goes to the generic kernel).
+typedef unsigned long long tckey_t;
+__device__ __forceinline__ tckey_t tc_key(int32_t k1, int32_t k2) { return ((tckey_t)(uint32_t)k1 << 32) | (tckey_t)(uint32_t)k2; }
+__device__ __forceinline__ uint32_t tc_k1(tckey_t v) { return (uint32_t)(v >> 32); }
+struct TcKey { const tckey_t *key; const uint16_t *dir; };
+__device__ __forceinline__ uint32_t tc_half(const tckey_t *key, uint32_t lo, uint32_t hi, uint32_t l, tckey_t T, bool &over)
 {
-    if (!found) return 0u;
-    // the pair's parts: the entries behind it with its keys (three asked for at once; more is rare)
-    uint32_t cnt = 1u;
-    for (uint32_t r = base + 1u; r < hi; r += 3u) {
-        const int2 q0 = key[r], q1 = key[min(r + 1u, hi - 1u)], q2 = key[min(r + 2u, hi - 1u)];
-        const bool e0 = q0.x == kb.x && q0.y == kb.y, e1 = e0 && r + 1u < hi && q1.x == kb.x && q1.y == kb.y, e2 = e1 && r + 2u < hi && q2.x == kb.x && q2.y == kb.y;
-        cnt += (e0 ? 1u : 0u) + (e1 ? 1u : 0u) + (e2 ? 1u : 0u);
-        if (!e2) break;
+    const uint32_t k1 = tc_k1(T);
+    const int li = (int)l;                               // (three words in front of the staging and two behind it may be read: not used)
+    const tckey_t f0 = key[li], f1 = key[li + 1], f2 = key[li + 2], g1 = key[li - 1], g2 = key[li - 2], g3 = key[li - 3];
+    const bool at = l < hi && tc_k1(f0) == k1, pair = at && f0 == T;
+    const bool p1 = at && l + 1u < hi && f1 == f0, p2 = p1 && l + 2u < hi && f2 == f0;
+    const bool b1 = !pair && l > lo && tc_k1(g1) == k1, b2 = b1 && l - 1u > lo && tc_k1(g2) == k1, b3 = b2 && l - 2u > lo && tc_k1(g3) == k1;
+    const bool q1 = b3 ? g2 == g3 : (b2 && g1 == g2), q2 = b3 && q1 && g1 == g3;           // the run of the first entry in front
+    uint32_t base = b1 ? l - (1u + (b2 ? 1u : 0u) + (b3 ? 1u : 0u)) : l;
+    uint32_t cnt = b1 ? 1u + (q1 ? 1u : 0u) + (q2 ? 1u : 0u) : 1u + (p1 ? 1u : 0u) + (p2 ? 1u : 0u);
+    const bool found = b1 || at;
+    const bool slow = b3 || (!b1 && p2);                 // maybe more in front / more parts
+    if (__any(slow)) {
+        if (slow) {
+            while (b1 && base > lo && tc_k1(key[(int)base - 1]) == k1) --base;
+            const tckey_t kb = key[base];
+            cnt = 1u;
+            while (base + cnt < hi && key[base + cnt] == kb) ++cnt;
+            if (cnt > 15u) { over = true; cnt = 15u; }
+        }
     }
-    if (cnt > 15u) { over = true; cnt = 15u; }
-    return base | (cnt << 9) | (pair ? 1u << 13 : 0u);
+    return found ? base | (cnt << 9) | (pair ? 1u << 13 : 0u) : 0u;
 }
 __device__ __forceinline__ uint32_t tc_lookup2(const TcKey &K0, const TcKey &K1, int b_off, uint32_t none, bool on0, bool on1, int32_t s, int32_t e, int32_t s2, bool &over)
 {
     const uint32_t ib0 = on0 ? min((uint32_t)((s >> SITE_SHIFT) + b_off), none) : none, ib1 = on1 ? min((uint32_t)((e >> SITE_SHIFT) + b_off), none) : none;
     const uint32_t lo0 = K0.dir[ib0], hi0 = K0.dir[ib0 + 1u], lo1 = K1.dir[ib1], hi1 = K1.dir[ib1 + 1u];
+    const tckey_t T0 = tc_key(s, e), T1 = tc_key(e, s2);
     uint32_t l0 = lo0, h0 = hi0, l1 = lo1, h1 = hi1;
     while (l0 < h0 || l1 < h1) {
         const uint32_t m0 = (l0 + h0) >> 1, m1 = (l1 + h1) >> 1;
-        const int2 q0 = K0.key[m0], q1 = K1.key[m1];           // (an empty range reads an entry of the staging or the word behind it: not used)
-        const bool less0 = q0.x < s || (q0.x == s && q0.y < e), less1 = q1.x < e || (q1.x == e && q1.y < s2);
+        const bool less0 = K0.key[m0] < T0, less1 = K1.key[m1] < T1;           // (an empty range reads an entry of the staging or the word behind it: not used)
         if (l0 < h0) { l0 = less0 ? m0 + 1u : l0; h0 = less0 ? h0 : m0; }
         if (l1 < h1) { l1 = less1 ? m1 + 1u : l1; h1 = less1 ? h1 : m1; }
     }
-    int2 kb0 = K0.key[l0], kb1 = K1.key[l1];
-    bool pair0 = l0 < hi0 && kb0.x == s && kb0.y == e, pair1 = l1 < hi1 && kb1.x == e && kb1.y == s2;
-    bool found0 = pair0, found1 = pair1;
-    uint32_t base0 = l0, base1 = l1;
-    if ((!pair0 && lo0 < hi0) || (!pair1 && lo1 < hi1)) {
-        // (the first entry with key 1: in front of the place the pair would have)
-        uint32_t a0 = lo0, b0 = pair0 ? lo0 : l0, a1 = lo1, b1 = pair1 ? lo1 : l1;
-        while (a0 < b0 || a1 < b1) {
-            const uint32_t m0 = (a0 + b0) >> 1, m1 = (a1 + b1) >> 1;
-            const bool less0 = K0.key[m0].x < s, less1 = K1.key[m1].x < e;
-            if (a0 < b0) { a0 = less0 ? m0 + 1u : a0; b0 = less0 ? b0 : m0; }
-            if (a1 < b1) { a1 = less1 ? m1 + 1u : a1; b1 = less1 ? b1 : m1; }
-        }
-        if (!pair0) { base0 = a0; kb0 = K0.key[a0]; found0 = a0 < hi0 && kb0.x == s; }
-        if (!pair1) { base1 = a1; kb1 = K1.key[a1]; found1 = a1 < hi1 && kb1.x == e; }
-    }
-    return tc_parts(K0.key, base0, hi0, found0, pair0, kb0, over) | (tc_parts(K1.key, base1, hi1, found1, pair1, kb1, over) << TC_HALF_BITS);
+    return tc_half(K0.key, lo0, hi0, l0, T0, over) | (tc_half(K1.key, lo1, hi1, l1, T1, over) << TC_HALF_BITS);
 }
 
 // overlapping_exon_members64 (l2r_wide.hip.h) on the split key / mask arrays
@@ -112,8 +114,8 @@ __device__ __forceinline__ m64_t tc_overlapping_exon_members(const TcLds &L, int
     m64_t m = 0ull;
     const uint32_t i1 = L.dir0[be + b_off + 1];
     for (uint32_t i = L.rdir[bs + b_off]; i < i1; ++i) {
-        const int2 q = L.key0[i];
-        if (q.x <= e && q.y >= s) m |= L.msk0[i].pm;
+        const unsigned long long q = L.key0[i];
+        if ((int)(uint32_t)(q >> 32) <= e && (int)(uint32_t)q >= s) m |= L.msk0[i].pm;
     }
     return m;
 }
@@ -234,7 +236,7 @@ __device__ __forceinline__ SiteMasks64 tc_map_exons(const TcLds &L, bool mapping
     return m;
 }
 
-constexpr int TC_LDS_BYTES = TILE_POS_CAP * (4 + 2 + 4) + TC_ST_CAP * 8 + (TC_ENT_POOL + 2) * 16 + 3 * TC_DIR_N * 2 + 2 * 64 * 16 + 64 * 8 + TC_TRIPS + TC_CHUNKS * 2 + 64;
+constexpr int TC_LDS_BYTES = TILE_POS_CAP * (4 + 2 + 4) + (TC_ST_CAP + 6) * 8 + (TC_ENT_POOL + 2) * 16 + 3 * TC_DIR_N * 2 + 2 * 64 * 16 + 64 * 8 + TC_TRIPS + TC_CHUNKS * 2 + 64;
 static_assert(TC_LDS_BYTES <= 40960, "k_tile_chunk: 4 workgroups per CU need 80 allocation granules of 512 bytes at most");
 
 template <int LEVEL>
@@ -246,7 +248,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
     __shared__ __attribute__((aligned(16))) uint32_t s_A[TILE_POS_CAP];          // row words: start - base | the chunk's work word << 18 (at the end: | flag byte << 18)
     __shared__ __attribute__((aligned(16))) uint16_t s_L[TILE_POS_CAP];          // lengths
     __shared__ __attribute__((aligned(16))) uint32_t s_R[TILE_POS_CAP];          // lookup words (tc_lookup): START | END << 14 | novel flags still standing << 28
-    __shared__ __attribute__((aligned(16))) int2 s_key0[TC_ST_CAP];              // START keys (the full-length evidence asks them in every chunk)
+    __shared__ __attribute__((aligned(16))) tckey_t s_key0_[TC_ST_CAP + 6];         // START keys, key 1 << 32 | key 2 (the full-length evidence asks them in every chunk); four words in front, two behind: tc_half
     // the entries' masks in the chunk's frame, START entries first; until the first chunk the END entries' KEYS live in the END part (the
     // lookups are through before a mask is written); two entries more: a part that is not there may be read
     __shared__ __attribute__((aligned(16))) TcMask s_msk[TC_ENT_POOL + 2];
@@ -257,7 +259,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
     __shared__ uint16_t s_chunk[TC_CHUNKS];
     __shared__ m64_t s_mask[2];
     __shared__ uint32_t s_lb[4], s_nchunk, s_bad;
-    int2 *const s_key1 = reinterpret_cast<int2 *>(s_msk + TC_ST_CAP);
+    tckey_t *const s_key0 = s_key0_ + 4, *const s_key1 = reinterpret_cast<tckey_t *>(s_msk + TC_ST_CAP);
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
     const PipeArgsK a = pipe_args();
@@ -316,7 +318,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
         if (e < n_ent) {
             const int4 *const qv = reinterpret_cast<const int4 *>(e < d.st_nk ? a->f.st.ent + d.st_r0 + e : a->f.en.ent + d.en_r0 + (e - d.st_nk));
             const int4 xa = qv[0], xb = qv[1];
-            if (e < d.st_nk) s_key0[e] = make_int2(xa.x, xa.y); else s_key1[e - d.st_nk] = make_int2(xa.x, xa.y);
+            if (e < d.st_nk) s_key0[e] = tc_key(xa.x, xa.y); else s_key1[e - d.st_nk] = tc_key(xa.x, xa.y);
             e_base[u] = xa.z;
             e_pm[u] = ((m64_t)(uint32_t)xb.y << 32) | (uint32_t)xb.x; e_sm[u] = ((m64_t)(uint32_t)xb.w << 32) | (uint32_t)xb.z;
         }
@@ -442,7 +444,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
     bool redo = active && (big || (n > 1 && !sane));
     const bool work0 = active && !redo;
     const uint32_t none = (uint32_t)d.nbk + 1u;
-    const int2 *const key0 = s_key0, *const key1 = s_key1;
+    const tckey_t *const key0 = s_key0, *const key1 = s_key1;
     {
         const TcKey K0{key0, s_dir0}, K1{key1, s_dir1};
         for (uint32_t q = threadIdx.x; q < total; q += (uint32_t)TILE_THREADS) {
