@@ -47,6 +47,13 @@ constexpr uint32_t TC_R_OVER = 1u << 13;                 // "the pair matches" w
 constexpr uint32_t TC_ROW_FIRST = 1u << 30, TC_ROW_LAST = 1u << 31;      // row word, until the first chunk's work words: the exon begins / ends its read
 constexpr uint32_t TC_HALF_MASK = (1u << TC_HALF_BITS) - 1u;
 
+// A chunk's members by their FIRST exon and by their LAST exon (the full-length evidence of levels 1-4 compares the read's terminal
+// exons with them): the isoforms of a locus share few terminal exons (measured: 6 + 8 distinct ones per 63 transcripts on cfg3_iso100,
+// 10 + 11 on cfg3_iso40, 30 + 30 where a stretch spans several genes), so a read tests each distinct exon once and ORs the mask of
+// the members that have it -- 7 vector instructions per group instead of 7 per member.  Wave 0 groups the staged headers per chunk
+// (one ballot per distinct exon); more than TC_GROUPS of a kind: the member pass compares member by member as before.
+constexpr int TC_GROUPS = 24;
+struct TcGroup { int2 key; m64_t members; };               // 16 bytes; first exons at [0, TC_GROUPS), last exons behind them
 struct TcMask { m64_t pm, sm; };                         // a staged entry's masks in the chunk's frame (bit j = transcript chunk base + j)
 struct TcLds { const unsigned long long *key0, *key1; const TcMask *msk0, *msk1; const uint16_t *dir0, *dir1, *rdir; const int4 *hk, *hx; };
 
@@ -125,7 +132,8 @@ __device__ __forceinline__ m64_t tc_overlapping_exon_members(const TcLds &L, int
 // members 0 .. 31 and 32 .. 62 are collected in two 32-bit words, highest member first, each predicate by ONE compare and ONE
 // add-with-carry (m = m + m + predicate) -- 10 vector instructions per member at level 3 where the 64-bit select-and-or form takes 24.
 template <int LEVEL>
-__device__ __forceinline__ ChunkVisit tc_visit(const int2 *s_se, const int4 *s_hx, int w_n, bool work, uint32_t n, const ReadEnds &re, const m64_t *tilemask)
+__device__ __forceinline__ ChunkVisit tc_visit(const int2 *s_se, const int4 *s_hx, const TcGroup *s_grp, uint32_t n_grp /* first | last << 8; 0xffff: member by member */,
+                                              int w_n, bool work, uint32_t n, const ReadEnds &re, const m64_t *tilemask)
 {
     ChunkVisit m{0ull, 0ull, 0ull, 0ull, false, false};
     if (!__any(work) || w_n <= 0) return m;
@@ -152,6 +160,49 @@ __device__ __forceinline__ ChunkVisit tc_visit(const int2 *s_se, const int4 *s_h
             }
         }
     };
+    const bool grouped = LR && n_grp != 0xffffu;                              // (wave-uniform)
+    if (grouped) {
+        // before / behind member by member (the staged {start, end} pairs alone; the next block's pairs are in flight), the terminal
+        // exons group by group (a group's 16 bytes in two reads, four groups asked for at once; `&`, not `&&`: the compiler turns a
+        // short-circuit into a branch around the second key's LDS read)
+#pragma unroll
+        for (int half = 1; half >= 0; --half) {
+            const int j_hi = half ? TC_MEMBERS_PER - 1 : 31, j_lo = half ? 32 : 0;
+            int2 se[MB], sn[MB];
+#pragma unroll
+            for (int u = 0; u < MB; ++u) se[u] = s_se[max(j_hi - u, 0)];
+            for (int j = j_hi; j >= j_lo; j -= MB) {
+#pragma unroll
+                for (int u = 0; u < MB; ++u) sn[u] = s_se[max(j - MB - u, 0)];
+                asm volatile("" :: "v"(se[0].x), "v"(se[1].x), "v"(se[2].x), "v"(sn[0].x), "v"(sn[1].x), "v"(sn[2].x));
+#pragma unroll
+                for (int u = 0; u < MB; ++u) {
+                    if (j - u < j_lo) break;
+                    shift_in_le(aft[half], re.el, se[u].x);
+                    shift_in_le(bef[half], se[u].y, re.s0);
+                }
+#pragma unroll
+                for (int u = 0; u < MB; ++u) se[u] = sn[u];
+            }
+        }
+        const int n1 = (int)(n_grp & 0xffu), n2 = LEVEL == 4 ? 0 : (int)(n_grp >> 8);
+        constexpr int GB = 4;
+        auto groups = [&](const TcGroup *grp, bool first_kind, int cnt, int qa, int qb, uint32_t (&acc)[2]) {      // the read's terminal exon [qa, qb]
+            for (int g0 = 0; g0 < cnt; g0 += GB) {
+                int2 k[GB]; uint2 mm[GB];
+#pragma unroll
+                for (int u = 0; u < GB; ++u) { const TcGroup *q = grp + min(g0 + u, TC_GROUPS - 1); k[u] = q->key; mm[u] = *reinterpret_cast<const uint2 *>(&q->members); }
+                asm volatile("" :: "v"(k[0].x), "v"(k[1].x), "v"(k[2].x), "v"(k[3].x), "v"(mm[0].x), "v"(mm[1].x), "v"(mm[2].x), "v"(mm[3].x));
+#pragma unroll
+                for (int u = 0; u < GB; ++u) {
+                    const bool c = (g0 + u < cnt) & (LEVEL == 1 ? (first_kind ? qb == k[u].y : qa == k[u].x) : ((qa <= k[u].y) & (k[u].x <= qb)));
+                    acc[0] |= c ? mm[u].x : 0u; acc[1] |= c ? mm[u].y : 0u;
+                }
+            }
+        };
+        groups(s_grp, true, n1, re.s0, re.e0, lm);
+        groups(s_grp + TC_GROUPS, false, n2, re.sl, re.el, rm);
+    } else {
 #pragma unroll
     for (int half = 1; half >= 0; --half) {
         const int j_hi = half ? TC_MEMBERS_PER - 1 : 31, j_lo = half ? 32 : 0;
@@ -163,6 +214,7 @@ __device__ __forceinline__ ChunkVisit tc_visit(const int2 *s_se, const int4 *s_h
             asm volatile("" :: "v"(seA[0].x), "v"(seA[1].x), "v"(seA[2].x), "v"(hxA[0].x), "v"(hxA[1].x), "v"(hxA[2].x));
             take(half, j, j_lo, seA, hxA);
         }
+    }
     }
     const m64_t m_aft = ((m64_t)aft[1] << 32) | aft[0], m_bef = ((m64_t)bef[1] << 32) | bef[0];
     m.lmask = ((m64_t)lm[1] << 32) | lm[0]; m.rmask = ((m64_t)rm[1] << 32) | rm[0];
@@ -258,7 +310,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
     __shared__ __attribute__((aligned(16))) uint8_t s_trip[TC_TRIPS];                                         // per stretch: 1 has a member | 2 the sweeps end in it
     __shared__ uint16_t s_chunk[TC_CHUNKS];
     __shared__ m64_t s_mask[2];
-    __shared__ uint32_t s_lb[4], s_nchunk, s_bad;
+    __shared__ uint32_t s_lb[4], s_nchunk, s_bad, s_ngrp[2];
     tckey_t *const s_key0 = s_key0_ + 4, *const s_key1 = reinterpret_cast<tckey_t *>(s_msk + TC_ST_CAP);
     (void)kernarg_block;
     const SlabArgsK sa = slab_args();
@@ -470,6 +522,9 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
     int ref = -1;
     bool pend = false; uint32_t lim_last = 62u;
     const TcLds L{key0, key1, s_msk, s_msk + TC_ST_CAP, s_dir0, s_dir1, s_rdir, s_hk, s_hx};
+    // (the END directory is through with the lookups: the chunks' terminal-exon groups live there)
+    static_assert(2 * TC_GROUPS * (int)sizeof(TcGroup) <= TC_DIR_N * 2 && (TC_DIR_N * 2) % 8 == 0, "the groups take the END directory's place");
+    TcGroup *const s_grp = reinterpret_cast<TcGroup *>(s_dir1);
     const TxHdr *const hdr = a->f.hdr;
     // (the headers of the chunk's transcripts: thread j < 63 asks for transcript cb + j one chunk ahead)
     int4 h0 = make_int4(0, 0, 0, 0), h1 = h0, h2 = h0;
@@ -478,6 +533,11 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
             const int j = d.j_lo + (int)s_chunk[ci] * TC_MEMBERS_PER + (int)threadIdx.x;
             if (j < n_tx) { const int4 *hp = reinterpret_cast<const int4 *>(hdr + j); h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; }
             else { h0 = make_int4(INT32_MAX, 0, 0, 0); h1 = make_int4(2, 0, TX_COMPACT, 0); h2 = make_int4(0, 0, 0, 0); }      // (behind the annotation: another chromosome, behind every read)
+        }
+        // (wave 1 groups the members by their last exon while wave 0 groups them by their first: it asks for the terminal exons as well)
+        if (LEVEL >= 1 && LEVEL <= 3 && ci < n_chunk && wv == 1 && lane < TC_MEMBERS_PER) {
+            const int j = d.j_lo + (int)s_chunk[ci] * TC_MEMBERS_PER + lane;
+            h2 = j < n_tx ? reinterpret_cast<const int4 *>(hdr + j)[2] : make_int4(0, 0, 0, 0);
         }
     };
     if (!bad) ask_headers(0u);
@@ -497,6 +557,33 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
             const unsigned long long b1 = __ballot(single), b2 = __ballot(loose);
             if (lane == 0) { s_mask[0] = b1; s_mask[1] = b2; }
         }
+        // the members by first exon (wave 0) and by last exon (wave 1), TcGroup: one ballot per distinct exon.  The loop runs in one wave
+        // while the others wait at the barrier below: one 64-bit compare per step, its lane mask taken as it is; a member only notes
+        // its group's number -- the groups' words are written behind the loop, by the members (LDS atomics for the masks)
+        if (LEVEL >= 1 && LEVEL <= 4 && wv < (LEVEL == 4 ? 1 : 2)) {
+            if (ablate & 131072) { if (lane == 0) s_ngrp[wv] = 0xffu; }
+            else {
+                __builtin_amdgcn_s_setprio(3);
+                TcGroup *const grp = s_grp + wv * TC_GROUPS;
+                unsigned long long rem = __ballot(lane < w_n);
+                const int kx = wv ? h2.z : h2.x, ky = wv ? h2.w : h2.y;
+                const unsigned long long key = ((unsigned long long)(uint32_t)ky << 32) | (uint32_t)kx;
+                uint32_t mine = 0u, g = 0u;
+                while (rem != 0ull && g < (uint32_t)TC_GROUPS) {
+                    const int ld = __builtin_ctzll(rem);
+                    const unsigned long long v = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(ky, ld) << 32) | (uint32_t)__builtin_amdgcn_readlane(kx, ld);
+                    const unsigned long long same = __builtin_amdgcn_uicmpl(key, v, 32) & rem;      // (32: equal)
+                    mine = ((same >> lane) & 1ull) ? g : mine;
+                    rem &= ~same; ++g;
+                }
+                if (rem == 0ull) {
+                    if (lane < TC_GROUPS) grp[lane].members = 0ull;
+                    if (lane < w_n) { grp[mine].key = make_int2(kx, ky); atomicOr(&grp[mine].members, 1ull << lane); }      // (every member of a group writes the same pair)
+                }
+                if (lane == 0) s_ngrp[wv] = rem != 0ull ? 0xffu : g;
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
         // this thread's entries in the chunk's frame
         const m64_t keepm = w_n >= 64 ? ~0ull : ((1ull << w_n) - 1ull);
 #pragma unroll
@@ -512,7 +599,9 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
         stamp.mark(3);
         ask_headers(ci + 1u);
         const bool work = work0 && !redo && !known && !stopped;
-        const ChunkVisit vm = tc_visit<LEVEL>(s_se, s_hx, (ablate & 8192) ? 0 : w_n, work, n, re, s_mask);
+        const uint32_t ng1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ngrp[0]), ng2 = LEVEL == 4 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ngrp[1]);
+        const uint32_t n_grp = ((ablate & 65536) || ng1 == 0xffu || ng2 == 0xffu) ? 0xffffu : (ng1 | (ng2 << 8));      // (bit 16: member by member)
+        const ChunkVisit vm = tc_visit<LEVEL>(s_se, s_hx, s_grp, n_grp, (ablate & 8192) ? 0 : w_n, work, n, re, s_mask);
         redo = redo || vm.redo;
         stamp.mark(4);
         const bool mapping = work && !vm.redo && n > 1 && !(ablate & 4096);

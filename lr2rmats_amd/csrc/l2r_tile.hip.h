@@ -331,7 +331,7 @@ __device__ __forceinline__ SlabVerdict tile_classify(PipeArgsK a, const TileDesc
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const bool fast = (d.flags & TD_FAST) != 0;
-    const int w_n = fast ? (int)d.n_win : 0;
+    const int w_n = (fast && !(a->f.p.ablate & 8192)) ? (int)d.n_win : 0;          // (bits 12, 13: timing diagnostics -- no probe rounds, no member pass; results wrong)
     const uint32_t n = pre >> PRE_N_SHIFT;
     const bool rev_in = (pre & PRE_REV) != 0u;
     uint32_t info = n << 8; int ref = -1;
@@ -341,7 +341,7 @@ __device__ __forceinline__ SlabVerdict tile_classify(PipeArgsK a, const TileDesc
     const VisitMasks vm = visit_window<LEVEL>(L, d, w_n, work, n, d.j_lo, re, tilemask);
     redo = redo || vm.redo;
     stamp.mark(2);
-    const bool mapping = work && !redo && n > 1;
+    const bool mapping = work && !redo && n > 1 && !(a->f.p.ablate & 4096);
     const SiteMasks sm = map_exons_lds<DIS>(L, d, mapping, n, vm.vpre, st, DIS ? a->f.p.ss_dis : 0, re.s0, re.el);
     stamp.mark(3);
     if (active && !mapping) {
