@@ -475,7 +475,7 @@ __device__ __forceinline__ SlabVerdict tile_classify_wide(PipeArgsK a, const Til
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const bool fast = (d.flags & TD_WIDE) != 0;
-    const int w_n = fast ? (int)d.n_win : 0;
+    const int w_n = (fast && !(a->f.p.ablate & 8192)) ? (int)d.n_win : 0;          // (bits 12, 13: timing diagnostics as in tile_classify)
     const uint32_t n = pre >> PRE_N_SHIFT;
     const bool rev_in = (pre & PRE_REV) != 0u;
     uint32_t info = n << 8; int ref = -1;
@@ -483,7 +483,7 @@ __device__ __forceinline__ SlabVerdict tile_classify_wide(PipeArgsK a, const Til
     const bool work = active && !redo;
     const VisitMasks64 vm = visit_window64<LEVEL>(L, d, w_n, work, n, d.j_lo, re, tilemask);
     redo = redo || vm.redo;
-    const bool mapping = work && !redo && n > 1;
+    const bool mapping = work && !redo && n > 1 && !(a->f.p.ablate & 4096);
     const int dis = DIS ? a->f.p.ss_dis : 0;
     const SiteMasks64 sm = map_exons_lds_wide(L, d, mapping, n, vm.vpre, st, dis, re.s0, re.el);
     if (active && !mapping) {
