@@ -12,15 +12,19 @@
 //                   the KEYS {k1, k2} of the tile's dictionary slices and their bucket directories into LDS, every entry at its own
 //                   place (no filter, no sort); the entries' masks stay in the REGISTERS of the threads that loaded them;
 //                   the key lookup: per exon one word -- where the parts of its START key / END key lie among the staged entries
-//                   (first part, number of parts, "the pair matches") -- kept beside the exon's row word (s_R);
+//                   (first part, number of parts, "the pair matches") -- kept beside the exon's row word (s_R); a staged key is one
+//                   64-bit word, both dictionaries' lower bounds run in one loop, one round of reads behind them says the rest
+//                   (tc_lookup2);
 //                   the window's CHUNKS: stretches of 63 consecutive transcripts from the tile's cursor value on, the ones with a
 //                   transcript that overlaps the tile's span listed up to the first transcript every read lies before (four waves, a
 //                   stretch each per round trip).
 //   per chunk       the 63 transcripts' headers (asked for one chunk ahead); every thread re-bases ITS entries' masks to the chunk
-//                   (two shifts per mask, from registers) and leaves them at the entries' places; one barrier; the member pass
-//                   (visit_chunk64); per exon the ORs over the parts its word names (no directory, no key compare); the sweep's
-//                   carried state exactly as in k_probe_slab_chunked (src/update_gtf.c:792-835).  A workgroup leaves the loop when
-//                   none of its reads is still sweeping (known / stopped).
+//                   (two shifts per mask, from registers) and leaves them at the entries' places; waves 0 and 1 group the 63 members
+//                   by first / last exon (TcGroup); one barrier; the member pass (tc_visit: before / behind member by member, the
+//                   full-length evidence of levels 1-4 once per distinct terminal exon); per exon the ORs over the parts its word
+//                   names (no directory, no key compare) and the flag clears the chunk before left to do; the sweep's carried state
+//                   exactly as in k_probe_slab_chunked (src/update_gtf.c:792-835).  A workgroup leaves the loop when none of its
+//                   reads is still sweeping (known / stopped).
 //
 // A chunk here is 63 CONSECUTIVE transcripts (not 63 members): a transcript of the stretch that does not overlap the tile's span lies
 // before every read or behind every read, which the member pass sees per read like for any other member (m_bef / m_aft), so masks are
