@@ -96,6 +96,7 @@ struct l2r_ctx {
     bool tile_starved = false;                              //                       a tile of k_tile has waited in vain for the counts in front of it (or the device cannot hold the workgroups its look-back needs): the slab pipeline from then on
     int64_t n_lb_fallback = 0;                              //                       ... runs that were done again on the slab pipeline for that reason (l2r_debug_counters)
     bool have_index = false;                                //                       the current upload has its tile index (slot records, op statistics)
+    bool pipeline_forced = false;                           // L2R_PIPELINE is set: the pipeline it names also for single-run uploads (tests, A/B runs)
     bool one_shot_upload = false;                           //                       ONE run will follow the upload (l2r_classify, l2r_hint_single_run): see l2r_classify
     float index_ms = 0.0f;                                  //                       GPU time of the last upload's k_tile_index (l2r_upload_index_ms)
     DevBuf<SlotRec> slot_rec;                               //                       the upload's slot records (k_tile_index)
@@ -269,7 +270,7 @@ l2r_ctx *l2r_create(int device)
         e = getenv("L2R_SIDE");
         if (e) c->side_on = atoi(e) != 0;
         e = getenv("L2R_PIPELINE");
-        if (e) c->want_pipeline = !strcmp(e, "classic") ? 0 : !strcmp(e, "slab") ? 1 : 2;
+        if (e) { c->want_pipeline = !strcmp(e, "classic") ? 0 : !strcmp(e, "slab") ? 1 : 2; c->pipeline_forced = true; }
         {   // k_tile's look-back: a tile may wait for one whose workgroup comes up to 8 * TILE_GROUP - 1 block indices later (fused_tile), so
             // that many workgroups + 1 have to be resident together -- guaranteed nowhere; checked here (small or partitioned devices, CU
             // masks): a device that cannot hold them takes the slab pipeline from the start
@@ -971,7 +972,7 @@ int l2r_upload_reads(l2r_ctx *c, const l2r_reads *r)
             // ... and an index of its CIGAR operations from which a run knows the tile's exon count unless a threshold is borderline in it
             c->h_tile_stat.assign(T, TileStat{0, INT32_MAX, 0, INT32_MAX});
             c->index_ms = 0.0f; c->have_index = false;
-            if (T && !c->wide_cigar && c->want_pipeline >= 2 && !(c->one_shot_upload && !c->env_tile_anyway)) {
+            if (T && !c->wide_cigar && c->want_pipeline >= 2 && !(c->one_shot_upload && !c->env_tile_anyway && !c->pipeline_forced)) {
                 c->have_index = true;
                 struct Ev { hipEvent_t a = nullptr, b = nullptr; ~Ev() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev;
                 HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b));
@@ -1788,7 +1789,7 @@ int l2r_classify(l2r_ctx *c, const l2r_reads *reads, l2r_result *res)
     // ONE run follows this upload: by total GPU time the two-kernel (slab) pipeline wins that case -- measured on 10 M reads 0.62 ms against
     // tile index + first run of the one-kernel path 0.68 ms (0.80 ms where the engine has to walk the CIGARs for the index itself); the
     // one-kernel path pays off from the second run of an upload on (0.50 ms a run).  So this upload makes no tile index and its run takes
-    // the slab pipeline (L2R_TILE_ANYWAY=1: index + tile path all the same).
+    // the slab pipeline (L2R_PIPELINE=tile or L2R_TILE_ANYWAY=1: index + tile path all the same).
     const bool was = c->one_shot_upload;
     c->one_shot_upload = true;
     int rc = l2r_upload_reads(c, reads);

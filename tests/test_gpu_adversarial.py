@@ -570,3 +570,51 @@ def test_chunk_lists_at_their_limits(oracle, shape, pipeline):
             assert cnt[0] <= 256, cnt                       # (the isoform-rich tiles stay off the redo list)
         if pipeline == "tile" and shape == "far_members":
             assert cnt[0] >= 4000, cnt                      # (the window scan gives up: the locus' reads are the generic kernel's)
+
+
+@pytest.mark.parametrize("variants", [1, 24, 25, 150])
+def test_terminal_exon_groups_of_a_chunk(oracle, variants, pipeline):
+    """k_tile_chunk takes the full-length evidence of levels 1-4 (src/update_gtf.c:803-822: the read's terminal exons against the
+    member's) once per DISTINCT first / last exon of a chunk's 63 transcripts (TcGroup, l2r_tchunk.hip.h), member by member when a
+    chunk has more than 24 of a kind.  150 isoforms around one another whose first exon ends and whose last exon begins in `variants`
+    different places: one group of each kind; exactly 24 (the cap); 25 (one more: member by member); every isoform its own.  Reads
+    that begin / end with an isoform's terminal exon (full length at level 1 only with the very same inner boundary), with a
+    shortened one, and inside the isoform."""
+    rng = np.random.default_rng(23 + variants)
+    pool = [(50_000 + 700 * k, 50_000 + 700 * k + 160) for k in range(1, 23)]
+
+    def isoform(t):
+        v = t % variants
+        keep = sorted(rng.choice(np.arange(len(pool)), size=int(rng.integers(5, 14)), replace=False))
+        return (0, t & 1, [(49_000, 49_200 + 3 * v)] + [pool[k] for k in keep] + [(70_000 + 3 * ((v * 7) % variants), 70_900)])
+    iso = [isoform(t) for t in range(150)]
+    quiet0 = [(0, 0, [(1_000 + 40 * g, 1_000 + 40 * g + 10), (1_000 + 40 * g + 20, 1_000 + 40 * g + 30)]) for g in range(50)]
+    quiet1 = [(1, 0, [(5_000 + 3_000 * g, 5_000 + 3_000 * g + 100), (5_000 + 3_000 * g + 500, 5_000 + 3_000 * g + 650)]) for g in range(20)]
+    af = _anno(quiet0 + iso + quiet1)
+    rows = []
+    for i in range(6000):
+        t = iso[int(rng.integers(len(iso)))][2]
+        kind = i % 5
+        if kind == 0:
+            ex = [list(x) for x in t]                                        # the whole isoform
+        elif kind == 1:
+            ex = [list(x) for x in t[:int(rng.integers(2, len(t)))]]         # from its first exon on
+        elif kind == 2:
+            ex = [list(x) for x in t[int(rng.integers(0, len(t) - 2)):]]     # up to its last exon
+        else:
+            a = int(rng.integers(0, len(t) - 2))
+            ex = [list(x) for x in t[a:a + int(rng.integers(2, 9))]]
+        if i % 3 == 0:
+            ex[0][0] += int(rng.integers(0, 150))                            # (the outer ends move, the inner boundaries stay)
+        if i % 4 == 0:
+            ex[-1][1] -= int(rng.integers(0, 150))
+        if i % 11 == 0 and len(ex) > 2:
+            ex[0][1] += 3                                                    # (another variant's first exon, or nobody's)
+        p, ops = _chain([tuple(x) for x in ex])
+        rows.append((0, p, i & 1, ops))
+    cnt = [0, 0, 0, 0]
+    for level in (1, 2, 3, 4):
+        got, want = _run(oracle, af, _reads(_sorted_rows(rows)), counters=cnt, full_level=level)
+        assert ((want.info & 4) != 0).sum() > 300 and ((want.info & 4) == 0).sum() > 300       # (I_FULL: full-length and not, both kinds of verdict)
+        if pipeline == "tile" and variants <= 25:
+            assert cnt[0] <= 256, cnt                       # (150 variants: more START entries than k_tile_chunk stages -- slab form, the old kernel, some reads generic)
