@@ -796,7 +796,8 @@ constexpr int TC_ST_CAP = 128, TC_EN_CAP = 512;          // k_tile_chunk (l2r_tc
 __device__ __forceinline__ bool tile_chunk_direct(uint32_t on, uint32_t flags, uint32_t chunk_on, const TileDesc &d, const TileStat &st, uint32_t n_act,
                                                   int min_exon, int min_intron, int max_delet, int dis, int ablate, bool late)
 {
-    return on != 0u && chunk_on != 0u && (late || (slab_tile_is_chunked(flags) && !(flags & TD_CHUNK))) && dis == 0 && d.nbk > 0 && d.st_nk <= (uint32_t)TC_ST_CAP && d.en_nk <= (uint32_t)TC_EN_CAP &&
+    return on != 0u && chunk_on != 0u && (late || (slab_tile_is_chunked(flags) && !(flags & TD_CHUNK))) && dis == 0 && d.nbk > 0 && d.st_nk < (uint32_t)TC_ST_CAP && d.en_nk <= (uint32_t)TC_EN_CAP &&      // (START: one slot behind the entries stays free -- the masks of "no entry", tc_map_exons)
+          
            tile_exact(st, min_exon, min_intron, max_delet) && !(ablate & 256) && n_act + (uint32_t)st.n_ops_n <= (uint32_t)TILE_POS_CAP;
 }
 

@@ -77,7 +77,7 @@ typedef unsigned long long tckey_t;
 __device__ __forceinline__ tckey_t tc_key(int32_t k1, int32_t k2) { return ((tckey_t)(uint32_t)k1 << 32) | (tckey_t)(uint32_t)k2; }
 __device__ __forceinline__ uint32_t tc_k1(tckey_t v) { return (uint32_t)(v >> 32); }
 struct TcKey { const tckey_t *key; const uint16_t *dir; };
-__device__ __forceinline__ uint32_t tc_half(const tckey_t *key, uint32_t lo, uint32_t hi, uint32_t l, tckey_t T, bool &over)
+__device__ __forceinline__ uint32_t tc_half(const tckey_t *key, uint32_t lo, uint32_t hi, uint32_t l, tckey_t T, uint32_t zero_slot, bool &over)
 {
     const uint32_t k1 = tc_k1(T);
     const int li = (int)l;                               // (three words in front of the staging and two behind it may be read: not used)
@@ -99,9 +99,9 @@ __device__ __forceinline__ uint32_t tc_half(const tckey_t *key, uint32_t lo, uin
             if (cnt > 15u) { over = true; cnt = 15u; }
         }
     }
-    return found ? base | (cnt << 9) | (pair ? 1u << 13 : 0u) : 0u;
+    return found ? base | (cnt << 9) | (pair ? 1u << 13 : 0u) : zero_slot;             // (nothing: the slot behind the entries, whose masks are 0; 0 parts)
 }
-__device__ __forceinline__ uint32_t tc_lookup2(const TcKey &K0, const TcKey &K1, int b_off, uint32_t none, bool on0, bool on1, int32_t s, int32_t e, int32_t s2, bool &over)
+__device__ __forceinline__ uint32_t tc_lookup2(const TcKey &K0, const TcKey &K1, int b_off, uint32_t none, uint32_t zero0, uint32_t zero1, bool on0, bool on1, int32_t s, int32_t e, int32_t s2, bool &over)
 {
     const uint32_t ib0 = on0 ? min((uint32_t)((s >> SITE_SHIFT) + b_off), none) : none, ib1 = on1 ? min((uint32_t)((e >> SITE_SHIFT) + b_off), none) : none;
     const uint32_t lo0 = K0.dir[ib0], hi0 = K0.dir[ib0 + 1u], lo1 = K1.dir[ib1], hi1 = K1.dir[ib1 + 1u];
@@ -113,7 +113,7 @@ __device__ __forceinline__ uint32_t tc_lookup2(const TcKey &K0, const TcKey &K1,
         if (l0 < h0) { l0 = less0 ? m0 + 1u : l0; h0 = less0 ? h0 : m0; }
         if (l1 < h1) { l1 = less1 ? m1 + 1u : l1; h1 = less1 ? h1 : m1; }
     }
-    return tc_half(K0.key, lo0, hi0, l0, T0, over) | (tc_half(K1.key, lo1, hi1, l1, T1, over) << TC_HALF_BITS);
+    return tc_half(K0.key, lo0, hi0, l0, T0, zero0, over) | (tc_half(K1.key, lo1, hi1, l1, T1, zero1, over) << TC_HALF_BITS);
 }
 
 // overlapping_exon_members64 (l2r_wide.hip.h) on the split key / mask arrays
@@ -253,7 +253,7 @@ __device__ __forceinline__ uint32_t tc_flag_clears(uint32_t w, uint32_t lim, boo
     if (sites) clr |= (((w >> 12) & 1u) ? (uint32_t)F_DON : 0u) | (((w >> 13) & 1u) ? (uint32_t)F_ACC : 0u);
     return clr << TC_F_SHIFT;
 }
-__device__ __forceinline__ SiteMasks64 tc_map_exons(const TcLds &L, bool mapping, bool pend, uint32_t *Ap, uint32_t *Rp, uint32_t n, m64_t vpre)
+__device__ __forceinline__ SiteMasks64 tc_map_exons(const TcLds &L, bool mapping, bool pend, uint32_t *Ap, uint32_t *Rp, uint32_t n, m64_t vpre, uint32_t zero0, uint32_t zero1)
 {
     SiteMasks64 m{~0ull, 0ull, 0ull, 0ull, 0ull};
     const int k_max = wave_max(mapping ? (int)n : 0);
@@ -261,12 +261,13 @@ __device__ __forceinline__ SiteMasks64 tc_map_exons(const TcLds &L, bool mapping
     uint32_t R = mapping ? Rp[0] : 0u;
     for (int k = 0; k < k_max; ++k) {
         const bool live = mapping && k < (int)n, junc = mapping && k + 1 < (int)n;
-        const uint32_t R0 = live ? R & TC_HALF_MASK : 0u, R1 = junc ? (R >> TC_HALF_BITS) & TC_HALF_MASK : 0u;
+        // (a key without an entry, an exon the lane does not have: the slot behind the dictionary's entries, whose masks are 0 -- and a
+        // second part that is not there reads that slot too: ORs without selects)
+        const uint32_t R0 = live ? R & TC_HALF_MASK : zero0, R1 = junc ? (R >> TC_HALF_BITS) & TC_HALF_MASK : zero1;
         const uint32_t i0 = R0 & 511u, c0 = (R0 >> 9) & 15u, i1 = R1 & 511u, c1 = (R1 >> 9) & 15u;
-        const TcMask a0 = L.msk0[i0], a1 = L.msk0[i0 + 1u], b0 = L.msk1[i1], b1 = L.msk1[i1 + 1u];
+        const TcMask a0 = L.msk0[i0], a1 = L.msk0[c0 > 1u ? i0 + 1u : zero0], b0 = L.msk1[i1], b1 = L.msk1[c1 > 1u ? i1 + 1u : zero1];
         const uint32_t Rn = mapping ? Rp[min((uint32_t)k + 1u, nm1)] : 0u;
-        m64_t xm = c0 ? a0.pm : 0ull, am = c0 ? a0.sm : 0ull, jm = c1 ? b0.pm : 0ull, dm = c1 ? b0.sm : 0ull;
-        xm |= c0 > 1u ? a1.pm : 0ull; am |= c0 > 1u ? a1.sm : 0ull; jm |= c1 > 1u ? b1.pm : 0ull; dm |= c1 > 1u ? b1.sm : 0ull;
+        m64_t xm = a0.pm | a1.pm, am = a0.sm | a1.sm, jm = b0.pm | b1.pm, dm = b0.sm | b1.sm;
         if (__any(c0 > 2u || c1 > 2u)) {
             for (uint32_t c = 2u; c < c0; ++c) { const TcMask q = L.msk0[i0 + c]; xm |= q.pm; am |= q.sm; }
             for (uint32_t c = 2u; c < c1; ++c) { const TcMask q = L.msk1[i1 + c]; jm |= q.pm; dm |= q.sm; }
@@ -509,11 +510,12 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
             const int s = tile_lo + (int)(aw & SLAB_REL_MASK), e = s + (int)s_L[q] - 1;
             const int s2 = last_x ? 0 : tile_lo + (int)(s_A[q + 1u] & SLAB_REL_MASK);
             bool over = false;
-            uint32_t w = (ablate & 16384) ? 0u : tc_lookup2(K0, K1, d.b_off, none, !(first_x && last_x), !last_x, s, e, s2, over);      // (bit 14, timing diagnostics: no lookups -- results wrong)
+            uint32_t w = (ablate & 16384) ? 0u : tc_lookup2(K0, K1, d.b_off, none, d.st_nk, d.en_nk, !(first_x && last_x), !last_x, s, e, s2, over);      // (bit 14, timing diagnostics: no lookups -- results wrong)
             if (over) w = TC_R_OVER;
             s_R[q] = w | (F_ALL << TC_F_SHIFT);
         }
     }
+    if (threadIdx.x < 2u) s_msk[threadIdx.x ? (uint32_t)TC_ST_CAP + d.en_nk : d.st_nk] = TcMask{0ull, 0ull};      // (the masks of "no entry": never written again)
     __syncthreads();                                         // (the chunk list)
     stamp.mark(2);
     const uint32_t n_chunk = s_nchunk;
@@ -609,7 +611,7 @@ void k_tile_chunk(SlabArgs kernarg_block, const TileRec *__restrict__ u_rec, con
         redo = redo || vm.redo;
         stamp.mark(4);
         const bool mapping = work && !vm.redo && n > 1 && !(ablate & 4096);
-        const SiteMasks64 sm = tc_map_exons(L, mapping, pend, Ap, Rp, n, vm.vpre);
+        const SiteMasks64 sm = tc_map_exons(L, mapping, pend, Ap, Rp, n, vm.vpre, d.st_nk, d.en_nk);
         stamp.mark(5);
         if (work && !vm.redo) {
             int jstar = -1;
